@@ -1,0 +1,217 @@
+/*
+ * rsb.h — C-ABI of the MI355X-native batched rigid-body simulator ("rsb" = RaiSim-batched).
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json's north_star:
+ * thousands of independent raisim::World replicas, each holding one raisim::ArticulatedSystem
+ * on a Ground / HeightMap, stepped in lock-step on one GPU.
+ *
+ * Reference interface replaced.  The mounted reference /root/reference is a
+ * three-file stub (.gitignore:1-12, .travis.yml:1-12, README.md:1) that contains NO headers, so
+ * every "replaces" note below names the upstream raisimLib symbol from recollection [RECALL] and
+ * the file the symbol would live in; the file:line is "absent" for all of them
+ * (SURVEY.md §0, §8a).
+ *
+ *   rsb_create / rsb_destroy            <- raisim::World::World(), ~World(),
+ *                                          World::addArticulatedSystem(urdf)      (World.hpp, absent)
+ *   rsb_set_ground / rsb_set_heightmap  <- World::addGround(z), World::addHeightMap(...)
+ *   rsb_set_timestep / rsb_set_gravity  <- World::setTimeStep, World::setGravity
+ *   rsb_set_erp / rsb_set_contact_solver_param / rsb_set_friction
+ *                                       <- World::setERP, World::setContactSolverParam,
+ *                                          World::setDefaultMaterial               (World.hpp, absent)
+ *   rsb_set_state / rsb_get_state       <- ArticulatedSystem::setState/getState    (ArticulatedSystem.hpp, absent)
+ *   rsb_set_pd_gains / rsb_set_pd_target / rsb_set_generalized_force / rsb_set_control_mode
+ *                                       <- ArticulatedSystem::setPdGains/setPdTarget/
+ *                                          setGeneralizedForce/setControlMode
+ *   rsb_integrate / rsb_integrate1 / rsb_integrate2
+ *                                       <- World::integrate(), integrate1(), integrate2()
+ *   rsb_get_contacts                    <- ArticulatedSystem::getContacts() (contact/Contact.hpp, absent)
+ *   rsb_get_mass_matrix / rsb_get_nonlinearities
+ *                                       <- ArticulatedSystem::getMassMatrix()/getNonlinearities()
+ *   rsb_gather_obs                      <- (new) the (q, u, contact-force) observation block that
+ *                                          VectorizedEnvironment::observe() is built from
+ *
+ * Conventions
+ *   - No exceptions cross this ABI. Every call returns RSB_OK (0) or a negative rsb_status;
+ *     rsb_last_error() returns a thread-local message for the last failure.
+ *   - Buffers are caller-owned.  `space` says whether a pointer is host or device memory.
+ *   - Batched arrays are row-major [num_envs, dim] float32 (the layout raisimGymTorch's
+ *     VectorizedEnvironment uses for observation/action matrices).
+ *   - Generalized coordinates follow RaiSim: gc = [x y z  qw qx qy qz  joints...] (nq = 7+nj),
+ *     gv = [world linear vel (3), world angular vel (3), joint vels...] (nv = 6+nj).
+ *   - One handle owns one HIP stream (or borrows the caller's, rsb_set_stream). A handle is not
+ *     re-entrant; distinct handles may be used from distinct threads.
+ *   - There is NO CPU fallback: rsb_create fails with RSB_E_NO_DEVICE when no HIP device exists.
+ */
+#ifndef RSB_H_
+#define RSB_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSB_MAX_BODIES 64      /* moving bodies incl. floating base                    */
+#define RSB_MAX_DOF (6 + RSB_MAX_BODIES - 1)
+#define RSB_MAX_COLLISIONS 64  /* collision spheres per articulated system             */
+#define RSB_MAX_CONTACTS 16    /* upper bound on the per-env contact cap (k_max)       */
+#define RSB_NAME_LEN 48
+
+typedef enum rsb_status {
+  RSB_OK = 0,
+  RSB_E_INVALID = -1,    /* bad argument                                   */
+  RSB_E_PARSE = -2,      /* URDF parse error                               */
+  RSB_E_UNSUPPORTED = -3,/* feature outside the supported subset           */
+  RSB_E_NO_DEVICE = -4,  /* no HIP device / HIP runtime failure            */
+  RSB_E_HIP = -5,        /* a HIP call failed                              */
+  RSB_E_STATE = -6       /* call not valid in the current state            */
+} rsb_status;
+
+typedef enum rsb_memspace { RSB_HOST = 0, RSB_DEVICE = 1 } rsb_memspace;
+
+/* raisim::ControlMode::Type [RECALL] */
+typedef enum rsb_control_mode {
+  RSB_FORCE_AND_TORQUE = 0,
+  RSB_PD_PLUS_FEEDFORWARD_TORQUE = 1
+} rsb_control_mode;
+
+typedef enum rsb_joint_type { RSB_JOINT_FLOATING = 0, RSB_JOINT_REVOLUTE = 1, RSB_JOINT_PRISMATIC = 2 } rsb_joint_type;
+
+/*
+ * Flat, immutable description of one articulated system (the "model blob").
+ * Body 0 is the floating base; body i>0 is attached to parent[i] < i by a 1-DoF joint whose
+ * frame sits at ptree[i] / rtree[i] in the parent body frame and moves about/along axis[i]
+ * (expressed in the joint = child-body frame).  Fixed URDF joints are already merged.
+ * Capsules are stored as their two end spheres (the contact set ODE's capsule-plane collider
+ * produces); every collision primitive is therefore a sphere.
+ */
+typedef struct rsb_model_blob {
+  int32_t nb, nq, nv, ncol, depth, reserved;
+  int32_t parent[RSB_MAX_BODIES];
+  int32_t level[RSB_MAX_BODIES];
+  int32_t jtype[RSB_MAX_BODIES];
+  double axis[RSB_MAX_BODIES][3];
+  double ptree[RSB_MAX_BODIES][3];
+  double rtree[RSB_MAX_BODIES][9];   /* row-major, parent <- joint frame            */
+  double mass[RSB_MAX_BODIES];
+  double com[RSB_MAX_BODIES][3];     /* body frame                                  */
+  double inertia[RSB_MAX_BODIES][6]; /* xx xy xz yy yz zz about com, body frame     */
+  double armature[RSB_MAX_BODIES];   /* rotor inertia added to M's diagonal         */
+  double damping[RSB_MAX_BODIES];    /* viscous joint damping                       */
+  double q_lower[RSB_MAX_BODIES], q_upper[RSB_MAX_BODIES];
+  double effort[RSB_MAX_BODIES];     /* |tau| limit, <=0 means unlimited            */
+  int32_t col_body[RSB_MAX_COLLISIONS];
+  double col_pos[RSB_MAX_COLLISIONS][3]; /* sphere centre, body frame                */
+  double col_radius[RSB_MAX_COLLISIONS];
+  char body_name[RSB_MAX_BODIES][RSB_NAME_LEN];   /* URDF link name of each moving body  */
+  char joint_name[RSB_MAX_BODIES][RSB_NAME_LEN];  /* URDF joint name (index 0: "base")   */
+  char col_name[RSB_MAX_COLLISIONS][RSB_NAME_LEN];
+} rsb_model_blob;
+
+/* One solved contact, as raisim::Contact exposes it (position/normal/impulse/body index). */
+typedef struct rsb_contact {
+  float position[3];   /* world frame                                          */
+  float normal[3];     /* world frame, pointing from terrain into the robot    */
+  float impulse[3];    /* world frame, impulse applied to the robot over dt    */
+  float depth;
+  int32_t body;        /* local body index of the articulated system           */
+  int32_t collision;   /* collision primitive index                            */
+} rsb_contact;
+
+typedef struct rsb_model rsb_model;  /* host-side parsed model           */
+typedef struct rsb_world rsb_world;  /* batched device world             */
+
+const char* rsb_last_error(void);
+const char* rsb_version(void);
+
+/* ---- model (host only; cold path) -------------------------------------- */
+int rsb_model_from_urdf_file(const char* path, rsb_model** out);
+int rsb_model_from_urdf_string(const char* xml, rsb_model** out);
+int rsb_model_from_blob(const rsb_model_blob* blob, rsb_model** out);
+int rsb_model_destroy(rsb_model* m);
+int rsb_model_get_blob(const rsb_model* m, rsb_model_blob* out);
+int rsb_model_body_index(const rsb_model* m, const char* link_name);   /* <0 if absent */
+int rsb_model_joint_index(const rsb_model* m, const char* joint_name); /* body index driven by joint */
+double rsb_model_total_mass(const rsb_model* m);
+
+/* ---- world ------------------------------------------------------------------------------ */
+int rsb_device_count(void);
+int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out);
+int rsb_destroy(rsb_world* w);
+int rsb_set_stream(rsb_world* w, void* hip_stream);   /* borrow caller's hipStream_t (NULL = own) */
+void* rsb_get_stream(rsb_world* w);
+int rsb_synchronize(rsb_world* w);
+
+int rsb_num_envs(const rsb_world* w);
+int rsb_dims(const rsb_world* w, int* nb, int* nq, int* nv, int* ncol, int* kmax);
+
+int rsb_set_timestep(rsb_world* w, double dt);
+double rsb_get_timestep(const rsb_world* w);
+double rsb_get_world_time(const rsb_world* w);
+int rsb_set_gravity(rsb_world* w, const double g[3]);
+int rsb_set_erp(rsb_world* w, double erp);
+int rsb_set_friction(rsb_world* w, double mu);
+int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min,
+                                 double alpha_decay, int max_iter, double threshold);
+int rsb_set_max_contacts(rsb_world* w, int kmax);   /* 1..RSB_MAX_CONTACTS */
+/* Kernel mapping knob: lanes of a wavefront that cooperate on one env (16, 32 or 64).
+ * 64 = the north star's "one wavefront per env"; 0 = pick the measured-fastest default. */
+int rsb_set_lanes_per_env(rsb_world* w, int lanes);
+int rsb_get_lanes_per_env(const rsb_world* w);
+
+int rsb_set_ground(rsb_world* w, double height);
+/* heights: host pointer, row-major [y_samples][x_samples] (x fastest), shared by all envs */
+int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size, double y_size,
+                      double center_x, double center_y, const float* heights);
+
+/* mask: optional uint8 [num_envs] (same memspace); envs with mask==0 are left untouched */
+int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t* mask, int space);
+int rsb_get_state(rsb_world* w, float* gc, float* gv, int space);
+
+int rsb_set_control_mode(rsb_world* w, int mode);
+int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd);      /* host, [nv] each  */
+int rsb_set_pd_target(rsb_world* w, const float* p_target, const float* d_target, int space); /* [N,nq],[N,nv]; either may be NULL */
+int rsb_set_generalized_force(rsb_world* w, const float* tau, int space);  /* [N,nv] feed-forward */
+
+int rsb_integrate(rsb_world* w, int n_substeps);
+int rsb_integrate1(rsb_world* w);
+int rsb_integrate2(rsb_world* w);
+
+/* contacts of the last sub-step: counts [N] int32, contacts [N,kmax] rsb_contact */
+int rsb_get_contacts(rsb_world* w, int32_t* counts, rsb_contact* contacts, int space);
+/* valid after rsb_integrate1: M [N,nv,nv], h [N,nv] */
+int rsb_get_mass_matrix(rsb_world* w, float* M, int space);
+int rsb_get_nonlinearities(rsb_world* w, float* h, int space);
+/* per-env status flags of the last step (bit0: contact overflow, bit1: non-finite state) */
+int rsb_get_flags(rsb_world* w, int32_t* flags, int space);
+/* iterations the contact solver used in the last sub-step, [N] int32 */
+int rsb_get_solver_iterations(rsb_world* w, int32_t* iters, int space);
+
+/* obs block [N, nq+nv+3*n_force_slots] = (q, u, contact force on chosen collision primitives).
+ * collision_indices: host array of n_force_slots collision-primitive indices (e.g. the feet);
+ * NULL = primitives 0..n_force_slots-1.  Force = impulse / dt of the last sub-step (world frame). */
+int rsb_obs_dim(const rsb_world* w, int n_force_slots);
+int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, int n_force_slots, int space);
+
+/* zero-copy access to the resident state (device pointers; row-major [N,dim] float32) */
+typedef enum rsb_field {
+  RSB_F_GC = 0, RSB_F_GV = 1, RSB_F_PTARGET = 2, RSB_F_DTARGET = 3, RSB_F_TAU_FF = 4,
+  RSB_F_CONTACT_COUNT = 5, RSB_F_CONTACTS = 6, RSB_F_FLAGS = 7
+} rsb_field;
+void* rsb_device_ptr(rsb_world* w, int field);
+
+/* elapsed device time (ms) of the most recent rsb_integrate launch, measured with HIP events
+ * on the handle's stream; also the kernel's static resource usage for reports. */
+int rsb_last_kernel_ms(rsb_world* w, float* ms);
+int rsb_enable_timing(rsb_world* w, int on);
+
+/* Debug aid (tests): dump one env's contact problem of the last sub-step of the next launches:
+ * nc, Delassus matrix G [3nc,3nc] row-major, free contact velocity c [3nc], impulses lam [3nc], all in
+ * contact-frame coordinates [t1 t2 n] per contact.  env < 0 disables the dump. */
+int rsb_debug_select_env(rsb_world* w, int env);
+int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, float* lam);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSB_H_ */

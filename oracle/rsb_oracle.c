@@ -1,0 +1,732 @@
+/*
+ * rsb_oracle.c — CPU fp64 oracle (see rsb_oracle.h: TEST INFRASTRUCTURE, PARITY UNPINNED).
+ *
+ * No reference file exists to cite; each block cites the published algorithm it
+ * follows instead.  "RBDA" = Featherstone, Rigid Body Dynamics Algorithms, Springer 2008.
+ *
+ * Formulation.  All spatial quantities of one step are expressed in ONE frame: world-aligned
+ * axes with origin O at the floating base's position at the start of the step.  In a common
+ * frame the parent<->child Pluecker transforms of RBDA's recursions are identities, so the
+ * recursions reduce to sums along the tree; and keeping O on the robot keeps |r| <= ~1 m so the
+ * device's fp32 version of the same formulation does not lose digits when the robot walks away
+ * from the world origin.  Spatial vectors are [angular(3); linear(3)].
+ *
+ * Generalized velocity follows RaiSim [RECALL]: u = [v_base (world), w_base (world), qdot].
+ * The base therefore has S = identity and a velocity-product acceleration [0; -w x v]
+ * (d/dt of the O-referenced linear velocity of a body whose origin moves with v).
+ */
+#include "rsb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define MAXB RSB_MAX_BODIES
+#define MAXV RSB_MAX_DOF
+#define MAXK RSB_MAX_CONTACTS
+#define ORC_JAM_KAPPA 0.1     /* jamming guard of the slip case, see solve_one_contact */
+#define ORC_LAMBDA_FLOOR 1e-3 /* N s; keeps the relative convergence test meaningful as impulses -> 0 */
+
+/* ------------------------------------------------------------------ small linear algebra */
+static void cross3(const double* a, const double* b, double* c) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  c[0] = x; c[1] = y; c[2] = z;
+}
+static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double dot6(const double* a, const double* b) { return dot3(a, b) + dot3(a + 3, b + 3); }
+static void mat3_mul(const double* A, const double* B, double* C) {
+  double T[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(C, T, sizeof T);
+}
+static void mat3_vec(const double* A, const double* x, double* y) {
+  double t[3];
+  for (int i = 0; i < 3; ++i) t[i] = A[3 * i] * x[0] + A[3 * i + 1] * x[1] + A[3 * i + 2] * x[2];
+  y[0] = t[0]; y[1] = t[1]; y[2] = t[2];
+}
+static void quat_to_rot(const double* qin, double* R) {
+  double n = sqrt(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+  double w = qin[0] / n, x = qin[1] / n, y = qin[2] / n, z = qin[3] / n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
+}
+/* Rodrigues: R = I + s K + (1-c) K^2, K = [a]x, |a| = 1 */
+static void axis_angle_rot(const double* a, double q, double* R) {
+  double s = sin(q), c = cos(q), v = 1 - c;
+  R[0] = c + a[0] * a[0] * v;        R[1] = a[0] * a[1] * v - a[2] * s; R[2] = a[0] * a[2] * v + a[1] * s;
+  R[3] = a[1] * a[0] * v + a[2] * s; R[4] = c + a[1] * a[1] * v;        R[5] = a[1] * a[2] * v - a[0] * s;
+  R[6] = a[2] * a[0] * v - a[1] * s; R[7] = a[2] * a[1] * v + a[0] * s; R[8] = c + a[2] * a[2] * v;
+}
+/* motion cross product  [w;v] x [a;s] = [w x a; w x s + v x a]   (RBDA eq. 2.31) */
+static void crm(const double* V, const double* S, double* out) {
+  double t1[3], t2[3], t3[3];
+  cross3(V, S, t1); cross3(V, S + 3, t2); cross3(V + 3, S, t3);
+  for (int i = 0; i < 3; ++i) { out[i] = t1[i]; out[3 + i] = t2[i] + t3[i]; }
+}
+/* force cross product  [w;v] x* [n;f] = [w x n + v x f; w x f]    (RBDA eq. 2.32) */
+static void crf(const double* V, const double* F, double* out) {
+  double t1[3], t2[3], t3[3];
+  cross3(V, F, t1); cross3(V + 3, F + 3, t2); cross3(V, F + 3, t3);
+  for (int i = 0; i < 3; ++i) { out[i] = t1[i] + t2[i]; out[3 + i] = t3[i]; }
+}
+static void mat6_vec(const double* A, const double* x, double* y) {
+  double t[6];
+  for (int i = 0; i < 6; ++i) { t[i] = 0; for (int j = 0; j < 6; ++j) t[i] += A[6 * i + j] * x[j]; }
+  memcpy(y, t, sizeof t);
+}
+/* dense SPD solve (Cholesky), n <= 6, A row-major, in place on copies */
+static void spd_solve(const double* Ain, const double* b, double* x, int n) {
+  double L[36], y[6];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = Ain[n * i + j];
+      for (int k = 0; k < j; ++k) s -= L[n * i + k] * L[n * j + k];
+      L[n * i + j] = (i == j) ? sqrt(s) : s / L[n * j + j];
+    }
+  for (int i = 0; i < n; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[n * i + k] * y[k]; y[i] = s / L[n * i + i]; }
+  for (int i = n - 1; i >= 0; --i) { double s = y[i]; for (int k = i + 1; k < n; ++k) s -= L[n * k + i] * x[k]; x[i] = s / L[n * i + i]; }
+}
+static void inv3(const double* A, double* B) {
+  double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
+  double id = 1.0 / (A[0] * c0 + A[1] * c1 + A[2] * c2);
+  B[0] = c0 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  B[3] = c1 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  B[6] = c2 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+/* --------------------------------------------------------------------------- kinematics */
+typedef struct kin_t {
+  double pbase[3];
+  double R[MAXB][9], r[MAXB][3], a[MAXB][3], S[MAXB][6], V[MAXB][6];
+  double com[MAXB][3];   /* relative to O */
+  double Isp[MAXB][36];  /* spatial inertia about O, [[A,B],[B^T,m1]] */
+} kin_t;
+
+static int dof_of(int body) { return body + 5; }   /* body >= 1 */
+static int qidx_of(int body) { return body + 6; }
+
+/* RBDA §4.1 (model), eq. 2.63 (spatial inertia about a displaced origin) */
+static void spatial_inertia(double mass, const double* c, const double* Ic, double* I6) {
+  double cc = dot3(c, c);
+  double A[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) A[3 * i + j] = Ic[3 * i + j] + mass * ((i == j ? cc : 0.0) - c[i] * c[j]);
+  double B[9] = {0, -mass * c[2], mass * c[1], mass * c[2], 0, -mass * c[0], -mass * c[1], mass * c[0], 0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      I6[6 * i + j] = A[3 * i + j];
+      I6[6 * i + 3 + j] = B[3 * i + j];
+      I6[6 * (3 + i) + j] = B[3 * j + i];
+      I6[6 * (3 + i) + 3 + j] = (i == j) ? mass : 0.0;
+    }
+}
+
+static void kinematics(const rsb_model_blob* m, const double* q, const double* u, kin_t* k) {
+  for (int i = 0; i < 3; ++i) { k->pbase[i] = q[i]; k->r[0][i] = 0; k->a[0][i] = 0; }
+  quat_to_rot(q + 3, k->R[0]);
+  for (int i = 0; i < 6; ++i) k->S[0][i] = 0;
+  if (u) { for (int i = 0; i < 3; ++i) { k->V[0][i] = u[3 + i]; k->V[0][3 + i] = u[i]; } }
+  else memset(k->V[0], 0, sizeof k->V[0]);
+  for (int i = 1; i < m->nb; ++i) {
+    int p = m->parent[i];
+    double t[3];
+    mat3_vec(k->R[p], m->ptree[i], t);
+    for (int c = 0; c < 3; ++c) k->r[i][c] = k->r[p][c] + t[c];
+    if (m->jtype[i] == RSB_JOINT_REVOLUTE) {
+      double Rq[9], E[9];
+      axis_angle_rot(m->axis[i], q[qidx_of(i)], Rq);
+      mat3_mul(m->rtree[i], Rq, E);
+      mat3_mul(k->R[p], E, k->R[i]);
+      mat3_vec(k->R[i], m->axis[i], k->a[i]);
+      for (int c = 0; c < 3; ++c) k->S[i][c] = k->a[i][c];
+      cross3(k->r[i], k->a[i], k->S[i] + 3);
+    } else { /* prismatic */
+      mat3_mul(k->R[p], m->rtree[i], k->R[i]);
+      mat3_vec(k->R[i], m->axis[i], k->a[i]);
+      for (int c = 0; c < 3; ++c) { k->r[i][c] += k->a[i][c] * q[qidx_of(i)]; k->S[i][c] = 0; k->S[i][3 + c] = k->a[i][c]; }
+    }
+    double qd = u ? u[dof_of(i)] : 0.0;
+    for (int c = 0; c < 6; ++c) k->V[i][c] = k->V[p][c] + k->S[i][c] * qd;
+  }
+  for (int i = 0; i < m->nb; ++i) {
+    double t[3], Il[9], T[9], Iw[9], Rt[9];
+    mat3_vec(k->R[i], m->com[i], t);
+    for (int c = 0; c < 3; ++c) k->com[i][c] = k->r[i][c] + t[c];
+    const double* I = m->inertia[i];
+    Il[0] = I[0]; Il[1] = I[1]; Il[2] = I[2]; Il[3] = I[1]; Il[4] = I[3]; Il[5] = I[4]; Il[6] = I[2]; Il[7] = I[4]; Il[8] = I[5];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) Rt[3 * a + b] = k->R[i][3 * b + a];
+    mat3_mul(k->R[i], Il, T);
+    mat3_mul(T, Rt, Iw);
+    spatial_inertia(m->mass[i], k->com[i], Iw, k->Isp[i]);
+  }
+}
+
+/* RNEA in the common frame (RBDA Table 5.1 with identity transforms). udot may be NULL. */
+static void rnea(const rsb_model_blob* m, const kin_t* k, const double* u, const double* udot,
+                 const double* gravity, double* tau) {
+  double A[MAXB][6], F[MAXB][6];
+  double wxv[3];
+  cross3(k->V[0], k->V[0] + 3, wxv);
+  for (int c = 0; c < 3; ++c) {
+    A[0][c] = udot ? udot[3 + c] : 0.0;
+    A[0][3 + c] = (udot ? udot[c] : 0.0) - wxv[c] - gravity[c];
+  }
+  for (int i = 1; i < m->nb; ++i) {
+    int p = m->parent[i];
+    double vs[6];
+    crm(k->V[p], k->S[i], vs);
+    double qd = u ? u[dof_of(i)] : 0.0, qdd = udot ? udot[dof_of(i)] : 0.0;
+    for (int c = 0; c < 6; ++c) A[i][c] = A[p][c] + k->S[i][c] * qdd + vs[c] * qd;
+  }
+  for (int i = 0; i < m->nb; ++i) {
+    double IA[6], IV[6], vf[6];
+    mat6_vec(k->Isp[i], A[i], IA);
+    mat6_vec(k->Isp[i], k->V[i], IV);
+    crf(k->V[i], IV, vf);
+    for (int c = 0; c < 6; ++c) F[i][c] = IA[c] + vf[c];
+  }
+  for (int i = m->nb - 1; i >= 1; --i) {
+    int p = m->parent[i];
+    tau[dof_of(i)] = dot6(k->S[i], F[i]);
+    for (int c = 0; c < 6; ++c) F[p][c] += F[i][c];
+  }
+  for (int c = 0; c < 3; ++c) { tau[c] = F[0][3 + c]; tau[3 + c] = F[0][c]; }
+}
+
+/* CRBA in the common frame (RBDA Table 6.2 with identity transforms) */
+static void crba(const rsb_model_blob* m, const kin_t* k, double* M) {
+  int nv = m->nv;
+  static const int perm[6] = {3, 4, 5, 0, 1, 2}; /* gv index -> spatial index */
+  double Ic[MAXB][36];
+  memcpy(Ic, k->Isp, sizeof(double) * 36 * m->nb);
+  memset(M, 0, sizeof(double) * nv * nv);
+  for (int i = m->nb - 1; i >= 1; --i) {
+    int p = m->parent[i];
+    for (int c = 0; c < 36; ++c) Ic[p][c] += Ic[i][c];
+  }
+  for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) M[a * nv + b] = Ic[0][6 * perm[a] + perm[b]];
+  for (int i = 1; i < m->nb; ++i) {
+    double F[6];
+    mat6_vec(Ic[i], k->S[i], F);
+    int di = dof_of(i);
+    M[di * nv + di] = dot6(k->S[i], F) + m->armature[i];
+    for (int j = m->parent[i]; j >= 1; j = m->parent[j]) {
+      int dj = dof_of(j);
+      M[di * nv + dj] = M[dj * nv + di] = dot6(k->S[j], F);
+    }
+    for (int a = 0; a < 6; ++a) M[di * nv + a] = M[a * nv + di] = F[perm[a]];
+  }
+}
+
+/* dof-level parent array ("lambda" of RBDA §6.5): base dofs form a chain 0<-1<-...<-5 */
+static void dof_parents(const rsb_model_blob* m, int* pd) {
+  pd[0] = -1;
+  for (int k = 1; k < 6; ++k) pd[k] = k - 1;
+  for (int i = 1; i < m->nb; ++i) pd[dof_of(i)] = m->parent[i] == 0 ? 5 : dof_of(m->parent[i]);
+}
+
+/* LTDL factorisation exploiting branch-induced sparsity, in place (RBDA Table 6.3).
+ * On exit: diagonal = D, strictly-lower entries on ancestor positions = L (unit diagonal). */
+static void ltdl(double* H, int nv, const int* pd) {
+  for (int k = nv - 1; k >= 0; --k) {
+    int i = pd[k];
+    while (i >= 0) {
+      double a = H[k * nv + i] / H[k * nv + k];
+      int j = i;
+      while (j >= 0) { H[i * nv + j] -= a * H[k * nv + j]; j = pd[j]; }
+      H[k * nv + i] = a;
+      i = pd[i];
+    }
+  }
+}
+/* x <- M^-1 x given the LTDL factors (RBDA Table 6.5) */
+static void ltdl_solve(const double* H, int nv, const int* pd, double* x) {
+  for (int k = nv - 1; k >= 0; --k) for (int i = pd[k]; i >= 0; i = pd[i]) x[i] -= H[k * nv + i] * x[k];
+  for (int k = 0; k < nv; ++k) x[k] /= H[k * nv + k];
+  for (int k = 0; k < nv; ++k) for (int i = pd[k]; i >= 0; i = pd[i]) x[k] -= H[k * nv + i] * x[i];
+}
+
+/* 3 x nv Jacobian (world axes) of a point x (relative to O) fixed on `body` */
+static void point_jacobian(const rsb_model_blob* m, const kin_t* k, int body, const double* x, double* J) {
+  int nv = m->nv;
+  memset(J, 0, sizeof(double) * 3 * nv);
+  for (int c = 0; c < 3; ++c) J[c * nv + c] = 1.0;
+  /* v = v_b + w x x  =>  d/dw = -[x]x */
+  J[0 * nv + 4] = x[2];  J[0 * nv + 5] = -x[1];
+  J[1 * nv + 3] = -x[2]; J[1 * nv + 5] = x[0];
+  J[2 * nv + 3] = x[1];  J[2 * nv + 4] = -x[0];
+  for (int j = body; j >= 1; j = m->parent[j]) {
+    double col[3];
+    if (m->jtype[j] == RSB_JOINT_REVOLUTE) {
+      double d[3] = {x[0] - k->r[j][0], x[1] - k->r[j][1], x[2] - k->r[j][2]};
+      cross3(k->a[j], d, col);
+    } else { col[0] = k->a[j][0]; col[1] = k->a[j][1]; col[2] = k->a[j][2]; }
+    for (int c = 0; c < 3; ++c) J[c * nv + dof_of(j)] = col[c];
+  }
+}
+
+/* ------------------------------------------------------------------------- public queries */
+void orc_default_params(orc_params* p) {
+  memset(p, 0, sizeof *p);
+  p->dt = 0.0025;
+  p->gravity[2] = -9.81;
+  p->mu = 0.8;
+  p->erp = 0.0;
+  p->alpha_init = 1.0; p->alpha_min = 1.0; p->alpha_decay = 1.0;
+  p->threshold = 1e-5;
+  p->max_iter = 150;
+  p->bisect_iters = 20;
+  p->kmax = 8;
+  p->control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
+  p->terrain_type = 0;
+  p->ground_z = 0.0;
+}
+
+void orc_mass_matrix(const rsb_model_blob* m, const double* q, double* M) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, NULL, k);
+  crba(m, k, M);
+  free(k);
+}
+
+void orc_mass_matrix_rne(const rsb_model_blob* m, const double* q, double* M) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, NULL, k);
+  double zero[3] = {0, 0, 0}, e[MAXV], col[MAXV];
+  for (int j = 0; j < m->nv; ++j) {
+    memset(e, 0, sizeof e);
+    e[j] = 1.0;
+    rnea(m, k, NULL, e, zero, col);
+    for (int i = 0; i < m->nv; ++i) M[i * m->nv + j] = col[i] + ((i == j && i >= 6) ? m->armature[i - 5] : 0.0);
+  }
+  free(k);
+}
+
+void orc_nonlinearities(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u, double* h) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, u, k);
+  rnea(m, k, u, NULL, p->gravity, h);
+  free(k);
+}
+
+void orc_inverse_dynamics(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+                          const double* udot, double* tau) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, u, k);
+  rnea(m, k, u, udot, p->gravity, tau);
+  for (int i = 1; i < m->nb; ++i) tau[dof_of(i)] += m->armature[i] * udot[dof_of(i)];
+  free(k);
+}
+
+void orc_forward_dynamics(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+                          const double* tau, double* udot) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  int nv = m->nv, pd[MAXV];
+  double* M = (double*)malloc(sizeof(double) * nv * nv);
+  double h[MAXV];
+  kinematics(m, q, u, k);
+  crba(m, k, M);
+  rnea(m, k, u, NULL, p->gravity, h);
+  dof_parents(m, pd);
+  ltdl(M, nv, pd);
+  for (int i = 0; i < nv; ++i) udot[i] = tau[i] - h[i];
+  ltdl_solve(M, nv, pd, udot);
+  free(M); free(k);
+}
+
+/* Articulated-body algorithm in the common frame (RBDA Table 7.1 with identity transforms). */
+void orc_aba(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+             const double* tau, double* udot) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, u, k);
+  int nb = m->nb;
+  double (*IA)[36] = (double (*)[36])malloc(sizeof(double) * 36 * nb);
+  double pA[MAXB][6], cb[MAXB][6], U[MAXB][6], D[MAXB], uu[MAXB], A[MAXB][6];
+  for (int i = 0; i < nb; ++i) {
+    double IV[6];
+    memcpy(IA[i], k->Isp[i], sizeof(double) * 36);
+    mat6_vec(k->Isp[i], k->V[i], IV);
+    crf(k->V[i], IV, pA[i]);
+    if (i >= 1) {
+      double vs[6];
+      crm(k->V[m->parent[i]], k->S[i], vs);
+      for (int c = 0; c < 6; ++c) cb[i][c] = vs[c] * u[dof_of(i)];
+    }
+  }
+  for (int i = nb - 1; i >= 1; --i) {
+    int par = m->parent[i];
+    mat6_vec(IA[i], k->S[i], U[i]);
+    D[i] = dot6(k->S[i], U[i]) + m->armature[i];
+    uu[i] = tau[dof_of(i)] - dot6(k->S[i], pA[i]);
+    double Ia[36], Iac[6];
+    for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) Ia[6 * a + b] = IA[i][6 * a + b] - U[i][a] * U[i][b] / D[i];
+    mat6_vec(Ia, cb[i], Iac);
+    for (int c = 0; c < 36; ++c) IA[par][c] += Ia[c];
+    for (int c = 0; c < 6; ++c) pA[par][c] += pA[i][c] + Iac[c] + U[i][c] * uu[i] / D[i];
+  }
+  /* base: IA_0 A_0 + pA_0 = [tau_ang; tau_lin] */
+  double rhs[6], A0[6], wxv[3];
+  for (int c = 0; c < 3; ++c) { rhs[c] = tau[3 + c] - pA[0][c]; rhs[3 + c] = tau[c] - pA[0][3 + c]; }
+  spd_solve(IA[0], rhs, A0, 6);
+  memcpy(A[0], A0, sizeof A0);
+  cross3(k->V[0], k->V[0] + 3, wxv);
+  for (int c = 0; c < 3; ++c) { udot[3 + c] = A0[c]; udot[c] = A0[3 + c] + wxv[c] + p->gravity[c]; }
+  for (int i = 1; i < nb; ++i) {
+    int par = m->parent[i];
+    double Ap[6];
+    for (int c = 0; c < 6; ++c) Ap[c] = A[par][c] + cb[i][c];
+    double qdd = (uu[i] - dot6(U[i], Ap)) / D[i];
+    udot[dof_of(i)] = qdd;
+    for (int c = 0; c < 6; ++c) A[i][c] = Ap[c] + k->S[i][c] * qdd;
+  }
+  free(IA); free(k);
+}
+
+void orc_point_jacobian(const rsb_model_blob* m, const double* q, int body, const double* p_local,
+                        double* pos_world, double* J) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, NULL, k);
+  double t[3], x[3];
+  mat3_vec(k->R[body], p_local, t);
+  for (int c = 0; c < 3; ++c) { x[c] = k->r[body][c] + t[c]; pos_world[c] = k->pbase[c] + x[c]; }
+  point_jacobian(m, k, body, x, J);
+  free(k);
+}
+
+void orc_energy(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+                double* kinetic, double* potential) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, u, k);
+  double T = 0, Upot = 0;
+  for (int i = 0; i < m->nb; ++i) {
+    double IV[6];
+    mat6_vec(k->Isp[i], k->V[i], IV);
+    T += 0.5 * dot6(k->V[i], IV);
+    if (i >= 1) T += 0.5 * m->armature[i] * u[dof_of(i)] * u[dof_of(i)];
+    double cw[3] = {k->pbase[0] + k->com[i][0], k->pbase[1] + k->com[i][1], k->pbase[2] + k->com[i][2]};
+    Upot -= m->mass[i] * dot3(p->gravity, cw);
+  }
+  *kinetic = T; *potential = Upot;
+  free(k);
+}
+
+void orc_momentum(const rsb_model_blob* m, const double* q, const double* u, double* lin, double* ang) {
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  kinematics(m, q, u, k);
+  double H[6] = {0};
+  for (int i = 0; i < m->nb; ++i) {
+    double IV[6];
+    mat6_vec(k->Isp[i], k->V[i], IV);
+    for (int c = 0; c < 6; ++c) H[c] += IV[c];
+  }
+  /* shift the angular momentum from O to the world origin: L_0 = L_O + p_base x P */
+  double pxP[3];
+  cross3(k->pbase, H + 3, pxP);
+  for (int c = 0; c < 3; ++c) { lin[c] = H[3 + c]; ang[c] = H[c] + pxP[c]; }
+  free(k);
+}
+
+/* ------------------------------------------------------------------------------ terrain */
+void orc_terrain(const orc_params* p, double x, double y, double* h, double* n) {
+  if (p->terrain_type == 0) { *h = p->ground_z; n[0] = 0; n[1] = 0; n[2] = 1; return; }
+  /* regular grid, each cell split along the (ix,iy)-(ix+1,iy+1) diagonal into two triangles */
+  int xs = p->hm_xs, ys = p->hm_ys;
+  double dx = p->hm_xsize / (xs - 1), dy = p->hm_ysize / (ys - 1);
+  double gx = (x - (p->hm_cx - 0.5 * p->hm_xsize)) / dx, gy = (y - (p->hm_cy - 0.5 * p->hm_ysize)) / dy;
+  if (gx < 0) gx = 0;
+  if (gx > xs - 1) gx = xs - 1;
+  if (gy < 0) gy = 0;
+  if (gy > ys - 1) gy = ys - 1;
+  int ix = (int)floor(gx), iy = (int)floor(gy);
+  if (ix > xs - 2) ix = xs - 2;
+  if (iy > ys - 2) iy = ys - 2;
+  double fx = gx - ix, fy = gy - iy;
+  double h00 = p->hm_heights[iy * xs + ix], h10 = p->hm_heights[iy * xs + ix + 1];
+  double h01 = p->hm_heights[(iy + 1) * xs + ix], h11 = p->hm_heights[(iy + 1) * xs + ix + 1];
+  double sx, sy;
+  if (fx >= fy) { sx = h10 - h00; sy = h11 - h10; } else { sx = h11 - h01; sy = h01 - h00; }
+  *h = h00 + sx * fx + sy * fy;
+  double gxs = sx / dx, gys = sy / dy, inv = 1.0 / sqrt(gxs * gxs + gys * gys + 1.0);
+  n[0] = -gxs * inv; n[1] = -gys * inv; n[2] = inv;
+}
+
+/* --------------------------------------------------------------------------- actuation */
+void orc_actuation(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+                   const double* kp, const double* kd, const double* p_target,
+                   const double* d_target, const double* tau_ff, double* tau) {
+  for (int d = 0; d < 6; ++d) tau[d] = tau_ff ? tau_ff[d] : 0.0;
+  for (int i = 1; i < m->nb; ++i) {
+    int d = dof_of(i), qi = qidx_of(i);
+    double t = tau_ff ? tau_ff[d] : 0.0;
+    if (p->control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && kp && kd) {
+      double pt = p_target ? p_target[qi] : 0.0, dt_ = d_target ? d_target[d] : 0.0;
+      t += kp[d] * (pt - q[qi]) + kd[d] * (dt_ - u[d]);
+    }
+    if (m->effort[i] > 0) { if (t > m->effort[i]) t = m->effort[i]; if (t < -m->effort[i]) t = -m->effort[i]; }
+    tau[d] = t - m->damping[i] * u[d];
+  }
+}
+
+/* ------------------------------------------------------------------- per-contact solver */
+/*
+ * One contact of the per-contact iteration (Hwangbo et al. 2018, §III): given the contact-space
+ * velocity v the contact would have with its own impulse removed, and its own 3x3 Delassus
+ * block G (contact frame [t1 t2 n]), return the impulse:
+ *   open : v_n > 0                         -> 0
+ *   stick: lam = -G^-1 v inside the cone   -> lam
+ *   slip : on {v_n^+ = 0} ∩ cone boundary, direction found by bisection so that the
+ *          post-impulse tangential velocity is anti-parallel to the friction impulse
+ *          (maximum dissipation).  The bisection runs on unit direction vectors, not angles.
+ */
+static void solve_one_contact(const double* G, const double* Ginv, const double* v, double mu,
+                              int bisect_iters, double* lam) {
+  if (v[2] > 0.0) { lam[0] = lam[1] = lam[2] = 0.0; return; }
+  double ls[3];
+  for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
+  double lt2 = ls[0] * ls[0] + ls[1] * ls[1];
+  if (ls[2] >= 0.0 && lt2 <= mu * mu * ls[2] * ls[2]) { lam[0] = ls[0]; lam[1] = ls[1]; lam[2] = ls[2]; return; }
+  double d0[2];
+  if (lt2 < 1e-30) { d0[0] = 1.0; d0[1] = 0.0; }
+  else { double il = 1.0 / sqrt(lt2); d0[0] = ls[0] * il; d0[1] = ls[1] * il; }
+  double lo[2] = {d0[1], -d0[0]}, hi[2] = {-d0[1], d0[0]}, d[2] = {d0[0], d0[1]};
+  double ln = 0.0, mue = mu;
+  for (int it = 0; it <= bisect_iters; ++it) {
+    /* Jamming guard: when the friction impulse along d would cancel the normal response
+     * (G_nn + mu G_nt.d < kappa G_nn, a Painleve-type configuration) the friction coefficient used along
+     * d is reduced so that the normal response stays kappa G_nn; the impulse stays inside the cone. */
+    double gd = G[6] * d[0] + G[7] * d[1];
+    mue = mu;
+    if (G[8] + mu * gd < ORC_JAM_KAPPA * G[8]) mue = (ORC_JAM_KAPPA - 1.0) * G[8] / gd;
+    ln = -v[2] / (G[8] + mue * gd);
+    if (it == bisect_iters) break;
+    double vt0 = v[0] + ln * (mue * (G[0] * d[0] + G[1] * d[1]) + G[2]);
+    double vt1 = v[1] + ln * (mue * (G[3] * d[0] + G[4] * d[1]) + G[5]);
+    double g = vt0 * d[1] - vt1 * d[0];
+    if (g > 0.0) { lo[0] = d[0]; lo[1] = d[1]; } else { hi[0] = d[0]; hi[1] = d[1]; }
+    double s0 = lo[0] + hi[0], s1 = lo[1] + hi[1];
+    double inv = 1.0 / sqrt(s0 * s0 + s1 * s1);
+    d[0] = s0 * inv; d[1] = s1 * inv;
+  }
+  lam[0] = mue * ln * d[0]; lam[1] = mue * ln * d[1]; lam[2] = ln;
+}
+
+static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {
+  double t1[3], t2[3];
+  double dn = n[0];
+  t1[0] = 1.0 - dn * n[0]; t1[1] = -dn * n[1]; t1[2] = -dn * n[2];
+  double il = 1.0 / sqrt(dot3(t1, t1));
+  for (int c = 0; c < 3; ++c) t1[c] *= il;
+  cross3(n, t1, t2);
+  for (int c = 0; c < 3; ++c) { Rc[3 * c] = t1[c]; Rc[3 * c + 1] = t2[c]; Rc[3 * c + 2] = n[c]; }
+}
+
+/* ---------------------------------------------------------------------------------- step */
+static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
+                      const double* kd, const double* p_target, const double* d_target,
+                      const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
+                      int32_t* flags, double* dbgG, double* dbgc, double* dbglam) {
+  int nv = m->nv, nq = m->nq, kmax = p->kmax > MAXK ? MAXK : p->kmax;
+  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
+  double* M = (double*)malloc(sizeof(double) * nv * nv);
+  double h[MAXV], tau[MAXV], ufree[MAXV];
+  int pd[MAXV], fl = 0;
+
+  /* integrate1: kinematics, collision detection, M, h */
+  kinematics(m, q, u, k);
+  crba(m, k, M);
+  rnea(m, k, u, NULL, p->gravity, h);
+  orc_actuation(m, p, q, u, kp, kd, p_target, d_target, tau_ff, tau);
+
+  int nc = 0;
+  double cx[MAXK][3], cn[MAXK][3], cdepth[MAXK], Rc[MAXK][9];
+  int cbody[MAXK], ccol[MAXK];
+  for (int s = 0; s < m->ncol; ++s) {
+    int b = m->col_body[s];
+    double t[3], c[3], hgt, n[3];
+    mat3_vec(k->R[b], m->col_pos[s], t);
+    for (int a = 0; a < 3; ++a) c[a] = k->r[b][a] + t[a];
+    orc_terrain(p, k->pbase[0] + c[0], k->pbase[1] + c[1], &hgt, n);
+    double dist = (k->pbase[2] + c[2] - hgt) * n[2];
+    double depth = m->col_radius[s] - dist;
+    if (depth > 0.0) {
+      if (nc >= kmax) { fl |= 1; continue; }
+      for (int a = 0; a < 3; ++a) { cx[nc][a] = c[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }
+      cdepth[nc] = depth; cbody[nc] = b; ccol[nc] = s;
+      contact_frame(n, Rc[nc]);
+      ++nc;
+    }
+  }
+
+  /* integrate2: u_free = u + dt M^-1 (tau - h) */
+  dof_parents(m, pd);
+  ltdl(M, nv, pd);
+  for (int i = 0; i < nv; ++i) ufree[i] = p->dt * (tau[i] - h[i]);
+  ltdl_solve(M, nv, pd, ufree);
+  for (int i = 0; i < nv; ++i) ufree[i] += u[i];
+
+  double lam[MAXK][3];
+  int it_used = 0;
+  double (*X)[3][MAXV] = NULL;
+  if (nc > 0) {
+    double (*Jc)[3][MAXV] = (double (*)[3][MAXV])malloc(sizeof(double) * nc * 3 * MAXV);
+    X = (double (*)[3][MAXV])malloc(sizeof(double) * nc * 3 * MAXV);
+    double* Jw = (double*)malloc(sizeof(double) * 3 * nv);
+    for (int i = 0; i < nc; ++i) {
+      point_jacobian(m, k, cbody[i], cx[i], Jw);
+      for (int r = 0; r < 3; ++r)
+        for (int d = 0; d < nv; ++d) {
+          double s = 0;
+          for (int c = 0; c < 3; ++c) s += Rc[i][3 * c + r] * Jw[c * nv + d];
+          Jc[i][r][d] = s; X[i][r][d] = s;
+        }
+      for (int r = 0; r < 3; ++r) ltdl_solve(M, nv, pd, X[i][r]);
+    }
+    /* Delassus blocks G_ij = J_i M^-1 J_j^T and free contact velocity c_i = J_i u_free */
+    double G[MAXK][MAXK][9], Ginv[MAXK][9], cfree[MAXK][3];
+    for (int i = 0; i < nc; ++i) {
+      for (int j = 0; j < nc; ++j)
+        for (int r = 0; r < 3; ++r)
+          for (int c = 0; c < 3; ++c) {
+            double s = 0;
+            for (int d = 0; d < nv; ++d) s += Jc[i][r][d] * X[j][c][d];
+            G[i][j][3 * r + c] = s;
+          }
+      inv3(G[i][i], Ginv[i]);
+      for (int r = 0; r < 3; ++r) {
+        double s = 0;
+        for (int d = 0; d < nv; ++d) s += Jc[i][r][d] * ufree[d];
+        cfree[i][r] = s;
+      }
+      cfree[i][2] -= p->erp * cdepth[i] / p->dt;
+      lam[i][0] = lam[i][1] = lam[i][2] = 0;
+    }
+    /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
+    if (dbgG)
+      for (int i = 0; i < nc; ++i)
+        for (int j = 0; j < nc; ++j)
+          for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) dbgG[(3 * i + r) * 3 * nc + 3 * j + c] = G[i][j][3 * r + c];
+    if (dbgc) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) dbgc[3 * i + r] = cfree[i][r];
+    /* Convergence: largest impulse change of the sweep <= threshold * (largest normal impulse + floor).
+     * A RELATIVE criterion on purpose: the device evaluates the same test in fp32, where the rounding
+     * noise of an impulse update is proportional to the impulse magnitudes (RaiSim's absolute fp64
+     * threshold [RECALL] cannot be met in fp32). */
+    double alpha = p->alpha_init;
+    for (int it = 0; it < p->max_iter; ++it) {
+      double err = 0, scale = 0;
+      for (int i = 0; i < nc; ++i) {
+        double v[3] = {cfree[i][0], cfree[i][1], cfree[i][2]}, ln[3];
+        for (int j = 0; j < nc; ++j) {
+          if (j == i) continue;
+          for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam[j][0] + G[i][j][3 * r + 1] * lam[j][1] + G[i][j][3 * r + 2] * lam[j][2];
+        }
+        solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->bisect_iters, ln);
+        for (int r = 0; r < 3; ++r) {
+          double dl = alpha * (ln[r] - lam[i][r]);
+          lam[i][r] += dl;
+          if (fabs(dl) > err) err = fabs(dl);
+        }
+      }
+      for (int i = 0; i < nc; ++i) if (lam[i][2] > scale) scale = lam[i][2];
+      it_used = it + 1;
+      alpha = alpha * p->alpha_decay;
+      if (alpha < p->alpha_min) alpha = p->alpha_min;
+      if (err <= p->threshold * (scale + ORC_LAMBDA_FLOOR)) break;
+    }
+    if (dbglam) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) dbglam[3 * i + r] = lam[i][r];
+    free(Jc); free(Jw);
+  }
+
+  /* u+ = u_free + M^-1 J^T lam ;  q+ = q (+) dt u+   (semi-implicit Euler) */
+  for (int i = 0; i < nc; ++i)
+    for (int r = 0; r < 3; ++r)
+      for (int d = 0; d < nv; ++d) ufree[d] += X[i][r][d] * lam[i][r];
+  if (X) free(X);
+  for (int d = 0; d < nv; ++d) u[d] = ufree[d];
+  for (int c = 0; c < 3; ++c) q[c] += p->dt * u[c];
+  {
+    double w[3] = {u[3], u[4], u[5]};
+    double wn = sqrt(dot3(w, w)), half = 0.5 * wn * p->dt;
+    double sc = (wn > 1e-12) ? sin(half) / wn : 0.5 * p->dt, cw = cos(half);
+    double dq[4] = {cw, sc * w[0], sc * w[1], sc * w[2]};
+    double a[4] = {q[3], q[4], q[5], q[6]}, r4[4];
+    r4[0] = dq[0] * a[0] - dq[1] * a[1] - dq[2] * a[2] - dq[3] * a[3];
+    r4[1] = dq[0] * a[1] + dq[1] * a[0] + dq[2] * a[3] - dq[3] * a[2];
+    r4[2] = dq[0] * a[2] - dq[1] * a[3] + dq[2] * a[0] + dq[3] * a[1];
+    r4[3] = dq[0] * a[3] + dq[1] * a[2] - dq[2] * a[1] + dq[3] * a[0];
+    double n4 = 1.0 / sqrt(r4[0] * r4[0] + r4[1] * r4[1] + r4[2] * r4[2] + r4[3] * r4[3]);
+    for (int c = 0; c < 4; ++c) q[3 + c] = r4[c] * n4;
+  }
+  for (int i = 1; i < m->nb; ++i) q[qidx_of(i)] += p->dt * u[dof_of(i)];
+
+  for (int i = 0; i < nq; ++i) if (!isfinite(q[i])) fl |= 2;
+  for (int i = 0; i < nv; ++i) if (!isfinite(u[i])) fl |= 2;
+
+  if (contacts)
+    for (int i = 0; i < nc; ++i) {
+      for (int c = 0; c < 3; ++c) {
+        contacts[i].position[c] = k->pbase[c] + cx[i][c];
+        contacts[i].normal[c] = cn[i][c];
+        contacts[i].impulse[c] = Rc[i][3 * c] * lam[i][0] + Rc[i][3 * c + 1] * lam[i][1] + Rc[i][3 * c + 2] * lam[i][2];
+      }
+      contacts[i].depth = cdepth[i]; contacts[i].body = cbody[i]; contacts[i].collision = ccol[i];
+    }
+  if (n_contacts) *n_contacts = nc;
+  if (iters) *iters = it_used;
+  if (flags) *flags = fl;
+  free(M); free(k);
+}
+
+void orc_step(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
+              const double* kd, const double* p_target, const double* d_target,
+              const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
+              int32_t* flags) {
+  step_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, contacts, n_contacts, iters, flags, NULL, NULL, NULL);
+}
+
+void orc_step_debug(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
+                    const double* kd, const double* p_target, const double* d_target,
+                    const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
+                    int32_t* flags, double* G, double* c, double* lam) {
+  step_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, contacts, n_contacts, iters, flags, G, c, lam);
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int substeps, double* q,
+                   double* u, const double* kp, const double* kd, const double* p_target,
+                   const double* d_target, const double* tau_ff, orc_contact* contacts,
+                   int32_t* n_contacts, int32_t* iters, int32_t* flags, int nthreads) {
+  int used = 1;
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+  used = nthreads;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+  for (int e = 0; e < N; ++e) {
+    int fl_acc = 0;
+    for (int s = 0; s < substeps; ++s) {
+      int32_t fl = 0;
+      orc_step(m, p, q + (size_t)e * m->nq, u + (size_t)e * m->nv, kp, kd,
+               p_target ? p_target + (size_t)e * m->nq : NULL,
+               d_target ? d_target + (size_t)e * m->nv : NULL,
+               tau_ff ? tau_ff + (size_t)e * m->nv : NULL,
+               contacts ? contacts + (size_t)e * p->kmax : NULL,
+               n_contacts ? n_contacts + e : NULL, iters ? iters + e : NULL, &fl);
+      fl_acc |= fl;
+    }
+    if (flags) flags[e] = fl_acc;
+  }
+  return used;
+}

@@ -1,0 +1,115 @@
+/*
+ * rsb_oracle.h — CPU fp64 oracle for the batched World::integrate() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as
+ * the checker / the timed CPU baseline.  The product path (raisimlib_amd/) never links,
+ * imports or calls it and has no CPU fallback.
+ *
+ * PARITY UNPINNED.  /root/reference (leggedrobotics/raisimLib @ v0) is a three-file stub
+ * (.gitignore, .travis.yml, README.md) with no source, binaries, tests or golden vectors
+ * (SURVEY.md §0, §8c), and RaiSim's engine is closed source upstream.  This oracle is therefore
+ * written from the published algorithms, not restated from reference files:
+ *   - Featherstone, "Rigid Body Dynamics Algorithms" (2008): RNEA (ch.5), CRBA + LTDL
+ *     factorisation (ch.6), ABA (ch.7), spatial algebra (ch.2).
+ *   - Hwangbo, Lee, Hutter, "Per-Contact Iteration Method for Solving Contact Dynamics",
+ *     IEEE RA-L 3(2), 2018: per-contact Gauss-Seidel with open / stick / slip(bisection) cases.
+ * It is pinned by analytic known-answer tests and internal cross-checks (tests/test_oracle_*.py).
+ * All parity statements in this repo are "vs. this in-repo oracle", never "vs. RaiSim".
+ */
+#ifndef RSB_ORACLE_H_
+#define RSB_ORACLE_H_
+
+#include "../include/rsb.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_params {
+  double dt;
+  double gravity[3];
+  double mu;
+  double erp;
+  double alpha_init, alpha_min, alpha_decay, threshold;
+  int32_t max_iter;
+  int32_t bisect_iters;
+  int32_t kmax;
+  int32_t control_mode;      /* rsb_control_mode */
+  int32_t terrain_type;      /* 0 = plane, 1 = heightmap */
+  int32_t hm_xs, hm_ys, pad_;
+  double ground_z;
+  double hm_xsize, hm_ysize, hm_cx, hm_cy;
+  const float* hm_heights;   /* [ys][xs], x fastest */
+} orc_params;
+
+typedef struct orc_contact {
+  double position[3];
+  double normal[3];
+  double impulse[3];  /* world frame */
+  double depth;
+  int32_t body, collision;
+} orc_contact;
+
+void orc_default_params(orc_params* p);
+
+/* M [nv*nv] row-major via CRBA (the algorithm the device kernel mirrors) */
+void orc_mass_matrix(const rsb_model_blob* m, const double* q, double* M);
+/* M via nv calls of RNEA with unit accelerations (independent cross-check) */
+void orc_mass_matrix_rne(const rsb_model_blob* m, const double* q, double* M);
+/* h(q,u): Coriolis/centrifugal + gravity, such that M udot + h = tau + J^T f */
+void orc_nonlinearities(const rsb_model_blob* m, const orc_params* p, const double* q,
+                        const double* u, double* h);
+/* inverse dynamics tau = M udot + h (RNEA with accelerations) */
+void orc_inverse_dynamics(const rsb_model_blob* m, const orc_params* p, const double* q,
+                          const double* u, const double* udot, double* tau);
+/* forward dynamics by the articulated-body algorithm (independent of CRBA/LTDL) */
+void orc_aba(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+             const double* tau, double* udot);
+/* forward dynamics via CRBA + LTDL solve */
+void orc_forward_dynamics(const rsb_model_blob* m, const orc_params* p, const double* q,
+                          const double* u, const double* tau, double* udot);
+/* world position of a body-frame point, and its 3 x nv Jacobian (row-major) */
+void orc_point_jacobian(const rsb_model_blob* m, const double* q, int body, const double* p_local,
+                        double* pos_world, double* J);
+void orc_energy(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+                double* kinetic, double* potential);
+/* linear momentum (3) and angular momentum about the world origin (3) */
+void orc_momentum(const rsb_model_blob* m, const double* q, const double* u, double* lin, double* ang);
+
+/* terrain height + unit normal under (x, y) (plane or triangulated height map) */
+void orc_terrain(const orc_params* p, double x, double y, double* h, double* n);
+
+/* tau from control mode: PD (joints only) + feed-forward, minus joint damping, clipped to effort */
+void orc_actuation(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+                   const double* kp, const double* kd, const double* p_target,
+                   const double* d_target, const double* tau_ff, double* tau);
+
+/* one World::integrate(): q,u updated in place.  contacts has room for p->kmax entries.
+ * flags bit0: contact overflow (more than kmax), bit1: non-finite state. */
+void orc_step(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
+              const double* kd, const double* p_target, const double* d_target,
+              const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
+              int32_t* flags);
+
+/* as orc_step, also returning the contact problem in contact-frame coordinates [t1 t2 n]:
+ * G [3nc*3nc] row-major Delassus matrix, c [3nc] free contact velocity, lam [3nc] solved impulses */
+void orc_step_debug(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
+                    const double* kd, const double* p_target, const double* d_target,
+                    const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
+                    int32_t* flags, double* G, double* c, double* lam);
+
+/* N independent envs, `substeps` integrate() calls each; OpenMP parallel-for over envs
+ * (mirrors raisimGymTorch's VectorizedEnvironment::step fan-out [RECALL]).
+ * q [N*nq], u [N*nv], p_target [N*nq], d_target [N*nv], tau_ff [N*nv] (may be NULL).
+ * contacts [N*kmax], n_contacts/iters/flags [N] (may be NULL). Returns threads used. */
+int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int substeps, double* q,
+                   double* u, const double* kp, const double* kd, const double* p_target,
+                   const double* d_target, const double* tau_ff, orc_contact* contacts,
+                   int32_t* n_contacts, int32_t* iters, int32_t* flags, int nthreads);
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,127 @@
+"""ctypes binding of the C-ABI declared in include/rsb.h (plumbing only — no physics here).
+
+The shared library `raisimlib_amd/lib/librsb.so` is built in-tree by `__graft_entry__.build()`
+(hipcc, gfx950).  Loading fails loudly if it is missing: there is no Python or CPU fallback.
+"""
+import ctypes as C
+import os
+
+RSB_MAX_BODIES = 64
+RSB_MAX_DOF = 6 + RSB_MAX_BODIES - 1
+RSB_MAX_COLLISIONS = 64
+RSB_MAX_CONTACTS = 16
+RSB_NAME_LEN = 48
+
+RSB_HOST, RSB_DEVICE = 0, 1
+RSB_FORCE_AND_TORQUE, RSB_PD_PLUS_FEEDFORWARD_TORQUE = 0, 1
+(RSB_F_GC, RSB_F_GV, RSB_F_PTARGET, RSB_F_DTARGET, RSB_F_TAU_FF, RSB_F_CONTACT_COUNT, RSB_F_CONTACTS,
+ RSB_F_FLAGS) = range(8)
+
+_B, _S = RSB_MAX_BODIES, RSB_MAX_COLLISIONS
+
+
+class ModelBlob(C.Structure):
+    _fields_ = [
+        ("nb", C.c_int32), ("nq", C.c_int32), ("nv", C.c_int32), ("ncol", C.c_int32), ("depth", C.c_int32),
+        ("reserved", C.c_int32),
+        ("parent", C.c_int32 * _B), ("level", C.c_int32 * _B), ("jtype", C.c_int32 * _B),
+        ("axis", (C.c_double * 3) * _B), ("ptree", (C.c_double * 3) * _B), ("rtree", (C.c_double * 9) * _B),
+        ("mass", C.c_double * _B), ("com", (C.c_double * 3) * _B), ("inertia", (C.c_double * 6) * _B),
+        ("armature", C.c_double * _B), ("damping", C.c_double * _B),
+        ("q_lower", C.c_double * _B), ("q_upper", C.c_double * _B), ("effort", C.c_double * _B),
+        ("col_body", C.c_int32 * _S), ("col_pos", (C.c_double * 3) * _S), ("col_radius", C.c_double * _S),
+        ("body_name", (C.c_char * RSB_NAME_LEN) * _B), ("joint_name", (C.c_char * RSB_NAME_LEN) * _B),
+        ("col_name", (C.c_char * RSB_NAME_LEN) * _S),
+    ]
+
+
+class Contact(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("normal", C.c_float * 3), ("impulse", C.c_float * 3),
+                ("depth", C.c_float), ("body", C.c_int32), ("collision", C.c_int32)]
+
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsb.so")
+
+# name -> (restype, argtypes); mirrors include/rsb.h one-to-one (tests check the two stay in sync)
+_VP, _I, _D, _FP, _CP = C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_char_p
+PROTOTYPES = {
+    "rsb_last_error": (C.c_char_p, []),
+    "rsb_version": (C.c_char_p, []),
+    "rsb_model_from_urdf_file": (_I, [_CP, C.POINTER(_VP)]),
+    "rsb_model_from_urdf_string": (_I, [_CP, C.POINTER(_VP)]),
+    "rsb_model_from_blob": (_I, [C.POINTER(ModelBlob), C.POINTER(_VP)]),
+    "rsb_model_destroy": (_I, [_VP]),
+    "rsb_model_get_blob": (_I, [_VP, C.POINTER(ModelBlob)]),
+    "rsb_model_body_index": (_I, [_VP, _CP]),
+    "rsb_model_joint_index": (_I, [_VP, _CP]),
+    "rsb_model_total_mass": (_D, [_VP]),
+    "rsb_device_count": (_I, []),
+    "rsb_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
+    "rsb_destroy": (_I, [_VP]),
+    "rsb_set_stream": (_I, [_VP, _VP]),
+    "rsb_get_stream": (_VP, [_VP]),
+    "rsb_synchronize": (_I, [_VP]),
+    "rsb_num_envs": (_I, [_VP]),
+    "rsb_dims": (_I, [_VP] + [C.POINTER(C.c_int)] * 5),
+    "rsb_set_timestep": (_I, [_VP, _D]),
+    "rsb_get_timestep": (_D, [_VP]),
+    "rsb_get_world_time": (_D, [_VP]),
+    "rsb_set_gravity": (_I, [_VP, C.POINTER(C.c_double)]),
+    "rsb_set_erp": (_I, [_VP, _D]),
+    "rsb_set_friction": (_I, [_VP, _D]),
+    "rsb_set_contact_solver_param": (_I, [_VP, _D, _D, _D, _I, _D]),
+    "rsb_set_max_contacts": (_I, [_VP, _I]),
+    "rsb_set_lanes_per_env": (_I, [_VP, _I]),
+    "rsb_get_lanes_per_env": (_I, [_VP]),
+    "rsb_set_ground": (_I, [_VP, _D]),
+    "rsb_set_heightmap": (_I, [_VP, _I, _I, _D, _D, _D, _D, _FP]),
+    "rsb_set_state": (_I, [_VP, _FP, _FP, _FP, _I]),
+    "rsb_get_state": (_I, [_VP, _FP, _FP, _I]),
+    "rsb_set_control_mode": (_I, [_VP, _I]),
+    "rsb_set_pd_gains": (_I, [_VP, _FP, _FP]),
+    "rsb_set_pd_target": (_I, [_VP, _FP, _FP, _I]),
+    "rsb_set_generalized_force": (_I, [_VP, _FP, _I]),
+    "rsb_integrate": (_I, [_VP, _I]),
+    "rsb_integrate1": (_I, [_VP]),
+    "rsb_integrate2": (_I, [_VP]),
+    "rsb_get_contacts": (_I, [_VP, _FP, _FP, _I]),
+    "rsb_get_mass_matrix": (_I, [_VP, _FP, _I]),
+    "rsb_get_nonlinearities": (_I, [_VP, _FP, _I]),
+    "rsb_get_flags": (_I, [_VP, _FP, _I]),
+    "rsb_get_solver_iterations": (_I, [_VP, _FP, _I]),
+    "rsb_obs_dim": (_I, [_VP, _I]),
+    "rsb_gather_obs": (_I, [_VP, _FP, _FP, _I, _I]),
+    "rsb_device_ptr": (_VP, [_VP, _I]),
+    "rsb_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
+    "rsb_enable_timing": (_I, [_VP, _I]),
+    "rsb_debug_select_env": (_I, [_VP, _I]),
+    "rsb_debug_read_contact_problem": (_I, [_VP, C.POINTER(C.c_int), _FP, _FP, _FP]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librsb.so once; raise (never fall back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). raisimlib_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library drift; fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class RsbError(RuntimeError):
+    pass
+
+
+def check(status, what=""):
+    if status != 0:
+        msg = lib().rsb_last_error()
+        raise RsbError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")

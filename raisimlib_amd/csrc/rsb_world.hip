@@ -1,0 +1,602 @@
+// rsb_world.hip — host side of the C-ABI (include/rsb.h): device-resident batched world.
+//
+// Plays the role of N x { raisim::World + one raisim::ArticulatedSystem + Ground/HeightMap }
+// [RECALL; World.hpp / ArticulatedSystem.hpp are absent from /root/reference, SURVEY.md §8b].
+// State lives in HBM as row-major [N, dim] float32 rows; rsb_integrate() launches the fused step
+// kernel (step_kernel.h) on the handle's stream.  No CPU fallback exists anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "query_kernel.h"
+#include "rsb.h"
+#include "rsb_internal.h"
+#include "step_kernel.h"
+
+using rsbk::DevModel;
+using rsbk::LdsLayout;
+using rsbk::StepArgs;
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      rsb::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+      return RSB_E_HIP;                                                                         \
+    }                                                                                           \
+  } while (0)
+
+struct rsb_world {
+  rsb_model_blob blob;
+  int N = 0, device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = true;
+  DevModel* d_model = nullptr;
+  float *d_gc = nullptr, *d_gv = nullptr, *d_pt = nullptr, *d_dt = nullptr, *d_tff = nullptr;
+  float *d_kp = nullptr, *d_kd = nullptr, *d_heights = nullptr;
+  float *d_tmp_gc = nullptr, *d_tmp_gv = nullptr;
+  uint8_t* d_tmp_mask = nullptr;
+  float *d_M = nullptr, *d_h = nullptr;
+  int32_t* d_obs_idx = nullptr;
+  float* d_dbg = nullptr;
+  int dbg_env = -1;
+  rsb_contact* d_contacts = nullptr;
+  int32_t *d_count = nullptr, *d_flags = nullptr, *d_iters = nullptr;
+  // parameters
+  double dt = 0.0025, gravity[3] = {0, 0, -9.81}, mu = 0.8, erp = 0.0;
+  double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
+  int max_iter = 150, bisect_iters = 20, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
+  int terrain_type = 0, hm_xs = 0, hm_ys = 0;
+  double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
+  int lpe = 0;
+  double world_time = 0;
+  bool integrate1_valid = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false;
+  float last_ms = -1.f;
+};
+
+namespace {
+
+int round4(int x) { return (x + 3) & ~3; }
+
+void build_dev_model(const rsb_model_blob& b, DevModel* d) {
+  std::memset(d, 0, sizeof *d);
+  d->nb = b.nb; d->nq = b.nq; d->nv = b.nv; d->ncol = b.ncol; d->depth = b.depth;
+  d->cw = round4(6 + b.depth - 1);
+  std::vector<std::vector<int>> kids(b.nb);
+  for (int i = 0; i < b.nb; ++i) {
+    d->parent[i] = b.parent[i]; d->level[i] = b.level[i]; d->jtype[i] = b.jtype[i];
+    if (i > 0) kids[b.parent[i]].push_back(i);
+    for (int c = 0; c < 3; ++c) { d->axis[i][c] = (float)b.axis[i][c]; d->ptree[i][c] = (float)b.ptree[i][c]; d->com[i][c] = (float)b.com[i][c]; }
+    for (int c = 0; c < 9; ++c) d->rtree[i][c] = (float)b.rtree[i][c];
+    for (int c = 0; c < 6; ++c) d->inertia[i][c] = (float)b.inertia[i][c];
+    d->mass[i] = (float)b.mass[i]; d->armature[i] = (float)b.armature[i];
+    d->damping[i] = (float)b.damping[i]; d->effort[i] = (float)b.effort[i];
+  }
+  int pos = 0;
+  for (int i = 0; i < b.nb; ++i) {
+    d->nchild[i] = (int)kids[i].size();
+    d->child_start[i] = pos;
+    for (int c : kids[i]) d->child_list[pos++] = c;
+    int l = b.level[i];
+    if (d->nchild[i] > d->maxchild_level[l]) d->maxchild_level[l] = d->nchild[i];
+  }
+  for (int i = 0; i < b.nb * b.depth; ++i) d->anc[i] = -1;
+  for (int i = 0; i < b.nb; ++i)
+    for (int j = i; j >= 0; j = b.parent[j]) d->anc[i * b.depth + b.level[j]] = j;
+  for (int s = 0; s < b.ncol; ++s) {
+    d->col_body[s] = b.col_body[s];
+    for (int c = 0; c < 3; ++c) d->col_pos[s][c] = (float)b.col_pos[s][c];
+    d->col_pos[s][3] = (float)b.col_radius[s];
+  }
+}
+
+LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
+  LdsLayout L;
+  int cw = round4(6 + b.depth - 1);
+  L.shared_ints = round4(round4(b.nb) + b.nb * b.depth);
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += round4(n); return r; };
+  L.q = take(b.nq); L.u = take(b.nv); L.tb = take(8);
+  L.body = take(b.nb * rsbk::kBodySlot);
+  L.ups = take(b.nb * rsbk::kUpSlot);
+  L.fact = take(b.nb * rsbk::kFactSlot);
+  L.chol = take(28);
+  L.wb = take(b.nv);
+  L.con = take(kcap * rsbk::kConSlot);
+  L.wc = take(3 * kcap * cw);
+  L.cv = take(3 * kcap);
+  L.gstride = 3 * kcap + 1;
+  L.g = take(3 * kcap * L.gstride);
+  L.lam = take(3 * kcap);
+  L.wv = take(8);
+  L.per_env = o;
+  return L;
+}
+
+int default_lpe(const rsb_model_blob& b, int kmax) {
+  int need = b.nb > kmax ? b.nb : kmax;
+  if (need <= 16) return 16;
+  if (need <= 32) return 32;
+  return 64;
+}
+
+__global__ void masked_row_copy(float* dst, const float* src, const uint8_t* mask, int N, int dim) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * dim) return;
+  int e = i / dim;
+  if (!mask || mask[e]) dst[i] = src[i];
+}
+
+__global__ void gather_obs_kernel(float* out, const float* gc, const float* gv, const rsb_contact* contacts,
+                                  const int32_t* count, const int32_t* idx, int N, int nq, int nv, int kmax,
+                                  int nslots, float inv_dt) {
+  int od = nq + nv + 3 * nslots;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * od) return;
+  int e = i / od, c = i - e * od;
+  float v;
+  if (c < nq) v = gc[(size_t)e * nq + c];
+  else if (c < nq + nv) v = gv[(size_t)e * nv + c - nq];
+  else {
+    int sl = (c - nq - nv) / 3, ax = (c - nq - nv) - 3 * sl;
+    int want = idx ? idx[sl] : sl;
+    v = 0.f;
+    int nc = count[e];
+    for (int k = 0; k < nc; ++k) {
+      const rsb_contact& ct = contacts[(size_t)e * kmax + k];
+      if (ct.collision == want) v = ct.impulse[ax] * inv_dt;
+    }
+  }
+  out[i] = v;
+}
+
+template <int LPE, int KMAX>
+int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes) {
+  auto kern = rsbk::rsb_step_kernel<LPE, KMAX>;
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  constexpr int EPW = 64 / LPE;
+  int blocks = (w->N + EPW - 1) / EPW;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds_bytes, w->stream, a);
+  HIP_TRY(hipGetLastError());
+  return RSB_OK;
+}
+
+int effective_lpe(const rsb_world* w) {
+  int lpe = w->lpe > 0 ? w->lpe : default_lpe(w->blob, w->kmax);
+  return lpe;
+}
+
+int check_lpe(const rsb_world* w, int lpe) {
+  if (lpe != 16 && lpe != 32 && lpe != 64) { rsb::set_error("lanes_per_env must be 16, 32 or 64"); return RSB_E_INVALID; }
+  if (lpe < w->blob.nb) { rsb::set_error("lanes_per_env must be >= number of bodies"); return RSB_E_INVALID; }
+  if (lpe < w->kmax) { rsb::set_error("lanes_per_env must be >= max contacts"); return RSB_E_INVALID; }
+  return RSB_OK;
+}
+
+int do_integrate(rsb_world* w, int nsub) {
+  HIP_TRY(hipSetDevice(w->device));
+  const int lpe = effective_lpe(w);
+  int st = check_lpe(w, lpe);
+  if (st != RSB_OK) return st;
+  const int kcap = w->kmax <= 8 ? 8 : 16;
+  StepArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.model = w->d_model;
+  a.gc = w->d_gc; a.gv = w->d_gv; a.ptarget = w->d_pt; a.dtarget = w->d_dt; a.tauff = w->d_tff;
+  a.kp = w->d_kp; a.kd = w->d_kd;
+  a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
+  a.heights = w->d_heights;
+  a.dbg = w->dbg_env >= 0 ? w->d_dbg : nullptr;
+  a.dbg_env = w->dbg_env;
+  a.N = w->N; a.nsub = nsub; a.kmax = w->kmax; a.control_mode = w->control_mode;
+  a.dt = (float)w->dt; a.gx = (float)w->gravity[0]; a.gy = (float)w->gravity[1]; a.gz = (float)w->gravity[2];
+  a.mu = (float)w->mu; a.erp = (float)w->erp;
+  a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
+  a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.bisect_iters = w->bisect_iters;
+  a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
+  if (w->terrain_type == 1) {
+    double dx = w->hm_xsize / (w->hm_xs - 1), dy = w->hm_ysize / (w->hm_ys - 1);
+    a.hm_x0 = (float)(w->hm_cx - 0.5 * w->hm_xsize); a.hm_y0 = (float)(w->hm_cy - 0.5 * w->hm_ysize);
+    a.hm_dx = (float)dx; a.hm_dy = (float)dy; a.hm_inv_dx = (float)(1.0 / dx); a.hm_inv_dy = (float)(1.0 / dy);
+  }
+  a.L = make_layout(w->blob, kcap);
+  const int epw = 64 / lpe;
+  size_t lds_bytes = sizeof(float) * ((size_t)a.L.shared_ints + (size_t)epw * a.L.per_env);
+  if (lds_bytes > 160 * 1024) { rsb::set_error("model needs more LDS per workgroup than a CU has (160 KiB)"); return RSB_E_UNSUPPORTED; }
+  if (w->timing) HIP_TRY(hipEventRecord(w->ev0, w->stream));
+  if (kcap == 8) {
+    if (lpe == 16) st = launch_step<16, 8>(w, a, lds_bytes);
+    else if (lpe == 32) st = launch_step<32, 8>(w, a, lds_bytes);
+    else st = launch_step<64, 8>(w, a, lds_bytes);
+  } else {
+    if (lpe == 16) st = launch_step<16, 16>(w, a, lds_bytes);
+    else if (lpe == 32) st = launch_step<32, 16>(w, a, lds_bytes);
+    else st = launch_step<64, 16>(w, a, lds_bytes);
+  }
+  if (st != RSB_OK) return st;
+  if (w->timing) HIP_TRY(hipEventRecord(w->ev1, w->stream));
+  w->world_time += nsub * w->dt;
+  w->integrate1_valid = false;
+  return RSB_OK;
+}
+
+int copy_in(rsb_world* w, float* dst, const float* src, size_t n, int space) {
+  HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(float), space == RSB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, w->stream));
+  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(w->stream));  // the caller may reuse its host buffer
+  return RSB_OK;
+}
+int copy_out(rsb_world* w, void* dst, const void* src, size_t bytes, int space) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, space == RSB_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, w->stream));
+  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(w->stream));
+  return RSB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsb_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
+  if (!m || !out || num_envs <= 0) { rsb::set_error("rsb_create: bad argument"); return RSB_E_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    rsb::set_error("rsb_create: no HIP device is visible (raisimlib_amd has no CPU fallback)");
+    return RSB_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { rsb::set_error("rsb_create: device index out of range"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(device));
+  auto w = std::make_unique<rsb_world>();
+  w->blob = m->blob;
+  w->N = num_envs;
+  w->device = device;
+  const int nq = w->blob.nq, nv = w->blob.nv;
+  const size_t N = (size_t)num_envs;
+  HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&w->ev0));
+  HIP_TRY(hipEventCreate(&w->ev1));
+  auto dm = std::make_unique<DevModel>();
+  build_dev_model(w->blob, dm.get());
+  HIP_TRY(hipMalloc(&w->d_model, sizeof(DevModel)));
+  HIP_TRY(hipMemcpy(w->d_model, dm.get(), sizeof(DevModel), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&w->d_gc, N * nq * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_gv, N * nv * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_pt, N * nq * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_dt, N * nv * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_tff, N * nv * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_kp, nv * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_kd, nv * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_contacts, N * RSB_MAX_CONTACTS * sizeof(rsb_contact)));
+  HIP_TRY(hipMalloc(&w->d_count, N * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&w->d_flags, N * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&w->d_iters, N * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&w->d_obs_idx, RSB_MAX_COLLISIONS * sizeof(int32_t)));
+  HIP_TRY(hipMemset(w->d_gc, 0, N * nq * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_gv, 0, N * nv * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_pt, 0, N * nq * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_dt, 0, N * nv * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_tff, 0, N * nv * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_kp, 0, nv * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_kd, 0, nv * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_contacts, 0, N * RSB_MAX_CONTACTS * sizeof(rsb_contact)));
+  HIP_TRY(hipMemset(w->d_count, 0, N * sizeof(int32_t)));
+  HIP_TRY(hipMemset(w->d_flags, 0, N * sizeof(int32_t)));
+  HIP_TRY(hipMemset(w->d_iters, 0, N * sizeof(int32_t)));
+  // default state: identity orientation, everything else zero
+  std::vector<float> gc(N * nq, 0.f);
+  for (size_t e = 0; e < N; ++e) gc[e * nq + 3] = 1.f;
+  HIP_TRY(hipMemcpy(w->d_gc, gc.data(), gc.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipDeviceSynchronize());
+  *out = w.release();
+  return RSB_OK;
+}
+
+int rsb_destroy(rsb_world* w) {
+  if (!w) return RSB_OK;
+  (void)hipSetDevice(w->device);
+  if (w->stream) (void)hipStreamSynchronize(w->stream);
+  void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
+                  w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_contacts,
+                  w->d_count, w->d_flags, w->d_iters};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (w->ev0) (void)hipEventDestroy(w->ev0);
+  if (w->ev1) (void)hipEventDestroy(w->ev1);
+  if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
+  delete w;
+  return RSB_OK;
+}
+
+int rsb_set_stream(rsb_world* w, void* hip_stream) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  if (w->own_stream && w->stream) HIP_TRY(hipStreamDestroy(w->stream));
+  if (hip_stream) { w->stream = (hipStream_t)hip_stream; w->own_stream = false; }
+  else { HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)); w->own_stream = true; }
+  return RSB_OK;
+}
+void* rsb_get_stream(rsb_world* w) { return w ? (void*)w->stream : nullptr; }
+int rsb_synchronize(rsb_world* w) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  return RSB_OK;
+}
+
+int rsb_num_envs(const rsb_world* w) { return w ? w->N : RSB_E_INVALID; }
+int rsb_dims(const rsb_world* w, int* nb, int* nq, int* nv, int* ncol, int* kmax) {
+  if (!w) return RSB_E_INVALID;
+  if (nb) *nb = w->blob.nb;
+  if (nq) *nq = w->blob.nq;
+  if (nv) *nv = w->blob.nv;
+  if (ncol) *ncol = w->blob.ncol;
+  if (kmax) *kmax = w->kmax;
+  return RSB_OK;
+}
+
+int rsb_set_timestep(rsb_world* w, double dt) {
+  if (!w || !(dt > 0)) { rsb::set_error("rsb_set_timestep: dt must be positive"); return RSB_E_INVALID; }
+  w->dt = dt;
+  return RSB_OK;
+}
+double rsb_get_timestep(const rsb_world* w) { return w ? w->dt : 0.0; }
+double rsb_get_world_time(const rsb_world* w) { return w ? w->world_time : 0.0; }
+int rsb_set_gravity(rsb_world* w, const double g[3]) {
+  if (!w || !g) return RSB_E_INVALID;
+  for (int i = 0; i < 3; ++i) w->gravity[i] = g[i];
+  return RSB_OK;
+}
+int rsb_set_erp(rsb_world* w, double erp) { if (!w) return RSB_E_INVALID; w->erp = erp; return RSB_OK; }
+int rsb_set_friction(rsb_world* w, double mu) {
+  if (!w || mu < 0) { rsb::set_error("rsb_set_friction: mu must be >= 0"); return RSB_E_INVALID; }
+  w->mu = mu;
+  return RSB_OK;
+}
+int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min, double alpha_decay,
+                                 int max_iter, double threshold) {
+  if (!w || max_iter < 1 || !(threshold >= 0) || !(alpha_init > 0)) { rsb::set_error("rsb_set_contact_solver_param: bad argument"); return RSB_E_INVALID; }
+  w->alpha_init = alpha_init; w->alpha_min = alpha_min; w->alpha_decay = alpha_decay;
+  w->max_iter = max_iter; w->threshold = threshold;
+  return RSB_OK;
+}
+int rsb_set_max_contacts(rsb_world* w, int kmax) {
+  if (!w || kmax < 1 || kmax > RSB_MAX_CONTACTS) { rsb::set_error("rsb_set_max_contacts: 1..RSB_MAX_CONTACTS"); return RSB_E_INVALID; }
+  w->kmax = kmax;
+  return RSB_OK;
+}
+int rsb_set_lanes_per_env(rsb_world* w, int lanes) {
+  if (!w) return RSB_E_INVALID;
+  if (lanes != 0) { int st = check_lpe(w, lanes); if (st != RSB_OK) return st; }
+  w->lpe = lanes;
+  return RSB_OK;
+}
+int rsb_get_lanes_per_env(const rsb_world* w) { return w ? effective_lpe(w) : RSB_E_INVALID; }
+
+int rsb_set_ground(rsb_world* w, double height) {
+  if (!w) return RSB_E_INVALID;
+  w->terrain_type = 0; w->ground_z = height;
+  return RSB_OK;
+}
+int rsb_set_heightmap(rsb_world* w, int xs, int ys, double x_size, double y_size, double cx, double cy, const float* heights) {
+  if (!w || !heights || xs < 2 || ys < 2 || !(x_size > 0) || !(y_size > 0)) { rsb::set_error("rsb_set_heightmap: bad argument"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  if (w->d_heights) { HIP_TRY(hipFree(w->d_heights)); w->d_heights = nullptr; }
+  HIP_TRY(hipMalloc(&w->d_heights, (size_t)xs * ys * sizeof(float)));
+  HIP_TRY(hipMemcpy(w->d_heights, heights, (size_t)xs * ys * sizeof(float), hipMemcpyHostToDevice));
+  w->terrain_type = 1; w->hm_xs = xs; w->hm_ys = ys; w->hm_xsize = x_size; w->hm_ysize = y_size; w->hm_cx = cx; w->hm_cy = cy;
+  return RSB_OK;
+}
+
+int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t* mask, int space) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
+  w->integrate1_valid = false;
+  if (!mask) {
+    if (gc) { int st = copy_in(w, w->d_gc, gc, N * nq, space); if (st) return st; }
+    if (gv) { int st = copy_in(w, w->d_gv, gv, N * nv, space); if (st) return st; }
+    return RSB_OK;
+  }
+  const uint8_t* dmask = mask;
+  const float *sgc = gc, *sgv = gv;
+  if (space == RSB_HOST) {
+    if (!w->d_tmp_gc) {
+      HIP_TRY(hipMalloc(&w->d_tmp_gc, N * nq * sizeof(float)));
+      HIP_TRY(hipMalloc(&w->d_tmp_gv, N * nv * sizeof(float)));
+      HIP_TRY(hipMalloc(&w->d_tmp_mask, N));
+    }
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_mask, mask, N, hipMemcpyHostToDevice, w->stream));
+    if (gc) HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, gc, N * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    if (gv) HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, gv, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    dmask = w->d_tmp_mask; sgc = gc ? w->d_tmp_gc : nullptr; sgv = gv ? w->d_tmp_gv : nullptr;
+  }
+  if (sgc) hipLaunchKernelGGL(masked_row_copy, dim3((N * nq + 255) / 256), dim3(256), 0, w->stream, w->d_gc, sgc, dmask, (int)N, (int)nq);
+  if (sgv) hipLaunchKernelGGL(masked_row_copy, dim3((N * nv + 255) / 256), dim3(256), 0, w->stream, w->d_gv, sgv, dmask, (int)N, (int)nv);
+  HIP_TRY(hipGetLastError());
+  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(w->stream));
+  return RSB_OK;
+}
+
+int rsb_get_state(rsb_world* w, float* gc, float* gv, int space) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t N = w->N;
+  if (gc) { int st = copy_out(w, gc, w->d_gc, N * w->blob.nq * sizeof(float), space); if (st) return st; }
+  if (gv) { int st = copy_out(w, gv, w->d_gv, N * w->blob.nv * sizeof(float), space); if (st) return st; }
+  return RSB_OK;
+}
+
+int rsb_set_control_mode(rsb_world* w, int mode) {
+  if (!w || (mode != RSB_FORCE_AND_TORQUE && mode != RSB_PD_PLUS_FEEDFORWARD_TORQUE)) { rsb::set_error("rsb_set_control_mode: unknown mode"); return RSB_E_INVALID; }
+  w->control_mode = mode;
+  return RSB_OK;
+}
+int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd) {
+  if (!w || !kp || !kd) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipMemcpyAsync(w->d_kp, kp, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  HIP_TRY(hipMemcpyAsync(w->d_kd, kd, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  return RSB_OK;
+}
+int rsb_set_pd_target(rsb_world* w, const float* p_target, const float* d_target, int space) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t N = w->N;
+  if (p_target) { int st = copy_in(w, w->d_pt, p_target, N * w->blob.nq, space); if (st) return st; }
+  if (d_target) { int st = copy_in(w, w->d_dt, d_target, N * w->blob.nv, space); if (st) return st; }
+  return RSB_OK;
+}
+int rsb_set_generalized_force(rsb_world* w, const float* tau, int space) {
+  if (!w || !tau) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  return copy_in(w, w->d_tff, tau, (size_t)w->N * w->blob.nv, space);
+}
+
+int rsb_integrate(rsb_world* w, int n_substeps) {
+  if (!w || n_substeps < 1) { rsb::set_error("rsb_integrate: n_substeps must be >= 1"); return RSB_E_INVALID; }
+  return do_integrate(w, n_substeps);
+}
+
+// integrate1(): collision detection + M, h for the CURRENT state, into query buffers.  The state is
+// not advanced; integrate2() then runs the fused step (which recomputes the same quantities from the
+// unchanged state, so the pair is equivalent to integrate()).
+int rsb_integrate1(rsb_world* w) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t N = w->N, nv = w->blob.nv;
+  if (!w->d_M) {
+    HIP_TRY(hipMalloc(&w->d_M, N * nv * nv * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_h, N * nv * sizeof(float)));
+  }
+  rsbq::QueryArgs qa;
+  qa.model = w->d_model; qa.gc = w->d_gc; qa.gv = w->d_gv; qa.M = w->d_M; qa.h = w->d_h; qa.N = w->N;
+  qa.gx = (float)w->gravity[0]; qa.gy = (float)w->gravity[1]; qa.gz = (float)w->gravity[2];
+  int st = rsbq::launch_query(qa, w->blob.nb, w->stream);
+  if (st != 0) { rsb::set_error("integrate1: query kernel launch failed"); return RSB_E_HIP; }
+  w->integrate1_valid = true;
+  return RSB_OK;
+}
+int rsb_integrate2(rsb_world* w) {
+  if (!w) return RSB_E_INVALID;
+  return do_integrate(w, 1);
+}
+
+int rsb_get_contacts(rsb_world* w, int32_t* counts, rsb_contact* contacts, int space) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t N = w->N;
+  if (counts) { int st = copy_out(w, counts, w->d_count, N * sizeof(int32_t), space); if (st) return st; }
+  if (contacts) { int st = copy_out(w, contacts, w->d_contacts, N * w->kmax * sizeof(rsb_contact), space); if (st) return st; }
+  return RSB_OK;
+}
+int rsb_get_mass_matrix(rsb_world* w, float* M, int space) {
+  if (!w || !M) return RSB_E_INVALID;
+  if (!w->integrate1_valid) { rsb::set_error("rsb_get_mass_matrix: call rsb_integrate1 first (state changed since)"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  return copy_out(w, M, w->d_M, (size_t)w->N * w->blob.nv * w->blob.nv * sizeof(float), space);
+}
+int rsb_get_nonlinearities(rsb_world* w, float* h, int space) {
+  if (!w || !h) return RSB_E_INVALID;
+  if (!w->integrate1_valid) { rsb::set_error("rsb_get_nonlinearities: call rsb_integrate1 first (state changed since)"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  return copy_out(w, h, w->d_h, (size_t)w->N * w->blob.nv * sizeof(float), space);
+}
+int rsb_get_flags(rsb_world* w, int32_t* flags, int space) {
+  if (!w || !flags) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  return copy_out(w, flags, w->d_flags, (size_t)w->N * sizeof(int32_t), space);
+}
+int rsb_get_solver_iterations(rsb_world* w, int32_t* iters, int space) {
+  if (!w || !iters) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  return copy_out(w, iters, w->d_iters, (size_t)w->N * sizeof(int32_t), space);
+}
+
+int rsb_obs_dim(const rsb_world* w, int n_force_slots) {
+  if (!w || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) return RSB_E_INVALID;
+  return w->blob.nq + w->blob.nv + 3 * n_force_slots;
+}
+int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, int n_force_slots, int space) {
+  if (!w || !out || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) { rsb::set_error("rsb_gather_obs: bad argument"); return RSB_E_INVALID; }
+  if (space != RSB_DEVICE) { rsb::set_error("rsb_gather_obs: out must be a device pointer"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  const int32_t* didx = nullptr;
+  if (collision_indices && n_force_slots > 0) {
+    HIP_TRY(hipMemcpyAsync(w->d_obs_idx, collision_indices, n_force_slots * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    didx = w->d_obs_idx;
+  }
+  const int od = w->blob.nq + w->blob.nv + 3 * n_force_slots;
+  const size_t total = (size_t)w->N * od;
+  hipLaunchKernelGGL(gather_obs_kernel, dim3((total + 255) / 256), dim3(256), 0, w->stream, out, w->d_gc, w->d_gv,
+                     w->d_contacts, w->d_count, didx, w->N, w->blob.nq, w->blob.nv, w->kmax, n_force_slots,
+                     (float)(1.0 / w->dt));
+  HIP_TRY(hipGetLastError());
+  return RSB_OK;
+}
+
+void* rsb_device_ptr(rsb_world* w, int field) {
+  if (!w) return nullptr;
+  switch (field) {
+    case RSB_F_GC: return w->d_gc;
+    case RSB_F_GV: return w->d_gv;
+    case RSB_F_PTARGET: return w->d_pt;
+    case RSB_F_DTARGET: return w->d_dt;
+    case RSB_F_TAU_FF: return w->d_tff;
+    case RSB_F_CONTACT_COUNT: return w->d_count;
+    case RSB_F_CONTACTS: return w->d_contacts;
+    case RSB_F_FLAGS: return w->d_flags;
+    default: return nullptr;
+  }
+}
+
+// Debug aid: the next rsb_integrate() launches dump env `env`'s contact problem of the LAST sub-step
+// (Delassus matrix G [3nc,3nc], free contact velocity c [3nc], solved impulses lam [3nc], contact frame
+// coordinates [t1 t2 n]); rsb_debug_read_contact_problem copies it to the host.  env < 0 disables.
+int rsb_debug_select_env(rsb_world* w, int env) {
+  if (!w || env >= w->N) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t n = 1 + 3 * RSB_MAX_CONTACTS * 3 * RSB_MAX_CONTACTS + 6 * RSB_MAX_CONTACTS;
+  if (!w->d_dbg) HIP_TRY(hipMalloc(&w->d_dbg, n * sizeof(float)));
+  HIP_TRY(hipMemsetAsync(w->d_dbg, 0, n * sizeof(float), w->stream));
+  w->dbg_env = env;
+  return RSB_OK;
+}
+int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, float* lam) {
+  if (!w || !nc || !w->d_dbg) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t n = 1 + 3 * RSB_MAX_CONTACTS * 3 * RSB_MAX_CONTACTS + 6 * RSB_MAX_CONTACTS;
+  std::vector<float> buf(n);
+  HIP_TRY(hipMemcpyAsync(buf.data(), w->d_dbg, n * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  const int k = (int)buf[0], n3 = 3 * k;
+  *nc = k;
+  if (G) std::memcpy(G, buf.data() + 1, sizeof(float) * n3 * n3);
+  if (c) std::memcpy(c, buf.data() + 1 + n3 * n3, sizeof(float) * n3);
+  if (lam) std::memcpy(lam, buf.data() + 1 + n3 * n3 + n3, sizeof(float) * n3);
+  return RSB_OK;
+}
+
+int rsb_enable_timing(rsb_world* w, int on) { if (!w) return RSB_E_INVALID; w->timing = on != 0; return RSB_OK; }
+int rsb_last_kernel_ms(rsb_world* w, float* ms) {
+  if (!w || !ms) return RSB_E_INVALID;
+  if (!w->timing) { rsb::set_error("rsb_last_kernel_ms: timing is disabled (rsb_enable_timing)"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipEventSynchronize(w->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, w->ev0, w->ev1));
+  return RSB_OK;
+}
+
+}  // extern "C"

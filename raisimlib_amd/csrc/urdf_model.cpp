@@ -1,0 +1,479 @@
+// urdf_model.cpp — host-side model loader: URDF subset -> flat rsb_model_blob (cold path).
+//
+// Plays the role of raisim::World::addArticulatedSystem(urdfPath) [RECALL; ArticulatedSystem.hpp /
+// World.hpp are absent from /root/reference, SURVEY.md §3.3]: parse the robot description once on the
+// host, merge fixed joints, and emit the immutable model blob that rsb_create uploads to the device.
+//
+// Supported subset: <link>/<inertial>/<collision> with <sphere> and <capsule> geometry,
+// <joint type="revolute|continuous|prismatic|fixed">, <origin xyz rpy>, <axis>, <limit>,
+// <dynamics damping rotor_inertia>.  The root link is the floating base.  Box / cylinder / mesh
+// collision geometry is ignored (counted in rsb_model::skipped_collisions); see DESIGN.md "out of scope".
+#include "rsb.h"
+#include "rsb_internal.h"
+
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace rsb {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+const char* last_error() { return g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------- tiny XML reader
+struct XmlNode {
+  std::string tag;
+  std::map<std::string, std::string> attr;
+  std::vector<std::unique_ptr<XmlNode>> kids;
+  const XmlNode* child(const char* t) const {
+    for (auto& k : kids) if (k->tag == t) return k.get();
+    return nullptr;
+  }
+  const char* get(const char* a) const {
+    auto it = attr.find(a);
+    return it == attr.end() ? nullptr : it->second.c_str();
+  }
+};
+
+class XmlParser {
+ public:
+  explicit XmlParser(const std::string& s) : s_(s), i_(0) {}
+  std::unique_ptr<XmlNode> parse() {
+    skip_misc();
+    auto n = element();
+    if (!n) throw std::runtime_error("URDF: no root element");
+    return n;
+  }
+
+ private:
+  const std::string& s_;
+  size_t i_;
+  bool starts(const char* p) const { return s_.compare(i_, std::strlen(p), p) == 0; }
+  void skip_ws() { while (i_ < s_.size() && std::isspace((unsigned char)s_[i_])) ++i_; }
+  void skip_until(const char* end) {
+    size_t p = s_.find(end, i_);
+    if (p == std::string::npos) throw std::runtime_error(std::string("URDF: unterminated '") + end + "'");
+    i_ = p + std::strlen(end);
+  }
+  void skip_misc() {
+    for (;;) {
+      skip_ws();
+      if (starts("<?")) skip_until("?>");
+      else if (starts("<!--")) skip_until("-->");
+      else if (starts("<!")) skip_until(">");
+      else break;
+    }
+  }
+  std::string name() {
+    size_t b = i_;
+    while (i_ < s_.size() && (std::isalnum((unsigned char)s_[i_]) || s_[i_] == '_' || s_[i_] == ':' || s_[i_] == '-' || s_[i_] == '.')) ++i_;
+    if (b == i_) throw std::runtime_error("URDF: expected a name at offset " + std::to_string(b));
+    return s_.substr(b, i_ - b);
+  }
+  std::unique_ptr<XmlNode> element() {
+    if (i_ >= s_.size() || s_[i_] != '<') return nullptr;
+    ++i_;
+    auto n = std::make_unique<XmlNode>();
+    n->tag = name();
+    for (;;) {
+      skip_ws();
+      if (i_ >= s_.size()) throw std::runtime_error("URDF: unexpected end in <" + n->tag + ">");
+      if (starts("/>")) { i_ += 2; return n; }
+      if (s_[i_] == '>') { ++i_; break; }
+      std::string a = name();
+      skip_ws();
+      if (i_ >= s_.size() || s_[i_] != '=') throw std::runtime_error("URDF: expected '=' after attribute " + a);
+      ++i_;
+      skip_ws();
+      char qc = s_[i_];
+      if (qc != '"' && qc != '\'') throw std::runtime_error("URDF: unquoted attribute " + a);
+      size_t e = s_.find(qc, i_ + 1);
+      if (e == std::string::npos) throw std::runtime_error("URDF: unterminated attribute " + a);
+      n->attr[a] = s_.substr(i_ + 1, e - i_ - 1);
+      i_ = e + 1;
+    }
+    for (;;) {  // children / text until </tag>
+      size_t lt = s_.find('<', i_);
+      if (lt == std::string::npos) throw std::runtime_error("URDF: missing </" + n->tag + ">");
+      i_ = lt;
+      if (starts("<!--")) { skip_until("-->"); continue; }
+      if (starts("<?")) { skip_until("?>"); continue; }
+      if (starts("</")) {
+        i_ += 2;
+        std::string t = name();
+        if (t != n->tag) throw std::runtime_error("URDF: </" + t + "> closes <" + n->tag + ">");
+        skip_ws();
+        if (i_ >= s_.size() || s_[i_] != '>') throw std::runtime_error("URDF: malformed </" + t + ">");
+        ++i_;
+        return n;
+      }
+      n->kids.push_back(element());
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------- small math
+struct V3 { double x = 0, y = 0, z = 0; };
+struct M3 { double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}; };
+struct Xf { M3 R; V3 p; };  // parent <- child
+
+static V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+static V3 mul(const M3& A, V3 v) {
+  return {A.m[0] * v.x + A.m[1] * v.y + A.m[2] * v.z, A.m[3] * v.x + A.m[4] * v.y + A.m[5] * v.z,
+          A.m[6] * v.x + A.m[7] * v.y + A.m[8] * v.z};
+}
+static M3 mul(const M3& A, const M3& B) {
+  M3 C;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C.m[3 * i + j] = A.m[3 * i] * B.m[j] + A.m[3 * i + 1] * B.m[3 + j] + A.m[3 * i + 2] * B.m[6 + j];
+  return C;
+}
+static M3 transpose(const M3& A) {
+  M3 T;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T.m[3 * i + j] = A.m[3 * j + i];
+  return T;
+}
+static Xf compose(const Xf& a, const Xf& b) { return {mul(a.R, b.R), a.p + mul(a.R, b.p)}; }
+// URDF rpy = fixed-axis roll(x), pitch(y), yaw(z): R = Rz(y) Ry(p) Rx(r)
+static M3 rpy(double r, double p, double y) {
+  double cr = std::cos(r), sr = std::sin(r), cp = std::cos(p), sp = std::sin(p), cy = std::cos(y), sy = std::sin(y);
+  M3 R;
+  R.m[0] = cy * cp; R.m[1] = cy * sp * sr - sy * cr; R.m[2] = cy * sp * cr + sy * sr;
+  R.m[3] = sy * cp; R.m[4] = sy * sp * sr + cy * cr; R.m[5] = sy * sp * cr - cy * sr;
+  R.m[6] = -sp;     R.m[7] = cp * sr;                R.m[8] = cp * cr;
+  return R;
+}
+static bool parse_doubles(const char* s, double* out, int n) {
+  if (!s) return false;
+  char* e;
+  for (int i = 0; i < n; ++i) {
+    out[i] = std::strtod(s, &e);
+    if (e == s) return false;
+    s = e;
+  }
+  return true;
+}
+static double attr_double(const XmlNode* n, const char* a, double dflt) {
+  double v;
+  if (n && parse_doubles(n->get(a), &v, 1)) return v;
+  return dflt;
+}
+static Xf parse_origin(const XmlNode* n) {
+  Xf x;
+  if (!n) return x;
+  double v[3];
+  if (parse_doubles(n->get("xyz"), v, 3)) x.p = {v[0], v[1], v[2]};
+  if (parse_doubles(n->get("rpy"), v, 3)) x.R = rpy(v[0], v[1], v[2]);
+  return x;
+}
+
+// ------------------------------------------------------------------------------ URDF -> blob
+struct UCollision { Xf x; int type; double radius, length; std::string name; };  // type 0 sphere, 1 capsule
+struct ULink {
+  std::string name;
+  double mass = 0;
+  Xf inertial;         // link <- inertial frame
+  double I[6] = {0, 0, 0, 0, 0, 0};  // xx xy xz yy yz zz in the inertial frame
+  std::vector<UCollision> cols;
+  std::vector<int> child_joints;
+  int parent_joint = -1;
+};
+struct UJoint {
+  std::string name, parent, child;
+  int type = 0;  // 0 fixed, 1 revolute/continuous, 2 prismatic
+  Xf origin;
+  V3 axis{1, 0, 0};
+  double lower = -1e30, upper = 1e30, effort = 0, damping = 0, armature = 0;
+};
+
+struct Builder {
+  std::vector<ULink> links;
+  std::vector<UJoint> joints;
+  std::map<std::string, int> link_ix;
+  rsb_model_blob blob;
+  int skipped_collisions = 0;
+
+  // accumulated rigid body (a moving link + everything fixed to it)
+  struct Acc { double m = 0; V3 mc; std::vector<std::pair<double, std::pair<V3, M3>>> parts; };
+  std::vector<Acc> acc;
+
+  void add_inertial(int body, const Xf& body_from_link, const ULink& L) {
+    if (L.mass <= 0) return;
+    Xf bi = compose(body_from_link, L.inertial);
+    M3 Il;
+    Il.m[0] = L.I[0]; Il.m[1] = L.I[1]; Il.m[2] = L.I[2];
+    Il.m[3] = L.I[1]; Il.m[4] = L.I[3]; Il.m[5] = L.I[4];
+    Il.m[6] = L.I[2]; Il.m[7] = L.I[4]; Il.m[8] = L.I[5];
+    M3 Ib = mul(mul(bi.R, Il), transpose(bi.R));
+    acc[body].m += L.mass;
+    acc[body].mc = acc[body].mc + L.mass * bi.p;
+    acc[body].parts.push_back({L.mass, {bi.p, Ib}});
+  }
+  void add_collisions(int body, const Xf& body_from_link, const ULink& L) {
+    for (auto& c : L.cols) {
+      Xf bc = compose(body_from_link, c.x);
+      int n = c.type == 1 ? 2 : 1;
+      for (int e = 0; e < n; ++e) {
+        if (blob.ncol >= RSB_MAX_COLLISIONS) throw std::runtime_error("URDF: more than RSB_MAX_COLLISIONS collision spheres");
+        V3 off{0, 0, 0};
+        if (c.type == 1) off = {0, 0, (e == 0 ? 0.5 : -0.5) * c.length};
+        V3 p = bc.p + mul(bc.R, off);
+        int s = blob.ncol++;
+        blob.col_body[s] = body;
+        blob.col_pos[s][0] = p.x; blob.col_pos[s][1] = p.y; blob.col_pos[s][2] = p.z;
+        blob.col_radius[s] = c.radius;
+        std::string nm = c.name.empty() ? L.name : c.name;
+        if (c.type == 1) nm += (e == 0 ? "/top" : "/bottom");
+        std::snprintf(blob.col_name[s], RSB_NAME_LEN, "%s", nm.c_str());
+      }
+    }
+  }
+  // depth-first over the URDF tree; `body` is the moving body `link` belongs to
+  void visit(int link, int body, const Xf& body_from_link) {
+    const ULink& L = links[link];
+    add_inertial(body, body_from_link, L);
+    add_collisions(body, body_from_link, L);
+    for (int jx : L.child_joints) {
+      const UJoint& J = joints[jx];
+      int child = link_ix.at(J.child);
+      Xf body_from_joint = compose(body_from_link, J.origin);
+      if (J.type == 0) { visit(child, body, body_from_joint); continue; }
+      if (blob.nb >= RSB_MAX_BODIES) throw std::runtime_error("URDF: more than RSB_MAX_BODIES moving bodies");
+      int b = blob.nb++;
+      acc.emplace_back();
+      blob.parent[b] = body;
+      blob.level[b] = blob.level[body] + 1;
+      if (blob.level[b] + 1 > blob.depth) blob.depth = blob.level[b] + 1;
+      blob.jtype[b] = J.type == 1 ? RSB_JOINT_REVOLUTE : RSB_JOINT_PRISMATIC;
+      double an = std::sqrt(J.axis.x * J.axis.x + J.axis.y * J.axis.y + J.axis.z * J.axis.z);
+      if (an < 1e-12) throw std::runtime_error("URDF: zero joint axis on " + J.name);
+      blob.axis[b][0] = J.axis.x / an; blob.axis[b][1] = J.axis.y / an; blob.axis[b][2] = J.axis.z / an;
+      blob.ptree[b][0] = body_from_joint.p.x; blob.ptree[b][1] = body_from_joint.p.y; blob.ptree[b][2] = body_from_joint.p.z;
+      for (int c = 0; c < 9; ++c) blob.rtree[b][c] = body_from_joint.R.m[c];
+      blob.armature[b] = J.armature; blob.damping[b] = J.damping;
+      blob.q_lower[b] = J.lower; blob.q_upper[b] = J.upper; blob.effort[b] = J.effort;
+      std::snprintf(blob.body_name[b], RSB_NAME_LEN, "%s", links[child].name.c_str());
+      std::snprintf(blob.joint_name[b], RSB_NAME_LEN, "%s", J.name.c_str());
+      visit(child, b, Xf{});
+    }
+  }
+  void finish_inertia() {
+    for (int b = 0; b < blob.nb; ++b) {
+      Acc& a = acc[b];
+      if (a.m <= 0) throw std::runtime_error(std::string("URDF: moving body '") + blob.body_name[b] + "' has no mass");
+      V3 c = (1.0 / a.m) * a.mc;
+      double I[9] = {0};
+      for (auto& part : a.parts) {
+        double mk = part.first;
+        V3 d = part.second.first - c;
+        const M3& Ik = part.second.second;
+        double dd = d.x * d.x + d.y * d.y + d.z * d.z, dv[3] = {d.x, d.y, d.z};
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j) I[3 * i + j] += Ik.m[3 * i + j] + mk * ((i == j ? dd : 0.0) - dv[i] * dv[j]);
+      }
+      blob.mass[b] = a.m;
+      blob.com[b][0] = c.x; blob.com[b][1] = c.y; blob.com[b][2] = c.z;
+      blob.inertia[b][0] = I[0]; blob.inertia[b][1] = I[1]; blob.inertia[b][2] = I[2];
+      blob.inertia[b][3] = I[4]; blob.inertia[b][4] = I[5]; blob.inertia[b][5] = I[8];
+    }
+  }
+};
+
+static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* skipped) {
+  XmlParser parser(xml);
+  auto root = parser.parse();
+  if (root->tag != "robot") throw std::runtime_error("URDF: root element is <" + root->tag + ">, expected <robot>");
+  Builder B;
+  std::memset(&B.blob, 0, sizeof B.blob);
+  for (auto& k : root->kids) {
+    if (k->tag == "link") {
+      ULink L;
+      const char* nm = k->get("name");
+      if (!nm) throw std::runtime_error("URDF: <link> without name");
+      L.name = nm;
+      if (const XmlNode* in = k->child("inertial")) {
+        L.inertial = parse_origin(in->child("origin"));
+        L.mass = attr_double(in->child("mass"), "value", 0.0);
+        const XmlNode* I = in->child("inertia");
+        static const char* keys[6] = {"ixx", "ixy", "ixz", "iyy", "iyz", "izz"};
+        for (int c = 0; c < 6; ++c) L.I[c] = attr_double(I, keys[c], 0.0);
+      }
+      for (auto& c : k->kids) {
+        if (c->tag != "collision") continue;
+        const XmlNode* g = c->child("geometry");
+        if (!g) continue;
+        UCollision col;
+        col.x = parse_origin(c->child("origin"));
+        if (const char* cn = c->get("name")) col.name = cn;
+        if (const XmlNode* s = g->child("sphere")) {
+          col.type = 0; col.radius = attr_double(s, "radius", 0.0); col.length = 0;
+        } else if (const XmlNode* cp = g->child("capsule")) {
+          col.type = 1; col.radius = attr_double(cp, "radius", 0.0); col.length = attr_double(cp, "length", 0.0);
+        } else { ++B.skipped_collisions; continue; }
+        if (col.radius <= 0) throw std::runtime_error("URDF: non-positive collision radius on link " + L.name);
+        L.cols.push_back(col);
+      }
+      if (B.link_ix.count(L.name)) throw std::runtime_error("URDF: duplicate link " + L.name);
+      B.link_ix[L.name] = (int)B.links.size();
+      B.links.push_back(std::move(L));
+    } else if (k->tag == "joint") {
+      UJoint J;
+      const char* nm = k->get("name");
+      const char* ty = k->get("type");
+      if (!nm || !ty) throw std::runtime_error("URDF: <joint> needs name and type");
+      J.name = nm;
+      std::string t = ty;
+      if (t == "fixed") J.type = 0;
+      else if (t == "revolute" || t == "continuous") J.type = 1;
+      else if (t == "prismatic") J.type = 2;
+      else throw std::runtime_error("URDF: unsupported joint type '" + t + "' on " + J.name);
+      const XmlNode* p = k->child("parent");
+      const XmlNode* c = k->child("child");
+      if (!p || !c || !p->get("link") || !c->get("link")) throw std::runtime_error("URDF: joint " + J.name + " needs <parent link> and <child link>");
+      J.parent = p->get("link"); J.child = c->get("link");
+      J.origin = parse_origin(k->child("origin"));
+      double v[3];
+      if (const XmlNode* ax = k->child("axis")) if (parse_doubles(ax->get("xyz"), v, 3)) J.axis = {v[0], v[1], v[2]};
+      if (const XmlNode* lim = k->child("limit")) {
+        if (t != "continuous") { J.lower = attr_double(lim, "lower", -1e30); J.upper = attr_double(lim, "upper", 1e30); }
+        J.effort = attr_double(lim, "effort", 0.0);
+      }
+      if (const XmlNode* dyn = k->child("dynamics")) {
+        J.damping = attr_double(dyn, "damping", 0.0);
+        J.armature = attr_double(dyn, "rotor_inertia", 0.0);
+      }
+      B.joints.push_back(std::move(J));
+    }
+  }
+  if (B.links.empty()) throw std::runtime_error("URDF: no links");
+  for (size_t j = 0; j < B.joints.size(); ++j) {
+    auto& J = B.joints[j];
+    if (!B.link_ix.count(J.parent) || !B.link_ix.count(J.child)) throw std::runtime_error("URDF: joint " + J.name + " references an unknown link");
+    ULink& ch = B.links[B.link_ix[J.child]];
+    if (ch.parent_joint >= 0) throw std::runtime_error("URDF: link " + ch.name + " has two parent joints (closed loops unsupported)");
+    ch.parent_joint = (int)j;
+    B.links[B.link_ix[J.parent]].child_joints.push_back((int)j);
+  }
+  int rootl = -1;
+  for (size_t l = 0; l < B.links.size(); ++l)
+    if (B.links[l].parent_joint < 0) {
+      if (rootl >= 0) throw std::runtime_error("URDF: more than one root link (" + B.links[rootl].name + ", " + B.links[l].name + ")");
+      rootl = (int)l;
+    }
+  if (rootl < 0) throw std::runtime_error("URDF: no root link");
+  if (B.links[rootl].name == "world") throw std::runtime_error("URDF: fixed-base systems (root link 'world') are outside the supported subset");
+  B.blob.nb = 1; B.blob.depth = 1;
+  B.blob.parent[0] = -1; B.blob.level[0] = 0; B.blob.jtype[0] = RSB_JOINT_FLOATING;
+  B.blob.q_lower[0] = -1e30; B.blob.q_upper[0] = 1e30;
+  std::snprintf(B.blob.body_name[0], RSB_NAME_LEN, "%s", B.links[rootl].name.c_str());
+  std::snprintf(B.blob.joint_name[0], RSB_NAME_LEN, "base");
+  B.acc.emplace_back();
+  B.visit(rootl, 0, Xf{});
+  B.finish_inertia();
+  B.blob.nq = 7 + B.blob.nb - 1;
+  B.blob.nv = 6 + B.blob.nb - 1;
+  *out = B.blob;
+  *skipped = B.skipped_collisions;
+}
+
+int validate_blob(const rsb_model_blob& b) {
+  if (b.nb < 1 || b.nb > RSB_MAX_BODIES) { set_error("model: nb out of range"); return RSB_E_INVALID; }
+  if (b.nq != 7 + b.nb - 1 || b.nv != 6 + b.nb - 1) { set_error("model: nq/nv inconsistent with nb"); return RSB_E_INVALID; }
+  if (b.ncol < 0 || b.ncol > RSB_MAX_COLLISIONS) { set_error("model: ncol out of range"); return RSB_E_INVALID; }
+  if (b.parent[0] != -1 || b.jtype[0] != RSB_JOINT_FLOATING) { set_error("model: body 0 must be the floating base"); return RSB_E_INVALID; }
+  int depth = 1;
+  for (int i = 1; i < b.nb; ++i) {
+    if (b.parent[i] < 0 || b.parent[i] >= i) { set_error("model: parent[i] must be in [0, i)"); return RSB_E_INVALID; }
+    if (b.level[i] != b.level[b.parent[i]] + 1) { set_error("model: level[] inconsistent with parent[]"); return RSB_E_INVALID; }
+    if (b.jtype[i] != RSB_JOINT_REVOLUTE && b.jtype[i] != RSB_JOINT_PRISMATIC) { set_error("model: unsupported joint type"); return RSB_E_UNSUPPORTED; }
+    if (!(b.mass[i] > 0)) { set_error("model: non-positive body mass"); return RSB_E_INVALID; }
+    if (b.level[i] + 1 > depth) depth = b.level[i] + 1;
+  }
+  if (b.depth != depth) { set_error("model: depth inconsistent"); return RSB_E_INVALID; }
+  for (int s = 0; s < b.ncol; ++s)
+    if (b.col_body[s] < 0 || b.col_body[s] >= b.nb || !(b.col_radius[s] > 0)) { set_error("model: bad collision sphere"); return RSB_E_INVALID; }
+  return RSB_OK;
+}
+
+}  // namespace rsb
+
+// ---------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+const char* rsb_last_error(void) { return rsb::last_error(); }
+const char* rsb_version(void) { return "raisimlib_amd 0.1 (gfx950)"; }
+
+int rsb_model_from_urdf_string(const char* xml, rsb_model** out) {
+  if (!xml || !out) { rsb::set_error("rsb_model_from_urdf_string: null argument"); return RSB_E_INVALID; }
+  try {
+    auto m = std::make_unique<rsb_model>();
+    rsb::build_from_xml(xml, &m->blob, &m->skipped_collisions);
+    int st = rsb::validate_blob(m->blob);
+    if (st != RSB_OK) return st;
+    *out = m.release();
+    return RSB_OK;
+  } catch (const std::exception& e) {
+    rsb::set_error(e.what());
+    return RSB_E_PARSE;
+  }
+}
+
+int rsb_model_from_urdf_file(const char* path, rsb_model** out) {
+  if (!path || !out) { rsb::set_error("rsb_model_from_urdf_file: null argument"); return RSB_E_INVALID; }
+  std::ifstream f(path);
+  if (!f) { rsb::set_error(std::string("cannot open URDF file: ") + path); return RSB_E_INVALID; }
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return rsb_model_from_urdf_string(ss.str().c_str(), out);
+}
+
+int rsb_model_from_blob(const rsb_model_blob* blob, rsb_model** out) {
+  if (!blob || !out) { rsb::set_error("rsb_model_from_blob: null argument"); return RSB_E_INVALID; }
+  int st = rsb::validate_blob(*blob);
+  if (st != RSB_OK) return st;
+  auto m = std::make_unique<rsb_model>();
+  m->blob = *blob;
+  m->skipped_collisions = 0;
+  *out = m.release();
+  return RSB_OK;
+}
+
+int rsb_model_destroy(rsb_model* m) { delete m; return RSB_OK; }
+
+int rsb_model_get_blob(const rsb_model* m, rsb_model_blob* out) {
+  if (!m || !out) { rsb::set_error("rsb_model_get_blob: null argument"); return RSB_E_INVALID; }
+  *out = m->blob;
+  return RSB_OK;
+}
+
+int rsb_model_body_index(const rsb_model* m, const char* link_name) {
+  if (!m || !link_name) return RSB_E_INVALID;
+  for (int i = 0; i < m->blob.nb; ++i) if (std::strcmp(m->blob.body_name[i], link_name) == 0) return i;
+  return RSB_E_INVALID;
+}
+
+int rsb_model_joint_index(const rsb_model* m, const char* joint_name) {
+  if (!m || !joint_name) return RSB_E_INVALID;
+  for (int i = 0; i < m->blob.nb; ++i) if (std::strcmp(m->blob.joint_name[i], joint_name) == 0) return i;
+  return RSB_E_INVALID;
+}
+
+double rsb_model_total_mass(const rsb_model* m) {
+  double s = 0;
+  if (m) for (int i = 0; i < m->blob.nb; ++i) s += m->blob.mass[i];
+  return s;
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+"""Thin Python host mirror of the batched world behind the C-ABI (include/rsb.h).
+
+`Model` wraps rsb_model (URDF -> flat blob, host only); `BatchedWorld` wraps rsb_world: N replicas of
+{raisim::World + one raisim::ArticulatedSystem + Ground/HeightMap} resident on one GPU.  Method names
+follow the raisim::World / raisim::ArticulatedSystem surface [RECALL, SURVEY.md §8b] in snake_case.
+Everything here is plumbing: pointers in, status codes out.  No physics and no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import (RSB_DEVICE, RSB_HOST, RSB_MAX_CONTACTS, Contact, ModelBlob, check, lib)
+
+RSC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rsc")
+
+CONTACT_DTYPE = np.dtype([("position", "f4", 3), ("normal", "f4", 3), ("impulse", "f4", 3), ("depth", "f4"),
+                          ("body", "i4"), ("collision", "i4")])
+assert CONTACT_DTYPE.itemsize == C.sizeof(Contact)
+
+
+def rsc_path(name):
+    return os.path.join(RSC_DIR, name)
+
+
+class Model:
+    """Host-side articulated-system description (the role of World::addArticulatedSystem's URDF load)."""
+
+    def __init__(self, urdf_path=None, urdf_string=None, blob=None):
+        L = lib()
+        h = C.c_void_p()
+        if urdf_path is not None:
+            check(L.rsb_model_from_urdf_file(os.fspath(urdf_path).encode(), C.byref(h)), "rsb_model_from_urdf_file")
+        elif urdf_string is not None:
+            check(L.rsb_model_from_urdf_string(urdf_string.encode(), C.byref(h)), "rsb_model_from_urdf_string")
+        elif blob is not None:
+            check(L.rsb_model_from_blob(C.byref(blob), C.byref(h)), "rsb_model_from_blob")
+        else:
+            raise ValueError("Model needs urdf_path, urdf_string or blob")
+        self.handle = h
+        self.blob = ModelBlob()
+        check(L.rsb_model_get_blob(self.handle, C.byref(self.blob)), "rsb_model_get_blob")
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            lib().rsb_model_destroy(h)
+            self.handle = None
+
+    nb = property(lambda self: self.blob.nb)
+    nq = property(lambda self: self.blob.nq)
+    nv = property(lambda self: self.blob.nv)
+    ncol = property(lambda self: self.blob.ncol)
+
+    def body_index(self, link_name):
+        return lib().rsb_model_body_index(self.handle, link_name.encode())
+
+    def joint_index(self, joint_name):
+        return lib().rsb_model_joint_index(self.handle, joint_name.encode())
+
+    def total_mass(self):
+        return lib().rsb_model_total_mass(self.handle)
+
+    def body_names(self):
+        return [self.blob.body_name[i].value.decode() for i in range(self.nb)]
+
+    def collision_names(self):
+        return [self.blob.col_name[i].value.decode() for i in range(self.ncol)]
+
+    def collision_indices(self, suffix):
+        return [i for i, n in enumerate(self.collision_names()) if n.endswith(suffix)]
+
+
+def _host(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def _hp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchedWorld:
+    def __init__(self, model: Model, num_envs: int, device: int = 0):
+        self.L = lib()
+        self.model = model
+        h = C.c_void_p()
+        check(self.L.rsb_create(model.handle, int(num_envs), int(device), C.byref(h)), "rsb_create")
+        self.handle = h
+        self.N, self.nq, self.nv = num_envs, model.nq, model.nv
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.rsb_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    # -- raisim::World surface ---------------------------------------------------------------
+    def set_time_step(self, dt):
+        check(self.L.rsb_set_timestep(self.handle, float(dt)), "rsb_set_timestep")
+
+    def get_time_step(self):
+        return self.L.rsb_get_timestep(self.handle)
+
+    def get_world_time(self):
+        return self.L.rsb_get_world_time(self.handle)
+
+    def set_gravity(self, g):
+        arr = (C.c_double * 3)(*[float(x) for x in g])
+        check(self.L.rsb_set_gravity(self.handle, arr), "rsb_set_gravity")
+
+    def set_erp(self, erp):
+        check(self.L.rsb_set_erp(self.handle, float(erp)), "rsb_set_erp")
+
+    def set_default_friction(self, mu):
+        check(self.L.rsb_set_friction(self.handle, float(mu)), "rsb_set_friction")
+
+    def set_contact_solver_param(self, alpha_init, alpha_min, alpha_decay, max_iter, threshold):
+        check(self.L.rsb_set_contact_solver_param(self.handle, float(alpha_init), float(alpha_min), float(alpha_decay),
+                                                  int(max_iter), float(threshold)), "rsb_set_contact_solver_param")
+
+    def set_max_contacts(self, kmax):
+        check(self.L.rsb_set_max_contacts(self.handle, int(kmax)), "rsb_set_max_contacts")
+
+    def max_contacts(self):
+        k = C.c_int()
+        check(self.L.rsb_dims(self.handle, None, None, None, None, C.byref(k)), "rsb_dims")
+        return k.value
+
+    def set_lanes_per_env(self, lanes):
+        check(self.L.rsb_set_lanes_per_env(self.handle, int(lanes)), "rsb_set_lanes_per_env")
+
+    def lanes_per_env(self):
+        return self.L.rsb_get_lanes_per_env(self.handle)
+
+    def add_ground(self, z=0.0):
+        check(self.L.rsb_set_ground(self.handle, float(z)), "rsb_set_ground")
+
+    def add_height_map(self, x_samples, y_samples, x_size, y_size, center_x, center_y, heights):
+        h = _host(heights, np.float32).reshape(y_samples, x_samples)
+        check(self.L.rsb_set_heightmap(self.handle, int(x_samples), int(y_samples), float(x_size), float(y_size),
+                                       float(center_x), float(center_y), _hp(h)), "rsb_set_heightmap")
+
+    def integrate(self, n_substeps=1):
+        check(self.L.rsb_integrate(self.handle, int(n_substeps)), "rsb_integrate")
+
+    def integrate1(self):
+        check(self.L.rsb_integrate1(self.handle), "rsb_integrate1")
+
+    def integrate2(self):
+        check(self.L.rsb_integrate2(self.handle), "rsb_integrate2")
+
+    def synchronize(self):
+        check(self.L.rsb_synchronize(self.handle), "rsb_synchronize")
+
+    def set_stream(self, hip_stream_ptr):
+        check(self.L.rsb_set_stream(self.handle, C.c_void_p(hip_stream_ptr)), "rsb_set_stream")
+
+    # -- raisim::ArticulatedSystem surface (batched) ---------------------------------------------
+    def set_state(self, gc=None, gv=None, mask=None):
+        gc, gv, mask = _host(gc, np.float32), _host(gv, np.float32), _host(mask, np.uint8)
+        check(self.L.rsb_set_state(self.handle, _hp(gc), _hp(gv), _hp(mask), RSB_HOST), "rsb_set_state")
+
+    def get_state(self):
+        gc = np.empty((self.N, self.nq), np.float32)
+        gv = np.empty((self.N, self.nv), np.float32)
+        check(self.L.rsb_get_state(self.handle, _hp(gc), _hp(gv), RSB_HOST), "rsb_get_state")
+        return gc, gv
+
+    def set_control_mode(self, mode):
+        check(self.L.rsb_set_control_mode(self.handle, int(mode)), "rsb_set_control_mode")
+
+    def set_pd_gains(self, kp, kd):
+        kp, kd = _host(kp, np.float32), _host(kd, np.float32)
+        assert kp.shape == (self.nv,) and kd.shape == (self.nv,)
+        check(self.L.rsb_set_pd_gains(self.handle, _hp(kp), _hp(kd)), "rsb_set_pd_gains")
+
+    def set_pd_target(self, p_target=None, d_target=None):
+        p, d = _host(p_target, np.float32), _host(d_target, np.float32)
+        check(self.L.rsb_set_pd_target(self.handle, _hp(p), _hp(d), RSB_HOST), "rsb_set_pd_target")
+
+    def set_pd_target_device(self, p_ptr=None, d_ptr=None):
+        check(self.L.rsb_set_pd_target(self.handle, C.c_void_p(p_ptr) if p_ptr else None,
+                                       C.c_void_p(d_ptr) if d_ptr else None, RSB_DEVICE), "rsb_set_pd_target")
+
+    def set_generalized_force(self, tau):
+        t = _host(tau, np.float32)
+        check(self.L.rsb_set_generalized_force(self.handle, _hp(t), RSB_HOST), "rsb_set_generalized_force")
+
+    def get_contacts(self):
+        kmax = self.max_contacts()
+        counts = np.empty(self.N, np.int32)
+        con = np.zeros((self.N, kmax), CONTACT_DTYPE)
+        check(self.L.rsb_get_contacts(self.handle, _hp(counts), _hp(con), RSB_HOST), "rsb_get_contacts")
+        return counts, con
+
+    def get_mass_matrix(self):
+        M = np.empty((self.N, self.nv, self.nv), np.float32)
+        check(self.L.rsb_get_mass_matrix(self.handle, _hp(M), RSB_HOST), "rsb_get_mass_matrix")
+        return M
+
+    def get_nonlinearities(self):
+        h = np.empty((self.N, self.nv), np.float32)
+        check(self.L.rsb_get_nonlinearities(self.handle, _hp(h), RSB_HOST), "rsb_get_nonlinearities")
+        return h
+
+    def get_flags(self):
+        f = np.empty(self.N, np.int32)
+        check(self.L.rsb_get_flags(self.handle, _hp(f), RSB_HOST), "rsb_get_flags")
+        return f
+
+    def get_solver_iterations(self):
+        f = np.empty(self.N, np.int32)
+        check(self.L.rsb_get_solver_iterations(self.handle, _hp(f), RSB_HOST), "rsb_get_solver_iterations")
+        return f
+
+    # -- observation block for the vectorised env / RCCL gather --------------------------------------
+    def obs_dim(self, n_force_slots):
+        return self.L.rsb_obs_dim(self.handle, int(n_force_slots))
+
+    def gather_obs(self, out_device_ptr, collision_indices):
+        idx = _host(collision_indices, np.int32)
+        n = 0 if idx is None else idx.shape[0]
+        check(self.L.rsb_gather_obs(self.handle, C.c_void_p(out_device_ptr), _hp(idx), n, RSB_DEVICE), "rsb_gather_obs")
+
+    def device_ptr(self, field):
+        return self.L.rsb_device_ptr(self.handle, int(field))
+
+    def enable_timing(self, on=True):
+        check(self.L.rsb_enable_timing(self.handle, 1 if on else 0), "rsb_enable_timing")
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(self.L.rsb_last_kernel_ms(self.handle, C.byref(ms)), "rsb_last_kernel_ms")
+        return ms.value
+
+    # -- debug aid: one env's contact problem (G, c, lam) of the last sub-step -----------------------
+    def debug_select_env(self, env):
+        check(self.L.rsb_debug_select_env(self.handle, int(env)), "rsb_debug_select_env")
+
+    def debug_contact_problem(self):
+        K = RSB_MAX_CONTACTS
+        G = np.zeros(9 * K * K, np.float32)
+        c = np.zeros(3 * K, np.float32)
+        lam = np.zeros(3 * K, np.float32)
+        nc = C.c_int()
+        check(self.L.rsb_debug_read_contact_problem(self.handle, C.byref(nc), _hp(G), _hp(c), _hp(lam)),
+              "rsb_debug_read_contact_problem")
+        n3 = 3 * nc.value
+        return nc.value, G[:n3 * n3].reshape(n3, n3).copy(), c[:n3].copy(), lam[:n3].copy()
