@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched World::integrate() hot path on N MI355X (BASELINE.json metric).
+
+One "step" = one control step of the vectorised env = 4 x integrate() (dt = 0.0025) for 4096 ANYmal-C-like envs
+per GPU on flat ground (BASELINE.json configs[1]), i.e. 16384 env-steps per GPU per step, run as ONE fused kernel
+launch through the C-ABI (rsb_integrate(w, 4)).  Per step, inside the timed region, every rank also
+  - copies the control step's PD targets (nominal + U(-0.3,0.3) rad) into the world (device->device),
+  - applies rsg_anymal's termination rule on device (any non-foot contact -> reset that env),
+  - gathers the (q, u, foot contact force) observation block and, for N>1, all-gathers it over RCCL/xGMI.
+State is resident in HBM when the timed region starts.  Envs are sharded 4096 per rank (weak scaling); the
+only collective is the obs all-gather.
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM; algorithmic bytes from
+SURVEY.md §8d: 456 B per env-step x 16384 env-steps per launch, over the step kernel's mean launch time measured
+with HIP events on the launch stream) and `cpu_baseline` (the in-repo fp64 oracle, OpenMP over envs on the host
+cores, same workload recipe, bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+BYTES_PER_ENV_STEP = 456.0        # SURVEY.md §8d contract number (unfused state traffic, fp32)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
+TARGET_BANK = 16                  # distinct pre-generated PD-target sets cycled through in the timed loop
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--max-iter", type=int, default=0, help="contact-solver iteration cap (0 = library default)")
+    ap.add_argument("--lanes-per-env", type=int, default=0)
+    ap.add_argument("--no-reset", action="store_true", help="disable the non-foot-contact termination rule")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(model, feet, max_iter, reset, budget_s):
+    """Time the fp64 oracle (OpenMP over envs) on a bounded sample of the same workload."""
+    from oracle.pyoracle import Oracle  # the CPU baseline leg is one of the three allowed oracle users
+    from raisimlib_amd import workload
+    orc = Oracle(model.blob)
+    if max_iter > 0:
+        orc.p.max_iter = max_iter
+    n = 1024
+    gc0, gv0 = workload.anymal_initial_state(n)
+    kp, kd = workload.anymal_gains()
+    kp, kd = kp.astype(np.float64), kd.astype(np.float64)
+    q, u = gc0.astype(np.float32).astype(np.float64), gv0.copy()
+    dtg = np.zeros((n, model.nv))
+    feet_set = np.zeros(model.ncol, bool)
+    feet_set[feet] = True
+    spent, env_steps, cs, threads = 0.0, 0, 0, 1
+    while spent < budget_s and cs < 4000:
+        pt = workload.anymal_targets(n, cs).astype(np.float32).astype(np.float64)
+        t0 = time.perf_counter()
+        r = orc.step_batch(q, u, workload.SUBSTEPS, kp, kd, pt, dtg, want_contacts=reset)
+        spent += time.perf_counter() - t0
+        q, u, threads = r["q"], r["u"], r["threads"]
+        if reset:
+            con, ncs = r["contacts"], r["n_contacts"]
+            valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
+            term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
+            q[term], u[term] = gc0[term], gv0[term]
+        env_steps += n * workload.SUBSTEPS
+        cs += 1
+    return {"value": env_steps / spent, "unit": "env-steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"{n} envs x {cs} control steps x {workload.SUBSTEPS} sub-steps of the same workload, "
+                      f"fp64 oracle, OpenMP schedule(static) over envs, {spent:.1f} s"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from raisimlib_amd import BatchedWorld, Model, rsc_path, workload
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+
+    N = args.envs_per_gpu
+    model = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+    feet = model.collision_indices("_foot")
+    world = BatchedWorld(model, N, device=local_rank)
+    stream = torch.cuda.current_stream()
+    world.set_stream(stream.cuda_stream)
+    if args.max_iter > 0:
+        world.set_contact_solver_param(1.0, 1.0, 1.0, args.max_iter, 1e-5)
+    if args.lanes_per_env:
+        world.set_lanes_per_env(args.lanes_per_env)
+    world.set_time_step(workload.DT)
+    kp, kd = workload.anymal_gains()
+    world.set_pd_gains(kp, kd)
+
+    # per-rank env shard: seeds offset by rank
+    gc0, gv0 = workload.anymal_initial_state(N, env_offset=rank * N)
+    gc0_d = torch.from_numpy(gc0.astype(np.float32)).to(dev)
+    gv0_d = torch.from_numpy(gv0.astype(np.float32)).to(dev)
+    world.set_state(gc0, gv0)
+    world.set_pd_target(None, np.zeros((N, model.nv), np.float32))
+    bank = [torch.from_numpy(workload.anymal_targets(N, k, env_offset=rank * N).astype(np.float32)).to(dev)
+            for k in range(TARGET_BANK)]
+    obs_dim = world.obs_dim(len(feet))
+    obs = torch.empty((N, obs_dim), dtype=torch.float32, device=dev)
+    all_obs = torch.empty((world_size * N, obs_dim), dtype=torch.float32, device=dev) if world_size > 1 else obs
+    feet_idx = np.asarray(feet, np.int32)
+    reset = not args.no_reset
+
+    def control_step(k, ev=None):
+        world.set_pd_target_device(bank[k % TARGET_BANK].data_ptr())
+        if ev is not None:
+            ev[0].record(stream)
+        world.integrate(workload.SUBSTEPS)
+        if ev is not None:
+            ev[1].record(stream)
+        world.gather_obs(obs.data_ptr(), feet_idx)
+        if reset:
+            world.reset_terminated_device(feet_idx, gc0_d.data_ptr(), gv0_d.data_ptr(), N)
+        if world_size > 1:
+            dist.all_gather_into_tensor(all_obs, obs)
+
+    for k in range(args.warmup):
+        control_step(k)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        control_step(args.warmup + k, events[k])
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    kernel_ms = np.array([a.elapsed_time(b) for a, b in events])
+    env_steps_per_step = N * workload.SUBSTEPS
+    total_env_steps = world_size * env_steps_per_step * args.steps
+    value = total_env_steps / elapsed
+    iters = world.get_solver_iterations()
+    counts, _ = world.get_contacts()
+    q_end, _ = world.get_state()
+
+    if rank == 0:
+        kmean = float(kernel_ms.mean()) * 1e-3
+        achieved = BYTES_PER_ENV_STEP * env_steps_per_step / kmean / 1e9
+        out = {
+            "metric": "env-steps/sec, 4096 ANYmal-C envs flat terrain dt=0.0025",
+            "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: 4096 ANYmal-C-like (synthetic stand-in URDF) envs per GPU, flat ground, "
+                            "dt=0.0025, 4 sub-steps per control step fused in one launch, PD kp=50 kd=0.2, targets = "
+                            "nominal + U(-0.3,0.3) rad per control step, per-env seed 1234+i"
+                            + (", non-foot contact -> reset (rsg_anymal rule)" if reset else ", no resets")
+                            + ", obs (q,u,foot force) gathered each control step",
+                "envs_per_gpu": N, "substeps_per_step": workload.SUBSTEPS,
+                "contact_solver": {"max_iter": args.max_iter or 150, "threshold_rel": 1e-5, "alpha": [1.0, 1.0, 1.0]},
+                "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
+            },
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "rsb_step_kernel", "kernel_ms_mean": float(kernel_ms.mean()),
+                         "kernel_ms_p50": float(np.median(kernel_ms)),
+                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * env_steps_per_step},
+            "state_at_end": {"solver_iters_mean": float(iters.mean()), "solver_iters_max": int(iters.max()),
+                             "contacts_per_env": float(counts.mean()), "base_height_mean": float(q_end[:, 2].mean())},
+        }
+        if world_size == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(model, feet, args.max_iter, reset, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    world.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

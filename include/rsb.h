@@ -193,6 +193,14 @@ int rsb_get_solver_iterations(rsb_world* w, int32_t* iters, int space);
 int rsb_obs_dim(const rsb_world* w, int n_force_slots);
 int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, int n_force_slots, int space);
 
+/* VectorizedEnvironment support (raisimGymTorch's isTerminalState()+reset() fan-out [RECALL]), on device:
+ * every env whose last sub-step holds a contact on a collision primitive NOT listed in
+ * allowed_collisions (host array; e.g. the feet -> "terminate on any non-foot contact"), or whose state is
+ * non-finite, is reset to row e (rows == N) or row 0 (rows == 1) of gc0/gv0.  done (uint8 [N], same
+ * memspace as gc0/gv0, may be NULL) receives 1 for the envs that were reset, 0 otherwise. */
+int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_allowed, const float* gc0,
+                         const float* gv0, int rows, uint8_t* done, int space);
+
 /* zero-copy access to the resident state (device pointers; row-major [N,dim] float32) */
 typedef enum rsb_field {
   RSB_F_GC = 0, RSB_F_GV = 1, RSB_F_PTARGET = 2, RSB_F_DTARGET = 3, RSB_F_TAU_FF = 4,
@@ -210,6 +218,9 @@ int rsb_enable_timing(rsb_world* w, int on);
  * contact-frame coordinates [t1 t2 n] per contact.  env < 0 disables the dump. */
 int rsb_debug_select_env(rsb_world* w, int env);
 int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, float* lam);
+/* Debug aid (profiling): shader-clock stamps at the phase boundaries of workgroup 0's last sub-step:
+ * out16[0..9] = stamps, [10] = solver iterations, [11] = wave-max contact count. */
+int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16);
 
 #ifdef __cplusplus
 }

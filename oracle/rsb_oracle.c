@@ -27,7 +27,6 @@
 #define MAXB RSB_MAX_BODIES
 #define MAXV RSB_MAX_DOF
 #define MAXK RSB_MAX_CONTACTS
-#define ORC_JAM_KAPPA 0.1     /* jamming guard of the slip case, see solve_one_contact */
 #define ORC_LAMBDA_FLOOR 1e-3 /* N s; keeps the relative convergence test meaningful as impulses -> 0 */
 
 /* ------------------------------------------------------------------ small linear algebra */
@@ -280,7 +279,7 @@ void orc_default_params(orc_params* p) {
   p->alpha_init = 1.0; p->alpha_min = 1.0; p->alpha_decay = 1.0;
   p->threshold = 1e-5;
   p->max_iter = 150;
-  p->bisect_iters = 20;
+  p->section_rounds = 5;
   p->kmax = 8;
   p->control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   p->terrain_type = 0;
@@ -474,45 +473,93 @@ void orc_actuation(const rsb_model_blob* m, const orc_params* p, const double* q
 
 /* ------------------------------------------------------------------- per-contact solver */
 /*
- * One contact of the per-contact iteration (Hwangbo et al. 2018, §III): given the contact-space
- * velocity v the contact would have with its own impulse removed, and its own 3x3 Delassus
- * block G (contact frame [t1 t2 n]), return the impulse:
+ * Slip case of one contact (Hwangbo et al. 2018 §III-B).  With the stick impulse lam_s = -G^-1 v outside the
+ * friction cone, the impulse is the point of  C = {lam in cone} ∩ {v_n^+ = 0}  that minimises the contact-space
+ * kinetic energy  E = 1/2 (lam - lam_s)^T G (lam - lam_s)  (= 1/2 v^+T G^-1 v^+).  E is strictly convex and C is
+ * convex, so the minimiser is unique and lies on the boundary curve
+ *      lam(d) = ln(d) (mu d, 1),   ln(d) = -v_n / (G_nn + mu G_nt.d),   |d| = 1,
+ * which is an ellipse when mu |G_nt| < G_nn and unbounded otherwise (E -> inf towards the asymptote, so the
+ * minimiser stays finite even in Painleve-type jamming configurations).  Since frictionless inelastic impact is
+ * a member of C, the result never increases the kinetic energy.
+ *
+ * slip_E  : E along direction d (+inf where G_nn + mu G_nt.d <= 0: no point of the curve in that direction)
+ * slip_dE : a positive multiple of dE/dtheta along the curve (theta = angle of d), used only for its sign:
+ *           dE/dtheta = v^+ . dlam/dtheta = mu ln [ v_t^+.dperp - (den'/den) v_t^+.d ],  den' = mu G_nt.dperp
+ */
+#define ORC_DEN_MIN 1e-6
+static const double kCos16[16] = {1.0, 0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
+                                  -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
+                                  -0.92387953251128674, -0.70710678118654752, -0.38268343236508977, 0.0,
+                                  0.38268343236508977, 0.70710678118654752, 0.92387953251128674};
+static const double kSin16[16] = {0.0, 0.38268343236508977, 0.70710678118654752, 0.92387953251128674, 1.0,
+                                  0.92387953251128674, 0.70710678118654752, 0.38268343236508977, 0.0,
+                                  -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
+                                  -0.92387953251128674, -0.70710678118654752, -0.38268343236508977};
+
+static double slip_E(const double* G, const double* v, const double* ls, double mu, double dx, double dy) {
+  double den = G[8] + mu * (G[6] * dx + G[7] * dy);
+  if (!(den > ORC_DEN_MIN * G[8])) return 1e300;
+  double ln = -v[2] / den;
+  double l0 = mu * ln * dx, l1 = mu * ln * dy;
+  double vt0 = v[0] + G[0] * l0 + G[1] * l1 + G[2] * ln;
+  double vt1 = v[1] + G[3] * l0 + G[4] * l1 + G[5] * ln;
+  return 0.5 * (vt0 * (l0 - ls[0]) + vt1 * (l1 - ls[1]));
+}
+static double slip_dE(const double* G, const double* v, double mu, double dx, double dy) {
+  double den = G[8] + mu * (G[6] * dx + G[7] * dy);
+  double dp = -G[6] * dy + G[7] * dx;                 /* G_nt . dperp, dperp = (-dy, dx) */
+  if (!(den > ORC_DEN_MIN * G[8])) return dp > 0.0 ? -1.0 : 1.0;   /* the feasible arc lies towards growing den */
+  double ln = -v[2] / den;
+  double vt0 = v[0] + ln * (mu * (G[0] * dx + G[1] * dy) + G[2]);
+  double vt1 = v[1] + ln * (mu * (G[3] * dx + G[4] * dy) + G[5]);
+  return den * (-vt0 * dy + vt1 * dx) - mu * dp * (vt0 * dx + vt1 * dy);
+}
+
+/*
+ * One contact of the per-contact iteration: given the contact-space velocity v the contact would have with its
+ * own impulse removed, and its own 3x3 Delassus block G (contact frame [t1 t2 n]), return the impulse:
  *   open : v_n > 0                         -> 0
- *   stick: lam = -G^-1 v inside the cone   -> lam
- *   slip : on {v_n^+ = 0} ∩ cone boundary, direction found by bisection so that the
- *          post-impulse tangential velocity is anti-parallel to the friction impulse
- *          (maximum dissipation).  The bisection runs on unit direction vectors, not angles.
+ *   stick: lam_s = -G^-1 v inside the cone -> lam_s
+ *   slip : minimum-energy point of the curve above, located by
+ *            round 0 : E at 16 directions 22.5 deg apart; the best one +-1 neighbour brackets the minimiser;
+ *            rounds 1..section_rounds : 16-section on the sign of dE/dtheta (15 interior candidates per round,
+ *                      the first candidate with dE >= 0 closes the bracket from above) -> 45deg / 16^5 = 7.5e-7 rad.
+ *          16-section instead of bisection because the device evaluates the 15 (16) candidates of a round on the
+ *          lanes of the env group at once; the oracle walks the same candidates sequentially.
  */
 static void solve_one_contact(const double* G, const double* Ginv, const double* v, double mu,
-                              int bisect_iters, double* lam) {
+                              int section_rounds, double* lam) {
   if (v[2] > 0.0) { lam[0] = lam[1] = lam[2] = 0.0; return; }
   double ls[3];
   for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
   double lt2 = ls[0] * ls[0] + ls[1] * ls[1];
   if (ls[2] >= 0.0 && lt2 <= mu * mu * ls[2] * ls[2]) { lam[0] = ls[0]; lam[1] = ls[1]; lam[2] = ls[2]; return; }
-  double d0[2];
-  if (lt2 < 1e-30) { d0[0] = 1.0; d0[1] = 0.0; }
-  else { double il = 1.0 / sqrt(lt2); d0[0] = ls[0] * il; d0[1] = ls[1] * il; }
-  double lo[2] = {d0[1], -d0[0]}, hi[2] = {-d0[1], d0[0]}, d[2] = {d0[0], d0[1]};
-  double ln = 0.0, mue = mu;
-  for (int it = 0; it <= bisect_iters; ++it) {
-    /* Jamming guard: when the friction impulse along d would cancel the normal response
-     * (G_nn + mu G_nt.d < kappa G_nn, a Painleve-type configuration) the friction coefficient used along
-     * d is reduced so that the normal response stays kappa G_nn; the impulse stays inside the cone. */
-    double gd = G[6] * d[0] + G[7] * d[1];
-    mue = mu;
-    if (G[8] + mu * gd < ORC_JAM_KAPPA * G[8]) mue = (ORC_JAM_KAPPA - 1.0) * G[8] / gd;
-    ln = -v[2] / (G[8] + mue * gd);
-    if (it == bisect_iters) break;
-    double vt0 = v[0] + ln * (mue * (G[0] * d[0] + G[1] * d[1]) + G[2]);
-    double vt1 = v[1] + ln * (mue * (G[3] * d[0] + G[4] * d[1]) + G[5]);
-    double g = vt0 * d[1] - vt1 * d[0];
-    if (g > 0.0) { lo[0] = d[0]; lo[1] = d[1]; } else { hi[0] = d[0]; hi[1] = d[1]; }
-    double s0 = lo[0] + hi[0], s1 = lo[1] + hi[1];
-    double inv = 1.0 / sqrt(s0 * s0 + s1 * s1);
-    d[0] = s0 * inv; d[1] = s1 * inv;
+  int kbest = 0;
+  double ebest = slip_E(G, v, ls, mu, kCos16[0], kSin16[0]);
+  for (int k = 1; k < 16; ++k) {
+    double e = slip_E(G, v, ls, mu, kCos16[k], kSin16[k]);
+    if (e < ebest) { ebest = e; kbest = k; }
   }
-  lam[0] = mue * ln * d[0]; lam[1] = mue * ln * d[1]; lam[2] = ln;
+  double lox = kCos16[(kbest + 15) & 15], loy = kSin16[(kbest + 15) & 15];
+  double hix = kCos16[(kbest + 1) & 15], hiy = kSin16[(kbest + 1) & 15];
+  for (int r = 0; r < section_rounds; ++r) {
+    double cx[15], cy[15];
+    int kstar = 15;
+    for (int k = 0; k < 15; ++k) {
+      double t = (k + 1) * (1.0 / 16.0);
+      double x = lox + t * (hix - lox), y = loy + t * (hiy - loy), inv = 1.0 / sqrt(x * x + y * y);
+      cx[k] = x * inv; cy[k] = y * inv;
+      if (kstar == 15 && slip_dE(G, v, mu, cx[k], cy[k]) >= 0.0) kstar = k;
+    }
+    if (kstar < 15) { hix = cx[kstar]; hiy = cy[kstar]; }
+    if (kstar > 0) { lox = cx[kstar - 1]; loy = cy[kstar - 1]; }
+  }
+  double x = lox + hix, y = loy + hiy, inv = 1.0 / sqrt(x * x + y * y);
+  x *= inv; y *= inv;
+  double den = G[8] + mu * (G[6] * x + G[7] * y);
+  if (!(den > ORC_DEN_MIN * G[8])) den = ORC_DEN_MIN * G[8];
+  double ln = -v[2] / den;
+  lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
 }
 
 static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {
@@ -625,7 +672,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
           if (j == i) continue;
           for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam[j][0] + G[i][j][3 * r + 1] * lam[j][1] + G[i][j][3 * r + 2] * lam[j][2];
         }
-        solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->bisect_iters, ln);
+        solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds, ln);
         for (int r = 0; r < 3; ++r) {
           double dl = alpha * (ln[r] - lam[i][r]);
           lam[i][r] += dl;

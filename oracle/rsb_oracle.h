@@ -33,7 +33,7 @@ typedef struct orc_params {
   double erp;
   double alpha_init, alpha_min, alpha_decay, threshold;
   int32_t max_iter;
-  int32_t bisect_iters;
+  int32_t section_rounds;
   int32_t kmax;
   int32_t control_mode;      /* rsb_control_mode */
   int32_t terrain_type;      /* 0 = plane, 1 = heightmap */

@@ -91,10 +91,12 @@ PROTOTYPES = {
     "rsb_get_solver_iterations": (_I, [_VP, _FP, _I]),
     "rsb_obs_dim": (_I, [_VP, _I]),
     "rsb_gather_obs": (_I, [_VP, _FP, _FP, _I, _I]),
+    "rsb_reset_terminated": (_I, [_VP, _FP, _I, _FP, _FP, _I, _FP, _I]),
     "rsb_device_ptr": (_VP, [_VP, _I]),
     "rsb_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
     "rsb_enable_timing": (_I, [_VP, _I]),
     "rsb_debug_select_env": (_I, [_VP, _I]),
+    "rsb_debug_phase_cycles": (_I, [_VP, _I, _FP]),
     "rsb_debug_read_contact_problem": (_I, [_VP, C.POINTER(C.c_int), _FP, _FP, _FP]),
 }
 

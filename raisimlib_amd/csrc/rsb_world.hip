@@ -44,13 +44,14 @@ struct rsb_world {
   float *d_M = nullptr, *d_h = nullptr;
   int32_t* d_obs_idx = nullptr;
   float* d_dbg = nullptr;
+  long long* d_prof = nullptr;
   int dbg_env = -1;
   rsb_contact* d_contacts = nullptr;
   int32_t *d_count = nullptr, *d_flags = nullptr, *d_iters = nullptr;
   // parameters
   double dt = 0.0025, gravity[3] = {0, 0, -9.81}, mu = 0.8, erp = 0.0;
   double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
-  int max_iter = 150, bisect_iters = 20, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
+  int max_iter = 150, section_rounds = 5, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
   int lpe = 0;
@@ -116,6 +117,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.g = take(3 * kcap * L.gstride);
   L.lam = take(3 * kcap);
   L.wv = take(8);
+  L.slip = take(16);
   L.per_env = o;
   return L;
 }
@@ -157,6 +159,27 @@ __global__ void gather_obs_kernel(float* out, const float* gc, const float* gv, 
   out[i] = v;
 }
 
+__global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact* contacts, int32_t* count,
+                                        int32_t* flags, unsigned long long allowed, const float* gc0, const float* gv0,
+                                        int rows, uint8_t* done, int N, int nq, int nv, int kmax) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  bool term = (flags[e] & 2) != 0;
+  const int nc = count[e];
+  for (int k = 0; k < nc; ++k) {
+    const int c = contacts[(size_t)e * kmax + k].collision;
+    if (!((allowed >> c) & 1ull)) term = true;
+  }
+  if (term) {
+    const size_t r = rows == 1 ? 0 : (size_t)e;
+    for (int i = 0; i < nq; ++i) gc[(size_t)e * nq + i] = gc0[r * nq + i];
+    for (int i = 0; i < nv; ++i) gv[(size_t)e * nv + i] = gv0[r * nv + i];
+    count[e] = 0;
+    flags[e] = 0;
+  }
+  if (done) done[e] = term ? 1 : 0;
+}
+
 template <int LPE, int KMAX>
 int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes) {
   auto kern = rsbk::rsb_step_kernel<LPE, KMAX>;
@@ -193,13 +216,14 @@ int do_integrate(rsb_world* w, int nsub) {
   a.kp = w->d_kp; a.kd = w->d_kd;
   a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
   a.heights = w->d_heights;
+  a.prof = w->d_prof;
   a.dbg = w->dbg_env >= 0 ? w->d_dbg : nullptr;
   a.dbg_env = w->dbg_env;
   a.N = w->N; a.nsub = nsub; a.kmax = w->kmax; a.control_mode = w->control_mode;
   a.dt = (float)w->dt; a.gx = (float)w->gravity[0]; a.gy = (float)w->gravity[1]; a.gz = (float)w->gravity[2];
   a.mu = (float)w->mu; a.erp = (float)w->erp;
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
-  a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.bisect_iters = w->bisect_iters;
+  a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {
     double dx = w->hm_xsize / (w->hm_xs - 1), dy = w->hm_ysize / (w->hm_ys - 1);
@@ -307,7 +331,7 @@ int rsb_destroy(rsb_world* w) {
   (void)hipSetDevice(w->device);
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
-                  w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_contacts,
+                  w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
@@ -547,6 +571,42 @@ int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, i
   return RSB_OK;
 }
 
+int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_allowed, const float* gc0,
+                         const float* gv0, int rows, uint8_t* done, int space) {
+  if (!w || !gc0 || !gv0 || (rows != 1 && rows != w->N) || n_allowed < 0 || (n_allowed > 0 && !allowed_collisions)) {
+    rsb::set_error("rsb_reset_terminated: bad argument");
+    return RSB_E_INVALID;
+  }
+  HIP_TRY(hipSetDevice(w->device));
+  unsigned long long allowed = 0;
+  for (int i = 0; i < n_allowed; ++i) {
+    if (allowed_collisions[i] < 0 || allowed_collisions[i] >= w->blob.ncol) { rsb::set_error("rsb_reset_terminated: collision index out of range"); return RSB_E_INVALID; }
+    allowed |= 1ull << allowed_collisions[i];
+  }
+  const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
+  const float *dgc0 = gc0, *dgv0 = gv0;
+  uint8_t* ddone = done;
+  if (space == RSB_HOST) {
+    if (!w->d_tmp_gc) {
+      HIP_TRY(hipMalloc(&w->d_tmp_gc, N * nq * sizeof(float)));
+      HIP_TRY(hipMalloc(&w->d_tmp_gv, N * nv * sizeof(float)));
+      HIP_TRY(hipMalloc(&w->d_tmp_mask, N));
+    }
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, gc0, (size_t)rows * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, gv0, (size_t)rows * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    dgc0 = w->d_tmp_gc; dgv0 = w->d_tmp_gv; ddone = done ? w->d_tmp_mask : nullptr;
+  }
+  hipLaunchKernelGGL(reset_terminated_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_contacts,
+                     w->d_count, w->d_flags, allowed, dgc0, dgv0, rows, ddone, (int)N, (int)nq, (int)nv, w->kmax);
+  HIP_TRY(hipGetLastError());
+  w->integrate1_valid = false;
+  if (space == RSB_HOST) {
+    if (done) HIP_TRY(hipMemcpyAsync(done, w->d_tmp_mask, N, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+  }
+  return RSB_OK;
+}
+
 void* rsb_device_ptr(rsb_world* w, int field) {
   if (!w) return nullptr;
   switch (field) {
@@ -586,6 +646,19 @@ int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, fl
   if (G) std::memcpy(G, buf.data() + 1, sizeof(float) * n3 * n3);
   if (c) std::memcpy(c, buf.data() + 1 + n3 * n3, sizeof(float) * n3);
   if (lam) std::memcpy(lam, buf.data() + 1 + n3 * n3 + n3, sizeof(float) * n3);
+  return RSB_OK;
+}
+
+// Debug aid: per-phase cycle stamps (s_memtime) of workgroup 0 in the last sub-step of each launch.
+int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  if (enable && !w->d_prof) { HIP_TRY(hipMalloc(&w->d_prof, 16 * sizeof(long long))); HIP_TRY(hipMemset(w->d_prof, 0, 16 * sizeof(long long))); }
+  if (out16 && w->d_prof) {
+    HIP_TRY(hipMemcpyAsync(out16, w->d_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+  }
+  if (!enable && w->d_prof) { HIP_TRY(hipStreamSynchronize(w->stream)); HIP_TRY(hipFree(w->d_prof)); w->d_prof = nullptr; }
   return RSB_OK;
 }
 

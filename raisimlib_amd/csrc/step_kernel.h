@@ -56,7 +56,7 @@ struct DevModel {
 
 struct LdsLayout {
   int shared_ints;  // per-block int table (parent|level, anc) size in floats
-  int q, u, tb, body, ups, fact, chol, wb, con, wc, cv, g, lam, wv;
+  int q, u, tb, body, ups, fact, chol, wb, con, wc, cv, g, lam, wv, slip;
   int gstride;
   int per_env;
 };
@@ -75,12 +75,13 @@ struct StepArgs {
   int32_t* flags;
   int32_t* iters;
   const float* heights;
+  long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
   float* dbg;      // optional [1 + 3K*3K + 3K + 3K] dump of env dbg_env's contact problem (nc, G, c, lam)
   int dbg_env;
   int N, nsub, kmax, control_mode;
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
-  int max_iter, bisect_iters;
+  int max_iter, section_rounds;
   int terrain_type, hm_xs, hm_ys;
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
   LdsLayout L;
@@ -159,35 +160,52 @@ __device__ __forceinline__ void terrain_eval(const StepArgs& a, float x, float y
   n[0] = -gxs * inv; n[1] = -gys * inv; n[2] = inv;
 }
 
-// One contact of the per-contact iteration: impulse for contact-space velocity v (own impulse
-// removed) and own Delassus block G (frame [t1 t2 n]).  Mirrors oracle solve_one_contact().
-__device__ __forceinline__ void solve_one_contact(const float* G, const float* Ginv, const float* v, float mu,
-                                                  int bisect_iters, float* lam) {
-  if (v[2] > 0.f) { lam[0] = lam[1] = lam[2] = 0.f; return; }
-  float ls[3];
-  RSB_UNROLL for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
-  float lt2 = ls[0] * ls[0] + ls[1] * ls[1];
-  if (ls[2] >= 0.f && lt2 <= mu * mu * ls[2] * ls[2]) { lam[0] = ls[0]; lam[1] = ls[1]; lam[2] = ls[2]; return; }
-  float d0, d1;
-  if (lt2 < 1e-30f) { d0 = 1.f; d1 = 0.f; }
-  else { float il = 1.0f / sqrtf(lt2); d0 = ls[0] * il; d1 = ls[1] * il; }
-  float lo0 = d1, lo1 = -d0, hi0 = -d1, hi1 = d0, ln = 0.f, mue = mu;
-  for (int it = 0; it <= bisect_iters; ++it) {
-    // jamming guard (oracle: ORC_JAM_KAPPA): keep the normal response >= kappa * G_nn along d
-    const float gd = G[6] * d0 + G[7] * d1;
-    mue = mu;
-    if (G[8] + mu * gd < kJamKappa * G[8]) mue = (kJamKappa - 1.0f) * G[8] / gd;
-    ln = -v[2] / (G[8] + mue * gd);
-    if (it == bisect_iters) break;
-    float vt0 = v[0] + ln * (mue * (G[0] * d0 + G[1] * d1) + G[2]);
-    float vt1 = v[1] + ln * (mue * (G[3] * d0 + G[4] * d1) + G[5]);
-    float g = vt0 * d1 - vt1 * d0;
-    if (g > 0.f) { lo0 = d0; lo1 = d1; } else { hi0 = d0; hi1 = d1; }
-    float s0 = lo0 + hi0, s1 = lo1 + hi1;
-    float inv = 1.0f / sqrtf(s0 * s0 + s1 * s1);
-    d0 = s0 * inv; d1 = s1 * inv;
+// Slip residual along unit direction (dx, dy); mirrors oracle slip_eval() (jamming guard included).
+// Uses the hardware reciprocal (v_rcp_f32, 1 ulp): this runs 15 candidates x 5 rounds per slipping contact.
+__device__ __forceinline__ float slip_eval(const float* G, const float* v, float mu, float dx, float dy, float& ln, float& mue) {
+  const float gd = G[6] * dx + G[7] * dy;
+  mue = mu;
+  if (G[8] + mu * gd < kJamKappa * G[8]) mue = (kJamKappa - 1.0f) * G[8] * __builtin_amdgcn_rcpf(gd);
+  ln = -v[2] * __builtin_amdgcn_rcpf(G[8] + mue * gd);
+  const float vt0 = v[0] + ln * (mue * (G[0] * dx + G[1] * dy) + G[2]);
+  const float vt1 = v[1] + ln * (mue * (G[3] * dx + G[4] * dy) + G[5]);
+  return vt0 * dy - vt1 * dx;
+}
+
+// Slip case of one contact, solved COOPERATIVELY by the LPE lanes of the env group: P holds the
+// problem (G 9, v 3, d0 2) that the contact's own lane staged in LDS.  Each of `rounds` rounds places
+// 15 candidate directions inside the bracket (lane s < 15 evaluates candidate s), finds the first
+// sign change with a ballot, and narrows the bracket 16x (= 4 bisection steps).  Mirrors the oracle's
+// sequential 16-section search exactly (same candidates, same "first non-positive" rule).
+template <int LPE>
+__device__ __forceinline__ void slip_search(const float* P, float mu, int rounds, int s, int el, float* lam) {
+  const float* G = P;
+  const float* v = P + 9;
+  const float d0x = P[12], d0y = P[13];
+  float ln, mue, lox, loy, hix, hiy;
+  if (slip_eval(G, v, mu, d0x, d0y, ln, mue) > 0.f) { lox = d0x; loy = d0y; hix = -d0y; hiy = d0x; }
+  else { lox = d0y; loy = -d0x; hix = d0x; hiy = d0y; }
+  const int k = s < 15 ? s : 14;
+  const float t = (float)(k + 1) * (1.0f / 16.0f);
+  for (int r = 0; r < rounds; ++r) {
+    float cx = lox + t * (hix - lox), cy = loy + t * (hiy - loy);
+    const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy);
+    cx *= inv; cy *= inv;
+    const float g = slip_eval(G, v, mu, cx, cy, ln, mue);
+    const unsigned long long bal = __ballot(g <= 0.f && s < 15);
+    const unsigned int gm = (LPE == 64) ? (unsigned int)(bal & 0x7fffull) : (unsigned int)((bal >> (el * LPE)) & 0x7fffull);
+    const int kstar = gm ? (__ffs((int)gm) - 1) : 15;
+    const int base = el * LPE;
+    const float nlx = __shfl(cx, base + (kstar > 0 ? kstar - 1 : 0)), nly = __shfl(cy, base + (kstar > 0 ? kstar - 1 : 0));
+    const float nhx = __shfl(cx, base + (kstar < 15 ? kstar : 14)), nhy = __shfl(cy, base + (kstar < 15 ? kstar : 14));
+    if (kstar > 0) { lox = nlx; loy = nly; }
+    if (kstar < 15) { hix = nhx; hiy = nhy; }
   }
-  lam[0] = mue * ln * d0; lam[1] = mue * ln * d1; lam[2] = ln;
+  float x = lox + hix, y = loy + hiy;
+  const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
+  x *= inv; y *= inv;
+  slip_eval(G, v, mu, x, y, ln, mue);
+  lam[0] = mue * ln * x; lam[1] = mue * ln * y; lam[2] = ln;
 }
 
 __device__ __forceinline__ void inv3(const float* A, float* B) {
@@ -234,6 +252,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   float* G = E + L.g;
   float* LAM = E + L.lam;
   float* WV = E + L.wv;
+  float* SLIP = E + L.slip;
   const int GS = L.gstride;
 
   for (int i = lane; i < nb; i += 64) PARLV[i] = (m.parent[i] + 1) | (m.level[i] << 8);
@@ -273,6 +292,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   __syncthreads();
 
   for (int sub = 0; sub < a.nsub; ++sub) {
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[0] = clock64();
     // =========================== down pass: R r S V A (level-synchronous, lane = body) ========
     float R[9], r[3], S[6], V[6], A[6], E9[9];
     float qb = 0.f, qd = 0.f;
@@ -342,6 +362,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
     }
 
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[1] = clock64();
     // =========================== per body: rigid inertia about O, bias force ===================
     float IA[21], Z[6];
     {
@@ -376,6 +397,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       IA[sym6(5, 0)] = mc[1];  IA[sym6(5, 1)] = -mc[0]; IA[sym6(5, 2)] = 0.f;    IA[sym6(5, 3)] = 0.f; IA[sym6(5, 4)] = 0.f; IA[sym6(5, 5)] = mass;
     }
 
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[2] = clock64();
     // =========================== up pass: articulated inertias + b column (lane = body) =========
     float UD[6], rsD = 0.f;
     RSB_UNROLL for (int i = 0; i < 6; ++i) UD[i] = 0.f;
@@ -443,6 +465,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
     }
 
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[3] = clock64();
     // =========================== collision detection (lane = collision sphere) ================
     pbx = Q[0]; pby = Q[1]; pbz = Q[2];
     nc = 0;
@@ -495,6 +518,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     }
     __syncthreads();
 
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[4] = clock64();
     float lam[3] = {0.f, 0.f, 0.f};
     iters_used = 0;
     if (ncw > 0) {
@@ -543,6 +567,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       }
       __syncthreads();
 
+      if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[5] = clock64();
       // ========================= Delassus blocks G_ij = W_i W_j^T (lane = block pair) =============
       const int npw = ncw * (ncw + 1) / 2;
       for (int p0 = 0; p0 < npw; p0 += LPE) {
@@ -577,6 +602,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       }
       __syncthreads();
 
+      if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[6] = clock64();
       // ========================= per-contact Gauss-Seidel (lane = contact) ========================
       {
         float Grow[3][3 * KMAX], Gii[9], Ginv[9], v[3];
@@ -599,12 +625,41 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           float err = 0.f, scale = 0.f;
           RSB_UNROLL for (int j = 0; j < KMAX; ++j) {
             if (j < ncw) {
-              float dl[3] = {0.f, 0.f, 0.f};
-              if (s == j && isc && !done) {
-                float vex[3], ln[3];
+              float dl[3] = {0.f, 0.f, 0.f}, ln[3] = {0.f, 0.f, 0.f};
+              const bool mine = (s == j) && isc && !done;
+              bool need = false;
+              if (mine) {
+                // open / stick cases on the contact's own lane (oracle: solve_one_contact)
+                float vex[3];
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
                   vex[rr] = v[rr] - (Gii[3 * rr] * lam[0] + Gii[3 * rr + 1] * lam[1] + Gii[3 * rr + 2] * lam[2]);
-                solve_one_contact(Gii, Ginv, vex, a.mu, a.bisect_iters, ln);
+                if (!(vex[2] > 0.f)) {
+                  float ls[3];
+                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+                    ls[rr] = -(Ginv[3 * rr] * vex[0] + Ginv[3 * rr + 1] * vex[1] + Ginv[3 * rr + 2] * vex[2]);
+                  const float lt2 = ls[0] * ls[0] + ls[1] * ls[1];
+                  if (ls[2] >= 0.f && lt2 <= a.mu * a.mu * ls[2] * ls[2]) { ln[0] = ls[0]; ln[1] = ls[1]; ln[2] = ls[2]; }
+                  else {
+                    need = true;
+                    float P[16];
+                    RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) P[q2] = Gii[q2];
+                    P[9] = vex[0]; P[10] = vex[1]; P[11] = vex[2];
+                    if (lt2 < 1e-30f) { P[12] = 1.f; P[13] = 0.f; }
+                    else { const float il = 1.0f / sqrtf(lt2); P[12] = ls[0] * il; P[13] = ls[1] * il; }
+                    P[14] = 0.f; P[15] = 0.f;
+                    stv<4>(SLIP, P);
+                  }
+                }
+              }
+              if (__any(need)) {
+                // slip case: the whole env group searches the friction direction together
+                __syncthreads();
+                float P[16], lsl[3];
+                ldv<4>(SLIP, P);
+                slip_search<LPE>(P, a.mu, a.section_rounds, s, el, lsl);
+                if (need) { ln[0] = lsl[0]; ln[1] = lsl[1]; ln[2] = lsl[2]; }
+              }
+              if (mine) {
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { dl[rr] = alpha * (ln[rr] - lam[rr]); lam[rr] += dl[rr]; }
               }
               const int src = el * LPE + j;
@@ -636,6 +691,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       }
     }
 
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[7] = clock64();
     // =========================== w = W_b + sum_c W_c lam_c  (base dofs on lanes 0..5, joints on body lanes)
     float wj = 0.f;
     if (hasb && b >= 1) {
@@ -656,6 +712,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     }
     __syncthreads();
 
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[8] = clock64();
     // =========================== du = L^-1 D^-1/2 w : root -> leaf pass, then integrate ==========
     for (int l = 0; l < depth; ++l) {
       if (lvl == l) {
@@ -702,6 +759,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       }
       __syncthreads();
     }
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[9] = clock64(); a.prof[10] = iters_used; a.prof[11] = ncw; }
   }  // substeps
 
   // ---- results: LDS -> HBM

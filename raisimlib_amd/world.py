@@ -225,6 +225,22 @@ class BatchedWorld:
         n = 0 if idx is None else idx.shape[0]
         check(self.L.rsb_gather_obs(self.handle, C.c_void_p(out_device_ptr), _hp(idx), n, RSB_DEVICE), "rsb_gather_obs")
 
+    def reset_terminated(self, allowed_collisions, gc0, gv0):
+        """Reset envs that touch the terrain with anything but `allowed_collisions` (host arrays). Returns done [N]."""
+        idx = _host(allowed_collisions, np.int32)
+        g0, v0 = _host(gc0, np.float32), _host(gv0, np.float32)
+        rows = 1 if g0.ndim == 1 or g0.shape[0] == 1 else g0.shape[0]
+        done = np.zeros(self.N, np.uint8)
+        check(self.L.rsb_reset_terminated(self.handle, _hp(idx), idx.shape[0], _hp(g0), _hp(v0), rows, _hp(done), RSB_HOST),
+              "rsb_reset_terminated")
+        return done
+
+    def reset_terminated_device(self, allowed_collisions, gc0_ptr, gv0_ptr, rows, done_ptr=None):
+        idx = _host(allowed_collisions, np.int32)
+        check(self.L.rsb_reset_terminated(self.handle, _hp(idx), idx.shape[0], C.c_void_p(gc0_ptr), C.c_void_p(gv0_ptr),
+                                          int(rows), C.c_void_p(done_ptr) if done_ptr else None, RSB_DEVICE),
+              "rsb_reset_terminated")
+
     def device_ptr(self, field):
         return self.L.rsb_device_ptr(self.handle, int(field))
 
@@ -250,3 +266,9 @@ class BatchedWorld:
               "rsb_debug_read_contact_problem")
         n3 = 3 * nc.value
         return nc.value, G[:n3 * n3].reshape(n3, n3).copy(), c[:n3].copy(), lam[:n3].copy()
+
+    def debug_phase_cycles(self, enable=True, read=True):
+        out = np.zeros(16, np.int64)
+        check(self.L.rsb_debug_phase_cycles(self.handle, 1 if enable else 0, _hp(out) if read else None),
+              "rsb_debug_phase_cycles")
+        return out

@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/rsb.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from common import ROOT
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "rsb.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsb_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_boundary():
+    names = header_functions()
+    for must in ["rsb_create", "rsb_destroy", "rsb_integrate", "rsb_integrate1", "rsb_integrate2", "rsb_set_state",
+                 "rsb_get_state", "rsb_set_pd_gains", "rsb_set_pd_target", "rsb_set_generalized_force", "rsb_set_ground",
+                 "rsb_set_heightmap", "rsb_get_contacts", "rsb_gather_obs", "rsb_model_from_urdf_file"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    for name in header_functions():
+        assert hasattr(built_lib, name), f"librsb.so does not export {name}"
+
+
+def test_python_prototypes_match_header(built_lib):
+    from raisimlib_amd import _capi
+    assert sorted(_capi.PROTOTYPES) == header_functions()
+
+
+def test_struct_layouts_match(built_lib):
+    """ModelBlob / Contact ctypes mirrors have the C sizes (checked through a round trip)."""
+    from raisimlib_amd import Model, rsc_path, _capi
+    m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+    m2 = Model(blob=m.blob)      # C side validates nb/nq/nv/parent/level consistency of what it received
+    assert m2.nb == m.nb == 13 and m2.nv == 18 and m2.nq == 19
+    assert C.sizeof(_capi.Contact) == 48
+
+
+def test_no_cpu_fallback(built_lib):
+    """Without a GPU rsb_create must fail loudly (RSB_E_NO_DEVICE), never fall back to a CPU path."""
+    from raisimlib_amd import BatchedWorld, Model, RsbError, rsc_path
+    if built_lib.rsb_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+    with pytest.raises(RsbError, match="no HIP device"):
+        BatchedWorld(m, 4)
+
+
+def test_product_never_imports_oracle():
+    """The product package must not include, import, link or dlopen the oracle (test infrastructure)."""
+    bad = re.compile(r'#\s*include\s*[<"][^>"]*oracle|\bimport\s+oracle|\bfrom\s+oracle|pyoracle|librsb_oracle|dlopen')
+    for top in ("raisimlib_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert not bad.search(txt), f"{f} references the oracle"

@@ -1,0 +1,39 @@
+"""The oracle reproduces its own frozen golden vectors (tests/golden/make_golden.py) — guards against silent drift."""
+import os
+
+import numpy as np
+
+from common import ROOT, Oracle
+from raisimlib_amd import workload
+
+
+def test_oracle_matches_golden_vectors(anymal):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "anymal_golden.npz"))
+    o = Oracle(anymal.blob)
+    kp, kd = workload.anymal_gains()
+    kp, kd = kp.astype(np.float64), kd.astype(np.float64)
+    r = o.step_batch(g["gc"], g["gv"], 1, kp, kd, g["pt"], np.zeros((24, 18)))
+    assert np.array_equal(r["n_contacts"], g["n_contacts"]) and np.array_equal(r["iters"], g["iters"])
+    assert np.allclose(r["q"], g["q1"], rtol=0, atol=1e-12) and np.allclose(r["u"], g["u1"], rtol=0, atol=1e-10)
+    for e in range(0, 24, 5):
+        assert np.allclose(o.mass_matrix(g["gc"][e]), g["M"][e], atol=1e-12)
+        assert np.allclose(o.nonlinearities(g["gc"][e], g["gv"][e]), g["h"][e], atol=1e-10)
+    for k, e in enumerate(g["prob_env"]):
+        n3 = int(g["prob_n3"][k])
+        d = o.step_debug(g["gc"][e], g["gv"][e], kp, kd, g["pt"][e], np.zeros(18))
+        assert np.allclose(d["G"], g["prob_G"][k][:n3, :n3], atol=1e-12)
+        assert np.allclose(d["c"], g["prob_c"][k][:n3], atol=1e-12)
+        assert np.allclose(d["lam"], g["prob_lam"][k][:n3], atol=1e-10)
+
+
+def test_oracle_trajectory_matches_golden(anymal):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "anymal_golden.npz"))
+    o = Oracle(anymal.blob)
+    kp, kd = workload.anymal_gains()
+    g0, v0 = workload.anymal_initial_state(1)
+    q, u = g0.astype(np.float32).astype(np.float64), v0.copy()
+    for cs in range(25):
+        pt = workload.anymal_targets(1, cs).astype(np.float32).astype(np.float64)
+        r = o.step_batch(q, u, 4, kp.astype(np.float64), kd.astype(np.float64), pt, np.zeros((1, 18)))
+        q, u = r["q"], r["u"]
+        assert np.allclose(np.r_[q[0], u[0]], g["traj"][cs], rtol=0, atol=1e-8)

@@ -1,0 +1,180 @@
+"""Analytic known-answer tests that pin the CPU oracle (parity with RaiSim itself is unpinned: SURVEY.md §8c)."""
+import numpy as np
+import pytest
+
+from common import PENDULUM_URDF, Oracle, sphere_urdf
+
+G = 9.81
+DT = 0.0025
+
+
+def make(urdf):
+    from raisimlib_amd import Model
+    m = Model(urdf_string=urdf)
+    return m, Oracle(m.blob)
+
+
+def test_free_fall_matches_discrete_closed_form(built_lib):
+    """Semi-implicit Euler under gravity: v_n = -g n dt, z_n = z0 - g dt^2 n(n+1)/2 (exact for this scheme)."""
+    _, o = make(sphere_urdf())
+    q = np.array([0.3, -0.2, 50.0, 1, 0, 0, 0.0])
+    u = np.zeros(6)
+    n = 400
+    for _ in range(n):
+        q, u, con, _, _ = o.step(q, u)
+        assert len(con) == 0
+    assert abs(u[2] + G * n * DT) < 1e-10
+    assert abs(q[2] - (50.0 - G * DT * DT * n * (n + 1) / 2)) < 1e-9
+    assert np.allclose(q[:2], [0.3, -0.2]) and np.allclose(q[3:], [1, 0, 0, 0])
+
+
+def test_sphere_rest_impulse_is_m_g_dt(built_lib):
+    m_, r = 2.0, 0.1
+    _, o = make(sphere_urdf(m_, r))
+    q = np.array([0, 0, r - 1e-4, 1, 0, 0, 0.0])
+    u = np.zeros(6)
+    for _ in range(5):
+        q, u, con, _, _ = o.step(q, u)
+    assert len(con) == 1
+    assert np.allclose(con["impulse"][0], [0, 0, m_ * G * DT], atol=1e-12)
+    assert np.allclose(u, 0, atol=1e-12)
+    assert np.allclose(con["normal"][0], [0, 0, 1]) and abs(con["position"][0][2] - (q[2] - r)) < 1e-12
+
+
+def test_sliding_friction_decelerates_at_mu_g(built_lib):
+    """While the contact slips, the centre of mass decelerates at mu*g (first steps of a fast sliding sphere)."""
+    m_, r, mu = 2.0, 0.1, 0.8
+    _, o = make(sphere_urdf(m_, r))
+    q = np.array([0, 0, r - 1e-5, 1, 0, 0, 0.0])
+    u = np.array([3.0, 0, 0, 0, 0, 0])
+    for k in range(10):
+        q, u2, con, _, _ = o.step(q, u)
+        assert abs((u2[0] - u[0]) + mu * G * DT) < 1e-9, k
+        lam = con["impulse"][0]
+        assert abs(np.hypot(lam[0], lam[1]) - mu * lam[2]) < 1e-9          # on the cone boundary
+        assert lam[0] < 0 and abs(lam[1]) < 2e-7                           # opposes the sliding direction
+        u = u2
+
+
+SLED = """<robot name="sled"><link name="sled">
+ <inertial><origin xyz="0 0 0"/><mass value="5"/><inertia ixx="0.2" ixy="0" ixz="0" iyy="0.3" iyz="0" izz="0.4"/></inertial>
+ <collision><origin xyz="0.3 0.2 0"/><geometry><sphere radius="0.05"/></geometry></collision>
+ <collision><origin xyz="0.3 -0.2 0"/><geometry><sphere radius="0.05"/></geometry></collision>
+ <collision><origin xyz="-0.3 0.2 0"/><geometry><sphere radius="0.05"/></geometry></collision>
+ <collision><origin xyz="-0.3 -0.2 0"/><geometry><sphere radius="0.05"/></geometry></collision>
+</link></robot>"""
+
+
+@pytest.mark.parametrize("angle_deg,sticks", [(30.0, True), (36.0, True), (42.0, False), (50.0, False)])
+def test_stick_slip_threshold_on_incline(built_lib, angle_deg, sticks):
+    """A four-point sled on a plane with tilted gravity sticks iff tan(theta) < mu = 0.8 (theta* = 38.66 deg);
+    above it, it accelerates at g (sin(theta) - mu cos(theta)).  The per-contact minimum-energy slip rule is exact
+    Coulomb only for contacts without normal/tangential coupling; the sled's contact points sit below its centre of
+    mass, which costs ~0.2% of the friction force, i.e. up to ~2% of the (small) net acceleration."""
+    _, o = make(SLED)
+    th = np.radians(angle_deg)
+    o.p.gravity[0], o.p.gravity[1], o.p.gravity[2] = G * np.sin(th), 0.0, -G * np.cos(th)
+    q = np.array([0, 0, 0.05 - 1e-5, 1, 0, 0, 0.0])
+    u = np.zeros(6)
+    n = 200
+    for _ in range(n):
+        q, u, con, it, _ = o.step(q, u)
+        assert len(con) == 4
+    if sticks:
+        assert np.abs(u).max() < 1e-4
+    else:
+        a = G * (np.sin(th) - 0.8 * np.cos(th))
+        assert abs(u[0] - a * n * DT) < 2e-2 * a * n * DT + 1e-6
+        mu_eff = (np.sin(th) - u[0] / (n * DT) / G) / np.cos(th)
+        assert abs(mu_eff - 0.8) < 2e-3
+        assert abs(u[2]) < 1e-6 and np.abs(u[3:]).max() < 1e-4
+
+
+def test_pendulum_spring_period(built_lib):
+    """Zero gravity, joint spring via the PD controller (kd = 0): harmonic oscillator with T = 2 pi sqrt(I/kp)."""
+    l, m_ = 0.5, 1.0
+    _, o = make(PENDULUM_URDF.format(l=l, m=m_))
+    o.p.gravity[2] = 0.0
+    kp = np.zeros(7); kd = np.zeros(7); kp[6] = 40.0
+    I = m_ * l * l + 1e-9
+    T = 2 * np.pi * np.sqrt(I / kp[6])
+    q = np.array([0, 0, 0, 1, 0, 0, 0, 0.1]); u = np.zeros(7)
+    pt = np.zeros(8); pt[3] = 1.0
+    dtg = np.zeros(7)
+    th, t = [], []
+    for k in range(int(5 * T / DT)):
+        q, u, _, _, _ = o.step(q, u, kp, kd, pt, dtg)
+        th.append(q[7]); t.append((k + 1) * DT)
+    th = np.array(th); t = np.array(t)
+    # upward zero crossings -> period
+    idx = np.where((th[:-1] < 0) & (th[1:] >= 0))[0]
+    tc = t[idx] + DT * (-th[idx]) / (th[idx + 1] - th[idx])
+    periods = np.diff(tc)
+    assert len(periods) >= 3
+    assert np.allclose(periods, T, rtol=2e-3)
+    assert abs(np.abs(th).max() - 0.1) < 2e-3
+
+
+def test_pendulum_gravity_period_on_heavy_anchor(built_lib):
+    """Real gravity: the 1e9 kg anchor free-falls, so relative to it the bob feels no gravity and must not swing;
+    with the anchor's fall cancelled by an upward feed-forward force the bob swings with the large-angle period."""
+    l, m_ = 0.5, 1.0
+    mdl, o = make(PENDULUM_URDF.format(l=l, m=m_))
+    th0 = 0.2
+    q = np.array([0, 0, 0, 1, 0, 0, 0, th0]); u = np.zeros(7)
+    tau = np.zeros(7); tau[2] = (1e9 + m_) * G          # hold the anchor up
+    o.p.control_mode = 0
+    th, t = [], []
+    T_small = 2 * np.pi * np.sqrt(l / G)
+    T = T_small * (1 + th0 ** 2 / 16 + 11 * th0 ** 4 / 3072)
+    for k in range(int(4.2 * T / DT)):
+        q, u, _, _, _ = o.step(q, u, None, None, None, None, tau)
+        th.append(q[7]); t.append((k + 1) * DT)
+    th = np.array(th); t = np.array(t)
+    idx = np.where((th[:-1] < 0) & (th[1:] >= 0))[0]
+    tc = t[idx] + DT * (-th[idx]) / (th[idx + 1] - th[idx])
+    assert np.allclose(np.diff(tc), T, rtol=3e-3)
+    assert abs(q[2]) < 1e-3                              # anchor stayed put
+
+
+def test_momentum_and_energy_of_torque_free_flight(anymal):
+    """No gravity, no actuation, no contact: momentum and energy are conserved up to the integrator's O(dt) error
+    (the drift over a fixed time must halve when dt halves, and be small in absolute terms)."""
+    o = Oracle(anymal.blob)
+    o.p.gravity[2] = 0.0
+    o.p.control_mode = 0
+    rng = np.random.default_rng(3)
+    q0 = np.zeros(19); q0[2] = 10; q0[3] = 1; q0[7:] = rng.uniform(-0.5, 0.5, 12)
+    u0 = rng.normal(size=18) * 0.5
+    drift = []
+    for dt, n in [(0.0025, 400), (0.00125, 800)]:
+        o.p.dt = dt
+        q, u = q0.copy(), u0.copy()
+        P0, L0 = o.momentum(q, u)
+        E0 = sum(o.energy(q, u))
+        for _ in range(n):
+            q, u, con, _, _ = o.step(q, u)
+            assert len(con) == 0
+        P1, L1 = o.momentum(q, u)
+        E1 = sum(o.energy(q, u))
+        drift.append((np.abs(P1 - P0).max(), np.abs(L1 - L0).max(), abs(E1 - E0)))
+        if dt == 0.0025:
+            assert drift[0][0] < 1e-4 * np.abs(P0).max() and drift[0][1] < 2e-3 * np.abs(L0).max() and drift[0][2] < 1e-4 * E0
+    ratio = np.array(drift[0]) / np.array(drift[1])
+    assert np.all(ratio > 1.8) and np.all(ratio < 2.2)
+
+
+def test_standing_anymal_carries_its_weight(anymal):
+    """After settling on stiff legs the foot impulses sum to m g dt and stay inside the friction cone."""
+    from raisimlib_amd import workload
+    o = Oracle(anymal.blob)
+    kp = np.zeros(18); kd = np.zeros(18); kp[6:] = 400.0; kd[6:] = 10.0
+    q = np.zeros(19); q[2] = 0.60; q[3] = 1; q[7:] = workload.ANYMAL_NOMINAL_JOINTS
+    u = np.zeros(18); pt = q.copy(); dtg = np.zeros(18)
+    for _ in range(1500):
+        q, u, con, it, fl = o.step(q, u, kp, kd, pt, dtg)
+    assert fl == 0 and len(con) == 4 and set(con["collision"]) == {7, 11, 15, 19}
+    lam = con["impulse"]
+    assert abs(lam[:, 2].sum() - anymal.total_mass() * G * DT) < 1e-4
+    assert np.all(np.hypot(lam[:, 0], lam[:, 1]) <= 0.8 * lam[:, 2] + 1e-9)
+    assert np.abs(u).max() < 1e-3

@@ -60,29 +60,53 @@ def trajectory(N=64, control_steps=50, lpe=16):
             print(f"  control step {cs+1}: max|dq|={np.abs(q1-q).max():.3e} max|du|={np.abs(u1-u).max():.3e} median env |du|={np.median(np.abs(u1-u).max(axis=1)):.3e} contacts={w.get_contacts()[0].sum()} z_mean={q1[:,2].mean():.3f}")
     w.close()
 
-def timing(N=4096, lpe=16, steps=200):
+def timing(N=4096, lpe=16, steps=200, max_iter=150, reset=False):
     m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
     w = BatchedWorld(m, N); w.set_lanes_per_env(lpe)
+    w.set_contact_solver_param(1.0, 1.0, 1.0, max_iter, 1e-5)
+    feet = m.collision_indices("_foot")
     gc, gv = workload.anymal_initial_state(N)
     kp, kd = workload.anymal_gains()
     w.set_pd_gains(kp, kd); w.set_state(gc, gv)
     w.set_pd_target(workload.anymal_targets(N, 0), np.zeros((N, 18)))
-    for _ in range(100): w.integrate(4)
+    g0 = gc.astype(np.float32); v0 = gv.astype(np.float32)
+    nreset = 0
+    for _ in range(100):
+        w.integrate(4)
+        if reset: nreset += int(w.reset_terminated(feet, g0, v0).sum())
     w.synchronize()
-    t = time.time()
-    for _ in range(steps): w.integrate(4)
-    w.synchronize()
-    el = time.time() - t
-    w.enable_timing(True); w.integrate(4); ms = w.last_kernel_ms()
-    print(f"timing lpe={lpe} N={N}: {el/steps*1e6:.1f} us per control step (4 substeps) -> {N*4*steps/el/1e6:.1f} M env-steps/s; last kernel {ms*1e3:.1f} us; iters max {w.get_solver_iterations().max()}")
+    w.enable_timing(True)
+    el = 0.0; kms = []
+    for _ in range(steps):
+        t = time.time(); w.integrate(4); w.synchronize(); el += time.time() - t
+        kms.append(w.last_kernel_ms())
+        if reset: nreset += int(w.reset_terminated(feet, g0, v0).sum())
+    kms = np.array(kms)
+    q1, _ = w.get_state()
+    w.debug_phase_cycles(True, False); w.integrate(4); pc = w.debug_phase_cycles(True, True)
+    names = ["down", "perbody", "up", "collide", "columns", "delassus", "gs", "w", "final"]
+    print("   phase cycles (wg0, last substep): " + " ".join(f"{n}={pc[i+1]-pc[i]}" for i, n in enumerate(names)) + f" total={pc[9]-pc[0]} iters={pc[10]} ncw={pc[11]}")
+    print(f"timing lpe={lpe} N={N} max_iter={max_iter} reset={reset}: kernel mean {kms.mean()*1e3:.1f} us p50 {np.median(kms)*1e3:.1f} us per control step (4 substeps) -> {N*4/kms.mean()/1e3:.1f} M env-steps/s; "
+          f"iters max {w.get_solver_iterations().max()} mean {w.get_solver_iterations().mean():.2f}; resets {nreset}; zmean {q1[:,2].mean():.3f} contacts/env {w.get_contacts()[0].mean():.2f}")
     w.close()
 
 if __name__ == "__main__":
-    for lpe in (16,) if len(sys.argv) > 1 else (16, 32, 64):
+    for lpe in () if (len(sys.argv) > 1 and sys.argv[1] == "time") else (16,) if len(sys.argv) > 1 else (16, 32, 64):
         one_step("anymal_c_like.urdf", 256, lpe, 0)
-    one_step("anymal_c_like.urdf", 256, 16, 5, z_range=(0.2, 0.5))
-    one_step("atlas_like.urdf", 128, 32, 1, kmax=16, z_range=(0.6, 1.3))
+    if not (len(sys.argv) > 1 and sys.argv[1] == "time"):
+        one_step("anymal_c_like.urdf", 256, 16, 5, z_range=(0.2, 0.5))
+        one_step("atlas_like.urdf", 128, 32, 1, kmax=16, z_range=(0.6, 1.3))
     if len(sys.argv) > 1 and sys.argv[1] == "quick": sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "time":
+        for mi in (1, 5):
+            timing(lpe=16, max_iter=mi, steps=50)
+        timing(lpe=16, max_iter=5, reset=True, steps=50)
+        timing(lpe=64, max_iter=5, reset=True, steps=50)
+        sys.exit(0)
     trajectory()
     for lpe in (16, 32, 64):
         timing(lpe=lpe)
+    for mi in (1, 5, 10, 30, 60):
+        timing(lpe=16, max_iter=mi)
+    for mi in (5, 30, 150):
+        timing(lpe=16, max_iter=mi, reset=True)
