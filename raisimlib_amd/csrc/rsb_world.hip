@@ -54,7 +54,7 @@ struct rsb_world {
   int max_iter = 150, section_rounds = 5, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
-  int lpe = 0;
+  int lpe = 0, max_cl = 0;
   double world_time = 0;
   bool integrate1_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -74,23 +74,56 @@ void build_dev_model(const rsb_model_blob& b, DevModel* d) {
   for (int i = 0; i < b.nb; ++i) {
     d->parent[i] = b.parent[i]; d->level[i] = b.level[i]; d->jtype[i] = b.jtype[i];
     if (i > 0) kids[b.parent[i]].push_back(i);
-    for (int c = 0; c < 3; ++c) { d->axis[i][c] = (float)b.axis[i][c]; d->ptree[i][c] = (float)b.ptree[i][c]; d->com[i][c] = (float)b.com[i][c]; }
-    for (int c = 0; c < 9; ++c) d->rtree[i][c] = (float)b.rtree[i][c];
-    for (int c = 0; c < 6; ++c) d->inertia[i][c] = (float)b.inertia[i][c];
-    d->mass[i] = (float)b.mass[i]; d->armature[i] = (float)b.armature[i];
-    d->damping[i] = (float)b.damping[i]; d->effort[i] = (float)b.effort[i];
-  }
-  int pos = 0;
-  for (int i = 0; i < b.nb; ++i) {
-    d->nchild[i] = (int)kids[i].size();
-    d->child_start[i] = pos;
-    for (int c : kids[i]) d->child_list[pos++] = c;
-    int l = b.level[i];
-    if (d->nchild[i] > d->maxchild_level[l]) d->maxchild_level[l] = d->nchild[i];
+    float* f = d->bodyf[i];
+    for (int c = 0; c < 3; ++c) {
+      d->axis[i][c] = f[c] = (float)b.axis[i][c];
+      d->ptree[i][c] = f[4 + c] = (float)b.ptree[i][c];
+      d->com[i][c] = f[17 + c] = (float)b.com[i][c];
+    }
+    std::memcpy(&f[3], &b.jtype[i], sizeof(int));
+    for (int c = 0; c < 9; ++c) d->rtree[i][c] = f[8 + c] = (float)b.rtree[i][c];
+    for (int c = 0; c < 6; ++c) d->inertia[i][c] = f[20 + c] = (float)b.inertia[i][c];
+    d->mass[i] = f[7] = (float)b.mass[i];
+    d->armature[i] = f[26] = (float)b.armature[i];
+    f[27] = (float)b.damping[i];
+    f[28] = (float)b.effort[i];
   }
   for (int i = 0; i < b.nb * b.depth; ++i) d->anc[i] = -1;
   for (int i = 0; i < b.nb; ++i)
     for (int j = i; j >= 0; j = b.parent[j]) d->anc[i * b.depth + b.level[j]] = j;
+  // kinematic chains: a body continues its parent's chain iff it is the parent's first child (parent != base)
+  std::vector<int> chain_of(b.nb, -1);
+  d->nch = 0; d->nclv = 0; d->max_cl = 0;
+  for (int i = 1; i < b.nb; ++i) {
+    const int p = b.parent[i];
+    if (p >= 1 && kids[p][0] == i) {
+      const int c = chain_of[p];
+      d->ch_body[c * rsbk::kMaxCL + d->ch_len[c]] = i;
+      d->ch_len[c] += 1;
+      chain_of[i] = c;
+    } else {
+      const int c = d->nch++;
+      d->ch_attach[c] = p;
+      d->ch_level[c] = p == 0 ? 1 : d->ch_level[chain_of[p]] + 1;
+      d->ch_body[c * rsbk::kMaxCL] = i;
+      d->ch_len[c] = 1;
+      chain_of[i] = c;
+    }
+  }
+  std::vector<std::vector<int>> cc(b.nb);
+  for (int c = 0; c < d->nch; ++c) {
+    if (d->ch_len[c] > d->max_cl) d->max_cl = d->ch_len[c];
+    if (d->ch_level[c] > d->nclv) d->nclv = d->ch_level[c];
+    cc[d->ch_attach[c]].push_back(c);
+  }
+  int pos = 0;
+  d->max_cc = 0;
+  for (int i = 0; i < b.nb; ++i) {
+    d->cc_start[i] = pos;
+    d->cc_count[i] = (int)cc[i].size();
+    for (int c : cc[i]) d->cc_list[pos++] = c;
+    if (i >= 1 && d->cc_count[i] > d->max_cc) d->max_cc = d->cc_count[i];
+  }
   for (int s = 0; s < b.ncol; ++s) {
     d->col_body[s] = b.col_body[s];
     for (int c = 0; c < 3; ++c) d->col_pos[s][c] = (float)b.col_pos[s][c];
@@ -98,34 +131,63 @@ void build_dev_model(const rsb_model_blob& b, DevModel* d) {
   }
 }
 
+// longest chain of the decomposition above (needed before a DevModel exists, to pick the kernel class)
+int longest_chain(const rsb_model_blob& b) {
+  auto dm = std::make_unique<DevModel>();
+  build_dev_model(b, dm.get());
+  return dm->max_cl;
+}
+
 LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   LdsLayout L;
-  int cw = round4(6 + b.depth - 1);
-  L.shared_ints = round4(round4(b.nb) + b.nb * b.depth);
+  const int cw = round4(6 + b.depth - 1);
   int o = 0;
   auto take = [&](int n) { int r = o; o += round4(n); return r; };
-  L.q = take(b.nq); L.u = take(b.nv); L.tb = take(8);
+  L.t_model = take(b.nb * rsbk::kModelSlot);
+  L.t_gain = take(2 * b.nb);
+  L.t_parlv = take(b.nb);
+  L.t_anc = take(b.nb * b.depth);
+  L.t_dir = take(32);
+  L.shared_total = o;
+  o = 0;
+  L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
+  L.pt = take(b.nq); L.dtg = take(b.nv); L.tf = take(b.nv < 8 ? 8 : b.nv);
   L.body = take(b.nb * rsbk::kBodySlot);
-  L.ups = take(b.nb * rsbk::kUpSlot);
+  L.ups = take((b.nb > 1 ? b.nb - 1 : 1) * rsbk::kUpSlot);
   L.fact = take(b.nb * rsbk::kFactSlot);
-  L.chol = take(28);
   L.wb = take(b.nv);
   L.con = take(kcap * rsbk::kConSlot);
   L.wc = take(3 * kcap * cw);
   L.cv = take(3 * kcap);
-  L.gstride = 3 * kcap + 1;
+  L.gstride = 3 * kcap + 4;
   L.g = take(3 * kcap * L.gstride);
-  L.lam = take(3 * kcap);
-  L.wv = take(8);
-  L.slip = take(16);
+  L.ginv = take(12 * kcap);
   L.per_env = o;
   return L;
 }
 
+size_t lds_bytes_for(const rsb_model_blob& b, int kcap, int lpe) {
+  LdsLayout L = make_layout(b, kcap);
+  return sizeof(float) * ((size_t)L.shared_total + (size_t)(64 / lpe) * L.per_env);
+}
+
+int count_chains(const rsb_model_blob& b) {
+  std::vector<int> first(b.nb, -1);
+  int n = 0;
+  for (int i = 1; i < b.nb; ++i) {
+    const int p = b.parent[i];
+    if (p >= 1 && first[p] < 0) first[p] = i; else ++n;
+  }
+  return n;
+}
+
+// Lanes per env: the smallest group whose workgroup (64/LPE envs) still leaves room for one workgroup per
+// SIMD in a CU's 160 KiB of LDS; at N = 4096 that is what puts one wave on every SIMD of the chip.
 int default_lpe(const rsb_model_blob& b, int kmax) {
-  int need = b.nb > kmax ? b.nb : kmax;
-  if (need <= 16) return 16;
-  if (need <= 32) return 32;
+  const int kcap = kmax <= 8 ? 8 : 16;
+  const int need = count_chains(b) > 16 ? (count_chains(b) > 32 ? 64 : 32) : 16;
+  for (int lpe = need; lpe < 64; lpe *= 2)
+    if (lds_bytes_for(b, kcap, lpe) <= 40 * 1024) return lpe;
   return 64;
 }
 
@@ -180,15 +242,22 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
   if (done) done[e] = term ? 1 : 0;
 }
 
-template <int LPE, int KMAX>
+template <int LPE, int KMAX, int CL, int ML>
 int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes) {
-  auto kern = rsbk::rsb_step_kernel<LPE, KMAX>;
+  auto kern = rsbk::rsb_step_kernel<LPE, KMAX, CL, ML>;
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   constexpr int EPW = 64 / LPE;
   int blocks = (w->N + EPW - 1) / EPW;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds_bytes, w->stream, a);
   HIP_TRY(hipGetLastError());
   return RSB_OK;
+}
+
+template <int KMAX, int CL, int ML>
+int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe) {
+  if (lpe == 16) return launch_step<16, KMAX, CL, ML>(w, a, lds_bytes);
+  if (lpe == 32) return launch_step<32, KMAX, CL, ML>(w, a, lds_bytes);
+  return launch_step<64, KMAX, CL, ML>(w, a, lds_bytes);
 }
 
 int effective_lpe(const rsb_world* w) {
@@ -198,8 +267,9 @@ int effective_lpe(const rsb_world* w) {
 
 int check_lpe(const rsb_world* w, int lpe) {
   if (lpe != 16 && lpe != 32 && lpe != 64) { rsb::set_error("lanes_per_env must be 16, 32 or 64"); return RSB_E_INVALID; }
-  if (lpe < w->blob.nb) { rsb::set_error("lanes_per_env must be >= number of bodies"); return RSB_E_INVALID; }
-  if (lpe < w->kmax) { rsb::set_error("lanes_per_env must be >= max contacts"); return RSB_E_INVALID; }
+  if (lpe < count_chains(w->blob)) { rsb::set_error("lanes_per_env must be >= number of kinematic chains"); return RSB_E_INVALID; }
+  const int kcap = w->kmax <= 8 ? 8 : 16;
+  if (lds_bytes_for(w->blob, kcap, lpe) > 160 * 1024) { rsb::set_error("lanes_per_env too small: the workgroup's envs do not fit in 160 KiB of LDS"); return RSB_E_INVALID; }
   return RSB_OK;
 }
 
@@ -231,18 +301,19 @@ int do_integrate(rsb_world* w, int nsub) {
     a.hm_dx = (float)dx; a.hm_dy = (float)dy; a.hm_inv_dx = (float)(1.0 / dx); a.hm_inv_dy = (float)(1.0 / dy);
   }
   a.L = make_layout(w->blob, kcap);
-  const int epw = 64 / lpe;
-  size_t lds_bytes = sizeof(float) * ((size_t)a.L.shared_ints + (size_t)epw * a.L.per_env);
-  if (lds_bytes > 160 * 1024) { rsb::set_error("model needs more LDS per workgroup than a CU has (160 KiB)"); return RSB_E_UNSUPPORTED; }
+  const size_t lds_bytes = lds_bytes_for(w->blob, kcap, lpe);
   if (w->timing) HIP_TRY(hipEventRecord(w->ev0, w->stream));
-  if (kcap == 8) {
-    if (lpe == 16) st = launch_step<16, 8>(w, a, lds_bytes);
-    else if (lpe == 32) st = launch_step<32, 8>(w, a, lds_bytes);
-    else st = launch_step<64, 8>(w, a, lds_bytes);
+  // kernel classes by (longest chain, deepest body level): <=4/<=4 (quadrupeds), <=8/<=12 (humanoids), <=16/<=16
+  const int mcl = w->max_cl, mlv = w->blob.depth - 1;
+  if (mcl <= 4 && mlv <= 4) {
+    st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe);
+  } else if (mcl <= 8 && mlv <= 12) {
+    st = launch_lpe<16, 8, 12>(w, a, lds_bytes, lpe);
+  } else if (mcl <= 16 && mlv <= 16) {
+    st = launch_step<64, 16, 16, 16>(w, a, lds_bytes);
   } else {
-    if (lpe == 16) st = launch_step<16, 16>(w, a, lds_bytes);
-    else if (lpe == 32) st = launch_step<32, 16>(w, a, lds_bytes);
-    else st = launch_step<64, 16>(w, a, lds_bytes);
+    rsb::set_error("model outside the compiled kernel classes (chain length <= 16, tree depth <= 17)");
+    return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
   if (w->timing) HIP_TRY(hipEventRecord(w->ev1, w->stream));
@@ -285,6 +356,7 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   w->blob = m->blob;
   w->N = num_envs;
   w->device = device;
+  w->max_cl = longest_chain(w->blob);
   const int nq = w->blob.nq, nv = w->blob.nv;
   const size_t N = (size_t)num_envs;
   HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));

@@ -2,28 +2,35 @@
 //
 // Replaces, for N independent envs at once, the hot path of SURVEY.md §8a (rows a1-a15):
 // raisim::World::integrate1() (kinematics, collision detection, per-object dynamics) and
-// World::integrate2() (Delassus blocks, per-contact bisection solver, time integration).
-// None of those files exist in /root/reference (3-file stub) — the algorithm follows the
-// published sources cited in oracle/rsb_oracle.h and is checked against that oracle.
+// World::integrate2() (Delassus blocks, per-contact solver, time integration).  None of those files exist
+// in /root/reference (3-file stub) — the algorithm follows the published sources cited in
+// oracle/rsb_oracle.h and is checked against that oracle.
 //
-// Mapping.  One workgroup = one wavefront (64 lanes).  A group of LPE lanes (16, 32 or 64) owns one
-// env; LPE=64 is the north star's "one wavefront per env", smaller LPE packs 64/LPE envs into a wave
-// (wave-instruction issue cost is the same for 16 or 64 active lanes, so packing is what fills the
-// chip at N=4096).  Within an env group lane s is BODY s for the tree recursions (level-synchronous:
-// all bodies of one tree level work in parallel), COLLISION SPHERE s for detection, CONTACT COLUMN s
-// for the impulse-response columns, CONTACT s for the Gauss-Seidel sweep.
-// All per-env intermediates (body transforms, articulated inertias, joint chains' S/U/D, contact
-// columns, Delassus blocks) live in LDS; HBM is touched only for the state rows at launch start/end.
+// Mapping.  One workgroup = one wavefront (64 lanes).  A group of LPE lanes (16, 32 or 64) owns one env;
+// LPE=64 is the north star's "one wavefront per env", smaller LPE packs 64/LPE envs into a wave (a wave
+// instruction costs the same for 16 or 64 active lanes, so packing is what fills the chip at N=4096).
+// At N=4096 there is one wave per SIMD, so the kernel is LATENCY bound: every design choice below
+// minimises dependent LDS round trips and barriers rather than instruction count.
+//   tree passes   : lane = kinematic CHAIN (a maximal parent->first-child path; ANYmal: 4 legs).  A lane
+//                   walks its chain serially in registers; LDS is touched once per chain LEVEL, not per body.
+//                   The floating base is computed redundantly by every lane (no exchange needed).
+//   collisions    : lane = collision sphere.      contact columns : lane = (contact, axis).
+//   Delassus      : lane = contact pair.          Gauss-Seidel    : every lane of the group runs the same
+//                   sweep redundantly from LDS-broadcast G rows (no cross-lane traffic inside the sweep);
+//                   the slip case's candidate directions are spread over the group's lanes.
+// All per-env intermediates live in LDS / registers; HBM is touched only for the state rows at launch
+// start / end ([N, dim] row-major rows: consecutive lanes read consecutive floats).
 //
 // Algorithm (fp32).  Common-frame spatial algebra with origin at the base position (see oracle):
-//   down pass : R, r, S, V, bias acceleration A per body
+//   down pass : R, r, S, V, bias acceleration A per body; rigid inertia and bias force
 //   up pass   : articulated-body inertia IA (RBDA Table 7.1), U = IA S, D = S.U; the same pass
 //               propagates Z = dt*(bias force) so that yhat_k = dt*tau_k - S_k.Z_k is the k-th entry
 //               of L^-T b (M = L^T D L).  The base's 6x6 articulated inertia is Cholesky-factored.
 //   columns   : for each contact axis the unit impulse [x×t; t] is propagated up the support chain
 //               (same recursion) giving a sparse column W_c = D^-1/2 L^-T J_c^T; G = W W^T,
 //               c = J u + W_c.W_b.
-//   solver    : per-contact Gauss-Seidel with open/stick/slip(bisection) cases (Hwangbo et al. 2018).
+//   solver    : per-contact Gauss-Seidel, open/stick/slip(minimum-energy point of the cone boundary)
+//               (Hwangbo et al. 2018), same rules and constants as oracle solve_one_contact().
 //   update    : du = L^-1 D^-1/2 (W_b + sum W_c lam) by one root->leaf pass; semi-implicit Euler.
 #pragma once
 
@@ -36,27 +43,38 @@ namespace rsbk {
 
 constexpr int kMaxB = RSB_MAX_BODIES;
 constexpr int kMaxC = RSB_MAX_COLLISIONS;
-constexpr int kBodySlot = 24;  // R9 r3 V6 A6
-constexpr int kUpSlot = 28;    // Ia21 Zc6 pad
-constexpr int kFactSlot = 16;  // S6 UD6 rsD invD pad2
-constexpr int kConSlot = 16;   // x3 depth | t1 body | t2 col | n pad
-constexpr float kJamKappa = 0.1f;      // jamming guard of the slip case (== ORC_JAM_KAPPA)
+constexpr int kMaxCL = 16;       // longest supported chain
+constexpr int kBodySlot = 24;    // R9 r3 V6 A6 (A is reused for the delta-velocity of the final pass)
+constexpr int kUpSlot = 28;      // Ia21 Zc6 pad   (one per chain)
+constexpr int kFactSlot = 16;    // S6 UD6 rsD invD pad2
+constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
+constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevModel::bodyf)
 constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence test (== ORC_LAMBDA_FLOOR)
+constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
-  int parent[kMaxB], level[kMaxB], jtype[kMaxB], nchild[kMaxB], child_start[kMaxB], child_list[kMaxB];
-  int maxchild_level[kMaxB];
-  int anc[kMaxB * kMaxB];  // anc[b*depth + l] = ancestor of b at level l (l <= level[b]), else -1
+  int nch, nclv, max_cl, max_cc;    // chains, chain levels, longest chain, max child chains of one body
+  int parent[kMaxB], level[kMaxB], jtype[kMaxB];
+  int anc[kMaxB * kMaxB];           // anc[b*depth + l] = ancestor of b at level l (l <= level[b]), else -1
+  // chains: ch_body[c*kMaxCL + k] = k-th body of chain c (root-most first)
+  int ch_len[kMaxB], ch_attach[kMaxB], ch_level[kMaxB], ch_body[kMaxB * kMaxCL];
+  int cc_start[kMaxB], cc_count[kMaxB], cc_list[kMaxB];  // chains hanging off each body
+  // bodyf[b]: 0-2 axis, 3 jtype (int bits), 4-6 ptree, 7 mass, 8-16 rtree, 17-19 com, 20-25 inertia,
+  //           26 armature, 27 damping, 28 effort
+  float bodyf[kMaxB][kModelSlot];
+  // fields used by the slow-path query kernel
   float axis[kMaxB][4], ptree[kMaxB][4], rtree[kMaxB][12], com[kMaxB][4], inertia[kMaxB][8];
-  float mass[kMaxB], armature[kMaxB], damping[kMaxB], effort[kMaxB];
+  float mass[kMaxB], armature[kMaxB];
   int col_body[kMaxC];
   float col_pos[kMaxC][4];  // xyz, radius
 };
 
 struct LdsLayout {
-  int shared_ints;  // per-block int table (parent|level, anc) size in floats
-  int q, u, tb, body, ups, fact, chol, wb, con, wc, cv, g, lam, wv, slip;
+  // per-block tables (floats from the start of LDS)
+  int t_model, t_gain, t_parlv, t_anc, t_dir, shared_total;
+  // per-env arrays (floats from the env base)
+  int q, u, pt, dtg, tf, body, ups, fact, wb, con, wc, cv, g, ginv;
   int gstride;
   int per_env;
 };
@@ -76,7 +94,7 @@ struct StepArgs {
   int32_t* iters;
   const float* heights;
   long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
-  float* dbg;      // optional [1 + 3K*3K + 3K + 3K] dump of env dbg_env's contact problem (nc, G, c, lam)
+  float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)
   int dbg_env;
   int N, nsub, kmax, control_mode;
   float dt, gx, gy, gz, mu, erp;
@@ -126,6 +144,16 @@ __device__ __forceinline__ void rigid_mul(const float* A6, const float* mc, floa
   cross3(mc, x, t);
   y[3] = m * x[3] - t[0]; y[4] = m * x[4] - t[1]; y[5] = m * x[5] - t[2];
 }
+// expand the 10-parameter rigid inertia to a packed symmetric 6x6 (spatial order [ang; lin])
+__device__ __forceinline__ void rigid_expand(const float* I10, float* IA) {
+  const float* mc = I10 + 6;
+  const float m = I10[9];
+  IA[sym6(0, 0)] = I10[0]; IA[sym6(1, 0)] = I10[1]; IA[sym6(1, 1)] = I10[3];
+  IA[sym6(2, 0)] = I10[2]; IA[sym6(2, 1)] = I10[4]; IA[sym6(2, 2)] = I10[5];
+  IA[sym6(3, 0)] = 0.f;    IA[sym6(3, 1)] = mc[2];  IA[sym6(3, 2)] = -mc[1]; IA[sym6(3, 3)] = m;
+  IA[sym6(4, 0)] = -mc[2]; IA[sym6(4, 1)] = 0.f;    IA[sym6(4, 2)] = mc[0];  IA[sym6(4, 3)] = 0.f; IA[sym6(4, 4)] = m;
+  IA[sym6(5, 0)] = mc[1];  IA[sym6(5, 1)] = -mc[0]; IA[sym6(5, 2)] = 0.f;    IA[sym6(5, 3)] = 0.f; IA[sym6(5, 4)] = 0.f; IA[sym6(5, 5)] = m;
+}
 __device__ __forceinline__ void ld4(const float* p, float* o) {
   float4 v = *reinterpret_cast<const float4*>(p);
   o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -160,52 +188,77 @@ __device__ __forceinline__ void terrain_eval(const StepArgs& a, float x, float y
   n[0] = -gxs * inv; n[1] = -gys * inv; n[2] = inv;
 }
 
-// Slip residual along unit direction (dx, dy); mirrors oracle slip_eval() (jamming guard included).
-// Uses the hardware reciprocal (v_rcp_f32, 1 ulp): this runs 15 candidates x 5 rounds per slipping contact.
-__device__ __forceinline__ float slip_eval(const float* G, const float* v, float mu, float dx, float dy, float& ln, float& mue) {
-  const float gd = G[6] * dx + G[7] * dy;
-  mue = mu;
-  if (G[8] + mu * gd < kJamKappa * G[8]) mue = (kJamKappa - 1.0f) * G[8] * __builtin_amdgcn_rcpf(gd);
-  ln = -v[2] * __builtin_amdgcn_rcpf(G[8] + mue * gd);
-  const float vt0 = v[0] + ln * (mue * (G[0] * dx + G[1] * dy) + G[2]);
-  const float vt1 = v[1] + ln * (mue * (G[3] * dx + G[4] * dy) + G[5]);
-  return vt0 * dy - vt1 * dx;
+// ---- slip case of one contact (oracle: slip_E / slip_dE / solve_one_contact) -----------------------
+// G: own 3x3 Delassus block, v: contact velocity without the own impulse, ls: stick impulse.
+__device__ __forceinline__ float slip_E(const float* G, const float* v, const float* ls, float mu, float dx, float dy) {
+  const float den = G[8] + mu * (G[6] * dx + G[7] * dy);
+  if (!(den > kDenMin * G[8])) return __int_as_float(0x7f800000);
+  const float ln = -v[2] * __builtin_amdgcn_rcpf(den);
+  const float l0 = mu * ln * dx, l1 = mu * ln * dy;
+  const float vt0 = v[0] + G[0] * l0 + G[1] * l1 + G[2] * ln;
+  const float vt1 = v[1] + G[3] * l0 + G[4] * l1 + G[5] * ln;
+  return fmaxf(0.5f * (vt0 * (l0 - ls[0]) + vt1 * (l1 - ls[1])), 0.f);
 }
-
-// Slip case of one contact, solved COOPERATIVELY by the LPE lanes of the env group: P holds the
-// problem (G 9, v 3, d0 2) that the contact's own lane staged in LDS.  Each of `rounds` rounds places
-// 15 candidate directions inside the bracket (lane s < 15 evaluates candidate s), finds the first
-// sign change with a ballot, and narrows the bracket 16x (= 4 bisection steps).  Mirrors the oracle's
-// sequential 16-section search exactly (same candidates, same "first non-positive" rule).
+__device__ __forceinline__ float slip_dE(const float* G, const float* v, float mu, float dx, float dy) {
+  const float den = G[8] + mu * (G[6] * dx + G[7] * dy);
+  const float dp = -G[6] * dy + G[7] * dx;
+  if (!(den > kDenMin * G[8])) return dp > 0.f ? -1.f : 1.f;
+  const float ln = -v[2] * __builtin_amdgcn_rcpf(den);
+  const float vt0 = v[0] + ln * (mu * (G[0] * dx + G[1] * dy) + G[2]);
+  const float vt1 = v[1] + ln * (mu * (G[3] * dx + G[4] * dy) + G[5]);
+  return den * (-vt0 * dy + vt1 * dx) - mu * dp * (vt0 * dx + vt1 * dy);
+}
+// 16-lane row minimum of an unsigned key (DPP row rotate: no LDS, no bpermute)
+__device__ __forceinline__ unsigned row_min_u32(unsigned x) {
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xf, 0xf, false));  // row_ror:8
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xf, 0xf, false));  // row_ror:4
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x122, 0xf, 0xf, false));  // row_ror:2
+  x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xf, 0xf, false));  // row_ror:1
+  return x;
+}
+// Cooperative slip solve: all lanes of the env group hold the same (G, v, ls); lane (s & 15) evaluates
+// candidate (s & 15) of every round.  DIR16 = 16 unit vectors 22.5 deg apart (cos[16], sin[16]) in LDS.
 template <int LPE>
-__device__ __forceinline__ void slip_search(const float* P, float mu, int rounds, int s, int el, float* lam) {
-  const float* G = P;
-  const float* v = P + 9;
-  const float d0x = P[12], d0y = P[13];
-  float ln, mue, lox, loy, hix, hiy;
-  if (slip_eval(G, v, mu, d0x, d0y, ln, mue) > 0.f) { lox = d0x; loy = d0y; hix = -d0y; hiy = d0x; }
-  else { lox = d0y; loy = -d0x; hix = d0x; hiy = d0y; }
-  const int k = s < 15 ? s : 14;
-  const float t = (float)(k + 1) * (1.0f / 16.0f);
+__device__ __forceinline__ void slip_search(const float* G, const float* v, const float* ls, float mu, int rounds,
+                                            int s, int el, const float* DIR16, float* lam) {
+  const int k = s & 15;
+  // round 0: global energy minimum over 16 directions
+  const float e0 = slip_E(G, v, ls, mu, DIR16[k], DIR16[16 + k]);
+  const unsigned key = (__float_as_uint(e0) & ~15u) | (unsigned)k;
+  const int kbest = (int)(row_min_u32(key) & 15u);
+  float lox = DIR16[(kbest + 15) & 15], loy = DIR16[16 + ((kbest + 15) & 15)];
+  float hix = DIR16[(kbest + 1) & 15], hiy = DIR16[16 + ((kbest + 1) & 15)];
+  const float t = (float)((k < 15 ? k : 14) + 1) * (1.0f / 16.0f);
   for (int r = 0; r < rounds; ++r) {
-    float cx = lox + t * (hix - lox), cy = loy + t * (hiy - loy);
+    const float ex = hix - lox, ey = hiy - loy;
+    float cx = lox + t * ex, cy = loy + t * ey;
     const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy);
     cx *= inv; cy *= inv;
-    const float g = slip_eval(G, v, mu, cx, cy, ln, mue);
-    const unsigned long long bal = __ballot(g <= 0.f && s < 15);
-    const unsigned int gm = (LPE == 64) ? (unsigned int)(bal & 0x7fffull) : (unsigned int)((bal >> (el * LPE)) & 0x7fffull);
+    const float h = slip_dE(G, v, mu, cx, cy);
+    const unsigned long long bal = __ballot(h >= 0.f && k < 15);
+    // every 16-lane row of the group holds the same candidates; use the group's first row
+    const unsigned gm = (unsigned)((bal >> (el * LPE)) & 0x7fffull);
     const int kstar = gm ? (__ffs((int)gm) - 1) : 15;
-    const int base = el * LPE;
-    const float nlx = __shfl(cx, base + (kstar > 0 ? kstar - 1 : 0)), nly = __shfl(cy, base + (kstar > 0 ? kstar - 1 : 0));
-    const float nhx = __shfl(cx, base + (kstar < 15 ? kstar : 14)), nhy = __shfl(cy, base + (kstar < 15 ? kstar : 14));
-    if (kstar > 0) { lox = nlx; loy = nly; }
-    if (kstar < 15) { hix = nhx; hiy = nhy; }
+    if (kstar < 15) {
+      const float th = (float)(kstar + 1) * (1.0f / 16.0f);
+      float x = lox + th * ex, y = loy + th * ey;
+      const float iv = __builtin_amdgcn_rsqf(x * x + y * y);
+      hix = x * iv; hiy = y * iv;
+    }
+    if (kstar > 0) {
+      const float tl = (float)kstar * (1.0f / 16.0f);
+      float x = lox + tl * ex, y = loy + tl * ey;
+      const float iv = __builtin_amdgcn_rsqf(x * x + y * y);
+      lox = x * iv; loy = y * iv;
+    }
   }
   float x = lox + hix, y = loy + hiy;
   const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
   x *= inv; y *= inv;
-  slip_eval(G, v, mu, x, y, ln, mue);
-  lam[0] = mue * ln * x; lam[1] = mue * ln * y; lam[2] = ln;
+  float den = G[8] + mu * (G[6] * x + G[7] * y);
+  den = fmaxf(den, kDenMin * G[8]);
+  const float ln = -v[2] * __builtin_amdgcn_rcpf(den);
+  lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
 }
 
 __device__ __forceinline__ void inv3(const float* A, float* B) {
@@ -219,8 +272,42 @@ __device__ __forceinline__ void inv3(const float* A, float* B) {
 // gv index (lin, ang) -> spatial index (ang, lin)
 __device__ __host__ constexpr int gv2sp(int a) { return a < 3 ? a + 3 : a - 3; }
 
+#define RSB_STAMP(i) \
+  if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[i] = clock64();
+
+// rigid inertia (10 parameters about O) + bias force of a body given (R, r, V, A) and its constants MF
+// (DevModel::bodyf layout); Zout = dt * f
+__device__ __forceinline__ void body_inertia(const float* Rb, const float* rb, const float* Vb, const float* Ab,
+                                             const float* MF, float dt, float* I10, float* Zout) {
+  const float mass = MF[7];
+  float c[3], t[3], T[9], Iw[6];
+  mat3_vec(Rb, MF + 17, t);
+  c[0] = rb[0] + t[0]; c[1] = rb[1] + t[1]; c[2] = rb[2] + t[2];
+  const float Il[9] = {MF[20], MF[21], MF[22], MF[21], MF[23], MF[24], MF[22], MF[24], MF[25]};
+  mat3_mul(Rb, Il, T);
+  Iw[0] = T[0] * Rb[0] + T[1] * Rb[1] + T[2] * Rb[2];
+  Iw[1] = T[0] * Rb[3] + T[1] * Rb[4] + T[2] * Rb[5];
+  Iw[2] = T[0] * Rb[6] + T[1] * Rb[7] + T[2] * Rb[8];
+  Iw[3] = T[3] * Rb[3] + T[4] * Rb[4] + T[5] * Rb[5];
+  Iw[4] = T[3] * Rb[6] + T[4] * Rb[7] + T[5] * Rb[8];
+  Iw[5] = T[6] * Rb[6] + T[7] * Rb[7] + T[8] * Rb[8];
+  const float cc = dot3(c, c);
+  I10[0] = Iw[0] + mass * (cc - c[0] * c[0]); I10[1] = Iw[1] - mass * c[0] * c[1]; I10[2] = Iw[2] - mass * c[0] * c[2];
+  I10[3] = Iw[3] + mass * (cc - c[1] * c[1]); I10[4] = Iw[4] - mass * c[1] * c[2];
+  I10[5] = Iw[5] + mass * (cc - c[2] * c[2]);
+  I10[6] = mass * c[0]; I10[7] = mass * c[1]; I10[8] = mass * c[2]; I10[9] = mass;
+  float IV[6], IAc[6], n1[3], n2[3], n3[3];
+  rigid_mul(I10, I10 + 6, mass, Vb, IV);
+  rigid_mul(I10, I10 + 6, mass, Ab, IAc);
+  // f = I A + V x* (I V) ;  [w;v] x* [n;f] = [w x n + v x f ; w x f]
+  cross3(Vb, IV, n1); cross3(Vb + 3, IV + 3, n2); cross3(Vb, IV + 3, n3);
+  RSB_UNROLL for (int i = 0; i < 3; ++i) { Zout[i] = dt * (IAc[i] + n1[i] + n2[i]); Zout[3 + i] = dt * (IAc[3 + i] + n3[i]); }
+}
+
 // ------------------------------------------------------------------------------- the kernel
-template <int LPE, int KMAX>
+// LPE : lanes per env.  KMAX : contact capacity.  CL : chain-length capacity (>= model's longest chain).
+// ML : body-level capacity (>= depth-1).
+template <int LPE, int KMAX, int CL, int ML>
 __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int EPW = 64 / LPE;
@@ -233,241 +320,180 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
 
   const DevModel& m = *a.model;
   const int nb = m.nb, nq = m.nq, nv = m.nv, depth = m.depth, ncol = m.ncol, cw = m.cw;
+  const int nch = m.nch, nclv = m.nclv, max_cc = m.max_cc;
   const LdsLayout& L = a.L;
 
-  int* PARLV = reinterpret_cast<int*>(lds);          // [nb] parent | level << 8  (parent+1 stored)
-  int* ANC = PARLV + ((nb + 3) & ~3);                // [nb*depth]
-  float* E = lds + L.shared_ints + el * L.per_env;
+  float* MODELF = lds + L.t_model;
+  float* GAIN = lds + L.t_gain;                                  // [nb][2] kp, kd of the body's joint
+  int* PARLV = reinterpret_cast<int*>(lds + L.t_parlv);          // [nb] (parent+1) | level << 8
+  int* ANC = reinterpret_cast<int*>(lds + L.t_anc);              // [nb*depth]
+  float* DIR16 = lds + L.t_dir;                                  // cos[16], sin[16]
+  float* E = lds + L.shared_total + el * L.per_env;
   float* Q = E + L.q;
   float* U = E + L.u;
-  float* TB = E + L.tb;
+  float* PT = E + L.pt;
+  float* DTG = E + L.dtg;
+  float* TF = E + L.tf;
   float* BODY = E + L.body;
   float* UPS = E + L.ups;
   float* FACT = E + L.fact;
-  float* CHOL = E + L.chol;
   float* WB = E + L.wb;
   float* CON = E + L.con;
   float* WC = E + L.wc;
   float* CV = E + L.cv;
   float* G = E + L.g;
-  float* LAM = E + L.lam;
-  float* WV = E + L.wv;
-  float* SLIP = E + L.slip;
+  float* GINV = E + L.ginv;
   const int GS = L.gstride;
 
-  for (int i = lane; i < nb; i += 64) PARLV[i] = (m.parent[i] + 1) | (m.level[i] << 8);
-  for (int i = lane; i < nb * depth; i += 64) ANC[i] = m.anc[i];
-
-  // ---- per-lane body constants (lane s = body s)
-  const bool hasb = s < nb;
-  const int b = hasb ? s : 0;
-  const int par = m.parent[b];
-  const int lvl = hasb ? m.level[b] : -1;
-  const int jt = m.jtype[b];
-  const int nchild = hasb ? m.nchild[b] : 0;
-  const int cstart = m.child_start[b];
-  float axis[3], ptree[3], rtree[9], coml[3], inl[6];
-  RSB_UNROLL for (int i = 0; i < 3; ++i) { axis[i] = m.axis[b][i]; ptree[i] = m.ptree[b][i]; coml[i] = m.com[b][i]; }
-  RSB_UNROLL for (int i = 0; i < 9; ++i) rtree[i] = m.rtree[b][i];
-  RSB_UNROLL for (int i = 0; i < 6; ++i) inl[i] = m.inertia[b][i];
-  const float mass = m.mass[b], arm = m.armature[b], damp = m.damping[b], eff = m.effort[b];
-
-  // ---- state rows: HBM -> LDS (row-major [N, dim]: consecutive lanes read consecutive floats)
-  for (int i = s; i < nq; i += LPE) Q[i] = a.gc[(size_t)env * nq + i];
-  for (int i = s; i < nv; i += LPE) U[i] = a.gv[(size_t)env * nv + i];
-  float kp = 0.f, kd = 0.f, ptg = 0.f, dtg = 0.f, tff = 0.f;
-  if (hasb && b >= 1) {
-    const int d = b + 5;
-    if (a.control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE) {
-      kp = a.kp[d]; kd = a.kd[d];
-      ptg = a.ptarget[(size_t)env * nq + b + 6];
-      dtg = a.dtarget[(size_t)env * nv + d];
-    }
-    tff = a.tauff[(size_t)env * nv + d];
+  // ---- per-block tables -> LDS
+  for (int i = lane; i < nb * kModelSlot; i += 64) MODELF[i] = (&m.bodyf[0][0])[i];
+  for (int i = lane; i < nb; i += 64) {
+    PARLV[i] = (m.parent[i] + 1) | (m.level[i] << 8);
+    const bool pd = a.control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && i >= 1;
+    GAIN[2 * i] = pd ? a.kp[i + 5] : 0.f;
+    GAIN[2 * i + 1] = pd ? a.kd[i + 5] : 0.f;
   }
-  if (s < 6) TB[s] = a.tauff[(size_t)env * nv + s];
+  for (int i = lane; i < nb * depth; i += 64) ANC[i] = m.anc[i];
+  if (lane < 16) {
+    float sn, cs;
+    sincospif((float)lane * 0.125f, &sn, &cs);
+    DIR16[lane] = cs; DIR16[16 + lane] = sn;
+  }
+
+  // ---- per-lane chain description (lane s = chain s)
+  const bool hasch = s < nch;
+  const int chi = hasch ? s : 0;
+  const int ch_len = hasch ? m.ch_len[chi] : 0;
+  const int ch_attach = m.ch_attach[chi];
+  const int ch_lev = hasch ? m.ch_level[chi] : -1;
+  const int lev0 = m.level[ch_attach] + 1;  // body level of the chain's first body
+  int chb[CL];
+  RSB_UNROLL for (int k = 0; k < CL; ++k) chb[k] = m.ch_body[chi * kMaxCL + k];
+
+  // ---- state rows: HBM -> LDS
+  for (int i = s; i < nq; i += LPE) { Q[i] = a.gc[(size_t)env * nq + i]; PT[i] = a.ptarget[(size_t)env * nq + i]; }
+  for (int i = s; i < nv; i += LPE) {
+    U[i] = a.gv[(size_t)env * nv + i];
+    DTG[i] = a.dtarget[(size_t)env * nv + i];
+    TF[i] = a.tauff[(size_t)env * nv + i];
+  }
   int flag = 0, iters_used = 0, nc = 0;
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
+  float lam_all[3 * KMAX];
+  RSB_UNROLL for (int i = 0; i < 3 * KMAX; ++i) lam_all[i] = 0.f;
   __syncthreads();
 
   for (int sub = 0; sub < a.nsub; ++sub) {
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[0] = clock64();
-    // =========================== down pass: R r S V A (level-synchronous, lane = body) ========
-    float R[9], r[3], S[6], V[6], A[6], E9[9];
-    float qb = 0.f, qd = 0.f;
-    RSB_UNROLL for (int i = 0; i < 6; ++i) { S[i] = 0.f; V[i] = 0.f; A[i] = 0.f; }
-    RSB_UNROLL for (int i = 0; i < 9; ++i) { R[i] = 0.f; E9[i] = 0.f; }
-    r[0] = r[1] = r[2] = 0.f;
-    if (hasb) {
-      if (b == 0) {
-        float w = Q[3], x = Q[4], y = Q[5], z = Q[6];
-        float in = 1.0f / sqrtf(w * w + x * x + y * y + z * z);
-        w *= in; x *= in; y *= in; z *= in;
-        R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z);     R[2] = 2 * (x * z + w * y);
-        R[3] = 2 * (x * y + w * z);     R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
-        R[6] = 2 * (x * z - w * y);     R[7] = 2 * (y * z + w * x);     R[8] = 1 - 2 * (x * x + y * y);
-        V[0] = U[3]; V[1] = U[4]; V[2] = U[5]; V[3] = U[0]; V[4] = U[1]; V[5] = U[2];
-        float wxv[3];
-        cross3(V, V + 3, wxv);
-        A[3] = -wxv[0] - a.gx; A[4] = -wxv[1] - a.gy; A[5] = -wxv[2] - a.gz;
-      } else {
-        qb = Q[b + 6]; qd = U[b + 5];
-        if (jt == RSB_JOINT_REVOLUTE) {
-          float sn, cs;
-          sincosf(qb, &sn, &cs);
-          const float v = 1.f - cs;
-          float Rq[9];
-          Rq[0] = cs + axis[0] * axis[0] * v;           Rq[1] = axis[0] * axis[1] * v - axis[2] * sn; Rq[2] = axis[0] * axis[2] * v + axis[1] * sn;
-          Rq[3] = axis[1] * axis[0] * v + axis[2] * sn; Rq[4] = cs + axis[1] * axis[1] * v;           Rq[5] = axis[1] * axis[2] * v - axis[0] * sn;
-          Rq[6] = axis[2] * axis[0] * v - axis[1] * sn; Rq[7] = axis[2] * axis[1] * v + axis[0] * sn; Rq[8] = cs + axis[2] * axis[2] * v;
-          mat3_mul(rtree, Rq, E9);
-        } else {
-          RSB_UNROLL for (int i = 0; i < 9; ++i) E9[i] = rtree[i];
-        }
-      }
-    }
-    for (int l = 0; l < depth; ++l) {
-      if (lvl == l) {
-        if (l > 0) {
-          float P[24];
-          ldv<6>(BODY + par * kBodySlot, P);
-          const float* Rp = P; const float* rp = P + 9; const float* Vp = P + 12; const float* Ap = P + 18;
-          float t[3], a3[3];
-          mat3_mul(Rp, E9, R);
-          mat3_vec(Rp, ptree, t);
-          r[0] = rp[0] + t[0]; r[1] = rp[1] + t[1]; r[2] = rp[2] + t[2];
-          mat3_vec(R, axis, a3);
-          if (jt == RSB_JOINT_REVOLUTE) {
-            S[0] = a3[0]; S[1] = a3[1]; S[2] = a3[2];
-            cross3(r, a3, S + 3);
-          } else {
-            r[0] += a3[0] * qb; r[1] += a3[1] * qb; r[2] += a3[2] * qb;
-            S[0] = S[1] = S[2] = 0.f; S[3] = a3[0]; S[4] = a3[1]; S[5] = a3[2];
-          }
-          // V = Vp + S qd ;  A = Ap + (Vp x S) qd
-          float c1[3], c2[3], c3[3];
-          cross3(Vp, S, c1); cross3(Vp, S + 3, c2); cross3(Vp + 3, S, c3);
-          RSB_UNROLL for (int i = 0; i < 3; ++i) {
-            V[i] = Vp[i] + S[i] * qd; V[3 + i] = Vp[3 + i] + S[3 + i] * qd;
-            A[i] = Ap[i] + c1[i] * qd; A[3 + i] = Ap[3 + i] + (c2[i] + c3[i]) * qd;
-          }
-        }
-        float P[24];
-        RSB_UNROLL for (int i = 0; i < 9; ++i) P[i] = R[i];
-        RSB_UNROLL for (int i = 0; i < 3; ++i) P[9 + i] = r[i];
-        RSB_UNROLL for (int i = 0; i < 6; ++i) { P[12 + i] = V[i]; P[18 + i] = A[i]; }
-        stv<6>(BODY + b * kBodySlot, P);
-      }
-      __syncthreads();
-    }
-
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[1] = clock64();
-    // =========================== per body: rigid inertia about O, bias force ===================
-    float IA[21], Z[6];
+    RSB_STAMP(0)
+    // =========================== base body, redundantly on every lane =========================
+    float R0[9], V0[6], A0[6], I10b[10], Zb[6];
     {
-      float c[3], t[3], T[9], Iw[6];
-      mat3_vec(R, coml, t);
-      c[0] = r[0] + t[0]; c[1] = r[1] + t[1]; c[2] = r[2] + t[2];
-      // Iw = R Il R^T (symmetric)
-      const float Il[9] = {inl[0], inl[1], inl[2], inl[1], inl[3], inl[4], inl[2], inl[4], inl[5]};
-      mat3_mul(R, Il, T);
-      Iw[0] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
-      Iw[1] = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
-      Iw[2] = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
-      Iw[3] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
-      Iw[4] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
-      Iw[5] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
-      const float cc = dot3(c, c);
-      float A6[6], mc[3] = {mass * c[0], mass * c[1], mass * c[2]};
-      A6[0] = Iw[0] + mass * (cc - c[0] * c[0]); A6[1] = Iw[1] - mass * c[0] * c[1]; A6[2] = Iw[2] - mass * c[0] * c[2];
-      A6[3] = Iw[3] + mass * (cc - c[1] * c[1]); A6[4] = Iw[4] - mass * c[1] * c[2];
-      A6[5] = Iw[5] + mass * (cc - c[2] * c[2]);
-      float IV[6], IAc[6], n1[3], n2[3], n3[3];
-      rigid_mul(A6, mc, mass, V, IV);
-      rigid_mul(A6, mc, mass, A, IAc);
-      // f = I A + V x* (I V) ;  [w;v] x* [n;f] = [w x n + v x f ; w x f]
-      cross3(V, IV, n1); cross3(V + 3, IV + 3, n2); cross3(V, IV + 3, n3);
-      RSB_UNROLL for (int i = 0; i < 3; ++i) { Z[i] = dt * (IAc[i] + n1[i] + n2[i]); Z[3 + i] = dt * (IAc[3 + i] + n3[i]); }
-      // expand the rigid inertia to a packed symmetric 6x6 (spatial order [ang; lin])
-      IA[sym6(0, 0)] = A6[0]; IA[sym6(1, 0)] = A6[1]; IA[sym6(1, 1)] = A6[3];
-      IA[sym6(2, 0)] = A6[2]; IA[sym6(2, 1)] = A6[4]; IA[sym6(2, 2)] = A6[5];
-      IA[sym6(3, 0)] = 0.f;    IA[sym6(3, 1)] = mc[2];  IA[sym6(3, 2)] = -mc[1]; IA[sym6(3, 3)] = mass;
-      IA[sym6(4, 0)] = -mc[2]; IA[sym6(4, 1)] = 0.f;    IA[sym6(4, 2)] = mc[0];  IA[sym6(4, 3)] = 0.f; IA[sym6(4, 4)] = mass;
-      IA[sym6(5, 0)] = mc[1];  IA[sym6(5, 1)] = -mc[0]; IA[sym6(5, 2)] = 0.f;    IA[sym6(5, 3)] = 0.f; IA[sym6(5, 4)] = 0.f; IA[sym6(5, 5)] = mass;
+      float qv[8], uv[8];
+      ldv<2>(Q, qv); ldv<2>(U, uv);
+      float w = qv[3], x = qv[4], y = qv[5], z = qv[6];
+      const float in = 1.0f / sqrtf(w * w + x * x + y * y + z * z);
+      w *= in; x *= in; y *= in; z *= in;
+      R0[0] = 1 - 2 * (y * y + z * z); R0[1] = 2 * (x * y - w * z);     R0[2] = 2 * (x * z + w * y);
+      R0[3] = 2 * (x * y + w * z);     R0[4] = 1 - 2 * (x * x + z * z); R0[5] = 2 * (y * z - w * x);
+      R0[6] = 2 * (x * z - w * y);     R0[7] = 2 * (y * z + w * x);     R0[8] = 1 - 2 * (x * x + y * y);
+      V0[0] = uv[3]; V0[1] = uv[4]; V0[2] = uv[5]; V0[3] = uv[0]; V0[4] = uv[1]; V0[5] = uv[2];
+      float wxv[3];
+      cross3(V0, V0 + 3, wxv);
+      A0[0] = A0[1] = A0[2] = 0.f;
+      A0[3] = -wxv[0] - a.gx; A0[4] = -wxv[1] - a.gy; A0[5] = -wxv[2] - a.gz;
+      pbx = qv[0]; pby = qv[1]; pbz = qv[2];
+      float MF[kModelSlot];
+      ldv<8>(MODELF, MF);
+      const float r0[3] = {0.f, 0.f, 0.f};
+      body_inertia(R0, r0, V0, A0, MF, dt, I10b, Zb);
+      if (s == 0) {
+        float P[24];
+        RSB_UNROLL for (int i = 0; i < 9; ++i) P[i] = R0[i];
+        P[9] = P[10] = P[11] = 0.f;
+        RSB_UNROLL for (int i = 0; i < 6; ++i) { P[12 + i] = V0[i]; P[18 + i] = A0[i]; }
+        stv<6>(BODY, P);
+      }
     }
 
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[2] = clock64();
-    // =========================== up pass: articulated inertias + b column (lane = body) =========
-    float UD[6], rsD = 0.f;
-    RSB_UNROLL for (int i = 0; i < 6; ++i) UD[i] = 0.f;
-    for (int l = depth - 1; l >= 0; --l) {
-      if (lvl == l) {
-        const int mcl = m.maxchild_level[l];
-        for (int ci = 0; ci < mcl; ++ci) {
-          if (ci < nchild) {
-            const int c = m.child_list[cstart + ci];
-            float P[28];
-            ldv<7>(UPS + c * kUpSlot, P);
-            RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
-            RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
-          }
-        }
-        if (l >= 1) {
-          float Uv[6];
-          sym6_vec(IA, S, Uv);
-          const float D = dot6(S, Uv) + arm;
-          const float invD = 1.0f / D;
-          rsD = sqrtf(invD);
-          float tau = tff;
-          if (a.control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE) tau += kp * (ptg - qb) + kd * (dtg - qd);
-          if (eff > 0.f) tau = fminf(fmaxf(tau, -eff), eff);
-          tau -= damp * qd;
-          const float yhat = dt * tau - dot6(S, Z);
-          const float yd = yhat * invD;
-          float P[28];
-          RSB_UNROLL for (int i = 0; i < 6; ++i) {
-            UD[i] = Uv[i] * invD;
-            RSB_UNROLL for (int j = 0; j <= i; ++j) P[sym6(i, j)] = IA[sym6(i, j)] - Uv[i] * UD[j];
-            P[21 + i] = Z[i] + Uv[i] * yd;
-          }
-          P[27] = 0.f;
-          stv<7>(UPS + b * kUpSlot, P);
-          float Fk[16];
-          RSB_UNROLL for (int i = 0; i < 6; ++i) { Fk[i] = S[i]; Fk[6 + i] = UD[i]; }
-          Fk[12] = rsD; Fk[13] = invD; Fk[14] = 0.f; Fk[15] = 0.f;
-          stv<4>(FACT + b * kFactSlot, Fk);
-          WB[b + 5] = yhat * rsD;
+    // =========================== down pass: lane = chain, serial walk in registers ==============
+    float cS[CL][6], cI10[CL][10], cZ[CL][6], cdtau[CL], carm[CL], cqb[CL], cqd[CL];
+    for (int clv = 1; clv <= nclv; ++clv) {
+      if (ch_lev == clv) {
+        float Rp[9], rp[3], Vp[6], Ap[6];
+        if (ch_attach == 0) {
+          RSB_UNROLL for (int i = 0; i < 9; ++i) Rp[i] = R0[i];
+          rp[0] = rp[1] = rp[2] = 0.f;
+          RSB_UNROLL for (int i = 0; i < 6; ++i) { Vp[i] = V0[i]; Ap[i] = A0[i]; }
         } else {
-          // base: Cholesky of the 6x6 articulated inertia in gv order (lin, ang); W_b base part
-          float C[21], idg[6], y[6];
-          RSB_UNROLL for (int i = 0; i < 6; ++i) {
-            RSB_UNROLL for (int j = 0; j <= i; ++j) {
-              float sacc = IA[sym6(gv2sp(i), gv2sp(j))];
-              RSB_UNROLL for (int k = 0; k < j; ++k) sacc -= C[sym6(i, k)] * C[sym6(j, k)];
-              if (i == j) { const float dgl = sqrtf(sacc); C[sym6(i, i)] = dgl; idg[i] = 1.0f / dgl; }
-              else C[sym6(i, j)] = sacc * idg[j];
+          float P[24];
+          ldv<6>(BODY + ch_attach * kBodySlot, P);
+          RSB_UNROLL for (int i = 0; i < 9; ++i) Rp[i] = P[i];
+          RSB_UNROLL for (int i = 0; i < 3; ++i) rp[i] = P[9 + i];
+          RSB_UNROLL for (int i = 0; i < 6; ++i) { Vp[i] = P[12 + i]; Ap[i] = P[18 + i]; }
+        }
+        RSB_UNROLL for (int k = 0; k < CL; ++k) {
+          if (k < ch_len) {
+            const int b = chb[k];
+            float MF[kModelSlot];
+            ldv<8>(MODELF + b * kModelSlot, MF);
+            const float qb = Q[b + 6], qd = U[b + 5];
+            const float* axis = MF;
+            const int jt = __float_as_int(MF[3]);
+            float E9[9], R[9], r[3], t[3], a3[3], S[6];
+            if (jt == RSB_JOINT_REVOLUTE) {
+              float sn, cs;
+              sincosf(qb, &sn, &cs);
+              const float v = 1.f - cs;
+              float Rq[9];
+              Rq[0] = cs + axis[0] * axis[0] * v;           Rq[1] = axis[0] * axis[1] * v - axis[2] * sn; Rq[2] = axis[0] * axis[2] * v + axis[1] * sn;
+              Rq[3] = axis[1] * axis[0] * v + axis[2] * sn; Rq[4] = cs + axis[1] * axis[1] * v;           Rq[5] = axis[1] * axis[2] * v - axis[0] * sn;
+              Rq[6] = axis[2] * axis[0] * v - axis[1] * sn; Rq[7] = axis[2] * axis[1] * v + axis[0] * sn; Rq[8] = cs + axis[2] * axis[2] * v;
+              mat3_mul(MF + 8, Rq, E9);
+            } else {
+              RSB_UNROLL for (int i = 0; i < 9; ++i) E9[i] = MF[8 + i];
             }
+            mat3_mul(Rp, E9, R);
+            mat3_vec(Rp, MF + 4, t);
+            r[0] = rp[0] + t[0]; r[1] = rp[1] + t[1]; r[2] = rp[2] + t[2];
+            mat3_vec(R, axis, a3);
+            if (jt == RSB_JOINT_REVOLUTE) {
+              S[0] = a3[0]; S[1] = a3[1]; S[2] = a3[2];
+              cross3(r, a3, S + 3);
+            } else {
+              r[0] += a3[0] * qb; r[1] += a3[1] * qb; r[2] += a3[2] * qb;
+              S[0] = S[1] = S[2] = 0.f; S[3] = a3[0]; S[4] = a3[1]; S[5] = a3[2];
+            }
+            // A = Ap + (Vp x S) qd uses the PARENT's V, so update A before V
+            float c1[3], c2[3], c3[3];
+            cross3(Vp, S, c1); cross3(Vp, S + 3, c2); cross3(Vp + 3, S, c3);
+            RSB_UNROLL for (int i = 0; i < 3; ++i) { Ap[i] += c1[i] * qd; Ap[3 + i] += (c2[i] + c3[i]) * qd; }
+            RSB_UNROLL for (int i = 0; i < 6; ++i) Vp[i] += S[i] * qd;
+            RSB_UNROLL for (int i = 0; i < 9; ++i) Rp[i] = R[i];
+            rp[0] = r[0]; rp[1] = r[1]; rp[2] = r[2];
+            float P[24];
+            RSB_UNROLL for (int i = 0; i < 9; ++i) P[i] = R[i];
+            RSB_UNROLL for (int i = 0; i < 3; ++i) P[9 + i] = r[i];
+            RSB_UNROLL for (int i = 0; i < 6; ++i) { P[12 + i] = Vp[i]; P[18 + i] = Ap[i]; }
+            stv<6>(BODY + b * kBodySlot, P);
+            body_inertia(R, r, Vp, Ap, MF, dt, cI10[k], cZ[k]);
+            RSB_UNROLL for (int i = 0; i < 6; ++i) cS[k][i] = S[i];
+            // actuation (oracle: orc_actuation)
+            float tau = TF[b + 5];
+            tau += GAIN[2 * b] * (PT[b + 6] - qb) + GAIN[2 * b + 1] * (DTG[b + 5] - qd);
+            const float eff = MF[28];
+            if (eff > 0.f) tau = fminf(fmaxf(tau, -eff), eff);
+            tau -= MF[27] * qd;
+            cdtau[k] = dt * tau; carm[k] = MF[26]; cqb[k] = qb; cqd[k] = qd;
           }
-          RSB_UNROLL for (int i = 0; i < 6; ++i) {
-            float sacc = dt * TB[i] - Z[gv2sp(i)];
-            RSB_UNROLL for (int k = 0; k < i; ++k) sacc -= C[sym6(i, k)] * y[k];
-            y[i] = sacc * idg[i];
-            WB[i] = y[i];
-          }
-          float P[28];
-          RSB_UNROLL for (int i = 0; i < 21; ++i) P[i] = C[i];
-          RSB_UNROLL for (int i = 0; i < 6; ++i) P[21 + i] = idg[i];
-          P[27] = 0.f;
-          stv<7>(CHOL, P);
         }
       }
       __syncthreads();
     }
+    if (nclv == 0) __syncthreads();
+    RSB_STAMP(1)
 
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[3] = clock64();
     // =========================== collision detection (lane = collision sphere) ================
-    pbx = Q[0]; pby = Q[1]; pbz = Q[2];
     nc = 0;
     for (int c0 = 0; c0 < ncol; c0 += LPE) {
       const int ci = c0 + s;
@@ -492,34 +518,114 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       const unsigned long long bal = __ballot(hit);
       const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
       const int slot = nc + __popcll(gm & ((1ull << s) - 1ull));
-      if (hit) {
-        if (slot < a.kmax) {
-          float P[16], t1[3], t2[3];
-          // contact frame: t1 = normalised projection of world x on the tangent plane, t2 = n x t1
-          const float dn = n[0];
-          t1[0] = 1.f - dn * n[0]; t1[1] = -dn * n[1]; t1[2] = -dn * n[2];
-          const float il = 1.0f / sqrtf(dot3(t1, t1));
-          t1[0] *= il; t1[1] *= il; t1[2] *= il;
-          cross3(n, t1, t2);
-          P[0] = cx[0]; P[1] = cx[1]; P[2] = cx[2]; P[3] = dep;
-          P[4] = t1[0]; P[5] = t1[1]; P[6] = t1[2]; P[7] = __int_as_float(cbody);
-          P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(ci);
-          P[12] = n[0]; P[13] = n[1]; P[14] = n[2]; P[15] = 0.f;
-          stv<4>(CON + slot * kConSlot, P);
-        }
+      if (hit && slot < a.kmax) {
+        float P[16], t1[3], t2[3];
+        // contact frame: t1 = normalised projection of world x on the tangent plane, t2 = n x t1
+        const float dn = n[0];
+        t1[0] = 1.f - dn * n[0]; t1[1] = -dn * n[1]; t1[2] = -dn * n[2];
+        const float il = 1.0f / sqrtf(dot3(t1, t1));
+        t1[0] *= il; t1[1] *= il; t1[2] *= il;
+        cross3(n, t1, t2);
+        P[0] = cx[0]; P[1] = cx[1]; P[2] = cx[2]; P[3] = dep;
+        P[4] = t1[0]; P[5] = t1[1]; P[6] = t1[2]; P[7] = __int_as_float(cbody);
+        P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(ci);
+        P[12] = n[0]; P[13] = n[1]; P[14] = n[2]; P[15] = 0.f;
+        stv<4>(CON + slot * kConSlot, P);
       }
       nc += __popcll(gm);
     }
     if (nc > a.kmax) { nc = a.kmax; flag |= 1; }
-    // wave-wide maximum contact count (loop bounds must be wave-uniform)
-    int ncw = nc;
+    int ncw = nc;  // wave-wide maximum contact count (loop bounds must be wave-uniform)
     if (EPW > 1) {
       RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) ncw = max(ncw, __shfl_xor(ncw, off));
     }
-    __syncthreads();
+    RSB_STAMP(2)
 
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[4] = clock64();
-    float lam[3] = {0.f, 0.f, 0.f};
+    // =========================== up pass: articulated inertias + b column (lane = chain) ========
+    float cUD[CL][6], crsD[CL];
+    for (int clv = nclv; clv >= 1; --clv) {
+      if (ch_lev == clv) {
+        float IAc[21], Zc[6];
+        RSB_UNROLL for (int i = 0; i < 21; ++i) IAc[i] = 0.f;
+        RSB_UNROLL for (int i = 0; i < 6; ++i) Zc[i] = 0.f;
+        RSB_UNROLL for (int kk = 0; kk < CL; ++kk) {
+          const int k = CL - 1 - kk;
+          if (k < ch_len) {
+            const int b = chb[k];
+            float IA[21], Z[6];
+            rigid_expand(cI10[k], IA);
+            RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += IAc[i];
+            RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = cZ[k][i] + Zc[i];
+            if (max_cc > 0) {  // chains hanging off this body (none for pure star topologies)
+              const int ccn = m.cc_count[b], ccs = m.cc_start[b];
+              for (int ci = 0; ci < ccn; ++ci) {
+                float P[28];
+                ldv<7>(UPS + m.cc_list[ccs + ci] * kUpSlot, P);
+                RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
+                RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
+              }
+            }
+            float Uv[6];
+            sym6_vec(IA, cS[k], Uv);
+            const float D = dot6(cS[k], Uv) + carm[k];
+            const float invD = 1.0f / D;
+            const float rsD = sqrtf(invD);
+            const float yhat = cdtau[k] - dot6(cS[k], Z);
+            const float yd = yhat * invD;
+            float Fk[16];
+            RSB_UNROLL for (int i = 0; i < 6; ++i) {
+              const float ud = Uv[i] * invD;
+              cUD[k][i] = ud;
+              Fk[i] = cS[k][i]; Fk[6 + i] = ud;
+              RSB_UNROLL for (int j = 0; j <= i; ++j) IAc[sym6(i, j)] = IA[sym6(i, j)] - Uv[i] * (Uv[j] * invD);
+              Zc[i] = Z[i] + Uv[i] * yd;
+            }
+            crsD[k] = rsD;
+            Fk[12] = rsD; Fk[13] = invD; Fk[14] = 0.f; Fk[15] = 0.f;
+            stv<4>(FACT + b * kFactSlot, Fk);
+            WB[b + 5] = yhat * rsD;
+          }
+        }
+        float P[28];
+        RSB_UNROLL for (int i = 0; i < 21; ++i) P[i] = IAc[i];
+        RSB_UNROLL for (int i = 0; i < 6; ++i) P[21 + i] = Zc[i];
+        P[27] = 0.f;
+        stv<7>(UPS + chi * kUpSlot, P);
+      }
+      __syncthreads();
+    }
+    if (nclv == 0) __syncthreads();
+    // base (every lane): gather the chains hanging off the base, Cholesky in gv order (lin, ang), W_b base part
+    float C[21], idg[6], wbb[6];
+    {
+      float IA[21], Z[6];
+      rigid_expand(I10b, IA);
+      RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = Zb[i];
+      const int ccn = m.cc_count[0], ccs = m.cc_start[0];
+      for (int ci = 0; ci < ccn; ++ci) {
+        float P[28];
+        ldv<7>(UPS + m.cc_list[ccs + ci] * kUpSlot, P);
+        RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
+        RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
+      }
+      RSB_UNROLL for (int i = 0; i < 6; ++i) {
+        RSB_UNROLL for (int j = 0; j <= i; ++j) {
+          float sacc = IA[sym6(gv2sp(i), gv2sp(j))];
+          RSB_UNROLL for (int k = 0; k < j; ++k) sacc -= C[sym6(i, k)] * C[sym6(j, k)];
+          if (i == j) { const float ri = 1.0f / sqrtf(sacc); C[sym6(i, i)] = sacc * ri; idg[i] = ri; }
+          else C[sym6(i, j)] = sacc * idg[j];
+        }
+      }
+      float tb[8];
+      ldv<2>(TF, tb);
+      RSB_UNROLL for (int i = 0; i < 6; ++i) {
+        float sacc = dt * tb[i] - Z[gv2sp(i)];
+        RSB_UNROLL for (int k = 0; k < i; ++k) sacc -= C[sym6(i, k)] * wbb[k];
+        wbb[i] = sacc * idg[i];
+      }
+    }
+    RSB_STAMP(3)
+
     iters_used = 0;
     if (ncw > 0) {
       // ========================= contact columns (lane = column): W_c = D^-1/2 L^-T J_c^T =======
@@ -531,34 +637,41 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           ldv<4>(CON + i * kConSlot, CN);
           const float* x = CN;
           const float* t = CN + 4 + 4 * rr;
-          int k = __float_as_int(CN[7]);
-          float Fres[6];
+          const int kb = __float_as_int(CN[7]);
+          const int lev = PARLV[kb] >> 8;
+          // prefetch the support chain's factors (independent loads), then propagate the unit impulse
+          float FK[ML][16], wbk[ML];
+          int node[ML];
+          RSB_UNROLL for (int l = 0; l < ML; ++l) {
+            node[l] = 0;
+            if (l < lev) node[l] = ANC[kb * depth + lev - l];
+          }
+          RSB_UNROLL for (int l = 0; l < ML; ++l) {
+            if (l < lev) { ldv<4>(FACT + node[l] * kFactSlot, FK[l]); wbk[l] = WB[node[l] + 5]; }
+          }
+          float Vb[8];
+          ld4(BODY + kb * kBodySlot + 12, Vb); Vb[4] = BODY[kb * kBodySlot + 16]; Vb[5] = BODY[kb * kBodySlot + 17];
+          float Fres[6], wxx[3];
           cross3(x, t, Fres);
           Fres[3] = t[0]; Fres[4] = t[1]; Fres[5] = t[2];
-          // J u = t . (v_body + w_body x x)
-          float Vb[6], wxx[3];
-          ld4(BODY + k * kBodySlot + 12, Vb); Vb[4] = BODY[k * kBodySlot + 16]; Vb[5] = BODY[k * kBodySlot + 17];
-          cross3(Vb, x, wxx);
+          cross3(Vb, x, wxx);  // J u = t . (v_body + w_body x x)
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
           float* Wc = WC + c * cw;
-          while (k >= 1) {
-            float Fk[16];
-            ldv<4>(FACT + k * kFactSlot, Fk);
-            const float yh = dot6(Fk, Fres);
-            const float wk = yh * Fk[12];
-            const int pl = PARLV[k];
-            Wc[5 + (pl >> 8)] = wk;
-            cv += wk * WB[k + 5];
-            RSB_UNROLL for (int j = 0; j < 6; ++j) Fres[j] -= Fk[6 + j] * yh;
-            k = (pl & 0xff) - 1;
+          RSB_UNROLL for (int l = 0; l < ML; ++l) {
+            if (l < lev) {
+              const float yh = dot6(FK[l], Fres);
+              const float wk = yh * FK[l][12];
+              Wc[5 + lev - l] = wk;
+              cv += wk * wbk[l];
+              RSB_UNROLL for (int j = 0; j < 6; ++j) Fres[j] -= FK[l][6 + j] * yh;
+            }
           }
-          float CH[28], z[6];
-          ldv<7>(CHOL, CH);
+          float z[6];
           RSB_UNROLL for (int j = 0; j < 6; ++j) {
             float sacc = Fres[gv2sp(j)];
-            RSB_UNROLL for (int q2 = 0; q2 < j; ++q2) sacc -= CH[sym6(j, q2)] * z[q2];
-            z[j] = sacc * CH[21 + j];
-            cv += z[j] * WB[j];
+            RSB_UNROLL for (int q2 = 0; q2 < j; ++q2) sacc -= C[sym6(j, q2)] * z[q2];
+            z[j] = sacc * idg[j];
+            cv += z[j] * wbb[j];
           }
           st4(Wc, z); Wc[4] = z[4]; Wc[5] = z[5];
           if (rr == 2) cv -= a.erp * CN[3] / dt;
@@ -566,9 +679,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         }
       }
       __syncthreads();
+      RSB_STAMP(4)
 
-      if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[5] = clock64();
-      // ========================= Delassus blocks G_ij = W_i W_j^T (lane = block pair) =============
+      // ========================= Delassus blocks G_ij = W_i W_j^T (lane = contact pair) ============
       const int npw = ncw * (ncw + 1) / 2;
       for (int p0 = 0; p0 < npw; p0 += LPE) {
         const int p = p0 + s;
@@ -598,77 +711,58 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               G[(3 * i + rr) * GS + 3 * j + cc] = acc[3 * rr + cc];
               G[(3 * j + cc) * GS + 3 * i + rr] = acc[3 * rr + cc];
             }
+          if (i == j) {
+            float gi[12];
+            inv3(acc, gi);
+            gi[9] = gi[10] = gi[11] = 0.f;
+            stv<3>(GINV + 12 * i, gi);
+          }
         }
       }
       __syncthreads();
+      RSB_STAMP(5)
 
-      if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[6] = clock64();
-      // ========================= per-contact Gauss-Seidel (lane = contact) ========================
+      // ========================= per-contact Gauss-Seidel, redundantly on every lane of the group ==
       {
-        float Grow[3][3 * KMAX], Gii[9], Ginv[9], v[3];
-        const bool isc = s < nc;
-        RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-          RSB_UNROLL for (int cc = 0; cc < 3 * KMAX; ++cc) Grow[rr][cc] = (isc && cc < 3 * nc) ? G[(3 * s + rr) * GS + cc] : 0.f;
-        RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) { Gii[q2] = 0.f; Ginv[q2] = 0.f; }
-        v[0] = v[1] = v[2] = 0.f;
-        if (isc) {
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-            RSB_UNROLL for (int cc = 0; cc < 3; ++cc) Gii[3 * rr + cc] = G[(3 * s + rr) * GS + 3 * s + cc];
-          inv3(Gii, Ginv);
-          v[0] = CV[3 * s]; v[1] = CV[3 * s + 1]; v[2] = CV[3 * s + 2];
-        }
+        float v_all[3 * KMAX];
+        RSB_UNROLL for (int i = 0; i < 3 * KMAX; ++i) { lam_all[i] = 0.f; v_all[i] = (i < 3 * nc) ? CV[i] : 0.f; }
         float alpha = a.alpha_init;
         bool done = (nc == 0);
-        float lamn_all[KMAX];  // every lane tracks all normal impulses of its env (for the relative test)
-        RSB_UNROLL for (int j = 0; j < KMAX; ++j) lamn_all[j] = 0.f;
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
           RSB_UNROLL for (int j = 0; j < KMAX; ++j) {
-            if (j < ncw) {
-              float dl[3] = {0.f, 0.f, 0.f}, ln[3] = {0.f, 0.f, 0.f};
-              const bool mine = (s == j) && isc && !done;
-              bool need = false;
-              if (mine) {
-                // open / stick cases on the contact's own lane (oracle: solve_one_contact)
-                float vex[3];
+            if (j < ncw) {                       // wave-uniform
+              if (j < nc && !done) {             // group-uniform
+                // rows 3j..3j+2 of G (= columns, G is symmetric) and the inverse of the own block
+                float Gr[3][3 * KMAX], Gi[12];
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                  vex[rr] = v[rr] - (Gii[3 * rr] * lam[0] + Gii[3 * rr + 1] * lam[1] + Gii[3 * rr + 2] * lam[2]);
+                  RSB_UNROLL for (int q4 = 0; q4 < (3 * KMAX) / 4; ++q4) ld4(G + (3 * j + rr) * GS + 4 * q4, &Gr[rr][4 * q4]);
+                ldv<3>(GINV + 12 * j, Gi);
+                float Gjj[9], vex[3], ln[3] = {0.f, 0.f, 0.f};
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+                  RSB_UNROLL for (int cc = 0; cc < 3; ++cc) Gjj[3 * rr + cc] = Gr[rr][3 * j + cc];
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+                  vex[rr] = v_all[3 * j + rr] - (Gjj[3 * rr] * lam_all[3 * j] + Gjj[3 * rr + 1] * lam_all[3 * j + 1] + Gjj[3 * rr + 2] * lam_all[3 * j + 2]);
                 if (!(vex[2] > 0.f)) {
                   float ls[3];
                   RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                    ls[rr] = -(Ginv[3 * rr] * vex[0] + Ginv[3 * rr + 1] * vex[1] + Ginv[3 * rr + 2] * vex[2]);
+                    ls[rr] = -(Gi[3 * rr] * vex[0] + Gi[3 * rr + 1] * vex[1] + Gi[3 * rr + 2] * vex[2]);
                   const float lt2 = ls[0] * ls[0] + ls[1] * ls[1];
                   if (ls[2] >= 0.f && lt2 <= a.mu * a.mu * ls[2] * ls[2]) { ln[0] = ls[0]; ln[1] = ls[1]; ln[2] = ls[2]; }
-                  else {
-                    need = true;
-                    float P[16];
-                    RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) P[q2] = Gii[q2];
-                    P[9] = vex[0]; P[10] = vex[1]; P[11] = vex[2];
-                    if (lt2 < 1e-30f) { P[12] = 1.f; P[13] = 0.f; }
-                    else { const float il = 1.0f / sqrtf(lt2); P[12] = ls[0] * il; P[13] = ls[1] * il; }
-                    P[14] = 0.f; P[15] = 0.f;
-                    stv<4>(SLIP, P);
-                  }
+                  else slip_search<LPE>(Gjj, vex, ls, a.mu, a.section_rounds, s, el, DIR16, ln);
                 }
+                float dl[3];
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+                  dl[rr] = alpha * (ln[rr] - lam_all[3 * j + rr]);
+                  lam_all[3 * j + rr] += dl[rr];
+                }
+                // v_i += G_ij dl for every contact i (G_ij[r][c] = Gr[c][3i + r]); entries beyond this env's
+                // 3*nc read stale LDS and are never used
+                RSB_UNROLL for (int q3 = 0; q3 < 3 * KMAX; ++q3)
+                  v_all[q3] += Gr[0][q3] * dl[0] + Gr[1][q3] * dl[1] + Gr[2][q3] * dl[2];
+                err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
+                scale = fmaxf(scale, lam_all[3 * j + 2]);
               }
-              if (__any(need)) {
-                // slip case: the whole env group searches the friction direction together
-                __syncthreads();
-                float P[16], lsl[3];
-                ldv<4>(SLIP, P);
-                slip_search<LPE>(P, a.mu, a.section_rounds, s, el, lsl);
-                if (need) { ln[0] = lsl[0]; ln[1] = lsl[1]; ln[2] = lsl[2]; }
-              }
-              if (mine) {
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { dl[rr] = alpha * (ln[rr] - lam[rr]); lam[rr] += dl[rr]; }
-              }
-              const int src = el * LPE + j;
-              dl[0] = __shfl(dl[0], src); dl[1] = __shfl(dl[1], src); dl[2] = __shfl(dl[2], src);
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                v[rr] += Grow[rr][3 * j] * dl[0] + Grow[rr][3 * j + 1] * dl[1] + Grow[rr][3 * j + 2] * dl[2];
-              err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
-              lamn_all[j] += dl[2];
-              scale = fmaxf(scale, lamn_all[j]);
             }
           }
           if (!done) {
@@ -679,87 +773,110 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           }
           if (!__any(!done)) break;
         }
-        if (isc) { LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2]; }
       }
-      __syncthreads();
       if (a.dbg && env == a.dbg_env && env_valid && s == 0) {
         const int n3 = 3 * nc;
         a.dbg[0] = (float)nc;
         for (int i = 0; i < n3; ++i)
           for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + j];
-        for (int i = 0; i < n3; ++i) { a.dbg[1 + n3 * n3 + i] = CV[i]; a.dbg[1 + n3 * n3 + n3 + i] = LAM[i]; }
+        for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
+        RSB_UNROLL for (int i = 0; i < 3 * KMAX; ++i) if (i < n3) a.dbg[1 + n3 * n3 + n3 + i] = lam_all[i];
       }
     }
+    RSB_STAMP(6)
 
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[7] = clock64();
-    // =========================== w = W_b + sum_c W_c lam_c  (base dofs on lanes 0..5, joints on body lanes)
-    float wj = 0.f;
-    if (hasb && b >= 1) {
-      wj = WB[b + 5];
-      for (int i = 0; i < nc; ++i) {
-        const int bi = __float_as_int(CON[i * kConSlot + 7]);
-        const int li = PARLV[bi] >> 8;
-        if (lvl <= li && ANC[bi * depth + lvl] == b) {
-          const float* Wc = WC + (3 * i) * cw + 5 + lvl;
-          wj += Wc[0] * LAM[3 * i] + Wc[cw] * LAM[3 * i + 1] + Wc[2 * cw] * LAM[3 * i + 2];
+    // =========================== du = L^-1 D^-1/2 (W_b + sum_c W_c lam_c), then integrate ========
+    // base part on every lane (C^T x = w by back substitution), chains walk root -> leaf in registers
+    float a0[6];
+    {
+      float wv[6];
+      RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] = wbb[i];
+      RSB_UNROLL for (int c = 0; c < 3 * KMAX; ++c) {
+        if (c < 3 * ncw) {
+          if (c < 3 * nc) {
+            float z[8];
+            ld4(WC + c * cw, z); z[4] = WC[c * cw + 4]; z[5] = WC[c * cw + 5];
+            RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] += z[i] * lam_all[c];
+          }
         }
       }
+      float x[6];
+      RSB_UNROLL for (int ii = 0; ii < 6; ++ii) {
+        const int i = 5 - ii;
+        float sacc = wv[i];
+        RSB_UNROLL for (int k = i + 1; k < 6; ++k) sacc -= C[sym6(k, i)] * x[k];
+        x[i] = sacc * idg[i];
+      }
+      a0[0] = x[3]; a0[1] = x[4]; a0[2] = x[5]; a0[3] = x[0]; a0[4] = x[1]; a0[5] = x[2];
+      if (s == 0) {
+        float qv[8], uv[8];
+        ldv<2>(Q, qv); ldv<2>(U, uv);
+        float un[6];
+        RSB_UNROLL for (int i = 0; i < 6; ++i) un[i] = uv[i] + x[i];
+        // q+ : position, quaternion (world-frame angular velocity), semi-implicit Euler
+        const float wn = sqrtf(un[3] * un[3] + un[4] * un[4] + un[5] * un[5]);
+        const float half = 0.5f * wn * dt;
+        float sh, chf;
+        sincosf(half, &sh, &chf);
+        const float sc = (wn > 1e-12f) ? sh / wn : 0.5f * dt;
+        const float d0 = chf, d1 = sc * un[3], d2 = sc * un[4], d3 = sc * un[5];
+        const float q0 = qv[3], q1 = qv[4], q2 = qv[5], q3 = qv[6];
+        float r0 = d0 * q0 - d1 * q1 - d2 * q2 - d3 * q3;
+        float r1 = d0 * q1 + d1 * q0 + d2 * q3 - d3 * q2;
+        float r2 = d0 * q2 - d1 * q3 + d2 * q0 + d3 * q1;
+        float r3 = d0 * q3 + d1 * q2 - d2 * q1 + d3 * q0;
+        const float in = 1.0f / sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+        // joint entries of Q / U are owned by the chain lanes: write only the base entries
+        Q[0] = qv[0] + dt * un[0]; Q[1] = qv[1] + dt * un[1]; Q[2] = qv[2] + dt * un[2];
+        Q[3] = r0 * in; Q[4] = r1 * in; Q[5] = r2 * in; Q[6] = r3 * in;
+        RSB_UNROLL for (int i = 0; i < 6; ++i) U[i] = un[i];
+      }
     }
-    if (s < 6) {
-      float wbase = WB[s];
-      for (int c = 0; c < 3 * nc; ++c) wbase += WC[c * cw + s] * LAM[c];
-      WV[s] = wbase;
-    }
-    __syncthreads();
-
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[8] = clock64();
-    // =========================== du = L^-1 D^-1/2 w : root -> leaf pass, then integrate ==========
-    for (int l = 0; l < depth; ++l) {
-      if (lvl == l) {
-        if (l == 0) {
-          float CH[28], x[6];
-          ldv<7>(CHOL, CH);
-          // C^T x = w  (back substitution)
-          RSB_UNROLL for (int i = 5; i >= 0; --i) {
-            float sacc = WV[i];
-            RSB_UNROLL for (int k = i + 1; k < 6; ++k) sacc -= CH[sym6(k, i)] * x[k];
-            x[i] = sacc * CH[21 + i];
-          }
-          float un[6];
-          RSB_UNROLL for (int i = 0; i < 6; ++i) { un[i] = U[i] + x[i]; U[i] = un[i]; }
-          // spatial delta-velocity of the base [ang; lin]
-          float* Ab = BODY + 18;
-          Ab[0] = x[3]; Ab[1] = x[4]; Ab[2] = x[5]; Ab[3] = x[0]; Ab[4] = x[1]; Ab[5] = x[2];
-          // q+ : position, quaternion (world-frame angular velocity), semi-implicit Euler
-          Q[0] += dt * un[0]; Q[1] += dt * un[1]; Q[2] += dt * un[2];
-          const float wn = sqrtf(un[3] * un[3] + un[4] * un[4] + un[5] * un[5]);
-          const float half = 0.5f * wn * dt;
-          float sh, ch;
-          sincosf(half, &sh, &ch);
-          const float sc = (wn > 1e-12f) ? sh / wn : 0.5f * dt;
-          const float d0 = ch, d1 = sc * un[3], d2 = sc * un[4], d3 = sc * un[5];
-          const float a0 = Q[3], a1 = Q[4], a2 = Q[5], a3 = Q[6];
-          float r0 = d0 * a0 - d1 * a1 - d2 * a2 - d3 * a3;
-          float r1 = d0 * a1 + d1 * a0 + d2 * a3 - d3 * a2;
-          float r2 = d0 * a2 - d1 * a3 + d2 * a0 + d3 * a1;
-          float r3 = d0 * a3 + d1 * a2 - d2 * a1 + d3 * a0;
-          const float in = 1.0f / sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
-          Q[3] = r0 * in; Q[4] = r1 * in; Q[5] = r2 * in; Q[6] = r3 * in;
+    for (int clv = 1; clv <= nclv; ++clv) {
+      if (ch_lev == clv) {
+        float ap[6];
+        if (ch_attach == 0) {
+          RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = a0[i];
         } else {
-          float ap[6];
-          const float* Ap = BODY + par * kBodySlot + 18;
-          RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = Ap[i];
-          const float xk = rsD * wj - dot6(UD, ap);
-          float* Ab = BODY + b * kBodySlot + 18;
-          RSB_UNROLL for (int i = 0; i < 6; ++i) Ab[i] = ap[i] + S[i] * xk;
-          const float un = qd + xk;
-          U[b + 5] = un;
-          Q[b + 6] = qb + dt * un;
+          float t6[8];
+          ld4(BODY + ch_attach * kBodySlot + 16, t6); ld4(BODY + ch_attach * kBodySlot + 20, t6 + 4);
+          RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = t6[2 + i];
+        }
+        RSB_UNROLL for (int k = 0; k < CL; ++k) {
+          if (k < ch_len) {
+            const int b = chb[k];
+            const int lv = lev0 + k;
+            float wj = WB[b + 5];
+            RSB_UNROLL for (int i = 0; i < KMAX; ++i) {
+              if (i < ncw) {
+                if (i < nc) {
+                  const int bi = __float_as_int(CON[i * kConSlot + 7]);
+                  if (ANC[bi * depth + min(lv, depth - 1)] == b) {
+                    const float* Wc = WC + (3 * i) * cw + 5 + lv;
+                    wj += Wc[0] * lam_all[3 * i] + Wc[cw] * lam_all[3 * i + 1] + Wc[2 * cw] * lam_all[3 * i + 2];
+                  }
+                }
+              }
+            }
+            const float xk = crsD[k] * wj - dot6(cUD[k], ap);
+            RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] += cS[k][i] * xk;
+            const float un = cqd[k] + xk;
+            U[b + 5] = un;
+            Q[b + 6] = cqb[k] + dt * un;
+            if (max_cc > 0) {
+              if (m.cc_count[b] > 0) {
+                float* Ab = BODY + b * kBodySlot + 18;
+                RSB_UNROLL for (int i = 0; i < 6; ++i) Ab[i] = ap[i];
+              }
+            }
+          }
         }
       }
       __syncthreads();
     }
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[9] = clock64(); a.prof[10] = iters_used; a.prof[11] = ncw; }
+    if (nclv == 0) __syncthreads();
+    RSB_STAMP(7)
+    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
   // ---- results: LDS -> HBM
@@ -773,7 +890,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     if (s < nc) {
       float CN[16];
       ldv<4>(CON + s * kConSlot, CN);
-      const float l0 = LAM[3 * s], l1 = LAM[3 * s + 1], l2 = LAM[3 * s + 2];
+      float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+      RSB_UNROLL for (int j = 0; j < KMAX; ++j)
+        if (s == j) { l0 = lam_all[3 * j]; l1 = lam_all[3 * j + 1]; l2 = lam_all[3 * j + 2]; }
       rsb_contact ct;
       ct.position[0] = pbx + CN[0];  // contact point at detection time (start of the last sub-step)
       ct.position[1] = pby + CN[1];

@@ -84,8 +84,8 @@ def timing(N=4096, lpe=16, steps=200, max_iter=150, reset=False):
     kms = np.array(kms)
     q1, _ = w.get_state()
     w.debug_phase_cycles(True, False); w.integrate(4); pc = w.debug_phase_cycles(True, True)
-    names = ["down", "perbody", "up", "collide", "columns", "delassus", "gs", "w", "final"]
-    print("   phase cycles (wg0, last substep): " + " ".join(f"{n}={pc[i+1]-pc[i]}" for i, n in enumerate(names)) + f" total={pc[9]-pc[0]} iters={pc[10]} ncw={pc[11]}")
+    names = ["base+down", "collide", "up+chol", "columns", "delassus", "gs", "final"]
+    print("   phase cycles (wg0, last substep): " + " ".join(f"{n}={pc[i+1]-pc[i]}" for i, n in enumerate(names)) + f" total={pc[7]-pc[0]} iters={pc[8]} ncw={pc[9]}")
     print(f"timing lpe={lpe} N={N} max_iter={max_iter} reset={reset}: kernel mean {kms.mean()*1e3:.1f} us p50 {np.median(kms)*1e3:.1f} us per control step (4 substeps) -> {N*4/kms.mean()/1e3:.1f} M env-steps/s; "
           f"iters max {w.get_solver_iterations().max()} mean {w.get_solver_iterations().mean():.2f}; resets {nreset}; zmean {q1[:,2].mean():.3f} contacts/env {w.get_contacts()[0].mean():.2f}")
     w.close()
