@@ -138,7 +138,7 @@ double rsb_model_total_mass(const rsb_model* m);
 int rsb_device_count(void);
 int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out);
 int rsb_destroy(rsb_world* w);
-int rsb_set_stream(rsb_world* w, void* hip_stream);   /* borrow caller's hipStream_t (NULL = own) */
+int rsb_set_stream(rsb_world* w, void* hip_stream);   /* borrow the caller's hipStream_t (NULL = HIP default stream) */
 void* rsb_get_stream(rsb_world* w);
 int rsb_synchronize(rsb_world* w);
 

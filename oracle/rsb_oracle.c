@@ -578,8 +578,17 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
                       const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
                       int32_t* flags, double* dbgG, double* dbgc, double* dbglam) {
   int nv = m->nv, nq = m->nq, kmax = p->kmax > MAXK ? MAXK : p->kmax;
-  kin_t* k = (kin_t*)malloc(sizeof(kin_t));
-  double* M = (double*)malloc(sizeof(double) * nv * nv);
+  /* per-thread scratch (no malloc in the stepping loop: this function is also the timed CPU baseline) */
+  static _Thread_local kin_t* tl_k = NULL;
+  static _Thread_local double* tl_M = NULL;
+  static _Thread_local double* tl_JX = NULL;
+  if (!tl_k) {
+    tl_k = (kin_t*)malloc(sizeof(kin_t));
+    tl_M = (double*)malloc(sizeof(double) * MAXV * MAXV);
+    tl_JX = (double*)malloc(sizeof(double) * (2 * MAXK * 3 * MAXV + 3 * MAXV));
+  }
+  kin_t* k = tl_k;
+  double* M = tl_M;
   double h[MAXV], tau[MAXV], ufree[MAXV];
   int pd[MAXV], fl = 0;
 
@@ -620,9 +629,9 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   int it_used = 0;
   double (*X)[3][MAXV] = NULL;
   if (nc > 0) {
-    double (*Jc)[3][MAXV] = (double (*)[3][MAXV])malloc(sizeof(double) * nc * 3 * MAXV);
-    X = (double (*)[3][MAXV])malloc(sizeof(double) * nc * 3 * MAXV);
-    double* Jw = (double*)malloc(sizeof(double) * 3 * nv);
+    double (*Jc)[3][MAXV] = (double (*)[3][MAXV])tl_JX;
+    X = (double (*)[3][MAXV])(tl_JX + MAXK * 3 * MAXV);
+    double* Jw = tl_JX + 2 * MAXK * 3 * MAXV;
     for (int i = 0; i < nc; ++i) {
       point_jacobian(m, k, cbody[i], cx[i], Jw);
       for (int r = 0; r < 3; ++r)
@@ -686,14 +695,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       if (err <= p->threshold * (scale + ORC_LAMBDA_FLOOR)) break;
     }
     if (dbglam) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) dbglam[3 * i + r] = lam[i][r];
-    free(Jc); free(Jw);
   }
 
   /* u+ = u_free + M^-1 J^T lam ;  q+ = q (+) dt u+   (semi-implicit Euler) */
   for (int i = 0; i < nc; ++i)
     for (int r = 0; r < 3; ++r)
       for (int d = 0; d < nv; ++d) ufree[d] += X[i][r][d] * lam[i][r];
-  if (X) free(X);
   for (int d = 0; d < nv; ++d) u[d] = ufree[d];
   for (int c = 0; c < 3; ++c) q[c] += p->dt * u[c];
   {
@@ -726,7 +733,6 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   if (n_contacts) *n_contacts = nc;
   if (iters) *iters = it_used;
   if (flags) *flags = fl;
-  free(M); free(k);
 }
 
 void orc_step(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,

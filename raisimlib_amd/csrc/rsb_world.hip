@@ -162,6 +162,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.gstride = 3 * kcap + 4;
   L.g = take(3 * kcap * L.gstride);
   L.ginv = take(12 * kcap);
+  L.lam = take(3 * kcap);
   L.per_env = o;
   return L;
 }
@@ -418,8 +419,8 @@ int rsb_set_stream(rsb_world* w, void* hip_stream) {
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipStreamSynchronize(w->stream));
   if (w->own_stream && w->stream) HIP_TRY(hipStreamDestroy(w->stream));
-  if (hip_stream) { w->stream = (hipStream_t)hip_stream; w->own_stream = false; }
-  else { HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking)); w->own_stream = true; }
+  w->stream = (hipStream_t)hip_stream;  // NULL is the (legacy) default stream, a valid stream to borrow
+  w->own_stream = false;
   return RSB_OK;
 }
 void* rsb_get_stream(rsb_world* w) { return w ? (void*)w->stream : nullptr; }

@@ -15,9 +15,9 @@
 //                   walks its chain serially in registers; LDS is touched once per chain LEVEL, not per body.
 //                   The floating base is computed redundantly by every lane (no exchange needed).
 //   collisions    : lane = collision sphere.      contact columns : lane = (contact, axis).
-//   Delassus      : lane = contact pair.          Gauss-Seidel    : every lane of the group runs the same
-//                   sweep redundantly from LDS-broadcast G rows (no cross-lane traffic inside the sweep);
-//                   the slip case's candidate directions are spread over the group's lanes.
+//   Delassus      : lane = contact pair.          Gauss-Seidel    : lane = contact (its G rows, velocity and
+//                   impulse live in registers); impulse changes are broadcast with DPP row_newbcast, the slip
+//                   case's candidate directions are spread over the 16 lanes of the row (ballot + DPP min).
 // All per-env intermediates live in LDS / registers; HBM is touched only for the state rows at launch
 // start / end ([N, dim] row-major rows: consecutive lanes read consecutive floats).
 //
@@ -36,6 +36,8 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "rsb.h"
 
@@ -74,7 +76,7 @@ struct LdsLayout {
   // per-block tables (floats from the start of LDS)
   int t_model, t_gain, t_parlv, t_anc, t_dir, shared_total;
   // per-env arrays (floats from the env base)
-  int q, u, pt, dtg, tf, body, ups, fact, wb, con, wc, cv, g, ginv;
+  int q, u, pt, dtg, tf, body, ups, fact, wb, con, wc, cv, g, ginv, lam;
   int gstride;
   int per_env;
 };
@@ -216,6 +218,21 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned x) {
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xf, 0xf, false));  // row_ror:1
   return x;
 }
+// compile-time loop (the index is needed as a template argument of row_bcast)
+template <int J, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (J < N) {
+    f(std::integral_constant<int, J>{});
+    static_for<J + 1, N>(f);
+  }
+}
+
+// lane J of every 16-lane row -> all lanes of that row (DPP row_newbcast: VALU speed, no LDS)
+template <int J>
+__device__ __forceinline__ float row_bcast(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + J, 0xf, 0xf, false));
+}
+
 // Cooperative slip solve: all lanes of the env group hold the same (G, v, ls); lane (s & 15) evaluates
 // candidate (s & 15) of every round.  DIR16 = 16 unit vectors 22.5 deg apart (cos[16], sin[16]) in LDS.
 template <int LPE>
@@ -343,6 +360,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   float* CV = E + L.cv;
   float* G = E + L.g;
   float* GINV = E + L.ginv;
+  float* LAM = E + L.lam;
   const int GS = L.gstride;
 
   // ---- per-block tables -> LDS
@@ -380,8 +398,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   int flag = 0, iters_used = 0, nc = 0;
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
-  float lam_all[3 * KMAX];
-  RSB_UNROLL for (int i = 0; i < 3 * KMAX; ++i) lam_all[i] = 0.f;
   __syncthreads();
 
   for (int sub = 0; sub < a.nsub; ++sub) {
@@ -722,49 +738,69 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
       RSB_STAMP(5)
 
-      // ========================= per-contact Gauss-Seidel, redundantly on every lane of the group ==
+      // ========================= per-contact Gauss-Seidel (lane = contact) ==========================
+      // Lane j (< nc) owns contact j: its G rows, own block, velocity and impulse stay in registers.  Per
+      // contact update the owner solves open/stick; the slip case is searched by the whole 16-lane row; the
+      // impulse change is broadcast with DPP row_newbcast and every lane updates its own contact velocity.
       {
-        float v_all[3 * KMAX];
-        RSB_UNROLL for (int i = 0; i < 3 * KMAX; ++i) { lam_all[i] = 0.f; v_all[i] = (i < 3 * nc) ? CV[i] : 0.f; }
+        const bool isc = s < nc;
+        float Grow[3][3 * KMAX], Gii[9], Ginv[12], v[3], lam[3] = {0.f, 0.f, 0.f};
+        RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+          RSB_UNROLL for (int q4 = 0; q4 < (3 * KMAX) / 4; ++q4) {
+            if (isc) ld4(G + (3 * s + rr) * GS + 4 * q4, &Grow[rr][4 * q4]);
+            else { Grow[rr][4 * q4] = Grow[rr][4 * q4 + 1] = Grow[rr][4 * q4 + 2] = Grow[rr][4 * q4 + 3] = 0.f; }
+          }
+        RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gii[q2] = 0.f;
+        RSB_UNROLL for (int q2 = 0; q2 < 12; ++q2) Ginv[q2] = 0.f;
+        v[0] = v[1] = v[2] = 0.f;
+        if (isc) {
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+            RSB_UNROLL for (int cc = 0; cc < 3; ++cc) Gii[3 * rr + cc] = G[(3 * s + rr) * GS + 3 * s + cc];
+          ldv<3>(GINV + 12 * s, Ginv);
+          v[0] = CV[3 * s]; v[1] = CV[3 * s + 1]; v[2] = CV[3 * s + 2];
+        }
+        float lamn_all[KMAX];  // every lane tracks all normal impulses of its env (for the relative test)
+        RSB_UNROLL for (int j = 0; j < KMAX; ++j) lamn_all[j] = 0.f;
         float alpha = a.alpha_init;
         bool done = (nc == 0);
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
-          RSB_UNROLL for (int j = 0; j < KMAX; ++j) {
-            if (j < ncw) {                       // wave-uniform
-              if (j < nc && !done) {             // group-uniform
-                // rows 3j..3j+2 of G (= columns, G is symmetric) and the inverse of the own block
-                float Gr[3][3 * KMAX], Gi[12];
+          static_for<0, KMAX>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < ncw) {  // wave-uniform
+              const bool mine = (s == j) && isc && !done;
+              bool need = false;
+              float ln[3] = {0.f, 0.f, 0.f}, vex[3] = {0.f, 0.f, 0.f}, ls[3] = {0.f, 0.f, 0.f};
+              if (mine) {
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                  RSB_UNROLL for (int q4 = 0; q4 < (3 * KMAX) / 4; ++q4) ld4(G + (3 * j + rr) * GS + 4 * q4, &Gr[rr][4 * q4]);
-                ldv<3>(GINV + 12 * j, Gi);
-                float Gjj[9], vex[3], ln[3] = {0.f, 0.f, 0.f};
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                  RSB_UNROLL for (int cc = 0; cc < 3; ++cc) Gjj[3 * rr + cc] = Gr[rr][3 * j + cc];
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                  vex[rr] = v_all[3 * j + rr] - (Gjj[3 * rr] * lam_all[3 * j] + Gjj[3 * rr + 1] * lam_all[3 * j + 1] + Gjj[3 * rr + 2] * lam_all[3 * j + 2]);
+                  vex[rr] = v[rr] - (Gii[3 * rr] * lam[0] + Gii[3 * rr + 1] * lam[1] + Gii[3 * rr + 2] * lam[2]);
                 if (!(vex[2] > 0.f)) {
-                  float ls[3];
                   RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                    ls[rr] = -(Gi[3 * rr] * vex[0] + Gi[3 * rr + 1] * vex[1] + Gi[3 * rr + 2] * vex[2]);
+                    ls[rr] = -(Ginv[3 * rr] * vex[0] + Ginv[3 * rr + 1] * vex[1] + Ginv[3 * rr + 2] * vex[2]);
                   const float lt2 = ls[0] * ls[0] + ls[1] * ls[1];
                   if (ls[2] >= 0.f && lt2 <= a.mu * a.mu * ls[2] * ls[2]) { ln[0] = ls[0]; ln[1] = ls[1]; ln[2] = ls[2]; }
-                  else slip_search<LPE>(Gjj, vex, ls, a.mu, a.section_rounds, s, el, DIR16, ln);
+                  else need = true;
                 }
-                float dl[3];
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
-                  dl[rr] = alpha * (ln[rr] - lam_all[3 * j + rr]);
-                  lam_all[3 * j + rr] += dl[rr];
-                }
-                // v_i += G_ij dl for every contact i (G_ij[r][c] = Gr[c][3i + r]); entries beyond this env's
-                // 3*nc read stale LDS and are never used
-                RSB_UNROLL for (int q3 = 0; q3 < 3 * KMAX; ++q3)
-                  v_all[q3] += Gr[0][q3] * dl[0] + Gr[1][q3] * dl[1] + Gr[2][q3] * dl[2];
-                err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
-                scale = fmaxf(scale, lam_all[3 * j + 2]);
               }
+              if (__any(need)) {
+                float Gb[9], vb[3], lb[3], lsl[3];
+                RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gb[q2] = row_bcast<j>(Gii[q2]);
+                RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) { vb[q2] = row_bcast<j>(vex[q2]); lb[q2] = row_bcast<j>(ls[q2]); }
+                slip_search<LPE>(Gb, vb, lb, a.mu, a.section_rounds, s, el, DIR16, lsl);
+                if (need) { ln[0] = lsl[0]; ln[1] = lsl[1]; ln[2] = lsl[2]; }
+              }
+              float dl[3] = {0.f, 0.f, 0.f};
+              if (mine) {
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { dl[rr] = alpha * (ln[rr] - lam[rr]); lam[rr] += dl[rr]; }
+              }
+              dl[0] = row_bcast<j>(dl[0]); dl[1] = row_bcast<j>(dl[1]); dl[2] = row_bcast<j>(dl[2]);
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+                v[rr] += Grow[rr][3 * j] * dl[0] + Grow[rr][3 * j + 1] * dl[1] + Grow[rr][3 * j + 2] * dl[2];
+              err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
+              lamn_all[j] += dl[2];
+              scale = fmaxf(scale, lamn_all[j]);
             }
-          }
+          });
           if (!done) {
             ++iters_used;
             alpha = fmaxf(alpha * a.alpha_decay, a.alpha_min);
@@ -773,14 +809,16 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           }
           if (!__any(!done)) break;
         }
+        if (isc) { LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2]; }
       }
+      __syncthreads();
       if (a.dbg && env == a.dbg_env && env_valid && s == 0) {
         const int n3 = 3 * nc;
         a.dbg[0] = (float)nc;
         for (int i = 0; i < n3; ++i)
           for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + j];
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
-        RSB_UNROLL for (int i = 0; i < 3 * KMAX; ++i) if (i < n3) a.dbg[1 + n3 * n3 + n3 + i] = lam_all[i];
+        for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + n3 + i] = LAM[i];
       }
     }
     RSB_STAMP(6)
@@ -791,14 +829,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     {
       float wv[6];
       RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] = wbb[i];
-      RSB_UNROLL for (int c = 0; c < 3 * KMAX; ++c) {
-        if (c < 3 * ncw) {
-          if (c < 3 * nc) {
-            float z[8];
-            ld4(WC + c * cw, z); z[4] = WC[c * cw + 4]; z[5] = WC[c * cw + 5];
-            RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] += z[i] * lam_all[c];
-          }
-        }
+      for (int c = 0; c < 3 * nc; ++c) {
+        float z[8];
+        ld4(WC + c * cw, z); z[4] = WC[c * cw + 4]; z[5] = WC[c * cw + 5];
+        const float lc = LAM[c];
+        RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] += z[i] * lc;
       }
       float x[6];
       RSB_UNROLL for (int ii = 0; ii < 6; ++ii) {
@@ -847,15 +882,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             const int b = chb[k];
             const int lv = lev0 + k;
             float wj = WB[b + 5];
-            RSB_UNROLL for (int i = 0; i < KMAX; ++i) {
-              if (i < ncw) {
-                if (i < nc) {
-                  const int bi = __float_as_int(CON[i * kConSlot + 7]);
-                  if (ANC[bi * depth + min(lv, depth - 1)] == b) {
-                    const float* Wc = WC + (3 * i) * cw + 5 + lv;
-                    wj += Wc[0] * lam_all[3 * i] + Wc[cw] * lam_all[3 * i + 1] + Wc[2 * cw] * lam_all[3 * i + 2];
-                  }
-                }
+            for (int i = 0; i < nc; ++i) {
+              const int bi = __float_as_int(CON[i * kConSlot + 7]);
+              if (ANC[bi * depth + lv] == b) {
+                const float* Wc = WC + (3 * i) * cw + 5 + lv;
+                wj += Wc[0] * LAM[3 * i] + Wc[cw] * LAM[3 * i + 1] + Wc[2 * cw] * LAM[3 * i + 2];
               }
             }
             const float xk = crsD[k] * wj - dot6(cUD[k], ap);
@@ -890,9 +921,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     if (s < nc) {
       float CN[16];
       ldv<4>(CON + s * kConSlot, CN);
-      float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-      RSB_UNROLL for (int j = 0; j < KMAX; ++j)
-        if (s == j) { l0 = lam_all[3 * j]; l1 = lam_all[3 * j + 1]; l2 = lam_all[3 * j + 2]; }
+      const float l0 = LAM[3 * s], l1 = LAM[3 * s + 1], l2 = LAM[3 * s + 2];
       rsb_contact ct;
       ct.position[0] = pbx + CN[0];  // contact point at detection time (start of the last sub-step)
       ct.position[1] = pby + CN[1];

@@ -1,0 +1,244 @@
+"""GPU parity tests proper: the HIP path (through the C-ABI) vs the fp64 oracle on identical inputs.
+
+Tolerances (fp32 device vs fp64 oracle, stated per test):
+  one integrate() from identical states ......... |dq| <= 2e-6 + 1e-6|q|,  |du| <= 2e-4 (1 + |u|_inf)   [converged envs]
+  Delassus matrix / free contact velocity ....... relative 2e-4 of the largest entry
+  M(q), h(q,u) (integrate1 query path) ........... relative 1e-5 / 2e-5
+  40-sub-step trajectories ......................... median env error, not max: contact dynamics is chaotic
+Envs whose oracle solve hit max_iter (non-convergent contact sets) are compared loosely: both sides stop at an
+arbitrary point of a non-converging iteration, so only boundedness is required there.
+"""
+import numpy as np
+import pytest
+
+from common import Oracle, f32, standing_states
+from raisimlib_amd import BatchedWorld, workload
+
+pytestmark = pytest.mark.gpu
+
+
+def run_one_step(model, gc, gv, pt, kp, kd, lpe=0, kmax=8, substeps=1, heightmap=None, tau_ff=None, mode=1):
+    N = gc.shape[0]
+    w = BatchedWorld(model, N)
+    w.set_max_contacts(kmax)
+    if lpe:
+        w.set_lanes_per_env(lpe)
+    o = Oracle(model.blob)
+    o.p.kmax = kmax
+    o.p.control_mode = mode
+    w.set_control_mode(mode)
+    if heightmap is not None:
+        w.add_height_map(*heightmap)
+        o.set_heightmap(*heightmap)
+    dtg = np.zeros((N, model.nv))
+    w.set_pd_gains(kp, kd)
+    w.set_pd_target(pt, dtg)
+    if tau_ff is not None:
+        w.set_generalized_force(tau_ff)
+    w.set_state(gc, gv)
+    w.integrate(substeps)
+    q1, u1 = w.get_state()
+    cnt, con = w.get_contacts()
+    its, fl = w.get_solver_iterations(), w.get_flags()
+    ref = o.step_batch(f32(gc), f32(gv), substeps, kp.astype(np.float64), kd.astype(np.float64), f32(pt), dtg,
+                       None if tau_ff is None else f32(tau_ff), want_contacts=True)
+    w.close()
+    return dict(q=q1, u=u1, cnt=cnt, con=con, iters=its, flags=fl), ref, o
+
+
+def check_step(dev, ref, max_iter=150, du_tol=2e-4):
+    assert np.array_equal(dev["cnt"], ref["n_contacts"])
+    conv = ref["iters"] < max_iter
+    assert conv.mean() > 0.9
+    eq = np.abs(dev["q"] - ref["q"])
+    eu = np.abs(dev["u"] - ref["u"]).max(axis=1)
+    su = 1 + np.abs(ref["u"]).max(axis=1)
+    assert np.all(eq[conv] <= 2e-6 + 1e-6 * np.abs(ref["q"][conv]))
+    assert np.all(eu[conv] <= du_tol * su[conv]), (eu[conv] / su[conv]).max()
+    assert np.median(eu) < 1e-5
+    # non-converged envs: bounded, finite
+    assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()
+    assert np.all(eu[~conv] <= 0.5 * su[~conv])
+    assert np.abs(dev["iters"][conv] - ref["iters"][conv]).max() <= 3
+
+
+@pytest.mark.parametrize("lpe", [16, 32, 64])
+def test_one_step_parity_anymal(anymal, lpe):
+    gc, gv = standing_states(512, seed=100 + lpe)
+    kp, kd = workload.anymal_gains()
+    pt = gc.copy()
+    pt[:, 7:] = workload.ANYMAL_NOMINAL_JOINTS + np.random.default_rng(1).uniform(-0.3, 0.3, (512, 12))
+    dev, ref, _ = run_one_step(anymal, gc, gv, pt, kp, kd, lpe=lpe)
+    assert ref["n_contacts"].sum() > 500 and (ref["n_contacts"] == 0).any()
+    check_step(dev, ref)
+
+
+def test_lanes_per_env_mappings_agree(anymal):
+    """The three wave mappings (16 / 32 / 64 lanes per env; 64 = one wavefront per env) run the same per-env
+    algorithm; they are separate template instantiations, so only rounding-level differences are allowed."""
+    gc, gv = standing_states(256, seed=7)
+    kp, kd = workload.anymal_gains()
+    outs = [run_one_step(anymal, gc, gv, gc, kp, kd, lpe=lpe) for lpe in (16, 32, 64)]
+    conv = outs[0][1]["iters"] < 150
+    for o2, _, _ in outs[1:]:
+        assert np.array_equal(outs[0][0]["cnt"], o2["cnt"])
+        assert np.abs(outs[0][0]["q"] - o2["q"])[conv].max() < 1e-6
+        assert (np.abs(outs[0][0]["u"] - o2["u"]).max(axis=1) / (1 + np.abs(o2["u"]).max(axis=1)))[conv].max() < 1e-4
+
+
+def test_golden_fixture_parity(anymal):
+    """Device vs the committed golden vectors (tests/golden/anymal_golden.npz)."""
+    import os
+    from common import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "anymal_golden.npz"))
+    kp, kd = workload.anymal_gains()
+    dev, _, _ = run_one_step(anymal, g["gc"], g["gv"], g["pt"], kp, kd)
+    assert np.array_equal(dev["cnt"], g["n_contacts"])
+    conv = g["iters"] < 150
+    assert np.abs(dev["q"] - g["q1"])[conv].max() < 3e-6
+    assert (np.abs(dev["u"] - g["u1"]).max(axis=1) / (1 + np.abs(g["u1"]).max(axis=1)))[conv].max() < 2e-4
+
+
+def test_contact_problem_parity(anymal):
+    """Delassus matrix G, free contact velocity c and solved impulses of single envs vs the oracle."""
+    gc, gv = standing_states(64, seed=21)
+    kp, kd = workload.anymal_gains()
+    o = Oracle(anymal.blob)
+    w = BatchedWorld(anymal, 64)
+    w.set_pd_gains(kp, kd)
+    dtg = np.zeros((64, 18))
+    checked = 0
+    for e in range(64):
+        d = o.step_debug(f32(gc[e]), f32(gv[e]), kp.astype(np.float64), kd.astype(np.float64), f32(gc[e]), dtg[e])
+        if len(d["c"]) == 0 or d["iters"] >= 150:
+            continue
+        w.set_pd_target(gc, dtg); w.set_state(gc, gv); w.debug_select_env(e); w.integrate(1)
+        nc, G, c, lam = w.debug_contact_problem()
+        assert 3 * nc == len(d["c"])
+        assert np.abs(G - d["G"]).max() <= 2e-4 * np.abs(d["G"]).max()
+        assert np.abs(c - d["c"]).max() <= 2e-4 * (1 + np.abs(d["c"]).max())
+        assert np.abs(lam - d["lam"]).max() <= 2e-3 * (1 + np.abs(d["lam"]).max())
+        checked += 1
+        if checked >= 12:
+            break
+    w.close()
+    assert checked >= 8
+
+
+def test_contacts_report(anymal):
+    """rsb_get_contacts: positions, normals, bodies, impulses (world frame) vs the oracle; cone + unilaterality."""
+    gc, gv = standing_states(256, seed=5)
+    kp, kd = workload.anymal_gains()
+    dev, ref, _ = run_one_step(anymal, gc, gv, gc, kp, kd)
+    conv = ref["iters"] < 150
+    for e in np.where(conv & (ref["n_contacts"] > 0))[0][:60]:
+        n = ref["n_contacts"][e]
+        d, r = dev["con"][e][:n], ref["contacts"][e][:n]
+        assert np.array_equal(d["collision"], r["collision"]) and np.array_equal(d["body"], r["body"])
+        assert np.abs(d["position"] - r["position"]).max() < 5e-6 and np.abs(d["normal"] - r["normal"]).max() < 1e-6
+        assert np.abs(d["depth"] - r["depth"]).max() < 5e-6
+        assert np.abs(d["impulse"] - r["impulse"]).max() <= 2e-3 * (1 + np.abs(r["impulse"]).max())
+        assert np.all(d["impulse"][:, 2] >= 0)
+        assert np.all(np.hypot(d["impulse"][:, 0], d["impulse"][:, 1]) <= 0.8 * d["impulse"][:, 2] * (1 + 1e-4) + 1e-7)
+
+
+def test_trajectory_parity_config2(anymal):
+    """Config-2 workload (fresh PD targets every control step), 40 control steps = 160 integrate() calls."""
+    N = 256
+    o = Oracle(anymal.blob)
+    w = BatchedWorld(anymal, N)
+    gc, gv = workload.anymal_initial_state(N)
+    kp, kd = workload.anymal_gains()
+    w.set_pd_gains(kp, kd); w.set_state(gc, gv)
+    q, u = f32(gc), gv.copy()
+    dtg = np.zeros((N, 18))
+    for cs in range(40):
+        pt = workload.anymal_targets(N, cs).astype(np.float32)
+        w.set_pd_target(pt, dtg)
+        w.integrate(workload.SUBSTEPS)
+        r = o.step_batch(q, u, workload.SUBSTEPS, kp.astype(np.float64), kd.astype(np.float64), pt.astype(np.float64), dtg)
+        q, u = r["q"], r["u"]
+    q1, u1 = w.get_state()
+    assert abs(w.get_world_time() - 40 * 4 * workload.DT) < 1e-9
+    w.close()
+    eq, eu = np.abs(q1 - q).max(axis=1), np.abs(u1 - u).max(axis=1)
+    assert np.median(eq) < 2e-5 and np.median(eu) < 2e-4          # typical env tracks the oracle
+    assert np.percentile(eq, 90) < 2e-3 and np.isfinite(q1).all()  # contact-timing flips stay small over 0.4 s
+    assert (q1[:, 2] > 0.2).all() and w.N == N
+
+
+def test_fused_substeps_equal_separate_launches(anymal):
+    gc, gv = standing_states(128, seed=9)
+    kp, kd = workload.anymal_gains()
+    a, _, _ = run_one_step(anymal, gc, gv, gc, kp, kd, substeps=4)
+    w = BatchedWorld(anymal, 128)
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((128, 18))); w.set_state(gc, gv)
+    for _ in range(4):
+        w.integrate(1)
+    q, u = w.get_state()
+    w.close()
+    assert np.array_equal(q, a["q"]) and np.array_equal(u, a["u"])
+
+
+def test_force_and_torque_mode(anymal):
+    gc, gv = standing_states(128, seed=13, z=(0.8, 1.0))
+    rng = np.random.default_rng(0)
+    tau = rng.normal(size=(128, 18)).astype(np.float32) * 5
+    kp, kd = workload.anymal_gains()
+    dev, ref, _ = run_one_step(anymal, gc, gv, gc, kp, kd, tau_ff=tau, mode=0)
+    check_step(dev, ref)
+
+
+def test_heightmap_one_step_parity(anymal):
+    """Config 3: sphere x triangulated height-field contacts, shared 64x64 map."""
+    H = workload.smoothed_heightmap(64, 64, amplitude=0.1, seed=7)
+    hm = (64, 64, 6.4, 6.4, 0.0, 0.0, H)
+    gc, gv = standing_states(512, seed=33, z=(0.45, 0.7))
+    kp, kd = workload.anymal_gains()
+    dev, ref, o = run_one_step(anymal, gc, gv, gc, kp, kd, heightmap=hm)
+    assert ref["n_contacts"].sum() > 300
+    # contact normals really are tilted
+    tilted = [c["normal"][0][2] for e, c in enumerate(ref["contacts"]) if ref["n_contacts"][e] > 0]
+    assert min(tilted) < 0.999
+    check_step(dev, ref)
+
+
+def test_atlas_one_step_parity(atlas):
+    """Config 5: deep chains (31 bodies, 36 DoF), multi-sphere feet, kmax = 16.  The mass matrix of this model
+    has condition number ~4e5 (0.125 kg talus links), so the fp32 tolerance is relative to the velocity scale."""
+    N = 256
+    rng = np.random.default_rng(3)
+    gc = np.zeros((N, 37)); gc[:, 2] = rng.uniform(0.88, 1.0, N); gc[:, 3] = 1.0
+    gc[:, 7:] = rng.uniform(-0.15, 0.15, (N, 30))
+    gv = rng.normal(size=(N, 36)) * 0.2
+    kp = np.zeros(36, np.float32); kd = np.zeros(36, np.float32); kp[6:] = 200.0; kd[6:] = 5.0
+    dev, ref, _ = run_one_step(atlas, gc, gv, gc, kp, kd, kmax=16)
+    assert ref["n_contacts"].sum() > 300
+    assert np.array_equal(dev["cnt"], ref["n_contacts"])
+    conv = ref["iters"] < 150
+    eu = np.abs(dev["u"] - ref["u"]).max(axis=1) / (1 + np.abs(ref["u"]).max(axis=1))
+    assert np.all(eu[conv] < 5e-3) and np.median(eu) < 5e-4
+    assert np.abs(dev["q"] - ref["q"])[conv].max() < 5e-5
+
+
+def test_mass_matrix_and_nonlinearities_query(anymal, atlas):
+    for model in (anymal, atlas):
+        N = 32
+        gc, gv = workload.random_state(model.nq, model.nv, N, seed=4, joint_range=1.0)
+        w = BatchedWorld(model, N)
+        w.set_state(gc, gv)
+        with pytest.raises(Exception, match="integrate1"):
+            w.get_mass_matrix()
+        w.integrate1()
+        M, h = w.get_mass_matrix(), w.get_nonlinearities()
+        o = Oracle(model.blob)
+        for e in range(N):
+            Mr, hr = o.mass_matrix(f32(gc[e])), o.nonlinearities(f32(gc[e]), f32(gv[e]))
+            assert np.abs(M[e] - Mr).max() <= 1e-5 * np.abs(Mr).max()
+            assert np.abs(h[e] - hr).max() <= 2e-5 * (1 + np.abs(hr).max())
+        # integrate1 does not advance the state; integrate2 does (== integrate)
+        q0, _ = w.get_state()
+        assert np.array_equal(q0, gc.astype(np.float32))
+        w.integrate2()
+        assert not np.array_equal(w.get_state()[0], q0)
+        w.close()

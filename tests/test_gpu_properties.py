@@ -1,0 +1,177 @@
+"""Size-independent properties at BASELINE.json's full size (N = 4096) and the host-side ops around the hot path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import f32, sphere_urdf, standing_states
+from raisimlib_amd import BatchedWorld, Model, RsbError, workload
+
+pytestmark = pytest.mark.gpu
+G, DT = 9.81, 0.0025
+
+
+def test_free_fall_closed_form_4096_envs(built_lib):
+    m = Model(urdf_string=sphere_urdf())
+    N = 4096
+    w = BatchedWorld(m, N)
+    rng = np.random.default_rng(0)
+    gc = np.zeros((N, 7), np.float32); gc[:, 2] = rng.uniform(20, 30, N); gc[:, 3] = 1
+    gv = np.zeros((N, 6), np.float32); gv[:, :2] = rng.normal(size=(N, 2))
+    w.set_state(gc, gv)
+    n = 200
+    w.integrate(n)
+    q, u = w.get_state()
+    w.close()
+    assert np.allclose(u[:, 2], -G * n * DT, rtol=2e-5)
+    assert np.allclose(q[:, 2], gc[:, 2] - G * DT * DT * n * (n + 1) / 2, atol=2e-4)
+    assert np.allclose(q[:, :2], gc[:, :2] + gv[:, :2] * n * DT, atol=1e-4) and np.allclose(u[:, :2], gv[:, :2])
+
+
+def test_full_size_standing_invariants(anymal):
+    """N = 4096, 25 control steps of the config-2 workload: finite state, unit quaternions, feet never below the
+    ground by more than a sphere radius, impulses inside the friction cone, weight roughly carried."""
+    N = 4096
+    w = BatchedWorld(anymal, N)
+    gc, gv = workload.anymal_initial_state(N)
+    kp, kd = workload.anymal_gains()
+    w.set_pd_gains(kp, kd); w.set_state(gc, gv)
+    dtg = np.zeros((N, 18), np.float32)
+    for cs in range(25):
+        w.set_pd_target(workload.anymal_targets(N, cs), dtg)
+        w.integrate(4)
+    q, u = w.get_state()
+    cnt, con = w.get_contacts()
+    fl = w.get_flags()
+    w.close()
+    assert np.isfinite(q).all() and np.isfinite(u).all() and not (fl & 2).any()
+    assert np.allclose(np.linalg.norm(q[:, 3:7], axis=1), 1.0, atol=1e-5)
+    assert (q[:, 2] > 0.25).all() and (q[:, 2] < 0.7).all()
+    valid = np.arange(con.shape[1])[None, :] < cnt[:, None]
+    imp = con["impulse"]
+    assert (imp[..., 2][valid] >= 0).all()
+    assert (np.hypot(imp[..., 0], imp[..., 1])[valid] <= 0.8 * imp[..., 2][valid] * (1 + 1e-4) + 1e-7).all()
+    assert (con["depth"][valid] > 0).all() and (con["depth"][valid] < 0.03).all()
+    fz = np.where(valid, imp[..., 2], 0).sum(axis=1) / DT
+    ratio = np.median(fz[cnt >= 3]) / (anymal.total_mass() * G)   # robots are still bouncing on soft PD legs
+    assert 0.3 < ratio < 3.0
+
+
+def test_determinism(anymal):
+    gc, gv = standing_states(512, seed=3)
+    kp, kd = workload.anymal_gains()
+    outs = []
+    for _ in range(2):
+        w = BatchedWorld(anymal, 512)
+        w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((512, 18))); w.set_state(gc, gv)
+        w.integrate(8)
+        outs.append(w.get_state())
+        w.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_env_independence_and_ragged_batch(anymal):
+    """Envs do not interact: an env's result is independent of its wave-mates; N not a multiple of the wave's
+    env count works (tail handling)."""
+    gc, gv = standing_states(67, seed=17)
+    kp, kd = workload.anymal_gains()
+    res = {}
+    for n in (67, 1, 5):
+        w = BatchedWorld(anymal, n)
+        w.set_pd_gains(kp, kd); w.set_pd_target(gc[:n], np.zeros((n, 18))); w.set_state(gc[:n], gv[:n])
+        w.integrate(4)
+        res[n] = w.get_state()
+        w.close()
+    assert np.array_equal(res[67][0][:5], res[5][0]) and np.array_equal(res[67][1][:1], res[1][1])
+
+
+def test_masked_set_state_and_reset_terminated(anymal):
+    N = 64
+    w = BatchedWorld(anymal, N)
+    gc, gv = standing_states(N, seed=1)
+    w.set_state(gc, gv)
+    mask = np.zeros(N, np.uint8); mask[::3] = 1
+    g2 = gc.copy(); g2[:, 2] += 5
+    w.set_state(g2, None, mask)
+    q, u = w.get_state()
+    assert np.allclose(q[::3, 2], g2[::3, 2].astype(np.float32)) and np.allclose(q[1::3, 2], gc[1::3, 2].astype(np.float32))
+    # belly-flop half of the envs: non-foot contacts -> reset to the init row
+    low = gc.copy(); low[:, 2] = np.where(np.arange(N) % 2 == 0, 0.08, 0.9)
+    low[:, 3:7] = [1, 0, 0, 0]
+    kp, kd = workload.anymal_gains()
+    w.set_pd_gains(kp, kd); w.set_pd_target(low, np.zeros((N, 18))); w.set_state(low, np.zeros((N, 18)))
+    w.integrate(1)
+    init_q, init_u = workload.anymal_initial_state(1)
+    done = w.reset_terminated(anymal.collision_indices("_foot"), init_q[0], init_u[0])
+    q, u = w.get_state()
+    assert done[::2].all() and not done[1::2].any()
+    assert np.allclose(q[::2], init_q[0].astype(np.float32)) and np.allclose(u[::2], 0)
+    assert (w.get_contacts()[0][::2] == 0).all()
+    w.close()
+
+
+def test_gather_obs_layout(anymal):
+    import torch
+    N = 128
+    w = BatchedWorld(anymal, N)
+    gc, gv = standing_states(N, seed=2, z=(0.45, 0.55))
+    kp, kd = workload.anymal_gains()
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv)
+    w.integrate(1)
+    feet = anymal.collision_indices("_foot")
+    od = w.obs_dim(len(feet))
+    assert od == 19 + 18 + 12
+    obs = torch.empty((N, od), dtype=torch.float32, device="cuda")
+    w.gather_obs(obs.data_ptr(), feet)
+    w.synchronize()
+    o = obs.cpu().numpy()
+    q, u = w.get_state()
+    cnt, con = w.get_contacts()
+    assert np.array_equal(o[:, :19], q) and np.array_equal(o[:, 19:37], u)
+    for e in range(N):
+        for k, f in enumerate(feet):
+            hit = [c for c in con[e][:cnt[e]] if c["collision"] == f]
+            want = hit[0]["impulse"] / DT if hit else np.zeros(3)
+            assert np.allclose(o[e, 37 + 3 * k:40 + 3 * k], want, rtol=1e-6, atol=1e-6)
+    w.close()
+
+
+def test_borrowed_stream_and_device_targets(anymal):
+    """The world runs on a caller-provided HIP stream (torch's), and accepts device-resident PD targets."""
+    import torch
+    N = 256
+    gc, gv = standing_states(N, seed=8)
+    kp, kd = workload.anymal_gains()
+    dtg = np.zeros((N, 18), np.float32)
+    w = BatchedWorld(anymal, N)
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, dtg); w.set_state(gc, gv); w.integrate(4)
+    ref = w.get_state()
+    w.close()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        w = BatchedWorld(anymal, N)
+        w.set_stream(stream.cuda_stream)
+        pt = torch.from_numpy(gc.astype(np.float32)).cuda()
+        w.set_pd_gains(kp, kd); w.set_pd_target(None, dtg); w.set_pd_target_device(pt.data_ptr()); w.set_state(gc, gv)
+        w.integrate(4)
+        stream.synchronize()
+        got = w.get_state()
+        w.close()
+    assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
+
+
+def test_api_errors(anymal):
+    w = BatchedWorld(anymal, 8)
+    with pytest.raises(RsbError):
+        w.set_lanes_per_env(8)
+    with pytest.raises(RsbError):
+        w.set_max_contacts(0)
+    with pytest.raises(RsbError):
+        w.set_time_step(-1.0)
+    with pytest.raises(RsbError):
+        w.integrate(0)
+    with pytest.raises(RsbError):
+        w.set_contact_solver_param(1, 1, 1, 0, 1e-5)
+    w.set_time_step(0.001)
+    assert abs(w.get_time_step() - 0.001) < 1e-15
+    w.close()
