@@ -1,0 +1,276 @@
+// raisim/World.hpp — raisim::World / ArticulatedSystem / Ground / HeightMap / Contact facade over the C-ABI (rsb.h).
+//
+// Re-authored from recollection of upstream raisim/World.hpp, object/ArticulatedSystem/ArticulatedSystem.hpp,
+// object/terrain/HeightMap.hpp, contact/Contact.hpp [RECALL — all absent from /root/reference, SURVEY.md §8b].
+// The engine behind these classes is the batched, GPU-resident world of librsb.so:
+//
+//   raisim::BatchedWorld   N replicas of {World + one ArticulatedSystem + terrain} on one GPU (new type; what a
+//                          batched VectorizedEnvironment drives directly — the fast path).
+//   raisim::World          the upstream per-env class.  Default-constructed it owns a BatchedWorld with N = 1 (so an
+//                          unmodified Environment.hpp runs, one launch per env: correctness path); constructed from
+//                          (BatchedWorld&, env) it is a view of one replica.
+//   raisim::ArticulatedSystem  per-env view (handle, env index); state setters/getters move one row host<->device.
+//
+// Errors follow upstream's RSFATAL: a failed call throws std::runtime_error with rsb_last_error().
+#pragma once
+
+#include <cmath>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "raisim/math.hpp"
+#include "rsb.h"
+
+#define RSFATAL_IF(cond, msg) do { if (cond) throw std::runtime_error(std::string(msg)); } while (0)
+#define RSB_CHECK(expr) do { int st_ = (expr); if (st_ != RSB_OK) throw std::runtime_error(std::string(#expr) + ": " + rsb_last_error()); } while (0)
+
+namespace raisim {
+
+namespace ControlMode {
+enum Type : int { FORCE_AND_TORQUE = RSB_FORCE_AND_TORQUE, PD_PLUS_FEEDFORWARD_TORQUE = RSB_PD_PLUS_FEEDFORWARD_TORQUE };
+}
+
+/// One solved contact of an articulated system (upstream raisim::Contact).
+class Contact {
+ public:
+  explicit Contact(const rsb_contact& c) : c_(c) {}
+  Vec<3> getPosition() const { return v3(c_.position); }
+  Vec<3> getNormal() const { return v3(c_.normal); }
+  Vec<3> getImpulse() const { return v3(c_.impulse); }   // world frame (upstream: contact frame + getContactFrame())
+  double getDepth() const { return c_.depth; }
+  size_t getlocalBodyIndex() const { return (size_t)c_.body; }
+  int getCollisionIndex() const { return c_.collision; }
+  bool isObjectA() const { return true; }
+  bool skip() const { return false; }
+ private:
+  static Vec<3> v3(const float* p) { Vec<3> v; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; return v; }
+  rsb_contact c_;
+};
+
+/// N lock-stepped replicas on one GPU.
+class BatchedWorld {
+ public:
+  BatchedWorld(const std::string& urdfPath, int numEnvs, int device = 0) {
+    RSB_CHECK(rsb_model_from_urdf_file(urdfPath.c_str(), &model_));
+    init(numEnvs, device);
+  }
+  ~BatchedWorld() { if (world_) rsb_destroy(world_); if (model_) rsb_model_destroy(model_); }
+  BatchedWorld(const BatchedWorld&) = delete;
+  BatchedWorld& operator=(const BatchedWorld&) = delete;
+
+  rsb_world* handle() { return world_; }
+  const rsb_model* model() const { return model_; }
+  const rsb_model_blob& blob() const { return blob_; }
+  int numEnvs() const { return n_; }
+  int gcDim() const { return blob_.nq; }
+  int dof() const { return blob_.nv; }
+
+  void setTimeStep(double dt) { RSB_CHECK(rsb_set_timestep(world_, dt)); }
+  double getTimeStep() const { return rsb_get_timestep(world_); }
+  double getWorldTime() const { return rsb_get_world_time(world_); }
+  void setGravity(const Vec<3>& g) { RSB_CHECK(rsb_set_gravity(world_, g.data())); }
+  void setERP(double erp, double = 0) { RSB_CHECK(rsb_set_erp(world_, erp)); }
+  void setDefaultMaterial(double friction, double /*restitution*/ = 0, double /*resThreshold*/ = 0) { RSB_CHECK(rsb_set_friction(world_, friction)); }
+  void setContactSolverParam(double alpha_init, double alpha_min, double alpha_decay, int maxIter, double threshold) {
+    RSB_CHECK(rsb_set_contact_solver_param(world_, alpha_init, alpha_min, alpha_decay, maxIter, threshold));
+  }
+  void addGround(double zHeight = 0.0) { RSB_CHECK(rsb_set_ground(world_, zHeight)); }
+  void addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
+                    const std::vector<double>& height) {
+    std::vector<float> h(height.begin(), height.end());
+    RSFATAL_IF((int)h.size() != xSamples * ySamples, "addHeightMap: height.size() != xSamples*ySamples");
+    RSB_CHECK(rsb_set_heightmap(world_, xSamples, ySamples, xSize, ySize, centerX, centerY, h.data()));
+  }
+  void integrate(int nSubsteps = 1) { RSB_CHECK(rsb_integrate(world_, nSubsteps)); }
+  void integrate1() { RSB_CHECK(rsb_integrate1(world_)); }
+  void integrate2() { RSB_CHECK(rsb_integrate2(world_)); }
+
+  // batched, caller-owned host buffers (row-major [N, dim] float32, the raisimGymTorch matrix layout)
+  void setState(const float* gc, const float* gv) { RSB_CHECK(rsb_set_state(world_, gc, gv, nullptr, RSB_HOST)); }
+  void getState(float* gc, float* gv) { RSB_CHECK(rsb_get_state(world_, gc, gv, RSB_HOST)); }
+  void setPdGains(const float* kp, const float* kd) { RSB_CHECK(rsb_set_pd_gains(world_, kp, kd)); }
+  void setPdTarget(const float* pTarget, const float* dTarget) { RSB_CHECK(rsb_set_pd_target(world_, pTarget, dTarget, RSB_HOST)); }
+  void setGeneralizedForce(const float* tau) { RSB_CHECK(rsb_set_generalized_force(world_, tau, RSB_HOST)); }
+  void setControlMode(ControlMode::Type m) { RSB_CHECK(rsb_set_control_mode(world_, (int)m)); }
+
+ private:
+  void init(int numEnvs, int device) {
+    RSB_CHECK(rsb_model_get_blob(model_, &blob_));
+    RSB_CHECK(rsb_create(model_, numEnvs, device, &world_));
+    n_ = numEnvs;
+  }
+  rsb_model* model_ = nullptr;
+  rsb_world* world_ = nullptr;
+  rsb_model_blob blob_;
+  int n_ = 0;
+};
+
+class Ground {};
+class HeightMap {
+ public:
+  HeightMap(BatchedWorld* w, int xs, int ys, double xSize, double ySize, double cx, double cy, std::vector<double> h)
+      : w_(w), xs_(xs), ys_(ys), xSize_(xSize), ySize_(ySize), cx_(cx), cy_(cy), h_(std::move(h)) {}
+  double getHeight(double x, double y) const {  // same triangulation as the device collider
+    const double dx = xSize_ / (xs_ - 1), dy = ySize_ / (ys_ - 1);
+    double gx = (x - (cx_ - 0.5 * xSize_)) / dx, gy = (y - (cy_ - 0.5 * ySize_)) / dy;
+    gx = gx < 0 ? 0 : (gx > xs_ - 1 ? xs_ - 1 : gx);
+    gy = gy < 0 ? 0 : (gy > ys_ - 1 ? ys_ - 1 : gy);
+    int ix = (int)std::floor(gx), iy = (int)std::floor(gy);
+    if (ix > xs_ - 2) ix = xs_ - 2;
+    if (iy > ys_ - 2) iy = ys_ - 2;
+    const double fx = gx - ix, fy = gy - iy;
+    const double h00 = h_[iy * xs_ + ix], h10 = h_[iy * xs_ + ix + 1], h01 = h_[(iy + 1) * xs_ + ix], h11 = h_[(iy + 1) * xs_ + ix + 1];
+    return fx >= fy ? h00 + (h10 - h00) * fx + (h11 - h10) * fy : h00 + (h11 - h01) * fx + (h01 - h00) * fy;
+  }
+  const std::vector<double>& getHeightVector() const { return h_; }
+ private:
+  BatchedWorld* w_;
+  int xs_, ys_;
+  double xSize_, ySize_, cx_, cy_;
+  std::vector<double> h_;
+};
+
+/// Per-env view of the articulated system (upstream raisim::ArticulatedSystem).
+class ArticulatedSystem {
+ public:
+  ArticulatedSystem(BatchedWorld* w, int env) : w_(w), env_(env), gc_(w->gcDim()), gv_(w->dof()) {}
+  size_t getGeneralizedCoordinateDim() const { return (size_t)w_->gcDim(); }
+  size_t getDOF() const { return (size_t)w_->dof(); }
+  void setName(const std::string& n) { name_ = n; }
+  const std::string& getName() const { return name_; }
+  double getTotalMass() const { return rsb_model_total_mass(w_->model()); }
+  size_t getBodyIdx(const std::string& link) const {
+    int i = rsb_model_body_index(w_->model(), link.c_str());
+    RSFATAL_IF(i < 0, "getBodyIdx: no such body: " + link);
+    return (size_t)i;
+  }
+  std::vector<std::string> getBodyNames() const {
+    std::vector<std::string> n;
+    for (int i = 0; i < w_->blob().nb; ++i) n.emplace_back(w_->blob().body_name[i]);
+    return n;
+  }
+
+  void setGeneralizedCoordinate(const VecDyn& gc) { putRow(RSB_F_GC, gc); }
+  void setGeneralizedVelocity(const VecDyn& gv) { putRow(RSB_F_GV, gv); }
+  void setState(const VecDyn& gc, const VecDyn& gv) { putRow(RSB_F_GC, gc); putRow(RSB_F_GV, gv); }
+  void getState(VecDyn& gc, VecDyn& gv) { getRow(RSB_F_GC, gc, w_->gcDim()); getRow(RSB_F_GV, gv, w_->dof()); }
+  const VecDyn& getGeneralizedCoordinate() { getRow(RSB_F_GC, gc_, w_->gcDim()); return gc_; }
+  const VecDyn& getGeneralizedVelocity() { getRow(RSB_F_GV, gv_, w_->dof()); return gv_; }
+
+  void setControlMode(ControlMode::Type m) { w_->setControlMode(m); }
+  /// gains are shared by all replicas of the batched world (one robot model, one controller tuning)
+  void setPdGains(const VecDyn& p, const VecDyn& d) {
+    std::vector<float> kp(p.v.begin(), p.v.end()), kd(d.v.begin(), d.v.end());
+    RSFATAL_IF((int)kp.size() != w_->dof() || (int)kd.size() != w_->dof(), "setPdGains: gain vectors must have DOF entries");
+    w_->setPdGains(kp.data(), kd.data());
+  }
+  void setPdTarget(const VecDyn& pTarget, const VecDyn& dTarget) { putRow(RSB_F_PTARGET, pTarget); putRow(RSB_F_DTARGET, dTarget); }
+  void setGeneralizedForce(const VecDyn& tau) { putRow(RSB_F_TAU_FF, tau); }
+
+  /// valid after World::integrate1() (upstream semantics): M(q) and h(q,u) of this env
+  const MatDyn& getMassMatrix() {
+    const int nv = w_->dof();
+    std::vector<float> M((size_t)w_->numEnvs() * nv * nv);
+    RSB_CHECK(rsb_get_mass_matrix(w_->handle(), M.data(), RSB_HOST));
+    M_.resize(nv, nv);
+    for (int i = 0; i < nv; ++i) for (int j = 0; j < nv; ++j) M_(i, j) = M[((size_t)env_ * nv + i) * nv + j];
+    return M_;
+  }
+  const VecDyn& getNonlinearities(const Vec<3>& /*gravity*/ = Vec<3>()) {
+    const int nv = w_->dof();
+    std::vector<float> h((size_t)w_->numEnvs() * nv);
+    RSB_CHECK(rsb_get_nonlinearities(w_->handle(), h.data(), RSB_HOST));
+    h_.resize(nv);
+    for (int i = 0; i < nv; ++i) h_[i] = h[(size_t)env_ * nv + i];
+    return h_;
+  }
+  /// contacts of the last integrate() of this env
+  std::vector<Contact>& getContacts() {
+    int kmax = 0;
+    RSB_CHECK(rsb_dims(w_->handle(), nullptr, nullptr, nullptr, nullptr, &kmax));
+    std::vector<int32_t> cnt(w_->numEnvs());
+    std::vector<rsb_contact> con((size_t)w_->numEnvs() * kmax);
+    RSB_CHECK(rsb_get_contacts(w_->handle(), cnt.data(), con.data(), RSB_HOST));
+    contacts_.clear();
+    for (int k = 0; k < cnt[env_]; ++k) contacts_.emplace_back(con[(size_t)env_ * kmax + k]);
+    return contacts_;
+  }
+  void getBaseOrientation(Mat<3, 3>& rot) {
+    const VecDyn& q = getGeneralizedCoordinate();
+    const double w = q[3], x = q[4], y = q[5], z = q[6];
+    rot(0, 0) = 1 - 2 * (y * y + z * z); rot(0, 1) = 2 * (x * y - w * z);     rot(0, 2) = 2 * (x * z + w * y);
+    rot(1, 0) = 2 * (x * y + w * z);     rot(1, 1) = 1 - 2 * (x * x + z * z); rot(1, 2) = 2 * (y * z - w * x);
+    rot(2, 0) = 2 * (x * z - w * y);     rot(2, 1) = 2 * (y * z + w * x);     rot(2, 2) = 1 - 2 * (x * x + y * y);
+  }
+
+ private:
+  void putRow(int field, const VecDyn& v) {
+    std::vector<float> f(v.v.begin(), v.v.end());
+    RSB_CHECK(rsb_set_env_row(w_->handle(), field, env_, f.data()));
+  }
+  void getRow(int field, VecDyn& v, int dim) {
+    std::vector<float> f(dim);
+    RSB_CHECK(rsb_get_env_row(w_->handle(), field, env_, f.data()));
+    v.resize(dim);
+    for (int i = 0; i < dim; ++i) v[i] = f[i];
+  }
+  BatchedWorld* w_;
+  int env_;
+  std::string name_;
+  VecDyn gc_, gv_, h_;
+  MatDyn M_;
+  std::vector<Contact> contacts_;
+};
+
+/// Upstream raisim::World: one env.  Owns a 1-replica BatchedWorld, or views replica `env` of a shared one.
+class World {
+ public:
+  World() = default;
+  World(BatchedWorld& shared, int env) : shared_(&shared), env_(env) {}
+  static void setActivationKey(const std::string&) {}  // nothing to activate in a from-scratch build
+
+  ArticulatedSystem* addArticulatedSystem(const std::string& urdfPath, const std::string& /*resDir*/ = "") {
+    RSFATAL_IF(robot_ != nullptr, "this build supports one ArticulatedSystem per World");
+    if (!shared_) { owned_ = std::make_unique<BatchedWorld>(urdfPath, 1); shared_ = owned_.get(); env_ = 0; applyPending(); }
+    robot_ = std::make_unique<ArticulatedSystem>(shared_, env_);
+    return robot_.get();
+  }
+  Ground* addGround(double zHeight = 0.0, const std::string& /*material*/ = "default") {
+    groundZ_ = zHeight; hasGround_ = true;
+    if (shared_) shared_->addGround(zHeight);
+    return &ground_;
+  }
+  HeightMap* addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
+                          const std::vector<double>& height, const std::string& /*material*/ = "default") {
+    RSFATAL_IF(!shared_, "addHeightMap: add the ArticulatedSystem first");
+    shared_->addHeightMap(xSamples, ySamples, xSize, ySize, centerX, centerY, height);
+    hm_ = std::make_unique<HeightMap>(shared_, xSamples, ySamples, xSize, ySize, centerX, centerY, height);
+    return hm_.get();
+  }
+  void setTimeStep(double dt) { dt_ = dt; if (shared_) shared_->setTimeStep(dt); }
+  double getTimeStep() const { return shared_ ? shared_->getTimeStep() : dt_; }
+  double getWorldTime() const { return shared_ ? shared_->getWorldTime() : 0.0; }
+  void setGravity(const Vec<3>& g) { need().setGravity(g); }
+  void setERP(double erp, double erp2 = 0) { need().setERP(erp, erp2); }
+  void setDefaultMaterial(double mu, double r = 0, double t = 0) { need().setDefaultMaterial(mu, r, t); }
+  void setContactSolverParam(double a0, double amin, double adec, int maxIter, double thr) { need().setContactSolverParam(a0, amin, adec, maxIter, thr); }
+  void integrate() { need().integrate(1); }
+  void integrate1() { need().integrate1(); }
+  void integrate2() { need().integrate2(); }
+
+ private:
+  BatchedWorld& need() { RSFATAL_IF(!shared_, "World: add the ArticulatedSystem before configuring the solver"); return *shared_; }
+  void applyPending() { if (dt_ > 0) shared_->setTimeStep(dt_); if (hasGround_) shared_->addGround(groundZ_); }
+  std::unique_ptr<BatchedWorld> owned_;
+  BatchedWorld* shared_ = nullptr;
+  int env_ = 0;
+  std::unique_ptr<ArticulatedSystem> robot_;
+  std::unique_ptr<HeightMap> hm_;
+  Ground ground_;
+  double dt_ = 0, groundZ_ = 0;
+  bool hasGround_ = false;
+};
+
+}  // namespace raisim

@@ -118,6 +118,12 @@ typedef struct rsb_contact {
   int32_t collision;   /* collision primitive index                            */
 } rsb_contact;
 
+/* resident state fields (row-major [N,dim] float32 unless noted) */
+typedef enum rsb_field {
+  RSB_F_GC = 0, RSB_F_GV = 1, RSB_F_PTARGET = 2, RSB_F_DTARGET = 3, RSB_F_TAU_FF = 4,
+  RSB_F_CONTACT_COUNT = 5, RSB_F_CONTACTS = 6, RSB_F_FLAGS = 7
+} rsb_field;
+
 typedef struct rsb_model rsb_model;  /* host-side parsed model           */
 typedef struct rsb_world rsb_world;  /* batched device world             */
 
@@ -168,6 +174,11 @@ int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size,
 int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t* mask, int space);
 int rsb_get_state(rsb_world* w, float* gc, float* gv, int space);
 
+/* one env's row of a state field (slow path behind the per-env raisim::ArticulatedSystem views):
+ * field = RSB_F_GC / RSB_F_GV / RSB_F_PTARGET / RSB_F_DTARGET / RSB_F_TAU_FF; data is a host pointer of dim floats */
+int rsb_set_env_row(rsb_world* w, int field, int env, const float* data);
+int rsb_get_env_row(rsb_world* w, int field, int env, float* data);
+
 int rsb_set_control_mode(rsb_world* w, int mode);
 int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd);      /* host, [nv] each  */
 int rsb_set_pd_target(rsb_world* w, const float* p_target, const float* d_target, int space); /* [N,nq],[N,nv]; either may be NULL */
@@ -201,11 +212,7 @@ int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, i
 int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_allowed, const float* gc0,
                          const float* gv0, int rows, uint8_t* done, int space);
 
-/* zero-copy access to the resident state (device pointers; row-major [N,dim] float32) */
-typedef enum rsb_field {
-  RSB_F_GC = 0, RSB_F_GV = 1, RSB_F_PTARGET = 2, RSB_F_DTARGET = 3, RSB_F_TAU_FF = 4,
-  RSB_F_CONTACT_COUNT = 5, RSB_F_CONTACTS = 6, RSB_F_FLAGS = 7
-} rsb_field;
+/* zero-copy access to the resident state (device pointers; row-major [N,dim] float32): see rsb_field */
 void* rsb_device_ptr(rsb_world* w, int field);
 
 /* elapsed device time (ms) of the most recent rsb_integrate launch, measured with HIP events

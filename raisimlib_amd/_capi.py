@@ -77,6 +77,8 @@ PROTOTYPES = {
     "rsb_set_heightmap": (_I, [_VP, _I, _I, _D, _D, _D, _D, _FP]),
     "rsb_set_state": (_I, [_VP, _FP, _FP, _FP, _I]),
     "rsb_get_state": (_I, [_VP, _FP, _FP, _I]),
+    "rsb_set_env_row": (_I, [_VP, _I, _I, _FP]),
+    "rsb_get_env_row": (_I, [_VP, _I, _I, _FP]),
     "rsb_set_control_mode": (_I, [_VP, _I]),
     "rsb_set_pd_gains": (_I, [_VP, _FP, _FP]),
     "rsb_set_pd_target": (_I, [_VP, _FP, _FP, _I]),

@@ -535,6 +535,38 @@ int rsb_get_state(rsb_world* w, float* gc, float* gv, int space) {
   return RSB_OK;
 }
 
+static int env_row(rsb_world* w, int field, int env, float** base, size_t* dim) {
+  if (!w || env < 0 || env >= w->N) { rsb::set_error("env row: env index out of range"); return RSB_E_INVALID; }
+  switch (field) {
+    case RSB_F_GC: *base = w->d_gc; *dim = w->blob.nq; break;
+    case RSB_F_GV: *base = w->d_gv; *dim = w->blob.nv; break;
+    case RSB_F_PTARGET: *base = w->d_pt; *dim = w->blob.nq; break;
+    case RSB_F_DTARGET: *base = w->d_dt; *dim = w->blob.nv; break;
+    case RSB_F_TAU_FF: *base = w->d_tff; *dim = w->blob.nv; break;
+    default: rsb::set_error("env row: unsupported field"); return RSB_E_INVALID;
+  }
+  return RSB_OK;
+}
+int rsb_set_env_row(rsb_world* w, int field, int env, const float* data) {
+  float* base; size_t dim;
+  int st = env_row(w, field, env, &base, &dim);
+  if (st != RSB_OK || !data) return st != RSB_OK ? st : RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipMemcpyAsync(base + (size_t)env * dim, data, dim * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  w->integrate1_valid = false;
+  return RSB_OK;
+}
+int rsb_get_env_row(rsb_world* w, int field, int env, float* data) {
+  float* base; size_t dim;
+  int st = env_row(w, field, env, &base, &dim);
+  if (st != RSB_OK || !data) return st != RSB_OK ? st : RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipMemcpyAsync(data, base + (size_t)env * dim, dim * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  return RSB_OK;
+}
+
 int rsb_set_control_mode(rsb_world* w, int mode) {
   if (!w || (mode != RSB_FORCE_AND_TORQUE && mode != RSB_PD_PLUS_FEEDFORWARD_TORQUE)) { rsb::set_error("rsb_set_control_mode: unknown mode"); return RSB_E_INVALID; }
   w->control_mode = mode;

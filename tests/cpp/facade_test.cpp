@@ -1,0 +1,86 @@
+// Compiles against include/raisim/*.hpp only (the way an upstream Environment.hpp would) and links librsb.so.
+// Exercises: per-env raisim::World (N = 1 replica), ArticulatedSystem views, integrate1/2 queries, contacts,
+// and the batched VectorizedEnvironment.  Exit code 0 = all checks passed.
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+#include "raisim/VectorizedEnvironment.hpp"
+#include "raisim/World.hpp"
+
+#define CHECK(c) do { if (!(c)) { std::printf("CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 2) { std::printf("usage: facade_test <urdf>\n"); return 2; }
+  const std::string urdf = argv[1];
+  try {
+    // ---- the upstream single-env pattern (what an rsg_anymal Environment.hpp does)
+    raisim::World world;
+    world.setTimeStep(0.0025);
+    auto* anymal = world.addArticulatedSystem(urdf);
+    world.addGround();
+    anymal->setName("anymal");
+    const int gcDim = (int)anymal->getGeneralizedCoordinateDim(), gvDim = (int)anymal->getDOF();
+    CHECK(gcDim == 19 && gvDim == 18);
+    raisim::VecDyn gc(gcDim), gv(gvDim), pT(gcDim), dT(gvDim), kp(gvDim), kd(gvDim);
+    const double nominal[12] = {0.03, 0.4, -0.8, -0.03, 0.4, -0.8, 0.03, -0.4, 0.8, -0.03, -0.4, 0.8};
+    gc[2] = 0.57; gc[3] = 1.0;
+    for (int j = 0; j < 12; ++j) { gc[7 + j] = nominal[j]; kp[6 + j] = 400.0; kd[6 + j] = 10.0; }
+    pT = gc.v;
+    anymal->setState(gc, gv);
+    anymal->setControlMode(raisim::ControlMode::PD_PLUS_FEEDFORWARD_TORQUE);
+    anymal->setPdGains(kp, kd);
+    anymal->setPdTarget(pT, dT);
+    world.integrate1();
+    const auto& M = anymal->getMassMatrix();
+    CHECK(std::fabs(M(0, 0) - anymal->getTotalMass()) < 1e-3 && std::fabs(M(3, 7) - M(7, 3)) < 1e-6);
+    const auto& h = anymal->getNonlinearities();
+    CHECK(std::fabs(h[2] - anymal->getTotalMass() * 9.81) < 1e-2);
+    world.integrate2();
+    for (int i = 0; i < 799; ++i) world.integrate();
+    CHECK(std::fabs(world.getWorldTime() - 2.0) < 1e-9);
+    auto& contacts = anymal->getContacts();
+    CHECK(contacts.size() == 4);
+    double fz = 0;
+    for (auto& c : contacts) { fz += c.getImpulse()[2] / world.getTimeStep(); CHECK(c.getlocalBodyIndex() % 3 == 0); }
+    CHECK(std::fabs(fz / (anymal->getTotalMass() * 9.81) - 1.0) < 0.05);
+    const auto& q = anymal->getGeneralizedCoordinate();
+    CHECK(q[2] > 0.45 && q[2] < 0.62);
+    raisim::Mat<3, 3> rot;
+    anymal->getBaseOrientation(rot);
+    CHECK(rot(2, 2) > 0.99);
+    std::printf("single-env World: z=%.3f fz/mg=%.3f contacts=%zu\n", q[2], fz / (anymal->getTotalMass() * 9.81), contacts.size());
+
+    // ---- the batched vectorised environment (one fused launch per step for all envs)
+    raisim::VecEnvConfig cfg;
+    cfg.num_envs = 512;
+    cfg.gc_init.assign(19, 0.0);
+    cfg.gc_init[2] = 0.57; cfg.gc_init[3] = 1.0;
+    for (int j = 0; j < 12; ++j) cfg.gc_init[7 + j] = nominal[j];
+    raisim::VectorizedEnvironment env(urdf, cfg);
+    env.init();
+    CHECK(env.getObDim() == 34 && env.getActionDim() == 12 && env.getNumOfEnvs() == 512);
+    std::vector<float> ob((size_t)512 * 34), act((size_t)512 * 12, 0.f), rew(512);
+    std::unique_ptr<bool[]> done(new bool[512]);
+    unsigned s = 12345u;
+    int resets = 0;
+    for (int it = 0; it < 50; ++it) {
+      for (auto& a : act) { s = s * 1664525u + 1013904223u; a = ((s >> 8) / 16777216.0f - 0.5f) * 2.0f; }
+      env.step(act.data(), 512, 12, rew.data(), done.get());
+      for (int e = 0; e < 512; ++e) resets += done[e] ? 1 : 0;
+    }
+    env.observe(ob.data(), 512, 34);
+    for (int e = 0; e < 512; ++e) {
+      CHECK(std::isfinite(ob[(size_t)e * 34]) && ob[(size_t)e * 34] > 0.2f && ob[(size_t)e * 34] < 0.7f);
+      CHECK(ob[(size_t)e * 34 + 3] > 0.5f);  // body z-axis still points up
+      CHECK(std::isfinite(rew[e]));
+    }
+    std::printf("VectorizedEnvironment: 50 control steps x 512 envs, %d resets, mean height %.3f\n", resets, ob[0]);
+  } catch (const std::exception& e) {
+    std::printf("exception: %s\n", e.what());
+    return 1;
+  }
+  std::printf("facade_test OK\n");
+  return 0;
+}

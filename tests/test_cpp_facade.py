@@ -1,0 +1,34 @@
+"""The C++ host side (include/raisim/*.hpp) compiles with plain g++ against the C-ABI; on a GPU it runs."""
+import os
+import subprocess
+
+import pytest
+
+from common import ROOT
+
+BIN = os.path.join(ROOT, "tests", "cpp", "_build", "facade_test")
+URDF = os.path.join(ROOT, "raisimlib_amd", "rsc", "anymal_c_like.urdf")
+
+
+def compile_facade():
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    lib = os.path.join(ROOT, "raisimlib_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", BIN,
+                    os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-L", lib, "-lrsb", f"-Wl,-rpath,{lib}"],
+                   check=True)
+
+
+def test_facade_compiles_with_gxx_and_fails_loudly_without_gpu(built_lib):
+    compile_facade()
+    if built_lib.rsb_device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu test")
+    r = subprocess.run([BIN, URDF], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_facade_runs_on_gpu(built_lib):
+    compile_facade()
+    r = subprocess.run([BIN, URDF], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "facade_test OK" in r.stdout
