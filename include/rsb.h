@@ -159,6 +159,10 @@ int rsb_set_erp(rsb_world* w, double erp);
 int rsb_set_friction(rsb_world* w, double mu);
 int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min,
                                  double alpha_decay, int max_iter, double threshold);
+/* Stagnation exit of the contact solver (not a RaiSim parameter): the Gauss-Seidel loop of an env stops when the
+ * best relative error of the last `window` sweeps is not below `factor` x the best of the previous window
+ * (defaults 10, 0.5; window = 0 disables it and only max_iter caps non-converging solves). */
+int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
 int rsb_set_max_contacts(rsb_world* w, int kmax);   /* 1..RSB_MAX_CONTACTS */
 /* Kernel mapping knob: lanes of a wavefront that cooperate on one env (16, 32 or 64).
  * 64 = the north star's "one wavefront per env"; 0 = pick the measured-fastest default. */
@@ -193,7 +197,8 @@ int rsb_get_contacts(rsb_world* w, int32_t* counts, rsb_contact* contacts, int s
 /* valid after rsb_integrate1: M [N,nv,nv], h [N,nv] */
 int rsb_get_mass_matrix(rsb_world* w, float* M, int space);
 int rsb_get_nonlinearities(rsb_world* w, float* h, int space);
-/* per-env status flags of the last step (bit0: contact overflow, bit1: non-finite state) */
+/* per-env status flags of the last launch (bit0: contact overflow, bit1: non-finite state, bit2: the contact
+ * solver of the last sub-step stopped without meeting the convergence test: max_iter or stagnation exit) */
 int rsb_get_flags(rsb_world* w, int32_t* flags, int space);
 /* iterations the contact solver used in the last sub-step, [N] int32 */
 int rsb_get_solver_iterations(rsb_world* w, int32_t* iters, int space);

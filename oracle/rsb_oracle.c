@@ -280,6 +280,8 @@ void orc_default_params(orc_params* p) {
   p->threshold = 1e-5;
   p->max_iter = 150;
   p->section_rounds = 5;
+  p->stall_window = 10;
+  p->stall_factor = 0.5;
   p->kmax = 8;
   p->control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   p->terrain_type = 0;
@@ -672,7 +674,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
      * A RELATIVE criterion on purpose: the device evaluates the same test in fp32, where the rounding
      * noise of an impulse update is proportional to the impulse magnitudes (RaiSim's absolute fp64
      * threshold [RECALL] cannot be met in fp32). */
-    double alpha = p->alpha_init;
+    /* Stagnation exit: redundant contact sets (several contacts on one link of a crouched robot) make the
+     * sweep cycle or crawl; the iteration is cut when the best relative error of the last `stall_window`
+     * sweeps is not below `stall_factor` x the best of the window before.  Such solves would otherwise run to
+     * max_iter without converging; on a lock-step GPU launch that worst case sets the launch time. */
+    double alpha = p->alpha_init, best_prev = 1e300, best_cur = 1e300;
+    int converged = 0;
     for (int it = 0; it < p->max_iter; ++it) {
       double err = 0, scale = 0;
       for (int i = 0; i < nc; ++i) {
@@ -692,8 +699,15 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       it_used = it + 1;
       alpha = alpha * p->alpha_decay;
       if (alpha < p->alpha_min) alpha = p->alpha_min;
-      if (err <= p->threshold * (scale + ORC_LAMBDA_FLOOR)) break;
+      if (err <= p->threshold * (scale + ORC_LAMBDA_FLOOR)) { converged = 1; break; }
+      double rel = err / (scale + ORC_LAMBDA_FLOOR);
+      if (rel < best_cur) best_cur = rel;
+      if (p->stall_window > 0 && (it + 1) % p->stall_window == 0) {
+        if (best_cur > p->stall_factor * best_prev) break;
+        best_prev = best_cur; best_cur = 1e300;
+      }
     }
+    if (!converged) fl |= 4;
     if (dbglam) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) dbglam[3 * i + r] = lam[i][r];
   }
 

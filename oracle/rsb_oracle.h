@@ -37,8 +37,9 @@ typedef struct orc_params {
   int32_t kmax;
   int32_t control_mode;      /* rsb_control_mode */
   int32_t terrain_type;      /* 0 = plane, 1 = heightmap */
-  int32_t hm_xs, hm_ys, pad_;
+  int32_t hm_xs, hm_ys, stall_window;  /* stagnation exit of the contact solver: window (sweeps), 0 = off */
   double ground_z;
+  double stall_factor;       /* ... and required improvement factor per window */
   double hm_xsize, hm_ysize, hm_cx, hm_cy;
   const float* hm_heights;   /* [ys][xs], x fastest */
 } orc_params;
@@ -86,7 +87,8 @@ void orc_actuation(const rsb_model_blob* m, const orc_params* p, const double* q
                    const double* d_target, const double* tau_ff, double* tau);
 
 /* one World::integrate(): q,u updated in place.  contacts has room for p->kmax entries.
- * flags bit0: contact overflow (more than kmax), bit1: non-finite state. */
+ * flags bit0: contact overflow (more than kmax), bit1: non-finite state, bit2: contact solver stopped
+ * without meeting the convergence test (max_iter or stagnation exit). */
 void orc_step(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
               const double* kd, const double* p_target, const double* d_target,
               const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,

@@ -33,6 +33,10 @@ def build(force=False, verbose=True, extra_flags=()):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function",
+           # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles
+           # than it saves and pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed
+           # at the stated parity tolerance (2.5 ulp hardware approximations + Newton step instead)
+           "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
            *extra_flags, "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

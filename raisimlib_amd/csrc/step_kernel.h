@@ -101,7 +101,8 @@ struct StepArgs {
   int N, nsub, kmax, control_mode;
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
-  int max_iter, section_rounds;
+  int max_iter, section_rounds, stall_window;
+  float stall_factor;
   int terrain_type, hm_xs, hm_ys;
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
   LdsLayout L;
@@ -761,8 +762,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         }
         float lamn_all[KMAX];  // every lane tracks all normal impulses of its env (for the relative test)
         RSB_UNROLL for (int j = 0; j < KMAX; ++j) lamn_all[j] = 0.f;
-        float alpha = a.alpha_init;
-        bool done = (nc == 0);
+        float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
+        bool done = (nc == 0), converged = (nc == 0);
+        int wcount = 0;
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
           static_for<0, KMAX>([&](auto jc) {
@@ -804,11 +806,20 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           if (!done) {
             ++iters_used;
             alpha = fmaxf(alpha * a.alpha_decay, a.alpha_min);
-            // relative (fp32-aware) test, identical to the oracle's: see rsb_oracle.c
-            if (err <= a.threshold * (scale + kLambdaFloor)) done = true;
+            // relative (fp32-aware) test and stagnation exit, identical to the oracle's: see rsb_oracle.c
+            if (err <= a.threshold * (scale + kLambdaFloor)) { done = true; converged = true; }
+            else {
+              best_cur = fminf(best_cur, err / (scale + kLambdaFloor));
+              if (a.stall_window > 0 && ++wcount == a.stall_window) {
+                wcount = 0;
+                if (best_cur > a.stall_factor * best_prev) done = true;
+                best_prev = best_cur; best_cur = 3e38f;
+              }
+            }
           }
           if (!__any(!done)) break;
         }
+        if (!converged) flag |= 4;
         if (isc) { LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2]; }
       }
       __syncthreads();

@@ -121,6 +121,9 @@ class BatchedWorld:
         check(self.L.rsb_set_contact_solver_param(self.handle, float(alpha_init), float(alpha_min), float(alpha_decay),
                                                   int(max_iter), float(threshold)), "rsb_set_contact_solver_param")
 
+    def set_solver_stagnation_exit(self, window, factor):
+        check(self.L.rsb_set_solver_stagnation_exit(self.handle, int(window), float(factor)), "rsb_set_solver_stagnation_exit")
+
     def set_max_contacts(self, kmax):
         check(self.L.rsb_set_max_contacts(self.handle, int(kmax)), "rsb_set_max_contacts")
 

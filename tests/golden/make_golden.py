@@ -48,7 +48,7 @@ def main():
             G[:n3, :n3] = d["G"]; c[:n3] = d["c"]; lam[:n3] = d["lam"]
             probs.append((e, n3, G, c, lam))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "anymal_golden.npz"),
-                        gc=gc, gv=gv, pt=pt, q1=r["q"], u1=r["u"], n_contacts=r["n_contacts"], iters=r["iters"],
+                        gc=gc, gv=gv, pt=pt, q1=r["q"], u1=r["u"], n_contacts=r["n_contacts"], iters=r["iters"], flags=r["flags"],
                         M=M, h=h, traj=np.array(traj),
                         prob_env=np.array([p[0] for p in probs]), prob_n3=np.array([p[1] for p in probs]),
                         prob_G=np.array([p[2] for p in probs]), prob_c=np.array([p[3] for p in probs]),

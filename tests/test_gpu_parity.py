@@ -48,7 +48,7 @@ def run_one_step(model, gc, gv, pt, kp, kd, lpe=0, kmax=8, substeps=1, heightmap
 
 def check_step(dev, ref, max_iter=150, du_tol=2e-4):
     assert np.array_equal(dev["cnt"], ref["n_contacts"])
-    conv = ref["iters"] < max_iter
+    conv = (ref["flags"] & 4) == 0          # oracle met its convergence test (no max_iter / stagnation exit)
     assert conv.mean() > 0.9
     eq = np.abs(dev["q"] - ref["q"])
     eu = np.abs(dev["u"] - ref["u"]).max(axis=1)
@@ -79,7 +79,7 @@ def test_lanes_per_env_mappings_agree(anymal):
     gc, gv = standing_states(256, seed=7)
     kp, kd = workload.anymal_gains()
     outs = [run_one_step(anymal, gc, gv, gc, kp, kd, lpe=lpe) for lpe in (16, 32, 64)]
-    conv = outs[0][1]["iters"] < 150
+    conv = (outs[0][1]["flags"] & 4) == 0
     for o2, _, _ in outs[1:]:
         assert np.array_equal(outs[0][0]["cnt"], o2["cnt"])
         assert np.abs(outs[0][0]["q"] - o2["q"])[conv].max() < 1e-6
@@ -94,7 +94,7 @@ def test_golden_fixture_parity(anymal):
     kp, kd = workload.anymal_gains()
     dev, _, _ = run_one_step(anymal, g["gc"], g["gv"], g["pt"], kp, kd)
     assert np.array_equal(dev["cnt"], g["n_contacts"])
-    conv = g["iters"] < 150
+    conv = (g["flags"] & 4) == 0
     assert np.abs(dev["q"] - g["q1"])[conv].max() < 3e-6
     assert (np.abs(dev["u"] - g["u1"]).max(axis=1) / (1 + np.abs(g["u1"]).max(axis=1)))[conv].max() < 2e-4
 
@@ -110,7 +110,7 @@ def test_contact_problem_parity(anymal):
     checked = 0
     for e in range(64):
         d = o.step_debug(f32(gc[e]), f32(gv[e]), kp.astype(np.float64), kd.astype(np.float64), f32(gc[e]), dtg[e])
-        if len(d["c"]) == 0 or d["iters"] >= 150:
+        if len(d["c"]) == 0 or (d["flags"] & 4):
             continue
         w.set_pd_target(gc, dtg); w.set_state(gc, gv); w.debug_select_env(e); w.integrate(1)
         nc, G, c, lam = w.debug_contact_problem()
@@ -130,7 +130,7 @@ def test_contacts_report(anymal):
     gc, gv = standing_states(256, seed=5)
     kp, kd = workload.anymal_gains()
     dev, ref, _ = run_one_step(anymal, gc, gv, gc, kp, kd)
-    conv = ref["iters"] < 150
+    conv = (ref["flags"] & 4) == 0
     for e in np.where(conv & (ref["n_contacts"] > 0))[0][:60]:
         n = ref["n_contacts"][e]
         d, r = dev["con"][e][:n], ref["contacts"][e][:n]
@@ -215,7 +215,7 @@ def test_atlas_one_step_parity(atlas):
     dev, ref, _ = run_one_step(atlas, gc, gv, gc, kp, kd, kmax=16)
     assert ref["n_contacts"].sum() > 300
     assert np.array_equal(dev["cnt"], ref["n_contacts"])
-    conv = ref["iters"] < 150
+    conv = (ref["flags"] & 4) == 0
     eu = np.abs(dev["u"] - ref["u"]).max(axis=1) / (1 + np.abs(ref["u"]).max(axis=1))
     assert np.all(eu[conv] < 5e-3) and np.median(eu) < 5e-4
     assert np.abs(dev["q"] - ref["q"])[conv].max() < 5e-5

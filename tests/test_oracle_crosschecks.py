@@ -118,7 +118,7 @@ def test_contact_solution_satisfies_the_per_contact_conditions(anymal):
     mu = 0.8
     for e in range(60):
         d = o.step_debug(gc[e], gv[e], kp.astype(float), kd.astype(float), gc[e], np.zeros(18))
-        if d["iters"] >= o.p.max_iter or len(d["c"]) == 0:
+        if (d["flags"] & 4) or len(d["c"]) == 0:
             continue
         G, lam = d["G"], d["lam"]
         v = d["c"] + G @ lam
