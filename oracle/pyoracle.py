@@ -21,6 +21,7 @@ class Params(C.Structure):
         ("alpha_init", C.c_double), ("alpha_min", C.c_double), ("alpha_decay", C.c_double),
         ("threshold", C.c_double),
         ("max_iter", C.c_int32), ("section_rounds", C.c_int32), ("kmax", C.c_int32), ("control_mode", C.c_int32),
+        ("warm_start", C.c_int32), ("pad0_", C.c_int32),
         ("terrain_type", C.c_int32), ("hm_xs", C.c_int32), ("hm_ys", C.c_int32), ("stall_window", C.c_int32),
         ("ground_z", C.c_double), ("stall_factor", C.c_double),
         ("hm_xsize", C.c_double), ("hm_ysize", C.c_double), ("hm_cx", C.c_double), ("hm_cy", C.c_double),
@@ -155,7 +156,7 @@ class Oracle:
                         _p(_d(dt_)), _p(_d(tau_ff)), _p(con), C.byref(nc), C.byref(it), C.byref(fl))
         return q, u, con[:nc.value], it.value, fl.value
 
-    def step_debug(self, q, u, kp=None, kd=None, pt=None, dt_=None, tau_ff=None):
+    def step_debug(self, q, u, kp=None, kd=None, pt=None, dt_=None, tau_ff=None, lam_warm=None):
         """As step(), plus the contact problem (G [3nc,3nc], c [3nc], lam [3nc]) in contact-frame coordinates."""
         q = np.array(q, dtype=np.float64).copy()
         u = np.array(u, dtype=np.float64).copy()
@@ -167,13 +168,17 @@ class Oracle:
         nc, it, fl = C.c_int32(), C.c_int32(), C.c_int32()
         self.L.orc_step_debug(C.byref(self.blob), C.byref(self.p), _p(q), _p(u), _p(_d(kp)), _p(_d(kd)), _p(_d(pt)),
                               _p(_d(dt_)), _p(_d(tau_ff)), _p(con), C.byref(nc), C.byref(it), C.byref(fl),
-                              _p(G), _p(c), _p(lam))
+                              _p(lam_warm), _p(G), _p(c), _p(lam))
         n3 = 3 * nc.value
         return dict(q=q, u=u, contacts=con[:nc.value], iters=it.value, flags=fl.value,
                     G=G[:n3 * n3].reshape(n3, n3).copy(), c=c[:n3].copy(), lam=lam[:n3].copy())
 
+    def new_warm_state(self, n):
+        """Zeroed warm-start state for n envs ([n, 3*ncol] float64), to be passed to step_batch(lam_warm=...)."""
+        return np.zeros((n, 3 * self.blob.ncol))
+
     def step_batch(self, q, u, substeps=1, kp=None, kd=None, pt=None, dt_=None, tau_ff=None, nthreads=0,
-                   want_contacts=False):
+                   want_contacts=False, lam_warm=None):
         """N envs x `substeps` integrate() calls (OpenMP over envs). q,u: [N,nq],[N,nv] float64, updated copies
         are returned."""
         q = np.ascontiguousarray(q, dtype=np.float64).copy()
@@ -186,7 +191,7 @@ class Oracle:
         fls = np.zeros(N, dtype=np.int32)
         used = self.L.orc_step_batch(C.byref(self.blob), C.byref(self.p), C.c_int(N), C.c_int(substeps), _p(q), _p(u),
                                      _p(_d(kp)), _p(_d(kd)), _p(_d(pt)), _p(_d(dt_)), _p(_d(tau_ff)), _p(con),
-                                     _p(ncs), _p(its), _p(fls), C.c_int(nthreads))
+                                     _p(ncs), _p(its), _p(fls), _p(lam_warm), C.c_int(nthreads))
         out = dict(q=q, u=u, n_contacts=ncs, iters=its, flags=fls, threads=used)
         if want_contacts:
             out["contacts"] = con

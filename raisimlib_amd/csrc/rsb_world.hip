@@ -148,7 +148,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.t_gain = take(2 * b.nb);
   L.t_parlv = take(b.nb);
   L.t_anc = take(b.nb * b.depth);
-  L.t_dir = take(32);
+  L.t_dir = take(64);
   L.shared_total = o;
   o = 0;
   L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
@@ -765,12 +765,23 @@ int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, fl
 int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16) {
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  if (enable && !w->d_prof) { HIP_TRY(hipMalloc(&w->d_prof, 16 * sizeof(long long))); HIP_TRY(hipMemset(w->d_prof, 0, 16 * sizeof(long long))); }
+  const size_t nprof = 16 + 4 * (size_t)w->N;  // 16 phase stamps + 4 words per workgroup (upper bound: one env per wave)
+  if (enable && !w->d_prof) { HIP_TRY(hipMalloc(&w->d_prof, nprof * sizeof(long long))); HIP_TRY(hipMemset(w->d_prof, 0, nprof * sizeof(long long))); }
   if (out16 && w->d_prof) {
     HIP_TRY(hipMemcpyAsync(out16, w->d_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
   }
   if (!enable && w->d_prof) { HIP_TRY(hipStreamSynchronize(w->stream)); HIP_TRY(hipFree(w->d_prof)); w->d_prof = nullptr; }
+  return RSB_OK;
+}
+
+// per-workgroup profile of the last launch: out [4 * n_blocks] = {total cycles, Gauss-Seidel cycles, sum over
+// sub-steps of the wave's max sweep count, max contact count}
+int rsb_debug_wave_profile(rsb_world* w, long long* out, int n_blocks) {
+  if (!w || !out || !w->d_prof || n_blocks > w->N) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipMemcpyAsync(out, w->d_prof + 16, 4 * (size_t)n_blocks * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
+  HIP_TRY(hipStreamSynchronize(w->stream));
   return RSB_OK;
 }
 

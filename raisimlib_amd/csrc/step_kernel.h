@@ -235,17 +235,19 @@ __device__ __forceinline__ float row_bcast(float x) {
 }
 
 // Cooperative slip solve: all lanes of the env group hold the same (G, v, ls); lane (s & 15) evaluates
-// candidate (s & 15) of every round.  DIR16 = 16 unit vectors 22.5 deg apart (cos[16], sin[16]) in LDS.
+// candidate (s & 15) of every round.  (c16, s16) = this lane's round-0 direction (22.5 deg grid); BR16[k] =
+// {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).
 template <int LPE>
 __device__ __forceinline__ void slip_search(const float* G, const float* v, const float* ls, float mu, int rounds,
-                                            int s, int el, const float* DIR16, float* lam) {
+                                            int s, int el, float c16, float s16, const float* BR16, float* lam) {
   const int k = s & 15;
   // round 0: global energy minimum over 16 directions
-  const float e0 = slip_E(G, v, ls, mu, DIR16[k], DIR16[16 + k]);
+  const float e0 = slip_E(G, v, ls, mu, c16, s16);
   const unsigned key = (__float_as_uint(e0) & ~15u) | (unsigned)k;
   const int kbest = (int)(row_min_u32(key) & 15u);
-  float lox = DIR16[(kbest + 15) & 15], loy = DIR16[16 + ((kbest + 15) & 15)];
-  float hix = DIR16[(kbest + 1) & 15], hiy = DIR16[16 + ((kbest + 1) & 15)];
+  float br[4];
+  ld4(BR16 + 4 * kbest, br);
+  float lox = br[0], loy = br[1], hix = br[2], hiy = br[3];
   const float t = (float)((k < 15 ? k : 14) + 1) * (1.0f / 16.0f);
   for (int r = 0; r < rounds; ++r) {
     const float ex = hix - lox, ey = hiy - loy;
@@ -255,20 +257,14 @@ __device__ __forceinline__ void slip_search(const float* G, const float* v, cons
     const float h = slip_dE(G, v, mu, cx, cy);
     const unsigned long long bal = __ballot(h >= 0.f && k < 15);
     // every 16-lane row of the group holds the same candidates; use the group's first row
-    const unsigned gm = (unsigned)((bal >> (el * LPE)) & 0x7fffull);
+    const unsigned gm = (unsigned)(bal >> (el * LPE)) & 0x7fffu;
     const int kstar = gm ? (__ffs((int)gm) - 1) : 15;
-    if (kstar < 15) {
-      const float th = (float)(kstar + 1) * (1.0f / 16.0f);
-      float x = lox + th * ex, y = loy + th * ey;
-      const float iv = __builtin_amdgcn_rsqf(x * x + y * y);
-      hix = x * iv; hiy = y * iv;
-    }
-    if (kstar > 0) {
-      const float tl = (float)kstar * (1.0f / 16.0f);
-      float x = lox + tl * ex, y = loy + tl * ey;
-      const float iv = __builtin_amdgcn_rsqf(x * x + y * y);
-      lox = x * iv; loy = y * iv;
-    }
+    // new bracket = candidates kstar-1 / kstar (kept as old lo / hi at the ends); recomputed, not exchanged
+    const float tl = (float)kstar * (1.0f / 16.0f), th = tl + (1.0f / 16.0f);
+    float xl = lox + tl * ex, yl = loy + tl * ey, xh = lox + th * ex, yh = loy + th * ey;
+    const float il = __builtin_amdgcn_rsqf(xl * xl + yl * yl), ih = __builtin_amdgcn_rsqf(xh * xh + yh * yh);
+    if (kstar < 15) { hix = xh * ih; hiy = yh * ih; }
+    if (kstar > 0) { lox = xl * il; loy = yl * il; }
   }
   float x = lox + hix, y = loy + hiy;
   const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
@@ -345,7 +341,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   float* GAIN = lds + L.t_gain;                                  // [nb][2] kp, kd of the body's joint
   int* PARLV = reinterpret_cast<int*>(lds + L.t_parlv);          // [nb] (parent+1) | level << 8
   int* ANC = reinterpret_cast<int*>(lds + L.t_anc);              // [nb*depth]
-  float* DIR16 = lds + L.t_dir;                                  // cos[16], sin[16]
+  float* DIR16 = lds + L.t_dir;                                  // float4 [16] slip-search brackets
   float* E = lds + L.shared_total + el * L.per_env;
   float* Q = E + L.q;
   float* U = E + L.u;
@@ -373,11 +369,16 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     GAIN[2 * i + 1] = pd ? a.kd[i + 5] : 0.f;
   }
   for (int i = lane; i < nb * depth; i += 64) ANC[i] = m.anc[i];
-  if (lane < 16) {
-    float sn, cs;
-    sincospif((float)lane * 0.125f, &sn, &cs);
-    DIR16[lane] = cs; DIR16[16 + lane] = sn;
+  if (lane < 16) {  // BR16[k] = {cos,sin((k-1) pi/8), cos,sin((k+1) pi/8)}: slip-search bracket around grid point k
+    float sn, cs, br[4];
+    sincospif((float)((lane + 15) & 15) * 0.125f, &sn, &cs);
+    br[0] = cs; br[1] = sn;
+    sincospif((float)((lane + 1) & 15) * 0.125f, &sn, &cs);
+    br[2] = cs; br[3] = sn;
+    st4(DIR16 + 4 * lane, br);
   }
+  float c16, s16;  // this lane's round-0 candidate direction of the slip search
+  sincospif((float)(lane & 15) * 0.125f, &s16, &c16);
 
   // ---- per-lane chain description (lane s = chain s)
   const bool hasch = s < nch;
@@ -397,6 +398,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     TF[i] = a.tauff[(size_t)env * nv + i];
   }
   int flag = 0, iters_used = 0, nc = 0;
+  long long t_start = 0, t_gs = 0; int p_iters = 0, p_ncw = 0;
+  if (a.prof) t_start = clock64();
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
   __syncthreads();
@@ -739,6 +742,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
       RSB_STAMP(5)
 
+      long long t_gs0 = 0; if (a.prof) t_gs0 = clock64();
       // ========================= per-contact Gauss-Seidel (lane = contact) ==========================
       // Lane j (< nc) owns contact j: its G rows, own block, velocity and impulse stay in registers.  Per
       // contact update the owner solves open/stick; the slip case is searched by the whole 16-lane row; the
@@ -762,40 +766,42 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         }
         float lamn_all[KMAX];  // every lane tracks all normal impulses of its env (for the relative test)
         RSB_UNROLL for (int j = 0; j < KMAX; ++j) lamn_all[j] = 0.f;
+        const float mu2 = a.mu * a.mu;
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
+          const bool active = isc && !done;
           static_for<0, KMAX>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (j < ncw) {  // wave-uniform
-              const bool mine = (s == j) && isc && !done;
-              bool need = false;
-              float ln[3] = {0.f, 0.f, 0.f}, vex[3] = {0.f, 0.f, 0.f}, ls[3] = {0.f, 0.f, 0.f};
-              if (mine) {
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                  vex[rr] = v[rr] - (Gii[3 * rr] * lam[0] + Gii[3 * rr + 1] * lam[1] + Gii[3 * rr + 2] * lam[2]);
-                if (!(vex[2] > 0.f)) {
-                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                    ls[rr] = -(Ginv[3 * rr] * vex[0] + Ginv[3 * rr + 1] * vex[1] + Ginv[3 * rr + 2] * vex[2]);
-                  const float lt2 = ls[0] * ls[0] + ls[1] * ls[1];
-                  if (ls[2] >= 0.f && lt2 <= a.mu * a.mu * ls[2] * ls[2]) { ln[0] = ls[0]; ln[1] = ls[1]; ln[2] = ls[2]; }
-                  else need = true;
-                }
-              }
+              // open / stick candidates: every lane evaluates its own contact branch-free, lane j's result is used
+              const bool mine = (s == j) && active;
+              float vex[3], ls[3];
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+                vex[rr] = v[rr] - (Gii[3 * rr] * lam[0] + Gii[3 * rr + 1] * lam[1] + Gii[3 * rr + 2] * lam[2]);
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+                ls[rr] = -(Ginv[3 * rr] * vex[0] + Ginv[3 * rr + 1] * vex[1] + Ginv[3 * rr + 2] * vex[2]);
+              const bool open = vex[2] > 0.f;
+              const bool stick = !open && ls[2] >= 0.f && (ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2];
+              const bool need = mine && !open && !stick;
+              float ln[3];
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
               if (__any(need)) {
                 float Gb[9], vb[3], lb[3], lsl[3];
                 RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gb[q2] = row_bcast<j>(Gii[q2]);
-                RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) { vb[q2] = row_bcast<j>(vex[q2]); lb[q2] = row_bcast<j>(ls[q2]); }
-                slip_search<LPE>(Gb, vb, lb, a.mu, a.section_rounds, s, el, DIR16, lsl);
-                if (need) { ln[0] = lsl[0]; ln[1] = lsl[1]; ln[2] = lsl[2]; }
+                RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) vb[q2] = row_bcast<j>(vex[q2]);
+                lb[0] = row_bcast<j>(ls[0]); lb[1] = row_bcast<j>(ls[1]); lb[2] = 0.f;
+                slip_search<LPE>(Gb, vb, lb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, lsl);
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = need ? lsl[rr] : ln[rr];
               }
-              float dl[3] = {0.f, 0.f, 0.f};
-              if (mine) {
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { dl[rr] = alpha * (ln[rr] - lam[rr]); lam[rr] += dl[rr]; }
+              float dl[3];
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+                dl[rr] = mine ? alpha * (ln[rr] - lam[rr]) : 0.f;
+                lam[rr] += dl[rr];
+                dl[rr] = row_bcast<j>(dl[rr]);
               }
-              dl[0] = row_bcast<j>(dl[0]); dl[1] = row_bcast<j>(dl[1]); dl[2] = row_bcast<j>(dl[2]);
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
                 v[rr] += Grow[rr][3 * j] * dl[0] + Grow[rr][3 * j + 1] * dl[1] + Grow[rr][3 * j + 2] * dl[2];
               err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
@@ -823,6 +829,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         if (isc) { LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2]; }
       }
       __syncthreads();
+      if (a.prof) { t_gs += clock64() - t_gs0; int itw = iters_used; RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) itw = max(itw, __shfl_xor(itw, off)); p_iters += itw; p_ncw = max(p_ncw, ncw); }
       if (a.dbg && env == a.dbg_env && env_valid && s == 0) {
         const int n3 = 3 * nc;
         a.dbg[0] = (float)nc;
@@ -921,6 +928,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
+  if (a.prof && lane == 0) { long long* P = a.prof + 16 + 4 * (long long)blockIdx.x; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; }
   // ---- results: LDS -> HBM
   if (env_valid) {
     bool bad = false;

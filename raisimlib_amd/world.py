@@ -275,3 +275,9 @@ class BatchedWorld:
         check(self.L.rsb_debug_phase_cycles(self.handle, 1 if enable else 0, _hp(out) if read else None),
               "rsb_debug_phase_cycles")
         return out
+
+    def debug_wave_profile(self):
+        nb = (self.N * self.lanes_per_env() + 63) // 64
+        out = np.zeros((nb, 4), np.int64)
+        check(self.L.rsb_debug_wave_profile(self.handle, _hp(out), nb), "rsb_debug_wave_profile")
+        return out
