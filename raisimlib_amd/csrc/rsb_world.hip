@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -305,6 +306,9 @@ int do_integrate(rsb_world* w, int nsub) {
   }
   a.L = make_layout(w->blob, kcap);
   const size_t lds_bytes = lds_bytes_for(w->blob, kcap, lpe);
+  static const bool poison = std::getenv("RSB_POISON_LDS") != nullptr;  // debug aid, see tests/test_gpu_properties.py
+  a.poison_lds = poison ? 1 : 0;
+  a.lds_floats = (int)(lds_bytes / sizeof(float));
   if (w->timing) HIP_TRY(hipEventRecord(w->ev0, w->stream));
   // kernel classes by (longest chain, deepest body level): <=4/<=4 (quadrupeds), <=8/<=12 (humanoids), <=16/<=16
   const int mcl = w->max_cl, mlv = w->blob.depth - 1;

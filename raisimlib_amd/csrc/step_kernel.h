@@ -98,6 +98,8 @@ struct StepArgs {
   long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
   float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)
   int dbg_env;
+  int poison_lds;   // debug: fill the whole LDS allocation with NaNs first (catches reads of never-written LDS)
+  int lds_floats;
   int N, nsub, kmax, control_mode;
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
@@ -171,6 +173,22 @@ __device__ __forceinline__ void ldv(const float* p, float* o) {
 template <int N4>
 __device__ __forceinline__ void stv(float* p, const float* o) {
   RSB_UNROLL for (int i = 0; i < N4; ++i) st4(p + 4 * i, o + 4 * i);
+}
+
+// sin/cos for joint angles and half rotation angles: Cody-Waite reduction by pi/2 (two-term) + the cephes
+// single-precision minimax polynomials on [-pi/4, pi/4]; |error| < 2e-7 for |x| < 1e3.  (ocml's sincosf carries a
+// Payne-Hanek path and ~4x the instructions.)
+__device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
+  const float kf = rintf(x * 0.63661977236758134f);
+  const int k = (int)kf;
+  float r = fmaf(kf, -1.5707962513f, x);
+  r = fmaf(kf, -7.5497894159e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z, fmaf(-0.5f, z, 1.0f));
+  const float s0 = (k & 1) ? pc : ps, c0 = (k & 1) ? ps : pc;
+  *sn = (k & 2) ? -s0 : s0;
+  *cs = ((k + 1) & 2) ? -c0 : c0;
 }
 
 // terrain height and unit normal under (x, y): plane or triangulated height map (oracle: orc_terrain)
@@ -360,6 +378,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   float* LAM = E + L.lam;
   const int GS = L.gstride;
 
+  if (a.poison_lds) {
+    for (int i = lane; i < a.lds_floats; i += 64) lds[i] = __int_as_float(0x7fc00000);
+    __syncthreads();
+  }
   // ---- per-block tables -> LDS
   for (int i = lane; i < nb * kModelSlot; i += 64) MODELF[i] = (&m.bodyf[0][0])[i];
   for (int i = lane; i < nb; i += 64) {
@@ -463,7 +485,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             float E9[9], R[9], r[3], t[3], a3[3], S[6];
             if (jt == RSB_JOINT_REVOLUTE) {
               float sn, cs;
-              sincosf(qb, &sn, &cs);
+              fast_sincos(qb, &sn, &cs);
               const float v = 1.f - cs;
               float Rq[9];
               Rq[0] = cs + axis[0] * axis[0] * v;           Rq[1] = axis[0] * axis[1] * v - axis[2] * sn; Rq[2] = axis[0] * axis[2] * v + axis[1] * sn;
@@ -711,20 +733,35 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         if (j < nc) {
           const int bi = __float_as_int(CON[i * kConSlot + 7]), bj = __float_as_int(CON[j * kConSlot + 7]);
           const int li = PARLV[bi] >> 8, lj = PARLV[bj] >> 8;
+          // shared support = base (6 entries) + the common prefix of the two support chains; all loads independent
+          int ai[ML], aj[ML];
+          RSB_UNROLL for (int l = 0; l < ML; ++l) {
+            ai[l] = (l + 1 <= li) ? ANC[bi * depth + l + 1] : -1;
+            aj[l] = (l + 1 <= lj) ? ANC[bj * depth + l + 1] : -2;
+          }
           int lca = 0;
-          for (int l = 1; l <= min(li, lj); ++l) {
-            if (ANC[bi * depth + l] == ANC[bj * depth + l]) lca = l; else break;
+          bool same = true;
+          RSB_UNROLL for (int l = 0; l < ML; ++l) { same = same && (ai[l] == aj[l]); lca += same ? 1 : 0; }
+          constexpr int CWC = 6 + ML;          // compile-time bound of the compact column width
+          float wi[3][CWC], wj[3][CWC];
+          const float* Wi = WC + (3 * i) * cw;
+          const float* Wj = WC + (3 * j) * cw;
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+            RSB_UNROLL for (int q4 = 0; q4 < (CWC + 3) / 4; ++q4) {
+              float t4[4], u4[4];
+              ld4(Wi + rr * cw + 4 * q4, t4); ld4(Wj + rr * cw + 4 * q4, u4);
+              RSB_UNROLL for (int e = 0; e < 4; ++e)
+                if (4 * q4 + e < CWC) { wi[rr][4 * q4 + e] = t4[e]; wj[rr][4 * q4 + e] = u4[e]; }
+            }
           }
           float acc[9];
           RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) acc[q2] = 0.f;
-          const float* Wi = WC + (3 * i) * cw;
-          const float* Wj = WC + (3 * j) * cw;
-          for (int e = 0; e < 6 + lca; ++e) {
-            const float a0 = Wi[e], a1 = Wi[cw + e], a2 = Wi[2 * cw + e];
-            const float b0 = Wj[e], b1 = Wj[cw + e], b2 = Wj[2 * cw + e];
-            acc[0] += a0 * b0; acc[1] += a0 * b1; acc[2] += a0 * b2;
-            acc[3] += a1 * b0; acc[4] += a1 * b1; acc[5] += a1 * b2;
-            acc[6] += a2 * b0; acc[7] += a2 * b1; acc[8] += a2 * b2;
+          RSB_UNROLL for (int e = 0; e < CWC; ++e) {
+            const bool on = e < 6 + lca;   // entries past the shared prefix belong to different bodies
+            float av[3], bv[3];   // both sides zeroed: entries past a column's own support are stale LDS
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { av[rr] = on ? wi[rr][e] : 0.f; bv[rr] = on ? wj[rr][e] : 0.f; }
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+              RSB_UNROLL for (int cc = 0; cc < 3; ++cc) acc[3 * rr + cc] += av[rr] * bv[cc];
           }
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
             RSB_UNROLL for (int cc = 0; cc < 3; ++cc) {
@@ -752,8 +789,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float Grow[3][3 * KMAX], Gii[9], Ginv[12], v[3], lam[3] = {0.f, 0.f, 0.f};
         RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
           RSB_UNROLL for (int q4 = 0; q4 < (3 * KMAX) / 4; ++q4) {
-            if (isc) ld4(G + (3 * s + rr) * GS + 4 * q4, &Grow[rr][4 * q4]);
-            else { Grow[rr][4 * q4] = Grow[rr][4 * q4 + 1] = Grow[rr][4 * q4 + 2] = Grow[rr][4 * q4 + 3] = 0.f; }
+            // columns past this env's 3*nc were never written (stale LDS, possibly NaN bit patterns): force them to 0
+            float g4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (isc) ld4(G + (3 * s + rr) * GS + 4 * q4, g4);
+            RSB_UNROLL for (int e = 0; e < 4; ++e) Grow[rr][4 * q4 + e] = (isc && 4 * q4 + e < 3 * nc) ? g4[e] : 0.f;
           }
         RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gii[q2] = 0.f;
         RSB_UNROLL for (int q2 = 0; q2 < 12; ++q2) Ginv[q2] = 0.f;
@@ -870,7 +909,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         const float wn = sqrtf(un[3] * un[3] + un[4] * un[4] + un[5] * un[5]);
         const float half = 0.5f * wn * dt;
         float sh, chf;
-        sincosf(half, &sh, &chf);
+        fast_sincos(half, &sh, &chf);
         const float sc = (wn > 1e-12f) ? sh / wn : 0.5f * dt;
         const float d0 = chf, d1 = sc * un[3], d2 = sc * un[4], d3 = sc * un[5];
         const float q0 = qv[3], q1 = qv[4], q2 = qv[5], q3 = qv[6];
@@ -895,19 +934,26 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           ld4(BODY + ch_attach * kBodySlot + 16, t6); ld4(BODY + ch_attach * kBodySlot + 20, t6 + 4);
           RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = t6[2 + i];
         }
+        // contact contributions to this chain's dofs: contacts outermost so that each contact's loads are issued together
+        float wacc[CL];
+        RSB_UNROLL for (int k = 0; k < CL; ++k) wacc[k] = (k < ch_len) ? WB[chb[k] + 5] : 0.f;
+        for (int i = 0; i < nc; ++i) {
+          const int bi = __float_as_int(CON[i * kConSlot + 7]);
+          const float l0 = LAM[3 * i], l1 = LAM[3 * i + 1], l2 = LAM[3 * i + 2];
+          RSB_UNROLL for (int k = 0; k < CL; ++k) {
+            if (k < ch_len) {
+              const int lv = lev0 + k;
+              if (ANC[bi * depth + lv] == chb[k]) {
+                const float* Wc = WC + (3 * i) * cw + 5 + lv;
+                wacc[k] += Wc[0] * l0 + Wc[cw] * l1 + Wc[2 * cw] * l2;
+              }
+            }
+          }
+        }
         RSB_UNROLL for (int k = 0; k < CL; ++k) {
           if (k < ch_len) {
             const int b = chb[k];
-            const int lv = lev0 + k;
-            float wj = WB[b + 5];
-            for (int i = 0; i < nc; ++i) {
-              const int bi = __float_as_int(CON[i * kConSlot + 7]);
-              if (ANC[bi * depth + lv] == b) {
-                const float* Wc = WC + (3 * i) * cw + 5 + lv;
-                wj += Wc[0] * LAM[3 * i] + Wc[cw] * LAM[3 * i + 1] + Wc[2 * cw] * LAM[3 * i + 2];
-              }
-            }
-            const float xk = crsD[k] * wj - dot6(cUD[k], ap);
+            const float xk = crsD[k] * wacc[k] - dot6(cUD[k], ap);
             RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] += cS[k][i] * xk;
             const float un = cqd[k] + xk;
             U[b + 5] = un;

@@ -175,3 +175,17 @@ def test_api_errors(anymal):
     w.set_time_step(0.001)
     assert abs(w.get_time_step() - 0.001) < 1e-15
     w.close()
+
+
+def test_no_use_of_uninitialised_lds():
+    """Re-run the parity + invariants tests in a child process with RSB_POISON_LDS=1: the kernel first fills its whole
+    LDS allocation with NaNs, so any read of never-written LDS that reaches a result turns into a test failure."""
+    import os
+    import subprocess
+    import sys
+    from common import ROOT
+    env = dict(os.environ, RSB_POISON_LDS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_properties.py"), "-k", "not uninitialised and not borrowed"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:]
