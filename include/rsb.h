@@ -161,7 +161,7 @@ int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_m
                                  double alpha_decay, int max_iter, double threshold);
 /* Stagnation exit of the contact solver (not a RaiSim parameter): the Gauss-Seidel loop of an env stops when the
  * best relative error of the last `window` sweeps is not below `factor` x the best of the previous window
- * (defaults 10, 0.5; window = 0 disables it and only max_iter caps non-converging solves). */
+ * (defaults 6, 0.5; window = 0 disables it and only max_iter caps non-converging solves). */
 int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
 int rsb_set_max_contacts(rsb_world* w, int kmax);   /* 1..RSB_MAX_CONTACTS */
 /* Kernel mapping knob: lanes of a wavefront that cooperate on one env (16, 32 or 64).

@@ -281,7 +281,7 @@ void orc_default_params(orc_params* p) {
   p->max_iter = 150;
   p->section_rounds = 5;
   p->warm_start = 0;  /* evaluated: 12% fewer sweeps on the config-2 workload, not worth the state; off, device has no counterpart */
-  p->stall_window = 10;
+  p->stall_window = 6;
   p->stall_factor = 0.5;
   p->kmax = 8;
   p->control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
@@ -499,23 +499,31 @@ static const double kSin16[16] = {0.0, 0.38268343236508977, 0.70710678118654752,
                                   -0.38268343236508977, -0.70710678118654752, -0.92387953251128674, -1.0,
                                   -0.92387953251128674, -0.70710678118654752, -0.38268343236508977};
 
-static double slip_E(const double* G, const double* v, const double* ls, double mu, double dx, double dy) {
-  double den = G[8] + mu * (G[6] * dx + G[7] * dy);
-  if (!(den > ORC_DEN_MIN * G[8])) return 1e300;
-  double ln = -v[2] / den;
-  double l0 = mu * ln * dx, l1 = mu * ln * dy;
-  double vt0 = v[0] + G[0] * l0 + G[1] * l1 + G[2] * ln;
-  double vt1 = v[1] + G[3] * l0 + G[4] * l1 + G[5] * ln;
-  return 0.5 * (vt0 * (l0 - ls[0]) + vt1 * (l1 - ls[1]));
+/* Both are evaluated through 9 coefficients that are constant during one slip solve:
+ *   den(d) = a0 + a1 x + a2 y,   N(d) := den * v_t^+ = [n00 + n01 x + n02 y ; n10 + n11 x + n12 y]
+ * so a candidate costs a handful of FMAs and slip_dE needs no division (its value is dE/dtheta times den^2 / (mu ln),
+ * a positive factor).  The device computes the coefficients once per solve on the contact's own lane. */
+typedef struct slip_coef { double a0, a1, a2, n00, n01, n02, n10, n11, n12, vn, ls0, ls1, mu; } slip_coef;
+
+static void slip_prepare(const double* G, const double* v, const double* ls, double mu, slip_coef* k) {
+  k->a0 = G[8]; k->a1 = mu * G[6]; k->a2 = mu * G[7];
+  k->n00 = k->a0 * v[0] - v[2] * G[2]; k->n01 = k->a1 * v[0] - v[2] * mu * G[0]; k->n02 = k->a2 * v[0] - v[2] * mu * G[1];
+  k->n10 = k->a0 * v[1] - v[2] * G[5]; k->n11 = k->a1 * v[1] - v[2] * mu * G[3]; k->n12 = k->a2 * v[1] - v[2] * mu * G[4];
+  k->vn = v[2]; k->ls0 = ls[0]; k->ls1 = ls[1]; k->mu = mu;
 }
-static double slip_dE(const double* G, const double* v, double mu, double dx, double dy) {
-  double den = G[8] + mu * (G[6] * dx + G[7] * dy);
-  double dp = -G[6] * dy + G[7] * dx;                 /* G_nt . dperp, dperp = (-dy, dx) */
-  if (!(den > ORC_DEN_MIN * G[8])) return dp > 0.0 ? -1.0 : 1.0;   /* the feasible arc lies towards growing den */
-  double ln = -v[2] / den;
-  double vt0 = v[0] + ln * (mu * (G[0] * dx + G[1] * dy) + G[2]);
-  double vt1 = v[1] + ln * (mu * (G[3] * dx + G[4] * dy) + G[5]);
-  return den * (-vt0 * dy + vt1 * dx) - mu * dp * (vt0 * dx + vt1 * dy);
+static double slip_E(const slip_coef* k, double x, double y) {
+  double den = k->a0 + k->a1 * x + k->a2 * y;
+  if (!(den > ORC_DEN_MIN * k->a0)) return 1e300;
+  double inv = 1.0 / den, ln = -k->vn * inv;
+  double vt0 = (k->n00 + k->n01 * x + k->n02 * y) * inv, vt1 = (k->n10 + k->n11 * x + k->n12 * y) * inv;
+  return 0.5 * (vt0 * (k->mu * ln * x - k->ls0) + vt1 * (k->mu * ln * y - k->ls1));
+}
+static double slip_dE(const slip_coef* k, double x, double y) {
+  double den = k->a0 + k->a1 * x + k->a2 * y;
+  double mdp = k->a2 * x - k->a1 * y;                 /* mu * G_nt . dperp, dperp = (-y, x) */
+  if (!(den > ORC_DEN_MIN * k->a0)) return mdp > 0.0 ? -1.0 : 1.0;   /* the feasible arc lies towards growing den */
+  double N0 = k->n00 + k->n01 * x + k->n02 * y, N1 = k->n10 + k->n11 * x + k->n12 * y;
+  return den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
 }
 
 /*
@@ -525,8 +533,9 @@ static double slip_dE(const double* G, const double* v, double mu, double dx, do
  *   stick: lam_s = -G^-1 v inside the cone -> lam_s
  *   slip : minimum-energy point of the curve above, located by
  *            round 0 : E at 16 directions 22.5 deg apart; the best one +-1 neighbour brackets the minimiser;
- *            rounds 1..section_rounds : 16-section on the sign of dE/dtheta (15 interior candidates per round,
- *                      the first candidate with dE >= 0 closes the bracket from above) -> 45deg / 16^5 = 7.5e-7 rad.
+ *            rounds 1..section_rounds : 16-section on the sign of dE/dtheta: 15 candidates on the chord between
+ *                      the bracket ends (normalised), the first candidate with dE >= 0 closes the bracket from
+ *                      above; the new ends are the (un-normalised) chord points -> 45deg / 16^5 = 7.5e-7 rad.
  *          16-section instead of bisection because the device evaluates the 15 (16) candidates of a round on the
  *          lanes of the env group at once; the oracle walks the same candidates sequentially.
  */
@@ -537,30 +546,33 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
   for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
   double lt2 = ls[0] * ls[0] + ls[1] * ls[1];
   if (ls[2] >= 0.0 && lt2 <= mu * mu * ls[2] * ls[2]) { lam[0] = ls[0]; lam[1] = ls[1]; lam[2] = ls[2]; return; }
+  slip_coef k;
+  slip_prepare(G, v, ls, mu, &k);
   int kbest = 0;
-  double ebest = slip_E(G, v, ls, mu, kCos16[0], kSin16[0]);
-  for (int k = 1; k < 16; ++k) {
-    double e = slip_E(G, v, ls, mu, kCos16[k], kSin16[k]);
-    if (e < ebest) { ebest = e; kbest = k; }
+  double ebest = slip_E(&k, kCos16[0], kSin16[0]);
+  for (int i = 1; i < 16; ++i) {
+    double e = slip_E(&k, kCos16[i], kSin16[i]);
+    if (e < ebest) { ebest = e; kbest = i; }
   }
   double lox = kCos16[(kbest + 15) & 15], loy = kSin16[(kbest + 15) & 15];
   double hix = kCos16[(kbest + 1) & 15], hiy = kSin16[(kbest + 1) & 15];
   for (int r = 0; r < section_rounds; ++r) {
-    double cx[15], cy[15];
+    double ex = hix - lox, ey = hiy - loy;
     int kstar = 15;
-    for (int k = 0; k < 15; ++k) {
-      double t = (k + 1) * (1.0 / 16.0);
-      double x = lox + t * (hix - lox), y = loy + t * (hiy - loy), inv = 1.0 / sqrt(x * x + y * y);
-      cx[k] = x * inv; cy[k] = y * inv;
-      if (kstar == 15 && slip_dE(G, v, mu, cx[k], cy[k]) >= 0.0) kstar = k;
+    for (int i = 0; i < 15; ++i) {
+      double t = (i + 1) * (1.0 / 16.0);
+      double x = lox + t * ex, y = loy + t * ey, inv = 1.0 / sqrt(x * x + y * y);
+      if (slip_dE(&k, x * inv, y * inv) >= 0.0) { kstar = i; break; }
     }
-    if (kstar < 15) { hix = cx[kstar]; hiy = cy[kstar]; }
-    if (kstar > 0) { lox = cx[kstar - 1]; loy = cy[kstar - 1]; }
+    double tl = kstar * (1.0 / 16.0), th = tl + (1.0 / 16.0);
+    double nlx = lox + tl * ex, nly = loy + tl * ey, nhx = lox + th * ex, nhy = loy + th * ey;
+    if (kstar < 15) { hix = nhx; hiy = nhy; }
+    if (kstar > 0) { lox = nlx; loy = nly; }
   }
   double x = lox + hix, y = loy + hiy, inv = 1.0 / sqrt(x * x + y * y);
   x *= inv; y *= inv;
-  double den = G[8] + mu * (G[6] * x + G[7] * y);
-  if (!(den > ORC_DEN_MIN * G[8])) den = ORC_DEN_MIN * G[8];
+  double den = k.a0 + k.a1 * x + k.a2 * y;
+  if (!(den > ORC_DEN_MIN * k.a0)) den = ORC_DEN_MIN * k.a0;
   double ln = -v[2] / den;
   lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
 }

@@ -209,25 +209,30 @@ __device__ __forceinline__ void terrain_eval(const StepArgs& a, float x, float y
   n[0] = -gxs * inv; n[1] = -gys * inv; n[2] = inv;
 }
 
-// ---- slip case of one contact (oracle: slip_E / slip_dE / solve_one_contact) -----------------------
-// G: own 3x3 Delassus block, v: contact velocity without the own impulse, ls: stick impulse.
-__device__ __forceinline__ float slip_E(const float* G, const float* v, const float* ls, float mu, float dx, float dy) {
-  const float den = G[8] + mu * (G[6] * dx + G[7] * dy);
-  if (!(den > kDenMin * G[8])) return __int_as_float(0x7f800000);
-  const float ln = -v[2] * __builtin_amdgcn_rcpf(den);
-  const float l0 = mu * ln * dx, l1 = mu * ln * dy;
-  const float vt0 = v[0] + G[0] * l0 + G[1] * l1 + G[2] * ln;
-  const float vt1 = v[1] + G[3] * l0 + G[4] * l1 + G[5] * ln;
-  return fmaxf(0.5f * (vt0 * (l0 - ls[0]) + vt1 * (l1 - ls[1])), 0.f);
+// ---- slip case of one contact (oracle: slip_prepare / slip_E / slip_dE / solve_one_contact) ---------------
+// The 9 coefficients of  den(d) = a0 + a1 x + a2 y  and  N(d) = den * v_t^+  are computed once per solve on the
+// contact's own lane and broadcast; a candidate direction then costs a handful of FMAs and no division.
+struct SlipCoef { float a0, a1, a2, n00, n01, n02, n10, n11, n12, vn, ls0, ls1; };
+
+__device__ __forceinline__ void slip_prepare(const float* G, const float* v, const float* ls, float mu, SlipCoef& k) {
+  k.a0 = G[8]; k.a1 = mu * G[6]; k.a2 = mu * G[7];
+  k.n00 = k.a0 * v[0] - v[2] * G[2]; k.n01 = k.a1 * v[0] - v[2] * mu * G[0]; k.n02 = k.a2 * v[0] - v[2] * mu * G[1];
+  k.n10 = k.a0 * v[1] - v[2] * G[5]; k.n11 = k.a1 * v[1] - v[2] * mu * G[3]; k.n12 = k.a2 * v[1] - v[2] * mu * G[4];
+  k.vn = v[2]; k.ls0 = ls[0]; k.ls1 = ls[1];
 }
-__device__ __forceinline__ float slip_dE(const float* G, const float* v, float mu, float dx, float dy) {
-  const float den = G[8] + mu * (G[6] * dx + G[7] * dy);
-  const float dp = -G[6] * dy + G[7] * dx;
-  if (!(den > kDenMin * G[8])) return dp > 0.f ? -1.f : 1.f;
-  const float ln = -v[2] * __builtin_amdgcn_rcpf(den);
-  const float vt0 = v[0] + ln * (mu * (G[0] * dx + G[1] * dy) + G[2]);
-  const float vt1 = v[1] + ln * (mu * (G[3] * dx + G[4] * dy) + G[5]);
-  return den * (-vt0 * dy + vt1 * dx) - mu * dp * (vt0 * dx + vt1 * dy);
+__device__ __forceinline__ float slip_E(const SlipCoef& k, float mu, float x, float y) {
+  const float den = k.a0 + k.a1 * x + k.a2 * y;
+  if (!(den > kDenMin * k.a0)) return __int_as_float(0x7f800000);
+  const float inv = __builtin_amdgcn_rcpf(den), ln = -k.vn * inv;
+  const float vt0 = (k.n00 + k.n01 * x + k.n02 * y) * inv, vt1 = (k.n10 + k.n11 * x + k.n12 * y) * inv;
+  return fmaxf(0.5f * (vt0 * (mu * ln * x - k.ls0) + vt1 * (mu * ln * y - k.ls1)), 0.f);
+}
+__device__ __forceinline__ float slip_dE(const SlipCoef& k, float x, float y) {
+  const float den = k.a0 + k.a1 * x + k.a2 * y;
+  const float mdp = k.a2 * x - k.a1 * y;
+  const float N0 = k.n00 + k.n01 * x + k.n02 * y, N1 = k.n10 + k.n11 * x + k.n12 * y;
+  const float h = den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
+  return (den > kDenMin * k.a0) ? h : (mdp > 0.f ? -1.f : 1.f);
 }
 // 16-lane row minimum of an unsigned key (DPP row rotate: no LDS, no bpermute)
 __device__ __forceinline__ unsigned row_min_u32(unsigned x) {
@@ -252,15 +257,15 @@ __device__ __forceinline__ float row_bcast(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + J, 0xf, 0xf, false));
 }
 
-// Cooperative slip solve: all lanes of the env group hold the same (G, v, ls); lane (s & 15) evaluates
+// Cooperative slip solve: all lanes of the env group hold the same coefficients; lane (s & 15) evaluates
 // candidate (s & 15) of every round.  (c16, s16) = this lane's round-0 direction (22.5 deg grid); BR16[k] =
-// {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).
+// {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).  Bracket ends stay un-normalised
+// chord points between rounds (as in the oracle); only candidates and the final direction are normalised.
 template <int LPE>
-__device__ __forceinline__ void slip_search(const float* G, const float* v, const float* ls, float mu, int rounds,
-                                            int s, int el, float c16, float s16, const float* BR16, float* lam) {
+__device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int rounds, int s, int el, float c16, float s16,
+                                            const float* BR16, float* lam) {
   const int k = s & 15;
-  // round 0: global energy minimum over 16 directions
-  const float e0 = slip_E(G, v, ls, mu, c16, s16);
+  const float e0 = slip_E(kf, mu, c16, s16);
   const unsigned key = (__float_as_uint(e0) & ~15u) | (unsigned)k;
   const int kbest = (int)(row_min_u32(key) & 15u);
   float br[4];
@@ -271,25 +276,21 @@ __device__ __forceinline__ void slip_search(const float* G, const float* v, cons
     const float ex = hix - lox, ey = hiy - loy;
     float cx = lox + t * ex, cy = loy + t * ey;
     const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy);
-    cx *= inv; cy *= inv;
-    const float h = slip_dE(G, v, mu, cx, cy);
+    const float h = slip_dE(kf, cx * inv, cy * inv);
     const unsigned long long bal = __ballot(h >= 0.f && k < 15);
     // every 16-lane row of the group holds the same candidates; use the group's first row
     const unsigned gm = (unsigned)(bal >> (el * LPE)) & 0x7fffu;
     const int kstar = gm ? (__ffs((int)gm) - 1) : 15;
-    // new bracket = candidates kstar-1 / kstar (kept as old lo / hi at the ends); recomputed, not exchanged
     const float tl = (float)kstar * (1.0f / 16.0f), th = tl + (1.0f / 16.0f);
-    float xl = lox + tl * ex, yl = loy + tl * ey, xh = lox + th * ex, yh = loy + th * ey;
-    const float il = __builtin_amdgcn_rsqf(xl * xl + yl * yl), ih = __builtin_amdgcn_rsqf(xh * xh + yh * yh);
-    if (kstar < 15) { hix = xh * ih; hiy = yh * ih; }
-    if (kstar > 0) { lox = xl * il; loy = yl * il; }
+    const float nlx = lox + tl * ex, nly = loy + tl * ey, nhx = lox + th * ex, nhy = loy + th * ey;
+    if (kstar < 15) { hix = nhx; hiy = nhy; }
+    if (kstar > 0) { lox = nlx; loy = nly; }
   }
   float x = lox + hix, y = loy + hiy;
   const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
   x *= inv; y *= inv;
-  float den = G[8] + mu * (G[6] * x + G[7] * y);
-  den = fmaxf(den, kDenMin * G[8]);
-  const float ln = -v[2] * __builtin_amdgcn_rcpf(den);
+  const float den = fmaxf(kf.a0 + kf.a1 * x + kf.a2 * y, kDenMin * kf.a0);
+  const float ln = -kf.vn * __builtin_amdgcn_rcpf(den);
   lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
 }
 
@@ -828,11 +829,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               float ln[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
               if (__any(need)) {
-                float Gb[9], vb[3], lb[3], lsl[3];
-                RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gb[q2] = row_bcast<j>(Gii[q2]);
-                RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) vb[q2] = row_bcast<j>(vex[q2]);
-                lb[0] = row_bcast<j>(ls[0]); lb[1] = row_bcast<j>(ls[1]); lb[2] = 0.f;
-                slip_search<LPE>(Gb, vb, lb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, lsl);
+                // the owner prepares the 12 solve constants; the row searches the direction together
+                SlipCoef kc, kb;
+                slip_prepare(Gii, vex, ls, a.mu, kc);
+                kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
+                kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
+                kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
+                kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
+                float lsl[3];
+                slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, lsl);
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = need ? lsl[rr] : ln[rr];
               }
               float dl[3];
