@@ -280,6 +280,7 @@ void orc_default_params(orc_params* p) {
   p->threshold = 1e-5;
   p->max_iter = 150;
   p->section_rounds = 5;
+  p->freeze_after = 6;
   p->warm_start = 0;  /* evaluated: 12% fewer sweeps on the config-2 workload, not worth the state; off, device has no counterpart */
   p->stall_window = 6;
   p->stall_factor = 0.5;
@@ -539,8 +540,11 @@ static double slip_dE(const slip_coef* k, double x, double y) {
  *          16-section instead of bisection because the device evaluates the 15 (16) candidates of a round on the
  *          lanes of the env group at once; the oracle walks the same candidates sequentially.
  */
+/* sdir (in/out, 3 doubles: dx, dy, valid): the friction direction of this contact's last slip solve.  With
+ * use_frozen != 0 and a valid direction the slip case keeps that direction and only re-solves the magnitude
+ * ("lagged friction direction", used by the caller after `freeze_after` sweeps). */
 static void solve_one_contact(const double* G, const double* Ginv, const double* v, double mu,
-                              int section_rounds, double* lam) {
+                              int section_rounds, int use_frozen, double* sdir, double* lam) {
   if (v[2] > 0.0) { lam[0] = lam[1] = lam[2] = 0.0; return; }
   double ls[3];
   for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
@@ -548,6 +552,13 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
   if (ls[2] >= 0.0 && lt2 <= mu * mu * ls[2] * ls[2]) { lam[0] = ls[0]; lam[1] = ls[1]; lam[2] = ls[2]; return; }
   slip_coef k;
   slip_prepare(G, v, ls, mu, &k);
+  if (use_frozen && sdir[2] != 0.0) {
+    double den = k.a0 + k.a1 * sdir[0] + k.a2 * sdir[1];
+    if (!(den > ORC_DEN_MIN * k.a0)) den = ORC_DEN_MIN * k.a0;
+    double ln = -v[2] / den;
+    lam[0] = mu * ln * sdir[0]; lam[1] = mu * ln * sdir[1]; lam[2] = ln;
+    return;
+  }
   int kbest = 0;
   double ebest = slip_E(&k, kCos16[0], kSin16[0]);
   for (int i = 1; i < 16; ++i) {
@@ -575,6 +586,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
   if (!(den > ORC_DEN_MIN * k.a0)) den = ORC_DEN_MIN * k.a0;
   double ln = -v[2] / den;
   lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
+  sdir[0] = x; sdir[1] = y; sdir[2] = 1.0;
 }
 
 static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {
@@ -693,6 +705,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
      * sweeps is not below `stall_factor` x the best of the window before.  Such solves would otherwise run to
      * max_iter without converging; on a lock-step GPU launch that worst case sets the launch time. */
     double alpha = p->alpha_init, best_prev = 1e300, best_cur = 1e300;
+    double sdir[MAXK][3];
+    for (int i = 0; i < nc; ++i) sdir[i][0] = sdir[i][1] = sdir[i][2] = 0.0;
     int converged = 0;
     for (int it = 0; it < p->max_iter; ++it) {
       double err = 0, scale = 0;
@@ -702,7 +716,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
           if (j == i) continue;
           for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam[j][0] + G[i][j][3 * r + 1] * lam[j][1] + G[i][j][3 * r + 2] * lam[j][2];
         }
-        solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds, ln);
+        solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds,
+                          p->freeze_after > 0 && it >= p->freeze_after, sdir[i], ln);
         for (int r = 0; r < 3; ++r) {
           double dl = alpha * (ln[r] - lam[i][r]);
           lam[i][r] += dl;

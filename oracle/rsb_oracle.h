@@ -37,7 +37,7 @@ typedef struct orc_params {
   int32_t kmax;
   int32_t control_mode;      /* rsb_control_mode */
   int32_t warm_start;        /* start the contact solve from the previous integrate()'s impulses (per collision primitive) */
-  int32_t pad0_;
+  int32_t freeze_after;      /* sweeps after which a slipping contact keeps its friction direction (0 = never) */
   int32_t terrain_type;      /* 0 = plane, 1 = heightmap */
   int32_t hm_xs, hm_ys, stall_window;  /* stagnation exit of the contact solver: window (sweeps), 0 = off */
   double ground_z;

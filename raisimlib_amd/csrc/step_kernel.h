@@ -103,7 +103,7 @@ struct StepArgs {
   int N, nsub, kmax, control_mode;
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
-  int max_iter, section_rounds, stall_window;
+  int max_iter, section_rounds, stall_window, freeze_after;
   float stall_factor;
   int terrain_type, hm_xs, hm_ys;
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
@@ -263,7 +263,7 @@ __device__ __forceinline__ float row_bcast(float x) {
 // chord points between rounds (as in the oracle); only candidates and the final direction are normalised.
 template <int LPE>
 __device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int rounds, int s, int el, float c16, float s16,
-                                            const float* BR16, float* lam) {
+                                            const float* BR16, float* lam, float* dir) {
   const int k = s & 15;
   const float e0 = slip_E(kf, mu, c16, s16);
   const unsigned key = (__float_as_uint(e0) & ~15u) | (unsigned)k;
@@ -292,6 +292,7 @@ __device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int ro
   const float den = fmaxf(kf.a0 + kf.a1 * x + kf.a2 * y, kDenMin * kf.a0);
   const float ln = -kf.vn * __builtin_amdgcn_rcpf(den);
   lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
+  dir[0] = x; dir[1] = y;
 }
 
 __device__ __forceinline__ void inv3(const float* A, float* B) {
@@ -807,6 +808,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float lamn_all[KMAX];  // every lane tracks all normal impulses of its env (for the relative test)
         RSB_UNROLL for (int j = 0; j < KMAX; ++j) lamn_all[j] = 0.f;
         const float mu2 = a.mu * a.mu;
+        float sdx = 0.f, sdy = 0.f;   // friction direction of this contact's last slip solve (|.| = 1 once set)
+        bool sdv = false;
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
@@ -825,7 +828,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                 ls[rr] = -(Ginv[3 * rr] * vex[0] + Ginv[3 * rr + 1] * vex[1] + Ginv[3 * rr + 2] * vex[2]);
               const bool open = vex[2] > 0.f;
               const bool stick = !open && ls[2] >= 0.f && (ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2];
-              const bool need = mine && !open && !stick;
+              const bool slip = mine && !open && !stick;
+              // lagged friction direction: after freeze_after sweeps a slipping contact keeps its last direction
+              const bool frozen = slip && sdv && a.freeze_after > 0 && it >= a.freeze_after;
+              const bool need = slip && !frozen;
               float ln[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
               if (__any(need)) {
@@ -836,9 +842,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                 kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
                 kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
                 kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
-                float lsl[3];
-                slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, lsl);
+                float lsl[3], dxy[2];
+                slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, lsl, dxy);
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = need ? lsl[rr] : ln[rr];
+                if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; }
+              }
+              if (frozen) {
+                const float den = fmaxf(Gii[8] + a.mu * (Gii[6] * sdx + Gii[7] * sdy), kDenMin * Gii[8]);
+                const float lnn = -vex[2] * __builtin_amdgcn_rcpf(den);
+                ln[0] = a.mu * lnn * sdx; ln[1] = a.mu * lnn * sdy; ln[2] = lnn;
               }
               float dl[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
