@@ -53,6 +53,7 @@ constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
 constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevModel::bodyf)
 constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence test (== ORC_LAMBDA_FLOOR)
 constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
+constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
@@ -808,6 +809,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float lamn_all[KMAX];  // every lane tracks all normal impulses of its env (for the relative test)
         RSB_UNROLL for (int j = 0; j < KMAX; ++j) lamn_all[j] = 0.f;
         const float mu2 = a.mu * a.mu;
+        float lam_best[3] = {0.f, 0.f, 0.f}, best_rel = 3e38f;   // calmest iterate (returned when the solve does not converge)
         float sdx = 0.f, sdy = 0.f;   // friction direction of this contact's last slip solve (|.| = 1 once set)
         bool sdv = false;
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
@@ -830,7 +832,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               const bool stick = !open && ls[2] >= 0.f && (ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2];
               const bool slip = mine && !open && !stick;
               // lagged friction direction: after freeze_after sweeps a slipping contact keeps its last direction
-              const bool frozen = slip && sdv && a.freeze_after > 0 && it >= a.freeze_after;
+              const float dfz = Gii[8] + a.mu * (Gii[6] * sdx + Gii[7] * sdy);   // normal response along the kept direction
+              const bool frozen = slip && sdv && a.freeze_after > 0 && it >= a.freeze_after && dfz >= kDenFreeze * Gii[8];
               const bool need = slip && !frozen;
               float ln[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
@@ -848,8 +851,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                 if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; }
               }
               if (frozen) {
-                const float den = fmaxf(Gii[8] + a.mu * (Gii[6] * sdx + Gii[7] * sdy), kDenMin * Gii[8]);
-                const float lnn = -vex[2] * __builtin_amdgcn_rcpf(den);
+                const float lnn = -vex[2] * __builtin_amdgcn_rcpf(dfz);
                 ln[0] = a.mu * lnn * sdx; ln[1] = a.mu * lnn * sdy; ln[2] = lnn;
               }
               float dl[3];
@@ -871,7 +873,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             // relative (fp32-aware) test and stagnation exit, identical to the oracle's: see rsb_oracle.c
             if (err <= a.threshold * (scale + kLambdaFloor)) { done = true; converged = true; }
             else {
-              best_cur = fminf(best_cur, err / (scale + kLambdaFloor));
+              const float rel = err / (scale + kLambdaFloor);
+              if (rel < best_rel) { best_rel = rel; lam_best[0] = lam[0]; lam_best[1] = lam[1]; lam_best[2] = lam[2]; }
+              best_cur = fminf(best_cur, rel);
               if (a.stall_window > 0 && ++wcount == a.stall_window) {
                 wcount = 0;
                 if (best_cur > a.stall_factor * best_prev) done = true;
@@ -881,7 +885,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           }
           if (!__any(!done)) break;
         }
-        if (!converged) flag |= 4;
+        if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
         if (isc) { LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2]; }
       }
       __syncthreads();
