@@ -505,7 +505,7 @@ static const double kSin16[16] = {0.0, 0.38268343236508977, 0.70710678118654752,
  *   den(d) = a0 + a1 x + a2 y,   N(d) := den * v_t^+ = [n00 + n01 x + n02 y ; n10 + n11 x + n12 y]
  * so a candidate costs a handful of FMAs and slip_dE needs no division (its value is dE/dtheta times den^2 / (mu ln),
  * a positive factor).  The device computes the coefficients once per solve on the contact's own lane. */
-typedef struct slip_coef { double a0, a1, a2, n00, n01, n02, n10, n11, n12, vn, ls0, ls1, mu; } slip_coef;
+typedef struct slip_coef { double a0, a1, a2, n00, n01, n02, n10, n11, n12, vn, ls0, ls1, mu, bx, by; } slip_coef;
 
 static void slip_prepare(const double* G, const double* v, const double* ls, double mu, slip_coef* k) {
   k->a0 = G[8]; k->a1 = mu * G[6]; k->a2 = mu * G[7];
@@ -523,7 +523,9 @@ static double slip_E(const slip_coef* k, double x, double y) {
 static double slip_dE(const slip_coef* k, double x, double y) {
   double den = k->a0 + k->a1 * x + k->a2 * y;
   double mdp = k->a2 * x - k->a1 * y;                 /* mu * G_nt . dperp, dperp = (-y, x) */
-  if (!(den > ORC_DEN_MIN * k->a0)) return mdp > 0.0 ? -1.0 : 1.0;   /* the feasible arc lies towards growing den */
+  /* no curve point in this direction: the infeasible arc is contiguous, < 180 deg and does not contain the
+   * round-0 best direction b, so the minimiser lies on b's side of the candidate */
+  if (!(den > ORC_DEN_MIN * k->a0)) return (k->bx * y - k->by * x > 0.0) ? 1.0 : -1.0;
   double N0 = k->n00 + k->n01 * x + k->n02 * y, N1 = k->n10 + k->n11 * x + k->n12 * y;
   return den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
 }
@@ -569,6 +571,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
     double e = slip_E(&k, kCos16[i], kSin16[i]);
     if (e < ebest) { ebest = e; kbest = i; }
   }
+  k.bx = kCos16[kbest]; k.by = kSin16[kbest];
   double lox = kCos16[(kbest + 15) & 15], loy = kSin16[(kbest + 15) & 15];
   double hix = kCos16[(kbest + 1) & 15], hiy = kSin16[(kbest + 1) & 15];
   for (int r = 0; r < section_rounds; ++r) {
@@ -591,6 +594,13 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
   double ln = -v[2] / den;
   lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
   sdir[0] = x; sdir[1] = y; sdir[2] = 1.0;
+}
+
+/* one contact solved in isolation (unit tests of the open/stick/slip rule against a dense minimisation) */
+void orc_solve_contact(const double* G, const double* v, double mu, int section_rounds, double* lam) {
+  double Ginv[9], sdir[3] = {0.0, 0.0, 0.0};
+  inv3(G, Ginv);
+  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, sdir, lam);
 }
 
 static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {

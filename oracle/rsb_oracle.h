@@ -88,6 +88,10 @@ void orc_actuation(const rsb_model_blob* m, const orc_params* p, const double* q
                    const double* kp, const double* kd, const double* p_target,
                    const double* d_target, const double* tau_ff, double* tau);
 
+/* the open / stick / slip rule for ONE contact in isolation: G [9] row-major 3x3 Delassus block in the contact
+ * frame [t1 t2 n], v [3] contact velocity without this contact's impulse -> lam [3] */
+void orc_solve_contact(const double* G, const double* v, double mu, int section_rounds, double* lam);
+
 /* one World::integrate(): q,u updated in place.  contacts has room for p->kmax entries.
  * flags bit0: contact overflow (more than kmax), bit1: non-finite state, bit2: contact solver stopped
  * without meeting the convergence test (max_iter or stagnation exit). */

@@ -228,12 +228,14 @@ __device__ __forceinline__ float slip_E(const SlipCoef& k, float mu, float x, fl
   const float vt0 = (k.n00 + k.n01 * x + k.n02 * y) * inv, vt1 = (k.n10 + k.n11 * x + k.n12 * y) * inv;
   return fmaxf(0.5f * (vt0 * (mu * ln * x - k.ls0) + vt1 * (mu * ln * y - k.ls1)), 0.f);
 }
-__device__ __forceinline__ float slip_dE(const SlipCoef& k, float x, float y) {
+// (bx, by): any positive multiple of the round-0 best direction; where the curve has no point (den <= 0) the
+// minimiser lies on that direction's side of the candidate (the infeasible arc is contiguous and < 180 deg)
+__device__ __forceinline__ float slip_dE(const SlipCoef& k, float x, float y, float bx, float by) {
   const float den = k.a0 + k.a1 * x + k.a2 * y;
   const float mdp = k.a2 * x - k.a1 * y;
   const float N0 = k.n00 + k.n01 * x + k.n02 * y, N1 = k.n10 + k.n11 * x + k.n12 * y;
   const float h = den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
-  return (den > kDenMin * k.a0) ? h : (mdp > 0.f ? -1.f : 1.f);
+  return (den > kDenMin * k.a0) ? h : ((bx * y - by * x > 0.f) ? 1.f : -1.f);
 }
 // 16-lane row minimum of an unsigned key (DPP row rotate: no LDS, no bpermute)
 __device__ __forceinline__ unsigned row_min_u32(unsigned x) {
@@ -272,12 +274,13 @@ __device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int ro
   float br[4];
   ld4(BR16 + 4 * kbest, br);
   float lox = br[0], loy = br[1], hix = br[2], hiy = br[3];
+  const float bx = lox + hix, by = loy + hiy;
   const float t = (float)((k < 15 ? k : 14) + 1) * (1.0f / 16.0f);
   for (int r = 0; r < rounds; ++r) {
     const float ex = hix - lox, ey = hiy - loy;
     float cx = lox + t * ex, cy = loy + t * ey;
     const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy);
-    const float h = slip_dE(kf, cx * inv, cy * inv);
+    const float h = slip_dE(kf, cx * inv, cy * inv, bx, by);
     const unsigned long long bal = __ballot(h >= 0.f && k < 15);
     // every 16-lane row of the group holds the same candidates; use the group's first row
     const unsigned gm = (unsigned)(bal >> (el * LPE)) & 0x7fffu;

@@ -158,3 +158,55 @@ def test_contact_order_and_overflow_flag(anymal):
     o.p.kmax = 16
     _, _, con, _, fl = o.step(q, np.zeros(18))
     assert len(con) > 8 and list(con["collision"]) == sorted(con["collision"])
+
+
+def test_single_contact_rule_matches_a_dense_minimisation(anymal):
+    """orc_solve_contact against a brute-force scan of the slip curve, on random SPD blocks that include the
+    Painleve-type case mu |G_nt| > G_nn (part of the circle of directions has no curve point) and the regression
+    case of env 824 (round-0 bracket whose lower end lies beyond the asymptote)."""
+    o = Oracle(anymal.blob)
+    rng = np.random.default_rng(5)
+    mu = 0.8
+    cases = [(np.array([[0.508181, -0.027939, -0.016591], [-0.027939, 0.559502, 0.241295],
+                        [-0.016591, 0.241295, 0.190953]]), np.array([-0.063748, 0.016365, -0.001398]))]
+    while len(cases) < 400:
+        A = rng.normal(size=(3, 3)) * np.array([1.0, 1.0, rng.uniform(0.3, 1.0)])
+        G = A.T @ A + 1e-3 * np.eye(3)
+        v = rng.normal(size=3)
+        v[2] = -abs(v[2]) * rng.choice([1.0, 0.02])
+        cases.append((G, v))
+    th = np.linspace(0, 2 * np.pi, 200001)
+    x, y = np.cos(th), np.sin(th)
+    kinds = {"stick": 0, "slip": 0, "jam": 0, "global": 0}
+    for G, v in cases:
+        lam = o.solve_contact(G, v, mu)
+        ls = -np.linalg.solve(G, v)
+        if ls[2] >= 0 and np.hypot(ls[0], ls[1]) <= mu * ls[2]:
+            kinds["stick"] += 1
+            assert np.allclose(lam, ls, rtol=1e-9, atol=1e-12)
+            continue
+        den = G[2, 2] + mu * (G[2, 0] * x + G[2, 1] * y)
+        ok = den > 1e-6 * G[2, 2]
+        ln = -v[2] / np.where(ok, den, 1.0)
+        L = np.stack([mu * ln * x, mu * ln * y, ln], 1) - ls
+        E = np.where(ok, 0.5 * np.einsum("ij,jk,ik->i", L, G, L), np.inf)
+        kinds["jam" if not ok.all() else "slip"] += 1
+        d = lam - ls
+        e = 0.5 * d @ G @ d
+        assert lam[2] >= 0 and abs(np.hypot(lam[0], lam[1]) - mu * lam[2]) <= 1e-9 * (1 + lam[2])
+        assert abs(v[2] + G[2] @ lam) <= 1e-9 * (1 + abs(v).max())            # v_n^+ = 0
+        # E restricted to the curve can have two local minima (normals from an outside point to a conic); the rule
+        # returns the one bracketed by the best of the 16 coarse directions: it must be a local minimum, never
+        # worse than the coarse scan, and the global one in all but rare cases.
+        th0 = np.arctan2(lam[1], lam[0])
+
+        def energy(t):
+            dd = np.array([np.cos(t), np.sin(t)])
+            l_n = -v[2] / (G[2, 2] + mu * G[2, :2] @ dd)
+            z = np.r_[mu * l_n * dd, l_n] - ls
+            return 0.5 * z @ G @ z if l_n >= 0 else np.inf
+        assert e <= energy(th0 + 1e-5) + 1e-9 * (1 + e) and e <= energy(th0 - 1e-5) + 1e-9 * (1 + e), (G, v, lam)
+        assert e <= E[::12500][:16].min() * (1 + 1e-9)
+        kinds["global"] += e <= E.min() * (1 + 1e-6) + 1e-12
+    assert kinds["stick"] > 10 and kinds["slip"] > 50 and kinds["jam"] > 20, kinds
+    assert kinds["global"] >= 0.98 * (kinds["slip"] + kinds["jam"]), kinds
