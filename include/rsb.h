@@ -165,8 +165,11 @@ int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_m
 int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
 /* Lagged friction directions (not a RaiSim parameter): from sweep `freeze_after` on, a slipping contact keeps the
  * friction direction of its last slip solve and only re-solves the impulse magnitude (default 6; 0 = always
- * re-optimise the direction).  Solves that converge within freeze_after sweeps are unaffected. */
-int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after);
+ * re-optimise the direction).  Solves that converge within freeze_after sweeps are unaffected.
+ * refine != 0 (default): before that, a contact that already slipped in this solve updates its direction by one
+ * guarded Newton step on the curve's energy instead of a new global search (falls back to the search when the
+ * step is not a safe descent step). */
+int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine);
 int rsb_set_max_contacts(rsb_world* w, int kmax);   /* 1..RSB_MAX_CONTACTS */
 /* Kernel mapping knob: lanes of a wavefront that cooperate on one env (16, 32 or 64).
  * 64 = the north star's "one wavefront per env"; 0 = pick the measured-fastest default. */

@@ -281,6 +281,7 @@ void orc_default_params(orc_params* p) {
   p->max_iter = 150;
   p->section_rounds = 5;
   p->freeze_after = 6;
+  p->refine = 1;
   p->warm_start = 0;  /* evaluated: 12% fewer sweeps on the config-2 workload, not worth the state; off, device has no counterpart */
   p->stall_window = 6;
   p->stall_factor = 0.5;
@@ -530,6 +531,41 @@ static double slip_dE(const slip_coef* k, double x, double y) {
   return den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
 }
 
+/* Local refinement of a previous slip direction (x0, y0): one Newton step on h(theta) = slip_dE along the curve,
+ *   h' = den (N1' x - N0' y) - a0 (N0 x + N1 y) - mdp (N0' x + N1' y),   N' = dN/dtheta = n.2 x - n.1 y,
+ * accepted only when it is a safe descent step: direction well inside the feasible arc before and after, h' > 0
+ * (a minimum, not a maximum, nearby), |dtheta| <= 0.25 rad, and for steps above 0.02 rad no energy increase.
+ * Returns 0 when rejected (the caller then runs the global search). */
+#define ORC_DEN_NEWTON 1e-3
+#ifdef ORC_STATS
+long orc_stats[8];   /* [0] newton accepted, [1..5] rejected at den0 / hp / |d| / den1 / E, [6] global searches */
+#define ORC_STAT(i) (++orc_stats[i])
+#else
+#define ORC_STAT(i) ((void)0)
+#endif
+static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, double* y1) {
+  double den = k->a0 + k->a1 * x0 + k->a2 * y0;
+  if (!(den > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(1); return 0; }
+  double mdp = k->a2 * x0 - k->a1 * y0;
+  double N0 = k->n00 + k->n01 * x0 + k->n02 * y0, N1 = k->n10 + k->n11 * x0 + k->n12 * y0;
+  double dN0 = k->n02 * x0 - k->n01 * y0, dN1 = k->n12 * x0 - k->n11 * y0;
+  double P = N1 * x0 - N0 * y0, Q = N0 * x0 + N1 * y0;
+  double h = den * P - mdp * Q;
+  double hp = den * (dN1 * x0 - dN0 * y0) - k->a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
+  if (!(hp > 0.0)) { ORC_STAT(2); return 0; }
+  double d = -h / hp;
+  if (!(fabs(d) <= 0.25)) { ORC_STAT(3); return 0; }
+  double d2 = d * d;
+  double c = 1.0 - d2 * (0.5 - d2 * (1.0 / 24.0)), s = d * (1.0 - d2 * ((1.0 / 6.0) - d2 * (1.0 / 120.0)));
+  double x = x0 * c - y0 * s, y = x0 * s + y0 * c, inv = 1.0 / sqrt(x * x + y * y);
+  x *= inv; y *= inv;
+  if (!(k->a0 + k->a1 * x + k->a2 * y > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(4); return 0; }
+  if (fabs(d) > 0.02 && !(slip_E(k, x, y) <= slip_E(k, x0, y0))) { ORC_STAT(5); return 0; }
+  ORC_STAT(0);
+  *x1 = x; *y1 = y;
+  return 1;
+}
+
 /*
  * One contact of the per-contact iteration: given the contact-space velocity v the contact would have with its
  * own impulse removed, and its own 3x3 Delassus block G (contact frame [t1 t2 n]), return the impulse:
@@ -545,9 +581,10 @@ static double slip_dE(const slip_coef* k, double x, double y) {
  */
 /* sdir (in/out, 3 doubles: dx, dy, valid): the friction direction of this contact's last slip solve.  With
  * use_frozen != 0 and a valid direction the slip case keeps that direction and only re-solves the magnitude
- * ("lagged friction direction", used by the caller after `freeze_after` sweeps). */
+ * ("lagged friction direction", used by the caller after `freeze_after` sweeps).  With refine != 0 and a valid
+ * direction the global search is replaced by slip_newton() whenever that step is accepted. */
 static void solve_one_contact(const double* G, const double* Ginv, const double* v, double mu,
-                              int section_rounds, int use_frozen, double* sdir, double* lam) {
+                              int section_rounds, int use_frozen, int refine, double* sdir, double* lam) {
   if (v[2] > 0.0) { lam[0] = lam[1] = lam[2] = 0.0; return; }
   double ls[3];
   for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
@@ -565,6 +602,16 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
       return;
     }
   }
+  if (refine && sdir[2] != 0.0) {
+    double x, y;
+    if (slip_newton(&k, sdir[0], sdir[1], &x, &y)) {
+      double ln = -v[2] / (k.a0 + k.a1 * x + k.a2 * y);
+      lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
+      sdir[0] = x; sdir[1] = y;
+      return;
+    }
+  }
+  ORC_STAT(6);
   int kbest = 0;
   double ebest = slip_E(&k, kCos16[0], kSin16[0]);
   for (int i = 1; i < 16; ++i) {
@@ -600,7 +647,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
 void orc_solve_contact(const double* G, const double* v, double mu, int section_rounds, double* lam) {
   double Ginv[9], sdir[3] = {0.0, 0.0, 0.0};
   inv3(G, Ginv);
-  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, sdir, lam);
+  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, 0, sdir, lam);
 }
 
 static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {
@@ -731,7 +778,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
           for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam[j][0] + G[i][j][3 * r + 1] * lam[j][1] + G[i][j][3 * r + 2] * lam[j][2];
         }
         solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds,
-                          p->freeze_after > 0 && it >= p->freeze_after, sdir[i], ln);
+                          p->freeze_after > 0 && it >= p->freeze_after, p->refine, sdir[i], ln);
         for (int r = 0; r < 3; ++r) {
           double dl = alpha * (ln[r] - lam[i][r]);
           lam[i][r] += dl;

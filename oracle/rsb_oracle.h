@@ -40,6 +40,8 @@ typedef struct orc_params {
   int32_t freeze_after;      /* sweeps after which a slipping contact keeps its friction direction (0 = never) */
   int32_t terrain_type;      /* 0 = plane, 1 = heightmap */
   int32_t hm_xs, hm_ys, stall_window;  /* stagnation exit of the contact solver: window (sweeps), 0 = off */
+  int32_t refine;            /* a contact that slipped earlier in this solve refines its direction by one guarded Newton step
+                                instead of a new global search (0 = always search) */
   double ground_z;
   double stall_factor;       /* ... and required improvement factor per window */
   double hm_xsize, hm_ysize, hm_cx, hm_cy;

