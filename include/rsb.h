@@ -240,8 +240,10 @@ int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, fl
 /* Debug aid (profiling): shader-clock stamps at the phase boundaries of workgroup 0's last sub-step:
  * out16[0..9] = stamps, [10] = solver iterations, [11] = wave-max contact count. */
 int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16);
-/* per-workgroup profile of the last launch (needs rsb_debug_phase_cycles(w, 1, ...) first): out [4*n_blocks] =
- * {total cycles, Gauss-Seidel cycles, sum over sub-steps of the wave's max sweep count, max contact count} */
+/* per-workgroup profile of the last launch (needs rsb_debug_phase_cycles(w, 1, ...) first): out [16*n_blocks] =
+ * {total cycles, Gauss-Seidel cycles, sum over sub-steps of the wave's max sweep count, max contact count,
+ *  global slip searches run, Newton refinements run, contact solves (sweeps x wave contact count), cycles in searches,
+ *  cycles of the solver set-up (G rows -> registers), cycles in Newton refinements, cycles in the per-sweep epilogue, 0...} */
 int rsb_debug_wave_profile(rsb_world* w, long long* out, int n_blocks);
 
 #ifdef __cplusplus

@@ -146,7 +146,7 @@ class Oracle:
                              _p(_d(pt)), _p(_d(dt_)), _p(_d(tau_ff)), _p(t))
         return t
 
-    def solve_contact(self, G, v, mu, section_rounds=5):
+    def solve_contact(self, G, v, mu, section_rounds=2):
         """Open / stick / slip rule for one isolated contact (G 3x3 contact-frame Delassus block, v free velocity)."""
         lam = np.zeros(3)
         self.L.orc_solve_contact(_p(_d(np.asarray(G).reshape(9))), _p(_d(v)), C.c_double(mu), C.c_int(section_rounds), _p(lam))

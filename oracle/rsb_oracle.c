@@ -279,7 +279,7 @@ void orc_default_params(orc_params* p) {
   p->alpha_init = 1.0; p->alpha_min = 1.0; p->alpha_decay = 1.0;
   p->threshold = 1e-5;
   p->max_iter = 150;
-  p->section_rounds = 5;
+  p->section_rounds = 2;
   p->freeze_after = 6;
   p->refine = 1;
   p->warm_start = 0;  /* evaluated: 12% fewer sweeps on the config-2 workload, not worth the state; off, device has no counterpart */
@@ -537,28 +537,39 @@ static double slip_dE(const slip_coef* k, double x, double y) {
  * (a minimum, not a maximum, nearby), |dtheta| <= 0.25 rad, and for steps above 0.02 rad no energy increase.
  * Returns 0 when rejected (the caller then runs the global search). */
 #define ORC_DEN_NEWTON 1e-3
+#define ORC_POLISH_STEPS 2
 #ifdef ORC_STATS
 long orc_stats[8];   /* [0] newton accepted, [1..5] rejected at den0 / hp / |d| / den1 / E, [6] global searches */
 #define ORC_STAT(i) (++orc_stats[i])
 #else
 #define ORC_STAT(i) ((void)0)
 #endif
-static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, double* y1) {
+/* Newton step of h(theta) = slip_dE at the unit direction (x0, y0): returns dtheta = -h / h' and h' through *hp */
+static double slip_newton_step(const slip_coef* k, double x0, double y0, double* hp) {
   double den = k->a0 + k->a1 * x0 + k->a2 * y0;
-  if (!(den > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(1); return 0; }
   double mdp = k->a2 * x0 - k->a1 * y0;
   double N0 = k->n00 + k->n01 * x0 + k->n02 * y0, N1 = k->n10 + k->n11 * x0 + k->n12 * y0;
   double dN0 = k->n02 * x0 - k->n01 * y0, dN1 = k->n12 * x0 - k->n11 * y0;
   double P = N1 * x0 - N0 * y0, Q = N0 * x0 + N1 * y0;
   double h = den * P - mdp * Q;
-  double hp = den * (dN1 * x0 - dN0 * y0) - k->a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
-  if (!(hp > 0.0)) { ORC_STAT(2); return 0; }
-  double d = -h / hp;
-  if (!(fabs(d) <= 0.25)) { ORC_STAT(3); return 0; }
+  *hp = den * (dN1 * x0 - dN0 * y0) - k->a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
+  return -h / *hp;
+}
+/* (x0, y0) rotated by the small angle d (|d| <= 0.25: degree-5 Taylor polynomials), renormalised */
+static void slip_rotate(double x0, double y0, double d, double* x1, double* y1) {
   double d2 = d * d;
   double c = 1.0 - d2 * (0.5 - d2 * (1.0 / 24.0)), s = d * (1.0 - d2 * ((1.0 / 6.0) - d2 * (1.0 / 120.0)));
   double x = x0 * c - y0 * s, y = x0 * s + y0 * c, inv = 1.0 / sqrt(x * x + y * y);
-  x *= inv; y *= inv;
+  *x1 = x * inv; *y1 = y * inv;
+}
+static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, double* y1) {
+  double den = k->a0 + k->a1 * x0 + k->a2 * y0, hp;
+  if (!(den > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(1); return 0; }
+  double d = slip_newton_step(k, x0, y0, &hp);
+  if (!(hp > 0.0)) { ORC_STAT(2); return 0; }
+  if (!(fabs(d) <= 0.25)) { ORC_STAT(3); return 0; }
+  double x, y;
+  slip_rotate(x0, y0, d, &x, &y);
   if (!(k->a0 + k->a1 * x + k->a2 * y > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(4); return 0; }
   if (fabs(d) > 0.02 && !(slip_E(k, x, y) <= slip_E(k, x0, y0))) { ORC_STAT(5); return 0; }
   ORC_STAT(0);
@@ -575,7 +586,9 @@ static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, dou
  *            round 0 : E at 16 directions 22.5 deg apart; the best one +-1 neighbour brackets the minimiser;
  *            rounds 1..section_rounds : 16-section on the sign of dE/dtheta: 15 candidates on the chord between
  *                      the bracket ends (normalised), the first candidate with dE >= 0 closes the bracket from
- *                      above; the new ends are the (un-normalised) chord points -> 45deg / 16^5 = 7.5e-7 rad.
+ *                      above; the new ends are the (un-normalised) chord points -> 45deg / 16^2 = 3e-3 rad;
+ *            polish  : two Newton steps on dE/dtheta from the bracket midpoint, clamped to the bracket
+ *                      (quadratic convergence: 1.5e-3 -> ~1e-6 -> ~1e-12 rad).
  *          16-section instead of bisection because the device evaluates the 15 (16) candidates of a round on the
  *          lanes of the env group at once; the oracle walks the same candidates sequentially.
  */
@@ -634,8 +647,17 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
     if (kstar < 15) { hix = nhx; hiy = nhy; }
     if (kstar > 0) { lox = nlx; loy = nly; }
   }
-  double x = lox + hix, y = loy + hiy, inv = 1.0 / sqrt(x * x + y * y);
-  x *= inv; y *= inv;
+  /* polish: two Newton steps from the bracket midpoint, each clamped to the bracket's half width */
+  double mx = lox + hix, my = loy + hiy, ex = hix - lox, ey = hiy - loy;
+  double im = 1.0 / sqrt(mx * mx + my * my), w = sqrt(ex * ex + ey * ey) * im;
+  double x = mx * im, y = my * im;
+  for (int r = 0; r < ORC_POLISH_STEPS; ++r) {
+    double hp, d = slip_newton_step(&k, x, y, &hp);
+    if (!(hp > 0.0)) d = 0.0;
+    if (d > w) d = w;
+    if (d < -w) d = -w;
+    slip_rotate(x, y, d, &x, &y);
+  }
   double den = k.a0 + k.a1 * x + k.a2 * y;
   if (!(den > ORC_DEN_MIN * k.a0)) den = ORC_DEN_MIN * k.a0;
   double ln = -v[2] / den;

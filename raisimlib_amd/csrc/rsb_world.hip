@@ -52,7 +52,7 @@ struct rsb_world {
   // parameters
   double dt = 0.0025, gravity[3] = {0, 0, -9.81}, mu = 0.8, erp = 0.0;
   double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
-  int max_iter = 150, section_rounds = 5, stall_window = 6, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
+  int max_iter = 150, section_rounds = 2, stall_window = 6, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
   double stall_factor = 0.5;
@@ -161,7 +161,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.con = take(kcap * rsbk::kConSlot);
   L.wc = take(3 * kcap * cw);
   L.cv = take(3 * kcap);
-  L.gstride = 3 * kcap + 4;
+  L.gstride = 4 * kcap + 4;   // 3x3 blocks on a 4-float pitch, +4 staggers the banks of consecutive rows
   L.g = take(3 * kcap * L.gstride);
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
@@ -308,6 +308,8 @@ int do_integrate(rsb_world* w, int nsub) {
   const size_t lds_bytes = lds_bytes_for(w->blob, kcap, lpe);
   static const bool poison = std::getenv("RSB_POISON_LDS") != nullptr;  // debug aid, see tests/test_gpu_properties.py
   a.poison_lds = poison ? 1 : 0;
+  static const bool prof_fine = std::getenv("RSB_PROF_FINE") != nullptr;  // debug aid: also time searches / Newton steps / epilogues
+  a.prof_fine = prof_fine ? 1 : 0;
   a.lds_floats = (int)(lds_bytes / sizeof(float));
   if (w->timing) HIP_TRY(hipEventRecord(w->ev0, w->stream));
   // kernel classes by (longest chain, deepest body level): <=4/<=4 (quadrupeds), <=8/<=12 (humanoids), <=16/<=16
@@ -774,7 +776,7 @@ int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, fl
 int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16) {
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  const size_t nprof = 16 + 4 * (size_t)w->N;  // 16 phase stamps + 4 words per workgroup (upper bound: one env per wave)
+  const size_t nprof = 16 + 16 * (size_t)w->N;  // 16 phase stamps + 16 words per workgroup (upper bound: one env per wave)
   if (enable && !w->d_prof) { HIP_TRY(hipMalloc(&w->d_prof, nprof * sizeof(long long))); HIP_TRY(hipMemset(w->d_prof, 0, nprof * sizeof(long long))); }
   if (out16 && w->d_prof) {
     HIP_TRY(hipMemcpyAsync(out16, w->d_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
@@ -789,7 +791,7 @@ int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16) {
 int rsb_debug_wave_profile(rsb_world* w, long long* out, int n_blocks) {
   if (!w || !out || !w->d_prof || n_blocks > w->N) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipMemcpyAsync(out, w->d_prof + 16, 4 * (size_t)n_blocks * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
+  HIP_TRY(hipMemcpyAsync(out, w->d_prof + 16, 16 * (size_t)n_blocks * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
   HIP_TRY(hipStreamSynchronize(w->stream));
   return RSB_OK;
 }

@@ -55,6 +55,7 @@ constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence
 constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
 constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
+constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
@@ -100,6 +101,7 @@ struct StepArgs {
   long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
   float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)
   int dbg_env;
+  int prof_fine;    // debug: stamp the inner solver blocks too (each stamp costs ~100 cycles)
   int poison_lds;   // debug: fill the whole LDS allocation with NaNs first (catches reads of never-written LDS)
   int lds_floats;
   int N, nsub, kmax, control_mode;
@@ -238,24 +240,35 @@ __device__ __forceinline__ float slip_dE(const SlipCoef& k, float x, float y, fl
   const float h = den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
   return (den > kDenMin * k.a0) ? h : ((bx * y - by * x > 0.f) ? 1.f : -1.f);
 }
-// One guarded Newton step on h(theta) = slip_dE from the direction (x0, y0) of an earlier slip solve of the same
-// contact (oracle: slip_newton).  Branch-free: every lane runs it on its own contact, `ok` says whether the step
-// is a safe descent step (else the caller runs the cooperative global search).
-__device__ __forceinline__ bool slip_newton(const SlipCoef& k, float mu, float x0, float y0, float& x1, float& y1) {
+// Newton step of h(theta) = slip_dE at the unit direction (x0, y0) (oracle: slip_newton_step): dtheta and h'
+__device__ __forceinline__ float slip_newton_step(const SlipCoef& k, float x0, float y0, float& hp) {
   const float den = k.a0 + k.a1 * x0 + k.a2 * y0;
   const float mdp = k.a2 * x0 - k.a1 * y0;
   const float N0 = k.n00 + k.n01 * x0 + k.n02 * y0, N1 = k.n10 + k.n11 * x0 + k.n12 * y0;
   const float dN0 = k.n02 * x0 - k.n01 * y0, dN1 = k.n12 * x0 - k.n11 * y0;
   const float P = N1 * x0 - N0 * y0, Q = N0 * x0 + N1 * y0;
   const float h = den * P - mdp * Q;
-  const float hp = den * (dN1 * x0 - dN0 * y0) - k.a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
-  const float d = -h * __builtin_amdgcn_rcpf(hp);
+  hp = den * (dN1 * x0 - dN0 * y0) - k.a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
+  return -h * __builtin_amdgcn_rcpf(hp);
+}
+// (x0, y0) rotated by the small angle d (oracle: slip_rotate), renormalised
+__device__ __forceinline__ void slip_rotate(float x0, float y0, float d, float& x1, float& y1) {
   const float d2 = d * d;
   const float c = 1.0f - d2 * (0.5f - d2 * (1.0f / 24.0f)), sn = d * (1.0f - d2 * ((1.0f / 6.0f) - d2 * (1.0f / 120.0f)));
-  float x = x0 * c - y0 * sn, y = x0 * sn + y0 * c;
+  const float x = x0 * c - y0 * sn, y = x0 * sn + y0 * c;
   const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
-  x *= inv; y *= inv;
-  bool ok = (den > kDenNewton * k.a0) && (hp > 0.f) && (fabsf(d) <= 0.25f) && (k.a0 + k.a1 * x + k.a2 * y > kDenNewton * k.a0);
+  x1 = x * inv; y1 = y * inv;
+}
+// One guarded Newton step from the direction (x0, y0) of an earlier slip solve of the same contact (oracle:
+// slip_newton).  Branch-free: every lane runs it on its own contact, the result says whether the step is a safe
+// descent step (else the caller runs the cooperative global search).
+__device__ __forceinline__ bool slip_newton(const SlipCoef& k, float mu, float x0, float y0, float& x1, float& y1) {
+  float hp;
+  const float d = slip_newton_step(k, x0, y0, hp);
+  float x, y;
+  slip_rotate(x0, y0, d, x, y);
+  bool ok = (k.a0 + k.a1 * x0 + k.a2 * y0 > kDenNewton * k.a0) && (hp > 0.f) && (fabsf(d) <= 0.25f) &&
+            (k.a0 + k.a1 * x + k.a2 * y > kDenNewton * k.a0);
   if (__any(ok && fabsf(d) > 0.02f)) ok = ok && (fabsf(d) <= 0.02f || slip_E(k, mu, x, y) <= slip_E(k, mu, x0, y0));
   x1 = x; y1 = y;
   return ok;
@@ -266,6 +279,14 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned x) {
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x124, 0xf, 0xf, false));  // row_ror:4
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x122, 0xf, 0xf, false));  // row_ror:2
   x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x121, 0xf, 0xf, false));  // row_ror:1
+  return x;
+}
+// 16-lane row maximum of a non-negative-or-any float (DPP row rotate)
+__device__ __forceinline__ float row_max_f32(float x) {
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true)));
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, true)));
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, true)));
+  x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, true)));
   return x;
 }
 // compile-time loop (the index is needed as a template argument of row_bcast)
@@ -280,16 +301,17 @@ __device__ __forceinline__ void static_for(F&& f) {
 // lane J of every 16-lane row -> all lanes of that row (DPP row_newbcast: VALU speed, no LDS)
 template <int J>
 __device__ __forceinline__ float row_bcast(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + J, 0xf, 0xf, false));
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + J, 0xf, 0xf, true));
 }
 
-// Cooperative slip solve: all lanes of the env group hold the same coefficients; lane (s & 15) evaluates
-// candidate (s & 15) of every round.  (c16, s16) = this lane's round-0 direction (22.5 deg grid); BR16[k] =
-// {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).  Bracket ends stay un-normalised
-// chord points between rounds (as in the oracle); only candidates and the final direction are normalised.
+// Cooperative slip direction search: all lanes of the env group hold the same coefficients; lane (s & 15)
+// evaluates candidate (s & 15) of every round.  (c16, s16) = this lane's round-0 direction (22.5 deg grid);
+// BR16[k] = {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).  Bracket ends stay
+// un-normalised chord points between rounds (as in the oracle); candidates are normalised.  After the section
+// rounds every lane polishes the bracket midpoint by two clamped Newton steps (oracle: ORC_POLISH_STEPS).
 template <int LPE>
 __device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int rounds, int s, int el, float c16, float s16,
-                                            const float* BR16, float* lam, float* dir) {
+                                            const float* BR16, float* dir) {
   const int k = s & 15;
   const float e0 = slip_E(kf, mu, c16, s16);
   const unsigned key = (__float_as_uint(e0) & ~15u) | (unsigned)k;
@@ -313,12 +335,17 @@ __device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int ro
     if (kstar < 15) { hix = nhx; hiy = nhy; }
     if (kstar > 0) { lox = nlx; loy = nly; }
   }
-  float x = lox + hix, y = loy + hiy;
-  const float inv = __builtin_amdgcn_rsqf(x * x + y * y);
-  x *= inv; y *= inv;
-  const float den = fmaxf(kf.a0 + kf.a1 * x + kf.a2 * y, kDenMin * kf.a0);
-  const float ln = -kf.vn * __builtin_amdgcn_rcpf(den);
-  lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
+  const float mx = lox + hix, my = loy + hiy, ex = hix - lox, ey = hiy - loy;
+  const float im = __builtin_amdgcn_rsqf(mx * mx + my * my);
+  const float w = sqrtf(ex * ex + ey * ey) * im;
+  float x = mx * im, y = my * im;
+  RSB_UNROLL for (int r = 0; r < kPolishSteps; ++r) {
+    float hp;
+    float d = slip_newton_step(kf, x, y, hp);
+    d = (hp > 0.f) ? d : 0.f;
+    d = fminf(fmaxf(d, -w), w);
+    slip_rotate(x, y, d, x, y);
+  }
   dir[0] = x; dir[1] = y;
 }
 
@@ -449,7 +476,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     TF[i] = a.tauff[(size_t)env * nv + i];
   }
   int flag = 0, iters_used = 0, nc = 0;
-  long long t_start = 0, t_gs = 0; int p_iters = 0, p_ncw = 0;
+  long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
   if (a.prof) t_start = clock64();
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
@@ -794,8 +821,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           }
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
             RSB_UNROLL for (int cc = 0; cc < 3; ++cc) {
-              G[(3 * i + rr) * GS + 3 * j + cc] = acc[3 * rr + cc];
-              G[(3 * j + cc) * GS + 3 * i + rr] = acc[3 * rr + cc];
+              G[(3 * i + rr) * GS + 4 * j + cc] = acc[3 * rr + cc];   // 3x3 blocks on a 4-float pitch (16-B aligned rows of a block)
+              G[(3 * j + cc) * GS + 4 * i + rr] = acc[3 * rr + cc];
             }
           if (i == j) {
             float gi[12];
@@ -815,79 +842,96 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       // impulse change is broadcast with DPP row_newbcast and every lane updates its own contact velocity.
       {
         const bool isc = s < nc;
-        float Grow[3][3 * KMAX], Gii[9], Ginv[12], v[3], lam[3] = {0.f, 0.f, 0.f};
-        RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-          RSB_UNROLL for (int q4 = 0; q4 < (3 * KMAX) / 4; ++q4) {
-            // columns past this env's 3*nc were never written (stale LDS, possibly NaN bit patterns): force them to 0
-            float g4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (isc) ld4(G + (3 * s + rr) * GS + 4 * q4, g4);
-            RSB_UNROLL for (int e = 0; e < 4; ++e) Grow[rr][4 * q4 + e] = (isc && 4 * q4 + e < 3 * nc) ? g4[e] : 0.f;
-          }
+        // The G rows of the own contact stay in LDS (one 3x3 block per contact update is read when needed): keeping
+        // all 3 x 3*KMAX entries in registers pushed the loop's working set into AGPRs.
+        float Gii[9], Ginv[12], v[3], lam[3] = {0.f, 0.f, 0.f};
+        const float* Gmine = G + 3 * s * GS;
         RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gii[q2] = 0.f;
         RSB_UNROLL for (int q2 = 0; q2 < 12; ++q2) Ginv[q2] = 0.f;
         v[0] = v[1] = v[2] = 0.f;
         if (isc) {
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-            RSB_UNROLL for (int cc = 0; cc < 3; ++cc) Gii[3 * rr + cc] = G[(3 * s + rr) * GS + 3 * s + cc];
+            RSB_UNROLL for (int cc = 0; cc < 3; ++cc) Gii[3 * rr + cc] = G[(3 * s + rr) * GS + 4 * s + cc];
           ldv<3>(GINV + 12 * s, Ginv);
           v[0] = CV[3 * s]; v[1] = CV[3 * s + 1]; v[2] = CV[3 * s + 2];
         }
-        float lamn_all[KMAX];  // every lane tracks all normal impulses of its env (for the relative test)
-        RSB_UNROLL for (int j = 0; j < KMAX; ++j) lamn_all[j] = 0.f;
         const float mu2 = a.mu * a.mu;
+        // per-solve constants of the own contact: den(d) = a0 + a1 x + a2 y; n01.. hold mu * G_tt (see slip_prepare)
+        SlipCoef sc;
+        sc.a0 = Gii[8]; sc.a1 = a.mu * Gii[6]; sc.a2 = a.mu * Gii[7];
+        sc.n01 = a.mu * Gii[0]; sc.n02 = a.mu * Gii[1]; sc.n11 = a.mu * Gii[3]; sc.n12 = a.mu * Gii[4];
+        sc.n00 = sc.n10 = sc.vn = sc.ls0 = sc.ls1 = 0.f;
         float lam_best[3] = {0.f, 0.f, 0.f}, best_rel = 3e38f;   // calmest iterate (returned when the solve does not converge)
         float sdx = 0.f, sdy = 0.f;   // friction direction of this contact's last slip solve (|.| = 1 once set)
         bool sdv = false;
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
+        if (a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
           const bool active = isc && !done;
+          const bool lag = a.freeze_after > 0 && it >= a.freeze_after;
           static_for<0, KMAX>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (j < ncw) {  // wave-uniform
-              // open / stick candidates: every lane evaluates its own contact branch-free, lane j's result is used
+              // open / stick candidates: every lane evaluates its own contact branch-free, lane j's result is used.
+              // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
               const bool mine = (s == j) && active;
-              float vex[3], ls[3];
+              // this contact's coupling block with contact j (columns of contacts this env does not have are stale LDS)
+              float gj[3][4];
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) RSB_UNROLL for (int e = 0; e < 4; ++e) gj[rr][e] = 0.f;
+              if (isc && j < nc) { RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]); }
+              float ls[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                vex[rr] = v[rr] - (Gii[3 * rr] * lam[0] + Gii[3 * rr + 1] * lam[1] + Gii[3 * rr + 2] * lam[2]);
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                ls[rr] = -(Ginv[3 * rr] * vex[0] + Ginv[3 * rr + 1] * vex[1] + Ginv[3 * rr + 2] * vex[2]);
-              const bool open = vex[2] > 0.f;
+                ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
+              const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
+              const bool open = vexn > 0.f;
               const bool stick = !open && ls[2] >= 0.f && (ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2];
               const bool slip = mine && !open && !stick;
-              // lagged friction direction: after freeze_after sweeps a slipping contact keeps its last direction
-              const float dfz = Gii[8] + a.mu * (Gii[6] * sdx + Gii[7] * sdy);   // normal response along the kept direction
-              const bool frozen = slip && sdv && a.freeze_after > 0 && it >= a.freeze_after && dfz >= kDenFreeze * Gii[8];
-              // a contact that slipped earlier in this solve refines its direction by one guarded Newton step on its own lane
-              const bool cand = slip && !frozen && sdv && a.refine != 0;
-              SlipCoef kc;
-              bool refined = false;
-              if (__any(slip && !frozen)) slip_prepare(Gii, vex, ls, a.mu, kc);
-              if (__any(cand)) {
-                float nx, ny;
-                refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny) && cand;
-                if (refined) { sdx = nx; sdy = ny; }
-              }
-              const bool need = slip && !frozen && !refined;
               float ln[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
-              if (__any(need)) {
-                // the owner's 12 solve constants are broadcast; the row searches the direction together
-                SlipCoef kb;
-                kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
-                kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
-                kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
-                kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
-                float lsl[3], dxy[2];
-                slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, lsl, dxy);
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = need ? lsl[rr] : ln[rr];
-                if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; }
-              }
-              if (frozen || refined) {
-                const float lnn = -vex[2] * __builtin_amdgcn_rcpf(Gii[8] + a.mu * (Gii[6] * sdx + Gii[7] * sdy));
-                ln[0] = a.mu * lnn * sdx; ln[1] = a.mu * lnn * sdy; ln[2] = lnn;
+              if (a.prof) ++p_solves;
+              if (__any(slip)) {
+                // lagged friction direction: after freeze_after sweeps a slipping contact keeps its last direction
+                // when the normal response along it is well conditioned
+                const bool frozen = slip && sdv && lag && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
+                if (__any(slip && !frozen)) {
+                  SlipCoef kc = sc;
+                  const float vex0 = v[0] - (Gii[0] * lam[0] + Gii[1] * lam[1] + Gii[2] * lam[2]);
+                  const float vex1 = v[1] - (Gii[3] * lam[0] + Gii[4] * lam[1] + Gii[5] * lam[2]);
+                  kc.n00 = sc.a0 * vex0 - vexn * Gii[2]; kc.n01 = sc.a1 * vex0 - vexn * sc.n01; kc.n02 = sc.a2 * vex0 - vexn * sc.n02;
+                  kc.n10 = sc.a0 * vex1 - vexn * Gii[5]; kc.n11 = sc.a1 * vex1 - vexn * sc.n11; kc.n12 = sc.a2 * vex1 - vexn * sc.n12;
+                  kc.vn = vexn; kc.ls0 = ls[0]; kc.ls1 = ls[1];
+                  // a contact that slipped earlier in this solve refines its direction by one guarded Newton step on its own lane
+                  const bool cand = slip && !frozen && sdv && a.refine != 0;
+                  bool refined = false;
+                  if (__any(cand)) {
+                    long long tn0 = 0; if (a.prof) { ++p_newton; if (a.prof_fine) tn0 = clock64(); }
+                    float nx, ny;
+                    refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny) && cand;
+                    if (refined) { sdx = nx; sdy = ny; }
+                    if (a.prof && a.prof_fine) t_newt += clock64() - tn0;
+                  }
+                  const bool need = slip && !frozen && !refined;
+                  if (__any(need)) {
+                    long long ts0 = 0; if (a.prof) { ++p_search; if (a.prof_fine) ts0 = clock64(); }
+                    // the owner's 12 solve constants are broadcast; the row searches the direction together
+                    SlipCoef kb;
+                    kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
+                    kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
+                    kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
+                    kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
+                    float dxy[2];
+                    slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, dxy);
+                    if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; }
+                    if (a.prof && a.prof_fine) t_srch += clock64() - ts0;
+                  }
+                }
+                // impulse along the kept / refined / searched direction: v_n^+ = 0 on the cone boundary
+                const float lnn = -vexn * __builtin_amdgcn_rcpf(fmaxf(sc.a0 + sc.a1 * sdx + sc.a2 * sdy, kDenMin * sc.a0));
+                const float ltn = a.mu * lnn;
+                ln[0] = slip ? ltn * sdx : ln[0]; ln[1] = slip ? ltn * sdy : ln[1]; ln[2] = slip ? lnn : ln[2];
               }
               float dl[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
@@ -896,12 +940,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                 dl[rr] = row_bcast<j>(dl[rr]);
               }
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                v[rr] += Grow[rr][3 * j] * dl[0] + Grow[rr][3 * j + 1] * dl[1] + Grow[rr][3 * j + 2] * dl[2];
+                v[rr] += gj[rr][0] * dl[0] + gj[rr][1] * dl[1] + gj[rr][2] * dl[2];
               err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
-              lamn_all[j] += dl[2];
-              scale = fmaxf(scale, lamn_all[j]);
             }
           });
+          scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
+          long long te0 = 0; if (a.prof && a.prof_fine) te0 = clock64();
           if (!done) {
             ++iters_used;
             alpha = fmaxf(alpha * a.alpha_decay, a.alpha_min);
@@ -918,6 +962,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               }
             }
           }
+          if (a.prof && a.prof_fine) t_epi += clock64() - te0;
           if (!__any(!done)) break;
         }
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
@@ -929,7 +974,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         const int n3 = 3 * nc;
         a.dbg[0] = (float)nc;
         for (int i = 0; i < n3; ++i)
-          for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + j];
+          for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + 4 * (j / 3) + (j % 3)];
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + n3 + i] = LAM[i];
       }
@@ -1030,7 +1075,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
-  if (a.prof && lane == 0) { long long* P = a.prof + 16 + 4 * (long long)blockIdx.x; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; }
+  if (a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
   // ---- results: LDS -> HBM
   if (env_valid) {
     bool bad = false;

@@ -281,6 +281,6 @@ class BatchedWorld:
 
     def debug_wave_profile(self):
         nb = (self.N * self.lanes_per_env() + 63) // 64
-        out = np.zeros((nb, 4), np.int64)
+        out = np.zeros((nb, 16), np.int64)
         check(self.L.rsb_debug_wave_profile(self.handle, _hp(out), nb), "rsb_debug_wave_profile")
         return out

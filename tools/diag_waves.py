@@ -28,4 +28,18 @@ t, g, it, nc = P[:, 0], P[:, 1], P[:, 2], P[:, 3]
 print("all: non-GS cycles by max ncw:", {int(k): int(np.median((t - g)[nc == k])) for k in np.unique(nc)})
 sw = it > 0
 print("GS cycles per sweep (median) by ncw:", {int(k): int(np.median((g[sw & (nc == k)] / it[sw & (nc == k)]))) for k in np.unique(nc) if (sw & (nc == k)).any()})
+ns, nn, nsol, tsr = P[:, 4], P[:, 5], P[:, 6], P[:, 7]
+print(f"per launch-wave medians: contact solves {np.median(nsol):.0f}, global searches {np.median(ns):.0f}, newton blocks {np.median(nn):.0f}, cycles in searches {np.median(tsr):.0f} ({np.median(tsr/np.maximum(g,1)):.2f} of GS), cycles/search {np.median(tsr/np.maximum(ns,1)):.0f}")
+print(f"  GS set-up cycles {np.median(P[:,8]):.0f}, newton cycles {np.median(P[:,9]):.0f} ({np.median(P[:,9]/np.maximum(nn,1)):.0f} each), sweep epilogue cycles {np.median(P[:,10]):.0f} ({np.median(P[:,10]/np.maximum(it,1)):.0f} per sweep)")
+o = np.argsort(-t)[:20]
+print(f"slowest 20 waves: solves {nsol[o].mean():.0f} searches {ns[o].mean():.0f} newton {nn[o].mean():.0f} search cycles {tsr[o].mean():.0f} of GS {g[o].mean():.0f} of total {t[o].mean():.0f}")
 print("sweeps per launch-wave: median", np.median(it), "p99", np.percentile(it, 99), "max", it.max())
+
+# marginal costs by least squares over all sampled waves: GS cycles ~ c0 + c1*sweeps + c2*solves + c3*newton + c4*searches
+A = np.stack([np.ones_like(g), it, nsol, nn, ns], 1).astype(np.float64)
+coef, *_ = np.linalg.lstsq(A, g.astype(np.float64), rcond=None)
+print("GS cycles fit: const %.0f + %.0f/sweep + %.0f/contact-solve + %.0f/newton block + %.0f/global search" % tuple(coef),
+      "| residual rms %.0f" % np.sqrt(np.mean((A @ coef - g) ** 2)))
+A2 = np.stack([np.ones_like(g), (nc >= 1) * 1.0, nc], 1).astype(np.float64)
+c2, *_ = np.linalg.lstsq(A2, (t - g).astype(np.float64), rcond=None)
+print("non-GS cycles fit: %.0f + %.0f (any contact) + %.0f per wave-max contact" % tuple(c2))
