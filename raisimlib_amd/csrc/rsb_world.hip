@@ -140,6 +140,8 @@ int longest_chain(const rsb_model_blob& b) {
   return dm->max_cl;
 }
 
+int count_chains(const rsb_model_blob& b);
+
 LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   LdsLayout L;
   const int cw = round4(6 + b.depth - 1);
@@ -150,12 +152,16 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.t_parlv = take(b.nb);
   L.t_anc = take(b.nb * b.depth);
   L.t_dir = take(64);
+  L.t_col = take(8 * b.ncol);
+  L.t_cc = take(b.nb);
+  L.t_ccl = take(count_chains(b) > 0 ? count_chains(b) : 1);
   L.shared_total = o;
   o = 0;
   L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
   L.pt = take(b.nq); L.dtg = take(b.nv); L.tf = take(b.nv < 8 ? 8 : b.nv);
   L.body = take(b.nb * rsbk::kBodySlot);
-  L.ups = take((b.nb > 1 ? b.nb - 1 : 1) * rsbk::kUpSlot);
+  L.ups = take((count_chains(b) > 0 ? count_chains(b) : 1) * rsbk::kUpSlot);
+  L.bacc = take(28);
   L.fact = take(b.nb * rsbk::kFactSlot);
   L.wb = take(b.nv);
   L.con = take(kcap * rsbk::kConSlot);

@@ -77,9 +77,9 @@ struct DevModel {
 
 struct LdsLayout {
   // per-block tables (floats from the start of LDS)
-  int t_model, t_gain, t_parlv, t_anc, t_dir, shared_total;
+  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_cc, t_ccl, shared_total;
   // per-env arrays (floats from the env base)
-  int q, u, pt, dtg, tf, body, ups, fact, wb, con, wc, cv, g, ginv, lam;
+  int q, u, pt, dtg, tf, body, ups, bacc, fact, wb, con, wc, cv, g, ginv, lam;
   int gstride;
   int per_env;
 };
@@ -416,6 +416,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   int* PARLV = reinterpret_cast<int*>(lds + L.t_parlv);          // [nb] (parent+1) | level << 8
   int* ANC = reinterpret_cast<int*>(lds + L.t_anc);              // [nb*depth]
   float* DIR16 = lds + L.t_dir;                                  // float4 [16] slip-search brackets
+  float* COLT = lds + L.t_col;                                   // [ncol][8] sphere centre (body frame), radius, body, pad
+  int* CCT = reinterpret_cast<int*>(lds + L.t_cc);               // [nb] cc_start | cc_count << 16 (chains hanging off the body)
+  int* CCL = reinterpret_cast<int*>(lds + L.t_ccl);              // [nch] chain ids, grouped by attachment body
   float* E = lds + L.shared_total + el * L.per_env;
   float* Q = E + L.q;
   float* U = E + L.u;
@@ -423,7 +426,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   float* DTG = E + L.dtg;
   float* TF = E + L.tf;
   float* BODY = E + L.body;
-  float* UPS = E + L.ups;
+  float* UPS = E + L.ups;                                        // [nch] articulated inertia + bias handed to the parent chain
+  float* BACC = E + L.bacc;                                      // [28] the same, summed over the chains attached to the base
   float* FACT = E + L.fact;
   float* WB = E + L.wb;
   float* CON = E + L.con;
@@ -447,6 +451,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     GAIN[2 * i + 1] = pd ? a.kd[i + 5] : 0.f;
   }
   for (int i = lane; i < nb * depth; i += 64) ANC[i] = m.anc[i];
+  for (int i = lane; i < nb; i += 64) CCT[i] = m.cc_start[i] | (m.cc_count[i] << 16);
+  for (int i = lane; i < nch; i += 64) CCL[i] = m.cc_list[i];
+  for (int i = lane; i < ncol; i += 64) {
+    float ct[8] = {m.col_pos[i][0], m.col_pos[i][1], m.col_pos[i][2], m.col_pos[i][3], __int_as_float(m.col_body[i]), 0.f, 0.f, 0.f};
+    stv<2>(COLT + 8 * i, ct);
+  }
   if (lane < 16) {  // BR16[k] = {cos,sin((k-1) pi/8), cos,sin((k+1) pi/8)}: slip-search bracket around grid point k
     float sn, cs, br[4];
     sincospif((float)((lane + 15) & 15) * 0.125f, &sn, &cs);
@@ -464,7 +474,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   const int ch_len = hasch ? m.ch_len[chi] : 0;
   const int ch_attach = m.ch_attach[chi];
   const int ch_lev = hasch ? m.ch_level[chi] : -1;
-  const int lev0 = m.level[ch_attach] + 1;  // body level of the chain's first body
   int chb[CL];
   RSB_UNROLL for (int k = 0; k < CL; ++k) chb[k] = m.ch_body[chi * kMaxCL + k];
 
@@ -484,6 +493,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
 
   for (int sub = 0; sub < a.nsub; ++sub) {
     RSB_STAMP(0)
+    for (int i = s; i < 28; i += LPE) BACC[i] = 0.f;   // summed into by the level-1 chains at the end of the up pass (a barrier lies in between)
     // =========================== base body, redundantly on every lane =========================
     float R0[9], V0[6], A0[6], I10b[10], Zb[6];
     {
@@ -599,8 +609,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       float cx[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 1.f}, dep = 0.f;
       int cbody = 0;
       if (ci < ncol) {
-        cbody = m.col_body[ci];
-        const float px = m.col_pos[ci][0], py = m.col_pos[ci][1], pz = m.col_pos[ci][2], rad = m.col_pos[ci][3];
+        float ct[8];
+        ld4(COLT + 8 * ci, ct); ct[4] = COLT[8 * ci + 4];
+        cbody = __float_as_int(ct[4]);
+        const float px = ct[0], py = ct[1], pz = ct[2], rad = ct[3];
         float P[12];
         ldv<3>(BODY + cbody * kBodySlot, P);
         const float pl[3] = {px, py, pz};
@@ -655,10 +667,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += IAc[i];
             RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = cZ[k][i] + Zc[i];
             if (max_cc > 0) {  // chains hanging off this body (none for pure star topologies)
-              const int ccn = m.cc_count[b], ccs = m.cc_start[b];
+              const int cct = CCT[b], ccn = cct >> 16, ccs = cct & 0xffff;
               for (int ci = 0; ci < ccn; ++ci) {
                 float P[28];
-                ldv<7>(UPS + m.cc_list[ccs + ci] * kUpSlot, P);
+                ldv<7>(UPS + CCL[ccs + ci] * kUpSlot, P);
                 RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
                 RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
               }
@@ -684,11 +696,17 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             WB[b + 5] = yhat * rsD;
           }
         }
-        float P[28];
-        RSB_UNROLL for (int i = 0; i < 21; ++i) P[i] = IAc[i];
-        RSB_UNROLL for (int i = 0; i < 6; ++i) P[21 + i] = Zc[i];
-        P[27] = 0.f;
-        stv<7>(UPS + chi * kUpSlot, P);
+        if (ch_attach == 0) {
+          // chains on the base: summed in LDS (float atomics of one instruction are served in lane order -> reproducible)
+          RSB_UNROLL for (int i = 0; i < 21; ++i) atomicAdd(&BACC[i], IAc[i]);
+          RSB_UNROLL for (int i = 0; i < 6; ++i) atomicAdd(&BACC[21 + i], Zc[i]);
+        } else {
+          float P[28];
+          RSB_UNROLL for (int i = 0; i < 21; ++i) P[i] = IAc[i];
+          RSB_UNROLL for (int i = 0; i < 6; ++i) P[21 + i] = Zc[i];
+          P[27] = 0.f;
+          stv<7>(UPS + chi * kUpSlot, P);
+        }
       }
       __syncthreads();
     }
@@ -699,10 +717,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       float IA[21], Z[6];
       rigid_expand(I10b, IA);
       RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = Zb[i];
-      const int ccn = m.cc_count[0], ccs = m.cc_start[0];
-      for (int ci = 0; ci < ccn; ++ci) {
+      {
         float P[28];
-        ldv<7>(UPS + m.cc_list[ccs + ci] * kUpSlot, P);
+        ldv<7>(BACC, P);
         RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
         RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
       }
@@ -734,7 +751,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           float CN[16];
           ldv<4>(CON + i * kConSlot, CN);
           const float* x = CN;
-          const float* t = CN + 4 + 4 * rr;
+          float t[4];
+          ld4(CON + i * kConSlot + 4 + 4 * rr, t);   // axis rr of the contact frame
           const int kb = __float_as_int(CN[7]);
           const int lev = PARLV[kb] >> 8;
           // prefetch the support chain's factors (independent loads), then propagate the unit impulse
@@ -835,6 +853,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
       RSB_STAMP(5)
 
+      if (a.dbg && env == a.dbg_env && env_valid && s == 0) {   // debug aid: the contact problem as the solver sees it
+        const int n3 = 3 * nc;
+        a.dbg[0] = (float)nc;
+        for (int i = 0; i < n3; ++i)
+          for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + 4 * (j / 3) + (j % 3)];
+        for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
+      }
       long long t_gs0 = 0; if (a.prof) t_gs0 = clock64();
       // ========================= per-contact Gauss-Seidel (lane = contact) ==========================
       // Lane j (< nc) owns contact j: its G rows, own block, velocity and impulse stay in registers.  Per
@@ -867,6 +892,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
+        // CV has been consumed: its first 6 floats now accumulate the base part of sum_c W_c lam_c
+        if (s < 6) CV[s] = 0.f;
         if (a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
@@ -966,16 +993,32 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           if (!__any(!done)) break;
         }
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
-        if (isc) { LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2]; }
+        if (isc) {
+          LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2];
+          // W^T lam scattered by the contact lanes (LDS float atomics; lanes of one instruction are served in lane
+          // order, so the sums are reproducible): base entries -> CV[0..5], joint entries -> WB of the support chain
+          const float* W0 = WC + 3 * s * cw;
+          float z0[8], z1[8], z2[8];
+          ld4(W0, z0); ld4(W0 + 4, z0 + 4); ld4(W0 + cw, z1); ld4(W0 + cw + 4, z1 + 4); ld4(W0 + 2 * cw, z2); ld4(W0 + 2 * cw + 4, z2 + 4);
+          const int bi = __float_as_int(CON[s * kConSlot + 7]);
+          RSB_UNROLL for (int i = 0; i < 6; ++i) atomicAdd(&CV[i], z0[i] * lam[0] + z1[i] * lam[1] + z2[i] * lam[2]);
+          RSB_UNROLL for (int lv = 1; lv <= ML; ++lv) {
+            if (lv < depth) {
+              const int b = ANC[bi * depth + lv];
+              if (b >= 0) {
+                float w0, w1, w2;
+                if (lv < 3) { w0 = z0[5 + lv]; w1 = z1[5 + lv]; w2 = z2[5 + lv]; }
+                else { w0 = W0[5 + lv]; w1 = W0[cw + 5 + lv]; w2 = W0[2 * cw + 5 + lv]; }
+                atomicAdd(&WB[b + 5], w0 * lam[0] + w1 * lam[1] + w2 * lam[2]);
+              }
+            }
+          }
+        }
       }
       __syncthreads();
       if (a.prof) { t_gs += clock64() - t_gs0; int itw = iters_used; RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) itw = max(itw, __shfl_xor(itw, off)); p_iters += itw; p_ncw = max(p_ncw, ncw); }
       if (a.dbg && env == a.dbg_env && env_valid && s == 0) {
         const int n3 = 3 * nc;
-        a.dbg[0] = (float)nc;
-        for (int i = 0; i < n3; ++i)
-          for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + 4 * (j / 3) + (j % 3)];
-        for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + n3 + i] = LAM[i];
       }
     }
@@ -987,11 +1030,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     {
       float wv[6];
       RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] = wbb[i];
-      for (int c = 0; c < 3 * nc; ++c) {
+      if (ncw > 0) {   // base part of sum_c W_c lam_c, accumulated by the contact lanes at the end of the solve
         float z[8];
-        ld4(WC + c * cw, z); z[4] = WC[c * cw + 4]; z[5] = WC[c * cw + 5];
-        const float lc = LAM[c];
-        RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] += z[i] * lc;
+        ld4(CV, z); z[4] = CV[4]; z[5] = CV[5];
+        RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] += z[i];
       }
       float x[6];
       RSB_UNROLL for (int ii = 0; ii < 6; ++ii) {
@@ -1035,22 +1077,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           ld4(BODY + ch_attach * kBodySlot + 16, t6); ld4(BODY + ch_attach * kBodySlot + 20, t6 + 4);
           RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = t6[2 + i];
         }
-        // contact contributions to this chain's dofs: contacts outermost so that each contact's loads are issued together
+        // WB = W_b plus the contact contributions scattered by the contact lanes
         float wacc[CL];
         RSB_UNROLL for (int k = 0; k < CL; ++k) wacc[k] = (k < ch_len) ? WB[chb[k] + 5] : 0.f;
-        for (int i = 0; i < nc; ++i) {
-          const int bi = __float_as_int(CON[i * kConSlot + 7]);
-          const float l0 = LAM[3 * i], l1 = LAM[3 * i + 1], l2 = LAM[3 * i + 2];
-          RSB_UNROLL for (int k = 0; k < CL; ++k) {
-            if (k < ch_len) {
-              const int lv = lev0 + k;
-              if (ANC[bi * depth + lv] == chb[k]) {
-                const float* Wc = WC + (3 * i) * cw + 5 + lv;
-                wacc[k] += Wc[0] * l0 + Wc[cw] * l1 + Wc[2 * cw] * l2;
-              }
-            }
-          }
-        }
         RSB_UNROLL for (int k = 0; k < CL; ++k) {
           if (k < ch_len) {
             const int b = chb[k];
@@ -1060,7 +1089,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             U[b + 5] = un;
             Q[b + 6] = cqb[k] + dt * un;
             if (max_cc > 0) {
-              if (m.cc_count[b] > 0) {
+              if ((CCT[b] >> 16) > 0) {
                 float* Ab = BODY + b * kBodySlot + 18;
                 RSB_UNROLL for (int i = 0; i < 6; ++i) Ab[i] = ap[i];
               }
