@@ -32,6 +32,23 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/
 TARGET_BANK = 16                  # distinct pre-generated PD-target sets cycled through in the timed loop
 
 
+def recorded_traffic(n_envs, substeps):
+    """HBM bytes per launch of the step kernel from the newest committed PMC pass (profiles/rNN_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, tools/collect_profiles.sh).
+    The counters cannot be collected from inside this process, so the committed measurement is reported - only
+    when it was taken on this workload - together with its provenance; otherwise null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files or n_envs != ENVS_PER_GPU or substeps != 4:
+        return None, None
+    try:
+        rec = json.load(open(files[-1]))
+        return float(rec["hbm_bytes_per_launch_raw"]), os.path.relpath(files[-1], ROOT) + \
+            " (FETCH_SIZE+WRITE_SIZE per launch, raw: gfx950 factors for 4 B/lane row accesses are uncalibrated)"
+    except Exception:
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,6 +218,7 @@ def main():
     if rank == 0:
         kmean = float(kernel_ms.mean()) * 1e-3
         achieved = BYTES_PER_ENV_STEP * env_steps_per_step / kmean / 1e9
+        traffic, traffic_src = recorded_traffic(N, workload.SUBSTEPS) if reset and not args.max_iter else (None, None)
         out = {
             "metric": "env-steps/sec, 4096 ANYmal-C envs flat terrain dt=0.0025",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -217,7 +235,7 @@ def main():
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rsb_step_kernel", "kernel_ms_mean": float(kernel_ms.mean()),
                          "kernel_ms_p50": float(np.median(kernel_ms)),
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * env_steps_per_step},

@@ -16,14 +16,24 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python $R/bench.py --no-cpu --steps 50 --warmup 50 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/pmc_sq -o run -- python $R/bench.py --no-cpu --steps 50 --warmup 50 > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq2 -o run -- python $R/bench.py --no-cpu --steps 50 --warmup 50 > /dev/null 2>&1
-python - <<PY
-import csv, glob, collections
+python - <<PY > $O/pmc_summary.txt
+import csv, glob, collections, json
+out = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    fs = glob.glob("$O/%s/*counter_collection.csv" % sub)
-    acc = collections.defaultdict(float); n = collections.Counter()
+    fs = glob.glob("$O/%s/**/*counter_collection.csv" % sub, recursive=True)
+    acc = collections.defaultdict(float); n = collections.Counter(); kn = ""
     for r in csv.DictReader(open(fs[0])):
         if "rsb_step_kernel" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+            acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1; kn = r["Kernel_Name"]
     for k, v in acc.items():
         print(sub, k, "mean per dispatch", v / n[k], "dispatches", n[k])
+        out[k] = v / n[k]
+    out["kernel"] = kn
+# FETCH_SIZE / WRITE_SIZE are reported in KB (TCC_EA0_RDREQ x 64 B etc.); this kernel's accesses are 4 B/lane rows, for
+# which the gfx950 counters are uncalibrated (MI355X_MICROARCH.md, HBM): raw values, no correction applied
+json.dump({"fetch_kb_per_launch": out.get("FETCH_SIZE"), "write_kb_per_launch": out.get("WRITE_SIZE"),
+           "hbm_bytes_per_launch_raw": 1024.0 * ((out.get("FETCH_SIZE") or 0) + (out.get("WRITE_SIZE") or 0)),
+           "kernel": out.get("kernel"), "workload": "bench.py --no-cpu --steps 50 --warmup 50 (4096 envs x 4 sub-steps per launch)",
+           "counters": out}, open("$O/pmc_traffic.json", "w"), indent=1)
 PY
+cat $O/pmc_summary.txt
