@@ -224,13 +224,26 @@ int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, i
 int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_allowed, const float* gc0,
                          const float* gv0, int rows, uint8_t* done, int space);
 
+/* One control step of VectorizedEnvironment::step() [RECALL raisimGymTorch/env/VectorizedEnvironment.hpp] enqueued
+ * with a single call on the handle's stream: rsb_set_pd_target (device pointers, either may be NULL) ->
+ * rsb_integrate(n_substeps) -> rsb_gather_obs (skipped when obs_out is NULL) -> rsb_reset_terminated (skipped
+ * when gc0 or gv0 is NULL).  Index lists are host arrays, everything else lives on the device. */
+int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target, int n_substeps, float* obs_out,
+                     const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
+                     int n_allowed, const float* gc0, const float* gv0, int rows);
+
 /* zero-copy access to the resident state (device pointers; row-major [N,dim] float32): see rsb_field */
 void* rsb_device_ptr(rsb_world* w, int field);
 
 /* elapsed device time (ms) of the most recent rsb_integrate launch, measured with HIP events
  * on the handle's stream; also the kernel's static resource usage for reports. */
 int rsb_last_kernel_ms(rsb_world* w, float* ms);
+/* on = 0: no events; 1: one event pair (rsb_last_kernel_ms); n > 1: a ring of n event pairs, one per launch,
+ * read back after the fact with rsb_read_kernel_ms (no per-launch synchronisation). */
 int rsb_enable_timing(rsb_world* w, int on);
+/* durations (ms) of the last min(n, launches recorded) step-kernel launches, oldest first; synchronises the
+ * stream; returns how many were written (or a negative status) */
+int rsb_read_kernel_ms(rsb_world* w, float* ms, int n);
 
 /* Debug aid (tests): dump one env's contact problem of the last sub-step of the next launches:
  * nc, Delassus matrix G [3nc,3nc] row-major, free contact velocity c [3nc], impulses lam [3nc], all in

@@ -99,6 +99,8 @@ PROTOTYPES = {
     "rsb_device_ptr": (_VP, [_VP, _I]),
     "rsb_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
     "rsb_enable_timing": (_I, [_VP, _I]),
+    "rsb_read_kernel_ms": (_I, [_VP, _FP, _I]),
+    "rsb_control_step": (_I, [_VP, _FP, _FP, _I, _FP, _FP, _I, _FP, _I, _FP, _FP, _I]),
     "rsb_debug_select_env": (_I, [_VP, _I]),
     "rsb_debug_phase_cycles": (_I, [_VP, _I, _FP]),
     "rsb_debug_wave_profile": (_I, [_VP, _FP, _I]),

@@ -44,6 +44,7 @@ struct rsb_world {
   uint8_t* d_tmp_mask = nullptr;
   float *d_M = nullptr, *d_h = nullptr;
   int32_t* d_obs_idx = nullptr;
+  std::vector<int32_t> obs_idx_host;   // what d_obs_idx currently holds (re-uploaded only when the caller's list changes)
   float* d_dbg = nullptr;
   long long* d_prof = nullptr;
   int dbg_env = -1;
@@ -61,6 +62,8 @@ struct rsb_world {
   bool integrate1_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
+  std::vector<hipEvent_t> ring0, ring1;   // event pairs around the most recent step-kernel launches (rsb_enable_timing(w, n))
+  size_t ring_next = 0, ring_count = 0;
   float last_ms = -1.f;
 };
 
@@ -317,7 +320,9 @@ int do_integrate(rsb_world* w, int nsub) {
   static const bool prof_fine = std::getenv("RSB_PROF_FINE") != nullptr;  // debug aid: also time searches / Newton steps / epilogues
   a.prof_fine = prof_fine ? 1 : 0;
   a.lds_floats = (int)(lds_bytes / sizeof(float));
-  if (w->timing) HIP_TRY(hipEventRecord(w->ev0, w->stream));
+  hipEvent_t e0 = w->ev0, e1 = w->ev1;
+  if (w->timing && !w->ring0.empty()) { e0 = w->ring0[w->ring_next]; e1 = w->ring1[w->ring_next]; }
+  if (w->timing) HIP_TRY(hipEventRecord(e0, w->stream));
   // kernel classes by (longest chain, deepest body level): <=4/<=4 (quadrupeds), <=8/<=12 (humanoids), <=16/<=16
   const int mcl = w->max_cl, mlv = w->blob.depth - 1;
   if (mcl <= 4 && mlv <= 4) {
@@ -331,7 +336,10 @@ int do_integrate(rsb_world* w, int nsub) {
     return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
-  if (w->timing) HIP_TRY(hipEventRecord(w->ev1, w->stream));
+  if (w->timing) {
+    HIP_TRY(hipEventRecord(e1, w->stream));
+    if (!w->ring0.empty()) { w->ring_next = (w->ring_next + 1) % w->ring0.size(); if (w->ring_count < w->ring0.size()) ++w->ring_count; }
+  }
   w->world_time += nsub * w->dt;
   w->integrate1_valid = false;
   return RSB_OK;
@@ -421,6 +429,8 @@ int rsb_destroy(rsb_world* w) {
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : w->ring1) (void)hipEventDestroy(e);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
@@ -688,7 +698,14 @@ int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, i
   HIP_TRY(hipSetDevice(w->device));
   const int32_t* didx = nullptr;
   if (collision_indices && n_force_slots > 0) {
-    HIP_TRY(hipMemcpyAsync(w->d_obs_idx, collision_indices, n_force_slots * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    // the index list is tiny and normally the same every control step: a pageable H2D copy per call would put a
+    // host-side staging round trip on the stream each step
+    if ((int)w->obs_idx_host.size() != n_force_slots ||
+        std::memcmp(w->obs_idx_host.data(), collision_indices, n_force_slots * sizeof(int32_t)) != 0) {
+      w->obs_idx_host.assign(collision_indices, collision_indices + n_force_slots);
+      HIP_TRY(hipMemcpyAsync(w->d_obs_idx, w->obs_idx_host.data(), n_force_slots * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+      HIP_TRY(hipStreamSynchronize(w->stream));
+    }
     didx = w->d_obs_idx;
   }
   const int od = w->blob.nq + w->blob.nv + 3 * n_force_slots;
@@ -734,6 +751,21 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
     HIP_TRY(hipStreamSynchronize(w->stream));
   }
   return RSB_OK;
+}
+
+// One control step of a vectorised env, enqueued with a single call: PD targets in, n_substeps x integrate(),
+// observation block out, terminated envs reset.  All pointers are device pointers; nothing synchronises.
+int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target, int n_substeps, float* obs_out,
+                     const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
+                     int n_allowed, const float* gc0, const float* gv0, int rows) {
+  if (!w) return RSB_E_INVALID;
+  int st = RSB_OK;
+  if (p_target || d_target) { st = rsb_set_pd_target(w, p_target, d_target, RSB_DEVICE); if (st != RSB_OK) return st; }
+  st = rsb_integrate(w, n_substeps);
+  if (st != RSB_OK) return st;
+  if (obs_out) { st = rsb_gather_obs(w, obs_out, force_collisions, n_force_slots, RSB_DEVICE); if (st != RSB_OK) return st; }
+  if (gc0 && gv0) st = rsb_reset_terminated(w, allowed_collisions, n_allowed, gc0, gv0, rows, nullptr, RSB_DEVICE);
+  return st;
 }
 
 void* rsb_device_ptr(rsb_world* w, int field) {
@@ -802,7 +834,32 @@ int rsb_debug_wave_profile(rsb_world* w, long long* out, int n_blocks) {
   return RSB_OK;
 }
 
-int rsb_enable_timing(rsb_world* w, int on) { if (!w) return RSB_E_INVALID; w->timing = on != 0; return RSB_OK; }
+int rsb_enable_timing(rsb_world* w, int on) {
+  if (!w || on < 0) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : w->ring1) (void)hipEventDestroy(e);
+  w->ring0.clear(); w->ring1.clear(); w->ring_next = w->ring_count = 0;
+  w->timing = on != 0;
+  if (on > 1) {
+    w->ring0.resize(on); w->ring1.resize(on);
+    for (int i = 0; i < on; ++i) { HIP_TRY(hipEventCreate(&w->ring0[i])); HIP_TRY(hipEventCreate(&w->ring1[i])); }
+  }
+  return RSB_OK;
+}
+int rsb_read_kernel_ms(rsb_world* w, float* ms, int n) {
+  if (!w || !ms || n < 0) return RSB_E_INVALID;
+  if (w->ring0.empty()) { rsb::set_error("rsb_read_kernel_ms: no timing ring (rsb_enable_timing(w, n) with n > 1)"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  const size_t have = w->ring_count, cap = w->ring0.size();
+  const size_t take = (size_t)n < have ? (size_t)n : have;
+  for (size_t i = 0; i < take; ++i) {   // oldest of the last `take` launches first
+    const size_t slot = (w->ring_next + cap - take + i) % cap;
+    HIP_TRY(hipEventElapsedTime(&ms[i], w->ring0[slot], w->ring1[slot]));
+  }
+  return (int)take;
+}
 int rsb_last_kernel_ms(rsb_world* w, float* ms) {
   if (!w || !ms) return RSB_E_INVALID;
   if (!w->timing) { rsb::set_error("rsb_last_kernel_ms: timing is disabled (rsb_enable_timing)"); return RSB_E_STATE; }

@@ -251,7 +251,33 @@ class BatchedWorld:
         return self.L.rsb_device_ptr(self.handle, int(field))
 
     def enable_timing(self, on=True):
-        check(self.L.rsb_enable_timing(self.handle, 1 if on else 0), "rsb_enable_timing")
+        """False/0: off; True/1: one event pair (last_kernel_ms); n > 1: ring of n event pairs (read_kernel_ms)."""
+        check(self.L.rsb_enable_timing(self.handle, int(on)), "rsb_enable_timing")
+
+    def read_kernel_ms(self, n):
+        """Durations (ms) of the last n step-kernel launches (oldest first); synchronises the stream."""
+        out = np.zeros(int(n), np.float32)
+        got = self.L.rsb_read_kernel_ms(self.handle, _hp(out), int(n))
+        if got < 0:
+            check(got, "rsb_read_kernel_ms")
+        return out[:got]
+
+    def control_step_plan(self, n_substeps, obs_ptr, force_collisions, allowed_collisions, gc0_ptr, gv0_ptr, rows):
+        """Pre-marshalled rsb_control_step call: returns f(p_target_ptr) that enqueues one control step (PD targets ->
+        n_substeps x integrate -> obs gather -> reset of terminated envs) with a single foreign call."""
+        fidx = _host(force_collisions, np.int32)
+        aidx = _host(allowed_collisions, np.int32) if allowed_collisions is not None else None
+        fn, h = self.L.rsb_control_step, self.handle
+        args = (int(n_substeps), C.c_void_p(obs_ptr) if obs_ptr else None, _hp(fidx), 0 if fidx is None else fidx.shape[0],
+                _hp(aidx), 0 if aidx is None else aidx.shape[0],
+                C.c_void_p(gc0_ptr) if gc0_ptr else None, C.c_void_p(gv0_ptr) if gv0_ptr else None, int(rows))
+        keep = (fidx, aidx)
+
+        def step(p_target_ptr, _keep=keep):
+            st = fn(h, C.c_void_p(p_target_ptr), None, *args)
+            if st != 0:
+                check(st, "rsb_control_step")
+        return step
 
     def last_kernel_ms(self):
         ms = C.c_float()
