@@ -62,6 +62,9 @@ struct rsb_world {
   bool integrate1_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
+  // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
+  struct Fuse { const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
+                int do_reset = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1; } fuse;
   std::vector<hipEvent_t> ring0, ring1;   // event pairs around the most recent step-kernel launches (rsb_enable_timing(w, n))
   size_t ring_next = 0, ring_count = 0;
   float last_ms = -1.f;
@@ -298,6 +301,11 @@ int do_integrate(rsb_world* w, int nsub) {
   a.kp = w->d_kp; a.kd = w->d_kd;
   a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
   a.heights = w->d_heights;
+  if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
+  a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
+  a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
+  if (!a.do_reset) { a.gc0 = w->d_gc; a.gv0 = w->d_gv; a.reset_rows = w->N; }   // never dereferenced, but keep the pointers valid
+  w->fuse = rsb_world::Fuse();
   a.prof = w->d_prof;
   a.dbg = w->dbg_env >= 0 ? w->d_dbg : nullptr;
   a.dbg_env = w->dbg_env;
@@ -688,6 +696,23 @@ int rsb_get_solver_iterations(rsb_world* w, int32_t* iters, int space) {
   return copy_out(w, iters, w->d_iters, (size_t)w->N * sizeof(int32_t), space);
 }
 
+}  // extern "C"
+namespace {
+// The index list is tiny and normally the same every control step: a pageable H2D copy per call would put a
+// host-side staging round trip on the stream each step, so it is re-uploaded only when it changes.
+int upload_obs_idx(rsb_world* w, const int32_t* idx, int n) {
+  for (int i = 0; i < n; ++i)
+    if (idx[i] < 0 || idx[i] >= w->blob.ncol) { rsb::set_error("collision index out of range"); return RSB_E_INVALID; }
+  if ((int)w->obs_idx_host.size() != n || std::memcmp(w->obs_idx_host.data(), idx, n * sizeof(int32_t)) != 0) {
+    w->obs_idx_host.assign(idx, idx + n);
+    HIP_TRY(hipMemcpyAsync(w->d_obs_idx, w->obs_idx_host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+  }
+  return RSB_OK;
+}
+}  // namespace
+extern "C" {
+
 int rsb_obs_dim(const rsb_world* w, int n_force_slots) {
   if (!w || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) return RSB_E_INVALID;
   return w->blob.nq + w->blob.nv + 3 * n_force_slots;
@@ -698,14 +723,8 @@ int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, i
   HIP_TRY(hipSetDevice(w->device));
   const int32_t* didx = nullptr;
   if (collision_indices && n_force_slots > 0) {
-    // the index list is tiny and normally the same every control step: a pageable H2D copy per call would put a
-    // host-side staging round trip on the stream each step
-    if ((int)w->obs_idx_host.size() != n_force_slots ||
-        std::memcmp(w->obs_idx_host.data(), collision_indices, n_force_slots * sizeof(int32_t)) != 0) {
-      w->obs_idx_host.assign(collision_indices, collision_indices + n_force_slots);
-      HIP_TRY(hipMemcpyAsync(w->d_obs_idx, w->obs_idx_host.data(), n_force_slots * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
-      HIP_TRY(hipStreamSynchronize(w->stream));
-    }
+    int st = upload_obs_idx(w, collision_indices, n_force_slots);
+    if (st != RSB_OK) return st;
     didx = w->d_obs_idx;
   }
   const int od = w->blob.nq + w->blob.nv + 3 * n_force_slots;
@@ -758,14 +777,33 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
 int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target, int n_substeps, float* obs_out,
                      const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
                      int n_allowed, const float* gc0, const float* gv0, int rows) {
-  if (!w) return RSB_E_INVALID;
-  int st = RSB_OK;
-  if (p_target || d_target) { st = rsb_set_pd_target(w, p_target, d_target, RSB_DEVICE); if (st != RSB_OK) return st; }
-  st = rsb_integrate(w, n_substeps);
-  if (st != RSB_OK) return st;
-  if (obs_out) { st = rsb_gather_obs(w, obs_out, force_collisions, n_force_slots, RSB_DEVICE); if (st != RSB_OK) return st; }
-  if (gc0 && gv0) st = rsb_reset_terminated(w, allowed_collisions, n_allowed, gc0, gv0, rows, nullptr, RSB_DEVICE);
-  return st;
+  if (!w || n_substeps < 1 || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS || n_allowed < 0 ||
+      (n_allowed > 0 && !allowed_collisions) || ((gc0 != nullptr) != (gv0 != nullptr)) || (gc0 && rows != 1 && rows != w->N)) {
+    rsb::set_error("rsb_control_step: bad argument");
+    return RSB_E_INVALID;
+  }
+  HIP_TRY(hipSetDevice(w->device));
+  if (d_target) { int st = copy_in(w, w->d_dt, d_target, (size_t)w->N * w->blob.nv, RSB_DEVICE); if (st) return st; }
+  rsb_world::Fuse f;
+  f.ptarget_src = p_target;   // read in place by the launch, which also refreshes the world's own copy
+  if (obs_out) {
+    f.obs_out = obs_out; f.obs_slots = n_force_slots;
+    if (force_collisions && n_force_slots > 0) {
+      int st = upload_obs_idx(w, force_collisions, n_force_slots);
+      if (st != RSB_OK) return st;
+      f.obs_idx = w->d_obs_idx;
+    }
+  }
+  if (gc0) {
+    unsigned long long allowed = 0;
+    for (int i = 0; i < n_allowed; ++i) {
+      if (allowed_collisions[i] < 0 || allowed_collisions[i] >= w->blob.ncol) { rsb::set_error("rsb_control_step: collision index out of range"); return RSB_E_INVALID; }
+      allowed |= 1ull << allowed_collisions[i];
+    }
+    f.do_reset = 1; f.allowed = allowed; f.gc0 = gc0; f.gv0 = gv0; f.rows = rows;
+  }
+  w->fuse = f;
+  return rsb_integrate(w, n_substeps);
 }
 
 void* rsb_device_ptr(rsb_world* w, int field) {

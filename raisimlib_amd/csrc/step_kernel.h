@@ -98,6 +98,16 @@ struct StepArgs {
   int32_t* flags;
   int32_t* iters;
   const float* heights;
+  // fused control-step epilogue / prologue (rsb_control_step); all optional
+  float* ptarget_store;        // p_target rows read from `ptarget` are also stored here (the world's own copy)
+  float* obs_out;              // [N, nq + nv + 3*obs_slots]: q, u, contact force of obs_idx[slot] (last sub-step)
+  const int32_t* obs_idx;      // [obs_slots] collision primitive of each force slot (NULL: slot k = primitive k)
+  int obs_slots;
+  int do_reset;                // envs with a non-finite state or a contact outside `allowed` restart from gc0 / gv0
+  unsigned long long allowed;  // bit c set: collision primitive c may touch the terrain
+  const float* gc0;            // [reset_rows, nq], reset_rows = 1 or N
+  const float* gv0;
+  int reset_rows;
   long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
   float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)
   int dbg_env;
@@ -478,7 +488,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   RSB_UNROLL for (int k = 0; k < CL; ++k) chb[k] = m.ch_body[chi * kMaxCL + k];
 
   // ---- state rows: HBM -> LDS
-  for (int i = s; i < nq; i += LPE) { Q[i] = a.gc[(size_t)env * nq + i]; PT[i] = a.ptarget[(size_t)env * nq + i]; }
+  for (int i = s; i < nq; i += LPE) {
+    Q[i] = a.gc[(size_t)env * nq + i];
+    const float pt = a.ptarget[(size_t)env * nq + i];
+    PT[i] = pt;
+    if (a.ptarget_store && env_valid) a.ptarget_store[(size_t)env * nq + i] = pt;
+  }
   for (int i = s; i < nv; i += LPE) {
     U[i] = a.gv[(size_t)env * nv + i];
     DTG[i] = a.dtarget[(size_t)env * nv + i];
@@ -1105,14 +1120,43 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   }  // substeps
 
   if (a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
-  // ---- results: LDS -> HBM
+  // ---- results: LDS -> HBM (with the optional control-step epilogue: observation block, reset of terminated envs)
   if (env_valid) {
     bool bad = false;
-    for (int i = s; i < nq; i += LPE) { const float vq = Q[i]; a.gc[(size_t)env * nq + i] = vq; bad |= !isfinite(vq); }
-    for (int i = s; i < nv; i += LPE) { const float vu = U[i]; a.gv[(size_t)env * nv + i] = vu; bad |= !isfinite(vu); }
-    const unsigned long long bb = __ballot(bad);
-    const unsigned long long gmb = (LPE == 64) ? bb : ((bb >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
-    if (gmb) flag |= 2;
+    for (int i = s; i < nq; i += LPE) bad |= !isfinite(Q[i]);
+    for (int i = s; i < nv; i += LPE) bad |= !isfinite(U[i]);
+    // contact lanes: anything but an allowed primitive touching the terrain terminates the episode (rsg_anymal rule)
+    int mycol = 0;
+    if (s < nc) mycol = __float_as_int(CON[s * kConSlot + 11]);
+    const bool illegal = a.do_reset && s < nc && !((a.allowed >> mycol) & 1ull);
+    const unsigned long long bb = __ballot(bad), bi = __ballot(illegal);
+    const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
+    if (bb & gsel) flag |= 2;
+    const bool term = a.do_reset && ((flag & 2) != 0 || (bi & gsel) != 0);
+    if (a.obs_out) {   // the observation is the state the episode ended in (before a reset), as rsb_gather_obs would read it
+      const int od = nq + nv + 3 * a.obs_slots;
+      float* ob = a.obs_out + (size_t)env * od;
+      for (int i = s; i < nq; i += LPE) ob[i] = Q[i];
+      for (int i = s; i < nv; i += LPE) ob[nq + i] = U[i];
+      const float inv_dt = 1.0f / dt;
+      for (int sl = s; sl < a.obs_slots; sl += LPE) {
+        const int want = a.obs_idx ? a.obs_idx[sl] : sl;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+        for (int k = 0; k < nc; ++k) {
+          if (__float_as_int(CON[k * kConSlot + 11]) == want) {
+            const float* CN = CON + k * kConSlot;
+            const float l0 = LAM[3 * k], l1 = LAM[3 * k + 1], l2 = LAM[3 * k + 2];
+            f0 = (CN[4] * l0 + CN[8] * l1 + CN[12] * l2) * inv_dt;
+            f1 = (CN[5] * l0 + CN[9] * l1 + CN[13] * l2) * inv_dt;
+            f2 = (CN[6] * l0 + CN[10] * l1 + CN[14] * l2) * inv_dt;
+          }
+        }
+        ob[nq + nv + 3 * sl] = f0; ob[nq + nv + 3 * sl + 1] = f1; ob[nq + nv + 3 * sl + 2] = f2;
+      }
+    }
+    const size_t r0 = (a.reset_rows == 1) ? 0 : (size_t)env;
+    for (int i = s; i < nq; i += LPE) a.gc[(size_t)env * nq + i] = term ? a.gc0[r0 * nq + i] : Q[i];
+    for (int i = s; i < nv; i += LPE) a.gv[(size_t)env * nv + i] = term ? a.gv0[r0 * nv + i] : U[i];
     if (s < nc) {
       float CN[16];
       ldv<4>(CON + s * kConSlot, CN);
@@ -1131,8 +1175,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       a.contacts[(size_t)env * a.kmax + s] = ct;
     }
     if (s == 0) {
-      a.contact_count[env] = nc;
-      a.flags[env] = flag;
+      a.contact_count[env] = term ? 0 : nc;   // a reset env starts its episode without contacts or flags
+      a.flags[env] = term ? 0 : flag;
       a.iters[env] = iters_used;
     }
   }

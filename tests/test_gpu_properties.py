@@ -160,6 +160,50 @@ def test_borrowed_stream_and_device_targets(anymal):
     assert np.array_equal(ref[0], got[0]) and np.array_equal(ref[1], got[1])
 
 
+def test_control_step_equals_the_separate_calls(anymal):
+    """rsb_control_step (targets, 4 x integrate, obs, reset fused into one launch) gives bit-identical state, obs,
+    contact counts and stored PD targets to rsb_set_pd_target + rsb_integrate + rsb_gather_obs + rsb_reset_terminated."""
+    import torch
+    N = 300          # ragged: not a multiple of the envs per workgroup
+    feet = anymal.collision_indices("_foot")
+    gc, gv = standing_states(N, seed=21, z=(0.3, 0.6), vel=1.5)
+    gc[::7, 2] = 0.1                                    # some envs start belly-down -> terminate
+    kp, kd = workload.anymal_gains()
+    init_q, init_u = workload.anymal_initial_state(N)
+    g0 = torch.from_numpy(init_q.astype(np.float32)).cuda(); v0 = torch.from_numpy(init_u.astype(np.float32)).cuda()
+    od = 19 + 18 + 3 * len(feet)
+    res = []
+    for fused in (False, True):
+        w = BatchedWorld(anymal, N)
+        w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv)
+        obs = torch.zeros((N, od), dtype=torch.float32, device="cuda")
+        step = w.control_step_plan(4, obs.data_ptr(), feet, feet, g0.data_ptr(), v0.data_ptr(), N)
+        hist = []
+        for k in range(6):
+            pt = torch.from_numpy(workload.anymal_targets(N, k).astype(np.float32)).cuda()
+            if fused:
+                step(pt.data_ptr())
+            else:
+                w.set_pd_target_device(pt.data_ptr())
+                w.integrate(4)
+                w.gather_obs(obs.data_ptr(), feet)
+                w.reset_terminated_device(feet, g0.data_ptr(), v0.data_ptr(), N)
+            w.synchronize()
+            q, u = w.get_state()
+            hist.append((q, u, obs.cpu().numpy().copy(), w.get_contacts()[0], w.get_flags()))
+        w.integrate(2)                                   # uses the world's own copy of the last PD targets
+        hist.append(w.get_state())
+        res.append(hist)
+        w.close()
+    terminated = 0
+    for a, b in zip(res[0][:6], res[1][:6]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        terminated += int((a[3] == 0).sum())
+    assert np.array_equal(res[0][6][0], res[1][6][0]) and np.array_equal(res[0][6][1], res[1][6][1])   # stored targets refreshed
+    assert terminated > 0
+
+
 def test_api_errors(anymal):
     w = BatchedWorld(anymal, 8)
     with pytest.raises(RsbError):
