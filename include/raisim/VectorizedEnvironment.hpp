@@ -2,8 +2,9 @@
 //
 // Upstream (raisimGymTorch/env/VectorizedEnvironment.hpp, absent from /root/reference — SURVEY.md §3.1, §8b) owns
 // num_envs ENVIRONMENT objects, each with its own raisim::World, and fans `step` out with an OpenMP parallel-for.
-// Here ONE BatchedWorld holds all replicas on the GPU and `step` is a single fused launch of
-// control_dt/simulation_dt sub-steps; the method names, argument meaning and in-place caller-owned buffers
+// Here ONE BatchedWorld holds all replicas on the GPU; `step` is a single fused launch of control_dt/simulation_dt
+// sub-steps plus two tiny kernels (action -> PD targets, reward/termination/reset), all through the C-ABI's rsb_env_*
+// entry points, and `stepDevice` / `observeDevice` take device buffers so a GPU-resident policy never crosses PCIe; the method names, argument meaning and in-place caller-owned buffers
 // (row-major float [num_envs, dim], bool [num_envs]) are upstream's, with (T*, rows, cols) spans instead of
 // Eigen::Ref (Eigen is not available here).
 //
@@ -54,49 +55,34 @@ class VectorizedEnvironment {
         std::string nm = b.col_name[c];
         if (nm.size() >= suf.size() && nm.compare(nm.size() - suf.size(), suf.size(), suf) == 0) feet_.push_back(c);
       }
-    gc_.assign((size_t)n_ * nq_, 0.f); gv_.assign((size_t)n_ * nv_, 0.f);
-    pTarget_.assign((size_t)n_ * nq_, 0.f); dTarget_.assign((size_t)n_ * nv_, 0.f);
     done_.assign(n_, 0);
+    // the task itself (action scaling, observation, reward, termination, reset) runs on the GPU: rsb_env_*
+    std::vector<float> pt0((size_t)n_ * nq_, 0.f), dt0((size_t)n_ * nv_, 0.f);
+    for (int e = 0; e < n_; ++e) pt0[(size_t)e * nq_ + 3] = 1.f;
+    world_.setPdTarget(pt0.data(), dt0.data());
+    configureEnv();
     reset();
   }
 
-  void reset() {
-    for (int e = 0; e < n_; ++e) {
-      std::copy(gcInit_.begin(), gcInit_.end(), gc_.begin() + (size_t)e * nq_);
-      std::copy(gvInit_.begin(), gvInit_.end(), gv_.begin() + (size_t)e * nv_);
-    }
-    world_.setState(gc_.data(), gv_.data());
-  }
+  void reset() { RSB_CHECK(rsb_env_reset(world_.handle())); }
 
   /// ob: float [num_envs, obDim] row-major, written in place (updateStatistics is accepted for source compatibility)
   void observe(float* ob, int rows, int cols, bool /*updateStatistics*/ = false) {
     RSFATAL_IF(rows != n_ || cols != obDim_, "observe: buffer must be [num_envs, obDim]");
-    world_.getState(gc_.data(), gv_.data());
-    for (int e = 0; e < n_; ++e) writeObs(e, ob + (size_t)e * obDim_);
+    RSB_CHECK(rsb_env_observe(world_.handle(), ob, RSB_HOST));
   }
+  /// the same with a device buffer (e.g. a torch CUDA tensor's data_ptr): nothing crosses PCIe, nothing synchronises
+  void observeDevice(float* ob_device) { RSB_CHECK(rsb_env_observe(world_.handle(), ob_device, RSB_DEVICE)); }
 
   /// action: float [num_envs, actionDim]; reward: float [num_envs]; done: bool [num_envs] — all written in place
   void step(const float* action, int rows, int cols, float* reward, bool* done) {
     RSFATAL_IF(rows != n_ || cols != actionDim_, "step: action must be [num_envs, actionDim]");
-    for (int e = 0; e < n_; ++e) {
-      float* pt = pTarget_.data() + (size_t)e * nq_;
-      for (int j = 0; j < nj_; ++j) pt[7 + j] = gcInit_[7 + j] + (float)cfg_.action_std * action[(size_t)e * actionDim_ + j];
-    }
-    world_.setPdTarget(pTarget_.data(), dTarget_.data());
-    world_.integrate(substeps_);                                           // ONE fused launch for all envs
-    RSB_CHECK(rsb_reset_terminated(world_.handle(), feet_.data(), (int)feet_.size(), gcInit_.data(), gvInit_.data(), 1,
-                                   done_.data(), RSB_HOST));
-    world_.getState(gc_.data(), gv_.data());
-    for (int e = 0; e < n_; ++e) {
-      const float* u = gv_.data() + (size_t)e * nv_;
-      const float* q = gc_.data() + (size_t)e * nq_;
-      const float* pt = pTarget_.data() + (size_t)e * nq_;
-      double torque2 = 0;
-      for (int j = 0; j < nj_; ++j) { const double t = cfg_.p_gain * (pt[7 + j] - q[7 + j]) - cfg_.d_gain * u[6 + j]; torque2 += t * t; }
-      double r = cfg_.forward_vel_reward_coeff * std::fmin(4.0, bodyVelX(q, u)) + cfg_.torque_reward_coeff * torque2;
-      done[e] = done_[e] != 0;
-      reward[e] = (float)(done[e] ? cfg_.terminal_reward : r);
-    }
+    RSB_CHECK(rsb_env_step(world_.handle(), action, reward, done_.data(), RSB_HOST));   // action kernel + ONE fused launch + reward/reset kernel
+    for (int e = 0; e < n_; ++e) done[e] = done_[e] != 0;
+  }
+  /// device buffers: action float [num_envs, actionDim], reward float [num_envs], done uint8 [num_envs]
+  void stepDevice(const float* action_device, float* reward_device, uint8_t* done_device) {
+    RSB_CHECK(rsb_env_step(world_.handle(), action_device, reward_device, done_device, RSB_DEVICE));
   }
 
   void isTerminalState(bool* terminalState) { for (int e = 0; e < n_; ++e) terminalState[e] = done_[e] != 0; }
@@ -105,39 +91,28 @@ class VectorizedEnvironment {
   void curriculumUpdate() {}
   void turnOnVisualization() {}
   void turnOffVisualization() {}
-  void setSimulationTimeStep(double dt) { cfg_.simulation_dt = dt; world_.setTimeStep(dt); substeps_ = (int)(cfg_.control_dt / dt + 1e-10); }
-  void setControlTimeStep(double dt) { cfg_.control_dt = dt; substeps_ = (int)(dt / cfg_.simulation_dt + 1e-10); }
+  void setSimulationTimeStep(double dt) { cfg_.simulation_dt = dt; world_.setTimeStep(dt); substeps_ = (int)(cfg_.control_dt / dt + 1e-10); configureEnv(); }
+  void setControlTimeStep(double dt) { cfg_.control_dt = dt; substeps_ = (int)(dt / cfg_.simulation_dt + 1e-10); configureEnv(); }
   int getObDim() const { return obDim_; }
   int getActionDim() const { return actionDim_; }
   int getNumOfEnvs() const { return n_; }
   BatchedWorld& world() { return world_; }
 
  private:
-  static void rotT(const float* q, double Rt[9]) {  // world -> body rotation from the base quaternion
-    const double w = q[3], x = q[4], y = q[5], z = q[6];
-    Rt[0] = 1 - 2 * (y * y + z * z); Rt[3] = 2 * (x * y - w * z);     Rt[6] = 2 * (x * z + w * y);
-    Rt[1] = 2 * (x * y + w * z);     Rt[4] = 1 - 2 * (x * x + z * z); Rt[7] = 2 * (y * z - w * x);
-    Rt[2] = 2 * (x * z - w * y);     Rt[5] = 2 * (y * z + w * x);     Rt[8] = 1 - 2 * (x * x + y * y);
+  void configureEnv() {
+    rsb_env_config ec{};
+    ec.n_substeps = substeps_;
+    ec.action_std = (float)cfg_.action_std;
+    ec.forward_vel_coeff = (float)cfg_.forward_vel_reward_coeff; ec.forward_vel_clip = 4.0f;
+    ec.torque_coeff = (float)cfg_.torque_reward_coeff; ec.terminal_reward = (float)cfg_.terminal_reward;
+    ec.n_foot = (int)feet_.size();
+    for (size_t i = 0; i < feet_.size(); ++i) ec.foot_collisions[i] = feet_[i];
+    RSB_CHECK(rsb_env_configure(world_.handle(), &ec, gcInit_.data() + 7, gcInit_.data(), gvInit_.data()));
   }
-  static double bodyVelX(const float* q, const float* u) { double Rt[9]; rotT(q, Rt); return Rt[0] * u[0] + Rt[1] * u[1] + Rt[2] * u[2]; }
-  void writeObs(int e, float* ob) const {
-    const float* q = gc_.data() + (size_t)e * nq_;
-    const float* u = gv_.data() + (size_t)e * nv_;
-    double Rt[9];
-    rotT(q, Rt);
-    int k = 0;
-    ob[k++] = q[2];
-    ob[k++] = (float)Rt[6]; ob[k++] = (float)Rt[7]; ob[k++] = (float)Rt[8];      // body z-axis in the world = R row 2
-    for (int j = 0; j < nj_; ++j) ob[k++] = q[7 + j];
-    for (int i = 0; i < 3; ++i) ob[k++] = (float)(Rt[3 * i] * u[0] + Rt[3 * i + 1] * u[1] + Rt[3 * i + 2] * u[2]);
-    for (int i = 0; i < 3; ++i) ob[k++] = (float)(Rt[3 * i] * u[3] + Rt[3 * i + 1] * u[4] + Rt[3 * i + 2] * u[5]);
-    for (int j = 0; j < nj_; ++j) ob[k++] = u[6 + j];
-  }
-
   VecEnvConfig cfg_;
   BatchedWorld world_;
   int n_ = 0, nq_ = 0, nv_ = 0, nj_ = 0, obDim_ = 0, actionDim_ = 0, substeps_ = 4;
-  std::vector<float> gcInit_, gvInit_, gc_, gv_, pTarget_, dTarget_;
+  std::vector<float> gcInit_, gvInit_;
   std::vector<int32_t> feet_;
   std::vector<uint8_t> done_;
 };

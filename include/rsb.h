@@ -232,6 +232,32 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
                      const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
                      int n_allowed, const float* gc0, const float* gv0, int rows);
 
+/* ---- device-resident vectorised env: the per-env observe / step / reward / terminate / reset of
+ * VectorizedEnvironment<ENVIRONMENT> with rsg_anymal's task [RECALL raisimGymTorch/env/envs/rsg_anymal/Environment.hpp,
+ * absent from /root/reference], computed on the GPU so that a learner whose policy runs on the same device never
+ * crosses PCIe:
+ *   action [N, nv-6]   -> PD position targets  action_mean + action_std * action  on the actuated joints
+ *   observation [N, 10 + 2(nv-6)] = height, body z-axis (3), joint angles, body-frame linear velocity (3),
+ *                        body-frame angular velocity (3), joint velocities
+ *   reward = forward_vel_coeff * min(forward_vel_clip, body-frame v_x) + torque_coeff * |PD torque|^2
+ *   done   = a contact on a primitive outside foot_collisions, or a non-finite state; such envs get
+ *            reward = terminal_reward and restart from gc_init / gv_init. */
+typedef struct rsb_env_config {
+  int32_t n_substeps;            /* control_dt / simulation_dt */
+  float action_std;
+  float forward_vel_coeff, forward_vel_clip, torque_coeff, terminal_reward;
+  int32_t n_foot;
+  int32_t foot_collisions[RSB_MAX_COLLISIONS];
+} rsb_env_config;
+/* action_mean [nv-6], gc_init [nq], gv_init [nv]: host arrays (copied) */
+int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* action_mean, const float* gc_init,
+                      const float* gv_init);
+int rsb_env_dims(const rsb_world* w, int* ob_dim, int* action_dim);
+int rsb_env_reset(rsb_world* w);                                   /* every env to gc_init / gv_init */
+int rsb_env_observe(rsb_world* w, float* ob, int space);           /* [N, ob_dim] */
+/* action [N, action_dim] in; reward [N] float, done [N] uint8 out (either may be NULL); all in `space` */
+int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done, int space);
+
 /* zero-copy access to the resident state (device pointers; row-major [N,dim] float32): see rsb_field */
 void* rsb_device_ptr(rsb_world* w, int field);
 

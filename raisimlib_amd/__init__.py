@@ -7,3 +7,4 @@ tests, the bench and the vectorised-env wrapper; it only moves pointers around.
 from ._capi import (RSB_DEVICE, RSB_FORCE_AND_TORQUE, RSB_HOST, RSB_MAX_CONTACTS,  # noqa: F401
                     RSB_PD_PLUS_FEEDFORWARD_TORQUE, RsbError)
 from .world import CONTACT_DTYPE, BatchedWorld, Model, rsc_path  # noqa: F401
+from .vecenv import VecEnv  # noqa: F401

@@ -40,6 +40,13 @@ class Contact(C.Structure):
                 ("depth", C.c_float), ("body", C.c_int32), ("collision", C.c_int32)]
 
 
+class EnvConfig(C.Structure):
+    """rsb_env_config"""
+    _fields_ = [("n_substeps", C.c_int32), ("action_std", C.c_float), ("forward_vel_coeff", C.c_float),
+                ("forward_vel_clip", C.c_float), ("torque_coeff", C.c_float), ("terminal_reward", C.c_float),
+                ("n_foot", C.c_int32), ("foot_collisions", C.c_int32 * RSB_MAX_COLLISIONS)]
+
+
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsb.so")
 
 # name -> (restype, argtypes); mirrors include/rsb.h one-to-one (tests check the two stay in sync)
@@ -96,6 +103,11 @@ PROTOTYPES = {
     "rsb_obs_dim": (_I, [_VP, _I]),
     "rsb_gather_obs": (_I, [_VP, _FP, _FP, _I, _I]),
     "rsb_reset_terminated": (_I, [_VP, _FP, _I, _FP, _FP, _I, _FP, _I]),
+    "rsb_env_configure": (_I, [_VP, C.POINTER(EnvConfig), _FP, _FP, _FP]),
+    "rsb_env_dims": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
+    "rsb_env_reset": (_I, [_VP]),
+    "rsb_env_observe": (_I, [_VP, _FP, _I]),
+    "rsb_env_step": (_I, [_VP, _FP, _FP, _FP, _I]),
     "rsb_device_ptr": (_VP, [_VP, _I]),
     "rsb_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
     "rsb_enable_timing": (_I, [_VP, _I]),

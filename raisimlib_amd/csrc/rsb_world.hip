@@ -65,6 +65,12 @@ struct rsb_world {
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
   struct Fuse { const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
                 int do_reset = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1; } fuse;
+  // device-resident vectorised env (rsb_env_*)
+  bool env_ready = false;
+  rsb_env_config env_cfg{};
+  unsigned long long env_allowed = 0;
+  float *d_env_mean = nullptr, *d_env_gc0 = nullptr, *d_env_gv0 = nullptr, *d_env_io = nullptr, *d_env_reward = nullptr;
+  uint8_t* d_env_done = nullptr;
   std::vector<hipEvent_t> ring0, ring1;   // event pairs around the most recent step-kernel launches (rsb_enable_timing(w, n))
   size_t ring_next = 0, ring_count = 0;
   float last_ms = -1.f;
@@ -257,6 +263,86 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
   if (done) done[e] = term ? 1 : 0;
 }
 
+// ---- device-resident vectorised env (rsg_anymal task semantics, see rsb.h) ------------------------------------
+__global__ void env_action_kernel(float* pt, const float* action, const float* mean, float std_, int N, int nq, int nj) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * nj) return;
+  const int e = i / nj, j = i - e * nj;
+  {  // two roundings, exactly as the host-side float expression of the CPU facade (no FMA contraction)
+#pragma clang fp contract(off)
+    const float scaled = std_ * action[i];
+    pt[(size_t)e * nq + 7 + j] = mean[j] + scaled;
+  }
+}
+
+__device__ inline void env_rot_t(const float* q, float* Rt) {  // world -> body rotation from the base quaternion
+  const float w = q[3], x = q[4], y = q[5], z = q[6];
+  Rt[0] = 1 - 2 * (y * y + z * z); Rt[3] = 2 * (x * y - w * z);     Rt[6] = 2 * (x * z + w * y);
+  Rt[1] = 2 * (x * y + w * z);     Rt[4] = 1 - 2 * (x * x + z * z); Rt[7] = 2 * (y * z - w * x);
+  Rt[2] = 2 * (x * z - w * y);     Rt[5] = 2 * (y * z + w * x);     Rt[8] = 1 - 2 * (x * x + y * y);
+}
+
+// reward and termination from the state the control step ended in, then the reset of terminated envs
+__global__ void env_post_kernel(float* gc, float* gv, const float* pt, const float* dtg, const float* kp, const float* kd,
+                                const rsb_contact* contacts, int32_t* count, int32_t* flags, unsigned long long allowed,
+                                const float* gc0, const float* gv0, float* reward, uint8_t* done, int N, int nq, int nv,
+                                int kmax, float fwd_coeff, float fwd_clip, float torque_coeff, float terminal_reward) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  float* q = gc + (size_t)e * nq;
+  float* u = gv + (size_t)e * nv;
+  bool term = (flags[e] & 2) != 0;
+  const int nc = count[e];
+  for (int k = 0; k < nc; ++k) {
+    const int c = contacts[(size_t)e * kmax + k].collision;
+    if (!((allowed >> c) & 1ull)) term = true;
+  }
+  float Rt[9];
+  env_rot_t(q, Rt);
+  const float vx = Rt[0] * u[0] + Rt[1] * u[1] + Rt[2] * u[2];
+  float t2 = 0.f;
+  for (int j = 6; j < nv; ++j) {
+    const float t = kp[j] * (pt[(size_t)e * nq + j + 1] - q[j + 1]) + kd[j] * (dtg[(size_t)e * nv + j] - u[j]);
+    t2 += t * t;
+  }
+  const float r = fwd_coeff * fminf(fwd_clip, vx) + torque_coeff * t2;
+  if (reward) reward[e] = term ? terminal_reward : r;
+  if (done) done[e] = term ? 1 : 0;
+  if (term) {
+    for (int i = 0; i < nq; ++i) q[i] = gc0[i];
+    for (int i = 0; i < nv; ++i) u[i] = gv0[i];
+    count[e] = 0;
+    flags[e] = 0;
+  }
+}
+
+__global__ void env_obs_kernel(float* ob, const float* gc, const float* gv, int N, int nq, int nv) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const float* q = gc + (size_t)e * nq;
+  const float* u = gv + (size_t)e * nv;
+  const int nj = nv - 6;
+  float* o = ob + (size_t)e * (10 + 2 * nj);
+  float Rt[9];
+  env_rot_t(q, Rt);
+  int k = 0;
+  o[k++] = q[2];
+  o[k++] = Rt[6]; o[k++] = Rt[7]; o[k++] = Rt[8];   // body z-axis in the world (third column of R)
+  for (int j = 0; j < nj; ++j) o[k++] = q[7 + j];
+  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[0] + Rt[3 * i + 1] * u[1] + Rt[3 * i + 2] * u[2];
+  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[3] + Rt[3 * i + 1] * u[4] + Rt[3 * i + 2] * u[5];
+  for (int j = 0; j < nj; ++j) o[k++] = u[6 + j];
+}
+
+__global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* flags, const float* gc0, const float* gv0,
+                                 int N, int nq, int nv) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  for (int i = 0; i < nq; ++i) gc[(size_t)e * nq + i] = gc0[i];
+  for (int i = 0; i < nv; ++i) gv[(size_t)e * nv + i] = gv0[i];
+  count[e] = 0; flags[e] = 0;
+}
+
 template <int LPE, int KMAX, int CL, int ML>
 int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes) {
   auto kern = rsbk::rsb_step_kernel<LPE, KMAX, CL, ML>;
@@ -435,6 +521,7 @@ int rsb_destroy(rsb_world* w) {
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_done,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -804,6 +891,96 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
   }
   w->fuse = f;
   return rsb_integrate(w, n_substeps);
+}
+
+// ---- device-resident vectorised env ------------------------------------------------------------------------------
+int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* action_mean, const float* gc_init,
+                      const float* gv_init) {
+  if (!w || !cfg || !action_mean || !gc_init || !gv_init || cfg->n_substeps < 1 || cfg->n_foot < 0 || cfg->n_foot > RSB_MAX_COLLISIONS) {
+    rsb::set_error("rsb_env_configure: bad argument");
+    return RSB_E_INVALID;
+  }
+  unsigned long long allowed = 0;
+  for (int i = 0; i < cfg->n_foot; ++i) {
+    if (cfg->foot_collisions[i] < 0 || cfg->foot_collisions[i] >= w->blob.ncol) { rsb::set_error("rsb_env_configure: foot collision index out of range"); return RSB_E_INVALID; }
+    allowed |= 1ull << cfg->foot_collisions[i];
+  }
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv, nj = nv - 6, od = 10 + 2 * nj;
+  if (!w->d_env_mean) {
+    HIP_TRY(hipMalloc(&w->d_env_mean, nj * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_env_gc0, nq * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_env_gv0, nv * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_env_io, N * od * sizeof(float)));      // staging for host-side action / observation buffers
+    HIP_TRY(hipMalloc(&w->d_env_reward, N * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_env_done, N));
+  }
+  HIP_TRY(hipMemcpyAsync(w->d_env_mean, action_mean, nj * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  HIP_TRY(hipMemcpyAsync(w->d_env_gc0, gc_init, nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  HIP_TRY(hipMemcpyAsync(w->d_env_gv0, gv_init, nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  w->env_cfg = *cfg; w->env_allowed = allowed; w->env_ready = true;
+  return RSB_OK;
+}
+int rsb_env_dims(const rsb_world* w, int* ob_dim, int* action_dim) {
+  if (!w) return RSB_E_INVALID;
+  if (ob_dim) *ob_dim = 10 + 2 * (w->blob.nv - 6);
+  if (action_dim) *action_dim = w->blob.nv - 6;
+  return RSB_OK;
+}
+static int env_check(rsb_world* w, const char* who) {
+  if (!w) return RSB_E_INVALID;
+  if (!w->env_ready) { rsb::set_error(std::string(who) + ": call rsb_env_configure first"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  return RSB_OK;
+}
+int rsb_env_reset(rsb_world* w) {
+  int st = env_check(w, "rsb_env_reset"); if (st != RSB_OK) return st;
+  hipLaunchKernelGGL(env_reset_kernel, dim3((w->N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_count,
+                     w->d_flags, w->d_env_gc0, w->d_env_gv0, w->N, w->blob.nq, w->blob.nv);
+  HIP_TRY(hipGetLastError());
+  w->integrate1_valid = false;
+  return RSB_OK;
+}
+int rsb_env_observe(rsb_world* w, float* ob, int space) {
+  int st = env_check(w, "rsb_env_observe"); if (st != RSB_OK) return st;
+  if (!ob) return RSB_E_INVALID;
+  const size_t od = 10 + 2 * (size_t)(w->blob.nv - 6);
+  float* dob = space == RSB_DEVICE ? ob : w->d_env_io;
+  hipLaunchKernelGGL(env_obs_kernel, dim3((w->N + 255) / 256), dim3(256), 0, w->stream, dob, w->d_gc, w->d_gv, w->N,
+                     w->blob.nq, w->blob.nv);
+  HIP_TRY(hipGetLastError());
+  if (space == RSB_HOST) return copy_out(w, ob, dob, (size_t)w->N * od * sizeof(float), RSB_HOST);
+  return RSB_OK;
+}
+int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done, int space) {
+  int st = env_check(w, "rsb_env_step"); if (st != RSB_OK) return st;
+  if (!action) return RSB_E_INVALID;
+  const int N = w->N, nq = w->blob.nq, nv = w->blob.nv, nj = nv - 6;
+  const float* dact = action;
+  if (space == RSB_HOST) {
+    HIP_TRY(hipMemcpyAsync(w->d_env_io, action, (size_t)N * nj * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    dact = w->d_env_io;
+  }
+  hipLaunchKernelGGL(env_action_kernel, dim3((N * nj + 255) / 256), dim3(256), 0, w->stream, w->d_pt, dact, w->d_env_mean,
+                     w->env_cfg.action_std, N, nq, nj);
+  HIP_TRY(hipGetLastError());
+  st = do_integrate(w, w->env_cfg.n_substeps);
+  if (st != RSB_OK) return st;
+  float* drew = space == RSB_DEVICE ? reward : (reward ? w->d_env_reward : nullptr);
+  uint8_t* ddone = space == RSB_DEVICE ? done : (done ? w->d_env_done : nullptr);
+  hipLaunchKernelGGL(env_post_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_pt, w->d_dt,
+                     w->d_kp, w->d_kd, w->d_contacts, w->d_count, w->d_flags, w->env_allowed, w->d_env_gc0, w->d_env_gv0,
+                     drew, ddone, N, nq, nv, w->kmax, w->env_cfg.forward_vel_coeff, w->env_cfg.forward_vel_clip,
+                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward);
+  HIP_TRY(hipGetLastError());
+  w->integrate1_valid = false;
+  if (space == RSB_HOST) {
+    if (reward) HIP_TRY(hipMemcpyAsync(reward, w->d_env_reward, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    if (done) HIP_TRY(hipMemcpyAsync(done, w->d_env_done, (size_t)N, hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+  }
+  return RSB_OK;
 }
 
 void* rsb_device_ptr(rsb_world* w, int field) {

@@ -1,0 +1,90 @@
+"""Device-resident vectorised env over the C-ABI's rsb_env_* entry points (plumbing only).
+
+Mirrors raisimGymTorch's Python wrapper `RaisimGymVecEnv` [RECALL raisimGymTorch/env/RaisimGymVecEnv.py, absent from
+/root/reference]: `reset()`, `observe()`, `step(action) -> (reward, done)`, `num_obs`, `num_acts`, `num_envs`, with
+rsg_anymal's task semantics computed on the GPU (see include/rsb.h, "device-resident vectorised env").  Actions,
+observations, rewards and dones are torch CUDA tensors when torch tensors are passed (zero-copy, on the caller's
+stream) and numpy arrays otherwise (staged through PCIe by the library).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+from ._capi import RSB_DEVICE, RSB_HOST, check
+from .world import BatchedWorld, Model, _hp
+
+
+class VecEnv:
+    def __init__(self, model, num_envs, device=0, simulation_dt=0.0025, control_dt=0.01, action_std=0.3, p_gain=50.0,
+                 d_gain=0.2, forward_vel_coeff=0.3, forward_vel_clip=4.0, torque_coeff=-4e-5, terminal_reward=-10.0,
+                 gc_init=None, foot_suffix="_foot", stream=None):
+        self.model = model if isinstance(model, Model) else Model(urdf_path=model)
+        self.world = BatchedWorld(self.model, num_envs, device=device)
+        w, m = self.world, self.model
+        if stream is not None:
+            w.set_stream(stream)
+        self.num_envs, self.nq, self.nv = num_envs, m.nq, m.nv
+        self.num_acts = m.nv - 6
+        self.num_obs = 10 + 2 * self.num_acts
+        w.set_time_step(simulation_dt)
+        kp = np.zeros(m.nv, np.float32); kd = np.zeros(m.nv, np.float32)
+        kp[6:] = p_gain; kd[6:] = d_gain
+        w.set_pd_gains(kp, kd)
+        if gc_init is None:
+            gc_init = np.zeros(m.nq, np.float32); gc_init[2] = 0.6; gc_init[3] = 1.0
+        self.gc_init = np.ascontiguousarray(gc_init, np.float32)
+        self.gv_init = np.zeros(m.nv, np.float32)
+        self.action_mean = np.ascontiguousarray(self.gc_init[7:], np.float32)
+        cfg = _capi.EnvConfig()
+        cfg.n_substeps = int(round(control_dt / simulation_dt))
+        cfg.action_std, cfg.forward_vel_coeff, cfg.forward_vel_clip = action_std, forward_vel_coeff, forward_vel_clip
+        cfg.torque_coeff, cfg.terminal_reward = torque_coeff, terminal_reward
+        feet = m.collision_indices(foot_suffix)
+        cfg.n_foot = len(feet)
+        for i, f in enumerate(feet):
+            cfg.foot_collisions[i] = f
+        self.cfg = cfg
+        w.set_pd_target(np.tile(np.r_[np.zeros(3), 1, np.zeros(m.nq - 4)], (num_envs, 1)), np.zeros((num_envs, m.nv)))
+        check(w.L.rsb_env_configure(w.handle, C.byref(cfg), _hp(self.action_mean), _hp(self.gc_init), _hp(self.gv_init)),
+              "rsb_env_configure")
+        self.reset()
+
+    # a torch tensor travels as its device pointer, anything else as a host array
+    @staticmethod
+    def _is_torch(x):
+        return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+    def reset(self):
+        check(self.world.L.rsb_env_reset(self.world.handle), "rsb_env_reset")
+
+    def observe(self, out=None):
+        w = self.world
+        if out is not None and self._is_torch(out):
+            assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (self.num_envs, self.num_obs)
+            check(w.L.rsb_env_observe(w.handle, C.c_void_p(out.data_ptr()), RSB_DEVICE), "rsb_env_observe")
+            return out
+        ob = np.zeros((self.num_envs, self.num_obs), np.float32) if out is None else out
+        check(w.L.rsb_env_observe(w.handle, _hp(ob), RSB_HOST), "rsb_env_observe")
+        return ob
+
+    def step(self, action, reward=None, done=None):
+        """action [num_envs, num_acts] -> (reward [num_envs] float32, done [num_envs] uint8/bool)."""
+        w = self.world
+        if self._is_torch(action):
+            import torch
+            assert action.is_cuda and action.is_contiguous() and action.dtype == torch.float32
+            reward = torch.empty(self.num_envs, dtype=torch.float32, device=action.device) if reward is None else reward
+            done = torch.empty(self.num_envs, dtype=torch.uint8, device=action.device) if done is None else done
+            check(w.L.rsb_env_step(w.handle, C.c_void_p(action.data_ptr()), C.c_void_p(reward.data_ptr()),
+                                   C.c_void_p(done.data_ptr()), RSB_DEVICE), "rsb_env_step")
+            return reward, done
+        a = np.ascontiguousarray(action, np.float32)
+        assert a.shape == (self.num_envs, self.num_acts)
+        reward = np.zeros(self.num_envs, np.float32) if reward is None else reward
+        done = np.zeros(self.num_envs, np.uint8) if done is None else done
+        check(w.L.rsb_env_step(w.handle, _hp(a), _hp(reward), _hp(done), RSB_HOST), "rsb_env_step")
+        return reward, done
+
+    def close(self):
+        self.world.close()

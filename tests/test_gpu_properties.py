@@ -233,3 +233,65 @@ def test_no_use_of_uninitialised_lds():
                         os.path.join(ROOT, "tests", "test_gpu_properties.py"), "-k", "not uninitialised and not borrowed"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def _env_reference(q, u, pt, kp, kd, counts, contacts, flags, feet, cfg):
+    """numpy restatement of the rsg_anymal-style reward / termination / observation (tests only)."""
+    N = q.shape[0]
+    w, x, y, z = q[:, 3], q[:, 4], q[:, 5], q[:, 6]
+    R = np.empty((N, 3, 3))
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - w * z); R[:, 0, 2] = 2 * (x * z + w * y)
+    R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
+    R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    vb = np.einsum("nji,nj->ni", R, u[:, 0:3]); wb = np.einsum("nji,nj->ni", R, u[:, 3:6])
+    obs = np.concatenate([q[:, 2:3], R[:, :, 2], q[:, 7:], vb, wb, u[:, 6:]], axis=1)   # R[:, :, 2]: body z-axis in the world
+    tau = kp[6:] * (pt[:, 7:] - q[:, 7:]) - kd[6:] * u[:, 6:]
+    r = cfg["fwd"] * np.minimum(cfg["clip"], vb[:, 0]) + cfg["tc"] * (tau ** 2).sum(1)
+    term = (flags & 2) != 0
+    for e in range(N):
+        term[e] |= bool(np.any(~np.isin(contacts[e][:counts[e]]["collision"], feet)))
+    return obs, np.where(term, cfg["term"], r), term
+
+
+def test_device_vecenv_matches_the_host_restatement(anymal):
+    """rsb_env_step / rsb_env_observe (device-resident rsg_anymal task) against the same quantities computed in numpy
+    from rsb_get_state / rsb_get_contacts of a twin world driven through the plain API, for torch and numpy I/O."""
+    import torch
+    from raisimlib_amd import VecEnv
+    N = 200
+    feet = anymal.collision_indices("_foot")
+    gc_init = workload.anymal_initial_state(1)[0][0].astype(np.float32)
+    cfg = dict(fwd=0.3, clip=4.0, tc=-4e-5, term=-10.0)
+    env = VecEnv(anymal, N, gc_init=gc_init)
+    assert (env.num_obs, env.num_acts) == (34, 12)
+    twin = BatchedWorld(anymal, N)
+    kp = np.zeros(18, np.float32); kd = np.zeros(18, np.float32); kp[6:] = 50.0; kd[6:] = 0.2
+    twin.set_pd_gains(kp, kd)
+    twin.set_state(np.tile(gc_init, (N, 1)), np.zeros((N, 18)))
+    ob0 = env.observe()
+    assert np.allclose(ob0[:, 0], gc_init[2]) and np.allclose(ob0[:, 1:4], [0, 0, 1]) and np.allclose(ob0[:, 4:16], gc_init[7:])
+    rng = np.random.default_rng(5)
+    n_done = 0
+    for k in range(40):
+        act = rng.normal(size=(N, 12)).astype(np.float32) * (3.0 if k % 9 == 8 else 1.0)   # big kicks make some fall
+        if k % 2 == 0:
+            rew, done = env.step(act)
+        else:
+            r_t, d_t = env.step(torch.from_numpy(act).cuda())
+            torch.cuda.synchronize()
+            rew, done = r_t.cpu().numpy(), d_t.cpu().numpy()
+        pt = np.zeros((N, 19), np.float32); pt[:, 3] = 1; pt[:, 7:] = gc_init[7:] + np.float32(0.3) * act
+        twin.set_pd_target(pt, np.zeros((N, 18), np.float32))
+        twin.integrate(4)
+        q, u = twin.get_state(); cnt, con = twin.get_contacts(); fl = twin.get_flags()
+        _, r_ref, term = _env_reference(q.astype(np.float64), u.astype(np.float64), pt.astype(np.float64), kp, kd, cnt, con, fl, feet, cfg)
+        assert np.array_equal(done.astype(bool), term)
+        assert np.allclose(rew, r_ref, rtol=2e-5, atol=2e-5)
+        twin.reset_terminated(feet, gc_init, np.zeros(18, np.float32))
+        q, u = twin.get_state()
+        ob_ref, _, _ = _env_reference(q.astype(np.float64), u.astype(np.float64), pt.astype(np.float64), kp, kd, cnt, con, fl, feet, cfg)
+        ob = env.observe() if k % 2 else env.observe(torch.empty((N, 34), device="cuda")).cpu().numpy()
+        assert np.allclose(ob, ob_ref, rtol=1e-5, atol=1e-5)
+        n_done += int(term.sum())
+    assert n_done > 0
+    env.close(); twin.close()
