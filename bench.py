@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--no-reset", action="store_true", help="disable the non-foot-contact termination rule")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--stall-window", type=int, default=-1, help="diagnostic: solver stagnation window (library default 6)")
+    ap.add_argument("--freeze-after", type=int, default=-1, help="diagnostic: sweeps before friction directions lag (default 6)")
+    ap.add_argument("--settle-tol", type=float, default=-1.0, help="diagnostic: settled-direction tolerance (default 1e-4 rad)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
     return ap.parse_args()
 
 
@@ -139,12 +144,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size > 1:
+    coll = world_size > 1 or args.force_collective     # the obs all-gather is part of the step
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world_size > 1:
+    if coll:
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     N = args.envs_per_gpu
@@ -158,6 +164,11 @@ def main():
         world.set_contact_solver_param(1.0, 1.0, 1.0, args.max_iter, 1e-5)
     if args.lanes_per_env:
         world.set_lanes_per_env(args.lanes_per_env)
+    if args.stall_window >= 0:
+        world.set_solver_stagnation_exit(args.stall_window, 0.5)
+    if args.freeze_after >= 0 or args.settle_tol >= 0:
+        world.set_solver_friction_lag(args.freeze_after if args.freeze_after >= 0 else 6, True,
+                                      args.settle_tol if args.settle_tol >= 0 else 1e-4)
     world.set_time_step(workload.DT)
     kp, kd = workload.anymal_gains()
     world.set_pd_gains(kp, kd)
@@ -172,7 +183,7 @@ def main():
             for k in range(TARGET_BANK)]
     obs_dim = world.obs_dim(len(feet))
     obs = torch.empty((N, obs_dim), dtype=torch.float32, device=dev)
-    all_obs = torch.empty((world_size * N, obs_dim), dtype=torch.float32, device=dev) if world_size > 1 else obs
+    all_obs = torch.empty((world_size * N, obs_dim), dtype=torch.float32, device=dev) if coll else obs
     feet_idx = np.asarray(feet, np.int32)
     reset = not args.no_reset
 
@@ -185,7 +196,7 @@ def main():
 
     def control_step(k):
         step_fn(bank_ptr[k % TARGET_BANK])
-        if world_size > 1:
+        if coll:
             dist.all_gather_into_tensor(all_obs, obs)
 
     for k in range(args.warmup):
@@ -244,10 +255,16 @@ def main():
         }
         if world_size == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(model, feet, args.max_iter, reset, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
     world.close()
-    if world_size > 1:
+    if coll:
         dist.destroy_process_group()
+    if rank == 0:
+        try:    # RCCL writes its version banner through C stdio; flush it so that the JSON line is the last line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -168,8 +168,10 @@ int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
  * re-optimise the direction).  Solves that converge within freeze_after sweeps are unaffected.
  * refine != 0 (default): before that, a contact that already slipped in this solve updates its direction by one
  * guarded Newton step on the curve's energy instead of a new global search (falls back to the search when the
- * step is not a safe descent step). */
-int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine);
+ * step is not a safe descent step).
+ * settle_tol (default 1e-4 rad): a refinement that moved the direction by less than this marks it settled; settled
+ * directions are kept like lagged ones for the rest of the solve (0 = never). */
+int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, double settle_tol);
 int rsb_set_max_contacts(rsb_world* w, int kmax);   /* 1..RSB_MAX_CONTACTS */
 /* Kernel mapping knob: lanes of a wavefront that cooperate on one env (16, 32 or 64).
  * 64 = the north star's "one wavefront per env"; 0 = pick the measured-fastest default. */

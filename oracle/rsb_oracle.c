@@ -282,6 +282,7 @@ void orc_default_params(orc_params* p) {
   p->section_rounds = 2;
   p->freeze_after = 6;
   p->refine = 1;
+  p->settle_tol = 1e-4;
   p->warm_start = 0;  /* evaluated: 12% fewer sweeps on the config-2 workload, not worth the state; off, device has no counterpart */
   p->stall_window = 6;
   p->stall_factor = 0.5;
@@ -562,7 +563,7 @@ static void slip_rotate(double x0, double y0, double d, double* x1, double* y1) 
   double x = x0 * c - y0 * s, y = x0 * s + y0 * c, inv = 1.0 / sqrt(x * x + y * y);
   *x1 = x * inv; *y1 = y * inv;
 }
-static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, double* y1) {
+static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, double* y1, double* step) {
   double den = k->a0 + k->a1 * x0 + k->a2 * y0, hp;
   if (!(den > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(1); return 0; }
   double d = slip_newton_step(k, x0, y0, &hp);
@@ -573,7 +574,7 @@ static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, dou
   if (!(k->a0 + k->a1 * x + k->a2 * y > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(4); return 0; }
   if (fabs(d) > 0.02 && !(slip_E(k, x, y) <= slip_E(k, x0, y0))) { ORC_STAT(5); return 0; }
   ORC_STAT(0);
-  *x1 = x; *y1 = y;
+  *x1 = x; *y1 = y; *step = d;
   return 1;
 }
 
@@ -594,10 +595,11 @@ static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, dou
  */
 /* sdir (in/out, 3 doubles: dx, dy, valid): the friction direction of this contact's last slip solve.  With
  * use_frozen != 0 and a valid direction the slip case keeps that direction and only re-solves the magnitude
- * ("lagged friction direction", used by the caller after `freeze_after` sweeps).  With refine != 0 and a valid
+ * ("lagged friction direction", used by the caller after `freeze_after` sweeps, and from the sweep after a Newton
+ * refinement moved the direction by less than settle_tol rad: sdir[2] = 2 marks such a settled direction).  With refine != 0 and a valid
  * direction the global search is replaced by slip_newton() whenever that step is accepted. */
 static void solve_one_contact(const double* G, const double* Ginv, const double* v, double mu,
-                              int section_rounds, int use_frozen, int refine, double* sdir, double* lam) {
+                              int section_rounds, int use_frozen, int refine, double settle_tol, double* sdir, double* lam) {
   if (v[2] > 0.0) { lam[0] = lam[1] = lam[2] = 0.0; return; }
   double ls[3];
   for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
@@ -605,7 +607,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
   if (ls[2] >= 0.0 && lt2 <= mu * mu * ls[2] * ls[2]) { lam[0] = ls[0]; lam[1] = ls[1]; lam[2] = ls[2]; return; }
   slip_coef k;
   slip_prepare(G, v, ls, mu, &k);
-  if (use_frozen && sdir[2] != 0.0) {
+  if ((use_frozen || sdir[2] == 2.0) && sdir[2] != 0.0) {
     /* only well-conditioned directions are kept: near the curve's asymptote (den -> 0) a stale direction would
      * amplify any change of v_n without bound */
     double den = k.a0 + k.a1 * sdir[0] + k.a2 * sdir[1];
@@ -616,11 +618,12 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
     }
   }
   if (refine && sdir[2] != 0.0) {
-    double x, y;
-    if (slip_newton(&k, sdir[0], sdir[1], &x, &y)) {
+    double x, y, d;
+    if (slip_newton(&k, sdir[0], sdir[1], &x, &y, &d)) {
       double ln = -v[2] / (k.a0 + k.a1 * x + k.a2 * y);
       lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
       sdir[0] = x; sdir[1] = y;
+      sdir[2] = (fabs(d) <= settle_tol) ? 2.0 : 1.0;   /* settled: the direction stopped moving, later sweeps keep it */
       return;
     }
   }
@@ -669,7 +672,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
 void orc_solve_contact(const double* G, const double* v, double mu, int section_rounds, double* lam) {
   double Ginv[9], sdir[3] = {0.0, 0.0, 0.0};
   inv3(G, Ginv);
-  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, 0, sdir, lam);
+  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, 0, 0.0, sdir, lam);
 }
 
 static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {
@@ -800,7 +803,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
           for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam[j][0] + G[i][j][3 * r + 1] * lam[j][1] + G[i][j][3 * r + 2] * lam[j][2];
         }
         solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds,
-                          p->freeze_after > 0 && it >= p->freeze_after, p->refine, sdir[i], ln);
+                          p->freeze_after > 0 && it >= p->freeze_after, p->refine, p->settle_tol, sdir[i], ln);
         for (int r = 0; r < 3; ++r) {
           double dl = alpha * (ln[r] - lam[i][r]);
           lam[i][r] += dl;

@@ -56,7 +56,7 @@ struct rsb_world {
   int max_iter = 150, section_rounds = 2, stall_window = 6, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
-  double stall_factor = 0.5;
+  double stall_factor = 0.5, settle_tol = 1e-4;
   int lpe = 0, max_cl = 0;
   double world_time = 0;
   bool integrate1_valid = false;
@@ -400,7 +400,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.mu = (float)w->mu; a.erp = (float)w->erp;
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
   a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
-  a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine;
+  a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {
     double dx = w->hm_xsize / (w->hm_xs - 1), dy = w->hm_ysize / (w->hm_ys - 1);
@@ -591,9 +591,9 @@ int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor) {
   w->stall_window = window; w->stall_factor = factor;
   return RSB_OK;
 }
-int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine) {
-  if (!w || freeze_after < 0) { rsb::set_error("rsb_set_solver_friction_lag: freeze_after >= 0"); return RSB_E_INVALID; }
-  w->freeze_after = freeze_after; w->refine = refine != 0;
+int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, double settle_tol) {
+  if (!w || freeze_after < 0 || !(settle_tol >= 0.0)) { rsb::set_error("rsb_set_solver_friction_lag: freeze_after >= 0, settle_tol >= 0"); return RSB_E_INVALID; }
+  w->freeze_after = freeze_after; w->refine = refine != 0; w->settle_tol = settle_tol;
   return RSB_OK;
 }
 int rsb_set_max_contacts(rsb_world* w, int kmax) {

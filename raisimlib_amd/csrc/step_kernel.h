@@ -118,7 +118,7 @@ struct StepArgs {
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
   int max_iter, section_rounds, stall_window, freeze_after, refine;
-  float stall_factor;
+  float stall_factor, settle_tol;
   int terrain_type, hm_xs, hm_ys;
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
   LdsLayout L;
@@ -272,7 +272,7 @@ __device__ __forceinline__ void slip_rotate(float x0, float y0, float d, float& 
 // One guarded Newton step from the direction (x0, y0) of an earlier slip solve of the same contact (oracle:
 // slip_newton).  Branch-free: every lane runs it on its own contact, the result says whether the step is a safe
 // descent step (else the caller runs the cooperative global search).
-__device__ __forceinline__ bool slip_newton(const SlipCoef& k, float mu, float x0, float y0, float& x1, float& y1) {
+__device__ __forceinline__ bool slip_newton(const SlipCoef& k, float mu, float x0, float y0, float& x1, float& y1, float& step) {
   float hp;
   const float d = slip_newton_step(k, x0, y0, hp);
   float x, y;
@@ -280,7 +280,7 @@ __device__ __forceinline__ bool slip_newton(const SlipCoef& k, float mu, float x
   bool ok = (k.a0 + k.a1 * x0 + k.a2 * y0 > kDenNewton * k.a0) && (hp > 0.f) && (fabsf(d) <= 0.25f) &&
             (k.a0 + k.a1 * x + k.a2 * y > kDenNewton * k.a0);
   if (__any(ok && fabsf(d) > 0.02f)) ok = ok && (fabsf(d) <= 0.02f || slip_E(k, mu, x, y) <= slip_E(k, mu, x0, y0));
-  x1 = x; y1 = y;
+  x1 = x; y1 = y; step = d;
   return ok;
 }
 // 16-lane row minimum of an unsigned key (DPP row rotate: no LDS, no bpermute)
@@ -903,7 +903,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         sc.n00 = sc.n10 = sc.vn = sc.ls0 = sc.ls1 = 0.f;
         float lam_best[3] = {0.f, 0.f, 0.f}, best_rel = 3e38f;   // calmest iterate (returned when the solve does not converge)
         float sdx = 0.f, sdy = 0.f;   // friction direction of this contact's last slip solve (|.| = 1 once set)
-        bool sdv = false;
+        bool sdv = false, sset = false;   // direction valid / settled (the last refinement moved it by less than settle_tol)
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
@@ -935,9 +935,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
               if (a.prof) ++p_solves;
               if (__any(slip)) {
-                // lagged friction direction: after freeze_after sweeps a slipping contact keeps its last direction
-                // when the normal response along it is well conditioned
-                const bool frozen = slip && sdv && lag && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
+                // lagged friction direction: after freeze_after sweeps, or once a refinement no longer moved it (settled), a
+                // slipping contact keeps its last direction when the normal response along it is well conditioned
+                const bool frozen = slip && sdv && (lag || sset) && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
                 if (__any(slip && !frozen)) {
                   SlipCoef kc = sc;
                   const float vex0 = v[0] - (Gii[0] * lam[0] + Gii[1] * lam[1] + Gii[2] * lam[2]);
@@ -950,9 +950,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                   bool refined = false;
                   if (__any(cand)) {
                     long long tn0 = 0; if (a.prof) { ++p_newton; if (a.prof_fine) tn0 = clock64(); }
-                    float nx, ny;
-                    refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny) && cand;
-                    if (refined) { sdx = nx; sdy = ny; }
+                    float nx, ny, dstep;
+                    refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny, dstep) && cand;
+                    if (refined) { sdx = nx; sdy = ny; sset = fabsf(dstep) <= a.settle_tol; }
                     if (a.prof && a.prof_fine) t_newt += clock64() - tn0;
                   }
                   const bool need = slip && !frozen && !refined;
@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                     kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
                     float dxy[2];
                     slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, dxy);
-                    if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; }
+                    if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; sset = false; }
                     if (a.prof && a.prof_fine) t_srch += clock64() - ts0;
                   }
                 }

@@ -124,8 +124,9 @@ class BatchedWorld:
     def set_solver_stagnation_exit(self, window, factor):
         check(self.L.rsb_set_solver_stagnation_exit(self.handle, int(window), float(factor)), "rsb_set_solver_stagnation_exit")
 
-    def set_solver_friction_lag(self, freeze_after, refine=True):
-        check(self.L.rsb_set_solver_friction_lag(self.handle, int(freeze_after), int(bool(refine))), "rsb_set_solver_friction_lag")
+    def set_solver_friction_lag(self, freeze_after, refine=True, settle_tol=1e-4):
+        check(self.L.rsb_set_solver_friction_lag(self.handle, int(freeze_after), int(bool(refine)), float(settle_tol)),
+              "rsb_set_solver_friction_lag")
 
     def set_max_contacts(self, kmax):
         check(self.L.rsb_set_max_contacts(self.handle, int(kmax)), "rsb_set_max_contacts")
