@@ -6,6 +6,7 @@
 // kernel (step_kernel.h) on the handle's stream.  No CPU fallback exists anywhere in this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -202,14 +203,23 @@ int count_chains(const rsb_model_blob& b) {
   return n;
 }
 
-// Lanes per env: the smallest group whose workgroup (64/LPE envs) still leaves room for one workgroup per
-// SIMD in a CU's 160 KiB of LDS; at N = 4096 that is what puts one wave on every SIMD of the chip.
+// Lanes per env: the group size that keeps the most envs resident on a CU.  The kernel runs at one wave per SIMD
+// (register budget), so a CU holds min(4, 160 KiB / workgroup LDS) workgroups of 64/LPE envs each.  ANYmal-like models:
+// LPE 16 (4 x 4 envs, 38 KB per workgroup: at N = 4096 one wave on every SIMD of the chip); Atlas-like, kmax 16
+// (25 KB per env): every choice holds 4 envs, LPE 64 keeps all four SIMDs busy.
 int default_lpe(const rsb_model_blob& b, int kmax) {
   const int kcap = kmax <= 8 ? 8 : 16;
   const int need = count_chains(b) > 16 ? (count_chains(b) > 32 ? 64 : 32) : 16;
-  for (int lpe = need; lpe < 64; lpe *= 2)
-    if (lds_bytes_for(b, kcap, lpe) <= 40 * 1024) return lpe;
-  return 64;
+  int best = 64, best_envs = 0, best_wgs = 0;
+  for (int lpe = need; lpe <= 64; lpe *= 2) {
+    const size_t wg = lds_bytes_for(b, kcap, lpe);
+    if (wg > 160 * 1024) continue;
+    const int wgs = (int)std::min<size_t>(4, (160 * 1024) / wg);
+    const int envs = wgs * (64 / lpe);
+    // ties go to the layout that keeps more SIMDs busy (more, smaller workgroups)
+    if (envs > best_envs || (envs == best_envs && wgs > best_wgs)) { best_envs = envs; best_wgs = wgs; best = lpe; }
+  }
+  return best;
 }
 
 __global__ void masked_row_copy(float* dst, const float* src, const uint8_t* mask, int N, int dim) {
