@@ -181,8 +181,9 @@ class Oracle:
                     G=G[:n3 * n3].reshape(n3, n3).copy(), c=c[:n3].copy(), lam=lam[:n3].copy())
 
     def new_warm_state(self, n):
-        """Zeroed warm-start state for n envs ([n, 3*ncol] float64), to be passed to step_batch(lam_warm=...)."""
-        return np.zeros((n, 3 * self.blob.ncol))
+        """Zeroed warm-start state for n envs ([n, 6*ncol] float64: impulse 3, friction direction 2, valid flag per
+        collision primitive), to be passed to step_batch(lam_warm=...) / step_debug(lam_warm=...)."""
+        return np.zeros((n, 6 * self.blob.ncol))
 
     def step_batch(self, q, u, substeps=1, kp=None, kd=None, pt=None, dt_=None, tau_ff=None, nthreads=0,
                    want_contacts=False, lam_warm=None):

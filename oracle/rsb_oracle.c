@@ -27,6 +27,7 @@
 #define MAXB RSB_MAX_BODIES
 #define MAXV RSB_MAX_DOF
 #define MAXK RSB_MAX_CONTACTS
+#define ORC_WARM 6   /* warm state per collision primitive: impulse (3, contact frame), friction direction (2), direction valid */
 #define ORC_LAMBDA_FLOOR 1e-3 /* N s; keeps the relative convergence test meaningful as impulses -> 0 */
 
 /* ------------------------------------------------------------------ small linear algebra */
@@ -283,7 +284,9 @@ void orc_default_params(orc_params* p) {
   p->freeze_after = 6;
   p->refine = 1;
   p->settle_tol = 1e-4;
-  p->warm_start = 0;  /* evaluated: 12% fewer sweeps on the config-2 workload, not worth the state; off, device has no counterpart */
+  p->warm_start = 1;  /* only has an effect when the caller carries a warm state (orc_step_warm / orc_step_batch with lam_warm):
+                         8% fewer sweeps and 7x fewer global searches on the config-2 workload.  The device has no counterpart yet
+                         (every rsb_integrate() sub-step starts cold), so parity tests and the CPU baseline run without a state. */
   p->stall_window = 6;
   p->stall_factor = 0.5;
   p->kmax = 8;
@@ -739,6 +742,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   for (int i = 0; i < nv; ++i) ufree[i] += u[i];
 
   double lam[MAXK][3];
+  double sdir_out[MAXK][3];   /* friction directions at the end of the solve (warm state of the next integrate()) */
+  for (int i = 0; i < MAXK; ++i) sdir_out[i][0] = sdir_out[i][1] = sdir_out[i][2] = 0.0;
   int it_used = 0;
   double (*X)[3][MAXV] = NULL;
   if (nc > 0) {
@@ -772,8 +777,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         cfree[i][r] = s;
       }
       cfree[i][2] -= p->erp * cdepth[i] / p->dt;
-      /* warm start: the impulse this collision primitive carried in the previous integrate() (contact frame) */
-      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start) ? lam_warm[3 * ccol[i] + r] : 0.0;
+      /* warm start: the impulse (contact frame) this collision primitive carried in the previous integrate() */
+      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
     }
     /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
     if (dbgG)
@@ -792,7 +797,13 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
      * max_iter without converging; on a lock-step GPU launch that worst case sets the launch time. */
     double alpha = p->alpha_init, best_prev = 1e300, best_cur = 1e300;
     double sdir[MAXK][3], lam_best[MAXK][3], best_rel = 1e300;
-    for (int i = 0; i < nc; ++i) { sdir[i][0] = sdir[i][1] = sdir[i][2] = 0.0; lam_best[i][0] = lam_best[i][1] = lam_best[i][2] = 0.0; }
+    for (int i = 0; i < nc; ++i) {
+      sdir[i][0] = sdir[i][1] = sdir[i][2] = 0.0;
+      lam_best[i][0] = lam_best[i][1] = lam_best[i][2] = 0.0;
+      if (lam_warm && p->warm_start && lam_warm[ORC_WARM * ccol[i] + 5] != 0.0) {   /* ... and its last friction direction */
+        sdir[i][0] = lam_warm[ORC_WARM * ccol[i] + 3]; sdir[i][1] = lam_warm[ORC_WARM * ccol[i] + 4]; sdir[i][2] = 1.0;
+      }
+    }
     int converged = 0;
     for (int it = 0; it < p->max_iter; ++it) {
       double err = 0, scale = 0;
@@ -833,6 +844,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam[i][r] = lam_best[i][r];
     }
     if (dbglam) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) dbglam[3 * i + r] = lam[i][r];
+    for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) sdir_out[i][r] = sdir[i][r];
   }
 
   /* u+ = u_free + M^-1 J^T lam ;  q+ = q (+) dt u+   (semi-implicit Euler) */
@@ -860,8 +872,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   for (int i = 0; i < nv; ++i) if (!isfinite(u[i])) fl |= 2;
 
   if (lam_warm) {
-    for (int i = 0; i < 3 * m->ncol; ++i) lam_warm[i] = 0.0;
-    for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam_warm[3 * ccol[i] + r] = lam[i][r];
+    for (int i = 0; i < ORC_WARM * m->ncol; ++i) lam_warm[i] = 0.0;
+    for (int i = 0; i < nc; ++i) {
+      double* wrm = lam_warm + ORC_WARM * ccol[i];
+      for (int r = 0; r < 3; ++r) wrm[r] = lam[i][r];
+      if (sdir_out[i][2] != 0.0) { wrm[3] = sdir_out[i][0]; wrm[4] = sdir_out[i][1]; wrm[5] = 1.0; }
+    }
   }
   if (contacts)
     for (int i = 0; i < nc; ++i) {
@@ -926,7 +942,7 @@ int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int subs
                     tau_ff ? tau_ff + (size_t)e * m->nv : NULL,
                     contacts ? contacts + (size_t)e * p->kmax : NULL,
                     n_contacts ? n_contacts + e : NULL, iters ? iters + e : NULL, &fl,
-                    lam_warm ? lam_warm + (size_t)e * 3 * m->ncol : NULL);
+                    lam_warm ? lam_warm + (size_t)e * ORC_WARM * m->ncol : NULL);
       fl_acc |= fl;
     }
     if (flags) flags[e] = fl_acc;

@@ -103,8 +103,9 @@ void orc_step(const rsb_model_blob* m, const orc_params* p, double* q, double* u
               const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
               int32_t* flags);
 
-/* orc_step with the solver's warm-start state: lam_warm [3*ncol] (contact-frame impulse each collision
- * primitive carried in the previous integrate(), zero where there was no contact) is read and updated. */
+/* orc_step with the solver's warm-start state: lam_warm [6*ncol] = per collision primitive the contact-frame impulse
+ * (3), the friction direction of its last slip solve (2) and a valid flag, as left by the previous integrate()
+ * (zero where there was no contact); read when p->warm_start != 0, always updated. */
 void orc_step_warm(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
                    const double* kd, const double* p_target, const double* d_target,
                    const double* tau_ff, orc_contact* contacts, int32_t* n_contacts, int32_t* iters,
@@ -120,7 +121,7 @@ void orc_step_debug(const rsb_model_blob* m, const orc_params* p, double* q, dou
 /* N independent envs, `substeps` integrate() calls each; OpenMP parallel-for over envs
  * (mirrors raisimGymTorch's VectorizedEnvironment::step fan-out [RECALL]).
  * q [N*nq], u [N*nv], p_target [N*nq], d_target [N*nv], tau_ff [N*nv] (may be NULL).
- * contacts [N*kmax], n_contacts/iters/flags [N] (may be NULL); lam_warm [N*3*ncol] in/out warm-start state
+ * contacts [N*kmax], n_contacts/iters/flags [N] (may be NULL); lam_warm [N*6*ncol] in/out warm-start state
  * (NULL = cold start every integrate()). Returns threads used. */
 int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int substeps, double* q,
                    double* u, const double* kp, const double* kd, const double* p_target,
