@@ -1,0 +1,113 @@
+"""The analytic known-answer tests of tests/test_oracle_kat.py run through the C-ABI on the GPU (fp32 tolerances):
+with parity to RaiSim unpinned, the HIP path is checked against closed-form physics directly, not only against the
+in-repo oracle.  Every KAT runs 64 identical envs (one wave would hide lane-mapping bugs of the others)."""
+import numpy as np
+import pytest
+
+from common import PENDULUM_URDF, sphere_urdf
+from raisimlib_amd import BatchedWorld, Model, workload
+from test_oracle_kat import SLED
+
+pytestmark = pytest.mark.gpu
+G, DT, N = 9.81, 0.0025, 64
+
+
+def world(urdf, gravity=None, mode=1):
+    m = Model(urdf_string=urdf)
+    w = BatchedWorld(m, N)
+    if gravity is not None:
+        w.set_gravity(gravity)
+    w.set_control_mode(mode)
+    return m, w
+
+
+def tile(x):
+    return np.tile(np.asarray(x, np.float64), (N, 1))
+
+
+def test_sphere_rest_impulse_is_m_g_dt(built_lib):
+    m_, r = 2.0, 0.1
+    _, w = world(sphere_urdf(m_, r))
+    w.set_state(tile([0, 0, r - 1e-4, 1, 0, 0, 0]), tile(np.zeros(6)))
+    w.integrate(5)
+    cnt, con = w.get_contacts(); q, u = w.get_state()
+    assert (cnt == 1).all()
+    imp = np.array([c[0]["impulse"] for c in con])
+    assert np.allclose(imp, [0, 0, m_ * G * DT], atol=2e-7) and np.abs(u).max() < 1e-6
+    assert np.ptp(imp, axis=0).max() == 0.0           # all 64 envs bit-identical
+    w.close()
+
+
+def test_sliding_friction_decelerates_at_mu_g(built_lib):
+    m_, r, mu = 2.0, 0.1, 0.8
+    _, w = world(sphere_urdf(m_, r))
+    u0 = np.array([3.0, 0, 0, 0, 0, 0])
+    w.set_state(tile([0, 0, r - 1e-5, 1, 0, 0, 0]), tile(u0))
+    prev = 3.0
+    for k in range(10):
+        w.integrate(1)
+        _, u = w.get_state(); cnt, con = w.get_contacts()
+        assert np.allclose(u[:, 0] - prev, -mu * G * DT, atol=3e-6), k
+        lam = np.array([c[0]["impulse"] for c in con])
+        assert np.allclose(np.hypot(lam[:, 0], lam[:, 1]), mu * lam[:, 2], rtol=1e-5)
+        assert (lam[:, 0] < 0).all() and np.abs(lam[:, 1]).max() < 1e-6
+        prev = u[0, 0]
+    w.close()
+
+
+@pytest.mark.parametrize("angle_deg,sticks", [(30.0, True), (36.0, True), (42.0, False), (50.0, False)])
+def test_stick_slip_threshold_on_incline(built_lib, angle_deg, sticks):
+    th = np.radians(angle_deg)
+    _, w = world(SLED, gravity=[G * np.sin(th), 0.0, -G * np.cos(th)])
+    w.set_state(tile([0, 0, 0.05 - 1e-5, 1, 0, 0, 0]), tile(np.zeros(6)))
+    n = 200
+    w.integrate(n)
+    _, u = w.get_state(); cnt, _ = w.get_contacts()
+    assert (cnt == 4).all()
+    if sticks:
+        assert np.abs(u).max() < 2e-4
+    else:
+        a = G * (np.sin(th) - 0.8 * np.cos(th))
+        assert np.allclose(u[:, 0], a * n * DT, rtol=2e-2)
+        mu_eff = (np.sin(th) - u[:, 0] / (n * DT) / G) / np.cos(th)
+        assert np.abs(mu_eff - 0.8).max() < 2e-3
+        assert np.abs(u[:, 2]).max() < 1e-4 and np.abs(u[:, 3:]).max() < 1e-3
+
+
+def test_pendulum_spring_period(built_lib):
+    l, m_ = 0.5, 1.0
+    _, w = world(PENDULUM_URDF.format(l=l, m=m_), gravity=[0, 0, 0])
+    kp = np.zeros(7, np.float32); kd = np.zeros(7, np.float32); kp[6] = 40.0
+    T = 2 * np.pi * np.sqrt((m_ * l * l + 1e-9) / kp[6])
+    pt = tile([0, 0, 0, 1, 0, 0, 0, 0.0])
+    w.set_pd_gains(kp, kd); w.set_pd_target(pt, tile(np.zeros(7)))
+    w.set_state(tile([0, 0, 0, 1, 0, 0, 0, 0.1]), tile(np.zeros(7)))
+    th, t = [], []
+    for k in range(int(5 * T / DT)):
+        w.integrate(1)
+        q, _ = w.get_state()
+        th.append(q[0, 7]); t.append((k + 1) * DT)
+        if k == 0:
+            assert np.ptp(q, axis=0).max() == 0.0
+    th = np.array(th, np.float64); t = np.array(t)
+    idx = np.where((th[:-1] < 0) & (th[1:] >= 0))[0]
+    tc = t[idx] + DT * (-th[idx]) / (th[idx + 1] - th[idx])
+    assert len(tc) >= 4 and np.allclose(np.diff(tc), T, rtol=3e-3)
+    assert abs(np.abs(th).max() - 0.1) < 3e-3
+    w.close()
+
+
+def test_standing_anymal_carries_its_weight(anymal):
+    w = BatchedWorld(anymal, N)
+    kp = np.zeros(18, np.float32); kd = np.zeros(18, np.float32); kp[6:] = 400.0; kd[6:] = 10.0
+    q0 = np.zeros(19); q0[2] = 0.60; q0[3] = 1; q0[7:] = workload.ANYMAL_NOMINAL_JOINTS
+    w.set_pd_gains(kp, kd); w.set_pd_target(tile(q0), tile(np.zeros(18))); w.set_state(tile(q0), tile(np.zeros(18)))
+    w.integrate(1500)
+    cnt, con = w.get_contacts(); _, u = w.get_state()
+    assert (cnt == 4).all() and (w.get_flags() == 0).all()
+    lam = np.array([[c["impulse"] for c in ce[:4]] for ce in con])
+    assert np.allclose(lam[:, :, 2].sum(1), anymal.total_mass() * G * DT, rtol=2e-4)
+    assert np.all(np.hypot(lam[:, :, 0], lam[:, :, 1]) <= 0.8 * lam[:, :, 2] * (1 + 1e-5) + 1e-7)
+    assert np.abs(u).max() < 2e-3
+    assert {int(c) for c in con[0][:4]["collision"]} == set(anymal.collision_indices("_foot"))
+    w.close()
