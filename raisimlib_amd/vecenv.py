@@ -4,7 +4,8 @@ Mirrors raisimGymTorch's Python wrapper `RaisimGymVecEnv` [RECALL raisimGymTorch
 /root/reference]: `reset()`, `observe()`, `step(action) -> (reward, done)`, `num_obs`, `num_acts`, `num_envs`, with
 rsg_anymal's task semantics computed on the GPU (see include/rsb.h, "device-resident vectorised env").  Actions,
 observations, rewards and dones are torch CUDA tensors when torch tensors are passed (zero-copy, on the caller's
-stream) and numpy arrays otherwise (staged through PCIe by the library).
+stream) and numpy arrays otherwise (staged through PCIe by the library).  All device work is enqueued on the HIP stream
+given as `stream` (a raw stream handle), by default torch's current stream at construction time.
 """
 import ctypes as C
 
@@ -22,6 +23,15 @@ class VecEnv:
         self.model = model if isinstance(model, Model) else Model(urdf_path=model)
         self.world = BatchedWorld(self.model, num_envs, device=device)
         w, m = self.world, self.model
+        if stream is None:
+            # torch tensors are produced / consumed on torch's current stream: run the world on it, otherwise the
+            # world's own (non-blocking) stream would race with the caller's tensor ops
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    stream = torch.cuda.current_stream(device).cuda_stream
+            except ImportError:
+                pass
         if stream is not None:
             w.set_stream(stream)
         self.num_envs, self.nq, self.nv = num_envs, m.nq, m.nv
@@ -85,6 +95,25 @@ class VecEnv:
         done = np.zeros(self.num_envs, np.uint8) if done is None else done
         check(w.L.rsb_env_step(w.handle, _hp(a), _hp(reward), _hp(done), RSB_HOST), "rsb_env_step")
         return reward, done
+
+    # -- running observation statistics (RaisimGymVecEnv's normalize_ob / RunningMeanStd [RECALL]) -------------------
+    def observe_normalized(self, out, update_statistics=True, clip=10.0, eps=1e-8):
+        """Observation tensor [num_envs, num_obs] (torch CUDA), normalised in place with running mean / variance kept on
+        the device (batched Welford update, as upstream's RunningMeanStd); returns `out`."""
+        import torch
+        self.observe(out)
+        if not hasattr(self, "ob_mean"):
+            self.ob_mean = torch.zeros(self.num_obs, dtype=torch.float32, device=out.device)
+            self.ob_var = torch.ones(self.num_obs, dtype=torch.float32, device=out.device)
+            self.ob_count = 1e-4
+        if update_statistics:
+            bm, bv, n = out.mean(0), out.var(0, unbiased=False), float(out.shape[0])
+            delta, tot = bm - self.ob_mean, self.ob_count + n
+            self.ob_mean = self.ob_mean + delta * (n / tot)
+            self.ob_var = (self.ob_var * self.ob_count + bv * n + delta * delta * (self.ob_count * n / tot)) / tot
+            self.ob_count = tot
+        out.sub_(self.ob_mean).div_(torch.sqrt(self.ob_var + eps)).clamp_(-clip, clip)
+        return out
 
     def close(self):
         self.world.close()

@@ -295,3 +295,25 @@ def test_device_vecenv_matches_the_host_restatement(anymal):
         n_done += int(term.sum())
     assert n_done > 0
     env.close(); twin.close()
+
+
+def test_vecenv_running_observation_statistics(anymal):
+    """observe_normalized keeps RunningMeanStd-style statistics on the device: after many batches the normalised
+    observations have ~zero mean / unit variance, and the statistics match a numpy recomputation over all batches."""
+    import torch
+    from raisimlib_amd import VecEnv
+    N = 256
+    gc_init = np.zeros(19, np.float32); gc_init[2] = 0.6; gc_init[3] = 1.0; gc_init[7:] = workload.ANYMAL_NOMINAL_JOINTS
+    env = VecEnv(anymal, N, gc_init=gc_init)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    raw, ob = [], torch.empty((N, 34), device="cuda")
+    for k in range(30):
+        env.step(torch.empty((N, 12), device="cuda").uniform_(-1, 1, generator=gen))
+        raw.append(env.observe().copy())
+        env.observe_normalized(ob)
+    allraw = np.concatenate(raw)
+    assert np.allclose(env.ob_mean.cpu().numpy(), allraw.mean(0), rtol=1e-3, atol=1e-4)
+    assert np.allclose(env.ob_var.cpu().numpy(), allraw.var(0), rtol=2e-2, atol=1e-5)
+    z = (raw[-1] - allraw.mean(0)) / np.sqrt(allraw.var(0) + 1e-8)
+    assert np.allclose(ob.cpu().numpy(), np.clip(z, -10, 10), rtol=2e-2, atol=2e-2)
+    env.close()
