@@ -87,6 +87,7 @@ def cpu_baseline(model, feet, max_iter, reset, budget_s):
     feet_set = np.zeros(model.ncol, bool)
     feet_set[feet] = True
     state = {"q": gc0.astype(np.float32).astype(np.float64), "u": gv0.copy(), "cs": 0}
+    warm = orc.new_warm_state(n)      # the solver warm state the device keeps per env (cleared on reset, as there)
 
     def run(threads, seconds):
         spent, steps = 0.0, 0
@@ -94,7 +95,7 @@ def cpu_baseline(model, feet, max_iter, reset, budget_s):
             pt = workload.anymal_targets(n, state["cs"]).astype(np.float32).astype(np.float64)
             t0 = time.perf_counter()
             r = orc.step_batch(state["q"], state["u"], workload.SUBSTEPS, kp, kd, pt, dtg, nthreads=threads,
-                               want_contacts=reset)
+                               want_contacts=reset, lam_warm=warm)
             spent += time.perf_counter() - t0
             q, u = r["q"], r["u"]
             if reset:
@@ -102,6 +103,7 @@ def cpu_baseline(model, feet, max_iter, reset, budget_s):
                 valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
                 term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
                 q[term], u[term] = gc0[term], gv0[term]
+                warm[term] = 0.0
             state["q"], state["u"] = q, u
             state["cs"] += 1
             steps += n * workload.SUBSTEPS
@@ -110,13 +112,15 @@ def cpu_baseline(model, feet, max_iter, reset, budget_s):
     hw = orc.max_threads()
     for _ in range(40):  # untimed: bring the population into the steady contact regime before probing thread counts
         pt = workload.anymal_targets(n, state["cs"]).astype(np.float32).astype(np.float64)
-        r = orc.step_batch(state["q"], state["u"], workload.SUBSTEPS, kp, kd, pt, dtg, nthreads=0, want_contacts=reset)
+        r = orc.step_batch(state["q"], state["u"], workload.SUBSTEPS, kp, kd, pt, dtg, nthreads=0, want_contacts=reset,
+                           lam_warm=warm)
         q, u = r["q"], r["u"]
         if reset:
             con, ncs = r["contacts"], r["n_contacts"]
             valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
             term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
             q[term], u[term] = gc0[term], gv0[term]
+            warm[term] = 0.0
         state["q"], state["u"] = q, u
         state["cs"] += 1
     try:

@@ -172,6 +172,10 @@ int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
  * settle_tol (default 1e-4 rad): a refinement that moved the direction by less than this marks it settled; settled
  * directions are kept like lagged ones for the rest of the solve (0 = never). */
 int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, double settle_tol);
+/* Warm start of the contact solver (not a RaiSim parameter; default on): every collision primitive in contact starts
+ * the next integrate() from the impulse and friction direction it ended the previous one with.  The state is per
+ * env, lives on the device, and is cleared for the envs touched by rsb_set_state / rsb_set_env_row / any reset. */
+int rsb_set_solver_warm_start(rsb_world* w, int on);
 int rsb_set_max_contacts(rsb_world* w, int kmax);   /* 1..RSB_MAX_CONTACTS */
 /* Kernel mapping knob: lanes of a wavefront that cooperate on one env (16, 32 or 64).
  * 64 = the north star's "one wavefront per env"; 0 = pick the measured-fastest default. */

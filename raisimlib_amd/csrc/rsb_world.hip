@@ -45,6 +45,8 @@ struct rsb_world {
   uint8_t* d_tmp_mask = nullptr;
   float *d_M = nullptr, *d_h = nullptr;
   int32_t* d_obs_idx = nullptr;
+  float* d_warm = nullptr;   // [N, 6*ncol] contact-solver warm state (impulse, friction direction per collision primitive)
+  bool warm_start = true;
   std::vector<int32_t> obs_idx_host;   // what d_obs_idx currently holds (re-uploaded only when the caller's list changes)
   float* d_dbg = nullptr;
   long long* d_prof = nullptr;
@@ -184,6 +186,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.g = take(3 * kcap * L.gstride);
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
+  L.warm = take(6 * b.ncol);
   L.per_env = o;
   return L;
 }
@@ -222,6 +225,13 @@ int default_lpe(const rsb_model_blob& b, int kmax) {
   return best;
 }
 
+// zero the solver's warm state of the envs whose state was overwritten (mask == NULL: all)
+__global__ void warm_clear_kernel(float* warm, const uint8_t* mask, int N, int n6) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * n6) return;
+  if (!mask || mask[i / n6]) warm[i] = 0.f;
+}
+
 __global__ void masked_row_copy(float* dst, const float* src, const uint8_t* mask, int N, int dim) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * dim) return;
@@ -254,7 +264,7 @@ __global__ void gather_obs_kernel(float* out, const float* gc, const float* gv, 
 
 __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact* contacts, int32_t* count,
                                         int32_t* flags, unsigned long long allowed, const float* gc0, const float* gv0,
-                                        int rows, uint8_t* done, int N, int nq, int nv, int kmax) {
+                                        int rows, uint8_t* done, int N, int nq, int nv, int kmax, float* warm, int n6) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   bool term = (flags[e] & 2) != 0;
@@ -267,6 +277,7 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
     const size_t r = rows == 1 ? 0 : (size_t)e;
     for (int i = 0; i < nq; ++i) gc[(size_t)e * nq + i] = gc0[r * nq + i];
     for (int i = 0; i < nv; ++i) gv[(size_t)e * nv + i] = gv0[r * nv + i];
+    for (int i = 0; i < n6; ++i) warm[(size_t)e * n6 + i] = 0.f;
     count[e] = 0;
     flags[e] = 0;
   }
@@ -296,7 +307,8 @@ __device__ inline void env_rot_t(const float* q, float* Rt) {  // world -> body 
 __global__ void env_post_kernel(float* gc, float* gv, const float* pt, const float* dtg, const float* kp, const float* kd,
                                 const rsb_contact* contacts, int32_t* count, int32_t* flags, unsigned long long allowed,
                                 const float* gc0, const float* gv0, float* reward, uint8_t* done, int N, int nq, int nv,
-                                int kmax, float fwd_coeff, float fwd_clip, float torque_coeff, float terminal_reward) {
+                                int kmax, float fwd_coeff, float fwd_clip, float torque_coeff, float terminal_reward,
+                                float* warm, int n6) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   float* q = gc + (size_t)e * nq;
@@ -321,6 +333,7 @@ __global__ void env_post_kernel(float* gc, float* gv, const float* pt, const flo
   if (term) {
     for (int i = 0; i < nq; ++i) q[i] = gc0[i];
     for (int i = 0; i < nv; ++i) u[i] = gv0[i];
+    for (int i = 0; i < n6; ++i) warm[(size_t)e * n6 + i] = 0.f;
     count[e] = 0;
     flags[e] = 0;
   }
@@ -345,11 +358,12 @@ __global__ void env_obs_kernel(float* ob, const float* gc, const float* gv, int 
 }
 
 __global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* flags, const float* gc0, const float* gv0,
-                                 int N, int nq, int nv) {
+                                 int N, int nq, int nv, float* warm, int n6) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   for (int i = 0; i < nq; ++i) gc[(size_t)e * nq + i] = gc0[i];
   for (int i = 0; i < nv; ++i) gv[(size_t)e * nv + i] = gv0[i];
+  for (int i = 0; i < n6; ++i) warm[(size_t)e * n6 + i] = 0.f;
   count[e] = 0; flags[e] = 0;
 }
 
@@ -397,6 +411,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.kp = w->d_kp; a.kd = w->d_kd;
   a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
   a.heights = w->d_heights;
+  a.warm = w->warm_start ? w->d_warm : nullptr;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
@@ -505,6 +520,8 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   HIP_TRY(hipMalloc(&w->d_flags, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_iters, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_obs_idx, RSB_MAX_COLLISIONS * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&w->d_warm, N * 6 * (size_t)(w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_warm, 0, N * 6 * (size_t)(w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float)));
   HIP_TRY(hipMemset(w->d_gc, 0, N * nq * sizeof(float)));
   HIP_TRY(hipMemset(w->d_gv, 0, N * nv * sizeof(float)));
   HIP_TRY(hipMemset(w->d_pt, 0, N * nq * sizeof(float)));
@@ -531,7 +548,7 @@ int rsb_destroy(rsb_world* w) {
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_done,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_done, w->d_warm,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -606,6 +623,13 @@ int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, doub
   w->freeze_after = freeze_after; w->refine = refine != 0; w->settle_tol = settle_tol;
   return RSB_OK;
 }
+int rsb_set_solver_warm_start(rsb_world* w, int on) {
+  if (!w) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  w->warm_start = on != 0;
+  HIP_TRY(hipMemsetAsync(w->d_warm, 0, (size_t)w->N * 6 * (w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float), w->stream));
+  return RSB_OK;
+}
 int rsb_set_max_contacts(rsb_world* w, int kmax) {
   if (!w || kmax < 1 || kmax > RSB_MAX_CONTACTS) { rsb::set_error("rsb_set_max_contacts: 1..RSB_MAX_CONTACTS"); return RSB_E_INVALID; }
   w->kmax = kmax;
@@ -640,7 +664,9 @@ int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t*
   HIP_TRY(hipSetDevice(w->device));
   const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
   w->integrate1_valid = false;
+  const int n6 = 6 * w->blob.ncol;
   if (!mask) {
+    if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, w->stream, w->d_warm, (const uint8_t*)nullptr, (int)N, n6);
     if (gc) { int st = copy_in(w, w->d_gc, gc, N * nq, space); if (st) return st; }
     if (gv) { int st = copy_in(w, w->d_gv, gv, N * nv, space); if (st) return st; }
     return RSB_OK;
@@ -660,6 +686,7 @@ int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t*
   }
   if (sgc) hipLaunchKernelGGL(masked_row_copy, dim3((N * nq + 255) / 256), dim3(256), 0, w->stream, w->d_gc, sgc, dmask, (int)N, (int)nq);
   if (sgv) hipLaunchKernelGGL(masked_row_copy, dim3((N * nv + 255) / 256), dim3(256), 0, w->stream, w->d_gv, sgv, dmask, (int)N, (int)nv);
+  if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, w->stream, w->d_warm, dmask, (int)N, n6);
   HIP_TRY(hipGetLastError());
   if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(w->stream));
   return RSB_OK;
@@ -692,6 +719,8 @@ int rsb_set_env_row(rsb_world* w, int field, int env, const float* data) {
   if (st != RSB_OK || !data) return st != RSB_OK ? st : RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipMemcpyAsync(base + (size_t)env * dim, data, dim * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  if ((field == RSB_F_GC || field == RSB_F_GV) && w->blob.ncol > 0)   // the env's state was overwritten: its solver state is stale
+    HIP_TRY(hipMemsetAsync(w->d_warm + (size_t)env * 6 * w->blob.ncol, 0, 6 * (size_t)w->blob.ncol * sizeof(float), w->stream));
   HIP_TRY(hipStreamSynchronize(w->stream));
   w->integrate1_valid = false;
   return RSB_OK;
@@ -859,7 +888,7 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
     dgc0 = w->d_tmp_gc; dgv0 = w->d_tmp_gv; ddone = done ? w->d_tmp_mask : nullptr;
   }
   hipLaunchKernelGGL(reset_terminated_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_contacts,
-                     w->d_count, w->d_flags, allowed, dgc0, dgv0, rows, ddone, (int)N, (int)nq, (int)nv, w->kmax);
+                     w->d_count, w->d_flags, allowed, dgc0, dgv0, rows, ddone, (int)N, (int)nq, (int)nv, w->kmax, w->d_warm, 6 * w->blob.ncol);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   if (space == RSB_HOST) {
@@ -947,7 +976,7 @@ static int env_check(rsb_world* w, const char* who) {
 int rsb_env_reset(rsb_world* w) {
   int st = env_check(w, "rsb_env_reset"); if (st != RSB_OK) return st;
   hipLaunchKernelGGL(env_reset_kernel, dim3((w->N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_count,
-                     w->d_flags, w->d_env_gc0, w->d_env_gv0, w->N, w->blob.nq, w->blob.nv);
+                     w->d_flags, w->d_env_gc0, w->d_env_gv0, w->N, w->blob.nq, w->blob.nv, w->d_warm, 6 * w->blob.ncol);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   return RSB_OK;
@@ -982,7 +1011,7 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   hipLaunchKernelGGL(env_post_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_pt, w->d_dt,
                      w->d_kp, w->d_kd, w->d_contacts, w->d_count, w->d_flags, w->env_allowed, w->d_env_gc0, w->d_env_gv0,
                      drew, ddone, N, nq, nv, w->kmax, w->env_cfg.forward_vel_coeff, w->env_cfg.forward_vel_clip,
-                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward);
+                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward, w->d_warm, 6 * w->blob.ncol);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   if (space == RSB_HOST) {

@@ -79,7 +79,7 @@ struct LdsLayout {
   // per-block tables (floats from the start of LDS)
   int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_cc, t_ccl, shared_total;
   // per-env arrays (floats from the env base)
-  int q, u, pt, dtg, tf, body, ups, bacc, fact, wb, con, wc, cv, g, ginv, lam;
+  int q, u, pt, dtg, tf, body, ups, bacc, fact, wb, con, wc, cv, g, ginv, lam, warm;
   int gstride;
   int per_env;
 };
@@ -98,6 +98,8 @@ struct StepArgs {
   int32_t* flags;
   int32_t* iters;
   const float* heights;
+  float* warm;                 // [N, 6*ncol] solver warm state per collision primitive: impulse (3, contact frame), friction
+                               // direction (2), direction valid; NULL = every solve starts cold
   // fused control-step epilogue / prologue (rsb_control_step); all optional
   float* ptarget_store;        // p_target rows read from `ptarget` are also stored here (the world's own copy)
   float* obs_out;              // [N, nq + nv + 3*obs_slots]: q, u, contact force of obs_idx[slot] (last sub-step)
@@ -446,6 +448,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   float* G = E + L.g;
   float* GINV = E + L.ginv;
   float* LAM = E + L.lam;
+  float* WARM = E + L.warm;                                      // [ncol][6] warm state of the contact solver (see StepArgs::warm)
+  const int nwarm = 6 * ncol;
   const int GS = L.gstride;
 
   if (a.poison_lds) {
@@ -499,6 +503,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     DTG[i] = a.dtarget[(size_t)env * nv + i];
     TF[i] = a.tauff[(size_t)env * nv + i];
   }
+  if (a.warm) for (int i = s; i < nwarm; i += LPE) WARM[i] = a.warm[(size_t)env * nwarm + i];
   int flag = 0, iters_used = 0, nc = 0;
   long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
   if (a.prof) t_start = clock64();
@@ -909,6 +914,33 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         int wcount = 0;
         // CV has been consumed: its first 6 floats now accumulate the base part of sum_c W_c lam_c
         if (s < 6) CV[s] = 0.f;
+        // warm start (oracle: lam_warm): the impulse and friction direction this collision primitive had at the end of
+        // the previous integrate(); the table is then cleared, contacts alive at the end of this solve re-enter it
+        int mycol = 0;
+        if (a.warm) {
+          if (isc) {
+            mycol = __float_as_int(CON[s * kConSlot + 11]);
+            const float* wr = WARM + 6 * mycol;
+            lam[0] = wr[0]; lam[1] = wr[1]; lam[2] = wr[2];
+            sdx = wr[3]; sdy = wr[4]; sdv = wr[5] != 0.f;
+          }
+          for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
+          if (__any(isc && (lam[0] != 0.f || lam[1] != 0.f || lam[2] != 0.f))) {
+            // v = c + G lam(0): one broadcast pass over the contacts (v carries the own impulse as well)
+            static_for<0, KMAX>([&](auto jc) {
+              constexpr int j = decltype(jc)::value;
+              if (j < ncw) {
+                float l0[3];
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) l0[rr] = row_bcast<j>(lam[rr]);
+                if (isc && j < nc) {
+                  float gj[3][4];
+                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
+                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) v[rr] += gj[rr][0] * l0[0] + gj[rr][1] * l0[1] + gj[rr][2] * l0[2];
+                }
+              }
+            });
+          }
+        }
         if (a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
@@ -1010,6 +1042,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
         if (isc) {
           LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2];
+          if (a.warm) {
+            float* wr = WARM + 6 * mycol;
+            wr[0] = lam[0]; wr[1] = lam[1]; wr[2] = lam[2];
+            wr[3] = sdv ? sdx : 0.f; wr[4] = sdv ? sdy : 0.f; wr[5] = sdv ? 1.f : 0.f;
+          }
           // W^T lam scattered by the contact lanes (LDS float atomics; lanes of one instruction are served in lane
           // order, so the sums are reproducible): base entries -> CV[0..5], joint entries -> WB of the support chain
           const float* W0 = WC + 3 * s * cw;
@@ -1036,6 +1073,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         const int n3 = 3 * nc;
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + n3 + i] = LAM[i];
       }
+    } else if (a.warm) {
+      for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;   // no contact anywhere in this wave: nothing survives
     }
     RSB_STAMP(6)
 
@@ -1154,6 +1193,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         ob[nq + nv + 3 * sl] = f0; ob[nq + nv + 3 * sl + 1] = f1; ob[nq + nv + 3 * sl + 2] = f2;
       }
     }
+    if (a.warm) for (int i = s; i < nwarm; i += LPE) a.warm[(size_t)env * nwarm + i] = term ? 0.f : WARM[i];
     const size_t r0 = (a.reset_rows == 1) ? 0 : (size_t)env;
     for (int i = s; i < nq; i += LPE) a.gc[(size_t)env * nq + i] = term ? a.gc0[r0 * nq + i] : Q[i];
     for (int i = s; i < nv; i += LPE) a.gv[(size_t)env * nv + i] = term ? a.gv0[r0 * nv + i] : U[i];

@@ -41,7 +41,8 @@ def run_one_step(model, gc, gv, pt, kp, kd, lpe=0, kmax=8, substeps=1, heightmap
     cnt, con = w.get_contacts()
     its, fl = w.get_solver_iterations(), w.get_flags()
     ref = o.step_batch(f32(gc), f32(gv), substeps, kp.astype(np.float64), kd.astype(np.float64), f32(pt), dtg,
-                       None if tau_ff is None else f32(tau_ff), want_contacts=True)
+                       None if tau_ff is None else f32(tau_ff), want_contacts=True,
+                       lam_warm=o.new_warm_state(N))      # the device warm-starts each sub-step from the previous one
     w.close()
     return dict(q=q1, u=u1, cnt=cnt, con=con, iters=its, flags=fl), ref, o
 
@@ -155,11 +156,13 @@ def test_trajectory_parity_config2(anymal):
     w.set_pd_gains(kp, kd); w.set_state(gc, gv)
     q, u = f32(gc), gv.copy()
     dtg = np.zeros((N, 18))
+    warm = o.new_warm_state(N)                  # the solver's warm state travels with the envs, as on the device
     for cs in range(40):
         pt = workload.anymal_targets(N, cs).astype(np.float32)
         w.set_pd_target(pt, dtg)
         w.integrate(workload.SUBSTEPS)
-        r = o.step_batch(q, u, workload.SUBSTEPS, kp.astype(np.float64), kd.astype(np.float64), pt.astype(np.float64), dtg)
+        r = o.step_batch(q, u, workload.SUBSTEPS, kp.astype(np.float64), kd.astype(np.float64), pt.astype(np.float64), dtg,
+                         lam_warm=warm)
         q, u = r["q"], r["u"]
     q1, u1 = w.get_state()
     assert abs(w.get_world_time() - 40 * 4 * workload.DT) < 1e-9
