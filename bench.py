@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--stall-window", type=int, default=-1, help="diagnostic: solver stagnation window (library default 6)")
     ap.add_argument("--freeze-after", type=int, default=-1, help="diagnostic: sweeps before friction directions lag (default 6)")
     ap.add_argument("--settle-tol", type=float, default=-1.0, help="diagnostic: settled-direction tolerance (default 1e-4 rad)")
+    ap.add_argument("--early-termination", action="store_true",
+                    help="NOT the headline workload: envs stop integrating at the sub-step of their first non-foot contact")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
     return ap.parse_args()
@@ -168,6 +170,8 @@ def main():
         world.set_contact_solver_param(1.0, 1.0, 1.0, args.max_iter, 1e-5)
     if args.lanes_per_env:
         world.set_lanes_per_env(args.lanes_per_env)
+    if args.early_termination:
+        world.set_early_termination(True)
     if args.stall_window >= 0:
         world.set_solver_stagnation_exit(args.stall_window, 0.5)
     if args.freeze_after >= 0 or args.settle_tol >= 0:
@@ -243,6 +247,7 @@ def main():
                             "dt=0.0025, 4 sub-steps per control step fused in one launch, PD kp=50 kd=0.2, targets = "
                             "nominal + U(-0.3,0.3) rad per control step, per-env seed 1234+i"
                             + (", non-foot contact -> reset (rsg_anymal rule)" if reset else ", no resets")
+                            + (", EARLY TERMINATION at the sub-step of the first non-foot contact (not upstream's rule)" if args.early_termination else "")
                             + ", obs (q,u,foot force) gathered each control step",
                 "envs_per_gpu": N, "substeps_per_step": workload.SUBSTEPS,
                 "contact_solver": {"max_iter": args.max_iter or 150, "threshold_rel": 1e-5, "alpha": [1.0, 1.0, 1.0]},

@@ -31,6 +31,7 @@ struct VecEnvConfig {
   std::vector<double> gc_init;            // size gcDim; default set by the constructor for ANYmal-like models
   std::vector<std::string> foot_collision_suffixes = {"_foot"};
   int device = 0;
+  bool early_termination = false;         // rsb_set_early_termination: not upstream's rule, see include/rsb.h
 };
 
 class VectorizedEnvironment {
@@ -42,6 +43,7 @@ class VectorizedEnvironment {
     obDim_ = 10 + 2 * nj_; actionDim_ = nj_;
     world_.setTimeStep(cfg_.simulation_dt);
     world_.addGround(0.0);
+    RSB_CHECK(rsb_set_early_termination(world_.handle(), cfg_.early_termination ? 1 : 0));
     substeps_ = (int)(cfg_.control_dt / cfg_.simulation_dt + 1e-10);
     std::vector<float> kp(nv_, 0.f), kd(nv_, 0.f);
     for (int i = 6; i < nv_; ++i) { kp[i] = (float)cfg_.p_gain; kd[i] = (float)cfg_.d_gain; }

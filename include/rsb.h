@@ -172,6 +172,14 @@ int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
  * settle_tol (default 1e-4 rad): a refinement that moved the direction by less than this marks it settled; settled
  * directions are kept like lagged ones for the rest of the solve (0 = never). */
 int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, double settle_tol);
+/* Early termination (not RaiSim behaviour; default OFF): in rsb_control_step / rsb_env_step - the calls that know which
+ * collision primitives may touch the terrain - an env stops integrating at the sub-step in which any other primitive
+ * touches; that sub-step and the rest of the control step are not integrated for it, the detected contacts are
+ * reported with zero impulses, flag bit 3 (8) is set and the env is terminated.  Upstream's rsg_anymal looks at the
+ * contacts of the LAST sub-step only, so a primitive that touches and lifts off again within one control step ends
+ * the episode here but not there.  What it buys: episodes in their last control step (a robot falling onto its knees)
+ * are the hardest contact problems of a launch and every launch waits for its slowest env. */
+int rsb_set_early_termination(rsb_world* w, int on);
 /* Warm start of the contact solver (not a RaiSim parameter; default on): every collision primitive in contact starts
  * the next integrate() from the impulse and friction direction it ended the previous one with.  The state is per
  * env, lives on the device, and is cleared for the envs touched by rsb_set_state / rsb_set_env_row / any reset. */

@@ -47,6 +47,7 @@ struct rsb_world {
   int32_t* d_obs_idx = nullptr;
   float* d_warm = nullptr;   // [N, 6*ncol] contact-solver warm state (impulse, friction direction per collision primitive)
   bool warm_start = true;
+  bool early_term = false;   // rsb_set_early_termination
   std::vector<int32_t> obs_idx_host;   // what d_obs_idx currently holds (re-uploaded only when the caller's list changes)
   float* d_dbg = nullptr;
   long long* d_prof = nullptr;
@@ -67,7 +68,7 @@ struct rsb_world {
   bool timing = false;
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
   struct Fuse { const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
-                int do_reset = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1; } fuse;
+                int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1; } fuse;
   // device-resident vectorised env (rsb_env_*)
   bool env_ready = false;
   rsb_env_config env_cfg{};
@@ -414,6 +415,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.warm = w->warm_start ? w->d_warm : nullptr;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
+  a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
   if (!a.do_reset) { a.gc0 = w->d_gc; a.gv0 = w->d_gv; a.reset_rows = w->N; }   // never dereferenced, but keep the pointers valid
   w->fuse = rsb_world::Fuse();
@@ -621,6 +623,11 @@ int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor) {
 int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, double settle_tol) {
   if (!w || freeze_after < 0 || !(settle_tol >= 0.0)) { rsb::set_error("rsb_set_solver_friction_lag: freeze_after >= 0, settle_tol >= 0"); return RSB_E_INVALID; }
   w->freeze_after = freeze_after; w->refine = refine != 0; w->settle_tol = settle_tol;
+  return RSB_OK;
+}
+int rsb_set_early_termination(rsb_world* w, int on) {
+  if (!w) return RSB_E_INVALID;
+  w->early_term = on != 0;
   return RSB_OK;
 }
 int rsb_set_solver_warm_start(rsb_world* w, int on) {
@@ -926,7 +933,7 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
       if (allowed_collisions[i] < 0 || allowed_collisions[i] >= w->blob.ncol) { rsb::set_error("rsb_control_step: collision index out of range"); return RSB_E_INVALID; }
       allowed |= 1ull << allowed_collisions[i];
     }
-    f.do_reset = 1; f.allowed = allowed; f.gc0 = gc0; f.gv0 = gv0; f.rows = rows;
+    f.do_reset = 1; f.have_allowed = 1; f.allowed = allowed; f.gc0 = gc0; f.gv0 = gv0; f.rows = rows;
   }
   w->fuse = f;
   return rsb_integrate(w, n_substeps);
@@ -1004,6 +1011,11 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   hipLaunchKernelGGL(env_action_kernel, dim3((N * nj + 255) / 256), dim3(256), 0, w->stream, w->d_pt, dact, w->d_env_mean,
                      w->env_cfg.action_std, N, nq, nj);
   HIP_TRY(hipGetLastError());
+  {
+    rsb_world::Fuse f;          // no fused epilogue, but the launch may know which primitives are allowed to touch
+    f.have_allowed = 1; f.allowed = w->env_allowed;
+    w->fuse = f;
+  }
   st = do_integrate(w, w->env_cfg.n_substeps);
   if (st != RSB_OK) return st;
   float* drew = space == RSB_DEVICE ? reward : (reward ? w->d_env_reward : nullptr);

@@ -105,6 +105,7 @@ struct StepArgs {
   float* obs_out;              // [N, nq + nv + 3*obs_slots]: q, u, contact force of obs_idx[slot] (last sub-step)
   const int32_t* obs_idx;      // [obs_slots] collision primitive of each force slot (NULL: slot k = primitive k)
   int obs_slots;
+  int early_term;              // an env stops integrating at the sub-step in which a contact outside `allowed` is detected
   int do_reset;                // envs with a non-finite state or a contact outside `allowed` restart from gc0 / gv0
   unsigned long long allowed;  // bit c set: collision primitive c may touch the terrain
   const float* gc0;            // [reset_rows, nq], reset_rows = 1 or N
@@ -505,6 +506,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   }
   if (a.warm) for (int i = s; i < nwarm; i += LPE) WARM[i] = a.warm[(size_t)env * nwarm + i];
   int flag = 0, iters_used = 0, nc = 0;
+  bool dead = false;   // early termination: this env no longer integrates (its contacts at that moment stay reported)
+  int nc_dead = 0;
   long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
   if (a.prof) t_start = clock64();
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
@@ -623,6 +626,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
 
     // =========================== collision detection (lane = collision sphere) ================
     nc = 0;
+    bool illegal = false;
     for (int c0 = 0; c0 < ncol; c0 += LPE) {
       const int ci = c0 + s;
       bool hit = false;
@@ -642,7 +646,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         terrain_eval(a, pbx + c[0], pby + c[1], h, n);
         const float dist = (pbz + c[2] - h) * n[2];
         dep = rad - dist;
-        hit = dep > 0.f;
+        hit = dep > 0.f && !dead;
+        illegal |= hit && !((a.allowed >> ci) & 1ull);
         cx[0] = c[0] - rad * n[0]; cx[1] = c[1] - rad * n[1]; cx[2] = c[2] - rad * n[2];
       }
       const unsigned long long bal = __ballot(hit);
@@ -665,6 +670,18 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       nc += __popcll(gm);
     }
     if (nc > a.kmax) { nc = a.kmax; flag |= 1; }
+    if (a.early_term) {
+      // early termination (opt-in, rsb_set_early_termination): the sub-step in which a primitive outside `allowed`
+      // touches the terrain is not integrated, nor are the following ones; the detected contacts stay reported
+      // with zero impulses and the env counts as terminated
+      const unsigned long long bil = __ballot(illegal);
+      const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
+      if (!dead && (bil & gsel)) {
+        dead = true; nc_dead = nc;
+        if (s < nc) { LAM[3 * s] = 0.f; LAM[3 * s + 1] = 0.f; LAM[3 * s + 2] = 0.f; }
+      }
+      if (dead) nc = 0;
+    }
     int ncw = nc;  // wave-wide maximum contact count (loop bounds must be wave-uniform)
     if (EPW > 1) {
       RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) ncw = max(ncw, __shfl_xor(ncw, off));
@@ -1097,7 +1114,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         x[i] = sacc * idg[i];
       }
       a0[0] = x[3]; a0[1] = x[4]; a0[2] = x[5]; a0[3] = x[0]; a0[4] = x[1]; a0[5] = x[2];
-      if (s == 0) {
+      if (s == 0 && !dead) {
         float qv[8], uv[8];
         ldv<2>(Q, qv); ldv<2>(U, uv);
         float un[6];
@@ -1140,8 +1157,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             const float xk = crsD[k] * wacc[k] - dot6(cUD[k], ap);
             RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] += cS[k][i] * xk;
             const float un = cqd[k] + xk;
-            U[b + 5] = un;
-            Q[b + 6] = cqb[k] + dt * un;
+            if (!dead) {
+              U[b + 5] = un;
+              Q[b + 6] = cqb[k] + dt * un;
+            }
             if (max_cc > 0) {
               if ((CCT[b] >> 16) > 0) {
                 float* Ab = BODY + b * kBodySlot + 18;
@@ -1165,6 +1184,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     for (int i = s; i < nq; i += LPE) bad |= !isfinite(Q[i]);
     for (int i = s; i < nv; i += LPE) bad |= !isfinite(U[i]);
     // contact lanes: anything but an allowed primitive touching the terrain terminates the episode (rsg_anymal rule)
+    if (dead) { nc = nc_dead; flag |= 8; }   // report the contacts that ended the episode
     int mycol = 0;
     if (s < nc) mycol = __float_as_int(CON[s * kConSlot + 11]);
     const bool illegal = a.do_reset && s < nc && !((a.allowed >> mycol) & 1ull);

@@ -19,7 +19,7 @@ from .world import BatchedWorld, Model, _hp
 class VecEnv:
     def __init__(self, model, num_envs, device=0, simulation_dt=0.0025, control_dt=0.01, action_std=0.3, p_gain=50.0,
                  d_gain=0.2, forward_vel_coeff=0.3, forward_vel_clip=4.0, torque_coeff=-4e-5, terminal_reward=-10.0,
-                 gc_init=None, foot_suffix="_foot", stream=None):
+                 gc_init=None, foot_suffix="_foot", stream=None, early_termination=False):
         self.model = model if isinstance(model, Model) else Model(urdf_path=model)
         self.world = BatchedWorld(self.model, num_envs, device=device)
         w, m = self.world, self.model
@@ -38,6 +38,8 @@ class VecEnv:
         self.num_acts = m.nv - 6
         self.num_obs = 10 + 2 * self.num_acts
         w.set_time_step(simulation_dt)
+        if early_termination:      # NOT upstream's rule (last sub-step only): see rsb_set_early_termination in include/rsb.h
+            w.set_early_termination(True)
         kp = np.zeros(m.nv, np.float32); kd = np.zeros(m.nv, np.float32)
         kp[6:] = p_gain; kd[6:] = d_gain
         w.set_pd_gains(kp, kd)

@@ -128,6 +128,9 @@ class BatchedWorld:
         check(self.L.rsb_set_solver_friction_lag(self.handle, int(freeze_after), int(bool(refine)), float(settle_tol)),
               "rsb_set_solver_friction_lag")
 
+    def set_early_termination(self, on=True):
+        check(self.L.rsb_set_early_termination(self.handle, 1 if on else 0), "rsb_set_early_termination")
+
     def set_solver_warm_start(self, on=True):
         check(self.L.rsb_set_solver_warm_start(self.handle, 1 if on else 0), "rsb_set_solver_warm_start")
 

@@ -317,3 +317,52 @@ def test_vecenv_running_observation_statistics(anymal):
     z = (raw[-1] - allraw.mean(0)) / np.sqrt(allraw.var(0) + 1e-8)
     assert np.allclose(ob.cpu().numpy(), np.clip(z, -10, 10), rtol=2e-2, atol=2e-2)
     env.close()
+
+
+def test_early_termination_freezes_the_env_at_its_first_illegal_contact(anymal):
+    """rsb_set_early_termination: envs without a non-foot contact are bit-identical to the default mode; an env whose
+    first non-foot contact is detected in sub-step k reports the state it had BEFORE sub-step k as its terminal
+    observation, is flagged (bit 3) and reset."""
+    import torch
+    N = 300
+    feet = anymal.collision_indices("_foot")
+    foot_mask = np.zeros(anymal.ncol, bool); foot_mask[feet] = True
+    gc, gv = standing_states(N, seed=31, z=(0.25, 0.6), vel=2.0)
+    gc[::5, 2] = 0.12                                   # belly-down starts: illegal contact in the first sub-steps
+    kp, kd = workload.anymal_gains()
+    init_q, init_u = workload.anymal_initial_state(N)
+    g0 = torch.from_numpy(init_q.astype(np.float32)).cuda(); v0 = torch.from_numpy(init_u.astype(np.float32)).cuda()
+    pt = torch.from_numpy(gc.astype(np.float32)).cuda()
+    od = 19 + 18 + 3 * len(feet)
+    out = {}
+    for early in (False, True):
+        w = BatchedWorld(anymal, N)
+        w.set_early_termination(early)
+        w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv)
+        obs = torch.zeros((N, od), dtype=torch.float32, device="cuda")
+        w.control_step_plan(4, obs.data_ptr(), feet, feet, g0.data_ptr(), v0.data_ptr(), N)(pt.data_ptr())
+        w.synchronize()
+        out[early] = (obs.cpu().numpy().copy(),) + w.get_state()
+        w.close()
+    # twin: sub-step by sub-step, to find each env's first illegal contact and the state before it
+    w = BatchedWorld(anymal, N)
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv)
+    first = np.full(N, -1); before = [None] * 4
+    for k in range(4):
+        before[k] = w.get_state()
+        w.integrate(1)
+        cnt, con = w.get_contacts()
+        valid = np.arange(con.shape[1])[None, :] < cnt[:, None]
+        ill = (valid & ~foot_mask[con["collision"]]).any(1)
+        first[(first < 0) & ill] = k
+    w.close()
+    clean = first < 0
+    assert clean.sum() > 50 and (~clean).sum() > 50 and len(set(first[~clean])) > 1
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a[clean], b[clean])                         # untouched envs: identical to the default mode
+    ob_e, q_e, u_e = out[True]
+    for e in np.where(~clean)[0]:
+        qb, ub = before[first[e]]
+        assert np.array_equal(ob_e[e, :19], qb[e]) and np.array_equal(ob_e[e, 19:37], ub[e])   # frozen before that sub-step
+        assert np.all(ob_e[e, 37:] == 0)                                  # its contacts carry no impulse
+        assert np.array_equal(q_e[e], init_q[e].astype(np.float32))       # and it was reset
