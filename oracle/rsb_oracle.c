@@ -281,13 +281,13 @@ void orc_default_params(orc_params* p) {
   p->threshold = 1e-5;
   p->max_iter = 150;
   p->section_rounds = 2;
-  p->freeze_after = 6;
+  p->freeze_after = 5;
   p->refine = 1;
   p->settle_tol = 1e-4;
   p->warm_start = 1;  /* only has an effect when the caller carries a warm state (orc_step_warm / orc_step_batch with lam_warm):
                          8% fewer sweeps and 7x fewer global searches on the config-2 workload.  The device has no counterpart yet
                          (every rsb_integrate() sub-step starts cold), so parity tests and the CPU baseline run without a state. */
-  p->stall_window = 6;
+  p->stall_window = 4;
   p->stall_factor = 0.5;
   p->kmax = 8;
   p->control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
