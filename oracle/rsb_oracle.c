@@ -464,20 +464,35 @@ void orc_terrain(const orc_params* p, double x, double y, double* h, double* n) 
 }
 
 /* --------------------------------------------------------------------------- actuation */
+/* PD controller, integrated implicitly ("stable PD", Tan, Liu, Turk 2011; RaiSim's controller is of this kind [RECALL]):
+ * the torque the joint feels over the step is  kp (q* - q+) + kd (u* - u+)  with  q+ = q + dt u+.  Written for
+ * the velocity update this is the explicit-looking torque
+ *      tau = kp (q* - q - dt u) + kd (u* - u)
+ * plus an extra joint-space inertia  B = dt (kd + dt kp)  on the diagonal of the mass matrix (returned in bdiag;
+ * the contact problem sees the same effective mass).  Unconditionally stable in kp, kd; an effort-clipped joint is a
+ * constant torque source (B = 0).  Joint damping stays explicit. */
+static void actuation_impl(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
+                           const double* kp, const double* kd, const double* p_target,
+                           const double* d_target, const double* tau_ff, double* tau, double* bdiag) {
+  for (int d = 0; d < 6; ++d) { tau[d] = tau_ff ? tau_ff[d] : 0.0; if (bdiag) bdiag[d] = 0.0; }
+  for (int i = 1; i < m->nb; ++i) {
+    int d = dof_of(i), qi = qidx_of(i);
+    double t = tau_ff ? tau_ff[d] : 0.0, B = 0.0;
+    if (p->control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && kp && kd) {
+      double pt = p_target ? p_target[qi] : 0.0, dt_ = d_target ? d_target[d] : 0.0;
+      t += kp[d] * (pt - q[qi] - p->dt * u[d]) + kd[d] * (dt_ - u[d]);
+      B = p->dt * (kd[d] + p->dt * kp[d]);
+    }
+    if (m->effort[i] > 0 && fabs(t) > m->effort[i]) { t = t > 0 ? m->effort[i] : -m->effort[i]; B = 0.0; }
+    tau[d] = t - m->damping[i] * u[d];
+    if (bdiag) bdiag[d] = B;
+  }
+}
+/* the torque part alone (tests) */
 void orc_actuation(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
                    const double* kp, const double* kd, const double* p_target,
                    const double* d_target, const double* tau_ff, double* tau) {
-  for (int d = 0; d < 6; ++d) tau[d] = tau_ff ? tau_ff[d] : 0.0;
-  for (int i = 1; i < m->nb; ++i) {
-    int d = dof_of(i), qi = qidx_of(i);
-    double t = tau_ff ? tau_ff[d] : 0.0;
-    if (p->control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && kp && kd) {
-      double pt = p_target ? p_target[qi] : 0.0, dt_ = d_target ? d_target[d] : 0.0;
-      t += kp[d] * (pt - q[qi]) + kd[d] * (dt_ - u[d]);
-    }
-    if (m->effort[i] > 0) { if (t > m->effort[i]) t = m->effort[i]; if (t < -m->effort[i]) t = -m->effort[i]; }
-    tau[d] = t - m->damping[i] * u[d];
-  }
+  actuation_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, tau, NULL);
 }
 
 /* ------------------------------------------------------------------- per-contact solver */
@@ -712,7 +727,11 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   kinematics(m, q, u, k);
   crba(m, k, M);
   rnea(m, k, u, NULL, p->gravity, h);
-  orc_actuation(m, p, q, u, kp, kd, p_target, d_target, tau_ff, tau);
+  {
+    double bdiag[MAXV];
+    actuation_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, tau, bdiag);
+    for (int d = 6; d < nv; ++d) M[d * nv + d] += bdiag[d];   /* implicit PD: see actuation_impl */
+  }
 
   int nc = 0;
   double cx[MAXK][3], cn[MAXK][3], cdepth[MAXK], Rc[MAXK][9];

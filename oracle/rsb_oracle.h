@@ -86,7 +86,8 @@ void orc_momentum(const rsb_model_blob* m, const double* q, const double* u, dou
 /* terrain height + unit normal under (x, y) (plane or triangulated height map) */
 void orc_terrain(const orc_params* p, double x, double y, double* h, double* n);
 
-/* tau from control mode: PD (joints only) + feed-forward, minus joint damping, clipped to effort */
+/* tau from control mode: implicit ("stable") PD on the joints, i.e. the position error is taken at q + dt u, +
+ * feed-forward, clipped to effort, minus joint damping; the step also adds dt (kd + dt kp) to the mass-matrix diagonal */
 void orc_actuation(const rsb_model_blob* m, const orc_params* p, const double* q, const double* u,
                    const double* kp, const double* kd, const double* p_target,
                    const double* d_target, const double* tau_ff, double* tau);

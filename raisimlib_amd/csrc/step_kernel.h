@@ -609,13 +609,16 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             stv<6>(BODY + b * kBodySlot, P);
             body_inertia(R, r, Vp, Ap, MF, dt, cI10[k], cZ[k]);
             RSB_UNROLL for (int i = 0; i < 6; ++i) cS[k][i] = S[i];
-            // actuation (oracle: orc_actuation)
+            // actuation (oracle: actuation_impl): implicit ("stable") PD = position error at q + dt u, plus the joint-space
+            // inertia dt (kd + dt kp) added to the armature; an effort-clipped joint is a constant torque source
             float tau = TF[b + 5];
-            tau += GAIN[2 * b] * (PT[b + 6] - qb) + GAIN[2 * b + 1] * (DTG[b + 5] - qd);
+            const float kpj = GAIN[2 * b], kdj = GAIN[2 * b + 1];
+            tau += kpj * (PT[b + 6] - qb - dt * qd) + kdj * (DTG[b + 5] - qd);
+            float Bpd = dt * (kdj + dt * kpj);
             const float eff = MF[28];
-            if (eff > 0.f) tau = fminf(fmaxf(tau, -eff), eff);
+            if (eff > 0.f && fabsf(tau) > eff) { tau = tau > 0.f ? eff : -eff; Bpd = 0.f; }
             tau -= MF[27] * qd;
-            cdtau[k] = dt * tau; carm[k] = MF[26]; cqb[k] = qb; cqd[k] = qd;
+            cdtau[k] = dt * tau; carm[k] = MF[26] + Bpd; cqb[k] = qb; cqd[k] = qd;
           }
         }
       }

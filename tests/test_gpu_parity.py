@@ -248,3 +248,39 @@ def test_mass_matrix_and_nonlinearities_query(anymal, atlas):
         w.integrate2()
         assert not np.array_equal(w.get_state()[0], q0)
         w.close()
+
+
+def test_multi_step_parity_with_warm_state_atlas_and_heightmap(anymal, atlas):
+    """Several control steps (the solver's warm state is exercised from the second sub-step on) for the deep-tree
+    model (LPE 64, kmax 16) and for the height-map terrain: the device tracks the oracle, which carries the same
+    warm state."""
+    H = workload.smoothed_heightmap(64, 64, amplitude=0.1, seed=7)
+    cases = []
+    gc, gv = standing_states(192, seed=41, z=(0.5, 0.7))
+    kp, kd = workload.anymal_gains()
+    cases.append(("anymal+heightmap", anymal, gc, gv, kp, kd, 8, (64, 64, 6.4, 6.4, 0.0, 0.0, H), 18))
+    rng = np.random.default_rng(4)
+    gca = np.zeros((128, 37)); gca[:, 2] = rng.uniform(0.88, 0.95, 128); gca[:, 3] = 1.0
+    gca[:, 7:] = rng.uniform(-0.1, 0.1, (128, 30))
+    kpa = np.zeros(36, np.float32); kda = np.zeros(36, np.float32); kpa[6:] = 200.0; kda[6:] = 5.0
+    cases.append(("atlas", atlas, gca, np.zeros((128, 36)), kpa, kda, 16, None, 36))
+    for name, model, g, v, kp_, kd_, kmax, hm, nv in cases:
+        N = g.shape[0]
+        w = BatchedWorld(model, N); w.set_max_contacts(kmax)
+        o = Oracle(model.blob); o.p.kmax = kmax
+        if hm is not None:
+            w.add_height_map(*hm); o.set_heightmap(*hm)
+        dtg = np.zeros((N, nv))
+        w.set_pd_gains(kp_, kd_); w.set_pd_target(g, dtg); w.set_state(g, v)
+        q, u, warm = f32(g), f32(v), o.new_warm_state(N)
+        for cs in range(6):
+            w.integrate(4)
+            r = o.step_batch(q, u, 4, kp_.astype(np.float64), kd_.astype(np.float64), f32(g), dtg, lam_warm=warm)
+            q, u = r["q"], r["u"]
+        q1, u1 = w.get_state()
+        cnt, _ = w.get_contacts()
+        w.close()
+        assert cnt.sum() > N, name                                   # the solver (and its warm state) was really in use
+        eq, eu = np.abs(q1 - q).max(axis=1), np.abs(u1 - u).max(axis=1) / (1 + np.abs(u).max(axis=1))
+        assert np.isfinite(q1).all() and np.median(eq) < 2e-5 and np.median(eu) < 5e-4, (name, np.median(eq), np.median(eu))
+        assert np.percentile(eq, 90) < 2e-3, (name, np.percentile(eq, 90))
