@@ -65,6 +65,9 @@ def parse():
     ap.add_argument("--settle-tol", type=float, default=-1.0, help="diagnostic: settled-direction tolerance (default 1e-4 rad)")
     ap.add_argument("--early-termination", action="store_true",
                     help="NOT the headline workload: envs stop integrating at the sub-step of their first non-foot contact")
+    ap.add_argument("--overlap-collective", action="store_true",
+                    help="double-buffer the obs block and overlap the all-gather of step k with the kernel of step k+1 "
+                         "(default: in line on the launch stream; the overlap could not be tried on >1 GPU here)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
     return ap.parse_args()
@@ -190,31 +193,50 @@ def main():
     bank = [torch.from_numpy(workload.anymal_targets(N, k, env_offset=rank * N).astype(np.float32)).to(dev)
             for k in range(TARGET_BANK)]
     obs_dim = world.obs_dim(len(feet))
-    obs = torch.empty((N, obs_dim), dtype=torch.float32, device=dev)
-    all_obs = torch.empty((world_size * N, obs_dim), dtype=torch.float32, device=dev) if coll else obs
+    # obs block of this rank and the gathered block of all ranks; with --overlap-collective double-buffered, so that the
+    # all-gather of control step k (RCCL, its own stream) overlaps the kernel of step k+1
+    nbuf = 2 if (coll and args.overlap_collective) else 1
+    obs_b = [torch.empty((N, obs_dim), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+    all_obs_b = [torch.empty((world_size * N, obs_dim), dtype=torch.float32, device=dev) for _ in range(nbuf)] if coll else obs_b
     feet_idx = np.asarray(feet, np.int32)
     reset = not args.no_reset
 
     # one foreign call per control step (rsb_control_step); the step kernel's launches are bracketed by HIP events
     # inside the library (ring of event pairs on the launch stream, read back after the timed region)
     world.enable_timing(args.steps if args.steps > 1 else 2)
-    step_fn = world.control_step_plan(workload.SUBSTEPS, obs.data_ptr(), feet_idx, feet_idx if reset else None,
-                                      gc0_d.data_ptr() if reset else 0, gv0_d.data_ptr() if reset else 0, N)
+    step_fns = [world.control_step_plan(workload.SUBSTEPS, o.data_ptr(), feet_idx, feet_idx if reset else None,
+                                        gc0_d.data_ptr() if reset else 0, gv0_d.data_ptr() if reset else 0, N) for o in obs_b]
     bank_ptr = [b.data_ptr() for b in bank]
+    pending = [None] * nbuf
 
     def control_step(k):
-        step_fn(bank_ptr[k % TARGET_BANK])
+        b = k % nbuf
+        if pending[b] is not None:          # the gather that still reads this buffer (stream-side wait, the host runs on)
+            pending[b].wait()
+            pending[b] = None
+        step_fns[b](bank_ptr[k % TARGET_BANK])
         if coll:
-            dist.all_gather_into_tensor(all_obs, obs)
+            if nbuf == 2:
+                pending[b] = dist.all_gather_into_tensor(all_obs_b[b], obs_b[b], async_op=True)
+            else:
+                dist.all_gather_into_tensor(all_obs_b[b], obs_b[b])
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for k in range(args.warmup):
         control_step(k)
+    drain()
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         control_step(args.warmup + k)
+    drain()
     t_enqueued = time.perf_counter() - t0       # host side done; the GPU may still be working
     if world_size > 1:
         dist.barrier()
@@ -252,6 +274,7 @@ def main():
                 "envs_per_gpu": N, "substeps_per_step": workload.SUBSTEPS,
                 "contact_solver": {"max_iter": args.max_iter or 150, "threshold_rel": 1e-5, "alpha": [1.0, 1.0, 1.0]},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
+                "obs_all_gather": ("overlapped with the next control step (double-buffered)" if nbuf == 2 else "in line") if coll else "none (1 rank)",
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
