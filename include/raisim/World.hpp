@@ -108,6 +108,15 @@ class BatchedWorld {
 };
 
 class Ground {};
+/// raisim::TerrainProperties [RECALL raisim/object/terrain/HeightMap.hpp]: parameters of a Perlin-noise terrain
+struct TerrainProperties {
+  double frequency = 0.1, zScale = 1.0, xSize = 10.0, ySize = 10.0;
+  size_t xSamples = 100, ySamples = 100, fractalOctaves = 5;
+  double fractalLacunarity = 2.0, fractalGain = 0.5, stepSize = 0.0;
+  std::uint32_t seed = 6479;
+  double heightOffset = 0.0;
+};
+
 class HeightMap {
  public:
   HeightMap(BatchedWorld* w, int xs, int ys, double xSize, double ySize, double cx, double cy, std::vector<double> h)
@@ -248,6 +257,32 @@ class World {
     shared_->addHeightMap(xSamples, ySamples, xSize, ySize, centerX, centerY, height);
     hm_ = std::make_unique<HeightMap>(shared_, xSamples, ySamples, xSize, ySize, centerX, centerY, height);
     return hm_.get();
+  }
+  /// Perlin-noise terrain (rsb_heightmap_perlin)
+  HeightMap* addHeightMap(double centerX, double centerY, TerrainProperties& tp, const std::string& material = "default") {
+    rsb_terrain_properties c{tp.frequency, tp.zScale, tp.xSize, tp.ySize, (int32_t)tp.xSamples, (int32_t)tp.ySamples,
+                             (int32_t)tp.fractalOctaves, tp.seed, tp.fractalLacunarity, tp.fractalGain, tp.stepSize, tp.heightOffset};
+    std::vector<float> h(tp.xSamples * tp.ySamples);
+    RSB_CHECK(rsb_heightmap_perlin(&c, h.data()));
+    return addHeightMap((int)tp.xSamples, (int)tp.ySamples, tp.xSize, tp.ySize, centerX, centerY, std::vector<double>(h.begin(), h.end()), material);
+  }
+  /// PNG terrain: height = pixel / max_pixel * heightScale + heightOffset (rsb_heightmap_png_*)
+  HeightMap* addHeightMap(const std::string& pngFileName, double centerX, double centerY, double xSize, double ySize,
+                          double heightScale, double heightOffset, const std::string& material = "default") {
+    int xs = 0, ys = 0;
+    RSB_CHECK(rsb_heightmap_png_size(pngFileName.c_str(), &xs, &ys));
+    std::vector<float> h((size_t)xs * ys);
+    RSB_CHECK(rsb_heightmap_png_read(pngFileName.c_str(), heightScale, heightOffset, h.data(), xs * ys));
+    return addHeightMap(xs, ys, xSize, ySize, centerX, centerY, std::vector<double>(h.begin(), h.end()), material);
+  }
+  /// text terrain file: "xSamples ySamples xSize ySize" + heights (rsb_heightmap_text_*)
+  HeightMap* addHeightMap(const std::string& raisimHeightMapFileName, double centerX, double centerY,
+                          const std::string& material = "default") {
+    int xs = 0, ys = 0; double sx = 0, sy = 0;
+    RSB_CHECK(rsb_heightmap_text_size(raisimHeightMapFileName.c_str(), &xs, &ys, &sx, &sy));
+    std::vector<float> h((size_t)xs * ys);
+    RSB_CHECK(rsb_heightmap_text_read(raisimHeightMapFileName.c_str(), h.data(), xs * ys));
+    return addHeightMap(xs, ys, sx, sy, centerX, centerY, std::vector<double>(h.begin(), h.end()), material);
   }
   void setTimeStep(double dt) { dt_ = dt; if (shared_) shared_->setTimeStep(dt); }
   double getTimeStep() const { return shared_ ? shared_->getTimeStep() : dt_; }

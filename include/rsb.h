@@ -195,6 +195,27 @@ int rsb_set_ground(rsb_world* w, double height);
 int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size, double y_size,
                       double center_x, double center_y, const float* heights);
 
+/* ---- height-map sources (host side, no GPU needed): fill a [y_samples][x_samples] float buffer for rsb_set_heightmap.
+ * Upstream counterparts [RECALL, absent]: World::addHeightMap(pngFile, centerX, centerY, xSize, ySize, heightScale,
+ * heightOffset), World::addHeightMap(centerX, centerY, TerrainProperties&), World::addHeightMap(textFile, ...).
+ * PNG: non-interlaced 8/16-bit grey / grey+alpha / RGB / RGBA (first channel); height = pixel / max_pixel *
+ * height_scale + height_offset; image row r, column c -> sample (y = r, x = c).
+ * Perlin: fractal sum of improved Perlin noise (this repo's own permutation from `seed`: terrains are reproducible
+ * here, not bit-identical to RaiSim's), h = z_scale * sum_o gain^o * noise(f lacunarity^o * (x, y)), optionally
+ * rounded to multiples of step_size, + height_offset.
+ * Text: "xSamples ySamples xSize ySize" followed by xSamples*ySamples heights (x fastest). */
+typedef struct rsb_terrain_properties {   /* field meaning of raisim::TerrainProperties [RECALL] */
+  double frequency, z_scale, x_size, y_size;
+  int32_t x_samples, y_samples, fractal_octaves;
+  uint32_t seed;
+  double fractal_lacunarity, fractal_gain, step_size, height_offset;
+} rsb_terrain_properties;
+int rsb_heightmap_png_size(const char* path, int* x_samples, int* y_samples);
+int rsb_heightmap_png_read(const char* path, double height_scale, double height_offset, float* heights, int n);
+int rsb_heightmap_perlin(const rsb_terrain_properties* tp, float* heights);
+int rsb_heightmap_text_size(const char* path, int* x_samples, int* y_samples, double* x_size, double* y_size);
+int rsb_heightmap_text_read(const char* path, float* heights, int n);
+
 /* mask: optional uint8 [num_envs] (same memspace); envs with mask==0 are left untouched */
 int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t* mask, int space);
 int rsb_get_state(rsb_world* w, float* gc, float* gv, int space);

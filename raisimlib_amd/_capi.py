@@ -40,6 +40,14 @@ class Contact(C.Structure):
                 ("depth", C.c_float), ("body", C.c_int32), ("collision", C.c_int32)]
 
 
+class TerrainProperties(C.Structure):
+    """rsb_terrain_properties (raisim::TerrainProperties field meaning)"""
+    _fields_ = [("frequency", C.c_double), ("z_scale", C.c_double), ("x_size", C.c_double), ("y_size", C.c_double),
+                ("x_samples", C.c_int32), ("y_samples", C.c_int32), ("fractal_octaves", C.c_int32), ("seed", C.c_uint32),
+                ("fractal_lacunarity", C.c_double), ("fractal_gain", C.c_double), ("step_size", C.c_double),
+                ("height_offset", C.c_double)]
+
+
 class EnvConfig(C.Structure):
     """rsb_env_config"""
     _fields_ = [("n_substeps", C.c_int32), ("action_std", C.c_float), ("forward_vel_coeff", C.c_float),
@@ -86,6 +94,11 @@ PROTOTYPES = {
     "rsb_get_lanes_per_env": (_I, [_VP]),
     "rsb_set_ground": (_I, [_VP, _D]),
     "rsb_set_heightmap": (_I, [_VP, _I, _I, _D, _D, _D, _D, _FP]),
+    "rsb_heightmap_png_size": (_I, [_CP, C.POINTER(_I), C.POINTER(_I)]),
+    "rsb_heightmap_png_read": (_I, [_CP, _D, _D, _FP, _I]),
+    "rsb_heightmap_perlin": (_I, [C.POINTER(TerrainProperties), _FP]),
+    "rsb_heightmap_text_size": (_I, [_CP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_D), C.POINTER(_D)]),
+    "rsb_heightmap_text_read": (_I, [_CP, _FP, _I]),
     "rsb_set_state": (_I, [_VP, _FP, _FP, _FP, _I]),
     "rsb_get_state": (_I, [_VP, _FP, _FP, _I]),
     "rsb_set_env_row": (_I, [_VP, _I, _I, _FP]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "librsb.so")
-SOURCES = ["urdf_model.cpp", "rsb_world.hip"]
+SOURCES = ["urdf_model.cpp", "terrain_io.cpp", "rsb_world.hip"]
 HEADERS = ["rsb_internal.h", "step_kernel.h", "query_kernel.h", os.path.join(ROOT, "include", "rsb.h")]
 
 
@@ -37,7 +37,7 @@ def build(force=False, verbose=True, extra_flags=()):
            # than it saves and pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed
            # at the stated parity tolerance (2.5 ulp hardware approximations + Newton step instead)
            "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           *extra_flags, "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+           *extra_flags, "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz"]   # zlib: PNG height maps
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -72,6 +72,38 @@ class Model:
         return [i for i, n in enumerate(self.collision_names()) if n.endswith(suffix)]
 
 
+def heightmap_from_png(path, height_scale=1.0, height_offset=0.0):
+    """[y_samples, x_samples] float32 heights of a PNG (rsb_heightmap_png_*)."""
+    L = lib()
+    xs, ys = C.c_int(), C.c_int()
+    check(L.rsb_heightmap_png_size(os.fspath(path).encode(), C.byref(xs), C.byref(ys)), "rsb_heightmap_png_size")
+    h = np.zeros((ys.value, xs.value), np.float32)
+    check(L.rsb_heightmap_png_read(os.fspath(path).encode(), float(height_scale), float(height_offset), _hp(h), h.size),
+          "rsb_heightmap_png_read")
+    return h
+
+
+def heightmap_perlin(x_samples=100, y_samples=100, x_size=10.0, y_size=10.0, frequency=0.1, z_scale=1.0, fractal_octaves=5,
+                     fractal_lacunarity=2.0, fractal_gain=0.5, step_size=0.0, seed=6479, height_offset=0.0):
+    """[y_samples, x_samples] float32 Perlin terrain (rsb_heightmap_perlin; defaults = raisim::TerrainProperties [RECALL])."""
+    tp = _capi.TerrainProperties(frequency, z_scale, x_size, y_size, x_samples, y_samples, fractal_octaves, seed,
+                                 fractal_lacunarity, fractal_gain, step_size, height_offset)
+    h = np.zeros((y_samples, x_samples), np.float32)
+    check(lib().rsb_heightmap_perlin(C.byref(tp), _hp(h)), "rsb_heightmap_perlin")
+    return h
+
+
+def heightmap_from_text(path):
+    """(heights [y_samples, x_samples] float32, x_size, y_size) of the text format (rsb_heightmap_text_*)."""
+    L = lib()
+    xs, ys, sx, sy = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+    check(L.rsb_heightmap_text_size(os.fspath(path).encode(), C.byref(xs), C.byref(ys), C.byref(sx), C.byref(sy)),
+          "rsb_heightmap_text_size")
+    h = np.zeros((ys.value, xs.value), np.float32)
+    check(L.rsb_heightmap_text_read(os.fspath(path).encode(), _hp(h), h.size), "rsb_heightmap_text_read")
+    return h, sx.value, sy.value
+
+
 def _host(a, dtype):
     return None if a is None else np.ascontiguousarray(a, dtype=dtype)
 

@@ -77,6 +77,29 @@ int main(int argc, char** argv) {
       CHECK(std::isfinite(rew[e]));
     }
     std::printf("VectorizedEnvironment: 50 control steps x 512 envs, %d resets, mean height %.3f\n", resets, ob[0]);
+
+    // ---- a Perlin-noise terrain through the TerrainProperties overload: the robot lands ON it
+    raisim::World hills;
+    hills.setTimeStep(0.0025);
+    auto* robot = hills.addArticulatedSystem(urdf);
+    raisim::TerrainProperties tp;
+    tp.frequency = 0.3; tp.zScale = 0.6; tp.xSize = 8.0; tp.ySize = 8.0; tp.xSamples = 81; tp.ySamples = 81; tp.seed = 11;
+    auto* hm = hills.addHeightMap(0.0, 0.0, tp);
+    CHECK(hm->getHeightVector().size() == 81u * 81u);
+    const double ground = hm->getHeight(0.0, 0.0);
+    raisim::VecDyn gch(gcDim), gvh(gvDim);
+    gch[2] = ground + 0.62; gch[3] = 1.0;
+    for (int j = 0; j < 12; ++j) gch[7 + j] = nominal[j];
+    robot->setState(gch, gvh);
+    robot->setPdGains(kp, kd);
+    pT = gch.v;
+    robot->setPdTarget(pT, dT);
+    for (int i = 0; i < 600; ++i) hills.integrate();
+    const auto& qh = robot->getGeneralizedCoordinate();
+    const double under = hm->getHeight(qh[0], qh[1]);
+    CHECK(robot->getContacts().size() >= 2);
+    CHECK(qh[2] - under > 0.25 && qh[2] - under < 0.75);
+    std::printf("Perlin terrain: ground %.3f under the robot, base %.3f above it, %zu contacts\n", under, qh[2] - under, robot->getContacts().size());
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 1;
