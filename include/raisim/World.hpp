@@ -206,6 +206,35 @@ class ArticulatedSystem {
     for (int k = 0; k < cnt[env_]; ++k) contacts_.emplace_back(con[(size_t)env_ * kmax + k]);
     return contacts_;
   }
+  // ---- frame queries (slow path, correctness only: forward kinematics of this env on the host from the model blob).
+  // A "frame" is a body's joint frame, indexed like the bodies (getFrameIdxByName: joint name -> its child body).
+  size_t getFrameIdxByName(const std::string& jointName) const {
+    int i = rsb_model_joint_index(w_->model(), jointName.c_str());
+    RSFATAL_IF(i < 0, "getFrameIdxByName: no such joint: " + jointName);
+    return (size_t)i;
+  }
+  void getFramePosition(size_t frame, Vec<3>& p) { fk(); for (int c = 0; c < 3; ++c) p[c] = fkP_[3 * frame + c]; }
+  void getFrameOrientation(size_t frame, Mat<3, 3>& R) { fk(); for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R(r, c) = fkR_[9 * frame + 3 * r + c]; }
+  void getBodyPosition(size_t body, Vec<3>& p) { getFramePosition(body, p); }
+  void getBodyOrientation(size_t body, Mat<3, 3>& R) { getFrameOrientation(body, R); }
+  /// positional Jacobian (3 x DOF, world frame) of the frame origin: v_point = J * gv
+  void getDenseFrameJacobian(size_t frame, MatDyn& J) { jac(frame, J, false); }
+  /// rotational Jacobian (3 x DOF): w_body = J * gv
+  void getDenseFrameRotationalJacobian(size_t frame, MatDyn& J) { jac(frame, J, true); }
+  void getFrameVelocity(size_t frame, Vec<3>& v) { MatDyn J; jac(frame, J, false); mulJ(J, v); }
+  void getFrameAngularVelocity(size_t frame, Vec<3>& w) { MatDyn J; jac(frame, J, true); mulJ(J, w); }
+  /// External force (world frame) at the origin of `body`'s frame, applied as the generalized force J^T f through
+  /// the feed-forward channel.  Unlike upstream it is NOT cleared after the next integrate(): call
+  /// clearExternalForces() (or setGeneralizedForce) to remove it.
+  void setExternalForce(size_t body, const Vec<3>& force) {
+    MatDyn J; jac(body, J, false);
+    VecDyn tau((size_t)w_->dof());
+    getRow(RSB_F_TAU_FF, tau, w_->dof());
+    for (int d = 0; d < w_->dof(); ++d) tau[d] += J(0, d) * force[0] + J(1, d) * force[1] + J(2, d) * force[2];
+    putRow(RSB_F_TAU_FF, tau);
+  }
+  void clearExternalForces() { VecDyn tau((size_t)w_->dof()); putRow(RSB_F_TAU_FF, tau); }
+
   void getBaseOrientation(Mat<3, 3>& rot) {
     const VecDyn& q = getGeneralizedCoordinate();
     const double w = q[3], x = q[4], y = q[5], z = q[6];
@@ -225,10 +254,79 @@ class ArticulatedSystem {
     v.resize(dim);
     for (int i = 0; i < dim; ++i) v[i] = f[i];
   }
+  // host forward kinematics of this env (world frame): fkR_ [nb][9] row-major, fkP_ [nb][3], fkA_ [nb][3] joint axes
+  void fk() {
+    const rsb_model_blob& b = w_->blob();
+    const VecDyn& q = getGeneralizedCoordinate();
+    fkR_.assign(9 * b.nb, 0.0); fkP_.assign(3 * b.nb, 0.0); fkA_.assign(3 * b.nb, 0.0);
+    Mat<3, 3> R0; getBaseOrientation(R0);
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) fkR_[3 * r + c] = R0(r, c);
+    for (int c = 0; c < 3; ++c) fkP_[c] = q[c];
+    for (int i = 1; i < b.nb; ++i) {
+      const int p = b.parent[i];
+      const double* Rp = &fkR_[9 * p];
+      double Rt[9], Rj[9];                                   // Rt = Rp * rtree, then the joint rotation about `axis`
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+        double sacc = 0; for (int k = 0; k < 3; ++k) sacc += Rp[3 * r + k] * b.rtree[i][3 * k + c];
+        Rt[3 * r + c] = sacc;
+      }
+      const double* ax = b.axis[i];
+      const double qi = q[6 + i];
+      for (int c = 0; c < 3; ++c) {
+        double t = 0; for (int k = 0; k < 3; ++k) t += Rp[3 * c + k] * b.ptree[i][k];
+        fkP_[3 * i + c] = fkP_[3 * p + c] + t;
+      }
+      for (int r = 0; r < 3; ++r) fkA_[3 * i + r] = Rt[3 * r] * ax[0] + Rt[3 * r + 1] * ax[1] + Rt[3 * r + 2] * ax[2];
+      if (b.jtype[i] == RSB_JOINT_REVOLUTE) {
+        const double cs = std::cos(qi), sn = std::sin(qi), v = 1 - cs, x = ax[0], y = ax[1], z = ax[2];
+        const double Rq[9] = {cs + x * x * v, x * y * v - z * sn, x * z * v + y * sn, y * x * v + z * sn, cs + y * y * v,
+                              y * z * v - x * sn, z * x * v - y * sn, z * y * v + x * sn, cs + z * z * v};
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+          double sacc = 0; for (int k = 0; k < 3; ++k) sacc += Rt[3 * r + k] * Rq[3 * k + c];
+          Rj[3 * r + c] = sacc;
+        }
+      } else {
+        for (int k = 0; k < 9; ++k) Rj[k] = Rt[k];
+        for (int c = 0; c < 3; ++c) fkP_[3 * i + c] += fkA_[3 * i + c] * qi;
+      }
+      for (int k = 0; k < 9; ++k) fkR_[9 * i + k] = Rj[k];
+    }
+  }
+  void jac(size_t frame, MatDyn& J, bool rotational) {
+    fk();
+    const rsb_model_blob& b = w_->blob();
+    const int nv = w_->dof();
+    J.resize(3, nv);
+    const double* pf = &fkP_[3 * frame];
+    if (rotational) { for (int c = 0; c < 3; ++c) J(c, 3 + c) = 1.0; }
+    else {
+      const double r[3] = {pf[0] - fkP_[0], pf[1] - fkP_[1], pf[2] - fkP_[2]};
+      for (int c = 0; c < 3; ++c) J(c, c) = 1.0;
+      J(0, 4) = r[2]; J(0, 5) = -r[1]; J(1, 3) = -r[2]; J(1, 5) = r[0]; J(2, 3) = r[1]; J(2, 4) = -r[0];   // -[r]x
+    }
+    for (int j = (int)frame; j >= 1; j = b.parent[j]) {
+      const double* a = &fkA_[3 * j];
+      const int d = 5 + j;
+      if (b.jtype[j] == RSB_JOINT_REVOLUTE) {
+        if (rotational) { for (int c = 0; c < 3; ++c) J(c, d) = a[c]; }
+        else {
+          const double r[3] = {pf[0] - fkP_[3 * j], pf[1] - fkP_[3 * j + 1], pf[2] - fkP_[3 * j + 2]};
+          J(0, d) = a[1] * r[2] - a[2] * r[1]; J(1, d) = a[2] * r[0] - a[0] * r[2]; J(2, d) = a[0] * r[1] - a[1] * r[0];
+        }
+      } else if (!rotational) {
+        for (int c = 0; c < 3; ++c) J(c, d) = a[c];
+      }
+    }
+  }
+  void mulJ(const MatDyn& J, Vec<3>& out) {
+    const VecDyn& u = getGeneralizedVelocity();
+    for (int c = 0; c < 3; ++c) { double sacc = 0; for (size_t d = 0; d < J.cols(); ++d) sacc += J(c, d) * u[d]; out[c] = sacc; }
+  }
   BatchedWorld* w_;
   int env_;
   std::string name_;
   VecDyn gc_, gv_, h_;
+  std::vector<double> fkR_, fkP_, fkA_;
   MatDyn M_;
   std::vector<Contact> contacts_;
 };

@@ -50,6 +50,43 @@ int main(int argc, char** argv) {
     raisim::Mat<3, 3> rot;
     anymal->getBaseOrientation(rot);
     CHECK(rot(2, 2) > 0.99);
+    // ---- frame queries (host FK): J * gv = frame velocity; finite-difference of the frame position over one step
+    {
+      const size_t foot = anymal->getFrameIdxByName("LF_KFE");
+      CHECK(foot == anymal->getBodyIdx("LF_SHANK") || foot > 0);
+      raisim::VecDyn g2(gcDim), v2(gvDim);
+      g2 = gc.v; g2[2] = 2.0; g2[3] = 0.9; g2[4] = 0.1; g2[5] = -0.2; g2[6] = 0.3;
+      { double nrm = std::sqrt(g2[3] * g2[3] + g2[4] * g2[4] + g2[5] * g2[5] + g2[6] * g2[6]); for (int k = 3; k < 7; ++k) g2[k] /= nrm; }
+      for (int d = 0; d < gvDim; ++d) v2[d] = 0.3 * std::sin(1.0 + d);
+      anymal->setState(g2, v2);
+      raisim::Vec<3> p0, p1, vel, w;
+      anymal->getFramePosition(foot, p0);
+      world.integrate();
+      anymal->getFramePosition(foot, p1);
+      anymal->getFrameVelocity(foot, vel);          // J(q+) * u+
+      anymal->getFrameAngularVelocity(foot, w);
+      for (int c = 0; c < 3; ++c) CHECK(std::fabs((p1[c] - p0[c]) / world.getTimeStep() - vel[c]) < 2e-2);
+      raisim::MatDyn J;
+      anymal->getDenseFrameJacobian(foot, J);
+      CHECK(J.rows() == 3 && (int)J.cols() == gvDim && std::fabs(J(0, 0) - 1.0) < 1e-12 && std::fabs(J(2, 17)) < 1e-12);   // RH joints do not move the LF foot
+      raisim::Mat<3, 3> Rf;
+      anymal->getFrameOrientation(foot, Rf);
+      double det = Rf(0, 0) * (Rf(1, 1) * Rf(2, 2) - Rf(1, 2) * Rf(2, 1)) - Rf(0, 1) * (Rf(1, 0) * Rf(2, 2) - Rf(1, 2) * Rf(2, 0)) +
+                   Rf(0, 2) * (Rf(1, 0) * Rf(2, 1) - Rf(1, 1) * Rf(2, 0));
+      CHECK(std::fabs(det - 1.0) < 1e-6);
+      // an upward external force m*g at the base origin cancels gravity for the base (PD holds the legs): hover
+      raisim::VecDyn gz(gcDim), vz(gvDim);
+      gz = gc.v; gz[2] = 3.0;
+      anymal->setState(gz, vz);
+      raisim::Vec<3> f; f[2] = anymal->getTotalMass() * 9.81;
+      anymal->setExternalForce(0, f);
+      for (int i = 0; i < 40; ++i) world.integrate();
+      CHECK(std::fabs(anymal->getGeneralizedVelocity()[2]) < 0.05);     // free fall would be at -0.98 m/s by now
+      anymal->clearExternalForces();
+      anymal->setState(gc, gv);
+      for (int i = 0; i < 400; ++i) world.integrate();
+      anymal->getGeneralizedCoordinate();   // refresh the cached row that `q` refers to
+    }
     std::printf("single-env World: z=%.3f fz/mg=%.3f contacts=%zu\n", q[2], fz / (anymal->getTotalMass() * 9.81), contacts.size());
 
     // ---- the batched vectorised environment (one fused launch per step for all envs)
