@@ -40,13 +40,13 @@ def recorded_traffic(n_envs, substeps):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files or n_envs != ENVS_PER_GPU or substeps != 4:
-        return None, None
+        return None, None, None
     try:
         rec = json.load(open(files[-1]))
         return float(rec["hbm_bytes_per_launch_raw"]), os.path.relpath(files[-1], ROOT) + \
-            " (FETCH_SIZE+WRITE_SIZE per launch, raw: gfx950 factors for 4 B/lane row accesses are uncalibrated)"
+            " (FETCH_SIZE+WRITE_SIZE per launch, raw: gfx950 factors for 4 B/lane row accesses are uncalibrated)", rec
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def parse():
@@ -258,7 +258,15 @@ def main():
     if rank == 0:
         kmean = float(kernel_ms.mean()) * 1e-3
         achieved = BYTES_PER_ENV_STEP * env_steps_per_step / kmean / 1e9
-        traffic, traffic_src = recorded_traffic(N, workload.SUBSTEPS) if reset and not args.max_iter else (None, None)
+        traffic, traffic_src, pmc = recorded_traffic(N, workload.SUBSTEPS) if reset and not args.max_iter else (None, None, None)
+        # what actually bounds the kernel: VALU issue slots of the one wave each SIMD holds (recorded SQ_INSTS_VALU x 4
+        # cycles over the measured launch time at the 2.4 GHz shader clock), reported next to the HBM roofline
+        valu = None
+        if pmc and pmc.get("counters", {}).get("SQ_INSTS_VALU"):
+            waves = -(-N * world.lanes_per_env() // 64)
+            valu = {"valu_inst_per_wave_per_launch": pmc["counters"]["SQ_INSTS_VALU"] / waves,
+                    "issue_slot_frac": pmc["counters"]["SQ_INSTS_VALU"] / waves * 4.0 / (kmean * 2.4e9),
+                    "note": "one wave per SIMD: (VALU instructions x 4 cycles) / launch cycles; recorded PMC pass, measured launch time"}
         out = {
             "metric": "env-steps/sec, 4096 ANYmal-C envs flat terrain dt=0.0025",
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -280,7 +288,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rsb_step_kernel", "kernel_ms_mean": float(kernel_ms.mean()),
                          "kernel_ms_p50": float(np.median(kernel_ms)),
-                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * env_steps_per_step},
+                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * env_steps_per_step, "valu_issue": valu},
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "state_at_end": {"solver_iters_mean": float(iters.mean()), "solver_iters_max": int(iters.max()),
                              "contacts_per_env": float(counts.mean()), "base_height_mean": float(q_end[:, 2].mean())},
