@@ -79,12 +79,13 @@ class VectorizedEnvironment {
   /// action: float [num_envs, actionDim]; reward: float [num_envs]; done: bool [num_envs] — all written in place
   void step(const float* action, int rows, int cols, float* reward, bool* done) {
     RSFATAL_IF(rows != n_ || cols != actionDim_, "step: action must be [num_envs, actionDim]");
-    RSB_CHECK(rsb_env_step(world_.handle(), action, reward, done_.data(), RSB_HOST));   // action kernel + ONE fused launch + reward/reset kernel
+    RSB_CHECK(rsb_env_step(world_.handle(), action, reward, done_.data(), nullptr, RSB_HOST));   // action kernel + ONE fused launch + reward/reset kernel
     for (int e = 0; e < n_; ++e) done[e] = done_[e] != 0;
   }
   /// device buffers: action float [num_envs, actionDim], reward float [num_envs], done uint8 [num_envs]
-  void stepDevice(const float* action_device, float* reward_device, uint8_t* done_device) {
-    RSB_CHECK(rsb_env_step(world_.handle(), action_device, reward_device, done_device, RSB_DEVICE));
+  /// ob_next_device (optional, float [num_envs, obDim]): the observation the next step starts from, from the same launch
+  void stepDevice(const float* action_device, float* reward_device, uint8_t* done_device, float* ob_next_device = nullptr) {
+    RSB_CHECK(rsb_env_step(world_.handle(), action_device, reward_device, done_device, ob_next_device, RSB_DEVICE));
   }
 
   void isTerminalState(bool* terminalState) { for (int e = 0; e < n_; ++e) terminalState[e] = done_[e] != 0; }

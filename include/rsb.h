@@ -290,8 +290,10 @@ int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* acti
 int rsb_env_dims(const rsb_world* w, int* ob_dim, int* action_dim);
 int rsb_env_reset(rsb_world* w);                                   /* every env to gc_init / gv_init */
 int rsb_env_observe(rsb_world* w, float* ob, int space);           /* [N, ob_dim] */
-/* action [N, action_dim] in; reward [N] float, done [N] uint8 out (either may be NULL); all in `space` */
-int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done, int space);
+/* action [N, action_dim] in; reward [N] float, done [N] uint8 and ob_next [N, ob_dim] (the observation the next step
+ * starts from, i.e. after the resets) out, any of which may be NULL; all in `space`.  Two launches: the step kernel
+ * (action -> PD targets in its prologue) and one reward / termination / reset / observation kernel. */
+int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done, float* ob_next, int space);
 
 /* zero-copy access to the resident state (device pointers; row-major [N,dim] float32): see rsb_field */
 void* rsb_device_ptr(rsb_world* w, int field);

@@ -122,7 +122,7 @@ PROTOTYPES = {
     "rsb_env_dims": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
     "rsb_env_reset": (_I, [_VP]),
     "rsb_env_observe": (_I, [_VP, _FP, _I]),
-    "rsb_env_step": (_I, [_VP, _FP, _FP, _FP, _I]),
+    "rsb_env_step": (_I, [_VP, _FP, _FP, _FP, _FP, _I]),
     "rsb_device_ptr": (_VP, [_VP, _I]),
     "rsb_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
     "rsb_enable_timing": (_I, [_VP, _I]),

@@ -67,7 +67,7 @@ struct rsb_world {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
-  struct Fuse { const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
+  struct Fuse { const float* act = nullptr; const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
                 int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1; } fuse;
   // device-resident vectorised env (rsb_env_*)
   bool env_ready = false;
@@ -286,17 +286,6 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
 }
 
 // ---- device-resident vectorised env (rsg_anymal task semantics, see rsb.h) ------------------------------------
-__global__ void env_action_kernel(float* pt, const float* action, const float* mean, float std_, int N, int nq, int nj) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * nj) return;
-  const int e = i / nj, j = i - e * nj;
-  {  // two roundings, exactly as the host-side float expression of the CPU facade (no FMA contraction)
-#pragma clang fp contract(off)
-    const float scaled = std_ * action[i];
-    pt[(size_t)e * nq + 7 + j] = mean[j] + scaled;
-  }
-}
-
 __device__ inline void env_rot_t(const float* q, float* Rt) {  // world -> body rotation from the base quaternion
   const float w = q[3], x = q[4], y = q[5], z = q[6];
   Rt[0] = 1 - 2 * (y * y + z * z); Rt[3] = 2 * (x * y - w * z);     Rt[6] = 2 * (x * z + w * y);
@@ -304,12 +293,25 @@ __device__ inline void env_rot_t(const float* q, float* Rt) {  // world -> body 
   Rt[2] = 2 * (x * z - w * y);     Rt[5] = 2 * (y * z + w * x);     Rt[8] = 1 - 2 * (x * x + y * y);
 }
 
+__device__ inline void env_write_obs(float* o, const float* q, const float* u, int nv) {
+  const int nj = nv - 6;
+  float Rt[9];
+  env_rot_t(q, Rt);
+  int k = 0;
+  o[k++] = q[2];
+  o[k++] = Rt[6]; o[k++] = Rt[7]; o[k++] = Rt[8];   // body z-axis in the world (third column of R)
+  for (int j = 0; j < nj; ++j) o[k++] = q[7 + j];
+  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[0] + Rt[3 * i + 1] * u[1] + Rt[3 * i + 2] * u[2];
+  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[3] + Rt[3 * i + 1] * u[4] + Rt[3 * i + 2] * u[5];
+  for (int j = 0; j < nj; ++j) o[k++] = u[6 + j];
+}
+
 // reward and termination from the state the control step ended in, then the reset of terminated envs
 __global__ void env_post_kernel(float* gc, float* gv, const float* pt, const float* dtg, const float* kp, const float* kd,
                                 const rsb_contact* contacts, int32_t* count, int32_t* flags, unsigned long long allowed,
                                 const float* gc0, const float* gv0, float* reward, uint8_t* done, int N, int nq, int nv,
                                 int kmax, float fwd_coeff, float fwd_clip, float torque_coeff, float terminal_reward,
-                                float* warm, int n6) {
+                                float* warm, int n6, float* ob) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
   float* q = gc + (size_t)e * nq;
@@ -338,24 +340,13 @@ __global__ void env_post_kernel(float* gc, float* gv, const float* pt, const flo
     count[e] = 0;
     flags[e] = 0;
   }
+  if (ob) env_write_obs(ob + (size_t)e * (10 + 2 * (nv - 6)), q, u, nv);   // observation of the state the next step starts from
 }
 
 __global__ void env_obs_kernel(float* ob, const float* gc, const float* gv, int N, int nq, int nv) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
-  const float* q = gc + (size_t)e * nq;
-  const float* u = gv + (size_t)e * nv;
-  const int nj = nv - 6;
-  float* o = ob + (size_t)e * (10 + 2 * nj);
-  float Rt[9];
-  env_rot_t(q, Rt);
-  int k = 0;
-  o[k++] = q[2];
-  o[k++] = Rt[6]; o[k++] = Rt[7]; o[k++] = Rt[8];   // body z-axis in the world (third column of R)
-  for (int j = 0; j < nj; ++j) o[k++] = q[7 + j];
-  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[0] + Rt[3 * i + 1] * u[1] + Rt[3 * i + 2] * u[2];
-  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[3] + Rt[3 * i + 1] * u[4] + Rt[3 * i + 2] * u[5];
-  for (int j = 0; j < nj; ++j) o[k++] = u[6 + j];
+  env_write_obs(ob + (size_t)e * (10 + 2 * (nv - 6)), gc + (size_t)e * nq, gv + (size_t)e * nv, nv);
 }
 
 __global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* flags, const float* gc0, const float* gv0,
@@ -414,6 +405,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.heights = w->d_heights;
   a.warm = w->warm_start ? w->d_warm : nullptr;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
+  if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
@@ -999,20 +991,19 @@ int rsb_env_observe(rsb_world* w, float* ob, int space) {
   if (space == RSB_HOST) return copy_out(w, ob, dob, (size_t)w->N * od * sizeof(float), RSB_HOST);
   return RSB_OK;
 }
-int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done, int space) {
+int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done, float* ob_next, int space) {
   int st = env_check(w, "rsb_env_step"); if (st != RSB_OK) return st;
   if (!action) return RSB_E_INVALID;
   const int N = w->N, nq = w->blob.nq, nv = w->blob.nv, nj = nv - 6;
+  const size_t od = 10 + 2 * (size_t)nj;
   const float* dact = action;
   if (space == RSB_HOST) {
     HIP_TRY(hipMemcpyAsync(w->d_env_io, action, (size_t)N * nj * sizeof(float), hipMemcpyHostToDevice, w->stream));
     dact = w->d_env_io;
   }
-  hipLaunchKernelGGL(env_action_kernel, dim3((N * nj + 255) / 256), dim3(256), 0, w->stream, w->d_pt, dact, w->d_env_mean,
-                     w->env_cfg.action_std, N, nq, nj);
-  HIP_TRY(hipGetLastError());
   {
-    rsb_world::Fuse f;          // no fused epilogue, but the launch may know which primitives are allowed to touch
+    rsb_world::Fuse f;          // action -> PD targets in the launch's prologue; the launch knows the allowed primitives
+    f.act = dact;
     f.have_allowed = 1; f.allowed = w->env_allowed;
     w->fuse = f;
   }
@@ -1020,15 +1011,17 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   if (st != RSB_OK) return st;
   float* drew = space == RSB_DEVICE ? reward : (reward ? w->d_env_reward : nullptr);
   uint8_t* ddone = space == RSB_DEVICE ? done : (done ? w->d_env_done : nullptr);
+  float* dob = ob_next ? (space == RSB_DEVICE ? ob_next : w->d_env_io) : nullptr;   // host staging: the action is consumed by now
   hipLaunchKernelGGL(env_post_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_pt, w->d_dt,
                      w->d_kp, w->d_kd, w->d_contacts, w->d_count, w->d_flags, w->env_allowed, w->d_env_gc0, w->d_env_gv0,
                      drew, ddone, N, nq, nv, w->kmax, w->env_cfg.forward_vel_coeff, w->env_cfg.forward_vel_clip,
-                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward, w->d_warm, 6 * w->blob.ncol);
+                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward, w->d_warm, 6 * w->blob.ncol, dob);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   if (space == RSB_HOST) {
     if (reward) HIP_TRY(hipMemcpyAsync(reward, w->d_env_reward, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     if (done) HIP_TRY(hipMemcpyAsync(done, w->d_env_done, (size_t)N, hipMemcpyDeviceToHost, w->stream));
+    if (ob_next) HIP_TRY(hipMemcpyAsync(ob_next, w->d_env_io, (size_t)N * od * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
   }
   return RSB_OK;

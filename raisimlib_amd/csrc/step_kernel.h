@@ -102,6 +102,9 @@ struct StepArgs {
                                // direction (2), direction valid; NULL = every solve starts cold
   // fused control-step epilogue / prologue (rsb_control_step); all optional
   float* ptarget_store;        // p_target rows read from `ptarget` are also stored here (the world's own copy)
+  const float* act;            // [N, nv-6] actions (rsb_env_step): joint targets = act_mean + act_std * act, NULL = use ptarget
+  const float* act_mean;       // [nv-6]
+  float act_std;
   float* obs_out;              // [N, nq + nv + 3*obs_slots]: q, u, contact force of obs_idx[slot] (last sub-step)
   const int32_t* obs_idx;      // [obs_slots] collision primitive of each force slot (NULL: slot k = primitive k)
   int obs_slots;
@@ -495,7 +498,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   // ---- state rows: HBM -> LDS
   for (int i = s; i < nq; i += LPE) {
     Q[i] = a.gc[(size_t)env * nq + i];
-    const float pt = a.ptarget[(size_t)env * nq + i];
+    float pt = a.ptarget[(size_t)env * nq + i];
+    if (a.act && i >= 7) {   // action -> joint target, two roundings as a host float expression (no FMA contraction)
+#pragma clang fp contract(off)
+      const float scaled = a.act_std * a.act[(size_t)env * (nq - 7) + (i - 7)];
+      pt = a.act_mean[i - 7] + scaled;
+    }
     PT[i] = pt;
     if (a.ptarget_store && env_valid) a.ptarget_store[(size_t)env * nq + i] = pt;
   }

@@ -80,22 +80,28 @@ class VecEnv:
         check(w.L.rsb_env_observe(w.handle, _hp(ob), RSB_HOST), "rsb_env_observe")
         return ob
 
-    def step(self, action, reward=None, done=None):
-        """action [num_envs, num_acts] -> (reward [num_envs] float32, done [num_envs] uint8/bool)."""
+    def step(self, action, reward=None, done=None, ob_next=None):
+        """action [num_envs, num_acts] -> (reward [num_envs] float32, done [num_envs] uint8).  ob_next (optional,
+        [num_envs, num_obs]) receives the observation the next step starts from (after the resets) from the same
+        launch, which saves the separate observe() call."""
         w = self.world
         if self._is_torch(action):
             import torch
             assert action.is_cuda and action.is_contiguous() and action.dtype == torch.float32
             reward = torch.empty(self.num_envs, dtype=torch.float32, device=action.device) if reward is None else reward
             done = torch.empty(self.num_envs, dtype=torch.uint8, device=action.device) if done is None else done
+            obp = None
+            if ob_next is not None:
+                assert ob_next.is_cuda and ob_next.is_contiguous() and tuple(ob_next.shape) == (self.num_envs, self.num_obs)
+                obp = C.c_void_p(ob_next.data_ptr())
             check(w.L.rsb_env_step(w.handle, C.c_void_p(action.data_ptr()), C.c_void_p(reward.data_ptr()),
-                                   C.c_void_p(done.data_ptr()), RSB_DEVICE), "rsb_env_step")
+                                   C.c_void_p(done.data_ptr()), obp, RSB_DEVICE), "rsb_env_step")
             return reward, done
         a = np.ascontiguousarray(action, np.float32)
         assert a.shape == (self.num_envs, self.num_acts)
         reward = np.zeros(self.num_envs, np.float32) if reward is None else reward
         done = np.zeros(self.num_envs, np.uint8) if done is None else done
-        check(w.L.rsb_env_step(w.handle, _hp(a), _hp(reward), _hp(done), RSB_HOST), "rsb_env_step")
+        check(w.L.rsb_env_step(w.handle, _hp(a), _hp(reward), _hp(done), _hp(ob_next), RSB_HOST), "rsb_env_step")
         return reward, done
 
     # -- running observation statistics (RaisimGymVecEnv's normalize_ob / RunningMeanStd [RECALL]) -------------------

@@ -274,12 +274,15 @@ def test_device_vecenv_matches_the_host_restatement(anymal):
     n_done = 0
     for k in range(40):
         act = rng.normal(size=(N, 12)).astype(np.float32) * (3.0 if k % 9 == 8 else 1.0)   # big kicks make some fall
+        ob_same_launch = None
         if k % 2 == 0:
-            rew, done = env.step(act)
+            ob_same_launch = np.zeros((N, 34), np.float32)
+            rew, done = env.step(act, ob_next=ob_same_launch) if k % 4 == 0 else env.step(act)
         else:
-            r_t, d_t = env.step(torch.from_numpy(act).cuda())
+            ob_t = torch.empty((N, 34), device="cuda")
+            r_t, d_t = env.step(torch.from_numpy(act).cuda(), ob_next=ob_t)
             torch.cuda.synchronize()
-            rew, done = r_t.cpu().numpy(), d_t.cpu().numpy()
+            rew, done, ob_same_launch = r_t.cpu().numpy(), d_t.cpu().numpy(), ob_t.cpu().numpy()
         pt = np.zeros((N, 19), np.float32); pt[:, 3] = 1; pt[:, 7:] = gc_init[7:] + np.float32(0.3) * act
         twin.set_pd_target(pt, np.zeros((N, 18), np.float32))
         twin.integrate(4)
@@ -292,6 +295,8 @@ def test_device_vecenv_matches_the_host_restatement(anymal):
         ob_ref, _, _ = _env_reference(q.astype(np.float64), u.astype(np.float64), pt.astype(np.float64), kp, kd, cnt, con, fl, feet, cfg)
         ob = env.observe() if k % 2 else env.observe(torch.empty((N, 34), device="cuda")).cpu().numpy()
         assert np.allclose(ob, ob_ref, rtol=1e-5, atol=1e-5)
+        if ob_same_launch is not None and (k % 2 == 1 or k % 4 == 0):
+            assert np.array_equal(ob_same_launch, ob)          # the fused observation is the same kernel code
         n_done += int(term.sum())
     assert n_done > 0
     env.close(); twin.close()

@@ -16,11 +16,11 @@ gen = torch.Generator(device=dev); gen.manual_seed(0)
 acts = [torch.empty((N, env.num_acts), device=dev).uniform_(-1, 1, generator=gen) for _ in range(16)]   # U(-1,1) * 0.3 rad
 ob = torch.empty((N, env.num_obs), device=dev); rew = torch.empty(N, device=dev); done = torch.empty(N, dtype=torch.uint8, device=dev)
 for k in range(WARM):
-    env.step(acts[k % 16], rew, done); env.observe(ob)
+    env.step(acts[k % 16], rew, done, ob)
 env.world.enable_timing(STEPS)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for k in range(STEPS):
-    env.step(acts[k % 16], rew, done); env.observe(ob)
+    env.step(acts[k % 16], rew, done, ob)
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize(); el = time.perf_counter() - t0
 kms = env.world.read_kernel_ms(STEPS)
