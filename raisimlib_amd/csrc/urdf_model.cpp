@@ -4,10 +4,11 @@
 // World.hpp are absent from /root/reference, SURVEY.md §3.3]: parse the robot description once on the
 // host, merge fixed joints, and emit the immutable model blob that rsb_create uploads to the device.
 //
-// Supported subset: <link>/<inertial>/<collision> with <sphere> and <capsule> geometry,
+// Supported subset: <link>/<inertial>/<collision> with <sphere>, <capsule>, <box> (its 8 corners) and <cylinder>
+// (the inscribed capsule) geometry,
 // <joint type="revolute|continuous|prismatic|fixed">, <origin xyz rpy>, <axis>, <limit>,
-// <dynamics damping rotor_inertia>.  The root link is the floating base.  Box / cylinder / mesh
-// collision geometry is ignored (counted in rsb_model::skipped_collisions); see DESIGN.md "out of scope".
+// <dynamics damping rotor_inertia>.  The root link is the floating base.  Mesh collision geometry is ignored
+// (counted in rsb_model::skipped_collisions); see DESIGN.md "out of scope".
 #include "rsb.h"
 #include "rsb_internal.h"
 
@@ -180,7 +181,7 @@ static Xf parse_origin(const XmlNode* n) {
 }
 
 // ------------------------------------------------------------------------------ URDF -> blob
-struct UCollision { Xf x; int type; double radius, length; std::string name; };  // type 0 sphere, 1 capsule
+struct UCollision { Xf x; int type; double radius, length; double size[3]; std::string name; };  // type 0 sphere, 1 capsule, 2 box
 struct ULink {
   std::string name;
   double mass = 0;
@@ -224,11 +225,12 @@ struct Builder {
   void add_collisions(int body, const Xf& body_from_link, const ULink& L) {
     for (auto& c : L.cols) {
       Xf bc = compose(body_from_link, c.x);
-      int n = c.type == 1 ? 2 : 1;
+      int n = c.type == 1 ? 2 : (c.type == 2 ? 8 : 1);
       for (int e = 0; e < n; ++e) {
         if (blob.ncol >= RSB_MAX_COLLISIONS) throw std::runtime_error("URDF: more than RSB_MAX_COLLISIONS collision spheres");
         V3 off{0, 0, 0};
         if (c.type == 1) off = {0, 0, (e == 0 ? 0.5 : -0.5) * c.length};
+        if (c.type == 2) off = {(e & 1 ? 0.5 : -0.5) * c.size[0], (e & 2 ? 0.5 : -0.5) * c.size[1], (e & 4 ? 0.5 : -0.5) * c.size[2]};
         V3 p = bc.p + mul(bc.R, off);
         int s = blob.ncol++;
         blob.col_body[s] = body;
@@ -236,6 +238,7 @@ struct Builder {
         blob.col_radius[s] = c.radius;
         std::string nm = c.name.empty() ? L.name : c.name;
         if (c.type == 1) nm += (e == 0 ? "/top" : "/bottom");
+        if (c.type == 2) nm += "/c" + std::to_string(e);
         std::snprintf(blob.col_name[s], RSB_NAME_LEN, "%s", nm.c_str());
       }
     }
@@ -321,8 +324,18 @@ static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* ski
           col.type = 0; col.radius = attr_double(s, "radius", 0.0); col.length = 0;
         } else if (const XmlNode* cp = g->child("capsule")) {
           col.type = 1; col.radius = attr_double(cp, "radius", 0.0); col.length = attr_double(cp, "length", 0.0);
-        } else { ++B.skipped_collisions; continue; }
-        if (col.radius <= 0) throw std::runtime_error("URDF: non-positive collision radius on link " + L.name);
+        } else if (const XmlNode* bx = g->child("box")) {
+          // a box touches a plane / height field with its corners: 8 zero-radius spheres (exact contact set on a plane)
+          col.type = 2; col.radius = 0; col.length = 0;
+          if (!parse_doubles(bx->get("size"), col.size, 3) || !(col.size[0] > 0 && col.size[1] > 0 && col.size[2] > 0))
+            throw std::runtime_error("URDF: <box> needs size=\"x y z\" > 0 on link " + L.name);
+        } else if (const XmlNode* cy = g->child("cylinder")) {
+          // a cylinder is replaced by the capsule inscribed in it (same radius, rounded rims): its two end spheres
+          col.type = 1; col.radius = attr_double(cy, "radius", 0.0);
+          const double len = attr_double(cy, "length", 0.0);
+          col.length = len > 2 * col.radius ? len - 2 * col.radius : 0.0;
+        } else { ++B.skipped_collisions; continue; }   // meshes
+        if (col.type != 2 && col.radius <= 0) throw std::runtime_error("URDF: non-positive collision radius on link " + L.name);
         L.cols.push_back(col);
       }
       if (B.link_ix.count(L.name)) throw std::runtime_error("URDF: duplicate link " + L.name);
@@ -403,7 +416,7 @@ int validate_blob(const rsb_model_blob& b) {
   }
   if (b.depth != depth) { set_error("model: depth inconsistent"); return RSB_E_INVALID; }
   for (int s = 0; s < b.ncol; ++s)
-    if (b.col_body[s] < 0 || b.col_body[s] >= b.nb || !(b.col_radius[s] > 0)) { set_error("model: bad collision sphere"); return RSB_E_INVALID; }
+    if (b.col_body[s] < 0 || b.col_body[s] >= b.nb || !(b.col_radius[s] >= 0)) { set_error("model: bad collision sphere"); return RSB_E_INVALID; }
   return RSB_OK;
 }
 

@@ -38,6 +38,8 @@ def link(name, mass, com, inertia_diag, collisions=(), inertia_rpy=(0, 0, 0), of
             s.append(f'      <geometry><capsule radius="{c["radius"]:.6g}" length="{c["length"]:.6g}"/></geometry>')
         elif c["type"] == "box":
             s.append(f'      <geometry><box size="{c["size"][0]:.6g} {c["size"][1]:.6g} {c["size"][2]:.6g}"/></geometry>')
+        elif c["type"] == "mesh":   # the loader ignores (and counts) mesh colliders: keeps the stand-ins' sphere sets fixed
+            s.append(f'      <geometry><mesh filename="{c["name"]}.stl"/></geometry>')
         s.append("    </collision>")
     s.append("  </link>")
     return "\n".join(s)
@@ -63,7 +65,7 @@ def anymal_c_like():
            '<robot name="anymal_c_like">']
     base_cols = [dict(name=f"base_{i}", type="sphere", xyz=(sx * 0.30, sy * 0.10, 0.0), radius=0.10)
                  for i, (sx, sy) in enumerate([(1, 1), (1, -1), (-1, 1), (-1, -1)])]
-    base_cols.append(dict(name="base_box_ignored", type="box", xyz=(0, 0, 0), size=(0.53, 0.27, 0.24)))
+    base_cols.append(dict(name="base_mesh_ignored", type="mesh", xyz=(0, 0, 0)))
     out.append(link("base", 19.2, (0.0, 0.0, 0.01), box_inertia(19.2, 0.53, 0.27, 0.24), base_cols,
                     off_diag=(0.001, -0.002, 0.0005)))
     # a payload rigidly attached with a rotated frame: exercises fixed-joint merging
@@ -102,7 +104,7 @@ def atlas_like():
     out.append(joint("back_bky", "revolute", "ltorso", "mtorso", (0.0, 0.0, 0.162), (0, 1, 0), effort=E))
     out.append(link("utorso", 63.7, (-0.06, 0.0, 0.26), (1.58, 1.30, 0.85),
                     [dict(name="utorso_back", type="capsule", xyz=(-0.12, 0.0, 0.25), radius=0.2, length=0.3),
-                     dict(name="utorso_mesh_ignored", type="box", xyz=(0, 0, 0.2), size=(0.4, 0.5, 0.6))]))
+                     dict(name="utorso_mesh_ignored", type="mesh", xyz=(0, 0, 0.2))]))
     out.append(joint("back_bkx", "revolute", "mtorso", "utorso", (0.0, 0.0, 0.05), (1, 0, 0), effort=E))
     out.append(link("head", 1.42, (-0.075, 0.0, 0.03), (0.0040, 0.0042, 0.0036),
                     [dict(name="head_s", type="sphere", xyz=(0.0, 0.0, 0.05), radius=0.12)]))

@@ -99,3 +99,40 @@ def test_missing_file(built_lib):
     from raisimlib_amd import Model, RsbError
     with pytest.raises(RsbError, match="cannot open"):
         Model(urdf_path="/nonexistent/robot.urdf")
+
+
+BOX_URDF = """<robot name="crate"><link name="crate">
+ <inertial><origin xyz="0 0 0"/><mass value="4"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.15" iyz="0" izz="0.2"/></inertial>
+ <collision><origin xyz="0.1 0 0" rpy="0 0 0.5"/><geometry><box size="0.6 0.4 0.2"/></geometry></collision>
+ <collision name="pipe"><origin xyz="0 0 0.3"/><geometry><cylinder radius="0.05" length="0.5"/></geometry></collision>
+ <collision><geometry><mesh filename="x.stl"/></geometry></collision>
+</link></robot>"""
+
+
+def test_box_becomes_its_corners_and_cylinder_its_inscribed_capsule(built_lib):
+    from raisimlib_amd import Model
+    m = Model(urdf_string=BOX_URDF)
+    b = m.blob
+    assert m.ncol == 10
+    pos = np.array([list(b.col_pos[i]) for i in range(10)]); rad = np.array([b.col_radius[i] for i in range(10)])
+    assert np.all(rad[:8] == 0) and np.allclose(rad[8:], 0.05)
+    c, s_ = np.cos(0.5), np.sin(0.5)
+    want = {(round(0.1 + c * x - s_ * y, 9), round(s_ * x + c * y, 9), z) for x in (-0.3, 0.3) for y in (-0.2, 0.2) for z in (-0.1, 0.1)}
+    got = {(round(p[0], 9), round(p[1], 9), round(p[2], 9)) for p in pos[:8]}
+    assert got == want
+    assert np.allclose(sorted(pos[8:, 2]), [0.3 - 0.2, 0.3 + 0.2]) and np.allclose(pos[8:, :2], 0)   # segment = length - 2 r
+    names = m.collision_names()
+    assert names[0].endswith("/c0") and names[7].endswith("/c7") and names[8] == "pipe/top"
+
+
+def test_crate_rests_on_its_four_bottom_corners(built_lib):
+    """Oracle KAT for the box collider: a crate dropped flat settles on its 4 bottom corners, which carry m g dt."""
+    from raisimlib_amd import Model
+    from common import Oracle
+    m = Model(urdf_string=BOX_URDF.replace(' rpy="0 0 0.5"', "").replace('xyz="0.1 0 0"', 'xyz="0 0 0"'))
+    o = Oracle(m.blob)
+    q = np.array([0, 0, 0.1 - 1e-4, 1, 0, 0, 0.0]); u = np.zeros(6)
+    for _ in range(40):
+        q, u, con, it, fl = o.step(q, u)
+    assert len(con) == 4 and set(con["collision"]) == {0, 1, 2, 3}          # the corners with z = -0.1
+    assert abs(con["impulse"][:, 2].sum() - 4 * 9.81 * 0.0025) < 1e-8 and np.abs(u).max() < 1e-7
