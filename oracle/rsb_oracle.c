@@ -753,6 +753,25 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     }
   }
 
+  /* joint limits (RaiSim enforces them in the same solver [RECALL]): a joint beyond its range adds one unilateral row
+   * s * qdot >= 0 (s = -1 above the upper limit, +1 below the lower one), carried through the solver as a contact whose
+   * two tangential rows are empty (unit dummy diagonal); it is not reported by getContacts */
+  const int nreal = nc;
+  double lim_sign[MAXK];
+  for (int i = 0; i < nc; ++i) lim_sign[i] = 0.0;
+  for (int i = 1; i < m->nb; ++i) {
+    const double lo = m->q_lower[i], hi = m->q_upper[i], qi = q[qidx_of(i)];
+    if (!(lo < hi)) continue;
+    double sgn = 0.0, viol = 0.0;
+    if (qi > hi) { sgn = -1.0; viol = qi - hi; } else if (qi < lo) { sgn = 1.0; viol = lo - qi; }
+    if (sgn != 0.0) {
+      if (nc >= kmax) { fl |= 1; continue; }
+      cbody[nc] = i; ccol[nc] = m->ncol + i; cdepth[nc] = viol; lim_sign[nc] = sgn;
+      for (int a = 0; a < 3; ++a) { cx[nc][a] = 0.0; cn[nc][a] = 0.0; }
+      ++nc;
+    }
+  }
+
   /* integrate2: u_free = u + dt M^-1 (tau - h) */
   dof_parents(m, pd);
   ltdl(M, nv, pd);
@@ -770,6 +789,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     X = (double (*)[3][MAXV])(tl_JX + MAXK * 3 * MAXV);
     double* Jw = tl_JX + 2 * MAXK * 3 * MAXV;
     for (int i = 0; i < nc; ++i) {
+      if (lim_sign[i] != 0.0) {   /* joint-limit row: J = [0; 0; s e_k] */
+        for (int r = 0; r < 3; ++r) for (int d = 0; d < nv; ++d) { Jc[i][r][d] = 0.0; X[i][r][d] = 0.0; }
+        Jc[i][2][dof_of(cbody[i])] = lim_sign[i]; X[i][2][dof_of(cbody[i])] = lim_sign[i];
+        ltdl_solve(M, nv, pd, X[i][2]);
+        continue;
+      }
       point_jacobian(m, k, cbody[i], cx[i], Jw);
       for (int r = 0; r < 3; ++r)
         for (int d = 0; d < nv; ++d) {
@@ -789,6 +814,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
             for (int d = 0; d < nv; ++d) s += Jc[i][r][d] * X[j][c][d];
             G[i][j][3 * r + c] = s;
           }
+      if (lim_sign[i] != 0.0) G[i][i][0] = G[i][i][4] = 1.0;   /* dummy tangential diagonal of a joint-limit row */
       inv3(G[i][i], Ginv[i]);
       for (int r = 0; r < 3; ++r) {
         double s = 0;
@@ -797,7 +823,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       }
       cfree[i][2] -= p->erp * cdepth[i] / p->dt;
       /* warm start: the impulse (contact frame) this collision primitive carried in the previous integrate() */
-      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
+      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
     }
     /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
     if (dbgG)
@@ -819,7 +845,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     for (int i = 0; i < nc; ++i) {
       sdir[i][0] = sdir[i][1] = sdir[i][2] = 0.0;
       lam_best[i][0] = lam_best[i][1] = lam_best[i][2] = 0.0;
-      if (lam_warm && p->warm_start && lam_warm[ORC_WARM * ccol[i] + 5] != 0.0) {   /* ... and its last friction direction */
+      if (lam_warm && p->warm_start && i < nreal && lam_warm[ORC_WARM * ccol[i] + 5] != 0.0) {   /* ... and its last friction direction */
         sdir[i][0] = lam_warm[ORC_WARM * ccol[i] + 3]; sdir[i][1] = lam_warm[ORC_WARM * ccol[i] + 4]; sdir[i][2] = 1.0;
       }
     }
@@ -892,14 +918,14 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
 
   if (lam_warm) {
     for (int i = 0; i < ORC_WARM * m->ncol; ++i) lam_warm[i] = 0.0;
-    for (int i = 0; i < nc; ++i) {
+    for (int i = 0; i < nreal; ++i) {
       double* wrm = lam_warm + ORC_WARM * ccol[i];
       for (int r = 0; r < 3; ++r) wrm[r] = lam[i][r];
       if (sdir_out[i][2] != 0.0) { wrm[3] = sdir_out[i][0]; wrm[4] = sdir_out[i][1]; wrm[5] = 1.0; }
     }
   }
   if (contacts)
-    for (int i = 0; i < nc; ++i) {
+    for (int i = 0; i < nreal; ++i) {
       for (int c = 0; c < 3; ++c) {
         contacts[i].position[c] = k->pbase[c] + cx[i][c];
         contacts[i].normal[c] = cn[i][c];
@@ -907,7 +933,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       }
       contacts[i].depth = cdepth[i]; contacts[i].body = cbody[i]; contacts[i].collision = ccol[i];
     }
-  if (n_contacts) *n_contacts = nc;
+  if (n_contacts) *n_contacts = nreal;
   if (iters) *iters = it_used;
   if (flags) *flags = fl;
 }

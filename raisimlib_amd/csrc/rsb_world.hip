@@ -105,6 +105,9 @@ void build_dev_model(const rsb_model_blob& b, DevModel* d) {
     d->armature[i] = f[26] = (float)b.armature[i];
     f[27] = (float)b.damping[i];
     f[28] = (float)b.effort[i];
+    const bool limited = i > 0 && b.q_lower[i] < b.q_upper[i] && b.q_lower[i] > -1e29 && b.q_upper[i] < 1e29;
+    f[29] = limited ? (float)b.q_lower[i] : -3e38f;   // joint range (an unlimited joint can never leave it)
+    f[30] = limited ? (float)b.q_upper[i] : 3e38f;
   }
   for (int i = 0; i < b.nb * b.depth; ++i) d->anc[i] = -1;
   for (int i = 0; i < b.nb; ++i)

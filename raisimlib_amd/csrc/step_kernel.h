@@ -66,7 +66,7 @@ struct DevModel {
   int ch_len[kMaxB], ch_attach[kMaxB], ch_level[kMaxB], ch_body[kMaxB * kMaxCL];
   int cc_start[kMaxB], cc_count[kMaxB], cc_list[kMaxB];  // chains hanging off each body
   // bodyf[b]: 0-2 axis, 3 jtype (int bits), 4-6 ptree, 7 mass, 8-16 rtree, 17-19 com, 20-25 inertia,
-  //           26 armature, 27 damping, 28 effort
+  //           26 armature, 27 damping, 28 effort, 29 q_lower, 30 q_upper
   float bodyf[kMaxB][kModelSlot];
   // fields used by the slow-path query kernel
   float axis[kMaxB][4], ptree[kMaxB][4], rtree[kMaxB][12], com[kMaxB][4], inertia[kMaxB][8];
@@ -514,6 +514,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   }
   if (a.warm) for (int i = s; i < nwarm; i += LPE) WARM[i] = a.warm[(size_t)env * nwarm + i];
   int flag = 0, iters_used = 0, nc = 0;
+  int nc_real = 0;     // contacts of the last sub-step without the joint-limit rows that follow them in the solver
   bool dead = false;   // early termination: this env no longer integrates (its contacts at that moment stay reported)
   int nc_dead = 0;
   long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
@@ -681,6 +682,32 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       nc += __popcll(gm);
     }
     if (nc > a.kmax) { nc = a.kmax; flag |= 1; }
+    // joint limits (oracle: "joint limits" in step_impl): a joint outside [q_lower, q_upper] adds one unilateral row
+    // s * qdot >= 0, carried through the solver as a contact with empty tangential rows; slots after the real contacts
+    nc_real = nc;
+    if (!dead) {
+      for (int b0 = 1; b0 < nb; b0 += LPE) {
+        const int b = b0 + s;
+        float sgn = 0.f, viol = 0.f;
+        if (b < nb) {
+          const float qj = Q[b + 6], lo = MODELF[b * kModelSlot + 29], hi = MODELF[b * kModelSlot + 30];
+          if (qj > hi) { sgn = -1.f; viol = qj - hi; } else if (qj < lo) { sgn = 1.f; viol = lo - qj; }
+        }
+        const unsigned long long bal = __ballot(sgn != 0.f);
+        if (bal) {   // rare: nothing below runs while every joint of the wave is inside its range
+          const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
+          const int slot = nc + __popcll(gm & ((1ull << s) - 1ull));
+          if (sgn != 0.f && slot < a.kmax) {
+            float P[16];
+            RSB_UNROLL for (int i = 0; i < 16; ++i) P[i] = 0.f;
+            P[3] = viol; P[7] = __int_as_float(b); P[11] = __int_as_float(ncol + b); P[15] = sgn;
+            stv<4>(CON + slot * kConSlot, P);
+          }
+          nc += __popcll(gm);
+        }
+      }
+      if (nc > a.kmax) { nc = a.kmax; flag |= 1; }
+    }
     if (a.early_term) {
       // early termination (opt-in, rsb_set_early_termination): the sub-step in which a primitive outside `allowed`
       // touches the terrain is not integrated, nor are the following ones; the detected contacts stay reported
@@ -688,7 +715,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       const unsigned long long bil = __ballot(illegal);
       const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
       if (!dead && (bil & gsel)) {
-        dead = true; nc_dead = nc;
+        dead = true; nc_dead = nc_real;
         if (s < nc) { LAM[3 * s] = 0.f; LAM[3 * s + 1] = 0.f; LAM[3 * s + 2] = 0.f; }
       }
       if (dead) nc = 0;
@@ -803,6 +830,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           ld4(CON + i * kConSlot + 4 + 4 * rr, t);   // axis rr of the contact frame
           const int kb = __float_as_int(CN[7]);
           const int lev = PARLV[kb] >> 8;
+          const float lsgn = CN[15];                 // != 0: joint-limit row of body kb (only its "normal" row is non-empty)
           // prefetch the support chain's factors (independent loads), then propagate the unit impulse
           float FK[ML][16], wbk[ML];
           int node[ML];
@@ -820,10 +848,17 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           Fres[3] = t[0]; Fres[4] = t[1]; Fres[5] = t[2];
           cross3(Vb, x, wxx);  // J u = t . (v_body + w_body x x)
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
+          const bool limit_row = lsgn != 0.f;
+          const bool empty_row = limit_row && rr < 2;
+          if (limit_row) {   // unit generalized force s on the joint itself instead of a spatial impulse on the body
+            RSB_UNROLL for (int j = 0; j < 6; ++j) Fres[j] = 0.f;
+            cv = (rr == 2) ? lsgn * U[kb + 5] : 0.f;
+          }
           float* Wc = WC + c * cw;
           RSB_UNROLL for (int l = 0; l < ML; ++l) {
             if (l < lev) {
-              const float yh = dot6(FK[l], Fres);
+              float yh = dot6(FK[l], Fres);
+              if (limit_row && l == 0) yh = (rr == 2) ? lsgn : 0.f;
               const float wk = yh * FK[l][12];
               Wc[5 + lev - l] = wk;
               cv += wk * wbk[l];
@@ -837,6 +872,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             z[j] = sacc * idg[j];
             cv += z[j] * wbb[j];
           }
+          if (empty_row) cv = 0.f;
           st4(Wc, z); Wc[4] = z[4]; Wc[5] = z[5];
           if (rr == 2) cv -= a.erp * CN[3] / dt;
           CV[c] = cv;
@@ -885,6 +921,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
               RSB_UNROLL for (int cc = 0; cc < 3; ++cc) acc[3 * rr + cc] += av[rr] * bv[cc];
           }
+          if (i == j && CON[i * kConSlot + 15] != 0.f) { acc[0] = 1.f; acc[4] = 1.f; }   // joint-limit row: dummy tangential diagonal
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
             RSB_UNROLL for (int cc = 0; cc < 3; ++cc) {
               G[(3 * i + rr) * GS + 4 * j + cc] = acc[3 * rr + cc];   // 3x3 blocks on a 4-float pitch (16-B aligned rows of a block)
@@ -948,9 +985,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         if (a.warm) {
           if (isc) {
             mycol = __float_as_int(CON[s * kConSlot + 11]);
-            const float* wr = WARM + 6 * mycol;
-            lam[0] = wr[0]; lam[1] = wr[1]; lam[2] = wr[2];
-            sdx = wr[3]; sdy = wr[4]; sdv = wr[5] != 0.f;
+            if (mycol < ncol) {   // joint-limit rows (ids >= ncol) start cold
+              const float* wr = WARM + 6 * mycol;
+              lam[0] = wr[0]; lam[1] = wr[1]; lam[2] = wr[2];
+              sdx = wr[3]; sdy = wr[4]; sdv = wr[5] != 0.f;
+            }
           }
           for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
           if (__any(isc && (lam[0] != 0.f || lam[1] != 0.f || lam[2] != 0.f))) {
@@ -1070,7 +1109,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
         if (isc) {
           LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2];
-          if (a.warm) {
+          if (a.warm && mycol < ncol) {
             float* wr = WARM + 6 * mycol;
             wr[0] = lam[0]; wr[1] = lam[1]; wr[2] = lam[2];
             wr[3] = sdv ? sdx : 0.f; wr[4] = sdv ? sdy : 0.f; wr[5] = sdv ? 1.f : 0.f;
@@ -1195,6 +1234,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     for (int i = s; i < nq; i += LPE) bad |= !isfinite(Q[i]);
     for (int i = s; i < nv; i += LPE) bad |= !isfinite(U[i]);
     // contact lanes: anything but an allowed primitive touching the terrain terminates the episode (rsg_anymal rule)
+    nc = nc_real;                              // joint-limit rows are not contacts
     if (dead) { nc = nc_dead; flag |= 8; }   // report the contacts that ended the episode
     int mycol = 0;
     if (s < nc) mycol = __float_as_int(CON[s * kConSlot + 11]);

@@ -111,3 +111,26 @@ def test_standing_anymal_carries_its_weight(anymal):
     assert np.abs(u).max() < 2e-3
     assert {int(c) for c in con[0][:4]["collision"]} == set(anymal.collision_indices("_foot"))
     w.close()
+
+
+def test_joint_limit_stops_the_pendulum_inelastically(built_lib):
+    urdf = PENDULUM_URDF.format(l=0.5, m=1.0).replace('lower="-10" upper="10"', 'lower="-0.3" upper="0.2"')
+    _, w = world(urdf, gravity=[0, 0, 0], mode=0)
+    u0 = np.zeros(7); u0[6] = 1.0
+    w.set_state(tile([0, 0, 0, 1, 0, 0, 0, 0.0]), tile(u0))
+    w.integrate(70)
+    q, u = w.get_state()
+    assert np.allclose(u[:, 6], 1.0, atol=1e-5) and np.allclose(q[:, 7], 70 * DT, atol=1e-5)     # still inside the range
+    w.integrate(50)
+    q, u = w.get_state(); cnt, _ = w.get_contacts()
+    assert (cnt == 0).all()                                   # limit rows are not contacts
+    assert (q[:, 7] > 0.2).all() and (q[:, 7] < 0.2 + 1.5 * DT).all() and np.abs(u[:, 6]).max() < 1e-5
+    tau = np.zeros((N, 7), np.float32); tau[:, 6] = 3.0
+    w.set_generalized_force(tau); w.integrate(40)
+    q, u = w.get_state()
+    assert (q[:, 7] < 0.2 + 1.5 * DT).all() and np.abs(u[:, 6]).max() < 1e-5
+    tau[:, 6] = -3.0
+    w.set_generalized_force(tau); w.integrate(1)
+    _, u = w.get_state()
+    assert np.allclose(u[:, 6], -3.0 / 0.25 * DT, rtol=1e-4)
+    w.close()

@@ -47,9 +47,11 @@ def run_one_step(model, gc, gv, pt, kp, kd, lpe=0, kmax=8, substeps=1, heightmap
     return dict(q=q1, u=u1, cnt=cnt, con=con, iters=its, flags=fl), ref, o
 
 
-def check_step(dev, ref, max_iter=150, du_tol=2e-4):
+def check_step(dev, ref, max_iter=150, du_tol=2e-4, both_converged=False):
     assert np.array_equal(dev["cnt"], ref["n_contacts"])
     conv = (ref["flags"] & 4) == 0          # oracle met its convergence test (no max_iter / stagnation exit)
+    if both_converged:                      # very slow solves (dozens of sweeps) can end on different sides of the exit tests
+        conv &= (dev["flags"] & 4) == 0
     assert conv.mean() > 0.9
     eq = np.abs(dev["q"] - ref["q"])
     eu = np.abs(dev["u"] - ref["u"]).max(axis=1)
@@ -284,3 +286,42 @@ def test_multi_step_parity_with_warm_state_atlas_and_heightmap(anymal, atlas):
         eq, eu = np.abs(q1 - q).max(axis=1), np.abs(u1 - u).max(axis=1) / (1 + np.abs(u).max(axis=1))
         assert np.isfinite(q1).all() and np.median(eq) < 2e-5 and np.median(eu) < 5e-4, (name, np.median(eq), np.median(eu))
         assert np.percentile(eq, 90) < 2e-3, (name, np.percentile(eq, 90))
+
+
+def test_joint_limit_rows_parity(anymal):
+    """Knees with a tight range: states with one or several joints outside their range (with and without ground
+    contacts) - one step and a short trajectory against the oracle."""
+    from raisimlib_amd import Model, rsc_path
+    txt = open(rsc_path("anymal_c_like.urdf")).read()
+    import re
+    n_before = txt.count('lower="-6.28" upper="6.28"')
+    assert n_before >= 12
+    tight = re.sub(r'(<joint name="[A-Z]{2}_KFE".*?)lower="-6.28" upper="6.28"', r'\1lower="-1.0" upper="1.0"', txt, flags=re.S)
+    tight = re.sub(r'(<joint name="[A-Z]{2}_HFE".*?)lower="-6.28" upper="6.28"', r'\1lower="-0.5" upper="0.5"', tight, flags=re.S)
+    model = Model(urdf_string=tight)
+    gc, gv = standing_states(384, seed=77, z=(0.45, 0.9), vel=2.0)
+    rng = np.random.default_rng(2)
+    gc[:, 7:] += rng.uniform(-0.5, 0.5, (384, 12))            # pushes a good share of the joints past their range
+    kp, kd = workload.anymal_gains()
+    dev, ref, o = run_one_step(model, gc, gv, gc, kp, kd)
+    lo, hi = np.array([model.blob.q_lower[i] for i in range(1, 13)]), np.array([model.blob.q_upper[i] for i in range(1, 13)])
+    viol = ((gc[:, 7:] > hi) | (gc[:, 7:] < lo)).sum(1)
+    assert (viol > 0).mean() > 0.5 and (viol >= 2).any() and (viol == 0).any()
+    check_step(dev, ref, both_converged=True)
+    # a violated joint does not move further out (velocity-level constraint)
+    u1 = dev["u"][:, 6:]
+    out_hi, out_lo = gc[:, 7:] > hi, gc[:, 7:] < lo
+    conv = ((ref["flags"] | dev["flags"]) & 5) == 0
+    assert (u1[out_hi & conv[:, None]] < 1e-3).all() and (u1[out_lo & conv[:, None]] > -1e-3).all()
+    # short trajectory with the warm state carried on both sides
+    w = BatchedWorld(model, 384)
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((384, 18))); w.set_state(gc, gv)
+    q, u, warm = f32(gc), f32(gv), o.new_warm_state(384)
+    for _ in range(5):
+        w.integrate(4)
+        r = o.step_batch(q, u, 4, kp.astype(np.float64), kd.astype(np.float64), f32(gc), np.zeros((384, 18)), lam_warm=warm)
+        q, u = r["q"], r["u"]
+    q1, u1 = w.get_state()
+    w.close()
+    eq = np.abs(q1 - q).max(axis=1)
+    assert np.isfinite(q1).all() and np.median(eq) < 5e-5 and np.percentile(eq, 90) < 5e-3

@@ -178,3 +178,26 @@ def test_standing_anymal_carries_its_weight(anymal):
     assert abs(lam[:, 2].sum() - anymal.total_mass() * G * DT) < 1e-4
     assert np.all(np.hypot(lam[:, 0], lam[:, 1]) <= 0.8 * lam[:, 2] + 1e-9)
     assert np.abs(u).max() < 1e-3
+
+
+def test_joint_limit_stops_the_pendulum_inelastically(built_lib):
+    """Zero gravity, hinge with range [-0.3, 0.2]: a bob swinging at +1 rad/s stops at the upper limit (overshoot below
+    one step), is held there against a feed-forward torque, and leaves freely when the torque reverses."""
+    urdf = PENDULUM_URDF.format(l=0.5, m=1.0).replace('lower="-10" upper="10"', 'lower="-0.3" upper="0.2"')
+    _, o = make(urdf)
+    o.p.gravity[2] = 0.0
+    o.p.control_mode = 0
+    q = np.array([0, 0, 0, 1, 0, 0, 0, 0.0]); u = np.zeros(7); u[6] = 1.0
+    for k in range(120):
+        q, u, con, _, _ = o.step(q, u)
+        assert len(con) == 0                                  # limit rows are not contacts
+        if (k + 1) * DT < 0.19:
+            assert abs(u[6] - 1.0) < 1e-9
+    assert 0.2 < q[7] < 0.2 + 1.5 * DT and abs(u[6]) < 1e-9
+    tau = np.zeros(7); tau[6] = 3.0                           # pushes into the limit: nothing moves
+    for _ in range(40):
+        q, u, _, _, _ = o.step(q, u, None, None, None, None, tau)
+    assert 0.2 < q[7] < 0.2 + 1.5 * DT and abs(u[6]) < 1e-9
+    tau[6] = -3.0                                             # pulls away: free again, acceleration tau / (m l^2)
+    q, u, _, _, _ = o.step(q, u, None, None, None, None, tau)
+    assert abs(u[6] + 3.0 / (1.0 * 0.25 + 1e-9) * DT) < 1e-6
