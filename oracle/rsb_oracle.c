@@ -826,12 +826,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
     }
     /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
-    if (dbgG)
-      for (int i = 0; i < nc; ++i)
-        for (int j = 0; j < nc; ++j)
+    if (dbgG)   /* debug views cover the real contacts (joint-limit rows follow them and are left out) */
+      for (int i = 0; i < nreal; ++i)
+        for (int j = 0; j < nreal; ++j)
           for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) dbgG[(3 * i + r) * 3 * nc + 3 * j + c] = G[i][j][3 * r + c];
-    if (dbgc) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) dbgc[3 * i + r] = cfree[i][r];
+            for (int c = 0; c < 3; ++c) dbgG[(3 * i + r) * 3 * nreal + 3 * j + c] = G[i][j][3 * r + c];
+    if (dbgc) for (int i = 0; i < nreal; ++i) for (int r = 0; r < 3; ++r) dbgc[3 * i + r] = cfree[i][r];
     /* Convergence: largest impulse change of the sweep <= threshold * (largest normal impulse + floor).
      * A RELATIVE criterion on purpose: the device evaluates the same test in fp32, where the rounding
      * noise of an impulse update is proportional to the impulse magnitudes (RaiSim's absolute fp64
@@ -888,7 +888,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       fl |= 4;
       for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam[i][r] = lam_best[i][r];
     }
-    if (dbglam) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) dbglam[3 * i + r] = lam[i][r];
+    if (dbglam) for (int i = 0; i < nreal; ++i) for (int r = 0; r < 3; ++r) dbglam[3 * i + r] = lam[i][r];
     for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) sdir_out[i][r] = sdir[i][r];
   }
 

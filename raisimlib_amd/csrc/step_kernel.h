@@ -938,9 +938,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
       RSB_STAMP(5)
 
-      if (a.dbg && env == a.dbg_env && env_valid && s == 0) {   // debug aid: the contact problem as the solver sees it
-        const int n3 = 3 * nc;
-        a.dbg[0] = (float)nc;
+      if (a.dbg && env == a.dbg_env && env_valid && s == 0) {   // debug aid: the contact problem of the real contacts (no limit rows)
+        const int n3 = 3 * nc_real;
+        a.dbg[0] = (float)nc_real;
         for (int i = 0; i < n3; ++i)
           for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + 4 * (j / 3) + (j % 3)];
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
       if (a.prof) { t_gs += clock64() - t_gs0; int itw = iters_used; RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) itw = max(itw, __shfl_xor(itw, off)); p_iters += itw; p_ncw = max(p_ncw, ncw); }
       if (a.dbg && env == a.dbg_env && env_valid && s == 0) {
-        const int n3 = 3 * nc;
+        const int n3 = 3 * nc_real;
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + n3 + i] = LAM[i];
       }
     } else if (a.warm) {
