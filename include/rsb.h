@@ -194,6 +194,10 @@ int rsb_set_ground(rsb_world* w, double height);
 /* heights: host pointer, row-major [y_samples][x_samples] (x fastest), shared by all envs */
 int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size, double y_size,
                       double center_x, double center_y, const float* heights);
+/* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
+ * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */
+int rsb_set_heightmaps(rsb_world* w, int n_maps, int x_samples, int y_samples, double x_size, double y_size,
+                       double center_x, double center_y, const float* heights, const int32_t* env_map);
 
 /* ---- height-map sources (host side, no GPU needed): fill a [y_samples][x_samples] float buffer for rsb_set_heightmap.
  * Upstream counterparts [RECALL, absent]: World::addHeightMap(pngFile, centerX, centerY, xSize, ySize, heightScale,

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "rsb_get_lanes_per_env": (_I, [_VP]),
     "rsb_set_ground": (_I, [_VP, _D]),
     "rsb_set_heightmap": (_I, [_VP, _I, _I, _D, _D, _D, _D, _FP]),
+    "rsb_set_heightmaps": (_I, [_VP, _I, _I, _I, _D, _D, _D, _D, _FP, _FP]),
     "rsb_heightmap_png_size": (_I, [_CP, C.POINTER(_I), C.POINTER(_I)]),
     "rsb_heightmap_png_read": (_I, [_CP, _D, _D, _FP, _I]),
     "rsb_heightmap_perlin": (_I, [C.POINTER(TerrainProperties), _FP]),

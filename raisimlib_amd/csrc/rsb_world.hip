@@ -45,6 +45,7 @@ struct rsb_world {
   uint8_t* d_tmp_mask = nullptr;
   float *d_M = nullptr, *d_h = nullptr;
   int32_t* d_obs_idx = nullptr;
+  int32_t* d_hm_index = nullptr;   // [N] height map of each env (rsb_set_heightmaps), NULL: all envs share map 0
   float* d_warm = nullptr;   // [N, 6*ncol] contact-solver warm state (impulse, friction direction per collision primitive)
   bool warm_start = true;
   bool early_term = false;   // rsb_set_early_termination
@@ -406,6 +407,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.kp = w->d_kp; a.kd = w->d_kd;
   a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
   a.heights = w->d_heights;
+  a.hm_index = w->d_hm_index;
   a.warm = w->warm_start ? w->d_warm : nullptr;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
   if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; }
@@ -545,7 +547,7 @@ int rsb_destroy(rsb_world* w) {
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_done, w->d_warm,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_done, w->d_warm, w->d_hm_index,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -650,15 +652,31 @@ int rsb_set_ground(rsb_world* w, double height) {
   w->terrain_type = 0; w->ground_z = height;
   return RSB_OK;
 }
-int rsb_set_heightmap(rsb_world* w, int xs, int ys, double x_size, double y_size, double cx, double cy, const float* heights) {
-  if (!w || !heights || xs < 2 || ys < 2 || !(x_size > 0) || !(y_size > 0)) { rsb::set_error("rsb_set_heightmap: bad argument"); return RSB_E_INVALID; }
+int rsb_set_heightmaps(rsb_world* w, int n_maps, int xs, int ys, double x_size, double y_size, double cx, double cy,
+                       const float* heights, const int32_t* env_map) {
+  if (!w || !heights || n_maps < 1 || xs < 2 || ys < 2 || !(x_size > 0) || !(y_size > 0) || (n_maps > 1 && !env_map)) {
+    rsb::set_error("rsb_set_heightmaps: bad argument");
+    return RSB_E_INVALID;
+  }
+  if (env_map)
+    for (int e = 0; e < w->N; ++e)
+      if (env_map[e] < 0 || env_map[e] >= n_maps) { rsb::set_error("rsb_set_heightmaps: env_map entry out of range"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipStreamSynchronize(w->stream));
   if (w->d_heights) { HIP_TRY(hipFree(w->d_heights)); w->d_heights = nullptr; }
-  HIP_TRY(hipMalloc(&w->d_heights, (size_t)xs * ys * sizeof(float)));
-  HIP_TRY(hipMemcpy(w->d_heights, heights, (size_t)xs * ys * sizeof(float), hipMemcpyHostToDevice));
+  if (w->d_hm_index) { HIP_TRY(hipFree(w->d_hm_index)); w->d_hm_index = nullptr; }
+  const size_t n = (size_t)n_maps * xs * ys;
+  HIP_TRY(hipMalloc(&w->d_heights, n * sizeof(float)));
+  HIP_TRY(hipMemcpy(w->d_heights, heights, n * sizeof(float), hipMemcpyHostToDevice));
+  if (env_map) {
+    HIP_TRY(hipMalloc(&w->d_hm_index, (size_t)w->N * sizeof(int32_t)));
+    HIP_TRY(hipMemcpy(w->d_hm_index, env_map, (size_t)w->N * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   w->terrain_type = 1; w->hm_xs = xs; w->hm_ys = ys; w->hm_xsize = x_size; w->hm_ysize = y_size; w->hm_cx = cx; w->hm_cy = cy;
   return RSB_OK;
+}
+int rsb_set_heightmap(rsb_world* w, int xs, int ys, double x_size, double y_size, double cx, double cy, const float* heights) {
+  return rsb_set_heightmaps(w, 1, xs, ys, x_size, y_size, cx, cy, heights, nullptr);
 }
 
 int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t* mask, int space) {

@@ -97,7 +97,8 @@ struct StepArgs {
   int32_t* contact_count;
   int32_t* flags;
   int32_t* iters;
-  const float* heights;
+  const float* heights;        // [n_maps][hm_ys][hm_xs]
+  const int32_t* hm_index;     // [N] height map of each env (NULL: every env uses map 0)
   float* warm;                 // [N, 6*ncol] solver warm state per collision primitive: impulse (3, contact frame), friction
                                // direction (2), direction valid; NULL = every solve starts cold
   // fused control-step epilogue / prologue (rsb_control_step); all optional
@@ -212,14 +213,14 @@ __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
 }
 
 // terrain height and unit normal under (x, y): plane or triangulated height map (oracle: orc_terrain)
-__device__ __forceinline__ void terrain_eval(const StepArgs& a, float x, float y, float& h, float* n) {
+__device__ __forceinline__ void terrain_eval(const StepArgs& a, const float* heights, float x, float y, float& h, float* n) {
   if (a.terrain_type == 0) { h = a.ground_z; n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; return; }
   float gx = (x - a.hm_x0) * a.hm_inv_dx, gy = (y - a.hm_y0) * a.hm_inv_dy;
   gx = fminf(fmaxf(gx, 0.f), (float)(a.hm_xs - 1));
   gy = fminf(fmaxf(gy, 0.f), (float)(a.hm_ys - 1));
   int ix = min((int)floorf(gx), a.hm_xs - 2), iy = min((int)floorf(gy), a.hm_ys - 2);
   float fx = gx - (float)ix, fy = gy - (float)iy;
-  const float* H = a.heights + iy * a.hm_xs + ix;
+  const float* H = heights + iy * a.hm_xs + ix;
   float h00 = H[0], h10 = H[1], h01 = H[a.hm_xs], h11 = H[a.hm_xs + 1];
   float sx, sy;
   if (fx >= fy) { sx = h10 - h00; sy = h11 - h10; } else { sx = h11 - h01; sy = h01 - h00; }
@@ -512,6 +513,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     DTG[i] = a.dtarget[(size_t)env * nv + i];
     TF[i] = a.tauff[(size_t)env * nv + i];
   }
+  const float* env_heights = a.heights;   // this env's height map (terrain curricula: rsb_set_heightmaps)
+  if (a.hm_index && a.terrain_type == 1) env_heights += (size_t)a.hm_index[env] * a.hm_xs * a.hm_ys;
   if (a.warm) for (int i = s; i < nwarm; i += LPE) WARM[i] = a.warm[(size_t)env * nwarm + i];
   int flag = 0, iters_used = 0, nc = 0;
   int nc_real = 0;     // contacts of the last sub-step without the joint-limit rows that follow them in the solver
@@ -655,7 +658,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float t[3], h;
         mat3_vec(P, pl, t);
         const float c[3] = {P[9] + t[0], P[10] + t[1], P[11] + t[2]};
-        terrain_eval(a, pbx + c[0], pby + c[1], h, n);
+        terrain_eval(a, env_heights, pbx + c[0], pby + c[1], h, n);
         const float dist = (pbz + c[2] - h) * n[2];
         dep = rad - dist;
         hit = dep > 0.f && !dead;

@@ -188,6 +188,14 @@ class BatchedWorld:
         check(self.L.rsb_set_heightmap(self.handle, int(x_samples), int(y_samples), float(x_size), float(y_size),
                                        float(center_x), float(center_y), _hp(h)), "rsb_set_heightmap")
 
+    def add_height_maps(self, heights, x_size, y_size, center_x, center_y, env_map):
+        """Terrain curricula: heights [n_maps, y_samples, x_samples], env_map [N] -> the map each env stands on."""
+        h = _host(heights, np.float32)
+        idx = _host(env_map, np.int32)
+        assert h.ndim == 3 and idx.shape == (self.N,)
+        check(self.L.rsb_set_heightmaps(self.handle, h.shape[0], h.shape[2], h.shape[1], float(x_size), float(y_size),
+                                        float(center_x), float(center_y), _hp(h), _hp(idx)), "rsb_set_heightmaps")
+
     def integrate(self, n_substeps=1):
         check(self.L.rsb_integrate(self.handle, int(n_substeps)), "rsb_integrate")
 

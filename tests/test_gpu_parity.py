@@ -325,3 +325,40 @@ def test_joint_limit_rows_parity(anymal):
     w.close()
     eq = np.abs(q1 - q).max(axis=1)
     assert np.isfinite(q1).all() and np.median(eq) < 5e-5 and np.percentile(eq, 90) < 5e-3
+
+
+def test_per_env_height_maps(anymal):
+    """Terrain curricula (rsb_set_heightmaps): three maps of different roughness, each env on its own; every env must
+    match a world that has only that env's map."""
+    from raisimlib_amd.world import heightmap_perlin
+    N = 96
+    maps = np.stack([heightmap_perlin(64, 64, 6.4, 6.4, frequency=f, z_scale=zs, seed=3 + i)
+                     for i, (f, zs) in enumerate([(0.2, 0.05), (0.5, 0.15), (0.9, 0.25)])])
+    env_map = np.arange(N) % 3
+    gc, gv = standing_states(N, seed=55, z=(0.55, 0.8))
+    gc[:, 0:2] *= 0.5
+    kp, kd = workload.anymal_gains()
+    w = BatchedWorld(anymal, N)
+    w.add_height_maps(maps, 6.4, 6.4, 0.0, 0.0, env_map)
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv)
+    w.integrate(40)
+    q, u = w.get_state(); cnt, _ = w.get_contacts()
+    w.close()
+    assert cnt.sum() > N
+    for k in range(3):
+        sel = np.where(env_map == k)[0]
+        w1 = BatchedWorld(anymal, len(sel))
+        w1.add_height_map(64, 64, 6.4, 6.4, 0.0, 0.0, maps[k])
+        w1.set_pd_gains(kp, kd); w1.set_pd_target(gc[sel], np.zeros((len(sel), 18))); w1.set_state(gc[sel], gv[sel])
+        w1.integrate(40)
+        q1, u1 = w1.get_state()
+        w1.close()
+        assert np.array_equal(q1, q[sel]) and np.array_equal(u1, u[sel])
+    # and the maps really are different terrains: on map 0 the envs of map 2 end up elsewhere
+    sel = np.where(env_map == 2)[0]
+    w0 = BatchedWorld(anymal, len(sel))
+    w0.add_height_map(64, 64, 6.4, 6.4, 0.0, 0.0, maps[0])
+    w0.set_pd_gains(kp, kd); w0.set_pd_target(gc[sel], np.zeros((len(sel), 18))); w0.set_state(gc[sel], gv[sel])
+    w0.integrate(40)
+    assert np.abs(w0.get_state()[0] - q[sel]).max() > 1e-3
+    w0.close()
