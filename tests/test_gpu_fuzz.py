@@ -73,3 +73,32 @@ def test_random_tree_one_step_parity(built_lib, seed):
     eq = np.abs(q1 - ref["q"]).max(axis=1)
     assert np.isfinite(q1).all() and np.isfinite(u1).all()
     assert eu[conv].max() < 2e-3 and np.median(eu) < 2e-5 and eq[conv].max() < 2e-5, (seed, n_links, eu[conv].max(), eq[conv].max())
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_tree_three_substeps_on_a_height_map(built_lib, seed):
+    """Same generator, three fused sub-steps (warm state in use from the second one) on a random Perlin terrain."""
+    from raisimlib_amd.world import heightmap_perlin
+    rng = np.random.default_rng(2000 + seed)
+    model = Model(urdf_string=random_urdf(rng, int(rng.integers(3, 9))))
+    nq, nv, N = model.nq, model.nv, 96
+    kmax = 16 if model.ncol > 8 else 8
+    H = heightmap_perlin(48, 48, 4.8, 4.8, frequency=0.6, z_scale=0.2, seed=int(rng.integers(1, 1000)))
+    hm = (48, 48, 4.8, 4.8, 0.0, 0.0, H)
+    gc = np.zeros((N, nq)); gc[:, 0:2] = rng.uniform(-1.5, 1.5, (N, 2)); gc[:, 2] = rng.uniform(0.0, 0.5, N)
+    qq = rng.normal(size=(N, 4)); gc[:, 3:7] = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+    gc[:, 7:] = rng.uniform(-0.4, 0.4, (N, nq - 7))
+    gv = rng.normal(size=(N, nv)) * 0.5
+    kp = np.zeros(nv, np.float32); kd = np.zeros(nv, np.float32); kp[6:] = 30.0; kd[6:] = 0.5
+    w = BatchedWorld(model, N); w.set_max_contacts(kmax); w.add_height_map(*hm)
+    o = Oracle(model.blob); o.p.kmax = kmax; o.set_heightmap(*hm)
+    dtg = np.zeros((N, nv))
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, dtg); w.set_state(gc, gv)
+    w.integrate(3)
+    q1, u1 = w.get_state(); fl = w.get_flags()
+    ref = o.step_batch(f32(gc), f32(gv), 3, kp.astype(np.float64), kd.astype(np.float64), f32(gc), dtg, lam_warm=o.new_warm_state(N))
+    w.close()
+    conv = ((ref["flags"] | fl) & 5) == 0
+    eu = np.abs(u1 - ref["u"]).max(axis=1) / (1 + np.abs(ref["u"]).max(axis=1))
+    assert np.isfinite(q1).all() and conv.mean() > 0.5
+    assert np.median(eu) < 5e-5 and np.percentile(eu[conv], 95) < 5e-3, (seed, np.median(eu), np.percentile(eu[conv], 95))
