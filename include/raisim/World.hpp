@@ -72,7 +72,7 @@ class BatchedWorld {
   double getWorldTime() const { return rsb_get_world_time(world_); }
   void setGravity(const Vec<3>& g) { RSB_CHECK(rsb_set_gravity(world_, g.data())); }
   void setERP(double erp, double = 0) { RSB_CHECK(rsb_set_erp(world_, erp)); }
-  void setDefaultMaterial(double friction, double /*restitution*/ = 0, double /*resThreshold*/ = 0) { RSB_CHECK(rsb_set_friction(world_, friction)); }
+  void setDefaultMaterial(double friction, double restitution = 0, double resThreshold = 0) { RSB_CHECK(rsb_set_material(world_, friction, restitution, resThreshold)); }
   void setContactSolverParam(double alpha_init, double alpha_min, double alpha_decay, int maxIter, double threshold) {
     RSB_CHECK(rsb_set_contact_solver_param(world_, alpha_init, alpha_min, alpha_decay, maxIter, threshold));
   }

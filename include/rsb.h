@@ -157,6 +157,9 @@ double rsb_get_world_time(const rsb_world* w);
 int rsb_set_gravity(rsb_world* w, const double g[3]);
 int rsb_set_erp(rsb_world* w, double erp);
 int rsb_set_friction(rsb_world* w, double mu);
+/* World::setDefaultMaterial(friction, restitution, resThreshold) [RECALL]: one material per world; a contact approaching
+ * faster than res_threshold (m/s) leaves with v_n+ = -restitution * v_n- (Newton restitution), slower ones are inelastic */
+int rsb_set_material(rsb_world* w, double mu, double restitution, double res_threshold);
 int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min,
                                  double alpha_decay, int max_iter, double threshold);
 /* Stagnation exit of the contact solver (not a RaiSim parameter): the Gauss-Seidel loop of an env stops when the

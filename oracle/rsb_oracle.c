@@ -284,6 +284,7 @@ void orc_default_params(orc_params* p) {
   p->freeze_after = 5;
   p->refine = 1;
   p->settle_tol = 1e-4;
+  p->restitution = 0.0; p->res_threshold = 0.0;
   p->warm_start = 1;  /* only has an effect when the caller carries a warm state (orc_step_warm / orc_step_batch with lam_warm):
                          8% fewer sweeps and 7x fewer global searches on the config-2 workload.  The device has no counterpart yet
                          (every rsb_integrate() sub-step starts cold), so parity tests and the CPU baseline run without a state. */
@@ -822,6 +823,11 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         cfree[i][r] = s;
       }
       cfree[i][2] -= p->erp * cdepth[i] / p->dt;
+      if (p->restitution > 0.0 && lim_sign[i] == 0.0) {   /* Newton restitution on the approach speed J u of this step */
+        double vn0 = 0;
+        for (int d = 0; d < nv; ++d) vn0 += Jc[i][2][d] * u[d];
+        if (vn0 < -p->res_threshold) cfree[i][2] += p->restitution * vn0;
+      }
       /* warm start: the impulse (contact frame) this collision primitive carried in the previous integrate() */
       for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
     }

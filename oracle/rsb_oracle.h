@@ -44,6 +44,8 @@ typedef struct orc_params {
                                 instead of a new global search (0 = always search) */
   double ground_z;
   double stall_factor;       /* ... and required improvement factor per window */
+  double restitution;        /* coefficient of restitution e of the (single) material: v_n+ = -e v_n- ... */
+  double res_threshold;      /* ... for approach speeds above this (m/s); slower impacts are inelastic */
   double settle_tol;         /* a refined friction direction that moved less than this (rad) is kept for the rest of the solve */
   double hm_xsize, hm_ysize, hm_cx, hm_cy;
   const float* hm_heights;   /* [ys][xs], x fastest */

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "rsb_set_gravity": (_I, [_VP, C.POINTER(C.c_double)]),
     "rsb_set_erp": (_I, [_VP, _D]),
     "rsb_set_friction": (_I, [_VP, _D]),
+    "rsb_set_material": (_I, [_VP, _D, _D, _D]),
     "rsb_set_contact_solver_param": (_I, [_VP, _D, _D, _D, _I, _D]),
     "rsb_set_solver_stagnation_exit": (_I, [_VP, _I, _D]),
     "rsb_set_solver_friction_lag": (_I, [_VP, _I, _I, _D]),

@@ -61,7 +61,7 @@ struct rsb_world {
   int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 5, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
-  double stall_factor = 0.5, settle_tol = 1e-4;
+  double stall_factor = 0.5, settle_tol = 1e-4, restitution = 0.0, res_threshold = 0.0;
   int lpe = 0, max_cl = 0;
   double world_time = 0;
   bool integrate1_valid = false;
@@ -424,7 +424,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.mu = (float)w->mu; a.erp = (float)w->erp;
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
   a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
-  a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol;
+  a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {
     double dx = w->hm_xsize / (w->hm_xs - 1), dy = w->hm_ysize / (w->hm_ys - 1);
@@ -603,6 +603,11 @@ int rsb_set_erp(rsb_world* w, double erp) { if (!w) return RSB_E_INVALID; w->erp
 int rsb_set_friction(rsb_world* w, double mu) {
   if (!w || mu < 0) { rsb::set_error("rsb_set_friction: mu must be >= 0"); return RSB_E_INVALID; }
   w->mu = mu;
+  return RSB_OK;
+}
+int rsb_set_material(rsb_world* w, double mu, double restitution, double res_threshold) {
+  if (!w || mu < 0 || restitution < 0 || restitution > 1 || res_threshold < 0) { rsb::set_error("rsb_set_material: mu >= 0, 0 <= restitution <= 1, res_threshold >= 0"); return RSB_E_INVALID; }
+  w->mu = mu; w->restitution = restitution; w->res_threshold = res_threshold;
   return RSB_OK;
 }
 int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min, double alpha_decay,

@@ -125,7 +125,7 @@ struct StepArgs {
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
   int max_iter, section_rounds, stall_window, freeze_after, refine;
-  float stall_factor, settle_tol;
+  float stall_factor, settle_tol, restitution, res_threshold;
   int terrain_type, hm_xs, hm_ys;
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
   LdsLayout L;
@@ -851,6 +851,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           Fres[3] = t[0]; Fres[4] = t[1]; Fres[5] = t[2];
           cross3(Vb, x, wxx);  // J u = t . (v_body + w_body x x)
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
+          // Newton restitution (oracle: "restitution"): the approach speed J u of this step re-enters the normal row
+          const float rest = (rr == 2 && lsgn == 0.f && a.restitution > 0.f && cv < -a.res_threshold) ? a.restitution * cv : 0.f;
           const bool limit_row = lsgn != 0.f;
           const bool empty_row = limit_row && rr < 2;
           if (limit_row) {   // unit generalized force s on the joint itself instead of a spatial impulse on the body
@@ -876,6 +878,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             cv += z[j] * wbb[j];
           }
           if (empty_row) cv = 0.f;
+          cv += rest;
           st4(Wc, z); Wc[4] = z[4]; Wc[5] = z[5];
           if (rr == 2) cv -= a.erp * CN[3] / dt;
           CV[c] = cv;

@@ -146,6 +146,9 @@ class BatchedWorld:
     def set_erp(self, erp):
         check(self.L.rsb_set_erp(self.handle, float(erp)), "rsb_set_erp")
 
+    def set_default_material(self, mu, restitution=0.0, res_threshold=0.0):
+        check(self.L.rsb_set_material(self.handle, float(mu), float(restitution), float(res_threshold)), "rsb_set_material")
+
     def set_default_friction(self, mu):
         check(self.L.rsb_set_friction(self.handle, float(mu)), "rsb_set_friction")
 

@@ -134,3 +134,22 @@ def test_joint_limit_stops_the_pendulum_inelastically(built_lib):
     _, u = w.get_state()
     assert np.allclose(u[:, 6], -3.0 / 0.25 * DT, rtol=1e-4)
     w.close()
+
+
+def test_restitution_bounces_the_ball(built_lib):
+    _, w = world(sphere_urdf(2.0, 0.1))
+    w.set_default_material(0.8, 0.5, 0.2)
+    w.set_state(tile([0, 0, 0.6, 1, 0, 0, 0]), tile(np.zeros(6)))
+    bounced, uz = 0, 0.0
+    for _ in range(1200):
+        w.integrate(1)
+        _, u = w.get_state(); cnt, _ = w.get_contacts()
+        if cnt[0] and uz < -0.2:
+            assert np.allclose(u[:, 2], -0.5 * uz, atol=2e-5)
+            bounced += 1
+        elif cnt[0] and uz <= 0:
+            assert np.abs(u[:, 2]).max() < 2e-5
+        uz = float(u[0, 2])
+    q, u = w.get_state()
+    assert bounced >= 3 and np.abs(u[:, 2]).max() < 2e-5 and np.abs(q[:, 2] - 0.1).max() < 2e-3
+    w.close()

@@ -201,3 +201,21 @@ def test_joint_limit_stops_the_pendulum_inelastically(built_lib):
     tau[6] = -3.0                                             # pulls away: free again, acceleration tau / (m l^2)
     q, u, _, _, _ = o.step(q, u, None, None, None, None, tau)
     assert abs(u[6] + 3.0 / (1.0 * 0.25 + 1e-9) * DT) < 1e-6
+
+
+def test_restitution_bounces_the_ball(built_lib):
+    """Newton restitution e = 0.5: the step in which the dropped sphere touches down returns it with -e x its approach
+    speed; below the threshold speed the contact is inelastic."""
+    _, o = make(sphere_urdf(2.0, 0.1))
+    o.p.restitution, o.p.res_threshold = 0.5, 0.2
+    q = np.array([0, 0, 0.6, 1, 0, 0, 0.0]); u = np.zeros(6)
+    bounced = 0
+    for _ in range(2000):
+        uz = u[2]
+        q, u, con, _, _ = o.step(q, u)
+        if len(con) and uz < -0.2:
+            assert abs(u[2] + 0.5 * uz) < 1e-9
+            bounced += 1
+        elif len(con) and uz <= 0:
+            assert abs(u[2]) < 1e-9                      # slow touch-down: inelastic, the ball stays down
+    assert bounced >= 3 and abs(u[2]) < 1e-9 and abs(q[2] - 0.1) < 1e-3
