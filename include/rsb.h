@@ -311,6 +311,9 @@ int rsb_last_kernel_ms(rsb_world* w, float* ms);
 /* on = 0: no events; 1: one event pair (rsb_last_kernel_ms); n > 1: a ring of n event pairs, one per launch,
  * read back after the fact with rsb_read_kernel_ms (no per-launch synchronisation). */
 int rsb_enable_timing(rsb_world* w, int on);
+/* bracket only every stride-th launch (default 1): an event pair costs ~7 us of stream time per launch, 5 % of a
+ * 0.16 ms control step, so a benchmark samples its timed region instead of bracketing all of it */
+int rsb_set_timing_stride(rsb_world* w, int stride);
 /* durations (ms) of the last min(n, launches recorded) step-kernel launches, oldest first; synchronises the
  * stream; returns how many were written (or a negative status) */
 int rsb_read_kernel_ms(rsb_world* w, float* ms, int n);

@@ -128,6 +128,7 @@ PROTOTYPES = {
     "rsb_device_ptr": (_VP, [_VP, _I]),
     "rsb_last_kernel_ms": (_I, [_VP, C.POINTER(C.c_float)]),
     "rsb_enable_timing": (_I, [_VP, _I]),
+    "rsb_set_timing_stride": (_I, [_VP, _I]),
     "rsb_read_kernel_ms": (_I, [_VP, _FP, _I]),
     "rsb_control_step": (_I, [_VP, _FP, _FP, _I, _FP, _FP, _I, _FP, _I, _FP, _FP, _I]),
     "rsb_debug_select_env": (_I, [_VP, _I]),

@@ -78,6 +78,8 @@ struct rsb_world {
   uint8_t* d_env_done = nullptr;
   std::vector<hipEvent_t> ring0, ring1;   // event pairs around the most recent step-kernel launches (rsb_enable_timing(w, n))
   size_t ring_next = 0, ring_count = 0;
+  int timing_stride = 1;       // events bracket every timing_stride-th launch only (an event pair costs ~7 us of stream time)
+  long long launch_index = 0;
   float last_ms = -1.f;
 };
 
@@ -439,8 +441,9 @@ int do_integrate(rsb_world* w, int nsub) {
   a.prof_fine = prof_fine ? 1 : 0;
   a.lds_floats = (int)(lds_bytes / sizeof(float));
   hipEvent_t e0 = w->ev0, e1 = w->ev1;
-  if (w->timing && !w->ring0.empty()) { e0 = w->ring0[w->ring_next]; e1 = w->ring1[w->ring_next]; }
-  if (w->timing) HIP_TRY(hipEventRecord(e0, w->stream));
+  const bool rec = w->timing && (w->launch_index++ % w->timing_stride == 0);
+  if (rec && !w->ring0.empty()) { e0 = w->ring0[w->ring_next]; e1 = w->ring1[w->ring_next]; }
+  if (rec) HIP_TRY(hipEventRecord(e0, w->stream));
   // kernel classes by (longest chain, deepest body level): <=4/<=4 (quadrupeds), <=8/<=12 (humanoids), <=16/<=16
   const int mcl = w->max_cl, mlv = w->blob.depth - 1;
   if (mcl <= 4 && mlv <= 4) {
@@ -454,7 +457,7 @@ int do_integrate(rsb_world* w, int nsub) {
     return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
-  if (w->timing) {
+  if (rec) {
     HIP_TRY(hipEventRecord(e1, w->stream));
     if (!w->ring0.empty()) { w->ring_next = (w->ring_next + 1) % w->ring0.size(); if (w->ring_count < w->ring0.size()) ++w->ring_count; }
   }
@@ -1125,11 +1128,17 @@ int rsb_enable_timing(rsb_world* w, int on) {
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
   for (hipEvent_t e : w->ring1) (void)hipEventDestroy(e);
   w->ring0.clear(); w->ring1.clear(); w->ring_next = w->ring_count = 0;
+  w->launch_index = 0;
   w->timing = on != 0;
   if (on > 1) {
     w->ring0.resize(on); w->ring1.resize(on);
     for (int i = 0; i < on; ++i) { HIP_TRY(hipEventCreate(&w->ring0[i])); HIP_TRY(hipEventCreate(&w->ring1[i])); }
   }
+  return RSB_OK;
+}
+int rsb_set_timing_stride(rsb_world* w, int stride) {
+  if (!w || stride < 1) return RSB_E_INVALID;
+  w->timing_stride = stride; w->launch_index = 0;
   return RSB_OK;
 }
 int rsb_read_kernel_ms(rsb_world* w, float* ms, int n) {

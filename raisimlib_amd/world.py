@@ -304,6 +304,9 @@ class BatchedWorld:
         """False/0: off; True/1: one event pair (last_kernel_ms); n > 1: ring of n event pairs (read_kernel_ms)."""
         check(self.L.rsb_enable_timing(self.handle, int(on)), "rsb_enable_timing")
 
+    def set_timing_stride(self, stride):
+        check(self.L.rsb_set_timing_stride(self.handle, int(stride)), "rsb_set_timing_stride")
+
     def read_kernel_ms(self, n):
         """Durations (ms) of the last n step-kernel launches (oldest first); synchronises the stream."""
         out = np.zeros(int(n), np.float32)
