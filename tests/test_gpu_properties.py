@@ -371,3 +371,32 @@ def test_early_termination_freezes_the_env_at_its_first_illegal_contact(anymal):
         assert np.array_equal(ob_e[e, :19], qb[e]) and np.array_equal(ob_e[e, 19:37], ub[e])   # frozen before that sub-step
         assert np.all(ob_e[e, 37:] == 0)                                  # its contacts carry no impulse
         assert np.array_equal(q_e[e], init_q[e].astype(np.float32))       # and it was reset
+
+
+def test_lanes_per_env_variants_run_the_full_control_step(anymal):
+    """The 32- and 64-lane mappings through the fused control step (warm start, resets, observation) over several
+    control steps: same terminations and, for envs that stayed clear of resets, the same trajectories up to fp32."""
+    import torch
+    N = 256
+    feet = anymal.collision_indices("_foot")
+    gc, gv = workload.anymal_initial_state(N)
+    gc[:, 2] = 0.52
+    kp, kd = workload.anymal_gains()
+    g0 = torch.from_numpy(gc.astype(np.float32)).cuda(); v0 = torch.from_numpy(gv.astype(np.float32)).cuda()
+    outs = {}
+    for lpe in (16, 32, 64):
+        w = BatchedWorld(anymal, N); w.set_lanes_per_env(lpe)
+        w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv)
+        obs = torch.zeros((N, 49), device="cuda")
+        step = w.control_step_plan(4, obs.data_ptr(), feet, feet, g0.data_ptr(), v0.data_ptr(), N)
+        for k in range(12):
+            pt = torch.from_numpy(workload.anymal_targets(N, k, amplitude=0.5).astype(np.float32)).cuda()
+            step(pt.data_ptr()); w.synchronize()
+        outs[lpe] = w.get_state() + (obs.cpu().numpy().copy(),)
+        assert w.lanes_per_env() == lpe
+        w.close()
+    q16, u16, o16 = outs[16]
+    for lpe in (32, 64):
+        q, u, o = outs[lpe]
+        dq = np.abs(q - q16).max(1)
+        assert np.isfinite(q).all() and np.median(dq) < 1e-5 and (dq < 1e-3).mean() > 0.9, (lpe, np.median(dq), (dq < 1e-3).mean())
