@@ -71,6 +71,8 @@ def parse():
                          "(default: in line on the launch stream; the overlap could not be tried on >1 GPU here)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: do not bracket the step kernel with HIP events (roofline fields become null)")
+    ap.add_argument("--target-amplitude", type=float, default=0.3,
+                    help="diagnostic: amplitude (rad) of the uniform PD-target noise around the nominal pose (config 2: 0.3)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
     return ap.parse_args()
@@ -193,7 +195,7 @@ def main():
     gv0_d = torch.from_numpy(gv0.astype(np.float32)).to(dev)
     world.set_state(gc0, gv0)
     world.set_pd_target(None, np.zeros((N, model.nv), np.float32))
-    bank = [torch.from_numpy(workload.anymal_targets(N, k, env_offset=rank * N).astype(np.float32)).to(dev)
+    bank = [torch.from_numpy(workload.anymal_targets(N, k, env_offset=rank * N, amplitude=args.target_amplitude).astype(np.float32)).to(dev)
             for k in range(TARGET_BANK)]
     obs_dim = world.obs_dim(len(feet))
     # obs block of this rank and the gathered block of all ranks; with --overlap-collective double-buffered, so that the
@@ -286,7 +288,7 @@ def main():
             "config": {
                 "workload": "configs[1]: 4096 ANYmal-C-like (synthetic stand-in URDF) envs per GPU, flat ground, "
                             "dt=0.0025, 4 sub-steps per control step fused in one launch, PD kp=50 kd=0.2, targets = "
-                            "nominal + U(-0.3,0.3) rad per control step, per-env seed 1234+i"
+                            f"nominal + U(-{args.target_amplitude:g},{args.target_amplitude:g}) rad per control step, per-env seed 1234+i"
                             + (", non-foot contact -> reset (rsg_anymal rule)" if reset else ", no resets")
                             + (", EARLY TERMINATION at the sub-step of the first non-foot contact (not upstream's rule)" if args.early_termination else "")
                             + ", obs (q,u,foot force) gathered each control step",
