@@ -187,6 +187,14 @@ class ArticulatedSystem {
     for (int i = 0; i < nv; ++i) for (int j = 0; j < nv; ++j) M_(i, j) = M[((size_t)env_ * nv + i) * nv + j];
     return M_;
   }
+  const MatDyn& getInverseMassMatrix() {
+    const int nv = w_->dof();
+    std::vector<float> Mi((size_t)w_->numEnvs() * nv * nv);
+    RSB_CHECK(rsb_get_inverse_mass_matrix(w_->handle(), Mi.data(), RSB_HOST));
+    Minv_.resize(nv, nv);
+    for (int i = 0; i < nv; ++i) for (int j = 0; j < nv; ++j) Minv_(i, j) = Mi[((size_t)env_ * nv + i) * nv + j];
+    return Minv_;
+  }
   const VecDyn& getNonlinearities(const Vec<3>& /*gravity*/ = Vec<3>()) {
     const int nv = w_->dof();
     std::vector<float> h((size_t)w_->numEnvs() * nv);
@@ -327,7 +335,7 @@ class ArticulatedSystem {
   std::string name_;
   VecDyn gc_, gv_, h_;
   std::vector<double> fkR_, fkP_, fkA_;
-  MatDyn M_;
+  MatDyn M_, Minv_;
   std::vector<Contact> contacts_;
 };
 

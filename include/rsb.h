@@ -246,6 +246,8 @@ int rsb_get_contacts(rsb_world* w, int32_t* counts, rsb_contact* contacts, int s
 /* valid after rsb_integrate1: M [N,nv,nv], h [N,nv] */
 int rsb_get_mass_matrix(rsb_world* w, float* M, int space);
 int rsb_get_nonlinearities(rsb_world* w, float* h, int space);
+/* ArticulatedSystem::getInverseMassMatrix() [RECALL]: M(q)^-1 [N, nv, nv] of the state rsb_integrate1 saw (slow path) */
+int rsb_get_inverse_mass_matrix(rsb_world* w, float* Minv, int space);
 /* per-env status flags of the last launch (bit0: contact overflow, bit1: non-finite state, bit2: the contact
  * solver of the last sub-step stopped without meeting the convergence test: max_iter or stagnation exit) */
 int rsb_get_flags(rsb_world* w, int32_t* flags, int space);

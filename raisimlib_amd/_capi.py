@@ -115,6 +115,7 @@ PROTOTYPES = {
     "rsb_get_contacts": (_I, [_VP, _FP, _FP, _I]),
     "rsb_get_mass_matrix": (_I, [_VP, _FP, _I]),
     "rsb_get_nonlinearities": (_I, [_VP, _FP, _I]),
+    "rsb_get_inverse_mass_matrix": (_I, [_VP, _FP, _I]),
     "rsb_get_flags": (_I, [_VP, _FP, _I]),
     "rsb_get_solver_iterations": (_I, [_VP, _FP, _I]),
     "rsb_obs_dim": (_I, [_VP, _I]),

@@ -154,6 +154,44 @@ __global__ void __launch_bounds__(64) rsb_query_kernel(const QueryArgs a) {
   }
 }
 
+// M^-1 per env (slow path): Cholesky M = L L^T, L^-1 by forward substitution, M^-1 = L^-T L^-1, all in global memory.
+// work and out are [N, nv, nv]; M is left untouched.
+__global__ void __launch_bounds__(64) rsb_minv_kernel(const float* M, float* work, float* out, int N, int nv) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  const float* Ms = M + (size_t)env * nv * nv;
+  float* A = work + (size_t)env * nv * nv;
+  float* O = out + (size_t)env * nv * nv;
+  for (int i = 0; i < nv * nv; ++i) A[i] = Ms[i];
+  for (int j = 0; j < nv; ++j) {
+    float d = A[j * nv + j];
+    for (int k = 0; k < j; ++k) d -= A[j * nv + k] * A[j * nv + k];
+    d = sqrtf(d);
+    A[j * nv + j] = d;
+    const float id = 1.0f / d;
+    for (int i = j + 1; i < nv; ++i) {
+      float sacc = A[i * nv + j];
+      for (int k = 0; k < j; ++k) sacc -= A[i * nv + k] * A[j * nv + k];
+      A[i * nv + j] = sacc * id;
+    }
+  }
+  for (int i = 0; i < nv; ++i) {           // L -> L^-1 in the lower triangle, row by row
+    const float ii = 1.0f / A[i * nv + i];
+    for (int j = 0; j < i; ++j) {
+      float sacc = 0.f;
+      for (int k = j; k < i; ++k) sacc += A[i * nv + k] * (k == j ? A[j * nv + j] : A[k * nv + j]);
+      A[i * nv + j] = -sacc * ii;
+    }
+    A[i * nv + i] = ii;
+  }
+  for (int a = 0; a < nv; ++a)
+    for (int b = 0; b <= a; ++b) {
+      float sacc = 0.f;
+      for (int k = a; k < nv; ++k) sacc += A[k * nv + a] * A[k * nv + b];
+      O[a * nv + b] = sacc; O[b * nv + a] = sacc;
+    }
+}
+
 inline int launch_query(const QueryArgs& a, int nb, hipStream_t stream) {
   const int threads = 64, blocks = (a.N + threads - 1) / threads;
   if (nb <= 16) hipLaunchKernelGGL(rsb_query_kernel<16>, dim3(blocks), dim3(threads), 0, stream, a);

@@ -43,7 +43,7 @@ struct rsb_world {
   float *d_kp = nullptr, *d_kd = nullptr, *d_heights = nullptr;
   float *d_tmp_gc = nullptr, *d_tmp_gv = nullptr;
   uint8_t* d_tmp_mask = nullptr;
-  float *d_M = nullptr, *d_h = nullptr;
+  float *d_M = nullptr, *d_h = nullptr, *d_Minv = nullptr, *d_Mwork = nullptr;
   int32_t* d_obs_idx = nullptr;
   int32_t* d_hm_index = nullptr;   // [N] height map of each env (rsb_set_heightmaps), NULL: all envs share map 0
   float* d_warm = nullptr;   // [N, 6*ncol] contact-solver warm state (impulse, friction direction per collision primitive)
@@ -549,7 +549,7 @@ int rsb_destroy(rsb_world* w) {
   (void)hipSetDevice(w->device);
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
-                  w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
+                  w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
                   w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_done, w->d_warm, w->d_hm_index,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -832,6 +832,19 @@ int rsb_get_mass_matrix(rsb_world* w, float* M, int space) {
   if (!w->integrate1_valid) { rsb::set_error("rsb_get_mass_matrix: call rsb_integrate1 first (state changed since)"); return RSB_E_STATE; }
   HIP_TRY(hipSetDevice(w->device));
   return copy_out(w, M, w->d_M, (size_t)w->N * w->blob.nv * w->blob.nv * sizeof(float), space);
+}
+int rsb_get_inverse_mass_matrix(rsb_world* w, float* Minv, int space) {
+  if (!w || !Minv) return RSB_E_INVALID;
+  if (!w->integrate1_valid) { rsb::set_error("rsb_get_inverse_mass_matrix: call rsb_integrate1 first (state changed since)"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t n = (size_t)w->N * w->blob.nv * w->blob.nv;
+  if (!w->d_Minv) {
+    HIP_TRY(hipMalloc(&w->d_Minv, n * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_Mwork, n * sizeof(float)));
+  }
+  hipLaunchKernelGGL(rsbq::rsb_minv_kernel, dim3((w->N + 63) / 64), dim3(64), 0, w->stream, w->d_M, w->d_Mwork, w->d_Minv, w->N, w->blob.nv);
+  HIP_TRY(hipGetLastError());
+  return copy_out(w, Minv, w->d_Minv, n * sizeof(float), space);
 }
 int rsb_get_nonlinearities(rsb_world* w, float* h, int space) {
   if (!w || !h) return RSB_E_INVALID;

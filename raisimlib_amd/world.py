@@ -257,6 +257,11 @@ class BatchedWorld:
         check(self.L.rsb_get_mass_matrix(self.handle, _hp(M), RSB_HOST), "rsb_get_mass_matrix")
         return M
 
+    def get_inverse_mass_matrix(self):
+        out = np.zeros((self.N, self.model.nv, self.model.nv), np.float32)
+        check(self.L.rsb_get_inverse_mass_matrix(self.handle, _hp(out), RSB_HOST), "rsb_get_inverse_mass_matrix")
+        return out
+
     def get_nonlinearities(self):
         h = np.empty((self.N, self.nv), np.float32)
         check(self.L.rsb_get_nonlinearities(self.handle, _hp(h), RSB_HOST), "rsb_get_nonlinearities")

@@ -238,12 +238,15 @@ def test_mass_matrix_and_nonlinearities_query(anymal, atlas):
         with pytest.raises(Exception, match="integrate1"):
             w.get_mass_matrix()
         w.integrate1()
-        M, h = w.get_mass_matrix(), w.get_nonlinearities()
+        M, h, Mi = w.get_mass_matrix(), w.get_nonlinearities(), w.get_inverse_mass_matrix()
         o = Oracle(model.blob)
         for e in range(N):
             Mr, hr = o.mass_matrix(f32(gc[e])), o.nonlinearities(f32(gc[e]), f32(gv[e]))
             assert np.abs(M[e] - Mr).max() <= 1e-5 * np.abs(Mr).max()
             assert np.abs(h[e] - hr).max() <= 2e-5 * (1 + np.abs(hr).max())
+            # getInverseMassMatrix: M^-1 M = I to fp32 accuracy for this conditioning (Atlas-like: cond(M) ~ 4e5)
+            assert np.abs(Mi[e].astype(np.float64) @ Mr - np.eye(model.nv)).max() < (5e-2 if model.nv > 20 else 2e-4)
+            assert np.abs(Mi[e] - Mi[e].T).max() == 0.0
         # integrate1 does not advance the state; integrate2 does (== integrate)
         q0, _ = w.get_state()
         assert np.array_equal(q0, gc.astype(np.float32))
