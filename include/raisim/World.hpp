@@ -28,6 +28,10 @@
 
 namespace raisim {
 
+namespace IntegrationScheme {
+enum Type : int { TRAPEZOID = 0, SEMI_IMPLICIT = 1, EULER = 2, RUNGE_KUTTA_4 = 3 };   // only SEMI_IMPLICIT (upstream's default) is implemented
+}
+
 namespace ControlMode {
 enum Type : int { FORCE_AND_TORQUE = RSB_FORCE_AND_TORQUE, PD_PLUS_FEEDFORWARD_TORQUE = RSB_PD_PLUS_FEEDFORWARD_TORQUE };
 }
@@ -169,6 +173,9 @@ class ArticulatedSystem {
   const VecDyn& getGeneralizedVelocity() { getRow(RSB_F_GV, gv_, w_->dof()); return gv_; }
 
   void setControlMode(ControlMode::Type m) { w_->setControlMode(m); }
+  void setIntegrationScheme(IntegrationScheme::Type scheme) {
+    RSFATAL_IF(scheme != IntegrationScheme::SEMI_IMPLICIT, "setIntegrationScheme: only SEMI_IMPLICIT is implemented");
+  }
   /// gains are shared by all replicas of the batched world (one robot model, one controller tuning)
   void setPdGains(const VecDyn& p, const VecDyn& d) {
     std::vector<float> kp(p.v.begin(), p.v.end()), kd(d.v.begin(), d.v.end());
@@ -239,6 +246,14 @@ class ArticulatedSystem {
     VecDyn tau((size_t)w_->dof());
     getRow(RSB_F_TAU_FF, tau, w_->dof());
     for (int d = 0; d < w_->dof(); ++d) tau[d] += J(0, d) * force[0] + J(1, d) * force[1] + J(2, d) * force[2];
+    putRow(RSB_F_TAU_FF, tau);
+  }
+  /// External torque (world frame) on `body`: generalized force J_rot^T t, same lifetime rule as setExternalForce
+  void setExternalTorque(size_t body, const Vec<3>& torque) {
+    MatDyn J; jac(body, J, true);
+    VecDyn tau((size_t)w_->dof());
+    getRow(RSB_F_TAU_FF, tau, w_->dof());
+    for (int d = 0; d < w_->dof(); ++d) tau[d] += J(0, d) * torque[0] + J(1, d) * torque[1] + J(2, d) * torque[2];
     putRow(RSB_F_TAU_FF, tau);
   }
   void clearExternalForces() { VecDyn tau((size_t)w_->dof()); putRow(RSB_F_TAU_FF, tau); }
@@ -396,6 +411,11 @@ class World {
   void setGravity(const Vec<3>& g) { need().setGravity(g); }
   void setERP(double erp, double erp2 = 0) { need().setERP(erp, erp2); }
   void setDefaultMaterial(double mu, double r = 0, double t = 0) { need().setDefaultMaterial(mu, r, t); }
+  /// one material per world: a pair property is accepted only for the ("default", "default") pair
+  void setMaterialPairProp(const std::string& m1, const std::string& m2, double mu, double r, double t) {
+    RSFATAL_IF(m1 != "default" || m2 != "default", "setMaterialPairProp: per-pair materials are not supported (one material per world)");
+    need().setDefaultMaterial(mu, r, t);
+  }
   void setContactSolverParam(double a0, double amin, double adec, int maxIter, double thr) { need().setContactSolverParam(a0, amin, adec, maxIter, thr); }
   void integrate() { need().integrate(1); }
   void integrate1() { need().integrate1(); }

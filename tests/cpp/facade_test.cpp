@@ -83,6 +83,14 @@ int main(int argc, char** argv) {
       for (int i = 0; i < 40; ++i) world.integrate();
       CHECK(std::fabs(anymal->getGeneralizedVelocity()[2]) < 0.05);     // free fall would be at -0.98 m/s by now
       anymal->clearExternalForces();
+      // a pure yaw torque on the floating base spins it about z and nothing else (no gravity coupling in free fall)
+      anymal->setState(gz, vz);
+      raisim::Vec<3> tq; tq[2] = 20.0;
+      anymal->setExternalTorque(0, tq);
+      anymal->setIntegrationScheme(raisim::IntegrationScheme::SEMI_IMPLICIT);
+      for (int i = 0; i < 20; ++i) world.integrate();
+      { const auto& uu = anymal->getGeneralizedVelocity(); CHECK(uu[5] > 0.05 && std::fabs(uu[3]) < 0.05 * uu[5] && std::fabs(uu[4]) < 0.05 * uu[5]); }
+      anymal->clearExternalForces();
       anymal->setState(gc, gv);
       for (int i = 0; i < 400; ++i) world.integrate();
       anymal->getGeneralizedCoordinate();   // refresh the cached row that `q` refers to
