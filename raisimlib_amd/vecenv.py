@@ -123,5 +123,32 @@ class VecEnv:
         out.sub_(self.ob_mean).div_(torch.sqrt(self.ob_var + eps)).clamp_(-clip, clip)
         return out
 
+    # -- the rest of RaisimGymVecEnv's surface [RECALL]: scaling files, seeds, no-op hooks ------------------------------
+    def save_scaling(self, dir_name, iteration):
+        """mean<iteration>.csv / var<iteration>.csv of the running observation statistics (upstream file names)."""
+        import os
+        np.savetxt(os.path.join(dir_name, f"mean{iteration}.csv"), self.ob_mean.cpu().numpy())
+        np.savetxt(os.path.join(dir_name, f"var{iteration}.csv"), self.ob_var.cpu().numpy())
+
+    def load_scaling(self, dir_name, iteration, count=1e5, device="cuda"):
+        import os
+        import torch
+        self.ob_mean = torch.from_numpy(np.loadtxt(os.path.join(dir_name, f"mean{iteration}.csv")).astype(np.float32)).to(device)
+        self.ob_var = torch.from_numpy(np.loadtxt(os.path.join(dir_name, f"var{iteration}.csv")).astype(np.float32)).to(device)
+        self.ob_count = float(count)
+
+    def seed(self, seed=None):
+        """The simulation itself is deterministic; randomness lives in the caller's actions."""
+        return seed
+
+    def curriculum_callback(self):
+        pass
+
+    def turn_on_visualization(self):
+        pass
+
+    def turn_off_visualization(self):
+        pass
+
     def close(self):
         self.world.close()

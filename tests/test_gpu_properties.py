@@ -321,6 +321,12 @@ def test_vecenv_running_observation_statistics(anymal):
     assert np.allclose(env.ob_var.cpu().numpy(), allraw.var(0), rtol=2e-2, atol=1e-5)
     z = (raw[-1] - allraw.mean(0)) / np.sqrt(allraw.var(0) + 1e-8)
     assert np.allclose(ob.cpu().numpy(), np.clip(z, -10, 10), rtol=2e-2, atol=2e-2)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:                  # scaling files round trip (upstream's mean<i>.csv / var<i>.csv)
+        env.save_scaling(d, 7)
+        m0, v0 = env.ob_mean.clone(), env.ob_var.clone()
+        env.ob_mean.zero_(); env.load_scaling(d, 7)
+        assert torch.allclose(env.ob_mean, m0, rtol=1e-6) and torch.allclose(env.ob_var, v0, rtol=1e-6)
     env.close()
 
 
