@@ -240,6 +240,11 @@ int rsb_set_generalized_force(rsb_world* w, const float* tau, int space);  /* [N
 int rsb_integrate(rsb_world* w, int n_substeps);
 int rsb_integrate1(rsb_world* w);
 int rsb_integrate2(rsb_world* w);
+/* World::integrate() of a SUBSET of the replicas: envs whose mask byte is 0 are not integrated and none of their rows
+ * (state, contacts, flags, warm state) is touched.  mask: uint8 [num_envs] in `space` (a host mask is staged to the
+ * device first).  This is what the per-env raisim::World views (include/raisim/World.hpp) flush through, so that N
+ * views calling integrate() cost one launch in which every env advances exactly once. */
+int rsb_integrate_masked(rsb_world* w, int n_substeps, const uint8_t* mask, int space);
 
 /* contacts of the last sub-step: counts [N] int32, contacts [N,kmax] rsb_contact */
 int rsb_get_contacts(rsb_world* w, int32_t* counts, rsb_contact* contacts, int space);
@@ -275,6 +280,10 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
 int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target, int n_substeps, float* obs_out,
                      const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
                      int n_allowed, const float* gc0, const float* gv0, int rows);
+
+/* done flags of the fused control step: when `done_device` (uint8 [num_envs], DEVICE memory, caller-owned) is set,
+ * every following rsb_control_step writes 1 for the envs it reset and 0 for the others (NULL switches it off). */
+int rsb_set_done_output(rsb_world* w, uint8_t* done_device);
 
 /* ---- device-resident vectorised env: the per-env observe / step / reward / terminate / reset of
  * VectorizedEnvironment<ENVIRONMENT> with rsg_anymal's task [RECALL raisimGymTorch/env/envs/rsg_anymal/Environment.hpp,

@@ -110,6 +110,8 @@ PROTOTYPES = {
     "rsb_set_pd_target": (_I, [_VP, _FP, _FP, _I]),
     "rsb_set_generalized_force": (_I, [_VP, _FP, _I]),
     "rsb_integrate": (_I, [_VP, _I]),
+    "rsb_integrate_masked": (_I, [_VP, _I, _VP, _I]),
+    "rsb_set_done_output": (_I, [_VP, _VP]),
     "rsb_integrate1": (_I, [_VP]),
     "rsb_integrate2": (_I, [_VP]),
     "rsb_get_contacts": (_I, [_VP, _FP, _FP, _I]),

@@ -2,45 +2,98 @@
 
 `python -m raisimlib_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.
 The .so stays in-tree (raisimlib_amd/lib/) so it travels to the GPU box with the repo snapshot.
+
+The fused step kernel has ten (LPE, KMAX, CL, ML) classes x {production, profiling}; each instance is its own object
+(step_instance.hip + five -D macros, list in step_launch.h) and the objects are compiled in parallel, so a clean build
+takes about a minute on 8 cores instead of several in one translation unit.  Objects are cached under
+raisimlib_amd/lib/obj/ and rebuilt when a source they depend on is newer.
 """
 import os
+import re
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "librsb.so")
-SOURCES = ["urdf_model.cpp", "terrain_io.cpp", "rsb_world.hip"]
-HEADERS = ["rsb_internal.h", "step_kernel.h", "query_kernel.h", os.path.join(ROOT, "include", "rsb.h")]
+OBJ = os.path.join(HERE, "lib", "obj")
+RSB_H = os.path.join(ROOT, "include", "rsb.h")
+HOST_SOURCES = {   # source -> headers it depends on
+    "urdf_model.cpp": ["rsb_internal.h", RSB_H],
+    "terrain_io.cpp": ["rsb_internal.h", RSB_H],
+    "rsb_world.hip": ["rsb_internal.h", "step_types.h", "step_launch.h", "query_kernel.h", RSB_H],
+}
+KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", RSB_H]
+# measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and
+# pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed at the stated parity tolerance
+# (2.5 ulp hardware approximations + Newton step instead)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 
 
-def _stale():
-    if not os.path.exists(OUT):
+def step_instances():
+    """[(lpe, kmax, cl, ml)] parsed from the RSB_STEP_INSTANCES line of step_launch.h (single source of truth)."""
+    txt = open(os.path.join(CSRC, "step_launch.h")).read()
+    line = re.search(r"RSB_STEP_INSTANCES:(.*)", txt).group(1)
+    return [tuple(int(x) for x in tok.split(",")) for tok in line.split()]
+
+
+def _path(p):
+    return p if os.path.isabs(p) else os.path.join(CSRC, p)
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(_path(d)) > t for d in deps)
 
 
-def build(force=False, verbose=True, extra_flags=()):
+def build(force=False, verbose=True, extra_flags=(), jobs=None):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: raisimlib_amd needs the ROCm toolchain (no CPU fallback exists)")
-    if not force and not _stale():
+    os.makedirs(OBJ, exist_ok=True)
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    tag = "_".join(f.strip("-").replace("=", "") for f in extra_flags)     # objects built with other flags do not mix
+    tasks = []   # (object path, command)
+    for src, deps in HOST_SOURCES.items():
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + (f".{tag}" if tag else "") + ".o")
+        if force or _newer(obj, [src] + deps):
+            tasks.append((obj, [hipcc, *FLAGS, *extra_flags, "-x", "hip", *inc, "-c", _path(src), "-o", obj]))
+    objs = [os.path.join(OBJ, os.path.splitext(src)[0] + (f".{tag}" if tag else "") + ".o") for src in HOST_SOURCES]
+    for lpe, kmax, cl, ml in step_instances():
+        for prof in (0, 1):
+            obj = os.path.join(OBJ, f"step_{lpe}_{kmax}_{cl}_{ml}_{prof}" + (f".{tag}" if tag else "") + ".o")
+            objs.append(obj)
+            if force or _newer(obj, KERNEL_DEPS):
+                tasks.append((obj, [hipcc, *FLAGS, *extra_flags, *inc, f"-DRSB_I_LPE={lpe}", f"-DRSB_I_KMAX={kmax}",
+                                    f"-DRSB_I_CL={cl}", f"-DRSB_I_ML={ml}", f"-DRSB_I_PROF={prof}", "-c",
+                                    _path("step_instance.hip"), "-o", obj]))
+    if not tasks and os.path.exists(OUT) and all(os.path.getmtime(o) <= os.path.getmtime(OUT) for o in objs):
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-Wall", "-Wno-unused-function",
-           # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles
-           # than it saves and pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed
-           # at the stated parity tolerance (2.5 ulp hardware approximations + Newton step instead)
-           "-fno-slp-vectorize", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-           *extra_flags, "-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + ["-lz"]   # zlib: PNG height maps
+
+    def run(task):
+        obj, cmd = task
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {os.path.basename(obj)}:\n{r.stdout}\n{r.stderr}")
+        if r.stderr.strip() and verbose:
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    jobs = jobs or int(os.environ.get("RSB_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(run, tasks))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-lz"]   # zlib: PNG height maps
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+        print(" ".join(link[:6]), f"... ({len(objs)} objects) -lz", file=sys.stderr)
+    subprocess.run(link, check=True)
     return OUT
 
 

@@ -18,7 +18,8 @@
 #include "query_kernel.h"
 #include "rsb.h"
 #include "rsb_internal.h"
-#include "step_kernel.h"
+#include "step_launch.h"
+#include "step_types.h"
 
 using rsbk::DevModel;
 using rsbk::LdsLayout;
@@ -48,6 +49,9 @@ struct rsb_world {
   int32_t* d_hm_index = nullptr;   // [N] height map of each env (rsb_set_heightmaps), NULL: all envs share map 0
   float* d_warm = nullptr;   // [N, 6*ncol] contact-solver warm state (impulse, friction direction per collision primitive)
   bool warm_start = true;
+  uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
+  const uint8_t* launch_mask = nullptr; // env mask of the next launch only (rsb_integrate_masked)
+  uint8_t* d_launch_mask = nullptr;     // staging for host masks
   bool early_term = false;   // rsb_set_early_termination
   std::vector<int32_t> obs_idx_host;   // what d_obs_idx currently holds (re-uploaded only when the caller's list changes)
   float* d_dbg = nullptr;
@@ -74,7 +78,7 @@ struct rsb_world {
   bool env_ready = false;
   rsb_env_config env_cfg{};
   unsigned long long env_allowed = 0;
-  float *d_env_mean = nullptr, *d_env_gc0 = nullptr, *d_env_gv0 = nullptr, *d_env_io = nullptr, *d_env_reward = nullptr;
+  float *d_env_mean = nullptr, *d_env_gc0 = nullptr, *d_env_gv0 = nullptr, *d_env_io = nullptr, *d_env_reward = nullptr, *d_env_tau2 = nullptr;
   uint8_t* d_env_done = nullptr;
   std::vector<hipEvent_t> ring0, ring1;   // event pairs around the most recent step-kernel launches (rsb_enable_timing(w, n))
   size_t ring_next = 0, ring_count = 0;
@@ -305,7 +309,7 @@ __device__ inline void env_write_obs(float* o, const float* q, const float* u, i
   env_rot_t(q, Rt);
   int k = 0;
   o[k++] = q[2];
-  o[k++] = Rt[6]; o[k++] = Rt[7]; o[k++] = Rt[8];   // body z-axis in the world (third column of R)
+  o[k++] = Rt[2]; o[k++] = Rt[5]; o[k++] = Rt[8];   // third ROW of the body->world rotation R (world z-axis in the body frame): rsg_anymal's rot.e().row(2)
   for (int j = 0; j < nj; ++j) o[k++] = q[7 + j];
   for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[0] + Rt[3 * i + 1] * u[1] + Rt[3 * i + 2] * u[2];
   for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[3] + Rt[3 * i + 1] * u[4] + Rt[3 * i + 2] * u[5];
@@ -313,7 +317,7 @@ __device__ inline void env_write_obs(float* o, const float* q, const float* u, i
 }
 
 // reward and termination from the state the control step ended in, then the reset of terminated envs
-__global__ void env_post_kernel(float* gc, float* gv, const float* pt, const float* dtg, const float* kp, const float* kd,
+__global__ void env_post_kernel(float* gc, float* gv, const float* tau2,
                                 const rsb_contact* contacts, int32_t* count, int32_t* flags, unsigned long long allowed,
                                 const float* gc0, const float* gv0, float* reward, uint8_t* done, int N, int nq, int nv,
                                 int kmax, float fwd_coeff, float fwd_clip, float torque_coeff, float terminal_reward,
@@ -331,13 +335,9 @@ __global__ void env_post_kernel(float* gc, float* gv, const float* pt, const flo
   float Rt[9];
   env_rot_t(q, Rt);
   const float vx = Rt[0] * u[0] + Rt[1] * u[1] + Rt[2] * u[2];
-  float t2 = 0.f;
-  for (int j = 6; j < nv; ++j) {
-    const float t = kp[j] * (pt[(size_t)e * nq + j + 1] - q[j + 1]) + kd[j] * (dtg[(size_t)e * nv + j] - u[j]);
-    t2 += t * t;
-  }
+  const float t2 = tau2[e];   // |actuator torque|^2 of the last sub-step, exported by the step kernel (upstream: getGeneralizedForce())
   const float r = fwd_coeff * fminf(fwd_clip, vx) + torque_coeff * t2;
-  if (reward) reward[e] = term ? terminal_reward : r;
+  if (reward) reward[e] = term ? r + terminal_reward : r;   // upstream perAgentStep: reward += terminalReward
   if (done) done[e] = term ? 1 : 0;
   if (term) {
     for (int i = 0; i < nq; ++i) q[i] = gc0[i];
@@ -366,21 +366,21 @@ __global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* 
 }
 
 template <int LPE, int KMAX, int CL, int ML>
-int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes) {
-  auto kern = rsbk::rsb_step_kernel<LPE, KMAX, CL, ML>;
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool prof) {
   constexpr int EPW = 64 / LPE;
-  int blocks = (w->N + EPW - 1) / EPW;
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds_bytes, w->stream, a);
-  HIP_TRY(hipGetLastError());
+  const int blocks = (w->N + EPW - 1) / EPW;
+  // the profiling instance carries the cycle stamps / contact-problem dump / LDS poisoning; production launches use the lean one
+  const hipError_t e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->stream)
+                            : rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
+  HIP_TRY(e);
   return RSB_OK;
 }
 
 template <int KMAX, int CL, int ML>
-int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe) {
-  if (lpe == 16) return launch_step<16, KMAX, CL, ML>(w, a, lds_bytes);
-  if (lpe == 32) return launch_step<32, KMAX, CL, ML>(w, a, lds_bytes);
-  return launch_step<64, KMAX, CL, ML>(w, a, lds_bytes);
+int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool prof) {
+  if (lpe == 16) return launch_step<16, KMAX, CL, ML>(w, a, lds_bytes, prof);
+  if (lpe == 32) return launch_step<32, KMAX, CL, ML>(w, a, lds_bytes, prof);
+  return launch_step<64, KMAX, CL, ML>(w, a, lds_bytes, prof);
 }
 
 int effective_lpe(const rsb_world* w) {
@@ -412,7 +412,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.hm_index = w->d_hm_index;
   a.warm = w->warm_start ? w->d_warm : nullptr;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
-  if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; }
+  if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; a.tau2_out = w->d_env_tau2; }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
@@ -440,6 +440,9 @@ int do_integrate(rsb_world* w, int nsub) {
   static const bool prof_fine = std::getenv("RSB_PROF_FINE") != nullptr;  // debug aid: also time searches / Newton steps / epilogues
   a.prof_fine = prof_fine ? 1 : 0;
   a.lds_floats = (int)(lds_bytes / sizeof(float));
+  const bool prof = a.prof != nullptr || a.dbg != nullptr || a.poison_lds != 0;
+  a.done_out = w->d_done_out;
+  a.env_mask = w->launch_mask; w->launch_mask = nullptr;
   hipEvent_t e0 = w->ev0, e1 = w->ev1;
   const bool rec = w->timing && (w->launch_index++ % w->timing_stride == 0);
   if (rec && !w->ring0.empty()) { e0 = w->ring0[w->ring_next]; e1 = w->ring1[w->ring_next]; }
@@ -447,11 +450,11 @@ int do_integrate(rsb_world* w, int nsub) {
   // kernel classes by (longest chain, deepest body level): <=4/<=4 (quadrupeds), <=8/<=12 (humanoids), <=16/<=16
   const int mcl = w->max_cl, mlv = w->blob.depth - 1;
   if (mcl <= 4 && mlv <= 4) {
-    st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe);
+    st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe, prof);
   } else if (mcl <= 8 && mlv <= 12) {
-    st = launch_lpe<16, 8, 12>(w, a, lds_bytes, lpe);
+    st = launch_lpe<16, 8, 12>(w, a, lds_bytes, lpe, prof);
   } else if (mcl <= 16 && mlv <= 16) {
-    st = launch_step<64, 16, 16, 16>(w, a, lds_bytes);
+    st = launch_step<64, 16, 16, 16>(w, a, lds_bytes, prof);
   } else {
     rsb::set_error("model outside the compiled kernel classes (chain length <= 16, tree depth <= 17)");
     return RSB_E_UNSUPPORTED;
@@ -496,7 +499,9 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   }
   if (device < 0 || device >= ndev) { rsb::set_error("rsb_create: device index out of range"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(device));
-  auto w = std::make_unique<rsb_world>();
+  // every early return below (HIP_TRY) goes through rsb_destroy, which frees whatever has been allocated so far
+  struct Destroyer { void operator()(rsb_world* p) const { rsb_destroy(p); } };
+  std::unique_ptr<rsb_world, Destroyer> w(new rsb_world());
   w->blob = m->blob;
   w->N = num_envs;
   w->device = device;
@@ -550,7 +555,7 @@ int rsb_destroy(rsb_world* w) {
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_done, w->d_warm, w->d_hm_index,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_hm_index, w->d_launch_mask,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -795,6 +800,26 @@ int rsb_integrate(rsb_world* w, int n_substeps) {
   return do_integrate(w, n_substeps);
 }
 
+int rsb_integrate_masked(rsb_world* w, int n_substeps, const uint8_t* mask, int space) {
+  if (!w || n_substeps < 1 || !mask) { rsb::set_error("rsb_integrate_masked: bad argument"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  const uint8_t* dmask = mask;
+  if (space == RSB_HOST) {
+    if (!w->d_launch_mask) HIP_TRY(hipMalloc(&w->d_launch_mask, (size_t)w->N));
+    HIP_TRY(hipMemcpyAsync(w->d_launch_mask, mask, (size_t)w->N, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));   // pageable host memory: the caller may reuse its buffer
+    dmask = w->d_launch_mask;
+  }
+  w->launch_mask = dmask;
+  return do_integrate(w, n_substeps);
+}
+
+int rsb_set_done_output(rsb_world* w, uint8_t* done_device) {
+  if (!w) return RSB_E_INVALID;
+  w->d_done_out = done_device;
+  return RSB_OK;
+}
+
 // integrate1(): collision detection + M, h for the CURRENT state, into query buffers.  The state is
 // not advanced; integrate2() then runs the fused step (which recomputes the same quantities from the
 // unchanged state, so the pair is equivalent to integrate()).
@@ -993,6 +1018,8 @@ int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* acti
     HIP_TRY(hipMalloc(&w->d_env_gv0, nv * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_env_io, N * od * sizeof(float)));      // staging for host-side action / observation buffers
     HIP_TRY(hipMalloc(&w->d_env_reward, N * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_env_tau2, N * sizeof(float)));
+    HIP_TRY(hipMemset(w->d_env_tau2, 0, N * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_env_done, N));
   }
   HIP_TRY(hipMemcpyAsync(w->d_env_mean, action_mean, nj * sizeof(float), hipMemcpyHostToDevice, w->stream));
@@ -1054,8 +1081,8 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   float* drew = space == RSB_DEVICE ? reward : (reward ? w->d_env_reward : nullptr);
   uint8_t* ddone = space == RSB_DEVICE ? done : (done ? w->d_env_done : nullptr);
   float* dob = ob_next ? (space == RSB_DEVICE ? ob_next : w->d_env_io) : nullptr;   // host staging: the action is consumed by now
-  hipLaunchKernelGGL(env_post_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_pt, w->d_dt,
-                     w->d_kp, w->d_kd, w->d_contacts, w->d_count, w->d_flags, w->env_allowed, w->d_env_gc0, w->d_env_gv0,
+  hipLaunchKernelGGL(env_post_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_env_tau2,
+                     w->d_contacts, w->d_count, w->d_flags, w->env_allowed, w->d_env_gc0, w->d_env_gv0,
                      drew, ddone, N, nq, nv, w->kmax, w->env_cfg.forward_vel_coeff, w->env_cfg.forward_vel_clip,
                      w->env_cfg.torque_coeff, w->env_cfg.terminal_reward, w->d_warm, 6 * w->blob.ncol, dob);
   HIP_TRY(hipGetLastError());

@@ -1,0 +1,24 @@
+// step_instance.hip — one instance of the fused step kernel (step_kernel.h) per object file.
+// Built by raisimlib_amd/build.py as   hipcc -c step_instance.hip -DRSB_I_LPE=16 -DRSB_I_KMAX=8 -DRSB_I_CL=4 -DRSB_I_ML=4 -DRSB_I_PROF=0
+// so that the ten kernel classes x {production, profiling} compile in parallel instead of in one 80 s translation unit.
+#include "step_kernel.h"
+#include "step_launch.h"
+
+#if !defined(RSB_I_LPE) || !defined(RSB_I_KMAX) || !defined(RSB_I_CL) || !defined(RSB_I_ML) || !defined(RSB_I_PROF)
+#error "step_instance.hip needs -DRSB_I_LPE= -DRSB_I_KMAX= -DRSB_I_CL= -DRSB_I_ML= -DRSB_I_PROF="
+#endif
+
+namespace rsbk {
+
+template <int LPE, int KMAX, int CL, int ML, bool PROF>
+hipError_t launch_step_instance(const StepArgs& a, int blocks, size_t lds_bytes, hipStream_t stream) {
+  auto kern = rsb_step_kernel<LPE, KMAX, CL, ML, PROF>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+
+template hipError_t launch_step_instance<RSB_I_LPE, RSB_I_KMAX, RSB_I_CL, RSB_I_ML, (RSB_I_PROF != 0)>(const StepArgs&, int, size_t, hipStream_t);
+
+}  // namespace rsbk

@@ -40,96 +40,9 @@
 #include <type_traits>
 
 #include "rsb.h"
+#include "step_types.h"
 
 namespace rsbk {
-
-constexpr int kMaxB = RSB_MAX_BODIES;
-constexpr int kMaxC = RSB_MAX_COLLISIONS;
-constexpr int kMaxCL = 16;       // longest supported chain
-constexpr int kBodySlot = 24;    // R9 r3 V6 A6 (A is reused for the delta-velocity of the final pass)
-constexpr int kUpSlot = 28;      // Ia21 Zc6 pad   (one per chain)
-constexpr int kFactSlot = 16;    // S6 UD6 rsD invD pad2
-constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
-constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevModel::bodyf)
-constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence test (== ORC_LAMBDA_FLOOR)
-constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
-constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
-constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
-constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
-
-struct DevModel {
-  int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
-  int nch, nclv, max_cl, max_cc;    // chains, chain levels, longest chain, max child chains of one body
-  int parent[kMaxB], level[kMaxB], jtype[kMaxB];
-  int anc[kMaxB * kMaxB];           // anc[b*depth + l] = ancestor of b at level l (l <= level[b]), else -1
-  // chains: ch_body[c*kMaxCL + k] = k-th body of chain c (root-most first)
-  int ch_len[kMaxB], ch_attach[kMaxB], ch_level[kMaxB], ch_body[kMaxB * kMaxCL];
-  int cc_start[kMaxB], cc_count[kMaxB], cc_list[kMaxB];  // chains hanging off each body
-  // bodyf[b]: 0-2 axis, 3 jtype (int bits), 4-6 ptree, 7 mass, 8-16 rtree, 17-19 com, 20-25 inertia,
-  //           26 armature, 27 damping, 28 effort, 29 q_lower, 30 q_upper
-  float bodyf[kMaxB][kModelSlot];
-  // fields used by the slow-path query kernel
-  float axis[kMaxB][4], ptree[kMaxB][4], rtree[kMaxB][12], com[kMaxB][4], inertia[kMaxB][8];
-  float mass[kMaxB], armature[kMaxB];
-  int col_body[kMaxC];
-  float col_pos[kMaxC][4];  // xyz, radius
-};
-
-struct LdsLayout {
-  // per-block tables (floats from the start of LDS)
-  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_cc, t_ccl, shared_total;
-  // per-env arrays (floats from the env base)
-  int q, u, pt, dtg, tf, body, ups, bacc, fact, wb, con, wc, cv, g, ginv, lam, warm;
-  int gstride;
-  int per_env;
-};
-
-struct StepArgs {
-  const DevModel* model;
-  float* gc;
-  float* gv;
-  const float* ptarget;
-  const float* dtarget;
-  const float* tauff;
-  const float* kp;
-  const float* kd;
-  rsb_contact* contacts;  // [N, kmax]
-  int32_t* contact_count;
-  int32_t* flags;
-  int32_t* iters;
-  const float* heights;        // [n_maps][hm_ys][hm_xs]
-  const int32_t* hm_index;     // [N] height map of each env (NULL: every env uses map 0)
-  float* warm;                 // [N, 6*ncol] solver warm state per collision primitive: impulse (3, contact frame), friction
-                               // direction (2), direction valid; NULL = every solve starts cold
-  // fused control-step epilogue / prologue (rsb_control_step); all optional
-  float* ptarget_store;        // p_target rows read from `ptarget` are also stored here (the world's own copy)
-  const float* act;            // [N, nv-6] actions (rsb_env_step): joint targets = act_mean + act_std * act, NULL = use ptarget
-  const float* act_mean;       // [nv-6]
-  float act_std;
-  float* obs_out;              // [N, nq + nv + 3*obs_slots]: q, u, contact force of obs_idx[slot] (last sub-step)
-  const int32_t* obs_idx;      // [obs_slots] collision primitive of each force slot (NULL: slot k = primitive k)
-  int obs_slots;
-  int early_term;              // an env stops integrating at the sub-step in which a contact outside `allowed` is detected
-  int do_reset;                // envs with a non-finite state or a contact outside `allowed` restart from gc0 / gv0
-  unsigned long long allowed;  // bit c set: collision primitive c may touch the terrain
-  const float* gc0;            // [reset_rows, nq], reset_rows = 1 or N
-  const float* gv0;
-  int reset_rows;
-  long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
-  float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)
-  int dbg_env;
-  int prof_fine;    // debug: stamp the inner solver blocks too (each stamp costs ~100 cycles)
-  int poison_lds;   // debug: fill the whole LDS allocation with NaNs first (catches reads of never-written LDS)
-  int lds_floats;
-  int N, nsub, kmax, control_mode;
-  float dt, gx, gy, gz, mu, erp;
-  float alpha_init, alpha_min, alpha_decay, threshold;
-  int max_iter, section_rounds, stall_window, freeze_after, refine;
-  float stall_factor, settle_tol, restitution, res_threshold;
-  int terrain_type, hm_xs, hm_ys;
-  float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
-  LdsLayout L;
-};
 
 // ------------------------------------------------------------------------------ small helpers
 #define RSB_UNROLL _Pragma("unroll")
@@ -378,7 +291,7 @@ __device__ __forceinline__ void inv3(const float* A, float* B) {
 __device__ __host__ constexpr int gv2sp(int a) { return a < 3 ? a + 3 : a - 3; }
 
 #define RSB_STAMP(i) \
-  if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[i] = clock64();
+  if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[i] = clock64();
 
 // rigid inertia (10 parameters about O) + bias force of a body given (R, r, V, A) and its constants MF
 // (DevModel::bodyf layout); Zout = dt * f
@@ -411,8 +324,9 @@ __device__ __forceinline__ void body_inertia(const float* Rb, const float* rb, c
 
 // ------------------------------------------------------------------------------- the kernel
 // LPE : lanes per env.  KMAX : contact capacity.  CL : chain-length capacity (>= model's longest chain).
-// ML : body-level capacity (>= depth-1).
-template <int LPE, int KMAX, int CL, int ML>
+// ML : body-level capacity (>= depth-1).  PROF : compile the cycle stamps / contact-problem dump / LDS poisoning of the
+// rsb_debug_* entry points in (the production instances carry none of it: fewer SGPRs, no branches in the solver loop).
+template <int LPE, int KMAX, int CL, int ML, bool PROF>
 __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int EPW = 64 / LPE;
@@ -420,8 +334,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   const int el = lane / LPE;
   const int s = lane - el * LPE;
   int env = blockIdx.x * EPW + el;
-  const bool env_valid = env < a.N;
+  bool env_valid = env < a.N;
   if (!env_valid) env = a.N - 1;
+  // masked launch (per-env raisim::World views, rsb_integrate_masked): a masked-off env runs along but writes nothing back
+  if (a.env_mask && !a.env_mask[env]) env_valid = false;
 
   const DevModel& m = *a.model;
   const int nb = m.nb, nq = m.nq, nv = m.nv, depth = m.depth, ncol = m.ncol, cw = m.cw;
@@ -457,7 +373,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   const int nwarm = 6 * ncol;
   const int GS = L.gstride;
 
-  if (a.poison_lds) {
+  if (PROF && a.poison_lds) {
     for (int i = lane; i < a.lds_floats; i += 64) lds[i] = __int_as_float(0x7fc00000);
     __syncthreads();
   }
@@ -521,13 +437,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   bool dead = false;   // early termination: this env no longer integrates (its contacts at that moment stay reported)
   int nc_dead = 0;
   long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
-  if (a.prof) t_start = clock64();
+  if (PROF && a.prof) t_start = clock64();
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
   __syncthreads();
 
+  float tsq = 0.f;     // this lane's share of |actuator torque|^2 in the current sub-step (StepArgs::tau2_out)
   for (int sub = 0; sub < a.nsub; ++sub) {
     RSB_STAMP(0)
+    tsq = 0.f;
     for (int i = s; i < 28; i += LPE) BACC[i] = 0.f;   // summed into by the level-1 chains at the end of the up pass (a barrier lies in between)
     // =========================== base body, redundantly on every lane =========================
     float R0[9], V0[6], A0[6], I10b[10], Zb[6];
@@ -629,6 +547,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             float Bpd = dt * (kdj + dt * kpj);
             const float eff = MF[28];
             if (eff > 0.f && fabsf(tau) > eff) { tau = tau > 0.f ? eff : -eff; Bpd = 0.f; }
+            tsq = fmaf(tau, tau, tsq);
             tau -= MF[27] * qd;
             cdtau[k] = dt * tau; carm[k] = MF[26] + Bpd; cqb[k] = qb; cqd[k] = qd;
           }
@@ -944,14 +863,14 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       __syncthreads();
       RSB_STAMP(5)
 
-      if (a.dbg && env == a.dbg_env && env_valid && s == 0) {   // debug aid: the contact problem of the real contacts (no limit rows)
+      if (PROF && a.dbg && env == a.dbg_env && env_valid && s == 0) {   // debug aid: the contact problem of the real contacts (no limit rows)
         const int n3 = 3 * nc_real;
         a.dbg[0] = (float)nc_real;
         for (int i = 0; i < n3; ++i)
           for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + 4 * (j / 3) + (j % 3)];
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
       }
-      long long t_gs0 = 0; if (a.prof) t_gs0 = clock64();
+      long long t_gs0 = 0; if (PROF && a.prof) t_gs0 = clock64();
       // ========================= per-contact Gauss-Seidel (lane = contact) ==========================
       // Lane j (< nc) owns contact j: its G rows, own block, velocity and impulse stay in registers.  Per
       // contact update the owner solves open/stick; the slip case is searched by the whole 16-lane row; the
@@ -1014,7 +933,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             });
           }
         }
-        if (a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
+        if (PROF && a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
         for (int it = 0; it < a.max_iter; ++it) {
           float err = 0.f, scale = 0.f;
           const bool active = isc && !done;
@@ -1038,7 +957,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               const bool slip = mine && !open && !stick;
               float ln[3];
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
-              if (a.prof) ++p_solves;
+              if (PROF && a.prof) ++p_solves;
               if (__any(slip)) {
                 // lagged friction direction: after freeze_after sweeps, or once a refinement no longer moved it (settled), a
                 // slipping contact keeps its last direction when the normal response along it is well conditioned
@@ -1054,15 +973,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                   const bool cand = slip && !frozen && sdv && a.refine != 0;
                   bool refined = false;
                   if (__any(cand)) {
-                    long long tn0 = 0; if (a.prof) { ++p_newton; if (a.prof_fine) tn0 = clock64(); }
+                    long long tn0 = 0; if (PROF && a.prof) { ++p_newton; if (a.prof_fine) tn0 = clock64(); }
                     float nx, ny, dstep;
                     refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny, dstep) && cand;
                     if (refined) { sdx = nx; sdy = ny; sset = fabsf(dstep) <= a.settle_tol; }
-                    if (a.prof && a.prof_fine) t_newt += clock64() - tn0;
+                    if (PROF && a.prof && a.prof_fine) t_newt += clock64() - tn0;
                   }
                   const bool need = slip && !frozen && !refined;
                   if (__any(need)) {
-                    long long ts0 = 0; if (a.prof) { ++p_search; if (a.prof_fine) ts0 = clock64(); }
+                    long long ts0 = 0; if (PROF && a.prof) { ++p_search; if (a.prof_fine) ts0 = clock64(); }
                     // the owner's 12 solve constants are broadcast; the row searches the direction together
                     SlipCoef kb;
                     kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
@@ -1072,7 +991,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                     float dxy[2];
                     slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, dxy);
                     if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; sset = false; }
-                    if (a.prof && a.prof_fine) t_srch += clock64() - ts0;
+                    if (PROF && a.prof && a.prof_fine) t_srch += clock64() - ts0;
                   }
                 }
                 // impulse along the kept / refined / searched direction: v_n^+ = 0 on the cone boundary
@@ -1092,7 +1011,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             }
           });
           scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
-          long long te0 = 0; if (a.prof && a.prof_fine) te0 = clock64();
+          long long te0 = 0; if (PROF && a.prof && a.prof_fine) te0 = clock64();
           if (!done) {
             ++iters_used;
             alpha = fmaxf(alpha * a.alpha_decay, a.alpha_min);
@@ -1109,7 +1028,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               }
             }
           }
-          if (a.prof && a.prof_fine) t_epi += clock64() - te0;
+          if (PROF && a.prof && a.prof_fine) t_epi += clock64() - te0;
           if (!__any(!done)) break;
         }
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
@@ -1141,8 +1060,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         }
       }
       __syncthreads();
-      if (a.prof) { t_gs += clock64() - t_gs0; int itw = iters_used; RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) itw = max(itw, __shfl_xor(itw, off)); p_iters += itw; p_ncw = max(p_ncw, ncw); }
-      if (a.dbg && env == a.dbg_env && env_valid && s == 0) {
+      if (PROF && a.prof) { t_gs += clock64() - t_gs0; int itw = iters_used; RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) itw = max(itw, __shfl_xor(itw, off)); p_iters += itw; p_ncw = max(p_ncw, ncw); }
+      if (PROF && a.dbg && env == a.dbg_env && env_valid && s == 0) {
         const int n3 = 3 * nc_real;
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + n3 + i] = LAM[i];
       }
@@ -1230,10 +1149,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     }
     if (nclv == 0) __syncthreads();
     RSB_STAMP(7)
-    if (a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
+    if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
-  if (a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
+  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
   // ---- results: LDS -> HBM (with the optional control-step epilogue: observation block, reset of terminated envs)
   if (env_valid) {
     bool bad = false;
@@ -1291,7 +1210,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       ct.collision = __float_as_int(CN[11]);
       a.contacts[(size_t)env * a.kmax + s] = ct;
     }
+    if (a.tau2_out) {
+      float t = tsq;
+      RSB_UNROLL for (int off = 1; off < LPE; off <<= 1) t += __shfl_xor(t, off);
+      if (s == 0) a.tau2_out[env] = t;
+    }
     if (s == 0) {
+      if (a.done_out) a.done_out[env] = term ? 1 : 0;
       a.contact_count[env] = term ? 0 : nc;   // a reset env starts its episode without contacts or flags
       a.flags[env] = term ? 0 : flag;
       a.iters[env] = iters_used;

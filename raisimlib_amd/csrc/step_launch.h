@@ -1,0 +1,21 @@
+// step_launch.h — host-callable launchers of the step kernel's instances.
+//
+// Each (LPE, KMAX, CL, ML, PROF) combination of rsbk::rsb_step_kernel is compiled in its own object file from
+// step_instance.hip (raisimlib_amd/build.py passes the five values as -D macros and builds the objects in parallel);
+// this header only declares the launcher template, so rsb_world.hip links against whichever instances were built.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "step_types.h"
+
+namespace rsbk {
+
+// the instance list, single source of truth for build.py (parsed there) and the dispatch in rsb_world.hip:
+// RSB_STEP_INSTANCES: 16,8,4,4 32,8,4,4 64,8,4,4 16,16,4,4 32,16,4,4 64,16,4,4 16,16,8,12 32,16,8,12 64,16,8,12 64,16,16,16
+
+// sets the dynamic-LDS attribute and launches `blocks` workgroups of one wavefront on `stream`
+template <int LPE, int KMAX, int CL, int ML, bool PROF>
+hipError_t launch_step_instance(const StepArgs& a, int blocks, size_t lds_bytes, hipStream_t stream);
+
+}  // namespace rsbk

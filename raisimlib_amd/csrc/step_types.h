@@ -1,0 +1,104 @@
+// step_types.h — argument / layout structs shared by the step kernel (step_kernel.h, device) and the host code that
+// fills them (rsb_world.hip).  Split out so that the host translation unit does not have to compile the kernel body:
+// every (LPE, KMAX, CL, ML, PROF) instance of the kernel is its own object file (step_instance.hip, built in parallel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rsb.h"
+
+namespace rsbk {
+
+constexpr int kMaxB = RSB_MAX_BODIES;
+constexpr int kMaxC = RSB_MAX_COLLISIONS;
+constexpr int kMaxCL = 16;       // longest supported chain
+constexpr int kBodySlot = 24;    // R9 r3 V6 A6 (A is reused for the delta-velocity of the final pass)
+constexpr int kUpSlot = 28;      // Ia21 Zc6 pad   (one per chain)
+constexpr int kFactSlot = 16;    // S6 UD6 rsD invD pad2
+constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
+constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevModel::bodyf)
+constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence test (== ORC_LAMBDA_FLOOR)
+constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
+constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
+constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
+constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
+
+struct DevModel {
+  int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
+  int nch, nclv, max_cl, max_cc;    // chains, chain levels, longest chain, max child chains of one body
+  int parent[kMaxB], level[kMaxB], jtype[kMaxB];
+  int anc[kMaxB * kMaxB];           // anc[b*depth + l] = ancestor of b at level l (l <= level[b]), else -1
+  // chains: ch_body[c*kMaxCL + k] = k-th body of chain c (root-most first)
+  int ch_len[kMaxB], ch_attach[kMaxB], ch_level[kMaxB], ch_body[kMaxB * kMaxCL];
+  int cc_start[kMaxB], cc_count[kMaxB], cc_list[kMaxB];  // chains hanging off each body
+  // bodyf[b]: 0-2 axis, 3 jtype (int bits), 4-6 ptree, 7 mass, 8-16 rtree, 17-19 com, 20-25 inertia,
+  //           26 armature, 27 damping, 28 effort, 29 q_lower, 30 q_upper
+  float bodyf[kMaxB][kModelSlot];
+  // fields used by the slow-path query kernel
+  float axis[kMaxB][4], ptree[kMaxB][4], rtree[kMaxB][12], com[kMaxB][4], inertia[kMaxB][8];
+  float mass[kMaxB], armature[kMaxB];
+  int col_body[kMaxC];
+  float col_pos[kMaxC][4];  // xyz, radius
+};
+
+struct LdsLayout {
+  // per-block tables (floats from the start of LDS)
+  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_cc, t_ccl, shared_total;
+  // per-env arrays (floats from the env base)
+  int q, u, pt, dtg, tf, body, ups, bacc, fact, wb, con, wc, cv, g, ginv, lam, warm;
+  int gstride;
+  int per_env;
+};
+
+struct StepArgs {
+  const DevModel* model;
+  float* gc;
+  float* gv;
+  const float* ptarget;
+  const float* dtarget;
+  const float* tauff;
+  const float* kp;
+  const float* kd;
+  rsb_contact* contacts;  // [N, kmax]
+  int32_t* contact_count;
+  int32_t* flags;
+  int32_t* iters;
+  const float* heights;        // [n_maps][hm_ys][hm_xs]
+  const int32_t* hm_index;     // [N] height map of each env (NULL: every env uses map 0)
+  float* warm;                 // [N, 6*ncol] solver warm state per collision primitive: impulse (3, contact frame), friction
+                               // direction (2), direction valid; NULL = every solve starts cold
+  // fused control-step epilogue / prologue (rsb_control_step); all optional
+  float* ptarget_store;        // p_target rows read from `ptarget` are also stored here (the world's own copy)
+  const float* act;            // [N, nv-6] actions (rsb_env_step): joint targets = act_mean + act_std * act, NULL = use ptarget
+  const float* act_mean;       // [nv-6]
+  float act_std;
+  float* obs_out;              // [N, nq + nv + 3*obs_slots]: q, u, contact force of obs_idx[slot] (last sub-step)
+  const int32_t* obs_idx;      // [obs_slots] collision primitive of each force slot (NULL: slot k = primitive k)
+  int obs_slots;
+  int early_term;              // an env stops integrating at the sub-step in which a contact outside `allowed` is detected
+  int do_reset;                // envs with a non-finite state or a contact outside `allowed` restart from gc0 / gv0
+  unsigned long long allowed;  // bit c set: collision primitive c may touch the terrain
+  const float* gc0;            // [reset_rows, nq], reset_rows = 1 or N
+  const float* gv0;
+  int reset_rows;
+  float* tau2_out;             // [N] optional: |actuator torque|^2 over the joints in the last sub-step (clipped PD + feed-forward), for the env reward
+  uint8_t* done_out;           // [N] optional: 1 for the envs this launch reset (do_reset), else 0 (rsb_set_done_output)
+  const uint8_t* env_mask;     // [N] optional: envs with 0 are not integrated and none of their rows is written (rsb_integrate_masked)
+  long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
+  float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)
+  int dbg_env;
+  int prof_fine;    // debug: stamp the inner solver blocks too (each stamp costs ~100 cycles)
+  int poison_lds;   // debug: fill the whole LDS allocation with NaNs first (catches reads of never-written LDS)
+  int lds_floats;
+  int N, nsub, kmax, control_mode;
+  float dt, gx, gy, gz, mu, erp;
+  float alpha_init, alpha_min, alpha_decay, threshold;
+  int max_iter, section_rounds, stall_window, freeze_after, refine;
+  float stall_factor, settle_tol, restitution, res_threshold;
+  int terrain_type, hm_xs, hm_ys;
+  float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
+  LdsLayout L;
+};
+
+}  // namespace rsbk

@@ -3,6 +3,12 @@
 Config 1/2: ANYmal-C-like stand-in on flat ground, dt = 0.0025, 4 sub-steps per control step,
 PD kp=50 / kd=0.2 on the 12 joints, targets = nominal + U(-0.3, 0.3) rad resampled per control step,
 per-env seed 1234+i, base xy jitter U(-0.1, 0.1) m, yaw U(-pi, pi).
+Config 3: the same robots on a shared 128 x 128 height map over 12.8 m x 12.8 m (smoothed noise, +-0.1 m, seed 7).
+Config 5: Atlas-like humanoid, standing PD (kp 200, kd 5) with U(-0.1, 0.1) rad target noise, kmax 16.
+
+Every random number is a pure function of (GLOBAL env index, control step, entry): env g draws from the
+counter-based stream keyed by seed0 + g, so a rank that owns envs [lo, hi) produces exactly rows lo..hi of the
+unsharded arrays ("per-env seed 1234+i", shard-invariant results).
 """
 import numpy as np
 
@@ -11,6 +17,31 @@ ANYMAL_INIT_HEIGHT = 0.60   # feet just above the ground with the stand-in's leg
 DT = 0.0025
 SUBSTEPS = 4
 KP, KD = 50.0, 0.2
+ATLAS_KP, ATLAS_KD = 200.0, 5.0
+ATLAS_INIT_HEIGHT = 0.95
+
+
+def _mix64(x):
+    """splitmix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def env_uniform(seeds, stream, count):
+    """U[0,1) numbers [len(seeds), count] (float64, 53 bits): entry (i, j) depends only on (seeds[i], stream, j).
+
+    Counter-based (splitmix64 of a key built from the three integers), so it can be evaluated for any subset of
+    envs, in any order, on any rank, with identical results."""
+    with np.errstate(over="ignore"):
+        s = np.asarray(seeds, np.uint64)[:, None]
+        j = np.arange(count, dtype=np.uint64)[None, :]
+        key = _mix64(s * np.uint64(0x9E3779B97F4A7C15) + np.uint64(stream) * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x2545F4914F6CDD1D))
+        x = _mix64(key + (j + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+_STREAM_INIT = 0xFFFFFFFF      # stream id of the initial-state draws; control step k uses stream k
 
 
 def anymal_gains(nv=18):
@@ -22,26 +53,49 @@ def anymal_gains(nv=18):
 
 
 def anymal_initial_state(n_envs, seed0=1234, env_offset=0, height=ANYMAL_INIT_HEIGHT):
-    """Per-env seeded initial state (gc [N,19], gv [N,18]) in float64."""
+    """Per-env seeded initial state (gc [N,19], gv [N,18]) in float64: env i of the call is global env env_offset + i."""
     gc = np.zeros((n_envs, 19))
     gv = np.zeros((n_envs, 18))
-    for i in range(n_envs):
-        rng = np.random.default_rng(seed0 + env_offset + i)
-        xy = rng.uniform(-0.1, 0.1, 2)
-        yaw = rng.uniform(-np.pi, np.pi)
-        gc[i, 0:2] = xy
-        gc[i, 2] = height
-        gc[i, 3] = np.cos(0.5 * yaw)
-        gc[i, 6] = np.sin(0.5 * yaw)
-        gc[i, 7:] = ANYMAL_NOMINAL_JOINTS
+    r = env_uniform(seed0 + env_offset + np.arange(n_envs), _STREAM_INIT, 3)
+    yaw = (2.0 * r[:, 2] - 1.0) * np.pi
+    gc[:, 0:2] = 0.2 * r[:, 0:2] - 0.1
+    gc[:, 2] = height
+    gc[:, 3] = np.cos(0.5 * yaw)
+    gc[:, 6] = np.sin(0.5 * yaw)
+    gc[:, 7:] = ANYMAL_NOMINAL_JOINTS
     return gc, gv
 
 
 def anymal_targets(n_envs, control_step, seed0=1234, env_offset=0, amplitude=0.3):
     """PD position targets [N,19] for one control step (base entries unused)."""
     pt = np.zeros((n_envs, 19))
-    rng = np.random.default_rng([seed0 + env_offset, control_step])
-    pt[:, 7:] = ANYMAL_NOMINAL_JOINTS + rng.uniform(-amplitude, amplitude, (n_envs, 12))
+    r = env_uniform(seed0 + env_offset + np.arange(n_envs), control_step, 12)
+    pt[:, 7:] = ANYMAL_NOMINAL_JOINTS + amplitude * (2.0 * r - 1.0)
+    pt[:, 3] = 1.0
+    return pt
+
+
+def atlas_gains(nv=36):
+    kp = np.zeros(nv, np.float32)
+    kd = np.zeros(nv, np.float32)
+    kp[6:] = ATLAS_KP
+    kd[6:] = ATLAS_KD
+    return kp, kd
+
+
+def atlas_initial_state(n_envs, nq=37, nv=36, height=ATLAS_INIT_HEIGHT):
+    """Config 5: every env starts upright at the nominal pose ("standing PD")."""
+    gc = np.zeros((n_envs, nq))
+    gc[:, 2] = height
+    gc[:, 3] = 1.0
+    return gc, np.zeros((n_envs, nv))
+
+
+def atlas_targets(n_envs, control_step, nq=37, seed0=77, env_offset=0, amplitude=0.1):
+    """Config 5 PD targets: zero pose + U(-amplitude, amplitude) rad per joint and control step, per-env seeded."""
+    pt = np.zeros((n_envs, nq))
+    r = env_uniform(seed0 + env_offset + np.arange(n_envs), control_step, nq - 7)
+    pt[:, 7:] = amplitude * (2.0 * r - 1.0)
     pt[:, 3] = 1.0
     return pt
 
@@ -67,3 +121,7 @@ def smoothed_heightmap(xs=128, ys=128, amplitude=0.1, seed=7, passes=3):
         h = (h + np.roll(h, 1, 0) + np.roll(h, -1, 0) + np.roll(h, 1, 1) + np.roll(h, -1, 1)) / 5.0
     h = h / np.abs(h).max() * amplitude
     return h.astype(np.float32)
+
+
+HEIGHTMAP_SIZE = 12.8          # config 3: 128 x 128 samples over 12.8 m x 12.8 m (0.1 m cells), centred on the origin
+HEIGHTMAP_CLEARANCE = 0.12     # initial base height is raised by this much so that no foot starts inside the +-0.1 m terrain
