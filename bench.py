@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — env-steps/s of the batched World::integrate() hot path on N MI355X (BASELINE.json metric).
 
-One "step" = one control step of the vectorised env = 4 x integrate() (dt = 0.0025) for 4096 ANYmal-C-like envs
-per GPU on flat ground (BASELINE.json configs[1]), i.e. 16384 env-steps per GPU per step, run as ONE fused kernel
-launch through the C-ABI (rsb_integrate(w, 4)).  Per step, inside the timed region, every rank also
-  - copies the control step's PD targets (nominal + U(-0.3,0.3) rad) into the world (device->device),
+One "step" = one control step of the vectorised env = 4 x integrate() (dt = 0.0025) for 4096 envs per GPU, i.e. 16384
+env-steps per GPU per step, run as ONE fused kernel launch through the C-ABI (rsb_control_step).  Per step, inside the
+timed region, every rank also
+  - reads the control step's PD targets (nominal + uniform noise, per-env seeded) in place,
   - applies rsg_anymal's termination rule on device (any non-foot contact -> reset that env),
-  - gathers the (q, u, foot contact force) observation block and, for N>1, all-gathers it over RCCL/xGMI.
-State is resident in HBM when the timed region starts.  Envs are sharded 4096 per rank (weak scaling); the
-only collective is the obs all-gather.
+  - writes the (q, u, foot contact force) observation block and, for N>1, all-gathers it over RCCL/xGMI.
+State is resident in HBM when the timed region starts.  Envs are sharded 4096 per rank (weak scaling); the only
+collective is the obs all-gather.
 
-Output: ONE JSON line on rank 0 (contract in the task statement) with `roofline` (HBM; algorithmic bytes from
-SURVEY.md §8d: 456 B per env-step x 16384 env-steps per launch, over the step kernel's mean launch time measured
-with HIP events on the launch stream) and `cpu_baseline` (the in-repo fp64 oracle, OpenMP over envs on the host
-cores, same workload recipe, bounded sample; rank 0, N=1 only).
+--config 2 (default, BASELINE.json configs[1], the configuration `metric` is quoted on): ANYmal-C-like envs on flat ground;
+--config 3: the same robots on a shared 128 x 128 height map; --config 5: Atlas-like humanoid, kmax 16.
+
+The regime is fixed by the bench, not by --steps / --warmup: PREROLL untimed control steps run first (the population of
+standing / falling / freshly reset robots is stationary after ~100 control steps), then --warmup, then the timed region.
+After the timed region a sampling pass of SAMPLE_LAUNCHES more control steps of the same sequence is run with every
+launch bracketed by HIP events on the launch stream (inside the library), so the kernel duration behind `roofline` never
+rests on a handful of brackets; the few brackets taken inside the timed region (every EVENT_STRIDE-th launch) are reported
+next to it.  The same pass counts resets per step and the env-age distribution (config.workload).
+
+Output: ONE JSON line on rank 0 with `roofline` (HBM; SURVEY.md §8d algorithmic bytes per env-step x env-steps per launch
+over the step kernel's mean launch duration) and `cpu_baseline` (the in-repo fp64 oracle, OpenMP over envs on the host
+cores, started from the GPU population's state at the start of the timed region; rank 0, N=1 only).
 """
 import argparse
 import json
@@ -27,27 +36,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
-BYTES_PER_ENV_STEP = 456.0        # SURVEY.md §8d contract number (unfused state traffic, fp32)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
-TARGET_BANK = 16                  # distinct pre-generated PD-target sets cycled through in the timed loop
-EVENT_STRIDE = 8                  # every 8th launch of the timed region is bracketed by HIP events
-
-
-def recorded_traffic(n_envs, substeps):
-    """HBM bytes per launch of the step kernel from the newest committed PMC pass (profiles/rNN_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command, tools/collect_profiles.sh).
-    The counters cannot be collected from inside this process, so the committed measurement is reported - only
-    when it was taken on this workload - together with its provenance; otherwise null."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-    if not files or n_envs != ENVS_PER_GPU or substeps != 4:
-        return None, None, None
-    try:
-        rec = json.load(open(files[-1]))
-        return float(rec["hbm_bytes_per_launch_raw"]), os.path.relpath(files[-1], ROOT) + \
-            " (FETCH_SIZE+WRITE_SIZE per launch, raw: gfx950 factors for 4 B/lane row accesses are uncalibrated)", rec
-    except Exception:
-        return None, None, None
+TARGET_BANK = 128                 # distinct pre-generated PD-target sets cycled through (per-env seeded, control step k -> set k % 128)
+EVENT_STRIDE = 8                  # inside the timed region every 8th launch is bracketed by HIP events (a bracket costs ~7 us of stream time)
+PREROLL = 200                     # untimed control steps before --warmup: the workload is the stationary population, whatever --warmup is
+SAMPLE_LAUNCHES = 64              # control steps of the post-timing sampling pass (every launch bracketed)
+# SURVEY.md §8d contract numbers: unfused state traffic per env-step, fp32
+BYTES_PER_ENV_STEP = {2: 456.0, 3: 520.0, 5: 1080.0}
 
 
 def parse():
@@ -55,7 +50,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
+                    help="BASELINE.json configs: 2 = ANYmal flat (headline), 3 = ANYmal on a 128x128 height map, 5 = Atlas-like")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--preroll", type=int, default=PREROLL, help="diagnostic: untimed control steps before --warmup")
     ap.add_argument("--max-iter", type=int, default=0, help="contact-solver iteration cap (0 = library default)")
     ap.add_argument("--lanes-per-env", type=int, default=0)
     ap.add_argument("--no-reset", action="store_true", help="disable the non-foot-contact termination rule")
@@ -70,69 +68,145 @@ def parse():
                     help="double-buffer the obs block and overlap the all-gather of step k with the kernel of step k+1 "
                          "(default: in line on the launch stream; the overlap could not be tried on >1 GPU here)")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="diagnostic: do not bracket the step kernel with HIP events (roofline fields become null)")
-    ap.add_argument("--target-amplitude", type=float, default=0.3,
-                    help="diagnostic: amplitude (rad) of the uniform PD-target noise around the nominal pose (config 2: 0.3)")
+                    help="diagnostic: no HIP-event brackets anywhere (roofline fields become null)")
+    ap.add_argument("--target-amplitude", type=float, default=-1.0,
+                    help="diagnostic: amplitude (rad) of the uniform PD-target noise (config 2/3: 0.3, config 5: 0.1)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
     return ap.parse_args()
 
 
-def cpu_baseline(model, feet, max_iter, reset, budget_s):
-    """Time the fp64 oracle (OpenMP over envs) on a bounded sample of the same workload.
+class Recipe:
+    """Everything that defines one BASELINE.json configuration: model, terrain, gains, initial state, targets."""
+
+    def __init__(self, config, amplitude):
+        from raisimlib_amd import Model, rsc_path, workload
+        self.config = config
+        self.wl = workload
+        if config == 5:
+            self.model = Model(urdf_path=rsc_path("atlas_like.urdf"))
+            self.kmax = 16
+            self.amp = amplitude if amplitude >= 0 else 0.1
+            self.kp, self.kd = workload.atlas_gains(self.model.nv)
+            self.feet = self.model.collision_indices("_foot_0") + self.model.collision_indices("_foot_1") + \
+                self.model.collision_indices("_foot_2") + self.model.collision_indices("_foot_3")
+            self.feet = sorted(self.feet)
+            self.name = ("configs[4]: 4096 Atlas-like humanoids (synthetic stand-in URDF, 31 bodies / 36 DoF, 18 collision spheres, "
+                         "kmax 16) per GPU, flat ground, implicit PD kp=200 kd=5, targets = zero pose + "
+                         f"U(-{self.amp:g},{self.amp:g}) rad per control step, per-env seed 77+i")
+            self.metric = "env-steps/sec, 4096 Atlas-like humanoid envs flat terrain dt=0.0025"
+        else:
+            self.model = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+            self.kmax = 8
+            self.amp = amplitude if amplitude >= 0 else 0.3
+            self.kp, self.kd = workload.anymal_gains(self.model.nv)
+            self.feet = self.model.collision_indices("_foot")
+            terrain = "flat ground" if config == 2 else \
+                "shared 128x128 height map over 12.8 m x 12.8 m (smoothed uniform noise, +-0.1 m, seed 7)"
+            self.name = (f"configs[{config - 1}]: 4096 ANYmal-C-like (synthetic stand-in URDF) envs per GPU, {terrain}, PD kp=50 kd=0.2, "
+                         f"targets = nominal + U(-{self.amp:g},{self.amp:g}) rad per control step, per-env seed 1234+i")
+            self.metric = "env-steps/sec, 4096 ANYmal-C envs flat terrain dt=0.0025" if config == 2 else \
+                "env-steps/sec, 4096 ANYmal-C envs on a 128x128 raisim::HeightMap dt=0.0025"
+        self.heights = workload.smoothed_heightmap(128, 128, amplitude=0.1, seed=7) if config == 3 else None
+
+    def initial_state(self, n, env_offset):
+        wl = self.wl
+        if self.config == 5:
+            return wl.atlas_initial_state(n, self.model.nq, self.model.nv)
+        gc, gv = wl.anymal_initial_state(n, env_offset=env_offset)
+        if self.config == 3:
+            gc[:, 2] += wl.HEIGHTMAP_CLEARANCE
+        return gc, gv
+
+    def targets(self, n, k, env_offset):
+        if self.config == 5:
+            return self.wl.atlas_targets(n, k, self.model.nq, env_offset=env_offset, amplitude=self.amp)
+        return self.wl.anymal_targets(n, k, env_offset=env_offset, amplitude=self.amp)
+
+    def setup_world(self, world):
+        wl = self.wl
+        if self.kmax != 8:
+            world.set_max_contacts(self.kmax)
+        world.set_time_step(wl.DT)
+        world.set_pd_gains(self.kp, self.kd)
+        if self.heights is not None:
+            world.add_height_map(128, 128, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, self.heights)
+
+    def setup_oracle(self, orc):
+        orc.p.kmax = self.kmax
+        if self.heights is not None:
+            wl = self.wl
+            orc.set_heightmap(128, 128, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, self.heights)
+
+
+def recorded_traffic(config, n_envs, substeps):
+    """HBM bytes per launch of the step kernel from the newest committed PMC pass of this configuration
+    (profiles/rNN_pmc_traffic*.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over this same command,
+    tools/collect_profiles.sh).  The counters cannot be collected from inside this process, so the committed measurement
+    is reported - only when it was taken on this workload - together with its provenance; otherwise null."""
+    import glob
+    pat = "r*_pmc_traffic.json" if config == 2 else f"r*_pmc_traffic_config{config}.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+    if not files or n_envs != ENVS_PER_GPU or substeps != 4:
+        return None, None, None
+    try:
+        rec = json.load(open(files[-1]))
+        val = rec.get("hbm_bytes_per_launch", rec.get("hbm_bytes_per_launch_raw"))
+        return float(val), os.path.relpath(files[-1], ROOT) + " (" + rec.get("note", "FETCH_SIZE+WRITE_SIZE per launch") + ")", rec
+    except Exception:
+        return None, None, None
+
+
+def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, step0):
+    """Time the fp64 oracle (OpenMP over envs) on a bounded sample of the same workload: it starts from the state the GPU
+    population had at the start of the timed region (so both legs see the same stationary mix of standing, falling and
+    freshly reset robots) and continues the same target sequence.
 
     The container's visible core count can exceed its CPU quota, so the leg first probes a few thread counts for
     ~1 s each and then spends the budget at the fastest one; `cores` reports the threads actually used.
     """
     from oracle.pyoracle import Oracle  # the CPU baseline leg is one of the three allowed oracle users
     from raisimlib_amd import workload
+    model = recipe.model
     orc = Oracle(model.blob)
+    recipe.setup_oracle(orc)
     if max_iter > 0:
         orc.p.max_iter = max_iter
-    n = 4096
-    gc0, gv0 = workload.anymal_initial_state(n)
-    kp, kd = workload.anymal_gains()
-    kp, kd = kp.astype(np.float64), kd.astype(np.float64)
+    n = q0.shape[0]
+    kp, kd = recipe.kp.astype(np.float64), recipe.kd.astype(np.float64)
     dtg = np.zeros((n, model.nv))
     feet_set = np.zeros(model.ncol, bool)
-    feet_set[feet] = True
-    state = {"q": gc0.astype(np.float32).astype(np.float64), "u": gv0.copy(), "cs": 0}
+    feet_set[recipe.feet] = True
+    state = {"q": q0.astype(np.float64), "u": u0.astype(np.float64), "cs": step0}
     warm = orc.new_warm_state(n)      # the solver warm state the device keeps per env (cleared on reset, as there)
 
-    def run(threads, seconds):
-        spent, steps = 0.0, 0
-        while spent < seconds:
-            pt = workload.anymal_targets(n, state["cs"]).astype(np.float32).astype(np.float64)
-            t0 = time.perf_counter()
-            r = orc.step_batch(state["q"], state["u"], workload.SUBSTEPS, kp, kd, pt, dtg, nthreads=threads,
-                               want_contacts=reset, lam_warm=warm)
-            spent += time.perf_counter() - t0
-            q, u = r["q"], r["u"]
-            if reset:
-                con, ncs = r["contacts"], r["n_contacts"]
-                valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
-                term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
-                q[term], u[term] = gc0[term], gv0[term]
-                warm[term] = 0.0
-            state["q"], state["u"] = q, u
-            state["cs"] += 1
-            steps += n * workload.SUBSTEPS
-        return steps / spent, spent, steps
-
-    hw = orc.max_threads()
-    for _ in range(40):  # untimed: bring the population into the steady contact regime before probing thread counts
-        pt = workload.anymal_targets(n, state["cs"]).astype(np.float32).astype(np.float64)
-        r = orc.step_batch(state["q"], state["u"], workload.SUBSTEPS, kp, kd, pt, dtg, nthreads=0, want_contacts=reset,
-                           lam_warm=warm)
+    def control_step(threads):
+        pt = recipe.targets(n, state["cs"] % TARGET_BANK, 0).astype(np.float32).astype(np.float64)
+        t0 = time.perf_counter()
+        r = orc.step_batch(state["q"], state["u"], workload.SUBSTEPS, kp, kd, pt, dtg, nthreads=threads,
+                           want_contacts=reset, lam_warm=warm)
+        dt_ = time.perf_counter() - t0
         q, u = r["q"], r["u"]
         if reset:
             con, ncs = r["contacts"], r["n_contacts"]
             valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
             term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
-            q[term], u[term] = gc0[term], gv0[term]
+            q[term], u[term] = gc_reset[term], gv_reset[term]
             warm[term] = 0.0
         state["q"], state["u"] = q, u
         state["cs"] += 1
+        return dt_
+
+    def run(threads, seconds):
+        spent, steps = 0.0, 0
+        while spent < seconds:
+            spent += control_step(threads)
+            steps += n * workload.SUBSTEPS
+        return steps / spent, spent, steps
+
+    hw = orc.max_threads()
+    for _ in range(3):     # untimed: build the solver warm state the GPU population already has
+        control_step(0)
     try:
         hw = min(hw, len(os.sched_getaffinity(0)))
     except AttributeError:
@@ -143,7 +217,8 @@ def cpu_baseline(model, feet, max_iter, reset, budget_s):
     rate, spent, steps = run(best, max(budget_s - len(cands), 2.0))
     return {"value": rate, "unit": "env-steps/s", "cores": int(best), "kind": "port",
             "single_thread": probe[1],
-            "sample": f"{n} envs, {steps} env-steps of the same workload in {spent:.1f} s, fp64 oracle, OpenMP "
+            "sample": f"{n} envs, {steps} env-steps of the same workload in {spent:.1f} s, started from the GPU population's state at "
+                      f"the start of the timed region (control step {step0}) after 3 untimed control steps, fp64 oracle, OpenMP "
                       f"schedule(static) over envs; thread-count probe {{threads: env-steps/s}} = "
                       + json.dumps({str(k): round(v) for k, v in probe.items()})}
 
@@ -153,7 +228,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from raisimlib_amd import BatchedWorld, Model, rsc_path, workload
+    from raisimlib_amd import BatchedWorld, workload
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,12 +243,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     N = args.envs_per_gpu
-    model = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
-    feet = model.collision_indices("_foot")
+    recipe = Recipe(args.config, args.target_amplitude)
+    model, feet = recipe.model, recipe.feet
     world = BatchedWorld(model, N, device=local_rank)
     stream = torch.cuda.Stream(device=dev)       # everything below (kernels, copies, events, collectives) is ordered on it
     torch.cuda.set_stream(stream)
     world.set_stream(stream.cuda_stream)
+    recipe.setup_world(world)
     if args.max_iter > 0:
         world.set_contact_solver_param(1.0, 1.0, 1.0, args.max_iter, 1e-5)
     if args.lanes_per_env:
@@ -185,18 +261,15 @@ def main():
     if args.freeze_after >= 0 or args.settle_tol >= 0:
         world.set_solver_friction_lag(args.freeze_after if args.freeze_after >= 0 else 5, True,
                                       args.settle_tol if args.settle_tol >= 0 else 1e-4)
-    world.set_time_step(workload.DT)
-    kp, kd = workload.anymal_gains()
-    world.set_pd_gains(kp, kd)
 
-    # per-rank env shard: seeds offset by rank
-    gc0, gv0 = workload.anymal_initial_state(N, env_offset=rank * N)
+    # per-rank env shard: rank r owns global envs [r*N, (r+1)*N); every random number is a function of the global index
+    off = rank * N
+    gc0, gv0 = recipe.initial_state(N, off)
     gc0_d = torch.from_numpy(gc0.astype(np.float32)).to(dev)
     gv0_d = torch.from_numpy(gv0.astype(np.float32)).to(dev)
     world.set_state(gc0, gv0)
     world.set_pd_target(None, np.zeros((N, model.nv), np.float32))
-    bank = [torch.from_numpy(workload.anymal_targets(N, k, env_offset=rank * N, amplitude=args.target_amplitude).astype(np.float32)).to(dev)
-            for k in range(TARGET_BANK)]
+    bank = [torch.from_numpy(recipe.targets(N, k, off).astype(np.float32)).to(dev) for k in range(TARGET_BANK)]
     obs_dim = world.obs_dim(len(feet))
     # obs block of this rank and the gathered block of all ranks; with --overlap-collective double-buffered, so that the
     # all-gather of control step k (RCCL, its own stream) overlaps the kernel of step k+1
@@ -205,17 +278,13 @@ def main():
     all_obs_b = [torch.empty((world_size * N, obs_dim), dtype=torch.float32, device=dev) for _ in range(nbuf)] if coll else obs_b
     feet_idx = np.asarray(feet, np.int32)
     reset = not args.no_reset
+    done_d = torch.zeros(N, dtype=torch.uint8, device=dev)         # done flags of the fused control step (rsb_set_done_output)
+    age_d = torch.zeros(N, dtype=torch.int32, device=dev)          # control steps since each env's last reset
+    if reset:
+        world.set_done_output(done_d.data_ptr())
 
-    # one foreign call per control step (rsb_control_step); the step kernel's launches are bracketed by HIP events
-    # inside the library (ring of event pairs on the launch stream, read back after the timed region)
-    # the library brackets every EVENT_STRIDE-th launch with a HIP event pair (an event pair costs ~7 us of stream time,
-    # 5 % of a step: bracketing every launch would lower the very number being measured)
-    n_sampled = max(args.steps // EVENT_STRIDE, 1)
-    if not args.no_kernel_events:
-        world.enable_timing(max(n_sampled, 2))
-        world.set_timing_stride(EVENT_STRIDE if args.steps >= 2 * EVENT_STRIDE else 1)
-        if args.steps < 2 * EVENT_STRIDE:
-            n_sampled = args.steps
+    # one foreign call per control step (rsb_control_step); the step kernel's launches are bracketed by HIP events inside
+    # the library (ring of event pairs on the launch stream, read back after the fact, no per-launch synchronisation)
     step_fns = [world.control_step_plan(workload.SUBSTEPS, o.data_ptr(), feet_idx, feet_idx if reset else None,
                                         gc0_d.data_ptr() if reset else 0, gv0_d.data_ptr() if reset else 0, N) for o in obs_b]
     bank_ptr = [b.data_ptr() for b in bank]
@@ -239,15 +308,35 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
-    for k in range(args.warmup):
-        control_step(k)
+    def track_ages():                       # untimed passes only: age += 1, reset envs start again at 0
+        age_d.add_(1).mul_(1 - done_d.to(torch.int32))
+
+    # ---- untimed: pre-roll into the stationary regime, then the caller's warm-up
+    kstep = 0
+    for _ in range(args.preroll + args.warmup):
+        control_step(kstep)
+        if reset:
+            track_ages()
+        kstep += 1
     drain()
+    torch.cuda.synchronize()
+    q_start, u_start = world.get_state()    # the population the timed region starts from (the CPU leg starts from it too)
+    step_start = kstep
+
+    # ---- timed region: exactly --steps control steps, every EVENT_STRIDE-th launch bracketed
+    n_in = 0
+    if not args.no_kernel_events:
+        stride = EVENT_STRIDE if args.steps >= 2 * EVENT_STRIDE else max(args.steps, 1)
+        n_in = (args.steps + stride - 1) // stride
+        world.enable_timing(max(n_in, 2))
+        world.set_timing_stride(stride)
     if world_size > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        control_step(args.warmup + k)
+    for _ in range(args.steps):
+        control_step(kstep)
+        kstep += 1
     drain()
     t_enqueued = time.perf_counter() - t0       # host side done; the GPU may still be working
     if world_size > 1:
@@ -258,56 +347,101 @@ def main():
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    kernel_ms_in = world.read_kernel_ms(n_in).astype(np.float64) if n_in else np.zeros(0)
 
-    kernel_ms = (world.read_kernel_ms(n_sampled).astype(np.float64) if not args.no_kernel_events   # launches sampled from the timed region
-                 else np.full(args.steps, elapsed / args.steps * 1e3))
+    # ---- sampling pass (untimed, same sequence continued): every launch bracketed; resets and env ages recorded
+    kernel_ms_s = np.zeros(0)
+    resets = []
+    if not args.no_kernel_events:
+        world.enable_timing(SAMPLE_LAUNCHES)
+        world.set_timing_stride(1)
+    for _ in range(SAMPLE_LAUNCHES):
+        control_step(kstep)
+        if reset:
+            track_ages()
+            resets.append(done_d.sum())
+        kstep += 1
+    drain()
+    torch.cuda.synchronize()
+    bracket_overhead_ms = None
+    if not args.no_kernel_events:
+        kernel_ms_s = world.read_kernel_ms(SAMPLE_LAUNCHES).astype(np.float64)
+        world.enable_timing(0)
+        # what an event pair measures with nothing in between, on the same stream: subtracted from the brackets
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+        for e0, e1 in evs:
+            e0.record(stream)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        bracket_overhead_ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
+
     env_steps_per_step = N * workload.SUBSTEPS
     total_env_steps = world_size * env_steps_per_step * args.steps
     value = total_env_steps / elapsed
     iters = world.get_solver_iterations()
     counts, _ = world.get_contacts()
     q_end, _ = world.get_state()
+    ages = age_d.cpu().numpy()
+    resets = [float(r.item()) for r in resets]
 
     if rank == 0:
-        kmean = float(kernel_ms.mean()) * 1e-3
-        achieved = BYTES_PER_ENV_STEP * env_steps_per_step / kmean / 1e9
-        traffic, traffic_src, pmc = recorded_traffic(N, workload.SUBSTEPS) if reset and not args.max_iter else (None, None, None)
-        # what actually bounds the kernel: VALU issue slots of the one wave each SIMD holds (recorded SQ_INSTS_VALU x 4
-        # cycles over the measured launch time at the 2.4 GHz shader clock), reported next to the HBM roofline
-        valu = None
-        if pmc and pmc.get("counters", {}).get("SQ_INSTS_VALU"):
-            waves = -(-N * world.lanes_per_env() // 64)
-            valu = {"valu_inst_per_wave_per_launch": pmc["counters"]["SQ_INSTS_VALU"] / waves,
-                    "issue_slot_frac": pmc["counters"]["SQ_INSTS_VALU"] / waves * 4.0 / (kmean * 2.4e9),
-                    "note": "one wave per SIMD: (VALU instructions x 4 cycles) / launch cycles; recorded PMC pass, measured launch time"}
+        bytes_per_env_step = BYTES_PER_ENV_STEP[args.config]
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        if len(kernel_ms_s):
+            raw = float(kernel_ms_s.mean())
+            kmean_ms = raw - bracket_overhead_ms
+            achieved = bytes_per_env_step * env_steps_per_step / (kmean_ms * 1e-3) / 1e9
+            traffic, traffic_src, pmc = recorded_traffic(args.config, N, workload.SUBSTEPS) if reset and not args.max_iter else (None, None, None)
+            # what actually bounds the kernel: issue slots of the one wave each SIMD holds (recorded SQ_INSTS_VALU x 4 cycles
+            # over the measured launch time at the 2.4 GHz shader clock), reported next to the HBM roofline
+            valu = None
+            if pmc and pmc.get("counters", {}).get("SQ_INSTS_VALU"):
+                waves = -(-N * world.lanes_per_env() // 64)
+                valu = {"valu_inst_per_wave_per_launch": pmc["counters"]["SQ_INSTS_VALU"] / waves,
+                        "issue_slot_frac": pmc["counters"]["SQ_INSTS_VALU"] / waves * 4.0 / (kmean_ms * 1e-3 * 2.4e9),
+                        "note": "one wave per SIMD: (VALU instructions x 4 cycles) / launch cycles; recorded PMC pass, measured launch time"}
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "kernel": "rsb_step_kernel", "kernel_ms_mean": kmean_ms,
+                    "kernel_ms_p50": float(np.median(kernel_ms_s)) - bracket_overhead_ms,
+                    "kernel_ms_max": float(kernel_ms_s.max()) - bracket_overhead_ms,
+                    "kernel_launches_timed": int(len(kernel_ms_s)),
+                    "kernel_ms_mean_bracket_raw": raw, "event_pair_overhead_ms": bracket_overhead_ms,
+                    "timed_region_brackets": {"n": int(len(kernel_ms_in)), "stride": EVENT_STRIDE,
+                                              "kernel_ms_mean": (float(kernel_ms_in.mean()) - bracket_overhead_ms) if len(kernel_ms_in) else None},
+                    "method": f"HIP event pairs recorded by the library on the launch stream around each of {len(kernel_ms_s)} launches of a "
+                              "sampling pass that continues the timed region's sequence; an empty event pair on the same stream is subtracted",
+                    "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                    "algorithmic_bytes_per_launch": bytes_per_env_step * env_steps_per_step, "valu_issue": valu}
+        age_pct = [int(x) for x in np.percentile(ages, [10, 50, 90, 99])] if reset else None
         out = {
-            "metric": "env-steps/sec, 4096 ANYmal-C envs flat terrain dt=0.0025",
+            "metric": recipe.metric,
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "configs[1]: 4096 ANYmal-C-like (synthetic stand-in URDF) envs per GPU, flat ground, "
-                            "dt=0.0025, 4 sub-steps per control step fused in one launch, PD kp=50 kd=0.2, targets = "
-                            f"nominal + U(-{args.target_amplitude:g},{args.target_amplitude:g}) rad per control step, per-env seed 1234+i"
+                "workload": recipe.name + ", dt=0.0025, 4 sub-steps per control step fused in one launch"
                             + (", non-foot contact -> reset (rsg_anymal rule)" if reset else ", no resets")
                             + (", EARLY TERMINATION at the sub-step of the first non-foot contact (not upstream's rule)" if args.early_termination else "")
-                            + ", obs (q,u,foot force) gathered each control step",
+                            + ", obs (q,u,foot force) written each control step"
+                            + f"; stationary regime: {args.preroll} untimed pre-roll control steps before --warmup",
+                "preroll_control_steps": args.preroll,
+                "regime": {"resets_per_control_step_mean": float(np.mean(resets)) if resets else None,
+                           "env_age_control_steps_p10_p50_p90_p99": age_pct,
+                           "sampled_over_control_steps": SAMPLE_LAUNCHES},
                 "envs_per_gpu": N, "substeps_per_step": workload.SUBSTEPS,
                 "contact_solver": {"max_iter": args.max_iter or 150, "threshold_rel": 1e-5, "alpha": [1.0, 1.0, 1.0]},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
                 "obs_all_gather": ("overlapped with the next control step (double-buffered)" if nbuf == 2 else "in line") if coll else "none (1 rank)",
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rsb_step_kernel", "kernel_ms_mean": float(kernel_ms.mean()),
-                         "kernel_ms_p50": float(np.median(kernel_ms)), "kernel_launches_timed": int(len(kernel_ms)),
-                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * env_steps_per_step, "valu_issue": valu},
+            "roofline": roof,
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "state_at_end": {"solver_iters_mean": float(iters.mean()), "solver_iters_max": int(iters.max()),
                              "contacts_per_env": float(counts.mean()), "base_height_mean": float(q_end[:, 2].mean())},
         }
         if world_size == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(model, feet, args.max_iter, reset, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(recipe, args.max_iter, reset, args.cpu_seconds, q_start, u_start,
+                                               gc0.astype(np.float32).astype(np.float64), gv0, step_start)
     world.close()
     if coll:
         dist.destroy_process_group()

@@ -65,7 +65,7 @@ struct rsb_world {
   int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 5, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
-  double stall_factor = 0.5, settle_tol = 1e-4, restitution = 0.0, res_threshold = 0.0;
+  double stall_factor = 0.5, settle_tol = 0.0, restitution = 0.0, res_threshold = 0.0;
   int lpe = 0, max_cl = 0;
   double world_time = 0;
   bool integrate1_valid = false;

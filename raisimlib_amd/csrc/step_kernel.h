@@ -899,6 +899,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float lam_best[3] = {0.f, 0.f, 0.f}, best_rel = 3e38f;   // calmest iterate (returned when the solve does not converge)
         float sdx = 0.f, sdy = 0.f;   // friction direction of this contact's last slip solve (|.| = 1 once set)
         bool sdv = false, sset = false;   // direction valid / settled (the last refinement moved it by less than settle_tol)
+        bool sdinh = false;                // direction inherited from the previous integrate() (warm state) and not used in this solve yet
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
@@ -913,7 +914,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             if (mycol < ncol) {   // joint-limit rows (ids >= ncol) start cold
               const float* wr = WARM + 6 * mycol;
               lam[0] = wr[0]; lam[1] = wr[1]; lam[2] = wr[2];
-              sdx = wr[3]; sdy = wr[4]; sdv = wr[5] != 0.f;
+              sdx = wr[3]; sdy = wr[4]; sdv = wr[5] != 0.f; sdinh = sdv;
             }
           }
           for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
@@ -961,7 +962,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               if (__any(slip)) {
                 // lagged friction direction: after freeze_after sweeps, or once a refinement no longer moved it (settled), a
                 // slipping contact keeps its last direction when the normal response along it is well conditioned
-                const bool frozen = slip && sdv && (lag || sset) && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
+                const bool frozen = slip && sdv && !sdinh && (lag || sset) && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
                 if (__any(slip && !frozen)) {
                   SlipCoef kc = sc;
                   const float vex0 = v[0] - (Gii[0] * lam[0] + Gii[1] * lam[1] + Gii[2] * lam[2]);
@@ -976,6 +977,18 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                     long long tn0 = 0; if (PROF && a.prof) { ++p_newton; if (a.prof_fine) tn0 = clock64(); }
                     float nx, ny, dstep;
                     refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny, dstep) && cand;
+                    if (__any(refined && sdinh)) {
+                      // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
+                      // local minimum the global search would not choose; the refined direction is accepted only if it is at
+                      // least as good as every direction of the search's coarse scan (16 lanes = 16 directions)
+                      SlipCoef kb;
+                      kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
+                      kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
+                      kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
+                      kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
+                      const float ebest = __uint_as_float(row_min_u32(__float_as_uint(slip_E(kb, a.mu, c16, s16))));   // E >= 0: bit order = value order
+                      if (sdinh && !(slip_E(kc, a.mu, nx, ny) <= ebest)) refined = false;
+                    }
                     if (refined) { sdx = nx; sdy = ny; sset = fabsf(dstep) <= a.settle_tol; }
                     if (PROF && a.prof && a.prof_fine) t_newt += clock64() - tn0;
                   }
@@ -994,6 +1007,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
                     if (PROF && a.prof && a.prof_fine) t_srch += clock64() - ts0;
                   }
                 }
+                if (slip) sdinh = false;   // the direction is this solve's own from here on
                 // impulse along the kept / refined / searched direction: v_n^+ = 0 on the cone boundary
                 const float lnn = -vexn * __builtin_amdgcn_rcpf(fmaxf(sc.a0 + sc.a1 * sdx + sc.a2 * sdy, kDenMin * sc.a0));
                 const float ltn = a.mu * lnn;

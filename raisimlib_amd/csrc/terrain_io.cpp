@@ -109,7 +109,9 @@ struct Perlin {
   }
   double operator()(double x, double y) const {
     const double fx = std::floor(x), fy = std::floor(y);
-    const int X = (int)fx & 255, Y = (int)fy & 255;
+    // lattice cell modulo 256 in floating point first: (int) of a double beyond INT_MAX is undefined behaviour, and
+    // frequency * lacunarity^octave grows without bound
+    const int X = (int)(fx - 256.0 * std::floor(fx / 256.0)) & 255, Y = (int)(fy - 256.0 * std::floor(fy / 256.0)) & 255;
     x -= fx; y -= fy;
     const double u = fade(x), v = fade(y);
     const int A = p[X] + Y, B = p[X + 1] + Y;
@@ -118,6 +120,8 @@ struct Perlin {
     return l0 + v * (l1 - l0);
   }
 };
+
+constexpr int kMaxSamples = 16384;   // per axis, for every height-map source (an untrusted file must not size an allocation freely)
 
 }  // namespace
 
@@ -137,7 +141,7 @@ int rsb_heightmap_png_read(const char* path, double height_scale, double height_
   Png png;
   const std::string err = read_png(path, false, png);
   if (!err.empty()) { rsb::set_error("rsb_heightmap_png_read: " + err); return RSB_E_PARSE; }
-  if (n != png.w * png.h) { rsb::set_error("rsb_heightmap_png_read: buffer size != x_samples * y_samples"); return RSB_E_INVALID; }
+  if ((long long)n != (long long)png.w * png.h) { rsb::set_error("rsb_heightmap_png_read: buffer size != x_samples * y_samples"); return RSB_E_INVALID; }
   const int bps = png.depth / 8, bpp = png.channels * bps;
   const double inv = 1.0 / (png.depth == 8 ? 255.0 : 65535.0);
   for (int y = 0; y < png.h; ++y)
@@ -150,7 +154,9 @@ int rsb_heightmap_png_read(const char* path, double height_scale, double height_
 }
 
 int rsb_heightmap_perlin(const rsb_terrain_properties* tp, float* heights) {
-  if (!tp || !heights || tp->x_samples < 2 || tp->y_samples < 2 || tp->fractal_octaves < 1 || !(tp->x_size > 0) || !(tp->y_size > 0)) {
+  if (!tp || !heights || tp->x_samples < 2 || tp->y_samples < 2 || tp->x_samples > kMaxSamples || tp->y_samples > kMaxSamples ||
+      tp->fractal_octaves < 1 || tp->fractal_octaves > 32 || !(tp->x_size > 0) || !(tp->y_size > 0) ||
+      !std::isfinite(tp->frequency) || !std::isfinite(tp->fractal_lacunarity) || !std::isfinite(tp->fractal_gain)) {
     rsb::set_error("rsb_heightmap_perlin: bad terrain properties");
     return RSB_E_INVALID;
   }
@@ -176,7 +182,7 @@ int rsb_heightmap_text_size(const char* path, int* x_samples, int* y_samples, do
   if (!f) { rsb::set_error(std::string("rsb_heightmap_text_size: cannot open ") + path); return RSB_E_PARSE; }
   const int got = std::fscanf(f, "%d %d %lf %lf", x_samples, y_samples, x_size, y_size);
   std::fclose(f);
-  if (got != 4 || *x_samples < 2 || *y_samples < 2) { rsb::set_error("rsb_heightmap_text_size: header must be 'xSamples ySamples xSize ySize'"); return RSB_E_PARSE; }
+  if (got != 4 || *x_samples < 2 || *y_samples < 2 || *x_samples > kMaxSamples || *y_samples > kMaxSamples) { rsb::set_error("rsb_heightmap_text_size: header must be 'xSamples ySamples xSize ySize' with 2..16384 samples per axis"); return RSB_E_PARSE; }
   return RSB_OK;
 }
 
@@ -186,7 +192,8 @@ int rsb_heightmap_text_read(const char* path, float* heights, int n) {
   if (!f) { rsb::set_error(std::string("rsb_heightmap_text_read: cannot open ") + path); return RSB_E_PARSE; }
   int xs = 0, ys = 0; double sx = 0, sy = 0;
   int st = RSB_OK;
-  if (std::fscanf(f, "%d %d %lf %lf", &xs, &ys, &sx, &sy) != 4 || xs * ys != n) st = RSB_E_PARSE;
+  if (std::fscanf(f, "%d %d %lf %lf", &xs, &ys, &sx, &sy) != 4 || xs < 2 || ys < 2 || xs > kMaxSamples || ys > kMaxSamples ||
+      (long long)xs * ys != (long long)n) st = RSB_E_PARSE;
   for (int i = 0; st == RSB_OK && i < n; ++i) {
     double v;
     if (std::fscanf(f, "%lf", &v) != 1) st = RSB_E_PARSE; else heights[i] = (float)v;

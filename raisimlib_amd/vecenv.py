@@ -35,6 +35,7 @@ class VecEnv:
         if stream is not None:
             w.set_stream(stream)
         self.num_envs, self.nq, self.nv = num_envs, m.nq, m.nv
+        self.device_index = int(device)
         self.num_acts = m.nv - 6
         self.num_obs = 10 + 2 * self.num_acts
         w.set_time_step(simulation_dt)
@@ -60,7 +61,23 @@ class VecEnv:
         w.set_pd_target(np.tile(np.r_[np.zeros(3), 1, np.zeros(m.nq - 4)], (num_envs, 1)), np.zeros((num_envs, m.nv)))
         check(w.L.rsb_env_configure(w.handle, C.byref(cfg), _hp(self.action_mean), _hp(self.gc_init), _hp(self.gv_init)),
               "rsb_env_configure")
+        self.ob_mean = self.ob_var = None      # running observation statistics (created on the env's device at first use)
+        self.ob_count = 1e-4
         self.reset()
+
+    def _check_tensor(self, t, shape, dtype, name):
+        """A wrongly shaped / typed / placed tensor would make the kernels read or write out of bounds on the device."""
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == dtype and tuple(t.shape) == tuple(shape)
+                and t.device.index == self.device_index):
+            raise ValueError(f"VecEnv: {name} must be a contiguous {dtype} CUDA tensor of shape {tuple(shape)} on cuda:{self.device_index}, "
+                             f"got {t.dtype} {tuple(t.shape)} on {t.device}")
+
+    def _stats(self, device=None):
+        import torch
+        if self.ob_mean is None:
+            dev = device if device is not None else torch.device("cuda", self.device_index)
+            self.ob_mean = torch.zeros(self.num_obs, dtype=torch.float32, device=dev)
+            self.ob_var = torch.ones(self.num_obs, dtype=torch.float32, device=dev)
 
     # a torch tensor travels as its device pointer, anything else as a host array
     @staticmethod
@@ -73,10 +90,13 @@ class VecEnv:
     def observe(self, out=None):
         w = self.world
         if out is not None and self._is_torch(out):
-            assert out.is_cuda and out.is_contiguous() and tuple(out.shape) == (self.num_envs, self.num_obs)
+            import torch
+            self._check_tensor(out, (self.num_envs, self.num_obs), torch.float32, "out")
             check(w.L.rsb_env_observe(w.handle, C.c_void_p(out.data_ptr()), RSB_DEVICE), "rsb_env_observe")
             return out
         ob = np.zeros((self.num_envs, self.num_obs), np.float32) if out is None else out
+        if not (isinstance(ob, np.ndarray) and ob.dtype == np.float32 and ob.flags.c_contiguous and ob.shape == (self.num_envs, self.num_obs)):
+            raise ValueError("VecEnv.observe: out must be a C-contiguous float32 array [num_envs, num_obs]")
         check(w.L.rsb_env_observe(w.handle, _hp(ob), RSB_HOST), "rsb_env_observe")
         return ob
 
@@ -87,12 +107,14 @@ class VecEnv:
         w = self.world
         if self._is_torch(action):
             import torch
-            assert action.is_cuda and action.is_contiguous() and action.dtype == torch.float32
+            self._check_tensor(action, (self.num_envs, self.num_acts), torch.float32, "action")
             reward = torch.empty(self.num_envs, dtype=torch.float32, device=action.device) if reward is None else reward
             done = torch.empty(self.num_envs, dtype=torch.uint8, device=action.device) if done is None else done
+            self._check_tensor(reward, (self.num_envs,), torch.float32, "reward")
+            self._check_tensor(done, (self.num_envs,), torch.uint8, "done")
             obp = None
             if ob_next is not None:
-                assert ob_next.is_cuda and ob_next.is_contiguous() and tuple(ob_next.shape) == (self.num_envs, self.num_obs)
+                self._check_tensor(ob_next, (self.num_envs, self.num_obs), torch.float32, "ob_next")
                 obp = C.c_void_p(ob_next.data_ptr())
             check(w.L.rsb_env_step(w.handle, C.c_void_p(action.data_ptr()), C.c_void_p(reward.data_ptr()),
                                    C.c_void_p(done.data_ptr()), obp, RSB_DEVICE), "rsb_env_step")
@@ -101,6 +123,10 @@ class VecEnv:
         assert a.shape == (self.num_envs, self.num_acts)
         reward = np.zeros(self.num_envs, np.float32) if reward is None else reward
         done = np.zeros(self.num_envs, np.uint8) if done is None else done
+        for arr, dt, shp, nm in ((reward, np.float32, (self.num_envs,), "reward"), (done, np.uint8, (self.num_envs,), "done"),
+                                 (ob_next, np.float32, (self.num_envs, self.num_obs), "ob_next")):
+            if arr is not None and not (isinstance(arr, np.ndarray) and arr.dtype == dt and arr.flags.c_contiguous and arr.shape == shp):
+                raise ValueError(f"VecEnv.step: {nm} must be a C-contiguous {np.dtype(dt).name} array of shape {shp}")
         check(w.L.rsb_env_step(w.handle, _hp(a), _hp(reward), _hp(done), _hp(ob_next), RSB_HOST), "rsb_env_step")
         return reward, done
 
@@ -110,10 +136,7 @@ class VecEnv:
         the device (batched Welford update, as upstream's RunningMeanStd); returns `out`."""
         import torch
         self.observe(out)
-        if not hasattr(self, "ob_mean"):
-            self.ob_mean = torch.zeros(self.num_obs, dtype=torch.float32, device=out.device)
-            self.ob_var = torch.ones(self.num_obs, dtype=torch.float32, device=out.device)
-            self.ob_count = 1e-4
+        self._stats(out.device)
         if update_statistics:
             bm, bv, n = out.mean(0), out.var(0, unbiased=False), float(out.shape[0])
             delta, tot = bm - self.ob_mean, self.ob_count + n
@@ -127,12 +150,14 @@ class VecEnv:
     def save_scaling(self, dir_name, iteration):
         """mean<iteration>.csv / var<iteration>.csv of the running observation statistics (upstream file names)."""
         import os
+        self._stats()
         np.savetxt(os.path.join(dir_name, f"mean{iteration}.csv"), self.ob_mean.cpu().numpy())
         np.savetxt(os.path.join(dir_name, f"var{iteration}.csv"), self.ob_var.cpu().numpy())
 
-    def load_scaling(self, dir_name, iteration, count=1e5, device="cuda"):
+    def load_scaling(self, dir_name, iteration, count=1e5, device=None):
         import os
         import torch
+        device = torch.device("cuda", self.device_index) if device is None else device
         self.ob_mean = torch.from_numpy(np.loadtxt(os.path.join(dir_name, f"mean{iteration}.csv")).astype(np.float32)).to(device)
         self.ob_var = torch.from_numpy(np.loadtxt(os.path.join(dir_name, f"var{iteration}.csv")).astype(np.float32)).to(device)
         self.ob_count = float(count)

@@ -202,6 +202,16 @@ class BatchedWorld:
     def integrate(self, n_substeps=1):
         check(self.L.rsb_integrate(self.handle, int(n_substeps)), "rsb_integrate")
 
+    def integrate_masked(self, mask, n_substeps=1):
+        """integrate() of the envs whose mask byte is non-zero only (host uint8 [N]); the others are left untouched."""
+        m = _host(mask, np.uint8)
+        assert m.shape == (self.N,)
+        check(self.L.rsb_integrate_masked(self.handle, int(n_substeps), _hp(m), RSB_HOST), "rsb_integrate_masked")
+
+    def set_done_output(self, done_device_ptr):
+        """Device uint8 [N] buffer that every following control step fills with its done flags (0 / None: off)."""
+        check(self.L.rsb_set_done_output(self.handle, C.c_void_p(done_device_ptr) if done_device_ptr else None), "rsb_set_done_output")
+
     def integrate1(self):
         check(self.L.rsb_integrate1(self.handle), "rsb_integrate1")
 

@@ -235,7 +235,7 @@ def test_no_use_of_uninitialised_lds():
     assert r.returncode == 0, r.stdout[-3000:]
 
 
-def _env_reference(q, u, pt, kp, kd, counts, contacts, flags, feet, cfg):
+def _env_reference(q, u, pt, kp, kd, counts, contacts, flags, feet, cfg, q3=None, u3=None, effort=None):
     """numpy restatement of the rsg_anymal-style reward / termination / observation (tests only)."""
     N = q.shape[0]
     w, x, y, z = q[:, 3], q[:, 4], q[:, 5], q[:, 6]
@@ -244,13 +244,20 @@ def _env_reference(q, u, pt, kp, kd, counts, contacts, flags, feet, cfg):
     R[:, 1, 0] = 2 * (x * y + w * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - w * x)
     R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
     vb = np.einsum("nji,nj->ni", R, u[:, 0:3]); wb = np.einsum("nji,nj->ni", R, u[:, 3:6])
-    obs = np.concatenate([q[:, 2:3], R[:, :, 2], q[:, 7:], vb, wb, u[:, 6:]], axis=1)   # R[:, :, 2]: body z-axis in the world
-    tau = kp[6:] * (pt[:, 7:] - q[:, 7:]) - kd[6:] * u[:, 6:]
+    obs = np.concatenate([q[:, 2:3], R[:, 2, :], q[:, 7:], vb, wb, u[:, 6:]], axis=1)   # R[:, 2, :]: third ROW of R = rsg_anymal's rot.e().row(2)
+    # torque cost: the actuator torque the LAST sub-step applied (implicit PD: position error at q + dt u, clipped to the
+    # effort limit), i.e. upstream's getGeneralizedForce() after the last integrate(); (q3, u3) = state that sub-step started from
+    q3 = q if q3 is None else q3
+    u3 = u if u3 is None else u3
+    tau = kp[6:] * (pt[:, 7:] - q3[:, 7:] - workload.DT * u3[:, 6:]) - kd[6:] * u3[:, 6:]
+    if effort is not None:
+        lim = np.where(effort > 0, effort, np.inf)
+        tau = np.clip(tau, -lim, lim)
     r = cfg["fwd"] * np.minimum(cfg["clip"], vb[:, 0]) + cfg["tc"] * (tau ** 2).sum(1)
     term = (flags & 2) != 0
     for e in range(N):
         term[e] |= bool(np.any(~np.isin(contacts[e][:counts[e]]["collision"], feet)))
-    return obs, np.where(term, cfg["term"], r), term
+    return obs, np.where(term, r + cfg["term"], r), term   # upstream perAgentStep: reward += terminalReward
 
 
 def test_device_vecenv_matches_the_host_restatement(anymal):
@@ -268,6 +275,7 @@ def test_device_vecenv_matches_the_host_restatement(anymal):
     kp = np.zeros(18, np.float32); kd = np.zeros(18, np.float32); kp[6:] = 50.0; kd[6:] = 0.2
     twin.set_pd_gains(kp, kd)
     twin.set_state(np.tile(gc_init, (N, 1)), np.zeros((N, 18)))
+    effort = np.array([anymal.blob.effort[b] for b in range(1, anymal.nb)])
     ob0 = env.observe()
     assert np.allclose(ob0[:, 0], gc_init[2]) and np.allclose(ob0[:, 1:4], [0, 0, 1]) and np.allclose(ob0[:, 4:16], gc_init[7:])
     rng = np.random.default_rng(5)
@@ -285,9 +293,12 @@ def test_device_vecenv_matches_the_host_restatement(anymal):
             rew, done, ob_same_launch = r_t.cpu().numpy(), d_t.cpu().numpy(), ob_t.cpu().numpy()
         pt = np.zeros((N, 19), np.float32); pt[:, 3] = 1; pt[:, 7:] = gc_init[7:] + np.float32(0.3) * act
         twin.set_pd_target(pt, np.zeros((N, 18), np.float32))
-        twin.integrate(4)
+        twin.integrate(3)
+        q3, u3 = twin.get_state()
+        twin.integrate(1)
         q, u = twin.get_state(); cnt, con = twin.get_contacts(); fl = twin.get_flags()
-        _, r_ref, term = _env_reference(q.astype(np.float64), u.astype(np.float64), pt.astype(np.float64), kp, kd, cnt, con, fl, feet, cfg)
+        _, r_ref, term = _env_reference(q.astype(np.float64), u.astype(np.float64), pt.astype(np.float64), kp, kd, cnt, con, fl, feet, cfg,
+                                        q3.astype(np.float64), u3.astype(np.float64), effort)
         assert np.array_equal(done.astype(bool), term)
         assert np.allclose(rew, r_ref, rtol=2e-5, atol=2e-5)
         twin.reset_terminated(feet, gc_init, np.zeros(18, np.float32))
