@@ -271,11 +271,11 @@ def main():
     world.set_pd_target(None, np.zeros((N, model.nv), np.float32))
     bank = [torch.from_numpy(recipe.targets(N, k, off).astype(np.float32)).to(dev) for k in range(TARGET_BANK)]
     obs_dim = world.obs_dim(len(feet))
-    # obs block of this rank and the gathered block of all ranks; with --overlap-collective double-buffered, so that the
-    # all-gather of control step k (RCCL, its own stream) overlaps the kernel of step k+1
-    nbuf = 2 if (coll and args.overlap_collective) else 1
-    obs_b = [torch.empty((N, obs_dim), dtype=torch.float32, device=dev) for _ in range(nbuf)]
-    all_obs_b = [torch.empty((world_size * N, obs_dim), dtype=torch.float32, device=dev) for _ in range(nbuf)] if coll else obs_b
+    # obs block of this rank and the gathered block of all ranks (raisimlib_amd/dist.py); with --overlap-collective
+    # double-buffered, so that the all-gather of control step k (RCCL, its own stream) overlaps the kernel of step k+1
+    from raisimlib_amd.dist import ObsGatherer
+    gath = ObsGatherer(N, obs_dim, dev, overlap=args.overlap_collective, force=args.force_collective)
+    obs_b, nbuf = gath.local_bufs, gath.nbuf
     feet_idx = np.asarray(feet, np.int32)
     reset = not args.no_reset
     done_d = torch.zeros(N, dtype=torch.uint8, device=dev)         # done flags of the fused control step (rsb_set_done_output)
@@ -288,25 +288,13 @@ def main():
     step_fns = [world.control_step_plan(workload.SUBSTEPS, o.data_ptr(), feet_idx, feet_idx if reset else None,
                                         gc0_d.data_ptr() if reset else 0, gv0_d.data_ptr() if reset else 0, N) for o in obs_b]
     bank_ptr = [b.data_ptr() for b in bank]
-    pending = [None] * nbuf
 
     def control_step(k):
-        b = k % nbuf
-        if pending[b] is not None:          # the gather that still reads this buffer (stream-side wait, the host runs on)
-            pending[b].wait()
-            pending[b] = None
-        step_fns[b](bank_ptr[k % TARGET_BANK])
-        if coll:
-            if nbuf == 2:
-                pending[b] = dist.all_gather_into_tensor(all_obs_b[b], obs_b[b], async_op=True)
-            else:
-                dist.all_gather_into_tensor(all_obs_b[b], obs_b[b])
+        gath.acquire(k)                     # the gather that still reads this buffer (stream-side wait, the host runs on)
+        step_fns[gath.slot(k)](bank_ptr[k % TARGET_BANK])
+        gath.gather(k)
 
-    def drain():
-        for b in range(nbuf):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+    drain = gath.drain
 
     def track_ages():                       # untimed passes only: age += 1, reset envs start again at 0
         age_d.add_(1).mul_(1 - done_d.to(torch.int32))
@@ -432,7 +420,7 @@ def main():
                 "envs_per_gpu": N, "substeps_per_step": workload.SUBSTEPS,
                 "contact_solver": {"max_iter": args.max_iter or 150, "threshold_rel": 1e-5, "alpha": [1.0, 1.0, 1.0]},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
-                "obs_all_gather": ("overlapped with the next control step (double-buffered)" if nbuf == 2 else "in line") if coll else "none (1 rank)",
+                "obs_all_gather": gath.describe(),
             },
             "roofline": roof,
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,

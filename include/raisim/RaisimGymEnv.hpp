@@ -1,0 +1,109 @@
+// raisim/RaisimGymEnv.hpp — the base class raisimGymTorch environments derive from, re-authored from recollection
+// [RECALL raisimGymTorch/env/RaisimGymEnv.hpp, Reward.hpp; absent from /root/reference, SURVEY.md §8b].
+// Same members and virtuals as upstream; Eigen::Ref<EigenVec> is replaced by raisim::EigenVecRef, a (float*, size)
+// span with operator[] / size() / setZero() (Eigen is not installed here; where <Eigen/Core> exists the span converts
+// from and to Eigen maps).  There is no RaisimServer (visualisation is out of scope): `server_` stays null.
+#pragma once
+
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "raisim/World.hpp"
+#include "raisim/Yaml.hpp"
+
+namespace raisim {
+
+/// stand-in for Eigen::Ref<Eigen::Matrix<float, -1, 1>> (one row of the [num_envs, dim] observation / action matrix)
+template <typename T>
+struct RowRef {
+  T* p = nullptr;
+  int n = 0;
+  RowRef() = default;
+  RowRef(T* data, int size) : p(data), n(size) {}
+  T& operator[](int i) const { return p[i]; }
+  T& operator()(int i) const { return p[i]; }
+  int size() const { return n; }
+  T* data() const { return p; }
+  void setZero() const { for (int i = 0; i < n; ++i) p[i] = T(0); }
+#ifdef RAISIM_HAS_EIGEN
+  Eigen::Map<Eigen::Matrix<typename std::remove_const<T>::type, Eigen::Dynamic, 1>> e() const { return {const_cast<typename std::remove_const<T>::type*>(p), n}; }
+#endif
+};
+using EigenVecRef = RowRef<float>;
+using ConstEigenVecRef = RowRef<const float>;
+
+/// upstream raisim::Reward: named reward terms with coefficients read from cfg["reward"]
+class Reward {
+ public:
+  void initializeFromConfigurationFile(const Yaml::Node& cfg) {
+    terms_.clear();
+    for (const std::string& k : cfg.Keys()) terms_[k] = Term{cfg[k]["coeff"].As<double>(), 0.0};
+  }
+  void record(const std::string& name, double reward, bool accumulate = false) {
+    auto it = terms_.find(name);
+    RSFATAL_IF(it == terms_.end(), "Reward::record: no such reward term: " + name);
+    RSFATAL_IF(!std::isfinite(reward), "Reward::record: " + name + " is not finite");
+    it->second.value = (accumulate ? it->second.value : 0.0) + reward * it->second.coeff;
+  }
+  float sum() const { double s = 0; for (const auto& t : terms_) s += t.second.value; return (float)s; }
+  float operator[](const std::string& name) const { return (float)terms_.at(name).value; }
+  void reset() { for (auto& t : terms_) t.second.value = 0.0; }
+  std::map<std::string, float> getStdMap() const {
+    std::map<std::string, float> m;
+    for (const auto& t : terms_) m[t.first] = (float)t.second.value;
+    m["reward_sum"] = sum();
+    return m;
+  }
+ private:
+  struct Term { double coeff, value; };
+  std::map<std::string, Term> terms_;
+};
+
+class RaisimServer;   // not provided (visualisation is out of scope)
+
+class RaisimGymEnv {
+ public:
+  explicit RaisimGymEnv(std::string resourceDir, const Yaml::Node& cfg) : resourceDir_(std::move(resourceDir)), cfg_(cfg) {}
+  virtual ~RaisimGymEnv() = default;
+
+  /////// implement these methods /////////
+  virtual void init() = 0;
+  virtual void reset() = 0;
+  virtual void observe(EigenVecRef ob) = 0;
+  virtual float step(const ConstEigenVecRef& action) = 0;
+  virtual bool isTerminalState(float& terminalReward) = 0;
+  ////////////////////////////////////////
+
+  /////// optional methods ///////
+  virtual void curriculumUpdate() {}
+  virtual void close() {}
+  virtual void setSeed(int) {}
+  ////////////////////////////////
+
+  void setSimulationTimeStep(double dt) { simulation_dt_ = dt; world_->setTimeStep(dt); }
+  void setControlTimeStep(double dt) { control_dt_ = dt; }
+  int getObDim() { return obDim_; }
+  int getActionDim() { return actionDim_; }
+  double getControlTimeStep() { return control_dt_; }
+  double getSimulationTimeStep() { return simulation_dt_; }
+  raisim::World* getWorld() { return world_.get(); }
+  void turnOffVisualization() {}
+  void turnOnVisualization() {}
+  void startRecordingVideo(const std::string&) {}
+  void stopRecordingVideo() {}
+  raisim::Reward& getRewards() { return rewards_; }
+
+ protected:
+  std::unique_ptr<raisim::World> world_;
+  double simulation_dt_ = 0.001;
+  double control_dt_ = 0.01;
+  std::string resourceDir_;
+  Yaml::Node cfg_;
+  int obDim_ = 0, actionDim_ = 0;
+  RaisimServer* server_ = nullptr;
+  raisim::Reward rewards_;
+};
+
+}  // namespace raisim

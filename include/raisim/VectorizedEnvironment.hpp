@@ -1,17 +1,24 @@
-// raisim/VectorizedEnvironment.hpp — the batched counterpart of raisimGymTorch's VectorizedEnvironment<ENV>.
+// raisim/VectorizedEnvironment.hpp — the two batched counterparts of raisimGymTorch's VectorizedEnvironment<ENV>.
 //
 // Upstream (raisimGymTorch/env/VectorizedEnvironment.hpp, absent from /root/reference — SURVEY.md §3.1, §8b) owns
 // num_envs ENVIRONMENT objects, each with its own raisim::World, and fans `step` out with an OpenMP parallel-for.
-// Here ONE BatchedWorld holds all replicas on the GPU; `step` is a single fused launch of control_dt/simulation_dt
-// sub-steps plus two tiny kernels (action -> PD targets, reward/termination/reset), all through the C-ABI's rsb_env_*
-// entry points, and `stepDevice` / `observeDevice` take device buffers so a GPU-resident policy never crosses PCIe; the method names, argument meaning and in-place caller-owned buffers
-// (row-major float [num_envs, dim], bool [num_envs]) are upstream's, with (T*, rows, cols) spans instead of
-// Eigen::Ref (Eigen is not available here).
 //
-// Task semantics are the rsg_anymal ones [RECALL]: action -> PD position targets (actionMean + action*actionStd on
-// the actuated joints), observation = [height, body z-axis(3), joint angles, body lin vel(3), body ang vel(3),
-// joint velocities] (obDim = 10 + 2*nJoints), reward = forward velocity - torque cost (coefficients in Config),
-// termination on any non-foot contact followed by reset to the initial state.
+//   raisim::VectorizedEnvironment<ChildEnvironment>   upstream's template, same constructor (resourceDir, cfg yaml text),
+//       same methods and in-place caller-owned buffers ((T*, rows, cols) spans where upstream takes Eigen::Ref).  The
+//       ChildEnvironment is ARBITRARY user code written against raisim::World / ArticulatedSystem (an rsg_anymal-style
+//       Environment.hpp): its N instances are constructed inside a raisim::BatchScope, so their N Worlds are the N
+//       replicas of ONE BatchedWorld, and step() runs the N env->step() bodies as fibers (raisim/Fiber.hpp) that park in
+//       World::integrate() - every integrate() of the control step is ONE kernel launch for the whole batch, whatever
+//       the environment computes around it on the host.  Per integrate(): one upload of the staged PD targets, one
+//       launch, one download of the state (+ contacts when an env asks for them).
+//
+//   raisim::DeviceVectorizedEnvironment   rsg_anymal's task compiled into the library (rsb_env_*): action scaling,
+//       observation, reward, termination and reset run on the GPU, a control step is one fused launch of
+//       control_dt/simulation_dt sub-steps plus one small kernel, and `stepDevice` / `observeDevice` take device buffers
+//       so that a GPU-resident policy never crosses PCIe.  Task semantics [RECALL rsg_anymal]: action -> PD position
+//       targets (actionMean + action*actionStd on the actuated joints), observation = [height, third row of the base
+//       rotation (3), joint angles, body lin vel(3), body ang vel(3), joint velocities] (obDim = 10 + 2*nJoints),
+//       reward = forward velocity - torque cost, termination on any non-foot contact followed by reset.
 #pragma once
 
 #include <cmath>
@@ -19,6 +26,7 @@
 #include <string>
 #include <vector>
 
+#include "raisim/RaisimGymEnv.hpp"
 #include "raisim/World.hpp"
 
 namespace raisim {
@@ -34,9 +42,9 @@ struct VecEnvConfig {
   bool early_termination = false;         // rsb_set_early_termination: not upstream's rule, see include/rsb.h
 };
 
-class VectorizedEnvironment {
+class DeviceVectorizedEnvironment {
  public:
-  VectorizedEnvironment(const std::string& urdfPath, const VecEnvConfig& cfg) : cfg_(cfg), world_(urdfPath, cfg.num_envs, cfg.device) {}
+  DeviceVectorizedEnvironment(const std::string& urdfPath, const VecEnvConfig& cfg) : cfg_(cfg), world_(urdfPath, cfg.num_envs, cfg.device) {}
 
   void init() {
     n_ = world_.numEnvs(); nq_ = world_.gcDim(); nv_ = world_.dof(); nj_ = nv_ - 6;
@@ -89,9 +97,9 @@ class VectorizedEnvironment {
   }
 
   void isTerminalState(bool* terminalState) { for (int e = 0; e < n_; ++e) terminalState[e] = done_[e] != 0; }
-  void setSeed(int) {}
+  void setSeed(int) {}            // the simulation is deterministic; randomness lives in the caller's actions
   void close() {}
-  void curriculumUpdate() {}
+  void curriculumUpdate() {}      // rsg_anymal has no curriculum
   void turnOnVisualization() {}
   void turnOffVisualization() {}
   void setSimulationTimeStep(double dt) { cfg_.simulation_dt = dt; world_.setTimeStep(dt); substeps_ = (int)(cfg_.control_dt / dt + 1e-10); configureEnv(); }
@@ -118,6 +126,147 @@ class VectorizedEnvironment {
   std::vector<float> gcInit_, gvInit_;
   std::vector<int32_t> feet_;
   std::vector<uint8_t> done_;
+};
+
+/// Upstream's template: N arbitrary ChildEnvironment objects on one GPU batch (see the header comment).
+template <class ChildEnvironment>
+class VectorizedEnvironment {
+ public:
+  explicit VectorizedEnvironment(std::string resourceDir, std::string cfg, bool normalizeObservation = true)
+      : resourceDir_(std::move(resourceDir)), cfgString_(std::move(cfg)), normalizeObservation_(normalizeObservation) {
+    Yaml::Parse(cfg_, cfgString_);
+    if (!cfg_["render"].IsNone()) render_ = cfg_["render"].template As<bool>();
+    init();
+  }
+  ~VectorizedEnvironment() { for (auto* env : environments_) delete env; }
+  VectorizedEnvironment(const VectorizedEnvironment&) = delete;
+  VectorizedEnvironment& operator=(const VectorizedEnvironment&) = delete;
+
+  const std::string& getResourceDir() const { return resourceDir_; }
+  const std::string& getCfgString() const { return cfgString_; }
+
+  void init() {
+    if (!environments_.empty()) return;
+    num_envs_ = cfg_["num_envs"].template As<int>();
+    const int device = cfg_["device"].template As<int>(0);      // (new key) GPU that holds the batch; cfg["num_threads"] is ignored
+    environments_.reserve(num_envs_);
+    rewardInformation_.reserve(num_envs_);
+    {
+      BatchScope scope(num_envs_, device);     // the N Worlds constructed below become the N replicas of one BatchedWorld
+      for (int i = 0; i < num_envs_; i++) {
+        environments_.push_back(new ChildEnvironment(resourceDir_, cfg_, render_ && i == 0));
+        environments_.back()->setSimulationTimeStep(cfg_["simulation_dt"].template As<double>());
+        environments_.back()->setControlTimeStep(cfg_["control_dt"].template As<double>());
+        rewardInformation_.push_back(environments_.back()->getRewards().getStdMap());
+      }
+      batch_ = scope.shared();
+    }
+    setSeed(0);
+    for (int i = 0; i < num_envs_; i++) {
+      environments_[i]->init();
+      environments_[i]->reset();
+    }
+    obDim_ = environments_[0]->getObDim();
+    actionDim_ = environments_[0]->getActionDim();
+    RSFATAL_IF(obDim_ == 0 || actionDim_ == 0, "Observation/Action dimension must be defined in the constructor of each environment!");
+    if (normalizeObservation_) {
+      obMean_.assign(obDim_, 0.f); obVar_.assign(obDim_, 1.f);
+      recentMean_.assign(obDim_, 0.f); recentVar_.assign(obDim_, 0.f); delta_.assign(obDim_, 0.f);
+    }
+  }
+
+  // resets all environments and returns observation
+  void reset() { for (auto env : environments_) env->reset(); }
+
+  /// ob: float [num_envs, obDim] row-major (upstream: Eigen::Ref<EigenRowMajorMat>&)
+  void observe(float* ob, int rows, int cols, bool updateStatistics) {
+    RSFATAL_IF(rows != num_envs_ || cols != obDim_, "observe: buffer must be [num_envs, obDim]");
+    for (int i = 0; i < num_envs_; i++) environments_[i]->observe(EigenVecRef(ob + (size_t)i * obDim_, obDim_));
+    if (normalizeObservation_) updateObservationStatisticsAndNormalize(ob, updateStatistics);
+  }
+
+  /// action: float [num_envs, actionDim]; reward: float [num_envs]; done: bool [num_envs] - written in place.
+  /// The N step() bodies run as fibers; each World::integrate() inside them is one launch for the whole batch.
+  void step(const float* action, int rows, int cols, float* reward, bool* done) {
+    RSFATAL_IF(rows != num_envs_ || cols != actionDim_, "step: action must be [num_envs, actionDim]");
+    auto body = [&](int i) { perAgentStep(i, action, reward, done); };
+    if (!batch_) { for (int i = 0; i < num_envs_; i++) body(i); return; }     // envs that never created a World
+    struct Guard { BatchedWorld* b; ~Guard() { b->setFiberBatch(false); } } guard{batch_.get()};
+    batch_->setFiberBatch(true);
+    fibers_.run(num_envs_, body, [this] { batch_->flushViews(); });
+  }
+
+  void turnOnVisualization() { if (render_) environments_[0]->turnOnVisualization(); }
+  void turnOffVisualization() { if (render_) environments_[0]->turnOffVisualization(); }
+  void startRecordingVideo(const std::string& videoName) { if (render_) environments_[0]->startRecordingVideo(videoName); }
+  void stopRecordingVideo() { if (render_) environments_[0]->stopRecordingVideo(); }
+  void getObStatistics(float* mean, float* var, float& count) {
+    for (int i = 0; i < obDim_; ++i) { mean[i] = obMean_[i]; var[i] = obVar_[i]; }
+    count = obCount_;
+  }
+  void setObStatistics(const float* mean, const float* var, float count) {
+    obMean_.assign(mean, mean + obDim_); obVar_.assign(var, var + obDim_); obCount_ = count;
+  }
+  void setSeed(int seed) { int seed_inc = seed; for (auto* env : environments_) env->setSeed(seed_inc++); }
+  void close() { for (auto* env : environments_) env->close(); }
+  void isTerminalState(bool* terminalState) {
+    for (int i = 0; i < num_envs_; i++) { float terminalReward; terminalState[i] = environments_[i]->isTerminalState(terminalReward); }
+  }
+  void setSimulationTimeStep(double dt) { for (auto* env : environments_) env->setSimulationTimeStep(dt); }
+  void setControlTimeStep(double dt) { for (auto* env : environments_) env->setControlTimeStep(dt); }
+  int getObDim() { return obDim_; }
+  int getActionDim() { return actionDim_; }
+  int getNumOfEnvs() { return num_envs_; }
+  void curriculumUpdate() { for (auto* env : environments_) env->curriculumUpdate(); }
+  const std::vector<std::map<std::string, float>>& getRewardInfo() { return rewardInformation_; }
+
+  /// (new) the batch behind the environments and how many launches its views have issued so far
+  BatchedWorld* batch() { return batch_.get(); }
+  ChildEnvironment* environment(int i) { return environments_[i]; }
+
+ private:
+  void updateObservationStatisticsAndNormalize(float* ob, bool updateStatistics) {
+    const int n = num_envs_, d = obDim_;
+    if (updateStatistics) {
+      for (int j = 0; j < d; ++j) { double m = 0; for (int i = 0; i < n; ++i) m += ob[(size_t)i * d + j]; recentMean_[j] = (float)(m / n); }
+      for (int j = 0; j < d; ++j) { double v = 0; for (int i = 0; i < n; ++i) { const double x = ob[(size_t)i * d + j] - recentMean_[j]; v += x * x; } recentVar_[j] = (float)(v / n); }
+      const float totCount = obCount_ + n;
+      for (int j = 0; j < d; ++j) {
+        delta_[j] = obMean_[j] - recentMean_[j];
+        delta_[j] = delta_[j] * delta_[j];
+        obMean_[j] = obMean_[j] * (obCount_ / totCount) + recentMean_[j] * (n / totCount);
+        obVar_[j] = (obVar_[j] * obCount_ + recentVar_[j] * n + delta_[j] * (obCount_ * n / totCount)) / totCount;
+      }
+      obCount_ = totCount;
+    }
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < d; ++j) ob[(size_t)i * d + j] = (ob[(size_t)i * d + j] - obMean_[j]) / std::sqrt(obVar_[j] + 1e-8f);
+  }
+
+  inline void perAgentStep(int agentId, const float* action, float* reward, bool* done) {
+    reward[agentId] = environments_[agentId]->step(ConstEigenVecRef(action + (size_t)agentId * actionDim_, actionDim_));
+    rewardInformation_[agentId] = environments_[agentId]->getRewards().getStdMap();
+    float terminalReward = 0;
+    done[agentId] = environments_[agentId]->isTerminalState(terminalReward);
+    if (done[agentId]) {
+      environments_[agentId]->reset();
+      reward[agentId] += terminalReward;
+    }
+  }
+
+  std::vector<ChildEnvironment*> environments_;
+  std::vector<std::map<std::string, float>> rewardInformation_;
+  std::shared_ptr<BatchedWorld> batch_;
+  detail::FiberScheduler fibers_;
+  int num_envs_ = 1, obDim_ = 0, actionDim_ = 0;
+  bool recordVideo_ = false, render_ = false;
+  std::string resourceDir_;
+  Yaml::Node cfg_;
+  std::string cfgString_;
+  /// observation running mean
+  bool normalizeObservation_ = true;
+  std::vector<float> obMean_, obVar_, recentMean_, recentVar_, delta_;
+  float obCount_ = 1e-4f;
 };
 
 }  // namespace raisim

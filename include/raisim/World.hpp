@@ -6,20 +6,35 @@
 //
 //   raisim::BatchedWorld   N replicas of {World + one ArticulatedSystem + terrain} on one GPU (new type; what a
 //                          batched VectorizedEnvironment drives directly — the fast path).
-//   raisim::World          the upstream per-env class.  Default-constructed it owns a BatchedWorld with N = 1 (so an
-//                          unmodified Environment.hpp runs, one launch per env: correctness path); constructed from
-//                          (BatchedWorld&, env) it is a view of one replica.
-//   raisim::ArticulatedSystem  per-env view (handle, env index); state setters/getters move one row host<->device.
+//   raisim::World          the upstream per-env class, always a VIEW of one replica of a BatchedWorld:
+//                            - default-constructed outside a batch scope it owns a 1-replica BatchedWorld (an unmodified
+//                              Environment.hpp runs, one launch per env: correctness path);
+//                            - default-constructed inside a raisim::BatchScope (what VectorizedEnvironment<ENV> opens
+//                              around the construction of its N environments) the k-th World becomes replica k of ONE
+//                              shared BatchedWorld with N replicas;
+//                            - World(BatchedWorld&, env) names the replica explicitly.
+//                          integrate() on a view advances THAT replica only: the call is recorded, and the batch is
+//                          flushed with a single launch once every replica has one pending (or, under
+//                          VectorizedEnvironment<ENV>, once every env's step() body is parked in integrate(): Fiber.hpp).
+//                          Global setters (setTimeStep, setGravity, addGround, setERP, materials, solver parameters,
+//                          PD gains) act on the shared world, i.e. on ALL replicas - every env of a vectorised
+//                          environment calls them with the same values, as upstream's ENVs do.
+//   raisim::ArticulatedSystem  per-env view.  Row writes (state, PD targets, feed-forward force) are staged on the host
+//                          and uploaded as whole arrays at the next flush; reads come from a host copy of the batch
+//                          refreshed once per flush - N envs cost a constant number of PCIe transfers per integrate().
 //
 // Errors follow upstream's RSFATAL: a failed call throws std::runtime_error with rsb_last_error().
 #pragma once
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+#include "raisim/Fiber.hpp"
 #include "raisim/math.hpp"
 #include "rsb.h"
 
@@ -87,28 +102,143 @@ class BatchedWorld {
     RSFATAL_IF((int)h.size() != xSamples * ySamples, "addHeightMap: height.size() != xSamples*ySamples");
     RSB_CHECK(rsb_set_heightmap(world_, xSamples, ySamples, xSize, ySize, centerX, centerY, h.data()));
   }
-  void integrate(int nSubsteps = 1) { RSB_CHECK(rsb_integrate(world_, nSubsteps)); }
-  void integrate1() { RSB_CHECK(rsb_integrate1(world_)); }
-  void integrate2() { RSB_CHECK(rsb_integrate2(world_)); }
+  /// the whole batch at once (fast path; staged view writes are uploaded first)
+  void integrate(int nSubsteps = 1) { uploadStaged(); RSB_CHECK(rsb_integrate(world_, nSubsteps)); stateCacheValid_ = false; contactsValid_ = false; }
+  void integrate1() { uploadStaged(); RSB_CHECK(rsb_integrate1(world_)); }
+  void integrate2() { uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; }
 
   // batched, caller-owned host buffers (row-major [N, dim] float32, the raisimGymTorch matrix layout)
-  void setState(const float* gc, const float* gv) { RSB_CHECK(rsb_set_state(world_, gc, gv, nullptr, RSB_HOST)); }
-  void getState(float* gc, float* gv) { RSB_CHECK(rsb_get_state(world_, gc, gv, RSB_HOST)); }
+  void setState(const float* gc, const float* gv) {
+    RSB_CHECK(rsb_set_state(world_, gc, gv, nullptr, RSB_HOST)); dropStage(RSB_F_GC); dropStage(RSB_F_GV); stateCacheValid_ = false;
+    std::fill(gcMask_.begin(), gcMask_.end(), 0); std::fill(gvMask_.begin(), gvMask_.end(), 0);
+  }
+  void getState(float* gc, float* gv) { uploadStaged(); RSB_CHECK(rsb_get_state(world_, gc, gv, RSB_HOST)); }
   void setPdGains(const float* kp, const float* kd) { RSB_CHECK(rsb_set_pd_gains(world_, kp, kd)); }
-  void setPdTarget(const float* pTarget, const float* dTarget) { RSB_CHECK(rsb_set_pd_target(world_, pTarget, dTarget, RSB_HOST)); }
-  void setGeneralizedForce(const float* tau) { RSB_CHECK(rsb_set_generalized_force(world_, tau, RSB_HOST)); }
+  void setPdTarget(const float* pTarget, const float* dTarget) { RSB_CHECK(rsb_set_pd_target(world_, pTarget, dTarget, RSB_HOST)); if (pTarget) dropStage(RSB_F_PTARGET); if (dTarget) dropStage(RSB_F_DTARGET); }
+  void setGeneralizedForce(const float* tau) { RSB_CHECK(rsb_set_generalized_force(world_, tau, RSB_HOST)); dropStage(RSB_F_TAU_FF); }
   void setControlMode(ControlMode::Type m) { RSB_CHECK(rsb_set_control_mode(world_, (int)m)); }
 
+ public:
+  // ---- staging and caches behind the per-env views (raisim::World / raisim::ArticulatedSystem) ---------------------
+  /// stage one env's row of GC / GV / PTARGET / DTARGET / TAU_FF; uploaded as a whole array at the next flush.
+  /// The host arrays double as the read mirror, so an env reading back what it just wrote costs no transfer.
+  void stageRow(int field, int env, const double* v, int dim) {
+    Stage& st = stage(field);
+    for (int i = 0; i < dim; ++i) st.host[(size_t)env * dim + i] = (float)v[i];
+    st.dirty = true;
+    if (field == RSB_F_GC) gcMask_[env] = 1;
+    if (field == RSB_F_GV) gvMask_[env] = 1;
+  }
+  /// one env's row of any of the five fields, as the device holds (or is about to hold) it
+  void readRow(int field, int env, double* out, int dim) {
+    requireNotPending(env, "a state read");
+    if (field == RSB_F_GC || field == RSB_F_GV) refreshState();
+    const float* src = stage(field).host.data();
+    for (int i = 0; i < dim; ++i) out[i] = src[(size_t)env * dim + i];
+  }
+  /// World::integrate() of replica `env`: recorded; flushed when every replica has one pending, or by the fiber scheduler
+  void integrateView(int env) {
+    if (pending_[env]) throw std::runtime_error("raisim::World::integrate(): this replica already has an un-flushed integrate(); "
+                                                "every World of the batch must call integrate() before the next one (or drive the envs through VectorizedEnvironment<ENV>)");
+    pending_[env] = 1; ++nPending_;
+    detail::FiberScheduler* fs = detail::FiberScheduler::current();
+    if (fs && fiberBatch_) { fs->park(); return; }       // flushed by the scheduler once every live env is parked here
+    if (nPending_ == n_) flushViews();
+  }
+  /// one launch for all pending replicas (no-op when none is pending)
+  void flushViews() {
+    if (nPending_ == 0) return;
+    uploadStaged();
+    if (nPending_ == n_) RSB_CHECK(rsb_integrate(world_, 1));
+    else RSB_CHECK(rsb_integrate_masked(world_, 1, pending_.data(), RSB_HOST));
+    std::fill(pending_.begin(), pending_.end(), 0);
+    nPending_ = 0;
+    ++viewLaunches_;
+    stateCacheValid_ = false; contactsValid_ = false;
+  }
+  void setFiberBatch(bool on) { fiberBatch_ = on; }
+  long viewLaunches() const { return viewLaunches_; }     ///< launches issued by flushViews() (tests: N views -> 1 launch)
+  int pendingViews() const { return nPending_; }
+  /// contacts of the last integrate() of every env, downloaded once per flush
+  const std::vector<rsb_contact>& contactsOf(int env, int& count, int& kmax) {
+    requireNotPending(env, "getContacts()");
+    if (!contactsValid_) {
+      RSB_CHECK(rsb_dims(world_, nullptr, nullptr, nullptr, nullptr, &kmax_));
+      cnt_.resize(n_); con_.resize((size_t)n_ * kmax_);
+      RSB_CHECK(rsb_get_contacts(world_, cnt_.data(), con_.data(), RSB_HOST));
+      contactsValid_ = true;
+    }
+    count = cnt_[env]; kmax = kmax_;
+    return con_;
+  }
+  /// staged rows -> device (before a launch, or before a query that must see them)
+  void uploadStaged() {
+    Stage& gc = stages_[RSB_F_GC]; Stage& gv = stages_[RSB_F_GV];
+    if (gc.dirty || gv.dirty) {
+      // masked upload: only the rows a view wrote are overwritten (and their solver warm state cleared).  A row written in
+      // only one of the two fields takes its other half from the mirror, which must then be current.
+      bool half = false;
+      for (int e = 0; e < n_ && !half; ++e) half = gcMask_[e] != gvMask_[e];
+      if (half) refreshState();
+      std::vector<uint8_t> m(n_);
+      for (int e = 0; e < n_; ++e) m[e] = gcMask_[e] | gvMask_[e];
+      RSB_CHECK(rsb_set_state(world_, stage(RSB_F_GC).host.data(), stage(RSB_F_GV).host.data(), m.data(), RSB_HOST));
+      gc.dirty = gv.dirty = false;
+      std::fill(gcMask_.begin(), gcMask_.end(), 0); std::fill(gvMask_.begin(), gvMask_.end(), 0);
+    }
+    Stage& pt = stages_[RSB_F_PTARGET]; Stage& dt = stages_[RSB_F_DTARGET]; Stage& tf = stages_[RSB_F_TAU_FF];
+    if (pt.dirty || dt.dirty) { RSB_CHECK(rsb_set_pd_target(world_, pt.dirty ? pt.host.data() : nullptr, dt.dirty ? dt.host.data() : nullptr, RSB_HOST)); pt.dirty = dt.dirty = false; }
+    if (tf.dirty) { RSB_CHECK(rsb_set_generalized_force(world_, tf.host.data(), RSB_HOST)); tf.dirty = false; }
+  }
+
  private:
+  struct Stage { std::vector<float> host; bool init = false, dirty = false; };
+  Stage& stage(int field) {
+    Stage& st = stages_[field];
+    if (!st.init) {          // the host copy starts as what the device holds
+      const int dim = (field == RSB_F_GC || field == RSB_F_PTARGET) ? blob_.nq : blob_.nv;
+      st.host.resize((size_t)n_ * dim);
+      RSB_CHECK(rsb_get_field(world_, field, st.host.data(), RSB_HOST));
+      st.init = true;
+    }
+    return st;
+  }
+  void dropStage(int field) { stages_[field].init = false; stages_[field].dirty = false; }
+  /// make the GC / GV mirrors current: one download after a launch; rows staged since then keep their staged values
+  void refreshState() {
+    if (stateCacheValid_ && stages_[RSB_F_GC].init && stages_[RSB_F_GV].init) return;
+    Stage& gc = stage(RSB_F_GC); Stage& gv = stage(RSB_F_GV);
+    tmpGc_.resize(gc.host.size()); tmpGv_.resize(gv.host.size());
+    RSB_CHECK(rsb_get_state(world_, tmpGc_.data(), tmpGv_.data(), RSB_HOST));
+    const int nq = blob_.nq, nv = blob_.nv;
+    for (int e = 0; e < n_; ++e) {
+      if (!gcMask_[e]) std::copy_n(&tmpGc_[(size_t)e * nq], nq, &gc.host[(size_t)e * nq]);
+      if (!gvMask_[e]) std::copy_n(&tmpGv_[(size_t)e * nv], nv, &gv.host[(size_t)e * nv]);
+    }
+    stateCacheValid_ = true;
+  }
+  void requireNotPending(int env, const char* what) const {
+    if (pending_[env]) throw std::runtime_error(std::string("raisim::World view: ") + what + " while this replica's integrate() is still waiting for the "
+                                                "other replicas of the batch (all views must call integrate() first, or use VectorizedEnvironment<ENV>)");
+  }
   void init(int numEnvs, int device) {
     RSB_CHECK(rsb_model_get_blob(model_, &blob_));
     RSB_CHECK(rsb_create(model_, numEnvs, device, &world_));
     n_ = numEnvs;
+    pending_.assign(n_, 0); gcMask_.assign(n_, 0); gvMask_.assign(n_, 0);
   }
   rsb_model* model_ = nullptr;
   rsb_world* world_ = nullptr;
   rsb_model_blob blob_;
   int n_ = 0;
+  Stage stages_[5];
+  std::vector<uint8_t> pending_, gcMask_, gvMask_;
+  int nPending_ = 0, kmax_ = 0;
+  long viewLaunches_ = 0;
+  bool fiberBatch_ = false, stateCacheValid_ = false, contactsValid_ = false;
+  std::vector<float> tmpGc_, tmpGv_;
+  std::vector<int32_t> cnt_;
+  std::vector<rsb_contact> con_;
 };
 
 class Ground {};
@@ -212,13 +342,10 @@ class ArticulatedSystem {
   }
   /// contacts of the last integrate() of this env
   std::vector<Contact>& getContacts() {
-    int kmax = 0;
-    RSB_CHECK(rsb_dims(w_->handle(), nullptr, nullptr, nullptr, nullptr, &kmax));
-    std::vector<int32_t> cnt(w_->numEnvs());
-    std::vector<rsb_contact> con((size_t)w_->numEnvs() * kmax);
-    RSB_CHECK(rsb_get_contacts(w_->handle(), cnt.data(), con.data(), RSB_HOST));
+    int kmax = 0, count = 0;
+    const std::vector<rsb_contact>& con = w_->contactsOf(env_, count, kmax);
     contacts_.clear();
-    for (int k = 0; k < cnt[env_]; ++k) contacts_.emplace_back(con[(size_t)env_ * kmax + k]);
+    for (int k = 0; k < count; ++k) contacts_.emplace_back(con[(size_t)env_ * kmax + k]);
     return contacts_;
   }
   // ---- frame queries (slow path, correctness only: forward kinematics of this env on the host from the model blob).
@@ -268,14 +395,13 @@ class ArticulatedSystem {
 
  private:
   void putRow(int field, const VecDyn& v) {
-    std::vector<float> f(v.v.begin(), v.v.end());
-    RSB_CHECK(rsb_set_env_row(w_->handle(), field, env_, f.data()));
+    const int dim = (field == RSB_F_GC || field == RSB_F_PTARGET) ? w_->gcDim() : w_->dof();
+    RSFATAL_IF((int)v.size() != dim, "ArticulatedSystem: vector has the wrong dimension");
+    w_->stageRow(field, env_, v.data(), dim);
   }
   void getRow(int field, VecDyn& v, int dim) {
-    std::vector<float> f(dim);
-    RSB_CHECK(rsb_get_env_row(w_->handle(), field, env_, f.data()));
     v.resize(dim);
-    for (int i = 0; i < dim; ++i) v[i] = f[i];
+    w_->readRow(field, env_, v.data(), dim);
   }
   // host forward kinematics of this env (world frame): fkR_ [nb][9] row-major, fkP_ [nb][3], fkA_ [nb][3] joint axes
   void fk() {
@@ -354,16 +480,58 @@ class ArticulatedSystem {
   std::vector<Contact> contacts_;
 };
 
-/// Upstream raisim::World: one env.  Owns a 1-replica BatchedWorld, or views replica `env` of a shared one.
+/// Opens a scope in which default-constructed raisim::World objects become replicas 0, 1, 2, ... of ONE shared
+/// BatchedWorld with `numEnvs` replicas (created by the first addArticulatedSystem call inside the scope).  This is how
+/// VectorizedEnvironment<ENV> puts N unmodified Environment objects - each of which does
+/// `world_ = std::make_unique<raisim::World>()` - onto one GPU batch.
+class BatchScope {
+ public:
+  BatchScope(int numEnvs, int device = 0) : n_(numEnvs), device_(device), prev_(active()) { active() = this; }
+  ~BatchScope() { active() = prev_; }
+  BatchScope(const BatchScope&) = delete;
+  BatchScope& operator=(const BatchScope&) = delete;
+  static BatchScope*& active() { static thread_local BatchScope* a = nullptr; return a; }
+  /// the shared world (null until the first World of the scope has loaded its URDF); outlives the scope
+  std::shared_ptr<BatchedWorld> shared() const { return shared_; }
+  int numEnvs() const { return n_; }
+ private:
+  friend class World;
+  int n_, device_, next_ = 0;
+  std::string urdf_;
+  std::shared_ptr<BatchedWorld> shared_;
+  BatchScope* prev_;
+};
+
+/// Upstream raisim::World: one env = one replica of a BatchedWorld (see the header comment for the three ways it binds).
 class World {
  public:
-  World() = default;
-  World(BatchedWorld& shared, int env) : shared_(&shared), env_(env) {}
+  World() {
+    if (BatchScope* sc = BatchScope::active()) {
+      RSFATAL_IF(sc->next_ >= sc->n_, "raisim::World: more Worlds constructed than the BatchScope has replicas");
+      scope_ = sc; env_ = sc->next_++;
+      if (sc->shared_) { keep_ = sc->shared_; shared_ = keep_.get(); }
+    }
+  }
+  World(BatchedWorld& shared, int env) : shared_(&shared), env_(env) {
+    RSFATAL_IF(env < 0 || env >= shared.numEnvs(), "raisim::World: replica index out of range");
+  }
   static void setActivationKey(const std::string&) {}  // nothing to activate in a from-scratch build
+  int replica() const { return env_; }
+  BatchedWorld* batch() { return shared_; }
 
   ArticulatedSystem* addArticulatedSystem(const std::string& urdfPath, const std::string& /*resDir*/ = "") {
     RSFATAL_IF(robot_ != nullptr, "this build supports one ArticulatedSystem per World");
-    if (!shared_) { owned_ = std::make_unique<BatchedWorld>(urdfPath, 1); shared_ = owned_.get(); env_ = 0; applyPending(); }
+    if (!shared_) {
+      if (scope_) {      // the first World of a BatchScope creates the shared batch, the others attach to it
+        if (!scope_->shared_) { scope_->shared_ = std::make_shared<BatchedWorld>(urdfPath, scope_->n_, scope_->device_); scope_->urdf_ = urdfPath; }
+        RSFATAL_IF(scope_->urdf_ != urdfPath, "raisim::World: every env of one batch must load the same URDF");
+        keep_ = scope_->shared_;
+      } else {
+        keep_ = std::make_shared<BatchedWorld>(urdfPath, 1); env_ = 0;
+      }
+      shared_ = keep_.get();
+      applyPending();
+    }
     robot_ = std::make_unique<ArticulatedSystem>(shared_, env_);
     return robot_.get();
   }
@@ -417,15 +585,18 @@ class World {
     need().setDefaultMaterial(mu, r, t);
   }
   void setContactSolverParam(double a0, double amin, double adec, int maxIter, double thr) { need().setContactSolverParam(a0, amin, adec, maxIter, thr); }
-  void integrate() { need().integrate(1); }
+  /// advances THIS replica by one time step; launched together with the other replicas' pending integrate() calls
+  void integrate() { need().integrateView(env_); }
+  /// M, h queries of the current state (computed for the whole batch, idempotent); integrate2() then advances this replica
   void integrate1() { need().integrate1(); }
-  void integrate2() { need().integrate2(); }
+  void integrate2() { need().integrateView(env_); }
 
  private:
   BatchedWorld& need() { RSFATAL_IF(!shared_, "World: add the ArticulatedSystem before configuring the solver"); return *shared_; }
   void applyPending() { if (dt_ > 0) shared_->setTimeStep(dt_); if (hasGround_) shared_->addGround(groundZ_); }
-  std::unique_ptr<BatchedWorld> owned_;
+  std::shared_ptr<BatchedWorld> keep_;     // owned 1-replica world, or a share of the BatchScope's world
   BatchedWorld* shared_ = nullptr;
+  BatchScope* scope_ = nullptr;
   int env_ = 0;
   std::unique_ptr<ArticulatedSystem> robot_;
   std::unique_ptr<HeightMap> hm_;

@@ -233,6 +233,9 @@ int rsb_get_state(rsb_world* w, float* gc, float* gv, int space);
 int rsb_set_env_row(rsb_world* w, int field, int env, const float* data);
 int rsb_get_env_row(rsb_world* w, int field, int env, float* data);
 
+/* a whole state field at once: field = RSB_F_GC / RSB_F_GV / RSB_F_PTARGET / RSB_F_DTARGET / RSB_F_TAU_FF, out [N, dim] float32 */
+int rsb_get_field(rsb_world* w, int field, float* out, int space);
+
 int rsb_set_control_mode(rsb_world* w, int mode);
 int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd);      /* host, [nv] each  */
 int rsb_set_pd_target(rsb_world* w, const float* p_target, const float* d_target, int space); /* [N,nq],[N,nv]; either may be NULL */
@@ -281,6 +284,20 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
 int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target, int n_substeps, float* obs_out,
                      const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
                      int n_allowed, const float* gc0, const float* gv0, int rows);
+
+/* ---- multi-GPU without Python: the obs all-gather over RCCL / xGMI.  One process per GPU; envs are sharded
+ * contiguously, rank r owns global envs [r*N, (r+1)*N); nothing inside integrate() communicates.  librccl.so.1 is loaded
+ * at run time by the first rsb_comm_* call (a host that never calls them needs no RCCL).  Upstream has no counterpart
+ * (RaiSim is single-process); this is the C/C++ twin of raisimlib_amd/dist.py.
+ *   rsb_comm_get_unique_id : rank 0 creates the id (ncclGetUniqueId), the launcher hands it to the other ranks
+ *   rsb_comm_init          : ncclCommInitRank on the world's device (collective: every rank calls it)
+ *   rsb_allgather_obs      : the rank's obs block (rsb_gather_obs semantics) -> out [n_ranks*N, obs_dim], rank-major, on the
+ *                            handle's stream; out in `space` (DEVICE: gathered in place, nothing synchronises; HOST: staged) */
+#define RSB_COMM_ID_BYTES 128
+int rsb_comm_get_unique_id(char id[RSB_COMM_ID_BYTES]);
+int rsb_comm_init(rsb_world* w, int n_ranks, int rank, const char id[RSB_COMM_ID_BYTES]);
+int rsb_comm_destroy(rsb_world* w);
+int rsb_allgather_obs(rsb_world* w, const int32_t* collision_indices, int n_force_slots, float* out, int space);
 
 /* done flags of the fused control step: when `done_device` (uint8 [num_envs], DEVICE memory, caller-owned) is set,
  * every following rsb_control_step writes 1 for the envs it reset and 0 for the others (NULL switches it off). */

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "rsb_get_state": (_I, [_VP, _FP, _FP, _I]),
     "rsb_set_env_row": (_I, [_VP, _I, _I, _FP]),
     "rsb_get_env_row": (_I, [_VP, _I, _I, _FP]),
+    "rsb_get_field": (_I, [_VP, _I, _FP, _I]),
     "rsb_set_control_mode": (_I, [_VP, _I]),
     "rsb_set_pd_gains": (_I, [_VP, _FP, _FP]),
     "rsb_set_pd_target": (_I, [_VP, _FP, _FP, _I]),
@@ -112,6 +113,10 @@ PROTOTYPES = {
     "rsb_integrate": (_I, [_VP, _I]),
     "rsb_integrate_masked": (_I, [_VP, _I, _VP, _I]),
     "rsb_set_done_output": (_I, [_VP, _VP]),
+    "rsb_comm_get_unique_id": (_I, [C.c_char_p]),
+    "rsb_comm_init": (_I, [_VP, _I, _I, C.c_char_p]),
+    "rsb_comm_destroy": (_I, [_VP]),
+    "rsb_allgather_obs": (_I, [_VP, _VP, _I, _FP, _I]),
     "rsb_integrate1": (_I, [_VP]),
     "rsb_integrate2": (_I, [_VP]),
     "rsb_get_contacts": (_I, [_VP, _FP, _FP, _I]),

@@ -4,6 +4,7 @@
 // [RECALL; World.hpp / ArticulatedSystem.hpp are absent from /root/reference, SURVEY.md §8b].
 // State lives in HBM as row-major [N, dim] float32 rows; rsb_integrate() launches the fused step
 // kernel (step_kernel.h) on the handle's stream.  No CPU fallback exists anywhere in this file.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -52,6 +53,10 @@ struct rsb_world {
   uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
   const uint8_t* launch_mask = nullptr; // env mask of the next launch only (rsb_integrate_masked)
   uint8_t* d_launch_mask = nullptr;     // staging for host masks
+  void* comm = nullptr;                 // ncclComm_t (rsb_comm_init)
+  int comm_ranks = 0, comm_rank = 0;
+  float *d_obs_local = nullptr, *d_obs_all = nullptr;   // staging of rsb_allgather_obs
+  size_t obs_local_cap = 0, obs_all_cap = 0;
   bool early_term = false;   // rsb_set_early_termination
   std::vector<int32_t> obs_idx_host;   // what d_obs_idx currently holds (re-uploaded only when the caller's list changes)
   float* d_dbg = nullptr;
@@ -553,9 +558,10 @@ int rsb_destroy(rsb_world* w) {
   if (!w) return RSB_OK;
   (void)hipSetDevice(w->device);
   if (w->stream) (void)hipStreamSynchronize(w->stream);
+  (void)rsb_comm_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_hm_index, w->d_launch_mask,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -766,6 +772,14 @@ int rsb_get_env_row(rsb_world* w, int field, int env, float* data) {
   HIP_TRY(hipMemcpyAsync(data, base + (size_t)env * dim, dim * sizeof(float), hipMemcpyDeviceToHost, w->stream));
   HIP_TRY(hipStreamSynchronize(w->stream));
   return RSB_OK;
+}
+
+int rsb_get_field(rsb_world* w, int field, float* out, int space) {
+  float* base; size_t dim;
+  int st = env_row(w, field, 0, &base, &dim);
+  if (st != RSB_OK || !out) return st != RSB_OK ? st : RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  return copy_out(w, out, base, (size_t)w->N * dim * sizeof(float), space);
 }
 
 int rsb_set_control_mode(rsb_world* w, int mode) {
@@ -1200,6 +1214,114 @@ int rsb_last_kernel_ms(rsb_world* w, float* ms) {
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipEventSynchronize(w->ev1));
   HIP_TRY(hipEventElapsedTime(ms, w->ev0, w->ev1));
+  return RSB_OK;
+}
+
+}  // extern "C"
+
+// ---- RCCL (loaded at run time: a single-GPU host never needs it) -------------------------------------------------
+namespace {
+struct Rccl {
+  struct UniqueId { char internal[RSB_COMM_ID_BYTES]; };     // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* handle = nullptr;
+  std::string error;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.handle ? &r : nullptr;
+  tried = true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.handle) break; }
+  if (!r.handle) { r.error = std::string("cannot load librccl.so.1: ") + dlerror(); return nullptr; }
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+    r.error = "librccl.so.1 lacks an expected ncclXxx symbol"; dlclose(r.handle); r.handle = nullptr; return nullptr;
+  }
+  return &r;
+}
+Rccl* need_rccl() {
+  Rccl* r = rccl();
+  if (!r) rsb::set_error("RCCL unavailable (multi-GPU entry points need /opt/rocm/lib/librccl.so.1)");
+  return r;
+}
+constexpr int kNcclFloat32 = 7;   // ncclDataType_t::ncclFloat32 (rccl.h)
+#define NCCL_TRY(expr)                                                                                   \
+  do {                                                                                                   \
+    int r_ = (expr);                                                                                     \
+    if (r_ != 0) { rsb::set_error(std::string(#expr) + ": " + R->GetErrorString(r_)); return RSB_E_HIP; } \
+  } while (0)
+}  // namespace
+
+extern "C" {
+
+int rsb_comm_get_unique_id(char id[RSB_COMM_ID_BYTES]) {
+  if (!id) return RSB_E_INVALID;
+  Rccl* R = need_rccl();
+  if (!R) return RSB_E_UNSUPPORTED;
+  Rccl::UniqueId u;
+  NCCL_TRY(R->GetUniqueId(&u));
+  std::memcpy(id, u.internal, RSB_COMM_ID_BYTES);
+  return RSB_OK;
+}
+
+int rsb_comm_init(rsb_world* w, int n_ranks, int rank, const char id[RSB_COMM_ID_BYTES]) {
+  if (!w || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) { rsb::set_error("rsb_comm_init: bad argument"); return RSB_E_INVALID; }
+  if (w->comm) { rsb::set_error("rsb_comm_init: the world already has a communicator"); return RSB_E_STATE; }
+  Rccl* R = need_rccl();
+  if (!R) return RSB_E_UNSUPPORTED;
+  HIP_TRY(hipSetDevice(w->device));
+  Rccl::UniqueId u;
+  std::memcpy(u.internal, id, RSB_COMM_ID_BYTES);
+  NCCL_TRY(R->CommInitRank(&w->comm, n_ranks, u, rank));
+  w->comm_ranks = n_ranks; w->comm_rank = rank;
+  return RSB_OK;
+}
+
+int rsb_comm_destroy(rsb_world* w) {
+  if (!w || !w->comm) return RSB_OK;
+  Rccl* R = rccl();
+  if (R) { (void)hipSetDevice(w->device); (void)hipStreamSynchronize(w->stream); (void)R->CommDestroy(w->comm); }
+  w->comm = nullptr; w->comm_ranks = 0;
+  return RSB_OK;
+}
+
+int rsb_allgather_obs(rsb_world* w, const int32_t* collision_indices, int n_force_slots, float* out, int space) {
+  if (!w || !out || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) { rsb::set_error("rsb_allgather_obs: bad argument"); return RSB_E_INVALID; }
+  if (!w->comm) { rsb::set_error("rsb_allgather_obs: call rsb_comm_init first"); return RSB_E_STATE; }
+  Rccl* R = need_rccl();
+  if (!R) return RSB_E_UNSUPPORTED;
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t local = (size_t)w->N * (w->blob.nq + w->blob.nv + 3 * n_force_slots), all = local * w->comm_ranks;
+  if (w->obs_local_cap < local) {
+    if (w->d_obs_local) HIP_TRY(hipFree(w->d_obs_local));
+    w->d_obs_local = nullptr; w->obs_local_cap = 0;
+    HIP_TRY(hipMalloc(&w->d_obs_local, local * sizeof(float)));
+    w->obs_local_cap = local;
+  }
+  float* dall = out;
+  if (space == RSB_HOST) {
+    if (w->obs_all_cap < all) {
+      if (w->d_obs_all) HIP_TRY(hipFree(w->d_obs_all));
+      w->d_obs_all = nullptr; w->obs_all_cap = 0;
+      HIP_TRY(hipMalloc(&w->d_obs_all, all * sizeof(float)));
+      w->obs_all_cap = all;
+    }
+    dall = w->d_obs_all;
+  }
+  int st = rsb_gather_obs(w, w->d_obs_local, collision_indices, n_force_slots, RSB_DEVICE);
+  if (st != RSB_OK) return st;
+  NCCL_TRY(R->AllGather(w->d_obs_local, dall, local, kNcclFloat32, w->comm, w->stream));
+  if (space == RSB_HOST) return copy_out(w, out, dall, all * sizeof(float), RSB_HOST);
   return RSB_OK;
 }
 

@@ -2,7 +2,17 @@
 
 One process per GPU; backend "nccl" (= RCCL on ROCm, over xGMI) on GPUs, "gloo" in the CPU tests.  Envs are
 independent, so rank r owns the contiguous global env range [r*n, (r+1)*n) and nothing inside integrate()
-communicates; once per control step every rank contributes its [n, obs_dim] observation block.
+communicates; once per control step every rank contributes its [n, obs_dim] observation block
+(q 19, u 18, foot force 12 = 196 B per ANYmal env: 0.8 MB per rank at n = 4096).
+
+Every workload quantity is a function of the GLOBAL env index (raisimlib_amd/workload.py), so a sharded run produces
+exactly the rows of the unsharded one (tests/test_distributed_gloo.py asserts it bit for bit).
+
+`ObsGatherer` owns the per-rank and gathered buffers and the two ways of issuing the collective:
+  in line      the all-gather of control step k is enqueued behind the step's kernel on the same stream (default);
+  overlapped   double-buffered: the all-gather of step k runs on the backend's own stream while the kernel of step k+1
+               writes the other buffer; a buffer is only rewritten after the gather that reads it has finished.
+The C++ host side has the same collective without Python: rsb_comm_* / rsb_allgather_obs in include/rsb.h.
 """
 import torch
 import torch.distributed as dist
@@ -22,3 +32,55 @@ def gather_obs(local_obs: torch.Tensor, out: torch.Tensor = None) -> torch.Tenso
         out = torch.empty((world * local_obs.shape[0], local_obs.shape[1]), dtype=local_obs.dtype, device=local_obs.device)
     dist.all_gather_into_tensor(out, local_obs.contiguous())
     return out
+
+
+class ObsGatherer:
+    """Buffers + issue policy of the per-control-step obs all-gather (see the module docstring)."""
+
+    def __init__(self, n_local, obs_dim, device, overlap=False, force=False, dtype=torch.float32):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
+        self.nbuf = 2 if (self.active and overlap) else 1
+        self.local_bufs = [torch.empty((n_local, obs_dim), dtype=dtype, device=device) for _ in range(self.nbuf)]
+        self.all_bufs = ([torch.empty((self.world * n_local, obs_dim), dtype=dtype, device=device) for _ in range(self.nbuf)]
+                         if self.active else self.local_bufs)
+        self.pending = [None] * self.nbuf
+
+    def slot(self, k):
+        return k % self.nbuf
+
+    def local(self, k):
+        """The buffer control step k writes its obs block into."""
+        return self.local_bufs[self.slot(k)]
+
+    def gathered(self, k):
+        """[world*n, d] block of control step k (valid after drain(), or after the next acquire() of the same slot)."""
+        return self.all_bufs[self.slot(k)]
+
+    def acquire(self, k):
+        """Before step k's kernel is enqueued: wait (stream-side) for the gather that still reads this slot."""
+        b = self.slot(k)
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+
+    def gather(self, k):
+        """After step k's kernel is enqueued: issue its all-gather."""
+        if not self.active:
+            return
+        b = self.slot(k)
+        if self.nbuf == 2:
+            self.pending[b] = dist.all_gather_into_tensor(self.all_bufs[b], self.local_bufs[b], async_op=True)
+        else:
+            dist.all_gather_into_tensor(self.all_bufs[b], self.local_bufs[b])
+
+    def drain(self):
+        for b in range(self.nbuf):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def describe(self):
+        if not self.active:
+            return "none (1 rank)"
+        return "overlapped with the next control step (double-buffered)" if self.nbuf == 2 else "in line"

@@ -6,6 +6,7 @@
 #include <memory>
 #include <vector>
 
+#include "anymal_env/Environment.hpp"
 #include "raisim/VectorizedEnvironment.hpp"
 #include "raisim/World.hpp"
 
@@ -103,7 +104,7 @@ int main(int argc, char** argv) {
     cfg.gc_init.assign(19, 0.0);
     cfg.gc_init[2] = 0.57; cfg.gc_init[3] = 1.0;
     for (int j = 0; j < 12; ++j) cfg.gc_init[7 + j] = nominal[j];
-    raisim::VectorizedEnvironment env(urdf, cfg);
+    raisim::DeviceVectorizedEnvironment env(urdf, cfg);
     env.init();
     CHECK(env.getObDim() == 34 && env.getActionDim() == 12 && env.getNumOfEnvs() == 512);
     std::vector<float> ob((size_t)512 * 34), act((size_t)512 * 12, 0.f), rew(512);
@@ -121,7 +122,106 @@ int main(int argc, char** argv) {
       CHECK(ob[(size_t)e * 34 + 3] > 0.5f);  // body z-axis still points up
       CHECK(std::isfinite(rew[e]));
     }
-    std::printf("VectorizedEnvironment: 50 control steps x 512 envs, %d resets, mean height %.3f\n", resets, ob[0]);
+    std::printf("DeviceVectorizedEnvironment: 50 control steps x 512 envs, %d resets, mean height %.3f\n", resets, ob[0]);
+
+    // ---- N per-env World VIEWS of one batch: N integrate() calls = ONE launch in which every replica advances once
+    {
+      const int NV = 8;
+      raisim::BatchedWorld batch(urdf, NV), twin(urdf, NV);
+      batch.setTimeStep(0.0025); twin.setTimeStep(0.0025);
+      std::vector<std::unique_ptr<raisim::World>> views;
+      std::vector<raisim::ArticulatedSystem*> robots;
+      std::vector<float> kpf(gvDim, 0.f), kdf(gvDim, 0.f);
+      for (int j = 6; j < gvDim; ++j) { kpf[j] = 50.f; kdf[j] = 0.2f; }
+      twin.setPdGains(kpf.data(), kdf.data());
+      std::vector<float> tgc((size_t)NV * gcDim), tgv((size_t)NV * gvDim, 0.f), tpt((size_t)NV * gcDim, 0.f), tdt((size_t)NV * gvDim, 0.f);
+      for (int e = 0; e < NV; ++e) {
+        views.push_back(std::make_unique<raisim::World>(batch, e));
+        robots.push_back(views.back()->addArticulatedSystem(urdf));
+        raisim::VecDyn g(gcDim), v(gvDim), p(gcDim), d(gvDim);
+        g = gc.v; g[2] = 0.54 + 0.01 * e; g[0] = 0.3 * e;
+        p = g.v; p[7] += 0.05 * e;
+        for (int i = 0; i < gcDim; ++i) { tgc[(size_t)e * gcDim + i] = (float)g[i]; tpt[(size_t)e * gcDim + i] = (float)p[i]; }
+        robots.back()->setState(g, v);
+        robots.back()->setPdTarget(p, d);
+      }
+      robots[0]->setPdGains(kp, kd);   // gains are shared by the replicas (kp 400 / kd 10 from above) ...
+      for (int j = 6; j < gvDim; ++j) { kpf[j] = (float)kp[j]; kdf[j] = (float)kd[j]; }
+      twin.setPdGains(kpf.data(), kdf.data());
+      twin.setState(tgc.data(), tgv.data());
+      twin.setPdTarget(tpt.data(), tdt.data());
+      for (int rep = 0; rep < 3; ++rep) {
+        const long before = batch.viewLaunches();
+        for (int e = 0; e < NV; ++e) {
+          views[e]->integrate();
+          if (e == 2) {               // a read while the batch is incomplete must fail loudly, not return a stale or half-stepped state
+            bool threw = false;
+            try { robots[e]->getGeneralizedCoordinate(); } catch (const std::exception&) { threw = true; }
+            CHECK(threw);
+          }
+        }
+        CHECK(batch.viewLaunches() == before + 1 && batch.pendingViews() == 0);
+        twin.integrate(1);
+      }
+      CHECK(std::fabs(batch.getWorldTime() - 3 * 0.0025) < 1e-12);      // 3 steps of world time, not 3 * NV
+      std::vector<float> bgc((size_t)NV * gcDim), bgv((size_t)NV * gvDim);
+      twin.getState(bgc.data(), bgv.data());
+      for (int e = 0; e < NV; ++e) {
+        const auto& qe = robots[e]->getGeneralizedCoordinate();
+        for (int i = 0; i < gcDim; ++i) CHECK((float)qe[i] == bgc[(size_t)e * gcDim + i]);   // bit-identical to the batched path
+      }
+      // a partial batch: only replicas 1 and 5 step (masked launch); the others must not move
+      std::vector<float> before_gc((size_t)NV * gcDim), after_gc((size_t)NV * gcDim), tmp_gv((size_t)NV * gvDim);
+      batch.getState(before_gc.data(), tmp_gv.data());
+      views[1]->integrate(); views[5]->integrate();
+      CHECK(batch.pendingViews() == 2);
+      batch.flushViews();
+      batch.getState(after_gc.data(), tmp_gv.data());
+      for (int e = 0; e < NV; ++e) {
+        bool moved = false;
+        for (int i = 0; i < gcDim; ++i) moved |= before_gc[(size_t)e * gcDim + i] != after_gc[(size_t)e * gcDim + i];
+        CHECK(moved == (e == 1 || e == 5));
+      }
+      std::printf("World views: %d replicas, one launch per round of integrate() calls, masked partial flush OK\n", NV);
+    }
+
+    // ---- upstream's template: N arbitrary ENVIRONMENT objects (tests/cpp/anymal_env/Environment.hpp) on one batch
+    {
+      const int NE = 64;
+      const std::string resourceDir = urdf.substr(0, urdf.find_last_of('/'));
+      const std::string yaml =
+          "num_envs: 64\nnum_threads: 8   # ignored\nsimulation_dt: 0.0025\ncontrol_dt: 0.01\nrender: false\naction_std: 0.3\n"
+          "reward:\n  forwardVel:\n    coeff: 0.3\n";
+      raisim::VectorizedEnvironment<raisim::ENVIRONMENT> venv(resourceDir, yaml, /*normalizeObservation=*/false);
+      CHECK(venv.getNumOfEnvs() == NE && venv.getObDim() == 34 && venv.getActionDim() == 12);
+      raisim::VecEnvConfig dc;
+      dc.num_envs = NE; dc.gc_init = cfg.gc_init; dc.torque_reward_coeff = 0.0; dc.forward_vel_reward_coeff = 0.3;
+      raisim::DeviceVectorizedEnvironment denv(urdf, dc);
+      denv.init();
+      std::vector<float> a((size_t)NE * 12), r1(NE), r2(NE), o1((size_t)NE * 34), o2((size_t)NE * 34);
+      std::unique_ptr<bool[]> d1(new bool[NE]), d2(new bool[NE]);
+      unsigned sd = 777u;
+      int ndone = 0;
+      const long l0 = venv.batch()->viewLaunches();
+      const int STEPS = 30;
+      for (int it = 0; it < STEPS; ++it) {
+        for (auto& x : a) { sd = sd * 1664525u + 1013904223u; x = ((sd >> 8) / 16777216.0f - 0.5f) * (it % 7 == 6 ? 8.0f : 2.0f); }
+        venv.step(a.data(), NE, 12, r1.data(), d1.get());
+        denv.step(a.data(), NE, 12, r2.data(), d2.get());
+        venv.observe(o1.data(), NE, 34, false);
+        denv.observe(o2.data(), NE, 34);
+        for (int e = 0; e < NE; ++e) {
+          CHECK(d1[e] == d2[e]);
+          CHECK(std::fabs(r1[e] - r2[e]) < 1e-4f);
+          ndone += d1[e] ? 1 : 0;
+          for (int k = 0; k < 34; ++k) CHECK(std::fabs(o1[(size_t)e * 34 + k] - o2[(size_t)e * 34 + k]) < 1e-4f);
+        }
+      }
+      CHECK(venv.batch()->viewLaunches() - l0 == STEPS * 4);       // one launch per integrate() of the control step, for all 64 envs
+      CHECK(ndone > 0);                                            // the big kicks made some robots fall and reset
+      std::printf("VectorizedEnvironment<ENVIRONMENT>: %d envs x %d control steps = %ld launches, %d resets, equal to the device-resident env\n",
+                  NE, STEPS, venv.batch()->viewLaunches() - l0, ndone);
+    }
 
     // ---- a Perlin-noise terrain through the TerrainProperties overload: the robot lands ON it
     raisim::World hills;

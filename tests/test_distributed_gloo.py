@@ -2,7 +2,8 @@
 
 Each rank steps ITS shard with the oracle standing in for the device world (this is a test; the product path has
 no CPU fallback), builds the obs block and all-gathers it; the result must equal the single-process run over all
-envs — i.e. sharding by global env index changes nothing."""
+envs — i.e. sharding by global env index changes nothing, bit for bit (every workload quantity is a function of the
+global env index).  Both issue policies of raisimlib_amd.dist.ObsGatherer (in line / double-buffered overlap) are run."""
 import os
 import sys
 
@@ -49,11 +50,30 @@ def worker(rank, world, n, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
-    from raisimlib_amd.dist import env_range, gather_obs
+    from raisimlib_amd.dist import ObsGatherer, env_range, gather_obs
     lo, hi = env_range(rank, n)
     local = torch.from_numpy(run_shard(lo, hi))
     full = gather_obs(local)
     assert full.shape == (world * n, local.shape[1])
+    # the bench's issue policies: three "control steps" whose obs blocks differ by a known offset
+    for overlap in (False, True):
+        g = ObsGatherer(n, local.shape[1], torch.device("cpu"), overlap=overlap)
+        assert g.active and g.nbuf == (2 if overlap else 1)
+        seen = []
+        for k in range(3):
+            g.acquire(k)
+            g.local(k).copy_(local + float(k))          # stands for the step kernel writing this rank's block
+            g.gather(k)
+            if not overlap:
+                seen.append(g.gathered(k).clone())
+            elif k >= 1:                                # the previous step's gather is complete once its slot is re-acquired
+                g.acquire(k + 1)
+                seen.append(g.gathered(k - 1).clone())
+        g.drain()
+        if overlap:
+            seen.append(g.gathered(2).clone())
+        for k, blk in enumerate(seen[:3]):
+            assert torch.equal(blk, full + float(k)), (overlap, k)
     if rank == 0:
         np.save(out, full.numpy())
     dist.barrier()
@@ -65,8 +85,8 @@ def test_sharded_obs_gather_equals_single_process(tmp_path, built_lib):
     out = str(tmp_path / "gathered.npy")
     mp.spawn(worker, args=(world, n, 29517, out), nprocs=world, join=True)
     gathered = np.load(out)
-    # note: workload.anymal_targets seeds by (env_offset, control_step) per shard, so compare shard by shard
-    ref = np.concatenate([run_shard(0, n), run_shard(n, 2 * n)], axis=0)
+    ref = run_shard(0, 2 * n)                           # ONE process stepping all 12 envs: sharded == unsharded, bit for bit
     assert gathered.shape == (12, 19 + 18 + 12)
     assert np.array_equal(gathered, ref)
+    assert np.array_equal(ref, np.concatenate([run_shard(0, n), run_shard(n, 2 * n)], axis=0))
     assert np.abs(gathered[:, 37:]).max() > 0          # feet were in contact: the force slots are populated

@@ -211,6 +211,31 @@ def test_heightmap_one_step_parity(anymal):
     check_step(dev, ref)
 
 
+def test_config3_heightmap_parity_on_the_benchmark_map(anymal):
+    """Config 3 as bench.py --config 3 runs it: the shared 128 x 128 map over 12.8 m x 12.8 m (0.1 m cells, +-0.1 m), robots
+    spread over the whole map (incl. cells at the border, where the collider clamps), one step and a 4-sub-step control step."""
+    H = workload.smoothed_heightmap(128, 128, amplitude=0.1, seed=7)
+    hm = (128, 128, workload.HEIGHTMAP_SIZE, workload.HEIGHTMAP_SIZE, 0.0, 0.0, H)
+    N = 1024
+    gc, gv = standing_states(N, seed=41, z=(0.45, 0.7))
+    rng = np.random.default_rng(9)
+    gc[:, 0:2] = rng.uniform(-6.6, 6.6, (N, 2))          # a few beyond the +-6.4 m edge
+    o = Oracle(anymal.blob); o.set_heightmap(*hm)
+    gc[:, 2] += np.array([o.terrain(x, y)[0] for x, y in gc[:, 0:2]])
+    kp, kd = workload.anymal_gains()
+    pt = gc.copy()
+    pt[:, 7:] = workload.ANYMAL_NOMINAL_JOINTS + rng.uniform(-0.3, 0.3, (N, 12))
+    dev, ref, _ = run_one_step(anymal, gc, gv, pt, kp, kd, heightmap=hm)
+    assert ref["n_contacts"].sum() > 1000
+    normals = np.array([c["normal"][k] for e, c in enumerate(ref["contacts"]) for k in range(ref["n_contacts"][e])])
+    assert normals[:, 2].min() < 0.97                     # slopes up to ~15 degrees are exercised
+    check_step(dev, ref)
+    dev4, ref4, _ = run_one_step(anymal, gc, gv, pt, kp, kd, heightmap=hm, substeps=4)
+    assert np.array_equal(dev4["cnt"], ref4["n_contacts"]) or (dev4["cnt"] != ref4["n_contacts"]).mean() < 0.01
+    eu = np.abs(dev4["u"] - ref4["u"]).max(axis=1) / (1 + np.abs(ref4["u"]).max(axis=1))
+    assert np.median(eu) < 2e-5 and np.percentile(eu, 90) < 2e-3
+
+
 def test_atlas_one_step_parity(atlas):
     """Config 5: deep chains (31 bodies, 36 DoF), multi-sphere feet, kmax = 16.  The mass matrix of this model
     has condition number ~4e5 (0.125 kg talus links), so the fp32 tolerance is relative to the velocity scale."""

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import f32, sphere_urdf, standing_states
+from common import Oracle, f32, sphere_urdf, standing_states
 from raisimlib_amd import BatchedWorld, Model, RsbError, workload
 
 pytestmark = pytest.mark.gpu
@@ -417,3 +417,174 @@ def test_lanes_per_env_variants_run_the_full_control_step(anymal):
         q, u, o = outs[lpe]
         dq = np.abs(q - q16).max(1)
         assert np.isfinite(q).all() and np.median(dq) < 1e-5 and (dq < 1e-3).mean() > 0.9, (lpe, np.median(dq), (dq < 1e-3).mean())
+
+
+def test_population_statistics_match_the_oracle_over_100_control_steps(anymal):
+    """The benchmark's own regime, N = 4096, 100 control steps with the reset rule, device vs fp64 oracle from identical
+    initial states and per-env seeded targets.  Individual trajectories diverge (contact dynamics is chaotic and the two
+    sides round differently), so the POPULATIONS are compared: resets, base-height distribution, contacts and sweeps."""
+    import torch
+    N, STEPS = 4096, 100
+    feet = anymal.collision_indices("_foot")
+    feet_set = np.zeros(anymal.ncol, bool); feet_set[feet] = True
+    kp, kd = workload.anymal_gains()
+    gc0, gv0 = workload.anymal_initial_state(N)
+    gc0 = f32(gc0)
+    # device: the fused control step with resets and done flags
+    w = BatchedWorld(anymal, N)
+    w.set_pd_gains(kp, kd); w.set_state(gc0, gv0); w.set_pd_target(None, np.zeros((N, 18), np.float32))
+    dev = torch.device("cuda")
+    stream = torch.cuda.current_stream(); w.set_stream(stream.cuda_stream)
+    done_d = torch.zeros(N, dtype=torch.uint8, device=dev); w.set_done_output(done_d.data_ptr())
+    obs = torch.empty((N, w.obs_dim(4)), device=dev)
+    g0d = torch.from_numpy(gc0.astype(np.float32)).to(dev); v0d = torch.from_numpy(gv0.astype(np.float32)).to(dev)
+    step = w.control_step_plan(4, obs.data_ptr(), feet, feet, g0d.data_ptr(), v0d.data_ptr(), N)
+    # oracle: the same recipe on the host
+    o = Oracle(anymal.blob)
+    q, u, warm = gc0.copy(), gv0.copy(), o.new_warm_state(N)
+    dev_resets, orc_resets, dev_iters, orc_iters = [], [], [], []
+    for cs in range(STEPS):
+        pt = f32(workload.anymal_targets(N, cs))
+        ptd = torch.from_numpy(pt.astype(np.float32)).to(dev)
+        step(ptd.data_ptr())
+        torch.cuda.synchronize()
+        dev_resets.append(int(done_d.sum().item()))
+        dev_iters.append(w.get_solver_iterations().mean())
+        r = o.step_batch(q, u, 4, kp.astype(np.float64), kd.astype(np.float64), pt, np.zeros((N, 18)), want_contacts=True, lam_warm=warm)
+        q, u = r["q"], r["u"]
+        con, ncs = r["contacts"], r["n_contacts"]
+        valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
+        term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
+        orc_resets.append(int(term.sum())); orc_iters.append(r["iters"].mean())
+        q[term], u[term], warm[term] = gc0[term], gv0[term], 0.0
+    qd, ud = w.get_state()
+    cnt_d, _ = w.get_contacts()
+    w.close()
+    dev_resets, orc_resets = np.array(dev_resets), np.array(orc_resets)
+    print(f"resets: device {dev_resets.sum()} oracle {orc_resets.sum()}; last-20-step mean {dev_resets[-20:].mean():.1f} vs {orc_resets[-20:].mean():.1f}; "
+          f"sweeps {np.mean(dev_iters[-20:]):.2f} vs {np.mean(orc_iters[-20:]):.2f}")
+    assert np.isfinite(qd).all() and np.isfinite(ud).all()
+    assert orc_resets.sum() > 500                                               # the regime does contain falling robots
+    assert abs(dev_resets.sum() - orc_resets.sum()) <= 0.03 * orc_resets.sum()  # cumulative resets within 3 %
+    # while the two populations are still the same trajectories (first control steps) the counts agree step by step
+    assert np.abs(dev_resets[:30] - orc_resets[:30]).max() <= 3
+    # the stationary populations have the same shape: base height quantiles within 5 mm, mean contacts within 0.05
+    for pct in (5, 25, 50, 75, 95):
+        assert abs(np.percentile(qd[:, 2], pct) - np.percentile(q[:, 2], pct)) < 5e-3, pct
+    assert abs(cnt_d.mean() - r["n_contacts"][~term].sum() / N) < 0.08
+    assert abs(np.mean(dev_iters[-20:]) - np.mean(orc_iters[-20:])) < 0.1      # sweeps of the last sub-step, population mean
+
+
+def test_masked_integrate_and_done_output(anymal):
+    """rsb_integrate_masked advances exactly the masked replicas (bit-identical to an unmasked launch for them, untouched
+    rows for the others); rsb_set_done_output reports the envs a fused control step reset."""
+    import torch
+    N = 96
+    gc, gv = standing_states(N, seed=3)
+    kp, kd = workload.anymal_gains()
+    a, b = BatchedWorld(anymal, N), BatchedWorld(anymal, N)
+    for w in (a, b):
+        w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv)
+        w.integrate(2)                                   # contacts + warm state exist before the masked launch
+    qa0, ua0 = a.get_state(); ca0, cona0 = a.get_contacts()
+    mask = (np.arange(N) % 3 == 0).astype(np.uint8)
+    a.integrate_masked(mask, 1)
+    b.integrate(1)
+    qa, ua = a.get_state(); qb, ub = b.get_state(); ca, cona = a.get_contacts(); cb, conb = b.get_contacts()
+    on = mask.astype(bool)
+    assert np.array_equal(qa[on], qb[on]) and np.array_equal(ua[on], ub[on]) and np.array_equal(ca[on], cb[on])
+    assert np.array_equal(qa[~on], qa0[~on]) and np.array_equal(ua[~on], ua0[~on]) and np.array_equal(ca[~on], ca0[~on])
+    assert cona[~on].tobytes() == cona0[~on].tobytes()
+    a.integrate_masked(1 - mask, 1)                      # now the others catch up: both worlds are equal again ...
+    a.integrate_masked(mask, 1); b.integrate(1)          # ... after one more step of the first group
+    qa, ua = a.get_state(); qb, ub = b.get_state()
+    assert np.array_equal(qa[on], qb[on])
+    # done flags of the fused control step
+    dev = torch.device("cuda")
+    done = torch.full((N,), 7, dtype=torch.uint8, device=dev)
+    b.set_stream(torch.cuda.current_stream().cuda_stream)
+    b.set_done_output(done.data_ptr())
+    feet = anymal.collision_indices("_foot")
+    g0 = torch.from_numpy(gc[0].astype(np.float32)).to(dev); v0 = torch.zeros(18, device=dev)
+    low = gc.copy(); low[: N // 2, 2] = 0.25             # half of the robots start with the belly in the ground
+    b.set_state(low, gv)
+    ptd = torch.from_numpy(gc.astype(np.float32)).to(dev)
+    obs = torch.empty((N, b.obs_dim(4)), device=dev)
+    b.control_step_plan(4, obs.data_ptr(), feet, feet, g0.data_ptr(), v0.data_ptr(), 1)(ptd.data_ptr())
+    torch.cuda.synchronize()
+    d = done.cpu().numpy()
+    assert set(np.unique(d)) <= {0, 1} and d[: N // 2].all() and d.sum() < N
+    q1, _ = b.get_state()
+    assert np.array_equal(q1[d.astype(bool)], np.tile(gc[0].astype(np.float32), (int(d.sum()), 1)))
+    a.close(); b.close()
+
+
+def test_device_shards_equal_the_unsharded_world_bit_for_bit(anymal):
+    """Two worlds owning global envs [0, n) and [n, 2n) (what two ranks hold) produce exactly the rows of one world with 2n
+    envs: state, contacts and the obs block, over several control steps with resets (no cross-env coupling)."""
+    import torch
+    n, steps = 300, 12          # 300 is not a multiple of the 4 envs per wave: env -> wave packing differs between the layouts
+    feet = anymal.collision_indices("_foot")
+    kp, kd = workload.anymal_gains()
+    dev = torch.device("cuda")
+
+    def run(lo, hi):
+        N = hi - lo
+        gc0, gv0 = workload.anymal_initial_state(N, env_offset=lo, height=0.56)
+        w = BatchedWorld(anymal, N)
+        w.set_stream(torch.cuda.current_stream().cuda_stream)
+        w.set_pd_gains(kp, kd); w.set_state(gc0, gv0); w.set_pd_target(None, np.zeros((N, 18), np.float32))
+        g0 = torch.from_numpy(gc0.astype(np.float32)).to(dev); v0 = torch.from_numpy(gv0.astype(np.float32)).to(dev)
+        obs = torch.empty((N, w.obs_dim(4)), device=dev)
+        step = w.control_step_plan(4, obs.data_ptr(), feet, feet, g0.data_ptr(), v0.data_ptr(), N)
+        for k in range(steps):
+            pt = torch.from_numpy(workload.anymal_targets(N, k, env_offset=lo, amplitude=0.6).astype(np.float32)).to(dev)
+            step(pt.data_ptr())
+        torch.cuda.synchronize()
+        q, u = w.get_state(); c, con = w.get_contacts()
+        w.close()
+        return q, u, c, con, obs.cpu().numpy()
+
+    full = run(0, 2 * n)
+    a, b = run(0, n), run(n, 2 * n)
+    for k in range(5):
+        sharded = np.concatenate([a[k], b[k]], axis=0)
+        assert sharded.tobytes() == full[k].tobytes(), k
+    assert (full[2] > 0).any()
+
+
+def test_rccl_allgather_through_the_c_abi_single_rank(anymal):
+    """rsb_comm_* / rsb_allgather_obs (the C/C++ host's collective, RCCL loaded at run time) on a one-rank communicator:
+    the gathered block equals rsb_gather_obs.  Runs in a child process without torch, under a timeout (a second RCCL
+    in a process that already holds torch's copy is not what a C++ host would do)."""
+    import os
+    import subprocess
+    import sys
+    from common import ROOT
+    script = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from raisimlib_amd import BatchedWorld, Model, rsc_path, workload
+from raisimlib_amd._capi import lib, check, RSB_HOST
+m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+N = 128
+w = BatchedWorld(m, N)
+gc, gv = workload.anymal_initial_state(N, height=0.55)
+kp, kd = workload.anymal_gains()
+w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((N, 18))); w.set_state(gc, gv); w.integrate(4)
+L = lib()
+ident = C.create_string_buffer(128)
+check(L.rsb_comm_get_unique_id(ident), "rsb_comm_get_unique_id")
+check(L.rsb_comm_init(w.handle, 1, 0, ident), "rsb_comm_init")
+feet = np.asarray(m.collision_indices("_foot"), np.int32)
+od = w.obs_dim(4)
+out = np.zeros((N, od), np.float32)
+check(L.rsb_allgather_obs(w.handle, feet.ctypes.data_as(C.c_void_p), 4, out.ctypes.data_as(C.c_void_p), RSB_HOST), "rsb_allgather_obs")
+q, u = w.get_state()
+assert np.array_equal(out[:, :19], q) and np.array_equal(out[:, 19:37], u) and np.abs(out[:, 37:]).max() > 0
+check(L.rsb_comm_destroy(w.handle), "rsb_comm_destroy")
+w.close()
+print("RCCL_OK")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
