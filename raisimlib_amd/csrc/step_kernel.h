@@ -126,7 +126,8 @@ __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
 }
 
 // terrain height and unit normal under (x, y): plane or triangulated height map (oracle: orc_terrain)
-__device__ __forceinline__ void terrain_eval(const StepArgs& a, const float* heights, float x, float y, float& h, float* n) {
+template <class Args>
+__device__ __forceinline__ void terrain_eval(const Args& a, const float* heights, float x, float y, float& h, float* n) {
   if (a.terrain_type == 0) { h = a.ground_z; n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; return; }
   float gx = (x - a.hm_x0) * a.hm_inv_dx, gy = (y - a.hm_y0) * a.hm_inv_dy;
   gx = fminf(fmaxf(gx, 0.f), (float)(a.hm_xs - 1));
@@ -254,6 +255,16 @@ __device__ __forceinline__ void row_bcast_dyn_n(float* x, int j) { row_bcast_tre
 template <int KMAX>
 __device__ __forceinline__ void row_bcast3_dyn(float* x, int j) { row_bcast_tree<0, KMAX, 3>(x, j); }
 
+// the coarse scan's 16 directions (22.5 deg apart), as compile-time immediates (oracle: kCos16 / kSin16)
+__device__ constexpr float kCos16[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                         -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                         -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.0f,
+                                         0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+__device__ constexpr float kSin16[16] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f,
+                                         0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f,
+                                         -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f,
+                                         -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+
 // Cooperative slip direction search: all lanes of the env group hold the same coefficients; lane (s & 15)
 // evaluates candidate (s & 15) of every round.  (c16, s16) = this lane's round-0 direction (22.5 deg grid);
 // BR16[k] = {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).  Bracket ends stay
@@ -310,6 +321,15 @@ __device__ __forceinline__ void inv3(const float* A, float* B) {
 // gv index (lin, ang) -> spatial index (ang, lin)
 __device__ __host__ constexpr int gv2sp(int a) { return a < 3 ? a + 3 : a - 3; }
 
+// Kernel arguments are read through the kernarg segment pointer, one "view" per phase: RSB_ARGS(x) declares a reference
+// whose loads cannot move above that point (the empty asm makes the pointer opaque), so an argument lives in SGPRs only
+// inside the phase that uses it.  Taken by value and referenced directly, all ~150 dwords of StepArgs are loaded at kernel
+// entry and the ones needed late (the epilogue's 14 pointers, the solver's parameters ...) are carried across every phase:
+// 217 spilled SGPRs and ~1000 v_readlane reloads in round 1's ISA - each one an issue slot of the one wave a SIMD holds.
+typedef const __attribute__((address_space(4))) StepArgs* KArgs;
+__device__ __forceinline__ KArgs rsb_cold(KArgs p) { asm volatile("" : "+s"(p)); return p; }
+#define RSB_ARGS(name) const __attribute__((address_space(4))) StepArgs& name = *rsb_cold(ka)
+
 #define RSB_STAMP(i) \
   if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) a.prof[i] = clock64();
 
@@ -347,7 +367,9 @@ __device__ __forceinline__ void body_inertia(const float* Rb, const float* rb, c
 // ML : body-level capacity (>= depth-1).  PROF : compile the cycle stamps / contact-problem dump / LDS poisoning of the
 // rsb_debug_* entry points in (the production instances carry none of it: fewer SGPRs, no branches in the solver loop).
 template <int LPE, int KMAX, int CL, int ML, bool PROF>
-__global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
+__global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
+  const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();   // the by-value StepArgs sits at offset 0 of the kernarg segment
+  RSB_ARGS(a);                                                     // the prologue's view (and the PROF-only fields)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int EPW = 64 / LPE;
   const int lane = threadIdx.x;
@@ -463,11 +485,14 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
   if (PROF && a.prof) t_start = clock64();
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
+  const int nsub = a.nsub, kmax = a.kmax;
+  const bool has_warm = a.warm != nullptr;
   __syncthreads();
 
   float tsq = 0.f;     // this lane's share of |actuator torque|^2 in the current sub-step (StepArgs::tau2_out)
-  for (int sub = 0; sub < a.nsub; ++sub) {
+  for (int sub = 0; sub < nsub; ++sub) {
     RSB_STAMP(0)
+    RSB_ARGS(ab);
     tsq = 0.f;
     for (int i = s; i < 28; i += LPE) BACC[i] = 0.f;   // summed into by the level-1 chains at the end of the up pass (a barrier lies in between)
     // =========================== base body, redundantly on every lane =========================
@@ -485,7 +510,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       float wxv[3];
       cross3(V0, V0 + 3, wxv);
       A0[0] = A0[1] = A0[2] = 0.f;
-      A0[3] = -wxv[0] - a.gx; A0[4] = -wxv[1] - a.gy; A0[5] = -wxv[2] - a.gz;
+      A0[3] = -wxv[0] - ab.gx; A0[4] = -wxv[1] - ab.gy; A0[5] = -wxv[2] - ab.gz;
       pbx = qv[0]; pby = qv[1]; pbz = qv[2];
       float MF[kModelSlot];
       ldv<8>(MODELF, MF);
@@ -580,6 +605,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     }
     if (nclv == 0) __syncthreads();
     RSB_STAMP(1)
+    RSB_ARGS(ac);
 
     // =========================== collision detection (lane = collision sphere) ================
     nc = 0;
@@ -600,17 +626,17 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float t[3], h;
         mat3_vec(P, pl, t);
         const float c[3] = {P[9] + t[0], P[10] + t[1], P[11] + t[2]};
-        terrain_eval(a, env_heights, pbx + c[0], pby + c[1], h, n);
+        terrain_eval(ac, env_heights, pbx + c[0], pby + c[1], h, n);
         const float dist = (pbz + c[2] - h) * n[2];
         dep = rad - dist;
         hit = dep > 0.f && !dead;
-        illegal |= hit && !((a.allowed >> ci) & 1ull);
+        illegal |= hit && !((ac.allowed >> ci) & 1ull);
         cx[0] = c[0] - rad * n[0]; cx[1] = c[1] - rad * n[1]; cx[2] = c[2] - rad * n[2];
       }
       const unsigned long long bal = __ballot(hit);
       const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
       const int slot = nc + __popcll(gm & ((1ull << s) - 1ull));
-      if (hit && slot < a.kmax) {
+      if (hit && slot < kmax) {
         float P[16], t1[3], t2[3];
         // contact frame: t1 = normalised projection of world x on the tangent plane, t2 = n x t1
         const float dn = n[0];
@@ -626,7 +652,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       }
       nc += __popcll(gm);
     }
-    if (nc > a.kmax) { nc = a.kmax; flag |= 1; }
+    if (nc > kmax) { nc = kmax; flag |= 1; }
     // joint limits (oracle: "joint limits" in step_impl): a joint outside [q_lower, q_upper] adds one unilateral row
     // s * qdot >= 0, carried through the solver as a contact with empty tangential rows; slots after the real contacts
     nc_real = nc;
@@ -642,7 +668,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         if (bal) {   // rare: nothing below runs while every joint of the wave is inside its range
           const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
           const int slot = nc + __popcll(gm & ((1ull << s) - 1ull));
-          if (sgn != 0.f && slot < a.kmax) {
+          if (sgn != 0.f && slot < kmax) {
             float P[16];
             RSB_UNROLL for (int i = 0; i < 16; ++i) P[i] = 0.f;
             P[3] = viol; P[7] = __int_as_float(b); P[11] = __int_as_float(ncol + b); P[15] = sgn;
@@ -651,9 +677,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           nc += __popcll(gm);
         }
       }
-      if (nc > a.kmax) { nc = a.kmax; flag |= 1; }
+      if (nc > kmax) { nc = kmax; flag |= 1; }
     }
-    if (a.early_term) {
+    if (ac.early_term) {
       // early termination (opt-in, rsb_set_early_termination): the sub-step in which a primitive outside `allowed`
       // touches the terrain is not integrated, nor are the following ones; the detected contacts stay reported
       // with zero impulses and the env counts as terminated
@@ -764,6 +790,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
 
     iters_used = 0;
     if (ncw > 0) {
+      RSB_ARGS(aw);
+      const float restitution = aw.restitution, res_threshold = aw.res_threshold, erp = aw.erp;
       // ========================= contact columns (lane = column): W_c = D^-1/2 L^-T J_c^T =======
       for (int c0 = 0; c0 < 3 * ncw; c0 += LPE) {
         const int c = c0 + s;
@@ -795,7 +823,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           cross3(Vb, x, wxx);  // J u = t . (v_body + w_body x x)
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
           // Newton restitution (oracle: "restitution"): the approach speed J u of this step re-enters the normal row
-          const float rest = (rr == 2 && lsgn == 0.f && a.restitution > 0.f && cv < -a.res_threshold) ? a.restitution * cv : 0.f;
+          const float rest = (rr == 2 && lsgn == 0.f && restitution > 0.f && cv < -res_threshold) ? restitution * cv : 0.f;
           const bool limit_row = lsgn != 0.f;
           const bool empty_row = limit_row && rr < 2;
           if (limit_row) {   // unit generalized force s on the joint itself instead of a spatial impulse on the body
@@ -823,7 +851,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           if (empty_row) cv = 0.f;
           cv += rest;
           st4(Wc, z); Wc[4] = z[4]; Wc[5] = z[5];
-          if (rr == 2) cv -= a.erp * CN[3] / dt;
+          if (rr == 2) cv -= erp * CN[3] / dt;
           CV[c] = cv;
         }
       }
@@ -921,7 +949,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           ldv<3>(GINV + 12 * s, Ginv);
           v[0] = CV[3 * s]; v[1] = CV[3 * s + 1]; v[2] = CV[3 * s + 2];
         }
-        const float mu = a.mu, mu2 = mu * mu;
+        // the solver's parameters, read here so that they occupy SGPRs during the solve only
+        RSB_ARGS(ag);
+        const float mu = ag.mu, mu2 = mu * mu;
+        const float alpha_init = ag.alpha_init, alpha_min = ag.alpha_min, alpha_decay = ag.alpha_decay, threshold = ag.threshold;
+        const float stall_factor = ag.stall_factor;
+        const int max_iter = ag.max_iter, section_rounds = ag.section_rounds, stall_window = ag.stall_window;
+        const int freeze_after = ag.freeze_after, refine = ag.refine;
         // per-solve constants of the own contact: den(d) = a0 + a1 x + a2 y; n01.. hold mu * G_tt (see slip_prepare)
         SlipCoef sc;
         sc.a0 = Gii[8]; sc.a1 = mu * Gii[6]; sc.a2 = mu * Gii[7];
@@ -930,7 +964,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         float lam_best[3] = {0.f, 0.f, 0.f}, best_rel = 3e38f;   // calmest iterate (returned when the solve does not converge)
         float sdx = 0.f, sdy = 0.f;   // friction direction of this contact (|.| = 1 once set)
         int sdst = 0;                 // 0: none, 1: found in this solve, 3: inherited from the previous integrate() (warm state), unused so far
-        float alpha = a.alpha_init, best_prev = 3e38f, best_cur = 3e38f;
+        float alpha = alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
         // CV has been consumed: its first 6 floats now accumulate the base part of sum_c W_c lam_c
@@ -938,7 +972,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         // warm start (oracle: lam_warm): the impulse and friction direction this collision primitive had at the end of
         // the previous integrate(); the table is then cleared, contacts alive at the end of this solve re-enter it
         int mycol = 0;
-        if (a.warm) {
+        if (has_warm) {
           if (isc) {
             mycol = __float_as_int(CON[s * kConSlot + 11]);
             if (mycol < ncol) {   // joint-limit rows (ids >= ncol) start cold
@@ -973,7 +1007,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           kb.a0 = c12[0]; kb.a1 = c12[1]; kb.a2 = c12[2]; kb.n00 = c12[3]; kb.n01 = c12[4]; kb.n02 = c12[5];
           kb.n10 = c12[6]; kb.n11 = c12[7]; kb.n12 = c12[8]; kb.vn = c12[9]; kb.ls0 = c12[10]; kb.ls1 = c12[11];
           float dxy[2];
-          slip_search<LPE>(kb, mu, a.section_rounds, s, el, c16, s16, DIR16, dxy);
+          slip_search<LPE>(kb, mu, section_rounds, s, el, c16, s16, DIR16, dxy);
           if (take) { sdx = dxy[0]; sdy = dxy[1]; sdst = 1; }
         };
         // own-contact slip coefficients for the current (v, lam): see slip_prepare
@@ -986,10 +1020,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           kc.vn = vexn; kc.ls0 = ls[0]; kc.ls1 = ls[1];
         };
 
-        for (int it = 0; it < a.max_iter; ++it) {
+        for (int it = 0; it < max_iter; ++it) {
           const bool active = isc && !done;
-          const bool lag = a.freeze_after > 0 && it >= a.freeze_after;
+          const bool lag = freeze_after > 0 && it >= freeze_after;
+          float gbuf[2][3][4];          // coupling blocks of the sequential pass (see phase B); block 0 is fetched behind phase (A)
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS, gbuf[0][rr]);
           // ---------------- (A) direction refresh of every slipping contact, from the sweep's initial state
+          long long ta0 = 0; if (PROF && a.prof && a.prof_fine) ta0 = clock64();
           {
             float ls[3];
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
@@ -1002,27 +1039,21 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
             if (__any(need)) {
               SlipCoef kc;
               own_coef(ls, vexn, kc);
-              const bool cand = need && sdst != 0 && a.refine != 0;
+              const bool cand = need && sdst != 0 && refine != 0;
               if (__any(cand)) {
                 if (PROF && a.prof) ++p_newton;
                 float nx, ny, dstep;
                 bool ok = slip_newton(kc, mu, sdx, sdy, nx, ny, dstep) && cand;
-                bool chk = ok && sdst == 3;
+                const bool chk = ok && sdst == 3;
                 if (__any(chk)) {
                   // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
                   // local minimum the global search would not choose; it is accepted only if it is at least as good as every
-                  // direction of the search's coarse scan (16 lanes = 16 directions), one contact at a time
-                  for (int j = 0; j < ncw; ++j) {
-                    if (__any(chk && s == j)) {
-                      float c12[12] = {kc.a0, kc.a1, kc.a2, kc.n00, kc.n01, kc.n02, kc.n10, kc.n11, kc.n12, kc.vn, kc.ls0, kc.ls1};
-                      row_bcast_dyn_n<KMAX, 12>(c12, j);
-                      SlipCoef kb;
-                      kb.a0 = c12[0]; kb.a1 = c12[1]; kb.a2 = c12[2]; kb.n00 = c12[3]; kb.n01 = c12[4]; kb.n02 = c12[5];
-                      kb.n10 = c12[6]; kb.n11 = c12[7]; kb.n12 = c12[8]; kb.vn = c12[9]; kb.ls0 = c12[10]; kb.ls1 = c12[11];
-                      const float ebest = __uint_as_float(row_min_u32(__float_as_uint(slip_E(kb, mu, c16, s16))));   // E >= 0: bit order = value order
-                      if (chk && s == j && !(slip_E(kc, mu, nx, ny) <= ebest)) ok = false;
-                    }
-                  }
+                  // direction of the search's coarse scan.  Every contact lane scans the 16 directions of its OWN contact
+                  // (all contacts at once: this runs in the first sweep of every integrate() for every slipping contact, and a
+                  // row-cooperative scan would serialise over the contacts).
+                  float ebest = slip_E(kc, mu, 1.0f, 0.0f);
+                  RSB_UNROLL for (int i = 1; i < 16; ++i) ebest = fminf(ebest, slip_E(kc, mu, kCos16[i], kSin16[i]));
+                  if (chk && !(slip_E(kc, mu, nx, ny) <= ebest)) ok = false;
                 }
                 if (ok) { sdx = nx; sdy = ny; sdst = 1; need = false; }
               }
@@ -1032,14 +1063,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
               }
             }
           }
+          if (PROF && a.prof && a.prof_fine) t_newt += clock64() - ta0;
           // ---------------- (B) the sequential pass
           // One contact update; `bcast3` broadcasts three floats from lane j of each row.  With can_search == false the
           // update bails out (returns true, nothing modified) when contact j needs a global search.
           float err = 0.f;
-          auto update = [&](int j, auto&& bcast3, bool can_search) -> bool {
+          auto update = [&](int j, const float (&gj)[3][4], auto&& bcast3, bool can_search) -> bool {
             const bool mine = (s == j) && active;
-            float gj[3][4];               // this contact's coupling block with contact j (zero-initialised G: stale blocks are finite)
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
             // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
             float ls[3];
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
@@ -1080,29 +1110,36 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
           };
           // fast path: the pass unrolled over j with immediate-lane DPP broadcasts and no search code; an update that
           // needs a search hands the rest of the sweep to the generic loop (runtime j, branch-tree broadcast, search)
+          // The coupling block of update j+1 is fetched from LDS while update j runs (two register buffers alternate), the
+          // block of update 0 before phase (A): the sequential chain never waits for an LDS round trip.
           int jres = ncw;
           static_for<0, KMAX>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if (j < ncw && jres == ncw) {   // wave-uniform
-              if (update(j, [&](float* x) { row_bcast_n<j, 3>(x); }, false)) jres = j;
+              if (j + 1 < KMAX) { RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (j + 1), gbuf[(j + 1) & 1][rr]); }
+              if (update(j, gbuf[j & 1], [&](float* x) { row_bcast_n<j, 3>(x); }, false)) jres = j;
             }
           });
-          for (int j = jres; j < ncw; ++j) update(j, [&](float* x) { row_bcast3_dyn<KMAX>(x, j); }, true);
+          for (int j = jres; j < ncw; ++j) {
+            float gj[3][4];               // this contact's coupling block with contact j (zero-initialised G: stale blocks are finite)
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
+            update(j, gj, [&](float* x) { row_bcast3_dyn<KMAX>(x, j); }, true);
+          }
           // ---------------- (C) convergence
           const float scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
           long long te0 = 0; if (PROF && a.prof && a.prof_fine) te0 = clock64();
           if (!done) {
             ++iters_used;
-            alpha = fmaxf(alpha * a.alpha_decay, a.alpha_min);
+            alpha = fmaxf(alpha * alpha_decay, alpha_min);
             // relative (fp32-aware) test and stagnation exit, identical to the oracle's: see rsb_oracle.c
-            if (err <= a.threshold * (scale + kLambdaFloor)) { done = true; converged = true; }
+            if (err <= threshold * (scale + kLambdaFloor)) { done = true; converged = true; }
             else {
               const float rel = err / (scale + kLambdaFloor);
               if (rel < best_rel) { best_rel = rel; lam_best[0] = lam[0]; lam_best[1] = lam[1]; lam_best[2] = lam[2]; }
               best_cur = fminf(best_cur, rel);
-              if (a.stall_window > 0 && ++wcount == a.stall_window) {
+              if (stall_window > 0 && ++wcount == stall_window) {
                 wcount = 0;
-                if (best_cur > a.stall_factor * best_prev) done = true;
+                if (best_cur > stall_factor * best_prev) done = true;
                 best_prev = best_cur; best_cur = 3e38f;
               }
             }
@@ -1113,7 +1150,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
         if (isc) {
           LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2];
-          if (a.warm && mycol < ncol) {
+          if (has_warm && mycol < ncol) {
             float* wr = WARM + 6 * mycol;
             wr[0] = lam[0]; wr[1] = lam[1]; wr[2] = lam[2];
             wr[3] = sdst ? sdx : 0.f; wr[4] = sdst ? sdy : 0.f; wr[5] = sdst ? 1.f : 0.f;
@@ -1144,7 +1181,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         const int n3 = 3 * nc_real;
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + n3 + i] = LAM[i];
       }
-    } else if (a.warm) {
+    } else if (has_warm) {
       for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;   // no contact anywhere in this wave: nothing survives
     }
     RSB_STAMP(6)
@@ -1233,6 +1270,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
 
   if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
   // ---- results: LDS -> HBM (with the optional control-step epilogue: observation block, reset of terminated envs)
+  RSB_ARGS(ae);
   if (env_valid) {
     bool bad = false;
     for (int i = s; i < nq; i += LPE) bad |= !isfinite(Q[i]);
@@ -1242,19 +1280,19 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
     if (dead) { nc = nc_dead; flag |= 8; }   // report the contacts that ended the episode
     int mycol = 0;
     if (s < nc) mycol = __float_as_int(CON[s * kConSlot + 11]);
-    const bool illegal = a.do_reset && s < nc && !((a.allowed >> mycol) & 1ull);
+    const bool illegal = ae.do_reset && s < nc && !((ae.allowed >> mycol) & 1ull);
     const unsigned long long bb = __ballot(bad), bi = __ballot(illegal);
     const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
     if (bb & gsel) flag |= 2;
-    const bool term = a.do_reset && ((flag & 2) != 0 || (bi & gsel) != 0);
-    if (a.obs_out) {   // the observation is the state the episode ended in (before a reset), as rsb_gather_obs would read it
-      const int od = nq + nv + 3 * a.obs_slots;
-      float* ob = a.obs_out + (size_t)env * od;
+    const bool term = ae.do_reset && ((flag & 2) != 0 || (bi & gsel) != 0);
+    if (ae.obs_out) {   // the observation is the state the episode ended in (before a reset), as rsb_gather_obs would read it
+      const int od = nq + nv + 3 * ae.obs_slots;
+      float* ob = ae.obs_out + (size_t)env * od;
       for (int i = s; i < nq; i += LPE) ob[i] = Q[i];
       for (int i = s; i < nv; i += LPE) ob[nq + i] = U[i];
       const float inv_dt = 1.0f / dt;
-      for (int sl = s; sl < a.obs_slots; sl += LPE) {
-        const int want = a.obs_idx ? a.obs_idx[sl] : sl;
+      for (int sl = s; sl < ae.obs_slots; sl += LPE) {
+        const int want = ae.obs_idx ? ae.obs_idx[sl] : sl;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
         for (int k = 0; k < nc; ++k) {
           if (__float_as_int(CON[k * kConSlot + 11]) == want) {
@@ -1268,10 +1306,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
         ob[nq + nv + 3 * sl] = f0; ob[nq + nv + 3 * sl + 1] = f1; ob[nq + nv + 3 * sl + 2] = f2;
       }
     }
-    if (a.warm) for (int i = s; i < nwarm; i += LPE) a.warm[(size_t)env * nwarm + i] = term ? 0.f : WARM[i];
-    const size_t r0 = (a.reset_rows == 1) ? 0 : (size_t)env;
-    for (int i = s; i < nq; i += LPE) a.gc[(size_t)env * nq + i] = term ? a.gc0[r0 * nq + i] : Q[i];
-    for (int i = s; i < nv; i += LPE) a.gv[(size_t)env * nv + i] = term ? a.gv0[r0 * nv + i] : U[i];
+    if (ae.warm) for (int i = s; i < nwarm; i += LPE) ae.warm[(size_t)env * nwarm + i] = term ? 0.f : WARM[i];
+    const size_t r0 = (ae.reset_rows == 1) ? 0 : (size_t)env;
+    for (int i = s; i < nq; i += LPE) ae.gc[(size_t)env * nq + i] = term ? ae.gc0[r0 * nq + i] : Q[i];
+    for (int i = s; i < nv; i += LPE) ae.gv[(size_t)env * nv + i] = term ? ae.gv0[r0 * nv + i] : U[i];
     if (s < nc) {
       float CN[16];
       ldv<4>(CON + s * kConSlot, CN);
@@ -1287,18 +1325,18 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs a) {
       ct.depth = CN[3];
       ct.body = __float_as_int(CN[7]);
       ct.collision = __float_as_int(CN[11]);
-      a.contacts[(size_t)env * a.kmax + s] = ct;
+      ae.contacts[(size_t)env * kmax + s] = ct;
     }
-    if (a.tau2_out) {
+    if (ae.tau2_out) {
       float t = tsq;
       RSB_UNROLL for (int off = 1; off < LPE; off <<= 1) t += __shfl_xor(t, off);
-      if (s == 0) a.tau2_out[env] = t;
+      if (s == 0) ae.tau2_out[env] = t;
     }
     if (s == 0) {
-      if (a.done_out) a.done_out[env] = term ? 1 : 0;
-      a.contact_count[env] = term ? 0 : nc;   // a reset env starts its episode without contacts or flags
-      a.flags[env] = term ? 0 : flag;
-      a.iters[env] = iters_used;
+      if (ae.done_out) ae.done_out[env] = term ? 1 : 0;
+      ae.contact_count[env] = term ? 0 : nc;   // a reset env starts its episode without contacts or flags
+      ae.flags[env] = term ? 0 : flag;
+      ae.iters[env] = iters_used;
     }
   }
 }
