@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   const DevModel& m = *a.model;
   const int nb = m.nb, nq = m.nq, nv = m.nv, depth = m.depth, ncol = m.ncol, cw = m.cw;
   const int nch = m.nch, nclv = m.nclv, max_cc = m.max_cc;
-  const LdsLayout& L = a.L;
+  const auto& L = a.L;
 
   float* MODELF = lds + L.t_model;
   float* GAIN = lds + L.t_gain;                                  // [nb][2] kp, kd of the body's joint
