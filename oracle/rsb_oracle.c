@@ -890,6 +890,10 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
           }
           solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds, lag, p->refine, 0.0, sdir[i], tmp);
         }
+        /* an inherited direction that the first refresh did not pick up is dropped: a contact that starts to slip later in
+         * the solve runs the global search (the device checks inherited directions against the coarse scan in the first
+         * sweep only) */
+        if (it == 0) for (int i = 0; i < nc; ++i) if (sdir[i][2] == 3.0) sdir[i][2] = 0.0;
       }
       for (int i = 0; i < nc; ++i) {
         double v[3] = {cfree[i][0], cfree[i][1], cfree[i][2]}, ln[3];

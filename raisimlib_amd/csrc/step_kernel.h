@@ -156,11 +156,12 @@ __device__ __forceinline__ void slip_prepare(const float* G, const float* v, con
   k.vn = v[2]; k.ls0 = ls[0]; k.ls1 = ls[1];
 }
 __device__ __forceinline__ float slip_E(const SlipCoef& k, float mu, float x, float y) {
+  // branch-free: directions without a curve point (den <= 0) evaluate to +inf through a select, not a jump
   const float den = k.a0 + k.a1 * x + k.a2 * y;
-  if (!(den > kDenMin * k.a0)) return __int_as_float(0x7f800000);
   const float inv = __builtin_amdgcn_rcpf(den), ln = -k.vn * inv;
   const float vt0 = (k.n00 + k.n01 * x + k.n02 * y) * inv, vt1 = (k.n10 + k.n11 * x + k.n12 * y) * inv;
-  return fmaxf(0.5f * (vt0 * (mu * ln * x - k.ls0) + vt1 * (mu * ln * y - k.ls1)), 0.f);
+  const float e = fmaxf(0.5f * (vt0 * (mu * ln * x - k.ls0) + vt1 * (mu * ln * y - k.ls1)), 0.f);
+  return (den > kDenMin * k.a0) ? e : __int_as_float(0x7f800000);
 }
 // (bx, by): any positive multiple of the round-0 best direction; where the curve has no point (den <= 0) the
 // minimiser lies on that direction's side of the candidate (the infeasible arc is contiguous and < 180 deg)
@@ -983,15 +984,21 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           }
           for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
           if (__any(isc && (lam[0] != 0.f || lam[1] != 0.f || lam[2] != 0.f))) {
-            // v = c + G lam(0): one broadcast pass over the contacts (v carries the own impulse as well)
-            static_for<0, KMAX>([&](auto jc) {
-              constexpr int j = decltype(jc)::value;
-              if (j < ncw) {
-                float l0[3] = {lam[0], lam[1], lam[2]};
-                row_bcast_n<j, 3>(l0);      // lanes beyond the env's contacts hold lam = 0
-                float gj[3][4];
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
-                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) v[rr] += gj[rr][0] * l0[0] + gj[rr][1] * l0[1] + gj[rr][2] * l0[2];
+            // v = c + G lam(0): one broadcast pass over the contacts (v carries the own impulse as well).  Blocks of four
+            // contacts: all twelve LDS reads are issued first, and a block runs whole - a contact slot its env does not use
+            // carries lam = 0 against a finite (zero-initialised) block - so there is one branch per four contacts, not four.
+            static_for<0, KMAX / 4>([&](auto bc) {
+              constexpr int j0 = 4 * decltype(bc)::value;
+              if (j0 < ncw) {
+                float gj[4][3][4];
+                RSB_UNROLL for (int k = 0; k < 4; ++k)
+                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (j0 + k), gj[k][rr]);
+                static_for<0, 4>([&](auto kc2) {
+                  constexpr int k = decltype(kc2)::value;
+                  float l0[3] = {lam[0], lam[1], lam[2]};
+                  row_bcast_n<j0 + k, 3>(l0);
+                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) v[rr] += gj[k][rr][0] * l0[0] + gj[k][rr][1] * l0[1] + gj[k][rr][2] * l0[2];
+                });
               }
             });
           }
@@ -1020,56 +1027,72 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           kc.vn = vexn; kc.ls0 = ls[0]; kc.ls1 = ls[1];
         };
 
-        for (int it = 0; it < max_iter; ++it) {
+        // Every branch costs a lone wave ~35-45 cycles taken or not (profiles/r02_ubench_lone_wave_latency.txt: v_cmp +
+        // s_cbranch = 44 cycles, a dependent v_fma = 4.8), i.e. as much as 8-9 VALU instructions.  The sweep below is
+        // therefore written with selects; the few branches that remain guard work that is both rare and large.
+        //
+        // (A) direction refresh of every slipping contact, from the sweep's initial state.  FIRST = first sweep of the solve:
+        // only there are directions inherited from the previous integrate() in play (and checked against the coarse scan).
+        auto refresh = [&](auto first_tag, bool lag) {
+          constexpr bool FIRST = decltype(first_tag)::value;
           const bool active = isc && !done;
-          const bool lag = freeze_after > 0 && it >= freeze_after;
-          float gbuf[2][3][4];          // coupling blocks of the sequential pass (see phase B); block 0 is fetched behind phase (A)
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS, gbuf[0][rr]);
-          // ---------------- (A) direction refresh of every slipping contact, from the sweep's initial state
-          long long ta0 = 0; if (PROF && a.prof && a.prof_fine) ta0 = clock64();
-          {
-            float ls[3];
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-              ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
-            const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
-            const bool slipnow = active && !(vexn > 0.f) && !(ls[2] >= 0.f && (ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2]);
-            // lagged directions: after freeze_after sweeps a usable direction of this solve is no longer refreshed
-            const bool keep = lag && sdst == 1 && (sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0;
-            bool need = slipnow && !keep;
-            if (__any(need)) {
-              SlipCoef kc;
-              own_coef(ls, vexn, kc);
-              const bool cand = need && sdst != 0 && refine != 0;
-              if (__any(cand)) {
-                if (PROF && a.prof) ++p_newton;
-                float nx, ny, dstep;
-                bool ok = slip_newton(kc, mu, sdx, sdy, nx, ny, dstep) && cand;
-                const bool chk = ok && sdst == 3;
-                if (__any(chk)) {
-                  // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
-                  // local minimum the global search would not choose; it is accepted only if it is at least as good as every
-                  // direction of the search's coarse scan.  Every contact lane scans the 16 directions of its OWN contact
-                  // (all contacts at once: this runs in the first sweep of every integrate() for every slipping contact, and a
-                  // row-cooperative scan would serialise over the contacts).
-                  float ebest = slip_E(kc, mu, 1.0f, 0.0f);
-                  RSB_UNROLL for (int i = 1; i < 16; ++i) ebest = fminf(ebest, slip_E(kc, mu, kCos16[i], kSin16[i]));
-                  if (chk && !(slip_E(kc, mu, nx, ny) <= ebest)) ok = false;
-                }
-                if (ok) { sdx = nx; sdy = ny; sdst = 1; need = false; }
-              }
-              if (__any(need)) {
-                for (int j = 0; j < ncw; ++j)
-                  if (__any(need && s == j)) search_row(j, kc, need && s == j);
+          float ls[3];
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+            ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
+          const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
+          const bool stick = (ls[2] >= 0.f) & ((ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2]);
+          const bool slipnow = active & !(vexn > 0.f) & !stick;
+          // lagged directions: after freeze_after sweeps a usable direction of this solve is no longer refreshed
+          const bool keep = lag & (sdst == 1) & ((sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0);
+          bool need = slipnow & !keep;
+          if (__any(need)) {
+            SlipCoef kc;
+            own_coef(ls, vexn, kc);
+            // one guarded Newton step on every lane (it is the common case; lanes without a candidate ignore the result)
+            if (PROF && a.prof) ++p_newton;
+            float nx, ny, dstep;
+            bool ok = slip_newton(kc, mu, sdx, sdy, nx, ny, dstep) & need & (sdst != 0) & (refine != 0);
+            if (FIRST) {
+              const bool chk = ok & (sdst == 3);
+              if (__any(chk)) {
+                // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
+                // local minimum the global search would not choose; it is accepted only if it is at least as good as every
+                // direction of the search's coarse scan.  Every contact lane scans the 16 directions of its OWN contact (all
+                // contacts at once; a row-cooperative scan would serialise over the contacts).
+                float ebest = slip_E(kc, mu, 1.0f, 0.0f);
+                RSB_UNROLL for (int i = 1; i < 16; ++i) ebest = fminf(ebest, slip_E(kc, mu, kCos16[i], kSin16[i]));
+                ok = ok & !(chk & !(slip_E(kc, mu, nx, ny) <= ebest));
               }
             }
+            sdx = ok ? nx : sdx; sdy = ok ? ny : sdy; sdst = ok ? 1 : sdst;
+            need = need & !ok;
+            if (__any(need)) {
+              for (int j = 0; j < ncw; ++j)
+                if (__any(need && s == j)) search_row(j, kc, need && s == j);
+            }
           }
+          // an inherited direction that was not picked up by the first refresh is dropped (oracle: same rule): a contact that
+          // starts to slip later in the solve runs the global search
+          if (FIRST) sdst = (sdst == 3) ? 0 : sdst;
+        };
+
+        for (int it = 0; it < max_iter; ++it) {
+          const bool active = isc && !done;
+          float gbuf[2][3][4];          // coupling blocks of the sequential pass (see phase B); block 0 is fetched behind phase (A)
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS, gbuf[0][rr]);
+          long long ta0 = 0; if (PROF && a.prof && a.prof_fine) ta0 = clock64();
+          if (it == 0) refresh(std::true_type{}, false);
+          else refresh(std::false_type{}, freeze_after > 0 && it >= freeze_after);
           if (PROF && a.prof && a.prof_fine) t_newt += clock64() - ta0;
           // ---------------- (B) the sequential pass
-          // One contact update; `bcast3` broadcasts three floats from lane j of each row.  With can_search == false the
-          // update bails out (returns true, nothing modified) when contact j needs a global search.
+          // One contact update; `bcast3` broadcasts three floats from lane j of each row.  FAST: no search code - an update
+          // whose contact slips without a usable direction only raises `bad` (the whole pass is then repeated by the
+          // generic loop below from the saved state: rare, and it keeps the common pass free of data-dependent branches).
           float err = 0.f;
-          auto update = [&](int j, const float (&gj)[3][4], auto&& bcast3, bool can_search) -> bool {
-            const bool mine = (s == j) && active;
+          bool bad = false;
+          auto update = [&](int j, const float (&gj)[3][4], auto&& bcast3, auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const bool mine = (s == j) & active;
             // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
             float ls[3];
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
@@ -1080,11 +1103,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             const bool slip = (!open) & (!stick);
             if (PROF && a.prof) ++p_solves;
             // a slipping contact keeps its direction when it has a usable one; otherwise (it started to slip inside this
-            // sweep, or the direction is inherited / ill conditioned) the global search runs right here
+            // sweep, or the direction is ill conditioned) the global search runs right here
             float den = sc.a0 + sc.a1 * sdx + sc.a2 * sdy;
             const bool nodir = mine & slip & !((sdst == 1) & (den >= kDenFreeze * sc.a0));
-            if (__any(nodir)) {
-              if (!can_search) return true;
+            if (FAST) bad |= nodir;
+            else if (__any(nodir)) {
               SlipCoef kc;
               own_coef(ls, vexn, kc);
               search_row(j, kc, nodir);
@@ -1106,43 +1129,54 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
               v[rr] += gj[rr][0] * dl[0] + gj[rr][1] * dl[1] + gj[rr][2] * dl[2];
             err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
-            return false;
           };
-          // fast path: the pass unrolled over j with immediate-lane DPP broadcasts and no search code; an update that
-          // needs a search hands the rest of the sweep to the generic loop (runtime j, branch-tree broadcast, search)
-          // The coupling block of update j+1 is fetched from LDS while update j runs (two register buffers alternate), the
-          // block of update 0 before phase (A): the sequential chain never waits for an LDS round trip.
-          int jres = ncw;
-          static_for<0, KMAX>([&](auto jc) {
+          // fast pass: unrolled over j with immediate-lane DPP broadcasts.  The coupling block of update j+1 is fetched from
+          // LDS while update j runs (two register buffers alternate): the sequential chain never waits for an LDS round trip.
+          const float lam_s[3] = {lam[0], lam[1], lam[2]}, v_s[3] = {v[0], v[1], v[2]};
+          auto fast = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if (j < ncw && jres == ncw) {   // wave-uniform
-              if (j + 1 < KMAX) { RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (j + 1), gbuf[(j + 1) & 1][rr]); }
-              if (update(j, gbuf[j & 1], [&](float* x) { row_bcast_n<j, 3>(x); }, false)) jres = j;
+            if (j + 1 < KMAX) { RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (j + 1), gbuf[(j + 1) & 1][rr]); }
+            update(j, gbuf[j & 1], [&](float* x) { row_bcast_n<j, 3>(x); }, std::true_type{});
+          };
+          // the usual wave has four or five contact slots in use: the first four updates then run as one straight block
+          // (a branch costs as much as a tenth of an update), the others behind one scalar test each
+          if (ncw >= 4) static_for<0, 4>(fast);
+          else static_for<0, 3>([&](auto jc) { if (decltype(jc)::value < ncw) fast(jc); });
+          static_for<4, KMAX>([&](auto jc) { if (decltype(jc)::value < ncw) fast(jc); });
+          if (__any(bad)) {
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { lam[rr] = lam_s[rr]; v[rr] = v_s[rr]; }
+            err = 0.f;
+            for (int j = 0; j < ncw; ++j) {
+              float gj[3][4];               // this contact's coupling block with contact j (zero-initialised G: stale blocks are finite)
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
+              update(j, gj, [&](float* x) { row_bcast3_dyn<KMAX>(x, j); }, std::false_type{});
             }
-          });
-          for (int j = jres; j < ncw; ++j) {
-            float gj[3][4];               // this contact's coupling block with contact j (zero-initialised G: stale blocks are finite)
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
-            update(j, gj, [&](float* x) { row_bcast3_dyn<KMAX>(x, j); }, true);
           }
-          // ---------------- (C) convergence
+          // ---------------- (C) convergence: relative (fp32-aware) test and stagnation exit, identical to the oracle's
+          // (rsb_oracle.c), written with selects (every lane of the env carries the same err / scale)
           const float scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
           long long te0 = 0; if (PROF && a.prof && a.prof_fine) te0 = clock64();
-          if (!done) {
-            ++iters_used;
+          {
+            const bool live = !done;
+            iters_used += live ? 1 : 0;
             alpha = fmaxf(alpha * alpha_decay, alpha_min);
-            // relative (fp32-aware) test and stagnation exit, identical to the oracle's: see rsb_oracle.c
-            if (err <= threshold * (scale + kLambdaFloor)) { done = true; converged = true; }
-            else {
-              const float rel = err / (scale + kLambdaFloor);
-              if (rel < best_rel) { best_rel = rel; lam_best[0] = lam[0]; lam_best[1] = lam[1]; lam_best[2] = lam[2]; }
-              best_cur = fminf(best_cur, rel);
-              if (stall_window > 0 && ++wcount == stall_window) {
-                wcount = 0;
-                if (best_cur > stall_factor * best_prev) done = true;
-                best_prev = best_cur; best_cur = 3e38f;
-              }
-            }
+            const float denom = scale + kLambdaFloor;
+            const bool conv_now = live & (err <= threshold * denom);
+            const float rel = err / denom;
+            const bool cont = live & !conv_now;
+            const bool better = cont & (rel < best_rel);      // the calmest iterate so far
+            best_rel = better ? rel : best_rel;
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) lam_best[rr] = better ? lam[rr] : lam_best[rr];
+            best_cur = cont ? fminf(best_cur, rel) : best_cur;
+            const bool wtick = cont & (stall_window > 0);
+            wcount += wtick ? 1 : 0;
+            const bool wfull = wtick & (wcount == stall_window);
+            const bool stalled = wfull & (best_cur > stall_factor * best_prev);
+            best_prev = wfull ? best_cur : best_prev;
+            best_cur = wfull ? 3e38f : best_cur;
+            wcount = wfull ? 0 : wcount;
+            converged |= conv_now;
+            done |= conv_now | stalled;
           }
           if (PROF && a.prof && a.prof_fine) t_epi += clock64() - te0;
           if (!__any(!done)) break;
