@@ -1093,25 +1093,27 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           auto update = [&](int j, const float (&gj)[3][4], auto&& bcast3, auto fast_tag) {
             constexpr bool FAST = decltype(fast_tag)::value;
             const bool mine = (s == j) & active;
-            // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
+            // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam.
+            // Explicit fmaf chains: the fast and the generic instance of this lambda must round identically (which of the two
+            // runs depends on the env's wave mates, the result must not), so nothing is left to the contraction heuristics.
             float ls[3];
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-              ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
-            const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
+              ls[rr] = fmaf(-Ginv[3 * rr + 2], v[2], fmaf(-Ginv[3 * rr + 1], v[1], fmaf(-Ginv[3 * rr], v[0], lam[rr])));
+            const float vexn = fmaf(-Gii[8], lam[2], fmaf(-Gii[7], lam[1], fmaf(-Gii[6], lam[0], v[2])));
             const bool open = vexn > 0.f;
-            const bool stick = (!open) & (ls[2] >= 0.f) & ((ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2]);
+            const bool stick = (!open) & (ls[2] >= 0.f) & (fmaf(ls[1], ls[1], ls[0] * ls[0]) <= (mu2 * ls[2]) * ls[2]);
             const bool slip = (!open) & (!stick);
             if (PROF && a.prof) ++p_solves;
             // a slipping contact keeps its direction when it has a usable one; otherwise (it started to slip inside this
             // sweep, or the direction is ill conditioned) the global search runs right here
-            float den = sc.a0 + sc.a1 * sdx + sc.a2 * sdy;
+            float den = fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0));
             const bool nodir = mine & slip & !((sdst == 1) & (den >= kDenFreeze * sc.a0));
             if (FAST) bad |= nodir;
             else if (__any(nodir)) {
               SlipCoef kc;
               own_coef(ls, vexn, kc);
               search_row(j, kc, nodir);
-              den = sc.a0 + sc.a1 * sdx + sc.a2 * sdy;
+              den = fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0));
             }
             // impulse along the direction: v_n^+ = 0 on the cone boundary
             const float lnn = -vexn * __builtin_amdgcn_rcpf(fmaxf(den, kDenMin * sc.a0));
@@ -1127,7 +1129,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             }
             bcast3(dl);
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-              v[rr] += gj[rr][0] * dl[0] + gj[rr][1] * dl[1] + gj[rr][2] * dl[2];
+              v[rr] = fmaf(gj[rr][2], dl[2], fmaf(gj[rr][1], dl[1], fmaf(gj[rr][0], dl[0], v[rr])));
             err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
           };
           // fast pass: unrolled over j with immediate-lane DPP broadcasts.  The coupling block of update j+1 is fetched from

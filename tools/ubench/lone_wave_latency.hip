@@ -13,6 +13,7 @@
   {                                                                                      \
     unsigned long long t0, t1;                                                           \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t0) :: "memory"); \
+    asm volatile("s_mov_b32 s42, 3" ::: "s42");                                         \
     asm volatile(".rept " STR(REP) "\n" body "\n.endr" : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(addr), "s"(sptr) : "vcc", "s40", "s41", "s42", "s43", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "memory"); \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t1) :: "memory"); \
     if (threadIdx.x == 0) out[idx] = (long long)(t1 - t0);                               \
@@ -48,6 +49,17 @@ __global__ void __launch_bounds__(64) ub(long long* out, float* sink, const floa
   TIMED(21, "v_fma_f32 %0, %0, %1, %2\n s_barrier")                             // barrier of a single-wave workgroup
   TIMED(22, "v_sqrt_f32 %0, %0")
   TIMED(23, "v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1\n s_branch 1f\n1:")   // unconditional taken branch every 4 VALU
+  TIMED(24, "s_cmp_lt_i32 s42, 5\n s_cbranch_scc0 1f\n v_fma_f32 %0, %0, %1, %2\n1:")               // scalar compare + branch NOT taken (s42 = 3)
+  TIMED(25, "s_cmp_gt_i32 s42, 5\n s_cbranch_scc0 1f\n v_fma_f32 %0, %0, %1, %2\n1:")               // scalar compare + branch TAKEN
+  TIMED(26, "v_cmp_gt_f32 vcc, %0, %1\n s_and_saveexec_b64 s[40:41], vcc\n s_cbranch_execz 1f\n v_fma_f32 %0, %0, %1, %2\n1:\n s_or_b64 exec, exec, s[40:41]")   // divergent if with execz skip, not taken
+  TIMED(27, "v_cmp_gt_f32 vcc, %0, %1\n s_and_saveexec_b64 s[40:41], vcc\n v_fma_f32 %0, %0, %1, %2\n s_or_b64 exec, exec, s[40:41]")   // divergent if, predication only (no branch)
+  TIMED(28, "v_cmp_gt_f32 vcc, %0, %1\n s_nop 4\n s_cbranch_vccz 1f\n v_fma_f32 %0, %0, %1, %2\n1:")   // is the cost a VALU->branch hazard? pad with s_nop
+  TIMED(29, "v_cmp_gt_f32 vcc, %0, %1\n v_fma_f32 %3, %3, %1, %2\n v_fma_f32 %3, %3, %1, %2\n v_fma_f32 %3, %3, %1, %2\n v_fma_f32 %3, %3, %1, %2\n v_fma_f32 %3, %3, %1, %2\n v_fma_f32 %3, %3, %1, %2\n s_cbranch_vccz 1f\n v_fma_f32 %0, %0, %1, %2\n1:")   // 6 independent FMAs between compare and branch
+  TIMED(30, "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n s_cmp_lt_i32 s42, 5\n s_cbranch_scc0 1f\n v_fma_f32 %0, %0, %1, %2\n1:")   // 16 FMAs + scalar branch not taken: amortised cost
+  TIMED(31, "v_pk_fma_f32 v[200:201], v[202:203], v[204:205], v[200:201]")                              // packed fp32 FMA, dependent
+  TIMED(32, "v_pk_fma_f32 v[200:201], v[202:203], v[204:205], v[206:207]\n v_pk_fma_f32 v[208:209], v[202:203], v[204:205], v[206:207]")   // 2 independent packed FMAs
+  TIMED(33, "ds_bpermute_b32 v200, %4, %0\n s_waitcnt lgkmcnt(0)")                                     // bpermute latency
+  TIMED(34, "v_mov_b32_dpp %0, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %2, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_mov_b32_dpp %3, %1 row_newbcast:3 row_mask:0xf bank_mask:0xf")   // 3 independent DPP movs
   sink[threadIdx.x] = x + y + z + w;
 }
 
@@ -65,8 +77,13 @@ int main() {
                          "v_cmp sgpr + s_and + s_cbranch_scc0 not taken + v_fma", "ds_read_b128 + wait (LDS latency)", "3 ds_read_b128 + wait",
                          "ds_read_b96 + 8 dependent v_fma + wait", "v_readlane + independent v_fma", "v_readlane + s_nop 3 + v_mul using it",
                          "s_load_dword (cached) + wait", "4 s_mov", "ds_write_b128 + wait", "ds_add_f32 + wait", "v_fma + s_barrier (1-wave workgroup)",
-                         "dependent v_sqrt", "4 v_mul + s_branch taken"};
+                         "dependent v_sqrt", "4 v_mul + s_branch taken",
+                         "s_cmp + s_cbranch_scc NOT taken + v_fma", "s_cmp + s_cbranch_scc TAKEN (skips v_fma)",
+                         "v_cmp + s_and_saveexec + s_cbranch_execz (not taken) + v_fma + s_or exec", "v_cmp + s_and_saveexec + v_fma + s_or exec (no branch)",
+                         "v_cmp + s_nop 4 + s_cbranch_vccz not taken + v_fma", "v_cmp + 6 independent v_fma + s_cbranch_vccz + v_fma",
+                         "16 dependent v_fma + s_cmp + s_cbranch_scc not taken + v_fma", "dependent v_pk_fma_f32", "2 independent v_pk_fma_f32",
+                         "ds_bpermute_b32 + wait", "3 independent DPP row_newbcast movs"};
   const double base = (double)h[0];
-  for (int i = 0; i < 24; ++i) std::printf("%2d %-58s %8.1f cycles per pattern\n", i, names[i], i == 0 ? base : (h[i] - base) / REP);
+  for (int i = 0; i < 35; ++i) std::printf("%2d %-58s %8.1f cycles per pattern\n", i, names[i], i == 0 ? base : (h[i] - base) / REP);
   return 0;
 }
