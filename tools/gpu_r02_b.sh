@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round-2 GPU call B: parity after the solver restructuring (per-sweep direction refresh), bench, wave diagnostics.
+# Round-2 GPU call B: parity after the solver restructuring (per-sweep direction refresh, branch-lean sweep), bench, wave diagnostics.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r02b}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-( time timeout 1200 python -m pytest tests -m gpu -x -q ) > $O/pytest.log 2>&1
+( time timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_kat.py tests/test_gpu_fuzz.py -m gpu -q --durations=12 ) > $O/pytest.log 2>&1
 echo "pytest rc=$?" >> $O/pytest.log
-tail -15 $O/pytest.log
+tail -40 $O/pytest.log
 cd /tmp && export TMPDIR=/tmp
 timeout 300 python $R/bench.py --no-cpu 2>$O/bench_c2.err | tail -1 > $O/bench_c2.json
 timeout 300 python $R/bench.py --no-cpu --config 3 2>$O/bench_c3.err | tail -1 > $O/bench_c3.json
