@@ -23,7 +23,7 @@ class Params(C.Structure):
         ("max_iter", C.c_int32), ("section_rounds", C.c_int32), ("kmax", C.c_int32), ("control_mode", C.c_int32),
         ("warm_start", C.c_int32), ("freeze_after", C.c_int32),
         ("terrain_type", C.c_int32), ("hm_xs", C.c_int32), ("hm_ys", C.c_int32), ("stall_window", C.c_int32),
-        ("dir_per_sweep", C.c_int32), ("refine", C.c_int32),
+        ("dir_per_sweep", C.c_int32), ("refine", C.c_int32), ("group_parallel", C.c_int32), ("reserved0", C.c_int32),
         ("ground_z", C.c_double), ("stall_factor", C.c_double), ("restitution", C.c_double), ("res_threshold", C.c_double),
         ("settle_tol", C.c_double),
         ("hm_xsize", C.c_double), ("hm_ysize", C.c_double), ("hm_cx", C.c_double), ("hm_cy", C.c_double),

@@ -55,7 +55,7 @@ class EnvConfig(C.Structure):
                 ("n_foot", C.c_int32), ("foot_collisions", C.c_int32 * RSB_MAX_COLLISIONS)]
 
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsb.so")
+LIB_PATH = os.environ.get("RSB_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsb.so")   # RSB_LIB_PATH: kernel experiments built by build.build(extra_flags=...)
 
 # name -> (restype, argtypes); mirrors include/rsb.h one-to-one (tests check the two stay in sync)
 _VP, _I, _D, _FP, _CP = C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_char_p

@@ -59,6 +59,7 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
     os.makedirs(OBJ, exist_ok=True)
     inc = ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
     tag = "_".join(f.strip("-").replace("=", "") for f in extra_flags)     # objects built with other flags do not mix
+    out = OUT if not tag else OUT[:-3] + f".{tag}.so"                      # ... and link into their own library (RSB_LIB_PATH selects it)
     tasks = []   # (object path, command)
     for src, deps in HOST_SOURCES.items():
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + (f".{tag}" if tag else "") + ".o")
@@ -73,8 +74,8 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
                 tasks.append((obj, [hipcc, *FLAGS, *extra_flags, *inc, f"-DRSB_I_LPE={lpe}", f"-DRSB_I_KMAX={kmax}",
                                     f"-DRSB_I_CL={cl}", f"-DRSB_I_ML={ml}", f"-DRSB_I_PROF={prof}", "-c",
                                     _path("step_instance.hip"), "-o", obj]))
-    if not tasks and os.path.exists(OUT) and all(os.path.getmtime(o) <= os.path.getmtime(OUT) for o in objs):
-        return OUT
+    if not tasks and os.path.exists(out) and all(os.path.getmtime(o) <= os.path.getmtime(out) for o in objs):
+        return out
 
     def run(task):
         obj, cmd = task
@@ -90,11 +91,11 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
     jobs = jobs or int(os.environ.get("RSB_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=jobs) as pool:
         list(pool.map(run, tasks))
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs, "-lz"]   # zlib: PNG height maps
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-lz"]   # zlib: PNG height maps
     if verbose:
         print(" ".join(link[:6]), f"... ({len(objs)} objects) -lz", file=sys.stderr)
     subprocess.run(link, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -221,6 +221,14 @@ __device__ __forceinline__ float row_max_f32(float x) {
   x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, true)));
   return x;
 }
+// 16-lane row sum (DPP row rotate): every lane of the row ends up with the sum, the order of the additions is fixed
+__device__ __forceinline__ float row_sum_f32(float x) {
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, true));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, true));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, true));
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, true));
+  return x;
+}
 // compile-time loop (the index is needed as a template argument of row_bcast)
 template <int J, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -482,7 +490,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   int nc_real = 0;     // contacts of the last sub-step without the joint-limit rows that follow them in the solver
   bool dead = false;   // early termination: this env no longer integrates (its contacts at that moment stay reported)
   int nc_dead = 0;
-  long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
+  long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0, t_rule = 0, t_exch = 0, t_end = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
   if (PROF && a.prof) t_start = clock64();
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
@@ -790,6 +798,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     RSB_STAMP(3)
 
     iters_used = 0;
+    float wlam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // base part of sum_c W_c lam_c (left by the solver on the lanes of the env's first row)
     if (ncw > 0) {
       RSB_ARGS(aw);
       const float restitution = aw.restitution, res_threshold = aw.res_threshold, erp = aw.erp;
@@ -923,17 +932,22 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + 4 * (j / 3) + (j % 3)];
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
       }
-      long long t_gs0 = 0; if (PROF && a.prof) t_gs0 = clock64();
-      // ========================= per-contact Gauss-Seidel (lane = contact) ==========================
+      long long t_gs0 = 0, tz0 = 0; if (PROF && a.prof) t_gs0 = clock64();
+      // ========================= per-contact iteration, grouped sweep (lane = contact) ===============
       // Lane j (< nc) owns contact j: own 3x3 block, its inverse, velocity (WITH the own impulse) and impulse stay in
-      // registers.  One sweep =
-      //   (A) direction refresh: every slipping contact refines its friction direction by one guarded Newton step (all
-      //       contact lanes at once; oracle: dir_per_sweep), falling back to the row-cooperative global search;
-      //   (B) the sequential pass: contact j = 0 .. ncw-1 in turn solves open / stick / slip-along-its-direction, the
-      //       impulse change is broadcast with DPP row_newbcast and every lane updates its own contact velocity;
-      //   (C) convergence test, stagnation exit, calmest iterate.
-      // Keeping the direction search out of (B) is what makes (B) ~70 instructions per contact: a lone wave issues one
-      // instruction per 4 cycles whatever its kind, so the sequential part is priced in instructions.
+      // registers.  Contacts are grouped by the limb they sit on (the subtree hanging off the base that holds the contact's
+      // body; contacts on the base form one more group).  Contacts of different limbs couple only through the base, contacts
+      // of one limb - above all two contacts on one link - couple strongly.  One sweep =
+      //   for k = 0 .. (largest group size - 1):  pass k
+      //     every contact that is the k-th of its group applies the per-contact rule (open / stick / slip with its friction
+      //     direction refined by one guarded Newton step, else the row-cooperative global search) to the impulses the pass
+      //     started with - ALL of them in one SIMD evaluation (block Jacobi across limbs, Gauss-Seidel within a limb; oracle:
+      //     group_parallel) - then the impulse changes are exchanged: lane i adds G_ij dl_j for every j (DPP row_newbcast);
+      //   convergence test, stagnation exit, calmest iterate.
+      // A lone wave issues one instruction per ~4 cycles whatever its kind (profiles/r02_ubench_lone_wave_latency.txt), so the
+      // solve is priced in instructions: a pass costs one evaluation of the rule (~60 instructions, + ~90 when a direction is
+      // refined) + 16 per contact for the exchange, where the sequential sweep paid one evaluation per contact.  The usual env
+      // (four feet on four legs) has one pass per sweep; sweep counts are those of the sequential iteration + 6 %.
       {
         const bool isc = s < nc;
         float Gii[9], Ginv[12], v[3], lam[3] = {0.f, 0.f, 0.f};
@@ -941,6 +955,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         RSB_UNROLL for (int q2 = 0; q2 < 9; ++q2) Gii[q2] = 0.f;
         RSB_UNROLL for (int q2 = 0; q2 < 12; ++q2) Ginv[q2] = 0.f;
         v[0] = v[1] = v[2] = 0.f;
+        int gidc = -1 - s;            // limb of the own contact (non-contact lanes: an id nobody shares)
         if (isc) {
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
             float g4[4];
@@ -949,6 +964,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           }
           ldv<3>(GINV + 12 * s, Ginv);
           v[0] = CV[3 * s]; v[1] = CV[3 * s + 1]; v[2] = CV[3 * s + 2];
+          const int kb = __float_as_int(CON[s * kConSlot + 7]);
+          gidc = ((PARLV[kb] >> 8) >= 1) ? ANC[kb * depth + 1] : 0;
         }
         // the solver's parameters, read here so that they occupy SGPRs during the solve only
         RSB_ARGS(ag);
@@ -968,8 +985,68 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         float alpha = alpha_init, best_prev = 3e38f, best_cur = 3e38f;
         bool done = (nc == 0), converged = (nc == 0);
         int wcount = 0;
-        // CV has been consumed: its first 6 floats now accumulate the base part of sum_c W_c lam_c
-        if (s < 6) CV[s] = 0.f;
+
+        // position of the own contact within its group, and the wave's largest group (= passes per sweep)
+        int gpos = 0, gdw = 1;
+        {
+          static_for<0, KMAX / 4>([&](auto bc) {
+            constexpr int j0 = 4 * decltype(bc)::value;
+            if (j0 < ncw) {
+              static_for<0, 4>([&](auto kc2) {
+                constexpr int j = j0 + decltype(kc2)::value;
+                const int gj = __builtin_amdgcn_update_dpp(0, gidc, 0x150 + j, 0xf, 0xf, true);
+                gpos += ((gj == gidc) & (j < s)) ? 1 : 0;
+              });
+            }
+          });
+          int gd = isc ? gpos + 1 : 1;
+          RSB_UNROLL for (int off = 1; off < 64; off <<= 1) gd = max(gd, __shfl_xor(gd, off));
+          gdw = __builtin_amdgcn_readfirstlane(gd);
+        }
+
+        // exchange of impulse changes: lane i adds G_ij x_j for every contact j of its env (x_j broadcast from lane j of the
+        // row).  Contacts 0-3 run as one straight block whatever the count (a slot its env does not use carries x = 0 against a
+        // finite, zero-initialised block); contacts 4-7 behind one nested scalar test each (the usual hard env has five), the
+        // rest in blocks of four.  The LDS reads of a block are issued before the previous block is consumed (two buffers).
+        float gbuf[2][4][3][4];
+        auto load_block = [&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          RSB_UNROLL for (int k = 0; k < 4; ++k)
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (4 * b + k), gbuf[b & 1][k][rr]);
+        };
+        auto exchange = [&](const float (&x)[3], float& emax) {   // the caller has issued load_block(0)
+          auto one = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            float l0[3] = {x[0], x[1], x[2]};
+            row_bcast_n<j, 3>(l0);
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+              v[rr] = fmaf(gbuf[(j / 4) & 1][j & 3][rr][2], l0[2], fmaf(gbuf[(j / 4) & 1][j & 3][rr][1], l0[1], fmaf(gbuf[(j / 4) & 1][j & 3][rr][0], l0[0], v[rr])));
+            emax = fmaxf(emax, fmaxf(fabsf(l0[0]), fmaxf(fabsf(l0[1]), fabsf(l0[2]))));
+          };
+          const bool more = ncw > 4;
+          if (more) load_block(std::integral_constant<int, 1>{});
+          static_for<0, 4>(one);
+          if (more) {
+            one(std::integral_constant<int, 4>{});
+            if (ncw > 5) {
+              one(std::integral_constant<int, 5>{});
+              if (ncw > 6) {
+                one(std::integral_constant<int, 6>{});
+                if (ncw > 7) {
+                  one(std::integral_constant<int, 7>{});
+                  static_for<2, KMAX / 4>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    if (4 * b < ncw) {   // (these blocks load late: only models with many contacts per env get here)
+                      load_block(bc);
+                      static_for<4 * b, 4 * b + 4>(one);
+                    }
+                  });
+                }
+              }
+            }
+          }
+        };
+
         // warm start (oracle: lam_warm): the impulse and friction direction this collision primitive had at the end of
         // the previous integrate(); the table is then cleared, contacts alive at the end of this solve re-enter it
         int mycol = 0;
@@ -984,23 +1061,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           }
           for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
           if (__any(isc && (lam[0] != 0.f || lam[1] != 0.f || lam[2] != 0.f))) {
-            // v = c + G lam(0): one broadcast pass over the contacts (v carries the own impulse as well).  Blocks of four
-            // contacts: all twelve LDS reads are issued first, and a block runs whole - a contact slot its env does not use
-            // carries lam = 0 against a finite (zero-initialised) block - so there is one branch per four contacts, not four.
-            static_for<0, KMAX / 4>([&](auto bc) {
-              constexpr int j0 = 4 * decltype(bc)::value;
-              if (j0 < ncw) {
-                float gj[4][3][4];
-                RSB_UNROLL for (int k = 0; k < 4; ++k)
-                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (j0 + k), gj[k][rr]);
-                static_for<0, 4>([&](auto kc2) {
-                  constexpr int k = decltype(kc2)::value;
-                  float l0[3] = {lam[0], lam[1], lam[2]};
-                  row_bcast_n<j0 + k, 3>(l0);
-                  RSB_UNROLL for (int rr = 0; rr < 3; ++rr) v[rr] += gj[k][rr][0] * l0[0] + gj[k][rr][1] * l0[1] + gj[k][rr][2] * l0[2];
-                });
-              }
-            });
+            // v = c + G lam(0): one exchange of the inherited impulses (v carries the own impulse as well)
+            load_block(std::integral_constant<int, 0>{});
+            float unused = 0.f;
+            exchange(lam, unused);
           }
         }
         if (PROF && a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
@@ -1017,85 +1081,18 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           slip_search<LPE>(kb, mu, section_rounds, s, el, c16, s16, DIR16, dxy);
           if (take) { sdx = dxy[0]; sdy = dxy[1]; sdst = 1; }
         };
-        // own-contact slip coefficients for the current (v, lam): see slip_prepare
-        auto own_coef = [&](const float* ls, float vexn, SlipCoef& kc) {
-          kc = sc;
-          const float vex0 = v[0] - (Gii[0] * lam[0] + Gii[1] * lam[1] + Gii[2] * lam[2]);
-          const float vex1 = v[1] - (Gii[3] * lam[0] + Gii[4] * lam[1] + Gii[5] * lam[2]);
-          kc.n00 = sc.a0 * vex0 - vexn * Gii[2]; kc.n01 = sc.a1 * vex0 - vexn * sc.n01; kc.n02 = sc.a2 * vex0 - vexn * sc.n02;
-          kc.n10 = sc.a0 * vex1 - vexn * Gii[5]; kc.n11 = sc.a1 * vex1 - vexn * sc.n11; kc.n12 = sc.a2 * vex1 - vexn * sc.n12;
-          kc.vn = vexn; kc.ls0 = ls[0]; kc.ls1 = ls[1];
-        };
 
-        // Every branch costs a lone wave ~35-45 cycles taken or not (profiles/r02_ubench_lone_wave_latency.txt: v_cmp +
-        // s_cbranch = 44 cycles, a dependent v_fma = 4.8), i.e. as much as 8-9 VALU instructions.  The sweep below is
-        // therefore written with selects; the few branches that remain guard work that is both rare and large.
-        //
-        // (A) direction refresh of every slipping contact, from the sweep's initial state.  FIRST = first sweep of the solve:
-        // only there are directions inherited from the previous integrate() in play (and checked against the coarse scan).
-        auto refresh = [&](auto first_tag, bool lag) {
-          constexpr bool FIRST = decltype(first_tag)::value;
-          const bool active = isc && !done;
-          float ls[3];
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-            ls[rr] = lam[rr] - (Ginv[3 * rr] * v[0] + Ginv[3 * rr + 1] * v[1] + Ginv[3 * rr + 2] * v[2]);
-          const float vexn = v[2] - (Gii[6] * lam[0] + Gii[7] * lam[1] + Gii[8] * lam[2]);
-          const bool stick = (ls[2] >= 0.f) & ((ls[0] * ls[0] + ls[1] * ls[1]) <= mu2 * ls[2] * ls[2]);
-          const bool slipnow = active & !(vexn > 0.f) & !stick;
-          // lagged directions: after freeze_after sweeps a usable direction of this solve is no longer refreshed
-          const bool keep = lag & (sdst == 1) & ((sc.a0 + sc.a1 * sdx + sc.a2 * sdy) >= kDenFreeze * sc.a0);
-          bool need = slipnow & !keep;
-          if (__any(need)) {
-            SlipCoef kc;
-            own_coef(ls, vexn, kc);
-            // one guarded Newton step on every lane (it is the common case; lanes without a candidate ignore the result)
-            if (PROF && a.prof) ++p_newton;
-            float nx, ny, dstep;
-            bool ok = slip_newton(kc, mu, sdx, sdy, nx, ny, dstep) & need & (sdst != 0) & (refine != 0);
-            if (FIRST) {
-              const bool chk = ok & (sdst == 3);
-              if (__any(chk)) {
-                // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
-                // local minimum the global search would not choose; it is accepted only if it is at least as good as every
-                // direction of the search's coarse scan.  Every contact lane scans the 16 directions of its OWN contact (all
-                // contacts at once; a row-cooperative scan would serialise over the contacts).
-                float ebest = slip_E(kc, mu, 1.0f, 0.0f);
-                RSB_UNROLL for (int i = 1; i < 16; ++i) ebest = fminf(ebest, slip_E(kc, mu, kCos16[i], kSin16[i]));
-                ok = ok & !(chk & !(slip_E(kc, mu, nx, ny) <= ebest));
-              }
-            }
-            sdx = ok ? nx : sdx; sdy = ok ? ny : sdy; sdst = ok ? 1 : sdst;
-            need = need & !ok;
-            if (__any(need)) {
-              for (int j = 0; j < ncw; ++j)
-                if (__any(need && s == j)) search_row(j, kc, need && s == j);
-            }
-          }
-          // an inherited direction that was not picked up by the first refresh is dropped (oracle: same rule): a contact that
-          // starts to slip later in the solve runs the global search
-          if (FIRST) sdst = (sdst == 3) ? 0 : sdst;
-        };
-
+        // Every branch costs a lone wave ~20-45 cycles taken or not (profiles/r02_ubench_lone_wave_latency.txt), i.e. as much
+        // as 5-10 VALU instructions: the pass is written with selects, the branches that remain guard work that is rare and large.
         for (int it = 0; it < max_iter; ++it) {
-          const bool active = isc && !done;
-          float gbuf[2][3][4];          // coupling blocks of the sequential pass (see phase B); block 0 is fetched behind phase (A)
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS, gbuf[0][rr]);
-          long long ta0 = 0; if (PROF && a.prof && a.prof_fine) ta0 = clock64();
-          if (it == 0) refresh(std::true_type{}, false);
-          else refresh(std::false_type{}, freeze_after > 0 && it >= freeze_after);
-          if (PROF && a.prof && a.prof_fine) t_newt += clock64() - ta0;
-          // ---------------- (B) the sequential pass
-          // One contact update; `bcast3` broadcasts three floats from lane j of each row.  FAST: no search code - an update
-          // whose contact slips without a usable direction only raises `bad` (the whole pass is then repeated by the
-          // generic loop below from the saved state: rare, and it keeps the common pass free of data-dependent branches).
+          const bool lag = freeze_after > 0 && it >= freeze_after;   // lagged directions: a usable direction of this solve is no longer refreshed
           float err = 0.f;
-          bool bad = false;
-          auto update = [&](int j, const float (&gj)[3][4], auto&& bcast3, auto fast_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value;
-            const bool mine = (s == j) & active;
-            // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam.
-            // Explicit fmaf chains: the fast and the generic instance of this lambda must round identically (which of the two
-            // runs depends on the env's wave mates, the result must not), so nothing is left to the contraction heuristics.
+          for (int kp = 0; kp < gdw; ++kp) {
+            long long tr0 = 0; if (PROF && a.prof && a.prof_fine) tr0 = clock64();
+            load_block(std::integral_constant<int, 0>{});            // the exchange's first coupling blocks arrive behind the rule
+            const bool mine = isc & !done & (gpos == kp);
+            if (PROF && a.prof) ++p_solves;
+            // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
             float ls[3];
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
               ls[rr] = fmaf(-Ginv[3 * rr + 2], v[2], fmaf(-Ginv[3 * rr + 1], v[1], fmaf(-Ginv[3 * rr], v[0], lam[rr])));
@@ -1103,19 +1100,45 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             const bool open = vexn > 0.f;
             const bool stick = (!open) & (ls[2] >= 0.f) & (fmaf(ls[1], ls[1], ls[0] * ls[0]) <= (mu2 * ls[2]) * ls[2]);
             const bool slip = (!open) & (!stick);
-            if (PROF && a.prof) ++p_solves;
-            // a slipping contact keeps its direction when it has a usable one; otherwise (it started to slip inside this
-            // sweep, or the direction is ill conditioned) the global search runs right here
-            float den = fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0));
-            const bool nodir = mine & slip & !((sdst == 1) & (den >= kDenFreeze * sc.a0));
-            if (FAST) bad |= nodir;
-            else if (__any(nodir)) {
+            const bool keep = lag & (sdst == 1) & (fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0)) >= kDenFreeze * sc.a0);
+            bool need = mine & slip & !keep;
+            if (PROF && a.prof && a.prof_fine) t_rule += clock64() - tr0;
+            if (__any(need)) {
+              long long ta0 = 0; if (PROF && a.prof && a.prof_fine) ta0 = clock64();
               SlipCoef kc;
-              own_coef(ls, vexn, kc);
-              search_row(j, kc, nodir);
-              den = fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0));
+              kc = sc;
+              {
+                const float vex0 = v[0] - (Gii[0] * lam[0] + Gii[1] * lam[1] + Gii[2] * lam[2]);
+                const float vex1 = v[1] - (Gii[3] * lam[0] + Gii[4] * lam[1] + Gii[5] * lam[2]);
+                kc.n00 = sc.a0 * vex0 - vexn * Gii[2]; kc.n01 = sc.a1 * vex0 - vexn * sc.n01; kc.n02 = sc.a2 * vex0 - vexn * sc.n02;
+                kc.n10 = sc.a0 * vex1 - vexn * Gii[5]; kc.n11 = sc.a1 * vex1 - vexn * sc.n11; kc.n12 = sc.a2 * vex1 - vexn * sc.n12;
+                kc.vn = vexn; kc.ls0 = ls[0]; kc.ls1 = ls[1];
+              }
+              // one guarded Newton step on every lane (the common case; lanes without a candidate ignore the result)
+              if (PROF && a.prof) ++p_newton;
+              float nx, ny, dstep;
+              bool ok = slip_newton(kc, mu, sdx, sdy, nx, ny, dstep) & need & (sdst != 0) & (refine != 0);
+              if (it == 0) {
+                const bool chk = ok & (sdst == 3);
+                if (__any(chk)) {
+                  // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the
+                  // local minimum the global search would not choose; it is accepted only if it is at least as good as every
+                  // direction of the search's coarse scan.  Every contact lane scans the 16 directions of its OWN contact.
+                  float ebest = slip_E(kc, mu, 1.0f, 0.0f);
+                  RSB_UNROLL for (int i = 1; i < 16; ++i) ebest = fminf(ebest, slip_E(kc, mu, kCos16[i], kSin16[i]));
+                  ok = ok & !(chk & !(slip_E(kc, mu, nx, ny) <= ebest));
+                }
+              }
+              sdx = ok ? nx : sdx; sdy = ok ? ny : sdy; sdst = ok ? 1 : sdst;
+              need = need & !ok;
+              if (__any(need)) {
+                for (int j = 0; j < ncw; ++j)
+                  if (__any(need && s == j)) search_row(j, kc, need && s == j);
+              }
+              if (PROF && a.prof && a.prof_fine) t_newt += clock64() - ta0;
             }
             // impulse along the direction: v_n^+ = 0 on the cone boundary
+            const float den = fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0));
             const float lnn = -vexn * __builtin_amdgcn_rcpf(fmaxf(den, kDenMin * sc.a0));
             const float ltn = mu * lnn;
             float ln[3];
@@ -1127,34 +1150,14 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
               dl[rr] = mine ? alpha * (ln[rr] - lam[rr]) : 0.f;
               lam[rr] += dl[rr];
             }
-            bcast3(dl);
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-              v[rr] = fmaf(gj[rr][2], dl[2], fmaf(gj[rr][1], dl[1], fmaf(gj[rr][0], dl[0], v[rr])));
-            err = fmaxf(err, fmaxf(fabsf(dl[0]), fmaxf(fabsf(dl[1]), fabsf(dl[2]))));
-          };
-          // fast pass: unrolled over j with immediate-lane DPP broadcasts.  The coupling block of update j+1 is fetched from
-          // LDS while update j runs (two register buffers alternate): the sequential chain never waits for an LDS round trip.
-          const float lam_s[3] = {lam[0], lam[1], lam[2]}, v_s[3] = {v[0], v[1], v[2]};
-          auto fast = [&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if (j + 1 < KMAX) { RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (j + 1), gbuf[(j + 1) & 1][rr]); }
-            update(j, gbuf[j & 1], [&](float* x) { row_bcast_n<j, 3>(x); }, std::true_type{});
-          };
-          // the usual wave has four or five contact slots in use: the first four updates then run as one straight block
-          // (a branch costs as much as a tenth of an update), the others behind one scalar test each
-          if (ncw >= 4) static_for<0, 4>(fast);
-          else static_for<0, 3>([&](auto jc) { if (decltype(jc)::value < ncw) fast(jc); });
-          static_for<4, KMAX>([&](auto jc) { if (decltype(jc)::value < ncw) fast(jc); });
-          if (__any(bad)) {
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { lam[rr] = lam_s[rr]; v[rr] = v_s[rr]; }
-            err = 0.f;
-            for (int j = 0; j < ncw; ++j) {
-              float gj[3][4];               // this contact's coupling block with contact j (zero-initialised G: stale blocks are finite)
-              RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * j, gj[rr]);
-              update(j, gj, [&](float* x) { row_bcast3_dyn<KMAX>(x, j); }, std::false_type{});
-            }
+            long long tx0 = 0; if (PROF && a.prof && a.prof_fine) tx0 = clock64();
+            exchange(dl, err);
+            if (PROF && a.prof && a.prof_fine) t_exch += clock64() - tx0;
           }
-          // ---------------- (C) convergence: relative (fp32-aware) test and stagnation exit, identical to the oracle's
+          // an inherited direction that the first sweep did not pick up is dropped (oracle: same rule): a contact that starts
+          // to slip later in the solve runs the global search
+          if (it == 0) sdst = (sdst == 3) ? 0 : sdst;
+          // ---------------- convergence: relative (fp32-aware) test and stagnation exit, identical to the oracle's
           // (rsb_oracle.c), written with selects (every lane of the env carries the same err / scale)
           const float scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
           long long te0 = 0; if (PROF && a.prof && a.prof_fine) te0 = clock64();
@@ -1164,7 +1167,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             alpha = fmaxf(alpha * alpha_decay, alpha_min);
             const float denom = scale + kLambdaFloor;
             const bool conv_now = live & (err <= threshold * denom);
-            const float rel = err / denom;
+            const float rel = err * __builtin_amdgcn_rcpf(denom);   // only ranks iterates (calmest iterate, stagnation window)
             const bool cont = live & !conv_now;
             const bool better = cont & (rel < best_rel);      // the calmest iterate so far
             best_rel = better ? rel : best_rel;
@@ -1183,6 +1186,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           if (PROF && a.prof && a.prof_fine) t_epi += clock64() - te0;
           if (!__any(!done)) break;
         }
+        if (PROF && a.prof && a.prof_fine) tz0 = clock64();
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
         if (isc) {
           LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2];
@@ -1191,27 +1195,36 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             wr[0] = lam[0]; wr[1] = lam[1]; wr[2] = lam[2];
             wr[3] = sdst ? sdx : 0.f; wr[4] = sdst ? sdy : 0.f; wr[5] = sdst ? 1.f : 0.f;
           }
-          // W^T lam scattered by the contact lanes (LDS float atomics; lanes of one instruction are served in lane
-          // order, so the sums are reproducible): base entries -> CV[0..5], joint entries -> WB of the support chain
-          const float* W0 = WC + 3 * s * cw;
+        }
+        // W^T lam: the base entries are summed over the contact lanes by a DPP row reduction (contact lanes sit in the env's
+        // first row, which also holds the chain lanes that use the sum); the joint entries are scattered into WB of the
+        // support chain with LDS float atomics (lanes of one instruction are served in lane order: reproducible)
+        {
+          const int sc2 = isc ? s : 0;
+          const float* W0 = WC + 3 * sc2 * cw;
           float z0[8], z1[8], z2[8];
           ld4(W0, z0); ld4(W0 + 4, z0 + 4); ld4(W0 + cw, z1); ld4(W0 + cw + 4, z1 + 4); ld4(W0 + 2 * cw, z2); ld4(W0 + 2 * cw + 4, z2 + 4);
-          const int bi = __float_as_int(CON[s * kConSlot + 7]);
-          RSB_UNROLL for (int i = 0; i < 6; ++i) atomicAdd(&CV[i], z0[i] * lam[0] + z1[i] * lam[1] + z2[i] * lam[2]);
-          RSB_UNROLL for (int lv = 1; lv <= ML; ++lv) {
-            if (lv < depth) {
-              const int b = ANC[bi * depth + lv];
-              if (b >= 0) {
-                float w0, w1, w2;
-                if (lv < 3) { w0 = z0[5 + lv]; w1 = z1[5 + lv]; w2 = z2[5 + lv]; }
-                else { w0 = W0[5 + lv]; w1 = W0[cw + 5 + lv]; w2 = W0[2 * cw + 5 + lv]; }
-                atomicAdd(&WB[b + 5], w0 * lam[0] + w1 * lam[1] + w2 * lam[2]);
+          const float l0 = isc ? lam[0] : 0.f, l1 = isc ? lam[1] : 0.f, l2 = isc ? lam[2] : 0.f;
+          // (select, not a product with a zero impulse: a lane without a contact reads column memory nobody wrote)
+          RSB_UNROLL for (int i = 0; i < 6; ++i) wlam[i] = row_sum_f32(isc ? z0[i] * l0 + z1[i] * l1 + z2[i] * l2 : 0.f);
+          if (isc) {
+            const int bi = __float_as_int(CON[s * kConSlot + 7]);
+            RSB_UNROLL for (int lv = 1; lv <= ML; ++lv) {
+              if (lv < depth) {
+                const int b = ANC[bi * depth + lv];
+                if (b >= 0) {
+                  float w0, w1, w2;
+                  if (lv < 3) { w0 = z0[5 + lv]; w1 = z1[5 + lv]; w2 = z2[5 + lv]; }
+                  else { w0 = W0[5 + lv]; w1 = W0[cw + 5 + lv]; w2 = W0[2 * cw + 5 + lv]; }
+                  atomicAdd(&WB[b + 5], w0 * l0 + w1 * l1 + w2 * l2);
+                }
               }
             }
           }
         }
       }
       __syncthreads();
+      if (PROF && a.prof && a.prof_fine) t_end += clock64() - tz0;
       if (PROF && a.prof) { t_gs += clock64() - t_gs0; int itw = iters_used; RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) itw = max(itw, __shfl_xor(itw, off)); p_iters += itw; p_ncw = max(p_ncw, ncw); }
       if (PROF && a.dbg && env == a.dbg_env && env_valid && s == 0) {
         const int n3 = 3 * nc_real;
@@ -1228,11 +1241,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     {
       float wv[6];
       RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] = wbb[i];
-      if (ncw > 0) {   // base part of sum_c W_c lam_c, accumulated by the contact lanes at the end of the solve
-        float z[8];
-        ld4(CV, z); z[4] = CV[4]; z[5] = CV[5];
-        RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] += z[i];
-      }
+      RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] += wlam[i];   // base part of sum_c W_c lam_c (zero without contacts)
       float x[6];
       RSB_UNROLL for (int ii = 0; ii < 6; ++ii) {
         const int i = 5 - ii;
@@ -1304,7 +1313,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
-  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
+  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
   // ---- results: LDS -> HBM (with the optional control-step epilogue: observation block, reset of terminated envs)
   RSB_ARGS(ae);
   if (env_valid) {
