@@ -71,7 +71,7 @@ struct rsb_world {
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
   double stall_factor = 0.5, settle_tol = 0.0, restitution = 0.0, res_threshold = 0.0;
-  int lpe = 0, max_cl = 0;
+  int lpe = 0;
   double world_time = 0;
   bool integrate1_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -124,38 +124,14 @@ void build_dev_model(const rsb_model_blob& b, DevModel* d) {
   for (int i = 0; i < b.nb * b.depth; ++i) d->anc[i] = -1;
   for (int i = 0; i < b.nb; ++i)
     for (int j = i; j >= 0; j = b.parent[j]) d->anc[i * b.depth + b.level[j]] = j;
-  // kinematic chains: a body continues its parent's chain iff it is the parent's first child (parent != base)
-  std::vector<int> chain_of(b.nb, -1);
-  d->nch = 0; d->nclv = 0; d->max_cl = 0;
-  for (int i = 1; i < b.nb; ++i) {
-    const int p = b.parent[i];
-    if (p >= 1 && kids[p][0] == i) {
-      const int c = chain_of[p];
-      d->ch_body[c * rsbk::kMaxCL + d->ch_len[c]] = i;
-      d->ch_len[c] += 1;
-      chain_of[i] = c;
-    } else {
-      const int c = d->nch++;
-      d->ch_attach[c] = p;
-      d->ch_level[c] = p == 0 ? 1 : d->ch_level[chain_of[p]] + 1;
-      d->ch_body[c * rsbk::kMaxCL] = i;
-      d->ch_len[c] = 1;
-      chain_of[i] = c;
-    }
-  }
-  std::vector<std::vector<int>> cc(b.nb);
-  for (int c = 0; c < d->nch; ++c) {
-    if (d->ch_len[c] > d->max_cl) d->max_cl = d->ch_len[c];
-    if (d->ch_level[c] > d->nclv) d->nclv = d->ch_level[c];
-    cc[d->ch_attach[c]].push_back(c);
-  }
+  // children lists (the step kernel's up pass gathers over them); the base's children lead the list
   int pos = 0;
-  d->max_cc = 0;
+  d->max_kid = 0;
   for (int i = 0; i < b.nb; ++i) {
-    d->cc_start[i] = pos;
-    d->cc_count[i] = (int)cc[i].size();
-    for (int c : cc[i]) d->cc_list[pos++] = c;
-    if (i >= 1 && d->cc_count[i] > d->max_cc) d->max_cc = d->cc_count[i];
+    d->kid_start[i] = pos;
+    d->kid_count[i] = (int)kids[i].size();
+    for (int c : kids[i]) d->kid_list[pos++] = c;
+    if (i >= 1 && d->kid_count[i] > d->max_kid) d->max_kid = d->kid_count[i];
   }
   for (int s = 0; s < b.ncol; ++s) {
     d->col_body[s] = b.col_body[s];
@@ -163,15 +139,6 @@ void build_dev_model(const rsb_model_blob& b, DevModel* d) {
     d->col_pos[s][3] = (float)b.col_radius[s];
   }
 }
-
-// longest chain of the decomposition above (needed before a DevModel exists, to pick the kernel class)
-int longest_chain(const rsb_model_blob& b) {
-  auto dm = std::make_unique<DevModel>();
-  build_dev_model(b, dm.get());
-  return dm->max_cl;
-}
-
-int count_chains(const rsb_model_blob& b);
 
 LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   LdsLayout L;
@@ -184,22 +151,19 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.t_anc = take(b.nb * b.depth);
   L.t_dir = take(64);
   L.t_col = take(8 * b.ncol);
-  L.t_cc = take(b.nb);
-  L.t_ccl = take(count_chains(b) > 0 ? count_chains(b) : 1);
+  L.t_kids = take(b.nb);
   L.shared_total = o;
   o = 0;
   L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
   L.pt = take(b.nq); L.dtg = take(b.nv); L.tf = take(b.nv < 8 ? 8 : b.nv);
   L.body = take(b.nb * rsbk::kBodySlot);
-  L.ups = take((count_chains(b) > 0 ? count_chains(b) : 1) * rsbk::kUpSlot);
-  L.bacc = take(28);
   L.fact = take(b.nb * rsbk::kFactSlot);
   L.wb = take(b.nv);
   L.con = take(kcap * rsbk::kConSlot);
   L.wc = take(3 * kcap * cw);
   L.cv = take(3 * kcap);
   L.gstride = 4 * kcap + 4;   // 3x3 blocks on a 4-float pitch, +4 staggers the banks of consecutive rows
-  L.g = take(3 * kcap * L.gstride);
+  L.g = take(std::max(3 * kcap * L.gstride, b.nb * rsbk::kUpSlot));   // the up pass's [nb][28] hand-over slots alias the Delassus rows
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
   L.warm = take(6 * b.ncol);
@@ -212,23 +176,13 @@ size_t lds_bytes_for(const rsb_model_blob& b, int kcap, int lpe) {
   return sizeof(float) * ((size_t)L.shared_total + (size_t)(64 / lpe) * L.per_env);
 }
 
-int count_chains(const rsb_model_blob& b) {
-  std::vector<int> first(b.nb, -1);
-  int n = 0;
-  for (int i = 1; i < b.nb; ++i) {
-    const int p = b.parent[i];
-    if (p >= 1 && first[p] < 0) first[p] = i; else ++n;
-  }
-  return n;
-}
-
 // Lanes per env: the group size that keeps the most envs resident on a CU.  The kernel runs at one wave per SIMD
 // (register budget), so a CU holds min(4, 160 KiB / workgroup LDS) workgroups of 64/LPE envs each.  ANYmal-like models:
 // LPE 16 (4 x 4 envs, 38 KB per workgroup: at N = 4096 one wave on every SIMD of the chip); Atlas-like, kmax 16
 // (25 KB per env): every choice holds 4 envs, LPE 64 keeps all four SIMDs busy.
 int default_lpe(const rsb_model_blob& b, int kmax) {
   const int kcap = kmax <= 8 ? 8 : 16;
-  const int need = count_chains(b) > 16 ? (count_chains(b) > 32 ? 64 : 32) : 16;
+  const int need = b.nb > 16 ? (b.nb > 32 ? 64 : 32) : 16;   // lane = body in the tree passes
   int best = 64, best_envs = 0, best_wgs = 0;
   for (int lpe = need; lpe <= 64; lpe *= 2) {
     const size_t wg = lds_bytes_for(b, kcap, lpe);
@@ -395,7 +349,7 @@ int effective_lpe(const rsb_world* w) {
 
 int check_lpe(const rsb_world* w, int lpe) {
   if (lpe != 16 && lpe != 32 && lpe != 64) { rsb::set_error("lanes_per_env must be 16, 32 or 64"); return RSB_E_INVALID; }
-  if (lpe < count_chains(w->blob)) { rsb::set_error("lanes_per_env must be >= number of kinematic chains"); return RSB_E_INVALID; }
+  if (lpe < w->blob.nb) { rsb::set_error("lanes_per_env must be >= number of moving bodies (lane = body in the tree passes)"); return RSB_E_INVALID; }
   const int kcap = w->kmax <= 8 ? 8 : 16;
   if (lds_bytes_for(w->blob, kcap, lpe) > 160 * 1024) { rsb::set_error("lanes_per_env too small: the workgroup's envs do not fit in 160 KiB of LDS"); return RSB_E_INVALID; }
   return RSB_OK;
@@ -452,16 +406,16 @@ int do_integrate(rsb_world* w, int nsub) {
   const bool rec = w->timing && (w->launch_index++ % w->timing_stride == 0);
   if (rec && !w->ring0.empty()) { e0 = w->ring0[w->ring_next]; e1 = w->ring1[w->ring_next]; }
   if (rec) HIP_TRY(hipEventRecord(e0, w->stream));
-  // kernel classes by (longest chain, deepest body level): <=4/<=4 (quadrupeds), <=8/<=12 (humanoids), <=16/<=16
-  const int mcl = w->max_cl, mlv = w->blob.depth - 1;
-  if (mcl <= 4 && mlv <= 4) {
-    st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe, prof);
-  } else if (mcl <= 8 && mlv <= 12) {
-    st = launch_lpe<16, 8, 12>(w, a, lds_bytes, lpe, prof);
-  } else if (mcl <= 16 && mlv <= 16) {
-    st = launch_step<64, 16, 16, 16>(w, a, lds_bytes, prof);
+  // kernel classes by the deepest body level (support-chain capacity of the contact-column / Delassus phases)
+  const int mlv = w->blob.depth - 1;
+  if (mlv <= 4) {
+    st = kcap == 8 ? launch_lpe<8, 0, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 4>(w, a, lds_bytes, lpe, prof);
+  } else if (mlv <= 12) {
+    st = launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
+  } else if (mlv <= 16) {
+    st = launch_lpe<16, 0, 16>(w, a, lds_bytes, lpe, prof);
   } else {
-    rsb::set_error("model outside the compiled kernel classes (chain length <= 16, tree depth <= 17)");
+    rsb::set_error("model outside the compiled kernel classes (tree depth <= 17)");
     return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
@@ -510,7 +464,7 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   w->blob = m->blob;
   w->N = num_envs;
   w->device = device;
-  w->max_cl = longest_chain(w->blob);
+
   const int nq = w->blob.nq, nv = w->blob.nv;
   const size_t N = (size_t)num_envs;
   HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));

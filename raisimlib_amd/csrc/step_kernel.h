@@ -392,7 +392,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
 
   const DevModel& m = *a.model;
   const int nb = m.nb, nq = m.nq, nv = m.nv, depth = m.depth, ncol = m.ncol, cw = m.cw;
-  const int nch = m.nch, nclv = m.nclv, max_cc = m.max_cc;
   const auto& L = a.L;
 
   float* MODELF = lds + L.t_model;
@@ -401,8 +400,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   int* ANC = reinterpret_cast<int*>(lds + L.t_anc);              // [nb*depth]
   float* DIR16 = lds + L.t_dir;                                  // float4 [16] slip-search brackets
   float* COLT = lds + L.t_col;                                   // [ncol][8] sphere centre (body frame), radius, body, pad
-  int* CCT = reinterpret_cast<int*>(lds + L.t_cc);               // [nb] cc_start | cc_count << 16 (chains hanging off the body)
-  int* CCL = reinterpret_cast<int*>(lds + L.t_ccl);              // [nch] chain ids, grouped by attachment body
+  int* KIDS = reinterpret_cast<int*>(lds + L.t_kids);            // [nb] child bodies, grouped by parent (DevModel::kid_start / kid_count)
   float* E = lds + L.shared_total + el * L.per_env;
   float* Q = E + L.q;
   float* U = E + L.u;
@@ -410,8 +408,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   float* DTG = E + L.dtg;
   float* TF = E + L.tf;
   float* BODY = E + L.body;
-  float* UPS = E + L.ups;                                        // [nch] articulated inertia + bias handed to the parent chain
-  float* BACC = E + L.bacc;                                      // [28] the same, summed over the chains attached to the base
+  float* UPS = E + L.g;                                          // [nb][28] articulated inertia + bias handed to the parent body; ALIASES G (dead before the Delassus phase)
   float* FACT = E + L.fact;
   float* WB = E + L.wb;
   float* CON = E + L.con;
@@ -437,8 +434,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     GAIN[2 * i + 1] = pd ? a.kd[i + 5] : 0.f;
   }
   for (int i = lane; i < nb * depth; i += 64) ANC[i] = m.anc[i];
-  for (int i = lane; i < nb; i += 64) CCT[i] = m.cc_start[i] | (m.cc_count[i] << 16);
-  for (int i = lane; i < nch; i += 64) CCL[i] = m.cc_list[i];
+  for (int i = lane; i < nb; i += 64) KIDS[i] = m.kid_list[i];
   for (int i = lane; i < ncol; i += 64) {
     float ct[8] = {m.col_pos[i][0], m.col_pos[i][1], m.col_pos[i][2], m.col_pos[i][3], __int_as_float(m.col_body[i]), 0.f, 0.f, 0.f};
     stv<2>(COLT + 8 * i, ct);
@@ -457,14 +453,14 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   float c16, s16;  // this lane's round-0 candidate direction of the slip search
   sincospif((float)(lane & 15) * 0.125f, &s16, &c16);
 
-  // ---- per-lane chain description (lane s = chain s)
-  const bool hasch = s < nch;
-  const int chi = hasch ? s : 0;
-  const int ch_len = hasch ? m.ch_len[chi] : 0;
-  const int ch_attach = m.ch_attach[chi];
-  const int ch_lev = hasch ? m.ch_level[chi] : -1;
-  int chb[CL];
-  RSB_UNROLL for (int k = 0; k < CL; ++k) chb[k] = m.ch_body[chi * kMaxCL + k];
+  // ---- per-lane body description (lane s = body s; the base is body 0 and is handled redundantly by every lane)
+  const bool isbody = s >= 1 && s < nb;
+  const int bb = isbody ? s : 0;
+  const int mylev = isbody ? m.level[bb] : -1;
+  const int mypar = m.parent[bb] < 0 ? 0 : m.parent[bb];
+  const int mykid = m.kid_start[bb] | (m.kid_count[bb] << 16);   // children of the own body: KIDS[start .. start + count)
+  const int nkid0 = m.kid_count[0];
+  const int max_kid = m.max_kid;                                 // most children of one moving body (loop bound of the up pass)
 
   // ---- state rows: HBM -> LDS
   for (int i = s; i < nq; i += LPE) {
@@ -503,7 +499,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     RSB_STAMP(0)
     RSB_ARGS(ab);
     tsq = 0.f;
-    for (int i = s; i < 28; i += LPE) BACC[i] = 0.f;   // summed into by the level-1 chains at the end of the up pass (a barrier lies in between)
     // =========================== base body, redundantly on every lane =========================
     float R0[9], V0[6], A0[6], I10b[10], Zb[6];
     {
@@ -534,85 +529,79 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       }
     }
 
-    // =========================== down pass: lane = chain, serial walk in registers ==============
-    float cS[CL][6], cI10[CL][10], cZ[CL][6], cdtau[CL], carm[CL], cqb[CL], cqd[CL];
-    for (int clv = 1; clv <= nclv; ++clv) {
-      if (ch_lev == clv) {
-        float Rp[9], rp[3], Vp[6], Ap[6];
-        if (ch_attach == 0) {
-          RSB_UNROLL for (int i = 0; i < 9; ++i) Rp[i] = R0[i];
-          rp[0] = rp[1] = rp[2] = 0.f;
-          RSB_UNROLL for (int i = 0; i < 6; ++i) { Vp[i] = V0[i]; Ap[i] = A0[i]; }
+    // =========================== down pass: lane = body ==========================================
+    // (1) every body lane: the joint's own transform E = rtree * R(axis, q)      (no dependence on the parent)
+    // (2) level by level: pose, joint axis S, velocity V and bias acceleration A from the parent's (one LDS round trip per level)
+    // (3) every body lane: rigid inertia about O, bias force, actuation                    (no dependence on the parent)
+    float bS[6], bI10[10], bZ[6], bdtau = 0.f, barm = 1.f, bqb = 0.f, bqd = 0.f;
+    RSB_UNROLL for (int i = 0; i < 6; ++i) { bS[i] = 0.f; bZ[i] = 0.f; }
+    RSB_UNROLL for (int i = 0; i < 10; ++i) bI10[i] = 0.f;
+    {
+      float MF[kModelSlot], E9[9], Rb[9], rb[3], Vb[6], Ab[6];
+      ldv<8>(MODELF + bb * kModelSlot, MF);
+      const int jt = __float_as_int(MF[3]);
+      const float* axis = MF;
+      if (isbody) {
+        bqb = Q[bb + 6]; bqd = U[bb + 5];
+        if (jt == RSB_JOINT_REVOLUTE) {
+          float sn, cs;
+          fast_sincos(bqb, &sn, &cs);
+          const float v = 1.f - cs;
+          float Rq[9];
+          Rq[0] = cs + axis[0] * axis[0] * v;           Rq[1] = axis[0] * axis[1] * v - axis[2] * sn; Rq[2] = axis[0] * axis[2] * v + axis[1] * sn;
+          Rq[3] = axis[1] * axis[0] * v + axis[2] * sn; Rq[4] = cs + axis[1] * axis[1] * v;           Rq[5] = axis[1] * axis[2] * v - axis[0] * sn;
+          Rq[6] = axis[2] * axis[0] * v - axis[1] * sn; Rq[7] = axis[2] * axis[1] * v + axis[0] * sn; Rq[8] = cs + axis[2] * axis[2] * v;
+          mat3_mul(MF + 8, Rq, E9);
         } else {
-          float P[24];
-          ldv<6>(BODY + ch_attach * kBodySlot, P);
-          RSB_UNROLL for (int i = 0; i < 9; ++i) Rp[i] = P[i];
-          RSB_UNROLL for (int i = 0; i < 3; ++i) rp[i] = P[9 + i];
-          RSB_UNROLL for (int i = 0; i < 6; ++i) { Vp[i] = P[12 + i]; Ap[i] = P[18 + i]; }
-        }
-        RSB_UNROLL for (int k = 0; k < CL; ++k) {
-          if (k < ch_len) {
-            const int b = chb[k];
-            float MF[kModelSlot];
-            ldv<8>(MODELF + b * kModelSlot, MF);
-            const float qb = Q[b + 6], qd = U[b + 5];
-            const float* axis = MF;
-            const int jt = __float_as_int(MF[3]);
-            float E9[9], R[9], r[3], t[3], a3[3], S[6];
-            if (jt == RSB_JOINT_REVOLUTE) {
-              float sn, cs;
-              fast_sincos(qb, &sn, &cs);
-              const float v = 1.f - cs;
-              float Rq[9];
-              Rq[0] = cs + axis[0] * axis[0] * v;           Rq[1] = axis[0] * axis[1] * v - axis[2] * sn; Rq[2] = axis[0] * axis[2] * v + axis[1] * sn;
-              Rq[3] = axis[1] * axis[0] * v + axis[2] * sn; Rq[4] = cs + axis[1] * axis[1] * v;           Rq[5] = axis[1] * axis[2] * v - axis[0] * sn;
-              Rq[6] = axis[2] * axis[0] * v - axis[1] * sn; Rq[7] = axis[2] * axis[1] * v + axis[0] * sn; Rq[8] = cs + axis[2] * axis[2] * v;
-              mat3_mul(MF + 8, Rq, E9);
-            } else {
-              RSB_UNROLL for (int i = 0; i < 9; ++i) E9[i] = MF[8 + i];
-            }
-            mat3_mul(Rp, E9, R);
-            mat3_vec(Rp, MF + 4, t);
-            r[0] = rp[0] + t[0]; r[1] = rp[1] + t[1]; r[2] = rp[2] + t[2];
-            mat3_vec(R, axis, a3);
-            if (jt == RSB_JOINT_REVOLUTE) {
-              S[0] = a3[0]; S[1] = a3[1]; S[2] = a3[2];
-              cross3(r, a3, S + 3);
-            } else {
-              r[0] += a3[0] * qb; r[1] += a3[1] * qb; r[2] += a3[2] * qb;
-              S[0] = S[1] = S[2] = 0.f; S[3] = a3[0]; S[4] = a3[1]; S[5] = a3[2];
-            }
-            // A = Ap + (Vp x S) qd uses the PARENT's V, so update A before V
-            float c1[3], c2[3], c3[3];
-            cross3(Vp, S, c1); cross3(Vp, S + 3, c2); cross3(Vp + 3, S, c3);
-            RSB_UNROLL for (int i = 0; i < 3; ++i) { Ap[i] += c1[i] * qd; Ap[3 + i] += (c2[i] + c3[i]) * qd; }
-            RSB_UNROLL for (int i = 0; i < 6; ++i) Vp[i] += S[i] * qd;
-            RSB_UNROLL for (int i = 0; i < 9; ++i) Rp[i] = R[i];
-            rp[0] = r[0]; rp[1] = r[1]; rp[2] = r[2];
-            float P[24];
-            RSB_UNROLL for (int i = 0; i < 9; ++i) P[i] = R[i];
-            RSB_UNROLL for (int i = 0; i < 3; ++i) P[9 + i] = r[i];
-            RSB_UNROLL for (int i = 0; i < 6; ++i) { P[12 + i] = Vp[i]; P[18 + i] = Ap[i]; }
-            stv<6>(BODY + b * kBodySlot, P);
-            body_inertia(R, r, Vp, Ap, MF, dt, cI10[k], cZ[k]);
-            RSB_UNROLL for (int i = 0; i < 6; ++i) cS[k][i] = S[i];
-            // actuation (oracle: actuation_impl): implicit ("stable") PD = position error at q + dt u, plus the joint-space
-            // inertia dt (kd + dt kp) added to the armature; an effort-clipped joint is a constant torque source
-            float tau = TF[b + 5];
-            const float kpj = GAIN[2 * b], kdj = GAIN[2 * b + 1];
-            tau += kpj * (PT[b + 6] - qb - dt * qd) + kdj * (DTG[b + 5] - qd);
-            float Bpd = dt * (kdj + dt * kpj);
-            const float eff = MF[28];
-            if (eff > 0.f && fabsf(tau) > eff) { tau = tau > 0.f ? eff : -eff; Bpd = 0.f; }
-            tsq = fmaf(tau, tau, tsq);
-            tau -= MF[27] * qd;
-            cdtau[k] = dt * tau; carm[k] = MF[26] + Bpd; cqb[k] = qb; cqd[k] = qd;
-          }
+          RSB_UNROLL for (int i = 0; i < 9; ++i) E9[i] = MF[8 + i];
         }
       }
-      __syncthreads();
+      __syncthreads();   // BODY[0] (written by lane 0 above) is visible
+      for (int lv = 1; lv < depth; ++lv) {
+        if (mylev == lv) {
+          float P[24];
+          ldv<6>(BODY + mypar * kBodySlot, P);
+          const float* Rp = P; const float* rp = P + 9; const float* Vp = P + 12; const float* Ap = P + 18;
+          float t[3], a3[3];
+          mat3_mul(Rp, E9, Rb);
+          mat3_vec(Rp, MF + 4, t);
+          rb[0] = rp[0] + t[0]; rb[1] = rp[1] + t[1]; rb[2] = rp[2] + t[2];
+          mat3_vec(Rb, axis, a3);
+          if (jt == RSB_JOINT_REVOLUTE) {
+            bS[0] = a3[0]; bS[1] = a3[1]; bS[2] = a3[2];
+            cross3(rb, a3, bS + 3);
+          } else {
+            rb[0] += a3[0] * bqb; rb[1] += a3[1] * bqb; rb[2] += a3[2] * bqb;
+            bS[0] = bS[1] = bS[2] = 0.f; bS[3] = a3[0]; bS[4] = a3[1]; bS[5] = a3[2];
+          }
+          // A = Ap + (Vp x S) qd uses the PARENT's V
+          float c1[3], c2[3], c3[3];
+          cross3(Vp, bS, c1); cross3(Vp, bS + 3, c2); cross3(Vp + 3, bS, c3);
+          RSB_UNROLL for (int i = 0; i < 3; ++i) { Ab[i] = Ap[i] + c1[i] * bqd; Ab[3 + i] = Ap[3 + i] + (c2[i] + c3[i]) * bqd; }
+          RSB_UNROLL for (int i = 0; i < 6; ++i) Vb[i] = Vp[i] + bS[i] * bqd;
+          float O[24];
+          RSB_UNROLL for (int i = 0; i < 9; ++i) O[i] = Rb[i];
+          RSB_UNROLL for (int i = 0; i < 3; ++i) O[9 + i] = rb[i];
+          RSB_UNROLL for (int i = 0; i < 6; ++i) { O[12 + i] = Vb[i]; O[18 + i] = Ab[i]; }
+          stv<6>(BODY + bb * kBodySlot, O);
+        }
+        __syncthreads();
+      }
+      if (isbody) {
+        body_inertia(Rb, rb, Vb, Ab, MF, dt, bI10, bZ);
+        // actuation (oracle: actuation_impl): implicit ("stable") PD = position error at q + dt u, plus the joint-space
+        // inertia dt (kd + dt kp) added to the armature; an effort-clipped joint is a constant torque source
+        float tau = TF[bb + 5];
+        const float kpj = GAIN[2 * bb], kdj = GAIN[2 * bb + 1];
+        tau += kpj * (PT[bb + 6] - bqb - dt * bqd) + kdj * (DTG[bb + 5] - bqd);
+        float Bpd = dt * (kdj + dt * kpj);
+        const float eff = MF[28];
+        if (eff > 0.f && fabsf(tau) > eff) { tau = tau > 0.f ? eff : -eff; Bpd = 0.f; }
+        tsq = fmaf(tau, tau, tsq);
+        tau -= MF[27] * bqd;
+        bdtau = dt * tau; barm = MF[26] + Bpd;
+      }
     }
-    if (nclv == 0) __syncthreads();
     RSB_STAMP(1)
     RSB_ARGS(ac);
 
@@ -707,75 +696,59 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     ncw = __builtin_amdgcn_readfirstlane(ncw);   // the same in every lane: tell the compiler, so that loops over it are scalar loops
     RSB_STAMP(2)
 
-    // =========================== up pass: articulated inertias + b column (lane = chain) ========
-    float cUD[CL][6], crsD[CL];
-    for (int clv = nclv; clv >= 1; --clv) {
-      if (ch_lev == clv) {
-        float IAc[21], Zc[6];
-        RSB_UNROLL for (int i = 0; i < 21; ++i) IAc[i] = 0.f;
-        RSB_UNROLL for (int i = 0; i < 6; ++i) Zc[i] = 0.f;
-        RSB_UNROLL for (int kk = 0; kk < CL; ++kk) {
-          const int k = CL - 1 - kk;
-          if (k < ch_len) {
-            const int b = chb[k];
-            float IA[21], Z[6];
-            rigid_expand(cI10[k], IA);
-            RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += IAc[i];
-            RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = cZ[k][i] + Zc[i];
-            if (max_cc > 0) {  // chains hanging off this body (none for pure star topologies)
-              const int cct = CCT[b], ccn = cct >> 16, ccs = cct & 0xffff;
-              for (int ci = 0; ci < ccn; ++ci) {
-                float P[28];
-                ldv<7>(UPS + CCL[ccs + ci] * kUpSlot, P);
-                RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
-                RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
-              }
-            }
-            float Uv[6];
-            sym6_vec(IA, cS[k], Uv);
-            const float D = dot6(cS[k], Uv) + carm[k];
-            const float invD = 1.0f / D;
-            const float rsD = sqrtf(invD);
-            const float yhat = cdtau[k] - dot6(cS[k], Z);
-            const float yd = yhat * invD;
-            float Fk[16];
-            RSB_UNROLL for (int i = 0; i < 6; ++i) {
-              const float ud = Uv[i] * invD;
-              cUD[k][i] = ud;
-              Fk[i] = cS[k][i]; Fk[6 + i] = ud;
-              RSB_UNROLL for (int j = 0; j <= i; ++j) IAc[sym6(i, j)] = IA[sym6(i, j)] - Uv[i] * (Uv[j] * invD);
-              Zc[i] = Z[i] + Uv[i] * yd;
-            }
-            crsD[k] = rsD;
-            Fk[12] = rsD; Fk[13] = invD; Fk[14] = 0.f; Fk[15] = 0.f;
-            stv<4>(FACT + b * kFactSlot, Fk);
-            WB[b + 5] = yhat * rsD;
+    // =========================== up pass: articulated inertias + b column (lane = body) ==========
+    // level by level from the leaves: a body gathers what its children left in UPS, factors its joint out and leaves its own
+    // articulated inertia + bias for its parent (RBDA Table 7.1)
+    float bUD[6], brsD = 0.f;
+    RSB_UNROLL for (int i = 0; i < 6; ++i) bUD[i] = 0.f;
+    for (int lv = depth - 1; lv >= 1; --lv) {
+      if (mylev == lv) {
+        float IA[21], Z[6];
+        rigid_expand(bI10, IA);
+        RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = bZ[i];
+        const int kn = mykid >> 16, ks = mykid & 0xffff;
+        for (int ci = 0; ci < max_kid; ++ci) {
+          if (ci < kn) {
+            float P[28];
+            ldv<7>(UPS + KIDS[ks + ci] * kUpSlot, P);
+            RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
+            RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
           }
         }
-        if (ch_attach == 0) {
-          // chains on the base: summed in LDS (float atomics of one instruction are served in lane order -> reproducible)
-          RSB_UNROLL for (int i = 0; i < 21; ++i) atomicAdd(&BACC[i], IAc[i]);
-          RSB_UNROLL for (int i = 0; i < 6; ++i) atomicAdd(&BACC[21 + i], Zc[i]);
-        } else {
-          float P[28];
-          RSB_UNROLL for (int i = 0; i < 21; ++i) P[i] = IAc[i];
-          RSB_UNROLL for (int i = 0; i < 6; ++i) P[21 + i] = Zc[i];
-          P[27] = 0.f;
-          stv<7>(UPS + chi * kUpSlot, P);
+        float Uv[6];
+        sym6_vec(IA, bS, Uv);
+        const float D = dot6(bS, Uv) + barm;
+        const float invD = 1.0f / D;
+        const float rsD = sqrtf(invD);
+        const float yhat = bdtau - dot6(bS, Z);
+        const float yd = yhat * invD;
+        float Fk[16], O[28];
+        RSB_UNROLL for (int i = 0; i < 6; ++i) {
+          const float ud = Uv[i] * invD;
+          bUD[i] = ud;
+          Fk[i] = bS[i]; Fk[6 + i] = ud;
+          RSB_UNROLL for (int j = 0; j <= i; ++j) O[sym6(i, j)] = IA[sym6(i, j)] - Uv[i] * (Uv[j] * invD);
+          O[21 + i] = Z[i] + Uv[i] * yd;
         }
+        O[27] = 0.f;
+        brsD = rsD;
+        Fk[12] = rsD; Fk[13] = invD; Fk[14] = 0.f; Fk[15] = 0.f;
+        stv<4>(FACT + bb * kFactSlot, Fk);
+        WB[bb + 5] = yhat * rsD;
+        stv<7>(UPS + bb * kUpSlot, O);
       }
       __syncthreads();
     }
-    if (nclv == 0) __syncthreads();
-    // base (every lane): gather the chains hanging off the base, Cholesky in gv order (lin, ang), W_b base part
+    if (depth <= 1) __syncthreads();
+    // base (every lane): gather the bodies hanging off the base, Cholesky in gv order (lin, ang), W_b base part
     float C[21], idg[6], wbb[6];
     {
       float IA[21], Z[6];
       rigid_expand(I10b, IA);
       RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = Zb[i];
-      {
+      for (int ci = 0; ci < nkid0; ++ci) {
         float P[28];
-        ldv<7>(BACC, P);
+        ldv<7>(UPS + KIDS[ci] * kUpSlot, P);   // the base's children lead the list (kid_start[0] == 0)
         RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
         RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
       }
@@ -988,6 +961,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
 
         // position of the own contact within its group, and the wave's largest group (= passes per sweep)
         int gpos = 0, gdw = 1;
+        bool light = false;   // light passes (oracle: ORC_LIGHT_DEPTH): an env with >= kLightDepth contacts on one limb refreshes ALL its directions in pass 0
         {
           static_for<0, KMAX / 4>([&](auto bc) {
             constexpr int j0 = 4 * decltype(bc)::value;
@@ -1000,7 +974,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             }
           });
           int gd = isc ? gpos + 1 : 1;
-          RSB_UNROLL for (int off = 1; off < 64; off <<= 1) gd = max(gd, __shfl_xor(gd, off));
+          RSB_UNROLL for (int off = 1; off < 16; off <<= 1) gd = max(gd, __shfl_xor(gd, off));   // the env's largest group (contact lanes sit in one row)
+          light = gd >= kLightDepth;
+          RSB_UNROLL for (int off = 16; off < 64; off <<= 1) gd = max(gd, __shfl_xor(gd, off));
           gdw = __builtin_amdgcn_readfirstlane(gd);
         }
 
@@ -1100,10 +1076,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             const bool open = vexn > 0.f;
             const bool stick = (!open) & (ls[2] >= 0.f) & (fmaf(ls[1], ls[1], ls[0] * ls[0]) <= (mu2 * ls[2]) * ls[2]);
             const bool slip = (!open) & (!stick);
-            const bool keep = lag & (sdst == 1) & (fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0)) >= kDenFreeze * sc.a0);
-            bool need = mine & slip & !keep;
+            const bool usable = (sdst == 1) & (fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0)) >= kDenFreeze * sc.a0);
+            const bool keep = lag & usable;
+            // who refreshes its direction in this pass: the pass's members; in an env with light passes every contact in pass 0
+            const bool refr = isc & !done & (light ? (kp == 0) : (gpos == kp));
+            bool need = refr & slip & !keep;
+            // a member of a light pass keeps its direction; without a usable one (it started to slip after pass 0) it searches
+            const bool lost = mine & slip & !refr & !usable;
             if (PROF && a.prof && a.prof_fine) t_rule += clock64() - tr0;
-            if (__any(need)) {
+            if (__any(need | lost)) {
               long long ta0 = 0; if (PROF && a.prof && a.prof_fine) ta0 = clock64();
               SlipCoef kc;
               kc = sc;
@@ -1130,7 +1111,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
                 }
               }
               sdx = ok ? nx : sdx; sdy = ok ? ny : sdy; sdst = ok ? 1 : sdst;
-              need = need & !ok;
+              need = (need & !ok) | lost;
               if (__any(need)) {
                 for (int j = 0; j < ncw; ++j)
                   if (__any(need && s == j)) search_row(j, kc, need && s == j);
@@ -1197,7 +1178,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           }
         }
         // W^T lam: the base entries are summed over the contact lanes by a DPP row reduction (contact lanes sit in the env's
-        // first row, which also holds the chain lanes that use the sum); the joint entries are scattered into WB of the
+        // first row; wider envs copy the sums to their other rows); the joint entries are scattered into WB of the
         // support chain with LDS float atomics (lanes of one instruction are served in lane order: reproducible)
         {
           const int sc2 = isc ? s : 0;
@@ -1207,6 +1188,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           const float l0 = isc ? lam[0] : 0.f, l1 = isc ? lam[1] : 0.f, l2 = isc ? lam[2] : 0.f;
           // (select, not a product with a zero impulse: a lane without a contact reads column memory nobody wrote)
           RSB_UNROLL for (int i = 0; i < 6; ++i) wlam[i] = row_sum_f32(isc ? z0[i] * l0 + z1[i] * l1 + z2[i] * l2 : 0.f);
+          if constexpr (LPE > 16) {   // body lanes beyond the env's first row need the sum too (level-1 bodies start from the base's delta-velocity)
+            RSB_UNROLL for (int i = 0; i < 6; ++i) wlam[i] = __shfl(wlam[i], (lane & ~(LPE - 1)) | (lane & 15));
+          }
           if (isc) {
             const int bi = __float_as_int(CON[s * kConSlot + 7]);
             RSB_UNROLL for (int lv = 1; lv <= ML; ++lv) {
@@ -1274,41 +1258,26 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         RSB_UNROLL for (int i = 0; i < 6; ++i) U[i] = un[i];
       }
     }
-    for (int clv = 1; clv <= nclv; ++clv) {
-      if (ch_lev == clv) {
-        float ap[6];
-        if (ch_attach == 0) {
-          RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = a0[i];
-        } else {
-          float t6[8];
-          ld4(BODY + ch_attach * kBodySlot + 16, t6); ld4(BODY + ch_attach * kBodySlot + 20, t6 + 4);
-          RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = t6[2 + i];
+    // joints, level by level from the base: a body takes its parent's delta-velocity from LDS (the A slot of the parent's
+    // BODY entry, free since the down pass), resolves its own joint and leaves its own for its children
+    for (int lv = 1; lv < depth; ++lv) {
+      if (mylev == lv) {
+        float t6[8], ap[6];
+        ld4(BODY + mypar * kBodySlot + 16, t6); ld4(BODY + mypar * kBodySlot + 20, t6 + 4);
+        RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] = (mypar == 0) ? a0[i] : t6[2 + i];   // the base's is in registers on every lane
+        const float xk = brsD * WB[bb + 5] - dot6(bUD, ap);   // WB = W_b plus the contact contributions scattered by the contact lanes
+        const float un = bqd + xk;
+        if (!dead) {
+          U[bb + 5] = un;
+          Q[bb + 6] = bqb + dt * un;
         }
-        // WB = W_b plus the contact contributions scattered by the contact lanes
-        float wacc[CL];
-        RSB_UNROLL for (int k = 0; k < CL; ++k) wacc[k] = (k < ch_len) ? WB[chb[k] + 5] : 0.f;
-        RSB_UNROLL for (int k = 0; k < CL; ++k) {
-          if (k < ch_len) {
-            const int b = chb[k];
-            const float xk = crsD[k] * wacc[k] - dot6(cUD[k], ap);
-            RSB_UNROLL for (int i = 0; i < 6; ++i) ap[i] += cS[k][i] * xk;
-            const float un = cqd[k] + xk;
-            if (!dead) {
-              U[b + 5] = un;
-              Q[b + 6] = cqb[k] + dt * un;
-            }
-            if (max_cc > 0) {
-              if ((CCT[b] >> 16) > 0) {
-                float* Ab = BODY + b * kBodySlot + 18;
-                RSB_UNROLL for (int i = 0; i < 6; ++i) Ab[i] = ap[i];
-              }
-            }
-          }
+        if ((mykid >> 16) > 0) {
+          float* Ab = BODY + bb * kBodySlot + 18;
+          RSB_UNROLL for (int i = 0; i < 6; ++i) Ab[i] = ap[i] + bS[i] * xk;
         }
       }
       __syncthreads();
     }
-    if (nclv == 0) __syncthreads();
     RSB_STAMP(7)
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps

@@ -12,7 +12,7 @@
 namespace rsbk {
 
 // the instance list, single source of truth for build.py (parsed there) and the dispatch in rsb_world.hip:
-// RSB_STEP_INSTANCES: 16,8,4,4 32,8,4,4 64,8,4,4 16,16,4,4 32,16,4,4 64,16,4,4 16,16,8,12 32,16,8,12 64,16,8,12 64,16,16,16
+// RSB_STEP_INSTANCES: 16,8,0,4 32,8,0,4 64,8,0,4 16,16,0,4 32,16,0,4 64,16,0,4 16,16,0,12 32,16,0,12 64,16,0,12 16,16,0,16 32,16,0,16 64,16,0,16
 
 // sets the dynamic-LDS attribute and launches `blocks` workgroups of one wavefront on `stream`
 template <int LPE, int KMAX, int CL, int ML, bool PROF>

@@ -12,9 +12,8 @@ namespace rsbk {
 
 constexpr int kMaxB = RSB_MAX_BODIES;
 constexpr int kMaxC = RSB_MAX_COLLISIONS;
-constexpr int kMaxCL = 16;       // longest supported chain
 constexpr int kBodySlot = 24;    // R9 r3 V6 A6 (A is reused for the delta-velocity of the final pass)
-constexpr int kUpSlot = 28;      // Ia21 Zc6 pad   (one per chain)
+constexpr int kUpSlot = 28;      // Ia21 Zc6 pad   (one per body)
 constexpr int kFactSlot = 16;    // S6 UD6 rsD invD pad2
 constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
 constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevModel::bodyf)
@@ -23,15 +22,14 @@ constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
 constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
+constexpr int kLightDepth = 3;        // == ORC_LIGHT_DEPTH
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
-  int nch, nclv, max_cl, max_cc;    // chains, chain levels, longest chain, max child chains of one body
+  int max_kid, reserved[3];         // most children of one MOVING body (the base's children are counted in kid_count[0])
   int parent[kMaxB], level[kMaxB], jtype[kMaxB];
   int anc[kMaxB * kMaxB];           // anc[b*depth + l] = ancestor of b at level l (l <= level[b]), else -1
-  // chains: ch_body[c*kMaxCL + k] = k-th body of chain c (root-most first)
-  int ch_len[kMaxB], ch_attach[kMaxB], ch_level[kMaxB], ch_body[kMaxB * kMaxCL];
-  int cc_start[kMaxB], cc_count[kMaxB], cc_list[kMaxB];  // chains hanging off each body
+  int kid_start[kMaxB], kid_count[kMaxB], kid_list[kMaxB];  // children of each body: kid_list[kid_start[b] .. + kid_count[b]); the base's lead the list
   // bodyf[b]: 0-2 axis, 3 jtype (int bits), 4-6 ptree, 7 mass, 8-16 rtree, 17-19 com, 20-25 inertia,
   //           26 armature, 27 damping, 28 effort, 29 q_lower, 30 q_upper
   float bodyf[kMaxB][kModelSlot];
@@ -44,9 +42,9 @@ struct DevModel {
 
 struct LdsLayout {
   // per-block tables (floats from the start of LDS)
-  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_cc, t_ccl, shared_total;
+  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_kids, shared_total;
   // per-env arrays (floats from the env base)
-  int q, u, pt, dtg, tf, body, ups, bacc, fact, wb, con, wc, cv, g, ginv, lam, warm;
+  int q, u, pt, dtg, tf, body, fact, wb, con, wc, cv, g, ginv, lam, warm;   // (the up pass's hand-over slots alias g)
   int gstride;
   int per_env;
 };
