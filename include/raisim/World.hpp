@@ -32,6 +32,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "raisim/Fiber.hpp"
@@ -92,6 +93,16 @@ class BatchedWorld {
   void setGravity(const Vec<3>& g) { RSB_CHECK(rsb_set_gravity(world_, g.data())); }
   void setERP(double erp, double = 0) { RSB_CHECK(rsb_set_erp(world_, erp)); }
   void setDefaultMaterial(double friction, double restitution = 0, double resThreshold = 0) { RSB_CHECK(rsb_set_material(world_, friction, restitution, resThreshold)); }
+  /// World::setMaterialPairProp [RECALL; upstream Materials.hpp absent]: (mu, restitution, resThreshold) of the material pair,
+  /// order-free.  The terrain is the only other object of an env, so the pair table is resolved into one triple per collision
+  /// primitive of the robot: (primitive's URDF material, terrain's material) -> rsb_set_collision_materials.
+  void setMaterialPairProp(const std::string& m1, const std::string& m2, double friction, double restitution, double resThreshold) {
+    RSFATAL_IF(friction < 0 || restitution < 0 || restitution > 1 || resThreshold < 0, "setMaterialPairProp: friction >= 0, 0 <= restitution <= 1, resThreshold >= 0");
+    pairProps_[pairKey(m1, m2)] = {friction, restitution, resThreshold};
+    resolveMaterials();
+  }
+  /// material of the terrain (addGround / addHeightMap's material argument)
+  void setTerrainMaterial(const std::string& material) { terrainMaterial_ = material; resolveMaterials(); }
   void setContactSolverParam(double alpha_init, double alpha_min, double alpha_decay, int maxIter, double threshold) {
     RSB_CHECK(rsb_set_contact_solver_param(world_, alpha_init, alpha_min, alpha_decay, maxIter, threshold));
   }
@@ -227,6 +238,20 @@ class BatchedWorld {
     n_ = numEnvs;
     pending_.assign(n_, 0); gcMask_.assign(n_, 0); gvMask_.assign(n_, 0);
   }
+  struct PairProp { double mu, restitution, resThreshold; };
+  static std::string pairKey(const std::string& a, const std::string& b) { return a < b ? a + "\n" + b : b + "\n" + a; }
+  void resolveMaterials() {
+    const int nc = blob_.ncol;
+    std::vector<double> mu(nc, -1.0), e(nc, -1.0), thr(nc, -1.0);   // negative = the world's default material
+    for (int i = 0; i < nc; ++i) {
+      const char* cm = rsb_model_collision_material(model_, i);
+      auto it = pairProps_.find(pairKey(cm ? cm : "default", terrainMaterial_));
+      if (it != pairProps_.end()) { mu[i] = it->second.mu; e[i] = it->second.restitution; thr[i] = it->second.resThreshold; }
+    }
+    RSB_CHECK(rsb_set_collision_materials(world_, mu.data(), e.data(), thr.data()));
+  }
+  std::map<std::string, PairProp> pairProps_;
+  std::string terrainMaterial_ = "default";
   rsb_model* model_ = nullptr;
   rsb_world* world_ = nullptr;
   rsb_model_blob blob_;
@@ -535,15 +560,16 @@ class World {
     robot_ = std::make_unique<ArticulatedSystem>(shared_, env_);
     return robot_.get();
   }
-  Ground* addGround(double zHeight = 0.0, const std::string& /*material*/ = "default") {
-    groundZ_ = zHeight; hasGround_ = true;
-    if (shared_) shared_->addGround(zHeight);
+  Ground* addGround(double zHeight = 0.0, const std::string& material = "default") {
+    groundZ_ = zHeight; hasGround_ = true; terrainMaterial_ = material;
+    if (shared_) { shared_->addGround(zHeight); shared_->setTerrainMaterial(material); }
     return &ground_;
   }
   HeightMap* addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
-                          const std::vector<double>& height, const std::string& /*material*/ = "default") {
+                          const std::vector<double>& height, const std::string& material = "default") {
     RSFATAL_IF(!shared_, "addHeightMap: add the ArticulatedSystem first");
     shared_->addHeightMap(xSamples, ySamples, xSize, ySize, centerX, centerY, height);
+    terrainMaterial_ = material; shared_->setTerrainMaterial(material);
     hm_ = std::make_unique<HeightMap>(shared_, xSamples, ySamples, xSize, ySize, centerX, centerY, height);
     return hm_.get();
   }
@@ -579,11 +605,9 @@ class World {
   void setGravity(const Vec<3>& g) { need().setGravity(g); }
   void setERP(double erp, double erp2 = 0) { need().setERP(erp, erp2); }
   void setDefaultMaterial(double mu, double r = 0, double t = 0) { need().setDefaultMaterial(mu, r, t); }
-  /// one material per world: a pair property is accepted only for the ("default", "default") pair
-  void setMaterialPairProp(const std::string& m1, const std::string& m2, double mu, double r, double t) {
-    RSFATAL_IF(m1 != "default" || m2 != "default", "setMaterialPairProp: per-pair materials are not supported (one material per world)");
-    need().setDefaultMaterial(mu, r, t);
-  }
+  /// friction / restitution of a material pair; materials are named by <collision><material name=../> in the URDF and by the
+  /// material argument of addGround / addHeightMap (in a batch every replica shares the table, like every other world parameter)
+  void setMaterialPairProp(const std::string& m1, const std::string& m2, double mu, double r, double t) { need().setMaterialPairProp(m1, m2, mu, r, t); }
   void setContactSolverParam(double a0, double amin, double adec, int maxIter, double thr) { need().setContactSolverParam(a0, amin, adec, maxIter, thr); }
   /// advances THIS replica by one time step; launched together with the other replicas' pending integrate() calls
   void integrate() { need().integrateView(env_); }
@@ -593,7 +617,8 @@ class World {
 
  private:
   BatchedWorld& need() { RSFATAL_IF(!shared_, "World: add the ArticulatedSystem before configuring the solver"); return *shared_; }
-  void applyPending() { if (dt_ > 0) shared_->setTimeStep(dt_); if (hasGround_) shared_->addGround(groundZ_); }
+  void applyPending() { if (dt_ > 0) shared_->setTimeStep(dt_); if (hasGround_) { shared_->addGround(groundZ_); shared_->setTerrainMaterial(terrainMaterial_); } }
+  std::string terrainMaterial_ = "default";
   std::shared_ptr<BatchedWorld> keep_;     // owned 1-replica world, or a share of the BatchScope's world
   BatchedWorld* shared_ = nullptr;
   BatchScope* scope_ = nullptr;

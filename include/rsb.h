@@ -106,6 +106,7 @@ typedef struct rsb_model_blob {
   char body_name[RSB_MAX_BODIES][RSB_NAME_LEN];   /* URDF link name of each moving body  */
   char joint_name[RSB_MAX_BODIES][RSB_NAME_LEN];  /* URDF joint name (index 0: "base")   */
   char col_name[RSB_MAX_COLLISIONS][RSB_NAME_LEN];
+  char col_material[RSB_MAX_COLLISIONS][RSB_NAME_LEN];  /* <collision><material name=".."/> of the URDF, "default" if absent */
 } rsb_model_blob;
 
 /* One solved contact, as raisim::Contact exposes it (position/normal/impulse/body index). */
@@ -139,6 +140,7 @@ int rsb_model_get_blob(const rsb_model* m, rsb_model_blob* out);
 int rsb_model_body_index(const rsb_model* m, const char* link_name);   /* <0 if absent */
 int rsb_model_joint_index(const rsb_model* m, const char* joint_name); /* body index driven by joint */
 double rsb_model_total_mass(const rsb_model* m);
+const char* rsb_model_collision_material(const rsb_model* m, int collision);   /* material name of a collision primitive ("default" if the URDF names none) */
 
 /* ---- world ------------------------------------------------------------------------------ */
 int rsb_device_count(void);
@@ -160,6 +162,12 @@ int rsb_set_friction(rsb_world* w, double mu);
 /* World::setDefaultMaterial(friction, restitution, resThreshold) [RECALL]: one material per world; a contact approaching
  * faster than res_threshold (m/s) leaves with v_n+ = -restitution * v_n- (Newton restitution), slower ones are inelastic */
 int rsb_set_material(rsb_world* w, double mu, double restitution, double res_threshold);
+/* World::setMaterialPairProp(material1, material2, friction, restitution, resThreshold) [RECALL; upstream Materials.hpp is
+ * absent from /root/reference]: every env holds ONE terrain object, so the pair table collapses to one (mu, restitution,
+ * res_threshold) triple per collision primitive of the robot = the pair (primitive's material, terrain's material).
+ * Arrays of rsb_dims().ncol doubles; a NULL array (or a negative entry) means "the world's default" (rsb_set_material).
+ * The C++ facade resolves material NAMES (rsb_model_collision_material, addGround(z, material)) into these arrays. */
+int rsb_set_collision_materials(rsb_world* w, const double* mu, const double* restitution, const double* res_threshold);
 int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min,
                                  double alpha_decay, int max_iter, double threshold);
 /* Stagnation exit of the contact solver (not a RaiSim parameter): the Gauss-Seidel loop of an env stops when the

@@ -28,6 +28,7 @@ class Params(C.Structure):
         ("settle_tol", C.c_double),
         ("hm_xsize", C.c_double), ("hm_ysize", C.c_double), ("hm_cx", C.c_double), ("hm_cy", C.c_double),
         ("hm_heights", C.c_void_p),
+        ("col_mu", C.c_void_p), ("col_restitution", C.c_void_p), ("col_res_threshold", C.c_void_p),
     ]
 
 
@@ -83,6 +84,11 @@ class Oracle:
         self.p.hm_xs, self.p.hm_ys = xs, ys
         self.p.hm_xsize, self.p.hm_ysize, self.p.hm_cx, self.p.hm_cy = xsize, ysize, cx, cy
         self.p.hm_heights = self._hm.ctypes.data
+
+    def set_collision_materials(self, mu=None, restitution=None, res_threshold=None):
+        """Per collision primitive contact material against the terrain ([ncol] arrays; None = the scalar default)."""
+        self._cm = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (mu, restitution, res_threshold)]
+        self.p.col_mu, self.p.col_restitution, self.p.col_res_threshold = (None if a is None else a.ctypes.data for a in self._cm)
 
     def set_ground(self, z):
         self.p.terrain_type = 0

@@ -843,10 +843,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         cfree[i][r] = s;
       }
       cfree[i][2] -= p->erp * cdepth[i] / p->dt;
-      if (p->restitution > 0.0 && lim_sign[i] == 0.0) {   /* Newton restitution on the approach speed J u of this step */
+      const double e_i = (i < nreal && p->col_restitution) ? p->col_restitution[ccol[i]] : p->restitution;
+      const double thr_i = (i < nreal && p->col_res_threshold) ? p->col_res_threshold[ccol[i]] : p->res_threshold;
+      if (e_i > 0.0 && lim_sign[i] == 0.0) {   /* Newton restitution on the approach speed J u of this step */
         double vn0 = 0;
         for (int d = 0; d < nv; ++d) vn0 += Jc[i][2][d] * u[d];
-        if (vn0 < -p->res_threshold) cfree[i][2] += p->restitution * vn0;
+        if (vn0 < -thr_i) cfree[i][2] += e_i * vn0;
       }
       /* warm start: the impulse (contact frame) this collision primitive carried in the previous integrate() */
       for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
@@ -866,6 +868,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
      * sweep cycle or crawl; the iteration is cut when the best relative error of the last `stall_window`
      * sweeps is not below `stall_factor` x the best of the window before.  Such solves would otherwise run to
      * max_iter without converging; on a lock-step GPU launch that worst case sets the launch time. */
+    double cmu[MAXK];   /* friction coefficient of each contact = its collision primitive's material against the terrain */
+    for (int i = 0; i < nc; ++i) cmu[i] = (i < nreal && p->col_mu) ? p->col_mu[ccol[i]] : p->mu;
     double alpha = p->alpha_init, best_prev = 1e300, best_cur = 1e300;
     double sdir[MAXK][3], lam_best[MAXK][3], best_rel = 1e300;
     for (int i = 0; i < nc; ++i) {
@@ -915,8 +919,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
               if (j == i) continue;
               for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam0[j][0] + G[i][j][3 * r + 1] * lam0[j][1] + G[i][j][3 * r + 2] * lam0[j][2];
             }
-            if (light && kpos > 0) solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds, 1, 0, 0.0, sdir[i], ln);
-            else solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds, lag, p->refine, 0.0, sdir[i], ln);
+            if (light && kpos > 0) solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, 1, 0, 0.0, sdir[i], ln);
+            else solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], ln);
             if (gpos[i] != kpos) continue;   /* light variant, pass 0: a later member only refreshed its direction */
             for (int r = 0; r < 3; ++r) {
               double dl = alpha * (ln[r] - lam0[i][r]);
@@ -941,7 +945,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
             if (j == i) continue;
             for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam0[j][0] + G[i][j][3 * r + 1] * lam0[j][1] + G[i][j][3 * r + 2] * lam0[j][2];
           }
-          solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds, lag, p->refine, 0.0, sdir[i], tmp);
+          solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], tmp);
         }
         /* an inherited direction that the first refresh did not pick up is dropped: a contact that starts to slip later in
          * the solve runs the global search (the device checks inherited directions against the coarse scan in the first
@@ -956,7 +960,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         }
         /* per-sweep mode: the pass keeps every usable direction (frozen formula); a contact without one - it started to slip
          * inside this sweep, or its direction is inherited / ill conditioned - runs the global search right here (no Newton) */
-        solve_one_contact(G[i][i], Ginv[i], v, p->mu, p->section_rounds,
+        solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds,
                           p->dir_per_sweep ? 1 : lag, p->dir_per_sweep ? 0 : p->refine, p->dir_per_sweep ? 0.0 : p->settle_tol, sdir[i], ln);
         for (int r = 0; r < 3; ++r) {
           double dl = alpha * (ln[r] - lam[i][r]);

@@ -52,6 +52,10 @@ typedef struct orc_params {
   double settle_tol;         /* a refined friction direction that moved less than this (rad) is kept for the rest of the solve */
   double hm_xsize, hm_ysize, hm_cx, hm_cy;
   const float* hm_heights;   /* [ys][xs], x fastest */
+  /* per collision primitive contact material against the terrain (material pairs; NULL = the scalars above for every primitive) */
+  const double* col_mu;
+  const double* col_restitution;
+  const double* col_res_threshold;
 } orc_params;
 
 typedef struct orc_contact {

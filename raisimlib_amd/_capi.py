@@ -31,7 +31,7 @@ class ModelBlob(C.Structure):
         ("q_lower", C.c_double * _B), ("q_upper", C.c_double * _B), ("effort", C.c_double * _B),
         ("col_body", C.c_int32 * _S), ("col_pos", (C.c_double * 3) * _S), ("col_radius", C.c_double * _S),
         ("body_name", (C.c_char * RSB_NAME_LEN) * _B), ("joint_name", (C.c_char * RSB_NAME_LEN) * _B),
-        ("col_name", (C.c_char * RSB_NAME_LEN) * _S),
+        ("col_name", (C.c_char * RSB_NAME_LEN) * _S), ("col_material", (C.c_char * RSB_NAME_LEN) * _S),
     ]
 
 
@@ -70,6 +70,7 @@ PROTOTYPES = {
     "rsb_model_body_index": (_I, [_VP, _CP]),
     "rsb_model_joint_index": (_I, [_VP, _CP]),
     "rsb_model_total_mass": (_D, [_VP]),
+    "rsb_model_collision_material": (C.c_char_p, [_VP, _I]),
     "rsb_device_count": (_I, []),
     "rsb_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
     "rsb_destroy": (_I, [_VP]),
@@ -85,6 +86,7 @@ PROTOTYPES = {
     "rsb_set_erp": (_I, [_VP, _D]),
     "rsb_set_friction": (_I, [_VP, _D]),
     "rsb_set_material": (_I, [_VP, _D, _D, _D]),
+    "rsb_set_collision_materials": (_I, [_VP, _VP, _VP, _VP]),
     "rsb_set_contact_solver_param": (_I, [_VP, _D, _D, _D, _I, _D]),
     "rsb_set_solver_stagnation_exit": (_I, [_VP, _I, _D]),
     "rsb_set_solver_friction_lag": (_I, [_VP, _I, _I, _D]),

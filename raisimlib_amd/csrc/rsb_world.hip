@@ -48,6 +48,9 @@ struct rsb_world {
   float *d_M = nullptr, *d_h = nullptr, *d_Minv = nullptr, *d_Mwork = nullptr;
   int32_t* d_obs_idx = nullptr;
   int32_t* d_hm_index = nullptr;   // [N] height map of each env (rsb_set_heightmaps), NULL: all envs share map 0
+  float* d_colmat = nullptr;          // [ncol][4] mu, restitution, res_threshold, pad per collision primitive (rsb_set_collision_materials)
+  std::vector<double> col_mu, col_rest, col_rthr;   // per-primitive overrides, < 0 = the world's default
+  bool colmat_dirty = true;
   float* d_warm = nullptr;   // [N, 6*ncol] contact-solver warm state (impulse, friction direction per collision primitive)
   bool warm_start = true;
   uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
@@ -370,6 +373,18 @@ int do_integrate(rsb_world* w, int nsub) {
   a.heights = w->d_heights;
   a.hm_index = w->d_hm_index;
   a.warm = w->warm_start ? w->d_warm : nullptr;
+  if (w->colmat_dirty) {   // per-primitive contact material: the override where one is set, else the world's default
+    std::vector<float> cm(4 * (size_t)RSB_MAX_COLLISIONS, 0.f);
+    for (int i = 0; i < w->blob.ncol; ++i) {
+      cm[4 * i] = (float)(w->col_mu[i] >= 0 ? w->col_mu[i] : w->mu);
+      cm[4 * i + 1] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);
+      cm[4 * i + 2] = (float)(w->col_rthr[i] >= 0 ? w->col_rthr[i] : w->res_threshold);
+    }
+    HIP_TRY(hipMemcpyAsync(w->d_colmat, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));   // cm is a stack-lifetime buffer
+    w->colmat_dirty = false;
+  }
+  a.colmat = w->d_colmat;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
   if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; a.tau2_out = w->d_env_tau2; }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
@@ -486,6 +501,8 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   HIP_TRY(hipMalloc(&w->d_flags, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_iters, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_obs_idx, RSB_MAX_COLLISIONS * sizeof(int32_t)));
+  HIP_TRY(hipMalloc(&w->d_colmat, 4 * (size_t)RSB_MAX_COLLISIONS * sizeof(float)));
+  w->col_mu.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rest.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rthr.assign(RSB_MAX_COLLISIONS, -1.0);
   HIP_TRY(hipMalloc(&w->d_warm, N * 6 * (size_t)(w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float)));
   HIP_TRY(hipMemset(w->d_warm, 0, N * 6 * (size_t)(w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float)));
   HIP_TRY(hipMemset(w->d_gc, 0, N * nq * sizeof(float)));
@@ -515,7 +532,7 @@ int rsb_destroy(rsb_world* w) {
   (void)rsb_comm_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_colmat, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -571,11 +588,26 @@ int rsb_set_erp(rsb_world* w, double erp) { if (!w) return RSB_E_INVALID; w->erp
 int rsb_set_friction(rsb_world* w, double mu) {
   if (!w || mu < 0) { rsb::set_error("rsb_set_friction: mu must be >= 0"); return RSB_E_INVALID; }
   w->mu = mu;
+  w->colmat_dirty = true;
   return RSB_OK;
 }
 int rsb_set_material(rsb_world* w, double mu, double restitution, double res_threshold) {
   if (!w || mu < 0 || restitution < 0 || restitution > 1 || res_threshold < 0) { rsb::set_error("rsb_set_material: mu >= 0, 0 <= restitution <= 1, res_threshold >= 0"); return RSB_E_INVALID; }
   w->mu = mu; w->restitution = restitution; w->res_threshold = res_threshold;
+  w->colmat_dirty = true;
+  return RSB_OK;
+}
+int rsb_set_collision_materials(rsb_world* w, const double* mu, const double* restitution, const double* res_threshold) {
+  if (!w) { rsb::set_error("rsb_set_collision_materials: null world"); return RSB_E_INVALID; }
+  for (int i = 0; i < w->blob.ncol; ++i) {
+    if (restitution && restitution[i] > 1.0) { rsb::set_error("rsb_set_collision_materials: restitution <= 1"); return RSB_E_INVALID; }
+  }
+  for (int i = 0; i < w->blob.ncol; ++i) {
+    w->col_mu[i] = mu ? mu[i] : -1.0;
+    w->col_rest[i] = restitution ? restitution[i] : -1.0;
+    w->col_rthr[i] = res_threshold ? res_threshold[i] : -1.0;
+  }
+  w->colmat_dirty = true;
   return RSB_OK;
 }
 int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min, double alpha_decay,

@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   int* PARLV = reinterpret_cast<int*>(lds + L.t_parlv);          // [nb] (parent+1) | level << 8
   int* ANC = reinterpret_cast<int*>(lds + L.t_anc);              // [nb*depth]
   float* DIR16 = lds + L.t_dir;                                  // float4 [16] slip-search brackets
-  float* COLT = lds + L.t_col;                                   // [ncol][8] sphere centre (body frame), radius, body, pad
+  float* COLT = lds + L.t_col;                                   // [ncol][8] sphere centre (body frame), radius, body, mu, restitution, res_threshold
   int* KIDS = reinterpret_cast<int*>(lds + L.t_kids);            // [nb] child bodies, grouped by parent (DevModel::kid_start / kid_count)
   float* E = lds + L.shared_total + el * L.per_env;
   float* Q = E + L.q;
@@ -436,7 +436,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   for (int i = lane; i < nb * depth; i += 64) ANC[i] = m.anc[i];
   for (int i = lane; i < nb; i += 64) KIDS[i] = m.kid_list[i];
   for (int i = lane; i < ncol; i += 64) {
-    float ct[8] = {m.col_pos[i][0], m.col_pos[i][1], m.col_pos[i][2], m.col_pos[i][3], __int_as_float(m.col_body[i]), 0.f, 0.f, 0.f};
+    float ct[8] = {m.col_pos[i][0], m.col_pos[i][1], m.col_pos[i][2], m.col_pos[i][3], __int_as_float(m.col_body[i]),
+                   a.colmat[4 * i], a.colmat[4 * i + 1], a.colmat[4 * i + 2]};   // + the primitive's contact material: mu, restitution, res_threshold
     stv<2>(COLT + 8 * i, ct);
   }
   if (lane < 16) {  // BR16[k] = {cos,sin((k-1) pi/8), cos,sin((k+1) pi/8)}: slip-search bracket around grid point k
@@ -774,7 +775,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     float wlam[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // base part of sum_c W_c lam_c (left by the solver on the lanes of the env's first row)
     if (ncw > 0) {
       RSB_ARGS(aw);
-      const float restitution = aw.restitution, res_threshold = aw.res_threshold, erp = aw.erp;
+      const float erp = aw.erp;
       // ========================= contact columns (lane = column): W_c = D^-1/2 L^-T J_c^T =======
       for (int c0 = 0; c0 < 3 * ncw; c0 += LPE) {
         const int c = c0 + s;
@@ -806,6 +807,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           cross3(Vb, x, wxx);  // J u = t . (v_body + w_body x x)
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
           // Newton restitution (oracle: "restitution"): the approach speed J u of this step re-enters the normal row
+          const int cprim = min(__float_as_int(CN[11]), ncol - 1);   // (joint-limit rows carry ids >= ncol and no restitution)
+          const float restitution = COLT[8 * cprim + 6], res_threshold = COLT[8 * cprim + 7];
           const float rest = (rr == 2 && lsgn == 0.f && restitution > 0.f && cv < -res_threshold) ? restitution * cv : 0.f;
           const bool limit_row = lsgn != 0.f;
           const bool empty_row = limit_row && rr < 2;
@@ -942,7 +945,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
         // the solver's parameters, read here so that they occupy SGPRs during the solve only
         RSB_ARGS(ag);
-        const float mu = ag.mu, mu2 = mu * mu;
+        // the own contact's friction coefficient: that of its collision primitive against the terrain (material pairs)
+        const int mycol = isc ? __float_as_int(CON[s * kConSlot + 11]) : 0;
+        const float mu = (isc && mycol < ncol) ? COLT[8 * mycol + 5] : ag.mu, mu2 = mu * mu;
         const float alpha_init = ag.alpha_init, alpha_min = ag.alpha_min, alpha_decay = ag.alpha_decay, threshold = ag.threshold;
         const float stall_factor = ag.stall_factor;
         const int max_iter = ag.max_iter, section_rounds = ag.section_rounds, stall_window = ag.stall_window;
@@ -1025,10 +1030,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
 
         // warm start (oracle: lam_warm): the impulse and friction direction this collision primitive had at the end of
         // the previous integrate(); the table is then cleared, contacts alive at the end of this solve re-enter it
-        int mycol = 0;
         if (has_warm) {
           if (isc) {
-            mycol = __float_as_int(CON[s * kConSlot + 11]);
             if (mycol < ncol) {   // joint-limit rows (ids >= ncol) start cold
               const float* wr = WARM + 6 * mycol;
               lam[0] = wr[0]; lam[1] = wr[1]; lam[2] = wr[2];
@@ -1048,13 +1051,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // global search of contact j's direction by its 16-lane row (coefficients broadcast from lane j)
         auto search_row = [&](int j, const SlipCoef& kc, bool take) {
           if (PROF && a.prof) ++p_search;
-          float c12[12] = {kc.a0, kc.a1, kc.a2, kc.n00, kc.n01, kc.n02, kc.n10, kc.n11, kc.n12, kc.vn, kc.ls0, kc.ls1};
-          row_bcast_dyn_n<KMAX, 12>(c12, j);
+          float c12[13] = {kc.a0, kc.a1, kc.a2, kc.n00, kc.n01, kc.n02, kc.n10, kc.n11, kc.n12, kc.vn, kc.ls0, kc.ls1, mu};
+          row_bcast_dyn_n<KMAX, 13>(c12, j);
           SlipCoef kb;
           kb.a0 = c12[0]; kb.a1 = c12[1]; kb.a2 = c12[2]; kb.n00 = c12[3]; kb.n01 = c12[4]; kb.n02 = c12[5];
           kb.n10 = c12[6]; kb.n11 = c12[7]; kb.n12 = c12[8]; kb.vn = c12[9]; kb.ls0 = c12[10]; kb.ls1 = c12[11];
           float dxy[2];
-          slip_search<LPE>(kb, mu, section_rounds, s, el, c16, s16, DIR16, dxy);
+          slip_search<LPE>(kb, c12[12], section_rounds, s, el, c16, s16, DIR16, dxy);
           if (take) { sdx = dxy[0]; sdy = dxy[1]; sdst = 1; }
         };
 

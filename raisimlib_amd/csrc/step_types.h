@@ -58,6 +58,7 @@ struct StepArgs {
   const float* tauff;
   const float* kp;
   const float* kd;
+  const float* colmat;         // [ncol][4] contact material of each collision primitive against the terrain: mu, restitution, res_threshold, pad
   rsb_contact* contacts;  // [N, kmax]
   int32_t* contact_count;
   int32_t* flags;

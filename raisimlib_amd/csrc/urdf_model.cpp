@@ -181,7 +181,7 @@ static Xf parse_origin(const XmlNode* n) {
 }
 
 // ------------------------------------------------------------------------------ URDF -> blob
-struct UCollision { Xf x; int type; double radius, length; double size[3]; std::string name; };  // type 0 sphere, 1 capsule, 2 box
+struct UCollision { Xf x; int type; double radius, length; double size[3]; std::string name, material; };  // type 0 sphere, 1 capsule, 2 box
 struct ULink {
   std::string name;
   double mass = 0;
@@ -240,6 +240,7 @@ struct Builder {
         if (c.type == 1) nm += (e == 0 ? "/top" : "/bottom");
         if (c.type == 2) nm += "/c" + std::to_string(e);
         std::snprintf(blob.col_name[s], RSB_NAME_LEN, "%s", nm.c_str());
+        std::snprintf(blob.col_material[s], RSB_NAME_LEN, "%s", c.material.empty() ? "default" : c.material.c_str());
       }
     }
   }
@@ -320,6 +321,7 @@ static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* ski
         UCollision col;
         col.x = parse_origin(c->child("origin"));
         if (const char* cn = c->get("name")) col.name = cn;
+        if (const XmlNode* mt = c->child("material")) { if (const char* mn = mt->get("name")) col.material = mn; }   // RaiSim reads the contact material from here [RECALL]
         if (const XmlNode* s = g->child("sphere")) {
           col.type = 0; col.radius = attr_double(s, "radius", 0.0); col.length = 0;
         } else if (const XmlNode* cp = g->child("capsule")) {
@@ -487,6 +489,11 @@ double rsb_model_total_mass(const rsb_model* m) {
   double s = 0;
   if (m) for (int i = 0; i < m->blob.nb; ++i) s += m->blob.mass[i];
   return s;
+}
+
+const char* rsb_model_collision_material(const rsb_model* m, int collision) {
+  if (!m || collision < 0 || collision >= m->blob.ncol) return nullptr;
+  return m->blob.col_material[collision][0] ? m->blob.col_material[collision] : "default";
 }
 
 }  // extern "C"

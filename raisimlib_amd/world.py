@@ -71,6 +71,10 @@ class Model:
     def collision_indices(self, suffix):
         return [i for i, n in enumerate(self.collision_names()) if n.endswith(suffix)]
 
+    def collision_materials(self):
+        """Material name of each collision primitive (<collision><material name=../> of the URDF, "default" if absent)."""
+        return [(self.blob.col_material[i].value.decode() or "default") for i in range(self.ncol)]
+
 
 def heightmap_from_png(path, height_scale=1.0, height_offset=0.0):
     """[y_samples, x_samples] float32 heights of a PNG (rsb_heightmap_png_*)."""
@@ -148,6 +152,16 @@ class BatchedWorld:
 
     def set_default_material(self, mu, restitution=0.0, res_threshold=0.0):
         check(self.L.rsb_set_material(self.handle, float(mu), float(restitution), float(res_threshold)), "rsb_set_material")
+
+    def set_collision_materials(self, mu=None, restitution=None, res_threshold=None):
+        """Per collision primitive contact material against the terrain (the resolved World::setMaterialPairProp table):
+        [ncol] arrays, None (or a negative entry) = the world's default material."""
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (mu, restitution, res_threshold)]
+        for a in arrs:
+            if a is not None and a.shape != (self.model.ncol,):
+                raise ValueError("set_collision_materials: arrays of ncol entries expected")
+        check(self.L.rsb_set_collision_materials(self.handle, *[None if a is None else a.ctypes.data for a in arrs]),
+              "rsb_set_collision_materials")
 
     def set_default_friction(self, mu):
         check(self.L.rsb_set_friction(self.handle, float(mu)), "rsb_set_friction")

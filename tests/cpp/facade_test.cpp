@@ -245,6 +245,38 @@ int main(int argc, char** argv) {
     CHECK(robot->getContacts().size() >= 2);
     CHECK(qh[2] - under > 0.25 && qh[2] - under < 0.75);
     std::printf("Perlin terrain: ground %.3f under the robot, base %.3f above it, %zu contacts\n", under, qh[2] - under, robot->getContacts().size());
+
+    // ---- material pairs: World::setMaterialPairProp(material of the primitive, material of the ground) resolves to one
+    //      friction coefficient per collision primitive; a sliding ball decelerates at the PAIR's mu * g
+    {
+      const char* ball = "<robot name=\"ball\"><link name=\"ball\"><inertial><origin xyz=\"0 0 0\"/><mass value=\"2\"/>"
+                         "<inertia ixx=\"0.008\" ixy=\"0\" ixz=\"0\" iyy=\"0.008\" iyz=\"0\" izz=\"0.008\"/></inertial>"
+                         "<collision><origin xyz=\"0 0 0\"/><geometry><sphere radius=\"0.1\"/></geometry><material name=\"rubber\"/></collision>"
+                         "</link></robot>";
+      const std::string path = "/tmp/rsb_facade_ball.urdf";
+      { FILE* f = std::fopen(path.c_str(), "w"); CHECK(f != nullptr); std::fputs(ball, f); std::fclose(f); }
+      for (int variant = 0; variant < 3; ++variant) {
+        raisim::World w;
+        w.setTimeStep(0.0025);
+        auto* b = w.addArticulatedSystem(path);
+        w.addGround(0.0, variant == 2 ? "ice" : "concrete");
+        w.setMaterialPairProp("concrete", "rubber", 1.1, 0.0, 0.0);     // order-free
+        w.setMaterialPairProp("rubber", "ice", 0.05, 0.0, 0.0);
+        if (variant == 1) w.setMaterialPairProp("rubber", "concrete", 0.4, 0.0, 0.0);   // overwrites the same pair
+        const double mu = variant == 0 ? 1.1 : (variant == 1 ? 0.4 : 0.05);
+        raisim::VecDyn q(7), u(6);
+        q[2] = 0.1 - 1e-5; q[3] = 1.0; u[0] = 3.0;
+        b->setState(q, u);
+        double prev = 3.0;
+        for (int i = 0; i < 5; ++i) {
+          w.integrate();
+          const double v = b->getGeneralizedVelocity()[0];
+          CHECK(std::fabs((v - prev) + mu * 9.81 * 0.0025) < 1e-5);
+          prev = v;
+        }
+      }
+      std::printf("material pairs: rubber on concrete / ice slide at their own mu\n");
+    }
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 1;

@@ -153,3 +153,30 @@ def test_restitution_bounces_the_ball(built_lib):
     q, u = w.get_state()
     assert bounced >= 3 and np.abs(u[:, 2]).max() < 2e-5 and np.abs(q[:, 2] - 0.1).max() < 2e-3
     w.close()
+
+
+def test_two_materials_on_one_body_decelerate_at_the_closed_form_rate(built_lib):
+    """rsb_set_collision_materials: per-primitive friction against the terrain (the resolved setMaterialPairProp table)."""
+    from test_oracle_kat import DUMBBELL, dumbbell_friction_force
+    m_, L, r, mu_f, mu_r = 4.0, 0.4, 0.1, 0.9, 0.2
+    _, w = world(DUMBBELL)
+    w.set_collision_materials(mu=np.array([mu_f, mu_r]))
+    w.set_state(tile([0, 0, r - 1e-6, 1, 0, 0, 0]), tile([2.0, 0, 0, 0, 0, 0]))
+    F = dumbbell_friction_force(m_, L, r, mu_f, mu_r)
+    w.integrate(20)
+    _, u = w.get_state(); prev = u[:, 0].copy()
+    for k in range(20):
+        w.integrate(1)
+        _, u = w.get_state(); cnt, con = w.get_contacts()
+        assert (cnt == 2).all()
+        assert np.allclose(u[:, 0] - prev, -F / m_ * DT, atol=2e-5), (k, (u[:, 0] - prev).mean(), -F / m_ * DT)
+        lam = np.array([[c[0]["impulse"], c[1]["impulse"]] for c in con])
+        assert np.allclose(np.hypot(lam[:, 0, 0], lam[:, 0, 1]), mu_f * lam[:, 0, 2], rtol=2e-5)
+        assert np.allclose(np.hypot(lam[:, 1, 0], lam[:, 1, 1]), mu_r * lam[:, 1, 2], rtol=2e-5)
+        prev = u[:, 0].copy()
+    # back to the world's default material: both spheres slide at the default mu
+    w.set_collision_materials()
+    w.set_state(tile([0, 0, r - 1e-6, 1, 0, 0, 0]), tile([2.0, 0, 0, 0, 0, 0]))
+    w.integrate(30); _, u0 = w.get_state(); w.integrate(1); _, u1 = w.get_state()
+    assert np.allclose(u1[:, 0] - u0[:, 0], -0.8 * G * DT, atol=2e-5)
+    w.close()

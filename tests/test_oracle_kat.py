@@ -219,3 +219,59 @@ def test_restitution_bounces_the_ball(built_lib):
         elif len(con) and uz <= 0:
             assert abs(u[2]) < 1e-9                      # slow touch-down: inelastic, the ball stays down
     assert bounced >= 3 and abs(u[2]) < 1e-9 and abs(q[2] - 0.1) < 1e-3
+
+
+# two spheres of DIFFERENT materials on one rigid body, sliding along the line that joins them (x): the friction below the
+# centre of mass pitches the body, which shifts load onto the leading sphere.  With N_f + N_r = m g and the pitch balance
+# (N_f - N_r) L = F r (no pitch acceleration while both touch), F = mu_f N_f + mu_r N_r has the closed form below.
+DUMBBELL = """<robot name="dumbbell"><link name="bar">
+ <inertial><origin xyz="0 0 0"/><mass value="4"/><inertia ixx="0.02" ixy="0" ixz="0" iyy="0.5" iyz="0" izz="0.5"/></inertial>
+ <collision name="front"><origin xyz="0.4 0 0"/><geometry><sphere radius="0.1"/></geometry><material name="rubber"/></collision>
+ <collision name="rear"><origin xyz="-0.4 0 0"/><geometry><sphere radius="0.1"/></geometry><material name="steel"/></collision>
+</link></robot>"""
+
+
+def dumbbell_friction_force(m_, L, r, mu_f, mu_r):
+    d = (mu_f + mu_r) * m_ * G * r / (4 * L) / (1 - (mu_f - mu_r) * r / (2 * L))
+    return mu_f * (m_ * G / 2 + d) + mu_r * (m_ * G / 2 - d)
+
+
+def test_material_names_are_read_from_the_urdf(built_lib):
+    m, _ = make(DUMBBELL)
+    assert m.collision_materials() == ["rubber", "steel"]
+    m2, _ = make(sphere_urdf())
+    assert m2.collision_materials() == ["default"]
+
+
+def test_two_materials_on_one_body_decelerate_at_the_closed_form_rate(built_lib):
+    """Per-primitive friction (World::setMaterialPairProp resolved against the terrain's material): each contact slides on its
+    own cone; the deceleration is the closed-form total friction / m."""
+    m_, L, r, mu_f, mu_r = 4.0, 0.4, 0.1, 0.9, 0.2
+    _, o = make(DUMBBELL)
+    o.set_collision_materials(mu=np.array([mu_f, mu_r]))
+    q = np.array([0, 0, r - 1e-6, 1, 0, 0, 0.0])
+    u = np.array([2.0, 0, 0, 0, 0, 0])
+    F = dumbbell_friction_force(m_, L, r, mu_f, mu_r)
+    for k in range(40):
+        q, u2, con, _, _ = o.step(q, u)
+        assert len(con) == 2
+        if k >= 20:      # the load transfer has settled (the pitch rate is zero again)
+            assert abs((u2[0] - u[0]) + F / m_ * DT) < 2e-6, (k, u2[0] - u[0], -F / m_ * DT)
+            lam = con["impulse"]
+            assert abs(np.hypot(lam[0][0], lam[0][1]) - mu_f * lam[0][2]) < 1e-9     # each contact on ITS cone
+            assert abs(np.hypot(lam[1][0], lam[1][1]) - mu_r * lam[1][2]) < 1e-9
+            assert lam[0][2] > lam[1][2]                                              # load moved to the leading sphere
+        u = u2
+
+
+def test_per_primitive_restitution(built_lib):
+    """One sphere with restitution 0.5 above a 0.1 m/s threshold bounces at half its impact speed; the default stays inelastic."""
+    _, o = make(sphere_urdf(2.0, 0.1))
+    o.set_collision_materials(restitution=np.array([0.5]), res_threshold=np.array([0.1]))
+    q = np.array([0, 0, 0.1 + 1e-4, 1, 0, 0, 0.0])
+    u = np.array([0, 0, -2.0, 0, 0, 0])
+    q, u1, con, _, _ = o.step(q, u)                    # still above the ground after this step? -> first contact next step
+    for _ in range(3):
+        if len(con): break
+        q, u1, con, _, _ = o.step(q, u1)
+    assert len(con) == 1 and abs(u1[2] - 0.5 * 2.0) < 0.03     # v+ = -e v- (gravity adds g dt per step on the way)
