@@ -470,6 +470,100 @@ void orc_terrain(const orc_params* p, double x, double y, double* h, double* n) 
   n[0] = -gxs * inv; n[1] = -gys * inv; n[2] = inv;
 }
 
+/* Closest point of the triangle (a, b, c) to the ORIGIN (the caller shifts the sphere centre there): the Voronoi-region
+ * walk of Ericson, "Real-Time Collision Detection" (2005), section 5.1.5 - vertex, edge and face regions. */
+static void closest_on_triangle(const double* a, const double* b, const double* c, double* out) {
+  double ab[3], ac[3], bc[3];
+  for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; bc[i] = c[i] - b[i]; }
+  const double d1 = -dot3(ab, a), d2 = -dot3(ac, a);
+  const double d3 = -dot3(ab, b), d4 = -dot3(ac, b);
+  const double d5 = -dot3(ab, c), d6 = -dot3(ac, c);
+  const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  double base[3] = {a[0], a[1], a[2]}, dir1[3] = {0, 0, 0}, dir2[3] = {0, 0, 0}, t1 = 0.0, t2 = 0.0;
+  if (d1 <= 0.0 && d2 <= 0.0) { /* vertex a */ }
+  else if (d3 >= 0.0 && d4 <= d3) { for (int i = 0; i < 3; ++i) base[i] = b[i]; }
+  else if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) { t1 = d1 / (d1 - d3); for (int i = 0; i < 3; ++i) dir1[i] = ab[i]; }
+  else if (d6 >= 0.0 && d5 <= d6) { for (int i = 0; i < 3; ++i) base[i] = c[i]; }
+  else if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { t1 = d2 / (d2 - d6); for (int i = 0; i < 3; ++i) dir1[i] = ac[i]; }
+  else if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
+    t1 = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    for (int i = 0; i < 3; ++i) { base[i] = b[i]; dir1[i] = bc[i]; }
+  } else {
+    const double den = 1.0 / (va + vb + vc);
+    t1 = vb * den; t2 = vc * den;
+    for (int i = 0; i < 3; ++i) { dir1[i] = ab[i]; dir2[i] = ac[i]; }
+  }
+  for (int i = 0; i < 3; ++i) out[i] = base[i] + t1 * dir1[i] + t2 * dir2[i];
+}
+
+/* Narrow phase sphere (centre c, world frame; radius r) x terrain: penetration depth and unit contact normal.
+ * Plane: depth = r - (c_z - z0), normal = z.  Height map: the CLOSEST FEATURE (face, edge or vertex) of the triangulated
+ * surface over the cells the sphere's xy bounding square overlaps (at most ORC_HM_CELLS x ORC_HM_CELLS of them, scanned
+ * row by row, the lower-right triangle of a cell first; the first of equally close features wins): normal = from the
+ * closest point to the centre, depth = r - distance.  A centre at or below the surface, or beyond the map's border, falls
+ * back to the plane of the triangle under it (see the end of the function).
+ * Upstream counterpart: the sphere x HeightMap collider of RaiSim's vendored ODE - absent from /root/reference. */
+#define ORC_HM_CELLS 3
+static int terrain_contact(const orc_params* p, const double* c, double r, double* depth, double* n) {
+  if (p->terrain_type == 0) {
+    n[0] = 0; n[1] = 0; n[2] = 1;
+    *depth = r - (c[2] - p->ground_z);
+    return *depth > 0.0;
+  }
+  const int xs = p->hm_xs, ys = p->hm_ys;
+  const double dx = p->hm_xsize / (xs - 1), dy = p->hm_ysize / (ys - 1);
+  const double x0 = p->hm_cx - 0.5 * p->hm_xsize, y0 = p->hm_cy - 0.5 * p->hm_ysize;
+  int ix0 = (int)floor((c[0] - r - x0) / dx), ix1 = (int)floor((c[0] + r - x0) / dx);
+  int iy0 = (int)floor((c[1] - r - y0) / dy), iy1 = (int)floor((c[1] + r - y0) / dy);
+  const int icx = (int)floor((c[0] - x0) / dx), icy = (int)floor((c[1] - y0) / dy);
+  if (ix1 - ix0 >= ORC_HM_CELLS) { ix0 = icx - ORC_HM_CELLS / 2; ix1 = ix0 + ORC_HM_CELLS - 1; }
+  if (iy1 - iy0 >= ORC_HM_CELLS) { iy0 = icy - ORC_HM_CELLS / 2; iy1 = iy0 + ORC_HM_CELLS - 1; }
+  if (ix0 < 0) ix0 = 0;
+  if (iy0 < 0) iy0 = 0;
+  if (ix1 > xs - 2) ix1 = xs - 2;
+  if (iy1 > ys - 2) iy1 = ys - 2;
+  if (ix0 > ix1) { ix0 = ix1 = ix0 > xs - 2 ? xs - 2 : 0; }     /* beyond the map's border: its outermost cells */
+  if (iy0 > iy1) { iy0 = iy1 = iy0 > ys - 2 ? ys - 2 : 0; }
+  double best = 1e300, bp[3] = {0, 0, 0}, bn[3] = {0, 0, 1};
+  for (int iy = iy0; iy <= iy1; ++iy)
+    for (int ix = ix0; ix <= ix1; ++ix) {
+      const float* H = p->hm_heights + iy * xs + ix;
+      const double ox = x0 + ix * dx - c[0], oy = y0 + iy * dy - c[1];
+      const double v00[3] = {ox, oy, H[0] - c[2]}, v10[3] = {ox + dx, oy, H[1] - c[2]};
+      const double v01[3] = {ox, oy + dy, H[xs] - c[2]}, v11[3] = {ox + dx, oy + dy, H[xs + 1] - c[2]};
+      for (int tri = 0; tri < 2; ++tri) {
+        const double* b = tri == 0 ? v10 : v11;
+        const double* cc = tri == 0 ? v11 : v01;
+        double q[3];
+        closest_on_triangle(v00, b, cc, q);
+        const double d2 = dot3(q, q);
+        /* equally close features (a point on an edge two triangles share) are ranked by the scan order, not by rounding noise:
+         * a later candidate must be closer by more than 4e-6 (relative, squared distance) to win - the device ranks its
+         * fp32 candidates the same way (5 mantissa bits of the squared distance carry the scan position) */
+        if (d2 < best * (1.0 - 4e-6)) {
+          best = d2;
+          double e1[3], e2[3];
+          for (int i = 0; i < 3; ++i) { bp[i] = q[i]; e1[i] = b[i] - v00[i]; e2[i] = cc[i] - v00[i]; }
+          cross3(e1, e2, bn);
+        }
+      }
+    }
+  const double dist = sqrt(best);
+  const int inside = c[0] >= x0 && c[0] <= x0 + p->hm_xsize && c[1] >= y0 && c[1] <= y0 + p->hm_ysize;
+  if (inside && -dot3(bp, bn) > 0.0 && dist > 1e-9) {
+    for (int i = 0; i < 3; ++i) n[i] = -bp[i] / dist;
+    *depth = r - dist;
+  } else {
+    /* the centre is at or below the surface (a zero-radius box corner, a sphere pushed in by more than its radius) or beyond
+     * the map's border (the terrain continues flat from its outermost samples): the triangle UNDER the centre decides -
+     * depth = r - distance to its plane, normal = its face normal */
+    double h;
+    orc_terrain(p, c[0], c[1], &h, n);
+    *depth = r - (c[2] - h) * n[2];
+  }
+  return *depth > 0.0;
+}
+
 /* --------------------------------------------------------------------------- actuation */
 /* PD controller, integrated implicitly ("stable PD", Tan, Liu, Turk 2011; RaiSim's controller is of this kind [RECALL]):
  * the torque the joint feels over the step is  kp (q* - q+) + kd (u* - u+)  with  q+ = q + dt u+.  Written for
@@ -759,13 +853,10 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   int cbody[MAXK], ccol[MAXK];
   for (int s = 0; s < m->ncol; ++s) {
     int b = m->col_body[s];
-    double t[3], c[3], hgt, n[3];
+    double t[3], c[3], cw[3], n[3], depth;
     mat3_vec(k->R[b], m->col_pos[s], t);
-    for (int a = 0; a < 3; ++a) c[a] = k->r[b][a] + t[a];
-    orc_terrain(p, k->pbase[0] + c[0], k->pbase[1] + c[1], &hgt, n);
-    double dist = (k->pbase[2] + c[2] - hgt) * n[2];
-    double depth = m->col_radius[s] - dist;
-    if (depth > 0.0) {
+    for (int a = 0; a < 3; ++a) { c[a] = k->r[b][a] + t[a]; cw[a] = k->pbase[a] + c[a]; }
+    if (terrain_contact(p, cw, m->col_radius[s], &depth, n)) {
       if (nc >= kmax) { fl |= 1; continue; }
       for (int a = 0; a < 3; ++a) { cx[nc][a] = c[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }
       cdepth[nc] = depth; cbody[nc] = b; ccol[nc] = s;

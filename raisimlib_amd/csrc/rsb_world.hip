@@ -73,6 +73,7 @@ struct rsb_world {
   int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 10, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
+  float hm_max = 0.f;
   double stall_factor = 0.5, settle_tol = 0.0, restitution = 0.0, res_threshold = 0.0;
   int lpe = 0;
   double world_time = 0;
@@ -406,6 +407,7 @@ int do_integrate(rsb_world* w, int nsub) {
     double dx = w->hm_xsize / (w->hm_xs - 1), dy = w->hm_ysize / (w->hm_ys - 1);
     a.hm_x0 = (float)(w->hm_cx - 0.5 * w->hm_xsize); a.hm_y0 = (float)(w->hm_cy - 0.5 * w->hm_ysize);
     a.hm_dx = (float)dx; a.hm_dy = (float)dy; a.hm_inv_dx = (float)(1.0 / dx); a.hm_inv_dy = (float)(1.0 / dy);
+    a.hm_max = w->hm_max;
   }
   a.L = make_layout(w->blob, kcap);
   const size_t lds_bytes = lds_bytes_for(w->blob, kcap, lpe);
@@ -678,6 +680,8 @@ int rsb_set_heightmaps(rsb_world* w, int n_maps, int xs, int ys, double x_size, 
     HIP_TRY(hipMemcpy(w->d_hm_index, env_map, (size_t)w->N * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   w->terrain_type = 1; w->hm_xs = xs; w->hm_ys = ys; w->hm_xsize = x_size; w->hm_ysize = y_size; w->hm_cx = cx; w->hm_cy = cy;
+  w->hm_max = heights[0];   // highest sample of all maps: the narrow phase skips every sphere whose lowest point lies above it
+  for (size_t i = 1; i < n; ++i) if (heights[i] > w->hm_max) w->hm_max = heights[i];
   return RSB_OK;
 }
 int rsb_set_heightmap(rsb_world* w, int xs, int ys, double x_size, double y_size, double cx, double cy, const float* heights) {

@@ -125,10 +125,76 @@ __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
   *cs = ((k + 1) & 2) ? -c0 : c0;
 }
 
-// terrain height and unit normal under (x, y): plane or triangulated height map (oracle: orc_terrain)
+// closest point of the triangle (a, b, c) to the origin (oracle: closest_on_triangle; Ericson 2005, 5.1.5), written as a
+// cascade of selects in the oracle's priority order: lanes of one wave sit in different Voronoi regions
+__device__ __forceinline__ void closest_on_triangle(const float* a, const float* b, const float* c, float* out) {
+  float ab[3], ac[3], bc[3];
+  RSB_UNROLL for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; bc[i] = c[i] - b[i]; }
+  const float d1 = -dot3(ab, a), d2 = -dot3(ac, a), d3 = -dot3(ab, b), d4 = -dot3(ac, b), d5 = -dot3(ab, c), d6 = -dot3(ac, c);
+  const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+  const bool ra = (d1 <= 0.f) & (d2 <= 0.f);
+  const bool rb = !ra & (d3 >= 0.f) & (d4 <= d3);
+  const bool rab = !ra & !rb & (vc <= 0.f) & (d1 >= 0.f) & (d3 <= 0.f);
+  const bool rc = !ra & !rb & !rab & (d6 >= 0.f) & (d5 <= d6);
+  const bool rac = !ra & !rb & !rab & !rc & (vb <= 0.f) & (d2 >= 0.f) & (d6 <= 0.f);
+  const bool rbc = !ra & !rb & !rab & !rc & !rac & (va <= 0.f) & ((d4 - d3) >= 0.f) & ((d5 - d6) >= 0.f);
+  const bool face = !ra & !rb & !rab & !rc & !rac & !rbc;
+  const float den = 1.0f / (va + vb + vc);
+  const float t1 = rab ? d1 / (d1 - d3) : (rac ? d2 / (d2 - d6) : (rbc ? (d4 - d3) / ((d4 - d3) + (d5 - d6)) : (face ? vb * den : 0.f)));
+  const float t2 = face ? vc * den : 0.f;
+  RSB_UNROLL for (int i = 0; i < 3; ++i) {
+    const float base = (rb | rbc) ? b[i] : (rc ? c[i] : a[i]);
+    const float dir1 = (rab | face) ? ab[i] : (rac ? ac[i] : (rbc ? bc[i] : 0.f));
+    const float dir2 = face ? ac[i] : 0.f;
+    out[i] = base + t1 * dir1 + t2 * dir2;
+  }
+}
+
+// narrow phase sphere x height map (oracle: terrain_contact): the closest feature (face / edge / vertex) of the triangulated
+// surface over the cells the sphere's xy bounding square overlaps, at most kHmCells x kHmCells of them, scanned row by row.
+// The work is spread over the lanes: hm_cell_range() on the sphere's own lane, hm_scan_cell() for ONE cell on the lanes of
+// the sphere's quad, hm_resolve() on the lane that found the closest feature.
+constexpr int kHmCells = 3;   // == ORC_HM_CELLS
+template <class Args>
+__device__ __forceinline__ void hm_cell_range(const Args& a, float x, float y, float r, int& ix0, int& iy0, int& nx, int& ny) {
+  const int xs = a.hm_xs, ys = a.hm_ys;
+  int ix1 = (int)floorf((x + r - a.hm_x0) * a.hm_inv_dx), iy1 = (int)floorf((y + r - a.hm_y0) * a.hm_inv_dy);
+  ix0 = (int)floorf((x - r - a.hm_x0) * a.hm_inv_dx); iy0 = (int)floorf((y - r - a.hm_y0) * a.hm_inv_dy);
+  const int icx = (int)floorf((x - a.hm_x0) * a.hm_inv_dx), icy = (int)floorf((y - a.hm_y0) * a.hm_inv_dy);
+  if (ix1 - ix0 >= kHmCells) { ix0 = icx - kHmCells / 2; ix1 = ix0 + kHmCells - 1; }
+  if (iy1 - iy0 >= kHmCells) { iy0 = icy - kHmCells / 2; iy1 = iy0 + kHmCells - 1; }
+  ix0 = max(ix0, 0); iy0 = max(iy0, 0); ix1 = min(ix1, xs - 2); iy1 = min(iy1, ys - 2);
+  if (ix0 > ix1) { ix0 = ix1 = ix0 > xs - 2 ? xs - 2 : 0; }   // beyond the map's border: its outermost cells
+  if (iy0 > iy1) { iy0 = iy1 = iy0 > ys - 2 ? ys - 2 : 0; }
+  nx = ix1 - ix0 + 1; ny = iy1 - iy0 + 1;
+}
+// the two triangles of cell (ix, iy) against the sphere centre (x, y, z): updates the lane's best candidate.  key = squared
+// distance with its 5 lowest mantissa bits replaced by the scan position `order` (2 * cell + triangle): candidates equally
+// close to within 2^-18 are ranked by the oracle's scan order
+template <class Args>
+__device__ __forceinline__ void hm_scan_cell(const Args& a, const float* heights, int ix, int iy, int order, float x, float y, float z,
+                                             unsigned& key, float* bp, float* bn) {
+  const float* H = heights + iy * a.hm_xs + ix;
+  const float ox = (a.hm_x0 + (float)ix * a.hm_dx) - x, oy = (a.hm_y0 + (float)iy * a.hm_dy) - y;
+  const float v00[3] = {ox, oy, H[0] - z}, v10[3] = {ox + a.hm_dx, oy, H[1] - z};
+  const float v01[3] = {ox, oy + a.hm_dy, H[a.hm_xs] - z}, v11[3] = {ox + a.hm_dx, oy + a.hm_dy, H[a.hm_xs + 1] - z};
+  RSB_UNROLL for (int tri = 0; tri < 2; ++tri) {
+    const float* b = tri == 0 ? v10 : v11;
+    const float* c = tri == 0 ? v11 : v01;
+    float q[3];
+    closest_on_triangle(v00, b, c, q);
+    const unsigned k = (__float_as_uint(dot3(q, q)) & ~31u) | (unsigned)(order + tri);
+    if (k < key) {
+      key = k;
+      float e1[3], e2[3];
+      RSB_UNROLL for (int i = 0; i < 3; ++i) { bp[i] = q[i]; e1[i] = b[i] - v00[i]; e2[i] = c[i] - v00[i]; }
+      cross3(e1, e2, bn);   // (not normalised yet)
+    }
+  }
+}
+// terrain height and unit normal of the triangle under (x, y), coordinates clamped to the map (oracle: orc_terrain)
 template <class Args>
 __device__ __forceinline__ void terrain_eval(const Args& a, const float* heights, float x, float y, float& h, float* n) {
-  if (a.terrain_type == 0) { h = a.ground_z; n[0] = 0.f; n[1] = 0.f; n[2] = 1.f; return; }
   float gx = (x - a.hm_x0) * a.hm_inv_dx, gy = (y - a.hm_y0) * a.hm_inv_dy;
   gx = fminf(fmaxf(gx, 0.f), (float)(a.hm_xs - 1));
   gy = fminf(fmaxf(gy, 0.f), (float)(a.hm_ys - 1));
@@ -142,6 +208,23 @@ __device__ __forceinline__ void terrain_eval(const Args& a, const float* heights
   float gxs = sx * a.hm_inv_dx, gys = sy * a.hm_inv_dy;
   float inv = 1.0f / sqrtf(gxs * gxs + gys * gys + 1.0f);
   n[0] = -gxs * inv; n[1] = -gys * inv; n[2] = inv;
+}
+// closest point bp (relative to the centre (x, y, z)) on a triangle with face normal bn -> penetration depth and unit contact
+// normal; a centre at / below the surface or beyond the map's border falls back to the plane of the triangle under it
+template <class Args>
+__device__ __forceinline__ void hm_resolve(const Args& a, const float* heights, const float* bp, const float* bn, float x, float y, float z, float r,
+                                           float& depth, float* n) {
+  const float dist = sqrtf(dot3(bp, bp));
+  const bool inside = (x >= a.hm_x0) & (x <= a.hm_x0 + a.hm_dx * (float)(a.hm_xs - 1)) & (y >= a.hm_y0) & (y <= a.hm_y0 + a.hm_dy * (float)(a.hm_ys - 1));
+  if (inside & (-dot3(bp, bn) > 0.f) & (dist > 1e-9f)) {
+    const float id = 1.0f / dist;
+    RSB_UNROLL for (int i = 0; i < 3; ++i) n[i] = -bp[i] * id;
+    depth = r - dist;
+  } else {
+    float h;
+    terrain_eval(a, heights, x, y, h, n);
+    depth = r - (z - h) * n[2];
+  }
 }
 
 // ---- slip case of one contact (oracle: slip_prepare / slip_E / slip_dE / solve_one_contact) ---------------
@@ -609,29 +692,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     // =========================== collision detection (lane = collision sphere) ================
     nc = 0;
     bool illegal = false;
-    for (int c0 = 0; c0 < ncol; c0 += LPE) {
-      const int ci = c0 + s;
-      bool hit = false;
-      float cx[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 1.f}, dep = 0.f;
-      int cbody = 0;
-      if (ci < ncol) {
-        float ct[8];
-        ld4(COLT + 8 * ci, ct); ct[4] = COLT[8 * ci + 4];
-        cbody = __float_as_int(ct[4]);
-        const float px = ct[0], py = ct[1], pz = ct[2], rad = ct[3];
-        float P[12];
-        ldv<3>(BODY + cbody * kBodySlot, P);
-        const float pl[3] = {px, py, pz};
-        float t[3], h;
-        mat3_vec(P, pl, t);
-        const float c[3] = {P[9] + t[0], P[10] + t[1], P[11] + t[2]};
-        terrain_eval(ac, env_heights, pbx + c[0], pby + c[1], h, n);
-        const float dist = (pbz + c[2] - h) * n[2];
-        dep = rad - dist;
-        hit = dep > 0.f && !dead;
-        illegal |= hit && !((ac.allowed >> ci) & 1ull);
-        cx[0] = c[0] - rad * n[0]; cx[1] = c[1] - rad * n[1]; cx[2] = c[2] - rad * n[2];
-      }
+    // writes the contacts of one pass over the primitives (ballot + popcount compaction, contacts in primitive order)
+    auto emit = [&](bool hit, int ci, int cbody, const float* c, float rad, const float* n, float dep) {
+      illegal |= hit && !((ac.allowed >> ci) & 1ull);
       const unsigned long long bal = __ballot(hit);
       const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
       const int slot = nc + __popcll(gm & ((1ull << s) - 1ull));
@@ -643,13 +706,122 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const float il = 1.0f / sqrtf(dot3(t1, t1));
         t1[0] *= il; t1[1] *= il; t1[2] *= il;
         cross3(n, t1, t2);
-        P[0] = cx[0]; P[1] = cx[1]; P[2] = cx[2]; P[3] = dep;
+        P[0] = c[0] - rad * n[0]; P[1] = c[1] - rad * n[1]; P[2] = c[2] - rad * n[2]; P[3] = dep;
         P[4] = t1[0]; P[5] = t1[1]; P[6] = t1[2]; P[7] = __int_as_float(cbody);
         P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(ci);
         P[12] = n[0]; P[13] = n[1]; P[14] = n[2]; P[15] = 0.f;
         stv<4>(CON + slot * kConSlot, P);
       }
       nc += __popcll(gm);
+    };
+    // sphere centre of primitive ci relative to the base position, radius and body
+    auto sphere_of = [&](int ci, float* c, float& rad, int& cbody) {
+      float ct[8];
+      ld4(COLT + 8 * ci, ct); ct[4] = COLT[8 * ci + 4];
+      cbody = __float_as_int(ct[4]);
+      rad = ct[3];
+      float P[12];
+      ldv<3>(BODY + cbody * kBodySlot, P);
+      const float pl[3] = {ct[0], ct[1], ct[2]};
+      float t[3];
+      mat3_vec(P, pl, t);
+      c[0] = P[9] + t[0]; c[1] = P[10] + t[1]; c[2] = P[11] + t[2];
+    };
+    if (ac.terrain_type == 0) {
+      // ---- plane: depth = r - (z - z0), normal z
+      const float nz[3] = {0.f, 0.f, 1.f};
+      for (int c0 = 0; c0 < ncol; c0 += LPE) {
+        const int ci = c0 + s;
+        bool hit = false;
+        float c[3] = {0.f, 0.f, 0.f}, rad = 0.f, dep = 0.f;
+        int cbody = 0;
+        if (ci < ncol) {
+          sphere_of(ci, c, rad, cbody);
+          dep = rad - (pbz + c[2] - ac.ground_z);
+          hit = dep > 0.f && !dead;
+        }
+        emit(hit, ci, cbody, c, rad, nz, dep);
+      }
+    } else {
+      // ---- height map: closest feature over the cells under the sphere (oracle: terrain_contact), in three steps:
+      //   (1) lane = primitive: spheres whose lowest point is above the map's highest sample are dropped (exact: the surface
+      //       is a convex combination of samples); the others get a slot and leave (centre, radius, cell range) in LDS;
+      //   (2) lane = (slot, cell): the four lanes of a quad scan the cells of one slot, two triangles each, and agree on the
+      //       closest feature (DPP quad minimum of the candidate keys); its lane resolves depth and normal;
+      //   (3) lane = primitive again: contacts in primitive order.
+      // Scratch: the first 352 floats of the Delassus rows (dead here; the up pass overwrites them with its hand-over slots).
+      float* REC = G;                                         // [kHmSlots][12] x y z r | ix0 iy0 nx ny | c (relative to the base) | pad
+      float* RES = G + 12 * kHmSlots;                         // [kHmSlots][4] depth, normal
+      int* SLOTOF = reinterpret_cast<int*>(G + 16 * kHmSlots);   // [ncol] slot + 1 of each primitive, 0 = dropped
+      int nnear = 0;
+      for (int c0 = 0; c0 < ncol; c0 += LPE) {
+        const int ci = c0 + s;
+        bool near = false;
+        float c[3] = {0.f, 0.f, 0.f}, rad = 0.f;
+        int cbody = 0;
+        if (ci < ncol) {
+          sphere_of(ci, c, rad, cbody);
+          near = (pbz + c[2] - rad <= ac.hm_max) && !dead;
+        }
+        const unsigned long long bal = __ballot(near);
+        const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
+        const int slot = nnear + __popcll(gm & ((1ull << s) - 1ull));
+        const bool take = near && slot < kHmSlots;
+        if (near && !take) flag |= 1;                        // more spheres near the ground than slots: reported as a contact overflow
+        if (take) {
+          int ix0, iy0, nx, ny;
+          hm_cell_range(ac, pbx + c[0], pby + c[1], rad, ix0, iy0, nx, ny);
+          const float R[12] = {pbx + c[0], pby + c[1], pbz + c[2], rad, __int_as_float(ix0), __int_as_float(iy0), __int_as_float(nx), __int_as_float(ny),
+                               c[0], c[1], c[2], 0.f};
+          stv<3>(REC + 12 * slot, R);
+        }
+        if (ci < ncol) SLOTOF[ci] = take ? slot + 1 : 0;
+        nnear += __popcll(gm);
+      }
+      nnear = min(nnear, kHmSlots);
+      int nnw = nnear;
+      if (EPW > 1) { RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) nnw = max(nnw, __shfl_xor(nnw, off)); }
+      nnw = __builtin_amdgcn_readfirstlane(nnw);
+      __syncthreads();
+      for (int k0 = 0; k0 < nnw; k0 += LPE / 4) {
+        const int k = k0 + (s >> 2), t = s & 3;
+        const bool valid = k < nnear;
+        float R[8];
+        ldv<2>(REC + 12 * (valid ? k : 0), R);
+        const int ix0 = __float_as_int(R[4]), iy0 = __float_as_int(R[5]), nx = __float_as_int(R[6]), ncell = valid ? nx * __float_as_int(R[7]) : 0;
+        unsigned key = 0xffffffffu;
+        float bp[3] = {0.f, 0.f, 0.f}, bn[3] = {0.f, 0.f, 1.f};
+        for (int cc = t; cc < ncell; cc += 4) {
+          const int cyy = cc / nx, cxx = cc - cyy * nx;
+          hm_scan_cell(ac, env_heights, ix0 + cxx, iy0 + cyy, 2 * cc, R[0], R[1], R[2], key, bp, bn);
+        }
+        unsigned kmin = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+        kmin = min(kmin, (unsigned)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x4E, 0xf, 0xf, false));            // quad_perm [2,3,0,1]
+        if (valid && key == kmin) {     // the scan position makes the keys of a quad distinct
+          float o4[4];
+          hm_resolve(ac, env_heights, bp, bn, R[0], R[1], R[2], R[3], o4[0], o4 + 1);
+          st4(RES + 4 * k, o4);
+        }
+      }
+      __syncthreads();
+      for (int c0 = 0; c0 < ncol; c0 += LPE) {
+        const int ci = c0 + s;
+        bool hit = false;
+        float c[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 1.f}, rad = 0.f, dep = 0.f;
+        int cbody = 0;
+        const int sl = ci < ncol ? SLOTOF[ci] : 0;
+        if (sl > 0) {
+          float o4[4], r4[4];
+          ld4(RES + 4 * (sl - 1), o4); ld4(REC + 12 * (sl - 1) + 8, r4);
+          dep = o4[0]; n[0] = o4[1]; n[1] = o4[2]; n[2] = o4[3];
+          c[0] = r4[0]; c[1] = r4[1]; c[2] = r4[2];
+          rad = REC[12 * (sl - 1) + 3];
+          cbody = __float_as_int(COLT[8 * ci + 4]);
+          hit = dep > 0.f;
+        }
+        emit(hit, ci, cbody, c, rad, n, dep);
+      }
+      __syncthreads();   // the scratch is free again (the up pass reuses it)
     }
     if (nc > kmax) { nc = kmax; flag |= 1; }
     // joint limits (oracle: "joint limits" in step_impl): a joint outside [q_lower, q_upper] adds one unilateral row

@@ -23,6 +23,7 @@ constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
 constexpr int kLightDepth = 3;        // == ORC_LIGHT_DEPTH
+constexpr int kHmSlots = 16;          // spheres per env the height-map narrow phase examines in one sub-step (those near the ground)
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
@@ -96,7 +97,7 @@ struct StepArgs {
   int max_iter, section_rounds, stall_window, freeze_after, refine;
   float stall_factor, settle_tol, restitution, res_threshold;
   int terrain_type, hm_xs, hm_ys;
-  float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy;
+  float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy, hm_max;
   LdsLayout L;
 };
 

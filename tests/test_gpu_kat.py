@@ -180,3 +180,25 @@ def test_two_materials_on_one_body_decelerate_at_the_closed_form_rate(built_lib)
     w.integrate(30); _, u0 = w.get_state(); w.integrate(1); _, u1 = w.get_state()
     assert np.allclose(u1[:, 0] - u0[:, 0], -0.8 * G * DT, atol=2e-5)
     w.close()
+
+
+def test_sphere_beside_a_ridge_touches_the_edge_not_the_flank(built_lib):
+    """Closest-feature sphere x height-map narrow phase through the C-ABI (see the oracle KAT of the same name)."""
+    from test_oracle_kat import ridge_map
+    r = 0.3
+    _, w = world(sphere_urdf(2.0, r))
+    w.add_height_map(*ridge_map())
+    w.set_state(tile([2.1, 2.5, 1.25, 1, 0, 0, 0]), tile(np.zeros(6)))
+    w.integrate(1)
+    cnt, con = w.get_contacts()
+    assert (cnt == 1).all()
+    d = np.hypot(0.1, 0.25)
+    assert abs(con[0][0]["depth"] - (r - d)) < 2e-6
+    assert np.allclose(con[0][0]["normal"], np.array([0.1, 0.0, 0.25]) / d, atol=2e-6)
+    h = np.zeros((5, 5), np.float32); h[2, 2] = 0.5
+    w.add_height_map(5, 5, 4.0, 4.0, 2.0, 2.0, h)
+    w.set_state(tile([2.0, 2.0, 0.7, 1, 0, 0, 0]), tile(np.zeros(6)))
+    w.integrate(1)
+    cnt, con = w.get_contacts()
+    assert (cnt == 1).all() and abs(con[5][0]["depth"] - 0.1) < 2e-6 and np.allclose(con[5][0]["normal"], [0, 0, 1], atol=2e-6)
+    w.close()

@@ -275,3 +275,40 @@ def test_per_primitive_restitution(built_lib):
         if len(con): break
         q, u1, con, _, _ = o.step(q, u1)
     assert len(con) == 1 and abs(u1[2] - 0.5 * 2.0) < 0.03     # v+ = -e v- (gravity adds g dt per step on the way)
+
+
+def ridge_map():
+    """5 x 5 samples, 1 m cells, centred on (2, 2): a tent ridge of height 1 along y at x = 2 (both flanks are planes at 45 deg)."""
+    h = np.zeros((5, 5), np.float32)
+    h[:, 2] = 1.0
+    return (5, 5, 4.0, 4.0, 2.0, 2.0, h)
+
+
+def test_sphere_beside_a_ridge_touches_the_edge_not_the_flank(built_lib):
+    """Closest-feature narrow phase: the centre sits 0.1 m beside the crest and 0.25 m above it; the foot of the perpendicular
+    onto the flank under the centre lies beyond the crest, so the closest feature is the ridge EDGE: distance
+    sqrt(0.1^2 + 0.25^2), normal along (0.1, 0, 0.25) - not the flank's plane (distance 0.2475, normal (1, 0, 1)/sqrt 2)."""
+    r = 0.3
+    _, o = make(sphere_urdf(2.0, r))
+    o.set_heightmap(*ridge_map())
+    q = np.array([2.1, 2.5, 1.25, 1, 0, 0, 0.0])
+    _, _, con, _, _ = o.step(q, np.zeros(6))
+    assert len(con) == 1
+    d = np.hypot(0.1, 0.25)
+    assert abs(con["depth"][0] - (r - d)) < 1e-9
+    assert np.allclose(con["normal"][0], np.array([0.1, 0.0, 0.25]) / d, atol=1e-9)
+    # on the flank proper (1 m from the crest) the face is the closest feature: the plane distance and the plane's normal
+    q = np.array([3.0, 2.5, 0.0 + 0.25 * np.sqrt(2.0), 1, 0, 0, 0.0])
+    _, _, con, _, _ = o.step(q, np.zeros(6))
+    assert len(con) == 1 and abs(con["depth"][0] - (r - 0.25)) < 1e-9
+    assert np.allclose(con["normal"][0], np.array([1.0, 0.0, 1.0]) / np.sqrt(2.0), atol=1e-9)
+    # above a VERTEX of a pyramid (one raised sample): distance to the apex, normal straight up
+    h = np.zeros((5, 5), np.float32); h[2, 2] = 0.5
+    o.set_heightmap(5, 5, 4.0, 4.0, 2.0, 2.0, h)
+    _, _, con, _, _ = o.step(np.array([2.0, 2.0, 0.5 + 0.2, 1, 0, 0, 0.0]), np.zeros(6))
+    assert len(con) == 1 and abs(con["depth"][0] - 0.1) < 1e-9 and np.allclose(con["normal"][0], [0, 0, 1], atol=1e-9)
+    # a valley floor: the sphere rests between two flanks -> the closer flank's face
+    h = np.ones((5, 5), np.float32); h[:, 2] = 0.0
+    o.set_heightmap(5, 5, 4.0, 4.0, 2.0, 2.0, h)
+    _, _, con, _, _ = o.step(np.array([2.05, 2.5, 0.36, 1, 0, 0, 0.0]), np.zeros(6))
+    assert len(con) == 1 and np.allclose(con["normal"][0], np.array([-1.0, 0.0, 1.0]) / np.sqrt(2.0), atol=1e-9)
