@@ -140,6 +140,7 @@ int rsb_model_get_blob(const rsb_model* m, rsb_model_blob* out);
 int rsb_model_body_index(const rsb_model* m, const char* link_name);   /* <0 if absent */
 int rsb_model_joint_index(const rsb_model* m, const char* joint_name); /* body index driven by joint */
 double rsb_model_total_mass(const rsb_model* m);
+int rsb_model_skipped_collisions(const rsb_model* m);   /* <collision> elements the loader could not turn into primitives (unreadable meshes, unknown geometry) */
 const char* rsb_model_collision_material(const rsb_model* m, int collision);   /* material name of a collision primitive ("default" if the URDF names none) */
 
 /* ---- world ------------------------------------------------------------------------------ */

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "rsb_model_joint_index": (_I, [_VP, _CP]),
     "rsb_model_total_mass": (_D, [_VP]),
     "rsb_model_collision_material": (C.c_char_p, [_VP, _I]),
+    "rsb_model_skipped_collisions": (_I, [_VP]),
     "rsb_device_count": (_I, []),
     "rsb_create": (_I, [_VP, _I, _I, C.POINTER(_VP)]),
     "rsb_destroy": (_I, [_VP]),

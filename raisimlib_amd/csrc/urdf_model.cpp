@@ -7,17 +7,24 @@
 // Supported subset: <link>/<inertial>/<collision> with <sphere>, <capsule>, <box> (its 8 corners) and <cylinder>
 // (the inscribed capsule) geometry,
 // <joint type="revolute|continuous|prismatic|fixed">, <origin xyz rpy>, <axis>, <limit>,
-// <dynamics damping rotor_inertia>.  The root link is the floating base.  Mesh collision geometry is ignored
-// (counted in rsb_model::skipped_collisions); see DESIGN.md "out of scope".
+// <dynamics damping rotor_inertia>.  The root link is the floating base.  <mesh filename=.. scale=..> collision geometry
+// (Wavefront OBJ, binary / ASCII STL; path relative to the URDF file, "package://" / "file://" prefixes stripped to the
+// longest existing suffix) becomes a POINT SET: up to kMeshPoints vertices of the mesh's convex hull (support vertices of
+// the body diagonals, axes and face diagonals), each a zero-radius sphere - against a plane this is the contact set of a
+// triangle-mesh x plane collider (vertices below the plane) thinned out to the budget.  Meshes that cannot be read
+// (Collada, missing files, URDFs given as strings without a directory) are skipped and counted in
+// rsb_model::skipped_collisions.
 #include "rsb.h"
 #include "rsb_internal.h"
 
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -181,7 +188,7 @@ static Xf parse_origin(const XmlNode* n) {
 }
 
 // ------------------------------------------------------------------------------ URDF -> blob
-struct UCollision { Xf x; int type; double radius, length; double size[3]; std::string name, material; };  // type 0 sphere, 1 capsule, 2 box
+struct UCollision { Xf x; int type; double radius, length; double size[3]; std::string name, material; std::vector<V3> pts; };  // type 0 sphere, 1 capsule, 2 box, 3 mesh point set
 struct ULink {
   std::string name;
   double mass = 0;
@@ -198,6 +205,102 @@ struct UJoint {
   V3 axis{1, 0, 0};
   double lower = -1e30, upper = 1e30, effort = 0, damping = 0, armature = 0;
 };
+
+
+// ------------------------------------------------------------------------------ mesh colliders
+constexpr int kMeshPoints = 8;   // collision points kept per mesh (the model holds RSB_MAX_COLLISIONS primitives in total)
+
+static bool file_exists(const std::string& p) { std::ifstream f(p, std::ios::binary); return (bool)f; }
+
+// URDF mesh URI -> a readable path: as given (absolute or relative to the URDF's directory), else the longest suffix of a
+// package:// / file:// URI that exists below the URDF's directory or one of its parents (ROS package layouts)
+static std::string resolve_mesh_path(const std::string& uri, const std::string& base_dir) {
+  std::string rel = uri;
+  for (const char* pre : {"package://", "file://", "model://"}) if (rel.rfind(pre, 0) == 0) rel = rel.substr(std::strlen(pre));
+  if (!rel.empty() && rel[0] == '/' && file_exists(rel)) return rel;
+  std::string dir = base_dir;
+  for (int up = 0; up < 4; ++up) {
+    std::string sub = rel;
+    while (true) {
+      const std::string cand = (dir.empty() ? std::string(".") : dir) + "/" + sub;
+      if (file_exists(cand)) return cand;
+      const size_t cut = sub.find('/');
+      if (cut == std::string::npos) break;
+      sub = sub.substr(cut + 1);
+    }
+    dir += "/..";
+  }
+  return "";
+}
+
+// vertices of an OBJ ("v x y z" lines) or STL (binary: 80-byte header, uint32 count, 50-byte facets; ASCII: "vertex x y z")
+static bool read_mesh_vertices(const std::string& path, std::vector<V3>* out) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::string data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  const size_t dot = path.rfind('.');
+  std::string ext = dot == std::string::npos ? "" : path.substr(dot + 1);
+  for (auto& ch : ext) ch = (char)std::tolower((unsigned char)ch);
+  out->clear();
+  if (ext == "obj") {
+    std::istringstream ss(data);
+    std::string line;
+    while (std::getline(ss, line)) {
+      if (line.size() > 2 && line[0] == 'v' && (line[1] == ' ' || line[1] == '\t')) {
+        double v[3];
+        if (std::sscanf(line.c_str() + 2, "%lf %lf %lf", &v[0], &v[1], &v[2]) == 3) out->push_back({v[0], v[1], v[2]});
+      }
+    }
+  } else if (ext == "stl") {
+    uint32_t nt = 0;
+    if (data.size() >= 84) std::memcpy(&nt, data.data() + 80, 4);
+    if (data.size() >= 84 && data.size() == 84 + (size_t)nt * 50) {        // binary
+      for (uint32_t t = 0; t < nt; ++t)
+        for (int k = 0; k < 3; ++k) {
+          float v[3];
+          std::memcpy(v, data.data() + 84 + (size_t)t * 50 + 12 + 12 * k, 12);
+          out->push_back({v[0], v[1], v[2]});
+        }
+    } else {                                                               // ASCII
+      size_t pos = 0;
+      while ((pos = data.find("vertex", pos)) != std::string::npos) {
+        double v[3];
+        if (std::sscanf(data.c_str() + pos + 6, "%lf %lf %lf", &v[0], &v[1], &v[2]) == 3) out->push_back({v[0], v[1], v[2]});
+        pos += 6;
+      }
+    }
+  } else {
+    return false;
+  }
+  return !out->empty();
+}
+
+// at most `budget` vertices of the cloud's CONVEX HULL: the support vertices (farthest along a direction) of the 8 body
+// diagonals, then the 6 axes, then the 12 face diagonals - a box keeps exactly its corners, a foot plate its outline
+static std::vector<V3> thin_point_set(const std::vector<V3>& v, int budget) {
+  std::vector<V3> sel;
+  std::vector<V3> dirs;
+  for (int sx = -1; sx <= 1; sx += 2) for (int sy = -1; sy <= 1; sy += 2) for (int sz = -1; sz <= 1; sz += 2) dirs.push_back({(double)sx, (double)sy, (double)sz});
+  for (int ax = 0; ax < 3; ++ax) for (int sg = -1; sg <= 1; sg += 2) dirs.push_back({ax == 0 ? (double)sg : 0.0, ax == 1 ? (double)sg : 0.0, ax == 2 ? (double)sg : 0.0});
+  for (int a = 0; a < 3; ++a) for (int sa = -1; sa <= 1; sa += 2) for (int sb = -1; sb <= 1; sb += 2) {
+    double d[3] = {0, 0, 0};
+    d[a] = sa; d[(a + 1) % 3] = sb;
+    dirs.push_back({d[0], d[1], d[2]});
+  }
+  for (const V3& d : dirs) {
+    if ((int)sel.size() >= budget) break;
+    size_t best = 0;
+    double sb = -1e300;
+    for (size_t i = 0; i < v.size(); ++i) {
+      const double sp = d.x * v[i].x + d.y * v[i].y + d.z * v[i].z;
+      if (sp > sb) { sb = sp; best = i; }
+    }
+    bool dup = false;
+    for (auto& q : sel) { V3 e = q - v[best]; if (e.x * e.x + e.y * e.y + e.z * e.z < 1e-18) dup = true; }
+    if (!dup) sel.push_back(v[best]);
+  }
+  return sel;
+}
 
 struct Builder {
   std::vector<ULink> links;
@@ -225,12 +328,13 @@ struct Builder {
   void add_collisions(int body, const Xf& body_from_link, const ULink& L) {
     for (auto& c : L.cols) {
       Xf bc = compose(body_from_link, c.x);
-      int n = c.type == 1 ? 2 : (c.type == 2 ? 8 : 1);
+      int n = c.type == 1 ? 2 : (c.type == 2 ? 8 : (c.type == 3 ? (int)c.pts.size() : 1));
       for (int e = 0; e < n; ++e) {
         if (blob.ncol >= RSB_MAX_COLLISIONS) throw std::runtime_error("URDF: more than RSB_MAX_COLLISIONS collision spheres");
         V3 off{0, 0, 0};
         if (c.type == 1) off = {0, 0, (e == 0 ? 0.5 : -0.5) * c.length};
         if (c.type == 2) off = {(e & 1 ? 0.5 : -0.5) * c.size[0], (e & 2 ? 0.5 : -0.5) * c.size[1], (e & 4 ? 0.5 : -0.5) * c.size[2]};
+        if (c.type == 3) off = c.pts[e];
         V3 p = bc.p + mul(bc.R, off);
         int s = blob.ncol++;
         blob.col_body[s] = body;
@@ -239,6 +343,7 @@ struct Builder {
         std::string nm = c.name.empty() ? L.name : c.name;
         if (c.type == 1) nm += (e == 0 ? "/top" : "/bottom");
         if (c.type == 2) nm += "/c" + std::to_string(e);
+        if (c.type == 3) nm += "/m" + std::to_string(e);
         std::snprintf(blob.col_name[s], RSB_NAME_LEN, "%s", nm.c_str());
         std::snprintf(blob.col_material[s], RSB_NAME_LEN, "%s", c.material.empty() ? "default" : c.material.c_str());
       }
@@ -295,7 +400,7 @@ struct Builder {
   }
 };
 
-static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* skipped) {
+static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* skipped, const std::string& base_dir = std::string()) {
   XmlParser parser(xml);
   auto root = parser.parse();
   if (root->tag != "robot") throw std::runtime_error("URDF: root element is <" + root->tag + ">, expected <robot>");
@@ -336,8 +441,19 @@ static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* ski
           col.type = 1; col.radius = attr_double(cy, "radius", 0.0);
           const double len = attr_double(cy, "length", 0.0);
           col.length = len > 2 * col.radius ? len - 2 * col.radius : 0.0;
-        } else { ++B.skipped_collisions; continue; }   // meshes
-        if (col.type != 2 && col.radius <= 0) throw std::runtime_error("URDF: non-positive collision radius on link " + L.name);
+        } else if (const XmlNode* ms = g->child("mesh")) {
+          // a mesh touches a plane with its vertices: a thinned-out point set of zero-radius spheres (see the file header)
+          std::vector<V3> verts;
+          const char* fn = ms->get("filename");
+          const std::string path = fn ? resolve_mesh_path(fn, base_dir) : std::string();
+          if (path.empty() || !read_mesh_vertices(path, &verts)) { ++B.skipped_collisions; continue; }
+          double sc[3] = {1, 1, 1};
+          if (ms->get("scale") && !parse_doubles(ms->get("scale"), sc, 3)) throw std::runtime_error("URDF: bad <mesh scale> on link " + L.name);
+          for (auto& v : verts) v = {v.x * sc[0], v.y * sc[1], v.z * sc[2]};
+          col.type = 3; col.radius = 0; col.length = 0;
+          col.pts = thin_point_set(verts, kMeshPoints);
+        } else { ++B.skipped_collisions; continue; }   // unknown geometry
+        if (col.type != 2 && col.type != 3 && col.radius <= 0) throw std::runtime_error("URDF: non-positive collision radius on link " + L.name);
         L.cols.push_back(col);
       }
       if (B.link_ix.count(L.name)) throw std::runtime_error("URDF: duplicate link " + L.name);
@@ -451,7 +567,21 @@ int rsb_model_from_urdf_file(const char* path, rsb_model** out) {
   if (!f) { rsb::set_error(std::string("cannot open URDF file: ") + path); return RSB_E_INVALID; }
   std::stringstream ss;
   ss << f.rdbuf();
-  return rsb_model_from_urdf_string(ss.str().c_str(), out);
+  if (!out) { rsb::set_error("rsb_model_from_urdf_file: null argument"); return RSB_E_INVALID; }
+  try {
+    auto m = std::make_unique<rsb_model>();
+    std::string dir = path;
+    const size_t cut = dir.find_last_of('/');
+    dir = cut == std::string::npos ? std::string(".") : dir.substr(0, cut);
+    rsb::build_from_xml(ss.str(), &m->blob, &m->skipped_collisions, dir);   // mesh files are looked up relative to the URDF
+    int st = rsb::validate_blob(m->blob);
+    if (st != RSB_OK) return st;
+    *out = m.release();
+    return RSB_OK;
+  } catch (const std::exception& e) {
+    rsb::set_error(e.what());
+    return RSB_E_PARSE;
+  }
 }
 
 int rsb_model_from_blob(const rsb_model_blob* blob, rsb_model** out) {
@@ -490,6 +620,8 @@ double rsb_model_total_mass(const rsb_model* m) {
   if (m) for (int i = 0; i < m->blob.nb; ++i) s += m->blob.mass[i];
   return s;
 }
+
+int rsb_model_skipped_collisions(const rsb_model* m) { return m ? m->skipped_collisions : RSB_E_INVALID; }
 
 const char* rsb_model_collision_material(const rsb_model* m, int collision) {
   if (!m || collision < 0 || collision >= m->blob.ncol) return nullptr;

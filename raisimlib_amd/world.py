@@ -52,6 +52,7 @@ class Model:
     nq = property(lambda self: self.blob.nq)
     nv = property(lambda self: self.blob.nv)
     ncol = property(lambda self: self.blob.ncol)
+    skipped_collisions = property(lambda self: lib().rsb_model_skipped_collisions(self.handle))   # <collision> elements the loader dropped
 
     def body_index(self, link_name):
         return lib().rsb_model_body_index(self.handle, link_name.encode())

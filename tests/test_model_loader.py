@@ -1,8 +1,11 @@
 """URDF subset loader (host logic, CPU): topology, fixed-joint merging, capsules, error behaviour."""
+import os
+
 import numpy as np
 import pytest
 
 from common import sphere_urdf
+from raisimlib_amd import Model
 
 
 def test_anymal_topology(anymal):
@@ -136,3 +139,69 @@ def test_crate_rests_on_its_four_bottom_corners(built_lib):
         q, u, con, it, fl = o.step(q, u)
     assert len(con) == 4 and set(con["collision"]) == {0, 1, 2, 3}          # the corners with z = -0.1
     assert abs(con["impulse"][:, 2].sum() - 4 * 9.81 * 0.0025) < 1e-8 and np.abs(u).max() < 1e-7
+
+
+MESH_URDF = """<robot name="crate"><link name="crate">
+ <inertial><origin xyz="0 0 0"/><mass value="3"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.1"/></inertial>
+ <collision name="hull"><origin xyz="0 0 0.1"/><geometry><mesh filename="package://crate_description/meshes/{fn}" scale="0.5 0.5 0.5"/></geometry>
+   <material name="wood"/></collision>
+</link></robot>"""
+
+
+def _write_box_mesh(dirpath, fn, half=(0.4, 0.3, 0.2), extra_interior=True):
+    """A box as OBJ or binary STL (12 triangles), plus a few interior / face points that the thinning must not prefer."""
+    import itertools, struct
+    hx, hy, hz = half
+    V = [(sx * hx, sy * hy, sz * hz) for sx, sy, sz in itertools.product((-1, 1), repeat=3)]
+    F = [(0, 1, 3), (0, 3, 2), (4, 6, 7), (4, 7, 5), (0, 4, 5), (0, 5, 1), (2, 3, 7), (2, 7, 6), (0, 2, 6), (0, 6, 4), (1, 5, 7), (1, 7, 3)]
+    os.makedirs(dirpath, exist_ok=True)
+    path = os.path.join(dirpath, fn)
+    if fn.endswith(".obj"):
+        with open(path, "w") as f:
+            f.write("# box\n")
+            for v in V + ([(0, 0, hz), (0.1, 0.0, 0.0)] if extra_interior else []):
+                f.write("v %.6f %.6f %.6f\n" % v)
+            for a, b, c in F:
+                f.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+    else:
+        with open(path, "wb") as f:
+            f.write(b"binary stl".ljust(80, b" ") + struct.pack("<I", len(F)))
+            for a, b, c in F:
+                f.write(struct.pack("<12fH", 0, 0, 0, *V[a], *V[b], *V[c], 0))
+    return path
+
+
+@pytest.mark.parametrize("fn", ["crate.obj", "crate.stl"])
+def test_mesh_collision_geometry_becomes_a_point_set(built_lib, tmp_path, fn):
+    """<mesh> colliders (OBJ, binary STL): package:// URI resolved below the URDF's directory, scale applied, the vertex cloud
+    thinned to 8 points - for a box exactly its corners - each a zero-radius primitive carrying the collision's material."""
+    pkg = tmp_path / "crate_description"
+    _write_box_mesh(str(pkg / "meshes"), fn)
+    urdf = pkg / "urdf" / "crate.urdf"
+    os.makedirs(urdf.parent)
+    urdf.write_text(MESH_URDF.format(fn=fn))
+    m = Model(urdf_path=str(urdf))
+    assert m.skipped_collisions == 0 and m.ncol == 8
+    P = np.array([[m.blob.col_pos[i][k] for k in range(3)] for i in range(8)])
+    want = np.array([[sx * 0.2, sy * 0.15, sz * 0.1 + 0.1] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    order = lambda A: A[np.lexsort(np.round(A, 4).T[::-1])]
+    assert np.allclose(order(P), order(want), atol=1e-7)            # (binary STL stores float32 vertices)
+    assert all(m.blob.col_radius[i] == 0.0 for i in range(8))
+    assert m.collision_names()[0].startswith("hull/m") and set(m.collision_materials()) == {"wood"}
+    # a URDF given as a string has no directory to resolve the mesh against: the collider is skipped and counted, not fatal
+    m2 = Model(urdf_string=MESH_URDF.format(fn=fn))
+    assert m2.ncol == 0 and m2.skipped_collisions == 1
+
+
+def test_mesh_crate_rests_on_its_four_lowest_vertices(built_lib, tmp_path):
+    from common import Oracle
+    pkg = tmp_path / "crate_description"
+    _write_box_mesh(str(pkg / "meshes"), "crate.obj")
+    urdf = pkg / "crate.urdf"
+    urdf.write_text(MESH_URDF.format(fn="crate.obj"))
+    m = Model(urdf_path=str(urdf))
+    o = Oracle(m.blob)
+    q = np.array([0, 0, -1e-4, 1, 0, 0, 0.0]); u = np.zeros(6)     # the lowest vertices (z = 0 in the body frame) just below the ground
+    for _ in range(20):
+        q, u, con, _, _ = o.step(q, u)
+    assert len(con) == 4 and abs(con["impulse"][:, 2].sum() - 3 * 9.81 * 0.0025) < 1e-9 and np.abs(u).max() < 1e-9
