@@ -51,7 +51,7 @@ struct rsb_world {
   float* d_colmat = nullptr;          // [ncol][4] mu, restitution, res_threshold, pad per collision primitive (rsb_set_collision_materials)
   std::vector<double> col_mu, col_rest, col_rthr;   // per-primitive overrides, < 0 = the world's default
   bool colmat_dirty = true;
-  float* d_warm = nullptr;   // [N, 6*ncol] contact-solver warm state (impulse, friction direction per collision primitive)
+  float* d_warm = nullptr;   // [N, kWarmRow] contact-solver warm state (StepArgs::warm: one record per contact of the last integrate())
   bool warm_start = true;
   uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
   const uint8_t* launch_mask = nullptr; // env mask of the next launch only (rsb_integrate_masked)
@@ -505,8 +505,8 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   HIP_TRY(hipMalloc(&w->d_obs_idx, RSB_MAX_COLLISIONS * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_colmat, 4 * (size_t)RSB_MAX_COLLISIONS * sizeof(float)));
   w->col_mu.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rest.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rthr.assign(RSB_MAX_COLLISIONS, -1.0);
-  HIP_TRY(hipMalloc(&w->d_warm, N * 6 * (size_t)(w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float)));
-  HIP_TRY(hipMemset(w->d_warm, 0, N * 6 * (size_t)(w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_warm, N * (size_t)rsbk::kWarmRow * sizeof(float)));
+  HIP_TRY(hipMemset(w->d_warm, 0, N * (size_t)rsbk::kWarmRow * sizeof(float)));
   HIP_TRY(hipMemset(w->d_gc, 0, N * nq * sizeof(float)));
   HIP_TRY(hipMemset(w->d_gv, 0, N * nv * sizeof(float)));
   HIP_TRY(hipMemset(w->d_pt, 0, N * nq * sizeof(float)));
@@ -638,7 +638,7 @@ int rsb_set_solver_warm_start(rsb_world* w, int on) {
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
   w->warm_start = on != 0;
-  HIP_TRY(hipMemsetAsync(w->d_warm, 0, (size_t)w->N * 6 * (w->blob.ncol > 0 ? w->blob.ncol : 1) * sizeof(float), w->stream));
+  HIP_TRY(hipMemsetAsync(w->d_warm, 0, (size_t)w->N * rsbk::kWarmRow * sizeof(float), w->stream));
   return RSB_OK;
 }
 int rsb_set_max_contacts(rsb_world* w, int kmax) {
@@ -693,7 +693,7 @@ int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t*
   HIP_TRY(hipSetDevice(w->device));
   const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
   w->integrate1_valid = false;
-  const int n6 = 6 * w->blob.ncol;
+  const int n6 = rsbk::kWarmRow;
   if (!mask) {
     if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, w->stream, w->d_warm, (const uint8_t*)nullptr, (int)N, n6);
     if (gc) { int st = copy_in(w, w->d_gc, gc, N * nq, space); if (st) return st; }
@@ -749,7 +749,7 @@ int rsb_set_env_row(rsb_world* w, int field, int env, const float* data) {
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipMemcpyAsync(base + (size_t)env * dim, data, dim * sizeof(float), hipMemcpyHostToDevice, w->stream));
   if ((field == RSB_F_GC || field == RSB_F_GV) && w->blob.ncol > 0)   // the env's state was overwritten: its solver state is stale
-    HIP_TRY(hipMemsetAsync(w->d_warm + (size_t)env * 6 * w->blob.ncol, 0, 6 * (size_t)w->blob.ncol * sizeof(float), w->stream));
+    HIP_TRY(hipMemsetAsync(w->d_warm + (size_t)env * rsbk::kWarmRow, 0, (size_t)rsbk::kWarmRow * sizeof(float), w->stream));
   HIP_TRY(hipStreamSynchronize(w->stream));
   w->integrate1_valid = false;
   return RSB_OK;
@@ -958,7 +958,7 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
     dgc0 = w->d_tmp_gc; dgv0 = w->d_tmp_gv; ddone = done ? w->d_tmp_mask : nullptr;
   }
   hipLaunchKernelGGL(reset_terminated_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_contacts,
-                     w->d_count, w->d_flags, allowed, dgc0, dgv0, rows, ddone, (int)N, (int)nq, (int)nv, w->kmax, w->d_warm, 6 * w->blob.ncol);
+                     w->d_count, w->d_flags, allowed, dgc0, dgv0, rows, ddone, (int)N, (int)nq, (int)nv, w->kmax, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   if (space == RSB_HOST) {
@@ -1048,7 +1048,7 @@ static int env_check(rsb_world* w, const char* who) {
 int rsb_env_reset(rsb_world* w) {
   int st = env_check(w, "rsb_env_reset"); if (st != RSB_OK) return st;
   hipLaunchKernelGGL(env_reset_kernel, dim3((w->N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_count,
-                     w->d_flags, w->d_env_gc0, w->d_env_gv0, w->N, w->blob.nq, w->blob.nv, w->d_warm, 6 * w->blob.ncol);
+                     w->d_flags, w->d_env_gc0, w->d_env_gv0, w->N, w->blob.nq, w->blob.nv, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   return RSB_OK;
@@ -1088,7 +1088,7 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   hipLaunchKernelGGL(env_post_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_env_tau2,
                      w->d_contacts, w->d_count, w->d_flags, w->env_allowed, w->d_env_gc0, w->d_env_gv0,
                      drew, ddone, N, nq, nv, w->kmax, w->env_cfg.forward_vel_coeff, w->env_cfg.forward_vel_clip,
-                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward, w->d_warm, 6 * w->blob.ncol, dob);
+                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward, w->d_warm, rsbk::kWarmRow, dob);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   if (space == RSB_HOST) {

@@ -565,7 +565,18 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   }
   const float* env_heights = a.heights;   // this env's height map (terrain curricula: rsb_set_heightmaps)
   if (a.hm_index && a.terrain_type == 1) env_heights += (size_t)a.hm_index[env] * a.hm_xs * a.hm_ys;
-  if (a.warm) for (int i = s; i < nwarm; i += LPE) WARM[i] = a.warm[(size_t)env * nwarm + i];
+  if (a.warm) {
+    // warm state: HBM holds one record per contact of the previous integrate() (not a row per primitive: 8 x 32 B instead of
+    // ncol x 24 B per env and direction); scattered into the per-primitive LDS table the solver looks its contacts up in
+    for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
+    __syncthreads();
+    if (s < a.kmax) {
+      float rec[8];
+      ldv<2>(a.warm + (size_t)env * kWarmRow + kWarmRec * s, rec);
+      const int col = __float_as_int(rec[6]) - 1;
+      if (col >= 0 && col < ncol) { RSB_UNROLL for (int i = 0; i < 6; ++i) WARM[6 * col + i] = rec[i]; }
+    }
+  }
   int flag = 0, iters_used = 0, nc = 0;
   int nc_real = 0;     // contacts of the last sub-step without the joint-limit rows that follow them in the solver
   bool dead = false;   // early termination: this env no longer integrates (its contacts at that moment stay reported)
@@ -1495,7 +1506,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         ob[nq + nv + 3 * sl] = f0; ob[nq + nv + 3 * sl + 1] = f1; ob[nq + nv + 3 * sl + 2] = f2;
       }
     }
-    if (ae.warm) for (int i = s; i < nwarm; i += LPE) ae.warm[(size_t)env * nwarm + i] = term ? 0.f : WARM[i];
+    if (ae.warm && s < kmax) {   // one record per contact of the last sub-step (see the prologue); empty records behind them
+      float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (s < nc && !term && !dead) {
+        const float* wr = WARM + 6 * mycol;
+        RSB_UNROLL for (int i = 0; i < 6; ++i) rec[i] = wr[i];
+        rec[6] = __int_as_float(mycol + 1);
+      }
+      stv<2>(ae.warm + (size_t)env * kWarmRow + kWarmRec * s, rec);
+    }
     const size_t r0 = (ae.reset_rows == 1) ? 0 : (size_t)env;
     for (int i = s; i < nq; i += LPE) ae.gc[(size_t)env * nq + i] = term ? ae.gc0[r0 * nq + i] : Q[i];
     for (int i = s; i < nv; i += LPE) ae.gv[(size_t)env * nv + i] = term ? ae.gv0[r0 * nv + i] : U[i];

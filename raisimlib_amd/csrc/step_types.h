@@ -23,6 +23,8 @@ constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
 constexpr int kLightDepth = 3;        // == ORC_LIGHT_DEPTH
+constexpr int kWarmRec = 8;           // floats per warm-state record in HBM: impulse (3), friction direction (2), direction valid, primitive + 1, pad
+constexpr int kWarmRow = kWarmRec * RSB_MAX_CONTACTS;   // floats per env row of StepArgs::warm
 constexpr int kHmSlots = 16;          // spheres per env the height-map narrow phase examines in one sub-step (those near the ground)
 
 struct DevModel {
@@ -66,8 +68,9 @@ struct StepArgs {
   int32_t* iters;
   const float* heights;        // [n_maps][hm_ys][hm_xs]
   const int32_t* hm_index;     // [N] height map of each env (NULL: every env uses map 0)
-  float* warm;                 // [N, 6*ncol] solver warm state per collision primitive: impulse (3, contact frame), friction
-                               // direction (2), direction valid; NULL = every solve starts cold
+  float* warm;                 // [N, kWarmRow] solver warm state, one kWarmRec-float record per CONTACT of the last integrate(): impulse (3,
+                               // contact frame), friction direction (2), direction valid, collision primitive + 1 (0 = empty record); the
+                               // first kmax records of a row are read and written.  NULL = every solve starts cold
   // fused control-step epilogue / prologue (rsb_control_step); all optional
   float* ptarget_store;        // p_target rows read from `ptarget` are also stored here (the world's own copy)
   const float* act;            // [N, nv-6] actions (rsb_env_step): joint targets = act_mean + act_std * act, NULL = use ptarget
