@@ -467,7 +467,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   const int lane = threadIdx.x;
   const int el = lane / LPE;
   const int s = lane - el * LPE;
-  int env = blockIdx.x * EPW + el;
+  // XCD-aware block -> env mapping: the dispatcher deals consecutive workgroups round-robin to the 8 XCDs (each with its own
+  // L2); consecutive env blocks share the cache lines at their row boundaries, so block b of XCD x takes env block
+  // x * (blocks / 8) + b / 8 and every XCD reads (and writes) one contiguous slice of every state array
+  // (profiles/r02_traffic_calibration.txt: 1.4x over-fetch of the 76-B rows without it)
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  int env = blk * EPW + el;
   bool env_valid = env < a.N;
   if (!env_valid) env = a.N - 1;
   // masked launch (per-env raisim::World views, rsb_integrate_masked): a masked-off env runs along but writes nothing back
@@ -1468,7 +1474,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
-  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blockIdx.x; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
+  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blk; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
   // ---- results: LDS -> HBM (with the optional control-step epilogue: observation block, reset of terminated envs)
   RSB_ARGS(ae);
   if (env_valid) {
