@@ -48,9 +48,10 @@ struct rsb_world {
   float *d_M = nullptr, *d_h = nullptr, *d_Minv = nullptr, *d_Mwork = nullptr;
   int32_t* d_obs_idx = nullptr;
   int32_t* d_hm_index = nullptr;   // [N] height map of each env (rsb_set_heightmaps), NULL: all envs share map 0
-  float* d_colmat = nullptr;          // [ncol][4] mu, restitution, res_threshold, pad per collision primitive (rsb_set_collision_materials)
+  float* d_image = nullptr;           // the step kernel's per-block tables in their LDS layout (StepArgs::lds_image), rebuilt when a setter dirties it
+  std::vector<float> h_kp, h_kd;      // host mirror of the PD gains (baked into the image)
   std::vector<double> col_mu, col_rest, col_rthr;   // per-primitive overrides, < 0 = the world's default
-  bool colmat_dirty = true;
+  bool image_dirty = true;
   float* d_warm = nullptr;   // [N, kWarmRow] contact-solver warm state (StepArgs::warm: one record per contact of the last integrate())
   bool warm_start = true;
   uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
@@ -156,6 +157,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.t_dir = take(64);
   L.t_col = take(8 * b.ncol);
   L.t_kids = take(b.nb);
+  L.t_kidx = take(b.nb);
   L.shared_total = o;
   o = 0;
   L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
@@ -359,6 +361,42 @@ int check_lpe(const rsb_world* w, int lpe) {
   return RSB_OK;
 }
 
+// The per-block tables of the step kernel exactly as they sit in LDS (LdsLayout::t_*): the kernel copies this image with
+// float4 loads instead of staging ten tables one latency-bound loop at a time.  Rebuilt when a setter changes what it bakes
+// in: PD gains, control mode, contact materials.  (The layout of the shared tables does not depend on the contact capacity.)
+std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
+  const rsb_model_blob& b = w->blob;
+  auto dm = std::make_unique<DevModel>();
+  build_dev_model(b, dm.get());
+  std::vector<float> img((size_t)L.shared_total, 0.f);
+  auto put_i = [&](int off, int v) { std::memcpy(&img[off], &v, sizeof(int)); };
+  for (int i = 0; i < b.nb; ++i) {
+    for (int c = 0; c < rsbk::kModelSlot; ++c) img[L.t_model + i * rsbk::kModelSlot + c] = dm->bodyf[i][c];
+    const bool pd = w->control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && i >= 1;
+    img[L.t_gain + 2 * i] = pd ? w->h_kp[i + 5] : 0.f;
+    img[L.t_gain + 2 * i + 1] = pd ? w->h_kd[i + 5] : 0.f;
+    put_i(L.t_parlv + i, (b.parent[i] + 1) | (b.level[i] << 8));
+    put_i(L.t_kids + i, dm->kid_list[i]);
+    put_i(L.t_kidx + i, dm->kid_start[i] | (dm->kid_count[i] << 16));
+  }
+  for (int i = 0; i < b.nb * b.depth; ++i) put_i(L.t_anc + i, dm->anc[i]);
+  for (int k = 0; k < 16; ++k) {   // slip-search bracket around grid point k: {cos, sin((k-1) pi/8), cos, sin((k+1) pi/8)}
+    const double lo = ((k + 15) & 15) * 0.125 * M_PI, hi = ((k + 1) & 15) * 0.125 * M_PI;
+    img[L.t_dir + 4 * k] = (float)std::cos(lo); img[L.t_dir + 4 * k + 1] = (float)std::sin(lo);
+    img[L.t_dir + 4 * k + 2] = (float)std::cos(hi); img[L.t_dir + 4 * k + 3] = (float)std::sin(hi);
+  }
+  for (int i = 0; i < b.ncol; ++i) {
+    float* ct = &img[L.t_col + 8 * i];
+    ct[0] = (float)b.col_pos[i][0]; ct[1] = (float)b.col_pos[i][1]; ct[2] = (float)b.col_pos[i][2]; ct[3] = (float)b.col_radius[i];
+    put_i(L.t_col + 8 * i + 4, b.col_body[i]);
+    // contact material of the primitive against the terrain: the per-primitive override where one is set, else the world's default
+    ct[5] = (float)(w->col_mu[i] >= 0 ? w->col_mu[i] : w->mu);
+    ct[6] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);
+    ct[7] = (float)(w->col_rthr[i] >= 0 ? w->col_rthr[i] : w->res_threshold);
+  }
+  return img;
+}
+
 int do_integrate(rsb_world* w, int nsub) {
   HIP_TRY(hipSetDevice(w->device));
   const int lpe = effective_lpe(w);
@@ -374,18 +412,13 @@ int do_integrate(rsb_world* w, int nsub) {
   a.heights = w->d_heights;
   a.hm_index = w->d_hm_index;
   a.warm = w->warm_start ? w->d_warm : nullptr;
-  if (w->colmat_dirty) {   // per-primitive contact material: the override where one is set, else the world's default
-    std::vector<float> cm(4 * (size_t)RSB_MAX_COLLISIONS, 0.f);
-    for (int i = 0; i < w->blob.ncol; ++i) {
-      cm[4 * i] = (float)(w->col_mu[i] >= 0 ? w->col_mu[i] : w->mu);
-      cm[4 * i + 1] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);
-      cm[4 * i + 2] = (float)(w->col_rthr[i] >= 0 ? w->col_rthr[i] : w->res_threshold);
-    }
-    HIP_TRY(hipMemcpyAsync(w->d_colmat, cm.data(), cm.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));   // cm is a stack-lifetime buffer
-    w->colmat_dirty = false;
+  if (w->image_dirty) {
+    std::vector<float> img = build_lds_image(w, make_layout(w->blob, kcap));
+    HIP_TRY(hipMemcpyAsync(w->d_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));   // img is a stack-lifetime buffer
+    w->image_dirty = false;
   }
-  a.colmat = w->d_colmat;
+  a.lds_image = w->d_image;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
   if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; a.tau2_out = w->d_env_tau2; }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
@@ -503,7 +536,8 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   HIP_TRY(hipMalloc(&w->d_flags, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_iters, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_obs_idx, RSB_MAX_COLLISIONS * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&w->d_colmat, 4 * (size_t)RSB_MAX_COLLISIONS * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_image, (size_t)make_layout(w->blob, 8).shared_total * sizeof(float)));
+  w->h_kp.assign(nv, 0.f); w->h_kd.assign(nv, 0.f);
   w->col_mu.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rest.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rthr.assign(RSB_MAX_COLLISIONS, -1.0);
   HIP_TRY(hipMalloc(&w->d_warm, N * (size_t)rsbk::kWarmRow * sizeof(float)));
   HIP_TRY(hipMemset(w->d_warm, 0, N * (size_t)rsbk::kWarmRow * sizeof(float)));
@@ -534,7 +568,7 @@ int rsb_destroy(rsb_world* w) {
   (void)rsb_comm_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_colmat, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -590,13 +624,13 @@ int rsb_set_erp(rsb_world* w, double erp) { if (!w) return RSB_E_INVALID; w->erp
 int rsb_set_friction(rsb_world* w, double mu) {
   if (!w || mu < 0) { rsb::set_error("rsb_set_friction: mu must be >= 0"); return RSB_E_INVALID; }
   w->mu = mu;
-  w->colmat_dirty = true;
+  w->image_dirty = true;
   return RSB_OK;
 }
 int rsb_set_material(rsb_world* w, double mu, double restitution, double res_threshold) {
   if (!w || mu < 0 || restitution < 0 || restitution > 1 || res_threshold < 0) { rsb::set_error("rsb_set_material: mu >= 0, 0 <= restitution <= 1, res_threshold >= 0"); return RSB_E_INVALID; }
   w->mu = mu; w->restitution = restitution; w->res_threshold = res_threshold;
-  w->colmat_dirty = true;
+  w->image_dirty = true;
   return RSB_OK;
 }
 int rsb_set_collision_materials(rsb_world* w, const double* mu, const double* restitution, const double* res_threshold) {
@@ -609,7 +643,7 @@ int rsb_set_collision_materials(rsb_world* w, const double* mu, const double* re
     w->col_rest[i] = restitution ? restitution[i] : -1.0;
     w->col_rthr[i] = res_threshold ? res_threshold[i] : -1.0;
   }
-  w->colmat_dirty = true;
+  w->image_dirty = true;
   return RSB_OK;
 }
 int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min, double alpha_decay,
@@ -775,6 +809,7 @@ int rsb_get_field(rsb_world* w, int field, float* out, int space) {
 int rsb_set_control_mode(rsb_world* w, int mode) {
   if (!w || (mode != RSB_FORCE_AND_TORQUE && mode != RSB_PD_PLUS_FEEDFORWARD_TORQUE)) { rsb::set_error("rsb_set_control_mode: unknown mode"); return RSB_E_INVALID; }
   w->control_mode = mode;
+  w->image_dirty = true;
   return RSB_OK;
 }
 int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd) {
@@ -783,6 +818,8 @@ int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd) {
   HIP_TRY(hipMemcpyAsync(w->d_kp, kp, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
   HIP_TRY(hipMemcpyAsync(w->d_kd, kd, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
   HIP_TRY(hipStreamSynchronize(w->stream));
+  w->h_kp.assign(kp, kp + w->blob.nv); w->h_kd.assign(kd, kd + w->blob.nv);
+  w->image_dirty = true;
   return RSB_OK;
 }
 int rsb_set_pd_target(rsb_world* w, const float* p_target, const float* d_target, int space) {

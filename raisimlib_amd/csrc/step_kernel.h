@@ -463,6 +463,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();   // the by-value StepArgs sits at offset 0 of the kernarg segment
   RSB_ARGS(a);                                                     // the prologue's view (and the PROF-only fields)
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  long long t_entry = 0; if (PROF) t_entry = clock64();
   constexpr int EPW = 64 / LPE;
   const int lane = threadIdx.x;
   const int el = lane / LPE;
@@ -490,6 +491,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   float* DIR16 = lds + L.t_dir;                                  // float4 [16] slip-search brackets
   float* COLT = lds + L.t_col;                                   // [ncol][8] sphere centre (body frame), radius, body, mu, restitution, res_threshold
   int* KIDS = reinterpret_cast<int*>(lds + L.t_kids);            // [nb] child bodies, grouped by parent (DevModel::kid_start / kid_count)
+  int* KIDX = reinterpret_cast<int*>(lds + L.t_kidx);            // [nb] kid_start | kid_count << 16
   float* E = lds + L.shared_total + el * L.per_env;
   float* Q = E + L.q;
   float* U = E + L.u;
@@ -514,74 +516,79 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     for (int i = lane; i < a.lds_floats; i += 64) lds[i] = __int_as_float(0x7fc00000);
     __syncthreads();
   }
-  // ---- per-block tables -> LDS
-  for (int i = lane; i < nb * kModelSlot; i += 64) MODELF[i] = (&m.bodyf[0][0])[i];
-  for (int i = lane; i < nb; i += 64) {
-    PARLV[i] = (m.parent[i] + 1) | (m.level[i] << 8);
-    const bool pd = a.control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && i >= 1;
-    GAIN[2 * i] = pd ? a.kp[i + 5] : 0.f;
-    GAIN[2 * i + 1] = pd ? a.kd[i + 5] : 0.f;
+  // ---- prologue.  Every global load of the launch is issued before the first wait: a lone wave pays the full HBM / L2 latency
+  // (~500-900 cycles) for every dependent load -> wait -> store round, and the table-by-table staging this replaces was ten
+  // of them (15 k cycles, 5 % of a launch).
+  //   (1) this lane's share of the env's state rows -> registers (two elements per lane and array cover nq <= LPE + 6)
+  //   (2) the per-block tables: ONE image in the LDS layout (host side: build_lds_image), copied as float4
+  //   (3) the solver's warm records
+  const float* env_heights = a.heights;   // this env's height map (terrain curricula: rsb_set_heightmaps)
+  if (a.hm_index && a.terrain_type == 1) env_heights += (size_t)a.hm_index[env] * a.hm_xs * a.hm_ys;
+  float rq[2], rpt[2], ru[2], rdt[2], rtf[2], ract[2] = {0.f, 0.f}, ramean[2] = {0.f, 0.f}, wrec[8];
+  RSB_UNROLL for (int k = 0; k < 2; ++k) {
+    const int i = s + k * LPE;
+    rq[k] = rpt[k] = ru[k] = rdt[k] = rtf[k] = 0.f;
+    if (i < nq) {
+      rq[k] = a.gc[(size_t)env * nq + i];
+      rpt[k] = a.ptarget[(size_t)env * nq + i];
+      if (a.act && i >= 7) { ract[k] = a.act[(size_t)env * (nq - 7) + (i - 7)]; ramean[k] = a.act_mean[i - 7]; }
+    }
+    if (i < nv) {
+      ru[k] = a.gv[(size_t)env * nv + i];
+      rdt[k] = a.dtarget[(size_t)env * nv + i];
+      rtf[k] = a.tauff[(size_t)env * nv + i];
+    }
   }
-  for (int i = lane; i < nb * depth; i += 64) ANC[i] = m.anc[i];
-  for (int i = lane; i < nb; i += 64) KIDS[i] = m.kid_list[i];
-  for (int i = lane; i < ncol; i += 64) {
-    float ct[8] = {m.col_pos[i][0], m.col_pos[i][1], m.col_pos[i][2], m.col_pos[i][3], __int_as_float(m.col_body[i]),
-                   a.colmat[4 * i], a.colmat[4 * i + 1], a.colmat[4 * i + 2]};   // + the primitive's contact material: mu, restitution, res_threshold
-    stv<2>(COLT + 8 * i, ct);
-  }
-  if (lane < 16) {  // BR16[k] = {cos,sin((k-1) pi/8), cos,sin((k+1) pi/8)}: slip-search bracket around grid point k
-    float sn, cs, br[4];
-    sincospif((float)((lane + 15) & 15) * 0.125f, &sn, &cs);
-    br[0] = cs; br[1] = sn;
-    sincospif((float)((lane + 1) & 15) * 0.125f, &sn, &cs);
-    br[2] = cs; br[3] = sn;
-    st4(DIR16 + 4 * lane, br);
+  RSB_UNROLL for (int i = 0; i < 8; ++i) wrec[i] = 0.f;
+  if (a.warm && s < a.kmax) ldv<2>(a.warm + (size_t)env * kWarmRow + kWarmRec * s, wrec);
+  {
+    const float4* img = reinterpret_cast<const float4*>(a.lds_image);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    const int n4 = L.shared_total >> 2;
+    for (int i0 = 0; i0 < n4; i0 += 256) {     // four float4 per lane in flight
+      float4 v[4];
+      RSB_UNROLL for (int k = 0; k < 4; ++k) { const int i = i0 + lane + 64 * k; if (i < n4) v[k] = img[i]; }
+      RSB_UNROLL for (int k = 0; k < 4; ++k) { const int i = i0 + lane + 64 * k; if (i < n4) dst[i] = v[k]; }
+    }
   }
   // The Delassus rows start as zeros: the solver reads coupling blocks unconditionally (a block the current contact set
   // does not define is multiplied by a zero impulse change, so it only has to be finite, never NaN bit patterns)
-  for (int i = s; i < 3 * KMAX * L.gstride; i += LPE) G[i] = 0.f;
+  {
+    const float z4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 4 * s; i < 3 * KMAX * L.gstride; i += 4 * LPE) st4(G + i, z4);
+    for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
+  }
   float c16, s16;  // this lane's round-0 candidate direction of the slip search
   sincospif((float)(lane & 15) * 0.125f, &s16, &c16);
-
+  RSB_UNROLL for (int k = 0; k < 2; ++k) {
+    const int i = s + k * LPE;
+    if (i < nq) {
+      Q[i] = rq[k];
+      float pt = rpt[k];
+      if (a.act && i >= 7) {   // action -> joint target, two roundings as a host float expression (no FMA contraction)
+#pragma clang fp contract(off)
+        const float scaled = a.act_std * ract[k];
+        pt = ramean[k] + scaled;
+      }
+      PT[i] = pt;
+      if (a.ptarget_store && env_valid) a.ptarget_store[(size_t)env * nq + i] = pt;
+    }
+    if (i < nv) { U[i] = ru[k]; DTG[i] = rdt[k]; TF[i] = rtf[k]; }
+  }
+  __syncthreads();   // tables, state rows and the cleared warm table are in LDS
   // ---- per-lane body description (lane s = body s; the base is body 0 and is handled redundantly by every lane)
   const bool isbody = s >= 1 && s < nb;
   const int bb = isbody ? s : 0;
-  const int mylev = isbody ? m.level[bb] : -1;
-  const int mypar = m.parent[bb] < 0 ? 0 : m.parent[bb];
-  const int mykid = m.kid_start[bb] | (m.kid_count[bb] << 16);   // children of the own body: KIDS[start .. start + count)
-  const int nkid0 = m.kid_count[0];
+  const int mylev = isbody ? (PARLV[bb] >> 8) : -1;
+  const int mypar = max((PARLV[bb] & 0xff) - 1, 0);
+  const int mykid = KIDX[bb];                                    // children of the own body: KIDS[start .. start + count), start | count << 16
+  const int nkid0 = KIDX[0] >> 16;
   const int max_kid = m.max_kid;                                 // most children of one moving body (loop bound of the up pass)
-
-  // ---- state rows: HBM -> LDS
-  for (int i = s; i < nq; i += LPE) {
-    Q[i] = a.gc[(size_t)env * nq + i];
-    float pt = a.ptarget[(size_t)env * nq + i];
-    if (a.act && i >= 7) {   // action -> joint target, two roundings as a host float expression (no FMA contraction)
-#pragma clang fp contract(off)
-      const float scaled = a.act_std * a.act[(size_t)env * (nq - 7) + (i - 7)];
-      pt = a.act_mean[i - 7] + scaled;
-    }
-    PT[i] = pt;
-    if (a.ptarget_store && env_valid) a.ptarget_store[(size_t)env * nq + i] = pt;
-  }
-  for (int i = s; i < nv; i += LPE) {
-    U[i] = a.gv[(size_t)env * nv + i];
-    DTG[i] = a.dtarget[(size_t)env * nv + i];
-    TF[i] = a.tauff[(size_t)env * nv + i];
-  }
-  const float* env_heights = a.heights;   // this env's height map (terrain curricula: rsb_set_heightmaps)
-  if (a.hm_index && a.terrain_type == 1) env_heights += (size_t)a.hm_index[env] * a.hm_xs * a.hm_ys;
-  if (a.warm) {
+  if (a.warm && s < a.kmax) {
     // warm state: HBM holds one record per contact of the previous integrate() (not a row per primitive: 8 x 32 B instead of
     // ncol x 24 B per env and direction); scattered into the per-primitive LDS table the solver looks its contacts up in
-    for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
-    __syncthreads();
-    if (s < a.kmax) {
-      float rec[8];
-      ldv<2>(a.warm + (size_t)env * kWarmRow + kWarmRec * s, rec);
-      const int col = __float_as_int(rec[6]) - 1;
-      if (col >= 0 && col < ncol) { RSB_UNROLL for (int i = 0; i < 6; ++i) WARM[6 * col + i] = rec[i]; }
-    }
+    const int col = __float_as_int(wrec[6]) - 1;
+    if (col >= 0 && col < ncol) { RSB_UNROLL for (int i = 0; i < 6; ++i) WARM[6 * col + i] = wrec[i]; }
   }
   int flag = 0, iters_used = 0, nc = 0;
   int nc_real = 0;     // contacts of the last sub-step without the joint-limit rows that follow them in the solver
@@ -1474,7 +1481,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
-  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blk; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
+  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blk; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[14] = t_start - t_entry; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
   // ---- results: LDS -> HBM (with the optional control-step epilogue: observation block, reset of terminated envs)
   RSB_ARGS(ae);
   if (env_valid) {

@@ -45,7 +45,7 @@ struct DevModel {
 
 struct LdsLayout {
   // per-block tables (floats from the start of LDS)
-  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_kids, shared_total;
+  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_kids, t_kidx, shared_total;
   // per-env arrays (floats from the env base)
   int q, u, pt, dtg, tf, body, fact, wb, con, wc, cv, g, ginv, lam, warm;   // (the up pass's hand-over slots alias g)
   int gstride;
@@ -61,7 +61,8 @@ struct StepArgs {
   const float* tauff;
   const float* kp;
   const float* kd;
-  const float* colmat;         // [ncol][4] contact material of each collision primitive against the terrain: mu, restitution, res_threshold, pad
+  const float* lds_image;      // [L.shared_total] the per-block tables exactly as they sit in LDS (rsb_world.hip: build_lds_image): body constants,
+                               // PD gains, parent / level, ancestors, slip-search brackets, collision primitives + their materials, children lists
   rsb_contact* contacts;  // [N, kmax]
   int32_t* contact_count;
   int32_t* flags;

@@ -34,6 +34,7 @@ print(f"  (RSB_PROF_FINE=1) GS set-up cycles {np.median(P[:,8]):.0f} per launch-
 print(f"  (RSB_PROF_FINE=1) per pass: rule {np.median(P[:,11]/np.maximum(nsol,1)):.0f}, exchange {np.median(P[:,12]/np.maximum(nsol,1)):.0f}; per launch-wave: solver end (W^T lam scatter) {np.median(P[:,13]):.0f}")
 o = np.argsort(-t)[:20]
 print(f"slowest 20 waves: solves {nsol[o].mean():.0f} searches {ns[o].mean():.0f} newton {nn[o].mean():.0f} search cycles {tsr[o].mean():.0f} of GS {g[o].mean():.0f} of total {t[o].mean():.0f}")
+print(f"prologue (kernel entry -> state in LDS, not part of the wave totals above): median {np.median(P[:,14]):.0f} cycles, max {P[:,14].max()}")
 print("sweeps per launch-wave: median", np.median(it), "p99", np.percentile(it, 99), "max", it.max())
 
 # marginal costs by least squares over all sampled waves: GS cycles ~ c0 + c1*sweeps + c2*solves + c3*newton + c4*searches
