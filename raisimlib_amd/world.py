@@ -45,7 +45,10 @@ class Model:
     def __del__(self):
         h = getattr(self, "handle", None)
         if h:
-            lib().rsb_model_destroy(h)
+            try:
+                lib().rsb_model_destroy(h)
+            except Exception:      # interpreter shutdown: the module globals lib() needs may already be gone
+                pass
             self.handle = None
 
     nb = property(lambda self: self.blob.nb)

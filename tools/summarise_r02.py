@@ -33,7 +33,11 @@ for c, name, abytes in ((2, "config2", 456.0), (3, "config3", 520.0), (5, "confi
     f, kn = counters(f"pmc_fetch_c{c}"); w, _ = counters(f"pmc_write_c{c}")
     fetch_kb, write_kb = f["FETCH_SIZE"], w["WRITE_SIZE"]
     hbm = 1024.0 * (2.0 * fetch_kb + write_kb)
-    json.dump({"fetch_kb_per_launch_raw": fetch_kb, "write_kb_per_launch_raw": write_kb, "hbm_bytes_per_launch": hbm,
+    extra = {}
+    if c == 2:
+        ca, _ = counters("pmc_sq"); cb, _ = counters("pmc_sq2")
+        extra = {"counters": {**ca, **cb}}      # bench.py derives roofline.valu_issue from SQ_INSTS_VALU of this pass
+    json.dump({**extra, "fetch_kb_per_launch_raw": fetch_kb, "write_kb_per_launch_raw": write_kb, "hbm_bytes_per_launch": hbm,
                "note": "2 x FETCH_SIZE + WRITE_SIZE per launch, calibrated on known byte counts (profiles/r02_traffic_calibration.txt)",
                "kernel": kn, "workload": f"bench.py --no-cpu --config {c} --steps 50 --warmup 50 (4096 envs x 4 sub-steps per launch)"},
               open(os.path.join(P, f"{tag}_pmc_traffic" + ("" if c == 2 else f"_config{c}") + ".json"), "w"), indent=1)
