@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--stall-window", type=int, default=-1, help="diagnostic: solver stagnation window (library default 4)")
-    ap.add_argument("--freeze-after", type=int, default=-1, help="diagnostic: sweeps before friction directions lag (default 5)")
+    ap.add_argument("--freeze-after", type=int, default=-1, help="diagnostic: sweeps before friction directions lag (default 6)")
     ap.add_argument("--settle-tol", type=float, default=-1.0, help="diagnostic: settled-direction tolerance (default 1e-4 rad)")
     ap.add_argument("--early-termination", action="store_true",
                     help="NOT the headline workload: envs stop integrating at the sub-step of their first non-foot contact")
@@ -259,8 +259,8 @@ def main():
     if args.stall_window >= 0:
         world.set_solver_stagnation_exit(args.stall_window, 0.5)
     if args.freeze_after >= 0 or args.settle_tol >= 0:
-        world.set_solver_friction_lag(args.freeze_after if args.freeze_after >= 0 else 5, True,
-                                      args.settle_tol if args.settle_tol >= 0 else 1e-4)
+        world.set_solver_friction_lag(args.freeze_after if args.freeze_after >= 0 else 6, True,
+                                      args.settle_tol if args.settle_tol >= 0 else 0.0)
 
     # per-rank env shard: rank r owns global envs [r*N, (r+1)*N); every random number is a function of the global index
     off = rank * N

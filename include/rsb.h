@@ -176,7 +176,7 @@ int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_m
  * (defaults 4, 0.5; window = 0 disables it and only max_iter caps non-converging solves). */
 int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
 /* Lagged friction directions (not a RaiSim parameter): from sweep `freeze_after` on, a slipping contact keeps the
- * friction direction of its last slip solve and only re-solves the impulse magnitude (default 5; 0 = always
+ * friction direction of its last slip solve and only re-solves the impulse magnitude (default 6; 0 = always
  * re-optimise the direction).  Solves that converge within freeze_after sweeps are unaffected.
  * refine != 0 (default): before that, a contact that already slipped in this solve updates its direction by one
  * guarded Newton step on the curve's energy instead of a new global search (falls back to the search when the

@@ -71,7 +71,7 @@ struct rsb_world {
   // parameters
   double dt = 0.0025, gravity[3] = {0, 0, -9.81}, mu = 0.8, erp = 0.0;
   double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
-  int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 10, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
+  int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
   float hm_max = 0.f;
