@@ -312,6 +312,23 @@ __device__ __forceinline__ float row_sum_f32(float x) {
   x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, true));
   return x;
 }
+// 16-lane row maximum of an int (DPP row rotate)
+__device__ __forceinline__ int row_max_i32(int x) {
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x124, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x122, 0xf, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x121, 0xf, 0xf, false));
+  return x;
+}
+// maximum over the wave's envs of a value that is uniform within each env's LPE lanes: v_readlane of the groups' first lanes +
+// scalar max (a ds_bpermute shuffle costs a lone wave ~60 cycles per step, profiles/r02_ubench_lone_wave_latency.txt)
+template <int LPE>
+__device__ __forceinline__ int env_groups_max(int x) {
+  int m = __builtin_amdgcn_readlane(x, 0);
+  if constexpr (LPE <= 32) m = max(m, __builtin_amdgcn_readlane(x, 32));
+  if constexpr (LPE <= 16) { m = max(m, __builtin_amdgcn_readlane(x, 16)); m = max(m, __builtin_amdgcn_readlane(x, 48)); }
+  return m;
+}
 // compile-time loop (the index is needed as a template argument of row_bcast)
 template <int J, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -803,9 +820,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         nnear += __popcll(gm);
       }
       nnear = min(nnear, kHmSlots);
-      int nnw = nnear;
-      if (EPW > 1) { RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) nnw = max(nnw, __shfl_xor(nnw, off)); }
-      nnw = __builtin_amdgcn_readfirstlane(nnw);
+      const int nnw = env_groups_max<LPE>(nnear);
       __syncthreads();
       for (int k0 = 0; k0 < nnw; k0 += LPE / 4) {
         const int k = k0 + (s >> 2), t = s & 3;
@@ -886,11 +901,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       }
       if (dead) nc = 0;
     }
-    int ncw = nc;  // wave-wide maximum contact count (loop bounds must be wave-uniform)
-    if (EPW > 1) {
-      RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) ncw = max(ncw, __shfl_xor(ncw, off));
-    }
-    ncw = __builtin_amdgcn_readfirstlane(ncw);   // the same in every lane: tell the compiler, so that loops over it are scalar loops
+    const int ncw = env_groups_max<LPE>(nc);   // wave-wide maximum contact count (loop bounds must be wave-uniform scalars)
     RSB_STAMP(2)
 
     // =========================== up pass: articulated inertias + b column (lane = body) ==========
@@ -1174,30 +1185,32 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
               });
             }
           });
-          int gd = isc ? gpos + 1 : 1;
-          RSB_UNROLL for (int off = 1; off < 16; off <<= 1) gd = max(gd, __shfl_xor(gd, off));   // the env's largest group (contact lanes sit in one row)
+          const int gd = row_max_i32(isc ? gpos + 1 : 1);   // the env's largest group (contact lanes sit in the env's first row)
           light = gd >= kLightDepth;
-          RSB_UNROLL for (int off = 16; off < 64; off <<= 1) gd = max(gd, __shfl_xor(gd, off));
-          gdw = __builtin_amdgcn_readfirstlane(gd);
+          gdw = env_groups_max<LPE>(gd);
         }
 
         // exchange of impulse changes: lane i adds G_ij x_j for every contact j of its env (x_j broadcast from lane j of the
         // row).  Contacts 0-3 run as one straight block whatever the count (a slot its env does not use carries x = 0 against a
-        // finite, zero-initialised block); contacts 4-7 behind one nested scalar test each (the usual hard env has five), the
-        // rest in blocks of four.  The LDS reads of a block are issued before the previous block is consumed (two buffers).
-        float gbuf[2][4][3][4];
+        // finite, zero-initialised block) on coupling blocks held in registers; contacts 4-7 behind one nested scalar test each
+        // (the usual hard env has five), the rest in blocks of four.
+        float g0[4][3][4];            // coupling blocks with contacts 0-3: constant during the solve, read from LDS once
+        RSB_UNROLL for (int k = 0; k < 4; ++k)
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * k, g0[k][rr]);
+        float gbuf[2][4][3][4];       // contacts 4.. : fetched per pass (only envs with five or more contacts get here)
         auto load_block = [&](auto bc) {
           constexpr int b = decltype(bc)::value;
           RSB_UNROLL for (int k = 0; k < 4; ++k)
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (4 * b + k), gbuf[b & 1][k][rr]);
         };
-        auto exchange = [&](const float (&x)[3], float& emax) {   // the caller has issued load_block(0)
+        auto exchange = [&](const float (&x)[3], float& emax) {
           auto one = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             float l0[3] = {x[0], x[1], x[2]};
             row_bcast_n<j, 3>(l0);
+            const float (&gj)[3][4] = j < 4 ? g0[j & 3] : gbuf[(j / 4) & 1][j & 3];
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-              v[rr] = fmaf(gbuf[(j / 4) & 1][j & 3][rr][2], l0[2], fmaf(gbuf[(j / 4) & 1][j & 3][rr][1], l0[1], fmaf(gbuf[(j / 4) & 1][j & 3][rr][0], l0[0], v[rr])));
+              v[rr] = fmaf(gj[rr][2], l0[2], fmaf(gj[rr][1], l0[1], fmaf(gj[rr][0], l0[0], v[rr])));
             emax = fmaxf(emax, fmaxf(fabsf(l0[0]), fmaxf(fabsf(l0[1]), fabsf(l0[2]))));
           };
           const bool more = ncw > 4;
@@ -1237,7 +1250,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
           if (__any(isc && (lam[0] != 0.f || lam[1] != 0.f || lam[2] != 0.f))) {
             // v = c + G lam(0): one exchange of the inherited impulses (v carries the own impulse as well)
-            load_block(std::integral_constant<int, 0>{});
             float unused = 0.f;
             exchange(lam, unused);
           }
@@ -1264,7 +1276,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           float err = 0.f;
           for (int kp = 0; kp < gdw; ++kp) {
             long long tr0 = 0; if (PROF && a.prof && a.prof_fine) tr0 = clock64();
-            load_block(std::integral_constant<int, 0>{});            // the exchange's first coupling blocks arrive behind the rule
             const bool mine = isc & !done & (gpos == kp);
             if (PROF && a.prof) ++p_solves;
             // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
