@@ -613,6 +613,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   int nc_dead = 0;
   long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0, t_rule = 0, t_exch = 0, t_end = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
   if (PROF && a.prof) t_start = clock64();
+  const bool pfine = PROF && a.prof && a.prof_fine;   // fine stamps: one clock read per boundary, each interval is charged to one accumulator
+  long long t_prev = 0, t_mag = 0;
+  auto lap = [&](long long& acc) { if (PROF && pfine) { const long long t = clock64(); acc += t - t_prev; t_prev = t; } };
   float pbx = 0.f, pby = 0.f, pbz = 0.f;
   const float dt = a.dt;
   const int nsub = a.nsub, kmax = a.kmax;
@@ -1254,7 +1257,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             exchange(lam, unused);
           }
         }
-        if (PROF && a.prof && a.prof_fine) t_setup += clock64() - t_gs0;
+        if (PROF && pfine) { t_prev = t_gs0; lap(t_setup); }
 
         // global search of contact j's direction by its 16-lane row (coefficients broadcast from lane j)
         auto search_row = [&](int j, const SlipCoef& kc, bool take) {
@@ -1275,7 +1278,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           const bool lag = freeze_after > 0 && it >= freeze_after;   // lagged directions: a usable direction of this solve is no longer refreshed
           float err = 0.f;
           for (int kp = 0; kp < gdw; ++kp) {
-            long long tr0 = 0; if (PROF && a.prof && a.prof_fine) tr0 = clock64();
             const bool mine = isc & !done & (gpos == kp);
             if (PROF && a.prof) ++p_solves;
             // v holds the velocity WITH the own impulse: lam_stick = lam - G_ii^-1 v, v_n without it = v_n - G_ii[n,:] lam
@@ -1293,9 +1295,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             bool need = refr & slip & !keep;
             // a member of a light pass keeps its direction; without a usable one (it started to slip after pass 0) it searches
             const bool lost = mine & slip & !refr & !usable;
-            if (PROF && a.prof && a.prof_fine) t_rule += clock64() - tr0;
+            lap(t_rule);
             if (__any(need | lost)) {
-              long long ta0 = 0; if (PROF && a.prof && a.prof_fine) ta0 = clock64();
               SlipCoef kc;
               kc = sc;
               {
@@ -1326,7 +1327,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
                 for (int j = 0; j < ncw; ++j)
                   if (__any(need && s == j)) search_row(j, kc, need && s == j);
               }
-              if (PROF && a.prof && a.prof_fine) t_newt += clock64() - ta0;
+              lap(t_newt);
             }
             // impulse along the direction: v_n^+ = 0 on the cone boundary
             const float den = fmaf(sc.a2, sdy, fmaf(sc.a1, sdx, sc.a0));
@@ -1341,9 +1342,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
               dl[rr] = mine ? alpha * (ln[rr] - lam[rr]) : 0.f;
               lam[rr] += dl[rr];
             }
-            long long tx0 = 0; if (PROF && a.prof && a.prof_fine) tx0 = clock64();
+            lap(t_mag);
             exchange(dl, err);
-            if (PROF && a.prof && a.prof_fine) t_exch += clock64() - tx0;
+            lap(t_exch);
           }
           // an inherited direction that the first sweep did not pick up is dropped (oracle: same rule): a contact that starts
           // to slip later in the solve runs the global search
@@ -1351,7 +1352,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           // ---------------- convergence: relative (fp32-aware) test and stagnation exit, identical to the oracle's
           // (rsb_oracle.c), written with selects (every lane of the env carries the same err / scale)
           const float scale = row_max_f32(isc ? lam[2] : 0.f);   // largest normal impulse of the env (contact lanes sit in the group's first row)
-          long long te0 = 0; if (PROF && a.prof && a.prof_fine) te0 = clock64();
           {
             const bool live = !done;
             iters_used += live ? 1 : 0;
@@ -1374,10 +1374,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             converged |= conv_now;
             done |= conv_now | stalled;
           }
-          if (PROF && a.prof && a.prof_fine) t_epi += clock64() - te0;
+          lap(t_epi);
           if (!__any(!done)) break;
         }
-        if (PROF && a.prof && a.prof_fine) tz0 = clock64();
+        if (PROF && pfine) tz0 = t_prev;
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
         if (isc) {
           LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2];
@@ -1418,7 +1418,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
       }
       __syncthreads();
-      if (PROF && a.prof && a.prof_fine) t_end += clock64() - tz0;
+      if (PROF && pfine) t_end += clock64() - tz0;
       if (PROF && a.prof) { t_gs += clock64() - t_gs0; int itw = iters_used; RSB_UNROLL for (int off = LPE; off < 64; off <<= 1) itw = max(itw, __shfl_xor(itw, off)); p_iters += itw; p_ncw = max(p_ncw, ncw); }
       if (PROF && a.dbg && env == a.dbg_env && env_valid && s == 0) {
         const int n3 = 3 * nc_real;
@@ -1492,7 +1492,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     if (PROF && a.prof && blockIdx.x == 0 && lane == 0 && sub == a.nsub - 1) { a.prof[8] = iters_used; a.prof[9] = ncw; }
   }  // substeps
 
-  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blk; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[14] = t_start - t_entry; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
+  if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blk; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[14] = t_start - t_entry; P[15] = t_mag; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
   // ---- results: LDS -> HBM (with the optional control-step epilogue: observation block, reset of terminated envs)
   RSB_ARGS(ae);
   if (env_valid) {

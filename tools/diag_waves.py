@@ -31,7 +31,7 @@ print("GS cycles per sweep (median) by ncw:", {int(k): int(np.median((g[sw & (nc
 ns, nn, nsol, tsr = P[:, 4], P[:, 5], P[:, 6], P[:, 7]
 print(f"per launch-wave medians: contact solves {np.median(nsol):.0f}, global searches {np.median(ns):.0f}, newton blocks {np.median(nn):.0f}, cycles in searches {np.median(tsr):.0f} ({np.median(tsr/np.maximum(g,1)):.2f} of GS), cycles/search {np.median(tsr/np.maximum(ns,1)):.0f}")
 print(f"  (RSB_PROF_FINE=1) GS set-up cycles {np.median(P[:,8]):.0f} per launch-wave; phase (A) direction refresh {np.median(P[:,9]):.0f} = {np.median(P[:,9]/np.maximum(it,1)):.0f} per sweep; phase (C) sweep epilogue {np.median(P[:,10]):.0f} = {np.median(P[:,10]/np.maximum(it,1)):.0f} per sweep; phase (B) = rest = {np.median((g-P[:,8]-P[:,9]-P[:,10])/np.maximum(nsol,1)):.0f} per contact solve (incl. the W^T lam scatter)")
-print(f"  (RSB_PROF_FINE=1) per pass: rule {np.median(P[:,11]/np.maximum(nsol,1)):.0f}, exchange {np.median(P[:,12]/np.maximum(nsol,1)):.0f}; per launch-wave: solver end (W^T lam scatter) {np.median(P[:,13]):.0f}")
+print(f"  (RSB_PROF_FINE=1, chained stamps) per pass: rule {np.median(P[:,11]/np.maximum(nsol,1)):.0f}, magnitude + dl {np.median(P[:,15]/np.maximum(nsol,1)):.0f}, exchange {np.median(P[:,12]/np.maximum(nsol,1)):.0f}; per launch-wave: solver end (W^T lam scatter) {np.median(P[:,13]):.0f}")
 o = np.argsort(-t)[:20]
 print(f"slowest 20 waves: solves {nsol[o].mean():.0f} searches {ns[o].mean():.0f} newton {nn[o].mean():.0f} search cycles {tsr[o].mean():.0f} of GS {g[o].mean():.0f} of total {t[o].mean():.0f}")
 print(f"prologue (kernel entry -> state in LDS, not part of the wave totals above): median {np.median(P[:,14]):.0f} cycles, max {P[:,14].max()}")
