@@ -418,7 +418,11 @@ def main():
                            "env_age_control_steps_p10_p50_p90_p99": age_pct,
                            "sampled_over_control_steps": SAMPLE_LAUNCHES},
                 "envs_per_gpu": N, "substeps_per_step": workload.SUBSTEPS,
-                "contact_solver": {"max_iter": args.max_iter or 150, "threshold_rel": 1e-5, "alpha": [1.0, 1.0, 1.0]},
+                "contact_solver": {"max_iter": args.max_iter or 150, "threshold_rel": 1e-5, "alpha": [1.0, 1.0, 1.0],
+                                   "sweep": "grouped (block Jacobi across limbs, Gauss-Seidel within a limb)",
+                                   "friction_directions_lag_after_sweeps": args.freeze_after if args.freeze_after >= 0 else 6,
+                                   "stagnation_exit": {"window": args.stall_window if args.stall_window >= 0 else 4, "factor": 0.5},
+                                   "warm_start": True},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
                 "obs_all_gather": gath.describe(),
             },
