@@ -304,8 +304,11 @@ class HeightMap {
 class ArticulatedSystem {
  public:
   ArticulatedSystem(BatchedWorld* w, int env) : w_(w), env_(env), gc_(w->gcDim()), gv_(w->dof()) {}
-  size_t getGeneralizedCoordinateDim() const { return (size_t)w_->gcDim(); }
-  size_t getDOF() const { return (size_t)w_->dof(); }
+  /// fixed-base systems (URDF root link "world") expose the joints only, as upstream does: gcDim = dof = number of joints.
+  /// (The batch keeps 7 + 6 inert base entries in front of them; putRow / getRow below pad and strip.)
+  bool isFixedBase() const { return w_->blob().fixed_base != 0; }
+  size_t getGeneralizedCoordinateDim() const { return (size_t)(w_->gcDim() - gcOff()); }
+  size_t getDOF() const { return (size_t)(w_->dof() - gvOff()); }
   void setName(const std::string& n) { name_ = n; }
   const std::string& getName() const { return name_; }
   double getTotalMass() const { return rsb_model_total_mass(w_->model()); }
@@ -333,8 +336,9 @@ class ArticulatedSystem {
   }
   /// gains are shared by all replicas of the batched world (one robot model, one controller tuning)
   void setPdGains(const VecDyn& p, const VecDyn& d) {
-    std::vector<float> kp(p.v.begin(), p.v.end()), kd(d.v.begin(), d.v.end());
-    RSFATAL_IF((int)kp.size() != w_->dof() || (int)kd.size() != w_->dof(), "setPdGains: gain vectors must have DOF entries");
+    RSFATAL_IF(p.size() != getDOF() || d.size() != getDOF(), "setPdGains: gain vectors must have DOF entries");
+    std::vector<float> kp((size_t)w_->dof(), 0.f), kd((size_t)w_->dof(), 0.f);     // (a fixed base's six inert entries lead the batch's rows)
+    for (size_t i = 0; i < p.size(); ++i) { kp[gvOff() + i] = (float)p[i]; kd[gvOff() + i] = (float)d[i]; }
     w_->setPdGains(kp.data(), kd.data());
   }
   void setPdTarget(const VecDyn& pTarget, const VecDyn& dTarget) { putRow(RSB_F_PTARGET, pTarget); putRow(RSB_F_DTARGET, dTarget); }
@@ -342,15 +346,16 @@ class ArticulatedSystem {
 
   /// valid after World::integrate1() (upstream semantics): M(q) and h(q,u) of this env
   const MatDyn& getMassMatrix() {
-    const int nv = w_->dof();
+    const int nv = w_->dof(), o = gvOff();
     std::vector<float> M((size_t)w_->numEnvs() * nv * nv);
     RSB_CHECK(rsb_get_mass_matrix(w_->handle(), M.data(), RSB_HOST));
-    M_.resize(nv, nv);
-    for (int i = 0; i < nv; ++i) for (int j = 0; j < nv; ++j) M_(i, j) = M[((size_t)env_ * nv + i) * nv + j];
+    M_.resize(nv - o, nv - o);
+    for (int i = o; i < nv; ++i) for (int j = o; j < nv; ++j) M_(i - o, j - o) = M[((size_t)env_ * nv + i) * nv + j];
     return M_;
   }
   const MatDyn& getInverseMassMatrix() {
-    const int nv = w_->dof();
+    const int nv = w_->dof(), o = gvOff();
+    RSFATAL_IF(o != 0, "getInverseMassMatrix: not available for fixed-base systems (the batch inverts the floating-base matrix)");
     std::vector<float> Mi((size_t)w_->numEnvs() * nv * nv);
     RSB_CHECK(rsb_get_inverse_mass_matrix(w_->handle(), Mi.data(), RSB_HOST));
     Minv_.resize(nv, nv);
@@ -358,11 +363,11 @@ class ArticulatedSystem {
     return Minv_;
   }
   const VecDyn& getNonlinearities(const Vec<3>& /*gravity*/ = Vec<3>()) {
-    const int nv = w_->dof();
+    const int nv = w_->dof(), o = gvOff();
     std::vector<float> h((size_t)w_->numEnvs() * nv);
     RSB_CHECK(rsb_get_nonlinearities(w_->handle(), h.data(), RSB_HOST));
-    h_.resize(nv);
-    for (int i = 0; i < nv; ++i) h_[i] = h[(size_t)env_ * nv + i];
+    h_.resize(nv - o);
+    for (int i = o; i < nv; ++i) h_[i - o] = h[(size_t)env_ * nv + i];
     return h_;
   }
   /// contacts of the last integrate() of this env
@@ -395,23 +400,23 @@ class ArticulatedSystem {
   /// clearExternalForces() (or setGeneralizedForce) to remove it.
   void setExternalForce(size_t body, const Vec<3>& force) {
     MatDyn J; jac(body, J, false);
-    VecDyn tau((size_t)w_->dof());
+    VecDyn tau(getDOF());
     getRow(RSB_F_TAU_FF, tau, w_->dof());
-    for (int d = 0; d < w_->dof(); ++d) tau[d] += J(0, d) * force[0] + J(1, d) * force[1] + J(2, d) * force[2];
+    for (int d = 0; d < (int)getDOF(); ++d) tau[d] += J(0, d) * force[0] + J(1, d) * force[1] + J(2, d) * force[2];
     putRow(RSB_F_TAU_FF, tau);
   }
   /// External torque (world frame) on `body`: generalized force J_rot^T t, same lifetime rule as setExternalForce
   void setExternalTorque(size_t body, const Vec<3>& torque) {
     MatDyn J; jac(body, J, true);
-    VecDyn tau((size_t)w_->dof());
+    VecDyn tau(getDOF());
     getRow(RSB_F_TAU_FF, tau, w_->dof());
-    for (int d = 0; d < w_->dof(); ++d) tau[d] += J(0, d) * torque[0] + J(1, d) * torque[1] + J(2, d) * torque[2];
+    for (int d = 0; d < (int)getDOF(); ++d) tau[d] += J(0, d) * torque[0] + J(1, d) * torque[1] + J(2, d) * torque[2];
     putRow(RSB_F_TAU_FF, tau);
   }
-  void clearExternalForces() { VecDyn tau((size_t)w_->dof()); putRow(RSB_F_TAU_FF, tau); }
+  void clearExternalForces() { VecDyn tau(getDOF()); putRow(RSB_F_TAU_FF, tau); }
 
   void getBaseOrientation(Mat<3, 3>& rot) {
-    const VecDyn& q = getGeneralizedCoordinate();
+    const VecDyn& q = fullGc();
     const double w = q[3], x = q[4], y = q[5], z = q[6];
     rot(0, 0) = 1 - 2 * (y * y + z * z); rot(0, 1) = 2 * (x * y - w * z);     rot(0, 2) = 2 * (x * z + w * y);
     rot(1, 0) = 2 * (x * y + w * z);     rot(1, 1) = 1 - 2 * (x * x + z * z); rot(1, 2) = 2 * (y * z - w * x);
@@ -419,21 +424,34 @@ class ArticulatedSystem {
   }
 
  private:
+  const VecDyn& fullGc() { fullq_.resize(w_->gcDim()); w_->readRow(RSB_F_GC, env_, fullq_.data(), w_->gcDim()); return fullq_; }   // incl. the base entries of a fixed-base system
+  int gcOff() const { return isFixedBase() ? 7 : 0; }
+  int gvOff() const { return isFixedBase() ? 6 : 0; }
   void putRow(int field, const VecDyn& v) {
-    const int dim = (field == RSB_F_GC || field == RSB_F_PTARGET) ? w_->gcDim() : w_->dof();
-    RSFATAL_IF((int)v.size() != dim, "ArticulatedSystem: vector has the wrong dimension");
-    w_->stageRow(field, env_, v.data(), dim);
+    const bool isq = field == RSB_F_GC || field == RSB_F_PTARGET;
+    const int dim = isq ? w_->gcDim() : w_->dof(), off = isq ? gcOff() : gvOff();
+    RSFATAL_IF((int)v.size() != dim - off, "ArticulatedSystem: vector has the wrong dimension");
+    if (off == 0) { w_->stageRow(field, env_, v.data(), dim); return; }
+    std::vector<double> full((size_t)dim, 0.0);          // fixed base: identity pose / zero velocity in front of the joints
+    if (isq) full[3] = 1.0;
+    for (int i = off; i < dim; ++i) full[i] = v[i - off];
+    w_->stageRow(field, env_, full.data(), dim);
   }
   void getRow(int field, VecDyn& v, int dim) {
-    v.resize(dim);
-    w_->readRow(field, env_, v.data(), dim);
+    const bool isq = field == RSB_F_GC || field == RSB_F_PTARGET;
+    const int off = isq ? gcOff() : gvOff();
+    if (off == 0) { v.resize(dim); w_->readRow(field, env_, v.data(), dim); return; }
+    std::vector<double> full((size_t)dim);
+    w_->readRow(field, env_, full.data(), dim);
+    v.resize(dim - off);
+    for (int i = off; i < dim; ++i) v[i - off] = full[i];
   }
   // host forward kinematics of this env (world frame): fkR_ [nb][9] row-major, fkP_ [nb][3], fkA_ [nb][3] joint axes
   void fk() {
     const rsb_model_blob& b = w_->blob();
-    const VecDyn& q = getGeneralizedCoordinate();
-    fkR_.assign(9 * b.nb, 0.0); fkP_.assign(3 * b.nb, 0.0); fkA_.assign(3 * b.nb, 0.0);
     Mat<3, 3> R0; getBaseOrientation(R0);
+    const VecDyn& q = fullGc();
+    fkR_.assign(9 * b.nb, 0.0); fkP_.assign(3 * b.nb, 0.0); fkA_.assign(3 * b.nb, 0.0);
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) fkR_[3 * r + c] = R0(r, c);
     for (int c = 0; c < 3; ++c) fkP_[c] = q[c];
     for (int i = 1; i < b.nb; ++i) {
@@ -491,6 +509,11 @@ class ArticulatedSystem {
         for (int c = 0; c < 3; ++c) J(c, d) = a[c];
       }
     }
+    if (isFixedBase()) {     // upstream's Jacobians of a fixed-base system have one column per joint
+      MatDyn Jj; Jj.resize(3, nv - 6);
+      for (int c = 0; c < 3; ++c) for (int d = 6; d < nv; ++d) Jj(c, d - 6) = J(c, d);
+      J = Jj;
+    }
   }
   void mulJ(const MatDyn& J, Vec<3>& out) {
     const VecDyn& u = getGeneralizedVelocity();
@@ -499,7 +522,7 @@ class ArticulatedSystem {
   BatchedWorld* w_;
   int env_;
   std::string name_;
-  VecDyn gc_, gv_, h_;
+  VecDyn gc_, gv_, h_, fullq_;
   std::vector<double> fkR_, fkP_, fkA_;
   MatDyn M_, Minv_;
   std::vector<Contact> contacts_;

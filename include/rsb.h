@@ -86,7 +86,9 @@ typedef enum rsb_joint_type { RSB_JOINT_FLOATING = 0, RSB_JOINT_REVOLUTE = 1, RS
  * produces); every collision primitive is therefore a sphere.
  */
 typedef struct rsb_model_blob {
-  int32_t nb, nq, nv, ncol, depth, reserved;
+  int32_t nb, nq, nv, ncol, depth;
+  int32_t fixed_base;   /* != 0: body 0 does not move (a URDF whose root link is named "world" [RECALL RaiSim's convention]); gc / gv keep their 7 / 6 base
+                           entries (ignored on input, constant on output), the joints follow as usual */
   int32_t parent[RSB_MAX_BODIES];
   int32_t level[RSB_MAX_BODIES];
   int32_t jtype[RSB_MAX_BODIES];

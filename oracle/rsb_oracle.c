@@ -840,6 +840,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   double h[MAXV], tau[MAXV], ufree[MAXV];
   int pd[MAXV], fl = 0;
 
+  if (m->fixed_base) for (int d = 0; d < 6; ++d) u[d] = 0.0;   /* a fixed base has no velocity, whatever the caller's row says */
   /* integrate1: kinematics, collision detection, M, h */
   kinematics(m, q, u, k);
   crba(m, k, M);
@@ -848,6 +849,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     double bdiag[MAXV];
     actuation_impl(m, p, q, u, kp, kd, p_target, d_target, tau_ff, tau, bdiag);
     for (int d = 6; d < nv; ++d) M[d * nv + d] += bdiag[d];   /* implicit PD: see actuation_impl */
+    if (m->fixed_base) for (int d = 0; d < 6; ++d) M[d * nv + d] += 1e30;   /* fixed base = a base of (numerically) infinite inertia */
   }
 
   int nc = 0;

@@ -23,7 +23,7 @@ _B, _S = RSB_MAX_BODIES, RSB_MAX_COLLISIONS
 class ModelBlob(C.Structure):
     _fields_ = [
         ("nb", C.c_int32), ("nq", C.c_int32), ("nv", C.c_int32), ("ncol", C.c_int32), ("depth", C.c_int32),
-        ("reserved", C.c_int32),
+        ("fixed_base", C.c_int32),
         ("parent", C.c_int32 * _B), ("level", C.c_int32 * _B), ("jtype", C.c_int32 * _B),
         ("axis", (C.c_double * 3) * _B), ("ptree", (C.c_double * 3) * _B), ("rtree", (C.c_double * 9) * _B),
         ("mass", C.c_double * _B), ("com", (C.c_double * 3) * _B), ("inertia", (C.c_double * 6) * _B),

@@ -105,6 +105,7 @@ void build_dev_model(const rsb_model_blob& b, DevModel* d) {
   std::memset(d, 0, sizeof *d);
   d->nb = b.nb; d->nq = b.nq; d->nv = b.nv; d->ncol = b.ncol; d->depth = b.depth;
   d->cw = round4(6 + b.depth - 1);
+  d->fixed_base = b.fixed_base;
   std::vector<std::vector<int>> kids(b.nb);
   for (int i = 0; i < b.nb; ++i) {
     d->parent[i] = b.parent[i]; d->level[i] = b.level[i]; d->jtype[i] = b.jtype[i];

@@ -590,7 +590,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       PT[i] = pt;
       if (a.ptarget_store && env_valid) a.ptarget_store[(size_t)env * nq + i] = pt;
     }
-    if (i < nv) { U[i] = ru[k]; DTG[i] = rdt[k]; TF[i] = rtf[k]; }
+    if (i < nv) { U[i] = (m.fixed_base && i < 6) ? 0.f : ru[k]; DTG[i] = rdt[k]; TF[i] = rtf[k]; }   // (a fixed base has no velocity, whatever the row says)
   }
   __syncthreads();   // tables, state rows and the cleared warm table are in LDS
   // ---- per-lane body description (lane s = body s; the base is body 0 and is handled redundantly by every lane)
@@ -971,6 +971,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           else C[sym6(i, j)] = sacc * idg[j];
         }
       }
+      // a fixed base is a base of infinite inertia: with 1 / diag(C) = 0 every base entry of the contact columns, of W_b and of
+      // the velocity update vanishes, and nothing else in the step has to know
+      if (m.fixed_base) { RSB_UNROLL for (int i = 0; i < 6; ++i) idg[i] = 0.f; }
       float tb[8];
       ldv<2>(TF, tb);
       RSB_UNROLL for (int i = 0; i < 6; ++i) {

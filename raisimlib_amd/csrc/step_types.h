@@ -29,7 +29,7 @@ constexpr int kHmSlots = 16;          // spheres per env the height-map narrow p
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
-  int max_kid, reserved[3];         // most children of one MOVING body (the base's children are counted in kid_count[0])
+  int max_kid, fixed_base, reserved[2];   // most children of one MOVING body (the base's are counted in kid_count[0]); fixed base: body 0 never moves
   int parent[kMaxB], level[kMaxB], jtype[kMaxB];
   int anc[kMaxB * kMaxB];           // anc[b*depth + l] = ancestor of b at level l (l <= level[b]), else -1
   int kid_start[kMaxB], kid_count[kMaxB], kid_list[kMaxB];  // children of each body: kid_list[kid_start[b] .. + kid_count[b]); the base's lead the list

@@ -7,7 +7,7 @@
 // Supported subset: <link>/<inertial>/<collision> with <sphere>, <capsule>, <box> (its 8 corners) and <cylinder>
 // (the inscribed capsule) geometry,
 // <joint type="revolute|continuous|prismatic|fixed">, <origin xyz rpy>, <axis>, <limit>,
-// <dynamics damping rotor_inertia>.  The root link is the floating base.  <mesh filename=.. scale=..> collision geometry
+// <dynamics damping rotor_inertia>.  The root link is the floating base, or - when it is named "world" - a fixed base.  <mesh filename=.. scale=..> collision geometry
 // (Wavefront OBJ, binary / ASCII STL; path relative to the URDF file, "package://" / "file://" prefixes stripped to the
 // longest existing suffix) becomes a POINT SET: up to kMeshPoints vertices of the mesh's convex hull (support vertices of
 // the body diagonals, axes and face diagonals), each a zero-radius sphere - against a plane this is the contact set of a
@@ -381,6 +381,10 @@ struct Builder {
   void finish_inertia() {
     for (int b = 0; b < blob.nb; ++b) {
       Acc& a = acc[b];
+      if (a.m <= 0 && b == 0 && blob.fixed_base) {   // a massless "world" root: any positive inertia will do, it is never used as a finite one
+        blob.mass[0] = 1.0; blob.inertia[0][0] = blob.inertia[0][3] = blob.inertia[0][5] = 1.0;
+        continue;
+      }
       if (a.m <= 0) throw std::runtime_error(std::string("URDF: moving body '") + blob.body_name[b] + "' has no mass");
       V3 c = (1.0 / a.m) * a.mc;
       double I[9] = {0};
@@ -504,7 +508,9 @@ static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* ski
       rootl = (int)l;
     }
   if (rootl < 0) throw std::runtime_error("URDF: no root link");
-  if (B.links[rootl].name == "world") throw std::runtime_error("URDF: fixed-base systems (root link 'world') are outside the supported subset");
+  // RaiSim's convention [RECALL]: a root link named "world" makes the system fixed-base.  The root body then never moves (the
+  // step treats its inertia as infinite); it keeps the 7 + 6 base entries of gc / gv, which stay at the identity pose and zero.
+  B.blob.fixed_base = B.links[rootl].name == "world" ? 1 : 0;
   B.blob.nb = 1; B.blob.depth = 1;
   B.blob.parent[0] = -1; B.blob.level[0] = 0; B.blob.jtype[0] = RSB_JOINT_FLOATING;
   B.blob.q_lower[0] = -1e30; B.blob.q_upper[0] = 1e30;

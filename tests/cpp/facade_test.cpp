@@ -277,6 +277,41 @@ int main(int argc, char** argv) {
       }
       std::printf("material pairs: rubber on concrete / ice slide at their own mu\n");
     }
+
+    // ---- fixed-base system (URDF root link "world"): the facade exposes the joints only, as upstream does
+    {
+      const char* arm = "<robot name=\"arm\"><link name=\"world\"/>"
+                        "<link name=\"bob\"><inertial><origin xyz=\"0 0 -0.5\"/><mass value=\"1\"/>"
+                        "<inertia ixx=\"1e-9\" ixy=\"0\" ixz=\"0\" iyy=\"1e-9\" iyz=\"0\" izz=\"1e-9\"/></inertial></link>"
+                        "<joint name=\"hinge\" type=\"revolute\"><origin xyz=\"0 0 2\"/><parent link=\"world\"/><child link=\"bob\"/><axis xyz=\"0 1 0\"/>"
+                        "<limit effort=\"0\" velocity=\"100\" lower=\"-10\" upper=\"10\"/></joint></robot>";
+      const std::string path = "/tmp/rsb_facade_arm.urdf";
+      { FILE* f = std::fopen(path.c_str(), "w"); CHECK(f != nullptr); std::fputs(arm, f); std::fclose(f); }
+      raisim::World w;
+      w.setTimeStep(0.0025);
+      auto* a = w.addArticulatedSystem(path);
+      w.addGround(-5.0);
+      CHECK(a->isFixedBase() && a->getGeneralizedCoordinateDim() == 1 && a->getDOF() == 1);
+      a->setControlMode(raisim::ControlMode::FORCE_AND_TORQUE);
+      raisim::VecDyn q(1), u(1);
+      q[0] = 0.05;
+      a->setState(q, u);
+      w.integrate1();
+      const auto& M = a->getMassMatrix();
+      CHECK(M.rows() == 1 && std::fabs(M(0, 0) - 0.25) < 1e-4);                    // m l^2
+      raisim::Vec<3> p; a->getFramePosition(1, p);
+      CHECK(std::fabs(p[2] - 2.0) < 1e-9);                                          // the hinge sits where the fixed base put it
+      double prev = 0.05, t = 0, t0 = -1, t1 = -1;
+      for (int i = 0; i < 1300; ++i) {
+        w.integrate();
+        t += 0.0025;
+        const double qi = a->getGeneralizedCoordinate()[0];
+        if (prev > 0 && qi <= 0) { const double tc = t - 0.0025 * qi / (qi - prev); if (t0 < 0) t0 = tc; else if (t1 < 0) t1 = tc; }
+        prev = qi;
+      }
+      CHECK(t1 > t0 && std::fabs((t1 - t0) / (2 * M_PI * std::sqrt(0.5 / 9.81)) - 1.0) < 1e-2);
+      std::printf("fixed base: 1-DoF pendulum period %.4f s\n", t1 - t0);
+    }
   } catch (const std::exception& e) {
     std::printf("exception: %s\n", e.what());
     return 1;

@@ -202,3 +202,22 @@ def test_sphere_beside_a_ridge_touches_the_edge_not_the_flank(built_lib):
     cnt, con = w.get_contacts()
     assert (cnt == 1).all() and abs(con[5][0]["depth"] - 0.1) < 2e-6 and np.allclose(con[5][0]["normal"], [0, 0, 1], atol=2e-6)
     w.close()
+
+
+def test_fixed_base_pendulum_period(built_lib):
+    from test_oracle_kat import FIXED_PENDULUM
+    l = 0.5
+    mod, w = world(FIXED_PENDULUM.format(l=l, m=1.0), mode=0)
+    assert mod.blob.fixed_base == 1
+    g0 = np.array([0, 0, 0, 1, 0, 0, 0, 0.05]); u0 = np.zeros(7); u0[:6] = 0.3
+    w.set_state(tile(g0), tile(u0))
+    zero, prev, t = [], 0.05, 0.0
+    for k in range(600):
+        w.integrate(4)
+        q, u = w.get_state()
+        t += 4 * DT
+        if prev > 0 >= q[0, 7]: zero.append(t - 4 * DT * q[0, 7] / (q[0, 7] - prev))
+        prev = q[0, 7]
+    assert np.allclose(q[:, :7], [0, 0, 0, 1, 0, 0, 0], atol=1e-7) and np.abs(u[:, :6]).max() < 1e-7
+    assert abs(np.diff(zero).mean() / (2 * np.pi * np.sqrt(l / G)) - 1) < 1e-2
+    w.close()

@@ -88,7 +88,6 @@ def test_single_body_model(built_lib):
     ("<robot name='r'><link name='a'/><joint name='j' type='revolute'><parent link='a'/><child link='zz'/></joint></robot>", "unknown link"),
     ("<robot name='r'><link name='a'/><link name='b'/></robot>", "more than one root"),
     ("<robot name='r'><link name='a'/><link name='b'/><joint name='j' type='planar'><parent link='a'/><child link='b'/></joint></robot>", "unsupported joint type"),
-    ("<robot name='r'><link name='world'/><link name='b'/><joint name='j' type='fixed'><parent link='world'/><child link='b'/></joint></robot>", "fixed-base"),
     ("<robot name='r'><link name='a'><inertial><mass value='1'/><inertia ixx='1' iyy='1' izz='1'/></inertial></link><link name='b'/>"
      "<joint name='j' type='revolute'><parent link='a'/><child link='b'/><axis xyz='0 0 1'/></joint></robot>", "no mass"),
 ])
@@ -205,3 +204,11 @@ def test_mesh_crate_rests_on_its_four_lowest_vertices(built_lib, tmp_path):
     for _ in range(20):
         q, u, con, _, _ = o.step(q, u)
     assert len(con) == 4 and abs(con["impulse"][:, 2].sum() - 3 * 9.81 * 0.0025) < 1e-9 and np.abs(u).max() < 1e-6   # (four redundant contacts: solved to the 1e-5 relative threshold)
+
+
+def test_world_root_link_makes_a_fixed_base_model(built_lib):
+    """RaiSim's convention: a root link named "world" = fixed base; a massless root is fine (its inertia is never used)."""
+    m = Model(urdf_string="<robot name='r'><link name='world'/><link name='b'><inertial><mass value='2'/><inertia ixx='1' iyy='1' izz='1'/></inertial></link>"
+                          "<joint name='j' type='revolute'><parent link='world'/><child link='b'/><axis xyz='0 0 1'/></joint></robot>")
+    assert m.blob.fixed_base == 1 and (m.nb, m.nq, m.nv) == (2, 8, 7)
+    assert Model(urdf_string=sphere_urdf()).blob.fixed_base == 0

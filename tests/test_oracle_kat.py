@@ -312,3 +312,40 @@ def test_sphere_beside_a_ridge_touches_the_edge_not_the_flank(built_lib):
     o.set_heightmap(5, 5, 4.0, 4.0, 2.0, 2.0, h)
     _, _, con, _, _ = o.step(np.array([2.05, 2.5, 0.36, 1, 0, 0, 0.0]), np.zeros(6))
     assert len(con) == 1 and np.allclose(con["normal"][0], np.array([-1.0, 0.0, 1.0]) / np.sqrt(2.0), atol=1e-9)
+
+
+FIXED_PENDULUM = """<?xml version="1.0"?>
+<robot name="arm">
+  <link name="world"/>
+  <link name="mount"><inertial><origin xyz="0 0 0"/><mass value="0.5"/><inertia ixx="1e-3" ixy="0" ixz="0" iyy="1e-3" iyz="0" izz="1e-3"/></inertial></link>
+  <joint name="bolt" type="fixed"><origin xyz="0 0 2"/><parent link="world"/><child link="mount"/></joint>
+  <link name="bob">
+    <inertial><origin xyz="0 0 -{l}"/><mass value="{m}"/>
+      <inertia ixx="1e-9" ixy="0" ixz="0" iyy="1e-9" iyz="0" izz="1e-9"/></inertial>
+  </link>
+  <joint name="hinge" type="revolute">
+    <origin xyz="0 0 0"/><parent link="mount"/><child link="bob"/><axis xyz="0 1 0"/>
+    <limit effort="0" velocity="100" lower="-10" upper="10"/>
+  </joint>
+</robot>
+"""
+
+
+def test_fixed_base_pendulum_period(built_lib):
+    """A URDF whose root link is "world" is a fixed-base system (RaiSim's convention): the base never moves, however light
+    it is, and a point-mass pendulum bolted to it swings with the small-angle period 2 pi sqrt(l / g)."""
+    l, m_ = 0.5, 1.0
+    mod, o = make(FIXED_PENDULUM.format(l=l, m=m_))
+    assert mod.blob.fixed_base == 1 and mod.nb == 2
+    o.p.control_mode = 0
+    q = np.array([0, 0, 0, 1, 0, 0, 0, 0.05]); u = np.zeros(7)
+    u[:6] = 0.3                                   # a base velocity in the row is ignored
+    zero, prev, t = [], q[7], 0.0
+    for k in range(2400):
+        q, u, _, _, _ = o.step(q, u)
+        t += DT
+        if prev > 0 >= q[7]: zero.append(t - DT * q[7] / (q[7] - prev))
+        prev = q[7]
+    assert np.allclose(q[:7], [0, 0, 0, 1, 0, 0, 0], atol=1e-12) and np.abs(u[:6]).max() < 1e-12
+    period = np.diff(zero).mean()
+    assert abs(period / (2 * np.pi * np.sqrt(l / G)) - 1) < 5e-3
