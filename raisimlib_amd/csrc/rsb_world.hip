@@ -76,7 +76,7 @@ struct rsb_world {
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
   float hm_max = 0.f;
   double stall_factor = 0.5, settle_tol = 0.0, restitution = 0.0, res_threshold = 0.0;
-  int lpe = 0;
+  int lpe = 0, max_kid = 0;
   double world_time = 0;
   bool integrate1_valid = false;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -431,6 +431,8 @@ int do_integrate(rsb_world* w, int nsub) {
   a.dbg = w->dbg_env >= 0 ? w->d_dbg : nullptr;
   a.dbg_env = w->dbg_env;
   a.N = w->N; a.nsub = nsub; a.kmax = w->kmax; a.control_mode = w->control_mode;
+  a.nb = w->blob.nb; a.nq = w->blob.nq; a.nv = w->blob.nv; a.ncol = w->blob.ncol; a.depth = w->blob.depth;
+  a.cw = round4(6 + w->blob.depth - 1); a.max_kid = w->max_kid; a.fixed_base = w->blob.fixed_base;
   a.dt = (float)w->dt; a.gx = (float)w->gravity[0]; a.gy = (float)w->gravity[1]; a.gz = (float)w->gravity[2];
   a.mu = (float)w->mu; a.erp = (float)w->erp;
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
@@ -525,6 +527,7 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   build_dev_model(w->blob, dm.get());
   HIP_TRY(hipMalloc(&w->d_model, sizeof(DevModel)));
   HIP_TRY(hipMemcpy(w->d_model, dm.get(), sizeof(DevModel), hipMemcpyHostToDevice));
+  w->max_kid = dm->max_kid;
   HIP_TRY(hipMalloc(&w->d_gc, N * nq * sizeof(float)));
   HIP_TRY(hipMalloc(&w->d_gv, N * nv * sizeof(float)));
   HIP_TRY(hipMalloc(&w->d_pt, N * nq * sizeof(float)));

@@ -497,8 +497,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   // masked launch (per-env raisim::World views, rsb_integrate_masked): a masked-off env runs along but writes nothing back
   if (a.env_mask && !a.env_mask[env]) env_valid = false;
 
-  const DevModel& m = *a.model;
-  const int nb = m.nb, nq = m.nq, nv = m.nv, depth = m.depth, ncol = m.ncol, cw = m.cw;
+  // model dimensions travel in the kernel arguments (read through a.model they cost one more dependent load before anything can start)
+  const int nb = a.nb, nq = a.nq, nv = a.nv, depth = a.depth, ncol = a.ncol, cw = a.cw;
+  const bool fixed_base = a.fixed_base != 0;
   const auto& L = a.L;
 
   float* MODELF = lds + L.t_model;
@@ -590,7 +591,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       PT[i] = pt;
       if (a.ptarget_store && env_valid) a.ptarget_store[(size_t)env * nq + i] = pt;
     }
-    if (i < nv) { U[i] = (m.fixed_base && i < 6) ? 0.f : ru[k]; DTG[i] = rdt[k]; TF[i] = rtf[k]; }   // (a fixed base has no velocity, whatever the row says)
+    if (i < nv) { U[i] = (fixed_base && i < 6) ? 0.f : ru[k]; DTG[i] = rdt[k]; TF[i] = rtf[k]; }   // (a fixed base has no velocity, whatever the row says)
   }
   __syncthreads();   // tables, state rows and the cleared warm table are in LDS
   // ---- per-lane body description (lane s = body s; the base is body 0 and is handled redundantly by every lane)
@@ -600,7 +601,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   const int mypar = max((PARLV[bb] & 0xff) - 1, 0);
   const int mykid = KIDX[bb];                                    // children of the own body: KIDS[start .. start + count), start | count << 16
   const int nkid0 = KIDX[0] >> 16;
-  const int max_kid = m.max_kid;                                 // most children of one moving body (loop bound of the up pass)
+  const int max_kid = a.max_kid;                                 // most children of one moving body (loop bound of the up pass)
   if (a.warm && s < a.kmax) {
     // warm state: HBM holds one record per contact of the previous integrate() (not a row per primitive: 8 x 32 B instead of
     // ncol x 24 B per env and direction); scattered into the per-primitive LDS table the solver looks its contacts up in
@@ -973,7 +974,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       }
       // a fixed base is a base of infinite inertia: with 1 / diag(C) = 0 every base entry of the contact columns, of W_b and of
       // the velocity update vanishes, and nothing else in the step has to know
-      if (m.fixed_base) { RSB_UNROLL for (int i = 0; i < 6; ++i) idg[i] = 0.f; }
+      if (fixed_base) { RSB_UNROLL for (int i = 0; i < 6; ++i) idg[i] = 0.f; }
       float tb[8];
       ldv<2>(TF, tb);
       RSB_UNROLL for (int i = 0; i < 6; ++i) {

@@ -96,6 +96,7 @@ struct StepArgs {
   int poison_lds;   // debug: fill the whole LDS allocation with NaNs first (catches reads of never-written LDS)
   int lds_floats;
   int N, nsub, kmax, control_mode;
+  int nb, nq, nv, ncol, depth, cw, max_kid, fixed_base;   // model dimensions (DevModel's, repeated here: see the kernel's first lines)
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
   int max_iter, section_rounds, stall_window, freeze_after, refine;
