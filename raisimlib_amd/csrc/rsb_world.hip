@@ -170,7 +170,8 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.wc = take(3 * kcap * cw);
   L.cv = take(3 * kcap);
   L.gstride = 4 * kcap + 4;   // 3x3 blocks on a 4-float pitch, +4 staggers the banks of consecutive rows
-  L.g = take(std::max(3 * kcap * L.gstride, b.nb * rsbk::kUpSlot));   // the up pass's [nb][28] hand-over slots alias the Delassus rows
+  // the up pass's [nb][28] hand-over slots and the height-map narrow phase's scratch alias the Delassus rows
+  L.g = take(std::max({3 * kcap * L.gstride, b.nb * rsbk::kUpSlot, (rsbk::kHmRec + 4) * rsbk::kHmSlots + RSB_MAX_COLLISIONS}));
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
   L.warm = take(6 * b.ncol);

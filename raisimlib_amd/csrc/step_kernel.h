@@ -172,12 +172,12 @@ __device__ __forceinline__ void hm_cell_range(const Args& a, float x, float y, f
 // distance with its 5 lowest mantissa bits replaced by the scan position `order` (2 * cell + triangle): candidates equally
 // close to within 2^-18 are ranked by the oracle's scan order
 template <class Args>
-__device__ __forceinline__ void hm_scan_cell(const Args& a, const float* heights, int ix, int iy, int order, float x, float y, float z,
+__device__ __forceinline__ void hm_scan_cell(const Args& a, const float* patch, int cxx, int cyy, int ix, int iy, int order, float x, float y, float z,
                                              unsigned& key, float* bp, float* bn) {
-  const float* H = heights + iy * a.hm_xs + ix;
+  const float* H = patch + 4 * cyy + cxx;      // the slot's 4 x 4 patch of corner heights (LDS), row pitch 4
   const float ox = (a.hm_x0 + (float)ix * a.hm_dx) - x, oy = (a.hm_y0 + (float)iy * a.hm_dy) - y;
   const float v00[3] = {ox, oy, H[0] - z}, v10[3] = {ox + a.hm_dx, oy, H[1] - z};
-  const float v01[3] = {ox, oy + a.hm_dy, H[a.hm_xs] - z}, v11[3] = {ox + a.hm_dx, oy + a.hm_dy, H[a.hm_xs + 1] - z};
+  const float v01[3] = {ox, oy + a.hm_dy, H[4] - z}, v11[3] = {ox + a.hm_dx, oy + a.hm_dy, H[5] - z};
   RSB_UNROLL for (int tri = 0; tri < 2; ++tri) {
     const float* b = tri == 0 ? v10 : v11;
     const float* c = tri == 0 ? v11 : v01;
@@ -794,19 +794,36 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       //   (2) lane = (slot, cell): the four lanes of a quad scan the cells of one slot, two triangles each, and agree on the
       //       closest feature (DPP quad minimum of the candidate keys); its lane resolves depth and normal;
       //   (3) lane = primitive again: contacts in primitive order.
-      // Scratch: the first 352 floats of the Delassus rows (dead here; the up pass overwrites them with its hand-over slots).
-      float* REC = G;                                         // [kHmSlots][12] x y z r | ix0 iy0 nx ny | c (relative to the base) | pad
-      float* RES = G + 12 * kHmSlots;                         // [kHmSlots][4] depth, normal
-      int* SLOTOF = reinterpret_cast<int*>(G + 16 * kHmSlots);   // [ncol] slot + 1 of each primitive, 0 = dropped
+      // Scratch: the first (kHmRec + 4) * kHmSlots + ncol floats of the Delassus rows (dead here; finite values only, the up pass
+      // overwrites most of them with its hand-over slots).
+      float* REC = G;                                         // [kHmSlots][kHmRec] x y z r | ix0 iy0 nx ny | c (relative to the base) pad | 4 x 4 corner heights
+      float* RES = G + kHmRec * kHmSlots;                     // [kHmSlots][4] depth, normal
+      int* SLOTOF = reinterpret_cast<int*>(G + (kHmRec + 4) * kHmSlots);   // [ncol] slot + 1 of each primitive, 0 = dropped
       int nnear = 0;
       for (int c0 = 0; c0 < ncol; c0 += LPE) {
         const int ci = c0 + s;
         bool near = false;
         float c[3] = {0.f, 0.f, 0.f}, rad = 0.f;
-        int cbody = 0;
+        int cbody = 0, ix0 = 0, iy0 = 0, nx = 1, ny = 1;
+        float hc[16];
+        RSB_UNROLL for (int i = 0; i < 16; ++i) hc[i] = 0.f;
         if (ci < ncol) {
           sphere_of(ci, c, rad, cbody);
           near = (pbz + c[2] - rad <= ac.hm_max) && !dead;
+          if (near) {
+            // the corner heights of the sphere's cells (<= 4 x 4 samples, all loads in flight at once): the sphere can touch
+            // the surface over these cells only if its lowest point is below their highest corner (exact), and the scan
+            // below reads them from LDS
+            hm_cell_range(ac, pbx + c[0], pby + c[1], rad, ix0, iy0, nx, ny);
+            const float* H = env_heights + iy0 * ac.hm_xs + ix0;
+            // (unconditional loads at clamped offsets: sixteen loads in flight, one wait; a predicated load would wait on its own)
+            RSB_UNROLL for (int j = 0; j < 4; ++j)
+              RSB_UNROLL for (int i = 0; i < 4; ++i) hc[4 * j + i] = H[min(j, ny) * ac.hm_xs + min(i, nx)];
+            float hmax = -3e38f;
+            RSB_UNROLL for (int j = 0; j < 4; ++j)
+              RSB_UNROLL for (int i = 0; i < 4; ++i) hmax = fmaxf(hmax, (i <= nx && j <= ny) ? hc[4 * j + i] : -3e38f);
+            near = pbz + c[2] - rad <= hmax;
+          }
         }
         const unsigned long long bal = __ballot(near);
         const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
@@ -814,11 +831,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const bool take = near && slot < kHmSlots;
         if (near && !take) flag |= 1;                        // more spheres near the ground than slots: reported as a contact overflow
         if (take) {
-          int ix0, iy0, nx, ny;
-          hm_cell_range(ac, pbx + c[0], pby + c[1], rad, ix0, iy0, nx, ny);
           const float R[12] = {pbx + c[0], pby + c[1], pbz + c[2], rad, __int_as_float(ix0), __int_as_float(iy0), __int_as_float(nx), __int_as_float(ny),
                                c[0], c[1], c[2], 0.f};
-          stv<3>(REC + 12 * slot, R);
+          stv<3>(REC + kHmRec * slot, R);
+          stv<4>(REC + kHmRec * slot + 12, hc);
         }
         if (ci < ncol) SLOTOF[ci] = take ? slot + 1 : 0;
         nnear += __popcll(gm);
@@ -830,13 +846,14 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const int k = k0 + (s >> 2), t = s & 3;
         const bool valid = k < nnear;
         float R[8];
-        ldv<2>(REC + 12 * (valid ? k : 0), R);
+        const float* rec = REC + kHmRec * (valid ? k : 0);
+        ldv<2>(rec, R);
         const int ix0 = __float_as_int(R[4]), iy0 = __float_as_int(R[5]), nx = __float_as_int(R[6]), ncell = valid ? nx * __float_as_int(R[7]) : 0;
         unsigned key = 0xffffffffu;
         float bp[3] = {0.f, 0.f, 0.f}, bn[3] = {0.f, 0.f, 1.f};
         for (int cc = t; cc < ncell; cc += 4) {
-          const int cyy = cc / nx, cxx = cc - cyy * nx;
-          hm_scan_cell(ac, env_heights, ix0 + cxx, iy0 + cyy, 2 * cc, R[0], R[1], R[2], key, bp, bn);
+          const int cyy = (cc >= nx ? 1 : 0) + (cc >= 2 * nx ? 1 : 0), cxx = cc - cyy * nx;   // cc / nx for nx, ny <= 3 without an integer division
+          hm_scan_cell(ac, rec + 12, cxx, cyy, ix0 + cxx, iy0 + cyy, 2 * cc, R[0], R[1], R[2], key, bp, bn);
         }
         unsigned kmin = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
         kmin = min(kmin, (unsigned)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x4E, 0xf, 0xf, false));            // quad_perm [2,3,0,1]
@@ -855,10 +872,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const int sl = ci < ncol ? SLOTOF[ci] : 0;
         if (sl > 0) {
           float o4[4], r4[4];
-          ld4(RES + 4 * (sl - 1), o4); ld4(REC + 12 * (sl - 1) + 8, r4);
+          ld4(RES + 4 * (sl - 1), o4); ld4(REC + kHmRec * (sl - 1) + 8, r4);
           dep = o4[0]; n[0] = o4[1]; n[1] = o4[2]; n[2] = o4[3];
           c[0] = r4[0]; c[1] = r4[1]; c[2] = r4[2];
-          rad = REC[12 * (sl - 1) + 3];
+          rad = REC[kHmRec * (sl - 1) + 3];
           cbody = __float_as_int(COLT[8 * ci + 4]);
           hit = dep > 0.f;
         }

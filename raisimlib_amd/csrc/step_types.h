@@ -25,6 +25,7 @@ constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
 constexpr int kLightDepth = 3;        // == ORC_LIGHT_DEPTH
 constexpr int kWarmRec = 8;           // floats per warm-state record in HBM: impulse (3), friction direction (2), direction valid, primitive + 1, pad
 constexpr int kWarmRow = kWarmRec * RSB_MAX_CONTACTS;   // floats per env row of StepArgs::warm
+constexpr int kHmRec = 28;            // floats per slot of the height-map narrow phase: sphere, cell range, 4 x 4 corner heights
 constexpr int kHmSlots = 16;          // spheres per env the height-map narrow phase examines in one sub-step (those near the ground)
 
 struct DevModel {

@@ -1,0 +1,29 @@
+"""Diagnostic (GPU): shader-cycle stamps at the phase boundaries of workgroup 0 (last sub-step of a launch),
+averaged over launches of the steady reset workload - config 3 (shared 128 x 128 height map)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from raisimlib_amd import Model, BatchedWorld, rsc_path, workload
+N = 4096
+m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+w = BatchedWorld(m, N); w.add_height_map(128, 128, workload.HEIGHTMAP_SIZE, workload.HEIGHTMAP_SIZE, 0.0, 0.0, workload.smoothed_heightmap(128, 128, amplitude=0.1, seed=7))
+gc, gv = workload.anymal_initial_state(N); gc[:, 2] += workload.HEIGHTMAP_CLEARANCE; kp, kd = workload.anymal_gains()
+w.set_pd_gains(kp, kd); w.set_state(gc, gv)
+feet = m.collision_indices("_foot"); g0, v0 = gc.astype(np.float32), gv.astype(np.float32)
+dtg = np.zeros((N, 18), np.float32)
+for cs in range(150):
+    w.set_pd_target(workload.anymal_targets(N, cs), dtg); w.integrate(4); w.reset_terminated(feet, g0, v0)
+w.debug_phase_cycles(True, False)
+rows = []
+for cs in range(150, 200):
+    w.set_pd_target(workload.anymal_targets(N, cs), dtg); w.integrate(4)
+    p = w.debug_phase_cycles(True, True)
+    w.reset_terminated(feet, g0, v0)
+    rows.append(np.r_[np.diff(p[:8]), p[8], p[9]])
+R = np.array(rows, dtype=np.float64)
+names = ["base + down pass (0->1)", "collision detection (1->2)", "up pass / ABA + base factor (2->3)",
+         "contact columns + c (3->4)", "Delassus G (4->5)", "Gauss-Seidel (5->6)", "delta-u + integrate (6->7)"]
+print("workgroup 0, last sub-step, median over %d launches (cycles):" % len(R))
+for i, n in enumerate(names):
+    print(f"  {n:36s} {np.median(R[:, i]):8.0f}")
+print("  sweeps (median)", np.median(R[:, 7]), "ncw (median)", np.median(R[:, 8]), "total", np.median(R[:, :7].sum(1)))
