@@ -563,10 +563,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     const float4* img = reinterpret_cast<const float4*>(a.lds_image);
     float4* dst = reinterpret_cast<float4*>(lds);
     const int n4 = L.shared_total >> 2;
-    for (int i0 = 0; i0 < n4; i0 += 256) {     // four float4 per lane in flight
-      float4 v[4];
-      RSB_UNROLL for (int k = 0; k < 4; ++k) { const int i = i0 + lane + 64 * k; if (i < n4) v[k] = img[i]; }
-      RSB_UNROLL for (int k = 0; k < 4; ++k) { const int i = i0 + lane + 64 * k; if (i < n4) dst[i] = v[k]; }
+    for (int i0 = 0; i0 < n4; i0 += 256) {     // four float4 per lane in flight (loads at clamped indices, so that none of them is predicated)
+      const int i_0 = i0 + lane, i_1 = i_0 + 64, i_2 = i_0 + 128, i_3 = i_0 + 192;
+      const float4 v0 = img[min(i_0, n4 - 1)], v1 = img[min(i_1, n4 - 1)], v2 = img[min(i_2, n4 - 1)], v3 = img[min(i_3, n4 - 1)];
+      if (i_0 < n4) dst[i_0] = v0;
+      if (i_1 < n4) dst[i_1] = v1;
+      if (i_2 < n4) dst[i_2] = v2;
+      if (i_3 < n4) dst[i_3] = v3;
     }
   }
   // The Delassus rows start as zeros: the solver reads coupling blocks unconditionally (a block the current contact set

@@ -1,0 +1,30 @@
+"""Static resources of the benchmark's step-kernel instance (hipcc cross-compiles without a GPU): no scratch (a spill to private
+memory costs HBM traffic and latency on every launch - it once hid in the prologue's table copy), one wave per SIMD by design."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from common import ROOT
+from raisimlib_amd import build as rb
+
+
+def test_default_step_instance_uses_no_scratch(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / "k.s"
+    csrc = os.path.join(ROOT, "raisimlib_amd", "csrc")
+    cmd = [hipcc, *rb.FLAGS, "-I", os.path.join(ROOT, "include"), "-I", csrc, "-DRSB_I_LPE=16", "-DRSB_I_KMAX=8", "-DRSB_I_CL=0", "-DRSB_I_ML=4",
+           "-DRSB_I_PROF=0", "--cuda-device-only", "-S", "-o", str(out), os.path.join(csrc, "step_instance.hip")]
+    subprocess.run(cmd, check=True, capture_output=True)
+    txt = out.read_text()
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", txt).group(1))
+    vgpr = int(re.search(r"\.vgpr_count:\s*(\d+)", txt).group(1))
+    spills = int(re.search(r"\.vgpr_spill_count:\s*(\d+)", txt).group(1))
+    assert scratch == 0 and spills == 0, (scratch, spills)
+    assert "scratch_store" not in txt and "scratch_load" not in txt
+    assert vgpr <= 512                       # arch VGPRs + AGPRs of the one wave a SIMD holds
+    assert not re.search(r"\bv_mfma", txt)   # documented in DESIGN.md section 4: no MFMA on this path, by measurement
