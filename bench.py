@@ -225,6 +225,7 @@ def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, 
 
 def main():
     args = parse()
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (this image's default; see rsb_world.hip)
     import torch
     import torch.distributed as dist
 
