@@ -108,6 +108,11 @@ typedef struct rsb_model_blob {
   char body_name[RSB_MAX_BODIES][RSB_NAME_LEN];   /* URDF link name of each moving body  */
   char joint_name[RSB_MAX_BODIES][RSB_NAME_LEN];  /* URDF joint name (index 0: "base")   */
   char col_name[RSB_MAX_COLLISIONS][RSB_NAME_LEN];
+  /* rim primitives (the end caps of a <cylinder>): col_rim[s] > 0 makes primitive s the LOWEST POINT of the circle of that radius
+   * around col_pos[s] in the plane normal to col_axis[s] (body frame) - lowest with respect to the terrain normal under the
+   * centre; col_radius[s] is 0 for them.  col_rim[s] == 0: a sphere. */
+  double col_axis[RSB_MAX_COLLISIONS][3];
+  double col_rim[RSB_MAX_COLLISIONS];
   char col_material[RSB_MAX_COLLISIONS][RSB_NAME_LEN];  /* <collision><material name=".."/> of the URDF, "default" if absent */
 } rsb_model_blob;
 

@@ -859,7 +859,19 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     int b = m->col_body[s];
     double t[3], c[3], cw[3], n[3], depth;
     mat3_vec(k->R[b], m->col_pos[s], t);
-    for (int a = 0; a < 3; ++a) { c[a] = k->r[b][a] + t[a]; cw[a] = k->pbase[a] + c[a]; }
+    for (int a = 0; a < 3; ++a) c[a] = k->r[b][a] + t[a];
+    if (m->col_rim[s] > 0.0) {
+      /* rim primitive (end cap of a cylinder): the point of the circle of radius col_rim around c, normal to the cap's axis,
+       * that is lowest along the world's vertical: c - rim * e / |e| with e = z - (z.a) a; a cap lying flat keeps its centre */
+      double aw[3];
+      mat3_vec(k->R[b], m->col_axis[s], aw);
+      const double len2 = 1.0 - aw[2] * aw[2];
+      if (len2 > 1e-12) {
+        const double kk = m->col_rim[s] / sqrt(len2);
+        c[0] += kk * aw[2] * aw[0]; c[1] += kk * aw[2] * aw[1]; c[2] -= kk * len2;
+      }
+    }
+    for (int a = 0; a < 3; ++a) cw[a] = k->pbase[a] + c[a];
     if (terrain_contact(p, cw, m->col_radius[s], &depth, n)) {
       if (nc >= kmax) { fl |= 1; continue; }
       for (int a = 0; a < 3; ++a) { cx[nc][a] = c[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }

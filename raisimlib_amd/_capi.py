@@ -31,7 +31,8 @@ class ModelBlob(C.Structure):
         ("q_lower", C.c_double * _B), ("q_upper", C.c_double * _B), ("effort", C.c_double * _B),
         ("col_body", C.c_int32 * _S), ("col_pos", (C.c_double * 3) * _S), ("col_radius", C.c_double * _S),
         ("body_name", (C.c_char * RSB_NAME_LEN) * _B), ("joint_name", (C.c_char * RSB_NAME_LEN) * _B),
-        ("col_name", (C.c_char * RSB_NAME_LEN) * _S), ("col_material", (C.c_char * RSB_NAME_LEN) * _S),
+        ("col_name", (C.c_char * RSB_NAME_LEN) * _S),
+        ("col_axis", (C.c_double * 3) * _S), ("col_rim", C.c_double * _S), ("col_material", (C.c_char * RSB_NAME_LEN) * _S),
     ]
 
 

@@ -161,7 +161,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.t_parlv = take(b.nb);
   L.t_anc = take(b.nb * b.depth);
   L.t_dir = take(64);
-  L.t_col = take(8 * b.ncol);
+  L.t_col = take(rsbk::kColSlot * b.ncol);
   L.t_kids = take(b.nb);
   L.t_kidx = take(b.nb);
   L.shared_total = o;
@@ -393,9 +393,10 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
     img[L.t_dir + 4 * k + 2] = (float)std::cos(hi); img[L.t_dir + 4 * k + 3] = (float)std::sin(hi);
   }
   for (int i = 0; i < b.ncol; ++i) {
-    float* ct = &img[L.t_col + 8 * i];
+    float* ct = &img[L.t_col + rsbk::kColSlot * i];
     ct[0] = (float)b.col_pos[i][0]; ct[1] = (float)b.col_pos[i][1]; ct[2] = (float)b.col_pos[i][2]; ct[3] = (float)b.col_radius[i];
-    put_i(L.t_col + 8 * i + 4, b.col_body[i]);
+    put_i(L.t_col + rsbk::kColSlot * i + 4, b.col_body[i]);
+    ct[8] = (float)b.col_axis[i][0]; ct[9] = (float)b.col_axis[i][1]; ct[10] = (float)b.col_axis[i][2]; ct[11] = (float)b.col_rim[i];
     // contact material of the primitive against the terrain: the per-primitive override where one is set, else the world's default
     ct[5] = (float)(w->col_mu[i] >= 0 ? w->col_mu[i] : w->mu);
     ct[6] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);

@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   int* PARLV = reinterpret_cast<int*>(lds + L.t_parlv);          // [nb] (parent+1) | level << 8
   int* ANC = reinterpret_cast<int*>(lds + L.t_anc);              // [nb*depth]
   float* DIR16 = lds + L.t_dir;                                  // float4 [16] slip-search brackets
-  float* COLT = lds + L.t_col;                                   // [ncol][8] sphere centre (body frame), radius, body, mu, restitution, res_threshold
+  float* COLT = lds + L.t_col;                                   // [ncol][kColSlot] sphere centre (body frame), radius | body, mu, restitution, res_threshold | axis, rim
   int* KIDS = reinterpret_cast<int*>(lds + L.t_kids);            // [nb] child bodies, grouped by parent (DevModel::kid_start / kid_count)
   int* KIDX = reinterpret_cast<int*>(lds + L.t_kidx);            // [nb] kid_start | kid_count << 16
   float* E = lds + L.shared_total + el * L.per_env;
@@ -764,8 +764,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     };
     // sphere centre of primitive ci relative to the base position, radius and body
     auto sphere_of = [&](int ci, float* c, float& rad, int& cbody) {
-      float ct[8];
-      ld4(COLT + 8 * ci, ct); ct[4] = COLT[8 * ci + 4];
+      float ct[8], ax[4];
+      ld4(COLT + kColSlot * ci, ct); ct[4] = COLT[kColSlot * ci + 4]; ld4(COLT + kColSlot * ci + 8, ax);
       cbody = __float_as_int(ct[4]);
       rad = ct[3];
       float P[12];
@@ -774,6 +774,17 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       float t[3];
       mat3_vec(P, pl, t);
       c[0] = P[9] + t[0]; c[1] = P[10] + t[1]; c[2] = P[11] + t[2];
+      if (ax[3] > 0.f) {
+        // rim primitive (end cap of a cylinder; oracle: "rim"): the point of the circle of radius ax[3] around c, normal to the
+        // cap's axis, that is lowest along the world's vertical; a cap lying flat keeps its centre
+        float aw[3];
+        mat3_vec(P, ax, aw);
+        const float len2 = 1.0f - aw[2] * aw[2];
+        if (len2 > 1e-12f) {
+          const float k = ax[3] * __builtin_amdgcn_rsqf(len2);
+          c[0] += k * aw[2] * aw[0]; c[1] += k * aw[2] * aw[1]; c[2] -= k * len2;
+        }
+      }
     };
     if (ac.terrain_type == 0) {
       // ---- plane: depth = r - (z - z0), normal z
@@ -879,7 +890,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           dep = o4[0]; n[0] = o4[1]; n[1] = o4[2]; n[2] = o4[3];
           c[0] = r4[0]; c[1] = r4[1]; c[2] = r4[2];
           rad = REC[kHmRec * (sl - 1) + 3];
-          cbody = __float_as_int(COLT[8 * ci + 4]);
+          cbody = __float_as_int(COLT[kColSlot * ci + 4]);
           hit = dep > 0.f;
         }
         emit(hit, ci, cbody, c, rad, n, dep);
@@ -1042,7 +1053,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
           // Newton restitution (oracle: "restitution"): the approach speed J u of this step re-enters the normal row
           const int cprim = min(__float_as_int(CN[11]), ncol - 1);   // (joint-limit rows carry ids >= ncol and no restitution)
-          const float restitution = COLT[8 * cprim + 6], res_threshold = COLT[8 * cprim + 7];
+          const float restitution = COLT[kColSlot * cprim + 6], res_threshold = COLT[kColSlot * cprim + 7];
           const float rest = (rr == 2 && lsgn == 0.f && restitution > 0.f && cv < -res_threshold) ? restitution * cv : 0.f;
           const bool limit_row = lsgn != 0.f;
           const bool empty_row = limit_row && rr < 2;
@@ -1181,7 +1192,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         RSB_ARGS(ag);
         // the own contact's friction coefficient: that of its collision primitive against the terrain (material pairs)
         const int mycol = isc ? __float_as_int(CON[s * kConSlot + 11]) : 0;
-        const float mu = (isc && mycol < ncol) ? COLT[8 * mycol + 5] : ag.mu, mu2 = mu * mu;
+        const float mu = (isc && mycol < ncol) ? COLT[kColSlot * mycol + 5] : ag.mu, mu2 = mu * mu;
         const float alpha_init = ag.alpha_init, alpha_min = ag.alpha_min, alpha_decay = ag.alpha_decay, threshold = ag.threshold;
         const float stall_factor = ag.stall_factor;
         const int max_iter = ag.max_iter, section_rounds = ag.section_rounds, stall_window = ag.stall_window;

@@ -16,6 +16,7 @@ constexpr int kBodySlot = 24;    // R9 r3 V6 A6 (A is reused for the delta-veloc
 constexpr int kUpSlot = 28;      // Ia21 Zc6 pad   (one per body)
 constexpr int kFactSlot = 16;    // S6 UD6 rsD invD pad2
 constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
+constexpr int kColSlot = 12;     // per collision primitive in LDS: centre3 radius | body mu restitution res_threshold | axis3 rim (rim > 0: see rsb_model_blob::col_rim)
 constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevModel::bodyf)
 constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence test (== ORC_LAMBDA_FLOOR)
 constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN

@@ -5,7 +5,7 @@
 // host, merge fixed joints, and emit the immutable model blob that rsb_create uploads to the device.
 //
 // Supported subset: <link>/<inertial>/<collision> with <sphere>, <capsule>, <box> (its 8 corners) and <cylinder>
-// (the inscribed capsule) geometry,
+// (the lowest rim point of each end cap) geometry,
 // <joint type="revolute|continuous|prismatic|fixed">, <origin xyz rpy>, <axis>, <limit>,
 // <dynamics damping rotor_inertia>.  The root link is the floating base, or - when it is named "world" - a fixed base.  <mesh filename=.. scale=..> collision geometry
 // (Wavefront OBJ, binary / ASCII STL; path relative to the URDF file, "package://" / "file://" prefixes stripped to the
@@ -188,7 +188,7 @@ static Xf parse_origin(const XmlNode* n) {
 }
 
 // ------------------------------------------------------------------------------ URDF -> blob
-struct UCollision { Xf x; int type; double radius, length; double size[3]; std::string name, material; std::vector<V3> pts; };  // type 0 sphere, 1 capsule, 2 box, 3 mesh point set
+struct UCollision { Xf x; int type; double radius, length; double size[3]; std::string name, material; std::vector<V3> pts; };  // type 0 sphere, 1 capsule, 2 box, 3 mesh point set, 4 cylinder (two rim primitives)
 struct ULink {
   std::string name;
   double mass = 0;
@@ -328,20 +328,25 @@ struct Builder {
   void add_collisions(int body, const Xf& body_from_link, const ULink& L) {
     for (auto& c : L.cols) {
       Xf bc = compose(body_from_link, c.x);
-      int n = c.type == 1 ? 2 : (c.type == 2 ? 8 : (c.type == 3 ? (int)c.pts.size() : 1));
+      int n = (c.type == 1 || c.type == 4) ? 2 : (c.type == 2 ? 8 : (c.type == 3 ? (int)c.pts.size() : 1));
       for (int e = 0; e < n; ++e) {
         if (blob.ncol >= RSB_MAX_COLLISIONS) throw std::runtime_error("URDF: more than RSB_MAX_COLLISIONS collision spheres");
         V3 off{0, 0, 0};
-        if (c.type == 1) off = {0, 0, (e == 0 ? 0.5 : -0.5) * c.length};
+        if (c.type == 1 || c.type == 4) off = {0, 0, (e == 0 ? 0.5 : -0.5) * c.length};
         if (c.type == 2) off = {(e & 1 ? 0.5 : -0.5) * c.size[0], (e & 2 ? 0.5 : -0.5) * c.size[1], (e & 4 ? 0.5 : -0.5) * c.size[2]};
         if (c.type == 3) off = c.pts[e];
         V3 p = bc.p + mul(bc.R, off);
         int s = blob.ncol++;
         blob.col_body[s] = body;
         blob.col_pos[s][0] = p.x; blob.col_pos[s][1] = p.y; blob.col_pos[s][2] = p.z;
-        blob.col_radius[s] = c.radius;
+        blob.col_radius[s] = c.type == 4 ? 0.0 : c.radius;
+        if (c.type == 4) {   // end cap of a cylinder: the lowest point of its rim (see rsb_model_blob::col_rim)
+          V3 ax = mul(bc.R, V3{0, 0, 1});
+          blob.col_axis[s][0] = ax.x; blob.col_axis[s][1] = ax.y; blob.col_axis[s][2] = ax.z;
+          blob.col_rim[s] = c.radius;
+        }
         std::string nm = c.name.empty() ? L.name : c.name;
-        if (c.type == 1) nm += (e == 0 ? "/top" : "/bottom");
+        if (c.type == 1 || c.type == 4) nm += (e == 0 ? "/top" : "/bottom");
         if (c.type == 2) nm += "/c" + std::to_string(e);
         if (c.type == 3) nm += "/m" + std::to_string(e);
         std::snprintf(blob.col_name[s], RSB_NAME_LEN, "%s", nm.c_str());
@@ -441,10 +446,11 @@ static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* ski
           if (!parse_doubles(bx->get("size"), col.size, 3) || !(col.size[0] > 0 && col.size[1] > 0 && col.size[2] > 0))
             throw std::runtime_error("URDF: <box> needs size=\"x y z\" > 0 on link " + L.name);
         } else if (const XmlNode* cy = g->child("cylinder")) {
-          // a cylinder is replaced by the capsule inscribed in it (same radius, rounded rims): its two end spheres
-          col.type = 1; col.radius = attr_double(cy, "radius", 0.0);
-          const double len = attr_double(cy, "length", 0.0);
-          col.length = len > 2 * col.radius ? len - 2 * col.radius : 0.0;
+          // a cylinder touches a plane with the lowest points of its two end-cap rims: two rim primitives (exact on a plane,
+          // lying, standing or tilted; on a height field the rim point is chosen by the terrain normal under the cap's centre)
+          col.type = 4; col.radius = attr_double(cy, "radius", 0.0);
+          col.length = attr_double(cy, "length", 0.0);
+          if (!(col.length > 0)) throw std::runtime_error("URDF: <cylinder> needs length > 0 on link " + L.name);
         } else if (const XmlNode* ms = g->child("mesh")) {
           // a mesh touches a plane with its vertices: a thinned-out point set of zero-radius spheres (see the file header)
           std::vector<V3> verts;

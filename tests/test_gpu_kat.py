@@ -221,3 +221,24 @@ def test_fixed_base_pendulum_period(built_lib):
     assert np.allclose(q[:, :7], [0, 0, 0, 1, 0, 0, 0], atol=1e-7) and np.abs(u[:, :6]).max() < 1e-7
     assert abs(np.diff(zero).mean() / (2 * np.pi * np.sqrt(l / G)) - 1) < 1e-2
     w.close()
+
+
+def test_cylinder_rests_on_its_rims(built_lib):
+    """Rim primitives of a <cylinder> through the C-ABI (see the oracle KAT): lying at height R on two contacts, tilted: one."""
+    from test_oracle_kat import CYLINDER, _quat_y
+    R, L, m_ = 0.1, 0.5, 3.0
+    _, w = world(CYLINDER)
+    w.set_state(tile([0, 0, R - 1e-5] + _quat_y(np.pi / 2)), tile(np.zeros(6)))
+    w.integrate(30)
+    cnt, con = w.get_contacts(); _, u = w.get_state()
+    assert (cnt == 2).all() and np.abs(u).max() < 1e-4
+    imp = np.array([[c[0]["impulse"][2], c[1]["impulse"][2]] for c in con])
+    assert np.allclose(imp.sum(axis=1), m_ * G * DT, rtol=1e-5)
+    a = np.pi / 6
+    drop = L / 2 * np.cos(a) + R * np.sin(a)
+    w.set_state(tile([0, 0, drop - 2e-3] + _quat_y(a)), tile(np.zeros(6)))
+    w.integrate(1)
+    cnt, con = w.get_contacts()
+    assert (cnt == 1).all() and abs(con[3][0]["depth"] - 2e-3) < 2e-6
+    assert np.allclose(con[3][0]["position"][:2], [-(L / 2) * np.sin(a) + R * np.cos(a), 0.0], atol=2e-6)
+    w.close()

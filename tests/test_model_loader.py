@@ -111,18 +111,19 @@ BOX_URDF = """<robot name="crate"><link name="crate">
 </link></robot>"""
 
 
-def test_box_becomes_its_corners_and_cylinder_its_inscribed_capsule(built_lib):
+def test_box_becomes_its_corners_and_cylinder_its_two_cap_rims(built_lib):
     from raisimlib_amd import Model
     m = Model(urdf_string=BOX_URDF)
     b = m.blob
     assert m.ncol == 10
     pos = np.array([list(b.col_pos[i]) for i in range(10)]); rad = np.array([b.col_radius[i] for i in range(10)])
-    assert np.all(rad[:8] == 0) and np.allclose(rad[8:], 0.05)
+    assert np.all(rad == 0)                                        # box corners and rim primitives are points
+    assert np.allclose([b.col_rim[i] for i in range(10)], [0] * 8 + [0.05] * 2) and np.allclose([list(b.col_axis[i]) for i in (8, 9)], [[0, 0, 1]] * 2)
     c, s_ = np.cos(0.5), np.sin(0.5)
     want = {(round(0.1 + c * x - s_ * y, 9), round(s_ * x + c * y, 9), z) for x in (-0.3, 0.3) for y in (-0.2, 0.2) for z in (-0.1, 0.1)}
     got = {(round(p[0], 9), round(p[1], 9), round(p[2], 9)) for p in pos[:8]}
     assert got == want
-    assert np.allclose(sorted(pos[8:, 2]), [0.3 - 0.2, 0.3 + 0.2]) and np.allclose(pos[8:, :2], 0)   # segment = length - 2 r
+    assert np.allclose(sorted(pos[8:, 2]), [0.3 - 0.25, 0.3 + 0.25]) and np.allclose(pos[8:, :2], 0)   # the centres of the two end caps
     names = m.collision_names()
     assert names[0].endswith("/c0") and names[7].endswith("/c7") and names[8] == "pipe/top"
 

@@ -349,3 +349,39 @@ def test_fixed_base_pendulum_period(built_lib):
     assert np.allclose(q[:7], [0, 0, 0, 1, 0, 0, 0], atol=1e-12) and np.abs(u[:6]).max() < 1e-12
     period = np.diff(zero).mean()
     assert abs(period / (2 * np.pi * np.sqrt(l / G)) - 1) < 5e-3
+
+
+CYLINDER = """<robot name="log"><link name="log">
+ <inertial><origin xyz="0 0 0"/><mass value="3"/><inertia ixx="0.07" ixy="0" ixz="0" iyy="0.07" iyz="0" izz="0.015"/></inertial>
+ <collision><origin xyz="0 0 0"/><geometry><cylinder radius="0.1" length="0.5"/></geometry></collision>
+</link></robot>"""
+
+
+def _quat_y(angle):
+    return [np.cos(angle / 2), 0.0, np.sin(angle / 2), 0.0]
+
+
+def test_cylinder_rests_on_its_rims_lying_standing_and_tilted(built_lib):
+    """A <cylinder> touches a plane with the lowest point of each end-cap rim (not with an inscribed capsule): lying on its
+    side it rests at height R on two contacts sharing m g dt; standing it rests at height L/2; tilted by 30 degrees the lower
+    cap's rim point is the only contact, at the closed-form depth."""
+    R, L, m_ = 0.1, 0.5, 3.0
+    _, o = make(CYLINDER)
+    # lying on its side (axis along x): both rim points, 2 x m g dt / 2
+    q = np.array([0, 0, R - 1e-5] + _quat_y(np.pi / 2)); u = np.zeros(6)
+    for _ in range(30):
+        q, u, con, _, _ = o.step(q, u)
+    assert len(con) == 2 and abs(con["impulse"][:, 2].sum() - m_ * G * DT) < 1e-9 and np.abs(u).max() < 1e-6
+    assert np.allclose(sorted(con["position"][:, 0]), [-L / 2, L / 2], atol=1e-6) and np.allclose(con["position"][:, 2], 0, atol=2e-5)
+    # standing on its lower cap: one contact (the cap's centre), full weight; nothing from the upper cap
+    q = np.array([0, 0, L / 2 - 1e-5, 1, 0, 0, 0.0]); u = np.zeros(6)
+    for _ in range(10):
+        q, u, con, _, _ = o.step(q, u)
+    assert len(con) == 1 and abs(con["impulse"][0][2] - m_ * G * DT) < 1e-9
+    # tilted by 30 degrees about y: the lowest rim point of the lower cap is L/2 cos a + R sin a below the centre
+    a = np.pi / 6
+    drop = L / 2 * np.cos(a) + R * np.sin(a)
+    q = np.array([0, 0, drop - 2e-3] + _quat_y(a)); u = np.zeros(6)
+    _, _, con, _, _ = o.step(q, u)
+    assert len(con) == 1 and abs(con["depth"][0] - 2e-3) < 1e-9
+    assert np.allclose(con["position"][0][:2], [-(L / 2) * np.sin(a) + R * np.cos(a), 0.0], atol=1e-9)
