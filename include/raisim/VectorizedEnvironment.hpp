@@ -14,7 +14,8 @@
 //
 //   raisim::DeviceVectorizedEnvironment   rsg_anymal's task compiled into the library (rsb_env_*): action scaling,
 //       observation, reward, termination and reset run on the GPU, a control step is one fused launch of
-//       control_dt/simulation_dt sub-steps plus one small kernel, and `stepDevice` / `observeDevice` take device buffers
+//       control_dt/simulation_dt sub-steps (reward, termination, reset and the next observation in its epilogue), and
+//       `stepDevice` / `observeDevice` take device buffers
 //       so that a GPU-resident policy never crosses PCIe.  Task semantics [RECALL rsg_anymal]: action -> PD position
 //       targets (actionMean + action*actionStd on the actuated joints), observation = [height, third row of the base
 //       rotation (3), joint angles, body lin vel(3), body ang vel(3), joint velocities] (obDim = 10 + 2*nJoints),

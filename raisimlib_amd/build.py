@@ -24,9 +24,9 @@ RSB_H = os.path.join(ROOT, "include", "rsb.h")
 HOST_SOURCES = {   # source -> headers it depends on
     "urdf_model.cpp": ["rsb_internal.h", RSB_H],
     "terrain_io.cpp": ["rsb_internal.h", RSB_H],
-    "rsb_world.hip": ["rsb_internal.h", "step_types.h", "step_launch.h", "query_kernel.h", RSB_H],
+    "rsb_world.hip": ["rsb_internal.h", "step_types.h", "step_launch.h", "query_kernel.h", "env_task.h", RSB_H],
 }
-KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", RSB_H]
+KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", RSB_H]
 # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and
 # pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed at the stated parity tolerance
 # (2.5 ulp hardware approximations + Newton step instead)

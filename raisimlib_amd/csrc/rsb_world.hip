@@ -20,6 +20,7 @@
 #include "rsb.h"
 #include "rsb_internal.h"
 #include "step_launch.h"
+#include "env_task.h"
 #include "step_types.h"
 
 using rsbk::DevModel;
@@ -83,12 +84,13 @@ struct rsb_world {
   bool timing = false;
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
   struct Fuse { const float* act = nullptr; const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
-                int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1; } fuse;
+                int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1;
+                float* env_reward = nullptr; float* env_ob = nullptr; uint8_t* env_done = nullptr; bool env_task = false; } fuse;
   // device-resident vectorised env (rsb_env_*)
   bool env_ready = false;
   rsb_env_config env_cfg{};
   unsigned long long env_allowed = 0;
-  float *d_env_mean = nullptr, *d_env_gc0 = nullptr, *d_env_gv0 = nullptr, *d_env_io = nullptr, *d_env_reward = nullptr, *d_env_tau2 = nullptr;
+  float *d_env_mean = nullptr, *d_env_gc0 = nullptr, *d_env_gv0 = nullptr, *d_env_io = nullptr, *d_env_ob = nullptr, *d_env_reward = nullptr, *d_env_tau2 = nullptr;
   uint8_t* d_env_done = nullptr;
   std::vector<hipEvent_t> ring0, ring1;   // event pairs around the most recent step-kernel launches (rsb_enable_timing(w, n))
   size_t ring_next = 0, ring_count = 0;
@@ -267,58 +269,12 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
   if (done) done[e] = term ? 1 : 0;
 }
 
-// ---- device-resident vectorised env (rsg_anymal task semantics, see rsb.h) ------------------------------------
-__device__ inline void env_rot_t(const float* q, float* Rt) {  // world -> body rotation from the base quaternion
-  const float w = q[3], x = q[4], y = q[5], z = q[6];
-  Rt[0] = 1 - 2 * (y * y + z * z); Rt[3] = 2 * (x * y - w * z);     Rt[6] = 2 * (x * z + w * y);
-  Rt[1] = 2 * (x * y + w * z);     Rt[4] = 1 - 2 * (x * x + z * z); Rt[7] = 2 * (y * z - w * x);
-  Rt[2] = 2 * (x * z - w * y);     Rt[5] = 2 * (y * z + w * x);     Rt[8] = 1 - 2 * (x * x + y * y);
-}
-
+// ---- device-resident vectorised env (rsg_anymal task semantics, see rsb.h and env_task.h) ----------------------
+// The step itself (action -> targets, sub-steps, reward, termination, reset, next observation) is ONE launch of the step
+// kernel (StepArgs::env_*); what remains here is the stand-alone observation and the reset of all envs.
 __device__ inline void env_write_obs(float* o, const float* q, const float* u, int nv) {
   const int nj = nv - 6;
-  float Rt[9];
-  env_rot_t(q, Rt);
-  int k = 0;
-  o[k++] = q[2];
-  o[k++] = Rt[2]; o[k++] = Rt[5]; o[k++] = Rt[8];   // third ROW of the body->world rotation R (world z-axis in the body frame): rsg_anymal's rot.e().row(2)
-  for (int j = 0; j < nj; ++j) o[k++] = q[7 + j];
-  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[0] + Rt[3 * i + 1] * u[1] + Rt[3 * i + 2] * u[2];
-  for (int i = 0; i < 3; ++i) o[k++] = Rt[3 * i] * u[3] + Rt[3 * i + 1] * u[4] + Rt[3 * i + 2] * u[5];
-  for (int j = 0; j < nj; ++j) o[k++] = u[6 + j];
-}
-
-// reward and termination from the state the control step ended in, then the reset of terminated envs
-__global__ void env_post_kernel(float* gc, float* gv, const float* tau2,
-                                const rsb_contact* contacts, int32_t* count, int32_t* flags, unsigned long long allowed,
-                                const float* gc0, const float* gv0, float* reward, uint8_t* done, int N, int nq, int nv,
-                                int kmax, float fwd_coeff, float fwd_clip, float torque_coeff, float terminal_reward,
-                                float* warm, int n6, float* ob) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N) return;
-  float* q = gc + (size_t)e * nq;
-  float* u = gv + (size_t)e * nv;
-  bool term = (flags[e] & 2) != 0;
-  const int nc = count[e];
-  for (int k = 0; k < nc; ++k) {
-    const int c = contacts[(size_t)e * kmax + k].collision;
-    if (!((allowed >> c) & 1ull)) term = true;
-  }
-  float Rt[9];
-  env_rot_t(q, Rt);
-  const float vx = Rt[0] * u[0] + Rt[1] * u[1] + Rt[2] * u[2];
-  const float t2 = tau2[e];   // |actuator torque|^2 of the last sub-step, exported by the step kernel (upstream: getGeneralizedForce())
-  const float r = fwd_coeff * fminf(fwd_clip, vx) + torque_coeff * t2;
-  if (reward) reward[e] = term ? r + terminal_reward : r;   // upstream perAgentStep: reward += terminalReward
-  if (done) done[e] = term ? 1 : 0;
-  if (term) {
-    for (int i = 0; i < nq; ++i) q[i] = gc0[i];
-    for (int i = 0; i < nv; ++i) u[i] = gv0[i];
-    for (int i = 0; i < n6; ++i) warm[(size_t)e * n6 + i] = 0.f;
-    count[e] = 0;
-    flags[e] = 0;
-  }
-  if (ob) env_write_obs(ob + (size_t)e * (10 + 2 * (nv - 6)), q, u, nv);   // observation of the state the next step starts from
+  for (int i = 0; i < 10 + 2 * nj; ++i) o[i] = rsbk::env_ob_entry(i, nj, [&](int k) { return q[k]; }, [&](int k) { return u[k]; });
 }
 
 __global__ void env_obs_kernel(float* ob, const float* gc, const float* gv, int N, int nq, int nv) {
@@ -429,6 +385,13 @@ int do_integrate(rsb_world* w, int nsub) {
   a.lds_image = w->d_image;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
   if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; a.tau2_out = w->d_env_tau2; }
+  uint8_t* env_done = nullptr;
+  if (w->fuse.env_task) {   // rsb_env_step: reward, termination, reset and the next observation in this launch's epilogue
+    a.env_reward = w->fuse.env_reward; a.env_ob = w->fuse.env_ob; env_done = w->fuse.env_done;
+    a.env_fwd_coeff = w->env_cfg.forward_vel_coeff; a.env_fwd_clip = w->env_cfg.forward_vel_clip;
+    a.env_torque_coeff = w->env_cfg.torque_coeff; a.env_terminal_reward = w->env_cfg.terminal_reward;
+    a.tau2_out = nullptr;
+  }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
@@ -460,7 +423,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.prof_fine = prof_fine ? 1 : 0;
   a.lds_floats = (int)(lds_bytes / sizeof(float));
   const bool prof = a.prof != nullptr || a.dbg != nullptr || a.poison_lds != 0;
-  a.done_out = w->d_done_out;
+  a.done_out = env_done ? env_done : w->d_done_out;
   a.env_mask = w->launch_mask; w->launch_mask = nullptr;
   hipEvent_t e0 = w->ev0, e1 = w->ev1;
   const bool rec = w->timing && (w->launch_index++ % w->timing_stride == 0);
@@ -579,7 +542,7 @@ int rsb_destroy(rsb_world* w) {
   (void)rsb_comm_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -1069,6 +1032,7 @@ int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* acti
     HIP_TRY(hipMalloc(&w->d_env_gc0, nq * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_env_gv0, nv * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_env_io, N * od * sizeof(float)));      // staging for host-side action / observation buffers
+    HIP_TRY(hipMalloc(&w->d_env_ob, N * od * sizeof(float)));      // the fused step's observation (never the action's buffer: other waves may still have to read their actions)
     HIP_TRY(hipMalloc(&w->d_env_reward, N * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_env_tau2, N * sizeof(float)));
     HIP_TRY(hipMemset(w->d_env_tau2, 0, N * sizeof(float)));
@@ -1122,27 +1086,26 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
     HIP_TRY(hipMemcpyAsync(w->d_env_io, action, (size_t)N * nj * sizeof(float), hipMemcpyHostToDevice, w->stream));
     dact = w->d_env_io;
   }
+  float* drew = space == RSB_DEVICE ? reward : (reward ? w->d_env_reward : nullptr);
+  uint8_t* ddone = space == RSB_DEVICE ? done : (done ? w->d_env_done : nullptr);
+  float* dob = ob_next ? (space == RSB_DEVICE ? ob_next : w->d_env_ob) : nullptr;
   {
-    rsb_world::Fuse f;          // action -> PD targets in the launch's prologue; the launch knows the allowed primitives
+    // ONE launch per vectorised step: action -> PD targets in the prologue, control_dt / simulation_dt sub-steps, then reward,
+    // termination (non-foot contact or non-finite state), reset and the next observation in the epilogue
+    rsb_world::Fuse f;
     f.act = dact;
     f.have_allowed = 1; f.allowed = w->env_allowed;
+    f.do_reset = 1; f.gc0 = w->d_env_gc0; f.gv0 = w->d_env_gv0; f.rows = 1;
+    f.env_task = true; f.env_reward = drew; f.env_ob = dob; f.env_done = ddone;
     w->fuse = f;
   }
   st = do_integrate(w, w->env_cfg.n_substeps);
   if (st != RSB_OK) return st;
-  float* drew = space == RSB_DEVICE ? reward : (reward ? w->d_env_reward : nullptr);
-  uint8_t* ddone = space == RSB_DEVICE ? done : (done ? w->d_env_done : nullptr);
-  float* dob = ob_next ? (space == RSB_DEVICE ? ob_next : w->d_env_io) : nullptr;   // host staging: the action is consumed by now
-  hipLaunchKernelGGL(env_post_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_env_tau2,
-                     w->d_contacts, w->d_count, w->d_flags, w->env_allowed, w->d_env_gc0, w->d_env_gv0,
-                     drew, ddone, N, nq, nv, w->kmax, w->env_cfg.forward_vel_coeff, w->env_cfg.forward_vel_clip,
-                     w->env_cfg.torque_coeff, w->env_cfg.terminal_reward, w->d_warm, rsbk::kWarmRow, dob);
-  HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   if (space == RSB_HOST) {
     if (reward) HIP_TRY(hipMemcpyAsync(reward, w->d_env_reward, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     if (done) HIP_TRY(hipMemcpyAsync(done, w->d_env_done, (size_t)N, hipMemcpyDeviceToHost, w->stream));
-    if (ob_next) HIP_TRY(hipMemcpyAsync(ob_next, w->d_env_io, (size_t)N * od * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    if (ob_next) HIP_TRY(hipMemcpyAsync(ob_next, w->d_env_ob, (size_t)N * od * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
   }
   return RSB_OK;

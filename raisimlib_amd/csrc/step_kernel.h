@@ -39,6 +39,7 @@
 
 #include <type_traits>
 
+#include "env_task.h"
 #include "rsb.h"
 #include "step_types.h"
 
@@ -1594,10 +1595,28 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       ct.collision = __float_as_int(CN[11]);
       ae.contacts[(size_t)env * kmax + s] = ct;
     }
-    if (ae.tau2_out) {
+    if (ae.tau2_out || ae.env_reward) {
       float t = tsq;
       RSB_UNROLL for (int off = 1; off < LPE; off <<= 1) t += __shfl_xor(t, off);
-      if (s == 0) ae.tau2_out[env] = t;
+      if (ae.tau2_out && s == 0) ae.tau2_out[env] = t;
+      if (ae.env_reward && s == 0) {
+        // rsg_anymal reward [RECALL] of the state the step ended in (before a reset): clipped forward velocity in the body
+        // frame and the torque cost of the last sub-step; upstream's perAgentStep adds the terminal reward on top
+        const float vx = env_forward_velocity([&](int i) { return Q[i]; }, [&](int i) { return U[i]; });
+        const float r = ae.env_fwd_coeff * fminf(ae.env_fwd_clip, vx) + ae.env_torque_coeff * t;
+        ae.env_reward[env] = term ? r + ae.env_terminal_reward : r;
+      }
+    }
+    if (ae.env_ob) {
+      // observation of the state the NEXT step starts from (a terminated env: its reset state), lane = observation entry
+      const int nj = nv - 6, od = 10 + 2 * nj;
+      auto qs = [&](int i) { return term ? ae.gc0[r0 * nq + i] : Q[i]; };
+      auto us = [&](int i) { return term ? ae.gv0[r0 * nv + i] : U[i]; };
+      float* ob = ae.env_ob + (size_t)env * od;
+      for (int i = s; i < od; i += LPE) {
+        const float v = env_ob_entry(i, nj, qs, us);
+        ob[i] = v;
+      }
     }
     if (s == 0) {
       if (ae.done_out) ae.done_out[env] = term ? 1 : 0;

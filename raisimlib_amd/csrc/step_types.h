@@ -90,6 +90,13 @@ struct StepArgs {
   int reset_rows;
   float* tau2_out;             // [N] optional: |actuator torque|^2 over the joints in the last sub-step (clipped PD + feed-forward), for the env reward
   uint8_t* done_out;           // [N] optional: 1 for the envs this launch reset (do_reset), else 0 (rsb_set_done_output)
+  // rsg_anymal task epilogue (rsb_env_step; all optional): reward of the state the control step ended in (forward velocity in the
+  // body frame, clipped, minus the torque cost of the last sub-step; + terminal_reward for a terminated env) and the observation
+  // (height, third row of the base rotation, joint angles, body-frame linear / angular velocity, joint velocities) of the state
+  // the NEXT step starts from (i.e. after the reset of a terminated env)
+  float* env_reward;           // [N]
+  float* env_ob;               // [N, 10 + 2 (nv - 6)]
+  float env_fwd_coeff, env_fwd_clip, env_torque_coeff, env_terminal_reward;
   const uint8_t* env_mask;     // [N] optional: envs with 0 are not integrated and none of their rows is written (rsb_integrate_masked)
   long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
   float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)
