@@ -190,7 +190,8 @@ def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, 
         if reset:
             con, ncs = r["contacts"], r["n_contacts"]
             valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
-            term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
+            term = (valid & ~(feet_set[con["collision"] & 0xffff] & (con["collision"] < 0x10000))).any(axis=1)   # (a self-collision entry carries flag bits: never a foot on the ground)
+            term = term | (r["flags"] & 2).astype(bool)
             q[term], u[term] = gc_reset[term], gv_reset[term]
             warm[term] = 0.0
         state["q"], state["u"] = q, u

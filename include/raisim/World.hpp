@@ -61,8 +61,10 @@ class Contact {
   Vec<3> getImpulse() const { return v3(c_.impulse); }   // world frame (upstream: contact frame + getContactFrame())
   double getDepth() const { return c_.depth; }
   size_t getlocalBodyIndex() const { return (size_t)c_.body; }
-  int getCollisionIndex() const { return c_.collision; }
-  bool isObjectA() const { return true; }
+  int getCollisionIndex() const { return RSB_CONTACT_PRIMITIVE(c_.collision); }
+  /// a self-collision is listed once per body: the two entries are neighbours in getContacts(), object A first
+  bool isSelfCollision() const { return (c_.collision & (RSB_CONTACT_SELF_A | RSB_CONTACT_SELF_B)) != 0; }
+  bool isObjectA() const { return (c_.collision & RSB_CONTACT_SELF_B) == 0; }
   bool skip() const { return false; }
  private:
   static Vec<3> v3(const float* p) { Vec<3> v; v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; return v; }
@@ -101,6 +103,9 @@ class BatchedWorld {
     pairProps_[pairKey(m1, m2)] = {friction, restitution, resThreshold};
     resolveMaterials();
   }
+  /// ArticulatedSystem::ignoreCollisionBetween(bodyIdx1, bodyIdx2) / self-collision on-off for every replica
+  void ignoreCollisionBetween(size_t bodyIdx1, size_t bodyIdx2) { RSB_CHECK(rsb_ignore_collision_between(world_, (int)bodyIdx1, (int)bodyIdx2)); resolveMaterials(); }
+  void setSelfCollision(bool on) { RSB_CHECK(rsb_set_self_collision(world_, on ? 1 : 0)); }
   /// material of the terrain (addGround / addHeightMap's material argument)
   void setTerrainMaterial(const std::string& material) { terrainMaterial_ = material; resolveMaterials(); }
   void setContactSolverParam(double alpha_init, double alpha_min, double alpha_decay, int maxIter, double threshold) {
@@ -249,6 +254,18 @@ class BatchedWorld {
       if (it != pairProps_.end()) { mu[i] = it->second.mu; e[i] = it->second.restitution; thr[i] = it->second.resThreshold; }
     }
     RSB_CHECK(rsb_set_collision_materials(world_, mu.data(), e.data(), thr.data()));
+    // self-collisions: the pair (material of primitive i, material of primitive j)
+    const int np = rsb_self_collision_pairs(world_, nullptr, 0);
+    std::vector<int32_t> pairs((size_t)2 * np);
+    if (np > 0) rsb_self_collision_pairs(world_, pairs.data(), np);
+    std::vector<double> smu(np, -1.0), se(np, -1.0), sthr(np, -1.0);
+    for (int k = 0; k < np; ++k) {
+      const char* mi = rsb_model_collision_material(model_, pairs[2 * k]);
+      const char* mj = rsb_model_collision_material(model_, pairs[2 * k + 1]);
+      auto it = pairProps_.find(pairKey(mi ? mi : "default", mj ? mj : "default"));
+      if (it != pairProps_.end()) { smu[k] = it->second.mu; se[k] = it->second.restitution; sthr[k] = it->second.resThreshold; }
+    }
+    RSB_CHECK(rsb_set_self_collision_materials(world_, smu.data(), se.data(), sthr.data()));
   }
   std::map<std::string, PairProp> pairProps_;
   std::string terrainMaterial_ = "default";
@@ -312,6 +329,8 @@ class ArticulatedSystem {
   void setName(const std::string& n) { name_ = n; }
   const std::string& getName() const { return name_; }
   double getTotalMass() const { return rsb_model_total_mass(w_->model()); }
+  /// upstream ArticulatedSystem::ignoreCollisionBetween; the replicas share one model, so it applies to all of them
+  void ignoreCollisionBetween(size_t bodyIdx1, size_t bodyIdx2) { w_->ignoreCollisionBetween(bodyIdx1, bodyIdx2); }
   size_t getBodyIdx(const std::string& link) const {
     int i = rsb_model_body_index(w_->model(), link.c_str());
     RSFATAL_IF(i < 0, "getBodyIdx: no such body: " + link);

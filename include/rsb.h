@@ -123,8 +123,13 @@ typedef struct rsb_contact {
   float impulse[3];    /* world frame, impulse applied to the robot over dt    */
   float depth;
   int32_t body;        /* local body index of the articulated system           */
-  int32_t collision;   /* collision primitive index                            */
+  int32_t collision;   /* collision primitive index; a self-collision is listed once per body (as raisim::Contact does:
+                          isSelfCollision(), isObjectA()) and carries RSB_CONTACT_SELF_A / _B in this field: the two entries
+                          sit next to each other, same position and depth, opposite normals and impulses */
 } rsb_contact;
+#define RSB_CONTACT_SELF_A 0x10000
+#define RSB_CONTACT_SELF_B 0x20000
+#define RSB_CONTACT_PRIMITIVE(c) ((c) & 0xffff)
 
 /* resident state fields (row-major [N,dim] float32 unless noted) */
 typedef enum rsb_field {
@@ -176,6 +181,18 @@ int rsb_set_material(rsb_world* w, double mu, double restitution, double res_thr
  * Arrays of rsb_dims().ncol doubles; a NULL array (or a negative entry) means "the world's default" (rsb_set_material).
  * The C++ facade resolves material NAMES (rsb_model_collision_material, addGround(z, material)) into these arrays. */
 int rsb_set_collision_materials(rsb_world* w, const double* mu, const double* restitution, const double* res_threshold);
+/* Self-collision: RaiSim collides the links of one articulated system with each other, parent-child pairs excepted [RECALL;
+ * upstream ArticulatedSystem.hpp is absent from /root/reference].  Here: sphere x sphere between collision primitives of two
+ * bodies that are not parent and child (capsule = its two end spheres, box = its corner points against spheres; rim
+ * primitives of cylinders take no part).  On by default; a self-collision takes two of the max_contacts slots.
+ * rsb_ignore_collision_between = ArticulatedSystem::ignoreCollisionBetween(bodyIdx1, bodyIdx2) (not undoable).
+ * rsb_self_collision_pairs lists the candidate primitive pairs (pairs[2k] < pairs[2k+1]) and returns their count;
+ * rsb_set_self_collision_materials takes one (mu, restitution, res_threshold) per candidate pair in that order
+ * (NULL array / negative entry = the world's default; reset when the candidate list changes). */
+int rsb_set_self_collision(rsb_world* w, int enable);
+int rsb_ignore_collision_between(rsb_world* w, int body_a, int body_b);
+int rsb_self_collision_pairs(const rsb_world* w, int32_t* pairs, int capacity);
+int rsb_set_self_collision_materials(rsb_world* w, const double* mu, const double* restitution, const double* res_threshold);
 int rsb_set_contact_solver_param(rsb_world* w, double alpha_init, double alpha_min,
                                  double alpha_decay, int max_iter, double threshold);
 /* Stagnation exit of the contact solver (not a RaiSim parameter): the Gauss-Seidel loop of an env stops when the

@@ -23,12 +23,13 @@ class Params(C.Structure):
         ("max_iter", C.c_int32), ("section_rounds", C.c_int32), ("kmax", C.c_int32), ("control_mode", C.c_int32),
         ("warm_start", C.c_int32), ("freeze_after", C.c_int32),
         ("terrain_type", C.c_int32), ("hm_xs", C.c_int32), ("hm_ys", C.c_int32), ("stall_window", C.c_int32),
-        ("dir_per_sweep", C.c_int32), ("refine", C.c_int32), ("group_parallel", C.c_int32), ("reserved0", C.c_int32),
+        ("dir_per_sweep", C.c_int32), ("refine", C.c_int32), ("group_parallel", C.c_int32), ("self_collision", C.c_int32),
         ("ground_z", C.c_double), ("stall_factor", C.c_double), ("restitution", C.c_double), ("res_threshold", C.c_double),
         ("settle_tol", C.c_double),
         ("hm_xsize", C.c_double), ("hm_ysize", C.c_double), ("hm_cx", C.c_double), ("hm_cy", C.c_double),
         ("hm_heights", C.c_void_p),
         ("col_mu", C.c_void_p), ("col_restitution", C.c_void_p), ("col_res_threshold", C.c_void_p),
+        ("self_ignore", C.c_void_p), ("self_mu", C.c_void_p), ("self_restitution", C.c_void_p), ("self_res_threshold", C.c_void_p),
     ]
 
 
@@ -89,6 +90,22 @@ class Oracle:
         """Per collision primitive contact material against the terrain ([ncol] arrays; None = the scalar default)."""
         self._cm = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (mu, restitution, res_threshold)]
         self.p.col_mu, self.p.col_restitution, self.p.col_res_threshold = (None if a is None else a.ctypes.data for a in self._cm)
+
+    def set_self_collision(self, enable=True, ignore=None, mu=None, restitution=None, res_threshold=None):
+        """Self-collision between non-adjacent bodies; ignore: [nb, nb] bool (ignoreCollisionBetween), materials per candidate pair."""
+        self.p.self_collision = int(bool(enable))
+        self._si = None if ignore is None else np.ascontiguousarray(ignore, dtype=np.uint8).reshape(self.nb, self.nb)
+        self.p.self_ignore = None if self._si is None else self._si.ctypes.data
+        self._sm = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (mu, restitution, res_threshold)]
+        self.p.self_mu, self.p.self_restitution, self.p.self_res_threshold = (None if a is None else a.ctypes.data for a in self._sm)
+
+    def self_pairs(self):
+        """[(i, j)] candidate primitive pairs of self-collision in enumeration order."""
+        ign = getattr(self, "_si", None)
+        n = self.L.orc_self_pairs(C.byref(self.blob), _p(ign), None, 0)
+        out = np.zeros((n, 2), np.int32)
+        self.L.orc_self_pairs(C.byref(self.blob), _p(ign), _p(out), n)
+        return out
 
     def set_ground(self, z):
         self.p.terrain_type = 0
@@ -183,7 +200,7 @@ class Oracle:
         self.L.orc_step_debug(C.byref(self.blob), C.byref(self.p), _p(q), _p(u), _p(_d(kp)), _p(_d(kd)), _p(_d(pt)),
                               _p(_d(dt_)), _p(_d(tau_ff)), _p(con), C.byref(nc), C.byref(it), C.byref(fl),
                               _p(lam_warm), _p(G), _p(c), _p(lam))
-        n3 = 3 * nc.value
+        n3 = 3 * (nc.value - int((con["collision"][:nc.value] & 0x20000).astype(bool).sum()))   # a self-collision: two entries, one solver contact
         return dict(q=q, u=u, contacts=con[:nc.value], iters=it.value, flags=fl.value,
                     G=G[:n3 * n3].reshape(n3, n3).copy(), c=c[:n3].copy(), lam=lam[:n3].copy())
 

@@ -28,6 +28,7 @@
 #define MAXV RSB_MAX_DOF
 #define MAXK RSB_MAX_CONTACTS
 #define ORC_WARM 6   /* warm state per collision primitive: impulse (3, contact frame), friction direction (2), direction valid */
+#define ORC_SELF_REG 1e-4     /* compliance of a self-collision's Delassus block, relative to its mean diagonal (see step_impl) */
 #define ORC_LAMBDA_FLOOR 1e-3 /* N s; keeps the relative convergence test meaningful as impulses -> 0 */
 
 /* ------------------------------------------------------------------ small linear algebra */
@@ -292,6 +293,7 @@ void orc_default_params(orc_params* p) {
                             no sweeps, but put the p99.9 velocity deviation from the plain per-contact iteration at 1.9e-4 m/s instead of
                             7e-6 (tests/test_oracle_solver_heuristics.py) */
   p->restitution = 0.0; p->res_threshold = 0.0;
+  p->self_collision = 1;   /* RaiSim's default: the links of one system collide with each other (parent-child pairs excepted) */
   p->warm_start = 1;  /* only has an effect when the caller carries a warm state (orc_step_warm / orc_step_batch with lam_warm):
                          8% fewer sweeps and 7x fewer global searches on the config-2 workload.  The device keeps the same state
                          per env (StepArgs::warm, rsb_set_solver_warm_start, default on), so parity tests over several
@@ -820,6 +822,30 @@ static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-ma
   for (int c = 0; c < 3; ++c) { Rc[3 * c] = t1[c]; Rc[3 * c + 1] = t2[c]; Rc[3 * c + 2] = n[c]; }
 }
 
+/* ---------------------------------------------------------------------------------- self-collision */
+/* Candidate pairs (RaiSim collides the links of one articulated system with each other, parent-child pairs excepted [RECALL]):
+ * primitives i < j on two different bodies that are not parent and child, not both points, not rim primitives (their point
+ * is defined against the terrain only), and whose bodies are not in the caller's ignore set (ignoreCollisionBetween). */
+static int self_pair_ok(const rsb_model_blob* m, const uint8_t* ignore, int i, int j) {
+  const int bi = m->col_body[i], bj = m->col_body[j];
+  if (bi == bj || m->parent[bi] == bj || m->parent[bj] == bi) return 0;
+  if (m->col_rim[i] > 0.0 || m->col_rim[j] > 0.0) return 0;
+  if (!(m->col_radius[i] + m->col_radius[j] > 0.0)) return 0;
+  if (ignore && (ignore[bi * m->nb + bj] || ignore[bj * m->nb + bi])) return 0;
+  return 1;
+}
+
+int orc_self_pairs(const rsb_model_blob* m, const uint8_t* ignore, int32_t* pairs, int cap) {
+  int n = 0;
+  for (int i = 0; i < m->ncol; ++i)
+    for (int j = i + 1; j < m->ncol; ++j)
+      if (self_pair_ok(m, ignore, i, j)) {
+        if (pairs && n < cap) { pairs[2 * n] = i; pairs[2 * n + 1] = j; }
+        ++n;
+      }
+  return n;
+}
+
 /* ---------------------------------------------------------------------------------- step */
 static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, double* u, const double* kp,
                       const double* kd, const double* p_target, const double* d_target,
@@ -855,6 +881,10 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   int nc = 0;
   double cx[MAXK][3], cn[MAXK][3], cdepth[MAXK], Rc[MAXK][9];
   int cbody[MAXK], ccol[MAXK];
+  int cbody2[MAXK], ccol2[MAXK];   /* second body / primitive of a self-collision (-1: contact with the terrain) */
+  double cmat[MAXK][3];            /* mu, restitution, threshold of a self-collision's material pair */
+  double cen[RSB_MAX_COLLISIONS][3];   /* primitive centres relative to the base position */
+  for (int i = 0; i < MAXK; ++i) { cbody2[i] = -1; ccol2[i] = -1; }
   for (int s = 0; s < m->ncol; ++s) {
     int b = m->col_body[s];
     double t[3], c[3], cw[3], n[3], depth;
@@ -871,7 +901,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         c[0] += kk * aw[2] * aw[0]; c[1] += kk * aw[2] * aw[1]; c[2] -= kk * len2;
       }
     }
-    for (int a = 0; a < 3; ++a) cw[a] = k->pbase[a] + c[a];
+    for (int a = 0; a < 3; ++a) { cw[a] = k->pbase[a] + c[a]; cen[s][a] = c[a]; }
     if (terrain_contact(p, cw, m->col_radius[s], &depth, n)) {
       if (nc >= kmax) { fl |= 1; continue; }
       for (int a = 0; a < 3; ++a) { cx[nc][a] = c[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }
@@ -879,6 +909,32 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       contact_frame(n, Rc[nc]);
       ++nc;
     }
+  }
+
+  /* Self-collision (sphere x sphere): two primitives of the candidate set closer than r_i + r_j touch in the middle of the
+   * overlap, normal from j to i.  ONE contact in the solver (J = J_i - J_j), TWO entries in the contact list (one per body,
+   * opposite normals and impulses, as RaiSim lists it) - and two of the kmax slots, as on the device. */
+  int nslots = nc, nself = 0;
+  if (p->self_collision) {
+    int pair = -1;
+    for (int i = 0; i < m->ncol; ++i)
+      for (int j = i + 1; j < m->ncol; ++j) {
+        if (!self_pair_ok(m, p->self_ignore, i, j)) continue;
+        ++pair;
+        double d[3] = {cen[i][0] - cen[j][0], cen[i][1] - cen[j][1], cen[i][2] - cen[j][2]};
+        const double rs = m->col_radius[i] + m->col_radius[j], d2 = dot3(d, d);
+        if (!(d2 < rs * rs) || d2 < 1e-12) continue;
+        if (nslots + 2 > kmax) { fl |= 1; continue; }
+        const double dist = sqrt(d2), depth = rs - dist;
+        double n[3] = {d[0] / dist, d[1] / dist, d[2] / dist};
+        for (int a = 0; a < 3; ++a) { cx[nc][a] = cen[i][a] - (m->col_radius[i] - 0.5 * depth) * n[a]; cn[nc][a] = n[a]; }
+        cdepth[nc] = depth; cbody[nc] = m->col_body[i]; ccol[nc] = i; cbody2[nc] = m->col_body[j]; ccol2[nc] = j;
+        cmat[nc][0] = p->self_mu ? p->self_mu[pair] : p->mu;
+        cmat[nc][1] = p->self_restitution ? p->self_restitution[pair] : p->restitution;
+        cmat[nc][2] = p->self_res_threshold ? p->self_res_threshold[pair] : p->res_threshold;
+        contact_frame(n, Rc[nc]);
+        ++nc; ++nself; nslots += 2;
+      }
   }
 
   /* joint limits (RaiSim enforces them in the same solver [RECALL]): a joint beyond its range adds one unilateral row
@@ -893,7 +949,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     double sgn = 0.0, viol = 0.0;
     if (qi > hi) { sgn = -1.0; viol = qi - hi; } else if (qi < lo) { sgn = 1.0; viol = lo - qi; }
     if (sgn != 0.0) {
-      if (nc >= kmax) { fl |= 1; continue; }
+      if (nslots >= kmax) { fl |= 1; continue; }
+      ++nslots;
       cbody[nc] = i; ccol[nc] = m->ncol + i; cdepth[nc] = viol; lim_sign[nc] = sgn;
       for (int a = 0; a < 3; ++a) { cx[nc][a] = 0.0; cn[nc][a] = 0.0; }
       ++nc;
@@ -928,8 +985,18 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         for (int d = 0; d < nv; ++d) {
           double s = 0;
           for (int c = 0; c < 3; ++c) s += Rc[i][3 * c + r] * Jw[c * nv + d];
-          Jc[i][r][d] = s; X[i][r][d] = s;
+          Jc[i][r][d] = s;
         }
+      if (cbody2[i] >= 0) {   /* self-collision: relative velocity of the two bodies' points */
+        point_jacobian(m, k, cbody2[i], cx[i], Jw);
+        for (int r = 0; r < 3; ++r)
+          for (int d = 0; d < nv; ++d) {
+            double s = 0;
+            for (int c = 0; c < 3; ++c) s += Rc[i][3 * c + r] * Jw[c * nv + d];
+            Jc[i][r][d] -= s;
+          }
+      }
+      for (int r = 0; r < 3; ++r) for (int d = 0; d < nv; ++d) X[i][r][d] = Jc[i][r][d];
       for (int r = 0; r < 3; ++r) ltdl_solve(M, nv, pd, X[i][r]);
     }
     /* Delassus blocks G_ij = J_i M^-1 J_j^T and free contact velocity c_i = J_i u_free */
@@ -943,6 +1010,13 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
             G[i][j][3 * r + c] = s;
           }
       if (lim_sign[i] != 0.0) G[i][i][0] = G[i][i][4] = 1.0;   /* dummy tangential diagonal of a joint-limit row */
+      if (cbody2[i] >= 0) {
+        /* two bodies joined by fewer than three joints cannot move relative to each other in every direction (thigh against
+         * trunk: two joints), so a self-collision's block can be rank deficient; a small compliance, relative to the block's
+         * mean diagonal, keeps the per-contact rule well posed */
+        const double reg = ORC_SELF_REG * (G[i][i][0] + G[i][i][4] + G[i][i][8]) / 3.0;
+        G[i][i][0] += reg; G[i][i][4] += reg; G[i][i][8] += reg;
+      }
       inv3(G[i][i], Ginv[i]);
       for (int r = 0; r < 3; ++r) {
         double s = 0;
@@ -950,15 +1024,16 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         cfree[i][r] = s;
       }
       cfree[i][2] -= p->erp * cdepth[i] / p->dt;
-      const double e_i = (i < nreal && p->col_restitution) ? p->col_restitution[ccol[i]] : p->restitution;
-      const double thr_i = (i < nreal && p->col_res_threshold) ? p->col_res_threshold[ccol[i]] : p->res_threshold;
+      const double e_i = cbody2[i] >= 0 ? cmat[i][1] : (i < nreal && p->col_restitution) ? p->col_restitution[ccol[i]] : p->restitution;
+      const double thr_i = cbody2[i] >= 0 ? cmat[i][2] : (i < nreal && p->col_res_threshold) ? p->col_res_threshold[ccol[i]] : p->res_threshold;
       if (e_i > 0.0 && lim_sign[i] == 0.0) {   /* Newton restitution on the approach speed J u of this step */
         double vn0 = 0;
         for (int d = 0; d < nv; ++d) vn0 += Jc[i][2][d] * u[d];
         if (vn0 < -thr_i) cfree[i][2] += e_i * vn0;
       }
       /* warm start: the impulse (contact frame) this collision primitive carried in the previous integrate() */
-      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
+      /* (a self-collision starts cold: the warm state is kept per primitive for its contact with the terrain) */
+      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal && cbody2[i] < 0) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
     }
     /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
     if (dbgG)   /* debug views cover the real contacts (joint-limit rows follow them and are left out) */
@@ -976,13 +1051,13 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
      * sweeps is not below `stall_factor` x the best of the window before.  Such solves would otherwise run to
      * max_iter without converging; on a lock-step GPU launch that worst case sets the launch time. */
     double cmu[MAXK];   /* friction coefficient of each contact = its collision primitive's material against the terrain */
-    for (int i = 0; i < nc; ++i) cmu[i] = (i < nreal && p->col_mu) ? p->col_mu[ccol[i]] : p->mu;
+    for (int i = 0; i < nc; ++i) cmu[i] = cbody2[i] >= 0 ? cmat[i][0] : (i < nreal && p->col_mu) ? p->col_mu[ccol[i]] : p->mu;
     double alpha = p->alpha_init, best_prev = 1e300, best_cur = 1e300;
     double sdir[MAXK][3], lam_best[MAXK][3], best_rel = 1e300;
     for (int i = 0; i < nc; ++i) {
       sdir[i][0] = sdir[i][1] = sdir[i][2] = 0.0;
       lam_best[i][0] = lam_best[i][1] = lam_best[i][2] = 0.0;
-      if (lam_warm && p->warm_start && i < nreal && lam_warm[ORC_WARM * ccol[i] + 5] != 0.0) {   /* ... and its last friction direction */
+      if (lam_warm && p->warm_start && i < nreal && cbody2[i] < 0 && lam_warm[ORC_WARM * ccol[i] + 5] != 0.0) {   /* ... and its last friction direction */
         sdir[i][0] = lam_warm[ORC_WARM * ccol[i] + 3]; sdir[i][1] = lam_warm[ORC_WARM * ccol[i] + 4]; sdir[i][2] = 3.0;
       }
     }
@@ -992,6 +1067,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     for (int i = 0; i < nc; ++i) {
       int b = cbody[i];
       while (b > 0 && m->parent[b] > 0) b = m->parent[b];
+      if (nself > 0) b = 0;   /* a self-collision couples two limbs strongly: every contact of such an env is solved in turn (one group) */
       gid[i] = b; gpos[i] = 0;
       for (int j = 0; j < i; ++j) if (gid[j] == b) ++gpos[i];
       if (gpos[i] + 1 > gdepth) gdepth = gpos[i] + 1;
@@ -1129,21 +1205,29 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   if (lam_warm) {
     for (int i = 0; i < ORC_WARM * m->ncol; ++i) lam_warm[i] = 0.0;
     for (int i = 0; i < nreal; ++i) {
+      if (cbody2[i] >= 0) continue;
       double* wrm = lam_warm + ORC_WARM * ccol[i];
       for (int r = 0; r < 3; ++r) wrm[r] = lam[i][r];
       if (sdir_out[i][2] != 0.0) { wrm[3] = sdir_out[i][0]; wrm[4] = sdir_out[i][1]; wrm[5] = 1.0; }
     }
   }
-  if (contacts)
-    for (int i = 0; i < nreal; ++i) {
+  int nout = 0;
+  for (int i = 0; i < nreal; ++i) {
+    const int two = cbody2[i] >= 0;
+    for (int h = 0; h <= two; ++h, ++nout) {
+      if (!contacts) continue;
+      const double sg = h ? -1.0 : 1.0;
       for (int c = 0; c < 3; ++c) {
-        contacts[i].position[c] = k->pbase[c] + cx[i][c];
-        contacts[i].normal[c] = cn[i][c];
-        contacts[i].impulse[c] = Rc[i][3 * c] * lam[i][0] + Rc[i][3 * c + 1] * lam[i][1] + Rc[i][3 * c + 2] * lam[i][2];
+        contacts[nout].position[c] = k->pbase[c] + cx[i][c];
+        contacts[nout].normal[c] = sg * cn[i][c];
+        contacts[nout].impulse[c] = sg * (Rc[i][3 * c] * lam[i][0] + Rc[i][3 * c + 1] * lam[i][1] + Rc[i][3 * c + 2] * lam[i][2]);
       }
-      contacts[i].depth = cdepth[i]; contacts[i].body = cbody[i]; contacts[i].collision = ccol[i];
+      contacts[nout].depth = cdepth[i];
+      contacts[nout].body = h ? cbody2[i] : cbody[i];
+      contacts[nout].collision = two ? (h ? (ccol2[i] | ORC_SELF_B) : (ccol[i] | ORC_SELF_A)) : ccol[i];
     }
-  if (n_contacts) *n_contacts = nreal;
+  }
+  if (n_contacts) *n_contacts = nout;
   if (iters) *iters = it_used;
   if (flags) *flags = fl;
 }

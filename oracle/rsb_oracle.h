@@ -44,7 +44,7 @@ typedef struct orc_params {
   int32_t refine;            /* a contact that slipped earlier in this solve refines its direction by one guarded Newton step
                                 instead of a new global search (0 = always search) */
   int32_t group_parallel;    /* grouped sweep: block Jacobi across limbs, Gauss-Seidel within a limb (see step_impl); 0 = sequential */
-  int32_t reserved0;
+  int32_t self_collision;    /* sphere x sphere contacts between primitives of two non-adjacent bodies of the system (see step_impl) */
   double ground_z;
   double stall_factor;       /* ... and required improvement factor per window */
   double restitution;        /* coefficient of restitution e of the (single) material: v_n+ = -e v_n- ... */
@@ -56,7 +56,20 @@ typedef struct orc_params {
   const double* col_mu;
   const double* col_restitution;
   const double* col_res_threshold;
+  /* self-collision: bodies whose pairs are ignored ([nb*nb] bytes, symmetric; NULL = none) and the contact material of every
+   * candidate pair in enumeration order (NULL = the scalars above) */
+  const uint8_t* self_ignore;
+  const double* self_mu;
+  const double* self_restitution;
+  const double* self_res_threshold;
 } orc_params;
+
+/* collision ids reported for the two entries of a self-collision (RaiSim lists it once per body): primitive id | flag */
+#define ORC_SELF_A 0x10000
+#define ORC_SELF_B 0x20000
+
+/* the candidate pairs of self-collision in enumeration order: pairs[2k], pairs[2k+1] = primitive ids i < j; returns the count */
+int orc_self_pairs(const rsb_model_blob* m, const uint8_t* ignore, int32_t* pairs, int cap);
 
 typedef struct orc_contact {
   double position[3];

@@ -13,6 +13,7 @@ RSB_MAX_CONTACTS = 16
 RSB_NAME_LEN = 48
 
 RSB_HOST, RSB_DEVICE = 0, 1
+RSB_CONTACT_SELF_A, RSB_CONTACT_SELF_B = 0x10000, 0x20000
 RSB_FORCE_AND_TORQUE, RSB_PD_PLUS_FEEDFORWARD_TORQUE = 0, 1
 (RSB_F_GC, RSB_F_GV, RSB_F_PTARGET, RSB_F_DTARGET, RSB_F_TAU_FF, RSB_F_CONTACT_COUNT, RSB_F_CONTACTS,
  RSB_F_FLAGS) = range(8)
@@ -89,6 +90,10 @@ PROTOTYPES = {
     "rsb_set_friction": (_I, [_VP, _D]),
     "rsb_set_material": (_I, [_VP, _D, _D, _D]),
     "rsb_set_collision_materials": (_I, [_VP, _VP, _VP, _VP]),
+    "rsb_set_self_collision": (_I, [_VP, _I]),
+    "rsb_ignore_collision_between": (_I, [_VP, _I, _I]),
+    "rsb_self_collision_pairs": (_I, [_VP, _FP, _I]),
+    "rsb_set_self_collision_materials": (_I, [_VP, _VP, _VP, _VP]),
     "rsb_set_contact_solver_param": (_I, [_VP, _D, _D, _D, _I, _D]),
     "rsb_set_solver_stagnation_exit": (_I, [_VP, _I, _D]),
     "rsb_set_solver_friction_lag": (_I, [_VP, _I, _I, _D]),

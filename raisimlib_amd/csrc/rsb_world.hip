@@ -53,6 +53,14 @@ struct rsb_world {
   std::vector<float> h_kp, h_kd;      // host mirror of the PD gains (baked into the image)
   std::vector<double> col_mu, col_rest, col_rthr;   // per-primitive overrides, < 0 = the world's default
   bool image_dirty = true;
+  // self-collision (rsb_set_self_collision): candidate primitive pairs i < j in enumeration order, body pairs the caller
+  // excluded (rsb_ignore_collision_between), per-pair material overrides (< 0 = the world's default)
+  bool self_collision = true;
+  std::vector<uint8_t> self_ignore;            // [nb * nb]
+  std::vector<int> self_pairs;                 // 2 ints per pair
+  std::vector<double> self_mu, self_rest, self_rthr;
+  float* d_self_mat = nullptr;
+  size_t self_mat_cap = 0;
   float* d_warm = nullptr;   // [N, kWarmRow] contact-solver warm state (StepArgs::warm: one record per contact of the last integrate())
   bool warm_start = true;
   uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
@@ -153,7 +161,23 @@ void build_dev_model(const rsb_model_blob& b, DevModel* d) {
   }
 }
 
-LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
+// candidate pairs of self-collision (oracle: self_pair_ok): primitives on two bodies that are not parent and child, not both
+// points, no rim primitives, bodies not excluded by the caller
+std::vector<int> enumerate_self_pairs(const rsb_model_blob& b, const std::vector<uint8_t>& ignore) {
+  std::vector<int> out;
+  for (int i = 0; i < b.ncol; ++i)
+    for (int j = i + 1; j < b.ncol; ++j) {
+      const int bi = b.col_body[i], bj = b.col_body[j];
+      if (bi == bj || b.parent[bi] == bj || b.parent[bj] == bi) continue;
+      if (b.col_rim[i] > 0.0 || b.col_rim[j] > 0.0) continue;
+      if (!(b.col_radius[i] + b.col_radius[j] > 0.0)) continue;
+      if (!ignore.empty() && (ignore[bi * b.nb + bj] || ignore[bj * b.nb + bi])) continue;
+      out.push_back(i); out.push_back(j);
+    }
+  return out;
+}
+
+LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   LdsLayout L;
   const int cw = round4(6 + b.depth - 1);
   int o = 0;
@@ -166,6 +190,8 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.t_col = take(rsbk::kColSlot * b.ncol);
   L.t_kids = take(b.nb);
   L.t_kidx = take(b.nb);
+  const int spad = rsbk::kSelfBatch * 64;   // whole batches for every lanes_per_env
+  L.t_spair = take(n_self > 0 ? (n_self + spad - 1) / spad * spad : 0);
   L.shared_total = o;
   o = 0;
   L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
@@ -182,12 +208,18 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap) {
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
   L.warm = take(6 * b.ncol);
+  // self-collision: the primitive centres live in the contact columns' space when they fit (dead until the column phase)
+  L.cen = L.wc; L.selft = 0;
+  if (n_self > 0) {
+    if (4 * b.ncol > 3 * kcap * cw) L.cen = take(4 * b.ncol);
+    L.selft = take(4 * kcap);
+  }
   L.per_env = o;
   return L;
 }
 
-size_t lds_bytes_for(const rsb_model_blob& b, int kcap, int lpe) {
-  LdsLayout L = make_layout(b, kcap);
+size_t lds_bytes_for(const rsb_model_blob& b, int kcap, int lpe, int n_self) {
+  LdsLayout L = make_layout(b, kcap, n_self);
   return sizeof(float) * ((size_t)L.shared_total + (size_t)(64 / lpe) * L.per_env);
 }
 
@@ -195,12 +227,12 @@ size_t lds_bytes_for(const rsb_model_blob& b, int kcap, int lpe) {
 // (register budget), so a CU holds min(4, 160 KiB / workgroup LDS) workgroups of 64/LPE envs each.  ANYmal-like models:
 // LPE 16 (4 x 4 envs, 38 KB per workgroup: at N = 4096 one wave on every SIMD of the chip); Atlas-like, kmax 16
 // (25 KB per env): every choice holds 4 envs, LPE 64 keeps all four SIMDs busy.
-int default_lpe(const rsb_model_blob& b, int kmax) {
+int default_lpe(const rsb_model_blob& b, int kmax, int n_self) {
   const int kcap = kmax <= 8 ? 8 : 16;
   const int need = b.nb > 16 ? (b.nb > 32 ? 64 : 32) : 16;   // lane = body in the tree passes
   int best = 64, best_envs = 0, best_wgs = 0;
   for (int lpe = need; lpe <= 64; lpe *= 2) {
-    const size_t wg = lds_bytes_for(b, kcap, lpe);
+    const size_t wg = lds_bytes_for(b, kcap, lpe, n_self);
     if (wg > 160 * 1024) continue;
     const int wgs = (int)std::min<size_t>(4, (160 * 1024) / wg);
     const int envs = wgs * (64 / lpe);
@@ -311,8 +343,10 @@ int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool 
   return launch_step<64, KMAX, CL, ML>(w, a, lds_bytes, prof);
 }
 
+int n_self_pairs(const rsb_world* w) { return w->self_collision ? (int)w->self_pairs.size() / 2 : 0; }
+
 int effective_lpe(const rsb_world* w) {
-  int lpe = w->lpe > 0 ? w->lpe : default_lpe(w->blob, w->kmax);
+  int lpe = w->lpe > 0 ? w->lpe : default_lpe(w->blob, w->kmax, n_self_pairs(w));
   return lpe;
 }
 
@@ -320,7 +354,8 @@ int check_lpe(const rsb_world* w, int lpe) {
   if (lpe != 16 && lpe != 32 && lpe != 64) { rsb::set_error("lanes_per_env must be 16, 32 or 64"); return RSB_E_INVALID; }
   if (lpe < w->blob.nb) { rsb::set_error("lanes_per_env must be >= number of moving bodies (lane = body in the tree passes)"); return RSB_E_INVALID; }
   const int kcap = w->kmax <= 8 ? 8 : 16;
-  if (lds_bytes_for(w->blob, kcap, lpe) > 160 * 1024) { rsb::set_error("lanes_per_env too small: the workgroup's envs do not fit in 160 KiB of LDS"); return RSB_E_INVALID; }
+  if (n_self_pairs(w) > 30 * lpe) { rsb::set_error("too many self-collision candidate pairs for this lanes_per_env (<= 30 per lane): exclude body pairs with rsb_ignore_collision_between or switch self-collision off"); return RSB_E_UNSUPPORTED; }
+  if (lds_bytes_for(w->blob, kcap, lpe, n_self_pairs(w)) > 160 * 1024) { rsb::set_error("lanes_per_env too small: the workgroup's envs do not fit in 160 KiB of LDS"); return RSB_E_INVALID; }
   return RSB_OK;
 }
 
@@ -358,6 +393,8 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
     ct[6] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);
     ct[7] = (float)(w->col_rthr[i] >= 0 ? w->col_rthr[i] : w->res_threshold);
   }
+  // self-collision pairs as byte offsets into the centre table (16 B per primitive); the padding entries pair primitive 0 with itself (never a hit)
+  for (int k = 0; k < n_self_pairs(w); ++k) put_i(L.t_spair + k, (16 * w->self_pairs[2 * k]) | ((16 * w->self_pairs[2 * k + 1]) << 16));
   return img;
 }
 
@@ -377,9 +414,25 @@ int do_integrate(rsb_world* w, int nsub) {
   a.hm_index = w->d_hm_index;
   a.warm = w->warm_start ? w->d_warm : nullptr;
   if (w->image_dirty) {
-    std::vector<float> img = build_lds_image(w, make_layout(w->blob, kcap));
+    std::vector<float> img = build_lds_image(w, make_layout(w->blob, kcap, n_self_pairs(w)));
     HIP_TRY(hipMemcpyAsync(w->d_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));   // img is a stack-lifetime buffer
+    const int np = n_self_pairs(w);
+    std::vector<float> mat((size_t)4 * np, 0.f);
+    for (int k = 0; k < np; ++k) {
+      mat[4 * k] = (float)(w->self_mu[k] >= 0 ? w->self_mu[k] : w->mu);
+      mat[4 * k + 1] = (float)(w->self_rest[k] >= 0 ? w->self_rest[k] : w->restitution);
+      mat[4 * k + 2] = (float)(w->self_rthr[k] >= 0 ? w->self_rthr[k] : w->res_threshold);
+    }
+    if (np > 0) {
+      if ((size_t)np > w->self_mat_cap) {
+        if (w->d_self_mat) HIP_TRY(hipFree(w->d_self_mat));
+        w->d_self_mat = nullptr; w->self_mat_cap = 0;
+        HIP_TRY(hipMalloc(&w->d_self_mat, (size_t)4 * np * sizeof(float)));
+        w->self_mat_cap = (size_t)np;
+      }
+      HIP_TRY(hipMemcpyAsync(w->d_self_mat, mat.data(), mat.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(w->stream));   // img / mat are stack-lifetime buffers
     w->image_dirty = false;
   }
   a.lds_image = w->d_image;
@@ -415,8 +468,9 @@ int do_integrate(rsb_world* w, int nsub) {
     a.hm_dx = (float)dx; a.hm_dy = (float)dy; a.hm_inv_dx = (float)(1.0 / dx); a.hm_inv_dy = (float)(1.0 / dy);
     a.hm_max = w->hm_max;
   }
-  a.L = make_layout(w->blob, kcap);
-  const size_t lds_bytes = lds_bytes_for(w->blob, kcap, lpe);
+  a.n_self = n_self_pairs(w); a.self_mat = w->d_self_mat;
+  a.L = make_layout(w->blob, kcap, a.n_self);
+  const size_t lds_bytes = lds_bytes_for(w->blob, kcap, lpe, n_self_pairs(w));
   static const bool poison = std::getenv("RSB_POISON_LDS") != nullptr;  // debug aid, see tests/test_gpu_properties.py
   a.poison_lds = poison ? 1 : 0;
   static const bool prof_fine = std::getenv("RSB_PROF_FINE") != nullptr;  // debug aid: also time searches / Newton steps / epilogues
@@ -510,7 +564,10 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   HIP_TRY(hipMalloc(&w->d_flags, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_iters, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_obs_idx, RSB_MAX_COLLISIONS * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&w->d_image, (size_t)make_layout(w->blob, 8).shared_total * sizeof(float)));
+  HIP_TRY(hipMalloc(&w->d_image, (size_t)make_layout(w->blob, 8, w->blob.ncol * (w->blob.ncol - 1) / 2).shared_total * sizeof(float)));   // (room for every primitive pair)
+  w->self_ignore.assign((size_t)w->blob.nb * w->blob.nb, 0);
+  w->self_pairs = enumerate_self_pairs(w->blob, w->self_ignore);
+  w->self_mu.assign(w->self_pairs.size() / 2, -1.0); w->self_rest = w->self_mu; w->self_rthr = w->self_mu;
   w->h_kp.assign(nv, 0.f); w->h_kd.assign(nv, 0.f);
   w->col_mu.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rest.assign(RSB_MAX_COLLISIONS, -1.0); w->col_rthr.assign(RSB_MAX_COLLISIONS, -1.0);
   HIP_TRY(hipMalloc(&w->d_warm, N * (size_t)rsbk::kWarmRow * sizeof(float)));
@@ -542,7 +599,7 @@ int rsb_destroy(rsb_world* w) {
   (void)rsb_comm_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -616,6 +673,40 @@ int rsb_set_collision_materials(rsb_world* w, const double* mu, const double* re
     w->col_mu[i] = mu ? mu[i] : -1.0;
     w->col_rest[i] = restitution ? restitution[i] : -1.0;
     w->col_rthr[i] = res_threshold ? res_threshold[i] : -1.0;
+  }
+  w->image_dirty = true;
+  return RSB_OK;
+}
+int rsb_set_self_collision(rsb_world* w, int enable) {
+  if (!w) { rsb::set_error("rsb_set_self_collision: null world"); return RSB_E_INVALID; }
+  w->self_collision = enable != 0;
+  w->image_dirty = true;
+  return RSB_OK;
+}
+int rsb_ignore_collision_between(rsb_world* w, int body_a, int body_b) {
+  if (!w || body_a < 0 || body_b < 0 || body_a >= w->blob.nb || body_b >= w->blob.nb) { rsb::set_error("rsb_ignore_collision_between: body index out of range"); return RSB_E_INVALID; }
+  w->self_ignore[(size_t)body_a * w->blob.nb + body_b] = 1;
+  w->self_ignore[(size_t)body_b * w->blob.nb + body_a] = 1;
+  w->self_pairs = enumerate_self_pairs(w->blob, w->self_ignore);
+  w->self_mu.assign(w->self_pairs.size() / 2, -1.0); w->self_rest = w->self_mu; w->self_rthr = w->self_mu;   // (the pair list changed: overrides are dropped)
+  w->image_dirty = true;
+  return RSB_OK;
+}
+int rsb_self_collision_pairs(const rsb_world* w, int32_t* pairs, int capacity) {
+  if (!w) { rsb::set_error("rsb_self_collision_pairs: null world"); return RSB_E_INVALID; }
+  const int np = (int)w->self_pairs.size() / 2;
+  for (int k = 0; pairs && k < np && k < capacity; ++k) { pairs[2 * k] = w->self_pairs[2 * k]; pairs[2 * k + 1] = w->self_pairs[2 * k + 1]; }
+  return np;
+}
+int rsb_set_self_collision_materials(rsb_world* w, const double* mu, const double* restitution, const double* res_threshold) {
+  if (!w) { rsb::set_error("rsb_set_self_collision_materials: null world"); return RSB_E_INVALID; }
+  const size_t np = w->self_pairs.size() / 2;
+  for (size_t k = 0; k < np; ++k)
+    if (restitution && restitution[k] > 1.0) { rsb::set_error("rsb_set_self_collision_materials: restitution <= 1"); return RSB_E_INVALID; }
+  for (size_t k = 0; k < np; ++k) {
+    w->self_mu[k] = mu ? mu[k] : -1.0;
+    w->self_rest[k] = restitution ? restitution[k] : -1.0;
+    w->self_rthr[k] = res_threshold ? res_threshold[k] : -1.0;
   }
   w->image_dirty = true;
   return RSB_OK;

@@ -528,6 +528,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   float* GINV = E + L.ginv;
   float* LAM = E + L.lam;
   float* WARM = E + L.warm;                                      // [ncol][6] warm state of the contact solver (see StepArgs::warm)
+  const int* SPAIR = reinterpret_cast<const int*>(lds + L.t_spair);   // candidate pairs of self-collision, padded to whole batches of kSelfBatch * LPE: byte offset of centre i in CEN | of centre j << 16
+  float* CEN = E + L.cen;                                        // [ncol][4] primitive centres (relative to the base position) + radius; may alias WC
+  float* SELFT = E + L.selft;                                    // [kmax][4] per contact slot of a self-collision: mu, restitution, threshold | J u of the slot's normal row
+  const int n_self = a.n_self;
   const int nwarm = 6 * ncol;
   const int GS = L.gstride;
 
@@ -614,6 +618,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   }
   int flag = 0, iters_used = 0, nc = 0;
   int nc_real = 0;     // contacts of the last sub-step without the joint-limit rows that follow them in the solver
+  int nselfc = 0;      // self-collisions of the env in the current sub-step (each holds two contact slots)
   bool dead = false;   // early termination: this env no longer integrates (its contacts at that moment stay reported)
   int nc_dead = 0;
   long long t_start = 0, t_gs = 0, t_srch = 0, t_setup = 0, t_newt = 0, t_epi = 0, t_rule = 0, t_exch = 0, t_end = 0; int p_iters = 0, p_ncw = 0, p_search = 0, p_newton = 0, p_solves = 0;
@@ -786,6 +791,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           c[0] += k * aw[2] * aw[0]; c[1] += k * aw[2] * aw[1]; c[2] -= k * len2;
         }
       }
+      if (n_self > 0) { const float c4[4] = {c[0], c[1], c[2], rad}; st4(CEN + 4 * ci, c4); }
     };
     if (ac.terrain_type == 0) {
       // ---- plane: depth = r - (z - z0), normal z
@@ -899,6 +905,80 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       __syncthreads();   // the scratch is free again (the up pass reuses it)
     }
     if (nc > kmax) { nc = kmax; flag |= 1; }
+    // ---- self-collision (oracle: "Self-collision" in step_impl): sphere x sphere over the candidate pairs (primitives of two
+    // bodies that are not parent and child), lane = pair.  A hit takes TWO contact slots, one per body with opposite frames
+    // (what RaiSim's contact list holds); the Delassus phase folds the pair into ONE solver contact (J = J_i - J_j).
+    // The sweep over the pairs only records a hit bit per lane; everything else runs when some env of the wave has a hit.
+    nselfc = 0;
+    if (n_self > 0) {
+      // lane = pair, batches of kSelfBatch passes (the table is padded to whole batches with pairs that cannot hit; the next
+      // batch's entries are in flight while the current one is tested).  An entry holds the byte offsets of the two centres.
+      const int npass = (n_self + LPE - 1) / LPE;
+      const char* cenb = reinterpret_cast<const char*>(CEN);
+      int prn[kSelfBatch];
+      RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) prn[q4] = SPAIR[q4 * LPE + s];
+      __syncthreads();   // the centres of this sub-step are in CEN
+      unsigned hbits = 0u;
+      for (int k0 = 0; k0 < npass; k0 += kSelfBatch) {
+        float ci4[kSelfBatch][4], cj4[kSelfBatch][4];
+        RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) {
+          ld4(reinterpret_cast<const float*>(cenb + (prn[q4] & 0xffff)), ci4[q4]);
+          ld4(reinterpret_cast<const float*>(cenb + ((unsigned)prn[q4] >> 16)), cj4[q4]);
+        }
+        RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) prn[q4] = SPAIR[(k0 + kSelfBatch + q4) * LPE + s];   // (past the table after the last batch: read, never used)
+        RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) {
+          const float dx = ci4[q4][0] - cj4[q4][0], dy = ci4[q4][1] - cj4[q4][1], dz = ci4[q4][2] - cj4[q4][2], rs = ci4[q4][3] + cj4[q4][3];
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          const bool hit = (d2 < rs * rs) & (d2 >= 1e-12f);
+          hbits |= hit ? (1u << (k0 + q4)) : 0u;
+        }
+      }
+      if (dead) hbits = 0u;
+      if (__any(hbits != 0u)) {   // rare
+        const int nc0 = nc;
+        for (int k = 0; k < npass; ++k) {
+          const bool hit = (hbits >> k) & 1u;
+          const unsigned long long bal = __ballot(hit);
+          if (!bal) continue;
+          const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
+          const int slot = nc + 2 * __popcll(gm & ((1ull << s) - 1ull));
+          illegal |= hit;           // a self-collision is never a foot on the terrain: it ends the episode under the rsg_anymal rule
+          if (hit && slot + 1 < kmax) {
+            const int p = k * LPE + s;
+            const int pr = SPAIR[p], pi = (pr & 0xffff) >> 4, pj = (int)((unsigned)pr >> 20);
+            float ci4[4], cj4[4], m4[4];
+            ld4(CEN + 4 * pi, ci4); ld4(CEN + 4 * pj, cj4);
+            ld4(a.self_mat + 4 * (size_t)p, m4);
+            float n[3] = {ci4[0] - cj4[0], ci4[1] - cj4[1], ci4[2] - cj4[2]};
+            const float dist = sqrtf(dot3(n, n)), idist = 1.0f / dist, dep = ci4[3] + cj4[3] - dist;
+            n[0] *= idist; n[1] *= idist; n[2] *= idist;
+            const float back = ci4[3] - 0.5f * dep;   // the middle of the overlap
+            float P[16], t1[3], t2[3];
+            const float dn = n[0];
+            t1[0] = 1.f - dn * n[0]; t1[1] = -dn * n[1]; t1[2] = -dn * n[2];
+            const float il = 1.0f / sqrtf(dot3(t1, t1));
+            t1[0] *= il; t1[1] *= il; t1[2] *= il;
+            cross3(n, t1, t2);
+            P[0] = ci4[0] - back * n[0]; P[1] = ci4[1] - back * n[1]; P[2] = ci4[2] - back * n[2]; P[3] = dep;
+            P[4] = t1[0]; P[5] = t1[1]; P[6] = t1[2]; P[7] = COLT[kColSlot * pi + 4];
+            P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(pi | kSelfA);
+            P[12] = n[0]; P[13] = n[1]; P[14] = n[2]; P[15] = 0.f;
+            stv<4>(CON + slot * kConSlot, P);
+            // second entry: the other body, opposite frame; its rows carry no depth of their own (the fold adds the two)
+            P[3] = 0.f;
+            RSB_UNROLL for (int i = 0; i < 3; ++i) { P[4 + i] = -P[4 + i]; P[8 + i] = -P[8 + i]; P[12 + i] = -P[12 + i]; }
+            P[7] = COLT[kColSlot * pj + 4]; P[11] = __int_as_float(pj | kSelfB);
+            stv<4>(CON + (slot + 1) * kConSlot, P);
+            m4[3] = 0.f;
+            st4(SELFT + 4 * slot, m4); st4(SELFT + 4 * (slot + 1), m4);
+          }
+          nc += 2 * __popcll(gm);
+        }
+        const int fit = nc0 + 2 * ((kmax - nc0) >> 1);   // a self-collision that does not get both slots is dropped
+        if (nc > fit) { nc = fit; flag |= 1; }
+        nselfc = (nc - nc0) >> 1;
+      }
+    }
     // joint limits (oracle: "joint limits" in step_impl): a joint outside [q_lower, q_upper] adds one unilateral row
     // s * qdot >= 0, carried through the solver as a contact with empty tangential rows; slots after the real contacts
     nc_real = nc;
@@ -1053,8 +1133,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           cross3(Vb, x, wxx);  // J u = t . (v_body + w_body x x)
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
           // Newton restitution (oracle: "restitution"): the approach speed J u of this step re-enters the normal row
-          const int cprim = min(__float_as_int(CN[11]), ncol - 1);   // (joint-limit rows carry ids >= ncol and no restitution)
-          const float restitution = COLT[kColSlot * cprim + 6], res_threshold = COLT[kColSlot * cprim + 7];
+          const int cid = __float_as_int(CN[11]);
+          const int cprim = min(cid, ncol - 1);   // (joint-limit rows carry ids >= ncol and no restitution)
+          const bool selfrow = cid >= kSelfA;     // entry of a self-collision: restitution is applied to the folded contact (approach speed = sum of the two entries')
+          if (selfrow && rr == 2) SELFT[4 * i + 3] = cv;
+          const float restitution = selfrow ? 0.f : COLT[kColSlot * cprim + 6], res_threshold = COLT[kColSlot * cprim + 7];
           const float rest = (rr == 2 && lsgn == 0.f && restitution > 0.f && cv < -res_threshold) ? restitution * cv : 0.f;
           const bool limit_row = lsgn != 0.f;
           const bool empty_row = limit_row && rr < 2;
@@ -1145,6 +1228,60 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
       }
       __syncthreads();
+      if (n_self > 0 && __any(nselfc > 0)) {
+        // fold the two entries of every self-collision into one solver contact: G <- P G P^T, c <- P c with P adding the second
+        // entry's rows to the first's.  The second entry stays in the solver as an inert contact (zero rows, unit diagonal,
+        // c = 0: its impulse stays 0) and receives the first one's impulse after the solve (same numbers in its opposite frame).
+        for (int sa = 0; sa + 1 < ncw; ++sa) {
+          const bool prim = sa + 1 < nc && (__float_as_int(CON[sa * kConSlot + 11]) & kSelfA) != 0;
+          if (!__any(prim)) continue;
+          const int sb = sa + 1;
+          const float z4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (prim && s < nc) {       // rows: lane = column block
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+              float ga[4], gb[4];
+              ld4(G + (3 * sa + rr) * GS + 4 * s, ga); ld4(G + (3 * sb + rr) * GS + 4 * s, gb);
+              RSB_UNROLL for (int e = 0; e < 4; ++e) ga[e] += gb[e];
+              st4(G + (3 * sa + rr) * GS + 4 * s, ga); st4(G + (3 * sb + rr) * GS + 4 * s, z4);
+            }
+          }
+          __syncthreads();
+          if (prim) {                 // columns: lane = row
+            for (int r = s; r < 3 * nc; r += LPE) {
+              float ga[4], gb[4];
+              ld4(G + r * GS + 4 * sa, ga); ld4(G + r * GS + 4 * sb, gb);
+              RSB_UNROLL for (int e = 0; e < 4; ++e) ga[e] += gb[e];
+              st4(G + r * GS + 4 * sa, ga); st4(G + r * GS + 4 * sb, z4);
+            }
+          }
+          __syncthreads();
+          if (prim && s == 0) {
+            float m4[4], acc[9], gi[12];
+            ld4(SELFT + 4 * sa, m4);
+            const float ju = m4[3] + SELFT[4 * sb + 3];   // approach speed of the two bodies' points
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { CV[3 * sa + rr] += CV[3 * sb + rr]; CV[3 * sb + rr] = 0.f; }
+            if (m4[1] > 0.f && ju < -m4[2]) CV[3 * sa + 2] += m4[1] * ju;
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+              float g4[4];
+              ld4(G + (3 * sa + rr) * GS + 4 * sa, g4);
+              acc[3 * rr] = g4[0]; acc[3 * rr + 1] = g4[1]; acc[3 * rr + 2] = g4[2];
+            }
+            // two bodies joined by fewer than three joints cannot move relative to each other in every direction: the block is
+            // rank deficient (thigh against trunk: two joints).  A small compliance keeps the per-contact rule well posed
+            // (oracle: ORC_SELF_REG)
+            const float reg = kSelfReg * (acc[0] + acc[4] + acc[8]) * (1.0f / 3.0f);
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { acc[4 * rr] += reg; G[(3 * sa + rr) * GS + 4 * sa + rr] = acc[4 * rr]; }
+            inv3(acc, gi);
+            gi[9] = gi[10] = gi[11] = 0.f;
+            stv<3>(GINV + 12 * sa, gi);
+            RSB_UNROLL for (int q2 = 0; q2 < 12; ++q2) gi[q2] = 0.f;
+            gi[0] = gi[4] = gi[8] = 1.f;
+            stv<3>(GINV + 12 * sb, gi);
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) G[(3 * sb + rr) * GS + 4 * sb + rr] = 1.f;
+          }
+          __syncthreads();
+        }
+      }
       RSB_STAMP(5)
 
       if (PROF && a.dbg && env == a.dbg_env && env_valid && s == 0) {   // debug aid: the contact problem of the real contacts (no limit rows)
@@ -1193,7 +1330,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         RSB_ARGS(ag);
         // the own contact's friction coefficient: that of its collision primitive against the terrain (material pairs)
         const int mycol = isc ? __float_as_int(CON[s * kConSlot + 11]) : 0;
-        const float mu = (isc && mycol < ncol) ? COLT[kColSlot * mycol + 5] : ag.mu, mu2 = mu * mu;
+        // a self-collision couples two limbs strongly: every contact of such an env is solved in turn (one group; oracle: same
+        // rule); the inert second entries keep ids of their own
+        if (nselfc > 0 && isc) gidc = (mycol & kSelfB) ? (-1 - s) : 0;
+        float mu = (isc && mycol < ncol) ? COLT[kColSlot * mycol + 5] : ag.mu;
+        if (mycol & kSelfA) mu = SELFT[4 * s];    // material pair of the two primitives
+        const float mu2 = mu * mu;
         const float alpha_init = ag.alpha_init, alpha_min = ag.alpha_min, alpha_decay = ag.alpha_decay, threshold = ag.threshold;
         const float stall_factor = ag.stall_factor;
         const int max_iter = ag.max_iter, section_rounds = ag.section_rounds, stall_window = ag.stall_window;
@@ -1415,6 +1557,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
         if (PROF && pfine) tz0 = t_prev;
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
+        if (n_self > 0 && __any(nselfc > 0)) {   // the second entry of a self-collision carries the first one's impulse (in its opposite frame)
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+            const float up = __shfl_up(lam[rr], 1);
+            lam[rr] = (mycol & kSelfB) ? up : lam[rr];
+          }
+        }
         if (isc) {
           LAM[3 * s] = lam[0]; LAM[3 * s + 1] = lam[1]; LAM[3 * s + 2] = lam[2];
           if (has_warm && mycol < ncol) {
@@ -1540,7 +1688,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     if (dead) { nc = nc_dead; flag |= 8; }   // report the contacts that ended the episode
     int mycol = 0;
     if (s < nc) mycol = __float_as_int(CON[s * kConSlot + 11]);
-    const bool illegal = ae.do_reset && s < nc && !((ae.allowed >> mycol) & 1ull);
+    const bool illegal = ae.do_reset && s < nc && (mycol >= kSelfA || !((ae.allowed >> mycol) & 1ull));
     const unsigned long long bb = __ballot(bad), bi = __ballot(illegal);
     const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
     if (bb & gsel) flag |= 2;
@@ -1568,7 +1716,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     }
     if (ae.warm && s < kmax) {   // one record per contact of the last sub-step (see the prologue); empty records behind them
       float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (s < nc && !term && !dead) {
+      if (s < nc && mycol < ncol && !term && !dead) {   // (a self-collision starts cold)
         const float* wr = WARM + 6 * mycol;
         RSB_UNROLL for (int i = 0; i < 6; ++i) rec[i] = wr[i];
         rec[6] = __int_as_float(mycol + 1);
@@ -1590,7 +1738,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         ct.normal[i] = CN[12 + i];
         ct.impulse[i] = CN[4 + i] * l0 + CN[8 + i] * l1 + CN[12 + i] * l2;
       }
-      ct.depth = CN[3];
+      ct.depth = (__float_as_int(CN[11]) & kSelfB) ? CON[(s - 1) * kConSlot + 3] : CN[3];   // (the second entry of a self-collision reports the pair's depth)
       ct.body = __float_as_int(CN[7]);
       ct.collision = __float_as_int(CN[11]);
       ae.contacts[(size_t)env * kmax + s] = ct;

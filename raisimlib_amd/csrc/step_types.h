@@ -24,6 +24,10 @@ constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
 constexpr int kLightDepth = 3;        // == ORC_LIGHT_DEPTH
+constexpr int kSelfA = 0x10000;       // collision id flags of the two entries of a self-collision (== RSB_CONTACT_SELF_A / _B, ORC_SELF_A / _B)
+constexpr int kSelfB = 0x20000;
+constexpr int kSelfBatch = 5;          // passes per batch of the self-collision sweep (the pair table is padded to whole batches for every lanes_per_env)
+constexpr float kSelfReg = 1e-4f;      // == ORC_SELF_REG: compliance of a self-collision's Delassus block, relative to its mean diagonal
 constexpr int kWarmRec = 8;           // floats per warm-state record in HBM: impulse (3), friction direction (2), direction valid, primitive + 1, pad
 constexpr int kWarmRow = kWarmRec * RSB_MAX_CONTACTS;   // floats per env row of StepArgs::warm
 constexpr int kHmRec = 28;            // floats per slot of the height-map narrow phase: sphere, cell range, 4 x 4 corner heights
@@ -47,9 +51,10 @@ struct DevModel {
 
 struct LdsLayout {
   // per-block tables (floats from the start of LDS)
-  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_kids, t_kidx, shared_total;
+  int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_kids, t_kidx, t_spair, shared_total;
   // per-env arrays (floats from the env base)
   int q, u, pt, dtg, tf, body, fact, wb, con, wc, cv, g, ginv, lam, warm;   // (the up pass's hand-over slots alias g)
+  int cen, selft;   // self-collision: primitive centres [ncol][4] (may alias wc: dead before the contact columns), per-slot pair record [kcap][4]
   int gstride;
   int per_env;
 };
@@ -97,6 +102,9 @@ struct StepArgs {
   float* env_reward;           // [N]
   float* env_ob;               // [N, 10 + 2 (nv - 6)]
   float env_fwd_coeff, env_fwd_clip, env_torque_coeff, env_terminal_reward;
+  // self-collision (rsb_set_self_collision): candidate primitive pairs (ids in the LDS image, LdsLayout::t_spair) and their materials
+  int n_self;                  // candidate pairs; 0 = self-collision off
+  const float* self_mat;       // [n_self][4] mu, restitution, restitution threshold, - of each pair
   const uint8_t* env_mask;     // [N] optional: envs with 0 are not integrated and none of their rows is written (rsb_integrate_masked)
   long long* prof;  // optional [16] cycle stamps (s_memtime) of block 0's phases in the last sub-step
   float* dbg;       // optional dump of env dbg_env's contact problem (nc, G, c, lam)

@@ -97,7 +97,7 @@ def atlas_like():
            '<robot name="atlas_like">']
     E = 400.0
     out.append(link("pelvis", 17.9, (0.011, 0.0, 0.027), (0.125, 0.086, 0.165),
-                    [dict(name="pelvis_s", type="sphere", xyz=(0, 0, 0.0), radius=0.16)]))
+                    [dict(name="pelvis_s", type="sphere", xyz=(0, 0, 0.0), radius=0.12)]))   # (clear of the torso capsule, three joints up: links of one system collide)
     out.append(link("ltorso", 2.4, (-0.011, 0.0, 0.075), (0.0040, 0.0055, 0.0035)))
     out.append(joint("back_bkz", "revolute", "pelvis", "ltorso", (-0.0125, 0.0, 0.0), (0, 0, 1), effort=E))
     out.append(link("mtorso", 0.69, (-0.008, 0.0, 0.04), (0.0005, 0.0004, 0.0008)))

@@ -167,6 +167,32 @@ class BatchedWorld:
         check(self.L.rsb_set_collision_materials(self.handle, *[None if a is None else a.ctypes.data for a in arrs]),
               "rsb_set_collision_materials")
 
+    def set_self_collision(self, enable=True):
+        """Collisions between non-adjacent bodies of the system (sphere x sphere; on by default, as in RaiSim)."""
+        check(self.L.rsb_set_self_collision(self.handle, int(bool(enable))), "rsb_set_self_collision")
+
+    def ignore_collision_between(self, body_a, body_b):
+        """ArticulatedSystem::ignoreCollisionBetween(bodyIdx1, bodyIdx2); per-pair materials are reset."""
+        check(self.L.rsb_ignore_collision_between(self.handle, int(body_a), int(body_b)), "rsb_ignore_collision_between")
+
+    def self_collision_pairs(self):
+        """[(i, j)] candidate primitive pairs (i < j) of self-collision."""
+        n = self.L.rsb_self_collision_pairs(self.handle, None, 0)
+        out = np.zeros((n, 2), np.int32)
+        if n:
+            self.L.rsb_self_collision_pairs(self.handle, out.ctypes.data, n)
+        return out
+
+    def set_self_collision_materials(self, mu=None, restitution=None, res_threshold=None):
+        """One (mu, restitution, res_threshold) per candidate pair of self_collision_pairs(); None / negative = world default."""
+        n = len(self.self_collision_pairs())
+        arrs = [None if a is None else np.ascontiguousarray(a, dtype=np.float64) for a in (mu, restitution, res_threshold)]
+        for a in arrs:
+            if a is not None and a.shape != (n,):
+                raise ValueError("set_self_collision_materials: one entry per candidate pair expected")
+        check(self.L.rsb_set_self_collision_materials(self.handle, *[None if a is None else a.ctypes.data for a in arrs]),
+              "rsb_set_self_collision_materials")
+
     def set_default_friction(self, mu):
         check(self.L.rsb_set_friction(self.handle, float(mu)), "rsb_set_friction")
 

@@ -278,6 +278,51 @@ int main(int argc, char** argv) {
       std::printf("material pairs: rubber on concrete / ice slide at their own mu\n");
     }
 
+    // ---- self-collision: a three-link chain folds its hand onto its own torso; the contact is listed once per body
+    //      (isSelfCollision, object A first), ignoreCollisionBetween removes it
+    {
+      const char* folder = "<robot name=\"folder\">"
+        "<link name=\"torso\"><inertial><origin xyz=\"0 0 0\"/><mass value=\"5\"/><inertia ixx=\"0.05\" ixy=\"0\" ixz=\"0\" iyy=\"0.05\" iyz=\"0\" izz=\"0.05\"/></inertial>"
+        "<collision><origin xyz=\"0 0 0\"/><geometry><sphere radius=\"0.1\"/></geometry></collision></link>"
+        "<link name=\"upper\"><inertial><origin xyz=\"0 0 -0.15\"/><mass value=\"1\"/><inertia ixx=\"0.01\" ixy=\"0\" ixz=\"0\" iyy=\"0.01\" iyz=\"0\" izz=\"0.002\"/></inertial></link>"
+        "<link name=\"lower\"><inertial><origin xyz=\"0 0 -0.15\"/><mass value=\"1\"/><inertia ixx=\"0.01\" ixy=\"0\" ixz=\"0\" iyy=\"0.01\" iyz=\"0\" izz=\"0.002\"/></inertial>"
+        "<collision><origin xyz=\"0 0 -0.3\"/><geometry><sphere radius=\"0.05\"/></geometry></collision></link>"
+        "<joint name=\"shoulder\" type=\"revolute\"><origin xyz=\"0.15 0 0\"/><parent link=\"torso\"/><child link=\"upper\"/><axis xyz=\"0 1 0\"/><limit effort=\"100\" velocity=\"100\" lower=\"-10\" upper=\"10\"/></joint>"
+        "<joint name=\"elbow\" type=\"revolute\"><origin xyz=\"0 0 -0.3\"/><parent link=\"upper\"/><child link=\"lower\"/><axis xyz=\"0 1 0\"/><limit effort=\"100\" velocity=\"100\" lower=\"-10\" upper=\"10\"/></joint>"
+        "</robot>";
+      const std::string path = "/tmp/rsb_facade_folder.urdf";
+      { FILE* f = std::fopen(path.c_str(), "w"); CHECK(f != nullptr); std::fputs(folder, f); std::fclose(f); }
+      for (int variant = 0; variant < 2; ++variant) {
+        raisim::World w;
+        w.setTimeStep(0.0025);
+        auto* r = w.addArticulatedSystem(path);
+        w.setGravity({0, 0, 0});
+        w.addGround(-10.0);
+        if (variant == 1) r->ignoreCollisionBetween(r->getBodyIdx("torso"), r->getBodyIdx("lower"));
+        raisim::VecDyn q(9), u(8), kp(8), kd(8), pt(9), dtg(8);
+        q[2] = 1.0; q[3] = 1.0; q[8] = 2.0;
+        kp[6] = kp[7] = 40.0; kd[6] = kd[7] = 2.0;
+        pt[7] = 0.3; pt[8] = 3.1;
+        r->setState(q, u);
+        r->setPdGains(kp, kd);
+        r->setPdTarget(pt, dtg);
+        int touched = 0;
+        for (int i = 0; i < 300; ++i) {
+          w.integrate();
+          auto& cs = r->getContacts();
+          if (cs.empty()) continue;
+          ++touched;
+          CHECK(cs.size() == 2 && cs[0].isSelfCollision() && cs[1].isSelfCollision() && cs[0].isObjectA() && !cs[1].isObjectA());
+          CHECK(cs[0].getlocalBodyIndex() == 0 && cs[1].getlocalBodyIndex() == 2 && cs[0].getCollisionIndex() == 0 && cs[1].getCollisionIndex() == 1);
+          for (int c = 0; c < 3; ++c) CHECK(std::fabs(cs[0].getImpulse()[c] + cs[1].getImpulse()[c]) < 1e-9 && std::fabs(cs[0].getNormal()[c] + cs[1].getNormal()[c]) < 1e-9);
+        }
+        CHECK(variant == 0 ? touched > 100 : touched == 0);
+        const double elbow = r->getGeneralizedCoordinate()[8];
+        CHECK(variant == 0 ? elbow < 3.0 : elbow > 3.0);     // the torso is in the way / the hand passes through it
+      }
+      std::printf("self-collision: listed per body, ignoreCollisionBetween removes it\n");
+    }
+
     // ---- fixed-base system (URDF root link "world"): the facade exposes the joints only, as upstream does
     {
       const char* arm = "<robot name=\"arm\"><link name=\"world\"/>"

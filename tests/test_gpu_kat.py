@@ -4,7 +4,7 @@ in-repo oracle.  Every KAT runs 64 identical envs (one wave would hide lane-mapp
 import numpy as np
 import pytest
 
-from common import PENDULUM_URDF, sphere_urdf
+from common import PENDULUM_URDF, Oracle, sphere_urdf
 from raisimlib_amd import BatchedWorld, Model, workload
 from test_oracle_kat import SLED
 
@@ -241,4 +241,36 @@ def test_cylinder_rests_on_its_rims(built_lib):
     cnt, con = w.get_contacts()
     assert (cnt == 1).all() and abs(con[3][0]["depth"] - 2e-3) < 2e-6
     assert np.allclose(con[3][0]["position"][:2], [-(L / 2) * np.sin(a) + R * np.cos(a), 0.0], atol=2e-6)
+    w.close()
+
+
+def test_self_collision_folds_the_hand_onto_the_torso(built_lib):
+    """The oracle KAT's three-link chain through the C-ABI: two flagged entries with opposite normals and impulses, the
+    overlap never grows, and the trajectory follows the oracle's."""
+    from test_oracle_kat import FOLDER
+    mod, w = world(FOLDER)
+    o = Oracle(mod.blob)
+    w.set_gravity([0, 0, 0]); o.p.gravity[2] = 0.0
+    kp = np.array([0] * 6 + [40.0, 40.0]); kd = np.array([0] * 6 + [2.0, 2.0])
+    pt = np.array([0, 0, 0, 0, 0, 0, 0, 0.3, 3.1])
+    w.set_pd_gains(kp, kd); w.set_pd_target(tile(pt), tile(np.zeros(8)))
+    q = np.array([0, 0, 1.0, 1, 0, 0, 0, 0.0, 2.0]); u = np.zeros(8)
+    w.set_state(tile(q), tile(u))
+    touched, first, worst = 0, None, 0.0
+    for k in range(400):
+        w.integrate(1)
+        q, u, con, _, _ = o.step(q, u, kp, kd, pt, np.zeros(8))
+        cnt, dc = w.get_contacts()
+        assert (cnt == len(con)).all()
+        if len(con):
+            touched += 1
+            d = dc[2][:2]
+            assert list(d["collision"]) == [0 | 0x10000, 1 | 0x20000] and list(d["body"]) == [0, 2]
+            assert np.allclose(d["normal"][0], -d["normal"][1]) and np.allclose(d["impulse"][0], -d["impulse"][1])
+            assert d["depth"][0] == d["depth"][1] and np.allclose(d["position"][0], d["position"][1])
+            first = d["depth"][0] if first is None else first
+            worst = max(worst, d["depth"][0])
+    qd, ud = w.get_state()
+    assert touched > 100 and worst <= first + 2e-4       # (+ the creep of the block's 1e-4 compliance, see the oracle KAT)
+    assert np.abs(qd[2] - q).max() < 2e-3 and np.abs(ud[2] - u).max() < 2e-2      # 400 steps of a PD-driven sliding contact, fp32 vs fp64
     w.close()

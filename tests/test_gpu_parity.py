@@ -50,12 +50,12 @@ def run_one_step(model, gc, gv, pt, kp, kd, lpe=0, kmax=8, substeps=1, heightmap
     return dict(q=q1, u=u1, cnt=cnt, con=con, iters=its, flags=fl), ref, o
 
 
-def check_step(dev, ref, max_iter=150, du_tol=2e-4, both_converged=False):
+def check_step(dev, ref, max_iter=150, du_tol=2e-4, both_converged=False, min_conv=0.9):
     assert np.array_equal(dev["cnt"], ref["n_contacts"])
     conv = (ref["flags"] & 4) == 0          # oracle met its convergence test (no max_iter / stagnation exit)
     if both_converged:                      # very slow solves (dozens of sweeps) can end on different sides of the exit tests
         conv &= (dev["flags"] & 4) == 0
-    assert conv.mean() > 0.9
+    assert conv.mean() > min_conv
     eq = np.abs(dev["q"] - ref["q"])
     eu = np.abs(dev["u"] - ref["u"]).max(axis=1)
     su = 1 + np.abs(ref["u"]).max(axis=1)
@@ -95,6 +95,82 @@ def test_per_primitive_materials_parity(anymal):
     # and the table matters: the default material gives a visibly different answer
     dev0, _, _ = run_one_step(anymal, gc, gv, gc, kp, kd, substeps=3)
     assert np.abs(dev0["u"] - dev["u"]).max() > 1e-2
+
+
+def _contorted_states(n, seed, z):
+    """ANYmal-like robots with joints anywhere in +-2.5 rad: legs fold onto the trunk and cross each other."""
+    rng = np.random.default_rng(seed)
+    gc, gv = standing_states(n, seed=seed, z=z, vel=1.0)
+    gc[:, 7:] = rng.uniform(-2.5, 2.5, (n, 12))
+    return gc, gv
+
+
+@pytest.mark.parametrize("lpe,z", [(16, (2.0, 2.1)), (32, (2.0, 2.1)), (16, (0.25, 0.5)), (64, (0.25, 0.5))])
+def test_self_collision_parity(anymal, lpe, z):
+    """Self-collision (spheres of non-adjacent bodies): contorted robots in the air (self-contacts only) and on the ground
+    (terrain contacts + self-contacts + contact overflow), one integrate() with PD towards the contorted pose, vs the oracle.
+    Same contact lists (two flagged entries per self-collision), velocities within the one-step tolerance."""
+    gc, gv = _contorted_states(512, 300 + lpe, z)
+    kp, kd = workload.anymal_gains()
+    dev, ref, o = run_one_step(anymal, gc, gv, gc, kp, kd, lpe=lpe)
+    rc = ref["contacts"]
+    valid = np.arange(rc.shape[1])[None, :] < ref["n_contacts"][:, None]
+    is_self = valid & (rc["collision"] >= 0x10000)
+    assert is_self.any(axis=1).sum() > 150 and (is_self.sum(axis=1) >= 4).sum() > 20    # many envs with one, some with two and more
+    if z[0] < 1:
+        assert (valid & ~is_self).any(axis=1).sum() > 200 and ((ref["flags"] & 1) != 0).sum() > 5   # terrain contacts and overflow too
+    assert np.array_equal(dev["cnt"], ref["n_contacts"])
+    assert np.array_equal((dev["flags"] & 1), (ref["flags"] & 1))
+    for e in range(len(gc)):
+        n = ref["n_contacts"][e]
+        d, r = dev["con"][e][:n], rc[e][:n]
+        assert np.array_equal(d["collision"], r["collision"]) and np.array_equal(d["body"], r["body"]), e
+        assert np.abs(d["position"] - r["position"]).max(initial=0) < 5e-6 and np.abs(d["normal"] - r["normal"]).max(initial=0) < 2e-4, e
+        assert np.abs(d["depth"] - r["depth"]).max(initial=0) < 2e-6, e
+    # velocities / positions: the one-step tolerance for (nearly) all converged envs.  These poses are far outside anything a
+    # controller produces (limbs buried in the trunk: ~10 % of the solves stagnate), so the tail is bounded, not pinned.
+    # Measured (4 populations x 512 envs): |du| / (1 + |u|) median 5e-8, p99 7e-5, max 7e-4; |dq| over its tolerance: 2 envs.
+    conv = ((ref["flags"] | dev["flags"]) & 4) == 0
+    assert conv.mean() > 0.8
+    eu = np.abs(dev["u"] - ref["u"]).max(axis=1) / (1 + np.abs(ref["u"]).max(axis=1))
+    eq = (np.abs(dev["q"] - ref["q"]) / (2e-6 + 1e-6 * np.abs(ref["q"]))).max(axis=1)
+    assert np.median(eu[conv]) < 1e-6 and np.percentile(eu[conv], 99) < 2e-4 and eu[conv].max() < 2e-3
+    assert np.percentile(eq[conv], 99) <= 1.0 and eq[conv].max() < 50
+    assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()
+    di = np.abs(dev["iters"][conv] - ref["iters"][conv])
+    assert (di <= 2).mean() > 0.9 and di.max() <= 10
+    # impulses: two bodies fewer than three joints apart cannot move relative to each other in every direction; the impulse
+    # component along such a direction does nothing and is only as well defined as the block's 1e-4 compliance makes it
+    imp_err = np.array([np.abs(dev["con"][e][:ref["n_contacts"][e]]["impulse"] - rc[e][:ref["n_contacts"][e]]["impulse"]).max(initial=0) for e in np.nonzero(conv)[0]])
+    assert np.median(imp_err) < 1e-5 and np.percentile(imp_err, 90) < 1e-3 and imp_err.max() < 0.3
+
+
+def test_self_collision_can_be_switched_off_and_pairs_ignored(anymal):
+    gc, gv = _contorted_states(128, 11, (2.0, 2.1))
+    kp, kd = workload.anymal_gains()
+    w = BatchedWorld(anymal, 128)
+    o = Oracle(anymal.blob)
+    assert np.array_equal(w.self_collision_pairs(), o.self_pairs()) and len(o.self_pairs()) == 160
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, np.zeros((128, 18)))
+    w.set_state(gc, gv); w.integrate(1)
+    cnt_on, _ = w.get_contacts()
+    w.set_self_collision(False)
+    w.set_state(gc, gv); w.integrate(1)
+    cnt_off, _ = w.get_contacts()
+    assert cnt_on.sum() > 50 and cnt_off.sum() == 0
+    # ignoreCollisionBetween(base, every shank): those pairs leave the candidate list, on the device as in the oracle
+    w.set_self_collision(True)
+    ign = np.zeros((anymal.nb, anymal.nb), bool)
+    for b in (3, 6, 9, 12):
+        w.ignore_collision_between(0, b); ign[0, b] = True
+    o.set_self_collision(True, ignore=ign)
+    assert np.array_equal(w.self_collision_pairs(), o.self_pairs()) and len(o.self_pairs()) < 160
+    w.set_state(gc, gv); w.integrate(1)
+    cnt_ign, con = w.get_contacts()
+    ref = o.step_batch(f32(gc), f32(gv), 1, kp.astype(np.float64), kd.astype(np.float64), f32(gc), np.zeros((128, 18)), want_contacts=True,
+                       lam_warm=o.new_warm_state(128))
+    assert np.array_equal(cnt_ign, ref["n_contacts"]) and 0 < cnt_ign.sum() < cnt_on.sum()
+    w.close()
 
 
 def test_lanes_per_env_mappings_agree(anymal):

@@ -385,3 +385,66 @@ def test_cylinder_rests_on_its_rims_lying_standing_and_tilted(built_lib):
     _, _, con, _, _ = o.step(q, u)
     assert len(con) == 1 and abs(con["depth"][0] - 2e-3) < 1e-9
     assert np.allclose(con["position"][0][:2], [-(L / 2) * np.sin(a) + R * np.cos(a), 0.0], atol=1e-9)
+
+
+FOLDER = """<robot name="folder">
+ <link name="torso"><inertial><origin xyz="0 0 0"/><mass value="5"/><inertia ixx="0.05" ixy="0" ixz="0" iyy="0.05" iyz="0" izz="0.05"/></inertial>
+  <collision><origin xyz="0 0 0"/><geometry><sphere radius="0.1"/></geometry></collision></link>
+ <link name="upper"><inertial><origin xyz="0 0 -0.15"/><mass value="1"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.002"/></inertial></link>
+ <link name="lower"><inertial><origin xyz="0 0 -0.15"/><mass value="1"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.002"/></inertial>
+  <collision><origin xyz="0 0 -0.3"/><geometry><sphere radius="0.05"/></geometry></collision></link>
+ <joint name="shoulder" type="revolute"><origin xyz="0.15 0 0"/><parent link="torso"/><child link="upper"/><axis xyz="0 1 0"/>
+  <limit effort="100" velocity="100" lower="-10" upper="10"/></joint>
+ <joint name="elbow" type="revolute"><origin xyz="0 0 -0.3"/><parent link="upper"/><child link="lower"/><axis xyz="0 1 0"/>
+  <limit effort="100" velocity="100" lower="-10" upper="10"/></joint>
+</robot>"""
+
+
+def test_self_collision_is_an_internal_force(built_lib):
+    """A floating three-link chain folds its hand onto its own torso (no gravity, PD drive).  Torso and forearm are not
+    parent and child, so their spheres collide: the contact is listed once per body with opposite normals and impulses,
+    it stops the penetration, and - being internal - its impulse leaves the system's linear and angular momentum untouched:
+    M(q) (u+ - u+ without the contact) = J^T lam has no resultant."""
+    mod, o = make(FOLDER)
+    _, off = make(FOLDER)
+    off.set_self_collision(False)
+    assert [tuple(p) for p in o.self_pairs()] == [(0, 1)]
+    o.p.gravity[2] = off.p.gravity[2] = 0.0
+    kp = np.array([0] * 6 + [40.0, 40.0]); kd = np.array([0] * 6 + [2.0, 2.0])
+    q = np.array([0, 0, 1.0, 1, 0, 0, 0, 0.0, 2.0]); u = np.zeros(8)
+    pt = np.array([0, 0, 0, 0, 0, 0, 0, 0.3, 3.1]); dtg = np.zeros(8)
+    touched, depth_max, depth_first, dmom, dvel = 0, 0.0, None, 0.0, 0.0
+    for k in range(800):
+        q0 = q.copy()
+        _, u_off, con_off, _, _ = off.step(q, u, kp, kd, pt, dtg)
+        q, u, con, _, fl = o.step(q, u, kp, kd, pt, dtg)
+        assert len(con_off) == 0 and fl == 0
+        if len(con):
+            touched += 1
+            assert len(con) == 2 and list(con["collision"]) == [0 | 0x10000, 1 | 0x20000] and list(con["body"]) == [0, 2]
+            assert np.allclose(con["position"][0], con["position"][1]) and con["depth"][0] == con["depth"][1]
+            assert np.allclose(con["normal"][0], -con["normal"][1]) and np.allclose(con["impulse"][0], -con["impulse"][1])
+            assert con["impulse"][0] @ con["normal"][0] >= -1e-12          # the torso is pushed away from the hand
+            assert abs(np.linalg.norm(con["normal"][0]) - 1) < 1e-12
+            depth_max = max(depth_max, con["depth"][0])
+            depth_first = con["depth"][0] if depth_first is None else depth_first
+            (l1, a1), (l0, a0) = o.momentum(q0, u), o.momentum(q0, u_off)
+            dmom = max(dmom, np.abs(l1 - l0).max(), np.abs(a1 - a0).max())
+            dvel = max(dvel, np.abs(u - u_off).max())
+        else:
+            assert np.array_equal(u, u_off)
+    assert touched > 300                      # the hand stays pressed on the torso
+    assert depth_max <= depth_first + 2e-4 < 0.01   # the overlap stays what the first detection found (erp 0; + the creep of the
+                                                    # block's 1e-4 compliance: the two bodies are two joints apart, their block is singular)
+    assert dvel > 1.0 and dmom < 1e-12        # the contact changes velocities by > 1 (m/s, rad/s) and the momentum by nothing
+    off_q = np.array([0, 0, 1.0, 1, 0, 0, 0, 0.0, 2.0]); off_u = np.zeros(8)   # without self-collision the hand sinks into the torso
+    for k in range(800):
+        off_q, off_u, con, _, _ = off.step(off_q, off_u, kp, kd, pt, dtg)
+    assert abs(off_q[8] - 3.1) < 0.05 and abs(off_q[7] - 0.3) < 0.05
+
+
+def test_ignore_collision_between_removes_the_pair(built_lib):
+    mod, o = make(FOLDER)
+    ign = np.zeros((3, 3), bool); ign[0, 2] = True
+    o.set_self_collision(True, ignore=ign)
+    assert len(o.self_pairs()) == 0

@@ -42,7 +42,7 @@ def _population(m, N, steps, collect_from, reset):
         if reset:
             con, ncs = r["contacts"], r["n_contacts"]
             valid = np.arange(con.shape[1])[None, :] < ncs[:, None]
-            term = (valid & ~feet_set[con["collision"]]).any(axis=1) | (r["flags"] & 2).astype(bool)
+            term = (valid & ~(feet_set[con["collision"] & 0xffff] & (con["collision"] < 0x10000))).any(axis=1) | (r["flags"] & 2).astype(bool)
             q[term], u[term], warm[term] = gc0[term], gv0[term], 0.0
     return samples
 

@@ -20,7 +20,7 @@ for cs in range(300):
         w.integrate(1)
         cnt, con = w.get_contacts()
         valid = np.arange(con.shape[1])[None, :] < cnt[:, None]
-        ill = (valid & ~feet[con["collision"]]).any(1)
+        ill = (valid & ~(feet[con["collision"] & 0xffff] & (con["collision"] < 0x10000))).any(1)
         anyill |= ill
     if cs >= 100:
         tot_last += int(ill.sum()); tot_any += int(anyill.sum()); tot_only_early += int((anyill & ~ill).sum())
