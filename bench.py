@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--stall-window", type=int, default=-1, help="diagnostic: solver stagnation window (library default 4)")
     ap.add_argument("--freeze-after", type=int, default=-1, help="diagnostic: sweeps before friction directions lag (default 6)")
     ap.add_argument("--settle-tol", type=float, default=-1.0, help="diagnostic: settled-direction tolerance (default 1e-4 rad)")
+    ap.add_argument("--no-self-collision", action="store_true", help="diagnostic: switch the self-collision sweep off (RaiSim's default, and this library's, is on)")
     ap.add_argument("--early-termination", action="store_true",
                     help="NOT the headline workload: envs stop integrating at the sub-step of their first non-foot contact")
     ap.add_argument("--overlap-collective", action="store_true",
@@ -157,7 +158,7 @@ def recorded_traffic(config, n_envs, substeps):
         return None, None, None
 
 
-def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, step0):
+def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, step0, self_collision=True):
     """Time the fp64 oracle (OpenMP over envs) on a bounded sample of the same workload: it starts from the state the GPU
     population had at the start of the timed region (so both legs see the same stationary mix of standing, falling and
     freshly reset robots) and continues the same target sequence.
@@ -170,6 +171,7 @@ def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, 
     model = recipe.model
     orc = Oracle(model.blob)
     recipe.setup_oracle(orc)
+    orc.p.self_collision = int(self_collision)
     if max_iter > 0:
         orc.p.max_iter = max_iter
     n = q0.shape[0]
@@ -258,6 +260,8 @@ def main():
         world.set_lanes_per_env(args.lanes_per_env)
     if args.early_termination:
         world.set_early_termination(True)
+    if args.no_self_collision:
+        world.set_self_collision(False)
     if args.stall_window >= 0:
         world.set_solver_stagnation_exit(args.stall_window, 0.5)
     if args.freeze_after >= 0 or args.settle_tol >= 0:
@@ -425,6 +429,7 @@ def main():
                                    "friction_directions_lag_after_sweeps": args.freeze_after if args.freeze_after >= 0 else 6,
                                    "stagnation_exit": {"window": args.stall_window if args.stall_window >= 0 else 4, "factor": 0.5},
                                    "warm_start": True},
+                "self_collision": {"enabled": not args.no_self_collision, "candidate_pairs": int(len(world.self_collision_pairs()))},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
                 "obs_all_gather": gath.describe(),
             },
@@ -435,7 +440,8 @@ def main():
         }
         if world_size == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(recipe, args.max_iter, reset, args.cpu_seconds, q_start, u_start,
-                                               gc0.astype(np.float32).astype(np.float64), gv0, step_start)
+                                               gc0.astype(np.float32).astype(np.float64), gv0, step_start,
+                                               self_collision=not args.no_self_collision)
     world.close()
     if coll:
         dist.destroy_process_group()

@@ -190,8 +190,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   L.t_col = take(rsbk::kColSlot * b.ncol);
   L.t_kids = take(b.nb);
   L.t_kidx = take(b.nb);
-  const int spad = rsbk::kSelfBatch * 64;   // whole batches for every lanes_per_env
-  L.t_spair = take(n_self > 0 ? (n_self + spad - 1) / spad * spad : 0);
+  L.t_spair = take(n_self > 0 ? n_self + 1 : 0);   // (+ one entry that cannot hit, read by the lanes past the list)
   L.shared_total = o;
   o = 0;
   L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
@@ -393,7 +392,7 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
     ct[6] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);
     ct[7] = (float)(w->col_rthr[i] >= 0 ? w->col_rthr[i] : w->res_threshold);
   }
-  // self-collision pairs as byte offsets into the centre table (16 B per primitive); the padding entries pair primitive 0 with itself (never a hit)
+  // self-collision pairs as byte offsets into the centre table (16 B per primitive); the entry behind the list pairs primitive 0 with itself (never a hit)
   for (int k = 0; k < n_self_pairs(w); ++k) put_i(L.t_spair + k, (16 * w->self_pairs[2 * k]) | ((16 * w->self_pairs[2 * k + 1]) << 16));
   return img;
 }

@@ -528,10 +528,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   float* GINV = E + L.ginv;
   float* LAM = E + L.lam;
   float* WARM = E + L.warm;                                      // [ncol][6] warm state of the contact solver (see StepArgs::warm)
-  const int* SPAIR = reinterpret_cast<const int*>(lds + L.t_spair);   // candidate pairs of self-collision, padded to whole batches of kSelfBatch * LPE: byte offset of centre i in CEN | of centre j << 16
+  const int* SPAIR = reinterpret_cast<const int*>(lds + L.t_spair);   // [n_self + 1] candidate pairs of self-collision: byte offset of centre i in CEN | of centre j << 16; the last entry pairs primitive 0 with itself (never a hit)
   float* CEN = E + L.cen;                                        // [ncol][4] primitive centres (relative to the base position) + radius; may alias WC
   float* SELFT = E + L.selft;                                    // [kmax][4] per contact slot of a self-collision: mu, restitution, threshold | J u of the slot's normal row
-  const int n_self = a.n_self;
+  const int n_self = a.n_self;                                   // candidate pairs; 0 = self-collision off
   const int nwarm = 6 * ncol;
   const int GS = L.gstride;
 
@@ -911,12 +911,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     // The sweep over the pairs only records a hit bit per lane; everything else runs when some env of the wave has a hit.
     nselfc = 0;
     if (n_self > 0) {
-      // lane = pair, batches of kSelfBatch passes (the table is padded to whole batches with pairs that cannot hit; the next
+      // lane = pair, batches of kSelfBatch passes (indices past the table read its last entry, a pair that cannot hit; the next
       // batch's entries are in flight while the current one is tested).  An entry holds the byte offsets of the two centres.
       const int npass = (n_self + LPE - 1) / LPE;
       const char* cenb = reinterpret_cast<const char*>(CEN);
       int prn[kSelfBatch];
-      RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) prn[q4] = SPAIR[q4 * LPE + s];
+      RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) prn[q4] = SPAIR[min(q4 * LPE + s, n_self)];
       __syncthreads();   // the centres of this sub-step are in CEN
       unsigned hbits = 0u;
       for (int k0 = 0; k0 < npass; k0 += kSelfBatch) {
@@ -925,7 +925,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           ld4(reinterpret_cast<const float*>(cenb + (prn[q4] & 0xffff)), ci4[q4]);
           ld4(reinterpret_cast<const float*>(cenb + ((unsigned)prn[q4] >> 16)), cj4[q4]);
         }
-        RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) prn[q4] = SPAIR[(k0 + kSelfBatch + q4) * LPE + s];   // (past the table after the last batch: read, never used)
+        RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) prn[q4] = SPAIR[min((k0 + kSelfBatch + q4) * LPE + s, n_self)];
         RSB_UNROLL for (int q4 = 0; q4 < kSelfBatch; ++q4) {
           const float dx = ci4[q4][0] - cj4[q4][0], dy = ci4[q4][1] - cj4[q4][1], dz = ci4[q4][2] - cj4[q4][2], rs = ci4[q4][3] + cj4[q4][3];
           const float d2 = dx * dx + dy * dy + dz * dz;
@@ -1228,7 +1228,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
       }
       __syncthreads();
-      if (n_self > 0 && __any(nselfc > 0)) {
+      if (__any(nselfc > 0)) {
         // fold the two entries of every self-collision into one solver contact: G <- P G P^T, c <- P c with P adding the second
         // entry's rows to the first's.  The second entry stays in the solver as an inert contact (zero rows, unit diagonal,
         // c = 0: its impulse stays 0) and receives the first one's impulse after the solve (same numbers in its opposite frame).
@@ -1557,7 +1557,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
         if (PROF && pfine) tz0 = t_prev;
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }
-        if (n_self > 0 && __any(nselfc > 0)) {   // the second entry of a self-collision carries the first one's impulse (in its opposite frame)
+        if (__any(nselfc > 0)) {   // the second entry of a self-collision carries the first one's impulse (in its opposite frame)
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
             const float up = __shfl_up(lam[rr], 1);
             lam[rr] = (mycol & kSelfB) ? up : lam[rr];

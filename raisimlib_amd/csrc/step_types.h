@@ -26,7 +26,7 @@ constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
 constexpr int kLightDepth = 3;        // == ORC_LIGHT_DEPTH
 constexpr int kSelfA = 0x10000;       // collision id flags of the two entries of a self-collision (== RSB_CONTACT_SELF_A / _B, ORC_SELF_A / _B)
 constexpr int kSelfB = 0x20000;
-constexpr int kSelfBatch = 5;          // passes per batch of the self-collision sweep (the pair table is padded to whole batches for every lanes_per_env)
+constexpr int kSelfBatch = 5;          // passes per batch of the self-collision sweep
 constexpr float kSelfReg = 1e-4f;      // == ORC_SELF_REG: compliance of a self-collision's Delassus block, relative to its mean diagonal
 constexpr int kWarmRec = 8;           // floats per warm-state record in HBM: impulse (3), friction direction (2), direction valid, primitive + 1, pad
 constexpr int kWarmRow = kWarmRec * RSB_MAX_CONTACTS;   // floats per env row of StepArgs::warm
