@@ -119,9 +119,9 @@ class BatchedWorld {
     RSB_CHECK(rsb_set_heightmap(world_, xSamples, ySamples, xSize, ySize, centerX, centerY, h.data()));
   }
   /// the whole batch at once (fast path; staged view writes are uploaded first)
-  void integrate(int nSubsteps = 1) { uploadStaged(); RSB_CHECK(rsb_integrate(world_, nSubsteps)); stateCacheValid_ = false; contactsValid_ = false; }
+  void integrate(int nSubsteps = 1) { uploadStaged(); RSB_CHECK(rsb_integrate(world_, nSubsteps)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; }
   void integrate1() { uploadStaged(); RSB_CHECK(rsb_integrate1(world_)); }
-  void integrate2() { uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; }
+  void integrate2() { uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; }
 
   // batched, caller-owned host buffers (row-major [N, dim] float32, the raisimGymTorch matrix layout)
   void setState(const float* gc, const float* gv) {
@@ -152,6 +152,16 @@ class BatchedWorld {
     const float* src = stage(field).host.data();
     for (int i = 0; i < dim; ++i) out[i] = src[(size_t)env * dim + i];
   }
+  /// the generalized force the actuators applied to replica `env` in its last integrate() (one download per launch)
+  void readGeneralizedForce(int env, double* out, int dim) {
+    requireNotPending(env, "getGeneralizedForce()");
+    if (!genfValid_) {
+      genf_.resize((size_t)n_ * dim);
+      RSB_CHECK(rsb_get_field(world_, RSB_F_GENERALIZED_FORCE, genf_.data(), RSB_HOST));
+      genfValid_ = true;
+    }
+    for (int i = 0; i < dim; ++i) out[i] = genf_[(size_t)env * dim + i];
+  }
   /// World::integrate() of replica `env`: recorded; flushed when every replica has one pending, or by the fiber scheduler
   void integrateView(int env) {
     if (pending_[env]) throw std::runtime_error("raisim::World::integrate(): this replica already has an un-flushed integrate(); "
@@ -170,7 +180,7 @@ class BatchedWorld {
     std::fill(pending_.begin(), pending_.end(), 0);
     nPending_ = 0;
     ++viewLaunches_;
-    stateCacheValid_ = false; contactsValid_ = false;
+    stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false;
   }
   void setFiberBatch(bool on) { fiberBatch_ = on; }
   long viewLaunches() const { return viewLaunches_; }     ///< launches issued by flushViews() (tests: N views -> 1 launch)
@@ -242,6 +252,7 @@ class BatchedWorld {
     RSB_CHECK(rsb_create(model_, numEnvs, device, &world_));
     n_ = numEnvs;
     pending_.assign(n_, 0); gcMask_.assign(n_, 0); gvMask_.assign(n_, 0);
+    RSB_CHECK(rsb_enable_generalized_force_output(world_, 1));   // ArticulatedSystem::getGeneralizedForce() (rsg_anymal's torque reward reads it)
   }
   struct PairProp { double mu, restitution, resThreshold; };
   static std::string pairKey(const std::string& a, const std::string& b) { return a < b ? a + "\n" + b : b + "\n" + a; }
@@ -277,7 +288,8 @@ class BatchedWorld {
   std::vector<uint8_t> pending_, gcMask_, gvMask_;
   int nPending_ = 0, kmax_ = 0;
   long viewLaunches_ = 0;
-  bool fiberBatch_ = false, stateCacheValid_ = false, contactsValid_ = false;
+  bool fiberBatch_ = false, stateCacheValid_ = false, contactsValid_ = false, genfValid_ = false;
+  std::vector<float> genf_;
   std::vector<float> tmpGc_, tmpGv_;
   std::vector<int32_t> cnt_;
   std::vector<rsb_contact> con_;
@@ -432,6 +444,17 @@ class ArticulatedSystem {
     for (int d = 0; d < (int)getDOF(); ++d) tau[d] += J(0, d) * torque[0] + J(1, d) * torque[1] + J(2, d) * torque[2];
     putRow(RSB_F_TAU_FF, tau);
   }
+  /// upstream ArticulatedSystem::getGeneralizedForce(): what the actuators applied in the last integrate() - clipped PD +
+  /// feed-forward on the joints, the feed-forward wrench on a floating base's six rows (zero before the first integrate())
+  const VecDyn& getGeneralizedForce() {
+    const int dim = w_->dof();
+    std::vector<double> full((size_t)dim);
+    w_->readGeneralizedForce(env_, full.data(), dim);
+    const int off = gvOff();
+    gf_.resize(dim - off);
+    for (int i = off; i < dim; ++i) gf_[i - off] = full[i];
+    return gf_;
+  }
   void clearExternalForces() { VecDyn tau(getDOF()); putRow(RSB_F_TAU_FF, tau); }
 
   void getBaseOrientation(Mat<3, 3>& rot) {
@@ -541,7 +564,7 @@ class ArticulatedSystem {
   BatchedWorld* w_;
   int env_;
   std::string name_;
-  VecDyn gc_, gv_, h_, fullq_;
+  VecDyn gc_, gv_, h_, fullq_, gf_;
   std::vector<double> fkR_, fkP_, fkA_;
   MatDyn M_, Minv_;
   std::vector<Contact> contacts_;

@@ -7,6 +7,7 @@
 
 #include <cstddef>
 #include <cstring>
+#include <cmath>
 #include <vector>
 
 #if __has_include(<Eigen/Core>)
@@ -54,6 +55,8 @@ struct VecDyn {
   double* data() { return v.data(); }
   const double* data() const { return v.data(); }
   void setZero() { std::fill(v.begin(), v.end(), 0.0); }
+  double squaredNorm() const { double s = 0; for (double x : v) s += x * x; return s; }
+  double norm() const { return std::sqrt(squaredNorm()); }
   VecDyn& operator=(const std::vector<double>& o) { v = o; return *this; }
 #ifdef RAISIM_HAS_EIGEN
   Eigen::Map<Eigen::VectorXd> e() { return Eigen::Map<Eigen::VectorXd>(v.data(), (Eigen::Index)v.size()); }

@@ -134,7 +134,8 @@ typedef struct rsb_contact {
 /* resident state fields (row-major [N,dim] float32 unless noted) */
 typedef enum rsb_field {
   RSB_F_GC = 0, RSB_F_GV = 1, RSB_F_PTARGET = 2, RSB_F_DTARGET = 3, RSB_F_TAU_FF = 4,
-  RSB_F_CONTACT_COUNT = 5, RSB_F_CONTACTS = 6, RSB_F_FLAGS = 7
+  RSB_F_CONTACT_COUNT = 5, RSB_F_CONTACTS = 6, RSB_F_FLAGS = 7,
+  RSB_F_GENERALIZED_FORCE = 8   /* output only, see rsb_enable_generalized_force_output */
 } rsb_field;
 
 typedef struct rsb_model rsb_model;  /* host-side parsed model           */
@@ -268,6 +269,11 @@ int rsb_get_env_row(rsb_world* w, int field, int env, float* data);
 
 /* a whole state field at once: field = RSB_F_GC / RSB_F_GV / RSB_F_PTARGET / RSB_F_DTARGET / RSB_F_TAU_FF, out [N, dim] float32 */
 int rsb_get_field(rsb_world* w, int field, float* out, int space);
+/* ArticulatedSystem::getGeneralizedForce() [RECALL; upstream ArticulatedSystem.hpp is absent from /root/reference]: the generalized
+ * force the actuators applied in the last sub-step of the last integrate() - clipped PD + feed-forward on the joints (without the
+ * joints' passive damping), the feed-forward wrench on the base rows.  Off by default (one more [N, nv] row written per launch);
+ * once enabled it is read as field RSB_F_GENERALIZED_FORCE with rsb_get_field / rsb_get_env_row. */
+int rsb_enable_generalized_force_output(rsb_world* w, int on);
 
 int rsb_set_control_mode(rsb_world* w, int mode);
 int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd);      /* host, [nv] each  */

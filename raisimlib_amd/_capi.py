@@ -16,7 +16,7 @@ RSB_HOST, RSB_DEVICE = 0, 1
 RSB_CONTACT_SELF_A, RSB_CONTACT_SELF_B = 0x10000, 0x20000
 RSB_FORCE_AND_TORQUE, RSB_PD_PLUS_FEEDFORWARD_TORQUE = 0, 1
 (RSB_F_GC, RSB_F_GV, RSB_F_PTARGET, RSB_F_DTARGET, RSB_F_TAU_FF, RSB_F_CONTACT_COUNT, RSB_F_CONTACTS,
- RSB_F_FLAGS) = range(8)
+ RSB_F_FLAGS, RSB_F_GENERALIZED_FORCE) = range(9)
 
 _B, _S = RSB_MAX_BODIES, RSB_MAX_COLLISIONS
 
@@ -115,6 +115,7 @@ PROTOTYPES = {
     "rsb_set_env_row": (_I, [_VP, _I, _I, _FP]),
     "rsb_get_env_row": (_I, [_VP, _I, _I, _FP]),
     "rsb_get_field": (_I, [_VP, _I, _FP, _I]),
+    "rsb_enable_generalized_force_output": (_I, [_VP, _I]),
     "rsb_set_control_mode": (_I, [_VP, _I]),
     "rsb_set_pd_gains": (_I, [_VP, _FP, _FP]),
     "rsb_set_pd_target": (_I, [_VP, _FP, _FP, _I]),

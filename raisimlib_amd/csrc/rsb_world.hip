@@ -60,6 +60,8 @@ struct rsb_world {
   std::vector<int> self_pairs;                 // 2 ints per pair
   std::vector<double> self_mu, self_rest, self_rthr;
   float* d_self_mat = nullptr;
+  float* d_genf = nullptr;              // [N, nv] generalized force applied in the last sub-step (rsb_enable_generalized_force_output)
+  bool want_genf = false;
   size_t self_mat_cap = 0;
   float* d_warm = nullptr;   // [N, kWarmRow] contact-solver warm state (StepArgs::warm: one record per contact of the last integrate())
   bool warm_start = true;
@@ -207,6 +209,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
   L.warm = take(6 * b.ncol);
+  L.tact = take(b.nv);
   // self-collision: the primitive centres live in the contact columns' space when they fit (dead until the column phase)
   L.cen = L.wc; L.selft = 0;
   if (n_self > 0) {
@@ -477,6 +480,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.lds_floats = (int)(lds_bytes / sizeof(float));
   const bool prof = a.prof != nullptr || a.dbg != nullptr || a.poison_lds != 0;
   a.done_out = env_done ? env_done : w->d_done_out;
+  a.tau_out = w->want_genf ? w->d_genf : nullptr;
   a.env_mask = w->launch_mask; w->launch_mask = nullptr;
   hipEvent_t e0 = w->ev0, e1 = w->ev1;
   const bool rec = w->timing && (w->launch_index++ % w->timing_stride == 0);
@@ -598,7 +602,7 @@ int rsb_destroy(rsb_world* w) {
   (void)rsb_comm_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_genf, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -836,12 +840,16 @@ static int env_row(rsb_world* w, int field, int env, float** base, size_t* dim) 
     case RSB_F_PTARGET: *base = w->d_pt; *dim = w->blob.nq; break;
     case RSB_F_DTARGET: *base = w->d_dt; *dim = w->blob.nv; break;
     case RSB_F_TAU_FF: *base = w->d_tff; *dim = w->blob.nv; break;
+    case RSB_F_GENERALIZED_FORCE:
+      if (!w->want_genf || !w->d_genf) { rsb::set_error("RSB_F_GENERALIZED_FORCE: call rsb_enable_generalized_force_output first"); return RSB_E_INVALID; }
+      *base = w->d_genf; *dim = w->blob.nv; break;
     default: rsb::set_error("env row: unsupported field"); return RSB_E_INVALID;
   }
   return RSB_OK;
 }
 int rsb_set_env_row(rsb_world* w, int field, int env, const float* data) {
   float* base; size_t dim;
+  if (field == RSB_F_GENERALIZED_FORCE) { rsb::set_error("RSB_F_GENERALIZED_FORCE is an output"); return RSB_E_INVALID; }
   int st = env_row(w, field, env, &base, &dim);
   if (st != RSB_OK || !data) return st != RSB_OK ? st : RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
@@ -870,6 +878,17 @@ int rsb_get_field(rsb_world* w, int field, float* out, int space) {
   return copy_out(w, out, base, (size_t)w->N * dim * sizeof(float), space);
 }
 
+int rsb_enable_generalized_force_output(rsb_world* w, int on) {
+  if (!w) { rsb::set_error("rsb_enable_generalized_force_output: null world"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  if (on && !w->d_genf) {
+    const size_t bytes = (size_t)w->N * w->blob.nv * sizeof(float);
+    HIP_TRY(hipMalloc(&w->d_genf, bytes));
+    HIP_TRY(hipMemset(w->d_genf, 0, bytes));
+  }
+  w->want_genf = on != 0;
+  return RSB_OK;
+}
 int rsb_set_control_mode(rsb_world* w, int mode) {
   if (!w || (mode != RSB_FORCE_AND_TORQUE && mode != RSB_PD_PLUS_FEEDFORWARD_TORQUE)) { rsb::set_error("rsb_set_control_mode: unknown mode"); return RSB_E_INVALID; }
   w->control_mode = mode;

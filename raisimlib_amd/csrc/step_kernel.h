@@ -527,6 +527,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   float* G = E + L.g;
   float* GINV = E + L.ginv;
   float* LAM = E + L.lam;
+  float* TACT = E + L.tact;                                      // [nv] actuator torque of every joint in the current sub-step
   float* WARM = E + L.warm;                                      // [ncol][6] warm state of the contact solver (see StepArgs::warm)
   const int* SPAIR = reinterpret_cast<const int*>(lds + L.t_spair);   // [n_self + 1] candidate pairs of self-collision: byte offset of centre i in CEN | of centre j << 16; the last entry pairs primitive 0 with itself (never a hit)
   float* CEN = E + L.cen;                                        // [ncol][4] primitive centres (relative to the base position) + radius; may alias WC
@@ -735,7 +736,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         float Bpd = dt * (kdj + dt * kpj);
         const float eff = MF[28];
         if (eff > 0.f && fabsf(tau) > eff) { tau = tau > 0.f ? eff : -eff; Bpd = 0.f; }
-        tsq = fmaf(tau, tau, tsq);
+        tsq = tau * tau;      // (clipped PD + feed-forward, without the joint's passive damping: StepArgs::tau2_out)
+        TACT[bb + 5] = tau;   // (StepArgs::tau_out)
         tau -= MF[27] * bqd;
         bdtau = dt * tau; barm = MF[26] + Bpd;
       }
@@ -1726,6 +1728,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     const size_t r0 = (ae.reset_rows == 1) ? 0 : (size_t)env;
     for (int i = s; i < nq; i += LPE) ae.gc[(size_t)env * nq + i] = term ? ae.gc0[r0 * nq + i] : Q[i];
     for (int i = s; i < nv; i += LPE) ae.gv[(size_t)env * nv + i] = term ? ae.gv0[r0 * nv + i] : U[i];
+    if (ae.tau_out)   // ArticulatedSystem::getGeneralizedForce(): what the actuators applied in the last sub-step (base rows: the feed-forward wrench)
+      for (int i = s; i < nv; i += LPE) ae.tau_out[(size_t)env * nv + i] = i < 6 ? TF[i] : TACT[i];
     if (s < nc) {
       float CN[16];
       ldv<4>(CON + s * kConSlot, CN);

@@ -54,6 +54,7 @@ struct LdsLayout {
   int t_model, t_gain, t_parlv, t_anc, t_dir, t_col, t_kids, t_kidx, t_spair, shared_total;
   // per-env arrays (floats from the env base)
   int q, u, pt, dtg, tf, body, fact, wb, con, wc, cv, g, ginv, lam, warm;   // (the up pass's hand-over slots alias g)
+  int tact;         // [nv] actuator torques of the current sub-step
   int cen, selft;   // self-collision: primitive centres [ncol][4] (may alias wc: dead before the contact columns), per-slot pair record [kcap][4]
   int gstride;
   int per_env;
@@ -121,6 +122,7 @@ struct StepArgs {
   int terrain_type, hm_xs, hm_ys;
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy, hm_max;
   LdsLayout L;
+  float* tau_out;              // [N, nv] optional: the generalized force the actuators applied in the last sub-step (rsb_enable_generalized_force_output)
 };
 
 }  // namespace rsbk

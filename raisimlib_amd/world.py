@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 from . import _capi
-from ._capi import (RSB_DEVICE, RSB_HOST, RSB_MAX_CONTACTS, Contact, ModelBlob, check, lib)
+from ._capi import (RSB_DEVICE, RSB_F_GENERALIZED_FORCE, RSB_HOST, RSB_MAX_CONTACTS, Contact, ModelBlob, check, lib)
 
 RSC_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rsc")
 
@@ -166,6 +166,16 @@ class BatchedWorld:
                 raise ValueError("set_collision_materials: arrays of ncol entries expected")
         check(self.L.rsb_set_collision_materials(self.handle, *[None if a is None else a.ctypes.data for a in arrs]),
               "rsb_set_collision_materials")
+
+    def enable_generalized_force_output(self, on=True):
+        """Have every launch also write the generalized force the actuators applied in its last sub-step ([N, nv])."""
+        check(self.L.rsb_enable_generalized_force_output(self.handle, int(bool(on))), "rsb_enable_generalized_force_output")
+
+    def get_generalized_force(self):
+        """ArticulatedSystem::getGeneralizedForce() of every env: clipped PD + feed-forward of the last sub-step, [N, nv]."""
+        out = np.zeros((self.N, self.model.nv), np.float32)
+        check(self.L.rsb_get_field(self.handle, RSB_F_GENERALIZED_FORCE, _hp(out), RSB_HOST), "rsb_get_field(GENERALIZED_FORCE)")
+        return out
 
     def set_self_collision(self, enable=True):
         """Collisions between non-adjacent bodies of the system (sphere x sphere; on by default, as in RaiSim)."""

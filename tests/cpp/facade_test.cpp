@@ -191,11 +191,11 @@ int main(int argc, char** argv) {
       const std::string resourceDir = urdf.substr(0, urdf.find_last_of('/'));
       const std::string yaml =
           "num_envs: 64\nnum_threads: 8   # ignored\nsimulation_dt: 0.0025\ncontrol_dt: 0.01\nrender: false\naction_std: 0.3\n"
-          "reward:\n  forwardVel:\n    coeff: 0.3\n";
+          "reward:\n  forwardVel:\n    coeff: 0.3\n  torque:\n    coeff: -4e-5\n";
       raisim::VectorizedEnvironment<raisim::ENVIRONMENT> venv(resourceDir, yaml, /*normalizeObservation=*/false);
       CHECK(venv.getNumOfEnvs() == NE && venv.getObDim() == 34 && venv.getActionDim() == 12);
       raisim::VecEnvConfig dc;
-      dc.num_envs = NE; dc.gc_init = cfg.gc_init; dc.torque_reward_coeff = 0.0; dc.forward_vel_reward_coeff = 0.3;
+      dc.num_envs = NE; dc.gc_init = cfg.gc_init; dc.torque_reward_coeff = -4e-5; dc.forward_vel_reward_coeff = 0.3;
       raisim::DeviceVectorizedEnvironment denv(urdf, dc);
       denv.init();
       std::vector<float> a((size_t)NE * 12), r1(NE), r2(NE), o1((size_t)NE * 34), o2((size_t)NE * 34);

@@ -588,3 +588,32 @@ print("RCCL_OK")
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=240, cwd=ROOT)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_generalized_force_output_is_the_clipped_pd_torque(anymal):
+    """rsb_enable_generalized_force_output / ArticulatedSystem::getGeneralizedForce(): the actuator torque of the LAST sub-step -
+    implicit PD evaluated at q + dt u of that sub-step's start, + feed-forward, clipped to the joint's effort limit."""
+    N = 256
+    gc, gv = standing_states(N, seed=21, vel=2.0)
+    kp, kd = workload.anymal_gains()
+    kp = kp * 8                                   # large errors: some joints clip at their effort limit
+    pt = gc.copy(); pt[:, 7:] += np.random.default_rng(3).uniform(-0.6, 0.6, (N, 12))
+    tff = np.zeros((N, 18), np.float32); tff[:, 6:] = np.random.default_rng(4).uniform(-5, 5, (N, 12)); tff[:, :6] = 0.25
+    w = BatchedWorld(anymal, N)
+    with pytest.raises(Exception):
+        w.get_generalized_force()                 # off by default: asking for it without enabling fails loudly
+    w.enable_generalized_force_output(True)
+    w.set_pd_gains(kp, kd); w.set_pd_target(pt, np.zeros((N, 18))); w.set_generalized_force(tff)
+    w.set_state(gc, gv)
+    w.integrate(2)
+    q2, u2 = w.get_state()
+    f2 = w.get_generalized_force()
+    w.set_state(gc, gv); w.integrate(1)           # the state the second sub-step started from
+    q1, u1 = w.get_state()
+    dt = 0.0025
+    eff = np.array([anymal.blob.effort[b] for b in range(1, anymal.nb)])
+    raw = kp[6:] * (np.float32(pt[:, 7:]) - q1[:, 7:] - dt * u1[:, 6:]) + kd[6:] * (0.0 - u1[:, 6:]) + tff[:, 6:]
+    want = np.where(eff > 0, np.clip(raw, -eff, eff), raw)
+    assert (np.abs(raw) > eff).sum() > 50 and (np.abs(raw) < eff).sum() > 50
+    assert np.allclose(f2[:, 6:], want, rtol=1e-4, atol=2e-3) and np.allclose(f2[:, :6], 0.25)
+    w.close()
