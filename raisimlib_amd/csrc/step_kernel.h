@@ -1118,14 +1118,18 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           const int lev = PARLV[kb] >> 8;
           const float lsgn = CN[15];                 // != 0: joint-limit row of body kb (only its "normal" row is non-empty)
           // prefetch the support chain's factors (independent loads), then propagate the unit impulse
-          float FK[ML][16], wbk[ML];
-          int node[ML];
-          RSB_UNROLL for (int l = 0; l < ML; ++l) {
-            node[l] = 0;
-            if (l < lev) node[l] = ANC[kb * depth + lev - l];
-          }
-          RSB_UNROLL for (int l = 0; l < ML; ++l) {
-            if (l < lev) { ldv<4>(FACT + node[l] * kFactSlot, FK[l]); wbk[l] = WB[node[l] + 5]; }
+          // (deep trees - ML > 4 - fetch the chain four levels at a time further down: 16 x ML registers of factors do not fit)
+          constexpr int MLP = ML <= 4 ? ML : 1;
+          float FK[MLP][16], wbk[MLP];
+          int node[MLP];
+          if constexpr (ML <= 4) {
+            RSB_UNROLL for (int l = 0; l < ML; ++l) {
+              node[l] = 0;
+              if (l < lev) node[l] = ANC[kb * depth + lev - l];
+            }
+            RSB_UNROLL for (int l = 0; l < ML; ++l) {
+              if (l < lev) { ldv<4>(FACT + node[l] * kFactSlot, FK[l]); wbk[l] = WB[node[l] + 5]; }
+            }
           }
           float Vb[8];
           ld4(BODY + kb * kBodySlot + 12, Vb); Vb[4] = BODY[kb * kBodySlot + 16]; Vb[5] = BODY[kb * kBodySlot + 17];
@@ -1148,14 +1152,39 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             cv = (rr == 2) ? lsgn * U[kb + 5] : 0.f;
           }
           float* Wc = WC + c * cw;
-          RSB_UNROLL for (int l = 0; l < ML; ++l) {
-            if (l < lev) {
-              float yh = dot6(FK[l], Fres);
-              if (limit_row && l == 0) yh = (rr == 2) ? lsgn : 0.f;
-              const float wk = yh * FK[l][12];
-              Wc[5 + lev - l] = wk;
-              cv += wk * wbk[l];
-              RSB_UNROLL for (int j = 0; j < 6; ++j) Fres[j] -= FK[l][6 + j] * yh;
+          if constexpr (ML <= 4) {
+            RSB_UNROLL for (int l = 0; l < ML; ++l) {
+              if (l < lev) {
+                float yh = dot6(FK[l], Fres);
+                if (limit_row && l == 0) yh = (rr == 2) ? lsgn : 0.f;
+                const float wk = yh * FK[l][12];
+                Wc[5 + lev - l] = wk;
+                cv += wk * wbk[l];
+                RSB_UNROLL for (int j = 0; j < 6; ++j) Fres[j] -= FK[l][6 + j] * yh;
+              }
+            }
+          } else {
+            RSB_UNROLL for (int l0 = 0; l0 < ML; l0 += 4) {
+              float FQ[4][16], wq[4];
+              int nq4[4];
+              RSB_UNROLL for (int q4 = 0; q4 < 4; ++q4) {
+                nq4[q4] = 0;
+                if (l0 + q4 < lev) nq4[q4] = ANC[kb * depth + lev - (l0 + q4)];
+              }
+              RSB_UNROLL for (int q4 = 0; q4 < 4; ++q4) {
+                if (l0 + q4 < lev) { ldv<4>(FACT + nq4[q4] * kFactSlot, FQ[q4]); wq[q4] = WB[nq4[q4] + 5]; }
+              }
+              RSB_UNROLL for (int q4 = 0; q4 < 4; ++q4) {
+                const int l = l0 + q4;
+                if (l < lev) {
+                  float yh = dot6(FQ[q4], Fres);
+                  if (limit_row && l == 0) yh = (rr == 2) ? lsgn : 0.f;
+                  const float wk = yh * FQ[q4][12];
+                  Wc[5 + lev - l] = wk;
+                  cv += wk * wq[q4];
+                  RSB_UNROLL for (int j = 0; j < 6; ++j) Fres[j] -= FQ[q4][6 + j] * yh;
+                }
+              }
             }
           }
           float z[6];
