@@ -1067,9 +1067,26 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     for (int i = 0; i < nc; ++i) {
       int b = cbody[i];
       while (b > 0 && m->parent[b] > 0) b = m->parent[b];
-      if (nself > 0) b = 0;   /* a self-collision couples two limbs strongly: every contact of such an env is solved in turn (one group) */
-      gid[i] = b; gpos[i] = 0;
-      for (int j = 0; j < i; ++j) if (gid[j] == b) ++gpos[i];
+      gid[i] = b;
+    }
+    if (nself > 0) {
+      /* a self-collision couples its two limbs strongly: their groups are merged (relabelling in contact order) */
+      int gid2[MAXK];
+      for (int i = 0; i < nc; ++i) {
+        int b = cbody2[i];
+        while (b > 0 && m->parent[b] > 0) b = m->parent[b];
+        gid2[i] = cbody2[i] >= 0 ? b : gid[i];
+      }
+      for (int j = 0; j < nc; ++j) {
+        if (cbody2[j] < 0) continue;
+        const int lo = gid[j] < gid2[j] ? gid[j] : gid2[j], hi = gid[j] < gid2[j] ? gid2[j] : gid[j];
+        if (lo == hi) continue;
+        for (int i = 0; i < nc; ++i) { if (gid[i] == hi) gid[i] = lo; if (gid2[i] == hi) gid2[i] = lo; }
+      }
+    }
+    for (int i = 0; i < nc; ++i) {
+      gpos[i] = 0;
+      for (int j = 0; j < i; ++j) if (gid[j] == gid[i]) ++gpos[i];
       if (gpos[i] + 1 > gdepth) gdepth = gpos[i] + 1;
     }
     int converged = 0;

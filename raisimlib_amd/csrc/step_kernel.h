@@ -1361,9 +1361,20 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         RSB_ARGS(ag);
         // the own contact's friction coefficient: that of its collision primitive against the terrain (material pairs)
         const int mycol = isc ? __float_as_int(CON[s * kConSlot + 11]) : 0;
-        // a self-collision couples two limbs strongly: every contact of such an env is solved in turn (one group; oracle: same
-        // rule); the inert second entries keep ids of their own
-        if (nselfc > 0 && isc) gidc = (mycol & kSelfB) ? (-1 - s) : 0;
+        if (__any(nselfc > 0)) {   // rare
+          // a self-collision couples its two limbs strongly: their groups are merged (oracle: the same relabelling, in contact
+          // order); the inert second entries keep ids of their own
+          const bool prim = isc && (mycol & kSelfA) != 0;
+          int gidb = __shfl_down(gidc, 1);   // the second body's limb: what the next slot (the second entry) computed for itself
+          gidb = prim ? gidb : gidc;
+          if (isc && (mycol & kSelfB)) { gidc = -1 - s; gidb = gidc; }
+          for (int j = 0; j + 1 < ncw; ++j) {
+            const int src = (lane & ~(LPE - 1)) | j;
+            const int ja = __shfl(gidc, src), jb = __shfl(gidb, src), jp = __shfl(prim ? 1 : 0, src);
+            const int lo = min(ja, jb), hi = max(ja, jb);
+            if (jp && lo != hi) { gidc = (gidc == hi) ? lo : gidc; gidb = (gidb == hi) ? lo : gidb; }
+          }
+        }
         float mu = (isc && mycol < ncol) ? COLT[kColSlot * mycol + 5] : ag.mu;
         if (mycol & kSelfA) mu = SELFT[4 * s];    // material pair of the two primitives
         const float mu2 = mu * mu;
