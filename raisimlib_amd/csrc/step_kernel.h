@@ -1420,7 +1420,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         float g0[4][3][4];            // coupling blocks with contacts 0-3: constant during the solve, read from LDS once
         RSB_UNROLL for (int k = 0; k < 4; ++k)
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * k, g0[k][rr]);
-        float gbuf[2][4][3][4];       // contacts 4.. : fetched per pass (only envs with five or more contacts get here)
+        float g1[4][3][4];            // ... and with contacts 4-7 (the hard envs of the tail have five contacts: no LDS round trip in their passes)
+        RSB_UNROLL for (int k = 0; k < 4; ++k)
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (4 + k), g1[k][rr]);
+        float gbuf[2][4][3][4];       // contacts 8.. : fetched per pass (only models with many contacts per env get here)
         auto load_block = [&](auto bc) {
           constexpr int b = decltype(bc)::value;
           RSB_UNROLL for (int k = 0; k < 4; ++k)
@@ -1431,13 +1434,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             constexpr int j = decltype(jc)::value;
             float l0[3] = {x[0], x[1], x[2]};
             row_bcast_n<j, 3>(l0);
-            const float (&gj)[3][4] = j < 4 ? g0[j & 3] : gbuf[(j / 4) & 1][j & 3];
+            const float (&gj)[3][4] = j < 4 ? g0[j & 3] : (j < 8 ? g1[j & 3] : gbuf[(j / 4) & 1][j & 3]);
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
               v[rr] = fmaf(gj[rr][2], l0[2], fmaf(gj[rr][1], l0[1], fmaf(gj[rr][0], l0[0], v[rr])));
             emax = fmaxf(emax, fmaxf(fabsf(l0[0]), fmaxf(fabsf(l0[1]), fabsf(l0[2]))));
           };
           const bool more = ncw > 4;
-          if (more) load_block(std::integral_constant<int, 1>{});
           static_for<0, 4>(one);
           if (more) {
             one(std::integral_constant<int, 4>{});
