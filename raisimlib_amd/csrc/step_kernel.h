@@ -1423,7 +1423,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         float g1[4][3][4];            // ... and with contacts 4-7 (the hard envs of the tail have five contacts: no LDS round trip in their passes)
         RSB_UNROLL for (int k = 0; k < 4; ++k)
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (4 + k), g1[k][rr]);
-        float gbuf[2][4][3][4];       // contacts 8.. : fetched per pass (only models with many contacts per env get here)
+        float g2[KMAX > 8 ? 4 : 1][3][4];   // ... and, in the large-model classes, with contacts 8-11 (a collapsed humanoid)
+        if constexpr (KMAX > 8) {
+          RSB_UNROLL for (int k = 0; k < 4; ++k)
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (8 + k), g2[k][rr]);
+        }
+        float gbuf[2][4][3][4];       // contacts 12.. : fetched per pass
         auto load_block = [&](auto bc) {
           constexpr int b = decltype(bc)::value;
           RSB_UNROLL for (int k = 0; k < 4; ++k)
@@ -1434,7 +1439,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             constexpr int j = decltype(jc)::value;
             float l0[3] = {x[0], x[1], x[2]};
             row_bcast_n<j, 3>(l0);
-            const float (&gj)[3][4] = j < 4 ? g0[j & 3] : (j < 8 ? g1[j & 3] : gbuf[(j / 4) & 1][j & 3]);
+            const float (&gj)[3][4] = j < 4 ? g0[j & 3] : (j < 8 ? g1[j & 3] : (j < 12 ? g2[(KMAX > 8 ? j : 0) & 3] : gbuf[(j / 4) & 1][j & 3]));
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
               v[rr] = fmaf(gj[rr][2], l0[2], fmaf(gj[rr][1], l0[1], fmaf(gj[rr][0], l0[0], v[rr])));
             emax = fmaxf(emax, fmaxf(fabsf(l0[0]), fmaxf(fabsf(l0[1]), fabsf(l0[2]))));
@@ -1452,7 +1457,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
                   static_for<2, KMAX / 4>([&](auto bc) {
                     constexpr int b = decltype(bc)::value;
                     if (4 * b < ncw) {   // (these blocks load late: only models with many contacts per env get here)
-                      load_block(bc);
+                      if constexpr (b >= 3) load_block(bc);
                       static_for<4 * b, 4 * b + 4>(one);
                     }
                   });
