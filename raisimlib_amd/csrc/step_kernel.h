@@ -1444,10 +1444,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
               v[rr] = fmaf(gj[rr][2], l0[2], fmaf(gj[rr][1], l0[1], fmaf(gj[rr][0], l0[0], v[rr])));
             emax = fmaxf(emax, fmaxf(fabsf(l0[0]), fmaxf(fabsf(l0[1]), fabsf(l0[2]))));
           };
-          const bool more = ncw > 4;
-          static_for<0, 4>(one);
-          if (more) {
-            one(std::integral_constant<int, 4>{});
+          // contacts 0-4 straight: the launch lasts as long as its slowest wave, and that wave holds a five-contact env (a robot
+          // on a knee); the usual four-contact waves finish a third earlier and can afford the one unused exchange
+          static_for<0, 5>(one);
+          {
             if (ncw > 5) {
               one(std::integral_constant<int, 5>{});
               if (ncw > 6) {
