@@ -236,6 +236,7 @@ int default_lpe(const rsb_model_blob& b, int kmax, int n_self) {
   for (int lpe = need; lpe <= 64; lpe *= 2) {
     const size_t wg = lds_bytes_for(b, kcap, lpe, n_self);
     if (wg > 160 * 1024) continue;
+    if (n_self > 30 * lpe) continue;   // the self-collision sweep holds one hit bit per pass of lpe pairs (check_lpe)
     const int wgs = (int)std::min<size_t>(4, (160 * 1024) / wg);
     const int envs = wgs * (64 / lpe);
     // ties go to the layout that keeps more SIMDs busy (more, smaller workgroups)

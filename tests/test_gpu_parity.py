@@ -173,6 +173,40 @@ def test_self_collision_can_be_switched_off_and_pairs_ignored(anymal):
     w.close()
 
 
+def _many_primitives_urdf():
+    """13 bodies, 40 collision spheres: more candidate self-collision pairs than a 16-lane mapping sweeps (30 per lane)."""
+    links = ['<link name="b0"><inertial><origin xyz="0 0 0"/><mass value="5"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.1"/></inertial>'
+             + "".join(f'<collision><origin xyz="{0.3 * i} 0 0"/><geometry><sphere radius="0.05"/></geometry></collision>' for i in range(4)) + "</link>"]
+    joints = []
+    for k in range(1, 13):
+        links.append(f'<link name="b{k}"><inertial><origin xyz="0 0 -0.1"/><mass value="1"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.01"/></inertial>'
+                     + "".join(f'<collision><origin xyz="0 {0.05 * i} -0.2"/><geometry><sphere radius="0.03"/></geometry></collision>' for i in range(3)) + "</link>")
+        par = 0 if k % 3 == 1 else k - 1
+        joints.append(f'<joint name="j{k}" type="revolute"><origin xyz="{0.1 * k} 0 0"/><parent link="b{par}"/><child link="b{k}"/><axis xyz="0 1 0"/>'
+                      '<limit effort="50" velocity="10" lower="-3" upper="3"/></joint>')
+    return '<robot name="many">' + "".join(links) + "".join(joints) + "</robot>"
+
+
+def test_many_primitives_pick_a_mapping_that_holds_the_pair_list():
+    """A model with more candidate pairs than 30 per lane of the 16-lane mapping: the default mapping widens (no error, no
+    silent loss of pairs), an explicit 16 is refused loudly, and one integrate() matches the oracle."""
+    from raisimlib_amd import Model, RsbError
+    m = Model(urdf_string=_many_primitives_urdf())
+    N = 128
+    w = BatchedWorld(m, N)
+    npairs = len(w.self_collision_pairs())
+    assert npairs > 30 * 16 and w.lanes_per_env() >= 32 and npairs <= 30 * w.lanes_per_env()
+    with pytest.raises(RsbError):
+        w.set_lanes_per_env(16)
+    w.close()
+    gc, gv = workload.random_state(m.nq, m.nv, N, seed=5, joint_range=1.5, z_range=(0.15, 0.6))
+    kp = np.zeros(m.nv, np.float32); kd = np.zeros(m.nv, np.float32); kp[6:] = 30.0; kd[6:] = 1.0
+    dev, ref, o = run_one_step(m, gc, gv, gc, kp, kd)
+    assert len(o.self_pairs()) == npairs and ref["n_contacts"].sum() > 100
+    assert ((ref["contacts"]["collision"] >= 0x10000) & (np.arange(ref["contacts"].shape[1])[None, :] < ref["n_contacts"][:, None])).any()
+    check_step(dev, ref, du_tol=1e-3, both_converged=True, min_conv=0.7)
+
+
 def test_lanes_per_env_mappings_agree(anymal):
     """The three wave mappings (16 / 32 / 64 lanes per env; 64 = one wavefront per env) run the same per-env
     algorithm; they are separate template instantiations, so only rounding-level differences are allowed."""
