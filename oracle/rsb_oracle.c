@@ -1010,11 +1010,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
             G[i][j][3 * r + c] = s;
           }
       if (lim_sign[i] != 0.0) G[i][i][0] = G[i][i][4] = 1.0;   /* dummy tangential diagonal of a joint-limit row */
-      if (cbody2[i] >= 0) {
+      if (cbody2[i] >= 0 || m->fixed_base) {
         /* two bodies joined by fewer than three joints cannot move relative to each other in every direction (thigh against
-         * trunk: two joints), so a self-collision's block can be rank deficient; a small compliance, relative to the block's
-         * mean diagonal, keeps the per-contact rule well posed */
-        const double reg = ORC_SELF_REG * (G[i][i][0] + G[i][i][4] + G[i][i][8]) / 3.0;
+         * trunk: two joints), so a self-collision's block can be rank deficient - and so can every block of a fixed-base
+         * system (a body fewer than three joints from the world); a small compliance, relative to the block's mean diagonal,
+         * keeps the per-contact rule well posed (once for either reason, twice for both) */
+        const double reg = ((cbody2[i] >= 0) + (m->fixed_base != 0)) * ORC_SELF_REG * (G[i][i][0] + G[i][i][4] + G[i][i][8]) / 3.0;
         G[i][i][0] += reg; G[i][i][4] += reg; G[i][i][8] += reg;
       }
       inv3(G[i][i], Ginv[i]);

@@ -487,14 +487,15 @@ int do_integrate(rsb_world* w, int nsub) {
   const bool rec = w->timing && (w->launch_index++ % w->timing_stride == 0);
   if (rec && !w->ring0.empty()) { e0 = w->ring0[w->ring_next]; e1 = w->ring1[w->ring_next]; }
   if (rec) HIP_TRY(hipEventRecord(e0, w->stream));
-  // kernel classes by the deepest body level (support-chain capacity of the contact-column / Delassus phases)
+  // kernel classes by the deepest body level (support-chain capacity of the contact-column / Delassus phases) and by the base (fixed-base systems have a class of their own)
   const int mlv = w->blob.depth - 1;
   if (mlv <= 4) {
-    st = kcap == 8 ? launch_lpe<8, 0, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 4>(w, a, lds_bytes, lpe, prof);
+    if (w->blob.fixed_base) st = kcap == 8 ? launch_lpe<8, 1, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 1, 4>(w, a, lds_bytes, lpe, prof);
+    else st = kcap == 8 ? launch_lpe<8, 0, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 4>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 12) {
-    st = launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
+    st = w->blob.fixed_base ? launch_lpe<16, 1, 12>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 16) {
-    st = launch_lpe<16, 0, 16>(w, a, lds_bytes, lpe, prof);
+    st = w->blob.fixed_base ? launch_lpe<16, 1, 16>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 16>(w, a, lds_bytes, lpe, prof);
   } else {
     rsb::set_error("model outside the compiled kernel classes (tree depth <= 17)");
     return RSB_E_UNSUPPORTED;

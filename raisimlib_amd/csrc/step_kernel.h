@@ -473,7 +473,7 @@ __device__ __forceinline__ void body_inertia(const float* Rb, const float* rb, c
 }
 
 // ------------------------------------------------------------------------------- the kernel
-// LPE : lanes per env.  KMAX : contact capacity.  CL : chain-length capacity (>= model's longest chain).
+// LPE : lanes per env.  KMAX : contact capacity.  CL : model class, 1 = fixed-base systems (their contact blocks get a compliance, see the Delassus phase), 0 = floating base.
 // ML : body-level capacity (>= depth-1).  PROF : compile the cycle stamps / contact-problem dump / LDS poisoning of the
 // rsb_debug_* entry points in (the production instances carry none of it: fewer SGPRs, no branches in the solver loop).
 template <int LPE, int KMAX, int CL, int ML, bool PROF>
@@ -1259,6 +1259,24 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
       }
       __syncthreads();
+      if constexpr (CL != 0) {   // (a class of its own: the floating-base kernels stay what they were, instruction for instruction)
+        // fixed-base systems: a body fewer than three joints from the world cannot move in every direction, its contact's block
+        // is rank deficient; the same small compliance as for a self-collision (whose fold below adds it for those)
+        if (s < nc && __float_as_int(CON[s * kConSlot + 11]) < kSelfA) {
+          float acc[9], gi[12];
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+            float g4[4];
+            ld4(G + (3 * s + rr) * GS + 4 * s, g4);
+            acc[3 * rr] = g4[0]; acc[3 * rr + 1] = g4[1]; acc[3 * rr + 2] = g4[2];
+          }
+          const float reg = kSelfReg * (acc[0] + acc[4] + acc[8]) * (1.0f / 3.0f);
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { acc[4 * rr] += reg; G[(3 * s + rr) * GS + 4 * s + rr] = acc[4 * rr]; }
+          inv3(acc, gi);
+          gi[9] = gi[10] = gi[11] = 0.f;
+          stv<3>(GINV + 12 * s, gi);
+        }
+        __syncthreads();
+      }
       if (__any(nselfc > 0)) {
         // fold the two entries of every self-collision into one solver contact: G <- P G P^T, c <- P c with P adding the second
         // entry's rows to the first's.  The second entry stays in the solver as an inert contact (zero rows, unit diagonal,
@@ -1300,7 +1318,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             // two bodies joined by fewer than three joints cannot move relative to each other in every direction: the block is
             // rank deficient (thigh against trunk: two joints).  A small compliance keeps the per-contact rule well posed
             // (oracle: ORC_SELF_REG)
-            const float reg = kSelfReg * (acc[0] + acc[4] + acc[8]) * (1.0f / 3.0f);
+            const float reg = (CL != 0 ? 2.f : 1.f) * kSelfReg * (acc[0] + acc[4] + acc[8]) * (1.0f / 3.0f);
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { acc[4 * rr] += reg; G[(3 * sa + rr) * GS + 4 * sa + rr] = acc[4 * rr]; }
             inv3(acc, gi);
             gi[9] = gi[10] = gi[11] = 0.f;

@@ -76,6 +76,42 @@ def test_random_tree_one_step_parity(built_lib, seed):
 
 
 @pytest.mark.parametrize("seed", range(6))
+def test_random_fixed_base_tree_parity(built_lib, seed):
+    """The same generator with the root link named "world" (a fixed-base system: the base rows are inert), joints anywhere in
+    +-1.5 rad so that links also hit each other (self-collision), a ground plane some of them reach; two sub-steps."""
+    rng = np.random.default_rng(4000 + seed)
+    n_links = int(rng.integers(3, 9))
+    urdf = random_urdf(rng, n_links).replace('"l0"', '"world"')
+    model = Model(urdf_string=urdf)
+    assert model.blob.fixed_base == 1
+    nq, nv, N = model.nq, model.nv, 128
+    gc = np.zeros((N, nq)); gc[:, 3] = 1.0
+    gc[:, 7:] = rng.uniform(-1.5, 1.5, (N, nq - 7))
+    gv = np.zeros((N, nv)); gv[:, 6:] = rng.normal(size=(N, nv - 6))
+    kp = np.zeros(nv, np.float32); kd = np.zeros(nv, np.float32)
+    kp[6:] = rng.uniform(0, 60, nv - 6); kd[6:] = rng.uniform(0, 1.0, nv - 6)
+    pt = gc.copy(); pt[:, 7:] += rng.uniform(-0.3, 0.3, (N, nq - 7))
+    w = BatchedWorld(model, N); w.set_max_contacts(16); w.add_ground(-0.25)
+    o = Oracle(model.blob); o.p.kmax = 16; o.set_ground(-0.25)
+    dtg = np.zeros((N, nv))
+    w.set_pd_gains(kp, kd); w.set_pd_target(pt, dtg); w.set_state(gc, gv)
+    w.integrate(2)
+    q1, u1 = w.get_state(); cnt, _ = w.get_contacts(); fl = w.get_flags()
+    ref = o.step_batch(f32(gc), f32(gv), 2, kp.astype(np.float64), kd.astype(np.float64), f32(pt), dtg, lam_warm=o.new_warm_state(N))
+    w.close()
+    assert np.array_equal(q1[:, :7], np.tile([0, 0, 0, 1, 0, 0, 0], (N, 1))) and not u1[:, :6].any()
+    conv = ((ref["flags"] | fl) & 5) == 0
+    same = cnt == ref["n_contacts"]
+    assert same.mean() > 0.97, (seed, same.mean())                 # (a contact that appears in the second sub-step sits at a threshold)
+    ok = conv & same
+    assert ok.mean() > 0.3, (seed, ok.mean())                       # (random poses start jammed into the ground: many solves stagnate)
+    eu = np.abs(u1 - ref["u"]).max(axis=1) / (1 + np.abs(ref["u"]).max(axis=1))
+    eq = np.abs(q1 - ref["q"]).max(axis=1)
+    assert np.isfinite(q1).all() and np.isfinite(u1).all()
+    assert np.percentile(eu[ok], 99) < 2e-3 and np.median(eu[ok]) < 2e-5 and np.percentile(eq[ok], 99) < 2e-5, (seed, n_links, eu[ok].max(), eq[ok].max())
+
+
+@pytest.mark.parametrize("seed", range(6))
 def test_random_tree_three_substeps_on_a_height_map(built_lib, seed):
     """Same generator, three fused sub-steps (warm state in use from the second one) on a random Perlin terrain."""
     from raisimlib_amd.world import heightmap_perlin
