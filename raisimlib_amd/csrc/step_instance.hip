@@ -1,6 +1,7 @@
 // step_instance.hip — one instance of the fused step kernel (step_kernel.h) per object file.
-// Built by raisimlib_amd/build.py as   hipcc -c step_instance.hip -DRSB_I_LPE=16 -DRSB_I_KMAX=8 -DRSB_I_CL=4 -DRSB_I_ML=4 -DRSB_I_PROF=0
-// so that the ten kernel classes x {production, profiling} compile in parallel instead of in one 80 s translation unit.
+// Built by raisimlib_amd/build.py as   hipcc -c step_instance.hip -DRSB_I_LPE=16 -DRSB_I_KMAX=8 -DRSB_I_CL=0 -DRSB_I_ML=4 -DRSB_I_PROF=0
+// so that the kernel classes of step_launch.h (lanes per env x contact capacity x base kind x tree depth) x {production, profiling}
+// compile in parallel instead of in one translation unit of several minutes.
 #include "step_kernel.h"
 #include "step_launch.h"
 
