@@ -448,3 +448,18 @@ def test_ignore_collision_between_removes_the_pair(built_lib):
     ign = np.zeros((3, 3), bool); ign[0, 2] = True
     o.set_self_collision(True, ignore=ign)
     assert len(o.self_pairs()) == 0
+
+
+def test_self_collision_candidates_of_the_benchmark_models(anymal):
+    """The candidate list (what the device sweeps every sub-step): primitives of two different bodies that are not parent and
+    child, never two points; 160 pairs on the ANYmal-like model, 138 on the Atlas-like one."""
+    from raisimlib_amd import Model, rsc_path
+    for model, want in ((anymal, 160), (Model(urdf_path=rsc_path("atlas_like.urdf")), 138)):
+        o = Oracle(model.blob)
+        pairs = o.self_pairs()
+        b = model.blob
+        assert len(pairs) == want and len({tuple(p) for p in pairs}) == want
+        for i, j in pairs:
+            bi, bj = b.col_body[i], b.col_body[j]
+            assert i < j and bi != bj and b.parent[bi] != bj and b.parent[bj] != bi
+            assert b.col_radius[i] + b.col_radius[j] > 0 and b.col_rim[i] == 0 and b.col_rim[j] == 0
