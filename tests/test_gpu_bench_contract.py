@@ -1,0 +1,36 @@
+"""bench.py end to end on the GPU with a short run: the one JSON line the driver parses carries every field of the contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from common import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("config", [2, 5])
+def test_bench_prints_the_contract_line(built_lib, config):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--preroll", "8",
+           "--config", str(config), "--cpu-seconds", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]
+    b = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in b, k
+    assert b["n_gpus"] == 1 and b["steps"] == 6 and b["warmup"] == 2 and b["higher_is_better"] is True and b["scaling"] == "weak"
+    assert b["unit"] == "env-steps/s" and b["value"] > 1e6 and b["vs_baseline"] is None and b["data"] == "synthetic" and b["dtype"] == "f32"
+    assert "workload" in b["config"] and "model" not in b["config"]
+    assert abs(b["value"] - 4096 * 4 * 6 / (b["ms_per_step"] * 6 * 1e-3)) < 1e-3 * b["value"]      # whole-job env-steps over the timed region
+    roof = b["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in roof, k
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cb = b["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["value"] > 0
