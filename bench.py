@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--stall-window", type=int, default=-1, help="diagnostic: solver stagnation window (library default 4)")
     ap.add_argument("--freeze-after", type=int, default=-1, help="diagnostic: sweeps before friction directions lag (default 6)")
-    ap.add_argument("--settle-tol", type=float, default=-1.0, help="diagnostic: settled-direction tolerance (default 1e-4 rad)")
+    ap.add_argument("--settle-tol", type=float, default=-1.0, help="diagnostic: settled-direction tolerance in rad (library default 0 = off)")
     ap.add_argument("--no-self-collision", action="store_true", help="diagnostic: switch the self-collision sweep off (RaiSim's default, and this library's, is on)")
     ap.add_argument("--early-termination", action="store_true",
                     help="NOT the headline workload: envs stop integrating at the sub-step of their first non-foot contact")
@@ -74,7 +74,108 @@ def parse():
                     help="diagnostic: amplitude (rad) of the uniform PD-target noise (config 2/3: 0.3, config 5: 0.1)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="plumbing check without GPUs: the ranks rendezvous on gloo, all-gather a host obs block per step and "
+                         "print the contract line with dry_run=true (no device world, no physics; value is not a measurement)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-exec this script N times, one rank per GPU (what
+    `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` would do), forward rank 0's stdout (the one JSON
+    line) and every rank's stderr, and fail if any rank fails.  Returns the exit code."""
+    import subprocess
+    n = args.gpus
+    if not args.dry_run_ranks:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have} (no CPU or single-GPU fallback for N>1)",
+                  file=sys.stderr)
+            return 2
+    port = int(os.environ.get("MASTER_PORT", "0")) or _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = None if r == 0 else subprocess.DEVNULL          # rank 0 owns stdout: exactly one JSON line reaches the caller
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env, stdout=out))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def dry_run_ranks(args, rank, world_size):
+    """The N>1 plumbing on CPU (gloo): rendezvous, env-shard bookkeeping, one obs all-gather per "step" through the same
+    ObsGatherer the device path uses, barrier-bracketed timing with the MAX over ranks, ONE JSON line on rank 0.  No physics."""
+    import torch
+    import torch.distributed as dist
+    from raisimlib_amd.dist import ObsGatherer, env_range
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    n, obs_dim = args.envs_per_gpu, 49
+    lo, hi = env_range(rank, n)
+    gath = ObsGatherer(n, obs_dim, torch.device("cpu"), overlap=args.overlap_collective, force=args.force_collective)
+    rows = torch.arange(lo, hi, dtype=torch.float32)[:, None].expand(n, obs_dim)
+
+    def step(k):
+        gath.acquire(k)
+        gath.local(k).copy_(rows + float(k))          # stands for the step kernel writing this rank's obs block
+        gath.gather(k)
+
+    for k in range(args.warmup):
+        step(k)
+    gath.drain()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        step(k)
+    gath.drain()
+    dist.barrier()
+    mine = time.perf_counter() - t0
+    t = torch.tensor([mine], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world_size)]
+    dist.all_gather(per_rank, torch.tensor([mine], dtype=torch.float64))
+    last = gath.gathered(args.warmup + args.steps - 1)
+    want = torch.arange(0, world_size * n, dtype=torch.float32) + float(args.warmup + args.steps - 1)
+    ok = bool(torch.equal(last[:, 0], want)) if gath.active else True
+    dist.destroy_process_group()
+    if rank == 0:
+        elapsed = float(t.item())
+        print(json.dumps({
+            "metric": "env-steps/sec (DRY RUN: rank plumbing only, no physics)", "value": world_size * n * 4 * args.steps / elapsed,
+            "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_by_rank": [float(x.item()) / args.steps * 1e3 for x in per_rank],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+            "config": {"workload": "dry run of the rank plumbing on gloo", "envs_per_gpu": n, "parallelism": f"env-shard x{world_size}",
+                       "obs_all_gather": gath.describe(), "gathered_rows_correct": ok}}), flush=True)
+    return 0 if ok else 1
 
 
 class Recipe:
@@ -228,15 +329,24 @@ def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started without a launcher: this process becomes the launcher of --gpus ranks (one per GPU)
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world_size} rank(s); the launcher's count is used", file=sys.stderr)
+    if args.dry_run_ranks:
+        sys.exit(dry_run_ranks(args, rank, world_size))
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (this image's default; see rsb_world.hip)
     import torch
     import torch.distributed as dist
 
     from raisimlib_amd import BatchedWorld, workload
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()} (no CPU fallback)")
     coll = world_size > 1 or args.force_collective     # the obs all-gather is part of the step
     if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -338,7 +448,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ms_by_rank = [elapsed / args.steps * 1e3]
     if world_size > 1:
+        every = torch.zeros(world_size, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, t)
+        ms_by_rank = [float(x) / args.steps * 1e3 for x in every.cpu()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     kernel_ms_in = world.read_kernel_ms(n_in).astype(np.float64) if n_in else np.zeros(0)
@@ -411,7 +525,7 @@ def main():
         out = {
             "metric": recipe.metric,
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_by_rank": ms_by_rank, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": recipe.name + ", dt=0.0025, 4 sub-steps per control step fused in one launch"

@@ -34,3 +34,14 @@ def test_bench_prints_the_contract_line(built_lib, config):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0
+
+
+def test_bench_collective_path_on_one_rank(built_lib):
+    """the obs all-gather (RCCL) of the N>1 step, forced onto a one-rank group: the same code path `--gpus N` runs per rank"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--preroll", "8",
+           "--force-collective", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 1 and b["config"]["obs_all_gather"] != "none (1 rank)"
+    assert len(b["ms_per_step_by_rank"]) == 1 and b["value"] > 1e6
