@@ -9,7 +9,9 @@
 // No threads, no locks: fibers run one at a time on the caller's thread, exactly like the serial loop they replace.
 #pragma once
 
+#include <sys/mman.h>
 #include <ucontext.h>
+#include <unistd.h>
 
 #include <cstddef>
 #include <cstdlib>
@@ -26,8 +28,15 @@ class FiberScheduler {
   /// the scheduler whose fiber is running on this thread right now (nullptr outside of run())
   static FiberScheduler*& current() { static thread_local FiberScheduler* c = nullptr; return c; }
 
-  explicit FiberScheduler(size_t stackBytes = 128 * 1024) : stackBytes_(stackBytes) {}
-  ~FiberScheduler() { std::free(stacks_); }
+  /// stackBytes: usable stack of one fiber (RSB_FIBER_STACK_KB overrides the default at run time: a ChildEnvironment::step()
+  /// with large locals or deep Eigen expression temporaries needs more).  Every stack is followed by a PROT_NONE guard page:
+  /// an overflow faults instead of silently overwriting the neighbouring env's stack.
+  explicit FiberScheduler(size_t stackBytes = 128 * 1024) {
+    if (const char* kb = std::getenv("RSB_FIBER_STACK_KB")) { const long v = std::atol(kb); if (v >= 16) stackBytes = (size_t)v * 1024; }
+    page_ = (size_t)sysconf(_SC_PAGESIZE);
+    stackBytes_ = (stackBytes + page_ - 1) / page_ * page_;
+  }
+  ~FiberScheduler() { release(); }
   FiberScheduler(const FiberScheduler&) = delete;
   FiberScheduler& operator=(const FiberScheduler&) = delete;
 
@@ -36,9 +45,14 @@ class FiberScheduler {
   void run(int n, const std::function<void(int)>& body, const std::function<void()>& onAllParked) {
     if (current()) throw std::runtime_error("FiberScheduler::run: nested fiber schedulers are not supported");
     if (n > cap_) {
-      std::free(stacks_);
-      stacks_ = static_cast<char*>(std::malloc((size_t)n * stackBytes_));   // virtual; pages are touched on demand
-      if (!stacks_) throw std::bad_alloc();
+      release();
+      // [guard | stack 0 | guard | stack 1 | ... ]: stacks grow downwards INTO the guard page below them.  Virtual memory;
+      // pages are touched on demand
+      const size_t slot = stackBytes_ + page_, total = (size_t)n * slot;
+      void* m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (m == MAP_FAILED) throw std::bad_alloc();
+      stacks_ = static_cast<char*>(m); mapped_ = total;
+      for (int i = 0; i < n; ++i) mprotect(stacks_ + (size_t)i * slot, page_, PROT_NONE);
       cap_ = n;
       ctx_.resize(n);
     }
@@ -47,7 +61,7 @@ class FiberScheduler {
     error_ = nullptr;
     for (int i = 0; i < n; ++i) {
       getcontext(&ctx_[i]);
-      ctx_[i].uc_stack.ss_sp = stacks_ + (size_t)i * stackBytes_;
+      ctx_[i].uc_stack.ss_sp = stacks_ + (size_t)i * (stackBytes_ + page_) + page_;
       ctx_[i].uc_stack.ss_size = stackBytes_;
       ctx_[i].uc_link = &main_;
       makecontext(&ctx_[i], reinterpret_cast<void (*)()>(&FiberScheduler::trampoline), 0);
@@ -88,7 +102,8 @@ class FiberScheduler {
     try { (*s->body_)(s->running_); } catch (...) { s->error_ = std::current_exception(); }
     // falling off the end switches to uc_link (= main_) with state_ still kRunning, which run() reads as "finished"
   }
-  size_t stackBytes_;
+  void release() { if (stacks_) munmap(stacks_, mapped_); stacks_ = nullptr; mapped_ = 0; cap_ = 0; }
+  size_t stackBytes_ = 0, page_ = 4096, mapped_ = 0;
   char* stacks_ = nullptr;
   int cap_ = 0;
   std::vector<ucontext_t> ctx_;

@@ -192,7 +192,7 @@ class VectorizedEnvironment {
     RSFATAL_IF(rows != num_envs_ || cols != actionDim_, "step: action must be [num_envs, actionDim]");
     auto body = [&](int i) { perAgentStep(i, action, reward, done); };
     if (!batch_) { for (int i = 0; i < num_envs_; i++) body(i); return; }     // envs that never created a World
-    struct Guard { BatchedWorld* b; ~Guard() { b->setFiberBatch(false); } } guard{batch_.get()};
+    struct Guard { BatchedWorld* b; ~Guard() { b->setFiberBatch(false); b->abortViews(); } } guard{batch_.get()};   // (after a clean run nothing is pending)
     batch_->setFiberBatch(true);
     fibers_.run(num_envs_, body, [this] { batch_->flushViews(); });
   }

@@ -119,13 +119,20 @@ class BatchedWorld {
     RSB_CHECK(rsb_set_heightmap(world_, xSamples, ySamples, xSize, ySize, centerX, centerY, h.data()));
   }
   /// the whole batch at once (fast path; staged view writes are uploaded first)
-  void integrate(int nSubsteps = 1) { uploadStaged(); RSB_CHECK(rsb_integrate(world_, nSubsteps)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; }
-  void integrate1() { uploadStaged(); RSB_CHECK(rsb_integrate1(world_)); }
-  void integrate2() { uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; }
+  void integrate(int nSubsteps = 1) { uploadStaged(); RSB_CHECK(rsb_integrate(world_, nSubsteps)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false; }
+  /// the whole-batch M / h query; N views calling it between two flushes cost ONE launch (valid until a launch or a staged write)
+  void integrate1() {
+    uploadStaged();
+    if (queryValid_) return;
+    RSB_CHECK(rsb_integrate1(world_));
+    queryValid_ = true; ++queryLaunches_;
+  }
+  void integrate2() { uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false; }
+  long queryLaunches() const { return queryLaunches_; }   ///< launches issued by integrate1() (tests: N views -> 1 launch)
 
   // batched, caller-owned host buffers (row-major [N, dim] float32, the raisimGymTorch matrix layout)
   void setState(const float* gc, const float* gv) {
-    RSB_CHECK(rsb_set_state(world_, gc, gv, nullptr, RSB_HOST)); dropStage(RSB_F_GC); dropStage(RSB_F_GV); stateCacheValid_ = false;
+    RSB_CHECK(rsb_set_state(world_, gc, gv, nullptr, RSB_HOST)); dropStage(RSB_F_GC); dropStage(RSB_F_GV); stateCacheValid_ = false; queryValid_ = false;
     std::fill(gcMask_.begin(), gcMask_.end(), 0); std::fill(gvMask_.begin(), gvMask_.end(), 0);
   }
   void getState(float* gc, float* gv) { uploadStaged(); RSB_CHECK(rsb_get_state(world_, gc, gv, RSB_HOST)); }
@@ -180,8 +187,11 @@ class BatchedWorld {
     std::fill(pending_.begin(), pending_.end(), 0);
     nPending_ = 0;
     ++viewLaunches_;
-    stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false;
+    stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false;
   }
+  /// drop every recorded-but-unflushed integrate() (error path of the fiber scheduler: the parked fibers are gone, their
+  /// pending flags must not outlive them or every later step() would throw "already has an un-flushed integrate()")
+  void abortViews() { std::fill(pending_.begin(), pending_.end(), 0); nPending_ = 0; }
   void setFiberBatch(bool on) { fiberBatch_ = on; }
   long viewLaunches() const { return viewLaunches_; }     ///< launches issued by flushViews() (tests: N views -> 1 launch)
   int pendingViews() const { return nPending_; }
@@ -209,10 +219,11 @@ class BatchedWorld {
       std::vector<uint8_t> m(n_);
       for (int e = 0; e < n_; ++e) m[e] = gcMask_[e] | gvMask_[e];
       RSB_CHECK(rsb_set_state(world_, stage(RSB_F_GC).host.data(), stage(RSB_F_GV).host.data(), m.data(), RSB_HOST));
-      gc.dirty = gv.dirty = false;
+      gc.dirty = gv.dirty = false; queryValid_ = false;
       std::fill(gcMask_.begin(), gcMask_.end(), 0); std::fill(gvMask_.begin(), gvMask_.end(), 0);
     }
     Stage& pt = stages_[RSB_F_PTARGET]; Stage& dt = stages_[RSB_F_DTARGET]; Stage& tf = stages_[RSB_F_TAU_FF];
+    if (pt.dirty || dt.dirty || tf.dirty) queryValid_ = false;
     if (pt.dirty || dt.dirty) { RSB_CHECK(rsb_set_pd_target(world_, pt.dirty ? pt.host.data() : nullptr, dt.dirty ? dt.host.data() : nullptr, RSB_HOST)); pt.dirty = dt.dirty = false; }
     if (tf.dirty) { RSB_CHECK(rsb_set_generalized_force(world_, tf.host.data(), RSB_HOST)); tf.dirty = false; }
   }
@@ -288,7 +299,8 @@ class BatchedWorld {
   std::vector<uint8_t> pending_, gcMask_, gvMask_;
   int nPending_ = 0, kmax_ = 0;
   long viewLaunches_ = 0;
-  bool fiberBatch_ = false, stateCacheValid_ = false, contactsValid_ = false, genfValid_ = false;
+  long queryLaunches_ = 0;
+  bool fiberBatch_ = false, stateCacheValid_ = false, contactsValid_ = false, genfValid_ = false, queryValid_ = false;
   std::vector<float> genf_;
   std::vector<float> tmpGc_, tmpGv_;
   std::vector<int32_t> cnt_;

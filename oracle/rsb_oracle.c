@@ -813,9 +813,12 @@ void orc_solve_contact(const double* G, const double* v, double mu, int section_
 }
 
 static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {
+  /* t1 = the normalised projection of a world axis on the tangent plane: world x, or world y when the normal is (nearly)
+   * along x - a self-collision between mirror-symmetric limbs has n = (+-1, 0, 0) exactly, and the projection of x vanishes */
   double t1[3], t2[3];
-  double dn = n[0];
-  t1[0] = 1.0 - dn * n[0]; t1[1] = -dn * n[1]; t1[2] = -dn * n[2];
+  const int ry = fabs(n[0]) > 0.9;
+  double dn = ry ? n[1] : n[0];
+  t1[0] = (ry ? 0.0 : 1.0) - dn * n[0]; t1[1] = (ry ? 1.0 : 0.0) - dn * n[1]; t1[2] = -dn * n[2];
   double il = 1.0 / sqrt(dot3(t1, t1));
   for (int c = 0; c < 3; ++c) t1[c] *= il;
   cross3(n, t1, t2);

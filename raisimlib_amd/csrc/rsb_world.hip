@@ -291,7 +291,9 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
   const int nc = count[e];
   for (int k = 0; k < nc; ++k) {
     const int c = contacts[(size_t)e * kmax + k].collision;
-    if (!((allowed >> c) & 1ull)) term = true;
+    // an entry of a self-collision (id | RSB_CONTACT_SELF_A / _B) is never a foot on the terrain: terminal, as in the fused
+    // epilogue of the step kernel (and a shift by >= 64 would be undefined)
+    if (c >= RSB_CONTACT_SELF_A || !((allowed >> c) & 1ull)) term = true;
   }
   if (term) {
     const size_t r = rows == 1 ? 0 : (size_t)e;
@@ -673,6 +675,9 @@ int rsb_set_collision_materials(rsb_world* w, const double* mu, const double* re
   if (!w) { rsb::set_error("rsb_set_collision_materials: null world"); return RSB_E_INVALID; }
   for (int i = 0; i < w->blob.ncol; ++i) {
     if (restitution && restitution[i] > 1.0) { rsb::set_error("rsb_set_collision_materials: restitution <= 1"); return RSB_E_INVALID; }
+    if ((mu && !std::isfinite(mu[i])) || (restitution && !std::isfinite(restitution[i])) || (res_threshold && !std::isfinite(res_threshold[i]))) {
+      rsb::set_error("rsb_set_collision_materials: non-finite material value"); return RSB_E_INVALID;
+    }
   }
   for (int i = 0; i < w->blob.ncol; ++i) {
     w->col_mu[i] = mu ? mu[i] : -1.0;
@@ -706,8 +711,12 @@ int rsb_self_collision_pairs(const rsb_world* w, int32_t* pairs, int capacity) {
 int rsb_set_self_collision_materials(rsb_world* w, const double* mu, const double* restitution, const double* res_threshold) {
   if (!w) { rsb::set_error("rsb_set_self_collision_materials: null world"); return RSB_E_INVALID; }
   const size_t np = w->self_pairs.size() / 2;
-  for (size_t k = 0; k < np; ++k)
+  for (size_t k = 0; k < np; ++k) {
     if (restitution && restitution[k] > 1.0) { rsb::set_error("rsb_set_self_collision_materials: restitution <= 1"); return RSB_E_INVALID; }
+    if ((mu && !std::isfinite(mu[k])) || (restitution && !std::isfinite(restitution[k])) || (res_threshold && !std::isfinite(res_threshold[k]))) {
+      rsb::set_error("rsb_set_self_collision_materials: non-finite material value"); return RSB_E_INVALID;
+    }
+  }
   for (size_t k = 0; k < np; ++k) {
     w->self_mu[k] = mu ? mu[k] : -1.0;
     w->self_rest[k] = restitution ? restitution[k] : -1.0;

@@ -11,8 +11,8 @@
 // instruction costs the same for 16 or 64 active lanes, so packing is what fills the chip at N=4096).
 // At N=4096 there is one wave per SIMD, so the kernel is LATENCY bound: every design choice below
 // minimises dependent LDS round trips and barriers rather than instruction count.
-//   tree passes   : lane = kinematic CHAIN (a maximal parent->first-child path; ANYmal: 4 legs).  A lane
-//                   walks its chain serially in registers; LDS is touched once per chain LEVEL, not per body.
+//   tree passes   : lane = BODY.  What does not depend on the parent (joint transform, rigid inertia, bias force, actuation)
+//                   runs once for all bodies; the propagation is level-synchronous, one LDS hand-over per tree LEVEL.
 //                   The floating base is computed redundantly by every lane (no exchange needed).
 //   collisions    : lane = collision sphere.      contact columns : lane = (contact, axis).
 //   Delassus      : lane = contact pair.          Gauss-Seidel    : lane = contact (its G rows, velocity and
@@ -226,6 +226,18 @@ __device__ __forceinline__ void hm_resolve(const Args& a, const float* heights, 
     terrain_eval(a, heights, x, y, h, n);
     depth = r - (z - h) * n[2];
   }
+}
+
+// contact frame [t1 t2 n] (oracle: contact_frame): t1 = the normalised projection of a world axis on the tangent plane - world x,
+// or world y when the normal is (nearly) along x (a self-collision between mirror-symmetric limbs, a closest-feature normal on
+// a height-map edge: the projection of x would vanish) -, t2 = n x t1
+__device__ __forceinline__ void contact_tangents(const float* n, float* t1, float* t2) {
+  const bool ry = fabsf(n[0]) > 0.9f;
+  const float dn = ry ? n[1] : n[0];
+  t1[0] = (ry ? 0.f : 1.f) - dn * n[0]; t1[1] = (ry ? 1.f : 0.f) - dn * n[1]; t1[2] = -dn * n[2];
+  const float il = 1.0f / sqrtf(dot3(t1, t1));
+  t1[0] *= il; t1[1] *= il; t1[2] *= il;
+  cross3(n, t1, t2);
 }
 
 // ---- slip case of one contact (oracle: slip_prepare / slip_E / slip_dE / solve_one_contact) ---------------
@@ -756,12 +768,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       const int slot = nc + __popcll(gm & ((1ull << s) - 1ull));
       if (hit && slot < kmax) {
         float P[16], t1[3], t2[3];
-        // contact frame: t1 = normalised projection of world x on the tangent plane, t2 = n x t1
-        const float dn = n[0];
-        t1[0] = 1.f - dn * n[0]; t1[1] = -dn * n[1]; t1[2] = -dn * n[2];
-        const float il = 1.0f / sqrtf(dot3(t1, t1));
-        t1[0] *= il; t1[1] *= il; t1[2] *= il;
-        cross3(n, t1, t2);
+        contact_tangents(n, t1, t2);
         P[0] = c[0] - rad * n[0]; P[1] = c[1] - rad * n[1]; P[2] = c[2] - rad * n[2]; P[3] = dep;
         P[4] = t1[0]; P[5] = t1[1]; P[6] = t1[2]; P[7] = __int_as_float(cbody);
         P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(ci);
@@ -956,11 +963,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             n[0] *= idist; n[1] *= idist; n[2] *= idist;
             const float back = ci4[3] - 0.5f * dep;   // the middle of the overlap
             float P[16], t1[3], t2[3];
-            const float dn = n[0];
-            t1[0] = 1.f - dn * n[0]; t1[1] = -dn * n[1]; t1[2] = -dn * n[2];
-            const float il = 1.0f / sqrtf(dot3(t1, t1));
-            t1[0] *= il; t1[1] *= il; t1[2] *= il;
-            cross3(n, t1, t2);
+            contact_tangents(n, t1, t2);
             P[0] = ci4[0] - back * n[0]; P[1] = ci4[1] - back * n[1]; P[2] = ci4[2] - back * n[2]; P[3] = dep;
             P[4] = t1[0]; P[5] = t1[1]; P[6] = t1[2]; P[7] = COLT[kColSlot * pi + 4];
             P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(pi | kSelfA);
@@ -1681,7 +1684,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     RSB_STAMP(6)
 
     // =========================== du = L^-1 D^-1/2 (W_b + sum_c W_c lam_c), then integrate ========
-    // base part on every lane (C^T x = w by back substitution), chains walk root -> leaf in registers
+    // base part on every lane (C^T x = w by back substitution), then the bodies level by level from the base (lane = body)
     float a0[6];
     {
       float wv[6];
@@ -1713,7 +1716,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         float r2 = d0 * q2 - d1 * q3 + d2 * q0 + d3 * q1;
         float r3 = d0 * q3 + d1 * q2 - d2 * q1 + d3 * q0;
         const float in = 1.0f / sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
-        // joint entries of Q / U are owned by the chain lanes: write only the base entries
+        // joint entries of Q / U are owned by the body lanes: write only the base entries
         Q[0] = qv[0] + dt * un[0]; Q[1] = qv[1] + dt * un[1]; Q[2] = qv[2] + dt * un[2];
         Q[3] = r0 * in; Q[4] = r1 * in; Q[5] = r2 * in; Q[6] = r3 * in;
         RSB_UNROLL for (int i = 0; i < 6; ++i) U[i] = un[i];

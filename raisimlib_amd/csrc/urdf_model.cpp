@@ -217,6 +217,12 @@ static bool file_exists(const std::string& p) { std::ifstream f(p, std::ios::bin
 static std::string resolve_mesh_path(const std::string& uri, const std::string& base_dir) {
   std::string rel = uri;
   for (const char* pre : {"package://", "file://", "model://"}) if (rel.rfind(pre, 0) == 0) rel = rel.substr(std::strlen(pre));
+  // a URI must not walk out of the directories probed below ("../../etc/.."): the probing itself climbs at most 4 parents of the URDF
+  for (size_t at = 0; at <= rel.size();) {
+    const size_t end = std::min(rel.find('/', at), rel.size());
+    if (rel.compare(at, end - at, "..") == 0) return "";
+    at = end + 1;
+  }
   if (!rel.empty() && rel[0] == '/' && file_exists(rel)) return rel;
   std::string dir = base_dir;
   for (int up = 0; up < 4; ++up) {
@@ -545,8 +551,18 @@ int validate_blob(const rsb_model_blob& b) {
     if (b.level[i] + 1 > depth) depth = b.level[i] + 1;
   }
   if (b.depth != depth) { set_error("model: depth inconsistent"); return RSB_E_INVALID; }
-  for (int s = 0; s < b.ncol; ++s)
-    if (b.col_body[s] < 0 || b.col_body[s] >= b.nb || !(b.col_radius[s] >= 0)) { set_error("model: bad collision sphere"); return RSB_E_INVALID; }
+  if (b.fixed_base != 0 && b.fixed_base != 1) { set_error("model: fixed_base must be 0 or 1"); return RSB_E_INVALID; }
+  for (int s = 0; s < b.ncol; ++s) {
+    if (b.col_body[s] < 0 || b.col_body[s] >= b.nb || !(b.col_radius[s] >= 0) || !std::isfinite(b.col_radius[s])) { set_error("model: bad collision sphere"); return RSB_E_INVALID; }
+    for (int a = 0; a < 3; ++a)
+      if (!std::isfinite(b.col_pos[s][a])) { set_error("model: non-finite collision primitive position"); return RSB_E_INVALID; }
+    if (!(b.col_rim[s] >= 0) || !std::isfinite(b.col_rim[s])) { set_error("model: col_rim must be finite and >= 0"); return RSB_E_INVALID; }
+    if (b.col_rim[s] > 0) {
+      const double n2 = b.col_axis[s][0] * b.col_axis[s][0] + b.col_axis[s][1] * b.col_axis[s][1] + b.col_axis[s][2] * b.col_axis[s][2];
+      if (!(std::fabs(n2 - 1.0) < 1e-6)) { set_error("model: col_axis of a rim primitive must be a unit vector"); return RSB_E_INVALID; }
+    }
+    if (!std::memchr(b.col_material[s], 0, RSB_NAME_LEN)) { set_error("model: col_material is not NUL-terminated"); return RSB_E_INVALID; }
+  }
   return RSB_OK;
 }
 

@@ -12,6 +12,33 @@
 
 #define CHECK(c) do { if (!(c)) { std::printf("CHECK failed: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
 
+// a minimal env whose step() throws on demand between its two integrate() calls (error path of the fiber scheduler)
+class FlakyEnv : public raisim::RaisimGymEnv {
+ public:
+  FlakyEnv(const std::string& resourceDir, const Yaml::Node& cfg, bool) : RaisimGymEnv(resourceDir, cfg) {
+    world_ = std::make_unique<raisim::World>();
+    robot_ = world_->addArticulatedSystem(resourceDir_ + "/anymal_c_like.urdf");
+    world_->addGround();
+    obDim_ = 1; actionDim_ = 1;
+    gc_.resize(robot_->getGeneralizedCoordinateDim()); gv_.resize(robot_->getDOF());
+    gc_[2] = 0.6; gc_[3] = 1.0;
+  }
+  void init() final {}
+  void reset() final { robot_->setState(gc_, gv_); }
+  void observe(raisim::EigenVecRef ob) final { ob[0] = (float)robot_->getGeneralizedCoordinate()[2]; }
+  float step(const raisim::ConstEigenVecRef& action) final {
+    world_->integrate();
+    if (action[0] > 100.f) throw std::runtime_error("flaky");
+    world_->integrate();
+    return 0.f;
+  }
+  bool isTerminalState(float& terminalReward) final { terminalReward = 0.f; return false; }
+
+ private:
+  raisim::ArticulatedSystem* robot_;
+  raisim::VecDyn gc_, gv_;
+};
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::printf("usage: facade_test <urdf>\n"); return 2; }
   const std::string urdf = argv[1];
@@ -182,7 +209,24 @@ int main(int argc, char** argv) {
         for (int i = 0; i < gcDim; ++i) moved |= before_gc[(size_t)e * gcDim + i] != after_gc[(size_t)e * gcDim + i];
         CHECK(moved == (e == 1 || e == 5));
       }
-      std::printf("World views: %d replicas, one launch per round of integrate() calls, masked partial flush OK\n", NV);
+      // integrate1() of N views between two flushes is ONE whole-batch query launch, renewed after the next launch / staged write
+      {
+        const long q0 = batch.queryLaunches();
+        for (int e = 0; e < NV; ++e) views[e]->integrate1();
+        CHECK(batch.queryLaunches() == q0 + 1);
+        const double m00 = robots[3]->getMassMatrix()(0, 0);
+        CHECK(std::fabs(m00 - robots[3]->getTotalMass()) < 1e-3 * m00);
+        for (int e = 0; e < NV; ++e) views[e]->integrate2();
+        CHECK(batch.pendingViews() == 0);
+        for (int e = 0; e < NV; ++e) views[e]->integrate1();
+        CHECK(batch.queryLaunches() == q0 + 2);
+        raisim::VecDyn g2(gcDim), v2(gvDim);
+        g2 = robots[0]->getGeneralizedCoordinate().v; v2 = robots[0]->getGeneralizedVelocity().v;
+        robots[0]->setState(g2, v2);                       // a staged write invalidates the query
+        views[0]->integrate1();
+        CHECK(batch.queryLaunches() == q0 + 3);
+      }
+      std::printf("World views: %d replicas, one launch per round of integrate() / integrate1() calls, masked partial flush OK\n", NV);
     }
 
     // ---- upstream's template: N arbitrary ENVIRONMENT objects (tests/cpp/anymal_env/Environment.hpp) on one batch
@@ -218,6 +262,26 @@ int main(int argc, char** argv) {
         }
       }
       CHECK(venv.batch()->viewLaunches() - l0 == STEPS * 4);       // one launch per integrate() of the control step, for all 64 envs
+      // an exception inside one env's step() surfaces from venv.step() and must leave the batch usable: env 5 throws between
+      // its two integrate() calls, when envs 0-4 are already parked on their second one with a recorded, un-flushed integrate()
+      {
+        const std::string yaml8 = "num_envs: 8\nsimulation_dt: 0.0025\ncontrol_dt: 0.005\nrender: false\n";
+        raisim::VectorizedEnvironment<FlakyEnv> fenv(resourceDir, yaml8, /*normalizeObservation=*/false);
+        std::vector<float> fa(8, 0.f), fr(8);
+        std::unique_ptr<bool[]> fd(new bool[8]);
+        fenv.reset();
+        fenv.step(fa.data(), 8, 1, fr.data(), fd.get());
+        const long fl0 = fenv.batch()->viewLaunches();
+        fa[5] = 1000.f;
+        bool threw = false;
+        try { fenv.step(fa.data(), 8, 1, fr.data(), fd.get()); } catch (const std::exception& e) { threw = std::string(e.what()) == "flaky"; }
+        CHECK(threw && fenv.batch()->viewLaunches() == fl0 + 1 && fenv.batch()->pendingViews() == 0);
+        fa[5] = 0.f;
+        fenv.reset();
+        fenv.step(fa.data(), 8, 1, fr.data(), fd.get());            // works again: two launches, nothing left pending
+        CHECK(fenv.batch()->viewLaunches() == fl0 + 3 && fenv.batch()->pendingViews() == 0);
+        std::printf("VectorizedEnvironment: an exception in one env's step() leaves the batch usable\n");
+      }
       CHECK(ndone > 0);                                            // the big kicks made some robots fall and reset
       std::printf("VectorizedEnvironment<ENVIRONMENT>: %d envs x %d control steps = %ld launches, %d resets, equal to the device-resident env\n",
                   NE, STEPS, venv.batch()->viewLaunches() - l0, ndone);

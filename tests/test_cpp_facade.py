@@ -42,3 +42,33 @@ def test_fiber_scheduler_and_yaml_parser_on_cpu():
                     os.path.join(ROOT, "tests", "cpp", "fiber_yaml_test.cpp")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "fiber_yaml_test OK" in r.stdout, r.stdout + r.stderr
+
+
+LAUNCHER = os.path.join(ROOT, "tests", "cpp", "_build", "comm_launcher")
+
+
+def compile_launcher():
+    os.makedirs(os.path.dirname(LAUNCHER), exist_ok=True)
+    lib = os.path.join(ROOT, "raisimlib_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", LAUNCHER,
+                    os.path.join(ROOT, "tests", "cpp", "comm_launcher.cpp"), "-L", lib, "-lrsb", f"-Wl,-rpath,{lib}"], check=True)
+
+
+def test_comm_launcher_compiles_and_reports_no_device(built_lib):
+    """the C-ABI multi-process launcher (fork + pipe of the RCCL unique id) builds with plain g++; without a GPU it says so (77)"""
+    compile_launcher()
+    if built_lib.rsb_device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the gpu test")
+    r = subprocess.run([LAUNCHER, URDF], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 77 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_comm_launcher_runs_rsb_allgather_obs_across_processes(built_lib):
+    """one process per GPU through rsb_comm_get_unique_id / rsb_comm_init / rsb_allgather_obs: two ranks on a box with >= 2
+    GPUs, one rank (same fork / pipe / communicator path) on a 1-GPU box"""
+    compile_launcher()
+    r = subprocess.run([LAUNCHER, URDF], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = 2 if built_lib.rsb_device_count() >= 2 else 1
+    assert f"comm_launcher OK ranks={want}" in r.stdout

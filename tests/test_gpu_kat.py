@@ -274,3 +274,28 @@ def test_self_collision_folds_the_hand_onto_the_torso(built_lib):
     assert touched > 100 and worst <= first + 2e-4       # (+ the creep of the block's 1e-4 compliance, see the oracle KAT)
     assert np.abs(qd[2] - q).max() < 2e-3 and np.abs(ud[2] - u).max() < 2e-2      # 400 steps of a PD-driven sliding contact, fp32 vs fp64
     w.close()
+
+
+def test_self_collision_with_the_normal_along_world_x(built_lib):
+    """The oracle KAT's clapping hands through the C-ABI: a self-collision whose normal is exactly +-x (the axis the contact
+    frame projects) must not produce NaNs; normals reported as +-x, hands stop at touching distance."""
+    from test_oracle_kat import CLAPPER
+    mod, w = world(CLAPPER, gravity=[0, 0, 0])
+    kp = np.array([0] * 6 + [200.0, 200.0]); kd = np.array([0] * 6 + [10.0, 10.0])
+    pt = np.array([0, 0, 0, 0, 0, 0, 0, 0.3, -0.3])
+    w.set_pd_gains(kp, kd); w.set_pd_target(tile(pt), tile(np.zeros(8)))
+    w.set_state(tile([0, 0, 1.0, 1, 0, 0, 0, 0.0, 0.0]), tile(np.zeros(8)))
+    touched = 0
+    for k in range(600):
+        w.integrate(1)
+        if k % 20 == 19:
+            cnt, dc = w.get_contacts()
+            if cnt[0]:
+                touched += 1
+                assert (cnt == 2).all()
+                assert np.allclose(dc[5][0]["normal"], [-1, 0, 0], atol=1e-6) and np.allclose(dc[5][1]["normal"], [1, 0, 0], atol=1e-6)
+    q, u = w.get_state()
+    assert np.isfinite(q).all() and np.isfinite(u).all() and (w.get_flags() == 0).all()
+    gap = (0.2 + q[:, 8]) - (-0.2 + q[:, 7])
+    assert touched > 15 and (gap > 0.08).all() and (gap < 0.1 + 1e-6).all() and np.abs(u[:, 6:]).max() < 1e-2
+    w.close()

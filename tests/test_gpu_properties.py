@@ -168,6 +168,11 @@ def test_control_step_equals_the_separate_calls(anymal):
     feet = anymal.collision_indices("_foot")
     gc, gv = standing_states(N, seed=21, z=(0.3, 0.6), vel=1.5)
     gc[::7, 2] = 0.1                                    # some envs start belly-down -> terminate
+    # ... and some start contorted in the air: self-collisions only, whose contact entries carry RSB_CONTACT_SELF_A / _B in the
+    # collision id - terminal in both paths, whatever the low bits of the id are (a foot primitive hitting a thigh included)
+    contorted = np.arange(3, N, 11)
+    gc[contorted, 7:] = np.random.default_rng(5).uniform(-2.5, 2.5, (len(contorted), 12))
+    gc[contorted, 2] = 2.0
     kp, kd = workload.anymal_gains()
     init_q, init_u = workload.anymal_initial_state(N)
     g0 = torch.from_numpy(init_q.astype(np.float32)).cuda(); v0 = torch.from_numpy(init_u.astype(np.float32)).cuda()
@@ -202,6 +207,9 @@ def test_control_step_equals_the_separate_calls(anymal):
         terminated += int((a[3] == 0).sum())
     assert np.array_equal(res[0][6][0], res[1][6][0]) and np.array_equal(res[0][6][1], res[1][6][1])   # stored targets refreshed
     assert terminated > 0
+    q0f = res[1][0][0]                                   # fused path after control step 0: self-colliding envs were reset
+    reset0 = np.all(q0f == init_q.astype(np.float32), axis=1)
+    assert reset0[contorted].sum() >= 5 and np.array_equal(reset0, np.all(res[0][0][0] == init_q.astype(np.float32), axis=1))
 
 
 def test_api_errors(anymal):
@@ -216,6 +224,13 @@ def test_api_errors(anymal):
         w.integrate(0)
     with pytest.raises(RsbError):
         w.set_contact_solver_param(1, 1, 1, 0, 1e-5)
+    bad = np.full(anymal.ncol, 0.8); bad[3] = np.nan
+    with pytest.raises(RsbError):
+        w.set_collision_materials(mu=bad)
+    with pytest.raises(RsbError):
+        w.set_collision_materials(res_threshold=np.full(anymal.ncol, np.inf))
+    with pytest.raises(RsbError):
+        w.set_self_collision_materials(mu=np.full(len(w.self_collision_pairs()), np.nan))
     w.set_time_step(0.001)
     assert abs(w.get_time_step() - 0.001) < 1e-15
     w.close()

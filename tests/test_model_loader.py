@@ -213,3 +213,44 @@ def test_world_root_link_makes_a_fixed_base_model(built_lib):
                           "<joint name='j' type='revolute'><parent link='world'/><child link='b'/><axis xyz='0 0 1'/></joint></robot>")
     assert m.blob.fixed_base == 1 and (m.nb, m.nq, m.nv) == (2, 8, 7)
     assert Model(urdf_string=sphere_urdf()).blob.fixed_base == 0
+
+
+def test_blob_validation_rejects_malformed_collision_fields(built_lib):
+    """rsb_model_from_blob is the entry a host language binds: rim / axis / fixed_base / material fields are checked, not trusted"""
+    import copy
+    from raisimlib_amd._capi import RsbError
+    good = Model(urdf_string=sphere_urdf()).blob
+    assert Model(blob=good).ncol == good.ncol
+
+    def broken(edit):
+        b = copy.deepcopy(good)
+        edit(b)
+        with pytest.raises(RsbError):
+            Model(blob=b)
+
+    broken(lambda b: setattr(b, "fixed_base", 7))
+    broken(lambda b: b.col_rim.__setitem__(0, -0.1))
+    broken(lambda b: b.col_rim.__setitem__(0, float("nan")))
+    broken(lambda b: b.col_radius.__setitem__(0, float("inf")))
+
+    def bad_axis(b):
+        b.col_rim[0] = 0.1
+        b.col_axis[0][0], b.col_axis[0][1], b.col_axis[0][2] = 0.0, 0.0, 2.0
+    broken(bad_axis)
+
+    def unterminated(b):
+        b.col_material[0].raw = b"x" * len(b.col_material[0].raw)
+    broken(unterminated)
+
+
+def test_mesh_uri_must_not_climb_out_of_the_probed_directories(built_lib, tmp_path):
+    """a <mesh filename> with '..' components is not resolved (the loader probes up to 4 parents of the URDF itself): skipped"""
+    (tmp_path / "secret.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\n")
+    d = tmp_path / "robot" / "urdf"
+    d.mkdir(parents=True)
+    urdf = """<robot name="r"><link name="base"><inertial><mass value="1"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial>
+ <collision><geometry><mesh filename="package://pkg/../../../secret.obj"/></geometry></collision>
+ <collision><geometry><sphere radius="0.1"/></geometry></collision></link></robot>"""
+    (d / "r.urdf").write_text(urdf)
+    m = Model(urdf_path=str(d / "r.urdf"))
+    assert m.ncol == 1 and m.skipped_collisions == 1

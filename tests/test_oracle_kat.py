@@ -443,6 +443,45 @@ def test_self_collision_is_an_internal_force(built_lib):
     assert abs(off_q[8] - 3.1) < 0.05 and abs(off_q[7] - 0.3) < 0.05
 
 
+CLAPPER = """<?xml version="1.0"?>
+<robot name="clapper">
+ <link name="torso"><inertial><mass value="4"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.1"/></inertial></link>
+ <link name="left"><inertial><mass value="1"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.01"/></inertial>
+  <collision><geometry><sphere radius="0.05"/></geometry></collision></link>
+ <link name="right"><inertial><mass value="1"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.01" iyz="0" izz="0.01"/></inertial>
+  <collision><geometry><sphere radius="0.05"/></geometry></collision></link>
+ <joint name="jl" type="prismatic"><origin xyz="-0.2 0 0"/><parent link="torso"/><child link="left"/><axis xyz="1 0 0"/>
+  <limit effort="1000" velocity="100" lower="-10" upper="10"/></joint>
+ <joint name="jr" type="prismatic"><origin xyz="0.2 0 0"/><parent link="torso"/><child link="right"/><axis xyz="1 0 0"/>
+  <limit effort="1000" velocity="100" lower="-10" upper="10"/></joint>
+</robot>"""
+
+
+def test_self_collision_with_the_normal_along_world_x(built_lib):
+    """Two hands on a common slide clap at yaw 0: the self-collision's normal is (+-1, 0, 0) EXACTLY, the direction the contact
+    frame used to project onto the tangent plane (t1 = 0 / |0| -> NaN).  The frame now takes world y there: the state stays
+    finite, the normal is reported as +-x, the hands stop at touching distance and the system's momentum is untouched."""
+    mod, o = make(CLAPPER)
+    assert [tuple(p) for p in o.self_pairs()] == [(0, 1)]
+    o.p.gravity[2] = 0.0
+    kp = np.array([0] * 6 + [200.0, 200.0]); kd = np.array([0] * 6 + [10.0, 10.0])
+    q = np.array([0, 0, 1.0, 1, 0, 0, 0, 0.0, 0.0]); u = np.zeros(8)
+    pt = np.array([0, 0, 0, 0, 0, 0, 0, 0.3, -0.3]); dtg = np.zeros(8)
+    touched = 0
+    for k in range(600):
+        q, u, con, _, fl = o.step(q, u, kp, kd, pt, dtg)
+        assert np.isfinite(q).all() and np.isfinite(u).all() and fl == 0
+        if len(con):
+            touched += 1
+            assert len(con) == 2 and np.allclose(con["normal"][0], [-1, 0, 0], atol=1e-12) and np.allclose(con["normal"][1], [1, 0, 0], atol=1e-12)
+            assert np.allclose(con["impulse"][0], -con["impulse"][1]) and con["impulse"][0][0] <= 1e-12 and np.abs(con["impulse"][0][1:]).max() < 1e-12
+    gap = (0.2 + q[8]) - (-0.2 + q[7])                # distance of the two sphere centres along the slide
+    assert touched > 300 and 0.08 < gap < 0.1 + 1e-9   # pressed together at ~r + r (erp 0; the hands are two joints apart, their block is
+                                                        # singular and carries the 1e-4 compliance: 40 N of PD push creep ~1 cm in 1.5 s)
+    lin, ang = o.momentum(q, u)
+    assert np.abs(lin).max() < 1e-10 and np.abs(ang).max() < 1e-10 and np.abs(u[6:]).max() < 1e-4   # (creeping at the compliance rate)
+
+
 def test_ignore_collision_between_removes_the_pair(built_lib):
     mod, o = make(FOLDER)
     ign = np.zeros((3, 3), bool); ign[0, 2] = True
