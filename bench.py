@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
                     help="BASELINE.json configs: 2 = ANYmal flat (headline), 3 = ANYmal on a 128x128 height map, 5 = Atlas-like")
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--atlas-regime", choices=("standing", "collapsing"), default="standing",
+                    help="config 5: 'standing' = gains that hold the humanoid up (SURVEY.md 8d: standing PD, multi-contact feet); "
+                         "'collapsing' = the kp 200 / kd 5 workload of rounds 1-2 (every env falls within 0.6 s and is reset)")
+    ap.add_argument("--per-env-maps", action="store_true", help="config 3 variant: one 128x128 height map per env (SURVEY.md 8d: 'to stress gathers')")
     ap.add_argument("--preroll", type=int, default=PREROLL, help="diagnostic: untimed control steps before --warmup")
     ap.add_argument("--max-iter", type=int, default=0, help="contact-solver iteration cap (0 = library default)")
     ap.add_argument("--lanes-per-env", type=int, default=0)
@@ -71,7 +75,8 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: no HIP-event brackets anywhere (roofline fields become null)")
     ap.add_argument("--target-amplitude", type=float, default=-1.0,
-                    help="diagnostic: amplitude (rad) of the uniform PD-target noise (config 2/3: 0.3, config 5: 0.1)")
+                    help="diagnostic: amplitude (rad) of the uniform PD-target noise (config 2/3: 0.3; config 5 collapsing: 0.1; "
+                         "config 5 standing: a SCALE on the per-class amplitudes 0.03 / 0.1 rad, default 1)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
     ap.add_argument("--dry-run-ranks", action="store_true",
@@ -181,21 +186,34 @@ def dry_run_ranks(args, rank, world_size):
 class Recipe:
     """Everything that defines one BASELINE.json configuration: model, terrain, gains, initial state, targets."""
 
-    def __init__(self, config, amplitude):
+    def __init__(self, config, amplitude, atlas_regime="standing", per_env_maps=False):
         from raisimlib_amd import Model, rsc_path, workload
         self.config = config
         self.wl = workload
+        self.per_env_maps = bool(per_env_maps) and config == 3
+        self.atlas_regime = atlas_regime
+        self._terrain = {}
         if config == 5:
             self.model = Model(urdf_path=rsc_path("atlas_like.urdf"))
             self.kmax = 16
-            self.amp = amplitude if amplitude >= 0 else 0.1
-            self.kp, self.kd = workload.atlas_gains(self.model.nv)
+            b = self.model.blob
+            self.joint_names = [b.joint_name[i].value.decode() for i in range(b.nb)]
             self.feet = self.model.collision_indices("_foot_0") + self.model.collision_indices("_foot_1") + \
                 self.model.collision_indices("_foot_2") + self.model.collision_indices("_foot_3")
             self.feet = sorted(self.feet)
-            self.name = ("configs[4]: 4096 Atlas-like humanoids (synthetic stand-in URDF, 31 bodies / 36 DoF, 18 collision spheres, "
-                         "kmax 16) per GPU, flat ground, implicit PD kp=200 kd=5, targets = zero pose + "
-                         f"U(-{self.amp:g},{self.amp:g}) rad per control step, per-env seed 77+i")
+            head = ("configs[4]: 4096 Atlas-like humanoids (synthetic stand-in URDF, 31 bodies / 36 DoF, 18 collision spheres, "
+                    "kmax 16) per GPU, flat ground, ")
+            if atlas_regime == "standing":
+                self.amp = amplitude if amplitude >= 0 else 1.0          # scale of the per-class noise amplitudes
+                self.kp, self.kd = workload.atlas_standing_gains(self.joint_names)
+                a0, a1 = (self.amp * x for x in workload.ATLAS_STAND_AMP)
+                self.name = head + ("STANDING regime: implicit PD kp 3000 / kd 60 on legs and back, kp 300 / kd 10 on arms and neck, targets = zero "
+                                    f"pose + U(-{a0:g},{a0:g}) rad (legs, back) / U(-{a1:g},{a1:g}) rad (arms, neck) per control step, per-env seed 77+i")
+            else:
+                self.amp = amplitude if amplitude >= 0 else 0.1
+                self.kp, self.kd = workload.atlas_gains(self.model.nv)
+                self.name = head + ("COLLAPSING regime (rounds 1-2; kp 200 cannot hold 164 kg up): implicit PD kp=200 kd=5, targets = zero pose + "
+                                    f"U(-{self.amp:g},{self.amp:g}) rad per control step, per-env seed 77+i")
             self.metric = "env-steps/sec, 4096 Atlas-like humanoid envs flat terrain dt=0.0025"
         else:
             self.model = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
@@ -203,42 +221,68 @@ class Recipe:
             self.amp = amplitude if amplitude >= 0 else 0.3
             self.kp, self.kd = workload.anymal_gains(self.model.nv)
             self.feet = self.model.collision_indices("_foot")
-            terrain = "flat ground" if config == 2 else \
-                "shared 128x128 height map over 12.8 m x 12.8 m (smoothed uniform noise, +-0.1 m, seed 7)"
+            if config == 2:
+                terrain = "flat ground"
+            elif self.per_env_maps:
+                terrain = ("ONE 128x128 height map PER ENV (12.8 m x 12.8 m, smoothed uniform noise, +-0.1 m, seed 7+i; 256 MB of maps per GPU), "
+                           "base xy spread over +-6 m of it (per-env seeded)")
+            else:
+                terrain = ("shared 128x128 height map over 12.8 m x 12.8 m (smoothed uniform noise, +-0.1 m, seed 7), base xy spread over "
+                           "+-6 m of it (per-env seeded)")
             self.name = (f"configs[{config - 1}]: 4096 ANYmal-C-like (synthetic stand-in URDF) envs per GPU, {terrain}, PD kp=50 kd=0.2, "
                          f"targets = nominal + U(-{self.amp:g},{self.amp:g}) rad per control step, per-env seed 1234+i")
             self.metric = "env-steps/sec, 4096 ANYmal-C envs flat terrain dt=0.0025" if config == 2 else \
                 "env-steps/sec, 4096 ANYmal-C envs on a 128x128 raisim::HeightMap dt=0.0025"
-        self.heights = workload.smoothed_heightmap(128, 128, amplitude=0.1, seed=7) if config == 3 else None
+
+    def terrain(self, n, env_offset):
+        """config 3: (maps [n_maps, 128, 128], env -> map [n]) of the envs [env_offset, env_offset + n)"""
+        key = (n, env_offset)
+        if key not in self._terrain:
+            wl = self.wl
+            if self.per_env_maps:
+                self._terrain[key] = (wl.env_heightmaps(n, 128, 128, amplitude=0.1, seed0=7, env_offset=env_offset), np.arange(n, dtype=np.int32))
+            else:
+                self._terrain[key] = (wl.smoothed_heightmap(128, 128, amplitude=0.1, seed=7)[None], np.zeros(n, np.int32))
+        return self._terrain[key]
 
     def initial_state(self, n, env_offset):
         wl = self.wl
         if self.config == 5:
             return wl.atlas_initial_state(n, self.model.nq, self.model.nv)
-        gc, gv = wl.anymal_initial_state(n, env_offset=env_offset)
         if self.config == 3:
-            gc[:, 2] += wl.HEIGHTMAP_CLEARANCE
-        return gc, gv
+            maps, env_map = self.terrain(n, env_offset)
+            return wl.anymal_initial_state_on_maps(n, maps, env_map, wl.HEIGHTMAP_SIZE, env_offset=env_offset)
+        return wl.anymal_initial_state(n, env_offset=env_offset)
 
     def targets(self, n, k, env_offset):
         if self.config == 5:
+            if self.atlas_regime == "standing":
+                return self.wl.atlas_standing_targets(n, k, self.joint_names, env_offset=env_offset, scale=self.amp)
             return self.wl.atlas_targets(n, k, self.model.nq, env_offset=env_offset, amplitude=self.amp)
         return self.wl.anymal_targets(n, k, env_offset=env_offset, amplitude=self.amp)
 
-    def setup_world(self, world):
+    def setup_world(self, world, n, env_offset):
         wl = self.wl
         if self.kmax != 8:
             world.set_max_contacts(self.kmax)
         world.set_time_step(wl.DT)
         world.set_pd_gains(self.kp, self.kd)
-        if self.heights is not None:
-            world.add_height_map(128, 128, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, self.heights)
+        if self.config == 3:
+            maps, env_map = self.terrain(n, env_offset)
+            if self.per_env_maps:
+                world.add_height_maps(maps, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, env_map)
+            else:
+                world.add_height_map(128, 128, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, maps[0])
 
-    def setup_oracle(self, orc):
+    def setup_oracle(self, orc, n, env_offset):
         orc.p.kmax = self.kmax
-        if self.heights is not None:
+        if self.config == 3:
             wl = self.wl
-            orc.set_heightmap(128, 128, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, self.heights)
+            maps, env_map = self.terrain(n, env_offset)
+            if self.per_env_maps:
+                orc.set_heightmaps(maps, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, env_map)
+            else:
+                orc.set_heightmap(128, 128, wl.HEIGHTMAP_SIZE, wl.HEIGHTMAP_SIZE, 0.0, 0.0, maps[0])
 
 
 def recorded_traffic(config, n_envs, substeps):
@@ -271,7 +315,7 @@ def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, 
     from raisimlib_amd import workload
     model = recipe.model
     orc = Oracle(model.blob)
-    recipe.setup_oracle(orc)
+    recipe.setup_oracle(orc, q0.shape[0], 0)
     orc.p.self_collision = int(self_collision)
     if max_iter > 0:
         orc.p.max_iter = max_iter
@@ -357,13 +401,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
     N = args.envs_per_gpu
-    recipe = Recipe(args.config, args.target_amplitude)
+    recipe = Recipe(args.config, args.target_amplitude, args.atlas_regime, args.per_env_maps)
     model, feet = recipe.model, recipe.feet
     world = BatchedWorld(model, N, device=local_rank)
     stream = torch.cuda.Stream(device=dev)       # everything below (kernels, copies, events, collectives) is ordered on it
     torch.cuda.set_stream(stream)
     world.set_stream(stream.cuda_stream)
-    recipe.setup_world(world)
+    recipe.setup_world(world, N, rank * N)
     if args.max_iter > 0:
         world.set_contact_solver_param(1.0, 1.0, 1.0, args.max_iter, 1e-5)
     if args.lanes_per_env:

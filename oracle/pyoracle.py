@@ -30,6 +30,7 @@ class Params(C.Structure):
         ("hm_heights", C.c_void_p),
         ("col_mu", C.c_void_p), ("col_restitution", C.c_void_p), ("col_res_threshold", C.c_void_p),
         ("self_ignore", C.c_void_p), ("self_mu", C.c_void_p), ("self_restitution", C.c_void_p), ("self_res_threshold", C.c_void_p),
+        ("hm_index", C.c_void_p),
     ]
 
 
@@ -85,6 +86,15 @@ class Oracle:
         self.p.hm_xs, self.p.hm_ys = xs, ys
         self.p.hm_xsize, self.p.hm_ysize, self.p.hm_cx, self.p.hm_cy = xsize, ysize, cx, cy
         self.p.hm_heights = self._hm.ctypes.data
+
+    def set_heightmaps(self, heights, xsize, ysize, cx, cy, env_map):
+        """Terrain curricula for step_batch(): heights [n_maps, ys, xs], env_map [N] -> the map env e stands on."""
+        h = np.ascontiguousarray(heights, dtype=np.float32)
+        self.set_heightmap(h.shape[2], h.shape[1], xsize, ysize, cx, cy, h[0])
+        self._hm = h
+        self._hmi = np.ascontiguousarray(env_map, dtype=np.int32)
+        self.p.hm_heights = self._hm.ctypes.data
+        self.p.hm_index = self._hmi.ctypes.data
 
     def set_collision_materials(self, mu=None, restitution=None, res_threshold=None):
         """Per collision primitive contact material against the terrain ([ncol] arrays; None = the scalar default)."""

@@ -304,6 +304,7 @@ void orc_default_params(orc_params* p) {
   p->control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   p->terrain_type = 0;
   p->ground_z = 0.0;
+  p->hm_index = NULL;
 }
 
 void orc_mass_matrix(const rsb_model_blob* m, const double* q, double* M) {
@@ -1294,9 +1295,11 @@ int orc_step_batch(const rsb_model_blob* m, const orc_params* p, int N, int subs
 #endif
   for (int e = 0; e < N; ++e) {
     int fl_acc = 0;
+    orc_params pe = *p;   /* this env's terrain: its own map of a curriculum (hm_index), else the shared one */
+    if (p->hm_index && p->terrain_type == 1) pe.hm_heights = p->hm_heights + (size_t)p->hm_index[e] * p->hm_xs * p->hm_ys;
     for (int s = 0; s < substeps; ++s) {
       int32_t fl = 0;
-      orc_step_warm(m, p, q + (size_t)e * m->nq, u + (size_t)e * m->nv, kp, kd,
+      orc_step_warm(m, &pe, q + (size_t)e * m->nq, u + (size_t)e * m->nv, kp, kd,
                     p_target ? p_target + (size_t)e * m->nq : NULL,
                     d_target ? d_target + (size_t)e * m->nv : NULL,
                     tau_ff ? tau_ff + (size_t)e * m->nv : NULL,

@@ -62,6 +62,9 @@ typedef struct orc_params {
   const double* self_mu;
   const double* self_restitution;
   const double* self_res_threshold;
+  /* terrain curricula (the device's rsb_set_heightmaps): orc_step_batch lets env e stand on map hm_index[e] of the
+   * [n_maps][ys][xs] array hm_heights (NULL = every env on map 0); single-env entry points ignore it */
+  const int32_t* hm_index;
 } orc_params;
 
 /* collision ids reported for the two entries of a self-collision (RaiSim lists it once per body): primitive id | flag */

@@ -3,8 +3,12 @@
 Config 1/2: ANYmal-C-like stand-in on flat ground, dt = 0.0025, 4 sub-steps per control step,
 PD kp=50 / kd=0.2 on the 12 joints, targets = nominal + U(-0.3, 0.3) rad resampled per control step,
 per-env seed 1234+i, base xy jitter U(-0.1, 0.1) m, yaw U(-pi, pi).
-Config 3: the same robots on a shared 128 x 128 height map over 12.8 m x 12.8 m (smoothed noise, +-0.1 m, seed 7).
-Config 5: Atlas-like humanoid, standing PD (kp 200, kd 5) with U(-0.1, 0.1) rad target noise, kmax 16.
+Config 3: the same robots on a shared 128 x 128 height map over 12.8 m x 12.8 m (smoothed noise, +-0.1 m, seed 7), base xy
+spread over +-6 m of it (per-env seeded) so that the envs of a batch gather from all over the map; variant: one map per env.
+Config 5: Atlas-like humanoid, kmax 16.  "standing" regime (default): legs and back kp 3000 / kd 60, arms and neck kp 300 / kd 10,
+targets = zero pose + U(-0.03, 0.03) rad (legs, back) / U(-0.1, 0.1) rad (arms, neck) per control step: the humanoid stays on
+its eight foot spheres indefinitely (oracle: 256 envs x 2000 control steps, no fall).  "collapsing" regime (rounds 1-2): kp 200 /
+kd 5 on every joint with U(-0.1, 0.1) rad noise - too weak for the 164 kg model, every env falls within 0.6 s and is reset.
 
 Every random number is a pure function of (GLOBAL env index, control step, entry): env g draws from the
 counter-based stream keyed by seed0 + g, so a rank that owns envs [lo, hi) produces exactly rows lo..hi of the
@@ -66,6 +70,34 @@ def anymal_initial_state(n_envs, seed0=1234, env_offset=0, height=ANYMAL_INIT_HE
     return gc, gv
 
 
+def env_heightmaps(n_envs, xs=128, ys=128, amplitude=0.1, seed0=7, env_offset=0):
+    """Config 3, per-env-map variant: one smoothed-noise map per env, [n_envs, ys, xs]; env g's map is seeded seed0 + g
+    (g = 0 is the shared map of the default variant), so a rank that owns envs [lo, hi) builds exactly those maps."""
+    return np.stack([smoothed_heightmap(xs, ys, amplitude, seed0 + env_offset + i) for i in range(n_envs)])
+
+
+def anymal_initial_state_on_maps(n_envs, maps, env_map, size, seed0=1234, env_offset=0, spread=6.0, clearance=0.02):
+    """Config 3: per-env seeded initial states spread over the map - base xy ~ U(-spread, spread)^2 - and dropped from just above
+    the terrain: base height = nominal + the highest sample within 0.5 m of the base + clearance.  maps [n_maps, ys, xs]
+    centred on the origin, `size` metres wide; env i stands on maps[env_map[i]]."""
+    from scipy.ndimage import maximum_filter
+    gc, gv = anymal_initial_state(n_envs, seed0, env_offset)
+    r = env_uniform(seed0 + env_offset + np.arange(n_envs), _STREAM_INIT, 5)   # entries 0-2 are anymal_initial_state's
+    gc[:, 0:2] = spread * (2.0 * r[:, 3:5] - 1.0)
+    ys, xs = maps.shape[1:]
+    cell = size / (xs - 1)
+    ix = np.clip(np.rint((gc[:, 0] + 0.5 * size) / cell).astype(int), 0, xs - 1)
+    iy = np.clip(np.rint((gc[:, 1] + 0.5 * size) / cell).astype(int), 0, ys - 1)
+    k = 2 * int(round(0.5 / cell)) + 1
+    env_map = np.asarray(env_map)
+    top = np.zeros(n_envs)
+    for mi in np.unique(env_map):
+        sel = env_map == mi
+        top[sel] = maximum_filter(maps[mi], size=k, mode="nearest")[iy[sel], ix[sel]]
+    gc[:, 2] = ANYMAL_INIT_HEIGHT + top + clearance
+    return gc, gv
+
+
 def anymal_targets(n_envs, control_step, seed0=1234, env_offset=0, amplitude=0.3):
     """PD position targets [N,19] for one control step (base entries unused)."""
     pt = np.zeros((n_envs, 19))
@@ -76,11 +108,44 @@ def anymal_targets(n_envs, control_step, seed0=1234, env_offset=0, amplitude=0.3
 
 
 def atlas_gains(nv=36):
+    """the "collapsing" regime of rounds 1-2: kp 200 / kd 5 on every joint (cannot hold the 164 kg model up)"""
     kp = np.zeros(nv, np.float32)
     kd = np.zeros(nv, np.float32)
     kp[6:] = ATLAS_KP
     kd[6:] = ATLAS_KD
     return kp, kd
+
+
+ATLAS_STAND_KP, ATLAS_STAND_KD = (3000.0, 300.0), (60.0, 10.0)     # (legs + back, arms + neck)
+ATLAS_STAND_AMP = (0.03, 0.1)                                        # target noise (rad), same classes
+
+
+def atlas_stiff_joints(joint_names):
+    """bool [nv - 6]: the joints that carry the body (legs, back) - stiff gains, small target noise - vs arms and neck"""
+    return np.array([("_leg_" in n) or n.startswith("back_") for n in joint_names[1:]])
+
+
+def atlas_standing_gains(joint_names):
+    """Config 5, "standing" regime: gains that hold the Atlas-like stand-in up (gravity stiffness about the ankles is
+    m g h ~ 1600 N m / rad, about the back ~ 200: kp 200 everywhere cannot)."""
+    stiff = atlas_stiff_joints(joint_names)
+    nv = 6 + len(stiff)
+    kp = np.zeros(nv, np.float32)
+    kd = np.zeros(nv, np.float32)
+    kp[6:] = np.where(stiff, ATLAS_STAND_KP[0], ATLAS_STAND_KP[1])
+    kd[6:] = np.where(stiff, ATLAS_STAND_KD[0], ATLAS_STAND_KD[1])
+    return kp, kd
+
+
+def atlas_standing_targets(n_envs, control_step, joint_names, seed0=77, env_offset=0, scale=1.0):
+    """Config 5, "standing" regime: zero pose + per-joint-class uniform noise, per-env seeded (same streams as atlas_targets)."""
+    stiff = atlas_stiff_joints(joint_names)
+    nq = 7 + len(stiff)
+    pt = np.zeros((n_envs, nq))
+    r = env_uniform(seed0 + env_offset + np.arange(n_envs), control_step, nq - 7)
+    pt[:, 7:] = scale * np.where(stiff, ATLAS_STAND_AMP[0], ATLAS_STAND_AMP[1]) * (2.0 * r - 1.0)
+    pt[:, 3] = 1.0
+    return pt
 
 
 def atlas_initial_state(n_envs, nq=37, nv=36, height=ATLAS_INIT_HEIGHT):
