@@ -191,6 +191,10 @@ class Recipe:
         self.config = config
         self.wl = workload
         self.per_env_maps = bool(per_env_maps) and config == 3
+        # solver settings of envs with redundant contact sets (rsb_set_solver_multi_contact: depth, light passes, freeze_after,
+        # stall_window).  Library default depth 3; the humanoid's feet also stand on two spheres of one edge, so config 5 uses
+        # depth 2 (tests/test_oracle_solver_heuristics.py pins exactly this setting on both config-5 populations)
+        self.multi_contact = (2 if config == 5 else 3, False, 0, 16)
         self.atlas_regime = atlas_regime
         self._terrain = {}
         if config == 5:
@@ -267,6 +271,7 @@ class Recipe:
             world.set_max_contacts(self.kmax)
         world.set_time_step(wl.DT)
         world.set_pd_gains(self.kp, self.kd)
+        world.set_solver_multi_contact(*self.multi_contact)
         if self.config == 3:
             maps, env_map = self.terrain(n, env_offset)
             if self.per_env_maps:
@@ -276,6 +281,7 @@ class Recipe:
 
     def setup_oracle(self, orc, n, env_offset):
         orc.p.kmax = self.kmax
+        orc.p.multi_depth, orc.p.multi_light, orc.p.multi_freeze_after, orc.p.multi_stall_window = (int(x) for x in self.multi_contact)
         if self.config == 3:
             wl = self.wl
             maps, env_map = self.terrain(n, env_offset)
@@ -586,6 +592,8 @@ def main():
                                    "sweep": "grouped (block Jacobi across limbs, Gauss-Seidel within a limb)",
                                    "friction_directions_lag_after_sweeps": args.freeze_after if args.freeze_after >= 0 else 6,
                                    "stagnation_exit": {"window": args.stall_window if args.stall_window >= 0 else 4, "factor": 0.5},
+                                   "multi_contact_envs": {"min_contacts_on_one_limb": recipe.multi_contact[0], "light_passes": bool(recipe.multi_contact[1]),
+                                                          "friction_directions_lag_after_sweeps": recipe.multi_contact[2], "stagnation_window": recipe.multi_contact[3]},
                                    "warm_start": True},
                 "self_collision": {"enabled": not args.no_self_collision, "candidate_pairs": int(len(world.self_collision_pairs()))},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",

@@ -210,6 +210,20 @@ int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor);
  * directions are kept like lagged ones for the rest of the solve.  1e-4 saved 19 % of the refinements in round 1 but put
  * the p99.9 deviation from the plain per-contact iteration at 1.9e-4 m/s instead of 7e-6, so it is off by default. */
 int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, double settle_tol);
+/* Redundant contact sets (not a RaiSim parameter).  An env that holds >= `depth` contacts on one limb in the current sub-step
+ * (the four spheres of a humanoid's foot, a quadruped on its belly) is a "multi-contact" env: the per-contact iteration
+ * converges linearly and slowly there, and the two accelerations above - tuned on the quadruped's usual one or two contacts
+ * per limb - cut it short (measured on the humanoid's standing population against the natural-map residual of the returned
+ * impulses: lagged directions make 10 % of the "converged" solves wrong by > 5e-3 relative, the 4-sweep stagnation window
+ * stops 8 % of them early; tests/test_oracle_solver_heuristics.py).  Such envs run with their own settings:
+ *   light_passes  != 0: friction directions of ALL contacts refreshed in the first pass of a sweep only (rounds 1-2;
+ *                 a third of the work per pass, 9 % of the standing solves unconverged after 150 sweeps); 0 (default): every
+ *                 pass refreshes its members' directions, as in every other env
+ *   freeze_after  sweeps before directions lag in such envs (default 0 = never)
+ *   stall_window  stagnation window in such envs (default 16; 0 = only max_iter caps the solve)
+ * depth: default 3; 2 also covers a foot standing on one of its edges (what the humanoid benchmark uses); 0 = no distinction
+ * (every env uses rsb_set_solver_friction_lag / rsb_set_solver_stagnation_exit). */
+int rsb_set_solver_multi_contact(rsb_world* w, int depth, int light_passes, int freeze_after, int stall_window);
 /* Early termination (not RaiSim behaviour; default OFF): in rsb_control_step / rsb_env_step - the calls that know which
  * collision primitives may touch the terrain - an env stops integrating at the sub-step in which any other primitive
  * touches; that sub-step and the rest of the control step are not integrated for it, the detected contacts are

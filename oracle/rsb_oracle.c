@@ -305,6 +305,7 @@ void orc_default_params(orc_params* p) {
   p->terrain_type = 0;
   p->ground_z = 0.0;
   p->hm_index = NULL;
+  p->multi_depth = 3; p->multi_light = 0; p->multi_freeze_after = 0; p->multi_stall_window = 16;
 }
 
 void orc_mass_matrix(const rsb_model_blob* m, const double* q, double* M) {
@@ -662,7 +663,6 @@ static double slip_dE(const slip_coef* k, double x, double y) {
  * (a minimum, not a maximum, nearby), |dtheta| <= 0.25 rad, and for steps above 0.02 rad no energy increase.
  * Returns 0 when rejected (the caller then runs the global search). */
 #define ORC_DEN_NEWTON 1e-3
-#define ORC_LIGHT_DEPTH 3
 #define ORC_POLISH_STEPS 2
 #ifdef ORC_STATS
 long orc_stats[8];   /* [0] newton accepted, [1..5] rejected at den0 / hp / |d| / den1 / E, [6] global searches */
@@ -1095,9 +1095,13 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       if (gpos[i] + 1 > gdepth) gdepth = gpos[i] + 1;
     }
     int converged = 0;
+    /* multi-contact envs (>= multi_depth contacts on one limb: redundant sets) run with their own lag / stagnation settings */
+    const int multi = p->multi_depth > 0 && gdepth >= p->multi_depth;
+    const int freeze_after = multi ? p->multi_freeze_after : p->freeze_after;
+    const int stall_window = multi ? p->multi_stall_window : p->stall_window;
     for (int it = 0; it < p->max_iter; ++it) {
       double err = 0, scale = 0;
-      const int lag = p->freeze_after > 0 && it >= p->freeze_after;
+      const int lag = freeze_after > 0 && it >= freeze_after;
       if (p->group_parallel) {
         /* Grouped sweep (what the device runs).  Contacts are grouped by the limb they sit on: the subtree hanging off the
          * base that holds the contact's body; contacts on the base itself form one more group.  Contacts of DIFFERENT limbs
@@ -1108,12 +1112,12 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
          * where the sequential sweep needs one evaluation per contact.  The fixed points are those of the per-contact
          * iteration; on the benchmark population the sweep count is that of the sequential sweep + 6 % and the deviation from
          * the plain iteration is unchanged (tests/test_oracle_solver_heuristics.py). */
-        /* Light passes: an env whose largest group has >= ORC_LIGHT_DEPTH members (many contacts on one limb: the four spheres
-         * of a humanoid's foot) refreshes the friction directions of ALL its contacts in pass 0, from the impulses the sweep
-         * starts with; the later passes keep the directions and only re-solve magnitudes (a contact without a usable direction
-         * runs the global search).  Same sweep counts there (measured on the Atlas-like workload: 9.95 vs 9.95), and a pass
-         * without a direction refinement is a third of the work on the device.  group_parallel = 2 forces it for every env. */
-        const int light = p->group_parallel == 2 || gdepth >= ORC_LIGHT_DEPTH;
+        /* Light passes (rounds 1-2; now opt-in, orc_params::multi_light): a multi-contact env refreshes the friction directions
+         * of ALL its contacts in pass 0, from the impulses the sweep starts with; the later passes keep the directions and only
+         * re-solve magnitudes (a contact without a usable direction runs the global search).  A third of the work per pass on
+         * the device - and, measured in round 3 on the standing humanoid, 9 % of the solves unconverged after 150 sweeps where
+         * refreshing inside every pass leaves 2 % (see orc_params).  group_parallel = 2 forces it for every env. */
+        const int light = p->group_parallel == 2 || (multi && p->multi_light);
         for (int kpos = 0; kpos < gdepth; ++kpos) {
           double lam0[MAXK][3];
           for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam0[i][r] = lam[i][r];
@@ -1185,7 +1189,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         best_rel = rel;
         for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam_best[i][r] = lam[i][r];
       }
-      if (p->stall_window > 0 && (it + 1) % p->stall_window == 0) {
+      if (stall_window > 0 && (it + 1) % stall_window == 0) {
         if (best_cur > p->stall_factor * best_prev) break;
         best_prev = best_cur; best_cur = 1e300;
       }

@@ -65,6 +65,19 @@ typedef struct orc_params {
   /* terrain curricula (the device's rsb_set_heightmaps): orc_step_batch lets env e stand on map hm_index[e] of the
    * [n_maps][ys][xs] array hm_heights (NULL = every env on map 0); single-env entry points ignore it */
   const int32_t* hm_index;
+  /* Redundant contact sets.  An env whose largest group (contacts on one limb) has >= multi_depth members - the four spheres of
+   * a humanoid's foot, a quadruped lying on its belly - is a "multi-contact" env: the per-contact iteration converges linearly
+   * and slowly there (redundant sticking contacts), and the accelerations tuned on the quadruped's usual contact sets (one or
+   * two contacts per limb) cut it short.  Measured on the Atlas-like standing population against the natural-map residual of
+   * the returned impulses (tests/test_oracle_solver_heuristics.py): lagged directions make 10 % of the "converged" solves wrong
+   * by > 5e-3 relative, light passes leave 9 % unconverged after 150 sweeps where the plain iteration leaves 2 %, and the
+   * 4-sweep stagnation window stops 8 % early.  So such envs get their own settings:
+   *   multi_light        1 = light passes (directions of ALL contacts refreshed in pass 0 only; rounds 1-2), 0 = every pass
+   *                      refreshes its members' directions (default)
+   *   multi_freeze_after sweeps before directions lag in such envs (default 0 = never)
+   *   multi_stall_window stagnation window in such envs (default 16; 0 = no stagnation exit)
+   * multi_depth = 0 switches the distinction off (every env uses freeze_after / stall_window; no light passes). */
+  int32_t multi_depth, multi_light, multi_freeze_after, multi_stall_window;
 } orc_params;
 
 /* collision ids reported for the two entries of a self-collision (RaiSim lists it once per body): primitive id | flag */

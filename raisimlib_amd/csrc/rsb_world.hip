@@ -83,6 +83,7 @@ struct rsb_world {
   double dt = 0.0025, gravity[3] = {0, 0, -9.81}, mu = 0.8, erp = 0.0;
   double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
   int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
+  int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
   float hm_max = 0.f;
@@ -465,6 +466,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.mu = (float)w->mu; a.erp = (float)w->erp;
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
   a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
+  a.multi_depth = w->multi_depth; a.multi_light = w->multi_light; a.multi_freeze_after = w->multi_freeze_after; a.multi_stall_window = w->multi_stall_window;
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {
@@ -740,6 +742,11 @@ int rsb_set_solver_stagnation_exit(rsb_world* w, int window, double factor) {
 int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, double settle_tol) {
   if (!w || freeze_after < 0 || !(settle_tol >= 0.0)) { rsb::set_error("rsb_set_solver_friction_lag: freeze_after >= 0, settle_tol >= 0"); return RSB_E_INVALID; }
   w->freeze_after = freeze_after; w->refine = refine != 0; w->settle_tol = settle_tol;
+  return RSB_OK;
+}
+int rsb_set_solver_multi_contact(rsb_world* w, int depth, int light_passes, int freeze_after, int stall_window) {
+  if (!w || depth < 0 || freeze_after < 0 || stall_window < 0) { rsb::set_error("rsb_set_solver_multi_contact: depth, freeze_after, stall_window >= 0"); return RSB_E_INVALID; }
+  w->multi_depth = depth; w->multi_light = light_passes != 0; w->multi_freeze_after = freeze_after; w->multi_stall_window = stall_window;
   return RSB_OK;
 }
 int rsb_set_early_termination(rsb_world* w, int on) {

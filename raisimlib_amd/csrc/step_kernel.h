@@ -1417,7 +1417,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
 
         // position of the own contact within its group, and the wave's largest group (= passes per sweep)
         int gpos = 0, gdw = 1;
-        bool light = false;   // light passes (oracle: ORC_LIGHT_DEPTH): an env with >= kLightDepth contacts on one limb refreshes ALL its directions in pass 0
+        bool light = false;   // light passes (oracle: multi_light; opt-in): a multi-contact env refreshes ALL its directions in pass 0 only
+        int fa_env = freeze_after, sw_env = stall_window;   // this env's lag / stagnation settings (multi-contact envs have their own)
         {
           static_for<0, KMAX / 4>([&](auto bc) {
             constexpr int j0 = 4 * decltype(bc)::value;
@@ -1430,7 +1431,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             }
           });
           const int gd = row_max_i32(isc ? gpos + 1 : 1);   // the env's largest group (contact lanes sit in the env's first row)
-          light = gd >= kLightDepth;
+          // multi-contact env (oracle: `multi`): >= multi_depth contacts on one limb - a redundant set, which the per-contact
+          // iteration solves slowly and the quadruped-tuned accelerations cut short (rsb_set_solver_multi_contact)
+          const bool multi = (ag.multi_depth > 0) & (gd >= ag.multi_depth);
+          light = multi & (ag.multi_light != 0);
+          fa_env = multi ? ag.multi_freeze_after : freeze_after;
+          sw_env = multi ? ag.multi_stall_window : stall_window;
           gdw = env_groups_max<LPE>(gd);
         }
 
@@ -1523,7 +1529,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // Every branch costs a lone wave ~20-45 cycles taken or not (profiles/r02_ubench_lone_wave_latency.txt), i.e. as much
         // as 5-10 VALU instructions: the pass is written with selects, the branches that remain guard work that is rare and large.
         for (int it = 0; it < max_iter; ++it) {
-          const bool lag = freeze_after > 0 && it >= freeze_after;   // lagged directions: a usable direction of this solve is no longer refreshed
+          const bool lag = (fa_env > 0) & (it >= fa_env);   // lagged directions: a usable direction of this solve is no longer refreshed
           float err = 0.f;
           for (int kp = 0; kp < gdw; ++kp) {
             const bool mine = isc & !done & (gpos == kp);
@@ -1612,9 +1618,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             best_rel = better ? rel : best_rel;
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) lam_best[rr] = better ? lam[rr] : lam_best[rr];
             best_cur = cont ? fminf(best_cur, rel) : best_cur;
-            const bool wtick = cont & (stall_window > 0);
+            const bool wtick = cont & (sw_env > 0);
             wcount += wtick ? 1 : 0;
-            const bool wfull = wtick & (wcount == stall_window);
+            const bool wfull = wtick & (wcount == sw_env);
             const bool stalled = wfull & (best_cur > stall_factor * best_prev);
             best_prev = wfull ? best_cur : best_prev;
             best_cur = wfull ? 3e38f : best_cur;

@@ -23,7 +23,6 @@ constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
 constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
-constexpr int kLightDepth = 3;        // == ORC_LIGHT_DEPTH
 constexpr int kSelfA = 0x10000;       // collision id flags of the two entries of a self-collision (== RSB_CONTACT_SELF_A / _B, ORC_SELF_A / _B)
 constexpr int kSelfB = 0x20000;
 constexpr int kSelfBatch = 5;          // passes per batch of the self-collision sweep
@@ -123,6 +122,8 @@ struct StepArgs {
   float ground_z, hm_x0, hm_y0, hm_dx, hm_dy, hm_inv_dx, hm_inv_dy, hm_max;
   LdsLayout L;
   float* tau_out;              // [N, nv] optional: the generalized force the actuators applied in the last sub-step (rsb_enable_generalized_force_output)
+  // multi-contact envs (>= multi_depth contacts on one limb in this sub-step: redundant sets; rsb_set_solver_multi_contact)
+  int multi_depth, multi_light, multi_freeze_after, multi_stall_window;
 };
 
 }  // namespace rsbk

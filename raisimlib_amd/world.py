@@ -217,6 +217,11 @@ class BatchedWorld:
         check(self.L.rsb_set_solver_friction_lag(self.handle, int(freeze_after), int(bool(refine)), float(settle_tol)),
               "rsb_set_solver_friction_lag")
 
+    def set_solver_multi_contact(self, depth=3, light_passes=False, freeze_after=0, stall_window=16):
+        """Solver settings of envs with >= depth contacts on one limb (redundant sets; see rsb.h). depth 0 = no distinction."""
+        check(self.L.rsb_set_solver_multi_contact(self.handle, int(depth), int(bool(light_passes)), int(freeze_after), int(stall_window)),
+              "rsb_set_solver_multi_contact")
+
     def set_early_termination(self, on=True):
         check(self.L.rsb_set_early_termination(self.handle, 1 if on else 0), "rsb_set_early_termination")
 
