@@ -1053,8 +1053,20 @@ int rsb_obs_dim(const rsb_world* w, int n_force_slots) {
 }
 int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, int n_force_slots, int space) {
   if (!w || !out || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) { rsb::set_error("rsb_gather_obs: bad argument"); return RSB_E_INVALID; }
-  if (space != RSB_DEVICE) { rsb::set_error("rsb_gather_obs: out must be a device pointer"); return RSB_E_INVALID; }
+  if (space != RSB_DEVICE && space != RSB_HOST) { rsb::set_error("rsb_gather_obs: space must be RSB_DEVICE or RSB_HOST"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));
+  if (space == RSB_HOST) {   // slow path (C hosts without a device allocator, tests): gathered on the device, then copied out
+    const size_t local = (size_t)w->N * (w->blob.nq + w->blob.nv + 3 * n_force_slots);
+    if (w->obs_local_cap < local) {
+      if (w->d_obs_local) HIP_TRY(hipFree(w->d_obs_local));
+      w->d_obs_local = nullptr; w->obs_local_cap = 0;
+      HIP_TRY(hipMalloc(&w->d_obs_local, local * sizeof(float)));
+      w->obs_local_cap = local;
+    }
+    const int st = rsb_gather_obs(w, w->d_obs_local, collision_indices, n_force_slots, RSB_DEVICE);
+    if (st != RSB_OK) return st;
+    return copy_out(w, out, w->d_obs_local, local * sizeof(float), RSB_HOST);
+  }
   const int32_t* didx = nullptr;
   if (collision_indices && n_force_slots > 0) {
     int st = upload_obs_idx(w, collision_indices, n_force_slots);

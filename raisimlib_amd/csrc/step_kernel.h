@@ -707,6 +707,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           RSB_UNROLL for (int i = 0; i < 9; ++i) E9[i] = MF[8 + i];
         }
       }
+      RSB_STAMP(10)
       __syncthreads();   // BODY[0] (written by lane 0 above) is visible
       for (int lv = 1; lv < depth; ++lv) {
         if (mylev == lv) {
@@ -738,6 +739,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
         __syncthreads();
       }
+      RSB_STAMP(11)
       if (isbody) {
         body_inertia(Rb, rb, Vb, Ab, MF, dt, bI10, bZ);
         // actuation (oracle: actuation_impl): implicit ("stable") PD = position error at q + dt u, plus the joint-space
@@ -914,6 +916,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       __syncthreads();   // the scratch is free again (the up pass reuses it)
     }
     if (nc > kmax) { nc = kmax; flag |= 1; }
+    RSB_STAMP(12)
     // ---- self-collision (oracle: "Self-collision" in step_impl): sphere x sphere over the candidate pairs (primitives of two
     // bodies that are not parent and child), lane = pair.  A hit takes TWO contact slots, one per body with opposite frames
     // (what RaiSim's contact list holds); the Delassus phase folds the pair into ONE solver contact (J = J_i - J_j).
@@ -987,6 +990,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     // joint limits (oracle: "joint limits" in step_impl): a joint outside [q_lower, q_upper] adds one unilateral row
     // s * qdot >= 0, carried through the solver as a contact with empty tangential rows; slots after the real contacts
     nc_real = nc;
+    RSB_STAMP(13)
     if (!dead) {
       for (int b0 = 1; b0 < nb; b0 += LPE) {
         const int b = b0 + s;
@@ -1069,6 +1073,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       __syncthreads();
     }
     if (depth <= 1) __syncthreads();
+    RSB_STAMP(14)
     // base (every lane): gather the bodies hanging off the base, Cholesky in gv order (lin, ang), W_b base part
     float C[21], idg[6], wbb[6];
     {

