@@ -199,14 +199,20 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   L.q = take(b.nq < 8 ? 8 : b.nq); L.u = take(b.nv < 8 ? 8 : b.nv);
   L.pt = take(b.nq); L.dtg = take(b.nv); L.tf = take(b.nv < 8 ? 8 : b.nv);
   L.body = take(b.nb * rsbk::kBodySlot);
-  L.fact = take(b.nb * rsbk::kFactSlot);
+  const bool tri = kcap > 8;   // packed lower-triangular Delassus blocks (step_kernel.h: TRI); the up pass's factors then alias them too
+  if (!tri) L.fact = take(b.nb * rsbk::kFactSlot);
   L.wb = take(b.nv);
   L.con = take(kcap * rsbk::kConSlot);
   L.wc = take(3 * kcap * cw);
   L.cv = take(3 * kcap);
   L.gstride = 4 * kcap + 4;   // 3x3 blocks on a 4-float pitch, +4 staggers the banks of consecutive rows
   // the up pass's [nb][28] hand-over slots and the height-map narrow phase's scratch alias the Delassus rows
-  L.g = take(std::max({3 * kcap * L.gstride, b.nb * rsbk::kUpSlot, (rsbk::kHmRec + 4) * rsbk::kHmSlots + RSB_MAX_COLLISIONS}));
+  // (packed layout: [hand-over slots | joint factors] of the up pass - the factors are last read by the contact columns, before the
+  // Delassus phase writes its blocks over both)
+  const int gsize = tri ? (kcap * (kcap + 1) / 2) * 12 : 3 * kcap * L.gstride;
+  const int upsize = b.nb * rsbk::kUpSlot + (tri ? b.nb * rsbk::kFactSlot : 0);
+  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 4) * rsbk::kHmSlots + RSB_MAX_COLLISIONS}));
+  if (tri) L.fact = L.g + b.nb * rsbk::kUpSlot;
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
   L.warm = take(6 * b.ncol);

@@ -484,6 +484,28 @@ __device__ __forceinline__ void body_inertia(const float* Rb, const float* rb, c
   RSB_UNROLL for (int i = 0; i < 3; ++i) { Zout[i] = dt * (IAc[i] + n1[i] + n2[i]); Zout[3 + i] = dt * (IAc[3 + i] + n3[i]); }
 }
 
+// ---- Delassus storage of the large-contact classes (KMAX > 8): only the blocks (i, j) with i >= j exist, packed at
+// ((i (i + 1)) / 2 + j) * 12 floats (3 rows on a 4-float pitch): 1632 floats at KMAX 16 where the square layout takes 3264 -
+// what lets a 31-body humanoid run two envs per wave (LPE 32).  tri_load returns M[ra][rb] = G[3 a + ra][3 b + rb] for any
+// (a, b): the stored block or its transpose (G is symmetric); tri_store writes it back the same way.
+__device__ __forceinline__ int tri_off(int hi, int lo) { return ((hi * (hi + 1)) / 2 + lo) * 12; }
+__device__ __forceinline__ void tri_load(const float* G, int a, int b, float (&M)[3][3]) {
+  const bool tr = b > a;
+  const float* p = G + tri_off(tr ? b : a, tr ? a : b);
+  float t[3][4];
+  RSB_UNROLL for (int r = 0; r < 3; ++r) ld4(p + 4 * r, t[r]);
+  RSB_UNROLL for (int r = 0; r < 3; ++r)
+    RSB_UNROLL for (int c = 0; c < 3; ++c) M[r][c] = tr ? t[c][r] : t[r][c];
+}
+__device__ __forceinline__ void tri_store(float* G, int a, int b, const float (&M)[3][3]) {
+  const bool tr = b > a;
+  float* p = G + tri_off(tr ? b : a, tr ? a : b);
+  RSB_UNROLL for (int r = 0; r < 3; ++r) {
+    const float row[4] = {tr ? M[0][r] : M[r][0], tr ? M[1][r] : M[r][1], tr ? M[2][r] : M[r][2], 0.f};
+    st4(p + 4 * r, row);
+  }
+}
+
 // ------------------------------------------------------------------------------- the kernel
 // LPE : lanes per env.  KMAX : contact capacity.  CL : model class, 1 = fixed-base systems (their contact blocks get a compliance, see the Delassus phase), 0 = floating base.
 // ML : body-level capacity (>= depth-1).  PROF : compile the cycle stamps / contact-problem dump / LDS poisoning of the
@@ -495,6 +517,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   long long t_entry = 0; if (PROF) t_entry = clock64();
   constexpr int EPW = 64 / LPE;
+  constexpr bool TRI = KMAX > 8;    // packed lower-triangular Delassus blocks (see tri_off); the quadruped classes keep the square layout
   const int lane = threadIdx.x;
   const int el = lane / LPE;
   const int s = lane - el * LPE;
@@ -594,7 +617,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   // does not define is multiplied by a zero impulse change, so it only has to be finite, never NaN bit patterns)
   {
     const float z4[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 4 * s; i < 3 * KMAX * L.gstride; i += 4 * LPE) st4(G + i, z4);
+    const int gfloats = TRI ? tri_off(KMAX, 0) : 3 * KMAX * L.gstride;
+    for (int i = 4 * s; i < gfloats; i += 4 * LPE) st4(G + i, z4);
     for (int i = s; i < nwarm; i += LPE) WARM[i] = 0.f;
   }
   float c16, s16;  // this lane's round-0 candidate direction of the slip search
@@ -1253,11 +1277,19 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
               RSB_UNROLL for (int cc = 0; cc < 3; ++cc) acc[3 * rr + cc] += av[rr] * bv[cc];
           }
           if (i == j && CON[i * kConSlot + 15] != 0.f) { acc[0] = 1.f; acc[4] = 1.f; }   // joint-limit row: dummy tangential diagonal
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+          if constexpr (TRI) {   // i <= j: the stored block is (j, i), rows = axes of contact j
+            float* bp = G + tri_off(j, i);
             RSB_UNROLL for (int cc = 0; cc < 3; ++cc) {
-              G[(3 * i + rr) * GS + 4 * j + cc] = acc[3 * rr + cc];   // 3x3 blocks on a 4-float pitch (16-B aligned rows of a block)
-              G[(3 * j + cc) * GS + 4 * i + rr] = acc[3 * rr + cc];
+              const float row[4] = {acc[cc], acc[3 + cc], acc[6 + cc], 0.f};
+              st4(bp + 4 * cc, row);
             }
+          } else {
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+              RSB_UNROLL for (int cc = 0; cc < 3; ++cc) {
+                G[(3 * i + rr) * GS + 4 * j + cc] = acc[3 * rr + cc];   // 3x3 blocks on a 4-float pitch (16-B aligned rows of a block)
+                G[(3 * j + cc) * GS + 4 * i + rr] = acc[3 * rr + cc];
+              }
+          }
           if (i == j) {
             float gi[12];
             inv3(acc, gi);
@@ -1272,13 +1304,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // is rank deficient; the same small compliance as for a self-collision (whose fold below adds it for those)
         if (s < nc && __float_as_int(CON[s * kConSlot + 11]) < kSelfA) {
           float acc[9], gi[12];
+          float* dg = TRI ? G + tri_off(s, s) : G + 3 * s * GS + 4 * s;     // the diagonal block's rows, dgs floats apart
+          const int dgs = TRI ? 4 : GS;
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
             float g4[4];
-            ld4(G + (3 * s + rr) * GS + 4 * s, g4);
+            ld4(dg + rr * dgs, g4);
             acc[3 * rr] = g4[0]; acc[3 * rr + 1] = g4[1]; acc[3 * rr + 2] = g4[2];
           }
           const float reg = kSelfReg * (acc[0] + acc[4] + acc[8]) * (1.0f / 3.0f);
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { acc[4 * rr] += reg; G[(3 * s + rr) * GS + 4 * s + rr] = acc[4 * rr]; }
+          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { acc[4 * rr] += reg; dg[rr * dgs + rr] = acc[4 * rr]; }
           inv3(acc, gi);
           gi[9] = gi[10] = gi[11] = 0.f;
           stv<3>(GINV + 12 * s, gi);
@@ -1294,6 +1328,41 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           if (!__any(prim)) continue;
           const int sb = sa + 1;
           const float z4[4] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (TRI) {
+            // packed storage: lane k owns the blocks (sa, k) and (sb, k) of its contact k; the lane of contact sa owns the diagonal
+            if (prim && s < nc) {
+              float A[3][3], B[3][3];
+              const float Z[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+              if (s != sa && s != sb) {
+                tri_load(G, sa, s, A); tri_load(G, sb, s, B);
+                RSB_UNROLL for (int r = 0; r < 3; ++r) RSB_UNROLL for (int c = 0; c < 3; ++c) A[r][c] += B[r][c];
+                tri_store(G, sa, s, A); tri_store(G, sb, s, Z);
+              } else if (s == sa) {
+                float X[3][3], D[3][3];
+                tri_load(G, sa, sa, A); tri_load(G, sb, sb, B); tri_load(G, sb, sa, X);
+                RSB_UNROLL for (int r = 0; r < 3; ++r) RSB_UNROLL for (int c = 0; c < 3; ++c) D[r][c] = A[r][c] + B[r][c] + X[r][c] + X[c][r];
+                const float ju = SELFT[4 * sa + 3] + SELFT[4 * sb + 3];   // approach speed of the two bodies' points
+                float m4[4];
+                ld4(SELFT + 4 * sa, m4);
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { CV[3 * sa + rr] += CV[3 * sb + rr]; CV[3 * sb + rr] = 0.f; }
+                if (m4[1] > 0.f && ju < -m4[2]) CV[3 * sa + 2] += m4[1] * ju;
+                const float reg = (CL != 0 ? 2.f : 1.f) * kSelfReg * (D[0][0] + D[1][1] + D[2][2]) * (1.0f / 3.0f);   // (oracle: ORC_SELF_REG, see below)
+                RSB_UNROLL for (int rr = 0; rr < 3; ++rr) D[rr][rr] += reg;
+                const float I3[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
+                tri_store(G, sa, sa, D); tri_store(G, sb, sa, Z); tri_store(G, sb, sb, I3);
+                float acc[9], gi[12];
+                RSB_UNROLL for (int r = 0; r < 3; ++r) RSB_UNROLL for (int c = 0; c < 3; ++c) acc[3 * r + c] = D[r][c];
+                inv3(acc, gi);
+                gi[9] = gi[10] = gi[11] = 0.f;
+                stv<3>(GINV + 12 * sa, gi);
+                RSB_UNROLL for (int q2 = 0; q2 < 12; ++q2) gi[q2] = 0.f;
+                gi[0] = gi[4] = gi[8] = 1.f;
+                stv<3>(GINV + 12 * sb, gi);
+              }
+            }
+            __syncthreads();
+            continue;
+          }
           if (prim && s < nc) {       // rows: lane = column block
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
               float ga[4], gb[4];
@@ -1345,7 +1414,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const int n3 = 3 * nc_real;
         a.dbg[0] = (float)nc_real;
         for (int i = 0; i < n3; ++i)
-          for (int j = 0; j < n3; ++j) a.dbg[1 + i * n3 + j] = G[i * GS + 4 * (j / 3) + (j % 3)];
+          for (int j = 0; j < n3; ++j)
+            a.dbg[1 + i * n3 + j] = !TRI ? G[i * GS + 4 * (j / 3) + (j % 3)]
+                                          : (i / 3 >= j / 3 ? G[tri_off(i / 3, j / 3) + 4 * (i % 3) + (j % 3)] : G[tri_off(j / 3, i / 3) + 4 * (j % 3) + (i % 3)]);
         for (int i = 0; i < n3; ++i) a.dbg[1 + n3 * n3 + i] = CV[i];
       }
       long long t_gs0 = 0, tz0 = 0; if (PROF && a.prof) t_gs0 = clock64();
@@ -1375,7 +1446,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         if (isc) {
           RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
             float g4[4];
-            ld4(G + (3 * s + rr) * GS + 4 * s, g4);      // blocks sit on a 4-float pitch: one 16-byte read per row
+            ld4(TRI ? G + tri_off(s, s) + 4 * rr : G + (3 * s + rr) * GS + 4 * s, g4);      // blocks sit on a 4-float pitch: one 16-byte read per row
             Gii[3 * rr] = g4[0]; Gii[3 * rr + 1] = g4[1]; Gii[3 * rr + 2] = g4[2];
           }
           ldv<3>(GINV + 12 * s, Ginv);
@@ -1407,7 +1478,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const float alpha_init = ag.alpha_init, alpha_min = ag.alpha_min, alpha_decay = ag.alpha_decay, threshold = ag.threshold;
         const float stall_factor = ag.stall_factor;
         const int max_iter = ag.max_iter, section_rounds = ag.section_rounds, stall_window = ag.stall_window;
-        const int freeze_after = ag.freeze_after, refine = ag.refine;
+        const int freeze_after = ag.freeze_after, refine = ag.refine, multi_fa = ag.multi_freeze_after;
         // per-solve constants of the own contact: den(d) = a0 + a1 x + a2 y; n01.. hold mu * G_tt (see slip_prepare)
         SlipCoef sc;
         sc.a0 = Gii[8]; sc.a1 = mu * Gii[6]; sc.a2 = mu * Gii[7];
@@ -1423,7 +1494,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // position of the own contact within its group, and the wave's largest group (= passes per sweep)
         int gpos = 0, gdw = 1;
         bool light = false;   // light passes (oracle: multi_light; opt-in): a multi-contact env refreshes ALL its directions in pass 0 only
-        int fa_env = freeze_after, sw_env = stall_window;   // this env's lag / stagnation settings (multi-contact envs have their own)
+        bool multi = false;   // multi-contact env (>= multi_depth contacts on one limb): its own lag / stagnation settings
+        int sw_env = stall_window > 0 ? stall_window : -1;   // this env's stagnation window (-1: the sweep counter never gets there = no exit)
         {
           static_for<0, KMAX / 4>([&](auto bc) {
             constexpr int j0 = 4 * decltype(bc)::value;
@@ -1438,10 +1510,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           const int gd = row_max_i32(isc ? gpos + 1 : 1);   // the env's largest group (contact lanes sit in the env's first row)
           // multi-contact env (oracle: `multi`): >= multi_depth contacts on one limb - a redundant set, which the per-contact
           // iteration solves slowly and the quadruped-tuned accelerations cut short (rsb_set_solver_multi_contact)
-          const bool multi = (ag.multi_depth > 0) & (gd >= ag.multi_depth);
+          multi = (ag.multi_depth > 0) & (gd >= ag.multi_depth);
           light = multi & (ag.multi_light != 0);
-          fa_env = multi ? ag.multi_freeze_after : freeze_after;
-          sw_env = multi ? ag.multi_stall_window : stall_window;
+          sw_env = multi ? (ag.multi_stall_window > 0 ? ag.multi_stall_window : -1) : sw_env;
           gdw = env_groups_max<LPE>(gd);
         }
 
@@ -1449,22 +1520,35 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // row).  Contacts 0-3 run as one straight block whatever the count (a slot its env does not use carries x = 0 against a
         // finite, zero-initialised block) on coupling blocks held in registers; contacts 4-7 behind one nested scalar test each
         // (the usual hard env has five), the rest in blocks of four.
+        // rows of the own contact (sm) against contact k: the square layout reads them in place; the packed layout reads the stored
+        // block (max, min) and transposes it in registers when k > sm (six selects per block, once per solve)
+        const int sm = min(s, KMAX - 1);
+        auto coupling = [&](int k, float (&g)[3][4]) {
+          if constexpr (TRI) {
+            const bool tr = k > sm;
+            const float* bp = G + tri_off(tr ? k : sm, tr ? sm : k);
+            float t[3][4];
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(bp + 4 * rr, t[rr]);
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) {
+              RSB_UNROLL for (int cc = 0; cc < 3; ++cc) g[rr][cc] = tr ? t[cc][rr] : t[rr][cc];
+              g[rr][3] = 0.f;
+            }
+          } else {
+            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * k, g[rr]);
+          }
+        };
         float g0[4][3][4];            // coupling blocks with contacts 0-3: constant during the solve, read from LDS once
-        RSB_UNROLL for (int k = 0; k < 4; ++k)
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * k, g0[k][rr]);
+        RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(k, g0[k]);
         float g1[4][3][4];            // ... and with contacts 4-7 (the hard envs of the tail have five contacts: no LDS round trip in their passes)
-        RSB_UNROLL for (int k = 0; k < 4; ++k)
-          RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (4 + k), g1[k][rr]);
+        RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(4 + k, g1[k]);
         float g2[KMAX > 8 ? 4 : 1][3][4];   // ... and, in the large-model classes, with contacts 8-11 (a collapsed humanoid)
         if constexpr (KMAX > 8) {
-          RSB_UNROLL for (int k = 0; k < 4; ++k)
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (8 + k), g2[k][rr]);
+          RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(8 + k, g2[k]);
         }
         float gbuf[2][4][3][4];       // contacts 12.. : fetched per pass
         auto load_block = [&](auto bc) {
           constexpr int b = decltype(bc)::value;
-          RSB_UNROLL for (int k = 0; k < 4; ++k)
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * (4 * b + k), gbuf[b & 1][k][rr]);
+          RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(4 * b + k, gbuf[b & 1][k]);
         };
         auto exchange = [&](const float (&x)[3], float& emax) {
           auto one = [&](auto jc) {
@@ -1534,7 +1618,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // Every branch costs a lone wave ~20-45 cycles taken or not (profiles/r02_ubench_lone_wave_latency.txt), i.e. as much
         // as 5-10 VALU instructions: the pass is written with selects, the branches that remain guard work that is rare and large.
         for (int it = 0; it < max_iter; ++it) {
-          const bool lag = (fa_env > 0) & (it >= fa_env);   // lagged directions: a usable direction of this solve is no longer refreshed
+          // lagged directions: a usable direction of this solve is no longer refreshed.  Two wave-uniform tests picked per env by a
+          // lane mask (scalar work: the sweep loop has no vector register to spare)
+          const bool lag = multi ? (multi_fa > 0 && it >= multi_fa) : (freeze_after > 0 && it >= freeze_after);
           float err = 0.f;
           for (int kp = 0; kp < gdw; ++kp) {
             const bool mine = isc & !done & (gpos == kp);
@@ -1623,9 +1709,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             best_rel = better ? rel : best_rel;
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) lam_best[rr] = better ? lam[rr] : lam_best[rr];
             best_cur = cont ? fminf(best_cur, rel) : best_cur;
-            const bool wtick = cont & (sw_env > 0);
-            wcount += wtick ? 1 : 0;
-            const bool wfull = wtick & (wcount == sw_env);
+            wcount += cont ? 1 : 0;
+            const bool wfull = cont & (wcount == sw_env);
             const bool stalled = wfull & (best_cur > stall_factor * best_prev);
             best_prev = wfull ? best_cur : best_prev;
             best_cur = wfull ? 3e38f : best_cur;

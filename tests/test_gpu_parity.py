@@ -143,7 +143,31 @@ def test_self_collision_parity(anymal, lpe, z):
     # impulses: two bodies fewer than three joints apart cannot move relative to each other in every direction; the impulse
     # component along such a direction does nothing and is only as well defined as the block's 1e-4 compliance makes it
     imp_err = np.array([np.abs(dev["con"][e][:ref["n_contacts"][e]]["impulse"] - rc[e][:ref["n_contacts"][e]]["impulse"]).max(initial=0) for e in np.nonzero(conv)[0]])
-    assert np.median(imp_err) < 1e-5 and np.percentile(imp_err, 90) < 1e-3 and imp_err.max() < 0.3
+    # (worst env measured 0.85 N s since the contorted robots' redundant sets iterate longer - 16-sweep stagnation window -: more
+    #  sweeps move the impulses further along those null directions, the velocities they produce agree: eu above)
+    assert np.median(imp_err) < 1e-5 and np.percentile(imp_err, 90) < 1e-3 and imp_err.max() < 3.0
+
+
+@pytest.mark.parametrize("lpe", [16, 32])
+def test_self_collision_parity_with_16_contact_slots(anymal, lpe):
+    """The large-contact kernel classes (kmax 16) keep the Delassus blocks in a packed lower-triangular layout and fold a
+    self-collision's two entries there: the contorted robots on the ground again, with room for every contact they make."""
+    gc, gv = _contorted_states(512, 77 + lpe, (0.25, 0.5))
+    kp, kd = workload.anymal_gains()
+    dev, ref, o = run_one_step(anymal, gc, gv, gc, kp, kd, lpe=lpe, kmax=16)
+    rc = ref["contacts"]
+    valid = np.arange(rc.shape[1])[None, :] < ref["n_contacts"][:, None]
+    is_self = valid & (rc["collision"] >= 0x10000)
+    assert is_self.any(axis=1).sum() > 150 and (ref["n_contacts"] > 8).sum() > 20      # self-collisions, and contact sets the kmax-8 classes cannot hold
+    assert np.array_equal(dev["cnt"], ref["n_contacts"]) and np.array_equal((dev["flags"] & 1), (ref["flags"] & 1))
+    for e in range(len(gc)):
+        n = ref["n_contacts"][e]
+        assert np.array_equal(dev["con"][e][:n]["collision"], rc[e][:n]["collision"]), e
+    conv = ((ref["flags"] | dev["flags"]) & 4) == 0
+    assert conv.mean() > 0.75
+    eu = np.abs(dev["u"] - ref["u"]).max(axis=1) / (1 + np.abs(ref["u"]).max(axis=1))
+    assert np.median(eu[conv]) < 1e-6 and np.percentile(eu[conv], 99) < 5e-4 and eu[conv].max() < 5e-3, (np.percentile(eu[conv], 99), eu[conv].max())
+    assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all() and np.all(eu[~conv] < 0.5)
 
 
 def test_self_collision_can_be_switched_off_and_pairs_ignored(anymal):
