@@ -79,6 +79,9 @@ def parse():
                          "config 5 standing: a SCALE on the per-class amplitudes 0.03 / 0.1 rad, default 1)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
+    ap.add_argument("--obs-exchange", choices=("rccl", "peer"), default="rccl",
+                    help="how the per-control-step obs block reaches the other ranks: 'rccl' = all-gather (default until a multi-GPU box has "
+                         "measured both), 'peer' = peer-mapped buffers written by the step kernel's epilogue (rsb_obs_peer_*: no collective, no copy kernel)")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="plumbing check without GPUs: the ranks rendezvous on gloo, all-gather a host obs block per step and "
                          "print the contract line with dry_run=true (no device world, no physics; value is not a measurement)")
@@ -439,8 +442,11 @@ def main():
     obs_dim = world.obs_dim(len(feet))
     # obs block of this rank and the gathered block of all ranks (raisimlib_amd/dist.py); with --overlap-collective
     # double-buffered, so that the all-gather of control step k (RCCL, its own stream) overlaps the kernel of step k+1
-    from raisimlib_amd.dist import ObsGatherer
-    gath = ObsGatherer(N, obs_dim, dev, overlap=args.overlap_collective, force=args.force_collective)
+    from raisimlib_amd.dist import ObsGatherer, PeerObsGatherer
+    if args.obs_exchange == "peer":
+        gath = PeerObsGatherer(world, np.asarray(feet, np.int32), force=args.force_collective)
+    else:
+        gath = ObsGatherer(N, obs_dim, dev, overlap=args.overlap_collective, force=args.force_collective)
     obs_b, nbuf = gath.local_bufs, gath.nbuf
     feet_idx = np.asarray(feet, np.int32)
     reset = not args.no_reset
@@ -451,7 +457,7 @@ def main():
 
     # one foreign call per control step (rsb_control_step); the step kernel's launches are bracketed by HIP events inside
     # the library (ring of event pairs on the launch stream, read back after the fact, no per-launch synchronisation)
-    step_fns = [world.control_step_plan(workload.SUBSTEPS, o.data_ptr(), feet_idx, feet_idx if reset else None,
+    step_fns = [world.control_step_plan(workload.SUBSTEPS, o.data_ptr() if o is not None else 0, feet_idx, feet_idx if reset else None,
                                         gc0_d.data_ptr() if reset else 0, gv0_d.data_ptr() if reset else 0, N) for o in obs_b]
     bank_ptr = [b.data_ptr() for b in bank]
 

@@ -346,11 +346,33 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
  *   rsb_comm_init          : ncclCommInitRank on the world's device (collective: every rank calls it)
  *   rsb_allgather_obs      : the rank's obs block (rsb_gather_obs semantics) -> out [n_ranks*N, obs_dim], rank-major, on the
  *                            handle's stream; out in `space` (DEVICE: gathered in place, nothing synchronises; HOST: staged) */
+#define RSB_MAX_RANKS 8           /* ranks of one node (peer-mapped obs exchange below) */
 #define RSB_COMM_ID_BYTES 128
 int rsb_comm_get_unique_id(char id[RSB_COMM_ID_BYTES]);
 int rsb_comm_init(rsb_world* w, int n_ranks, int rank, const char id[RSB_COMM_ID_BYTES]);
 int rsb_comm_destroy(rsb_world* w);
 int rsb_allgather_obs(rsb_world* w, const int32_t* collision_indices, int n_force_slots, float* out, int space);
+
+/* ---- the same exchange WITHOUT a collective or a copy kernel: peer-mapped gathered buffers.  The step kernel fills every CU
+ * of the chip, so a collective's copy kernel cannot overlap it and costs a kernel slot per control step (measured: 8 % at one
+ * rank).  Here every rank owns a gathered buffer [n_ranks * N, obs_dim] (double-buffered by control-step parity) that the other
+ * ranks map - hipIpc handles across processes, plain pointers within one process -, and the epilogue of rsb_control_step's ONE
+ * launch stores each env's obs row into the buffer of every rank (the other GPUs' over xGMI); the last wave of the launch
+ * publishes the step number in every rank's flag array, and rsb_obs_peer_wait makes the stream wait (command-processor poll of
+ * the flag words, no kernel) until every rank has delivered the rows of the last control step issued.
+ *   rsb_obs_peer_create       allocate this rank's buffer (fine-grained device memory); `handle` (may be NULL) receives its IPC handle
+ *   rsb_obs_peer_connect      handles [n_ranks][RSB_OBS_HANDLE_BYTES] of all ranks (own entry ignored), e.g. from an all-gather of the launcher
+ *   rsb_obs_peer_connect_ptrs the same within ONE process: base pointers (rsb_obs_peer_base) of the other worlds, peer access enabled by the caller
+ *   rsb_obs_peer_wait         see above; *gathered (may be NULL) receives the device pointer of the complete block of that step, rank-major
+ * From rsb_obs_peer_connect on, every rsb_control_step of the world runs the exchange (obs_out may be NULL).  Floating-base models
+ * of tree depth <= 13.  RCCL (above) stays the default of bench.py until a multi-GPU box has measured both. */
+#define RSB_OBS_HANDLE_BYTES 64
+int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* collision_indices, int n_force_slots, char handle[RSB_OBS_HANDLE_BYTES]);
+int rsb_obs_peer_connect(rsb_world* w, const char* handles);
+int rsb_obs_peer_connect_ptrs(rsb_world* w, void* const* bases);
+void* rsb_obs_peer_base(rsb_world* w);
+int rsb_obs_peer_wait(rsb_world* w, float** gathered);
+int rsb_obs_peer_destroy(rsb_world* w);
 
 /* done flags of the fused control step: when `done_device` (uint8 [num_envs], DEVICE memory, caller-owned) is set,
  * every following rsb_control_step writes 1 for the envs it reset and 0 for the others (NULL switches it off). */

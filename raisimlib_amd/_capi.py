@@ -128,6 +128,12 @@ PROTOTYPES = {
     "rsb_comm_init": (_I, [_VP, _I, _I, C.c_char_p]),
     "rsb_comm_destroy": (_I, [_VP]),
     "rsb_allgather_obs": (_I, [_VP, _VP, _I, _FP, _I]),
+    "rsb_obs_peer_create": (_I, [_VP, _I, _I, _FP, _I, C.c_char_p]),
+    "rsb_obs_peer_connect": (_I, [_VP, C.c_char_p]),
+    "rsb_obs_peer_connect_ptrs": (_I, [_VP, C.POINTER(_VP)]),
+    "rsb_obs_peer_base": (_VP, [_VP]),
+    "rsb_obs_peer_wait": (_I, [_VP, C.POINTER(_VP)]),
+    "rsb_obs_peer_destroy": (_I, [_VP]),
     "rsb_integrate1": (_I, [_VP]),
     "rsb_integrate2": (_I, [_VP]),
     "rsb_get_contacts": (_I, [_VP, _FP, _FP, _I]),

@@ -84,6 +84,20 @@ struct rsb_world {
   double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
   int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
+  // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
+  //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
+  //   [flags, parity 0 | parity 1]            2 x RSB_MAX_RANKS uint32: flags[parity][p] = last control step whose rows rank p delivered
+  //   [arrival counter]                       uint32 (local use)
+  struct Peer {
+    int ranks = 0, rank = 0, slots = 0, od = 0;
+    bool connected = false, wait_by_kernel = false;
+    void* base = nullptr; size_t bytes = 0;
+    void* peer_base[RSB_MAX_RANKS] = {};
+    bool imported[RSB_MAX_RANKS] = {};
+    uint32_t step = 0;                       // sequence number of the last control step issued with the exchange
+    std::vector<int32_t> idx;                // force slots' collision primitives (empty: 0..slots-1)
+    int32_t* d_idx = nullptr;
+  } peer;
   int terrain_type = 0, hm_xs = 0, hm_ys = 0;
   double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
   float hm_max = 0.f;
@@ -94,7 +108,7 @@ struct rsb_world {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
-  struct Fuse { const float* act = nullptr; const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
+  struct Fuse { bool peer = false; const float* act = nullptr; const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
                 int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1;
                 float* env_reward = nullptr; float* env_ob = nullptr; uint8_t* env_done = nullptr; bool env_task = false; } fuse;
   // device-resident vectorised env (rsb_env_*)
@@ -458,6 +472,21 @@ int do_integrate(rsb_world* w, int nsub) {
     a.tau2_out = nullptr;
   }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
+  const bool peer = w->fuse.peer;
+  if (peer) {   // rsb_control_step with the peer-mapped obs exchange connected: rows go to every rank's gathered buffer of this step's parity
+    rsb_world::Peer& P = w->peer;
+    const uint32_t step = ++P.step;
+    const int par = (int)(step & 1u);
+    const size_t bufsz = (size_t)P.ranks * w->N * P.od;
+    for (int p = 0; p < P.ranks; ++p) {
+      float* pb = static_cast<float*>(P.peer_base[p]);
+      a.obs_peer[p] = pb + (size_t)par * bufsz;
+      a.obs_flag[p] = reinterpret_cast<uint32_t*>(pb + 2 * bufsz) + (size_t)par * RSB_MAX_RANKS + P.rank;
+    }
+    a.obs_ctr = reinterpret_cast<uint32_t*>(static_cast<float*>(P.base) + 2 * bufsz) + 2 * RSB_MAX_RANKS;
+    a.n_obs_peers = P.ranks; a.obs_row0 = P.rank * w->N; a.obs_step = step;
+    a.obs_slots = P.slots; a.obs_idx = P.idx.empty() ? nullptr : P.d_idx;
+  }
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
   if (!a.do_reset) { a.gc0 = w->d_gc; a.gv0 = w->d_gv; a.reset_rows = w->N; }   // never dereferenced, but keep the pointers valid
@@ -501,9 +530,10 @@ int do_integrate(rsb_world* w, int nsub) {
   const int mlv = w->blob.depth - 1;
   if (mlv <= 4) {
     if (w->blob.fixed_base) st = kcap == 8 ? launch_lpe<8, 1, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 1, 4>(w, a, lds_bytes, lpe, prof);
+    else if (peer) st = kcap == 8 ? launch_lpe<8, 2, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 2, 4>(w, a, lds_bytes, lpe, prof);
     else st = kcap == 8 ? launch_lpe<8, 0, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 4>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 12) {
-    st = w->blob.fixed_base ? launch_lpe<16, 1, 12>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
+    st = w->blob.fixed_base ? launch_lpe<16, 1, 12>(w, a, lds_bytes, lpe, prof) : peer ? launch_lpe<16, 2, 12>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 16) {
     st = w->blob.fixed_base ? launch_lpe<16, 1, 16>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 16>(w, a, lds_bytes, lpe, prof);
   } else {
@@ -612,6 +642,7 @@ int rsb_destroy(rsb_world* w) {
   (void)hipSetDevice(w->device);
   if (w->stream) (void)hipStreamSynchronize(w->stream);
   (void)rsb_comm_destroy(w);
+  (void)rsb_obs_peer_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
                   w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_genf, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
@@ -1138,6 +1169,11 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
   if (d_target) { int st = copy_in(w, w->d_dt, d_target, (size_t)w->N * w->blob.nv, RSB_DEVICE); if (st) return st; }
   rsb_world::Fuse f;
   f.ptarget_src = p_target;   // read in place by the launch, which also refreshes the world's own copy
+  if (w->peer.connected) {
+    if (w->blob.fixed_base || w->blob.depth - 1 > 12) { rsb::set_error("rsb_control_step: the peer-mapped obs exchange is compiled for floating-base models of tree depth <= 13"); return RSB_E_UNSUPPORTED; }
+    if (obs_out && n_force_slots != w->peer.slots) { rsb::set_error("rsb_control_step: obs_out must use the force slots the peer exchange was created with"); return RSB_E_INVALID; }
+    f.peer = true;
+  }
   if (obs_out) {
     f.obs_out = obs_out; f.obs_slots = n_force_slots;
     if (force_collisions && n_force_slots > 0) {
@@ -1438,6 +1474,116 @@ int rsb_comm_destroy(rsb_world* w) {
   Rccl* R = rccl();
   if (R) { (void)hipSetDevice(w->device); (void)hipStreamSynchronize(w->stream); (void)R->CommDestroy(w->comm); }
   w->comm = nullptr; w->comm_ranks = 0;
+  return RSB_OK;
+}
+
+// ---- peer-mapped obs exchange: no collective, no copy kernel (see rsb.h) -------------------------------------------------
+__global__ void obs_peer_wait_kernel(const uint32_t* flags, int n, uint32_t step) {
+  // fallback of rsb_obs_peer_wait when the stream cannot wait on a memory value: lane p spins until rank p's flag has the step
+  const int p = threadIdx.x;
+  if (p < n) while ((int32_t)(__hip_atomic_load(flags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) __builtin_amdgcn_s_sleep(8);
+}
+
+int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* collision_indices, int n_force_slots, char handle[RSB_OBS_HANDLE_BYTES]) {
+  if (!w || n_ranks < 1 || n_ranks > RSB_MAX_RANKS || rank < 0 || rank >= n_ranks || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) {
+    rsb::set_error("rsb_obs_peer_create: bad argument (1 <= n_ranks <= RSB_MAX_RANKS)"); return RSB_E_INVALID;
+  }
+  if (w->peer.base) { rsb::set_error("rsb_obs_peer_create: the world already has an exchange (rsb_obs_peer_destroy first)"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  rsb_world::Peer& P = w->peer;
+  P.ranks = n_ranks; P.rank = rank; P.slots = n_force_slots; P.od = w->blob.nq + w->blob.nv + 3 * n_force_slots;
+  P.idx.clear();
+  if (collision_indices) {
+    for (int i = 0; i < n_force_slots; ++i) {
+      if (collision_indices[i] < 0 || collision_indices[i] >= w->blob.ncol) { rsb::set_error("rsb_obs_peer_create: collision index out of range"); return RSB_E_INVALID; }
+      P.idx.push_back(collision_indices[i]);
+    }
+  }
+  const size_t bufsz = (size_t)n_ranks * w->N * P.od;
+  P.bytes = 2 * bufsz * sizeof(float) + (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t);
+  // fine-grained memory: stores of OTHER devices' kernels (and their system-scope flag writes) become visible without a kernel
+  // boundary on this device; plain hipMalloc is the fallback where the runtime refuses the flag
+  if (hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc(&P.base, P.bytes)); }
+  HIP_TRY(hipMemsetAsync(P.base, 0, P.bytes, w->stream));
+  if (!P.idx.empty()) {
+    HIP_TRY(hipMalloc(&P.d_idx, P.idx.size() * sizeof(int32_t)));
+    HIP_TRY(hipMemcpyAsync(P.d_idx, P.idx.data(), P.idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  if (handle) {
+    std::memset(handle, 0, RSB_OBS_HANDLE_BYTES);
+    hipIpcMemHandle_t h;
+    static_assert(sizeof(hipIpcMemHandle_t) <= RSB_OBS_HANDLE_BYTES, "IPC handle does not fit RSB_OBS_HANDLE_BYTES");
+    if (hipIpcGetMemHandle(&h, P.base) == hipSuccess) std::memcpy(handle, &h, sizeof h);
+    else (void)hipGetLastError();       // (no IPC on this system: rsb_obs_peer_connect_ptrs within one process still works)
+  }
+  return RSB_OK;
+}
+
+static int obs_peer_finish_connect(rsb_world* w) {
+  w->peer.connected = true; w->peer.step = 0;
+  return RSB_OK;
+}
+
+int rsb_obs_peer_connect(rsb_world* w, const char* handles) {
+  if (!w || !handles) { rsb::set_error("rsb_obs_peer_connect: bad argument"); return RSB_E_INVALID; }
+  if (!w->peer.base) { rsb::set_error("rsb_obs_peer_connect: call rsb_obs_peer_create first"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  rsb_world::Peer& P = w->peer;
+  for (int p = 0; p < P.ranks; ++p) {
+    if (p == P.rank) { P.peer_base[p] = P.base; continue; }
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles + (size_t)p * RSB_OBS_HANDLE_BYTES, sizeof h);
+    void* ptr = nullptr;
+    HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    P.peer_base[p] = ptr; P.imported[p] = true;
+  }
+  return obs_peer_finish_connect(w);
+}
+
+int rsb_obs_peer_connect_ptrs(rsb_world* w, void* const* bases) {
+  if (!w || !bases) { rsb::set_error("rsb_obs_peer_connect_ptrs: bad argument"); return RSB_E_INVALID; }
+  if (!w->peer.base) { rsb::set_error("rsb_obs_peer_connect_ptrs: call rsb_obs_peer_create first"); return RSB_E_STATE; }
+  rsb_world::Peer& P = w->peer;
+  for (int p = 0; p < P.ranks; ++p) {
+    if (p != P.rank && !bases[p]) { rsb::set_error("rsb_obs_peer_connect_ptrs: null base pointer"); return RSB_E_INVALID; }
+    P.peer_base[p] = p == P.rank ? P.base : bases[p];
+  }
+  return obs_peer_finish_connect(w);
+}
+
+void* rsb_obs_peer_base(rsb_world* w) { return w ? w->peer.base : nullptr; }
+
+int rsb_obs_peer_wait(rsb_world* w, float** gathered) {
+  if (!w) return RSB_E_INVALID;
+  rsb_world::Peer& P = w->peer;
+  if (!P.connected || P.step == 0) { rsb::set_error("rsb_obs_peer_wait: no control step has been issued with the exchange"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t bufsz = (size_t)P.ranks * w->N * P.od;
+  const int par = (int)(P.step & 1u);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(static_cast<float*>(P.base) + 2 * bufsz) + (size_t)par * RSB_MAX_RANKS;
+  if (!P.wait_by_kernel) {
+    // the command processor polls the flag words: no kernel, no CU
+    for (int p = 0; p < P.ranks && !P.wait_by_kernel; ++p)
+      if (hipStreamWaitValue32(w->stream, flags + p, P.step, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) { (void)hipGetLastError(); P.wait_by_kernel = true; }
+  }
+  if (P.wait_by_kernel) {
+    hipLaunchKernelGGL(obs_peer_wait_kernel, dim3(1), dim3(64), 0, w->stream, flags, P.ranks, P.step);
+    HIP_TRY(hipGetLastError());
+  }
+  if (gathered) *gathered = static_cast<float*>(P.base) + (size_t)par * bufsz;
+  return RSB_OK;
+}
+
+int rsb_obs_peer_destroy(rsb_world* w) {
+  if (!w || !w->peer.base) return RSB_OK;
+  (void)hipSetDevice(w->device);
+  (void)hipStreamSynchronize(w->stream);
+  rsb_world::Peer& P = w->peer;
+  for (int p = 0; p < P.ranks; ++p) if (P.imported[p]) (void)hipIpcCloseMemHandle(P.peer_base[p]);
+  (void)hipFree(P.base);
+  if (P.d_idx) (void)hipFree(P.d_idx);
+  w->peer = rsb_world::Peer();
   return RSB_OK;
 }
 

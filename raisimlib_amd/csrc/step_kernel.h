@@ -507,7 +507,9 @@ __device__ __forceinline__ void tri_store(float* G, int a, int b, const float (&
 }
 
 // ------------------------------------------------------------------------------- the kernel
-// LPE : lanes per env.  KMAX : contact capacity.  CL : model class, 1 = fixed-base systems (their contact blocks get a compliance, see the Delassus phase), 0 = floating base.
+// LPE : lanes per env.  KMAX : contact capacity.  CL : kernel class bits: 1 = fixed-base systems (their contact blocks get a compliance, see the Delassus
+// phase), 2 = peer-mapped obs exchange in the epilogue (rsb_obs_peer_*); 0 = floating base, no exchange - the benchmark's class stays what it was,
+// instruction for instruction (code added to the shared epilogue moved the register allocation of the sub-step loop: +26 spill moves).
 // ML : body-level capacity (>= depth-1).  PROF : compile the cycle stamps / contact-problem dump / LDS poisoning of the
 // rsb_debug_* entry points in (the production instances carry none of it: fewer SGPRs, no branches in the solver loop).
 template <int LPE, int KMAX, int CL, int ML, bool PROF>
@@ -517,6 +519,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   long long t_entry = 0; if (PROF) t_entry = clock64();
   constexpr int EPW = 64 / LPE;
+  constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0;
   constexpr bool TRI = KMAX > 8;    // packed lower-triangular Delassus blocks (see tri_off); the quadruped classes keep the square layout
   const int lane = threadIdx.x;
   const int el = lane / LPE;
@@ -1299,7 +1302,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
       }
       __syncthreads();
-      if constexpr (CL != 0) {   // (a class of its own: the floating-base kernels stay what they were, instruction for instruction)
+      if constexpr (FIXED) {   // (a class of its own: the floating-base kernels stay what they were, instruction for instruction)
         // fixed-base systems: a body fewer than three joints from the world cannot move in every direction, its contact's block
         // is rank deficient; the same small compliance as for a self-collision (whose fold below adds it for those)
         if (s < nc && __float_as_int(CON[s * kConSlot + 11]) < kSelfA) {
@@ -1346,7 +1349,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
                 ld4(SELFT + 4 * sa, m4);
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { CV[3 * sa + rr] += CV[3 * sb + rr]; CV[3 * sb + rr] = 0.f; }
                 if (m4[1] > 0.f && ju < -m4[2]) CV[3 * sa + 2] += m4[1] * ju;
-                const float reg = (CL != 0 ? 2.f : 1.f) * kSelfReg * (D[0][0] + D[1][1] + D[2][2]) * (1.0f / 3.0f);   // (oracle: ORC_SELF_REG, see below)
+                const float reg = (FIXED ? 2.f : 1.f) * kSelfReg * (D[0][0] + D[1][1] + D[2][2]) * (1.0f / 3.0f);   // (oracle: ORC_SELF_REG, see below)
                 RSB_UNROLL for (int rr = 0; rr < 3; ++rr) D[rr][rr] += reg;
                 const float I3[3][3] = {{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}};
                 tri_store(G, sa, sa, D); tri_store(G, sb, sa, Z); tri_store(G, sb, sb, I3);
@@ -1395,7 +1398,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             // two bodies joined by fewer than three joints cannot move relative to each other in every direction: the block is
             // rank deficient (thigh against trunk: two joints).  A small compliance keeps the per-contact rule well posed
             // (oracle: ORC_SELF_REG)
-            const float reg = (CL != 0 ? 2.f : 1.f) * kSelfReg * (acc[0] + acc[4] + acc[8]) * (1.0f / 3.0f);
+            const float reg = (FIXED ? 2.f : 1.f) * kSelfReg * (acc[0] + acc[4] + acc[8]) * (1.0f / 3.0f);
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) { acc[4 * rr] += reg; G[(3 * sa + rr) * GS + 4 * sa + rr] = acc[4 * rr]; }
             inv3(acc, gi);
             gi[9] = gi[10] = gi[11] = 0.f;
@@ -1859,9 +1862,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
     if (bb & gsel) flag |= 2;
     const bool term = ae.do_reset && ((flag & 2) != 0 || (bi & gsel) != 0);
-    if (ae.obs_out) {   // the observation is the state the episode ended in (before a reset), as rsb_gather_obs would read it
-      const int od = nq + nv + 3 * ae.obs_slots;
-      float* ob = ae.obs_out + (size_t)env * od;
+    // the observation is the state the episode ended in (before a reset), as rsb_gather_obs would read it: written through
+    // `put` to the caller's block and / or to every rank's gathered buffer (peer-mapped obs exchange, StepArgs::obs_peer)
+    auto write_obs = [&](float* ob) {
       for (int i = s; i < nq; i += LPE) ob[i] = Q[i];
       for (int i = s; i < nv; i += LPE) ob[nq + i] = U[i];
       const float inv_dt = 1.0f / dt;
@@ -1879,6 +1882,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         }
         ob[nq + nv + 3 * sl] = f0; ob[nq + nv + 3 * sl + 1] = f1; ob[nq + nv + 3 * sl + 2] = f2;
       }
+    };
+    if constexpr (!PEER) {
+      if (ae.obs_out) write_obs(ae.obs_out + (size_t)env * (nq + nv + 3 * ae.obs_slots));
+    } else {
+      // destinations: the caller's block first (when there is one), then every rank's gathered buffer
+      const int own = ae.obs_out ? 1 : 0, ndst = own + ae.n_obs_peers;
+      const size_t od = (size_t)(nq + nv + 3 * ae.obs_slots);
+      for (int d = 0; d < ndst; ++d)
+        write_obs(d < own ? ae.obs_out + (size_t)env * od : ae.obs_peer[d - own] + (size_t)(ae.obs_row0 + env) * od);
     }
     if (ae.warm && s < kmax) {   // one record per contact of the last sub-step (see the prologue); empty records behind them
       float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1939,6 +1951,19 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       ae.contact_count[env] = term ? 0 : nc;   // a reset env starts its episode without contacts or flags
       ae.flags[env] = term ? 0 : flag;
       ae.iters[env] = iters_used;
+    }
+  }
+  if constexpr (PEER) if (ae.n_obs_peers > 0) {
+    // peer-mapped obs exchange: this wave's rows are out (system-scope release), it checks in; the LAST wave of the launch
+    // publishes the step counter in every rank's flag array - what rsb_obs_peer_wait() on that rank waits for
+    __threadfence_system();
+    if (lane == 0) {
+      const unsigned arrived = __hip_atomic_fetch_add(ae.obs_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (arrived == gridDim.x - 1) {
+        __hip_atomic_store(ae.obs_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
+        for (int p = 0; p < ae.n_obs_peers; ++p) __hip_atomic_store(ae.obs_flag[p], ae.obs_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }

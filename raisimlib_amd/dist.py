@@ -84,3 +84,50 @@ class ObsGatherer:
         if not self.active:
             return "none (1 rank)"
         return "overlapped with the next control step (double-buffered)" if self.nbuf == 2 else "in line"
+
+
+class PeerObsGatherer:
+    """The same job without a collective: every rank's gathered block is mapped by the other ranks (hipIpc handles exchanged once
+    through torch.distributed), the step kernel's epilogue stores each env's obs row into all of them and the last wave publishes
+    the step number; `gather` only enqueues the stream-side wait (rsb_obs_peer_wait).  Interface of ObsGatherer, so bench.py can
+    switch with a flag; `local_bufs` is [None]: the control step needs no obs block of its own."""
+
+    def __init__(self, world, force_collisions, force=False):
+        self.world = world
+        self.ranks = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.active = self.ranks > 1 or force
+        self.nbuf = 1
+        self.local_bufs = [None]
+        self._last = None
+        if not self.active:
+            return
+        handle = world.obs_peer_create(self.ranks, self.rank, force_collisions)
+        if self.ranks > 1:
+            every = [None] * self.ranks
+            dist.all_gather_object(every, handle)
+            world.obs_peer_connect(b"".join(every))
+        else:
+            world.obs_peer_connect(handle)          # one rank: the own entry is the only one (and is ignored)
+
+    def slot(self, k):
+        return 0
+
+    def acquire(self, k):
+        pass                                        # the library double-buffers by control-step parity
+
+    def gather(self, k):
+        if self.active:
+            self._last = self.world.obs_peer_wait()
+
+    def gathered_ptr(self):
+        """device pointer of the last complete [ranks * n, obs_dim] block"""
+        return self._last
+
+    def drain(self):
+        pass
+
+    def describe(self):
+        if not self.active:
+            return "none (1 rank)"
+        return "peer-mapped buffers: rows stored by the step kernel's epilogue into every rank's block, stream-side flag wait (no collective, no copy kernel)"

@@ -406,6 +406,38 @@ class BatchedWorld:
                 check(st, "rsb_control_step")
         return step
 
+    # -- peer-mapped obs exchange (rsb_obs_peer_*: no collective, no copy kernel; see include/rsb.h) ------------
+    OBS_HANDLE_BYTES = 64
+
+    def obs_peer_create(self, n_ranks, rank, force_collisions):
+        """Allocates this rank's gathered buffer; returns its IPC handle (64 bytes; zeros when the system has no hipIpc)."""
+        fidx = _host(force_collisions, np.int32)
+        buf = C.create_string_buffer(self.OBS_HANDLE_BYTES)
+        check(self.L.rsb_obs_peer_create(self.handle, int(n_ranks), int(rank), _hp(fidx), 0 if fidx is None else fidx.shape[0], buf),
+              "rsb_obs_peer_create")
+        return buf.raw
+
+    def obs_peer_connect(self, handles):
+        """handles: the n_ranks IPC handles in rank order (bytes of n_ranks * 64), e.g. from dist.all_gather_object."""
+        check(self.L.rsb_obs_peer_connect(self.handle, bytes(handles)), "rsb_obs_peer_connect")
+
+    def obs_peer_connect_ptrs(self, bases):
+        """Within one process: base pointers (obs_peer_base()) of all ranks' worlds in rank order (own entry ignored)."""
+        arr = (C.c_void_p * len(bases))(*[C.c_void_p(b) for b in bases])
+        check(self.L.rsb_obs_peer_connect_ptrs(self.handle, arr), "rsb_obs_peer_connect_ptrs")
+
+    def obs_peer_base(self):
+        return self.L.rsb_obs_peer_base(self.handle)
+
+    def obs_peer_wait(self):
+        """Stream-side wait for every rank's rows of the last control step issued; returns the gathered block's device pointer."""
+        out = C.c_void_p()
+        check(self.L.rsb_obs_peer_wait(self.handle, C.byref(out)), "rsb_obs_peer_wait")
+        return out.value
+
+    def obs_peer_destroy(self):
+        check(self.L.rsb_obs_peer_destroy(self.handle), "rsb_obs_peer_destroy")
+
     def last_kernel_ms(self):
         ms = C.c_float()
         check(self.L.rsb_last_kernel_ms(self.handle, C.byref(ms)), "rsb_last_kernel_ms")
