@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/
 TARGET_BANK = 128                 # distinct pre-generated PD-target sets cycled through (per-env seeded, control step k -> set k % 128)
 EVENT_STRIDE = 8                  # inside the timed region every 8th launch is bracketed by HIP events (a bracket costs ~7 us of stream time)
 PREROLL = 200                     # untimed control steps before --warmup: the workload is the stationary population, whatever --warmup is
-SAMPLE_LAUNCHES = 64              # control steps of the post-timing sampling pass (every launch bracketed)
+SAMPLE_LAUNCHES = 256             # control steps of the post-timing sampling pass (every launch bracketed; long enough that its mean and the timed region's agree)
 # SURVEY.md §8d contract numbers: unfused state traffic per env-step, fp32
 BYTES_PER_ENV_STEP = {2: 456.0, 3: 520.0, 5: 1080.0}
 

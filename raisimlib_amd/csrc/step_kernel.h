@@ -1953,19 +1953,6 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       ae.iters[env] = iters_used;
     }
   }
-  if constexpr (PEER) if (ae.n_obs_peers > 0) {
-    // peer-mapped obs exchange: this wave's rows are out (system-scope release), it checks in; the LAST wave of the launch
-    // publishes the step counter in every rank's flag array - what rsb_obs_peer_wait() on that rank waits for
-    __threadfence_system();
-    if (lane == 0) {
-      const unsigned arrived = __hip_atomic_fetch_add(ae.obs_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (arrived == gridDim.x - 1) {
-        __hip_atomic_store(ae.obs_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();
-        for (int p = 0; p < ae.n_obs_peers; ++p) __hip_atomic_store(ae.obs_flag[p], ae.obs_step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
 }
 
 }  // namespace rsbk

@@ -125,13 +125,11 @@ struct StepArgs {
   // multi-contact envs (>= multi_depth contacts on one limb in this sub-step: redundant sets; rsb_set_solver_multi_contact)
   int multi_depth, multi_light, multi_freeze_after, multi_stall_window;
   // peer-mapped obs exchange (rsb_obs_peer_*): the epilogue stores the env's obs row (the obs_out layout) into the gathered buffer
-  // of EVERY rank at row obs_row0 + env - plain stores through peer-mapped pointers, over xGMI for the other GPUs - and the last
-  // wave of the launch to finish publishes this rank's step counter in every rank's flag array.  No copy kernel, no collective.
+  // of EVERY rank at row obs_row0 + env - plain stores through peer-mapped pointers, over xGMI for the other GPUs.  No fence, no
+  // counter in the kernel (a system-scope release per wave wrote the whole L2 back: +15 % kernel time, measured): the rows are
+  // released by the end of the kernel, and the host side enqueues the ranks' flag words behind it as stream memory writes.
   float* obs_peer[RSB_MAX_RANKS];        // [n_obs_peers] rank p's gathered buffer [n_ranks * N, obs_dim] of this control step's parity
-  uint32_t* obs_flag[RSB_MAX_RANKS];     // [n_obs_peers] &flags_of_rank_p[parity][my rank]
-  uint32_t* obs_ctr;                     // this rank's wave-arrival counter (device memory, zero between launches)
   int n_obs_peers, obs_row0;
-  uint32_t obs_step;                     // value published in the flags: the control step's sequence number (>= 1)
 };
 
 }  // namespace rsbk

@@ -8,11 +8,11 @@
 // (the lowest rim point of each end cap) geometry,
 // <joint type="revolute|continuous|prismatic|fixed">, <origin xyz rpy>, <axis>, <limit>,
 // <dynamics damping rotor_inertia>.  The root link is the floating base, or - when it is named "world" - a fixed base.  <mesh filename=.. scale=..> collision geometry
-// (Wavefront OBJ, binary / ASCII STL; path relative to the URDF file, "package://" / "file://" prefixes stripped to the
+// (Wavefront OBJ, binary / ASCII STL, Collada .dae; path relative to the URDF file, "package://" / "file://" prefixes stripped to the
 // longest existing suffix) becomes a POINT SET: up to kMeshPoints vertices of the mesh's convex hull (support vertices of
 // the body diagonals, axes and face diagonals), each a zero-radius sphere - against a plane this is the contact set of a
 // triangle-mesh x plane collider (vertices below the plane) thinned out to the budget.  Meshes that cannot be read
-// (Collada, missing files, URDFs given as strings without a directory) are skipped and counted in
+// (other formats, missing files, URDFs given as strings without a directory) are skipped and counted in
 // rsb_model::skipped_collisions.
 #include "rsb.h"
 #include "rsb_internal.h"
@@ -239,7 +239,8 @@ static std::string resolve_mesh_path(const std::string& uri, const std::string& 
   return "";
 }
 
-// vertices of an OBJ ("v x y z" lines) or STL (binary: 80-byte header, uint32 count, 50-byte facets; ASCII: "vertex x y z")
+// vertices of an OBJ ("v x y z" lines), an STL (binary: 80-byte header, uint32 count, 50-byte facets; ASCII: "vertex x y z")
+// or a Collada file (.dae: the POSITION float arrays of its meshes)
 static bool read_mesh_vertices(const std::string& path, std::vector<V3>* out) {
   std::ifstream f(path, std::ios::binary);
   if (!f) return false;
@@ -273,6 +274,50 @@ static bool read_mesh_vertices(const std::string& path, std::vector<V3>* out) {
         double v[3];
         if (std::sscanf(data.c_str() + pos + 6, "%lf %lf %lf", &v[0], &v[1], &v[2]) == 3) out->push_back({v[0], v[1], v[2]});
         pos += 6;
+      }
+    }
+  } else if (ext == "dae") {
+    // Collada: the POSITION source of every <mesh> - <vertices><input semantic="POSITION" source="#id"/> names the <source> whose
+    // <float_array> holds x y z triples.  <unit meter=".."> scales to metres; <up_axis>Y_UP</up_axis> is turned to the URDF's z-up.
+    // Node transforms of the visual scene are NOT applied (collision meshes are exported with identity transforms in practice).
+    auto attr = [&](size_t tag_pos, const char* name) -> std::string {
+      const size_t end = data.find('>', tag_pos);
+      const std::string key = std::string(name) + "=\"";
+      const size_t a = data.find(key, tag_pos);
+      if (end == std::string::npos || a == std::string::npos || a > end) return "";
+      const size_t b = data.find('"', a + key.size());
+      return b == std::string::npos ? "" : data.substr(a + key.size(), b - a - key.size());
+    };
+    double unit = 1.0;
+    if (const size_t u = data.find("<unit"); u != std::string::npos) { const std::string m = attr(u, "meter"); if (!m.empty()) unit = std::atof(m.c_str()); }
+    const bool y_up = data.find("<up_axis>Y_UP</up_axis>") != std::string::npos;
+    size_t pos = 0;
+    while ((pos = data.find("<vertices", pos)) != std::string::npos) {
+      const size_t vend = data.find("</vertices>", pos);
+      size_t in = pos;
+      std::string src;
+      while ((in = data.find("<input", in + 1)) != std::string::npos && (vend == std::string::npos || in < vend))
+        if (attr(in, "semantic") == "POSITION") src = attr(in, "source");
+      pos += 9;
+      if (src.size() < 2 || src[0] != '#') continue;
+      const size_t sp = data.find("<source id=\"" + src.substr(1) + "\"");
+      if (sp == std::string::npos) continue;
+      const size_t fa = data.find("<float_array", sp), send = data.find("</source>", sp);
+      if (fa == std::string::npos || (send != std::string::npos && fa > send)) continue;
+      const size_t b = data.find('>', fa), e = data.find("</float_array>", fa);
+      if (b == std::string::npos || e == std::string::npos) continue;
+      const char* c = data.c_str() + b + 1;
+      const char* stop = data.c_str() + e;
+      std::vector<double> f;
+      while (c < stop) {
+        char* nx = nullptr;
+        const double v = std::strtod(c, &nx);
+        if (nx == c) break;
+        f.push_back(v); c = nx;
+      }
+      for (size_t i = 0; i + 2 < f.size(); i += 3) {
+        const double x = f[i] * unit, y = f[i + 1] * unit, z = f[i + 2] * unit;
+        if (y_up) out->push_back({x, -z, y}); else out->push_back({x, y, z});
       }
     }
   } else {

@@ -163,6 +163,25 @@ def _write_box_mesh(dirpath, fn, half=(0.4, 0.3, 0.2), extra_interior=True):
                 f.write("v %.6f %.6f %.6f\n" % v)
             for a, b, c in F:
                 f.write("f %d %d %d\n" % (a + 1, b + 1, c + 1))
+    elif fn.endswith(".dae"):
+        # a minimal Collada document: centimetres, y-up (what many CAD exporters write): the loader scales to metres and turns to z-up
+        zup = [(x, y, z) for x, y, z in V]
+        yup = [(x * 100, z * 100, -y * 100) for x, y, z in zup]          # (x, y, z)_zup = (x, -z_yup, y_yup)
+        floats = " ".join("%.6f" % c for v in yup for c in v)
+        tris = " ".join(str(i) for tri in F for i in tri)
+        with open(path, "w") as f:
+            f.write(f"""<?xml version="1.0" encoding="utf-8"?>
+<COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+  <asset><unit name="centimeter" meter="0.01"/><up_axis>Y_UP</up_axis></asset>
+  <library_geometries><geometry id="box-mesh" name="box"><mesh>
+    <source id="box-mesh-normals"><float_array id="box-mesh-normals-array" count="3">0 0 1</float_array></source>
+    <source id="box-mesh-positions"><float_array id="box-mesh-positions-array" count="{3 * len(yup)}">{floats}</float_array>
+      <technique_common><accessor source="#box-mesh-positions-array" count="{len(yup)}" stride="3"><param name="X" type="float"/><param name="Y" type="float"/><param name="Z" type="float"/></accessor></technique_common></source>
+    <vertices id="box-mesh-vertices"><input semantic="POSITION" source="#box-mesh-positions"/></vertices>
+    <triangles count="{len(F)}"><input semantic="VERTEX" source="#box-mesh-vertices" offset="0"/><p>{tris}</p></triangles>
+  </mesh></geometry></library_geometries>
+</COLLADA>
+""")
     else:
         with open(path, "wb") as f:
             f.write(b"binary stl".ljust(80, b" ") + struct.pack("<I", len(F)))
@@ -171,9 +190,9 @@ def _write_box_mesh(dirpath, fn, half=(0.4, 0.3, 0.2), extra_interior=True):
     return path
 
 
-@pytest.mark.parametrize("fn", ["crate.obj", "crate.stl"])
+@pytest.mark.parametrize("fn", ["crate.obj", "crate.stl", "crate.dae"])
 def test_mesh_collision_geometry_becomes_a_point_set(built_lib, tmp_path, fn):
-    """<mesh> colliders (OBJ, binary STL): package:// URI resolved below the URDF's directory, scale applied, the vertex cloud
+    """<mesh> colliders (OBJ, binary STL, Collada with its <unit> and <up_axis>): package:// URI resolved below the URDF's directory, scale applied, the vertex cloud
     thinned to 8 points - for a box exactly its corners - each a zero-radius primitive carrying the collision's material."""
     pkg = tmp_path / "crate_description"
     _write_box_mesh(str(pkg / "meshes"), fn)
