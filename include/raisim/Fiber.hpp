@@ -6,17 +6,24 @@
 // behind all envs, the i-th integrate() of env 0 must not run before every other env has issued its own i-th
 // integrate().  So each env's step() body runs on its own fiber (ucontext); raisim::World::integrate() on a view parks
 // the fiber, and when every live fiber is parked the scheduler flushes the batch with ONE launch and resumes them all.
-// No threads, no locks: fibers run one at a time on the caller's thread, exactly like the serial loop they replace.
+// By default the fibers run one at a time on the caller's thread, exactly like the serial loop they replace; with threads > 1
+// they are dealt to a pool (cfg["num_threads"], what upstream's OpenMP loop uses) and the host part of the N step() bodies -
+// observation, reward, contact queries - runs in parallel between two flushes.
 #pragma once
 
 #include <sys/mman.h>
 #include <ucontext.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdlib>
 #include <exception>
 #include <functional>
+#include <mutex>
+#include <thread>
 #include <stdexcept>
 #include <vector>
 
@@ -26,7 +33,7 @@ namespace detail {
 class FiberScheduler {
  public:
   /// the scheduler whose fiber is running on this thread right now (nullptr outside of run())
-  static FiberScheduler*& current() { static thread_local FiberScheduler* c = nullptr; return c; }
+  static FiberScheduler*& current() { return tls().sched; }
 
   /// stackBytes: usable stack of one fiber (RSB_FIBER_STACK_KB overrides the default at run time: a ChildEnvironment::step()
   /// with large locals or deep Eigen expression temporaries needs more).  Every stack is followed by a PROT_NONE guard page:
@@ -41,9 +48,13 @@ class FiberScheduler {
   FiberScheduler& operator=(const FiberScheduler&) = delete;
 
   /// Runs body(i) for i in [0, n) as fibers.  Whenever all unfinished fibers are parked, onAllParked() is called
-  /// (the batch flush) and they are resumed.  An exception thrown inside a fiber is re-thrown here.
-  void run(int n, const std::function<void(int)>& body, const std::function<void()>& onAllParked) {
+  /// (the batch flush, on the calling thread) and they are resumed.  An exception thrown inside a fiber is re-thrown here.
+  /// threads > 1: the fibers are dealt to that many threads in contiguous blocks (upstream fans the N step() bodies out with
+  /// an OpenMP parallel-for over cfg["num_threads"]); a fiber always runs on the thread it was dealt to, the bodies of one round
+  /// run concurrently - whatever they share must be thread-safe (raisim::BatchedWorld is) - and the rounds stay lock-step.
+  void run(int n, const std::function<void(int)>& body, const std::function<void()>& onAllParked, int threads = 1) {
     if (current()) throw std::runtime_error("FiberScheduler::run: nested fiber schedulers are not supported");
+    threads = std::max(1, std::min(threads, n));
     if (n > cap_) {
       release();
       // [guard | stack 0 | guard | stack 1 | ... ]: stacks grow downwards INTO the guard page below them.  Virtual memory;
@@ -59,59 +70,107 @@ class FiberScheduler {
     body_ = &body;
     state_.assign(n, kReady);
     error_ = nullptr;
+    failedFlag_.store(false);
+    mains_.assign(threads, ucontext_t());
+    auto owner = [&](int i) { return (int)((long long)i * threads / n); };
     for (int i = 0; i < n; ++i) {
       getcontext(&ctx_[i]);
       ctx_[i].uc_stack.ss_sp = stacks_ + (size_t)i * (stackBytes_ + page_) + page_;
       ctx_[i].uc_stack.ss_size = stackBytes_;
-      ctx_[i].uc_link = &main_;
+      ctx_[i].uc_link = &mains_[owner(i)];
       makecontext(&ctx_[i], reinterpret_cast<void (*)()>(&FiberScheduler::trampoline), 0);
     }
-    current() = this;
-    int live = n;
-    while (live > 0 && !error_) {
-      int parked = 0;
-      for (int i = 0; i < n && !error_; ++i) {
-        if (state_[i] == kDone) continue;
-        running_ = i;
+    // one round of thread t: resume each of its unfinished fibers once; returns (still live, parked now)
+    auto round = [&](int t, int& live, int& parked) {
+      Tls& me = tls();
+      me.sched = this; me.thread = t;
+      const int lo = (int)(((long long)t * n + threads - 1) / threads), hi = (int)(((long long)(t + 1) * n + threads - 1) / threads);
+      live = parked = 0;
+      for (int i = lo; i < hi && !failed(); ++i) {
+        if (owner(i) != t || state_[i] == kDone) continue;
+        me.running = i;
         state_[i] = kRunning;
-        swapcontext(&main_, &ctx_[i]);
-        if (state_[i] == kRunning) { state_[i] = kDone; --live; }   // returned through uc_link: the body finished
-        else ++parked;
+        swapcontext(&mains_[t], &ctx_[i]);
+        if (state_[i] == kRunning) state_[i] = kDone;   // returned through uc_link: the body finished
+        else { ++parked; ++live; }
       }
-      if (parked > 0 && !error_) {
-        try { onAllParked(); } catch (...) { error_ = std::current_exception(); }
+      me.sched = nullptr; me.running = -1;
+    };
+    if (threads == 1) {
+      int live = n, parked = 0;
+      while (live > 0 && !failed()) {
+        round(0, live, parked);
+        if (parked > 0 && !failed()) { try { onAllParked(); } catch (...) { fail(std::current_exception()); } }
       }
+    } else {
+      // workers 1 .. threads-1 wait for a round number, run their block, report; the caller is worker 0 and runs the flush
+      std::mutex m;
+      std::condition_variable cv;
+      int roundNo = 0, reported = 0, liveSum = 0, parkedSum = 0;
+      bool quit = false;
+      std::vector<std::thread> pool;
+      for (int t = 1; t < threads; ++t)
+        pool.emplace_back([&, t] {
+          int seen = 0;
+          for (;;) {
+            { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return quit || roundNo != seen; }); if (quit) return; seen = roundNo; }
+            int live, parked;
+            round(t, live, parked);
+            { std::lock_guard<std::mutex> lk(m); liveSum += live; parkedSum += parked; ++reported; }
+            cv.notify_all();
+          }
+        });
+      for (;;) {
+        { std::lock_guard<std::mutex> lk(m); ++roundNo; reported = 0; liveSum = parkedSum = 0; }
+        cv.notify_all();
+        int live, parked;
+        round(0, live, parked);
+        { std::unique_lock<std::mutex> lk(m); liveSum += live; parkedSum += parked; ++reported; cv.wait(lk, [&] { return reported == threads; }); }
+        if (failed() || liveSum == 0) break;
+        if (parkedSum > 0) { try { onAllParked(); } catch (...) { fail(std::current_exception()); break; } }
+      }
+      { std::lock_guard<std::mutex> lk(m); quit = true; }
+      cv.notify_all();
+      for (auto& th : pool) th.join();
     }
-    current() = nullptr;
-    running_ = -1;
     if (error_) { auto e = error_; error_ = nullptr; std::rethrow_exception(e); }   // fibers left parked are simply dropped
   }
 
   /// called from inside a fiber: give control back to the scheduler until the next flush
   void park() {
-    const int i = running_;
+    Tls& me = tls();
+    const int i = me.running;
     state_[i] = kParked;
-    swapcontext(&ctx_[i], &main_);
+    swapcontext(&ctx_[i], &mains_[me.thread]);
   }
-  int running() const { return running_; }
+  int running() const { return tls().running; }
 
  private:
   enum State : char { kReady, kRunning, kParked, kDone };
+  struct Tls { FiberScheduler* sched = nullptr; int running = -1, thread = 0; };
+  static Tls& tls() { static thread_local Tls t; return t; }
   static void trampoline() {
     FiberScheduler* s = current();
-    try { (*s->body_)(s->running_); } catch (...) { s->error_ = std::current_exception(); }
-    // falling off the end switches to uc_link (= main_) with state_ still kRunning, which run() reads as "finished"
+    try { (*s->body_)(tls().running); } catch (...) { s->fail(std::current_exception()); }
+    // falling off the end switches to uc_link (= the owner thread's main context) with state_ still kRunning, which the round
+    // reads as "finished"
+  }
+  bool failed() const { return failedFlag_.load(std::memory_order_acquire); }
+  void fail(std::exception_ptr e) {
+    std::lock_guard<std::mutex> lk(errMutex_);
+    if (!error_) error_ = e;
+    failedFlag_.store(true, std::memory_order_release);
   }
   void release() { if (stacks_) munmap(stacks_, mapped_); stacks_ = nullptr; mapped_ = 0; cap_ = 0; }
   size_t stackBytes_ = 0, page_ = 4096, mapped_ = 0;
   char* stacks_ = nullptr;
   int cap_ = 0;
-  std::vector<ucontext_t> ctx_;
-  ucontext_t main_;
+  std::vector<ucontext_t> ctx_, mains_;
   std::vector<char> state_;
   const std::function<void(int)>* body_ = nullptr;
   std::exception_ptr error_;
-  int running_ = -1;
+  std::mutex errMutex_;
+  std::atomic<bool> failedFlag_{false};
 };
 
 }  // namespace detail

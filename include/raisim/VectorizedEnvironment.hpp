@@ -22,9 +22,12 @@
 //       reward = forward velocity - torque cost, termination on any non-foot contact followed by reset.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "raisim/RaisimGymEnv.hpp"
@@ -149,7 +152,12 @@ class VectorizedEnvironment {
   void init() {
     if (!environments_.empty()) return;
     num_envs_ = cfg_["num_envs"].template As<int>();
-    const int device = cfg_["device"].template As<int>(0);      // (new key) GPU that holds the batch; cfg["num_threads"] is ignored
+    const int device = cfg_["device"].template As<int>(0);      // (new key) GPU that holds the batch
+    // cfg["num_threads"] (upstream: the OpenMP team of the per-env loop): host threads that run the N step() bodies between two
+    // flushes of the batch, capped by the machine; RSB_FIBER_THREADS overrides it, 1 = everything on the caller's thread
+    threads_ = cfg_["num_threads"].IsNone() ? 1 : cfg_["num_threads"].template As<int>();
+    if (const char* ft = std::getenv("RSB_FIBER_THREADS")) threads_ = std::atoi(ft);
+    threads_ = std::max(1, std::min(threads_, (int)std::max(1u, std::thread::hardware_concurrency())));
     environments_.reserve(num_envs_);
     rewardInformation_.reserve(num_envs_);
     {
@@ -194,7 +202,7 @@ class VectorizedEnvironment {
     if (!batch_) { for (int i = 0; i < num_envs_; i++) body(i); return; }     // envs that never created a World
     struct Guard { BatchedWorld* b; ~Guard() { b->setFiberBatch(false); b->abortViews(); } } guard{batch_.get()};   // (after a clean run nothing is pending)
     batch_->setFiberBatch(true);
-    fibers_.run(num_envs_, body, [this] { batch_->flushViews(); });
+    fibers_.run(num_envs_, body, [this] { batch_->flushViews(); }, threads_);
   }
 
   void turnOnVisualization() { if (render_) environments_[0]->turnOnVisualization(); }
@@ -218,6 +226,7 @@ class VectorizedEnvironment {
   int getObDim() { return obDim_; }
   int getActionDim() { return actionDim_; }
   int getNumOfEnvs() { return num_envs_; }
+  int getNumOfThreads() const { return threads_; }     ///< (new) host threads the N step() bodies are dealt to
   void curriculumUpdate() { for (auto* env : environments_) env->curriculumUpdate(); }
   const std::vector<std::map<std::string, float>>& getRewardInfo() { return rewardInformation_; }
 
@@ -259,7 +268,7 @@ class VectorizedEnvironment {
   std::vector<std::map<std::string, float>> rewardInformation_;
   std::shared_ptr<BatchedWorld> batch_;
   detail::FiberScheduler fibers_;
-  int num_envs_ = 1, obDim_ = 0, actionDim_ = 0;
+  int num_envs_ = 1, obDim_ = 0, actionDim_ = 0, threads_ = 1;
   bool recordVideo_ = false, render_ = false;
   std::string resourceDir_;
   Yaml::Node cfg_;

@@ -27,9 +27,11 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <map>
@@ -89,12 +91,12 @@ class BatchedWorld {
   int gcDim() const { return blob_.nq; }
   int dof() const { return blob_.nv; }
 
-  void setTimeStep(double dt) { RSB_CHECK(rsb_set_timestep(world_, dt)); }
+  void setTimeStep(double dt) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_timestep(world_, dt)); }
   double getTimeStep() const { return rsb_get_timestep(world_); }
   double getWorldTime() const { return rsb_get_world_time(world_); }
-  void setGravity(const Vec<3>& g) { RSB_CHECK(rsb_set_gravity(world_, g.data())); }
-  void setERP(double erp, double = 0) { RSB_CHECK(rsb_set_erp(world_, erp)); }
-  void setDefaultMaterial(double friction, double restitution = 0, double resThreshold = 0) { RSB_CHECK(rsb_set_material(world_, friction, restitution, resThreshold)); }
+  void setGravity(const Vec<3>& g) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_gravity(world_, g.data())); }
+  void setERP(double erp, double = 0) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_erp(world_, erp)); }
+  void setDefaultMaterial(double friction, double restitution = 0, double resThreshold = 0) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_material(world_, friction, restitution, resThreshold)); }
   /// World::setMaterialPairProp [RECALL; upstream Materials.hpp absent]: (mu, restitution, resThreshold) of the material pair,
   /// order-free.  The terrain is the only other object of an env, so the pair table is resolved into one triple per collision
   /// primitive of the robot: (primitive's URDF material, terrain's material) -> rsb_set_collision_materials.
@@ -104,42 +106,45 @@ class BatchedWorld {
     resolveMaterials();
   }
   /// ArticulatedSystem::ignoreCollisionBetween(bodyIdx1, bodyIdx2) / self-collision on-off for every replica
-  void ignoreCollisionBetween(size_t bodyIdx1, size_t bodyIdx2) { RSB_CHECK(rsb_ignore_collision_between(world_, (int)bodyIdx1, (int)bodyIdx2)); resolveMaterials(); }
-  void setSelfCollision(bool on) { RSB_CHECK(rsb_set_self_collision(world_, on ? 1 : 0)); }
+  void ignoreCollisionBetween(size_t bodyIdx1, size_t bodyIdx2) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_ignore_collision_between(world_, (int)bodyIdx1, (int)bodyIdx2)); resolveMaterials(); }
+  void setSelfCollision(bool on) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_self_collision(world_, on ? 1 : 0)); }
   /// material of the terrain (addGround / addHeightMap's material argument)
   void setTerrainMaterial(const std::string& material) { terrainMaterial_ = material; resolveMaterials(); }
   void setContactSolverParam(double alpha_init, double alpha_min, double alpha_decay, int maxIter, double threshold) {
     RSB_CHECK(rsb_set_contact_solver_param(world_, alpha_init, alpha_min, alpha_decay, maxIter, threshold));
   }
-  void addGround(double zHeight = 0.0) { RSB_CHECK(rsb_set_ground(world_, zHeight)); }
+  void addGround(double zHeight = 0.0) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_ground(world_, zHeight)); }
   void addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
                     const std::vector<double>& height) {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     std::vector<float> h(height.begin(), height.end());
     RSFATAL_IF((int)h.size() != xSamples * ySamples, "addHeightMap: height.size() != xSamples*ySamples");
     RSB_CHECK(rsb_set_heightmap(world_, xSamples, ySamples, xSize, ySize, centerX, centerY, h.data()));
   }
   /// the whole batch at once (fast path; staged view writes are uploaded first)
-  void integrate(int nSubsteps = 1) { uploadStaged(); RSB_CHECK(rsb_integrate(world_, nSubsteps)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false; }
+  void integrate(int nSubsteps = 1) { std::lock_guard<std::recursive_mutex> lk(mu_); uploadStaged(); RSB_CHECK(rsb_integrate(world_, nSubsteps)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false; }
   /// the whole-batch M / h query; N views calling it between two flushes cost ONE launch (valid until a launch or a staged write)
   void integrate1() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     uploadStaged();
     if (queryValid_) return;
     RSB_CHECK(rsb_integrate1(world_));
     queryValid_ = true; ++queryLaunches_;
   }
-  void integrate2() { uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false; }
+  void integrate2() { std::lock_guard<std::recursive_mutex> lk(mu_); uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false; }
   long queryLaunches() const { return queryLaunches_; }   ///< launches issued by integrate1() (tests: N views -> 1 launch)
 
   // batched, caller-owned host buffers (row-major [N, dim] float32, the raisimGymTorch matrix layout)
   void setState(const float* gc, const float* gv) {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     RSB_CHECK(rsb_set_state(world_, gc, gv, nullptr, RSB_HOST)); dropStage(RSB_F_GC); dropStage(RSB_F_GV); stateCacheValid_ = false; queryValid_ = false;
     std::fill(gcMask_.begin(), gcMask_.end(), 0); std::fill(gvMask_.begin(), gvMask_.end(), 0);
   }
-  void getState(float* gc, float* gv) { uploadStaged(); RSB_CHECK(rsb_get_state(world_, gc, gv, RSB_HOST)); }
-  void setPdGains(const float* kp, const float* kd) { RSB_CHECK(rsb_set_pd_gains(world_, kp, kd)); }
-  void setPdTarget(const float* pTarget, const float* dTarget) { RSB_CHECK(rsb_set_pd_target(world_, pTarget, dTarget, RSB_HOST)); if (pTarget) dropStage(RSB_F_PTARGET); if (dTarget) dropStage(RSB_F_DTARGET); }
-  void setGeneralizedForce(const float* tau) { RSB_CHECK(rsb_set_generalized_force(world_, tau, RSB_HOST)); dropStage(RSB_F_TAU_FF); }
-  void setControlMode(ControlMode::Type m) { RSB_CHECK(rsb_set_control_mode(world_, (int)m)); }
+  void getState(float* gc, float* gv) { std::lock_guard<std::recursive_mutex> lk(mu_); uploadStaged(); RSB_CHECK(rsb_get_state(world_, gc, gv, RSB_HOST)); }
+  void setPdGains(const float* kp, const float* kd) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_pd_gains(world_, kp, kd)); }
+  void setPdTarget(const float* pTarget, const float* dTarget) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_pd_target(world_, pTarget, dTarget, RSB_HOST)); if (pTarget) dropStage(RSB_F_PTARGET); if (dTarget) dropStage(RSB_F_DTARGET); }
+  void setGeneralizedForce(const float* tau) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_generalized_force(world_, tau, RSB_HOST)); dropStage(RSB_F_TAU_FF); }
+  void setControlMode(ControlMode::Type m) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_control_mode(world_, (int)m)); }
 
  public:
   // ---- staging and caches behind the per-env views (raisim::World / raisim::ArticulatedSystem) ---------------------
@@ -163,9 +168,12 @@ class BatchedWorld {
   void readGeneralizedForce(int env, double* out, int dim) {
     requireNotPending(env, "getGeneralizedForce()");
     if (!genfValid_) {
-      genf_.resize((size_t)n_ * dim);
-      RSB_CHECK(rsb_get_field(world_, RSB_F_GENERALIZED_FORCE, genf_.data(), RSB_HOST));
-      genfValid_ = true;
+      std::lock_guard<std::recursive_mutex> lk(mu_);
+      if (!genfValid_) {
+        genf_.resize((size_t)n_ * dim);
+        RSB_CHECK(rsb_get_field(world_, RSB_F_GENERALIZED_FORCE, genf_.data(), RSB_HOST));
+        genfValid_ = true;
+      }
     }
     for (int i = 0; i < dim; ++i) out[i] = genf_[(size_t)env * dim + i];
   }
@@ -180,6 +188,7 @@ class BatchedWorld {
   }
   /// one launch for all pending replicas (no-op when none is pending)
   void flushViews() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     if (nPending_ == 0) return;
     uploadStaged();
     if (nPending_ == n_) RSB_CHECK(rsb_integrate(world_, 1));
@@ -199,16 +208,20 @@ class BatchedWorld {
   const std::vector<rsb_contact>& contactsOf(int env, int& count, int& kmax) {
     requireNotPending(env, "getContacts()");
     if (!contactsValid_) {
-      RSB_CHECK(rsb_dims(world_, nullptr, nullptr, nullptr, nullptr, &kmax_));
-      cnt_.resize(n_); con_.resize((size_t)n_ * kmax_);
-      RSB_CHECK(rsb_get_contacts(world_, cnt_.data(), con_.data(), RSB_HOST));
-      contactsValid_ = true;
+      std::lock_guard<std::recursive_mutex> lk(mu_);
+      if (!contactsValid_) {
+        RSB_CHECK(rsb_dims(world_, nullptr, nullptr, nullptr, nullptr, &kmax_));
+        cnt_.resize(n_); con_.resize((size_t)n_ * kmax_);
+        RSB_CHECK(rsb_get_contacts(world_, cnt_.data(), con_.data(), RSB_HOST));
+        contactsValid_ = true;
+      }
     }
     count = cnt_[env]; kmax = kmax_;
     return con_;
   }
   /// staged rows -> device (before a launch, or before a query that must see them)
   void uploadStaged() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     Stage& gc = stages_[RSB_F_GC]; Stage& gv = stages_[RSB_F_GV];
     if (gc.dirty || gv.dirty) {
       // masked upload: only the rows a view wrote are overwritten (and their solver warm state cleared).  A row written in
@@ -229,9 +242,11 @@ class BatchedWorld {
   }
 
  private:
-  struct Stage { std::vector<float> host; bool init = false, dirty = false; };
+  struct Stage { std::vector<float> host; std::atomic<bool> init{false}, dirty{false}; };
   Stage& stage(int field) {
     Stage& st = stages_[field];
+    if (st.init) return st;  // (fast path: no lock once the mirror exists)
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     if (!st.init) {          // the host copy starts as what the device holds
       const int dim = (field == RSB_F_GC || field == RSB_F_PTARGET) ? blob_.nq : blob_.nv;
       st.host.resize((size_t)n_ * dim);
@@ -243,6 +258,8 @@ class BatchedWorld {
   void dropStage(int field) { stages_[field].init = false; stages_[field].dirty = false; }
   /// make the GC / GV mirrors current: one download after a launch; rows staged since then keep their staged values
   void refreshState() {
+    if (stateCacheValid_ && stages_[RSB_F_GC].init && stages_[RSB_F_GV].init) return;     // (fast path without the lock)
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     if (stateCacheValid_ && stages_[RSB_F_GC].init && stages_[RSB_F_GV].init) return;
     Stage& gc = stage(RSB_F_GC); Stage& gv = stage(RSB_F_GV);
     tmpGc_.resize(gc.host.size()); tmpGv_.resize(gv.host.size());
@@ -268,6 +285,7 @@ class BatchedWorld {
   struct PairProp { double mu, restitution, resThreshold; };
   static std::string pairKey(const std::string& a, const std::string& b) { return a < b ? a + "\n" + b : b + "\n" + a; }
   void resolveMaterials() {
+    std::lock_guard<std::recursive_mutex> lk(mu_);
     const int nc = blob_.ncol;
     std::vector<double> mu(nc, -1.0), e(nc, -1.0), thr(nc, -1.0);   // negative = the world's default material
     for (int i = 0; i < nc; ++i) {
@@ -297,10 +315,14 @@ class BatchedWorld {
   int n_ = 0;
   Stage stages_[5];
   std::vector<uint8_t> pending_, gcMask_, gvMask_;
-  int nPending_ = 0, kmax_ = 0;
+  std::atomic<int> nPending_{0};
+  int kmax_ = 0;
   long viewLaunches_ = 0;
   long queryLaunches_ = 0;
-  bool fiberBatch_ = false, stateCacheValid_ = false, contactsValid_ = false, genfValid_ = false, queryValid_ = false;
+  bool fiberBatch_ = false;
+  // set once per flush by the first env that asks, read by all: the N env bodies between two flushes may run on several threads
+  std::atomic<bool> stateCacheValid_{false}, contactsValid_{false}, genfValid_{false}, queryValid_{false};
+  std::recursive_mutex mu_;   // serialises every call into the C-ABI handle (not re-entrant per handle) and the lazy downloads
   std::vector<float> genf_;
   std::vector<float> tmpGc_, tmpGv_;
   std::vector<int32_t> cnt_;

@@ -1521,7 +1521,8 @@ int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* coll
   P.bytes = 2 * bufsz * sizeof(float) + (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t);
   // fine-grained memory: stores of OTHER devices' kernels (and their system-scope flag writes) become visible without a kernel
   // boundary on this device; plain hipMalloc is the fallback where the runtime refuses the flag
-  if (hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc(&P.base, P.bytes)); }
+  static const bool coarse = std::getenv("RSB_OBS_PEER_COARSE") != nullptr;   // diagnostic: plain hipMalloc
+  if (coarse || hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc(&P.base, P.bytes)); }
   HIP_TRY(hipMemsetAsync(P.base, 0, P.bytes, w->stream));
   if (!P.idx.empty()) {
     HIP_TRY(hipMalloc(&P.d_idx, P.idx.size() * sizeof(int32_t)));

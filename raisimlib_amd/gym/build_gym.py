@@ -39,7 +39,7 @@ def build_env_module(env_dir, name=None, force=False, verbose=False):
         [os.path.join(ROOT, "include", "rsb.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
-    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wall",
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-Wall", "-pthread",
            f"-DRSG_ENVIRONMENT_HEADER=\"{header}\"", f"-DRSG_MODULE_NAME={name}",
            "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"], "-I", os.path.join(ROOT, "include"), "-I", env_dir,
            SRC, "-o", out, "-L", LIB, "-lrsb", "-Wl,-rpath,$ORIGIN"]

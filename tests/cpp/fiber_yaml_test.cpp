@@ -1,8 +1,11 @@
 // CPU-only checks of the host-side machinery behind VectorizedEnvironment<ENV>: the fiber scheduler (raisim/Fiber.hpp)
 // and the cfg.yaml subset parser (raisim/Yaml.hpp).  No GPU, no librsb.
+#include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "raisim/Fiber.hpp"
@@ -37,6 +40,38 @@ int main() {
     // an exception inside a fiber surfaces in run()
     bool threw = false;
     try { fs.run(4, [&](int i) { if (i == 2) throw std::runtime_error("boom"); FiberScheduler::current()->park(); }, [] {}); }
+    catch (const std::runtime_error& e) { threw = std::string(e.what()) == "boom"; }
+    CHECK(threw && FiberScheduler::current() == nullptr);
+  }
+  {  // the same on a pool of threads (cfg["num_threads"]): the bodies of a round run concurrently, the rounds stay lock-step,
+     // every fiber stays on the thread it started on
+    const int N = 1003, T = 7;
+    FiberScheduler fs(64 * 1024);
+    std::vector<int> parks(N, 0), done(N, 0);
+    std::vector<std::thread::id> first(N), last(N);
+    std::atomic<int> parked_now{0};
+    int flushes = 0;
+    std::vector<int> parked_at_flush;
+    const auto caller = std::this_thread::get_id();
+    bool flush_on_caller = true;
+    auto body = [&](int i) {
+      first[i] = std::this_thread::get_id();
+      const int k = 4 + (i % 3 == 0 ? 1 : 0);
+      for (int s = 0; s < k; ++s) { ++parks[i]; ++parked_now; FiberScheduler::current()->park(); }
+      last[i] = std::this_thread::get_id();
+      done[i] = 1;
+    };
+    fs.run(N, body, [&] { ++flushes; parked_at_flush.push_back(parked_now.exchange(0)); flush_on_caller = flush_on_caller && std::this_thread::get_id() == caller; }, T);
+    CHECK(flushes == 5 && flush_on_caller);
+    CHECK(parked_at_flush[0] == N && parked_at_flush[3] == N && parked_at_flush[4] == (N + 2) / 3);
+    std::vector<std::thread::id> ids;
+    for (int i = 0; i < N; ++i) {
+      CHECK(done[i] == 1 && parks[i] == 4 + (i % 3 == 0 ? 1 : 0) && first[i] == last[i]);
+      if (std::find(ids.begin(), ids.end(), first[i]) == ids.end()) ids.push_back(first[i]);
+    }
+    CHECK((int)ids.size() == T && FiberScheduler::current() == nullptr);
+    bool threw = false;     // an exception on a worker thread surfaces on the caller; the pool is joined
+    try { fs.run(64, [&](int i) { if (i == 50) throw std::runtime_error("boom"); FiberScheduler::current()->park(); }, [] {}, 4); }
     catch (const std::runtime_error& e) { threw = std::string(e.what()) == "boom"; }
     CHECK(threw && FiberScheduler::current() == nullptr);
   }

@@ -13,7 +13,7 @@ URDF = os.path.join(ROOT, "raisimlib_amd", "rsc", "anymal_c_like.urdf")
 def compile_facade():
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     lib = os.path.join(ROOT, "raisimlib_amd", "lib")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"), "-o", BIN,
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"), "-o", BIN,
                     os.path.join(ROOT, "tests", "cpp", "facade_test.cpp"), "-L", lib, "-lrsb", f"-Wl,-rpath,{lib}"],
                    check=True)
 
@@ -38,7 +38,7 @@ def test_fiber_scheduler_and_yaml_parser_on_cpu():
     """The host-side machinery of VectorizedEnvironment<ENV> (fibers parking in integrate(), cfg.yaml subset) needs no GPU."""
     os.makedirs(os.path.dirname(BIN), exist_ok=True)
     exe = os.path.join(os.path.dirname(BIN), "fiber_yaml_test")
-    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-o", exe,
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", exe,
                     os.path.join(ROOT, "tests", "cpp", "fiber_yaml_test.cpp")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "fiber_yaml_test OK" in r.stdout, r.stdout + r.stderr

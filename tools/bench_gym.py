@@ -15,13 +15,14 @@ from raisimlib_amd.gym import RaisimGymVecEnv, build_env_module, load_env_module
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 RSC = os.path.join(ROOT, "raisimlib_amd", "rsc")
-CFG = (f"num_envs: {N}\nsimulation_dt: 0.0025\ncontrol_dt: 0.01\nrender: false\naction_std: 0.3\n"
+THREADS = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+CFG = (f"num_envs: {N}\nnum_threads: {THREADS}\nsimulation_dt: 0.0025\ncontrol_dt: 0.01\nrender: false\naction_std: 0.3\n"
        "reward:\n  forwardVel:\n    coeff: 0.3\n  torque:\n    coeff: -4e-5\n")
 build_env_module(os.path.join(ROOT, "tests", "cpp", "anymal_env"), name="rsg_anymal")
 mod = load_env_module("rsg_anymal")
 rng = np.random.default_rng(0)
 acts = [rng.uniform(-1, 1, (N, 12)).astype(np.float32) for _ in range(8)]
-out = {"num_envs": N, "control_steps_timed": STEPS, "substeps_per_control_step": 4}
+out = {"num_envs": N, "control_steps_timed": STEPS, "substeps_per_control_step": 4, "num_threads_cfg": THREADS}
 
 t0 = time.perf_counter()
 env = RaisimGymVecEnv(mod.RaisimGymEnv(RSC, CFG, False), normalize_ob=False)
