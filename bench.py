@@ -82,6 +82,7 @@ def parse():
     ap.add_argument("--obs-exchange", choices=("rccl", "peer"), default="rccl",
                     help="how the per-control-step obs block reaches the other ranks: 'rccl' = all-gather (default until a multi-GPU box has "
                          "measured both), 'peer' = peer-mapped buffers written by the step kernel's epilogue (rsb_obs_peer_*: no collective, no copy kernel)")
+    ap.add_argument("--peer-no-wait", action="store_true", help="diagnostic (--obs-exchange peer): rows and flags are written, nobody waits for them")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="plumbing check without GPUs: the ranks rendezvous on gloo, all-gather a host obs block per step and "
                          "print the contract line with dry_run=true (no device world, no physics; value is not a measurement)")
@@ -444,7 +445,7 @@ def main():
     # double-buffered, so that the all-gather of control step k (RCCL, its own stream) overlaps the kernel of step k+1
     from raisimlib_amd.dist import ObsGatherer, PeerObsGatherer
     if args.obs_exchange == "peer":
-        gath = PeerObsGatherer(world, np.asarray(feet, np.int32), force=args.force_collective)
+        gath = PeerObsGatherer(world, np.asarray(feet, np.int32), force=args.force_collective, no_wait=args.peer_no_wait)
     else:
         gath = ObsGatherer(N, obs_dim, dev, overlap=args.overlap_collective, force=args.force_collective)
     obs_b, nbuf = gath.local_bufs, gath.nbuf

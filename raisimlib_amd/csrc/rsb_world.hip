@@ -1540,6 +1540,9 @@ int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* coll
 }
 
 static int obs_peer_finish_connect(rsb_world* w) {
+  // diagnostics: force the one-wave kernels instead of the stream's memory-write / memory-wait packets
+  w->peer.flag_by_kernel = std::getenv("RSB_OBS_PEER_FLAG_KERNEL") != nullptr;
+  w->peer.wait_by_kernel = std::getenv("RSB_OBS_PEER_WAIT_KERNEL") != nullptr;
   w->peer.connected = true; w->peer.step = 0;
   return RSB_OK;
 }

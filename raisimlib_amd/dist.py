@@ -92,8 +92,9 @@ class PeerObsGatherer:
     step number into every rank's flag word behind the launch; `gather` only enqueues the stream-side wait (rsb_obs_peer_wait).  Interface of ObsGatherer, so bench.py can
     switch with a flag; `local_bufs` is [None]: the control step needs no obs block of its own."""
 
-    def __init__(self, world, force_collisions, force=False):
+    def __init__(self, world, force_collisions, force=False, no_wait=False):
         self.world = world
+        self.no_wait = no_wait          # diagnostic: the producer side only (rows + flags), nobody waits for them
         self.ranks = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.active = self.ranks > 1 or force
@@ -117,7 +118,7 @@ class PeerObsGatherer:
         pass                                        # the library double-buffers by control-step parity
 
     def gather(self, k):
-        if self.active:
+        if self.active and not self.no_wait:
             self._last = self.world.obs_peer_wait()
 
     def gathered_ptr(self):
