@@ -357,10 +357,9 @@ int rsb_allgather_obs(rsb_world* w, const int32_t* collision_indices, int n_forc
  * of the chip, so a collective's copy kernel cannot overlap it and costs a kernel slot per control step (measured: 8 % at one
  * rank).  Here every rank owns a gathered buffer [n_ranks * N, obs_dim] (double-buffered by control-step parity) that the other
  * ranks map - hipIpc handles across processes, plain pointers within one process -, and the epilogue of rsb_control_step's ONE
- * launch stores each env's obs row into the buffer of every rank (the other GPUs' over xGMI); behind the launch the stream writes
- * the step number into every rank's flag array (memory-write packets of the command processor: after the kernel and the release
- * of its stores, no kernel of their own), and rsb_obs_peer_wait makes the stream wait (command-processor poll of the flag words,
- * no kernel either) until every rank has delivered the rows of the last control step issued.
+ * launch stores each env's obs row into the buffer of every rank (write-through stores; the other GPUs' over xGMI); the last wave
+ * of the launch to finish writes the step number into every rank's flag array, and rsb_obs_peer_wait makes the stream wait
+ * (command-processor poll of the flag words, no kernel) until every rank has delivered the rows of the last control step issued.
  *   rsb_obs_peer_create       allocate this rank's buffer (fine-grained device memory); `handle` (may be NULL) receives its IPC handle
  *   rsb_obs_peer_connect      handles [n_ranks][RSB_OBS_HANDLE_BYTES] of all ranks (own entry ignored), e.g. from an all-gather of the launcher
  *   rsb_obs_peer_connect_ptrs the same within ONE process: base pointers (rsb_obs_peer_base) of the other worlds, peer access enabled by the caller

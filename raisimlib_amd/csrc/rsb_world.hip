@@ -89,7 +89,7 @@ struct rsb_world {
   //   [flags, parity 0 | parity 1]            2 x RSB_MAX_RANKS uint32: flags[parity][p] = last control step whose rows rank p delivered
   struct Peer {
     int ranks = 0, rank = 0, slots = 0, od = 0;
-    bool connected = false, wait_by_kernel = false, flag_by_kernel = false;
+    bool connected = false, wait_by_kernel = false;
     void* base = nullptr; size_t bytes = 0;
     void* peer_base[RSB_MAX_RANKS] = {};
     bool imported[RSB_MAX_RANKS] = {};
@@ -350,12 +350,6 @@ __global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* 
   count[e] = 0; flags[e] = 0;
 }
 
-struct ObsFlagArgs { uint32_t* flag[RSB_MAX_RANKS]; };
-__global__ void obs_peer_flag_kernel(ObsFlagArgs fa, int n, uint32_t step) {
-  const int p = threadIdx.x;
-  if (p < n) __hip_atomic_store(fa.flag[p], step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 template <int LPE, int KMAX, int CL, int ML>
 int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool prof) {
   constexpr int EPW = 64 / LPE;
@@ -483,8 +477,13 @@ int do_integrate(rsb_world* w, int nsub) {
     const uint32_t step = ++P.step;
     const int par = (int)(step & 1u);
     const size_t bufsz = (size_t)P.ranks * w->N * P.od;
-    for (int p = 0; p < P.ranks; ++p) a.obs_peer[p] = static_cast<float*>(P.peer_base[p]) + (size_t)par * bufsz;
-    a.n_obs_peers = P.ranks; a.obs_row0 = P.rank * w->N;
+    for (int p = 0; p < P.ranks; ++p) {
+      float* pb = static_cast<float*>(P.peer_base[p]);
+      a.obs_peer[p] = pb + (size_t)par * bufsz;
+      a.obs_flag[p] = reinterpret_cast<uint32_t*>(pb + 2 * bufsz) + (size_t)par * RSB_MAX_RANKS + P.rank;
+    }
+    a.obs_ctr = reinterpret_cast<uint32_t*>(static_cast<float*>(P.base) + 2 * bufsz) + 2 * RSB_MAX_RANKS;
+    a.n_obs_peers = P.ranks; a.obs_row0 = P.rank * w->N; a.obs_step = step;
     a.obs_slots = P.slots; a.obs_idx = P.idx.empty() ? nullptr : P.d_idx;
   }
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
@@ -541,24 +540,6 @@ int do_integrate(rsb_world* w, int nsub) {
     return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
-  if (peer) {
-    // publish: this rank's step number in every rank's flag array, as memory writes of the STREAM (command-processor packets
-    // behind the launch: they execute when the kernel - and the release of its stores at its end - has completed; no kernel)
-    rsb_world::Peer& P = w->peer;
-    const size_t bufsz = (size_t)P.ranks * w->N * P.od;
-    const int par = (int)(P.step & 1u);
-    uint32_t* fl[RSB_MAX_RANKS];
-    for (int p = 0; p < P.ranks; ++p)
-      fl[p] = reinterpret_cast<uint32_t*>(static_cast<float*>(P.peer_base[p]) + 2 * bufsz) + (size_t)par * RSB_MAX_RANKS + P.rank;
-    for (int p = 0; p < P.ranks && !P.flag_by_kernel; ++p)
-      if (hipStreamWriteValue32(w->stream, fl[p], P.step, 0) != hipSuccess) { (void)hipGetLastError(); P.flag_by_kernel = true; }
-    if (P.flag_by_kernel) {   // fallback where the stream cannot write the (peer-mapped) word: a one-wave kernel does (re-writing a flag is harmless)
-      ObsFlagArgs fa;
-      for (int p = 0; p < P.ranks; ++p) fa.flag[p] = fl[p];
-      hipLaunchKernelGGL(obs_peer_flag_kernel, dim3(1), dim3(64), 0, w->stream, fa, P.ranks, P.step);
-      HIP_TRY(hipGetLastError());
-    }
-  }
   if (rec) {
     HIP_TRY(hipEventRecord(e1, w->stream));
     if (!w->ring0.empty()) { w->ring_next = (w->ring_next + 1) % w->ring0.size(); if (w->ring_count < w->ring0.size()) ++w->ring_count; }
@@ -1540,8 +1521,7 @@ int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* coll
 }
 
 static int obs_peer_finish_connect(rsb_world* w) {
-  // diagnostics: force the one-wave kernels instead of the stream's memory-write / memory-wait packets
-  w->peer.flag_by_kernel = std::getenv("RSB_OBS_PEER_FLAG_KERNEL") != nullptr;
+  // diagnostic: force the one-wave wait kernel instead of the stream's memory-wait packet
   w->peer.wait_by_kernel = std::getenv("RSB_OBS_PEER_WAIT_KERNEL") != nullptr;
   w->peer.connected = true; w->peer.step = 0;
   return RSB_OK;

@@ -1864,9 +1864,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     const bool term = ae.do_reset && ((flag & 2) != 0 || (bi & gsel) != 0);
     // the observation is the state the episode ended in (before a reset), as rsb_gather_obs would read it: written through
     // `put` to the caller's block and / or to every rank's gathered buffer (peer-mapped obs exchange, StepArgs::obs_peer)
-    auto write_obs = [&](float* ob) {
-      for (int i = s; i < nq; i += LPE) ob[i] = Q[i];
-      for (int i = s; i < nv; i += LPE) ob[nq + i] = U[i];
+    auto write_obs = [&](float* ob, bool sys) {
+      // sys: write-through stores at system scope (the peers' fine-grained gathered buffers: visible without a cache flush)
+      auto put = [&](float* p, float v) { if (PEER && sys) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); else *p = v; };
+      for (int i = s; i < nq; i += LPE) put(ob + i, Q[i]);
+      for (int i = s; i < nv; i += LPE) put(ob + nq + i, U[i]);
       const float inv_dt = 1.0f / dt;
       for (int sl = s; sl < ae.obs_slots; sl += LPE) {
         const int want = ae.obs_idx ? ae.obs_idx[sl] : sl;
@@ -1880,17 +1882,17 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             f2 = (CN[6] * l0 + CN[10] * l1 + CN[14] * l2) * inv_dt;
           }
         }
-        ob[nq + nv + 3 * sl] = f0; ob[nq + nv + 3 * sl + 1] = f1; ob[nq + nv + 3 * sl + 2] = f2;
+        put(ob + nq + nv + 3 * sl, f0); put(ob + nq + nv + 3 * sl + 1, f1); put(ob + nq + nv + 3 * sl + 2, f2);
       }
     };
     if constexpr (!PEER) {
-      if (ae.obs_out) write_obs(ae.obs_out + (size_t)env * (nq + nv + 3 * ae.obs_slots));
+      if (ae.obs_out) write_obs(ae.obs_out + (size_t)env * (nq + nv + 3 * ae.obs_slots), false);
     } else {
       // destinations: the caller's block first (when there is one), then every rank's gathered buffer
       const int own = ae.obs_out ? 1 : 0, ndst = own + ae.n_obs_peers;
       const size_t od = (size_t)(nq + nv + 3 * ae.obs_slots);
       for (int d = 0; d < ndst; ++d)
-        write_obs(d < own ? ae.obs_out + (size_t)env * od : ae.obs_peer[d - own] + (size_t)(ae.obs_row0 + env) * od);
+        write_obs(d < own ? ae.obs_out + (size_t)env * od : ae.obs_peer[d - own] + (size_t)(ae.obs_row0 + env) * od, d >= own);
     }
     if (ae.warm && s < kmax) {   // one record per contact of the last sub-step (see the prologue); empty records behind them
       float rec[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1951,6 +1953,19 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       ae.contact_count[env] = term ? 0 : nc;   // a reset env starts its episode without contacts or flags
       ae.flags[env] = term ? 0 : flag;
       ae.iters[env] = iters_used;
+    }
+  }
+  if constexpr (PEER) if (ae.n_obs_peers > 0) {
+    // publication (see StepArgs::obs_peer): this wave's rows are acknowledged, it checks in; the last wave of the launch stores the
+    // step number into every rank's flag array.  Relaxed atomics on purpose: a release at agent / system scope writes the L2 back,
+    // and nothing of this exchange lives in a write-back cache (write-through stores into fine-grained memory).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const unsigned arrived = __hip_atomic_fetch_add(ae.obs_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (arrived == gridDim.x - 1) {
+        __hip_atomic_store(ae.obs_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int p = 0; p < ae.n_obs_peers; ++p) __hip_atomic_store(ae.obs_flag[p], ae.obs_step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }

@@ -125,11 +125,16 @@ struct StepArgs {
   // multi-contact envs (>= multi_depth contacts on one limb in this sub-step: redundant sets; rsb_set_solver_multi_contact)
   int multi_depth, multi_light, multi_freeze_after, multi_stall_window;
   // peer-mapped obs exchange (rsb_obs_peer_*): the epilogue stores the env's obs row (the obs_out layout) into the gathered buffer
-  // of EVERY rank at row obs_row0 + env - plain stores through peer-mapped pointers, over xGMI for the other GPUs.  No fence, no
-  // counter in the kernel (a system-scope release per wave wrote the whole L2 back: +15 % kernel time, measured): the rows are
-  // released by the end of the kernel, and the host side enqueues the ranks' flag words behind it as stream memory writes.
+  // of EVERY rank at row obs_row0 + env - system-scope (write-through) stores through peer-mapped pointers into fine-grained
+  // memory, over xGMI for the other GPUs.  Publication without a cache flush: a wave waits for its stores to be acknowledged
+  // (s_waitcnt vmcnt(0)) and checks in on a device counter; the LAST wave of the launch then stores this rank's step number into
+  // every rank's flag array.  (A system-scope RELEASE per wave writes the whole L2 back: +15 % kernel time, measured; a stream
+  // memory-write packet behind the launch costs 8 us, a one-wave flag kernel 3 us: profiles/r03_ab_log.txt.)
   float* obs_peer[RSB_MAX_RANKS];        // [n_obs_peers] rank p's gathered buffer [n_ranks * N, obs_dim] of this control step's parity
+  uint32_t* obs_flag[RSB_MAX_RANKS];     // [n_obs_peers] &flags_of_rank_p[parity][my rank]
+  uint32_t* obs_ctr;                     // this rank's wave-arrival counter (device memory, zero between launches)
   int n_obs_peers, obs_row0;
+  uint32_t obs_step;                     // value published in the flags: the control step's sequence number (>= 1)
 };
 
 }  // namespace rsbk

@@ -88,8 +88,8 @@ class ObsGatherer:
 
 class PeerObsGatherer:
     """The same job without a collective: every rank's gathered block is mapped by the other ranks (hipIpc handles exchanged once
-    through torch.distributed), the step kernel's epilogue stores each env's obs row into all of them and the stream writes the
-    step number into every rank's flag word behind the launch; `gather` only enqueues the stream-side wait (rsb_obs_peer_wait).  Interface of ObsGatherer, so bench.py can
+    through torch.distributed), the step kernel's epilogue stores each env's obs row into all of them (write-through stores) and
+    the last wave of the launch writes the step number into every rank's flag word; `gather` only enqueues the stream-side wait (rsb_obs_peer_wait).  Interface of ObsGatherer, so bench.py can
     switch with a flag; `local_bufs` is [None]: the control step needs no obs block of its own."""
 
     def __init__(self, world, force_collisions, force=False, no_wait=False):

@@ -1,5 +1,6 @@
 """The peer-mapped obs exchange (rsb_obs_peer_*, include/rsb.h): the step kernel's epilogue stores each env's obs row into every
-rank's gathered buffer and the stream writes the step number into every rank's flag word behind the launch; no collective, no copy kernel.
+rank's gathered buffer (write-through stores) and the last wave of the launch writes the step number into every rank's flag word; no
+collective, no copy kernel, no cache flush.
 
 A 1-GPU box can check the mechanism, not the xGMI path: one rank mapped onto itself, two worlds of one process as two ranks
 (plain pointers), and two PROCESSES sharing the GPU through hipIpc handles (tests/cpp/peer_launcher.cpp)."""

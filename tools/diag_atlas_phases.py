@@ -2,15 +2,27 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from raisimlib_amd import Model, BatchedWorld, rsc_path, workload
+from raisimlib_amd import Model, BatchedWorld, rsc_path
+import bench
+regime = sys.argv[1] if len(sys.argv) > 1 else "standing"
 N = 4096
-m = Model(urdf_path=rsc_path("atlas_like.urdf"))
-w = BatchedWorld(m, N); w.set_max_contacts(16)
-gc, gv = workload.atlas_initial_state(N, m.nq, m.nv); kp, kd = workload.atlas_gains(m.nv)
-w.set_pd_gains(kp, kd); w.set_state(gc, gv)
-feet = sorted(sum((m.collision_indices("_foot_%d" % i) for i in range(4)), []))
+recipe = bench.Recipe(5, -1.0, regime)          # the benchmark's config-5 recipe: gains, targets, multi-contact solver settings
+m = recipe.model
+w = BatchedWorld(m, N)
+recipe.setup_world(w, N, 0)
+if len(sys.argv) > 2:
+    w.set_lanes_per_env(int(sys.argv[2]))
+gc, gv = recipe.initial_state(N, 0)
+w.set_state(gc, gv)
+feet = recipe.feet
 g0, v0 = gc.astype(np.float32), gv.astype(np.float32)
 dtg = np.zeros((N, m.nv), np.float32)
+class _W:   # the old script's target helper, on the recipe
+    @staticmethod
+    def atlas_targets(n, cs, nq):
+        return recipe.targets(n, cs, 0)
+workload = _W
+print("config 5, regime", regime)
 print("lanes per env", w.lanes_per_env(), "nb", m.nb, "ncol", m.ncol)
 for cs in range(60):
     w.set_pd_target(workload.atlas_targets(N, cs, m.nq), dtg); w.integrate(4); w.reset_terminated(feet, g0, v0)
