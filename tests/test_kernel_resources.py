@@ -11,7 +11,7 @@ from common import ROOT
 from raisimlib_amd import build as rb
 
 
-@pytest.mark.parametrize("lpe,kmax,ml", [(16, 8, 4), (64, 16, 12)])   # the benchmark's ANYmal-like and Atlas-like instances
+@pytest.mark.parametrize("lpe,kmax,ml", [(16, 8, 4), (32, 16, 12), (64, 16, 12)])   # the benchmark's ANYmal-like and Atlas-like (two envs / one env per wave) instances
 def test_step_instances_use_no_scratch(tmp_path, lpe, kmax, ml):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
