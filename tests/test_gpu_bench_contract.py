@@ -45,3 +45,13 @@ def test_bench_collective_path_on_one_rank(built_lib):
     b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == 1 and b["config"]["obs_all_gather"] != "none (1 rank)"
     assert len(b["ms_per_step_by_rank"]) == 1 and b["value"] > 1e6
+
+
+def test_bench_peer_obs_exchange_on_one_rank(built_lib):
+    """`--obs-exchange peer`: the rows reach the gathered block from the step kernel's epilogue (no collective); same line contract"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--preroll", "8",
+           "--force-collective", "--obs-exchange", "peer", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 1 and b["config"]["obs_all_gather"].startswith("peer-mapped") and b["value"] > 1e6
