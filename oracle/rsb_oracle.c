@@ -1118,22 +1118,34 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
          * the device - and, measured in round 3 on the standing humanoid, 9 % of the solves unconverged after 150 sweeps where
          * refreshing inside every pass leaves 2 % (see orc_params).  group_parallel = 2 forces it for every env. */
         const int light = p->group_parallel == 2 || (multi && p->multi_light);
+        /* group_parallel = 3 (ablation, "group-local sweep"): ONE snapshot per sweep - a member sees the new impulses of its own group's
+         * earlier members and the sweep-start impulses of every other group (block Jacobi across limbs per SWEEP, not per pass).  Same
+         * fixed points and sweep counts (humanoid 19.8 vs 19.4 / 16.8 vs 16.0, quadruped identical: tests/test_oracle_solver_heuristics.py).
+         * Built on the device in round 3 for the kmax > 8 classes (one masked exchange per sweep + a ds_bpermute / LDS hand-over inside
+         * the limb per pass) and measured SLOWER than the per-pass exchange (config 5 standing 10.9 vs 12.0 M): not what the device runs. */
+        const int glocal = p->group_parallel == 3;
+        double lamS[MAXK][3];
+        for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lamS[i][r] = lam[i][r];
         for (int kpos = 0; kpos < gdepth; ++kpos) {
           double lam0[MAXK][3];
           for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam0[i][r] = lam[i][r];
+          if (glocal)   /* other groups: as the sweep started; own group: current (handled per member below) */
+            for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam0[i][r] = lamS[i][r];
           for (int i = 0; i < nc; ++i) {
             if (gpos[i] != kpos && !(light && kpos == 0)) continue;
             double v[3] = {cfree[i][0], cfree[i][1], cfree[i][2]}, ln[3];
             for (int j = 0; j < nc; ++j) {
               if (j == i) continue;
-              for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam0[j][0] + G[i][j][3 * r + 1] * lam0[j][1] + G[i][j][3 * r + 2] * lam0[j][2];
+              const double* lj = (glocal && gid[j] == gid[i]) ? lam[j] : lam0[j];
+              for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lj[0] + G[i][j][3 * r + 1] * lj[1] + G[i][j][3 * r + 2] * lj[2];
             }
             if (light && kpos > 0) solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, 1, 0, 0.0, sdir[i], ln);
             else solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], ln);
             if (gpos[i] != kpos) continue;   /* light variant, pass 0: a later member only refreshed its direction */
             for (int r = 0; r < 3; ++r) {
-              double dl = alpha * (ln[r] - lam0[i][r]);
-              lam[i][r] = lam0[i][r] + dl;
+              const double base = glocal ? lam[i][r] : lam0[i][r];
+              double dl = alpha * (ln[r] - base);
+              lam[i][r] = base + dl;
               if (fabs(dl) > err) err = fabs(dl);
             }
           }

@@ -43,7 +43,9 @@ typedef struct orc_params {
   int32_t dir_per_sweep;     /* friction directions are refreshed once per sweep (all contacts, from the sweep's initial impulses) instead of inside every contact update */
   int32_t refine;            /* a contact that slipped earlier in this solve refines its direction by one guarded Newton step
                                 instead of a new global search (0 = always search) */
-  int32_t group_parallel;    /* grouped sweep: block Jacobi across limbs, Gauss-Seidel within a limb (see step_impl); 0 = sequential */
+  int32_t group_parallel;    /* grouped sweep: block Jacobi across limbs, Gauss-Seidel within a limb (see step_impl); 0 = sequential; 1 = what the device
+                                runs (impulse changes cross limbs once per pass); 2 = light passes forced; 3 = group-local sweep (ablation: they cross
+                                limbs once per sweep) */
   int32_t self_collision;    /* sphere x sphere contacts between primitives of two non-adjacent bodies of the system (see step_impl) */
   double ground_z;
   double stall_factor;       /* ... and required improvement factor per window */
