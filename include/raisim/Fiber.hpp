@@ -43,7 +43,7 @@ class FiberScheduler {
     page_ = (size_t)sysconf(_SC_PAGESIZE);
     stackBytes_ = (stackBytes + page_ - 1) / page_ * page_;
   }
-  ~FiberScheduler() { release(); }
+  ~FiberScheduler() { stopPool(); release(); }
   FiberScheduler(const FiberScheduler&) = delete;
   FiberScheduler& operator=(const FiberScheduler&) = delete;
 
@@ -103,35 +103,20 @@ class FiberScheduler {
         if (parked > 0 && !failed()) { try { onAllParked(); } catch (...) { fail(std::current_exception()); } }
       }
     } else {
-      // workers 1 .. threads-1 wait for a round number, run their block, report; the caller is worker 0 and runs the flush
-      std::mutex m;
-      std::condition_variable cv;
-      int roundNo = 0, reported = 0, liveSum = 0, parkedSum = 0;
-      bool quit = false;
-      std::vector<std::thread> pool;
-      for (int t = 1; t < threads; ++t)
-        pool.emplace_back([&, t] {
-          int seen = 0;
-          for (;;) {
-            { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return quit || roundNo != seen; }); if (quit) return; seen = roundNo; }
-            int live, parked;
-            round(t, live, parked);
-            { std::lock_guard<std::mutex> lk(m); liveSum += live; parkedSum += parked; ++reported; }
-            cv.notify_all();
-          }
-        });
+      // workers 1 .. threads-1 (a pool kept across run() calls: a control step is one run()) wait for a round number, run their
+      // block, report; the caller is worker 0 and runs the flush
+      ensurePool(threads);
+      roundFn_ = [&](int t, int& live, int& parked) { round(t, live, parked); };
       for (;;) {
-        { std::lock_guard<std::mutex> lk(m); ++roundNo; reported = 0; liveSum = parkedSum = 0; }
-        cv.notify_all();
+        { std::lock_guard<std::mutex> lk(poolMutex_); ++roundNo_; reported_ = 0; liveSum_ = parkedSum_ = 0; }
+        poolCv_.notify_all();
         int live, parked;
         round(0, live, parked);
-        { std::unique_lock<std::mutex> lk(m); liveSum += live; parkedSum += parked; ++reported; cv.wait(lk, [&] { return reported == threads; }); }
-        if (failed() || liveSum == 0) break;
-        if (parkedSum > 0) { try { onAllParked(); } catch (...) { fail(std::current_exception()); break; } }
+        { std::unique_lock<std::mutex> lk(poolMutex_); liveSum_ += live; parkedSum_ += parked; ++reported_; poolCv_.wait(lk, [&] { return reported_ == threads; }); }
+        if (failed() || liveSum_ == 0) break;
+        if (parkedSum_ > 0) { try { onAllParked(); } catch (...) { fail(std::current_exception()); break; } }
       }
-      { std::lock_guard<std::mutex> lk(m); quit = true; }
-      cv.notify_all();
-      for (auto& th : pool) th.join();
+      roundFn_ = nullptr;
     }
     if (error_) { auto e = error_; error_ = nullptr; std::rethrow_exception(e); }   // fibers left parked are simply dropped
   }
@@ -162,6 +147,29 @@ class FiberScheduler {
     failedFlag_.store(true, std::memory_order_release);
   }
   void release() { if (stacks_) munmap(stacks_, mapped_); stacks_ = nullptr; mapped_ = 0; cap_ = 0; }
+  void ensurePool(int threads) {
+    if ((int)pool_.size() == threads - 1) return;
+    stopPool();
+    int start;
+    { std::lock_guard<std::mutex> lk(poolMutex_); quit_ = false; start = roundNo_; }
+    for (int t = 1; t < threads; ++t)
+      pool_.emplace_back([this, t, start] {
+        int seen = start;     // (the round number at creation, NOT at first run: a worker that starts late must not miss round one)
+        for (;;) {
+          { std::unique_lock<std::mutex> lk(poolMutex_); poolCv_.wait(lk, [&] { return quit_ || roundNo_ != seen; }); if (quit_) return; seen = roundNo_; }
+          int live = 0, parked = 0;
+          roundFn_(t, live, parked);
+          { std::lock_guard<std::mutex> lk(poolMutex_); liveSum_ += live; parkedSum_ += parked; ++reported_; }
+          poolCv_.notify_all();
+        }
+      });
+  }
+  void stopPool() {
+    { std::lock_guard<std::mutex> lk(poolMutex_); quit_ = true; }
+    poolCv_.notify_all();
+    for (auto& th : pool_) th.join();
+    pool_.clear();
+  }
   size_t stackBytes_ = 0, page_ = 4096, mapped_ = 0;
   char* stacks_ = nullptr;
   int cap_ = 0;
@@ -171,6 +179,13 @@ class FiberScheduler {
   std::exception_ptr error_;
   std::mutex errMutex_;
   std::atomic<bool> failedFlag_{false};
+  // worker pool of the threaded rounds
+  std::vector<std::thread> pool_;
+  std::mutex poolMutex_;
+  std::condition_variable poolCv_;
+  std::function<void(int, int&, int&)> roundFn_;
+  int roundNo_ = 0, reported_ = 0, liveSum_ = 0, parkedSum_ = 0;
+  bool quit_ = false;
 };
 
 }  // namespace detail

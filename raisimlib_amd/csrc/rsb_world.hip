@@ -236,7 +236,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
     if (4 * b.ncol > 3 * kcap * cw) L.cen = take(4 * b.ncol);
     L.selft = take(4 * kcap);
   }
-  L.per_env = o;
+  L.per_env = o + rsbk::kEnvPad;
   return L;
 }
 

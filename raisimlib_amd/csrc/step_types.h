@@ -12,8 +12,18 @@ namespace rsbk {
 
 constexpr int kMaxB = RSB_MAX_BODIES;
 constexpr int kMaxC = RSB_MAX_COLLISIONS;
-constexpr int kBodySlot = 24;    // R9 r3 V6 A6 (A is reused for the delta-velocity of the final pass)
-constexpr int kUpSlot = 28;      // Ia21 Zc6 pad   (one per body)
+#ifndef RSB_X_BODYSLOT            // (layout experiments: slot pitches and the per-env pad decide the LDS bank pattern, not the instruction stream)
+#define RSB_X_BODYSLOT 24
+#endif
+#ifndef RSB_X_UPSLOT
+#define RSB_X_UPSLOT 28
+#endif
+#ifndef RSB_X_ENVPAD
+#define RSB_X_ENVPAD 0
+#endif
+constexpr int kBodySlot = RSB_X_BODYSLOT;    // R9 r3 V6 A6 (A is reused for the delta-velocity of the final pass) [+ pad]
+constexpr int kUpSlot = RSB_X_UPSLOT;        // Ia21 Zc6 pad   (one per body)
+constexpr int kEnvPad = RSB_X_ENVPAD;        // floats added to an env's LDS region (shifts the banks the wave's envs start on)
 constexpr int kFactSlot = 16;    // S6 UD6 rsD invD pad2
 constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
 constexpr int kColSlot = 12;     // per collision primitive in LDS: centre3 radius | body mu restitution res_threshold | axis3 rim (rim > 0: see rsb_model_blob::col_rim)

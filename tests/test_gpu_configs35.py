@@ -98,6 +98,19 @@ def test_population_statistics_config3():
     assert abs(s["dev_iters"][-20:].mean() - s["orc_iters"][-20:].mean()) < 0.12
 
 
+def test_population_statistics_config3_one_map_per_env():
+    """the variant SURVEY.md 8d names "to stress gathers": every env on its own 128 x 128 map (512 envs = 32 MB of maps), 60 control steps"""
+    recipe = bench.Recipe(3, -1.0, per_env_maps=True)
+    s = _run_population(recipe, 512, 60)
+    print(f"config 3, one map per env: resets device {s['dev_resets'].sum()} oracle {s['orc_resets'].sum()}; contacts {s['cnt_d'].mean():.2f} vs {s['cnt_o'].mean():.2f}")
+    assert np.isfinite(s["qd"]).all() and s["orc_resets"].sum() > 150
+    assert abs(s["dev_resets"].sum() - s["orc_resets"].sum()) <= 0.08 * s["orc_resets"].sum() + 3
+    assert np.abs(s["dev_resets"][:15] - s["orc_resets"][:15]).max() <= 3
+    for pct in (25, 50, 75):
+        assert abs(np.percentile(s["qd"][:, 2], pct) - np.percentile(s["q"][:, 2], pct)) < 1.5e-2, pct
+    assert abs(s["cnt_d"].mean() - s["cnt_o"].mean()) < 0.2
+
+
 @pytest.mark.parametrize("regime,steps", [("standing", 60), ("collapsing", 60)])
 def test_population_statistics_config5(regime, steps):
     """4096 Atlas-like envs under the benchmark's config-5 recipe (kmax 16, self-collision on, multi-contact solver settings)"""
