@@ -32,6 +32,7 @@ class Params(C.Structure):
         ("self_ignore", C.c_void_p), ("self_mu", C.c_void_p), ("self_restitution", C.c_void_p), ("self_res_threshold", C.c_void_p),
         ("hm_index", C.c_void_p),
         ("multi_depth", C.c_int32), ("multi_light", C.c_int32), ("multi_freeze_after", C.c_int32), ("multi_stall_window", C.c_int32),
+        ("body_stick", C.c_int32),
     ]
 
 

@@ -100,6 +100,29 @@ static void inv3(const double* A, double* B) {
   B[6] = c2 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 
+/* inverse of a 6 x 6 matrix by Gauss-Jordan with partial pivoting; returns 0 when a pivot is below tol * (largest |entry|) */
+static int inv6(const double* A, double* B, double tol) {
+  double a[6][12], big = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) { a[i][j] = A[6 * i + j]; a[i][6 + j] = i == j ? 1.0 : 0.0; if (fabs(a[i][j]) > big) big = fabs(a[i][j]); }
+  if (!(big > 0)) return 0;
+  for (int c = 0; c < 6; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 6; ++r) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+    if (fabs(a[piv][c]) < tol * big) return 0;
+    if (piv != c) for (int j = 0; j < 12; ++j) { double t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t; }
+    const double ip = 1.0 / a[c][c];
+    for (int j = 0; j < 12; ++j) a[c][j] *= ip;
+    for (int r = 0; r < 6; ++r) {
+      if (r == c) continue;
+      const double f = a[r][c];
+      if (f != 0.0) for (int j = 0; j < 12; ++j) a[r][j] -= f * a[c][j];
+    }
+  }
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) B[6 * i + j] = a[i][6 + j];
+  return 1;
+}
+
 /* --------------------------------------------------------------------------- kinematics */
 typedef struct kin_t {
   double pbase[3];
@@ -1124,6 +1147,130 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
          * Built on the device in round 3 for the kmax > 8 classes (one masked exchange per sweep + a ds_bpermute / LDS hand-over inside
          * the limb per pass) and measured SLOWER than the per-pass exchange (config 5 standing 10.9 vs 12.0 M): not what the device runs. */
         const int glocal = p->group_parallel == 3;
+        /* Body-level stick solve (prototype, orc_params::body_stick).  Several contacts on ONE rigid body couple through the body's
+         * 6 x 6 inverse operational inertia: G_ij = X_i L X_j^T with X_i = R_i^T [I | -[r_i]x] (contact-frame point velocity of a body
+         * twist about the contacts' centroid) - a 3k x 3k block of rank <= 6 on which the per-contact sweeps crawl.  If all k contacts
+         * stick, the body's contact points stop: with v0 = the point velocities WITHOUT the body's own impulses (a rigid twist t0,
+         * v0_i = X_i t0), the net wrench is unique, w = -L^-1 t0, and lam_i = X_i (X^T X)^-1 w is the minimum-norm distribution that
+         * produces it.  L = P (X^T G X) P with P = (X^T X)^-1 needs nothing but the blocks already there.  Accepted only when every
+         * lam_i lies inside its cone (then it IS a solution of the per-contact conditions: zero velocity, admissible impulse);
+         * otherwise the body's contacts take their ordinary passes.  The velocities it leads to are those of the per-contact
+         * iteration (the stick solution is unique in u); the split of the wrench over the redundant contacts is not unique anyway. */
+        int body_done[MAXK];
+        for (int i = 0; i < nc; ++i) body_done[i] = 0;
+        if (p->body_stick) {
+          for (int i0 = 0; i0 < nc; ++i0) {
+            if (body_done[i0] || cbody2[i0] >= 0 || lim_sign[i0] != 0.0 || i0 >= nreal) continue;
+            int idx[MAXK], k = 0;
+            for (int j = i0; j < nreal; ++j) if (cbody[j] == cbody[i0] && cbody2[j] < 0 && lim_sign[j] == 0.0 && !body_done[j]) idx[k++] = j;
+            if (k < 2) continue;
+            if (k == 2) {
+              /* two contacts on one body (a foot on its edge, a shank on knee + foot): the stick equations G_BB lam = -v0 (6 x 6) have
+               * rank 5 - the squeeze mode n = (+d, -d) along the line through the two points produces no wrench.  Solve with that known
+               * null vector deflated, (G_BB + s n n^T) lam = -v0, and project it out again: the minimum-norm all-stick impulses. */
+              const int ia = idx[0], ib = idx[1];
+              double d[3] = {cx[ib][0] - cx[ia][0], cx[ib][1] - cx[ia][1], cx[ib][2] - cx[ia][2]};
+              const double dn = sqrt(dot3(d, d));
+              if (!(dn > 1e-9)) continue;
+              for (int c = 0; c < 3; ++c) d[c] /= dn;
+              double n6[6], A[36], Ai[36], rhs[6], l6[6];
+              for (int ax = 0; ax < 3; ++ax) {
+                n6[ax] = (Rc[ia][ax] * d[0] + Rc[ia][3 + ax] * d[1] + Rc[ia][6 + ax] * d[2]) * 0.70710678118654752;
+                n6[3 + ax] = -(Rc[ib][ax] * d[0] + Rc[ib][3 + ax] * d[1] + Rc[ib][6 + ax] * d[2]) * 0.70710678118654752;
+              }
+              double tr = 0;
+              for (int a = 0; a < 2; ++a) for (int b2 = 0; b2 < 2; ++b2) for (int ra = 0; ra < 3; ++ra) for (int rb = 0; rb < 3; ++rb)
+                A[6 * (3 * a + ra) + 3 * b2 + rb] = G[idx[a]][idx[b2]][3 * ra + rb];
+              for (int c = 0; c < 6; ++c) tr += A[7 * c];
+              for (int c = 0; c < 6; ++c) for (int e2 = 0; e2 < 6; ++e2) A[6 * c + e2] += (tr / 6.0) * n6[c] * n6[e2];
+              if (!inv6(A, Ai, 1e-10)) continue;
+              for (int a = 0; a < 2; ++a) {
+                const int i = idx[a];
+                double v0[3] = {cfree[i][0], cfree[i][1], cfree[i][2]};
+                for (int j = 0; j < nc; ++j) {
+                  if (j == ia || j == ib) continue;
+                  for (int r2 = 0; r2 < 3; ++r2) v0[r2] += G[i][j][3 * r2] * lam[j][0] + G[i][j][3 * r2 + 1] * lam[j][1] + G[i][j][3 * r2 + 2] * lam[j][2];
+                }
+                for (int r2 = 0; r2 < 3; ++r2) rhs[3 * a + r2] = -v0[r2];
+              }
+              double nl = 0;
+              for (int c = 0; c < 6; ++c) { double t = 0; for (int e2 = 0; e2 < 6; ++e2) t += Ai[6 * c + e2] * rhs[e2]; l6[c] = t; }
+              for (int c = 0; c < 6; ++c) nl += n6[c] * l6[c];
+              for (int c = 0; c < 6; ++c) l6[c] -= nl * n6[c];
+              int ok2 = 1;
+              for (int a = 0; a < 2 && ok2; ++a) {
+                const double mu_i = cmu[idx[a]];
+                ok2 = l6[3 * a + 2] >= 0.0 && l6[3 * a] * l6[3 * a] + l6[3 * a + 1] * l6[3 * a + 1] <= mu_i * mu_i * l6[3 * a + 2] * l6[3 * a + 2];
+              }
+              if (!ok2) continue;
+              for (int a = 0; a < 2; ++a) {
+                const int i = idx[a];
+                for (int r2 = 0; r2 < 3; ++r2) { const double dl = l6[3 * a + r2] - lam[i][r2]; lam[i][r2] = l6[3 * a + r2]; if (fabs(dl) > err) err = fabs(dl); }
+                body_done[i] = 1;
+              }
+              continue;
+            }
+            double cen[3] = {0, 0, 0};
+            for (int a = 0; a < k; ++a) for (int c = 0; c < 3; ++c) cen[c] += cx[idx[a]][c] / k;
+            double Xb[MAXK][3][6];     /* X_i: rows = contact axes (t1, t2, n), columns = twist (v_ref, omega) */
+            for (int a = 0; a < k; ++a) {
+              const int i = idx[a];
+              const double r[3] = {cx[i][0] - cen[0], cx[i][1] - cen[1], cx[i][2] - cen[2]};
+              for (int ax = 0; ax < 3; ++ax) {
+                const double e[3] = {Rc[i][ax], Rc[i][3 + ax], Rc[i][6 + ax]};      /* column ax of Rc = the axis in world coordinates */
+                double rxe[3];
+                cross3(r, e, rxe);                                                 /* e . (omega x r) = omega . (r x e) */
+                for (int c = 0; c < 3; ++c) { Xb[a][ax][c] = e[c]; Xb[a][ax][3 + c] = rxe[c]; }
+              }
+            }
+            double XtX[36], P[36];
+            for (int q = 0; q < 36; ++q) XtX[q] = 0;
+            for (int a = 0; a < k; ++a) for (int ax = 0; ax < 3; ++ax) for (int c = 0; c < 6; ++c) for (int d = 0; d < 6; ++d) XtX[6 * c + d] += Xb[a][ax][c] * Xb[a][ax][d];
+            if (!inv6(XtX, P, 1e-9)) continue;                                      /* collinear contact points: the body can still turn about their line */
+            double XtGX[36], T1[36], Li[36], Lm[36];
+            for (int q = 0; q < 36; ++q) XtGX[q] = 0;
+            for (int a = 0; a < k; ++a) for (int b2 = 0; b2 < k; ++b2) {
+              const double* Gab = G[idx[a]][idx[b2]];
+              for (int ra = 0; ra < 3; ++ra) for (int rb = 0; rb < 3; ++rb) {
+                const double g = Gab[3 * ra + rb];
+                for (int c = 0; c < 6; ++c) for (int d = 0; d < 6; ++d) XtGX[6 * c + d] += Xb[a][ra][c] * g * Xb[b2][rb][d];
+              }
+            }
+            for (int c = 0; c < 6; ++c) for (int d = 0; d < 6; ++d) { double t = 0; for (int e2 = 0; e2 < 6; ++e2) t += P[6 * c + e2] * XtGX[6 * e2 + d]; T1[6 * c + d] = t; }
+            for (int c = 0; c < 6; ++c) for (int d = 0; d < 6; ++d) { double t = 0; for (int e2 = 0; e2 < 6; ++e2) t += T1[6 * c + e2] * P[6 * e2 + d]; Li[6 * c + d] = t; }
+            if (!inv6(Li, Lm, 1e-10)) continue;
+            /* point velocities without the body's own impulses, as a twist */
+            double xtv[6] = {0, 0, 0, 0, 0, 0};
+            for (int a = 0; a < k; ++a) {
+              const int i = idx[a];
+              double v0[3] = {cfree[i][0], cfree[i][1], cfree[i][2]};
+              for (int j = 0; j < nc; ++j) {
+                int own = 0;
+                for (int b2 = 0; b2 < k; ++b2) own |= idx[b2] == j;
+                if (own) continue;
+                for (int r2 = 0; r2 < 3; ++r2) v0[r2] += G[i][j][3 * r2] * lam[j][0] + G[i][j][3 * r2 + 1] * lam[j][1] + G[i][j][3 * r2 + 2] * lam[j][2];
+              }
+              for (int ax = 0; ax < 3; ++ax) for (int c = 0; c < 6; ++c) xtv[c] += Xb[a][ax][c] * v0[ax];
+            }
+            double t0[6], w[6], pw[6];
+            for (int c = 0; c < 6; ++c) { double t = 0; for (int d = 0; d < 6; ++d) t += P[6 * c + d] * xtv[d]; t0[c] = t; }
+            for (int c = 0; c < 6; ++c) { double t = 0; for (int d = 0; d < 6; ++d) t += Lm[6 * c + d] * t0[d]; w[c] = -t; }
+            for (int c = 0; c < 6; ++c) { double t = 0; for (int d = 0; d < 6; ++d) t += P[6 * c + d] * w[d]; pw[c] = t; }
+            double lc[MAXK][3];
+            int ok = 1;
+            for (int a = 0; a < k && ok; ++a) {
+              for (int ax = 0; ax < 3; ++ax) { double t = 0; for (int c = 0; c < 6; ++c) t += Xb[a][ax][c] * pw[c]; lc[a][ax] = t; }
+              const double mu_i = cmu[idx[a]];
+              ok = lc[a][2] >= 0.0 && lc[a][0] * lc[a][0] + lc[a][1] * lc[a][1] <= mu_i * mu_i * lc[a][2] * lc[a][2];
+            }
+            if (!ok) continue;
+            for (int a = 0; a < k; ++a) {
+              const int i = idx[a];
+              for (int r2 = 0; r2 < 3; ++r2) { const double dl = lc[a][r2] - lam[i][r2]; lam[i][r2] = lc[a][r2]; if (fabs(dl) > err) err = fabs(dl); }
+              body_done[i] = 1;
+            }
+          }
+        }
         double lamS[MAXK][3];
         for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lamS[i][r] = lam[i][r];
         for (int kpos = 0; kpos < gdepth; ++kpos) {
@@ -1133,6 +1280,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
             for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam0[i][r] = lamS[i][r];
           for (int i = 0; i < nc; ++i) {
             if (gpos[i] != kpos && !(light && kpos == 0)) continue;
+            if (body_done[i]) continue;     /* its body took the all-stick solution in this sweep */
             double v[3] = {cfree[i][0], cfree[i][1], cfree[i][2]}, ln[3];
             for (int j = 0; j < nc; ++j) {
               if (j == i) continue;

@@ -80,6 +80,9 @@ typedef struct orc_params {
    *   multi_stall_window stagnation window in such envs (default 16; 0 = no stagnation exit)
    * multi_depth = 0 switches the distinction off (every env uses freeze_after / stall_window; no light passes). */
   int32_t multi_depth, multi_light, multi_freeze_after, multi_stall_window;
+  /* body-level stick solve (round-3 prototype, off by default; see step_impl): a body with >= 3 non-collinear terrain contacts whose
+   * all-stick solution lies inside every cone gets that solution directly, once per sweep, instead of its Gauss-Seidel passes */
+  int32_t body_stick;
 } orc_params;
 
 /* collision ids reported for the two entries of a self-collision (RaiSim lists it once per body): primitive id | flag */
