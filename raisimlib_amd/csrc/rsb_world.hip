@@ -355,8 +355,15 @@ int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool prof) {
   constexpr int EPW = 64 / LPE;
   const int blocks = (w->N + EPW - 1) / EPW;
   // the profiling instance carries the cycle stamps / contact-problem dump / LDS poisoning; production launches use the lean one
-  const hipError_t e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->stream)
-                            : rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
+  // (the peer-exchange classes, CL bit 2, are built without a profiling twin: profile the exchange-free class instead)
+  hipError_t e;
+  if constexpr ((CL & 2) != 0) {
+    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange kernel class: disconnect the exchange (rsb_obs_peer_destroy) first"); return RSB_E_UNSUPPORTED; }
+    e = rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
+  } else {
+    e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->stream)
+             : rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
+  }
   HIP_TRY(e);
   return RSB_OK;
 }
