@@ -147,6 +147,14 @@ const char* rsb_version(void);
 /* ---- model (host only; cold path) -------------------------------------- */
 int rsb_model_from_urdf_file(const char* path, rsb_model** out);
 int rsb_model_from_urdf_string(const char* xml, rsb_model** out);
+/* Sampled colliders (no upstream counterpart; opt-in).  The loader turns a capsule into its two end spheres and a box into its eight
+ * corners: the exact contact sets on a plane.  With sample_spacing h > 0 a capsule also gets spheres of its radius along its axis and
+ * a box zero-radius points on the lattice of its edges and faces, no further apart than h, so that a height-field feature under the
+ * MIDDLE of a capsule or of a box face, and a capsule touching another link with its middle, are found to within h by the same sphere
+ * tests (the narrow phase of the kernel is unchanged).  Costs primitives (at most RSB_MAX_COLLISIONS per model) and adds redundant
+ * contacts where the unsampled set was already exact.  h = 0: the functions above. */
+int rsb_model_from_urdf_file_sampled(const char* path, double sample_spacing, rsb_model** out);
+int rsb_model_from_urdf_string_sampled(const char* xml, double sample_spacing, rsb_model** out);
 int rsb_model_from_blob(const rsb_model_blob* blob, rsb_model** out);
 int rsb_model_destroy(rsb_model* m);
 int rsb_model_get_blob(const rsb_model* m, rsb_model_blob* out);

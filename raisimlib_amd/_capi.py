@@ -66,6 +66,8 @@ PROTOTYPES = {
     "rsb_version": (C.c_char_p, []),
     "rsb_model_from_urdf_file": (_I, [_CP, C.POINTER(_VP)]),
     "rsb_model_from_urdf_string": (_I, [_CP, C.POINTER(_VP)]),
+    "rsb_model_from_urdf_file_sampled": (_I, [_CP, _D, C.POINTER(_VP)]),
+    "rsb_model_from_urdf_string_sampled": (_I, [_CP, _D, C.POINTER(_VP)]),
     "rsb_model_from_blob": (_I, [C.POINTER(ModelBlob), C.POINTER(_VP)]),
     "rsb_model_destroy": (_I, [_VP]),
     "rsb_model_get_blob": (_I, [_VP, C.POINTER(ModelBlob)]),

@@ -359,6 +359,7 @@ struct Builder {
   std::map<std::string, int> link_ix;
   rsb_model_blob blob;
   int skipped_collisions = 0;
+  double sample_spacing = 0.0;   // > 0: capsules and boxes also get sample primitives on their surface (rsb_model_from_urdf_*_sampled)
 
   // accumulated rigid body (a moving link + everything fixed to it)
   struct Acc { double m = 0; V3 mc; std::vector<std::pair<double, std::pair<V3, M3>>> parts; };
@@ -380,8 +381,38 @@ struct Builder {
     for (auto& c : L.cols) {
       Xf bc = compose(body_from_link, c.x);
       int n = (c.type == 1 || c.type == 4) ? 2 : (c.type == 2 ? 8 : (c.type == 3 ? (int)c.pts.size() : 1));
-      for (int e = 0; e < n; ++e) {
-        if (blob.ncol >= RSB_MAX_COLLISIONS) throw std::runtime_error("URDF: more than RSB_MAX_COLLISIONS collision spheres");
+      // Sampled colliders (opt-in): the end spheres of a capsule and the corners of a box are its exact contact set on a PLANE only.
+      // With a sample spacing h, a capsule also gets spheres of its radius along its axis and a box zero-radius points on the
+      // lattice of its edges and faces, both no further apart than h: against a height field (a ridge under the middle of a
+      // capsule, a bump under a box face) and against the other links (capsule x capsule) the contact is then found to within h -
+      // by the same sphere tests, no new narrow phase in the kernel.  More primitives, more (redundant) contacts on a plane.
+      std::vector<V3> extra;
+      if (sample_spacing > 0.0 && c.type == 1 && c.length > sample_spacing) {
+        const int seg = (int)std::ceil(c.length / sample_spacing);
+        for (int q = 1; q < seg; ++q) extra.push_back({0, 0, (0.5 - (double)q / seg) * c.length});
+      }
+      if (sample_spacing > 0.0 && c.type == 2) {
+        int nn[3];
+        for (int a = 0; a < 3; ++a) nn[a] = std::max(1, (int)std::ceil(c.size[a] / sample_spacing));
+        for (int i = 0; i <= nn[0]; ++i) for (int j = 0; j <= nn[1]; ++j) for (int k2 = 0; k2 <= nn[2]; ++k2) {
+          const int ext = (i == 0 || i == nn[0]) + (j == 0 || j == nn[1]) + (k2 == 0 || k2 == nn[2]);
+          if (ext == 0 || ext == 3) continue;      // inside the box / a corner (already a primitive)
+          extra.push_back({((double)i / nn[0] - 0.5) * c.size[0], ((double)j / nn[1] - 0.5) * c.size[1], ((double)k2 / nn[2] - 0.5) * c.size[2]});
+        }
+      }
+      for (int e = 0; e < n + (int)extra.size(); ++e) {
+        if (blob.ncol >= RSB_MAX_COLLISIONS) throw std::runtime_error("URDF: more than RSB_MAX_COLLISIONS collision primitives" + std::string(sample_spacing > 0.0 ? " (sampled colliders: use a larger spacing)" : ""));
+        if (e >= n) {   // a sample primitive
+          V3 p = bc.p + mul(bc.R, extra[e - n]);
+          int s2 = blob.ncol++;
+          blob.col_body[s2] = body;
+          blob.col_pos[s2][0] = p.x; blob.col_pos[s2][1] = p.y; blob.col_pos[s2][2] = p.z;
+          blob.col_radius[s2] = c.type == 1 ? c.radius : 0.0;
+          std::string nm2 = (c.name.empty() ? L.name : c.name) + "/s" + std::to_string(e - n);
+          std::snprintf(blob.col_name[s2], RSB_NAME_LEN, "%s", nm2.c_str());
+          std::snprintf(blob.col_material[s2], RSB_NAME_LEN, "%s", c.material.empty() ? "default" : c.material.c_str());
+          continue;
+        }
         V3 off{0, 0, 0};
         if (c.type == 1 || c.type == 4) off = {0, 0, (e == 0 ? 0.5 : -0.5) * c.length};
         if (c.type == 2) off = {(e & 1 ? 0.5 : -0.5) * c.size[0], (e & 2 ? 0.5 : -0.5) * c.size[1], (e & 4 ? 0.5 : -0.5) * c.size[2]};
@@ -460,11 +491,12 @@ struct Builder {
   }
 };
 
-static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* skipped, const std::string& base_dir = std::string()) {
+static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* skipped, const std::string& base_dir = std::string(), double sample_spacing = 0.0) {
   XmlParser parser(xml);
   auto root = parser.parse();
   if (root->tag != "robot") throw std::runtime_error("URDF: root element is <" + root->tag + ">, expected <robot>");
   Builder B;
+  B.sample_spacing = sample_spacing;
   std::memset(&B.blob, 0, sizeof B.blob);
   for (auto& k : root->kids) {
     if (k->tag == "link") {
@@ -619,11 +651,14 @@ extern "C" {
 const char* rsb_last_error(void) { return rsb::last_error(); }
 const char* rsb_version(void) { return "raisimlib_amd 0.1 (gfx950)"; }
 
-int rsb_model_from_urdf_string(const char* xml, rsb_model** out) {
-  if (!xml || !out) { rsb::set_error("rsb_model_from_urdf_string: null argument"); return RSB_E_INVALID; }
+int rsb_model_from_urdf_string(const char* xml, rsb_model** out) { return rsb_model_from_urdf_string_sampled(xml, 0.0, out); }
+int rsb_model_from_urdf_file(const char* path, rsb_model** out) { return rsb_model_from_urdf_file_sampled(path, 0.0, out); }
+
+int rsb_model_from_urdf_string_sampled(const char* xml, double sample_spacing, rsb_model** out) {
+  if (!xml || !out || !(sample_spacing >= 0.0)) { rsb::set_error("rsb_model_from_urdf_string: null argument / negative spacing"); return RSB_E_INVALID; }
   try {
     auto m = std::make_unique<rsb_model>();
-    rsb::build_from_xml(xml, &m->blob, &m->skipped_collisions);
+    rsb::build_from_xml(xml, &m->blob, &m->skipped_collisions, std::string(), sample_spacing);
     int st = rsb::validate_blob(m->blob);
     if (st != RSB_OK) return st;
     *out = m.release();
@@ -634,8 +669,8 @@ int rsb_model_from_urdf_string(const char* xml, rsb_model** out) {
   }
 }
 
-int rsb_model_from_urdf_file(const char* path, rsb_model** out) {
-  if (!path || !out) { rsb::set_error("rsb_model_from_urdf_file: null argument"); return RSB_E_INVALID; }
+int rsb_model_from_urdf_file_sampled(const char* path, double sample_spacing, rsb_model** out) {
+  if (!path || !out || !(sample_spacing >= 0.0)) { rsb::set_error("rsb_model_from_urdf_file: null argument / negative spacing"); return RSB_E_INVALID; }
   std::ifstream f(path);
   if (!f) { rsb::set_error(std::string("cannot open URDF file: ") + path); return RSB_E_INVALID; }
   std::stringstream ss;
@@ -646,7 +681,7 @@ int rsb_model_from_urdf_file(const char* path, rsb_model** out) {
     std::string dir = path;
     const size_t cut = dir.find_last_of('/');
     dir = cut == std::string::npos ? std::string(".") : dir.substr(0, cut);
-    rsb::build_from_xml(ss.str(), &m->blob, &m->skipped_collisions, dir);   // mesh files are looked up relative to the URDF
+    rsb::build_from_xml(ss.str(), &m->blob, &m->skipped_collisions, dir, sample_spacing);   // mesh files are looked up relative to the URDF
     int st = rsb::validate_blob(m->blob);
     if (st != RSB_OK) return st;
     *out = m.release();

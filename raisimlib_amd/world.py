@@ -27,13 +27,14 @@ def rsc_path(name):
 class Model:
     """Host-side articulated-system description (the role of World::addArticulatedSystem's URDF load)."""
 
-    def __init__(self, urdf_path=None, urdf_string=None, blob=None):
+    def __init__(self, urdf_path=None, urdf_string=None, blob=None, sample_spacing=0.0):
+        """sample_spacing > 0: sampled colliders (capsule axes / box surfaces get sample primitives no further apart; rsb.h)"""
         L = lib()
         h = C.c_void_p()
         if urdf_path is not None:
-            check(L.rsb_model_from_urdf_file(os.fspath(urdf_path).encode(), C.byref(h)), "rsb_model_from_urdf_file")
+            check(L.rsb_model_from_urdf_file_sampled(os.fspath(urdf_path).encode(), float(sample_spacing), C.byref(h)), "rsb_model_from_urdf_file")
         elif urdf_string is not None:
-            check(L.rsb_model_from_urdf_string(urdf_string.encode(), C.byref(h)), "rsb_model_from_urdf_string")
+            check(L.rsb_model_from_urdf_string_sampled(urdf_string.encode(), float(sample_spacing), C.byref(h)), "rsb_model_from_urdf_string")
         elif blob is not None:
             check(L.rsb_model_from_blob(C.byref(blob), C.byref(h)), "rsb_model_from_blob")
         else:

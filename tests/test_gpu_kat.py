@@ -299,3 +299,36 @@ def test_self_collision_with_the_normal_along_world_x(built_lib):
     gap = (0.2 + q[:, 8]) - (-0.2 + q[:, 7])
     assert touched > 15 and (gap > 0.08).all() and (gap < 0.1 + 1e-6).all() and np.abs(u[:, 6:]).max() < 1e-2
     w.close()
+
+
+@pytest.mark.parametrize("which", ["capsule over a ridge", "box on a bump"])
+def test_sampled_colliders_carry_the_body_on_its_middle(built_lib, which):
+    """Sampled colliders through the C-ABI (rsb_model_from_urdf_string_sampled; the oracle KAT of the same name): the sampled log / slab
+    is carried by the ridge / bump under its middle from the first step on, the unsampled one (end spheres / corners) falls past it."""
+    from test_oracle_kat import LOG_URDF, SLAB_URDF, _bump_map, _ridge_map
+    if which.startswith("capsule"):
+        urdf, hm, z0, mass, fine = LOG_URDF, _ridge_map(), 0.3 + 0.05 - 1e-4, 4.0, 0.1
+    else:
+        urdf, hm, z0, mass, fine = SLAB_URDF, _bump_map(), 0.2 + 0.05 - 1e-4, 6.0, 0.2
+    out = {}
+    for spacing in (0.0, fine):
+        m = Model(urdf_string=urdf, sample_spacing=spacing)
+        w = BatchedWorld(m, N)
+        w.add_height_map(65, 65, 3.2, 3.2, 0.0, 0.0, hm)
+        w.set_state(tile([0, 0, z0, 1, 0, 0, 0.0]), tile(np.zeros(6)))
+        w.integrate(1)
+        cnt, con = w.get_contacts()
+        first = (cnt.copy(), con.copy())
+        w.integrate(39)
+        q, _ = w.get_state()
+        assert (w.get_flags() == 0).all()
+        out[spacing] = (q.copy(), first)
+        w.close()
+    q_plain, (cnt_plain, _) = out[0.0]
+    q_samp, (cnt, con) = out[fine]
+    assert (cnt_plain == 0).all() and (q_plain[:, 2] < z0 - 0.04).all()
+    assert (cnt > 0).all() and (np.abs(q_samp[:, 2] - z0) < 2e-3).all()
+    for e in (0, N - 1):
+        c = con[e][:cnt[e]]
+        assert np.abs(c["position"][:, :2]).max() < 0.11
+        assert abs(c["impulse"][:, 2].sum() - mass * G * DT) < 1e-3 * mass * G * DT

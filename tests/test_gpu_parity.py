@@ -543,3 +543,21 @@ def test_per_env_height_maps(anymal):
     w0.integrate(40)
     assert np.abs(w0.get_state()[0] - q[sel]).max() > 1e-3
     w0.close()
+
+
+def test_sampled_collider_model_parity_on_a_height_map(built_lib):
+    """ANYmal with sampled colliders (24 primitives instead of 20: mid spheres on the leg capsules, rsb_model_from_urdf_file_sampled)
+    on a rough 64x64 map, shins and thighs lying on it: the same kernel, the same parity bar as the unsampled model."""
+    from raisimlib_amd import Model, rsc_path
+    m = Model(urdf_path=rsc_path("anymal_c_like.urdf"), sample_spacing=0.1)
+    assert m.ncol == 24
+    H = workload.smoothed_heightmap(64, 64, amplitude=0.2, seed=11)
+    hm = (64, 64, 6.4, 6.4, 0.0, 0.0, H)
+    gc, gv = standing_states(512, seed=41, z=(0.2, 0.55))          # low: knees and thighs reach the ground too
+    kp, kd = workload.anymal_gains()
+    dev, ref, o = run_one_step(m, gc, gv, gc, kp, kd, heightmap=hm, kmax=16)
+    names = m.collision_names()
+    mids = {i for i, n in enumerate(names) if "/s" in n}
+    hit = sum(int(c["collision"][k] in mids) for e, c in enumerate(ref["contacts"]) for k in range(ref["n_contacts"][e]))
+    assert ref["n_contacts"].sum() > 1000 and hit > 20              # sample spheres do make contacts here
+    check_step(dev, ref, min_conv=0.8)

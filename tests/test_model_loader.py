@@ -273,3 +273,40 @@ def test_mesh_uri_must_not_climb_out_of_the_probed_directories(built_lib, tmp_pa
     (d / "r.urdf").write_text(urdf)
     m = Model(urdf_path=str(d / "r.urdf"))
     assert m.ncol == 1 and m.skipped_collisions == 1
+
+
+def test_sampled_colliders_fill_capsule_axes_and_box_surfaces(built_lib):
+    """rsb_model_from_urdf_*_sampled: with a spacing h a capsule gets spheres of its own radius along its axis, a box zero-radius points
+    on the lattice of its edges and faces, no two neighbours further apart than h; spheres, cylinders and meshes are left as they are;
+    spacing 0 is the plain loader; too many primitives is reported with the remedy."""
+    from raisimlib_amd import Model
+    from raisimlib_amd import RsbError, rsc_path
+    log = """<robot name="log"><link name="log"><inertial><mass value="1"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial>
+     <collision name="c"><origin xyz="0 0 0.5" rpy="0 1.5707963267948966 0"/><geometry><capsule radius="0.05" length="1.0"/></geometry></collision>
+     <collision name="b"><geometry><box size="0.4 0.2 0.1"/></geometry></collision>
+     <collision name="s"><geometry><sphere radius="0.1"/></geometry></collision></link></robot>"""
+    plain, samp = Model(urdf_string=log), Model(urdf_string=log, sample_spacing=0.25)
+    assert plain.ncol == 2 + 8 + 1 and Model(urdf_string=log, sample_spacing=0.0).ncol == plain.ncol
+    names = samp.collision_names()
+    b = samp.blob
+    cap = [i for i, n in enumerate(names) if n.startswith("c/")]
+    assert len(cap) == 2 + 3                                            # 1.0 / 0.25 = 4 segments: 3 spheres between the two ends
+    xs = sorted(b.col_pos[i][0] for i in cap)
+    assert np.allclose(xs, [-0.5, -0.25, 0.0, 0.25, 0.5]) and all(abs(b.col_pos[i][2] - 0.5) < 1e-12 and b.col_radius[i] == 0.05 for i in cap)
+    box = [i for i, n in enumerate(names) if n.startswith("b/")]
+    pts = np.array([list(b.col_pos[i]) for i in box])
+    assert len(box) == 3 * 2 * 2 and all(b.col_radius[i] == 0.0 for i in box)    # lattice 3 x 2 x 2 (0.4 -> 2 cells, 0.2 and 0.1 -> 1): all on the surface
+    assert sorted(set(np.round(pts[:, 0], 9))) == [-0.2, 0.0, 0.2]
+    assert len({tuple(np.round(p, 9)) for p in pts}) == len(pts)
+    fine = Model(urdf_string=log, sample_spacing=0.1)
+    pf = np.array([list(fine.blob.col_pos[i]) for i, n in enumerate(fine.collision_names()) if n.startswith("b/")])
+    assert len(pf) == 5 * 3 * 2                                         # 4 x 2 x 1 cells, no interior lattice point with one cell in z
+    on_surface = (np.abs(np.abs(pf) - [0.2, 0.1, 0.05]) < 1e-12).any(axis=1)
+    assert on_surface.all()
+    assert [n for n in names if n.startswith("s")] == ["s"]
+    an = Model(urdf_path=rsc_path("anymal_c_like.urdf"), sample_spacing=0.1)                  # ANYmal: the leg capsules get mid spheres
+    assert an.ncol == 24 and Model(urdf_path=rsc_path("anymal_c_like.urdf")).ncol == 20
+    with pytest.raises(RsbError, match="larger spacing"):
+        Model(urdf_string=log, sample_spacing=0.01)
+    with pytest.raises(RsbError):
+        Model(urdf_string=log, sample_spacing=-1.0)

@@ -502,3 +502,61 @@ def test_self_collision_candidates_of_the_benchmark_models(anymal):
             bi, bj = b.col_body[i], b.col_body[j]
             assert i < j and bi != bj and b.parent[bi] != bj and b.parent[bj] != bi
             assert b.col_radius[i] + b.col_radius[j] > 0 and b.col_rim[i] == 0 and b.col_rim[j] == 0
+
+
+LOG_URDF = """<robot name="log"><link name="log">
+ <inertial><mass value="4"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.12" iyz="0" izz="0.12"/></inertial>
+ <collision><origin rpy="0 1.5707963267948966 0"/><geometry><capsule radius="0.05" length="0.6"/></geometry></collision>
+</link></robot>"""
+SLAB_URDF = """<robot name="slab"><link name="slab">
+ <inertial><mass value="6"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.2"/></inertial>
+ <collision><geometry><box size="0.6 0.6 0.1"/></geometry></collision>
+</link></robot>"""
+
+
+def _ridge_map(n=65, size=3.2, height=0.3, half_width=0.1):
+    """a ridge along y at x = 0 (tent profile over one cell on either side), flat elsewhere; n x n samples, cells of size / (n - 1)"""
+    xs = np.linspace(-size / 2, size / 2, n)
+    prof = np.maximum(0.0, height * (1.0 - np.abs(xs) / half_width))
+    return np.tile(prof[None, :], (n, 1)).astype(np.float32)
+
+
+def _bump_map(n=65, size=3.2, height=0.2):
+    h = np.zeros((n, n), np.float32)
+    c = n // 2
+    h[c - 3:c + 4, c - 3:c + 4] = height          # a plateau of +-0.15 m around the origin (cells of 0.05 m), sloping to the ground within one cell
+    return h
+
+
+@pytest.mark.parametrize("which", ["capsule over a ridge", "box on a bump"])
+def test_sampled_colliders_find_the_contact_under_the_middle(built_lib, which):
+    """Sampled colliders (rsb_model_from_urdf_*_sampled): a capsule lying ACROSS a ridge touches it with its middle, a slab lying on a
+    bump touches it with the middle of its bottom face - where the unsampled primitive sets (two end spheres / eight corners: exact on a
+    plane) hang in the air.  The sampled body is carried (a contact under its middle with the weight's impulse m g dt), the unsampled one
+    falls through until its ends / corners reach the ground."""
+    from raisimlib_amd import Model
+    if which.startswith("capsule"):
+        urdf, hm, z0, mass = LOG_URDF, _ridge_map(), 0.3 + 0.05 - 1e-4, 4.0
+    else:
+        urdf, hm, z0, mass = SLAB_URDF, _bump_map(), 0.2 + 0.05 - 1e-4, 6.0
+    res = {}
+    fine = 0.1 if which.startswith("capsule") else 0.2
+    for spacing in (0.0, fine):
+        m = Model(urdf_string=urdf, sample_spacing=spacing)
+        o = Oracle(m.blob)
+        o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, hm)
+        q = np.array([0, 0, z0, 1, 0, 0, 0.0]); u = np.zeros(6)
+        first = None
+        for k in range(40):
+            q, u, con, _, fl = o.step(q, u)
+            if first is None and len(con):
+                first = (k, con.copy())
+        res[spacing] = (m.ncol, q.copy(), first)
+    n0, q_plain, first_plain = res[0.0]
+    n1, q_samp, first_samp = res[fine]
+    assert n1 > n0 and n0 == (2 if which.startswith("capsule") else 8)
+    assert first_plain is None and q_plain[2] < z0 - 0.04            # 40 steps of free fall: 0.5 g t^2 = 4.9 cm, nothing touched
+    k, con = first_samp
+    assert k == 0 and abs(q_samp[2] - z0) < 2e-3                     # carried from the first step on
+    assert np.abs(con["position"][:, :2]).max() < 0.11               # under the middle, not at the ends / corners
+    assert abs(con["impulse"][:, 2].sum() - mass * 9.81 * 0.0025) < 1e-3 * mass * 9.81 * 0.0025
