@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--preroll", type=int, default=PREROLL, help="diagnostic: untimed control steps before --warmup")
     ap.add_argument("--max-iter", type=int, default=0, help="contact-solver iteration cap (0 = library default)")
     ap.add_argument("--lanes-per-env", type=int, default=0)
+    ap.add_argument("--anderson", type=int, default=-1, help="diagnostic: first sweep of the Anderson step in multi-contact envs of kmax > 8 worlds (library default 2; 0 = off)")
     ap.add_argument("--no-reset", action="store_true", help="disable the non-foot-contact termination rule")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -199,6 +200,9 @@ class Recipe:
         # stall_window).  Library default depth 3; the humanoid's feet also stand on two spheres of one edge, so config 5 uses
         # depth 2 (tests/test_oracle_solver_heuristics.py pins exactly this setting on both config-5 populations)
         self.multi_contact = (2 if config == 5 else 3, False, 0, 16)
+        # Anderson acceleration of the sweep in those envs (rsb_set_solver_anderson: first sweep, clip; kmax > 8 worlds only = config 5):
+        # the library default, spelled out so that world and oracle are set from one place (--anderson 0 switches it off for an A/B)
+        self.anderson = (2, 20.0)
         self.atlas_regime = atlas_regime
         self._terrain = {}
         if config == 5:
@@ -276,6 +280,7 @@ class Recipe:
         world.set_time_step(wl.DT)
         world.set_pd_gains(self.kp, self.kd)
         world.set_solver_multi_contact(*self.multi_contact)
+        world.set_solver_anderson(*self.anderson)
         if self.config == 3:
             maps, env_map = self.terrain(n, env_offset)
             if self.per_env_maps:
@@ -286,6 +291,7 @@ class Recipe:
     def setup_oracle(self, orc, n, env_offset):
         orc.p.kmax = self.kmax
         orc.p.multi_depth, orc.p.multi_light, orc.p.multi_freeze_after, orc.p.multi_stall_window = (int(x) for x in self.multi_contact)
+        orc.p.anderson, orc.p.anderson_clip = int(self.anderson[0]), float(self.anderson[1])
         if self.config == 3:
             wl = self.wl
             maps, env_map = self.terrain(n, env_offset)
@@ -412,6 +418,8 @@ def main():
 
     N = args.envs_per_gpu
     recipe = Recipe(args.config, args.target_amplitude, args.atlas_regime, args.per_env_maps)
+    if args.anderson >= 0:
+        recipe.anderson = (args.anderson, recipe.anderson[1])
     model, feet = recipe.model, recipe.feet
     world = BatchedWorld(model, N, device=local_rank)
     stream = torch.cuda.Stream(device=dev)       # everything below (kernels, copies, events, collectives) is ordered on it
@@ -600,7 +608,8 @@ def main():
                                    "friction_directions_lag_after_sweeps": args.freeze_after if args.freeze_after >= 0 else 6,
                                    "stagnation_exit": {"window": args.stall_window if args.stall_window >= 0 else 4, "factor": 0.5},
                                    "multi_contact_envs": {"min_contacts_on_one_limb": recipe.multi_contact[0], "light_passes": bool(recipe.multi_contact[1]),
-                                                          "friction_directions_lag_after_sweeps": recipe.multi_contact[2], "stagnation_window": recipe.multi_contact[3]},
+                                                          "friction_directions_lag_after_sweeps": recipe.multi_contact[2], "stagnation_window": recipe.multi_contact[3],
+                                                          "anderson_depth1": ({"first_sweep": recipe.anderson[0], "clip": recipe.anderson[1]} if recipe.kmax > 8 and recipe.anderson[0] > 0 else None)},
                                    "warm_start": True},
                 "self_collision": {"enabled": not args.no_self_collision, "candidate_pairs": int(len(world.self_collision_pairs()))},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",

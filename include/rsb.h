@@ -232,6 +232,16 @@ int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, doub
  * depth: default 3; 2 also covers a foot standing on one of its edges (what the humanoid benchmark uses); 0 = no distinction
  * (every env uses rsb_set_solver_friction_lag / rsb_set_solver_stagnation_exit). */
 int rsb_set_solver_multi_contact(rsb_world* w, int depth, int light_passes, int freeze_after, int stall_window);
+/* Anderson acceleration of the sweep (not RaiSim behaviour; default ON, first_sweep 2, clip 20) in multi-contact envs of worlds
+ * with more than 8 contact slots (rsb_set_max_contacts > 8: the large-model kernel classes; the quadruped's classes do not carry
+ * it - their envs converge in 3-4 sweeps).  A sweep is a fixed-point map g of the impulses; on redundant contact sets the
+ * iteration crawls along one dominant mode.  From sweep `first_sweep` on, the sweep's result g(x_k) is replaced as the START of
+ * the next sweep by the depth-1 Anderson (secant) step  x_k+1 = g(x_k) - gamma (g(x_k) - g(x_k-1)),
+ * gamma = <r_k, r_k - r_k-1> / |r_k - r_k-1|^2,  r = g(x) - x,  projected into the friction cones; |gamma| > clip drops the step.
+ * The convergence test stays the sweep's own |g(x) - x|: the fixed points are those of the per-contact iteration, and a solve
+ * never returns an extrapolated iterate unchecked.  Measured on the Atlas-like standing population (oracle): 18.8 -> 10.6 sweeps,
+ * p99 86 -> 41, unconverged 3.9 % -> 0.9 %, natural-map residual p99 2.7e-2 -> 1.1e-5.  first_sweep = 0 switches it off. */
+int rsb_set_solver_anderson(rsb_world* w, int first_sweep, double clip);
 /* Early termination (not RaiSim behaviour; default OFF): in rsb_control_step / rsb_env_step - the calls that know which
  * collision primitives may touch the terrain - an env stops integrating at the sub-step in which any other primitive
  * touches; that sub-step and the rest of the control step are not integrated for it, the detected contacts are

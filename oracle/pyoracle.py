@@ -33,6 +33,8 @@ class Params(C.Structure):
         ("hm_index", C.c_void_p),
         ("multi_depth", C.c_int32), ("multi_light", C.c_int32), ("multi_freeze_after", C.c_int32), ("multi_stall_window", C.c_int32),
         ("body_stick", C.c_int32),
+        ("anderson", C.c_int32),
+        ("anderson_clip", C.c_double),
     ]
 
 

@@ -329,6 +329,7 @@ void orc_default_params(orc_params* p) {
   p->ground_z = 0.0;
   p->hm_index = NULL;
   p->multi_depth = 3; p->multi_light = 0; p->multi_freeze_after = 0; p->multi_stall_window = 16;
+  p->anderson = 2; p->anderson_clip = 20.0;
 }
 
 void orc_mass_matrix(const rsb_model_blob* m, const double* q, double* M) {
@@ -1122,9 +1123,13 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     const int multi = p->multi_depth > 0 && gdepth >= p->multi_depth;
     const int freeze_after = multi ? p->multi_freeze_after : p->freeze_after;
     const int stall_window = multi ? p->multi_stall_window : p->stall_window;
+    double aa_x[MAXK][3], aa_g[MAXK][3], aa_r[MAXK][3], aa_next[MAXK][3];
+    int aa_have = 0, aa_apply = 0;
+    const int aa_on = p->anderson > 0 && multi && p->kmax > 8;   /* the device carries it in its large-model kernel classes only */
     for (int it = 0; it < p->max_iter; ++it) {
       double err = 0, scale = 0;
       const int lag = freeze_after > 0 && it >= freeze_after;
+      if (aa_on) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) aa_x[i][r] = lam[i][r];
       if (p->group_parallel) {
         /* Grouped sweep (what the device runs).  Contacts are grouped by the limb they sit on: the subtree hanging off the
          * base that holds the contact's body; contacts on the base itself form one more group.  Contacts of DIFFERENT limbs
@@ -1338,6 +1343,31 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         }
       }
       }   /* sequential sweeps (ablations) */
+      if (aa_on) {
+        /* Anderson acceleration, depth 1 (orc_params::anderson).  A sweep is a fixed-point map g; with x the impulses the
+         * sweep started from, r = g(x) - x.  From two consecutive pairs the secant step x+ = g - gamma (g - g_prev),
+         * gamma = <r, r - r_prev> / |r - r_prev|^2, is exact for an affine contraction with one dominant mode - which is what the
+         * crawl of redundant sticking contact sets is - and is projected back into the friction cones.  The convergence test stays
+         * the sweep's own |g(x) - x|: an extrapolated iterate is only ever the START of a sweep, never returned unchecked. */
+        double rr[MAXK][3], num = 0, den = 0;
+        for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) rr[i][r] = lam[i][r] - aa_x[i][r];
+        if (aa_have && it + 1 >= p->anderson) {
+          for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) { const double dr = rr[i][r] - aa_r[i][r]; num += rr[i][r] * dr; den += dr * dr; }
+        }
+        double gam = den > 1e-300 ? num / den : 0.0;
+        if (!(fabs(gam) <= p->anderson_clip)) gam = 0.0;
+        for (int i = 0; i < nc; ++i) {
+          double xn[3];
+          for (int r = 0; r < 3; ++r) { xn[r] = lam[i][r] - gam * (lam[i][r] - aa_g[i][r]); aa_g[i][r] = lam[i][r]; aa_r[i][r] = rr[i][r]; }
+          if (xn[2] <= 0.0) xn[0] = xn[1] = xn[2] = 0.0;
+          else {
+            const double t = sqrt(xn[0] * xn[0] + xn[1] * xn[1]), lim = cmu[i] * xn[2];
+            if (t > lim) { xn[0] *= lim / t; xn[1] *= lim / t; }
+          }
+          for (int r = 0; r < 3; ++r) aa_next[i][r] = xn[r];
+        }
+        aa_have = 1; aa_apply = gam != 0.0;
+      }
       for (int i = 0; i < nc; ++i) if (lam[i][2] > scale) scale = lam[i][2];
       it_used = it + 1;
       alpha = alpha * p->alpha_decay;
@@ -1353,6 +1383,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         if (best_cur > p->stall_factor * best_prev) break;
         best_prev = best_cur; best_cur = 1e300;
       }
+      if (aa_on && aa_apply) for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam[i][r] = aa_next[i][r];
     }
     if (!converged) {
       /* per-contact iteration that cycles or crawls can sit at a wild iterate when it is cut off (measured: a

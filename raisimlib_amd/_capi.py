@@ -100,6 +100,7 @@ PROTOTYPES = {
     "rsb_set_solver_stagnation_exit": (_I, [_VP, _I, _D]),
     "rsb_set_solver_friction_lag": (_I, [_VP, _I, _I, _D]),
     "rsb_set_solver_multi_contact": (_I, [_VP, _I, _I, _I, _I]),
+    "rsb_set_solver_anderson": (_I, [_VP, _I, _D]),
     "rsb_set_early_termination": (_I, [_VP, _I]),
     "rsb_set_solver_warm_start": (_I, [_VP, _I]),
     "rsb_set_max_contacts": (_I, [_VP, _I]),

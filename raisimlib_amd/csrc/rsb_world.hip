@@ -84,6 +84,7 @@ struct rsb_world {
   double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
   int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
+  int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
   //   [flags, parity 0 | parity 1]            2 x RSB_MAX_RANKS uint32: flags[parity][p] = last control step whose rows rank p delivered
@@ -224,7 +225,9 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   // Delassus phase writes its blocks over both)
   const int gsize = tri ? (kcap * (kcap + 1) / 2) * 12 : 3 * kcap * L.gstride;
   const int upsize = b.nb * rsbk::kUpSlot + (tri ? b.nb * rsbk::kFactSlot : 0);
-  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 4) * rsbk::kHmSlots + RSB_MAX_COLLISIONS}));
+  // (one narrow-phase slot per primitive: every sphere of the model may be near the ground at once - a robot lying in a hollow)
+  L.hm_slots = std::max(rsbk::kHmSlots, (int)b.ncol);
+  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 4) * L.hm_slots + RSB_MAX_COLLISIONS}));
   if (tri) L.fact = L.g + b.nb * rsbk::kUpSlot;
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
@@ -508,6 +511,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
   a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
   a.multi_depth = w->multi_depth; a.multi_light = w->multi_light; a.multi_freeze_after = w->multi_freeze_after; a.multi_stall_window = w->multi_stall_window;
+  a.anderson = w->anderson; a.anderson_clip = (float)w->anderson_clip;
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {
@@ -790,6 +794,11 @@ int rsb_set_solver_friction_lag(rsb_world* w, int freeze_after, int refine, doub
 int rsb_set_solver_multi_contact(rsb_world* w, int depth, int light_passes, int freeze_after, int stall_window) {
   if (!w || depth < 0 || freeze_after < 0 || stall_window < 0) { rsb::set_error("rsb_set_solver_multi_contact: depth, freeze_after, stall_window >= 0"); return RSB_E_INVALID; }
   w->multi_depth = depth; w->multi_light = light_passes != 0; w->multi_freeze_after = freeze_after; w->multi_stall_window = stall_window;
+  return RSB_OK;
+}
+int rsb_set_solver_anderson(rsb_world* w, int first_sweep, double clip) {
+  if (!w || first_sweep < 0 || !(clip > 0.0)) { rsb::set_error("rsb_set_solver_anderson: first_sweep >= 0 (0 = off), clip > 0"); return RSB_E_INVALID; }
+  w->anderson = first_sweep; w->anderson_clip = clip;
   return RSB_OK;
 }
 int rsb_set_early_termination(rsb_world* w, int on) {

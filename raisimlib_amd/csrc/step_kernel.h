@@ -853,11 +853,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       //   (2) lane = (slot, cell): the four lanes of a quad scan the cells of one slot, two triangles each, and agree on the
       //       closest feature (DPP quad minimum of the candidate keys); its lane resolves depth and normal;
       //   (3) lane = primitive again: contacts in primitive order.
-      // Scratch: the first (kHmRec + 4) * kHmSlots + ncol floats of the Delassus rows (dead here; finite values only, the up pass
+      // Scratch: the first (kHmRec + 4) * hm_slots + ncol floats of the Delassus rows (dead here; finite values only, the up pass
       // overwrites most of them with its hand-over slots).
-      float* REC = G;                                         // [kHmSlots][kHmRec] x y z r | ix0 iy0 nx ny | c (relative to the base) pad | 4 x 4 corner heights
-      float* RES = G + kHmRec * kHmSlots;                     // [kHmSlots][4] depth, normal
-      int* SLOTOF = reinterpret_cast<int*>(G + (kHmRec + 4) * kHmSlots);   // [ncol] slot + 1 of each primitive, 0 = dropped
+      const int hm_slots = L.hm_slots;                        // one per primitive of the model (>= kHmSlots)
+      float* REC = G;                                         // [hm_slots][kHmRec] x y z r | ix0 iy0 nx ny | c (relative to the base) pad | 4 x 4 corner heights
+      float* RES = G + kHmRec * hm_slots;                     // [hm_slots][4] depth, normal
+      int* SLOTOF = reinterpret_cast<int*>(G + (kHmRec + 4) * hm_slots);   // [ncol] slot + 1 of each primitive, 0 = dropped
       int nnear = 0;
       for (int c0 = 0; c0 < ncol; c0 += LPE) {
         const int ci = c0 + s;
@@ -887,8 +888,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const unsigned long long bal = __ballot(near);
         const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
         const int slot = nnear + __popcll(gm & ((1ull << s) - 1ull));
-        const bool take = near && slot < kHmSlots;
-        if (near && !take) flag |= 1;                        // more spheres near the ground than slots: reported as a contact overflow
+        const bool take = near && slot < hm_slots;
         if (take) {
           const float R[12] = {pbx + c[0], pby + c[1], pbz + c[2], rad, __int_as_float(ix0), __int_as_float(iy0), __int_as_float(nx), __int_as_float(ny),
                                c[0], c[1], c[2], 0.f};
@@ -898,7 +898,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         if (ci < ncol) SLOTOF[ci] = take ? slot + 1 : 0;
         nnear += __popcll(gm);
       }
-      nnear = min(nnear, kHmSlots);
+      if (nnear > hm_slots) flag |= 1;                        // more spheres near the ground than slots (cannot happen with one slot per primitive): a contact overflow
+      nnear = min(nnear, hm_slots);
       const int nnw = env_groups_max<LPE>(nnear);
       __syncthreads();
       for (int k0 = 0; k0 < nnw; k0 += LPE / 4) {
@@ -1518,6 +1519,14 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           sw_env = multi ? (ag.multi_stall_window > 0 ? ag.multi_stall_window : -1) : sw_env;
           gdw = env_groups_max<LPE>(gd);
         }
+        // Anderson acceleration of the sweep map (oracle: orc_params::anderson; rsb_set_solver_anderson) - the large-model classes
+        // only: the quadruped's sweep loop has no register to spare and its envs converge in 3-4 sweeps.  aa_x: the impulse the sweep
+        // started from; aa_g / aa_r: the previous sweep's result and residual.
+        constexpr bool AA = TRI;
+        const int aa_first = AA ? ag.anderson : 0;
+        const float aa_clip = ag.anderson_clip;
+        const bool aa_on = AA && multi && aa_first > 0;
+        float aa_x[3] = {0.f, 0.f, 0.f}, aa_g[3] = {0.f, 0.f, 0.f}, aa_r[3] = {0.f, 0.f, 0.f};
 
         // exchange of impulse changes: lane i adds G_ij x_j for every contact j of its env (x_j broadcast from lane j of the
         // row).  Contacts 0-3 run as one straight block whatever the count (a slot its env does not use carries x = 0 against a
@@ -1625,6 +1634,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           // lane mask (scalar work: the sweep loop has no vector register to spare)
           const bool lag = multi ? (multi_fa > 0 && it >= multi_fa) : (freeze_after > 0 && it >= freeze_after);
           float err = 0.f;
+          if constexpr (AA) { aa_x[0] = lam[0]; aa_x[1] = lam[1]; aa_x[2] = lam[2]; }
           for (int kp = 0; kp < gdw; ++kp) {
             const bool mine = isc & !done & (gpos == kp);
             if (PROF && a.prof) ++p_solves;
@@ -1723,6 +1733,35 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           }
           lap(t_epi);
           if (!__any(!done)) break;
+          if constexpr (AA) {
+            if (__any(aa_on & !done)) {
+              // x+ = g - gamma (g - g_prev), gamma = <r, r - r_prev> / |r - r_prev|^2 over the env's contacts (they sit in the env's
+              // first row: one DPP row reduction each), back into the cone, and one exchange of the change so that v follows
+              float rr[3], num = 0.f, den = 0.f;
+              RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) {
+                rr[q2] = lam[q2] - aa_x[q2];
+                const float dr = rr[q2] - aa_r[q2];
+                num = fmaf(rr[q2], dr, num); den = fmaf(dr, dr, den);
+              }
+              num = row_sum_f32(isc ? num : 0.f); den = row_sum_f32(isc ? den : 0.f);
+              if constexpr (LPE > 16) {   // (lanes beyond the env's first row hold no contact; they follow the first row's verdict for uniformity only)
+                num = __shfl(num, (lane & ~(LPE - 1)) | (lane & 15)); den = __shfl(den, (lane & ~(LPE - 1)) | (lane & 15));
+              }
+              const bool use = aa_on & !done & (it >= 1) & (it + 1 >= aa_first) & (den > 1e-30f);
+              float gam = use ? num / den : 0.f;
+              gam = (fabsf(gam) <= aa_clip) ? gam : 0.f;
+              float xn[3], dl[3];
+              RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) { xn[q2] = fmaf(-gam, lam[q2] - aa_g[q2], lam[q2]); aa_g[q2] = lam[q2]; aa_r[q2] = rr[q2]; }
+              const float t2 = fmaf(xn[1], xn[1], xn[0] * xn[0]), lim = mu * xn[2];
+              const float sh = (t2 > lim * lim) ? lim * __builtin_amdgcn_rsqf(t2) : 1.f;
+              const bool off = xn[2] <= 0.f;
+              xn[0] = off ? 0.f : xn[0] * sh; xn[1] = off ? 0.f : xn[1] * sh; xn[2] = off ? 0.f : xn[2];
+              const bool app = isc & (gam != 0.f);
+              RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) { dl[q2] = app ? xn[q2] - lam[q2] : 0.f; lam[q2] += dl[q2]; }
+              float unused = 0.f;
+              exchange(dl, unused);
+            }
+          }
         }
         if (PROF && pfine) tz0 = t_prev;
         if (!converged) { flag |= 4; lam[0] = lam_best[0]; lam[1] = lam_best[1]; lam[2] = lam_best[2]; }

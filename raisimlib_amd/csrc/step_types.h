@@ -40,7 +40,7 @@ constexpr float kSelfReg = 1e-4f;      // == ORC_SELF_REG: compliance of a self-
 constexpr int kWarmRec = 8;           // floats per warm-state record in HBM: impulse (3), friction direction (2), direction valid, primitive + 1, pad
 constexpr int kWarmRow = kWarmRec * RSB_MAX_CONTACTS;   // floats per env row of StepArgs::warm
 constexpr int kHmRec = 28;            // floats per slot of the height-map narrow phase: sphere, cell range, 4 x 4 corner heights
-constexpr int kHmSlots = 16;          // spheres per env the height-map narrow phase examines in one sub-step (those near the ground)
+constexpr int kHmSlots = 16;          // least number of slots of the height-map narrow phase (LdsLayout::hm_slots: one per primitive of the model)
 
 struct DevModel {
   int nb, nq, nv, ncol, depth, cw;  // cw: compact contact-column width = 6 + depth-1 rounded up to 4
@@ -67,6 +67,7 @@ struct LdsLayout {
   int cen, selft;   // self-collision: primitive centres [ncol][4] (may alias wc: dead before the contact columns), per-slot pair record [kcap][4]
   int gstride;
   int per_env;
+  int hm_slots;     // spheres per env the height-map narrow phase can examine in one sub-step (= the model's primitives, at least kHmSlots)
 };
 
 struct StepArgs {
@@ -134,6 +135,9 @@ struct StepArgs {
   float* tau_out;              // [N, nv] optional: the generalized force the actuators applied in the last sub-step (rsb_enable_generalized_force_output)
   // multi-contact envs (>= multi_depth contacts on one limb in this sub-step: redundant sets; rsb_set_solver_multi_contact)
   int multi_depth, multi_light, multi_freeze_after, multi_stall_window;
+  // Anderson acceleration of the sweep map in multi-contact envs of the KMAX > 8 classes (rsb_set_solver_anderson): first sweep (0 = off), clip
+  int anderson;
+  float anderson_clip;
   // peer-mapped obs exchange (rsb_obs_peer_*): the epilogue stores the env's obs row (the obs_out layout) into the gathered buffer
   // of EVERY rank at row obs_row0 + env - system-scope (write-through) stores through peer-mapped pointers into fine-grained
   // memory, over xGMI for the other GPUs.  Publication without a cache flush: a wave waits for its stores to be acknowledged

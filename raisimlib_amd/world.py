@@ -223,6 +223,10 @@ class BatchedWorld:
         check(self.L.rsb_set_solver_multi_contact(self.handle, int(depth), int(bool(light_passes)), int(freeze_after), int(stall_window)),
               "rsb_set_solver_multi_contact")
 
+    def set_solver_anderson(self, first_sweep=2, clip=20.0):
+        """Anderson acceleration of the sweep in multi-contact envs of worlds with > 8 contact slots (see rsb.h). first_sweep 0 = off."""
+        check(self.L.rsb_set_solver_anderson(self.handle, int(first_sweep), float(clip)), "rsb_set_solver_anderson")
+
     def set_early_termination(self, on=True):
         check(self.L.rsb_set_early_termination(self.handle, 1 if on else 0), "rsb_set_early_termination")
 

@@ -213,3 +213,34 @@ def test_atlas_parity_from_the_benchmarks_stationary_states(regime):
     print(f"   after 12 integrate(): |dq| median {np.median(eq):.1e} p90 {np.percentile(eq, 90):.1e} p99 {np.percentile(eq, 99):.1e} max {eq.max():.1e}")
     assert np.isfinite(qd).all() and np.median(eq) < 2e-5 and np.percentile(eq, 90) < 2e-3
     assert eq.max() < (0.05 if regime == "standing" else 0.5)     # worst env: a standing robot cannot drift apart; a collapsing one hits the ground elsewhere
+
+
+def test_anderson_step_on_the_device_matches_the_oracles_with_it_on_and_off():
+    """rsb_set_solver_anderson through the C-ABI on the standing humanoids' stationary states: with the step off device and oracle run the
+    plain grouped sweep and agree as before; with it on (the default) both need about half the sweeps, and still agree."""
+    recipe = bench.Recipe(5, -1.0, "standing")
+    n = 1024
+    q0, u0 = _stationary_states(recipe, n, 40)
+    kp, kd = recipe.kp.astype(np.float64), recipe.kd.astype(np.float64)
+    pt = f32(recipe.targets(n, 40, 0)); dtg = np.zeros((n, recipe.model.nv))
+    mean_sweeps = {}
+    for first in (0, 2):
+        recipe.anderson = (first, 20.0)
+        w = _device_world(recipe, n)
+        w.set_pd_target(pt, dtg); w.set_state(q0, u0)
+        o = _oracle(recipe, n)
+        warm = o.new_warm_state(n)
+        for k in range(3):                       # three integrate() calls: the second and third start warm
+            w.integrate(1)
+            r = o.step_batch(q0 if k == 0 else r["q"], u0 if k == 0 else r["u"], 1, kp, kd, pt, dtg, lam_warm=warm)
+        q1, u1 = w.get_state(); fl = w.get_flags(); its = w.get_solver_iterations(); cnt, _ = w.get_contacts()
+        w.close()
+        conv = (cnt == r["n_contacts"]) & (((r["flags"] | fl) & 4) == 0)
+        eu = np.abs(u1 - r["u"]).max(axis=1) / (1 + np.abs(r["u"]).max(axis=1))
+        mean_sweeps[first] = (its.mean(), r["iters"].mean(), np.percentile(its, 99), ((fl & 4) != 0).mean())
+        print(f"anderson first sweep {first}: sweeps device {its.mean():.2f} (p99 {np.percentile(its, 99):.0f}) oracle {r['iters'].mean():.2f}, unconverged device {100 * ((fl & 4) != 0).mean():.1f} % "
+              f"oracle {100 * ((r['flags'] & 4) != 0).mean():.1f} %, |du| rel median {np.median(eu[conv]):.1e} p99 {np.percentile(eu[conv], 99):.1e}")
+        assert conv.mean() > 0.8 and np.median(eu[conv]) < 1e-3 and np.percentile(eu[conv], 99) < 2e-2
+        assert abs(its.mean() - r["iters"].mean()) < 0.15 * r["iters"].mean() + 0.3
+    assert mean_sweeps[2][0] < 0.7 * mean_sweeps[0][0] and mean_sweeps[2][2] < 0.7 * mean_sweeps[0][2]
+    assert mean_sweeps[2][3] <= mean_sweeps[0][3] + 0.005

@@ -144,8 +144,8 @@ def _atlas_oracle(recipe, **kw):
     return o
 
 
-_PLAIN = dict(group_parallel=0, dir_per_sweep=0, freeze_after=0, stall_window=0, refine=0, warm_start=0, max_iter=2000, threshold=1e-10, multi_depth=0)
-_ROUND2 = dict(multi_depth=3, multi_light=1, multi_freeze_after=6, multi_stall_window=4)     # what rounds 1-2 shipped
+_PLAIN = dict(group_parallel=0, dir_per_sweep=0, freeze_after=0, stall_window=0, refine=0, warm_start=0, max_iter=2000, threshold=1e-10, multi_depth=0, anderson=0)
+_ROUND2 = dict(multi_depth=3, multi_light=1, multi_freeze_after=6, multi_stall_window=4, anderson=0)     # what rounds 1-2 shipped
 
 
 def _natural_map_residuals(recipe, samples, every, **kw):
@@ -293,10 +293,10 @@ def test_body_level_stick_solve_prototype():
     for regime, gain in (("standing", 0.90), ("collapsing", 0.65)):
         recipe = bench.Recipe(5, -1.0, regime)
         samples, _ = _atlas_population(recipe, 64, 60, 30, depth=2)
-        base = _natural_map_residuals(recipe, samples, 1, multi_depth=2)
-        body = _natural_map_residuals(recipe, samples, 1, multi_depth=2, body_stick=1)
+        base = _natural_map_residuals(recipe, samples, 1, multi_depth=2, anderson=0)       # (recorded without the Anderson step, as prototyped)
+        body = _natural_map_residuals(recipe, samples, 1, multi_depth=2, body_stick=1, anderson=0)
         kp, kd = recipe.kp.astype(np.float64), recipe.kd.astype(np.float64)
-        a, b = _atlas_oracle(recipe, multi_depth=2), _atlas_oracle(recipe, multi_depth=2, body_stick=1)
+        a, b = _atlas_oracle(recipe, multi_depth=2, anderson=0), _atlas_oracle(recipe, multi_depth=2, body_stick=1, anderson=0)
         ia, ib, du = [], [], []
         for q, u, pt, w in samples:
             z = np.zeros((q.shape[0], recipe.model.nv))
@@ -309,3 +309,47 @@ def test_body_level_stick_solve_prototype():
         assert ib.mean() <= gain * ia.mean()                                        # measured 18.5 -> 14.9 (standing), 16.3 -> 9.0 (collapsing)
         assert np.percentile(body[:, 0], 90) <= 2e-5 and body[:, 1].mean() <= base[:, 1].mean() + 0.01
         assert np.percentile(du, 90) <= 1e-4 and np.percentile(du, 99) <= 5e-3      # the same velocities wherever both converge
+
+
+def test_anderson_acceleration_of_the_sweep_on_redundant_contact_sets():
+    """Depth-1 Anderson acceleration of the sweep map (orc_params::anderson; what the device's large-model classes run): on the
+    humanoid's redundant contact sets the per-contact iteration crawls along one dominant mode, and the secant step takes it out -
+    about half the sweeps, a third of the p99, most of the unconverged solves gone, and natural-map residuals that are BETTER
+    (fewer solves are cut off).  Recorded against the same iteration without it."""
+    import bench
+    for regime, (mean_gain, p99_gain) in (("standing", (0.65, 0.6)), ("collapsing", (0.7, 0.5))):
+        recipe = bench.Recipe(5, -1.0, regime)
+        samples, _ = _atlas_population(recipe, 128, 70, 30, depth=2)
+        kp, kd = recipe.kp.astype(np.float64), recipe.kd.astype(np.float64)
+        out = {}
+        for name, kw in (("off", dict(multi_depth=2, anderson=0)), ("on", dict(multi_depth=2))):
+            o = _atlas_oracle(recipe, **kw)
+            assert o.p.anderson == (0 if name == "off" else 2)          # on by default
+            its, fl, us = [], [], []
+            for q, u, pt, w in samples:
+                r = o.step_batch(q, u, 1, kp, kd, pt, np.zeros((q.shape[0], recipe.model.nv)), lam_warm=w.copy())
+                its.append(r["iters"]); fl.append(r["flags"]); us.append(r["u"])
+            R = _natural_map_residuals(recipe, samples[::4], 2, **kw)
+            out[name] = (np.concatenate(its), (np.concatenate(fl) & 4) != 0, np.concatenate(us), R)
+        (i0, f0, u0, R0), (i1, f1, u1, R1) = out["off"], out["on"]
+        du = np.abs(u0 - u1).max(axis=1)[~f0 & ~f1]
+        print(f"config 5 {regime}: sweeps {i0.mean():.1f} -> {i1.mean():.1f}, p99 {np.percentile(i0, 99):.0f} -> {np.percentile(i1, 99):.0f}, max {i0.max()} -> {i1.max()}, "
+              f"unconverged {100 * f0.mean():.1f} % -> {100 * f1.mean():.1f} %, residual p99 {np.percentile(R0[:, 0], 99):.1e} -> {np.percentile(R1[:, 0], 99):.1e}, "
+              f"|du| between them p90 {np.percentile(du, 90):.1e} p99 {np.percentile(du, 99):.1e}")
+        # measured: standing 18.8 -> 10.6, p99 86 -> 41, unconverged 3.9 -> 0.9 %, residual p99 2.7e-2 -> 1.1e-5; collapsing 15.1 -> 9.2, p99 66 -> 22
+        assert i1.mean() <= mean_gain * i0.mean() and np.percentile(i1, 99) <= p99_gain * np.percentile(i0, 99)
+        assert f1.mean() <= 0.5 * f0.mean() + 1e-3
+        assert np.percentile(R1[:, 0], 90) <= 1e-5 and np.percentile(R1[:, 0], 99) <= max(2e-5, np.percentile(R0[:, 0], 99))
+        assert np.percentile(du, 90) <= 1e-4 and np.percentile(du, 99) <= 2e-3      # the same velocities (non-unique problems aside)
+
+
+def test_anderson_acceleration_leaves_the_quadruped_classes_alone():
+    """kmax <= 8 worlds (the quadruped's kernel classes) do not carry the step: bit-identical results with the parameter on or off."""
+    m = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+    samples = _population(m, 64, 40, 30, False)
+    kp, kd = (a.astype(np.float64) for a in workload.anymal_gains())
+    a, b = Oracle(m.blob), Oracle(m.blob)
+    b.p.anderson = 0
+    for q, u, pt, w in samples:
+        ra = a.step_batch(q, u, 1, kp, kd, pt, np.zeros((64, 18)), lam_warm=w.copy()); rb = b.step_batch(q, u, 1, kp, kd, pt, np.zeros((64, 18)), lam_warm=w.copy())
+        assert np.array_equal(ra["u"], rb["u"]) and np.array_equal(ra["iters"], rb["iters"])
