@@ -1634,6 +1634,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           // lane mask (scalar work: the sweep loop has no vector register to spare)
           const bool lag = multi ? (multi_fa > 0 && it >= multi_fa) : (freeze_after > 0 && it >= freeze_after);
           float err = 0.f;
+          float dl_last[3] = {0.f, 0.f, 0.f};
           if constexpr (AA) { aa_x[0] = lam[0]; aa_x[1] = lam[1]; aa_x[2] = lam[2]; }
           for (int kp = 0; kp < gdw; ++kp) {
             const bool mine = isc & !done & (gpos == kp);
@@ -1701,9 +1702,17 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
               lam[rr] += dl[rr];
             }
             lap(t_mag);
-            exchange(dl, err);
+            if constexpr (AA) {
+              // the last pass's exchange waits for the Anderson step (one exchange carries both changes)
+              if (kp + 1 < gdw) exchange(dl, err);
+              else { dl_last[0] = dl[0]; dl_last[1] = dl[1]; dl_last[2] = dl[2]; }
+            } else {
+              exchange(dl, err);
+            }
             lap(t_exch);
           }
+          if constexpr (AA)   // the deferred pass's share of the sweep's largest change (its members sit in the env's first row)
+            err = fmaxf(err, row_max_f32(fmaxf(fabsf(dl_last[0]), fmaxf(fabsf(dl_last[1]), fabsf(dl_last[2])))));
           // an inherited direction that the first sweep did not pick up is dropped (oracle: same rule): a contact that starts
           // to slip later in the solve runs the global search
           if (it == 0) sdst = (sdst == 3) ? 0 : sdst;
@@ -1736,7 +1745,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           if constexpr (AA) {
             if (__any(aa_on & !done)) {
               // x+ = g - gamma (g - g_prev), gamma = <r, r - r_prev> / |r - r_prev|^2 over the env's contacts (they sit in the env's
-              // first row: one DPP row reduction each), back into the cone, and one exchange of the change so that v follows
+              // first row: one DPP row reduction each), back into the cone; the change rides on the last pass's deferred exchange
               float rr[3], num = 0.f, den = 0.f;
               RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) {
                 rr[q2] = lam[q2] - aa_x[q2];
@@ -1757,10 +1766,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
               const bool off = xn[2] <= 0.f;
               xn[0] = off ? 0.f : xn[0] * sh; xn[1] = off ? 0.f : xn[1] * sh; xn[2] = off ? 0.f : xn[2];
               const bool app = isc & (gam != 0.f);
-              RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) { dl[q2] = app ? xn[q2] - lam[q2] : 0.f; lam[q2] += dl[q2]; }
-              float unused = 0.f;
-              exchange(dl, unused);
+              RSB_UNROLL for (int q2 = 0; q2 < 3; ++q2) { dl[q2] = app ? xn[q2] - lam[q2] : 0.f; lam[q2] += dl[q2]; dl_last[q2] += dl[q2]; }
             }
+            float unused = 0.f;
+            exchange(dl_last, unused);   // the last pass's changes + the Anderson step's
           }
         }
         if (PROF && pfine) tz0 = t_prev;
