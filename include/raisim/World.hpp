@@ -66,6 +66,7 @@ class Contact {
   int getCollisionIndex() const { return RSB_CONTACT_PRIMITIVE(c_.collision); }
   /// a self-collision is listed once per body: the two entries are neighbours in getContacts(), object A first
   bool isSelfCollision() const { return (c_.collision & (RSB_CONTACT_SELF_A | RSB_CONTACT_SELF_B)) != 0; }
+  bool isSecondTerrainContact() const { return (c_.collision & RSB_CONTACT_SECOND) != 0; }   // extension: rsb_set_heightmap_contacts
   bool isObjectA() const { return (c_.collision & RSB_CONTACT_SELF_B) == 0; }
   bool skip() const { return false; }
  private:

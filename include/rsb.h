@@ -127,6 +127,7 @@ typedef struct rsb_contact {
                           isSelfCollision(), isObjectA()) and carries RSB_CONTACT_SELF_A / _B in this field: the two entries
                           sit next to each other, same position and depth, opposite normals and impulses */
 } rsb_contact;
+#define RSB_CONTACT_SECOND 0x40000   /* a primitive's second contact with a height map (rsb_set_heightmap_contacts) */
 #define RSB_CONTACT_SELF_A 0x10000
 #define RSB_CONTACT_SELF_B 0x20000
 #define RSB_CONTACT_PRIMITIVE(c) ((c) & 0xffff)
@@ -264,6 +265,15 @@ int rsb_set_ground(rsb_world* w, double height);
 /* heights: host pointer, row-major [y_samples][x_samples] (x fastest), shared by all envs */
 int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size, double y_size,
                       double center_x, double center_y, const float* heights);
+/* Contacts per collision primitive against a height map (not RaiSim's collider; default 1 = the closest feature).  With 2, a
+ * sphere that penetrates a SECOND flank - the closest penetrating point of the surface whose direction differs from the first
+ * contact's normal by more than min_angle_deg (oracle default 25.84 deg = acos 0.9) - reports it as a second contact: a ball in
+ * a valley then rests on both sides instead of rattling between them.  The second contact carries RSB_CONTACT_SECOND in
+ * rsb_contact::collision, uses its primitive's material, starts cold in every solve, follows all first contacts in the list and
+ * counts as its primitive for the termination rule and the foot forces of rsb_control_step.  A kernel class of its own (the
+ * default kernels are what they were): floating-base systems of tree depth <= 13, no peer-mapped obs exchange, no profiling /
+ * debug instrumentation (RSB_E_UNSUPPORTED from the step otherwise). */
+int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle_deg);
 /* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
  * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */
 int rsb_set_heightmaps(rsb_world* w, int n_maps, int x_samples, int y_samples, double x_size, double y_size,

@@ -35,6 +35,8 @@ class Params(C.Structure):
         ("body_stick", C.c_int32),
         ("anderson", C.c_int32),
         ("anderson_clip", C.c_double),
+        ("hm_contacts", C.c_int32),
+        ("hm_second_cos", C.c_double),
     ]
 
 

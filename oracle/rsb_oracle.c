@@ -330,6 +330,7 @@ void orc_default_params(orc_params* p) {
   p->hm_index = NULL;
   p->multi_depth = 3; p->multi_light = 0; p->multi_freeze_after = 0; p->multi_stall_window = 16;
   p->anderson = 2; p->anderson_clip = 20.0;
+  p->hm_contacts = 1; p->hm_second_cos = 0.9;
 }
 
 void orc_mass_matrix(const rsb_model_blob* m, const double* q, double* M) {
@@ -534,7 +535,11 @@ static void closest_on_triangle(const double* a, const double* b, const double* 
  * back to the plane of the triangle under it (see the end of the function).
  * Upstream counterpart: the sphere x HeightMap collider of RaiSim's vendored ODE - absent from /root/reference. */
 #define ORC_HM_CELLS 3
-static int terrain_contact(const orc_params* p, const double* c, double r, double* depth, double* n) {
+/* depth2 / n2 (may be NULL): with orc_params::hm_contacts >= 2 a sphere in a valley also reports the closest feature of a SECOND flank -
+ * the closest penetrating triangle point whose direction differs from the first contact's normal by more than acos(hm_second_cos);
+ * *depth2 <= 0 when there is none. */
+static int terrain_contact(const orc_params* p, const double* c, double r, double* depth, double* n, double* depth2, double* n2) {
+  if (depth2) *depth2 = 0.0;
   if (p->terrain_type == 0) {
     n[0] = 0; n[1] = 0; n[2] = 1;
     *depth = r - (c[2] - p->ground_z);
@@ -583,6 +588,39 @@ static int terrain_contact(const orc_params* p, const double* c, double r, doubl
   if (inside && -dot3(bp, bn) > 0.0 && dist > 1e-9) {
     for (int i = 0; i < 3; ++i) n[i] = -bp[i] / dist;
     *depth = r - dist;
+    if (depth2 && p->hm_contacts >= 2 && *depth > 0.0) {
+      /* second flank: the same scan, restricted to points that penetrate, lie on the outer side of their triangle and whose direction
+       * is at least acos(hm_second_cos) away from the first normal (coplanar neighbours and the far side of a shared edge give the
+       * first contact's direction again and drop out) */
+      double best2 = r * r, q2[3] = {0, 0, 0};
+      int found = 0;
+      for (int iy = iy0; iy <= iy1; ++iy)
+        for (int ix = ix0; ix <= ix1; ++ix) {
+          const float* H = p->hm_heights + iy * xs + ix;
+          const double ox = x0 + ix * dx - c[0], oy = y0 + iy * dy - c[1];
+          const double v00[3] = {ox, oy, H[0] - c[2]}, v10[3] = {ox + dx, oy, H[1] - c[2]};
+          const double v01[3] = {ox, oy + dy, H[xs] - c[2]}, v11[3] = {ox + dx, oy + dy, H[xs + 1] - c[2]};
+          for (int tri = 0; tri < 2; ++tri) {
+            const double* b = tri == 0 ? v10 : v11;
+            const double* cc = tri == 0 ? v11 : v01;
+            double q[3], e1[3], e2[3], tn[3];
+            closest_on_triangle(v00, b, cc, q);
+            const double d2 = dot3(q, q);
+            if (!(d2 < best2 * (1.0 - 4e-6)) || d2 < 1e-18) continue;
+            for (int i = 0; i < 3; ++i) { e1[i] = b[i] - v00[i]; e2[i] = cc[i] - v00[i]; }
+            cross3(e1, e2, tn);
+            if (!(-dot3(q, tn) > 0.0)) continue;
+            if (!(-dot3(q, n) < p->hm_second_cos * sqrt(d2))) continue;     /* direction . n1 < cos */
+            best2 = d2; found = 1;
+            for (int i = 0; i < 3; ++i) q2[i] = q[i];
+          }
+        }
+      if (found) {
+        const double dist2 = sqrt(best2);
+        for (int i = 0; i < 3; ++i) n2[i] = -q2[i] / dist2;
+        *depth2 = r - dist2;
+      }
+    }
   } else {
     /* the centre is at or below the surface (a zero-radius box corner, a sphere pushed in by more than its radius) or beyond
      * the map's border (the terrain continues flat from its outermost samples): the triangle UNDER the centre decides -
@@ -912,7 +950,9 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   int cbody2[MAXK], ccol2[MAXK];   /* second body / primitive of a self-collision (-1: contact with the terrain) */
   double cmat[MAXK][3];            /* mu, restitution, threshold of a self-collision's material pair */
   double cen[RSB_MAX_COLLISIONS][3];   /* primitive centres relative to the base position */
-  for (int i = 0; i < MAXK; ++i) { cbody2[i] = -1; ccol2[i] = -1; }
+  int csecond[MAXK];               /* second contact of a primitive with the terrain (a valley's other flank) */
+  double sec_depth[RSB_MAX_COLLISIONS], sec_n[RSB_MAX_COLLISIONS][3], sec_c[RSB_MAX_COLLISIONS][3];
+  for (int i = 0; i < MAXK; ++i) { cbody2[i] = -1; ccol2[i] = -1; csecond[i] = 0; }
   for (int s = 0; s < m->ncol; ++s) {
     int b = m->col_body[s];
     double t[3], c[3], cw[3], n[3], depth;
@@ -930,13 +970,26 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       }
     }
     for (int a = 0; a < 3; ++a) { cw[a] = k->pbase[a] + c[a]; cen[s][a] = c[a]; }
-    if (terrain_contact(p, cw, m->col_radius[s], &depth, n)) {
+    double depth2 = 0.0, n2[3] = {0, 0, 1};
+    const int hit = terrain_contact(p, cw, m->col_radius[s], &depth, n, &depth2, n2);
+    sec_depth[s] = hit ? depth2 : 0.0; for (int a = 0; a < 3; ++a) { sec_n[s][a] = n2[a]; sec_c[s][a] = c[a]; }
+    if (hit) {
       if (nc >= kmax) { fl |= 1; continue; }
       for (int a = 0; a < 3; ++a) { cx[nc][a] = c[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }
       cdepth[nc] = depth; cbody[nc] = b; ccol[nc] = s;
       contact_frame(n, Rc[nc]);
       ++nc;
     }
+  }
+  /* the second flank of a valley (orc_params::hm_contacts): after all first contacts, in primitive order (the device emits them in a
+   * second pass over the primitives); its own slot, the primitive's material, a cold start */
+  for (int s = 0; s < m->ncol; ++s) {
+    if (!(sec_depth[s] > 0.0)) continue;
+    if (nc >= kmax) { fl |= 1; continue; }
+    for (int a = 0; a < 3; ++a) { cx[nc][a] = sec_c[s][a] - m->col_radius[s] * sec_n[s][a]; cn[nc][a] = sec_n[s][a]; }
+    cdepth[nc] = sec_depth[s]; cbody[nc] = m->col_body[s]; ccol[nc] = s; csecond[nc] = 1;
+    contact_frame(sec_n[s], Rc[nc]);
+    ++nc;
   }
 
   /* Self-collision (sphere x sphere): two primitives of the candidate set closer than r_i + r_j touch in the middle of the
@@ -1062,7 +1115,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       }
       /* warm start: the impulse (contact frame) this collision primitive carried in the previous integrate() */
       /* (a self-collision starts cold: the warm state is kept per primitive for its contact with the terrain) */
-      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal && cbody2[i] < 0) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
+      for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal && cbody2[i] < 0 && !csecond[i]) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
     }
     /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
     if (dbgG)   /* debug views cover the real contacts (joint-limit rows follow them and are left out) */
@@ -1086,7 +1139,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     for (int i = 0; i < nc; ++i) {
       sdir[i][0] = sdir[i][1] = sdir[i][2] = 0.0;
       lam_best[i][0] = lam_best[i][1] = lam_best[i][2] = 0.0;
-      if (lam_warm && p->warm_start && i < nreal && cbody2[i] < 0 && lam_warm[ORC_WARM * ccol[i] + 5] != 0.0) {   /* ... and its last friction direction */
+      if (lam_warm && p->warm_start && i < nreal && cbody2[i] < 0 && !csecond[i] && lam_warm[ORC_WARM * ccol[i] + 5] != 0.0) {   /* ... and its last friction direction */
         sdir[i][0] = lam_warm[ORC_WARM * ccol[i] + 3]; sdir[i][1] = lam_warm[ORC_WARM * ccol[i] + 4]; sdir[i][2] = 3.0;
       }
     }
@@ -1422,7 +1475,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   if (lam_warm) {
     for (int i = 0; i < ORC_WARM * m->ncol; ++i) lam_warm[i] = 0.0;
     for (int i = 0; i < nreal; ++i) {
-      if (cbody2[i] >= 0) continue;
+      if (cbody2[i] >= 0 || csecond[i]) continue;
       double* wrm = lam_warm + ORC_WARM * ccol[i];
       for (int r = 0; r < 3; ++r) wrm[r] = lam[i][r];
       if (sdir_out[i][2] != 0.0) { wrm[3] = sdir_out[i][0]; wrm[4] = sdir_out[i][1]; wrm[5] = 1.0; }
@@ -1441,7 +1494,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       }
       contacts[nout].depth = cdepth[i];
       contacts[nout].body = h ? cbody2[i] : cbody[i];
-      contacts[nout].collision = two ? (h ? (ccol2[i] | ORC_SELF_B) : (ccol[i] | ORC_SELF_A)) : ccol[i];
+      contacts[nout].collision = two ? (h ? (ccol2[i] | ORC_SELF_B) : (ccol[i] | ORC_SELF_A)) : (csecond[i] ? (ccol[i] | ORC_SECOND) : ccol[i]);
     }
   }
   if (n_contacts) *n_contacts = nout;

@@ -90,11 +90,17 @@ typedef struct orc_params {
    * residual p99 2.7e-2 -> 1.1e-5 (tests/test_oracle_solver_heuristics.py). */
   int32_t anderson;
   double anderson_clip;
+  /* contacts per collision primitive against a height map (default 1 = the closest feature; 2 = also the closest feature of a second
+   * flank: a sphere in a valley rests on both sides) and the cosine of the least angle between the two normals (default 0.9) */
+  int32_t hm_contacts;
+  double hm_second_cos;
 } orc_params;
 
 /* collision ids reported for the two entries of a self-collision (RaiSim lists it once per body): primitive id | flag */
 #define ORC_SELF_A 0x10000
 #define ORC_SELF_B 0x20000
+/* ... and for the second contact of a primitive with the terrain (orc_params::hm_contacts) */
+#define ORC_SECOND 0x40000
 
 /* the candidate pairs of self-collision in enumeration order: pairs[2k], pairs[2k+1] = primitive ids i < j; returns the count */
 int orc_self_pairs(const rsb_model_blob* m, const uint8_t* ignore, int32_t* pairs, int cap);

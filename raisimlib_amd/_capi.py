@@ -13,7 +13,7 @@ RSB_MAX_CONTACTS = 16
 RSB_NAME_LEN = 48
 
 RSB_HOST, RSB_DEVICE = 0, 1
-RSB_CONTACT_SELF_A, RSB_CONTACT_SELF_B = 0x10000, 0x20000
+RSB_CONTACT_SELF_A, RSB_CONTACT_SELF_B, RSB_CONTACT_SECOND = 0x10000, 0x20000, 0x40000
 RSB_FORCE_AND_TORQUE, RSB_PD_PLUS_FEEDFORWARD_TORQUE = 0, 1
 (RSB_F_GC, RSB_F_GV, RSB_F_PTARGET, RSB_F_DTARGET, RSB_F_TAU_FF, RSB_F_CONTACT_COUNT, RSB_F_CONTACTS,
  RSB_F_FLAGS, RSB_F_GENERALIZED_FORCE) = range(9)
@@ -101,6 +101,7 @@ PROTOTYPES = {
     "rsb_set_solver_friction_lag": (_I, [_VP, _I, _I, _D]),
     "rsb_set_solver_multi_contact": (_I, [_VP, _I, _I, _I, _I]),
     "rsb_set_solver_anderson": (_I, [_VP, _I, _D]),
+    "rsb_set_heightmap_contacts": (_I, [_VP, _I, _D]),
     "rsb_set_early_termination": (_I, [_VP, _I]),
     "rsb_set_solver_warm_start": (_I, [_VP, _I]),
     "rsb_set_max_contacts": (_I, [_VP, _I]),

@@ -85,6 +85,7 @@ struct rsb_world {
   int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
   int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
   int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
+  int hm_contacts = 1; double hm_second_cos = 0.9;                                         // rsb_set_heightmap_contacts
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
   //   [flags, parity 0 | parity 1]            2 x RSB_MAX_RANKS uint32: flags[parity][p] = last control step whose rows rank p delivered
@@ -227,7 +228,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   const int upsize = b.nb * rsbk::kUpSlot + (tri ? b.nb * rsbk::kFactSlot : 0);
   // (one narrow-phase slot per primitive: every sphere of the model may be near the ground at once - a robot lying in a hollow)
   L.hm_slots = std::max(rsbk::kHmSlots, (int)b.ncol);
-  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 4) * L.hm_slots + RSB_MAX_COLLISIONS}));
+  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 8) * L.hm_slots + RSB_MAX_COLLISIONS}));
   if (tri) L.fact = L.g + b.nb * rsbk::kUpSlot;
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
@@ -299,7 +300,7 @@ __global__ void gather_obs_kernel(float* out, const float* gc, const float* gv, 
     int nc = count[e];
     for (int k = 0; k < nc; ++k) {
       const rsb_contact& ct = contacts[(size_t)e * kmax + k];
-      if (ct.collision == want) v = ct.impulse[ax] * inv_dt;
+      if ((ct.collision & ~RSB_CONTACT_SECOND) == want) v += ct.impulse[ax] * inv_dt;   // (a primitive's two contacts with a height map add up)
     }
   }
   out[i] = v;
@@ -313,7 +314,7 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
   bool term = (flags[e] & 2) != 0;
   const int nc = count[e];
   for (int k = 0; k < nc; ++k) {
-    const int c = contacts[(size_t)e * kmax + k].collision;
+    const int c = contacts[(size_t)e * kmax + k].collision & ~RSB_CONTACT_SECOND;   // (a second flank's contact counts as its primitive's)
     // an entry of a self-collision (id | RSB_CONTACT_SELF_A / _B) is never a foot on the terrain: terminal, as in the fused
     // epilogue of the step kernel (and a shift by >= 64 would be undefined)
     if (c >= RSB_CONTACT_SELF_A || !((allowed >> c) & 1ull)) term = true;
@@ -358,10 +359,10 @@ int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool prof) {
   constexpr int EPW = 64 / LPE;
   const int blocks = (w->N + EPW - 1) / EPW;
   // the profiling instance carries the cycle stamps / contact-problem dump / LDS poisoning; production launches use the lean one
-  // (the peer-exchange classes, CL bit 2, are built without a profiling twin: profile the exchange-free class instead)
+  // (the peer-exchange and second-flank classes, CL bits 2 and 4, are built without a profiling twin: profile the plain class instead)
   hipError_t e;
-  if constexpr ((CL & 2) != 0) {
-    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange kernel class: disconnect the exchange (rsb_obs_peer_destroy) first"); return RSB_E_UNSUPPORTED; }
+  if constexpr ((CL & 6) != 0) {
+    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange and second-flank kernel classes: disconnect the exchange (rsb_obs_peer_destroy) / set one contact per primitive (rsb_set_heightmap_contacts) first"); return RSB_E_UNSUPPORTED; }
     e = rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
   } else {
     e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->stream)
@@ -482,6 +483,12 @@ int do_integrate(rsb_world* w, int nsub) {
   }
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
   const bool peer = w->fuse.peer;
+  // a second contact per primitive against a height map (rsb_set_heightmap_contacts): a kernel class of its own, floating base, no peer exchange
+  const bool hm2 = w->hm_contacts >= 2 && w->terrain_type == 1;
+  if (hm2 && (w->blob.fixed_base || peer || w->blob.depth - 1 > 12)) {
+    rsb::set_error("two contacts per primitive against a height map: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange");
+    return RSB_E_UNSUPPORTED;
+  }
   if (peer) {   // rsb_control_step with the peer-mapped obs exchange connected: rows go to every rank's gathered buffer of this step's parity
     rsb_world::Peer& P = w->peer;
     const uint32_t step = ++P.step;
@@ -512,6 +519,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
   a.multi_depth = w->multi_depth; a.multi_light = w->multi_light; a.multi_freeze_after = w->multi_freeze_after; a.multi_stall_window = w->multi_stall_window;
   a.anderson = w->anderson; a.anderson_clip = (float)w->anderson_clip;
+  a.hm_contacts = w->hm_contacts; a.hm_second_cos = (float)w->hm_second_cos;
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {
@@ -540,10 +548,12 @@ int do_integrate(rsb_world* w, int nsub) {
   const int mlv = w->blob.depth - 1;
   if (mlv <= 4) {
     if (w->blob.fixed_base) st = kcap == 8 ? launch_lpe<8, 1, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 1, 4>(w, a, lds_bytes, lpe, prof);
+    else if (hm2) st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe, prof);
     else if (peer) st = kcap == 8 ? launch_lpe<8, 2, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 2, 4>(w, a, lds_bytes, lpe, prof);
     else st = kcap == 8 ? launch_lpe<8, 0, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 4>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 12) {
-    st = w->blob.fixed_base ? launch_lpe<16, 1, 12>(w, a, lds_bytes, lpe, prof) : peer ? launch_lpe<16, 2, 12>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
+    st = w->blob.fixed_base ? launch_lpe<16, 1, 12>(w, a, lds_bytes, lpe, prof) : hm2 ? launch_lpe<16, 4, 12>(w, a, lds_bytes, lpe, prof)
+         : peer ? launch_lpe<16, 2, 12>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 16) {
     st = w->blob.fixed_base ? launch_lpe<16, 1, 16>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 16>(w, a, lds_bytes, lpe, prof);
   } else {
@@ -799,6 +809,13 @@ int rsb_set_solver_multi_contact(rsb_world* w, int depth, int light_passes, int 
 int rsb_set_solver_anderson(rsb_world* w, int first_sweep, double clip) {
   if (!w || first_sweep < 0 || !(clip > 0.0)) { rsb::set_error("rsb_set_solver_anderson: first_sweep >= 0 (0 = off), clip > 0"); return RSB_E_INVALID; }
   w->anderson = first_sweep; w->anderson_clip = clip;
+  return RSB_OK;
+}
+int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle_deg) {
+  if (!w || per_primitive < 1 || per_primitive > 2 || !(min_angle_deg > 0.0 && min_angle_deg < 90.0)) {
+    rsb::set_error("rsb_set_heightmap_contacts: per_primitive is 1 or 2, 0 < min_angle_deg < 90"); return RSB_E_INVALID;
+  }
+  w->hm_contacts = per_primitive; w->hm_second_cos = std::cos(min_angle_deg * 3.14159265358979323846 / 180.0);
   return RSB_OK;
 }
 int rsb_set_early_termination(rsb_world* w, int on) {

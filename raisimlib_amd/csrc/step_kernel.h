@@ -193,6 +193,29 @@ __device__ __forceinline__ void hm_scan_cell(const Args& a, const float* patch, 
     }
   }
 }
+// ... and the scan for a SECOND flank (class-4 kernels; oracle: terrain_contact, "second flank"): only points that penetrate (d2 < r2),
+// lie on the outer side of their triangle and whose direction is at least acos(cos2) away from the first normal n1
+template <class Args>
+__device__ __forceinline__ void hm_scan_cell2(const Args& a, const float* patch, int cxx, int cyy, int ix, int iy, int order, float x, float y, float z,
+                                              float r2, const float* n1, float cos2, unsigned& key, float* bp) {
+  const float* H = patch + 4 * cyy + cxx;
+  const float ox = (a.hm_x0 + (float)ix * a.hm_dx) - x, oy = (a.hm_y0 + (float)iy * a.hm_dy) - y;
+  const float v00[3] = {ox, oy, H[0] - z}, v10[3] = {ox + a.hm_dx, oy, H[1] - z};
+  const float v01[3] = {ox, oy + a.hm_dy, H[4] - z}, v11[3] = {ox + a.hm_dx, oy + a.hm_dy, H[5] - z};
+  RSB_UNROLL for (int tri = 0; tri < 2; ++tri) {
+    const float* b = tri == 0 ? v10 : v11;
+    const float* c = tri == 0 ? v11 : v01;
+    float q[3], e1[3], e2[3], tn[3];
+    closest_on_triangle(v00, b, c, q);
+    const float d2 = dot3(q, q);
+    RSB_UNROLL for (int i = 0; i < 3; ++i) { e1[i] = b[i] - v00[i]; e2[i] = c[i] - v00[i]; }
+    cross3(e1, e2, tn);
+    const unsigned k = (__float_as_uint(d2) & ~31u) | (unsigned)(order + tri);
+    const bool c1 = d2 < r2, c2 = d2 >= 1e-18f, c3 = -dot3(q, tn) > 0.f, c4 = -dot3(q, n1) < cos2 * sqrtf(d2);
+    const bool ok = c1 & c2 & c3 & c4;
+    if (ok && k < key) { key = k; RSB_UNROLL for (int i = 0; i < 3; ++i) bp[i] = q[i]; }
+  }
+}
 // terrain height and unit normal of the triangle under (x, y), coordinates clamped to the map (oracle: orc_terrain)
 template <class Args>
 __device__ __forceinline__ void terrain_eval(const Args& a, const float* heights, float x, float y, float& h, float* n) {
@@ -213,11 +236,12 @@ __device__ __forceinline__ void terrain_eval(const Args& a, const float* heights
 // closest point bp (relative to the centre (x, y, z)) on a triangle with face normal bn -> penetration depth and unit contact
 // normal; a centre at / below the surface or beyond the map's border falls back to the plane of the triangle under it
 template <class Args>
-__device__ __forceinline__ void hm_resolve(const Args& a, const float* heights, const float* bp, const float* bn, float x, float y, float z, float r,
+__device__ __forceinline__ bool hm_resolve(const Args& a, const float* heights, const float* bp, const float* bn, float x, float y, float z, float r,
                                            float& depth, float* n) {
   const float dist = sqrtf(dot3(bp, bp));
   const bool inside = (x >= a.hm_x0) & (x <= a.hm_x0 + a.hm_dx * (float)(a.hm_xs - 1)) & (y >= a.hm_y0) & (y <= a.hm_y0 + a.hm_dy * (float)(a.hm_ys - 1));
-  if (inside & (-dot3(bp, bn) > 0.f) & (dist > 1e-9f)) {
+  const bool feature = inside & (-dot3(bp, bn) > 0.f) & (dist > 1e-9f);   // (returned: the contact is the closest feature's, not the fallback's)
+  if (feature) {
     const float id = 1.0f / dist;
     RSB_UNROLL for (int i = 0; i < 3; ++i) n[i] = -bp[i] * id;
     depth = r - dist;
@@ -226,6 +250,7 @@ __device__ __forceinline__ void hm_resolve(const Args& a, const float* heights, 
     terrain_eval(a, heights, x, y, h, n);
     depth = r - (z - h) * n[2];
   }
+  return feature;
 }
 
 // contact frame [t1 t2 n] (oracle: contact_frame): t1 = the normalised projection of a world axis on the tangent plane - world x,
@@ -519,7 +544,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   long long t_entry = 0; if (PROF) t_entry = clock64();
   constexpr int EPW = 64 / LPE;
-  constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0;
+  constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0, HM2 = (CL & 4) != 0;
   constexpr bool TRI = KMAX > 8;    // packed lower-triangular Delassus blocks (see tri_off); the quadruped classes keep the square layout
   const int lane = threadIdx.x;
   const int el = lane / LPE;
@@ -790,7 +815,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     nc = 0;
     bool illegal = false;
     // writes the contacts of one pass over the primitives (ballot + popcount compaction, contacts in primitive order)
-    auto emit = [&](bool hit, int ci, int cbody, const float* c, float rad, const float* n, float dep) {
+    auto emit = [&](bool hit, int ci, int cid, int cbody, const float* c, float rad, const float* n, float dep) {   // ci: primitive, cid: the id reported (flags)
       illegal |= hit && !((ac.allowed >> ci) & 1ull);
       const unsigned long long bal = __ballot(hit);
       const unsigned long long gm = (LPE == 64) ? bal : ((bal >> (el * LPE)) & ((1ull << (LPE % 64)) - 1ull));
@@ -800,7 +825,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         contact_tangents(n, t1, t2);
         P[0] = c[0] - rad * n[0]; P[1] = c[1] - rad * n[1]; P[2] = c[2] - rad * n[2]; P[3] = dep;
         P[4] = t1[0]; P[5] = t1[1]; P[6] = t1[2]; P[7] = __int_as_float(cbody);
-        P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(ci);
+        P[8] = t2[0]; P[9] = t2[1]; P[10] = t2[2]; P[11] = __int_as_float(cid);
         P[12] = n[0]; P[13] = n[1]; P[14] = n[2]; P[15] = 0.f;
         stv<4>(CON + slot * kConSlot, P);
       }
@@ -844,7 +869,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           dep = rad - (pbz + c[2] - ac.ground_z);
           hit = dep > 0.f && !dead;
         }
-        emit(hit, ci, cbody, c, rad, nz, dep);
+        emit(hit, ci, ci, cbody, c, rad, nz, dep);
       }
     } else {
       // ---- height map: closest feature over the cells under the sphere (oracle: terrain_contact), in three steps:
@@ -853,12 +878,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       //   (2) lane = (slot, cell): the four lanes of a quad scan the cells of one slot, two triangles each, and agree on the
       //       closest feature (DPP quad minimum of the candidate keys); its lane resolves depth and normal;
       //   (3) lane = primitive again: contacts in primitive order.
-      // Scratch: the first (kHmRec + 4) * hm_slots + ncol floats of the Delassus rows (dead here; finite values only, the up pass
+      // Scratch: the first (kHmRec + 8) * hm_slots + ncol floats of the Delassus rows (dead here; finite values only, the up pass
       // overwrites most of them with its hand-over slots).
       const int hm_slots = L.hm_slots;                        // one per primitive of the model (>= kHmSlots)
       float* REC = G;                                         // [hm_slots][kHmRec] x y z r | ix0 iy0 nx ny | c (relative to the base) pad | 4 x 4 corner heights
       float* RES = G + kHmRec * hm_slots;                     // [hm_slots][4] depth, normal
-      int* SLOTOF = reinterpret_cast<int*>(G + (kHmRec + 4) * hm_slots);   // [ncol] slot + 1 of each primitive, 0 = dropped
+      float* RES2 = G + (kHmRec + 4) * hm_slots;              // [hm_slots][4] class-4 kernels: depth and normal of the second flank's contact (depth 0: none)
+      int* SLOTOF = reinterpret_cast<int*>(G + (kHmRec + 8) * hm_slots);   // [ncol] slot + 1 of each primitive, 0 = dropped
       int nnear = 0;
       for (int c0 = 0; c0 < ncol; c0 += LPE) {
         const int ci = c0 + s;
@@ -919,11 +945,42 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         kmin = min(kmin, (unsigned)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x4E, 0xf, 0xf, false));            // quad_perm [2,3,0,1]
         if (valid && key == kmin) {     // the scan position makes the keys of a quad distinct
           float o4[4];
-          hm_resolve(ac, env_heights, bp, bn, R[0], R[1], R[2], R[3], o4[0], o4 + 1);
+          const bool feature = hm_resolve(ac, env_heights, bp, bn, R[0], R[1], R[2], R[3], o4[0], o4 + 1);
           st4(RES + 4 * k, o4);
+          if constexpr (HM2) { const float f4[4] = {(feature && o4[0] > 0.f) ? 1.f : 0.f, 0.f, 0.f, 1.f}; st4(RES2 + 4 * k, f4); }
         }
       }
       __syncthreads();
+      if constexpr (HM2) {
+        // (2b) the second flank: the quad scans its slot's cells again for the closest penetrating point at least acos(hm_second_cos)
+        // away from the first normal; RES2[k] = depth (0: none), normal
+        if (ac.hm_contacts >= 2) {
+          for (int k0 = 0; k0 < nnw; k0 += LPE / 4) {
+            const int k = k0 + (s >> 2), t = s & 3;
+            const bool valid = k < nnear;
+            float R[8], o1[4], f1[4];
+            const float* rec = REC + kHmRec * (valid ? k : 0);
+            ldv<2>(rec, R); ld4(RES + 4 * (valid ? k : 0), o1); ld4(RES2 + 4 * (valid ? k : 0), f1);
+            const bool go = valid && f1[0] > 0.f;
+            const int ix0 = __float_as_int(R[4]), iy0 = __float_as_int(R[5]), nx = __float_as_int(R[6]), ncell = go ? nx * __float_as_int(R[7]) : 0;
+            unsigned key = 0xffffffffu;
+            float bp[3] = {0.f, 0.f, 0.f};
+            for (int cc = t; cc < ncell; cc += 4) {
+              const int cyy = (cc >= nx ? 1 : 0) + (cc >= 2 * nx ? 1 : 0), cxx = cc - cyy * nx;
+              hm_scan_cell2(ac, rec + 12, cxx, cyy, ix0 + cxx, iy0 + cyy, 2 * cc, R[0], R[1], R[2], R[3] * R[3], o1 + 1, ac.hm_second_cos, key, bp);
+            }
+            unsigned kmin = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xf, 0xf, false));
+            kmin = min(kmin, (unsigned)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x4E, 0xf, 0xf, false));
+            const bool found = kmin != 0xffffffffu;
+            if (valid && (found ? key == kmin : t == 0)) {
+              const float dist = sqrtf(dot3(bp, bp)), id = found ? 1.0f / dist : 0.f;
+              const float o4[4] = {found ? R[3] - dist : 0.f, -bp[0] * id, -bp[1] * id, found ? -bp[2] * id : 1.f};
+              st4(RES2 + 4 * k, o4);
+            }
+          }
+          __syncthreads();
+        }
+      }
       for (int c0 = 0; c0 < ncol; c0 += LPE) {
         const int ci = c0 + s;
         bool hit = false;
@@ -939,7 +996,29 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           cbody = __float_as_int(COLT[kColSlot * ci + 4]);
           hit = dep > 0.f;
         }
-        emit(hit, ci, cbody, c, rad, n, dep);
+        emit(hit, ci, ci, cbody, c, rad, n, dep);
+      }
+      if constexpr (HM2) {
+        // second flanks: after all first contacts, in primitive order (oracle: the same), flagged ids
+        if (ac.hm_contacts >= 2) {
+          for (int c0 = 0; c0 < ncol; c0 += LPE) {
+            const int ci = c0 + s;
+            bool hit = false;
+            float c[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 1.f}, rad = 0.f, dep = 0.f;
+            int cbody = 0;
+            const int sl = ci < ncol ? SLOTOF[ci] : 0;
+            if (sl > 0) {
+              float o4[4], r4[4];
+              ld4(RES2 + 4 * (sl - 1), o4); ld4(REC + kHmRec * (sl - 1) + 8, r4);
+              dep = o4[0]; n[0] = o4[1]; n[1] = o4[2]; n[2] = o4[3];
+              c[0] = r4[0]; c[1] = r4[1]; c[2] = r4[2];
+              rad = REC[kHmRec * (sl - 1) + 3];
+              cbody = __float_as_int(COLT[kColSlot * ci + 4]);
+              hit = dep > 0.f && RES[4 * (sl - 1)] > 0.f;
+            }
+            emit(hit, ci, ci | kSecond, cbody, c, rad, n, dep);
+          }
+        }
       }
       __syncthreads();   // the scratch is free again (the up pass reuses it)
     }
@@ -1176,8 +1255,9 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
           // Newton restitution (oracle: "restitution"): the approach speed J u of this step re-enters the normal row
           const int cid = __float_as_int(CN[11]);
-          const int cprim = min(cid, ncol - 1);   // (joint-limit rows carry ids >= ncol and no restitution)
-          const bool selfrow = cid >= kSelfA;     // entry of a self-collision: restitution is applied to the folded contact (approach speed = sum of the two entries')
+          const bool second = HM2 && (cid & kSecond) != 0;   // a primitive's second contact with the height map: the primitive's material
+          const int cprim = second ? (cid & 0xffff) : min(cid, ncol - 1);   // (joint-limit rows carry ids >= ncol and no restitution)
+          const bool selfrow = !second && cid >= kSelfA;     // entry of a self-collision: restitution is applied to the folded contact (approach speed = sum of the two entries')
           if (selfrow && rr == 2) SELFT[4 * i + 3] = cv;
           const float restitution = selfrow ? 0.f : COLT[kColSlot * cprim + 6], res_threshold = COLT[kColSlot * cprim + 7];
           const float rest = (rr == 2 && lsgn == 0.f && restitution > 0.f && cv < -res_threshold) ? restitution * cv : 0.f;
@@ -1477,6 +1557,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           }
         }
         float mu = (isc && mycol < ncol) ? COLT[kColSlot * mycol + 5] : ag.mu;
+        if constexpr (HM2) { if (isc && (mycol & kSecond)) mu = COLT[kColSlot * (mycol & 0xffff) + 5]; }
         if (mycol & kSelfA) mu = SELFT[4 * s];    // material pair of the two primitives
         const float mu2 = mu * mu;
         const float alpha_init = ag.alpha_init, alpha_min = ag.alpha_min, alpha_decay = ag.alpha_decay, threshold = ag.threshold;
@@ -1905,6 +1986,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     if (dead) { nc = nc_dead; flag |= 8; }   // report the contacts that ended the episode
     int mycol = 0;
     if (s < nc) mycol = __float_as_int(CON[s * kConSlot + 11]);
+    if constexpr (HM2) { if (mycol & kSecond) mycol &= 0xffff; }   // a second flank's contact counts as its primitive's (rule, warm record: none is kept twice)
     const bool illegal = ae.do_reset && s < nc && (mycol >= kSelfA || !((ae.allowed >> mycol) & 1ull));
     const unsigned long long bb = __ballot(bad), bi = __ballot(illegal);
     const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
@@ -1922,12 +2004,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const int want = ae.obs_idx ? ae.obs_idx[sl] : sl;
         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
         for (int k = 0; k < nc; ++k) {
-          if (__float_as_int(CON[k * kConSlot + 11]) == want) {
+          const int kid = __float_as_int(CON[k * kConSlot + 11]);
+          if ((HM2 ? (kid & ~kSecond) : kid) == want) {   // (class 4: a primitive's two contacts with the height map add up; f starts at 0, every other class has one match)
             const float* CN = CON + k * kConSlot;
             const float l0 = LAM[3 * k], l1 = LAM[3 * k + 1], l2 = LAM[3 * k + 2];
-            f0 = (CN[4] * l0 + CN[8] * l1 + CN[12] * l2) * inv_dt;
-            f1 = (CN[5] * l0 + CN[9] * l1 + CN[13] * l2) * inv_dt;
-            f2 = (CN[6] * l0 + CN[10] * l1 + CN[14] * l2) * inv_dt;
+            f0 += (CN[4] * l0 + CN[8] * l1 + CN[12] * l2) * inv_dt;
+            f1 += (CN[5] * l0 + CN[9] * l1 + CN[13] * l2) * inv_dt;
+            f2 += (CN[6] * l0 + CN[10] * l1 + CN[14] * l2) * inv_dt;
           }
         }
         put(ob + nq + nv + 3 * sl, f0); put(ob + nq + nv + 3 * sl + 1, f1); put(ob + nq + nv + 3 * sl + 2, f2);

@@ -33,6 +33,7 @@ constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
 constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
+constexpr int kSecond = 0x40000;      // collision id flag of a primitive's SECOND contact with a height map (== RSB_CONTACT_SECOND, ORC_SECOND)
 constexpr int kSelfA = 0x10000;       // collision id flags of the two entries of a self-collision (== RSB_CONTACT_SELF_A / _B, ORC_SELF_A / _B)
 constexpr int kSelfB = 0x20000;
 constexpr int kSelfBatch = 5;          // passes per batch of the self-collision sweep
@@ -138,6 +139,9 @@ struct StepArgs {
   // Anderson acceleration of the sweep map in multi-contact envs of the KMAX > 8 classes (rsb_set_solver_anderson): first sweep (0 = off), clip
   int anderson;
   float anderson_clip;
+  // height map: contacts per primitive (2: the class-4 kernels also report the closest feature of a second flank) and the cosine of the least angle between the two normals
+  int hm_contacts;
+  float hm_second_cos;
   // peer-mapped obs exchange (rsb_obs_peer_*): the epilogue stores the env's obs row (the obs_out layout) into the gathered buffer
   // of EVERY rank at row obs_row0 + env - system-scope (write-through) stores through peer-mapped pointers into fine-grained
   // memory, over xGMI for the other GPUs.  Publication without a cache flush: a wave waits for its stores to be acknowledged

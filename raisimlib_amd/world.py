@@ -223,6 +223,10 @@ class BatchedWorld:
         check(self.L.rsb_set_solver_multi_contact(self.handle, int(depth), int(bool(light_passes)), int(freeze_after), int(stall_window)),
               "rsb_set_solver_multi_contact")
 
+    def set_heightmap_contacts(self, per_primitive=2, min_angle_deg=25.841932763167124):
+        """Contacts per collision primitive against a height map (1 = closest feature; 2 = also a second flank's; see rsb.h)."""
+        check(self.L.rsb_set_heightmap_contacts(self.handle, int(per_primitive), float(min_angle_deg)), "rsb_set_heightmap_contacts")
+
     def set_solver_anderson(self, first_sweep=2, clip=20.0):
         """Anderson acceleration of the sweep in multi-contact envs of worlds with > 8 contact slots (see rsb.h). first_sweep 0 = off."""
         check(self.L.rsb_set_solver_anderson(self.handle, int(first_sweep), float(clip)), "rsb_set_solver_anderson")

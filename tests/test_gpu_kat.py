@@ -332,3 +332,40 @@ def test_sampled_colliders_carry_the_body_on_its_middle(built_lib, which):
         c = con[e][:cnt[e]]
         assert np.abs(c["position"][:, :2]).max() < 0.11
         assert abs(c["impulse"][:, 2].sum() - mass * G * DT) < 1e-3 * mass * G * DT
+
+
+@pytest.mark.parametrize("mu", [0.8, 0.0])
+def test_ball_in_a_valley_rests_on_both_flanks(built_lib, mu):
+    """rsb_set_heightmap_contacts(2) through the C-ABI (the oracle KAT of the same name): two contacts of one primitive, the second one
+    flagged RSB_CONTACT_SECOND, the ball at rest; with one contact per primitive it rattles."""
+    from test_oracle_kat import valley_map
+    from raisimlib_amd._capi import RSB_CONTACT_SECOND
+    r, slope, mass = 0.3, 0.5, 2.0
+    al = np.arctan(slope)
+    res = {}
+    for hc in (1, 2):
+        _, w = world(sphere_urdf(mass, r))
+        w.add_height_map(33, 33, 12.8, 12.8, 0.0, 0.0, valley_map(slope=slope))
+        w.set_heightmap_contacts(hc)
+        w.set_collision_materials(np.array([mu]), np.array([0.0]), np.array([0.0]))
+        w.set_state(tile([0.0, 0.1, r / np.cos(al) - 1e-4, 1, 0, 0, 0.0]), tile(np.zeros(6)))
+        w.integrate(60)
+        vmax = 0.0
+        for k in range(35):
+            w.integrate(4)
+            vmax = max(vmax, np.abs(w.get_state()[1]).max())
+        q, u = w.get_state(); cnt, con = w.get_contacts()
+        assert (w.get_flags() == 0).all()
+        res[hc] = (q, cnt, con, vmax)
+        w.close()
+    q, cnt, con, vmax = res[2]
+    assert (cnt == 2).all() and (con[:, 0]["collision"] == 0).all() and (con[:, 1]["collision"] == RSB_CONTACT_SECOND).all()
+    assert vmax < 2e-4 and np.abs(q[:, 0]).max() < 1e-4 and np.abs(q[:, 2] - r / np.cos(al)).max() < 3e-4
+    c = con[5][:2]
+    nrm = c["normal"][np.argsort(c["normal"][:, 0])]
+    assert np.allclose(nrm, [[-np.sin(al), 0, np.cos(al)], [np.sin(al), 0, np.cos(al)]], atol=2e-5)
+    assert abs(c["impulse"][:, 2].sum() - mass * G * DT) < 2e-4 * mass * G * DT + 1e-6
+    if mu == 0.0:
+        lam_n = np.einsum("ij,ij->i", c["impulse"], c["normal"])
+        assert np.allclose(lam_n, mass * G * DT / (2 * np.cos(al)), rtol=1e-3)
+    assert (res[1][1] == 1).all() and res[1][3] > 5e-3

@@ -571,3 +571,38 @@ def test_sampled_collider_model_parity_on_a_height_map(built_lib):
     assert same.mean() > 0.99
     check_step({k: v[same] for k, v in dev.items()}, {k: (v[same] if isinstance(v, np.ndarray) and len(v) == len(same) else v) for k, v in ref.items()},
                min_conv=0.8, max_di=80)   # (kmax 16: multi-contact envs take the Anderson step, whose fp32 / fp64 paths part on a hard solve: 43 sweeps on one env of one build)
+
+
+def test_two_contacts_per_primitive_on_a_rough_map_parity(anymal):
+    """rsb_set_heightmap_contacts(2) (kernel class 4) vs the oracle with hm_contacts = 2: ANYmal-like robots dropped low onto a rough map
+    whose cells are about a foot radius wide - spheres sit in the creases between triangles; same contact lists (second contacts
+    flagged, after all first ones), the usual one-step tolerance."""
+    H = workload.smoothed_heightmap(64, 64, amplitude=0.25, seed=5)
+    hm = (64, 64, 3.2, 3.2, 0.0, 0.0, H)                              # cells of 5 cm: the knee / foot spheres (r 3-6 cm) reach two flanks
+    gc, gv = standing_states(512, seed=19, z=(0.3, 0.6))
+    gc[:, :2] *= 0.2                                                  # keep every robot on the map
+    kp, kd = workload.anymal_gains()
+    N = gc.shape[0]
+    w = BatchedWorld(anymal, N)
+    o = Oracle(anymal.blob)
+    w.add_height_map(*hm); o.set_heightmap(*hm)
+    w.set_heightmap_contacts(2); o.p.hm_contacts = 2
+    dtg = np.zeros((N, anymal.nv))
+    w.set_pd_gains(kp, kd); w.set_pd_target(gc, dtg); w.set_state(gc, gv)
+    w.integrate(1)
+    q1, u1 = w.get_state(); cnt, con = w.get_contacts()
+    dev = dict(q=q1, u=u1, cnt=cnt, con=con, iters=w.get_solver_iterations(), flags=w.get_flags())
+    ref = o.step_batch(f32(gc), f32(gv), 1, kp.astype(np.float64), kd.astype(np.float64), f32(gc), dtg, None, want_contacts=True, lam_warm=o.new_warm_state(N))
+    w.close()
+    valid = np.arange(ref["contacts"].shape[1])[None, :] < ref["n_contacts"][:, None]
+    second = valid & ((ref["contacts"]["collision"] & 0x40000) != 0)
+    assert second.sum() > 40 and second.any(axis=1).sum() > 30          # the option matters on this map
+    same = dev["cnt"] == ref["n_contacts"]
+    for e in np.nonzero(same)[0]:
+        same[e] = np.array_equal(dev["con"][e][:cnt[e]]["collision"], ref["contacts"][e][:cnt[e]]["collision"])
+    assert same.mean() > 0.98, same.mean()                              # (a second flank within 1e-6 of touching rounds either way)
+    for e in np.nonzero(same & second.any(axis=1))[0][:40]:
+        n = cnt[e]
+        assert np.abs(dev["con"][e][:n]["normal"] - ref["contacts"][e][:n]["normal"]).max() < 2e-4, e
+        assert np.abs(dev["con"][e][:n]["depth"] - ref["contacts"][e][:n]["depth"]).max() < 5e-6, e
+    check_step({k: v[same] for k, v in dev.items()}, {k: (v[same] if isinstance(v, np.ndarray) and len(v) == len(same) else v) for k, v in ref.items()}, min_conv=0.8)

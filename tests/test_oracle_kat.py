@@ -560,3 +560,42 @@ def test_sampled_colliders_find_the_contact_under_the_middle(built_lib, which):
     assert k == 0 and abs(q_samp[2] - z0) < 2e-3                     # carried from the first step on
     assert np.abs(con["position"][:, :2]).max() < 0.11               # under the middle, not at the ends / corners
     assert abs(con["impulse"][:, 2].sum() - mass * 9.81 * 0.0025) < 1e-3 * mass * 9.81 * 0.0025
+
+
+def valley_map(n=33, size=12.8, slope=0.5):
+    """a V-shaped valley along y at x = 0, flanks of the given slope; cells of size / (n - 1) = 0.4 m"""
+    xs = np.linspace(-size / 2, size / 2, n)
+    return np.tile((slope * np.abs(xs))[None, :], (n, 1)).astype(np.float32)
+
+
+@pytest.mark.parametrize("mu", [0.8, 0.0])
+def test_ball_in_a_valley_rests_on_both_flanks_with_two_contacts_per_primitive(built_lib, mu):
+    """orc_params::hm_contacts = 2 (rsb_set_heightmap_contacts): a ball lowered into a V-shaped valley touches BOTH flanks - two contacts
+    of one primitive, normals (-+sin a, 0, cos a), the second one flagged ORC_SECOND - and rests: zero velocity, the two impulses carry
+    m g dt between them (frictionless: each normal impulse m g dt / (2 cos a)).  With one contact per primitive (the default) the same
+    ball rattles from flank to flank."""
+    from raisimlib_amd import Model
+    r, slope, mass = 0.3, 0.5, 2.0
+    al = np.arctan(slope)
+    m = Model(urdf_string=sphere_urdf(mass, r))
+    out = {}
+    for hc in (1, 2):
+        o = Oracle(m.blob)
+        o.p.hm_contacts, o.p.mu = hc, mu
+        o.set_heightmap(33, 33, 12.8, 12.8, 0.0, 0.0, valley_map(slope=slope))
+        q = np.array([0.0, 0.1, r / np.cos(al) - 1e-4, 1, 0, 0, 0.0]); u = np.zeros(6)
+        vmax = 0.0
+        for k in range(200):
+            q, u, con, it, fl = o.step(q, u)
+            vmax = max(vmax, np.abs(u).max()) if k > 50 else vmax
+        out[hc] = (q, u, con, vmax)
+    q, u, con, vmax = out[2]
+    assert len(con) == 2 and list(con["collision"]) == [0, 0x40000]
+    assert vmax < 1e-5 and abs(q[0]) < 1e-6 and abs(q[2] - r / np.cos(al)) < 2e-4
+    nrm = con["normal"][np.argsort(con["normal"][:, 0])]
+    assert np.allclose(nrm, [[-np.sin(al), 0, np.cos(al)], [np.sin(al), 0, np.cos(al)]], atol=1e-6)
+    assert abs(con["impulse"][:, 2].sum() - mass * 9.81 * 0.0025) < 1e-6 and abs(con["impulse"][:, 0].sum()) < 1e-6
+    if mu == 0.0:
+        lam_n = np.einsum("ij,ij->i", con["impulse"], con["normal"])
+        assert np.allclose(lam_n, mass * 9.81 * 0.0025 / (2 * np.cos(al)), rtol=1e-6)
+    assert len(out[1][2]) == 1 and out[1][3] > 5e-3            # one contact: the ball keeps rattling between the flanks
