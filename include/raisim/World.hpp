@@ -114,6 +114,11 @@ class BatchedWorld {
   void setContactSolverParam(double alpha_init, double alpha_min, double alpha_decay, int maxIter, double threshold) {
     RSB_CHECK(rsb_set_contact_solver_param(world_, alpha_init, alpha_min, alpha_decay, maxIter, threshold));
   }
+  /// extensions (no upstream counterpart; rsb.h): solver settings of redundant contact sets, the Anderson step, two contacts per
+  /// primitive against a height map
+  void setMultiContactSolverParam(int depth, bool lightPasses, int freezeAfter, int stallWindow) { RSB_CHECK(rsb_set_solver_multi_contact(world_, depth, lightPasses ? 1 : 0, freezeAfter, stallWindow)); }
+  void setSolverAcceleration(int firstSweep, double clip = 20.0) { RSB_CHECK(rsb_set_solver_anderson(world_, firstSweep, clip)); }
+  void setHeightMapContactsPerPrimitive(int n, double minAngleDeg = 25.841932763167124) { RSB_CHECK(rsb_set_heightmap_contacts(world_, n, minAngleDeg)); }
   void addGround(double zHeight = 0.0) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_ground(world_, zHeight)); }
   void addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
                     const std::vector<double>& height) {

@@ -11,14 +11,14 @@ from common import ROOT
 from raisimlib_amd import build as rb
 
 
-@pytest.mark.parametrize("lpe,kmax,ml", [(16, 8, 4), (32, 16, 12), (64, 16, 12)])   # the benchmark's ANYmal-like and Atlas-like (two envs / one env per wave) instances
-def test_step_instances_use_no_scratch(tmp_path, lpe, kmax, ml):
+@pytest.mark.parametrize("lpe,kmax,ml,cl", [(16, 8, 4, 0), (32, 16, 12, 0), (64, 16, 12, 0), (16, 8, 4, 4)])   # the benchmark's ANYmal-like and Atlas-like (two envs / one env per wave) instances; the second-flank class
+def test_step_instances_use_no_scratch(tmp_path, lpe, kmax, ml, cl):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
     out = tmp_path / "k.s"
     csrc = os.path.join(ROOT, "raisimlib_amd", "csrc")
-    cmd = [hipcc, *rb.FLAGS, "-I", os.path.join(ROOT, "include"), "-I", csrc, f"-DRSB_I_LPE={lpe}", f"-DRSB_I_KMAX={kmax}", "-DRSB_I_CL=0", f"-DRSB_I_ML={ml}",
+    cmd = [hipcc, *rb.FLAGS, "-I", os.path.join(ROOT, "include"), "-I", csrc, f"-DRSB_I_LPE={lpe}", f"-DRSB_I_KMAX={kmax}", f"-DRSB_I_CL={cl}", f"-DRSB_I_ML={ml}",
            "-DRSB_I_PROF=0", "--cuda-device-only", "-S", "-o", str(out), os.path.join(csrc, "step_instance.hip")]
     subprocess.run(cmd, check=True, capture_output=True)
     txt = out.read_text()
