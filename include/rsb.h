@@ -271,8 +271,8 @@ int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size,
  * a valley then rests on both sides instead of rattling between them.  The second contact carries RSB_CONTACT_SECOND in
  * rsb_contact::collision, uses its primitive's material, starts cold in every solve, follows all first contacts in the list and
  * counts as its primitive for the termination rule and the foot forces of rsb_control_step.  A kernel class of its own (the
- * default kernels are what they were): floating-base systems of tree depth <= 13, no peer-mapped obs exchange, no profiling /
- * debug instrumentation (RSB_E_UNSUPPORTED from the step otherwise). */
+ * default kernels are what they were): floating-base systems of tree depth <= 13, no peer-mapped obs exchange
+ * (RSB_E_UNSUPPORTED from the step otherwise). */
 int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle_deg);
 /* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
  * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */

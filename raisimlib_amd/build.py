@@ -67,7 +67,7 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
             tasks.append((obj, [hipcc, *FLAGS, *extra_flags, "-x", "hip", *inc, "-c", _path(src), "-o", obj]))
     objs = [os.path.join(OBJ, os.path.splitext(src)[0] + (f".{tag}" if tag else "") + ".o") for src in HOST_SOURCES]
     for lpe, kmax, cl, ml in step_instances():
-        for prof in ((0,) if cl & 6 else (0, 1)):      # (the peer-exchange and second-flank classes have no profiling twin: rsb_world.hip, launch_step)
+        for prof in ((0,) if cl & 2 else (0, 1)):      # (the peer-exchange classes have no profiling twin: rsb_world.hip, launch_step)
             obj = os.path.join(OBJ, f"step_{lpe}_{kmax}_{cl}_{ml}_{prof}" + (f".{tag}" if tag else "") + ".o")
             objs.append(obj)
             if force or _newer(obj, KERNEL_DEPS):

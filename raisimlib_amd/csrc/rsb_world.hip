@@ -195,6 +195,9 @@ std::vector<int> enumerate_self_pairs(const rsb_model_blob& b, const std::vector
   return out;
 }
 
+// slots of the height-map narrow phase: one per primitive (every sphere of the model may be near the ground at once - a robot lying in a hollow)
+int hm_slots_for(const rsb_model_blob& b) { return std::max(rsbk::kHmSlots, (int)b.ncol); }
+
 LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   LdsLayout L;
   const int cw = round4(6 + b.depth - 1);
@@ -226,9 +229,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   // Delassus phase writes its blocks over both)
   const int gsize = tri ? (kcap * (kcap + 1) / 2) * 12 : 3 * kcap * L.gstride;
   const int upsize = b.nb * rsbk::kUpSlot + (tri ? b.nb * rsbk::kFactSlot : 0);
-  // (one narrow-phase slot per primitive: every sphere of the model may be near the ground at once - a robot lying in a hollow)
-  L.hm_slots = std::max(rsbk::kHmSlots, (int)b.ncol);
-  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 8) * L.hm_slots + RSB_MAX_COLLISIONS}));
+  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 8) * hm_slots_for(b) + RSB_MAX_COLLISIONS}));
   if (tri) L.fact = L.g + b.nb * rsbk::kUpSlot;
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
@@ -359,10 +360,10 @@ int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool prof) {
   constexpr int EPW = 64 / LPE;
   const int blocks = (w->N + EPW - 1) / EPW;
   // the profiling instance carries the cycle stamps / contact-problem dump / LDS poisoning; production launches use the lean one
-  // (the peer-exchange and second-flank classes, CL bits 2 and 4, are built without a profiling twin: profile the plain class instead)
+  // (the peer-exchange classes, CL bit 2, are built without a profiling twin: profile the exchange-free class instead)
   hipError_t e;
-  if constexpr ((CL & 6) != 0) {
-    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange and second-flank kernel classes: disconnect the exchange (rsb_obs_peer_destroy) / set one contact per primitive (rsb_set_heightmap_contacts) first"); return RSB_E_UNSUPPORTED; }
+  if constexpr ((CL & 2) != 0) {
+    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange kernel class: disconnect the exchange (rsb_obs_peer_destroy) first"); return RSB_E_UNSUPPORTED; }
     e = rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
   } else {
     e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->stream)
@@ -519,7 +520,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
   a.multi_depth = w->multi_depth; a.multi_light = w->multi_light; a.multi_freeze_after = w->multi_freeze_after; a.multi_stall_window = w->multi_stall_window;
   a.anderson = w->anderson; a.anderson_clip = (float)w->anderson_clip;
-  a.hm_contacts = w->hm_contacts; a.hm_second_cos = (float)w->hm_second_cos;
+  a.hm_contacts = w->hm_contacts; a.hm_second_cos = (float)w->hm_second_cos; a.hm_slots = hm_slots_for(w->blob);
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {

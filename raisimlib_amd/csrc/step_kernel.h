@@ -540,6 +540,9 @@ __device__ __forceinline__ void tri_store(float* G, int a, int b, const float (&
 template <int LPE, int KMAX, int CL, int ML, bool PROF>
 __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();   // the by-value StepArgs sits at offset 0 of the kernarg segment
+#ifdef RSB_X_NOPS   /* experiment: shift the whole kernel's code by RSB_X_NOPS x 4 bytes (alignment of the hot loops' fetch windows) */
+  static_for<0, RSB_X_NOPS>([&](auto) { asm volatile("s_nop 0"); });
+#endif
   RSB_ARGS(a);                                                     // the prologue's view (and the PROF-only fields)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   long long t_entry = 0; if (PROF) t_entry = clock64();
@@ -880,7 +883,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       //   (3) lane = primitive again: contacts in primitive order.
       // Scratch: the first (kHmRec + 8) * hm_slots + ncol floats of the Delassus rows (dead here; finite values only, the up pass
       // overwrites most of them with its hand-over slots).
-      const int hm_slots = L.hm_slots;                        // one per primitive of the model (>= kHmSlots)
+      const int hm_slots = ac.hm_slots;                       // one per primitive of the model (>= kHmSlots)
       float* REC = G;                                         // [hm_slots][kHmRec] x y z r | ix0 iy0 nx ny | c (relative to the base) pad | 4 x 4 corner heights
       float* RES = G + kHmRec * hm_slots;                     // [hm_slots][4] depth, normal
       float* RES2 = G + (kHmRec + 4) * hm_slots;              // [hm_slots][4] class-4 kernels: depth and normal of the second flank's contact (depth 0: none)
@@ -1710,6 +1713,18 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
 
         // Every branch costs a lone wave ~20-45 cycles taken or not (profiles/r02_ubench_lone_wave_latency.txt), i.e. as much
         // as 5-10 VALU instructions: the pass is written with selects, the branches that remain guard work that is rare and large.
+        // The sweep loop's place in the 32-byte instruction-fetch windows is pinned here instead of left to whatever code precedes it: the
+        // same kernel shifted by n x 4 bytes measures 147.6 ... 149.5 M env-steps/s with a period of 32 bytes (profiles/r03_ab_log.txt, "alignment
+        // sweep": a lone wave has nobody to hide a fetch bubble behind), and two unrelated commits had moved it from the best phase to the
+        // worst.  Phase found by sweep for the quadruped classes (5-6 of 8 words: 148.8 / 149.2 M; 0-4 and 7: 146.8 ... 148.0 M); executed once
+        // per solve.  RSB_X_ALIGN_SWEEP overrides the phase for a new sweep.
+#ifndef RSB_X_ALIGN_SWEEP
+#define RSB_X_ALIGN_SWEEP 6
+#endif
+        if constexpr (!TRI) {
+          asm volatile(".p2align 5");
+          static_for<0, RSB_X_ALIGN_SWEEP>([&](auto) { asm volatile("s_nop 0"); });
+        }
         for (int it = 0; it < max_iter; ++it) {
           // lagged directions: a usable direction of this solve is no longer refreshed.  Two wave-uniform tests picked per env by a
           // lane mask (scalar work: the sweep loop has no vector register to spare)

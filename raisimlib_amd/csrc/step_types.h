@@ -68,7 +68,6 @@ struct LdsLayout {
   int cen, selft;   // self-collision: primitive centres [ncol][4] (may alias wc: dead before the contact columns), per-slot pair record [kcap][4]
   int gstride;
   int per_env;
-  int hm_slots;     // spheres per env the height-map narrow phase can examine in one sub-step (= the model's primitives, at least kHmSlots)
 };
 
 struct StepArgs {
@@ -142,17 +141,29 @@ struct StepArgs {
   // height map: contacts per primitive (2: the class-4 kernels also report the closest feature of a second flank) and the cosine of the least angle between the two normals
   int hm_contacts;
   float hm_second_cos;
+  // spheres per env the height-map narrow phase can examine in one sub-step (= the model's primitives, at least kHmSlots).  Here, not in
+  // LdsLayout: the layout is loaded once and lives in SGPRs for the whole kernel - one more word there costs the plane path 0.8 %
+  // (same-box bisect, profiles/r03_ab_log.txt); this one is read inside the height-map branch only
+  int hm_slots;
   // peer-mapped obs exchange (rsb_obs_peer_*): the epilogue stores the env's obs row (the obs_out layout) into the gathered buffer
   // of EVERY rank at row obs_row0 + env - system-scope (write-through) stores through peer-mapped pointers into fine-grained
   // memory, over xGMI for the other GPUs.  Publication without a cache flush: a wave waits for its stores to be acknowledged
   // (s_waitcnt vmcnt(0)) and checks in on a device counter; the LAST wave of the launch then stores this rank's step number into
   // every rank's flag array.  (A system-scope RELEASE per wave writes the whole L2 back: +15 % kernel time, measured; a stream
   // memory-write packet behind the launch costs 8 us, a one-wave flag kernel 3 us: profiles/r03_ab_log.txt.)
+#ifdef RSB_X_SMALLARGS   /* experiment: does the kernarg segment's size matter? (peer exchange unusable in this variant) */
+  float* obs_peer[1];
+  uint32_t* obs_flag[1];
+#else
   float* obs_peer[RSB_MAX_RANKS];        // [n_obs_peers] rank p's gathered buffer [n_ranks * N, obs_dim] of this control step's parity
   uint32_t* obs_flag[RSB_MAX_RANKS];     // [n_obs_peers] &flags_of_rank_p[parity][my rank]
+#endif
   uint32_t* obs_ctr;                     // this rank's wave-arrival counter (device memory, zero between launches)
   int n_obs_peers, obs_row0;
   uint32_t obs_step;                     // value published in the flags: the control step's sequence number (>= 1)
+#ifdef RSB_X_ARGPAD
+  char x_pad[RSB_X_ARGPAD];
+#endif
 };
 
 }  // namespace rsbk
