@@ -1633,10 +1633,25 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * k, g[rr]);
           }
         };
-        float g0[4][3][4];            // coupling blocks with contacts 0-3: constant during the solve, read from LDS once
-        RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(k, g0[k]);
-        float g1[4][3][4];            // ... and with contacts 4-7 (the hard envs of the tail have five contacts: no LDS round trip in their passes)
-        RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(4 + k, g1[k]);
+        // Packed fp32 in the quadruped classes: rows 0 and 1 of a coupling block's column sit in one register pair (read as such: ds_read2_b32 at
+        // the two rows' offsets), so that a column updates both rows with ONE v_pk_fma_f32 (the impulse component broadcast by op_sel):
+        // 6 instead of 9 FMA instructions per contact and exchange.
+        constexpr bool PK = !TRI;
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        float g0[PK ? 1 : 4][3][4];   // coupling blocks with contacts 0-3: constant during the solve, read from LDS once
+        float g1[PK ? 1 : 4][3][4];   // ... and with contacts 4-7 (the hard envs of the tail have five contacts: no LDS round trip in their passes)
+        float2v gp[PK ? 8 : 1][3];    // PK: rows (0, 1) of column c of the block with contact k
+        float gr[PK ? 8 : 1][3];      // PK: row 2
+        if constexpr (PK) {
+          RSB_UNROLL for (int k = 0; k < 8; ++k)
+            RSB_UNROLL for (int cc = 0; cc < 3; ++cc) {
+              gp[k][cc] = float2v{Gmine[4 * k + cc], Gmine[GS + 4 * k + cc]};
+              gr[k][cc] = Gmine[2 * GS + 4 * k + cc];
+            }
+        } else {
+          RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(k, g0[k]);
+          RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(4 + k, g1[k]);
+        }
         float g2[KMAX > 8 ? 4 : 1][3][4];   // ... and, in the large-model classes, with contacts 8-11 (a collapsed humanoid)
         if constexpr (KMAX > 8) {
           RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(8 + k, g2[k]);
@@ -1651,9 +1666,16 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             constexpr int j = decltype(jc)::value;
             float l0[3] = {x[0], x[1], x[2]};
             row_bcast_n<j, 3>(l0);
-            const float (&gj)[3][4] = j < 4 ? g0[j & 3] : (j < 8 ? g1[j & 3] : (j < 12 ? g2[(KMAX > 8 ? j : 0) & 3] : gbuf[(j / 4) & 1][j & 3]));
-            RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
-              v[rr] = fmaf(gj[rr][2], l0[2], fmaf(gj[rr][1], l0[1], fmaf(gj[rr][0], l0[0], v[rr])));
+            if constexpr (PK) {
+              float2v acc = {v[0], v[1]};
+              RSB_UNROLL for (int cc = 0; cc < 3; ++cc) acc = __builtin_elementwise_fma(gp[j & 7][cc], float2v{l0[cc], l0[cc]}, acc);
+              v[0] = acc.x; v[1] = acc.y;
+              v[2] = fmaf(gr[j & 7][2], l0[2], fmaf(gr[j & 7][1], l0[1], fmaf(gr[j & 7][0], l0[0], v[2])));
+            } else {
+              const float (&gj)[3][4] = j < 4 ? g0[j & 3] : (j < 8 ? g1[j & 3] : (j < 12 ? g2[(KMAX > 8 ? j : 0) & 3] : gbuf[(j / 4) & 1][j & 3]));
+              RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
+                v[rr] = fmaf(gj[rr][2], l0[2], fmaf(gj[rr][1], l0[1], fmaf(gj[rr][0], l0[0], v[rr])));
+            }
             emax = fmaxf(emax, fmaxf(fabsf(l0[0]), fmaxf(fabsf(l0[1]), fabsf(l0[2]))));
           };
           // contacts 0-4 straight: the launch lasts as long as its slowest wave, and that wave holds a five-contact env (a robot
@@ -1716,10 +1738,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // The sweep loop's place in the 32-byte instruction-fetch windows is pinned here instead of left to whatever code precedes it: the
         // same kernel shifted by n x 4 bytes measures 147.6 ... 149.5 M env-steps/s with a period of 32 bytes (profiles/r03_ab_log.txt, "alignment
         // sweep": a lone wave has nobody to hide a fetch bubble behind), and two unrelated commits had moved it from the best phase to the
-        // worst.  Phase found by sweep for the quadruped classes (5-6 of 8 words: 148.8 / 149.2 M; 0-4 and 7: 146.8 ... 148.0 M); executed once
-        // per solve.  RSB_X_ALIGN_SWEEP overrides the phase for a new sweep.
+        // worst.  Phase found by sweep for the quadruped classes - and again after the loop body changed (packed fp32 in the exchange: k = 0..7
+        // 149.9 151.6 151.4 150.1 149.4 149.4 148.9 149.7 M; before that change k = 5-6 was the place to be); executed once per solve.
+        // RSB_X_ALIGN_SWEEP overrides the phase for a new sweep: a change of the loop body needs one.
 #ifndef RSB_X_ALIGN_SWEEP
-#define RSB_X_ALIGN_SWEEP 6
+#define RSB_X_ALIGN_SWEEP 2
 #endif
         // The large-model classes (measured on the Atlas-like instance, config 5): phases 0-3 17.7-17.8 M, 4-7 17.4 M, unpinned 17.5 M.
 #ifndef RSB_X_ALIGN_SWEEP_TRI
