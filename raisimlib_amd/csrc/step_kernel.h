@@ -1633,27 +1633,37 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             RSB_UNROLL for (int rr = 0; rr < 3; ++rr) ld4(Gmine + rr * GS + 4 * k, g[rr]);
           }
         };
-        // Packed fp32 in the quadruped classes: rows 0 and 1 of a coupling block's column sit in one register pair (read as such: ds_read2_b32 at
+        // Packed fp32: rows 0 and 1 of a coupling block's column sit in one register pair (read as such: ds_read2_b32 at
         // the two rows' offsets), so that a column updates both rows with ONE v_pk_fma_f32 (the impulse component broadcast by op_sel):
         // 6 instead of 9 FMA instructions per contact and exchange.
-        constexpr bool PK = !TRI;
+#ifndef RSB_X_PK_TRI
+#define RSB_X_PK_TRI 1   /* (0: the unpacked exchange of the large-model classes, for an A/B) */
+#endif
+        constexpr bool PK = !TRI || RSB_X_PK_TRI;
+        constexpr int NPK = TRI ? 12 : 8;   // blocks held in registers for the whole solve
         typedef float float2v __attribute__((ext_vector_type(2)));
         float g0[PK ? 1 : 4][3][4];   // coupling blocks with contacts 0-3: constant during the solve, read from LDS once
         float g1[PK ? 1 : 4][3][4];   // ... and with contacts 4-7 (the hard envs of the tail have five contacts: no LDS round trip in their passes)
-        float2v gp[PK ? 8 : 1][3];    // PK: rows (0, 1) of column c of the block with contact k
-        float gr[PK ? 8 : 1][3];      // PK: row 2
-        if constexpr (PK) {
+        float2v gp[PK ? NPK : 1][3];  // PK: rows (0, 1) of column c of the block with contact k
+        float gr[PK ? NPK : 1][3];    // PK: row 2
+        if constexpr (PK && !TRI) {
           RSB_UNROLL for (int k = 0; k < 8; ++k)
             RSB_UNROLL for (int cc = 0; cc < 3; ++cc) {
               gp[k][cc] = float2v{Gmine[4 * k + cc], Gmine[GS + 4 * k + cc]};
               gr[k][cc] = Gmine[2 * GS + 4 * k + cc];
             }
+        } else if constexpr (PK) {   // packed-triangular layout: the block or its transpose, then paired (the selects write the pairs directly)
+          RSB_UNROLL for (int k = 0; k < NPK; ++k) {
+            float t[3][4];
+            coupling(k, t);
+            RSB_UNROLL for (int cc = 0; cc < 3; ++cc) { gp[k][cc] = float2v{t[0][cc], t[1][cc]}; gr[k][cc] = t[2][cc]; }
+          }
         } else {
           RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(k, g0[k]);
           RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(4 + k, g1[k]);
         }
-        float g2[KMAX > 8 ? 4 : 1][3][4];   // ... and, in the large-model classes, with contacts 8-11 (a collapsed humanoid)
-        if constexpr (KMAX > 8) {
+        float g2[(KMAX > 8 && !PK) ? 4 : 1][3][4];   // ... and, in the large-model classes, with contacts 8-11 (a collapsed humanoid)
+        if constexpr (KMAX > 8 && !PK) {
           RSB_UNROLL for (int k = 0; k < 4; ++k) coupling(8 + k, g2[k]);
         }
         float gbuf[2][4][3][4];       // contacts 12.. : fetched per pass
@@ -1666,13 +1676,13 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             constexpr int j = decltype(jc)::value;
             float l0[3] = {x[0], x[1], x[2]};
             row_bcast_n<j, 3>(l0);
-            if constexpr (PK) {
+            if constexpr (PK && j < NPK) {
               float2v acc = {v[0], v[1]};
-              RSB_UNROLL for (int cc = 0; cc < 3; ++cc) acc = __builtin_elementwise_fma(gp[j & 7][cc], float2v{l0[cc], l0[cc]}, acc);
+              RSB_UNROLL for (int cc = 0; cc < 3; ++cc) acc = __builtin_elementwise_fma(gp[j][cc], float2v{l0[cc], l0[cc]}, acc);
               v[0] = acc.x; v[1] = acc.y;
-              v[2] = fmaf(gr[j & 7][2], l0[2], fmaf(gr[j & 7][1], l0[1], fmaf(gr[j & 7][0], l0[0], v[2])));
+              v[2] = fmaf(gr[j][2], l0[2], fmaf(gr[j][1], l0[1], fmaf(gr[j][0], l0[0], v[2])));
             } else {
-              const float (&gj)[3][4] = j < 4 ? g0[j & 3] : (j < 8 ? g1[j & 3] : (j < 12 ? g2[(KMAX > 8 ? j : 0) & 3] : gbuf[(j / 4) & 1][j & 3]));
+              const float (&gj)[3][4] = j < 4 ? g0[PK ? 0 : (j & 3)] : (j < 8 ? g1[PK ? 0 : (j & 3)] : (j < 12 ? g2[(KMAX > 8 && !PK ? j : 0) & 3] : gbuf[(j / 4) & 1][j & 3]));
               RSB_UNROLL for (int rr = 0; rr < 3; ++rr)
                 v[rr] = fmaf(gj[rr][2], l0[2], fmaf(gj[rr][1], l0[1], fmaf(gj[rr][0], l0[0], v[rr])));
             }
@@ -1744,7 +1754,8 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
 #ifndef RSB_X_ALIGN_SWEEP
 #define RSB_X_ALIGN_SWEEP 2
 #endif
-        // The large-model classes (measured on the Atlas-like instance, config 5): phases 0-3 17.7-17.8 M, 4-7 17.4 M, unpinned 17.5 M.
+        // The large-model classes (measured on the Atlas-like instance, config 5): phases 0-3 17.7-17.8 M, 4-7 17.4 M, unpinned 17.5 M; with the
+        // packed exchange k = 0..7: 18.40 18.40 18.35 18.21 18.03 17.93 18.19 18.30 M.
 #ifndef RSB_X_ALIGN_SWEEP_TRI
 #define RSB_X_ALIGN_SWEEP_TRI 1
 #endif
