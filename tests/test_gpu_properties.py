@@ -231,9 +231,29 @@ def test_api_errors(anymal):
         w.set_collision_materials(res_threshold=np.full(anymal.ncol, np.inf))
     with pytest.raises(RsbError):
         w.set_self_collision_materials(mu=np.full(len(w.self_collision_pairs()), np.nan))
+    for bad_args in ((-1, 20.0), (2, 0.0), (2, float("nan"))):
+        with pytest.raises(RsbError):
+            w.set_solver_anderson(*bad_args)
+    for bad_args in ((0, 25.0), (3, 25.0), (2, 0.0), (2, 90.0)):
+        with pytest.raises(RsbError):
+            w.set_heightmap_contacts(*bad_args)
     w.set_time_step(0.001)
     assert abs(w.get_time_step() - 0.001) < 1e-15
     w.close()
+    # two contacts per primitive against a height map: a kernel class of the floating-base systems - a fixed-base model is refused at the step
+    from test_oracle_kat import FIXED_PENDULUM
+    from raisimlib_amd import Model
+    fixed = Model(urdf_string=FIXED_PENDULUM.format(l=0.5, m=1.0))
+    assert fixed.blob.fixed_base
+    if True:
+        wf = BatchedWorld(fixed, 8)
+        wf.add_height_map(5, 5, 4.0, 4.0, 0.0, 0.0, np.zeros((5, 5), np.float32))
+        wf.set_heightmap_contacts(2)
+        with pytest.raises(RsbError, match="floating-base"):
+            wf.integrate(1)
+        wf.set_heightmap_contacts(1)
+        wf.integrate(1)
+        wf.close()
 
 
 def test_no_use_of_uninitialised_lds():
