@@ -47,7 +47,7 @@
 namespace raisim {
 
 namespace IntegrationScheme {
-enum Type : int { TRAPEZOID = 0, SEMI_IMPLICIT = 1, EULER = 2, RUNGE_KUTTA_4 = 3 };   // only SEMI_IMPLICIT (upstream's default) is implemented
+enum Type : int { TRAPEZOID = 0, SEMI_IMPLICIT = 1, EULER = 2, RUNGE_KUTTA_4 = 3 };   // RUNGE_KUTTA_4 is refused (rsb_set_integration_scheme)
 }
 
 namespace ControlMode {
@@ -116,6 +116,7 @@ class BatchedWorld {
   }
   /// extensions (no upstream counterpart; rsb.h): solver settings of redundant contact sets, the Anderson step, two contacts per
   /// primitive against a height map
+  void setIntegrationScheme(int scheme) { RSB_CHECK(rsb_set_integration_scheme(world_, scheme)); }
   void setMultiContactSolverParam(int depth, bool lightPasses, int freezeAfter, int stallWindow) { RSB_CHECK(rsb_set_solver_multi_contact(world_, depth, lightPasses ? 1 : 0, freezeAfter, stallWindow)); }
   void setSolverAcceleration(int firstSweep, double clip = 20.0) { RSB_CHECK(rsb_set_solver_anderson(world_, firstSweep, clip)); }
   void setHeightMapContactsPerPrimitive(int n, double minAngleDeg = 25.841932763167124) { RSB_CHECK(rsb_set_heightmap_contacts(world_, n, minAngleDeg)); }
@@ -402,9 +403,7 @@ class ArticulatedSystem {
   const VecDyn& getGeneralizedVelocity() { getRow(RSB_F_GV, gv_, w_->dof()); return gv_; }
 
   void setControlMode(ControlMode::Type m) { w_->setControlMode(m); }
-  void setIntegrationScheme(IntegrationScheme::Type scheme) {
-    RSFATAL_IF(scheme != IntegrationScheme::SEMI_IMPLICIT, "setIntegrationScheme: only SEMI_IMPLICIT is implemented");
-  }
+  void setIntegrationScheme(IntegrationScheme::Type scheme) { w_->setIntegrationScheme((int)scheme); }
   /// gains are shared by all replicas of the batched world (one robot model, one controller tuning)
   void setPdGains(const VecDyn& p, const VecDyn& d) {
     RSFATAL_IF(p.size() != getDOF() || d.size() != getDOF(), "setPdGains: gain vectors must have DOF entries");

@@ -243,6 +243,20 @@ int rsb_set_solver_multi_contact(rsb_world* w, int depth, int light_passes, int 
  * never returns an extrapolated iterate unchecked.  Measured on the Atlas-like standing population (oracle): 18.8 -> 10.6 sweeps,
  * p99 86 -> 41, unconverged 3.9 % -> 0.9 %, natural-map residual p99 2.7e-2 -> 1.1e-5.  first_sweep = 0 switches it off. */
 int rsb_set_solver_anderson(rsb_world* w, int first_sweep, double clip);
+/* ArticulatedSystem::setIntegrationScheme [RECALL; upstream file absent].  The velocity update is the same for every scheme (one
+ * dynamics evaluation, one contact solve: u+ = u + M^-1 (dt tau + J^T lambda)); the scheme picks the velocity the positions move with:
+ *   RSB_INTEGRATION_SEMI_IMPLICIT (default, RaiSim's)  q+ = q (+) dt u+
+ *   RSB_INTEGRATION_EULER                               q+ = q (+) dt u
+ *   RSB_INTEGRATION_TRAPEZOID                           q+ = q (+) dt (u + u+) / 2     (exact positions under a constant acceleration)
+ *   RSB_INTEGRATION_RUNGE_KUTTA_4                       RSB_E_UNSUPPORTED
+ * (the enum values are raisim::IntegrationScheme's [RECALL]).  EULER and TRAPEZOID run in a kernel class of their own (floating-base systems
+ * of tree depth <= 13, no peer-mapped obs exchange, one contact per primitive; RSB_E_UNSUPPORTED from the step otherwise): the default's
+ * kernels do not carry the choice. */
+#define RSB_INTEGRATION_TRAPEZOID 0
+#define RSB_INTEGRATION_SEMI_IMPLICIT 1
+#define RSB_INTEGRATION_EULER 2
+#define RSB_INTEGRATION_RUNGE_KUTTA_4 3
+int rsb_set_integration_scheme(rsb_world* w, int scheme);
 /* Early termination (not RaiSim behaviour; default OFF): in rsb_control_step / rsb_env_step - the calls that know which
  * collision primitives may touch the terrain - an env stops integrating at the sub-step in which any other primitive
  * touches; that sub-step and the rest of the control step are not integrated for it, the detected contacts are

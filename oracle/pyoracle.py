@@ -37,6 +37,7 @@ class Params(C.Structure):
         ("anderson_clip", C.c_double),
         ("hm_contacts", C.c_int32),
         ("hm_second_cos", C.c_double),
+        ("integ_theta", C.c_double),
     ]
 
 

@@ -331,6 +331,7 @@ void orc_default_params(orc_params* p) {
   p->multi_depth = 3; p->multi_light = 0; p->multi_freeze_after = 0; p->multi_stall_window = 16;
   p->anderson = 2; p->anderson_clip = 20.0;
   p->hm_contacts = 1; p->hm_second_cos = 0.9;
+  p->integ_theta = 1.0;
 }
 
 void orc_mass_matrix(const rsb_model_blob* m, const double* q, double* M) {
@@ -1452,10 +1453,13 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   for (int i = 0; i < nc; ++i)
     for (int r = 0; r < 3; ++r)
       for (int d = 0; d < nv; ++d) ufree[d] += X[i][r][d] * lam[i][r];
-  for (int d = 0; d < nv; ++d) u[d] = ufree[d];
-  for (int c = 0; c < 3; ++c) q[c] += p->dt * u[c];
+  /* the position update's velocity: theta u+ + (1 - theta) u  (orc_params::integ_theta: 1 = semi-implicit Euler, RaiSim's default; 0 = explicit
+   * Euler; 0.5 = trapezoid) */
+  double ub[MAXV];
+  for (int d = 0; d < nv; ++d) { ub[d] = p->integ_theta * ufree[d] + (1.0 - p->integ_theta) * u[d]; u[d] = ufree[d]; }
+  for (int c = 0; c < 3; ++c) q[c] += p->dt * ub[c];
   {
-    double w[3] = {u[3], u[4], u[5]};
+    double w[3] = {ub[3], ub[4], ub[5]};
     double wn = sqrt(dot3(w, w)), half = 0.5 * wn * p->dt;
     double sc = (wn > 1e-12) ? sin(half) / wn : 0.5 * p->dt, cw = cos(half);
     double dq[4] = {cw, sc * w[0], sc * w[1], sc * w[2]};
@@ -1467,7 +1471,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     double n4 = 1.0 / sqrt(r4[0] * r4[0] + r4[1] * r4[1] + r4[2] * r4[2] + r4[3] * r4[3]);
     for (int c = 0; c < 4; ++c) q[3 + c] = r4[c] * n4;
   }
-  for (int i = 1; i < m->nb; ++i) q[qidx_of(i)] += p->dt * u[dof_of(i)];
+  for (int i = 1; i < m->nb; ++i) q[qidx_of(i)] += p->dt * ub[dof_of(i)];
 
   for (int i = 0; i < nq; ++i) if (!isfinite(q[i])) fl |= 2;
   for (int i = 0; i < nv; ++i) if (!isfinite(u[i])) fl |= 2;

@@ -94,6 +94,9 @@ typedef struct orc_params {
    * flank: a sphere in a valley rests on both sides) and the cosine of the least angle between the two normals (default 0.9) */
   int32_t hm_contacts;
   double hm_second_cos;
+  /* integration scheme of the positions: q+ = q (+) dt (theta u+ + (1 - theta) u); 1 = semi-implicit Euler (default), 0 = explicit Euler,
+   * 0.5 = trapezoid (RaiSim's IntegrationScheme::SEMI_IMPLICIT / EULER / TRAPEZOID [RECALL]) */
+  double integ_theta;
 } orc_params;
 
 /* collision ids reported for the two entries of a self-collision (RaiSim lists it once per body): primitive id | flag */

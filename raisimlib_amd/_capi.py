@@ -102,6 +102,7 @@ PROTOTYPES = {
     "rsb_set_solver_multi_contact": (_I, [_VP, _I, _I, _I, _I]),
     "rsb_set_solver_anderson": (_I, [_VP, _I, _D]),
     "rsb_set_heightmap_contacts": (_I, [_VP, _I, _D]),
+    "rsb_set_integration_scheme": (_I, [_VP, _I]),
     "rsb_set_early_termination": (_I, [_VP, _I]),
     "rsb_set_solver_warm_start": (_I, [_VP, _I]),
     "rsb_set_max_contacts": (_I, [_VP, _I]),

@@ -86,6 +86,7 @@ struct rsb_world {
   int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
   int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
   int hm_contacts = 1; double hm_second_cos = 0.9;                                         // rsb_set_heightmap_contacts
+  double integ_theta = 1.0;                                                                // rsb_set_integration_scheme
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
   //   [flags, parity 0 | parity 1]            2 x RSB_MAX_RANKS uint32: flags[parity][p] = last control step whose rows rank p delivered
@@ -485,6 +486,12 @@ int do_integrate(rsb_world* w, int nsub) {
   a.obs_out = w->fuse.obs_out; a.obs_idx = w->fuse.obs_idx; a.obs_slots = w->fuse.obs_slots;
   const bool peer = w->fuse.peer;
   // a second contact per primitive against a height map (rsb_set_heightmap_contacts): a kernel class of its own, floating base, no peer exchange
+  // an integration scheme other than semi-implicit Euler (rsb_set_integration_scheme): likewise a class of its own
+  const bool th = w->integ_theta != 1.0;
+  if (th && (w->blob.fixed_base || peer || (w->hm_contacts >= 2 && w->terrain_type == 1) || w->blob.depth - 1 > 12)) {
+    rsb::set_error("integration schemes other than SEMI_IMPLICIT: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange and with one contact per primitive");
+    return RSB_E_UNSUPPORTED;
+  }
   const bool hm2 = w->hm_contacts >= 2 && w->terrain_type == 1;
   if (hm2 && (w->blob.fixed_base || peer || w->blob.depth - 1 > 12)) {
     rsb::set_error("two contacts per primitive against a height map: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange");
@@ -521,6 +528,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.multi_depth = w->multi_depth; a.multi_light = w->multi_light; a.multi_freeze_after = w->multi_freeze_after; a.multi_stall_window = w->multi_stall_window;
   a.anderson = w->anderson; a.anderson_clip = (float)w->anderson_clip;
   a.hm_contacts = w->hm_contacts; a.hm_second_cos = (float)w->hm_second_cos; a.hm_slots = hm_slots_for(w->blob);
+  a.integ_theta = (float)w->integ_theta;
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
   if (w->terrain_type == 1) {
@@ -550,11 +558,12 @@ int do_integrate(rsb_world* w, int nsub) {
   if (mlv <= 4) {
     if (w->blob.fixed_base) st = kcap == 8 ? launch_lpe<8, 1, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 1, 4>(w, a, lds_bytes, lpe, prof);
     else if (hm2) st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe, prof);
+    else if (th) st = kcap == 8 ? launch_lpe<8, 8, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 8, 4>(w, a, lds_bytes, lpe, prof);
     else if (peer) st = kcap == 8 ? launch_lpe<8, 2, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 2, 4>(w, a, lds_bytes, lpe, prof);
     else st = kcap == 8 ? launch_lpe<8, 0, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 4>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 12) {
     st = w->blob.fixed_base ? launch_lpe<16, 1, 12>(w, a, lds_bytes, lpe, prof) : hm2 ? launch_lpe<16, 4, 12>(w, a, lds_bytes, lpe, prof)
-         : peer ? launch_lpe<16, 2, 12>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
+         : th ? launch_lpe<16, 8, 12>(w, a, lds_bytes, lpe, prof) : peer ? launch_lpe<16, 2, 12>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 12>(w, a, lds_bytes, lpe, prof);
   } else if (mlv <= 16) {
     st = w->blob.fixed_base ? launch_lpe<16, 1, 16>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 0, 16>(w, a, lds_bytes, lpe, prof);
   } else {
@@ -817,6 +826,15 @@ int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle
     rsb::set_error("rsb_set_heightmap_contacts: per_primitive is 1 or 2, 0 < min_angle_deg < 90"); return RSB_E_INVALID;
   }
   w->hm_contacts = per_primitive; w->hm_second_cos = std::cos(min_angle_deg * 3.14159265358979323846 / 180.0);
+  return RSB_OK;
+}
+int rsb_set_integration_scheme(rsb_world* w, int scheme) {
+  if (!w) return RSB_E_INVALID;
+  if (scheme == RSB_INTEGRATION_SEMI_IMPLICIT) w->integ_theta = 1.0;
+  else if (scheme == RSB_INTEGRATION_EULER) w->integ_theta = 0.0;
+  else if (scheme == RSB_INTEGRATION_TRAPEZOID) w->integ_theta = 0.5;
+  else if (scheme == RSB_INTEGRATION_RUNGE_KUTTA_4) { rsb::set_error("rsb_set_integration_scheme: RUNGE_KUTTA_4 is not implemented (one dynamics evaluation and one contact solve per step)"); return RSB_E_UNSUPPORTED; }
+  else { rsb::set_error("rsb_set_integration_scheme: unknown scheme"); return RSB_E_INVALID; }
   return RSB_OK;
 }
 int rsb_set_early_termination(rsb_world* w, int on) {

@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   long long t_entry = 0; if (PROF) t_entry = clock64();
   constexpr int EPW = 64 / LPE;
-  constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0, HM2 = (CL & 4) != 0;
+  constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0, HM2 = (CL & 4) != 0, TH = (CL & 8) != 0;
   constexpr bool TRI = KMAX > 8;    // packed lower-triangular Delassus blocks (see tri_off); the quadruped classes keep the square layout
   const int lane = threadIdx.x;
   const int el = lane / LPE;
@@ -1965,6 +1965,11 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     // =========================== du = L^-1 D^-1/2 (W_b + sum_c W_c lam_c), then integrate ========
     // base part on every lane (C^T x = w by back substitution), then the bodies level by level from the base (lane = body)
     float a0[6];
+    // integration scheme of the positions (StepArgs::integ_theta; rsb_set_integration_scheme).  Schemes other than semi-implicit Euler are a kernel
+    // class of their own (bit 8): the four instructions they add here moved the register allocation of the whole sub-step (-0.9 % on config 2,
+    // same-box A/B) - in every other class theta is the constant 1 and the code below folds to what it was
+    float theta = 1.f;
+    if constexpr (TH) { RSB_ARGS(ai); theta = ai.integ_theta; }
     {
       float wv[6];
       RSB_UNROLL for (int i = 0; i < 6; ++i) wv[i] = wbb[i];
@@ -1980,15 +1985,15 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       if (s == 0 && !dead) {
         float qv[8], uv[8];
         ldv<2>(Q, qv); ldv<2>(U, uv);
-        float un[6];
-        RSB_UNROLL for (int i = 0; i < 6; ++i) un[i] = uv[i] + x[i];
-        // q+ : position, quaternion (world-frame angular velocity), semi-implicit Euler
-        const float wn = sqrtf(un[3] * un[3] + un[4] * un[4] + un[5] * un[5]);
+        float un[6], up[6];
+        RSB_UNROLL for (int i = 0; i < 6; ++i) { un[i] = uv[i] + x[i]; up[i] = TH ? fmaf(theta, x[i], uv[i]) : un[i]; }   // up: the velocity the positions move with
+        // q+ : position, quaternion (world-frame angular velocity); theta = 1: semi-implicit Euler
+        const float wn = sqrtf(up[3] * up[3] + up[4] * up[4] + up[5] * up[5]);
         const float half = 0.5f * wn * dt;
         float sh, chf;
         fast_sincos(half, &sh, &chf);
         const float sc = (wn > 1e-12f) ? sh / wn : 0.5f * dt;
-        const float d0 = chf, d1 = sc * un[3], d2 = sc * un[4], d3 = sc * un[5];
+        const float d0 = chf, d1 = sc * up[3], d2 = sc * up[4], d3 = sc * up[5];
         const float q0 = qv[3], q1 = qv[4], q2 = qv[5], q3 = qv[6];
         float r0 = d0 * q0 - d1 * q1 - d2 * q2 - d3 * q3;
         float r1 = d0 * q1 + d1 * q0 + d2 * q3 - d3 * q2;
@@ -1996,7 +2001,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         float r3 = d0 * q3 + d1 * q2 - d2 * q1 + d3 * q0;
         const float in = 1.0f / sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
         // joint entries of Q / U are owned by the body lanes: write only the base entries
-        Q[0] = qv[0] + dt * un[0]; Q[1] = qv[1] + dt * un[1]; Q[2] = qv[2] + dt * un[2];
+        Q[0] = qv[0] + dt * up[0]; Q[1] = qv[1] + dt * up[1]; Q[2] = qv[2] + dt * up[2];
         Q[3] = r0 * in; Q[4] = r1 * in; Q[5] = r2 * in; Q[6] = r3 * in;
         RSB_UNROLL for (int i = 0; i < 6; ++i) U[i] = un[i];
       }
@@ -2012,7 +2017,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         const float un = bqd + xk;
         if (!dead) {
           U[bb + 5] = un;
-          Q[bb + 6] = bqb + dt * un;
+          Q[bb + 6] = bqb + dt * (TH ? fmaf(theta, xk, bqd) : un);
         }
         if ((mykid >> 16) > 0) {
           float* Ab = BODY + bb * kBodySlot + 18;

@@ -145,6 +145,8 @@ struct StepArgs {
   // LdsLayout: the layout is loaded once and lives in SGPRs for the whole kernel - one more word there costs the plane path 0.8 %
   // (same-box bisect, profiles/r03_ab_log.txt); this one is read inside the height-map branch only
   int hm_slots;
+  // integration scheme of the positions (rsb_set_integration_scheme; class-8 kernels): q+ = q (+) dt (u + theta (u+ - u)); 0 = explicit Euler, 0.5 = trapezoid
+  float integ_theta;
   // peer-mapped obs exchange (rsb_obs_peer_*): the epilogue stores the env's obs row (the obs_out layout) into the gathered buffer
   // of EVERY rank at row obs_row0 + env - system-scope (write-through) stores through peer-mapped pointers into fine-grained
   // memory, over xGMI for the other GPUs.  Publication without a cache flush: a wave waits for its stores to be acknowledged

@@ -369,3 +369,39 @@ def test_ball_in_a_valley_rests_on_both_flanks(built_lib, mu):
         lam_n = np.einsum("ij,ij->i", c["impulse"], c["normal"])
         assert np.allclose(lam_n, mass * G * DT / (2 * np.cos(al)), rtol=1e-3)
     assert (res[1][1] == 1).all() and res[1][3] > 5e-3
+
+
+@pytest.mark.parametrize("scheme,theta", [("semi_implicit", 1.0), ("euler", 0.0), ("trapezoid", 0.5)])
+def test_integration_schemes(anymal, scheme, theta):
+    """rsb_set_integration_scheme through the C-ABI: the free-fall closed forms of the oracle KAT, one-step parity of the quadruped on
+    the ground against the oracle with the same theta, and RUNGE_KUTTA_4 refused."""
+    _, w = world(sphere_urdf(2.0, 0.1))
+    w.set_integration_scheme(scheme)
+    n = 40
+    w.set_state(tile([0, 0, 5.0, 1, 0, 0, 0.0]), tile([0.3, 0, 0, 0, 0, 2.0]))
+    w.integrate(n)
+    q, u = w.get_state()
+    k2 = {1.0: n * (n + 1) / 2, 0.0: n * (n - 1) / 2, 0.5: n * n / 2}[theta]
+    assert np.abs(q[:, 2] - (5.0 - G * DT * DT * k2)).max() < 2e-6 and np.abs(u[:, 2] + G * DT * n).max() < 2e-6
+    ang = 2.0 * DT * n
+    assert np.allclose(q[:, 3:], [np.cos(ang / 2), 0, 0, np.sin(ang / 2)], atol=2e-6)
+    with pytest.raises(Exception, match="RUNGE_KUTTA_4"):
+        w.set_integration_scheme("runge_kutta_4")
+    w.close()
+    from test_gpu_parity import standing_states, f32
+    gc, gv = standing_states(N, seed=5, z=(0.45, 0.6), vel=0.5)
+    kp, kd = workload.anymal_gains()
+    wa = BatchedWorld(anymal, N)
+    wa.set_integration_scheme(scheme)
+    wa.set_pd_gains(kp, kd); wa.set_pd_target(gc, np.zeros((N, 18))); wa.set_state(gc, gv)
+    wa.integrate(1)
+    q1, u1 = wa.get_state()
+    wa.close()
+    o = Oracle(anymal.blob)
+    o.p.integ_theta = theta
+    r = o.step_batch(f32(gc), f32(gv), 1, kp.astype(np.float64), kd.astype(np.float64), f32(gc), np.zeros((N, 18)), None, lam_warm=o.new_warm_state(N))
+    assert np.abs(q1 - r["q"]).max() < 5e-6 and np.abs(u1 - r["u"]).max() < 2e-3
+    if theta != 1.0:      # ... and the scheme matters: not the semi-implicit positions
+        o1 = Oracle(anymal.blob)
+        r1 = o1.step_batch(f32(gc), f32(gv), 1, kp.astype(np.float64), kd.astype(np.float64), f32(gc), np.zeros((N, 18)), None, lam_warm=o1.new_warm_state(N))
+        assert np.abs(r1["q"] - r["q"]).max() > 1e-4

@@ -599,3 +599,23 @@ def test_ball_in_a_valley_rests_on_both_flanks_with_two_contacts_per_primitive(b
         lam_n = np.einsum("ij,ij->i", con["impulse"], con["normal"])
         assert np.allclose(lam_n, mass * 9.81 * 0.0025 / (2 * np.cos(al)), rtol=1e-6)
     assert len(out[1][2]) == 1 and out[1][3] > 5e-3            # one contact: the ball keeps rattling between the flanks
+
+
+@pytest.mark.parametrize("scheme,theta", [("semi_implicit", 1.0), ("euler", 0.0), ("trapezoid", 0.5)])
+def test_integration_schemes_in_free_fall_and_free_spin(built_lib, scheme, theta):
+    """orc_params::integ_theta (rsb_set_integration_scheme): the velocity update is the same for every scheme, the positions move with
+    theta u+ + (1 - theta) u.  A ball in free fall after n steps: z = z0 - g dt^2 n (n + 1) / 2 (semi-implicit), n (n - 1) / 2 (explicit
+    Euler), n^2 / 2 (trapezoid: exact); a torque-free spin about z turns the quaternion by w dt per step whatever the scheme."""
+    from raisimlib_amd import Model
+    m = Model(urdf_string=sphere_urdf(2.0, 0.1))
+    o = Oracle(m.blob)
+    o.p.integ_theta = theta
+    n, dt, g = 40, 0.0025, 9.81
+    q = np.array([0, 0, 5.0, 1, 0, 0, 0.0]); u = np.array([0.3, 0, 0, 0, 0, 2.0])
+    for k in range(n):
+        q, u, con, it, fl = o.step(q, u)
+    k2 = {1.0: n * (n + 1) / 2, 0.0: n * (n - 1) / 2, 0.5: n * n / 2}[theta]
+    assert abs(q[2] - (5.0 - g * dt * dt * k2)) < 1e-12 and abs(u[2] + g * dt * n) < 1e-12
+    assert abs(q[0] - 0.3 * dt * n) < 1e-12
+    ang = 2.0 * dt * n
+    assert np.allclose(q[3:], [np.cos(ang / 2), 0, 0, np.sin(ang / 2)], atol=1e-12)
