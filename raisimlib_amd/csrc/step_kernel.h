@@ -1150,13 +1150,23 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         rigid_expand(bI10, IA);
         RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = bZ[i];
         const int kn = mykid >> 16, ks = mykid & 0xffff;
-        for (int ci = 0; ci < max_kid; ++ci) {
-          if (ci < kn) {
-            float P[28];
-            ldv<7>(UPS + KIDS[ks + ci] * kUpSlot, P);
-            RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
-            RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
+        // the children's 27 sums as 14 v_pk_add_f32: [IA | Z | pad] in the hand-over slot's layout, pairs as they come from ds_read_b128
+        {
+          typedef float float2v __attribute__((ext_vector_type(2)));
+          float2v A2[14];
+          RSB_UNROLL for (int k2 = 0; k2 < 14; ++k2) {
+            const int i0 = 2 * k2, i1 = 2 * k2 + 1;
+            A2[k2] = float2v{i0 < 21 ? IA[i0 < 21 ? i0 : 0] : Z[(i0 - 21) < 6 ? (i0 - 21) : 0], i1 < 21 ? IA[i1 < 21 ? i1 : 0] : (i1 < 27 ? Z[(i1 - 21) < 6 ? (i1 - 21) : 0] : 0.f)};
           }
+          for (int ci = 0; ci < max_kid; ++ci) {
+            if (ci < kn) {
+              float P[28];
+              ldv<7>(UPS + KIDS[ks + ci] * kUpSlot, P);
+              RSB_UNROLL for (int k2 = 0; k2 < 14; ++k2) A2[k2] += float2v{P[2 * k2], P[2 * k2 + 1]};
+            }
+          }
+          RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] = (i & 1) ? A2[i >> 1].y : A2[i >> 1].x;
+          RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = ((21 + i) & 1) ? A2[(21 + i) >> 1].y : A2[(21 + i) >> 1].x;
         }
         float Uv[6];
         sym6_vec(IA, bS, Uv);
@@ -1190,11 +1200,20 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
       float IA[21], Z[6];
       rigid_expand(I10b, IA);
       RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = Zb[i];
-      for (int ci = 0; ci < nkid0; ++ci) {
-        float P[28];
-        ldv<7>(UPS + KIDS[ci] * kUpSlot, P);   // the base's children lead the list (kid_start[0] == 0)
-        RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] += P[i];
-        RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] += P[21 + i];
+      {
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        float2v A2[14];
+        RSB_UNROLL for (int k2 = 0; k2 < 14; ++k2) {
+          const int i0 = 2 * k2, i1 = 2 * k2 + 1;
+          A2[k2] = float2v{i0 < 21 ? IA[i0 < 21 ? i0 : 0] : Z[(i0 - 21) < 6 ? (i0 - 21) : 0], i1 < 21 ? IA[i1 < 21 ? i1 : 0] : (i1 < 27 ? Z[(i1 - 21) < 6 ? (i1 - 21) : 0] : 0.f)};
+        }
+        for (int ci = 0; ci < nkid0; ++ci) {
+          float P[28];
+          ldv<7>(UPS + KIDS[ci] * kUpSlot, P);   // the base's children lead the list (kid_start[0] == 0)
+          RSB_UNROLL for (int k2 = 0; k2 < 14; ++k2) A2[k2] += float2v{P[2 * k2], P[2 * k2 + 1]};
+        }
+        RSB_UNROLL for (int i = 0; i < 21; ++i) IA[i] = (i & 1) ? A2[i >> 1].y : A2[i >> 1].x;
+        RSB_UNROLL for (int i = 0; i < 6; ++i) Z[i] = ((21 + i) & 1) ? A2[(21 + i) >> 1].y : A2[(21 + i) >> 1].x;
       }
       RSB_UNROLL for (int i = 0; i < 6; ++i) {
         RSB_UNROLL for (int j = 0; j <= i; ++j) {
@@ -1752,12 +1771,12 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // 149.9 151.6 151.4 150.1 149.4 149.4 148.9 149.7 M; before that change k = 5-6 was the place to be); executed once per solve.
         // RSB_X_ALIGN_SWEEP overrides the phase for a new sweep: a change of the loop body needs one.
 #ifndef RSB_X_ALIGN_SWEEP
-#define RSB_X_ALIGN_SWEEP 2
+#define RSB_X_ALIGN_SWEEP 7   /* (re-swept after the packed sums of the up pass moved one instruction of the loop body: 151.1 150.0 150.1 149.5 150.6 150.6 151.4 152.1) */
 #endif
         // The large-model classes (measured on the Atlas-like instance, config 5): phases 0-3 17.7-17.8 M, 4-7 17.4 M, unpinned 17.5 M; with the
         // packed exchange k = 0..7: 18.40 18.40 18.35 18.21 18.03 17.93 18.19 18.30 M.
 #ifndef RSB_X_ALIGN_SWEEP_TRI
-#define RSB_X_ALIGN_SWEEP_TRI 1
+#define RSB_X_ALIGN_SWEEP_TRI 7   /* (with the packed sums of the up pass, k = 0, 2..7: 18.23 18.39 17.89 18.21 18.40 18.41 18.47; k = 1: 18.33) */
 #endif
         asm volatile(".p2align 5");
         static_for<0, (TRI ? RSB_X_ALIGN_SWEEP_TRI : RSB_X_ALIGN_SWEEP)>([&](auto) { asm volatile("s_nop 0"); });
