@@ -25,6 +25,7 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <functional>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -41,6 +42,7 @@ const char* last_error() { return g_last_error.c_str(); }
 // ---------------------------------------------------------------------------- tiny XML reader
 struct XmlNode {
   std::string tag;
+  std::string text;   // character data between the children (Collada float arrays; URDF has none)
   std::map<std::string, std::string> attr;
   std::vector<std::unique_ptr<XmlNode>> kids;
   const XmlNode* child(const char* t) const {
@@ -113,6 +115,7 @@ class XmlParser {
     for (;;) {  // children / text until </tag>
       size_t lt = s_.find('<', i_);
       if (lt == std::string::npos) throw std::runtime_error("URDF: missing </" + n->tag + ">");
+      if (lt > i_) n->text.append(s_, i_, lt - i_);
       i_ = lt;
       if (starts("<!--")) { skip_until("-->"); continue; }
       if (starts("<?")) { skip_until("?>"); continue; }
@@ -278,48 +281,95 @@ static bool read_mesh_vertices(const std::string& path, std::vector<V3>* out) {
     }
   } else if (ext == "dae") {
     // Collada: the POSITION source of every <mesh> - <vertices><input semantic="POSITION" source="#id"/> names the <source> whose
-    // <float_array> holds x y z triples.  <unit meter=".."> scales to metres; <up_axis>Y_UP</up_axis> is turned to the URDF's z-up.
-    // Node transforms of the visual scene are NOT applied (collision meshes are exported with identity transforms in practice).
-    auto attr = [&](size_t tag_pos, const char* name) -> std::string {
-      const size_t end = data.find('>', tag_pos);
-      const std::string key = std::string(name) + "=\"";
-      const size_t a = data.find(key, tag_pos);
-      if (end == std::string::npos || a == std::string::npos || a > end) return "";
-      const size_t b = data.find('"', a + key.size());
-      return b == std::string::npos ? "" : data.substr(a + key.size(), b - a - key.size());
-    };
+    // <float_array> holds x y z triples - placed by the node transforms of the visual scene (<matrix>, <translate>, <rotate>, <scale> of the
+    // <node> chain down to each <instance_geometry url="#geometry">; a geometry no node instantiates is taken as it is).  <unit meter="..">
+    // scales to metres; <up_axis>Y_UP</up_axis> is turned to the URDF's z-up.
+    std::unique_ptr<XmlNode> root;
+    try { XmlParser parser(data); root = parser.parse(); } catch (const std::exception&) { return false; }
+    if (!root) return false;
+    struct M4 { double m[16]; };
+    auto ident = [] { M4 r; for (int i = 0; i < 16; ++i) r.m[i] = (i % 5 == 0) ? 1.0 : 0.0; return r; };
+    auto mul4 = [](const M4& A, const M4& B) { M4 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double t = 0; for (int k = 0; k < 4; ++k) t += A.m[4 * i + k] * B.m[4 * k + j]; r.m[4 * i + j] = t; } return r; };
+    auto numbers = [](const std::string& t) { std::vector<double> f; const char* c = t.c_str(); for (;;) { char* nx = nullptr; const double v = std::strtod(c, &nx); if (nx == c) break; f.push_back(v); c = nx; } return f; };
     double unit = 1.0;
-    if (const size_t u = data.find("<unit"); u != std::string::npos) { const std::string m = attr(u, "meter"); if (!m.empty()) unit = std::atof(m.c_str()); }
-    const bool y_up = data.find("<up_axis>Y_UP</up_axis>") != std::string::npos;
-    size_t pos = 0;
-    while ((pos = data.find("<vertices", pos)) != std::string::npos) {
-      const size_t vend = data.find("</vertices>", pos);
-      size_t in = pos;
-      std::string src;
-      while ((in = data.find("<input", in + 1)) != std::string::npos && (vend == std::string::npos || in < vend))
-        if (attr(in, "semantic") == "POSITION") src = attr(in, "source");
-      pos += 9;
-      if (src.size() < 2 || src[0] != '#') continue;
-      const size_t sp = data.find("<source id=\"" + src.substr(1) + "\"");
-      if (sp == std::string::npos) continue;
-      const size_t fa = data.find("<float_array", sp), send = data.find("</source>", sp);
-      if (fa == std::string::npos || (send != std::string::npos && fa > send)) continue;
-      const size_t b = data.find('>', fa), e = data.find("</float_array>", fa);
-      if (b == std::string::npos || e == std::string::npos) continue;
-      const char* c = data.c_str() + b + 1;
-      const char* stop = data.c_str() + e;
-      std::vector<double> f;
-      while (c < stop) {
-        char* nx = nullptr;
-        const double v = std::strtod(c, &nx);
-        if (nx == c) break;
-        f.push_back(v); c = nx;
-      }
-      for (size_t i = 0; i + 2 < f.size(); i += 3) {
-        const double x = f[i] * unit, y = f[i + 1] * unit, z = f[i + 2] * unit;
-        if (y_up) out->push_back({x, -z, y}); else out->push_back({x, y, z});
+    bool y_up = false;
+    if (const XmlNode* as = root->child("asset")) {
+      if (const XmlNode* un = as->child("unit")) { if (const char* mt = un->get("meter")) unit = std::atof(mt); }
+      if (const XmlNode* up = as->child("up_axis")) y_up = up->text.find("Y_UP") != std::string::npos;
+    }
+    // geometry id -> its meshes' POSITION triples
+    std::map<std::string, std::vector<V3>> geo;
+    std::vector<std::string> geo_order;
+    for (auto& lib : root->kids) {
+      if (lib->tag != "library_geometries") continue;
+      for (auto& g : lib->kids) {
+        if (g->tag != "geometry") continue;
+        const char* gid = g->get("id");
+        std::vector<V3> pts;
+        for (auto& mesh : g->kids) {
+          if (mesh->tag != "mesh") continue;
+          for (auto& vs : mesh->kids) {
+            if (vs->tag != "vertices") continue;
+            std::string src;
+            for (auto& in : vs->kids) if (in->tag == "input" && in->get("semantic") && std::string(in->get("semantic")) == "POSITION" && in->get("source")) src = in->get("source");
+            if (src.size() < 2 || src[0] != '#') continue;
+            for (auto& so : mesh->kids) {
+              if (so->tag != "source" || !so->get("id") || src.substr(1) != so->get("id")) continue;
+              if (const XmlNode* fa = so->child("float_array")) {
+                const std::vector<double> f = numbers(fa->text);
+                for (size_t i = 0; i + 2 < f.size(); i += 3) pts.push_back({f[i], f[i + 1], f[i + 2]});
+              }
+            }
+          }
+        }
+        const std::string key = gid ? gid : ("#" + std::to_string(geo.size()));
+        geo[key] = pts; geo_order.push_back(key);
       }
     }
+    // the scene's nodes: accumulated transform down to every <instance_geometry>
+    std::vector<std::pair<std::string, M4>> inst;
+    std::function<void(const XmlNode*, const M4&)> walk = [&](const XmlNode* nd, const M4& parent) {
+      M4 T = parent;
+      for (auto& k : nd->kids) {
+        if (k->tag == "matrix") { const auto f = numbers(k->text); if (f.size() >= 16) { M4 L; for (int i = 0; i < 16; ++i) L.m[i] = f[i]; T = mul4(T, L); } }
+        else if (k->tag == "translate") { const auto f = numbers(k->text); if (f.size() >= 3) { M4 L = ident(); L.m[3] = f[0]; L.m[7] = f[1]; L.m[11] = f[2]; T = mul4(T, L); } }
+        else if (k->tag == "scale") { const auto f = numbers(k->text); if (f.size() >= 3) { M4 L = ident(); L.m[0] = f[0]; L.m[5] = f[1]; L.m[10] = f[2]; T = mul4(T, L); } }
+        else if (k->tag == "rotate") {
+          const auto f = numbers(k->text);
+          if (f.size() >= 4) {
+            const double n = std::sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+            if (n > 1e-12) {
+              const double x = f[0] / n, y = f[1] / n, z = f[2] / n, an = f[3] * 3.14159265358979323846 / 180.0, c = std::cos(an), sn = std::sin(an), t = 1 - c;
+              M4 L = ident();
+              L.m[0] = t * x * x + c;      L.m[1] = t * x * y - sn * z; L.m[2] = t * x * z + sn * y;
+              L.m[4] = t * x * y + sn * z; L.m[5] = t * y * y + c;      L.m[6] = t * y * z - sn * x;
+              L.m[8] = t * x * z - sn * y; L.m[9] = t * y * z + sn * x; L.m[10] = t * z * z + c;
+              T = mul4(T, L);
+            }
+          }
+        }
+      }
+      for (auto& k : nd->kids) {
+        if (k->tag == "instance_geometry" && k->get("url") && k->get("url")[0] == '#') inst.push_back({std::string(k->get("url") + 1), T});
+        else if (k->tag == "node") walk(k.get(), T);
+      }
+    };
+    for (auto& lib : root->kids)
+      if (lib->tag == "library_visual_scenes")
+        for (auto& sc : lib->kids)
+          if (sc->tag == "visual_scene")
+            for (auto& nd : sc->kids)
+              if (nd->tag == "node") walk(nd.get(), ident());
+    auto emit = [&](const std::vector<V3>& pts, const M4& T) {
+      for (const V3& v : pts) {
+        const double x = (T.m[0] * v.x + T.m[1] * v.y + T.m[2] * v.z + T.m[3]) * unit, y = (T.m[4] * v.x + T.m[5] * v.y + T.m[6] * v.z + T.m[7]) * unit,
+                     z = (T.m[8] * v.x + T.m[9] * v.y + T.m[10] * v.z + T.m[11]) * unit;
+        if (y_up) out->push_back({x, -z, y}); else out->push_back({x, y, z});
+      }
+    };
+    std::map<std::string, int> used;
+    for (auto& in : inst) { auto it = geo.find(in.first); if (it != geo.end()) { emit(it->second, in.second); ++used[in.first]; } }
+    for (auto& key : geo_order) if (!used.count(key)) emit(geo[key], ident());
   } else {
     return false;
   }

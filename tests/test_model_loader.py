@@ -310,3 +310,38 @@ def test_sampled_colliders_fill_capsule_axes_and_box_surfaces(built_lib):
         Model(urdf_string=log, sample_spacing=0.01)
     with pytest.raises(RsbError):
         Model(urdf_string=log, sample_spacing=-1.0)
+
+
+def test_collada_node_transforms_place_the_geometry(built_lib, tmp_path):
+    """Collada visual-scene nodes (<translate>, <rotate>, <scale>, nested <matrix>) down to <instance_geometry> are applied to the mesh's
+    vertices - a unit cube (z-up metres) instanced under translate(1,0,0) . rotate(z, 90 deg) . scale(2,1,1) and, below it, a child node
+    whose <matrix> lifts by 0.5: the collider's points are the transformed corners; a geometry no node instantiates is taken as it is."""
+    import itertools
+    pkg = tmp_path / "cube_description"
+    os.makedirs(pkg / "meshes"); os.makedirs(pkg / "urdf")
+    V = [(sx * 0.5, sy * 0.5, sz * 0.5) for sx, sy, sz in itertools.product((-1, 1), repeat=3)]
+    floats = " ".join("%.6f" % c for v in V for c in v)
+    (pkg / "meshes" / "cube.dae").write_text(f"""<?xml version="1.0" encoding="utf-8"?>
+<COLLADA xmlns="http://www.collada.org/2005/11/COLLADASchema" version="1.4.1">
+  <asset><unit name="meter" meter="1"/><up_axis>Z_UP</up_axis></asset>
+  <library_geometries><geometry id="cube"><mesh>
+    <source id="cube-pos"><float_array id="cube-pos-array" count="24">{floats}</float_array></source>
+    <vertices id="cube-vtx"><input semantic="POSITION" source="#cube-pos"/></vertices>
+  </mesh></geometry></library_geometries>
+  <library_visual_scenes><visual_scene id="Scene">
+    <node id="outer"><translate>1 0 0</translate><rotate>0 0 1 90</rotate><scale>2 1 1</scale>
+      <node id="inner"><matrix>1 0 0 0  0 1 0 0  0 0 1 0.5  0 0 0 1</matrix><instance_geometry url="#cube"/></node>
+    </node>
+  </visual_scene></library_visual_scenes>
+</COLLADA>
+""")
+    (pkg / "urdf" / "cube.urdf").write_text(MESH_URDF.format(fn="cube.dae").replace('scale="0.5 0.5 0.5"', 'scale="1 1 1"'))
+    m = Model(urdf_path=str(pkg / "urdf" / "cube.urdf"))
+    assert m.skipped_collisions == 0 and m.ncol == 8
+    P = np.array([[m.blob.col_pos[i][k] for k in range(3)] for i in range(8)])
+    # v -> T R S M v: lift z by 0.5, scale x by 2, rotate 90 deg about z ((x, y) -> (-y, x)), shift x by 1; then the URDF's collision origin
+    base = np.array([[-(y), 2 * x, z + 0.5] for x, y, z in V]) + [1.0, 0.0, 0.0]
+    off = P.mean(axis=0) - base.mean(axis=0)                          # the <collision><origin> of MESH_URDF
+    order = lambda A: A[np.lexsort(np.round(A, 4).T[::-1])]
+    assert np.allclose(order(P - off), order(base), atol=1e-9)
+    assert np.allclose(np.ptp(P, axis=0), [1.0, 2.0, 1.0], atol=1e-9)   # the cube became 1 x 2 x 1 (scaled along x, then turned)
