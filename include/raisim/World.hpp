@@ -413,6 +413,28 @@ class ArticulatedSystem {
   }
   void setPdTarget(const VecDyn& pTarget, const VecDyn& dTarget) { putRow(RSB_F_PTARGET, pTarget); putRow(RSB_F_DTARGET, dTarget); }
   void setGeneralizedForce(const VecDyn& tau) { putRow(RSB_F_TAU_FF, tau); }
+  /// upstream's one-sided setters and the common dimension aliases
+  void setPTarget(const VecDyn& pTarget) { putRow(RSB_F_PTARGET, pTarget); }
+  void setDTarget(const VecDyn& dTarget) { putRow(RSB_F_DTARGET, dTarget); }
+  size_t getGeneralizedVelocityDim() const { return getDOF(); }
+  /// upstream ArticulatedSystem::getPosition(bodyIdx, point_B, point_W): a point given in the body frame, in the world frame
+  void getPosition(size_t body, const Vec<3>& pointB, Vec<3>& pointW) {
+    Vec<3> p; Mat<3, 3> R;
+    getBodyPosition(body, p); getBodyOrientation(body, R);
+    for (int r = 0; r < 3; ++r) pointW[r] = p[r] + R(r, 0) * pointB[0] + R(r, 1) * pointB[1] + R(r, 2) * pointB[2];
+  }
+  /// upstream getVelocity(bodyIdx, vel_w) / getAngularVelocity(bodyIdx, angVel_w): the body frame's origin
+  void getVelocity(size_t body, Vec<3>& velW) { getFrameVelocity(body, velW); }
+  void getAngularVelocity(size_t body, Vec<3>& angVelW) { getFrameAngularVelocity(body, angVelW); }
+  /// ... and of a point given in the body frame: v_origin + w x (R point_B)
+  void getVelocity(size_t body, const Vec<3>& pointB, Vec<3>& velW) {
+    Vec<3> v, w; Mat<3, 3> R;
+    getFrameVelocity(body, v); getFrameAngularVelocity(body, w); getBodyOrientation(body, R);
+    double r[3];
+    for (int k = 0; k < 3; ++k) r[k] = R(k, 0) * pointB[0] + R(k, 1) * pointB[1] + R(k, 2) * pointB[2];
+    velW[0] = v[0] + w[1] * r[2] - w[2] * r[1]; velW[1] = v[1] + w[2] * r[0] - w[0] * r[2]; velW[2] = v[2] + w[0] * r[1] - w[1] * r[0];
+  }
+  void getBasePosition(Vec<3>& pos) { getBodyPosition(0, pos); }
 
   /// valid after World::integrate1() (upstream semantics): M(q) and h(q,u) of this env
   const MatDyn& getMassMatrix() {

@@ -60,6 +60,7 @@ int main(int argc, char** argv) {
     anymal->setControlMode(raisim::ControlMode::PD_PLUS_FEEDFORWARD_TORQUE);
     anymal->setPdGains(kp, kd);
     anymal->setPdTarget(pT, dT);
+    anymal->setPTarget(pT); anymal->setDTarget(dT);   // (upstream's one-sided setters: the same targets again)
     world.integrate1();
     const auto& M = anymal->getMassMatrix();
     CHECK(std::fabs(M(0, 0) - anymal->getTotalMass()) < 1e-3 && std::fabs(M(3, 7) - M(7, 3)) < 1e-6);
@@ -94,6 +95,26 @@ int main(int argc, char** argv) {
       anymal->getFrameVelocity(foot, vel);          // J(q+) * u+
       anymal->getFrameAngularVelocity(foot, w);
       for (int c = 0; c < 3; ++c) CHECK(std::fabs((p1[c] - p0[c]) / world.getTimeStep() - vel[c]) < 2e-2);
+      {   // upstream's point queries: a point of the body frame in the world, its velocity = v_origin + w x r; finite difference over the step
+        raisim::Vec<3> pb, pw, vw, vo, bp;
+        pb[0] = 0.05; pb[1] = -0.02; pb[2] = -0.1;
+        anymal->getPosition(foot, pb, pw);
+        anymal->getVelocity(foot, pb, vw);
+        anymal->getVelocity(foot, vo);
+        CHECK(std::fabs(vo[0] - vel[0]) < 1e-12 && std::fabs(vo[2] - vel[2]) < 1e-12);
+        raisim::Mat<3, 3> Rb;
+        anymal->getBodyOrientation(foot, Rb);
+        double r[3];
+        for (int k = 0; k < 3; ++k) r[k] = Rb(k, 0) * pb[0] + Rb(k, 1) * pb[1] + Rb(k, 2) * pb[2];
+        CHECK(std::fabs(pw[0] - (p1[0] + r[0])) < 1e-12 && std::fabs(pw[2] - (p1[2] + r[2])) < 1e-12);
+        CHECK(std::fabs(vw[0] - (vel[0] + w[1] * r[2] - w[2] * r[1])) < 1e-12);
+        raisim::Vec<3> wb;
+        anymal->getAngularVelocity(foot, wb);
+        CHECK(std::fabs(wb[1] - w[1]) < 1e-12);
+        anymal->getBasePosition(bp);
+        CHECK(std::fabs(bp[2] - anymal->getGeneralizedCoordinate()[2]) < 1e-6);
+        CHECK(anymal->getGeneralizedVelocityDim() == (size_t)gvDim);
+      }
       raisim::MatDyn J;
       anymal->getDenseFrameJacobian(foot, J);
       CHECK(J.rows() == 3 && (int)J.cols() == gvDim && std::fabs(J(0, 0) - 1.0) < 1e-12 && std::fabs(J(2, 17)) < 1e-12);   // RH joints do not move the LF foot
