@@ -119,7 +119,7 @@ class BatchedWorld {
   void setIntegrationScheme(int scheme) { RSB_CHECK(rsb_set_integration_scheme(world_, scheme)); }
   void setMultiContactSolverParam(int depth, bool lightPasses, int freezeAfter, int stallWindow) { RSB_CHECK(rsb_set_solver_multi_contact(world_, depth, lightPasses ? 1 : 0, freezeAfter, stallWindow)); }
   void setSolverAcceleration(int firstSweep, double clip = 20.0) { RSB_CHECK(rsb_set_solver_anderson(world_, firstSweep, clip)); }
-  void setHeightMapContactsPerPrimitive(int n, double minAngleDeg = 25.841932763167124) { RSB_CHECK(rsb_set_heightmap_contacts(world_, n, minAngleDeg)); }
+  void setHeightMapContactsPerPrimitive(int n, double minAngleDeg = 45.0) { RSB_CHECK(rsb_set_heightmap_contacts(world_, n, minAngleDeg)); }
   void addGround(double zHeight = 0.0) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_ground(world_, zHeight)); }
   void addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
                     const std::vector<double>& height) {

@@ -281,7 +281,7 @@ int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size,
                       double center_x, double center_y, const float* heights);
 /* Contacts per collision primitive against a height map (not RaiSim's collider; default 1 = the closest feature).  With 2, a
  * sphere that penetrates a SECOND flank - the closest penetrating point of the surface whose direction differs from the first
- * contact's normal by more than min_angle_deg (oracle default 25.84 deg = acos 0.9) - reports it as a second contact: a ball in
+ * contact's normal by more than min_angle_deg (pass 45: the oracle's default) - reports it as a second contact: a ball in
  * a valley then rests on both sides instead of rattling between them.  The second contact carries RSB_CONTACT_SECOND in
  * rsb_contact::collision, uses its primitive's material, starts cold in every solve, follows all first contacts in the list and
  * counts as its primitive for the termination rule and the foot forces of rsb_control_step.  A kernel class of its own (the

@@ -330,7 +330,7 @@ void orc_default_params(orc_params* p) {
   p->hm_index = NULL;
   p->multi_depth = 3; p->multi_light = 0; p->multi_freeze_after = 0; p->multi_stall_window = 16;
   p->anderson = 2; p->anderson_clip = 20.0;
-  p->hm_contacts = 1; p->hm_second_cos = 0.9;
+  p->hm_contacts = 1; p->hm_second_cos = 0.70710678118654752;
   p->integ_theta = 1.0;
 }
 

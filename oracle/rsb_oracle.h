@@ -91,7 +91,8 @@ typedef struct orc_params {
   int32_t anderson;
   double anderson_clip;
   /* contacts per collision primitive against a height map (default 1 = the closest feature; 2 = also the closest feature of a second
-   * flank: a sphere in a valley rests on both sides) and the cosine of the least angle between the two normals (default 0.9) */
+   * flank: a sphere in a valley rests on both sides) and the cosine of the least angle between the two normals (default cos 45 deg: near-parallel
+   * contacts of one sphere - the crease between two triangles of a smooth slope - are a redundant pair the per-contact iteration crawls on) */
   int32_t hm_contacts;
   double hm_second_cos;
   /* integration scheme of the positions: q+ = q (+) dt (theta u+ + (1 - theta) u); 1 = semi-implicit Euler (default), 0 = explicit Euler,

@@ -228,7 +228,7 @@ class BatchedWorld:
         code = {"trapezoid": 0, "semi_implicit": 1, "euler": 2, "runge_kutta_4": 3}[scheme] if isinstance(scheme, str) else int(scheme)
         check(self.L.rsb_set_integration_scheme(self.handle, code), "rsb_set_integration_scheme")
 
-    def set_heightmap_contacts(self, per_primitive=2, min_angle_deg=25.841932763167124):
+    def set_heightmap_contacts(self, per_primitive=2, min_angle_deg=45.0):
         """Contacts per collision primitive against a height map (1 = closest feature; 2 = also a second flank's; see rsb.h)."""
         check(self.L.rsb_set_heightmap_contacts(self.handle, int(per_primitive), float(min_angle_deg)), "rsb_set_heightmap_contacts")
 

@@ -573,7 +573,8 @@ def test_sampled_collider_model_parity_on_a_height_map(built_lib):
                min_conv=0.8, max_di=80)   # (kmax 16: multi-contact envs take the Anderson step, whose fp32 / fp64 paths part on a hard solve: 43 sweeps on one env of one build)
 
 
-def test_two_contacts_per_primitive_on_a_rough_map_parity(anymal):
+@pytest.mark.parametrize("angle", [None, 26.0])
+def test_two_contacts_per_primitive_on_a_rough_map_parity(anymal, angle):
     """rsb_set_heightmap_contacts(2) (kernel class 4) vs the oracle with hm_contacts = 2: ANYmal-like robots dropped low onto a rough map
     whose cells are about a foot radius wide - spheres sit in the creases between triangles; same contact lists (second contacts
     flagged, after all first ones), the usual one-step tolerance."""
@@ -586,7 +587,11 @@ def test_two_contacts_per_primitive_on_a_rough_map_parity(anymal):
     w = BatchedWorld(anymal, N)
     o = Oracle(anymal.blob)
     w.add_height_map(*hm); o.set_heightmap(*hm)
-    w.set_heightmap_contacts(2); o.p.hm_contacts = 2
+    o.p.hm_contacts = 2
+    if angle is None:
+        w.set_heightmap_contacts(2)                                    # the default least angle between the two normals: 45 deg on both sides
+    else:
+        w.set_heightmap_contacts(2, angle); o.p.hm_second_cos = np.cos(np.radians(angle))
     dtg = np.zeros((N, anymal.nv))
     w.set_pd_gains(kp, kd); w.set_pd_target(gc, dtg); w.set_state(gc, gv)
     w.integrate(1)
@@ -605,4 +610,13 @@ def test_two_contacts_per_primitive_on_a_rough_map_parity(anymal):
         n = cnt[e]
         assert np.abs(dev["con"][e][:n]["normal"] - ref["contacts"][e][:n]["normal"]).max() < 2e-4, e
         assert np.abs(dev["con"][e][:n]["depth"] - ref["contacts"][e][:n]["depth"]).max() < 5e-6, e
-    check_step({k: v[same] for k, v in dev.items()}, {k: (v[same] if isinstance(v, np.ndarray) and len(v) == len(same) else v) for k, v in ref.items()}, min_conv=0.8)
+    # envs without a second contact: the usual one-step bar.  Envs with one hold a redundant pair (two contacts on one sphere): the contact
+    # problem need not have ONE answer there, fp32 and fp64 may settle on different ones - bounded like the humanoid's redundant feet
+    has2 = second.any(axis=1)
+    pick = lambda m_: ({k: v[m_] for k, v in dev.items()}, {k: (v[m_] if isinstance(v, np.ndarray) and len(v) == len(m_) else v) for k, v in ref.items()})
+    check_step(*pick(same & ~has2), min_conv=0.75, both_converged=True)   # (robots dropped low onto a rough map: 13 % of the solves are slow ones that end on either side of the exit tests)
+    m2 = same & has2 & (((ref["flags"] | dev["flags"]) & 4) == 0)
+    assert m2.sum() > 20
+    eu = np.abs(dev["u"][m2] - ref["u"][m2]).max(axis=1) / (1 + np.abs(ref["u"][m2]).max(axis=1))
+    assert np.median(eu) < 1e-5 and np.percentile(eu, 90) < 2e-3 and eu.max() < 5e-2, (np.median(eu), np.percentile(eu, 90), eu.max())
+    assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()
