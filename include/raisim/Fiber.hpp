@@ -9,16 +9,24 @@
 // By default the fibers run one at a time on the caller's thread, exactly like the serial loop they replace; with threads > 1
 // they are dealt to a pool (cfg["num_threads"], what upstream's OpenMP loop uses) and the host part of the N step() bodies -
 // observation, reward, contact queries - runs in parallel between two flushes.
+//
+// Context switch.  glibc's swapcontext saves and restores the signal mask: one rt_sigprocmask system call per switch, i.e.
+// ~10 N system calls per control step of N envs (40 000 at N = 4096: round 3's drop-in path spent more time there than on the
+// GPU).  On x86-64 the switch is therefore hand-written (detail::fiber_switch below: the callee-saved registers of the SysV ABI
+// + the stack pointer, no system call, ~20 instructions); other architectures keep ucontext.
 #pragma once
 
 #include <sys/mman.h>
-#include <ucontext.h>
 #include <unistd.h>
+#if !defined(__x86_64__)
+#include <ucontext.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstddef>
+#include <cstdint>
 #include <cstdlib>
 #include <exception>
 #include <functional>
@@ -29,6 +37,56 @@
 
 namespace raisim {
 namespace detail {
+
+#if defined(__x86_64__)
+/// A parked context is its stack pointer; the stack holds (from the pointer upwards) rbx, rbp and the address to continue at.
+struct FiberContext { void* sp = nullptr; };
+/// Saves the running context into `from`, continues `to`.  Every register the SysV ABI lets a callee keep is either saved on the
+/// stack (rbx, rbp: not allowed in a clobber list when they are the PIC / frame register) or declared clobbered, so the compiler
+/// spills what is live around the call; 128 bytes are skipped first because the enclosing function may keep data in the red zone.
+__attribute__((noinline)) inline void fiber_switch(FiberContext* from, const FiberContext* to) {
+  void** save = &from->sp;
+  void* next = to->sp;
+  asm volatile(
+      "leaq -128(%%rsp), %%rsp\n\t"
+      "leaq 1f(%%rip), %%rax\n\t"
+      "pushq %%rax\n\t"
+      "pushq %%rbp\n\t"
+      "pushq %%rbx\n\t"
+      "movq %%rsp, (%0)\n\t"
+      "movq %1, %%rsp\n\t"
+      "popq %%rbx\n\t"
+      "popq %%rbp\n\t"
+      "popq %%rax\n\t"
+      "jmpq *%%rax\n\t"
+      "1:\n\t"
+      "endbr64\n\t"
+      "leaq 128(%%rsp), %%rsp\n\t"
+      : "+D"(save), "+S"(next)
+      :
+      : "rax", "rcx", "rdx", "r8", "r9", "r10", "r11", "r12", "r13", "r14", "r15", "memory", "cc",
+        "xmm0", "xmm1", "xmm2", "xmm3", "xmm4", "xmm5", "xmm6", "xmm7", "xmm8", "xmm9", "xmm10", "xmm11", "xmm12", "xmm13", "xmm14", "xmm15");
+}
+/// A fresh context that starts `entry` (which must never return) on the stack [stack, stack + bytes)
+inline void fiber_make(FiberContext* c, void* stack, size_t bytes, void (*entry)()) {
+  // at `entry`'s first instruction rsp + 8 must be 16-byte aligned, as after a call: [top - 8] is the (null) return address
+  uintptr_t top = (reinterpret_cast<uintptr_t>(stack) + bytes) & ~static_cast<uintptr_t>(15);
+  void** sp = reinterpret_cast<void**>(top);
+  *--sp = nullptr;                                 // return address of `entry`: never used
+  *--sp = reinterpret_cast<void*>(entry);          // continue here
+  *--sp = nullptr;                                 // rbp
+  *--sp = nullptr;                                 // rbx
+  c->sp = sp;
+}
+#else
+struct FiberContext { ucontext_t uc; };
+inline void fiber_switch(FiberContext* from, const FiberContext* to) { swapcontext(&from->uc, &to->uc); }
+inline void fiber_make(FiberContext* c, void* stack, size_t bytes, void (*entry)()) {
+  getcontext(&c->uc);
+  c->uc.uc_stack.ss_sp = stack; c->uc.uc_stack.ss_size = bytes; c->uc.uc_link = nullptr;
+  makecontext(&c->uc, entry, 0);
+}
+#endif
 
 class FiberScheduler {
  public:
@@ -71,15 +129,9 @@ class FiberScheduler {
     state_.assign(n, kReady);
     error_ = nullptr;
     failedFlag_.store(false);
-    mains_.assign(threads, ucontext_t());
+    mains_.assign(threads, FiberContext());
     auto owner = [&](int i) { return (int)((long long)i * threads / n); };
-    for (int i = 0; i < n; ++i) {
-      getcontext(&ctx_[i]);
-      ctx_[i].uc_stack.ss_sp = stacks_ + (size_t)i * (stackBytes_ + page_) + page_;
-      ctx_[i].uc_stack.ss_size = stackBytes_;
-      ctx_[i].uc_link = &mains_[owner(i)];
-      makecontext(&ctx_[i], reinterpret_cast<void (*)()>(&FiberScheduler::trampoline), 0);
-    }
+    for (int i = 0; i < n; ++i) fiber_make(&ctx_[i], stacks_ + (size_t)i * (stackBytes_ + page_) + page_, stackBytes_, &FiberScheduler::trampoline);
     // one round of thread t: resume each of its unfinished fibers once; returns (still live, parked now)
     auto round = [&](int t, int& live, int& parked) {
       Tls& me = tls();
@@ -90,9 +142,8 @@ class FiberScheduler {
         if (owner(i) != t || state_[i] == kDone) continue;
         me.running = i;
         state_[i] = kRunning;
-        swapcontext(&mains_[t], &ctx_[i]);
-        if (state_[i] == kRunning) state_[i] = kDone;   // returned through uc_link: the body finished
-        else { ++parked; ++live; }
+        fiber_switch(&mains_[t], &ctx_[i]);
+        if (state_[i] != kDone) { ++parked; ++live; }
       }
       me.sched = nullptr; me.running = -1;
     };
@@ -126,7 +177,7 @@ class FiberScheduler {
     Tls& me = tls();
     const int i = me.running;
     state_[i] = kParked;
-    swapcontext(&ctx_[i], &mains_[me.thread]);
+    fiber_switch(&ctx_[i], &mains_[me.thread]);
   }
   int running() const { return tls().running; }
 
@@ -137,8 +188,11 @@ class FiberScheduler {
   static void trampoline() {
     FiberScheduler* s = current();
     try { (*s->body_)(tls().running); } catch (...) { s->fail(std::current_exception()); }
-    // falling off the end switches to uc_link (= the owner thread's main context) with state_ still kRunning, which the round
-    // reads as "finished"
+    // the body is finished: back to the owner thread's main context for good (this context is never resumed)
+    Tls& me = tls();
+    s->state_[me.running] = kDone;
+    fiber_switch(&s->ctx_[me.running], &s->mains_[me.thread]);
+    std::abort();
   }
   bool failed() const { return failedFlag_.load(std::memory_order_acquire); }
   void fail(std::exception_ptr e) {
@@ -173,7 +227,7 @@ class FiberScheduler {
   size_t stackBytes_ = 0, page_ = 4096, mapped_ = 0;
   char* stacks_ = nullptr;
   int cap_ = 0;
-  std::vector<ucontext_t> ctx_, mains_;
+  std::vector<FiberContext> ctx_, mains_;
   std::vector<char> state_;
   const std::function<void(int)>* body_ = nullptr;
   std::exception_ptr error_;

@@ -45,6 +45,7 @@
 #ifndef RSB_H_
 #define RSB_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -344,6 +345,32 @@ int rsb_integrate2(rsb_world* w);
  * device first).  This is what the per-env raisim::World views (include/raisim/World.hpp) flush through, so that N
  * views calling integrate() cost one launch in which every env advances exactly once. */
 int rsb_integrate_masked(rsb_world* w, int n_substeps, const uint8_t* mask, int space);
+
+/* One flush of the per-env raisim::World views (include/raisim/World.hpp) in ONE call and ONE stream synchronisation:
+ * staged uploads -> launch -> the downloads the environments read.  What upstream's VectorizedEnvironment<ENV>::step pays per
+ * World::integrate() is nothing (its worlds live on the host); here every crossing of PCIe costs a latency, so the facade
+ * bundles them: round 3 paid up to five synchronous copies per integrate().  All pointers are HOST pointers (page-locked memory
+ * from rsb_host_alloc makes the copies asynchronous up to the final synchronisation); a NULL pointer skips that transfer.
+ *   uploads   p_target [N,nq], d_target [N,nv], tau_ff [N,nv]; gc / gv [N,nq] / [N,nv] with state_mask [N] (rows with mask 0 stay,
+ *             rows with mask 1 are overwritten and their solver warm state cleared: rsb_set_state's semantics)
+ *   launches  n_launches entries: launch_substeps[i] sub-steps for the envs whose launch_masks[i * N + env] != 0
+ *             (launch_masks NULL = every env in every launch)
+ *   downloads gc_out, gv_out, contact_counts [N], contacts [N,kmax], generalized_force [N,nv] (needs
+ *             rsb_enable_generalized_force_output) */
+typedef struct rsb_view_io {
+  const float* p_target; const float* d_target; const float* tau_ff;
+  const float* gc; const float* gv; const uint8_t* state_mask;
+  int32_t n_launches;
+  const int32_t* launch_substeps;
+  const uint8_t* launch_masks;
+  float* gc_out; float* gv_out;
+  int32_t* contact_counts; rsb_contact* contacts;
+  float* generalized_force;
+} rsb_view_io;
+int rsb_view_exchange(rsb_world* w, const rsb_view_io* io);
+/* page-locked host memory for the buffers of rsb_view_exchange (and any other RSB_HOST argument) */
+int rsb_host_alloc(size_t bytes, void** out);
+int rsb_host_free(void* p);
 
 /* contacts of the last sub-step: counts [N] int32, contacts [N,kmax] rsb_contact */
 int rsb_get_contacts(rsb_world* w, int32_t* counts, rsb_contact* contacts, int space);

@@ -1044,6 +1044,72 @@ int rsb_integrate_masked(rsb_world* w, int n_substeps, const uint8_t* mask, int 
   return do_integrate(w, n_substeps);
 }
 
+int rsb_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) { rsb::set_error("rsb_host_alloc: bad argument"); return RSB_E_INVALID; }
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return RSB_OK;
+}
+int rsb_host_free(void* p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return RSB_OK;
+}
+
+// One flush of the facade's per-env views: uploads, launches and downloads queued on the world's stream, ONE synchronisation at the end.
+int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
+  if (!w || !io || io->n_launches < 0 || (io->n_launches > 0 && !io->launch_substeps)) { rsb::set_error("rsb_view_exchange: bad argument"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
+  if (io->p_target) HIP_TRY(hipMemcpyAsync(w->d_pt, io->p_target, N * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  if (io->d_target) HIP_TRY(hipMemcpyAsync(w->d_dt, io->d_target, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  if (io->tau_ff) HIP_TRY(hipMemcpyAsync(w->d_tff, io->tau_ff, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  if (io->gc || io->gv) {
+    if (!io->state_mask) { rsb::set_error("rsb_view_exchange: state rows need state_mask"); return RSB_E_INVALID; }
+    if (!w->d_tmp_gc) {
+      HIP_TRY(hipMalloc(&w->d_tmp_gc, N * nq * sizeof(float)));
+      HIP_TRY(hipMalloc(&w->d_tmp_gv, N * nv * sizeof(float)));
+      HIP_TRY(hipMalloc(&w->d_tmp_mask, N));
+    }
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_mask, io->state_mask, N, hipMemcpyHostToDevice, w->stream));
+    if (io->gc) {
+      HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, io->gc, N * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
+      hipLaunchKernelGGL(masked_row_copy, dim3((N * nq + 255) / 256), dim3(256), 0, w->stream, w->d_gc, (const float*)w->d_tmp_gc, (const uint8_t*)w->d_tmp_mask, (int)N, (int)nq);
+    }
+    if (io->gv) {
+      HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, io->gv, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+      hipLaunchKernelGGL(masked_row_copy, dim3((N * nv + 255) / 256), dim3(256), 0, w->stream, w->d_gv, (const float*)w->d_tmp_gv, (const uint8_t*)w->d_tmp_mask, (int)N, (int)nv);
+    }
+    hipLaunchKernelGGL(warm_clear_kernel, dim3((N * rsbk::kWarmRow + 255) / 256), dim3(256), 0, w->stream, w->d_warm, (const uint8_t*)w->d_tmp_mask, (int)N, rsbk::kWarmRow);
+    HIP_TRY(hipGetLastError());
+    w->integrate1_valid = false;
+  }
+  if (io->n_launches > 0 && io->launch_masks) {
+    const size_t need = (size_t)io->n_launches * N;
+    if (w->view_masks_cap < need) {
+      if (w->d_view_masks) HIP_TRY(hipFree(w->d_view_masks));
+      w->d_view_masks = nullptr; w->view_masks_cap = 0;
+      HIP_TRY(hipMalloc(&w->d_view_masks, need));
+      w->view_masks_cap = need;
+    }
+    HIP_TRY(hipMemcpyAsync(w->d_view_masks, io->launch_masks, need, hipMemcpyHostToDevice, w->stream));
+  }
+  for (int i = 0; i < io->n_launches; ++i) {
+    if (io->launch_substeps[i] < 1) { rsb::set_error("rsb_view_exchange: launch_substeps must be >= 1"); return RSB_E_INVALID; }
+    if (io->launch_masks) w->launch_mask = w->d_view_masks + (size_t)i * N;
+    const int st = do_integrate(w, io->launch_substeps[i]);
+    if (st != RSB_OK) return st;
+  }
+  if (io->gc_out) HIP_TRY(hipMemcpyAsync(io->gc_out, w->d_gc, N * nq * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  if (io->gv_out) HIP_TRY(hipMemcpyAsync(io->gv_out, w->d_gv, N * nv * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  if (io->contact_counts) HIP_TRY(hipMemcpyAsync(io->contact_counts, w->d_count, N * sizeof(int32_t), hipMemcpyDeviceToHost, w->stream));
+  if (io->contacts) HIP_TRY(hipMemcpyAsync(io->contacts, w->d_contacts, N * w->kmax * sizeof(rsb_contact), hipMemcpyDeviceToHost, w->stream));
+  if (io->generalized_force) {
+    if (!w->want_genf || !w->d_genf) { rsb::set_error("rsb_view_exchange: generalized_force needs rsb_enable_generalized_force_output"); return RSB_E_INVALID; }
+    HIP_TRY(hipMemcpyAsync(io->generalized_force, w->d_genf, N * nv * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(w->stream));
+  return RSB_OK;
+}
+
 int rsb_set_done_output(rsb_world* w, uint8_t* done_device) {
   if (!w) return RSB_E_INVALID;
   w->d_done_out = done_device;
