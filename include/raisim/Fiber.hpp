@@ -172,6 +172,29 @@ class FiberScheduler {
     if (error_) { auto e = error_; error_ = nullptr; std::rethrow_exception(e); }   // fibers left parked are simply dropped
   }
 
+  /// fn(i) for i in [0, n) on the same pool of threads, without fibers: for the per-env loops that never touch the batch's launch
+  /// (observe(): upstream runs it as an OpenMP parallel-for as well).  fn must not call park().
+  void forEach(int n, const std::function<void(int)>& fn, int threads = 1) {
+    if (current()) throw std::runtime_error("FiberScheduler::forEach: called from inside a fiber");
+    threads = std::max(1, std::min(threads, n));
+    if (threads == 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    error_ = nullptr; failedFlag_.store(false);
+    auto block = [&](int t, int& live, int& parked) {
+      live = parked = 0;
+      const int lo = (int)((long long)t * n / threads), hi = (int)((long long)(t + 1) * n / threads);
+      try { for (int i = lo; i < hi && !failed(); ++i) fn(i); } catch (...) { fail(std::current_exception()); }
+    };
+    ensurePool(threads);
+    roundFn_ = block;
+    { std::lock_guard<std::mutex> lk(poolMutex_); ++roundNo_; reported_ = 0; liveSum_ = parkedSum_ = 0; }
+    poolCv_.notify_all();
+    int live, parked;
+    block(0, live, parked);
+    { std::unique_lock<std::mutex> lk(poolMutex_); ++reported_; poolCv_.wait(lk, [&] { return reported_ == threads; }); }
+    roundFn_ = nullptr;
+    if (error_) { auto e = error_; error_ = nullptr; std::rethrow_exception(e); }
+  }
+
   /// called from inside a fiber: give control back to the scheduler until the next flush
   void park() {
     Tls& me = tls();

@@ -50,15 +50,20 @@ class Reward {
   float sum() const { double s = 0; for (const auto& t : terms_) s += t.second.value; return (float)s; }
   float operator[](const std::string& name) const { return (float)terms_.at(name).value; }
   void reset() { for (auto& t : terms_) t.second.value = 0.0; }
-  std::map<std::string, float> getStdMap() const {
-    std::map<std::string, float> m;
-    for (const auto& t : terms_) m[t.first] = (float)t.second.value;
-    m["reward_sum"] = sum();
-    return m;
+  /// the terms and their sum as upstream logs them; the map is a member updated in place (upstream returns a reference as well
+  /// [RECALL]): VectorizedEnvironment copies it for every env in every step, and a freshly built map cost three allocations each time
+  const std::map<std::string, float>& getStdMap() {
+    if (log_.size() != terms_.size() + 1) { log_.clear(); for (const auto& t : terms_) log_[t.first] = 0.f; sumIt_ = log_.emplace("reward_sum", 0.f).first; }
+    auto it = log_.begin();
+    for (const auto& t : terms_) { if (it == sumIt_) ++it; it->second = (float)t.second.value; ++it; }   // (both maps iterate in key order)
+    sumIt_->second = sum();
+    return log_;
   }
  private:
   struct Term { double coeff, value; };
   std::map<std::string, Term> terms_;
+  std::map<std::string, float> log_;
+  std::map<std::string, float>::iterator sumIt_;
 };
 
 class RaisimServer;   // not provided (visualisation is out of scope)

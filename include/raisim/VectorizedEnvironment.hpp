@@ -7,10 +7,11 @@
 //       same methods and in-place caller-owned buffers ((T*, rows, cols) spans where upstream takes Eigen::Ref).  The
 //       ChildEnvironment is ARBITRARY user code written against raisim::World / ArticulatedSystem (an rsg_anymal-style
 //       Environment.hpp): its N instances are constructed inside a raisim::BatchScope, so their N Worlds are the N
-//       replicas of ONE BatchedWorld, and step() runs the N env->step() bodies as fibers (raisim/Fiber.hpp) that park in
-//       World::integrate() - every integrate() of the control step is ONE kernel launch for the whole batch, whatever
-//       the environment computes around it on the host.  Per integrate(): one upload of the staged PD targets, one
-//       launch, one download of the state (+ contacts when an env asks for them).
+//       replicas of ONE BatchedWorld, and step() runs the N env->step() bodies as fibers (raisim/Fiber.hpp).  World::integrate()
+//       only records a sub-step; the first read after it parks the fiber, and once every env is parked the batch is flushed:
+//       the control_dt / simulation_dt integrate() calls of an rsg_anymal-style step() are ONE fused kernel launch for the
+//       whole batch (the launch the benchmark times), bracketed by one upload of the staged PD targets and one download of
+//       what the environments read (state, contacts, generalized force) - a single rsb_view_exchange per control step.
 //
 //   raisim::DeviceVectorizedEnvironment   rsg_anymal's task compiled into the library (rsb_env_*): action scaling,
 //       observation, reward, termination and reset run on the GPU, a control step is one fused launch of
@@ -190,7 +191,7 @@ class VectorizedEnvironment {
   /// ob: float [num_envs, obDim] row-major (upstream: Eigen::Ref<EigenRowMajorMat>&)
   void observe(float* ob, int rows, int cols, bool updateStatistics) {
     RSFATAL_IF(rows != num_envs_ || cols != obDim_, "observe: buffer must be [num_envs, obDim]");
-    for (int i = 0; i < num_envs_; i++) environments_[i]->observe(EigenVecRef(ob + (size_t)i * obDim_, obDim_));
+    fibers_.forEach(num_envs_, [&](int i) { environments_[i]->observe(EigenVecRef(ob + (size_t)i * obDim_, obDim_)); }, threads_);   // (upstream: an OpenMP parallel-for)
     if (normalizeObservation_) updateObservationStatisticsAndNormalize(ob, updateStatistics);
   }
 
@@ -203,6 +204,7 @@ class VectorizedEnvironment {
     struct Guard { BatchedWorld* b; ~Guard() { b->setFiberBatch(false); b->abortViews(); } } guard{batch_.get()};   // (after a clean run nothing is pending)
     batch_->setFiberBatch(true);
     fibers_.run(num_envs_, body, [this] { batch_->flushViews(); }, threads_);
+    batch_->flushViews();      // integrate() calls of bodies that ended without reading anything afterwards
   }
 
   void turnOnVisualization() { if (render_) environments_[0]->turnOnVisualization(); }

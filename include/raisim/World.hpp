@@ -14,8 +14,14 @@
 //                              shared BatchedWorld with N replicas;
 //                            - World(BatchedWorld&, env) names the replica explicitly.
 //                          integrate() on a view advances THAT replica only: the call is recorded, and the batch is
-//                          flushed with a single launch once every replica has one pending (or, under
-//                          VectorizedEnvironment<ENV>, once every env's step() body is parked in integrate(): Fiber.hpp).
+//                          flushed with a single launch once every replica has one pending.  Under VectorizedEnvironment<ENV>
+//                          (Fiber.hpp) the call is recorded and the env's step() body simply CONTINUES: integrate() returns
+//                          nothing an env could look at, so k integrate() calls in a row are k recorded sub-steps, and only the
+//                          first read (or staged write) that follows parks the fiber.  Once every live env is parked the whole
+//                          batch is flushed by ONE rsb_view_exchange: staged uploads, ONE launch of k sub-steps (the fused
+//                          kernel the benchmark runs; envs with different counts go in masked launches), the downloads the
+//                          environments have been reading, one stream synchronisation.  RSB_VIEW_FUSE=0 restores round 3's
+//                          behaviour (a flush per integrate()).
 //                          Global setters (setTimeStep, setGravity, addGround, setERP, materials, solver parameters,
 //                          PD gains) act on the shared world, i.e. on ALL replicas - every env of a vectorised
 //                          environment calls them with the same values, as upstream's ENVs do.
@@ -30,8 +36,11 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <stdexcept>
 #include <string>
 #include <map>
@@ -53,6 +62,34 @@ enum Type : int { TRAPEZOID = 0, SEMI_IMPLICIT = 1, EULER = 2, RUNGE_KUTTA_4 = 3
 namespace ControlMode {
 enum Type : int { FORCE_AND_TORQUE = RSB_FORCE_AND_TORQUE, PD_PLUS_FEEDFORWARD_TORQUE = RSB_PD_PLUS_FEEDFORWARD_TORQUE };
 }
+
+/// Page-locked host array (rsb_host_alloc): the mirrors behind the per-env views, so that a flush's copies run asynchronously on
+/// the world's stream up to its single synchronisation.
+template <class T>
+class PinnedArray {
+ public:
+  PinnedArray() = default;
+  ~PinnedArray() { if (p_) rsb_host_free(p_); }
+  PinnedArray(const PinnedArray&) = delete;
+  PinnedArray& operator=(const PinnedArray&) = delete;
+  void resize(size_t n) {
+    if (n == n_) return;
+    if (p_) { rsb_host_free(p_); p_ = nullptr; n_ = 0; }
+    if (n == 0) return;
+    void* m = nullptr;
+    RSB_CHECK(rsb_host_alloc(n * sizeof(T), &m));
+    p_ = static_cast<T*>(m); n_ = n;
+    std::memset(static_cast<void*>(p_), 0, n * sizeof(T));
+  }
+  T* data() { return p_; }
+  const T* data() const { return p_; }
+  size_t size() const { return n_; }
+  T& operator[](size_t i) { return p_[i]; }
+  const T& operator[](size_t i) const { return p_[i]; }
+ private:
+  T* p_ = nullptr;
+  size_t n_ = 0;
+};
 
 /// One solved contact of an articulated system (upstream raisim::Contact).
 class Contact {
@@ -157,24 +194,31 @@ class BatchedWorld {
   // ---- staging and caches behind the per-env views (raisim::World / raisim::ArticulatedSystem) ---------------------
   /// stage one env's row of GC / GV / PTARGET / DTARGET / TAU_FF; uploaded as a whole array at the next flush.
   /// The host arrays double as the read mirror, so an env reading back what it just wrote costs no transfer.
+  /// Thread-safe against the whole-array operations: N step() bodies stage their rows concurrently (shared lock, distinct rows),
+  /// an upload / refresh of the mirrors takes the lock exclusively and so never sees a half-written row or clears the flags of
+  /// a row that is being written (a staged write used to be able to vanish that way).
   void stageRow(int field, int env, const double* v, int dim) {
-    Stage& st = stage(field);
+    syncView(env, "a staged write");          // integrate() calls recorded before this write must run before it
+    Stage& st = stage(field);                  // (creates the mirror on first use; takes mu_, so before the stage lock)
+    std::shared_lock<std::shared_mutex> sl(stageMu_);
     for (int i = 0; i < dim; ++i) st.host[(size_t)env * dim + i] = (float)v[i];
-    st.dirty = true;
     if (field == RSB_F_GC) gcMask_[env] = 1;
     if (field == RSB_F_GV) gvMask_[env] = 1;
+    raise(st.dirty);
   }
   /// one env's row of any of the five fields, as the device holds (or is about to hold) it
   void readRow(int field, int env, double* out, int dim) {
-    requireNotPending(env, "a state read");
+    if (field == RSB_F_GC || field == RSB_F_GV) raise(wantState_);
+    syncView(env, "a state read");
     if (field == RSB_F_GC || field == RSB_F_GV) refreshState();
     const float* src = stage(field).host.data();
     for (int i = 0; i < dim; ++i) out[i] = src[(size_t)env * dim + i];
   }
   /// the generalized force the actuators applied to replica `env` in its last integrate() (one download per launch)
   void readGeneralizedForce(int env, double* out, int dim) {
-    requireNotPending(env, "getGeneralizedForce()");
-    if (!genfValid_) {
+    raise(wantGenf_);
+    syncView(env, "getGeneralizedForce()");
+    if (!genfValid_.load(std::memory_order_acquire)) {
       std::lock_guard<std::recursive_mutex> lk(mu_);
       if (!genfValid_) {
         genf_.resize((size_t)n_ * dim);
@@ -184,37 +228,82 @@ class BatchedWorld {
     }
     for (int i = 0; i < dim; ++i) out[i] = genf_[(size_t)env * dim + i];
   }
-  /// World::integrate() of replica `env`: recorded; flushed when every replica has one pending, or by the fiber scheduler
+  /// World::integrate() of replica `env`: recorded.  Outside a fiber batch it is flushed when every replica has one pending;
+  /// inside one (VectorizedEnvironment<ENV>) the body continues and the record is flushed at the env's next read / staged write
+  /// (syncView), together with everybody else's - k integrate() calls in a row become ONE launch of k sub-steps.
   void integrateView(int env) {
+    detail::FiberScheduler* fs = detail::FiberScheduler::current();
+    if (fs && fiberBatch_) {
+      if (pending_[env]++ == 0) ++nPending_;
+      if (!fuse_) fs->park();                            // RSB_VIEW_FUSE=0: a flush per integrate(), as in round 3
+      return;
+    }
     if (pending_[env]) throw std::runtime_error("raisim::World::integrate(): this replica already has an un-flushed integrate(); "
                                                 "every World of the batch must call integrate() before the next one (or drive the envs through VectorizedEnvironment<ENV>)");
     pending_[env] = 1; ++nPending_;
-    detail::FiberScheduler* fs = detail::FiberScheduler::current();
-    if (fs && fiberBatch_) { fs->park(); return; }       // flushed by the scheduler once every live env is parked here
     if (nPending_ == n_) flushViews();
   }
-  /// one launch for all pending replicas (no-op when none is pending)
+  /// integrate1() of a view: the whole-batch query, after this replica's recorded integrate() calls have run
+  void integrate1View(int env) { syncView(env, "integrate1()"); integrate1(); }
+  /// time of replica `env`: the batch's clock plus the integrate() calls this replica has recorded but not yet run
+  double worldTimeOf(int env) const { return rsb_get_world_time(world_) + pending_[env] * rsb_get_timestep(world_); }
+  /// one rsb_view_exchange for everything that is pending: staged rows up, the recorded integrate() calls (ONE launch when every
+  /// replica recorded the same number, else masked launches by count), the fields the environments read down; one synchronisation
   void flushViews() {
     std::lock_guard<std::recursive_mutex> lk(mu_);
     if (nPending_ == 0) return;
-    uploadStaged();
-    if (nPending_ == n_) RSB_CHECK(rsb_integrate(world_, 1));
-    else RSB_CHECK(rsb_integrate_masked(world_, 1, pending_.data(), RSB_HOST));
+    std::unique_lock<std::shared_mutex> sl(stageMu_);
+    rsb_view_io io{};
+    collectUploads(io);
+    // launches: distinct counts c_1 < c_2 < ...; launch i runs c_i - c_(i-1) sub-steps for the envs with count >= c_i
+    int cmin = 1 << 30, cmax = 0;
+    for (int e = 0; e < n_; ++e) { cmin = std::min(cmin, pending_[e]); cmax = std::max(cmax, pending_[e]); }
+    launchSub_.clear();
+    if (cmin == cmax) launchSub_.push_back(cmax);         // (the usual case: every env of the batch ran the same step() body)
+    else {
+      std::vector<int> levels(pending_.begin(), pending_.end());
+      std::sort(levels.begin(), levels.end());
+      levels.erase(std::unique(levels.begin(), levels.end()), levels.end());
+      if (levels.front() == 0) levels.erase(levels.begin());
+      launchMasks_.resize((size_t)levels.size() * n_);
+      int prev = 0;
+      for (size_t i = 0; i < levels.size(); ++i) {
+        launchSub_.push_back(levels[i] - prev); prev = levels[i];
+        for (int e = 0; e < n_; ++e) launchMasks_[i * n_ + e] = pending_[e] >= levels[i] ? 1 : 0;
+      }
+      io.launch_masks = launchMasks_.data();
+    }
+    io.n_launches = (int32_t)launchSub_.size(); io.launch_substeps = launchSub_.data();
+    // downloads: what the environments have been reading since the batch exists (sticky: an env that reads its contacts in one
+    // control step reads them in the next).  The mirrors' staged rows have just been uploaded, so whole arrays can be overwritten.
+    const bool st = wantState_, ct = wantContacts_, gf = wantGenf_;
+    if (st) { Stage& gc = stageLocked(RSB_F_GC); Stage& gv = stageLocked(RSB_F_GV); io.gc_out = gc.host.data(); io.gv_out = gv.host.data(); }
+    if (ct) {
+      if (kmax_ == 0) RSB_CHECK(rsb_dims(world_, nullptr, nullptr, nullptr, nullptr, &kmax_));
+      cnt_.resize(n_); con_.resize((size_t)n_ * kmax_);
+      io.contact_counts = cnt_.data(); io.contacts = con_.data();
+    }
+    if (gf) { genf_.resize((size_t)n_ * blob_.nv); io.generalized_force = genf_.data(); }
+    RSB_CHECK(rsb_view_exchange(world_, &io));
     std::fill(pending_.begin(), pending_.end(), 0);
     nPending_ = 0;
-    ++viewLaunches_;
-    stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false;
+    viewLaunches_ += (long)launchSub_.size();
+    ++viewFlushes_;
+    stateCacheValid_ = st; contactsValid_ = ct; genfValid_ = gf; queryValid_ = false;
   }
   /// drop every recorded-but-unflushed integrate() (error path of the fiber scheduler: the parked fibers are gone, their
   /// pending flags must not outlive them or every later step() would throw "already has an un-flushed integrate()")
   void abortViews() { std::fill(pending_.begin(), pending_.end(), 0); nPending_ = 0; }
   void setFiberBatch(bool on) { fiberBatch_ = on; }
-  long viewLaunches() const { return viewLaunches_; }     ///< launches issued by flushViews() (tests: N views -> 1 launch)
+  void setFuseIntegrateCalls(bool on) { fuse_ = on; }     ///< (tests, A/B) false = a flush per integrate()
+  long viewLaunches() const { return viewLaunches_; }     ///< launches issued by flushViews() (tests: N views x k integrate() -> 1 launch)
+  long viewFlushes() const { return viewFlushes_; }       ///< rsb_view_exchange calls issued by flushViews()
   int pendingViews() const { return nPending_; }
   /// contacts of the last integrate() of every env, downloaded once per flush
-  const std::vector<rsb_contact>& contactsOf(int env, int& count, int& kmax) {
-    requireNotPending(env, "getContacts()");
-    if (!contactsValid_) {
+  const PinnedArray<rsb_contact>& contactsOf(int env, int& count, int& kmax) {
+    raise(wantContacts_);
+    syncView(env, "getContacts()");
+    if (!contactsValid_.load(std::memory_order_acquire)) {
       std::lock_guard<std::recursive_mutex> lk(mu_);
       if (!contactsValid_) {
         RSB_CHECK(rsb_dims(world_, nullptr, nullptr, nullptr, nullptr, &kmax_));
@@ -229,31 +318,24 @@ class BatchedWorld {
   /// staged rows -> device (before a launch, or before a query that must see them)
   void uploadStaged() {
     std::lock_guard<std::recursive_mutex> lk(mu_);
-    Stage& gc = stages_[RSB_F_GC]; Stage& gv = stages_[RSB_F_GV];
-    if (gc.dirty || gv.dirty) {
-      // masked upload: only the rows a view wrote are overwritten (and their solver warm state cleared).  A row written in
-      // only one of the two fields takes its other half from the mirror, which must then be current.
-      bool half = false;
-      for (int e = 0; e < n_ && !half; ++e) half = gcMask_[e] != gvMask_[e];
-      if (half) refreshState();
-      std::vector<uint8_t> m(n_);
-      for (int e = 0; e < n_; ++e) m[e] = gcMask_[e] | gvMask_[e];
-      RSB_CHECK(rsb_set_state(world_, stage(RSB_F_GC).host.data(), stage(RSB_F_GV).host.data(), m.data(), RSB_HOST));
-      gc.dirty = gv.dirty = false; queryValid_ = false;
-      std::fill(gcMask_.begin(), gcMask_.end(), 0); std::fill(gvMask_.begin(), gvMask_.end(), 0);
-    }
-    Stage& pt = stages_[RSB_F_PTARGET]; Stage& dt = stages_[RSB_F_DTARGET]; Stage& tf = stages_[RSB_F_TAU_FF];
-    if (pt.dirty || dt.dirty || tf.dirty) queryValid_ = false;
-    if (pt.dirty || dt.dirty) { RSB_CHECK(rsb_set_pd_target(world_, pt.dirty ? pt.host.data() : nullptr, dt.dirty ? dt.host.data() : nullptr, RSB_HOST)); pt.dirty = dt.dirty = false; }
-    if (tf.dirty) { RSB_CHECK(rsb_set_generalized_force(world_, tf.host.data(), RSB_HOST)); tf.dirty = false; }
+    std::unique_lock<std::shared_mutex> sl(stageMu_);
+    rsb_view_io io{};
+    if (collectUploads(io)) RSB_CHECK(rsb_view_exchange(world_, &io));
   }
 
  private:
-  struct Stage { std::vector<float> host; std::atomic<bool> init{false}, dirty{false}; };
+  struct Stage { PinnedArray<float> host; std::atomic<bool> init{false}, dirty{false}; };
+  /// set a flag that N env bodies on several threads raise over and over: a plain load when it is already up (a store - let alone a
+  /// sequentially consistent one - would bounce the flag's cache line between the threads on every read of every env)
+  static void raise(std::atomic<bool>& f) { if (!f.load(std::memory_order_relaxed)) f.store(true, std::memory_order_release); }
   Stage& stage(int field) {
     Stage& st = stages_[field];
-    if (st.init) return st;  // (fast path: no lock once the mirror exists)
+    if (st.init.load(std::memory_order_acquire)) return st;  // (fast path: no lock once the mirror exists)
     std::lock_guard<std::recursive_mutex> lk(mu_);
+    return stageLocked(field);
+  }
+  Stage& stageLocked(int field) {     // mu_ held
+    Stage& st = stages_[field];
     if (!st.init) {          // the host copy starts as what the device holds
       const int dim = (field == RSB_F_GC || field == RSB_F_PTARGET) ? blob_.nq : blob_.nv;
       st.host.resize((size_t)n_ * dim);
@@ -262,13 +344,41 @@ class BatchedWorld {
     }
     return st;
   }
+  /// the staged rows as uploads of one rsb_view_exchange (mu_ and stageMu_ held; the exchange must follow): true if there are any
+  bool collectUploads(rsb_view_io& io) {
+    bool any = false;
+    Stage& gc = stages_[RSB_F_GC]; Stage& gv = stages_[RSB_F_GV];
+    if (gc.dirty || gv.dirty) {
+      // masked upload: only the rows a view wrote are overwritten (and their solver warm state cleared).  A row written in
+      // only one of the two fields takes its other half from the mirror, which must then be current.
+      bool half = false;
+      for (int e = 0; e < n_ && !half; ++e) half = gcMask_[e] != gvMask_[e];
+      if (half) refreshStateLocked();
+      stateMask_.resize(n_);
+      for (int e = 0; e < n_; ++e) stateMask_[e] = gcMask_[e] | gvMask_[e];
+      io.gc = stageLocked(RSB_F_GC).host.data(); io.gv = stageLocked(RSB_F_GV).host.data(); io.state_mask = stateMask_.data();
+      gc.dirty = gv.dirty = false;
+      std::fill(gcMask_.begin(), gcMask_.end(), 0); std::fill(gvMask_.begin(), gvMask_.end(), 0);
+      any = true;
+    }
+    Stage& pt = stages_[RSB_F_PTARGET]; Stage& dt = stages_[RSB_F_DTARGET]; Stage& tf = stages_[RSB_F_TAU_FF];
+    if (pt.dirty) { io.p_target = pt.host.data(); pt.dirty = false; any = true; }
+    if (dt.dirty) { io.d_target = dt.host.data(); dt.dirty = false; any = true; }
+    if (tf.dirty) { io.tau_ff = tf.host.data(); tf.dirty = false; any = true; }
+    if (any) queryValid_ = false;
+    return any;
+  }
   void dropStage(int field) { stages_[field].init = false; stages_[field].dirty = false; }
   /// make the GC / GV mirrors current: one download after a launch; rows staged since then keep their staged values
   void refreshState() {
-    if (stateCacheValid_ && stages_[RSB_F_GC].init && stages_[RSB_F_GV].init) return;     // (fast path without the lock)
+    if (stateCacheValid_.load(std::memory_order_acquire) && stages_[RSB_F_GC].init.load(std::memory_order_acquire) && stages_[RSB_F_GV].init.load(std::memory_order_acquire)) return;     // (fast path without the lock)
     std::lock_guard<std::recursive_mutex> lk(mu_);
+    std::unique_lock<std::shared_mutex> sl(stageMu_);       // no row is being staged while the mirrors are overwritten
+    refreshStateLocked();
+  }
+  void refreshStateLocked() {       // mu_ and stageMu_ (exclusively) held
     if (stateCacheValid_ && stages_[RSB_F_GC].init && stages_[RSB_F_GV].init) return;
-    Stage& gc = stage(RSB_F_GC); Stage& gv = stage(RSB_F_GV);
+    Stage& gc = stageLocked(RSB_F_GC); Stage& gv = stageLocked(RSB_F_GV);
     tmpGc_.resize(gc.host.size()); tmpGv_.resize(gv.host.size());
     RSB_CHECK(rsb_get_state(world_, tmpGc_.data(), tmpGv_.data(), RSB_HOST));
     const int nq = blob_.nq, nv = blob_.nv;
@@ -278,8 +388,13 @@ class BatchedWorld {
     }
     stateCacheValid_ = true;
   }
-  void requireNotPending(int env, const char* what) const {
-    if (pending_[env]) throw std::runtime_error(std::string("raisim::World view: ") + what + " while this replica's integrate() is still waiting for the "
+  /// a read or staged write of replica `env`: its recorded integrate() calls run first.  In a fiber batch the fiber parks until the
+  /// scheduler has flushed the batch; outside one the caller has broken the "every view integrates, then reads" protocol
+  void syncView(int env, const char* what) {
+    if (!pending_[env]) return;
+    detail::FiberScheduler* fs = detail::FiberScheduler::current();
+    if (fs && fiberBatch_) { while (pending_[env]) fs->park(); return; }
+    throw std::runtime_error(std::string("raisim::World view: ") + what + " while this replica's integrate() is still waiting for the "
                                                 "other replicas of the batch (all views must call integrate() first, or use VectorizedEnvironment<ENV>)");
   }
   void init(int numEnvs, int device) {
@@ -321,19 +436,25 @@ class BatchedWorld {
   rsb_model_blob blob_;
   int n_ = 0;
   Stage stages_[5];
-  std::vector<uint8_t> pending_, gcMask_, gvMask_;
-  std::atomic<int> nPending_{0};
+  std::vector<int> pending_;                  // integrate() calls each replica has recorded since the last flush
+  std::vector<uint8_t> gcMask_, gvMask_;
+  std::atomic<int> nPending_{0};              // replicas with a non-zero count
+  std::vector<int32_t> launchSub_;
+  PinnedArray<uint8_t> launchMasks_, stateMask_;
   int kmax_ = 0;
-  long viewLaunches_ = 0;
+  long viewLaunches_ = 0, viewFlushes_ = 0;
+  bool fuse_ = !(std::getenv("RSB_VIEW_FUSE") && std::atoi(std::getenv("RSB_VIEW_FUSE")) == 0);
+  std::atomic<bool> wantState_{false}, wantContacts_{false}, wantGenf_{false};   // what the environments read: downloaded by every flush
+  std::shared_mutex stageMu_;                 // shared: an env stages one of its rows; exclusive: whole-array upload / refresh of the mirrors (after mu_)
   long queryLaunches_ = 0;
   bool fiberBatch_ = false;
   // set once per flush by the first env that asks, read by all: the N env bodies between two flushes may run on several threads
   std::atomic<bool> stateCacheValid_{false}, contactsValid_{false}, genfValid_{false}, queryValid_{false};
   std::recursive_mutex mu_;   // serialises every call into the C-ABI handle (not re-entrant per handle) and the lazy downloads
-  std::vector<float> genf_;
+  PinnedArray<float> genf_;
   std::vector<float> tmpGc_, tmpGv_;
-  std::vector<int32_t> cnt_;
-  std::vector<rsb_contact> con_;
+  PinnedArray<int32_t> cnt_;
+  PinnedArray<rsb_contact> con_;
 };
 
 class Ground {};
@@ -465,7 +586,7 @@ class ArticulatedSystem {
   /// contacts of the last integrate() of this env
   std::vector<Contact>& getContacts() {
     int kmax = 0, count = 0;
-    const std::vector<rsb_contact>& con = w_->contactsOf(env_, count, kmax);
+    const PinnedArray<rsb_contact>& con = w_->contactsOf(env_, count, kmax);
     contacts_.clear();
     for (int k = 0; k < count; ++k) contacts_.emplace_back(con[(size_t)env_ * kmax + k]);
     return contacts_;
@@ -508,11 +629,11 @@ class ArticulatedSystem {
   /// upstream ArticulatedSystem::getGeneralizedForce(): what the actuators applied in the last integrate() - clipped PD +
   /// feed-forward on the joints, the feed-forward wrench on a floating base's six rows (zero before the first integrate())
   const VecDyn& getGeneralizedForce() {
-    const int dim = w_->dof();
+    const int dim = w_->dof(), off = gvOff();
+    if ((int)gf_.size() != dim - off) gf_.resize(dim - off);
+    if (off == 0) { w_->readGeneralizedForce(env_, gf_.data(), dim); return gf_; }
     std::vector<double> full((size_t)dim);
     w_->readGeneralizedForce(env_, full.data(), dim);
-    const int off = gvOff();
-    gf_.resize(dim - off);
     for (int i = off; i < dim; ++i) gf_[i - off] = full[i];
     return gf_;
   }
@@ -527,7 +648,7 @@ class ArticulatedSystem {
   }
 
  private:
-  const VecDyn& fullGc() { fullq_.resize(w_->gcDim()); w_->readRow(RSB_F_GC, env_, fullq_.data(), w_->gcDim()); return fullq_; }   // incl. the base entries of a fixed-base system
+  const VecDyn& fullGc() { if ((int)fullq_.size() != w_->gcDim()) fullq_.resize(w_->gcDim()); w_->readRow(RSB_F_GC, env_, fullq_.data(), w_->gcDim()); return fullq_; }   // incl. the base entries of a fixed-base system
   int gcOff() const { return isFixedBase() ? 7 : 0; }
   int gvOff() const { return isFixedBase() ? 6 : 0; }
   void putRow(int field, const VecDyn& v) {
@@ -543,7 +664,7 @@ class ArticulatedSystem {
   void getRow(int field, VecDyn& v, int dim) {
     const bool isq = field == RSB_F_GC || field == RSB_F_PTARGET;
     const int off = isq ? gcOff() : gvOff();
-    if (off == 0) { v.resize(dim); w_->readRow(field, env_, v.data(), dim); return; }
+    if (off == 0) { if ((int)v.size() != dim) v.resize(dim); w_->readRow(field, env_, v.data(), dim); return; }
     std::vector<double> full((size_t)dim);
     w_->readRow(field, env_, full.data(), dim);
     v.resize(dim - off);
@@ -727,7 +848,7 @@ class World {
   }
   void setTimeStep(double dt) { dt_ = dt; if (shared_) shared_->setTimeStep(dt); }
   double getTimeStep() const { return shared_ ? shared_->getTimeStep() : dt_; }
-  double getWorldTime() const { return shared_ ? shared_->getWorldTime() : 0.0; }
+  double getWorldTime() const { return shared_ ? shared_->worldTimeOf(env_) : 0.0; }
   void setGravity(const Vec<3>& g) { need().setGravity(g); }
   void setERP(double erp, double erp2 = 0) { need().setERP(erp, erp2); }
   void setDefaultMaterial(double mu, double r = 0, double t = 0) { need().setDefaultMaterial(mu, r, t); }
@@ -738,7 +859,7 @@ class World {
   /// advances THIS replica by one time step; launched together with the other replicas' pending integrate() calls
   void integrate() { need().integrateView(env_); }
   /// M, h queries of the current state (computed for the whole batch, idempotent); integrate2() then advances this replica
-  void integrate1() { need().integrate1(); }
+  void integrate1() { need().integrate1View(env_); }
   void integrate2() { need().integrateView(env_); }
 
  private:

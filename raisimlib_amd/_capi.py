@@ -128,6 +128,9 @@ PROTOTYPES = {
     "rsb_set_generalized_force": (_I, [_VP, _FP, _I]),
     "rsb_integrate": (_I, [_VP, _I]),
     "rsb_integrate_masked": (_I, [_VP, _I, _VP, _I]),
+    "rsb_view_exchange": (_I, [_VP, _VP]),
+    "rsb_host_alloc": (_I, [C.c_size_t, _VP]),
+    "rsb_host_free": (_I, [_VP]),
     "rsb_set_done_output": (_I, [_VP, _VP]),
     "rsb_comm_get_unique_id": (_I, [C.c_char_p]),
     "rsb_comm_init": (_I, [_VP, _I, _I, C.c_char_p]),

@@ -68,6 +68,8 @@ struct rsb_world {
   uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
   const uint8_t* launch_mask = nullptr; // env mask of the next launch only (rsb_integrate_masked)
   uint8_t* d_launch_mask = nullptr;     // staging for host masks
+  uint8_t* d_view_masks = nullptr;      // [n_launches][N] launch masks of rsb_view_exchange
+  size_t view_masks_cap = 0;
   void* comm = nullptr;                 // ncclComm_t (rsb_comm_init)
   int comm_ranks = 0, comm_rank = 0;
   float *d_obs_local = nullptr, *d_obs_all = nullptr;   // staging of rsb_allgather_obs
@@ -675,7 +677,7 @@ int rsb_destroy(rsb_world* w) {
   (void)rsb_obs_peer_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_genf, w->d_hm_index, w->d_launch_mask, w->d_obs_local, w->d_obs_all,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_genf, w->d_hm_index, w->d_launch_mask, w->d_view_masks, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);

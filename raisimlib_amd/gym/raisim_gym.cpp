@@ -13,6 +13,8 @@
 // Upstream takes Eigen::Ref<EigenRowMajorMat> / EigenVec / EigenBoolVec (pybind11/eigen.h); Eigen is not installed here, so
 // the bindings take C-contiguous numpy arrays of the same dtypes and shapes (float32 [num_envs, dim], float32 [num_envs],
 // bool [num_envs]) through the buffer protocol and write them in place - the Python side cannot tell the difference.
+// Every in-place argument is bound .noconvert(): an array of another dtype or layout raises TypeError, as upstream's Eigen::Ref
+// bindings do, instead of being converted to a temporary copy that would swallow the results.
 // A second class, DeviceRaisimGymEnv, binds raisim::DeviceVectorizedEnvironment (rsg_anymal's task compiled into the library;
 // pointer arguments are device addresses, e.g. torch.Tensor.data_ptr()).
 #include <pybind11/numpy.h>
@@ -59,20 +61,20 @@ PYBIND11_MODULE(RSG_MODULE_NAME, m) {
       .def("observe", [](VecEnv& e, FMat ob, bool updateStatistics) {
              e.observe(mat(ob, e.getNumOfEnvs(), e.getObDim(), "observe: ob must be a writeable C-contiguous float32 [num_envs, obDim] array"),
                        e.getNumOfEnvs(), e.getObDim(), updateStatistics);
-           }, py::arg("ob"), py::arg("updateStatistics") = true)
+           }, py::arg("ob").noconvert(), py::arg("updateStatistics") = true)
       .def("step", [](VecEnv& e, FMat action, FMat reward, BVec done) {
              need(action.ndim() == 2 && action.shape(0) == e.getNumOfEnvs() && action.shape(1) == e.getActionDim(), "step: action must be float32 [num_envs, actionDim]");
              need(done.size() == e.getNumOfEnvs() && done.writeable(), "step: done must be a writeable bool [num_envs] array");
              float* r = vec(reward, e.getNumOfEnvs(), "step: reward must be a writeable float32 [num_envs] array");
              py::gil_scoped_release nogil;      // the N Environment::step() bodies and their launches run without the GIL
              e.step(action.data(), e.getNumOfEnvs(), e.getActionDim(), r, done.mutable_data());
-           }, py::arg("action"), py::arg("reward"), py::arg("done"))
+           }, py::arg("action").noconvert(), py::arg("reward").noconvert(), py::arg("done").noconvert())
       .def("setSeed", &VecEnv::setSeed)
       .def("close", &VecEnv::close)
       .def("isTerminalState", [](VecEnv& e, BVec t) {
              need(t.size() == e.getNumOfEnvs() && t.writeable(), "isTerminalState: bool [num_envs] array expected");
              e.isTerminalState(t.mutable_data());
-           })
+           }, py::arg("terminalState").noconvert())
       .def("setSimulationTimeStep", &VecEnv::setSimulationTimeStep)
       .def("setControlTimeStep", &VecEnv::setControlTimeStep)
       .def("getObDim", &VecEnv::getObDim)
@@ -87,13 +89,13 @@ PYBIND11_MODULE(RSG_MODULE_NAME, m) {
              float count = 0.f;
              e.getObStatistics(vec(mean, e.getObDim(), "getObStatistics: mean must be float32 [obDim]"), vec(var, e.getObDim(), "getObStatistics: var must be float32 [obDim]"), count);
              return count;       // (upstream passes count by reference; a Python float cannot be written in place)
-           })
+           }, py::arg("mean").noconvert(), py::arg("var").noconvert())
       .def("setObStatistics", [](VecEnv& e, FMat mean, FMat var, float count) {
              need(mean.size() == e.getObDim() && var.size() == e.getObDim(), "setObStatistics: float32 [obDim] arrays expected");
              e.setObStatistics(mean.data(), var.data(), count);
            })
       .def("getRewardInfo", &VecEnv::getRewardInfo)
-      // what upstream does not have: how many kernel launches the batch has issued (tests: N envs -> ONE launch per integrate())
+      // what upstream does not have: how many kernel launches the batch has issued (tests: N envs x k integrate() calls -> ONE fused launch)
       .def("viewLaunches", [](VecEnv& e) { return e.batch() ? e.batch()->viewLaunches() : 0L; });
 
   py::class_<raisim::VecEnvConfig>(m, "VecEnvConfig")
@@ -116,12 +118,12 @@ PYBIND11_MODULE(RSG_MODULE_NAME, m) {
       .def("init", &DevEnv::init)
       .def("reset", &DevEnv::reset)
       .def("observe", [](DevEnv& e, FMat ob, bool u) { e.observe(mat(ob, e.getNumOfEnvs(), e.getObDim(), "observe: float32 [num_envs, obDim]"), e.getNumOfEnvs(), e.getObDim(), u); },
-           py::arg("ob"), py::arg("updateStatistics") = false)
+           py::arg("ob").noconvert(), py::arg("updateStatistics") = false)
       .def("step", [](DevEnv& e, FMat action, FMat reward, BVec done) {
              need(action.ndim() == 2 && action.shape(0) == e.getNumOfEnvs() && action.shape(1) == e.getActionDim(), "step: action must be float32 [num_envs, actionDim]");
              need(done.size() == e.getNumOfEnvs() && done.writeable(), "step: done must be a writeable bool [num_envs] array");
              e.step(action.data(), e.getNumOfEnvs(), e.getActionDim(), vec(reward, e.getNumOfEnvs(), "step: reward float32 [num_envs]"), done.mutable_data());
-           })
+           }, py::arg("action").noconvert(), py::arg("reward").noconvert(), py::arg("done").noconvert())
       // device-resident loop: the arguments are DEVICE addresses (torch.Tensor.data_ptr()); nothing crosses PCIe, nothing synchronises
       .def("observeDevice", [](DevEnv& e, std::uintptr_t ob) { e.observeDevice(reinterpret_cast<float*>(ob)); })
       .def("stepDevice", [](DevEnv& e, std::uintptr_t action, std::uintptr_t reward, std::uintptr_t done, std::uintptr_t ob_next) {

@@ -282,9 +282,10 @@ int main(int argc, char** argv) {
           for (int k = 0; k < 34; ++k) CHECK(std::fabs(o1[(size_t)e * 34 + k] - o2[(size_t)e * 34 + k]) < 1e-4f);
         }
       }
-      CHECK(venv.batch()->viewLaunches() - l0 == STEPS * 4);       // one launch per integrate() of the control step, for all 64 envs
+      CHECK(venv.batch()->viewLaunches() - l0 == STEPS && venv.batch()->viewFlushes() >= STEPS);       // the 4 integrate() calls of a control step: ONE fused launch of 4 sub-steps for all 64 envs
       // an exception inside one env's step() surfaces from venv.step() and must leave the batch usable: env 5 throws between
-      // its two integrate() calls, when envs 0-4 are already parked on their second one with a recorded, un-flushed integrate()
+      // its two integrate() calls, when envs 0-4 have finished their bodies with two recorded, un-flushed integrate() calls each
+      // (dropped with the failed step: nothing is launched)
       {
         const std::string yaml8 = "num_envs: 8\nsimulation_dt: 0.0025\ncontrol_dt: 0.005\nrender: false\n";
         raisim::VectorizedEnvironment<FlakyEnv> fenv(resourceDir, yaml8, /*normalizeObservation=*/false);
@@ -296,11 +297,11 @@ int main(int argc, char** argv) {
         fa[5] = 1000.f;
         bool threw = false;
         try { fenv.step(fa.data(), 8, 1, fr.data(), fd.get()); } catch (const std::exception& e) { threw = std::string(e.what()) == "flaky"; }
-        CHECK(threw && fenv.batch()->viewLaunches() == fl0 + 1 && fenv.batch()->pendingViews() == 0);
+        CHECK(threw && fenv.batch()->viewLaunches() == fl0 && fenv.batch()->pendingViews() == 0);
         fa[5] = 0.f;
         fenv.reset();
-        fenv.step(fa.data(), 8, 1, fr.data(), fd.get());            // works again: two launches, nothing left pending
-        CHECK(fenv.batch()->viewLaunches() == fl0 + 3 && fenv.batch()->pendingViews() == 0);
+        fenv.step(fa.data(), 8, 1, fr.data(), fd.get());            // works again: one fused launch of two sub-steps, nothing left pending
+        CHECK(fenv.batch()->viewLaunches() == fl0 + 1 && fenv.batch()->pendingViews() == 0);
         std::printf("VectorizedEnvironment: an exception in one env's step() leaves the batch usable\n");
       }
       CHECK(ndone > 0);                                            // the big kicks made some robots fall and reset

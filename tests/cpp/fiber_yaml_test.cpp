@@ -74,6 +74,17 @@ int main() {
     try { fs.run(64, [&](int i) { if (i == 50) throw std::runtime_error("boom"); FiberScheduler::current()->park(); }, [] {}, 4); }
     catch (const std::runtime_error& e) { threw = std::string(e.what()) == "boom"; }
     CHECK(threw && FiberScheduler::current() == nullptr);
+    // forEach: the same pool without fibers (observe()); every index once, exceptions surface, run() still works afterwards
+    std::vector<std::atomic<int>> hits(1000);
+    fs.forEach(1000, [&](int i) { ++hits[i]; }, 6);
+    for (int i = 0; i < 1000; ++i) CHECK(hits[i] == 1);
+    threw = false;
+    try { fs.forEach(100, [&](int i) { if (i == 77) throw std::runtime_error("each"); }, 3); } catch (const std::runtime_error& e) { threw = std::string(e.what()) == "each"; }
+    CHECK(threw);
+    int ran = 0, fl = 0;
+    fs.run(8, [&](int) { FiberScheduler::current()->park(); }, [&] { ++fl; }, 2);
+    fs.forEach(5, [&](int) { ++ran; }, 1);
+    CHECK(fl == 1 && ran == 5);
   }
   {  // the cfg.yaml subset
     const std::string text =

@@ -44,6 +44,23 @@ def test_fiber_scheduler_and_yaml_parser_on_cpu():
     assert r.returncode == 0 and "fiber_yaml_test OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_facade_host_side_against_the_c_abi_double():
+    """The per-env World views, their fused flush, lazy downloads and the threaded scheduler under VectorizedEnvironment<ENVIRONMENT>
+    (unmodified tests/cpp/anymal_env/Environment.hpp) against tests/cpp/rsb_host_double.cpp - a TEST DOUBLE of the rsb_world entry
+    points with a toy update rule (test infrastructure: linked into this binary only, never into librsb.so).  Pins: 4 integrate()
+    calls = ONE launch of 4 sub-steps and ONE rsb_view_exchange per control step, bit-identical to a flush per integrate(), on 1 and
+    on 5 threads; bodies of different shapes (masked launches by count, writes between integrate() calls, integrate1() inside
+    step()); no staged write is lost when other envs force uploads in the same round."""
+    os.makedirs(os.path.dirname(BIN), exist_ok=True)
+    exe = os.path.join(os.path.dirname(BIN), "facade_host_test")
+    csrc = os.path.join(ROOT, "raisimlib_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc, "-I", os.path.join(ROOT, "tests", "cpp"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "facade_host_test.cpp"), os.path.join(ROOT, "tests", "cpp", "rsb_host_double.cpp"),
+                    os.path.join(csrc, "urdf_model.cpp"), os.path.join(csrc, "terrain_io.cpp"), "-lz"], check=True)
+    r = subprocess.run([exe, os.path.join(ROOT, "raisimlib_amd", "rsc")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "facade_host_test OK" in r.stdout, r.stdout + r.stderr
+
+
 LAUNCHER = os.path.join(ROOT, "tests", "cpp", "_build", "comm_launcher")
 
 

@@ -59,7 +59,7 @@ def test_raisim_gym_vec_env_steps_unmodified_environments_on_the_gpu(gym_module)
         o1 = env.observe(False)
         assert np.array_equal(d1, d2) and np.abs(r1 - r2).max() < 1e-4 and np.abs(o1 - o2).max() < 1e-4      # == the device-resident env
         resets += int(d1.sum())
-    assert env.wrapper.viewLaunches() - l0 == 25 * 4        # ONE launch per integrate() of the control step for all 64 envs
+    assert env.wrapper.viewLaunches() - l0 == 25            # the 4 integrate() calls of a control step are ONE fused launch for all 64 envs
     assert resets > 0
     with pytest.raises(Exception):
         env.wrapper.step(np.zeros((n, 11), np.float32), env._reward, env._done)      # shape errors are Python exceptions, not crashes

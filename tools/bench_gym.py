@@ -1,5 +1,5 @@
 """env-steps/s of the raisimGymTorch-shaped Python boundary at N = 4096 (not the headline: what an UNMODIFIED Environment.hpp
-gets through RaisimGymVecEnv -> pybind11 -> VectorizedEnvironment<ENVIRONMENT> -> one launch per integrate()), next to the
+gets through RaisimGymVecEnv -> pybind11 -> VectorizedEnvironment<ENVIRONMENT> -> the control step's integrate() calls fused into one launch), next to the
 device-resident env (DeviceRaisimGymEnv: one fused launch per control step, host buffers) on the same box."""
 import json
 import os
@@ -36,7 +36,7 @@ for k in range(STEPS):
     env.step(acts[k % 8]); env.observe(False)
 dt = time.perf_counter() - t0
 out["template_path"] = {"env_steps_per_s": N * 4 * STEPS / dt, "ms_per_control_step": dt / STEPS * 1e3, "launches": env.wrapper.viewLaunches() - l0,
-                        "what": "RaisimGymVecEnv.step + observe on numpy buffers; N unmodified Environment.hpp objects as fibers, ONE launch per integrate()"}
+                        "what": "RaisimGymVecEnv.step + observe on numpy buffers; N unmodified Environment.hpp objects as fibers, the control step's 4 integrate() calls = ONE fused launch + one rsb_view_exchange"}
 
 cfg = mod.VecEnvConfig(); cfg.num_envs = N
 cfg.gc_init = [0, 0, 0.57, 1.0, 0.0, 0.0, 0.0, 0.03, 0.4, -0.8, -0.03, 0.4, -0.8, 0.03, -0.4, 0.8, -0.03, -0.4, 0.8]
