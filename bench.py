@@ -87,6 +87,9 @@ def parse():
                     help="how the per-control-step obs block reaches the other ranks: 'rccl' = all-gather (default until a multi-GPU box has "
                          "measured both), 'peer' = peer-mapped buffers written by the step kernel's epilogue (rsb_obs_peer_*: no collective, no copy kernel)")
     ap.add_argument("--peer-no-wait", action="store_true", help="diagnostic (--obs-exchange peer): rows and flags are written, nobody waits for them")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="headline only: skip the `secondary` block (configs 3 and 5 with the same --steps / --warmup) and `boundary_template_path` "
+                         "that the default single-GPU run of config 2 appends")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="plumbing check without GPUs: the ranks rendezvous on gloo, all-gather a host obs block per step and "
                          "print the contract line with dry_run=true (no device world, no physics; value is not a measurement)")
@@ -390,35 +393,49 @@ def cpu_baseline(recipe, max_iter, reset, budget_s, q0, u0, gc_reset, gv_reset, 
                       + json.dumps({str(k): round(v) for k, v in probe.items()})}
 
 
-def main():
-    args = parse()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        # started without a launcher: this process becomes the launcher of --gpus ranks (one per GPU)
-        sys.exit(spawn_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    if world_size != args.gpus and rank == 0:
-        print(f"bench.py: --gpus {args.gpus} but the launcher started {world_size} rank(s); the launcher's count is used", file=sys.stderr)
-    if args.dry_run_ranks:
-        sys.exit(dry_run_ranks(args, rank, world_size))
-    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (this image's default; see rsb_world.hip)
+def template_path(n, steps, threads=0):
+    """The headline workload through the reference's own boundary: RaisimGymVecEnv -> the raisim_gym-style pybind11 module
+    -> VectorizedEnvironment<ENVIRONMENT> over the UNMODIFIED rsg_anymal-style tests/cpp/anymal_env/Environment.hpp, numpy buffers in place.
+    The n step() bodies run as fibers on `threads` host threads (default: the box's cores, at most 32); their integrate() calls are
+    recorded and flushed as one fused launch + one rsb_view_exchange per control step (include/raisim/World.hpp)."""
+    from raisimlib_amd.gym import RaisimGymVecEnv, build_env_module, load_env_module
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = threads or max(1, min(32, cores))
+    rsc = os.path.join(ROOT, "raisimlib_amd", "rsc")
+    cfg = (f"num_envs: {n}\nnum_threads: {threads}\nsimulation_dt: 0.0025\ncontrol_dt: 0.01\nrender: false\naction_std: 0.3\n"
+           "reward:\n  forwardVel:\n    coeff: 0.3\n  torque:\n    coeff: -4e-5\n")
+    build_env_module(os.path.join(ROOT, "tests", "cpp", "anymal_env"), name="rsg_anymal")
+    mod = load_env_module("rsg_anymal")
+    rng = np.random.default_rng(0)
+    acts = [rng.uniform(-1, 1, (n, 12)).astype(np.float32) for _ in range(8)]
+    env = RaisimGymVecEnv(mod.RaisimGymEnv(rsc, cfg, False), normalize_ob=False)
+    env.reset()
+    for k in range(10):
+        env.step(acts[k % 8]); env.observe(False)
+    l0 = env.wrapper.viewLaunches()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(acts[k % 8]); env.observe(False)
+    dt = time.perf_counter() - t0
+    res = {"env_steps_per_s": n * 4 * steps / dt, "ms_per_control_step": dt / steps * 1e3, "control_steps_timed": steps, "host_threads": threads,
+           "kernel_launches_per_control_step": (env.wrapper.viewLaunches() - l0) / steps,
+           "what": "RaisimGymVecEnv.step + observe (numpy buffers, host round trip included) over N unmodified Environment.hpp objects: "
+                   "setPdTarget, 4 x World::integrate(), state / contact / generalized-force reads, reward, termination, reset per env"}
+    env.close()
+    return res
+
+
+def measure(args, rank, local_rank, world_size, dev, coll):
+    """One configuration end to end on this rank: world, pre-roll, warm-up, the timed region (barrier + synchronise on both sides, MAX
+    over ranks), the sampling pass behind `roofline`, the CPU leg.  Returns the contract dictionary on rank 0, None elsewhere."""
     import torch
     import torch.distributed as dist
 
     from raisimlib_amd import BatchedWorld, workload
-
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()} (no CPU fallback)")
-    coll = world_size > 1 or args.force_collective     # the obs all-gather is part of the step
-    if coll:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if coll:
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
-
+    out = None
     N = args.envs_per_gpu
     recipe = Recipe(args.config, args.target_amplitude, args.atlas_regime, args.per_env_maps)
     if args.anderson >= 0:
@@ -579,9 +596,15 @@ def main():
             valu = None
             if pmc and pmc.get("counters", {}).get("SQ_INSTS_VALU"):
                 waves = -(-N * world.lanes_per_env() // 64)
-                valu = {"valu_inst_per_wave_per_launch": pmc["counters"]["SQ_INSTS_VALU"] / waves,
-                        "issue_slot_frac": pmc["counters"]["SQ_INSTS_VALU"] / waves * 4.0 / (kmean_ms * 1e-3 * 2.4e9),
-                        "note": "one wave per SIMD: (VALU instructions x 4 cycles) / launch cycles; recorded PMC pass, measured launch time"}
+                per_wave = pmc["counters"]["SQ_INSTS_VALU"] / waves
+                cyc = kmean_ms * 1e-3 * 2.4e9
+                valu = {"valu_inst_per_wave_per_launch": per_wave,
+                        "issue_slot_frac": per_wave * 4.0 / cyc,
+                        "valu_pipe_frac": per_wave * 2.0 / cyc,
+                        "note": "one wave per SIMD.  issue_slot_frac: (VALU instructions x 4 cycles) / launch cycles - the rate a LONE wave can issue at "
+                                "(profiles/r02_ubench_lone_wave_latency.txt); valu_pipe_frac: the same at 2 cycles per wave64 instruction - what the "
+                                "SIMD-32 pipe can take from SEVERAL co-resident waves (MI355X_MICROARCH.md; profiles/r04_ubench_two_waves.txt: two waves "
+                                "per SIMD run dependent FMA chains and the sweep-loop mix at 0.8-1.0x the lone wave's time EACH).  Recorded PMC pass, measured launch time"}
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "rsb_step_kernel", "kernel_ms_mean": kmean_ms,
@@ -634,6 +657,63 @@ def main():
                                                gc0.astype(np.float32).astype(np.float64), gv0, step_start,
                                                self_collision=not args.no_self_collision)
     world.close()
+    return out
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started without a launcher: this process becomes the launcher of --gpus ranks (one per GPU)
+        sys.exit(spawn_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world_size} rank(s); the launcher's count is used", file=sys.stderr)
+    if args.dry_run_ranks:
+        sys.exit(dry_run_ranks(args, rank, world_size))
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (this image's default; see rsb_world.hip)
+    import torch
+    import torch.distributed as dist
+
+    from raisimlib_amd import BatchedWorld, workload
+
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()} (no CPU fallback)")
+    coll = world_size > 1 or args.force_collective     # the obs all-gather is part of the step
+    if coll:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if coll:
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+
+    out = measure(args, rank, local_rank, world_size, dev, coll)
+    default_run = (world_size == 1 and args.config == 2 and not args.no_secondary and not args.no_cpu and args.envs_per_gpu == ENVS_PER_GPU
+                   and not (args.early_termination or args.no_reset or args.max_iter or args.lanes_per_env or args.no_self_collision or args.force_collective))
+    if rank == 0 and default_run:
+        # what the driver's default run also records: the other single-GPU configurations of BASELINE.json with
+        # the same --steps / --warmup, and the headline workload through the reference's own boundary
+        import copy
+        out["secondary"] = {}
+        for cfg in (3, 5):
+            a2 = copy.copy(args)
+            a2.config, a2.cpu_seconds = cfg, min(args.cpu_seconds, 7.0)
+            try:
+                o2 = measure(a2, rank, local_rank, world_size, dev, coll)
+                r2, c2 = o2["roofline"], o2.get("cpu_baseline") or {}
+                out["secondary"][f"config{cfg}"] = {
+                    "metric": o2["metric"], "value": o2["value"], "unit": o2["unit"], "steps": o2["steps"], "warmup": o2["warmup"], "ms_per_step": o2["ms_per_step"],
+                    "kernel_ms_mean": r2.get("kernel_ms_mean"), "roofline": {k: r2.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch")},
+                    "cpu_baseline": {k: c2.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if c2 else None,
+                    "workload": o2["config"]["workload"], "regime": o2["config"]["regime"], "state_at_end": o2["state_at_end"]}
+            except Exception as e:      # a secondary line must never take the headline down
+                out["secondary"][f"config{cfg}"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            out["boundary_template_path"] = template_path(args.envs_per_gpu, max(args.steps // 4, 20))
+        except Exception as e:
+            out["boundary_template_path"] = {"error": f"{type(e).__name__}: {e}"}
     if coll:
         dist.destroy_process_group()
     if rank == 0:

@@ -43,6 +43,7 @@
 #include <shared_mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <map>
 #include <vector>
 
@@ -62,6 +63,36 @@ enum Type : int { TRAPEZOID = 0, SEMI_IMPLICIT = 1, EULER = 2, RUNGE_KUTTA_4 = 3
 namespace ControlMode {
 enum Type : int { FORCE_AND_TORQUE = RSB_FORCE_AND_TORQUE, PD_PLUS_FEEDFORWARD_TORQUE = RSB_PD_PLUS_FEEDFORWARD_TORQUE };
 }
+
+/// Reader-writer lock whose readers do not share a cache line (a "big-reader" lock): N env bodies on T threads stage their rows as
+/// readers thousands of times per control step - through one pthread rwlock word that was 16 000 contended atomic operations per step
+/// and the reason the bodies did not scale with the threads -, a writer (whole-array upload / refresh of the mirrors) is rare.
+class BigReaderLock {
+ public:
+  void lock_shared() {
+    Slot& s = slots_[slot()];
+    for (;;) {
+      s.readers.fetch_add(1, std::memory_order_seq_cst);
+      if (!writer_.load(std::memory_order_seq_cst)) return;
+      s.readers.fetch_sub(1, std::memory_order_seq_cst);        // a writer is in or waiting: step back and let it through
+      while (writer_.load(std::memory_order_acquire)) std::this_thread::yield();
+    }
+  }
+  void unlock_shared() { slots_[slot()].readers.fetch_sub(1, std::memory_order_release); }
+  void lock() {
+    wmu_.lock();
+    writer_.store(true, std::memory_order_seq_cst);
+    for (Slot& s : slots_) while (s.readers.load(std::memory_order_seq_cst) != 0) std::this_thread::yield();
+  }
+  void unlock() { writer_.store(false, std::memory_order_release); wmu_.unlock(); }
+ private:
+  struct alignas(64) Slot { std::atomic<int> readers{0}; };
+  static constexpr int kSlots = 64;
+  static int slot() { static std::atomic<int> next{0}; static thread_local int mine = next.fetch_add(1) % kSlots; return mine; }
+  Slot slots_[kSlots];
+  std::atomic<bool> writer_{false};
+  std::mutex wmu_;
+};
 
 /// Page-locked host array (rsb_host_alloc): the mirrors behind the per-env views, so that a flush's copies run asynchronously on
 /// the world's stream up to its single synchronisation.
@@ -177,6 +208,10 @@ class BatchedWorld {
   }
   void integrate2() { std::lock_guard<std::recursive_mutex> lk(mu_); uploadStaged(); RSB_CHECK(rsb_integrate2(world_)); stateCacheValid_ = false; contactsValid_ = false; genfValid_ = false; queryValid_ = false; }
   long queryLaunches() const { return queryLaunches_; }   ///< launches issued by integrate1() (tests: N views -> 1 launch)
+  /// the whole-batch query results, serialised like every other call into the handle (env bodies on several threads ask for them)
+  void getMassMatrices(float* M) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_get_mass_matrix(world_, M, RSB_HOST)); }
+  void getInverseMassMatrices(float* Mi) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_get_inverse_mass_matrix(world_, Mi, RSB_HOST)); }
+  void getNonlinearitiesAll(float* h) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_get_nonlinearities(world_, h, RSB_HOST)); }
 
   // batched, caller-owned host buffers (row-major [N, dim] float32, the raisimGymTorch matrix layout)
   void setState(const float* gc, const float* gv) {
@@ -200,7 +235,7 @@ class BatchedWorld {
   void stageRow(int field, int env, const double* v, int dim) {
     syncView(env, "a staged write");          // integrate() calls recorded before this write must run before it
     Stage& st = stage(field);                  // (creates the mirror on first use; takes mu_, so before the stage lock)
-    std::shared_lock<std::shared_mutex> sl(stageMu_);
+    std::shared_lock<BigReaderLock> sl(stageMu_);
     for (int i = 0; i < dim; ++i) st.host[(size_t)env * dim + i] = (float)v[i];
     if (field == RSB_F_GC) gcMask_[env] = 1;
     if (field == RSB_F_GV) gvMask_[env] = 1;
@@ -234,7 +269,7 @@ class BatchedWorld {
   void integrateView(int env) {
     detail::FiberScheduler* fs = detail::FiberScheduler::current();
     if (fs && fiberBatch_) {
-      if (pending_[env]++ == 0) ++nPending_;
+      ++pending_[env];                                   // (the env's own counter: no shared word is touched; flushViews scans them)
       if (!fuse_) fs->park();                            // RSB_VIEW_FUSE=0: a flush per integrate(), as in round 3
       return;
     }
@@ -251,13 +286,13 @@ class BatchedWorld {
   /// replica recorded the same number, else masked launches by count), the fields the environments read down; one synchronisation
   void flushViews() {
     std::lock_guard<std::recursive_mutex> lk(mu_);
-    if (nPending_ == 0) return;
-    std::unique_lock<std::shared_mutex> sl(stageMu_);
+    int cmin = 1 << 30, cmax = 0;
+    for (int e = 0; e < n_; ++e) { cmin = std::min(cmin, pending_[e]); cmax = std::max(cmax, pending_[e]); }
+    if (cmax == 0) return;
+    std::unique_lock<BigReaderLock> sl(stageMu_);
     rsb_view_io io{};
     collectUploads(io);
     // launches: distinct counts c_1 < c_2 < ...; launch i runs c_i - c_(i-1) sub-steps for the envs with count >= c_i
-    int cmin = 1 << 30, cmax = 0;
-    for (int e = 0; e < n_; ++e) { cmin = std::min(cmin, pending_[e]); cmax = std::max(cmax, pending_[e]); }
     launchSub_.clear();
     if (cmin == cmax) launchSub_.push_back(cmax);         // (the usual case: every env of the batch ran the same step() body)
     else {
@@ -298,7 +333,7 @@ class BatchedWorld {
   void setFuseIntegrateCalls(bool on) { fuse_ = on; }     ///< (tests, A/B) false = a flush per integrate()
   long viewLaunches() const { return viewLaunches_; }     ///< launches issued by flushViews() (tests: N views x k integrate() -> 1 launch)
   long viewFlushes() const { return viewFlushes_; }       ///< rsb_view_exchange calls issued by flushViews()
-  int pendingViews() const { return nPending_; }
+  int pendingViews() const { int k = 0; for (int c : pending_) k += c != 0; return k; }
   /// contacts of the last integrate() of every env, downloaded once per flush
   const PinnedArray<rsb_contact>& contactsOf(int env, int& count, int& kmax) {
     raise(wantContacts_);
@@ -318,7 +353,7 @@ class BatchedWorld {
   /// staged rows -> device (before a launch, or before a query that must see them)
   void uploadStaged() {
     std::lock_guard<std::recursive_mutex> lk(mu_);
-    std::unique_lock<std::shared_mutex> sl(stageMu_);
+    std::unique_lock<BigReaderLock> sl(stageMu_);
     rsb_view_io io{};
     if (collectUploads(io)) RSB_CHECK(rsb_view_exchange(world_, &io));
   }
@@ -373,7 +408,7 @@ class BatchedWorld {
   void refreshState() {
     if (stateCacheValid_.load(std::memory_order_acquire) && stages_[RSB_F_GC].init.load(std::memory_order_acquire) && stages_[RSB_F_GV].init.load(std::memory_order_acquire)) return;     // (fast path without the lock)
     std::lock_guard<std::recursive_mutex> lk(mu_);
-    std::unique_lock<std::shared_mutex> sl(stageMu_);       // no row is being staged while the mirrors are overwritten
+    std::unique_lock<BigReaderLock> sl(stageMu_);       // no row is being staged while the mirrors are overwritten
     refreshStateLocked();
   }
   void refreshStateLocked() {       // mu_ and stageMu_ (exclusively) held
@@ -445,7 +480,7 @@ class BatchedWorld {
   long viewLaunches_ = 0, viewFlushes_ = 0;
   bool fuse_ = !(std::getenv("RSB_VIEW_FUSE") && std::atoi(std::getenv("RSB_VIEW_FUSE")) == 0);
   std::atomic<bool> wantState_{false}, wantContacts_{false}, wantGenf_{false};   // what the environments read: downloaded by every flush
-  std::shared_mutex stageMu_;                 // shared: an env stages one of its rows; exclusive: whole-array upload / refresh of the mirrors (after mu_)
+  BigReaderLock stageMu_;                    // shared: an env stages one of its rows; exclusive: whole-array upload / refresh of the mirrors (after mu_)
   long queryLaunches_ = 0;
   bool fiberBatch_ = false;
   // set once per flush by the first env that asks, read by all: the N env bodies between two flushes may run on several threads
@@ -561,7 +596,7 @@ class ArticulatedSystem {
   const MatDyn& getMassMatrix() {
     const int nv = w_->dof(), o = gvOff();
     std::vector<float> M((size_t)w_->numEnvs() * nv * nv);
-    RSB_CHECK(rsb_get_mass_matrix(w_->handle(), M.data(), RSB_HOST));
+    w_->getMassMatrices(M.data());
     M_.resize(nv - o, nv - o);
     for (int i = o; i < nv; ++i) for (int j = o; j < nv; ++j) M_(i - o, j - o) = M[((size_t)env_ * nv + i) * nv + j];
     return M_;
@@ -570,7 +605,7 @@ class ArticulatedSystem {
     const int nv = w_->dof(), o = gvOff();
     RSFATAL_IF(o != 0, "getInverseMassMatrix: not available for fixed-base systems (the batch inverts the floating-base matrix)");
     std::vector<float> Mi((size_t)w_->numEnvs() * nv * nv);
-    RSB_CHECK(rsb_get_inverse_mass_matrix(w_->handle(), Mi.data(), RSB_HOST));
+    w_->getInverseMassMatrices(Mi.data());
     Minv_.resize(nv, nv);
     for (int i = 0; i < nv; ++i) for (int j = 0; j < nv; ++j) Minv_(i, j) = Mi[((size_t)env_ * nv + i) * nv + j];
     return Minv_;
@@ -578,7 +613,7 @@ class ArticulatedSystem {
   const VecDyn& getNonlinearities(const Vec<3>& /*gravity*/ = Vec<3>()) {
     const int nv = w_->dof(), o = gvOff();
     std::vector<float> h((size_t)w_->numEnvs() * nv);
-    RSB_CHECK(rsb_get_nonlinearities(w_->handle(), h.data(), RSB_HOST));
+    w_->getNonlinearitiesAll(h.data());
     h_.resize(nv - o);
     for (int i = o; i < nv; ++i) h_[i - o] = h[(size_t)env_ * nv + i];
     return h_;

@@ -64,6 +64,7 @@ _VP, _I, _D, _FP, _CP = C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_char_p
 PROTOTYPES = {
     "rsb_last_error": (C.c_char_p, []),
     "rsb_version": (C.c_char_p, []),
+    "rsb_source_hash": (C.c_char_p, []),
     "rsb_model_from_urdf_file": (_I, [_CP, C.POINTER(_VP)]),
     "rsb_model_from_urdf_string": (_I, [_CP, C.POINTER(_VP)]),
     "rsb_model_from_urdf_file_sampled": (_I, [_CP, _D, C.POINTER(_VP)]),

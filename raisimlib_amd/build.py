@@ -8,6 +8,7 @@ The fused step kernel has ten (LPE, KMAX, CL, ML) classes x {production, profili
 takes about a minute on 8 cores instead of several in one translation unit.  Objects are cached under
 raisimlib_amd/lib/obj/ and rebuilt when a source they depend on is newer.
 """
+import hashlib
 import os
 import re
 import shutil
@@ -21,12 +22,13 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "lib", "librsb.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 RSB_H = os.path.join(ROOT, "include", "rsb.h")
+RSB_TYPES_H = os.path.join(ROOT, "include", "rsb_types.h")    # the part of the ABI the kernels compile against
 HOST_SOURCES = {   # source -> headers it depends on
-    "urdf_model.cpp": ["rsb_internal.h", RSB_H],
-    "terrain_io.cpp": ["rsb_internal.h", RSB_H],
-    "rsb_world.hip": ["rsb_internal.h", "step_types.h", "step_launch.h", "query_kernel.h", "env_task.h", RSB_H],
+    "urdf_model.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
+    "terrain_io.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
+    "rsb_world.hip": ["rsb_internal.h", "step_types.h", "step_launch.h", "query_kernel.h", "env_task.h", RSB_H, RSB_TYPES_H],
 }
-KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", RSB_H]
+KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", RSB_TYPES_H]
 # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and
 # pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed at the stated parity tolerance
 # (2.5 ulp hardware approximations + Newton step instead)
@@ -39,6 +41,19 @@ def step_instances():
     txt = open(os.path.join(CSRC, "step_launch.h")).read()
     line = re.search(r"RSB_STEP_INSTANCES:(.*)", txt).group(1)
     return [tuple(int(x) for x in tok.split(",")) for tok in line.split()]
+
+
+def source_hash(extra_flags=()):
+    """sha256 over everything librsb.so is compiled from: the files of csrc/, include/rsb.h and the compiler flags.  build() links it
+    into the library (rsb_source_hash()); tests/conftest.py compares the two, so a library built from other sources than the tree's -
+    a stale object cache, a binary that travelled to the GPU box without its sources - fails the suite instead of passing it."""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))) + [RSB_H, RSB_TYPES_H]
+    for f in files:
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    h.update(" ".join([*FLAGS, *extra_flags]).encode())
+    return h.hexdigest()[:32]
 
 
 def _path(p):
@@ -66,14 +81,28 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
         if force or _newer(obj, [src] + deps):
             tasks.append((obj, [hipcc, *FLAGS, *extra_flags, "-x", "hip", *inc, "-c", _path(src), "-o", obj]))
     objs = [os.path.join(OBJ, os.path.splitext(src)[0] + (f".{tag}" if tag else "") + ".o") for src in HOST_SOURCES]
+    # RSB_BUILD_ONLY="16,8,0,4 32,16,0,12": kernel experiments rebuild these instances only; the other objects are linked as they are
+    # (rsb_source_hash() then no longer describes the library: the test-suite refuses it - a full build() is what ships)
+    only = {tuple(int(x) for x in tok.split(",")) for tok in os.environ.get("RSB_BUILD_ONLY", "").split()}
     for lpe, kmax, cl, ml in step_instances():
         for prof in ((0,) if cl & 2 else (0, 1)):      # (the peer-exchange classes have no profiling twin: rsb_world.hip, launch_step)
             obj = os.path.join(OBJ, f"step_{lpe}_{kmax}_{cl}_{ml}_{prof}" + (f".{tag}" if tag else "") + ".o")
             objs.append(obj)
+            if only and (lpe, kmax, cl, ml) not in only and os.path.exists(obj):
+                continue
             if force or _newer(obj, KERNEL_DEPS):
                 tasks.append((obj, [hipcc, *FLAGS, *extra_flags, *inc, f"-DRSB_I_LPE={lpe}", f"-DRSB_I_KMAX={kmax}",
                                     f"-DRSB_I_CL={cl}", f"-DRSB_I_ML={ml}", f"-DRSB_I_PROF={prof}", "-c",
                                     _path("step_instance.hip"), "-o", obj]))
+    # build provenance: the hash of the sources this library is built from, as a translation unit of its own (rsb_source_hash())
+    shash = source_hash(extra_flags)
+    stamp_src = os.path.join(OBJ, "build_stamp" + (f".{tag}" if tag else "") + ".cpp")
+    stamp_obj = stamp_src[:-4] + ".o"
+    stamp_txt = f'extern "C" const char* rsb_source_hash(void) {{ return "{shash}"; }}\n'
+    if not os.path.exists(stamp_src) or open(stamp_src).read() != stamp_txt or not os.path.exists(stamp_obj):
+        open(stamp_src, "w").write(stamp_txt)
+        tasks.append((stamp_obj, ["g++", "-O1", "-fPIC", "-c", stamp_src, "-o", stamp_obj]))
+    objs.append(stamp_obj)
     if not tasks and os.path.exists(out) and all(os.path.getmtime(o) <= os.path.getmtime(out) for o in objs):
         return out
 

@@ -40,7 +40,7 @@
 #include <type_traits>
 
 #include "env_task.h"
-#include "rsb.h"
+#include "rsb_types.h"
 #include "step_types.h"
 
 namespace rsbk {

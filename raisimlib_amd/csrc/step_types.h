@@ -6,7 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "rsb.h"
+#include "rsb_types.h"
 
 namespace rsbk {
 

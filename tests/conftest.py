@@ -18,7 +18,13 @@ def built_lib():
     from raisimlib_amd import build
     build.build(verbose=False)
     from raisimlib_amd import _capi
-    return _capi.lib()
+    lib = _capi.lib()
+    # provenance: the library under test must have been built from THIS tree's sources (a stale object cache or a binary shipped
+    # without rebuilding would otherwise pass every test with yesterday's kernels)
+    have, want = lib.rsb_source_hash().decode(), build.source_hash()
+    if have != want and not os.environ.get("RSB_LIB_PATH"):
+        raise RuntimeError(f"librsb.so was built from other sources than this tree's (library {have}, tree {want}): rebuild with python -m raisimlib_amd.build --force")
+    return lib
 
 
 @pytest.fixture(scope="session")

@@ -11,7 +11,7 @@ from common import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("config", [2, 5])
+@pytest.mark.parametrize("config", [2, 3, 5])
 def test_bench_prints_the_contract_line(built_lib, config):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--preroll", "8",
            "--config", str(config), "--cpu-seconds", "2"]
@@ -34,6 +34,20 @@ def test_bench_prints_the_contract_line(built_lib, config):
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
     assert cb["kind"] == "port" and cb["value"] > 0
+    if config == 2:
+        # the default single-GPU run of the headline configuration also carries configs 3 and 5 (same --steps / --warmup) and the
+        # headline workload through the reference's own boundary, inside the same JSON object
+        sec = b["secondary"]
+        for name in ("config3", "config5"):
+            c = sec[name]
+            assert "error" not in c, c
+            assert c["steps"] == 6 and c["warmup"] == 2 and c["value"] > 1e5 and c["kernel_ms_mean"] > 0 and c["roofline"]["frac"] > 0
+            assert c["cpu_baseline"]["value"] > 0 and abs(c["value"] - 4096 * 4 * 6 / (c["ms_per_step"] * 6 * 1e-3)) < 1e-3 * c["value"]
+        tp = b["boundary_template_path"]
+        assert "error" not in tp, tp
+        assert tp["env_steps_per_s"] > 1e5 and tp["kernel_launches_per_control_step"] == 1.0
+    else:
+        assert "secondary" not in b
 
 
 def test_bench_collective_path_on_one_rank(built_lib):
