@@ -80,7 +80,9 @@ def parse():
                     help="diagnostic: no HIP-event brackets anywhere (roofline fields become null)")
     ap.add_argument("--target-amplitude", type=float, default=-1.0,
                     help="diagnostic: amplitude (rad) of the uniform PD-target noise (config 2/3: 0.3; config 5 collapsing: 0.1; "
-                         "config 5 standing: a SCALE on the per-class amplitudes 0.03 / 0.1 rad, default 1)")
+                         "config 5 standing has two amplitude classes: use --target-scale there)")
+    ap.add_argument("--target-scale", type=float, default=1.0,
+                    help="diagnostic (config 5 standing): scale on the per-class noise amplitudes 0.03 rad (legs, back) / 0.1 rad (arms, neck)")
     ap.add_argument("--force-collective", action="store_true",
                     help="diagnostic: run the obs all-gather (RCCL) even with one rank, to see its per-step cost")
     ap.add_argument("--obs-exchange", choices=("rccl", "peer"), default="rccl",
@@ -197,7 +199,7 @@ def dry_run_ranks(args, rank, world_size):
 class Recipe:
     """Everything that defines one BASELINE.json configuration: model, terrain, gains, initial state, targets."""
 
-    def __init__(self, config, amplitude, atlas_regime="standing", per_env_maps=False):
+    def __init__(self, config, amplitude, atlas_regime="standing", per_env_maps=False, target_scale=1.0):
         from raisimlib_amd import Model, rsc_path, workload
         self.config = config
         self.wl = workload
@@ -222,7 +224,9 @@ class Recipe:
             head = ("configs[4]: 4096 Atlas-like humanoids (synthetic stand-in URDF, 31 bodies / 36 DoF, 18 collision spheres, "
                     "kmax 16) per GPU, flat ground, ")
             if atlas_regime == "standing":
-                self.amp = amplitude if amplitude >= 0 else 1.0          # scale of the per-class noise amplitudes
+                if amplitude >= 0:
+                    raise SystemExit("config 5 (standing) has two noise amplitude classes: scale them with --target-scale (--target-amplitude is in rad and means one amplitude)")
+                self.amp = float(target_scale)                           # scale of the per-class noise amplitudes
                 self.kp, self.kd = workload.atlas_standing_gains(self.joint_names)
                 a0, a1 = (self.amp * x for x in workload.ATLAS_STAND_AMP)
                 self.name = head + ("STANDING regime: implicit PD kp 3000 / kd 60 on legs and back, kp 300 / kd 10 on arms and neck, targets = zero "
@@ -437,7 +441,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     from raisimlib_amd import BatchedWorld, workload
     out = None
     N = args.envs_per_gpu
-    recipe = Recipe(args.config, args.target_amplitude, args.atlas_regime, args.per_env_maps)
+    recipe = Recipe(args.config, args.target_amplitude, args.atlas_regime, args.per_env_maps, args.target_scale)
     if args.anderson >= 0:
         recipe.anderson = (args.anderson, recipe.anderson[1])
     model, feet = recipe.model, recipe.feet
@@ -630,6 +634,10 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                             + (", EARLY TERMINATION at the sub-step of the first non-foot contact (not upstream's rule)" if args.early_termination else "")
                             + ", obs (q,u,foot force) written each control step"
                             + f"; stationary regime: {args.preroll} untimed pre-roll control steps before --warmup",
+                # the workload definitions behind the metric strings changed in round 3 (config 3: bases spread over +-6 m of the map instead
+                # of its centre; config 5: the STANDING regime is the default, rounds 1-2 measured what is now --atlas-regime collapsing):
+                # lines are comparable only at equal workload_version (and regime_name for config 5)
+                "workload_version": 3, "regime_name": (args.atlas_regime if args.config == 5 else "reset-on-non-foot-contact" if reset else "no-reset"),
                 "preroll_control_steps": args.preroll,
                 "regime": {"resets_per_control_step_mean": float(np.mean(resets)) if resets else None,
                            "env_age_control_steps_p10_p50_p90_p99": age_pct,

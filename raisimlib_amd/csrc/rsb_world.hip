@@ -201,6 +201,12 @@ std::vector<int> enumerate_self_pairs(const rsb_model_blob& b, const std::vector
 // slots of the height-map narrow phase: one per primitive (every sphere of the model may be near the ground at once - a robot lying in a hollow)
 int hm_slots_for(const rsb_model_blob& b) { return std::max(rsbk::kHmSlots, (int)b.ncol); }
 
+// Contact capacity of the kernel class a world is dispatched to (the template's KMAX): 8 for the shallow, few-contact models (the
+// quadruped's classes), 16 for kmax > 8 AND for every model deeper than five levels, whose only compiled classes are the large ones
+// (do_integrate).  ONE quantity decides layout, dispatch and LDS size: the layout used to follow kmax alone, so a deep model at the
+// default kmax 8 ran the KMAX-16 kernel (packed triangular Delassus blocks) on the square layout.
+int kcap_of(const rsb_model_blob& b, int kmax) { return (kmax <= 8 && b.depth - 1 <= 4) ? 8 : 16; }
+
 LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   LdsLayout L;
   const int cw = round4(6 + b.depth - 1);
@@ -258,7 +264,7 @@ size_t lds_bytes_for(const rsb_model_blob& b, int kcap, int lpe, int n_self) {
 // LPE 16 (4 x 4 envs, 38 KB per workgroup: at N = 4096 one wave on every SIMD of the chip); Atlas-like, kmax 16
 // (25 KB per env): every choice holds 4 envs, LPE 64 keeps all four SIMDs busy.
 int default_lpe(const rsb_model_blob& b, int kmax, int n_self) {
-  const int kcap = kmax <= 8 ? 8 : 16;
+  const int kcap = kcap_of(b, kmax);
   const int need = b.nb > 16 ? (b.nb > 32 ? 64 : 32) : 16;   // lane = body in the tree passes
   int best = 64, best_envs = 0, best_wgs = 0;
   for (int lpe = need; lpe <= 64; lpe *= 2) {
@@ -393,7 +399,7 @@ int effective_lpe(const rsb_world* w) {
 int check_lpe(const rsb_world* w, int lpe) {
   if (lpe != 16 && lpe != 32 && lpe != 64) { rsb::set_error("lanes_per_env must be 16, 32 or 64"); return RSB_E_INVALID; }
   if (lpe < w->blob.nb) { rsb::set_error("lanes_per_env must be >= number of moving bodies (lane = body in the tree passes)"); return RSB_E_INVALID; }
-  const int kcap = w->kmax <= 8 ? 8 : 16;
+  const int kcap = kcap_of(w->blob, w->kmax);
   if (n_self_pairs(w) > 30 * lpe) { rsb::set_error("too many self-collision candidate pairs for this lanes_per_env (<= 30 per lane): exclude body pairs with rsb_ignore_collision_between or switch self-collision off"); return RSB_E_UNSUPPORTED; }
   if (lds_bytes_for(w->blob, kcap, lpe, n_self_pairs(w)) > 160 * 1024) { rsb::set_error("lanes_per_env too small: the workgroup's envs do not fit in 160 KiB of LDS"); return RSB_E_INVALID; }
   return RSB_OK;
@@ -443,7 +449,7 @@ int do_integrate(rsb_world* w, int nsub) {
   const int lpe = effective_lpe(w);
   int st = check_lpe(w, lpe);
   if (st != RSB_OK) return st;
-  const int kcap = w->kmax <= 8 ? 8 : 16;
+  const int kcap = kcap_of(w->blob, w->kmax);
   StepArgs a;
   std::memset(&a, 0, sizeof a);
   a.model = w->d_model;
@@ -528,7 +534,8 @@ int do_integrate(rsb_world* w, int nsub) {
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
   a.threshold = (float)w->threshold; a.max_iter = w->max_iter; a.section_rounds = w->section_rounds;
   a.multi_depth = w->multi_depth; a.multi_light = w->multi_light; a.multi_freeze_after = w->multi_freeze_after; a.multi_stall_window = w->multi_stall_window;
-  a.anderson = w->anderson; a.anderson_clip = (float)w->anderson_clip;
+  a.anderson = w->kmax > 8 ? w->anderson : 0;   // (rsb.h, oracle: worlds with kmax > 8 only - the large kernel classes also serve deep models at kmax <= 8)
+  a.anderson_clip = (float)w->anderson_clip;
   a.hm_contacts = w->hm_contacts; a.hm_second_cos = (float)w->hm_second_cos; a.hm_slots = hm_slots_for(w->blob);
   a.integ_theta = (float)w->integ_theta;
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
@@ -1291,6 +1298,12 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
   if (w->peer.connected) {
     if (w->blob.fixed_base || w->blob.depth - 1 > 12) { rsb::set_error("rsb_control_step: the peer-mapped obs exchange is compiled for floating-base models of tree depth <= 13"); return RSB_E_UNSUPPORTED; }
     if (obs_out && n_force_slots != w->peer.slots) { rsb::set_error("rsb_control_step: obs_out must use the force slots the peer exchange was created with"); return RSB_E_INVALID; }
+    if (obs_out) {   // ... and the same primitives in them: the launch writes ONE obs row layout to the caller's block and to the peers'
+      for (int i = 0; i < n_force_slots; ++i) {
+        const int32_t want = w->peer.idx.empty() ? i : w->peer.idx[i], got = force_collisions ? force_collisions[i] : i;
+        if (want != got) { rsb::set_error("rsb_control_step: force_collisions differ from the list the peer exchange was created with"); return RSB_E_INVALID; }
+      }
+    }
     f.peer = true;
   }
   if (obs_out) {
@@ -1622,14 +1635,29 @@ int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* coll
   P.bytes = 2 * bufsz * sizeof(float) + (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t);
   // fine-grained memory: stores of OTHER devices' kernels (and their system-scope flag writes) become visible without a kernel
   // boundary on this device; plain hipMalloc is the fallback where the runtime refuses the flag
-  static const bool coarse = std::getenv("RSB_OBS_PEER_COARSE") != nullptr;   // diagnostic: plain hipMalloc
-  if (coarse || hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); HIP_TRY(hipMalloc(&P.base, P.bytes)); }
-  HIP_TRY(hipMemsetAsync(P.base, 0, P.bytes, w->stream));
-  if (!P.idx.empty()) {
-    HIP_TRY(hipMalloc(&P.d_idx, P.idx.size() * sizeof(int32_t)));
-    HIP_TRY(hipMemcpyAsync(P.d_idx, P.idx.data(), P.idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
+  // Coarse-grained memory gives NO such guarantee (a remote rank's write-through stores and the flag a consumer polls may sit in a
+  // cache until a kernel boundary: a wait can hang), so without fine-grained memory the exchange is refused - RSB_OBS_PEER_COARSE=1
+  // forces plain hipMalloc for single-device diagnostics.
+  static const bool coarse = std::getenv("RSB_OBS_PEER_COARSE") != nullptr;
+  if (coarse) HIP_TRY(hipMalloc(&P.base, P.bytes));
+  else if (hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError(); P.base = nullptr;
+    rsb::set_error("rsb_obs_peer_create: no fine-grained device memory on this system (the exchange's visibility rests on it); use the RCCL all-gather");
+    return RSB_E_UNSUPPORTED;
   }
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  auto fail = [&](hipError_t e) {      // nothing half-created survives an error: a retry must not see "already has an exchange"
+    rsb::set_error(std::string("rsb_obs_peer_create: ") + hipGetErrorString(e));
+    (void)hipFree(P.base); P.base = nullptr;
+    if (P.d_idx) { (void)hipFree(P.d_idx); P.d_idx = nullptr; }
+    return RSB_E_HIP;
+  };
+  hipError_t e = hipMemsetAsync(P.base, 0, P.bytes, w->stream);
+  if (e != hipSuccess) return fail(e);
+  if (!P.idx.empty()) {
+    if ((e = hipMalloc(&P.d_idx, P.idx.size() * sizeof(int32_t))) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(P.d_idx, P.idx.data(), P.idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, w->stream)) != hipSuccess) return fail(e);
+  }
+  if ((e = hipStreamSynchronize(w->stream)) != hipSuccess) return fail(e);
   if (handle) {
     std::memset(handle, 0, RSB_OBS_HANDLE_BYTES);
     hipIpcMemHandle_t h;
@@ -1643,6 +1671,16 @@ int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* coll
 static int obs_peer_finish_connect(rsb_world* w) {
   // diagnostic: force the one-wave wait kernel instead of the stream's memory-wait packet
   w->peer.wait_by_kernel = std::getenv("RSB_OBS_PEER_WAIT_KERNEL") != nullptr;
+  // a RE-connect starts the step numbers again at 0: the flag words and the arrival counter must not keep the numbers of the earlier
+  // connection, or the first waits (>= 1) would pass on stale rows.  (The first connect finds them zeroed by rsb_obs_peer_create; the ranks
+  // of a reconnecting job must meet at a barrier between their connects and their first control step, like at start-up.)
+  rsb_world::Peer& P = w->peer;
+  if (P.step != 0) {
+    const size_t bufsz = (size_t)P.ranks * w->N * P.od;
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipMemsetAsync(static_cast<float*>(P.base) + 2 * bufsz, 0, (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t), w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+  }
   w->peer.connected = true; w->peer.step = 0;
   return RSB_OK;
 }

@@ -1,1 +1,1 @@
-extern "C" const char* rsb_source_hash(void) { return "15c729411753df1f5eaa63bc02ec2377"; }
+extern "C" const char* rsb_source_hash(void) { return "1acc282d51d359097b533cc7a3e3f449"; }
