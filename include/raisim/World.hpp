@@ -135,6 +135,7 @@ class Contact {
   /// a self-collision is listed once per body: the two entries are neighbours in getContacts(), object A first
   bool isSelfCollision() const { return (c_.collision & (RSB_CONTACT_SELF_A | RSB_CONTACT_SELF_B)) != 0; }
   bool isSecondTerrainContact() const { return (c_.collision & RSB_CONTACT_SECOND) != 0; }   // extension: rsb_set_heightmap_contacts
+  bool isCapsuleCylinderContact() const { return (c_.collision & RSB_CONTACT_CAPSULE) != 0; }  // extension: rsb_set_capsule_contacts (the id is the capsule's first end sphere's)
   bool isObjectA() const { return (c_.collision & RSB_CONTACT_SELF_B) == 0; }
   bool skip() const { return false; }
  private:
@@ -188,6 +189,7 @@ class BatchedWorld {
   void setMultiContactSolverParam(int depth, bool lightPasses, int freezeAfter, int stallWindow) { RSB_CHECK(rsb_set_solver_multi_contact(world_, depth, lightPasses ? 1 : 0, freezeAfter, stallWindow)); }
   void setSolverAcceleration(int firstSweep, double clip = 20.0) { RSB_CHECK(rsb_set_solver_anderson(world_, firstSweep, clip)); }
   void setHeightMapContactsPerPrimitive(int n, double minAngleDeg = 45.0) { RSB_CHECK(rsb_set_heightmap_contacts(world_, n, minAngleDeg)); }
+  void setExactCapsuleContacts(bool on) { RSB_CHECK(rsb_set_capsule_contacts(world_, on ? 1 : 0)); }
   void addGround(double zHeight = 0.0) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_ground(world_, zHeight)); }
   void addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
                     const std::vector<double>& height) {

@@ -59,7 +59,7 @@ typedef struct rsb_world rsb_world;  /* batched device world             */
 
 const char* rsb_last_error(void);
 const char* rsb_version(void);
-/* build provenance: hash of the sources (raisimlib_amd/csrc/*, this header, compiler flags) the loaded library was built from,
+/* build provenance: hash of the sources (the files of raisimlib_amd/csrc, this header, compiler flags) the loaded library was built from,
  * as raisimlib_amd/build.py: source_hash() computes it for the tree (the test-suite refuses a library that does not match its tree) */
 const char* rsb_source_hash(void);
 
@@ -206,6 +206,16 @@ int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size,
  * default kernels are what they were): floating-base systems of tree depth <= 13, no peer-mapped obs exchange
  * (RSB_E_UNSUPPORTED from the step otherwise). */
 int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle_deg);
+/* Exact capsule x height map (default off: a capsule is its two end spheres - its exact contact set on a PLANE).  With on != 0 the
+ * cylinder between the two end spheres of every capsule of the model (rsb_model_blob::col_capsule; <capsule> elements of the URDF)
+ * also reports its deepest point against a height map when that point penetrates and is deeper than both end spheres by more than
+ * 0.1 mm: a shank lying across a ridge rests on the ridge.  The point is located by four rounds of four closest-feature queries along
+ * the capsule's axis (resolution 1.3 % of its length; faces, edges and vertices of the triangulated surface alike).  The contact
+ * carries RSB_CONTACT_CAPSULE | the FIRST end sphere's index in rsb_contact::collision, uses that primitive's material, starts cold
+ * in every solve, follows the first (and second-flank) contacts in the list and counts as that primitive for the termination rule
+ * and the foot forces.  Runs in the kernel class of rsb_set_heightmap_contacts (same restrictions); no effect on a plane.
+ * Upstream counterpart: RaiSim's ODE capsule x height-field collider [RECALL; absent from /root/reference]. */
+int rsb_set_capsule_contacts(rsb_world* w, int on);
 /* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
  * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */
 int rsb_set_heightmaps(rsb_world* w, int n_maps, int x_samples, int y_samples, double x_size, double y_size,

@@ -76,6 +76,10 @@ typedef struct rsb_model_blob {
   double col_axis[RSB_MAX_COLLISIONS][3];
   double col_rim[RSB_MAX_COLLISIONS];
   char col_material[RSB_MAX_COLLISIONS][RSB_NAME_LEN];  /* <collision><material name=".."/> of the URDF, "default" if absent */
+  /* capsules: col_capsule[s] = e + 1 makes primitives s and e the two END SPHERES of one capsule (same body, same radius; set on the
+   * first of the two, 0 everywhere else).  On a plane the two end spheres are the capsule's exact contact set; against a height
+   * map the cylinder between them can touch where neither end does (a shank lying across a ridge): rsb_set_capsule_contacts. */
+  int32_t col_capsule[RSB_MAX_COLLISIONS];
 } rsb_model_blob;
 
 /* One solved contact, as raisim::Contact exposes it (position/normal/impulse/body index). */
@@ -90,6 +94,7 @@ typedef struct rsb_contact {
                           sit next to each other, same position and depth, opposite normals and impulses */
 } rsb_contact;
 #define RSB_CONTACT_SECOND 0x40000   /* a primitive's second contact with a height map (rsb_set_heightmap_contacts) */
+#define RSB_CONTACT_CAPSULE 0x80000  /* contact of a capsule's cylinder, between its end spheres, with a height map; the id is the FIRST end sphere's (rsb_set_capsule_contacts) */
 #define RSB_CONTACT_SELF_A 0x10000
 #define RSB_CONTACT_SELF_B 0x20000
 #define RSB_CONTACT_PRIMITIVE(c) ((c) & 0xffff)

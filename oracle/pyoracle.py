@@ -38,6 +38,7 @@ class Params(C.Structure):
         ("hm_contacts", C.c_int32),
         ("hm_second_cos", C.c_double),
         ("integ_theta", C.c_double),
+        ("hm_capsule", C.c_int32),
     ]
 
 

@@ -331,6 +331,7 @@ void orc_default_params(orc_params* p) {
   p->multi_depth = 3; p->multi_light = 0; p->multi_freeze_after = 0; p->multi_stall_window = 16;
   p->anderson = 2; p->anderson_clip = 20.0;
   p->hm_contacts = 1; p->hm_second_cos = 0.70710678118654752;
+  p->hm_capsule = 0;
   p->integ_theta = 1.0;
 }
 
@@ -539,7 +540,16 @@ static void closest_on_triangle(const double* a, const double* b, const double* 
 /* depth2 / n2 (may be NULL): with orc_params::hm_contacts >= 2 a sphere in a valley also reports the closest feature of a SECOND flank -
  * the closest penetrating triangle point whose direction differs from the first contact's normal by more than acos(hm_second_cos);
  * *depth2 <= 0 when there is none. */
+static int terrain_contact_ex(const orc_params* p, const double* c, double r, double* depth, double* n, double* depth2, double* n2, int above_test);
 static int terrain_contact(const orc_params* p, const double* c, double r, double* depth, double* n, double* depth2, double* n2) {
+  return terrain_contact_ex(p, c, r, depth, n, depth2, n2, 0);
+}
+/* above_test = 1 (the capsule search): "the centre is outside the terrain" is decided by the height field itself (c_z above the surface
+ * at (c_x, c_y)) instead of by the plane of the triangle that holds the closest point.  At a CONVEX edge sharper than the sphere is
+ * close the two differ: past the ridge line the centre is below the extended plane of the first face although it is above the
+ * surface, and the sphere path then falls back to the plane of the face under the centre (a usable answer for one sphere; for the
+ * capsule search it would rank a point beside the ridge deeper than the point above it). */
+static int terrain_contact_ex(const orc_params* p, const double* c, double r, double* depth, double* n, double* depth2, double* n2, int above_test) {
   if (depth2) *depth2 = 0.0;
   if (p->terrain_type == 0) {
     n[0] = 0; n[1] = 0; n[2] = 1;
@@ -586,7 +596,9 @@ static int terrain_contact(const orc_params* p, const double* c, double r, doubl
     }
   const double dist = sqrt(best);
   const int inside = c[0] >= x0 && c[0] <= x0 + p->hm_xsize && c[1] >= y0 && c[1] <= y0 + p->hm_ysize;
-  if (inside && -dot3(bp, bn) > 0.0 && dist > 1e-9) {
+  int outer = -dot3(bp, bn) > 0.0;
+  if (above_test) { double hh, nh[3]; orc_terrain(p, c[0], c[1], &hh, nh); outer = c[2] > hh; }
+  if (inside && outer && dist > 1e-9) {
     for (int i = 0; i < 3; ++i) n[i] = -bp[i] / dist;
     *depth = r - dist;
     if (depth2 && p->hm_contacts >= 2 && *depth > 0.0) {
@@ -631,6 +643,42 @@ static int terrain_contact(const orc_params* p, const double* c, double r, doubl
     *depth = r - (c[2] - h) * n[2];
   }
   return *depth > 0.0;
+}
+
+/* Capsule x height map (orc_params::hm_capsule).  A capsule is stored as its two end spheres (rsb_model_blob::col_capsule); on a plane
+ * they are its exact contact set.  Against a height map the cylinder between them can touch where neither end does.  The deepest
+ * point of the capsule's AXIS SEGMENT a + t (b - a), t in (0, 1), is located by a nested sampling of the sphere narrow phase above -
+ * four rounds of four samples, each round centred on the best sample of the round before with 0.4 x its spacing (final spacing
+ * 1.3 % of the capsule's length) - and reported as a contact of its own when it penetrates AND is deeper than both end spheres by
+ * more than ORC_CAPSULE_MARGIN (a capsule lying on flat ground is held by its two ends: a third, redundant contact between them
+ * would only slow the solver down).  Face, edge and vertex contacts all come from the same closest-feature test; the depth along
+ * the segment is not unimodal over rough terrain, the first round's four samples decide which dip is refined.
+ * The device runs the same rounds (step_kernel.h, class-4 kernels): lane = (sample, cell).
+ * Upstream counterpart: ODE's capsule x height-field collider - absent from /root/reference. */
+#define ORC_CAPSULE_MARGIN 1e-4
+#define ORC_CAPSULE_ROUNDS 4
+static int capsule_contact(const orc_params* p, const double* a, const double* b, double r, double dep_ends, double* c_out, double* depth, double* n) {
+  static const double off[4] = {-0.6, -0.2, 0.2, 0.6};
+  if (p->terrain_type != 1) return 0;
+  double c = 0.5, w = 0.5, best_d = 0.0, best_n[3] = {0, 0, 1}, best_t = 0.5;
+  for (int round = 0; round < ORC_CAPSULE_ROUNDS; ++round) {
+    int have = 0;
+    for (int k = 0; k < 4; ++k) {
+      double t = c + w * off[k];
+      t = t < 0.02 ? 0.02 : (t > 0.98 ? 0.98 : t);
+      const double pt[3] = {a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2])};
+      double d, nn[3];
+      terrain_contact_ex(p, pt, r, &d, nn, NULL, NULL, 1);
+      /* a later sample must be deeper by more than 2e-6 r to win: equal depths (a flat stretch) are ranked by the sample order on
+       * both sides, not by rounding noise */
+      if (!have || d > best_d + 2e-6 * r) { have = 1; best_d = d; best_t = t; for (int i = 0; i < 3; ++i) best_n[i] = nn[i]; }
+    }
+    c = best_t; w *= 0.4;
+  }
+  if (!(best_d > 0.0 && best_d > dep_ends + ORC_CAPSULE_MARGIN)) return 0;
+  for (int i = 0; i < 3; ++i) { c_out[i] = a[i] + best_t * (b[i] - a[i]); n[i] = best_n[i]; }
+  *depth = best_d;
+  return 1;
 }
 
 /* --------------------------------------------------------------------------- actuation */
@@ -953,6 +1001,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   double cen[RSB_MAX_COLLISIONS][3];   /* primitive centres relative to the base position */
   int csecond[MAXK];               /* second contact of a primitive with the terrain (a valley's other flank) */
   double sec_depth[RSB_MAX_COLLISIONS], sec_n[RSB_MAX_COLLISIONS][3], sec_c[RSB_MAX_COLLISIONS][3];
+  double first_depth[RSB_MAX_COLLISIONS];   /* penetration of each primitive's first contact (0: none) */
   for (int i = 0; i < MAXK; ++i) { cbody2[i] = -1; ccol2[i] = -1; csecond[i] = 0; }
   for (int s = 0; s < m->ncol; ++s) {
     int b = m->col_body[s];
@@ -974,6 +1023,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     double depth2 = 0.0, n2[3] = {0, 0, 1};
     const int hit = terrain_contact(p, cw, m->col_radius[s], &depth, n, &depth2, n2);
     sec_depth[s] = hit ? depth2 : 0.0; for (int a = 0; a < 3; ++a) { sec_n[s][a] = n2[a]; sec_c[s][a] = c[a]; }
+    first_depth[s] = hit ? depth : 0.0;
     if (hit) {
       if (nc >= kmax) { fl |= 1; continue; }
       for (int a = 0; a < 3; ++a) { cx[nc][a] = c[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }
@@ -991,6 +1041,23 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
     cdepth[nc] = sec_depth[s]; cbody[nc] = m->col_body[s]; ccol[nc] = s; csecond[nc] = 1;
     contact_frame(sec_n[s], Rc[nc]);
     ++nc;
+  }
+  /* the cylinders of the capsules (orc_params::hm_capsule), after the second flanks, in primitive order; a slot of its own, the first
+   * end sphere's material, a cold start (csecond = 2) */
+  if (p->hm_capsule && p->terrain_type == 1) {
+    for (int s = 0; s < m->ncol; ++s) {
+      if (m->col_capsule[s] == 0) continue;
+      const int e = m->col_capsule[s] - 1;
+      double aw[3], bw[3], cc[3], n[3], depth;
+      for (int a = 0; a < 3; ++a) { aw[a] = k->pbase[a] + cen[s][a]; bw[a] = k->pbase[a] + cen[e][a]; }
+      const double dep_ends = first_depth[s] > first_depth[e] ? first_depth[s] : first_depth[e];
+      if (!capsule_contact(p, aw, bw, m->col_radius[s], dep_ends, cc, &depth, n)) continue;
+      if (nc >= kmax) { fl |= 1; continue; }
+      for (int a = 0; a < 3; ++a) { cx[nc][a] = cc[a] - k->pbase[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }
+      cdepth[nc] = depth; cbody[nc] = m->col_body[s]; ccol[nc] = s; csecond[nc] = 2;
+      contact_frame(n, Rc[nc]);
+      ++nc;
+    }
   }
 
   /* Self-collision (sphere x sphere): two primitives of the candidate set closer than r_i + r_j touch in the middle of the
@@ -1498,7 +1565,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       }
       contacts[nout].depth = cdepth[i];
       contacts[nout].body = h ? cbody2[i] : cbody[i];
-      contacts[nout].collision = two ? (h ? (ccol2[i] | ORC_SELF_B) : (ccol[i] | ORC_SELF_A)) : (csecond[i] ? (ccol[i] | ORC_SECOND) : ccol[i]);
+      contacts[nout].collision = two ? (h ? (ccol2[i] | ORC_SELF_B) : (ccol[i] | ORC_SELF_A)) : (csecond[i] == 2 ? (ccol[i] | ORC_CAPSULE) : csecond[i] ? (ccol[i] | ORC_SECOND) : ccol[i]);
     }
   }
   if (n_contacts) *n_contacts = nout;

@@ -98,6 +98,10 @@ typedef struct orc_params {
   /* integration scheme of the positions: q+ = q (+) dt (theta u+ + (1 - theta) u); 1 = semi-implicit Euler (default), 0 = explicit Euler,
    * 0.5 = trapezoid (RaiSim's IntegrationScheme::SEMI_IMPLICIT / EULER / TRAPEZOID [RECALL]) */
   double integ_theta;
+  /* exact capsule x height map (the device's rsb_set_capsule_contacts; default 0 = a capsule is its two end spheres): the cylinder
+   * between the end spheres of a capsule (rsb_model_blob::col_capsule) also reports its deepest point when that point is deeper than
+   * both ends - a shank lying across a ridge.  See capsule_contact() in rsb_oracle.c for the search both sides run. */
+  int32_t hm_capsule;
 } orc_params;
 
 /* collision ids reported for the two entries of a self-collision (RaiSim lists it once per body): primitive id | flag */
@@ -105,6 +109,8 @@ typedef struct orc_params {
 #define ORC_SELF_B 0x20000
 /* ... and for the second contact of a primitive with the terrain (orc_params::hm_contacts) */
 #define ORC_SECOND 0x40000
+/* ... and for the contact of a capsule's cylinder (orc_params::hm_capsule): first end sphere's id | flag */
+#define ORC_CAPSULE 0x80000
 
 /* the candidate pairs of self-collision in enumeration order: pairs[2k], pairs[2k+1] = primitive ids i < j; returns the count */
 int orc_self_pairs(const rsb_model_blob* m, const uint8_t* ignore, int32_t* pairs, int cap);

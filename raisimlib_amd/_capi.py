@@ -13,7 +13,7 @@ RSB_MAX_CONTACTS = 16
 RSB_NAME_LEN = 48
 
 RSB_HOST, RSB_DEVICE = 0, 1
-RSB_CONTACT_SELF_A, RSB_CONTACT_SELF_B, RSB_CONTACT_SECOND = 0x10000, 0x20000, 0x40000
+RSB_CONTACT_SELF_A, RSB_CONTACT_SELF_B, RSB_CONTACT_SECOND, RSB_CONTACT_CAPSULE = 0x10000, 0x20000, 0x40000, 0x80000
 RSB_FORCE_AND_TORQUE, RSB_PD_PLUS_FEEDFORWARD_TORQUE = 0, 1
 (RSB_F_GC, RSB_F_GV, RSB_F_PTARGET, RSB_F_DTARGET, RSB_F_TAU_FF, RSB_F_CONTACT_COUNT, RSB_F_CONTACTS,
  RSB_F_FLAGS, RSB_F_GENERALIZED_FORCE) = range(9)
@@ -34,6 +34,7 @@ class ModelBlob(C.Structure):
         ("body_name", (C.c_char * RSB_NAME_LEN) * _B), ("joint_name", (C.c_char * RSB_NAME_LEN) * _B),
         ("col_name", (C.c_char * RSB_NAME_LEN) * _S),
         ("col_axis", (C.c_double * 3) * _S), ("col_rim", C.c_double * _S), ("col_material", (C.c_char * RSB_NAME_LEN) * _S),
+        ("col_capsule", C.c_int32 * _S),
     ]
 
 
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "rsb_set_solver_multi_contact": (_I, [_VP, _I, _I, _I, _I]),
     "rsb_set_solver_anderson": (_I, [_VP, _I, _D]),
     "rsb_set_heightmap_contacts": (_I, [_VP, _I, _D]),
+    "rsb_set_capsule_contacts": (_I, [_VP, _I]),
     "rsb_set_integration_scheme": (_I, [_VP, _I]),
     "rsb_set_early_termination": (_I, [_VP, _I]),
     "rsb_set_solver_warm_start": (_I, [_VP, _I]),

@@ -88,6 +88,7 @@ struct rsb_world {
   int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
   int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
   int hm_contacts = 1; double hm_second_cos = 0.70710678118654752;                                        // rsb_set_heightmap_contacts
+  bool hm_capsule = false;                                                                               // rsb_set_capsule_contacts
   double integ_theta = 1.0;                                                                // rsb_set_integration_scheme
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
@@ -238,7 +239,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   // Delassus phase writes its blocks over both)
   const int gsize = tri ? (kcap * (kcap + 1) / 2) * 12 : 3 * kcap * L.gstride;
   const int upsize = b.nb * rsbk::kUpSlot + (tri ? b.nb * rsbk::kFactSlot : 0);
-  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 8) * hm_slots_for(b) + RSB_MAX_COLLISIONS}));
+  L.g = take(std::max({gsize, upsize, (rsbk::kHmRec + 8) * hm_slots_for(b) + RSB_MAX_COLLISIONS + 16}));   // (+ 16: the capsule search's four sample results)
   if (tri) L.fact = L.g + b.nb * rsbk::kUpSlot;
   L.ginv = take(12 * kcap);
   L.lam = take(3 * kcap);
@@ -310,7 +311,7 @@ __global__ void gather_obs_kernel(float* out, const float* gc, const float* gv, 
     int nc = count[e];
     for (int k = 0; k < nc; ++k) {
       const rsb_contact& ct = contacts[(size_t)e * kmax + k];
-      if ((ct.collision & ~RSB_CONTACT_SECOND) == want) v += ct.impulse[ax] * inv_dt;   // (a primitive's two contacts with a height map add up)
+      if ((ct.collision & ~(RSB_CONTACT_SECOND | RSB_CONTACT_CAPSULE)) == want) v += ct.impulse[ax] * inv_dt;   // (a primitive's contacts with a height map add up)
     }
   }
   out[i] = v;
@@ -324,7 +325,7 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
   bool term = (flags[e] & 2) != 0;
   const int nc = count[e];
   for (int k = 0; k < nc; ++k) {
-    const int c = contacts[(size_t)e * kmax + k].collision & ~RSB_CONTACT_SECOND;   // (a second flank's contact counts as its primitive's)
+    const int c = contacts[(size_t)e * kmax + k].collision & ~(RSB_CONTACT_SECOND | RSB_CONTACT_CAPSULE);   // (a second flank's / a capsule cylinder's contact counts as its primitive's)
     // an entry of a self-collision (id | RSB_CONTACT_SELF_A / _B) is never a foot on the terrain: terminal, as in the fused
     // epilogue of the step kernel (and a shift by >= 64 would be undefined)
     if (c >= RSB_CONTACT_SELF_A || !((allowed >> c) & 1ull)) term = true;
@@ -434,6 +435,7 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
     ct[0] = (float)b.col_pos[i][0]; ct[1] = (float)b.col_pos[i][1]; ct[2] = (float)b.col_pos[i][2]; ct[3] = (float)b.col_radius[i];
     put_i(L.t_col + rsbk::kColSlot * i + 4, b.col_body[i]);
     ct[8] = (float)b.col_axis[i][0]; ct[9] = (float)b.col_axis[i][1]; ct[10] = (float)b.col_axis[i][2]; ct[11] = (float)b.col_rim[i];
+    if (b.col_capsule[i] != 0) { put_i(L.t_col + rsbk::kColSlot * i + 8, b.col_capsule[i] - 1); ct[11] = -1.0f; }   // first end sphere of a capsule: rim < 0, the other end's index in the axis slot (step_kernel.h: capsule search)
     // contact material of the primitive against the terrain: the per-primitive override where one is set, else the world's default
     ct[5] = (float)(w->col_mu[i] >= 0 ? w->col_mu[i] : w->mu);
     ct[6] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);
@@ -496,11 +498,11 @@ int do_integrate(rsb_world* w, int nsub) {
   // a second contact per primitive against a height map (rsb_set_heightmap_contacts): a kernel class of its own, floating base, no peer exchange
   // an integration scheme other than semi-implicit Euler (rsb_set_integration_scheme): likewise a class of its own
   const bool th = w->integ_theta != 1.0;
-  if (th && (w->blob.fixed_base || peer || (w->hm_contacts >= 2 && w->terrain_type == 1) || w->blob.depth - 1 > 12)) {
+  if (th && (w->blob.fixed_base || peer || ((w->hm_contacts >= 2 || w->hm_capsule) && w->terrain_type == 1) || w->blob.depth - 1 > 12)) {
     rsb::set_error("integration schemes other than SEMI_IMPLICIT: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange and with one contact per primitive");
     return RSB_E_UNSUPPORTED;
   }
-  const bool hm2 = w->hm_contacts >= 2 && w->terrain_type == 1;
+  const bool hm2 = (w->hm_contacts >= 2 || w->hm_capsule) && w->terrain_type == 1;   // class-4 kernels: more than one contact per primitive against a height map
   if (hm2 && (w->blob.fixed_base || peer || w->blob.depth - 1 > 12)) {
     rsb::set_error("two contacts per primitive against a height map: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange");
     return RSB_E_UNSUPPORTED;
@@ -537,6 +539,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.anderson = w->kmax > 8 ? w->anderson : 0;   // (rsb.h, oracle: worlds with kmax > 8 only - the large kernel classes also serve deep models at kmax <= 8)
   a.anderson_clip = (float)w->anderson_clip;
   a.hm_contacts = w->hm_contacts; a.hm_second_cos = (float)w->hm_second_cos; a.hm_slots = hm_slots_for(w->blob);
+  a.hm_capsule = w->hm_capsule ? 1 : 0;
   a.integ_theta = (float)w->integ_theta;
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
@@ -835,6 +838,11 @@ int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle
     rsb::set_error("rsb_set_heightmap_contacts: per_primitive is 1 or 2, 0 < min_angle_deg < 90"); return RSB_E_INVALID;
   }
   w->hm_contacts = per_primitive; w->hm_second_cos = std::cos(min_angle_deg * 3.14159265358979323846 / 180.0);
+  return RSB_OK;
+}
+int rsb_set_capsule_contacts(rsb_world* w, int on) {
+  if (!w) { rsb::set_error("rsb_set_capsule_contacts: null world"); return RSB_E_INVALID; }
+  w->hm_capsule = on != 0;
   return RSB_OK;
 }
 int rsb_set_integration_scheme(rsb_world* w, int scheme) {

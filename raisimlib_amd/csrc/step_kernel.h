@@ -253,6 +253,47 @@ __device__ __forceinline__ bool hm_resolve(const Args& a, const float* heights, 
   return feature;
 }
 
+// ---- capsule search (class-4 kernels only; oracle: capsule_contact / terrain_contact_ex): one cell against a sample point of the capsule's
+// axis, the corner heights read from the map itself (the sphere path stages a 4 x 4 patch in LDS; the samples move from round to round)
+template <class Args>
+__device__ __forceinline__ void hm_scan_cell_map(const Args& a, const float* heights, int ix, int iy, int order, float x, float y, float z,
+                                                 unsigned& key, float* bp, float* bn) {
+  const float* H = heights + iy * a.hm_xs + ix;
+  const float ox = (a.hm_x0 + (float)ix * a.hm_dx) - x, oy = (a.hm_y0 + (float)iy * a.hm_dy) - y;
+  const float v00[3] = {ox, oy, H[0] - z}, v10[3] = {ox + a.hm_dx, oy, H[1] - z};
+  const float v01[3] = {ox, oy + a.hm_dy, H[a.hm_xs] - z}, v11[3] = {ox + a.hm_dx, oy + a.hm_dy, H[a.hm_xs + 1] - z};
+  RSB_UNROLL for (int tri = 0; tri < 2; ++tri) {
+    const float* b = tri == 0 ? v10 : v11;
+    const float* c = tri == 0 ? v11 : v01;
+    float q[3];
+    closest_on_triangle(v00, b, c, q);
+    const unsigned k = (__float_as_uint(dot3(q, q)) & ~31u) | (unsigned)(order + tri);
+    if (k < key) {
+      key = k;
+      float e1[3], e2[3];
+      RSB_UNROLL for (int i = 0; i < 3; ++i) { bp[i] = q[i]; e1[i] = b[i] - v00[i]; e2[i] = c[i] - v00[i]; }
+      cross3(e1, e2, bn);
+    }
+  }
+}
+// ... and its resolve: "outside the terrain" is decided by the height field itself (the centre is above the surface at its xy), not by the
+// plane of the triangle that holds the closest point - at a convex edge the two differ (oracle: terrain_contact_ex, above_test)
+template <class Args>
+__device__ __forceinline__ void hm_resolve_above(const Args& a, const float* heights, const float* bp, float x, float y, float z, float r, float& depth, float* n) {
+  const float dist = sqrtf(dot3(bp, bp));
+  float h, nh[3];
+  terrain_eval(a, heights, x, y, h, nh);
+  const bool inside = (x >= a.hm_x0) & (x <= a.hm_x0 + a.hm_dx * (float)(a.hm_xs - 1)) & (y >= a.hm_y0) & (y <= a.hm_y0 + a.hm_dy * (float)(a.hm_ys - 1));
+  if (inside & (z > h) & (dist > 1e-9f)) {
+    const float id = 1.0f / dist;
+    RSB_UNROLL for (int i = 0; i < 3; ++i) n[i] = -bp[i] * id;
+    depth = r - dist;
+  } else {
+    RSB_UNROLL for (int i = 0; i < 3; ++i) n[i] = nh[i];
+    depth = r - (z - h) * nh[2];
+  }
+}
+
 // contact frame [t1 t2 n] (oracle: contact_frame): t1 = the normalised projection of a world axis on the tangent plane - world x,
 // or world y when the normal is (nearly) along x (a self-collision between mirror-symmetric limbs, a closest-feature normal on
 // a height-map edge: the projection of x would vanish) -, t2 = n x t1
@@ -1022,6 +1063,76 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
             emit(hit, ci, ci | kSecond, cbody, c, rad, n, dep);
           }
         }
+        // ---- the cylinders of the capsules (rsb_set_capsule_contacts; oracle: capsule_contact): the deepest point of the axis segment
+        // between the two end spheres, located by kCapsuleRounds rounds of four samples (lane = (sample, cell): the four lanes of a quad
+        // scan the cells under one sample); a contact of its own when it penetrates and is deeper than both ends by kCapsuleMargin
+        if (ac.hm_capsule) {
+          float* CAPR = G + (kHmRec + 8) * hm_slots + RSB_MAX_COLLISIONS;    // [4][4] depth, normal of the round's four samples
+          for (int ci = 0; ci < ncol; ++ci) {
+            if (!(COLT[kColSlot * ci + 11] < 0.f)) continue;                  // (the model's data: uniform over the wave)
+            const int ce = __float_as_int(COLT[kColSlot * ci + 8]);           // the capsule's other end sphere
+            float ca[3], cb[3];
+            int cbody = 0;
+            float rad = 0.f;
+            {
+              float ct[4], P[12], t[3];
+              ld4(COLT + kColSlot * ci, ct);
+              cbody = __float_as_int(COLT[kColSlot * ci + 4]);
+              rad = ct[3];
+              ldv<3>(BODY + cbody * kBodySlot, P);
+              mat3_vec(P, ct, t);
+              ca[0] = P[9] + t[0]; ca[1] = P[10] + t[1]; ca[2] = P[11] + t[2];
+              ld4(COLT + kColSlot * ce, ct);
+              mat3_vec(P, ct, t);
+              cb[0] = P[9] + t[0]; cb[1] = P[10] + t[1]; cb[2] = P[11] + t[2];
+            }
+            const bool near = (pbz + fminf(ca[2], cb[2]) - rad <= ac.hm_max) && !dead;
+            if (!__any(near)) continue;
+            const int sa = SLOTOF[ci], sb = SLOTOF[ce];
+            const float dep_ends = fmaxf(fmaxf(sa > 0 ? RES[4 * (sa - 1)] : 0.f, sb > 0 ? RES[4 * (sb - 1)] : 0.f), 0.f);
+            float cc = 0.5f, ww = 0.5f, bd = 0.f, bt = 0.5f, bn3[3] = {0.f, 0.f, 1.f};
+            const int ks = (s >> 2) & 3, t4 = s & 3;
+            for (int round = 0; round < kCapsuleRounds; ++round) {
+              {
+                const float t = fminf(fmaxf(cc + ww * (-0.6f + 0.4f * (float)ks), 0.02f), 0.98f);
+                const float x = pbx + ca[0] + t * (cb[0] - ca[0]), y = pby + ca[1] + t * (cb[1] - ca[1]), z = pbz + ca[2] + t * (cb[2] - ca[2]);
+                int ix0, iy0, nx, ny;
+                hm_cell_range(ac, x, y, rad, ix0, iy0, nx, ny);
+                const int ncell = (near && s < 16) ? nx * ny : 0;
+                unsigned key = 0xffffffffu;
+                float bp[3] = {0.f, 0.f, 0.f}, bnn[3] = {0.f, 0.f, 1.f};
+                for (int q = t4; q < ncell; q += 4) {
+                  const int cyy = (q >= nx ? 1 : 0) + (q >= 2 * nx ? 1 : 0), cxx = q - cyy * nx;
+                  hm_scan_cell_map(ac, env_heights, ix0 + cxx, iy0 + cyy, 2 * q, x, y, z, key, bp, bnn);
+                }
+                unsigned kmin = min(key, (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0xB1, 0xf, 0xf, false));
+                kmin = min(kmin, (unsigned)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x4E, 0xf, 0xf, false));
+                if (near && s < 16 && key == kmin) {
+                  float o4[4];
+                  hm_resolve_above(ac, env_heights, bp, x, y, z, rad, o4[0], o4 + 1);
+                  st4(CAPR + 4 * ks, o4);
+                }
+              }
+              __syncthreads();
+              // every lane ranks the four samples the same way: a later one must be deeper by more than 2e-6 r to win (oracle: the same rule)
+              bool have = false;
+              RSB_UNROLL for (int k2 = 0; k2 < 4; ++k2) {
+                float o4[4];
+                ld4(CAPR + 4 * k2, o4);
+                const float tk = fminf(fmaxf(cc + ww * (-0.6f + 0.4f * (float)k2), 0.02f), 0.98f);
+                const bool take = !have || o4[0] > bd + 2e-6f * rad;
+                bd = take ? o4[0] : bd; bt = take ? tk : bt;
+                bn3[0] = take ? o4[1] : bn3[0]; bn3[1] = take ? o4[2] : bn3[1]; bn3[2] = take ? o4[3] : bn3[2];
+                have = true;
+              }
+              cc = bt; ww *= 0.4f;
+              __syncthreads();
+            }
+            const bool hitc = near && bd > 0.f && bd > dep_ends + kCapsuleMargin && s == 0;
+            const float crel[3] = {ca[0] + bt * (cb[0] - ca[0]), ca[1] + bt * (cb[1] - ca[1]), ca[2] + bt * (cb[2] - ca[2])};
+            emit(hitc, ci, ci | kCapsule, cbody, crel, rad, bn3, bd);
+          }
+        }
       }
       __syncthreads();   // the scratch is free again (the up pass reuses it)
     }
@@ -1277,7 +1388,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           float cv = t[0] * (Vb[3] + wxx[0]) + t[1] * (Vb[4] + wxx[1]) + t[2] * (Vb[5] + wxx[2]);
           // Newton restitution (oracle: "restitution"): the approach speed J u of this step re-enters the normal row
           const int cid = __float_as_int(CN[11]);
-          const bool second = HM2 && (cid & kSecond) != 0;   // a primitive's second contact with the height map: the primitive's material
+          const bool second = HM2 && (cid & kExtra) != 0;    // a primitive's second contact with the height map / the cylinder of its capsule: the primitive's material
           const int cprim = second ? (cid & 0xffff) : min(cid, ncol - 1);   // (joint-limit rows carry ids >= ncol and no restitution)
           const bool selfrow = !second && cid >= kSelfA;     // entry of a self-collision: restitution is applied to the folded contact (approach speed = sum of the two entries')
           if (selfrow && rr == 2) SELFT[4 * i + 3] = cv;
@@ -1579,7 +1690,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
           }
         }
         float mu = (isc && mycol < ncol) ? COLT[kColSlot * mycol + 5] : ag.mu;
-        if constexpr (HM2) { if (isc && (mycol & kSecond)) mu = COLT[kColSlot * (mycol & 0xffff) + 5]; }
+        if constexpr (HM2) { if (isc && (mycol & kExtra)) mu = COLT[kColSlot * (mycol & 0xffff) + 5]; }
         if (mycol & kSelfA) mu = SELFT[4 * s];    // material pair of the two primitives
         const float mu2 = mu * mu;
         const float alpha_init = ag.alpha_init, alpha_min = ag.alpha_min, alpha_decay = ag.alpha_decay, threshold = ag.threshold;
@@ -2061,7 +2172,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
     if (dead) { nc = nc_dead; flag |= 8; }   // report the contacts that ended the episode
     int mycol = 0;
     if (s < nc) mycol = __float_as_int(CON[s * kConSlot + 11]);
-    if constexpr (HM2) { if (mycol & kSecond) mycol &= 0xffff; }   // a second flank's contact counts as its primitive's (rule, warm record: none is kept twice)
+    if constexpr (HM2) { if (mycol & kExtra) mycol &= 0xffff; }    // a second flank's / a capsule cylinder's contact counts as its primitive's (rule, warm record: none is kept twice)
     const bool illegal = ae.do_reset && s < nc && (mycol >= kSelfA || !((ae.allowed >> mycol) & 1ull));
     const unsigned long long bb = __ballot(bad), bi = __ballot(illegal);
     const unsigned long long gsel = (LPE == 64) ? ~0ull : (((1ull << (LPE % 64)) - 1ull) << (el * LPE));
@@ -2080,7 +2191,7 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         float f0 = 0.f, f1 = 0.f, f2 = 0.f;
         for (int k = 0; k < nc; ++k) {
           const int kid = __float_as_int(CON[k * kConSlot + 11]);
-          if ((HM2 ? (kid & ~kSecond) : kid) == want) {   // (class 4: a primitive's two contacts with the height map add up; f starts at 0, every other class has one match)
+          if ((HM2 ? (kid & ~kExtra) : kid) == want) {   // (class 4: a primitive's two contacts with the height map add up; f starts at 0, every other class has one match)
             const float* CN = CON + k * kConSlot;
             const float l0 = LAM[3 * k], l1 = LAM[3 * k + 1], l2 = LAM[3 * k + 2];
             f0 += (CN[4] * l0 + CN[8] * l1 + CN[12] * l2) * inv_dt;

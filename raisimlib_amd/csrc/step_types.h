@@ -34,6 +34,10 @@ constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
 constexpr float kDenNewton = 1e-3f;   // == ORC_DEN_NEWTON
 constexpr int kPolishSteps = 2;       // == ORC_POLISH_STEPS
 constexpr int kSecond = 0x40000;      // collision id flag of a primitive's SECOND contact with a height map (== RSB_CONTACT_SECOND, ORC_SECOND)
+constexpr int kCapsule = 0x80000;     // ... of the contact of a capsule's cylinder, carried by its first end sphere's id (== RSB_CONTACT_CAPSULE, ORC_CAPSULE)
+constexpr int kExtra = kSecond | kCapsule;   // contacts that belong to a primitive besides its first one (class-4 kernels): the primitive's material, a cold start
+constexpr float kCapsuleMargin = 1e-4f;   // == ORC_CAPSULE_MARGIN
+constexpr int kCapsuleRounds = 4;         // == ORC_CAPSULE_ROUNDS
 constexpr int kSelfA = 0x10000;       // collision id flags of the two entries of a self-collision (== RSB_CONTACT_SELF_A / _B, ORC_SELF_A / _B)
 constexpr int kSelfB = 0x20000;
 constexpr int kSelfBatch = 5;          // passes per batch of the self-collision sweep
@@ -163,6 +167,9 @@ struct StepArgs {
   uint32_t* obs_ctr;                     // this rank's wave-arrival counter (device memory, zero between launches)
   int n_obs_peers, obs_row0;
   uint32_t obs_step;                     // value published in the flags: the control step's sequence number (>= 1)
+  // exact capsule x height map (rsb_set_capsule_contacts; class-4 kernels): the cylinder between a capsule's end spheres reports its deepest point.
+  // At the END of the struct: every offset the benchmark classes read stays where it was
+  int hm_capsule;
 #ifdef RSB_X_ARGPAD
   char x_pad[RSB_X_ARGPAD];
 #endif

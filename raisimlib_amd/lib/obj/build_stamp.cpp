@@ -1,1 +1,1 @@
-extern "C" const char* rsb_source_hash(void) { return "1acc282d51d359097b533cc7a3e3f449"; }
+extern "C" const char* rsb_source_hash(void) { return "a4f90b5ac8f95a192fe5559007d0ead1"; }

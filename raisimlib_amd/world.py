@@ -232,6 +232,10 @@ class BatchedWorld:
         """Contacts per collision primitive against a height map (1 = closest feature; 2 = also a second flank's; see rsb.h)."""
         check(self.L.rsb_set_heightmap_contacts(self.handle, int(per_primitive), float(min_angle_deg)), "rsb_set_heightmap_contacts")
 
+    def set_capsule_contacts(self, on=True):
+        """Exact capsule x height map: the cylinder between a capsule's end spheres reports its deepest point (rsb_set_capsule_contacts)."""
+        check(self.L.rsb_set_capsule_contacts(self.handle, int(bool(on))), "rsb_set_capsule_contacts")
+
     def set_solver_anderson(self, first_sweep=2, clip=20.0):
         """Anderson acceleration of the sweep in multi-contact envs of worlds with > 8 contact slots (see rsb.h). first_sweep 0 = off."""
         check(self.L.rsb_set_solver_anderson(self.handle, int(first_sweep), float(clip)), "rsb_set_solver_anderson")

@@ -371,6 +371,41 @@ def test_ball_in_a_valley_rests_on_both_flanks(built_lib, mu):
     assert (res[1][1] == 1).all() and res[1][3] > 5e-3
 
 
+def test_capsule_lying_across_a_ridge_rests_on_its_cylinder(built_lib):
+    """rsb_set_capsule_contacts through the C-ABI (the oracle KAT of the same name): a 0.6 m capsule lying across a 0.3 m ridge rests on
+    it with its cylinder - ONE contact flagged RSB_CONTACT_CAPSULE on the first end sphere's id, on the ridge line, wherever along the
+    capsule the ridge sits - and is carried there; with the option off (a capsule = its two end spheres) the same log falls through."""
+    from test_oracle_kat import LOG_URDF, _ridge_map
+    from raisimlib_amd._capi import RSB_CONTACT_CAPSULE
+    mass = 4.0
+    res = {}
+    for on in (False, True):
+        _, w = world(LOG_URDF)
+        w.add_height_map(65, 65, 3.2, 3.2, 0.0, 0.0, _ridge_map())
+        w.set_capsule_contacts(on)
+        w.set_collision_materials(np.array([0.8, 0.8]), np.zeros(2), np.zeros(2))
+        gc = tile([0.0, 0.4, 0.3 + 0.05 - 1e-3, 1, 0, 0, 0.0])
+        gc[:, 0] = np.linspace(-0.22, 0.22, N)                         # the ridge under a different point of every env's capsule
+        w.set_state(gc, tile(np.zeros(6)))
+        w.integrate(1)
+        q, u = w.get_state(); cnt, con = w.get_contacts()
+        res[on] = (q, u, cnt, con, gc)
+        w.close()
+    q0, u0, cnt0, _, _ = res[False]
+    assert (cnt0 == 0).all() and np.abs(u0[:, 2] + G * DT).max() < 1e-6  # end spheres only: free fall
+    q, u, cnt, con, gc = res[True]
+    assert (cnt == 1).all() and (con[:, 0]["collision"] == RSB_CONTACT_CAPSULE).all() and (con[:, 0]["body"] == 0).all()
+    assert np.abs(con[:, 0]["position"][:, 0]).max() < 0.012 and np.abs(con[:, 0]["position"][:, 1] - 0.4).max() < 1e-5
+    assert np.abs(con[:, 0]["normal"][:, 2] - 1.0).max() < 5e-3 and np.abs(con[:, 0]["depth"] - 1e-3).max() < 1e-4      # (the located point is within 0.65 % of the capsule's length of the ridge line: the normal tilts by up to 0.08 rad)
+    # the contact point stops (v_z + (w x r)_z = 0); centred envs carry the full weight, off-centre ones tip towards their heavy side
+    lever = con[:, 0]["position"][:, 0] - gc[:, 0]
+    assert np.abs(u[:, 2] - u[:, 4] * lever).max() < 2e-5
+    mid = np.abs(gc[:, 0]) < 0.004
+    assert mid.any() and np.abs(con[mid, 0]["impulse"][:, 2] - mass * G * DT).max() < 2e-3 * mass * G * DT
+    off = np.abs(gc[:, 0]) > 0.05
+    assert (u[off, 4] * gc[off, 0] > 0).all()
+
+
 @pytest.mark.parametrize("scheme,theta", [("semi_implicit", 1.0), ("euler", 0.0), ("trapezoid", 0.5)])
 def test_integration_schemes(anymal, scheme, theta):
     """rsb_set_integration_scheme through the C-ABI: the free-fall closed forms of the oracle KAT, one-step parity of the quadruped on

@@ -111,7 +111,7 @@ def test_per_env_parity_on_the_benchmark_population_at_4096(anymal):
     pt = recipe.targets(N, 60, 0)
     for substeps in (1, workload.SUBSTEPS):
         dev, ref, _ = run_one_step(anymal, q.astype(np.float64), u.astype(np.float64), pt, kp, kd, substeps=substeps)
-        assert ref["n_contacts"].sum() > 2.5 * N
+        assert ref["n_contacts"].sum() > 1.5 * N
         conv = (ref["flags"] & 4) == 0
         print(f"N = {N}, {substeps} sub-step(s): contacts {int(ref['n_contacts'].sum())}, oracle solves converged {conv.mean() * 100:.2f} %, "
               f"max |du| on converged envs {np.abs(dev['u'] - ref['u']).max(axis=1)[conv].max():.1e}")
@@ -657,3 +657,60 @@ def test_two_contacts_per_primitive_on_a_rough_map_parity(anymal, angle):
     eu = np.abs(dev["u"][m2] - ref["u"][m2]).max(axis=1) / (1 + np.abs(ref["u"][m2]).max(axis=1))
     assert np.median(eu) < 1e-5 and np.percentile(eu, 90) < 2e-3 and eu.max() < 5e-2, (np.median(eu), np.percentile(eu, 90), eu.max())
     assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()
+
+
+def test_capsule_cylinder_contacts_on_a_rough_map_parity(built_lib):
+    """rsb_set_capsule_contacts (kernel class 4) vs the oracle with hm_capsule = 1: 512 free capsules (0.6 m long, r 5 cm) at random
+    poses just above / in a rough map whose bumps are narrower than a capsule is long.  Same contact lists (cylinder contacts flagged
+    RSB_CONTACT_CAPSULE, after the end spheres'), the located points and normals equal to the sampling's fp32 resolution, states within
+    the one-step tolerance; and the same for the quadruped (thigh capsules) dropped onto the map."""
+    from raisimlib_amd import Model
+    from test_oracle_kat import LOG_URDF
+    H = workload.smoothed_heightmap(64, 64, amplitude=0.25, seed=9)
+    hm = (64, 64, 3.2, 3.2, 0.0, 0.0, H)
+    rng = np.random.default_rng(4)
+    for name, model in (("capsule", Model(urdf_string=LOG_URDF)), ("quadruped", Model(urdf_path=__import__("raisimlib_amd").rsc_path("anymal_c_like.urdf")))):
+        N = 512
+        if name == "capsule":
+            gc = np.zeros((N, 7)); gv = rng.normal(size=(N, 6)) * 0.3
+            gc[:, :2] = rng.uniform(-1.0, 1.0, (N, 2))
+            ang = rng.uniform(-np.pi, np.pi, N); tilt = rng.uniform(-0.25, 0.25, N)
+            # yaw about z, then a small pitch: quaternion of Rz(ang) Ry(tilt)
+            cz, sz, cy, sy = np.cos(ang / 2), np.sin(ang / 2), np.cos(tilt / 2), np.sin(tilt / 2)
+            gc[:, 3], gc[:, 4], gc[:, 5], gc[:, 6] = cz * cy, -sz * sy, cz * sy, sz * cy
+            o0 = Oracle(model.blob); o0.set_heightmap(*hm)
+            gc[:, 2] = [o0.terrain(x, y)[0] for x, y in gc[:, :2]] + rng.uniform(0.0, 0.12, N)
+            kp = kd = np.zeros(6)
+        else:
+            gc, gv = standing_states(N, seed=23, z=(0.22, 0.5), joint_noise=0.5)      # low and contorted: thighs reach the bumps
+            gc[:, :2] *= 0.2
+            kp, kd = workload.anymal_gains()
+        w = BatchedWorld(model, N)
+        o = Oracle(model.blob)
+        w.add_height_map(*hm); o.set_heightmap(*hm)
+        w.set_capsule_contacts(True); o.p.hm_capsule = 1
+        dtg = np.zeros((N, model.nv))
+        w.set_pd_gains(kp, kd); w.set_pd_target(gc, dtg); w.set_state(gc, gv)
+        w.integrate(1)
+        q1, u1 = w.get_state(); cnt, con = w.get_contacts()
+        dev = dict(q=q1, u=u1, cnt=cnt, con=con, iters=w.get_solver_iterations(), flags=w.get_flags())
+        ref = o.step_batch(f32(gc), f32(gv), 1, kp.astype(np.float64), kd.astype(np.float64), f32(gc), dtg, None, want_contacts=True, lam_warm=o.new_warm_state(N))
+        w.close()
+        valid = np.arange(ref["contacts"].shape[1])[None, :] < ref["n_contacts"][:, None]
+        cyl = valid & ((ref["contacts"]["collision"] & 0x80000) != 0)
+        print(f"{name}: {int(ref['n_contacts'].sum())} contacts, {int(cyl.sum())} on capsule cylinders in {int(cyl.any(axis=1).sum())} envs")
+        assert cyl.sum() > (60 if name == "capsule" else 5)                # the option matters on this map
+        same = dev["cnt"] == ref["n_contacts"]
+        for e in np.nonzero(same)[0]:
+            same[e] = np.array_equal(dev["con"][e][:cnt[e]]["collision"], ref["contacts"][e][:cnt[e]]["collision"])
+        assert same.mean() > 0.97, same.mean()      # (a cylinder 0.1 mm deeper than its ends, or a sample pair within 2e-6 r of a tie, rounds either way)
+        worst_p = worst_n = 0.0
+        for e in np.nonzero(same & cyl.any(axis=1))[0]:
+            n = cnt[e]
+            k = np.nonzero(cyl[e][:n])[0]
+            worst_p = max(worst_p, np.abs(dev["con"][e][:n]["position"][k] - ref["contacts"][e][:n]["position"][k]).max())
+            worst_n = max(worst_n, np.abs(dev["con"][e][:n]["normal"][k] - ref["contacts"][e][:n]["normal"][k]).max())
+        assert worst_p < 2e-4 and worst_n < 2e-3, (worst_p, worst_n)         # the same samples on both sides (fp32 vs fp64 coordinates)
+        pick = lambda m_: ({k: v[m_] for k, v in dev.items()}, {k: (v[m_] if isinstance(v, np.ndarray) and len(v) == len(m_) else v) for k, v in ref.items()})   # noqa: E731
+        check_step(*pick(same), min_conv=0.75, both_converged=True, du_tol=5e-4)
+        assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()

@@ -562,6 +562,51 @@ def test_sampled_colliders_find_the_contact_under_the_middle(built_lib, which):
     assert abs(con["impulse"][:, 2].sum() - mass * 9.81 * 0.0025) < 1e-3 * mass * 9.81 * 0.0025
 
 
+@pytest.mark.parametrize("shift", [0.0, 0.13, -0.21])
+def test_capsule_lying_across_a_ridge_rests_on_its_cylinder(built_lib, shift):
+    """Exact capsule x height map (orc_params::hm_capsule, the device's rsb_set_capsule_contacts): a 0.6 m capsule lying ACROSS a 0.3 m
+    ridge touches it with its cylinder - wherever along its length the ridge happens to sit - while its two end spheres hang in the
+    air.  ONE contact, flagged ORC_CAPSULE on the first end sphere's id, at the ridge line, carrying the weight; off centre the log also
+    starts to tip about the ridge (torque m g * shift).  Without the option the same log falls through the ridge.  On flat ground the
+    option changes nothing: the two end spheres hold the capsule, no third contact appears between them."""
+    from raisimlib_amd import Model
+    m = Model(urdf_string=LOG_URDF)
+    assert m.ncol == 2 and list(m.blob.col_capsule[:2]) == [2, 0]          # the loader pairs the two end spheres
+    hm, z0, mass, dt = _ridge_map(), 0.3 + 0.05 - 1e-3, 4.0, 0.0025      # 1 mm into the ridge (the cylinder's contact needs 0.1 mm more depth than the ends have)
+    res = {}
+    for on in (0, 1):
+        o = Oracle(m.blob)
+        o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, hm)
+        o.p.hm_capsule = on
+        q = np.array([shift, 0.4, z0, 1, 0, 0, 0.0]); u = np.zeros(6)
+        q, u, con, _, fl = o.step(q, u)
+        res[on] = (q, u, con)
+    q0, u0, con0 = res[0]
+    q1, u1, con1 = res[1]
+    assert len(con0) == 0 and abs(u0[2] + 9.81 * dt) < 1e-9                # two end spheres: free fall through the ridge
+    assert len(con1) == 1 and con1["collision"][0] == (0 | 0x80000) and con1["body"][0] == 0
+    assert abs(con1["position"][0, 0]) < 0.012 and abs(con1["position"][0, 1] - 0.4) < 1e-6    # on the ridge line (sampling resolution 1.3 % of 0.6 m), under the axis
+    assert abs(con1["normal"][0, 2] - 1.0) < 5e-3 and abs(con1["depth"][0] - 1e-3) < 1e-4
+    # the contact stops the point above the ridge (normal velocity 0 after the step); the impulse is the weight's when the ridge is under the centre
+    lever = con1["position"][0, 0] - q1[0] + 0.0
+    v_point = u1[2] - u1[4] * (con1["position"][0, 0] - shift)             # v_z + (w x r)_z with w about y
+    assert abs(v_point) < 1e-6
+    if shift == 0.0:
+        assert abs(con1["impulse"][0, 2] - mass * 9.81 * dt) < 1e-6 and abs(u1[2]) < 1e-6 and np.abs(u1[3:]).max() < 1e-4
+    else:
+        assert 0 < con1["impulse"][0, 2] < mass * 9.81 * dt and u1[4] * shift > 0    # tips about the ridge, towards its heavy side
+    del lever
+    # flat ground: nothing changes
+    for on in (0, 1):
+        o = Oracle(m.blob)
+        o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, np.zeros((65, 65), np.float32))
+        o.p.hm_capsule = on
+        q, u, con, _, _ = o.step(np.array([0.8, 0.4, 0.05 - 1e-4, 1, 0, 0, 0.0]), np.zeros(6))
+        assert len(con) == 2 and set(con["collision"]) == {0, 1}
+        res[("flat", on)] = (q, u)
+    assert np.array_equal(res[("flat", 0)][0], res[("flat", 1)][0]) and np.array_equal(res[("flat", 0)][1], res[("flat", 1)][1])
+
+
 def valley_map(n=33, size=12.8, slope=0.5):
     """a V-shaped valley along y at x = 0, flanks of the given slope; cells of size / (n - 1) = 0.4 m"""
     xs = np.linspace(-size / 2, size / 2, n)
