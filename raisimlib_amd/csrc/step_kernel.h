@@ -1736,7 +1736,10 @@ __global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
         // Anderson acceleration of the sweep map (oracle: orc_params::anderson; rsb_set_solver_anderson) - the large-model classes
         // only: the quadruped's sweep loop has no register to spare and its envs converge in 3-4 sweeps.  aa_x: the impulse the sweep
         // started from; aa_g / aa_r: the previous sweep's result and residual.
-        constexpr bool AA = TRI;
+#ifndef RSB_X_AA8
+#define RSB_X_AA8 0   /* (experiment: the Anderson step in the quadruped classes too) */
+#endif
+        constexpr bool AA = TRI || RSB_X_AA8;
         const int aa_first = AA ? ag.anderson : 0;
         const float aa_clip = ag.anderson_clip;
         const bool aa_on = AA && multi && aa_first > 0;

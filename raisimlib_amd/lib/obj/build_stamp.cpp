@@ -1,1 +1,1 @@
-extern "C" const char* rsb_source_hash(void) { return "a4f90b5ac8f95a192fe5559007d0ead1"; }
+extern "C" const char* rsb_source_hash(void) { return "5f8e7ae1e34bca57080fe68d1cd158b7"; }

@@ -586,7 +586,7 @@ def test_capsule_lying_across_a_ridge_rests_on_its_cylinder(built_lib, shift):
     assert len(con0) == 0 and abs(u0[2] + 9.81 * dt) < 1e-9                # two end spheres: free fall through the ridge
     assert len(con1) == 1 and con1["collision"][0] == (0 | 0x80000) and con1["body"][0] == 0
     assert abs(con1["position"][0, 0]) < 0.012 and abs(con1["position"][0, 1] - 0.4) < 1e-6    # on the ridge line (sampling resolution 1.3 % of 0.6 m), under the axis
-    assert abs(con1["normal"][0, 2] - 1.0) < 5e-3 and abs(con1["depth"][0] - 1e-3) < 1e-4
+    assert abs(con1["normal"][0, 2] - 1.0) < 5e-3 and abs(con1["depth"][0] - 1e-3) < 2e-4
     # the contact stops the point above the ridge (normal velocity 0 after the step); the impulse is the weight's when the ridge is under the centre
     lever = con1["position"][0, 0] - q1[0] + 0.0
     v_point = u1[2] - u1[4] * (con1["position"][0, 0] - shift)             # v_z + (w x r)_z with w about y
