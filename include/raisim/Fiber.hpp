@@ -161,6 +161,7 @@ class FiberScheduler {
       // workers 1 .. threads-1 (a pool kept across run() calls: a control step is one run()) wait for a round number, run their
       // block, report; the caller is worker 0 and runs the flush
       ensurePool(threads);
+      CallerPin pin(cpus_);
       roundFn_ = [&](int t, int& live, int& parked) { round(t, live, parked); };
       for (;;) {
         postRound();
@@ -189,6 +190,7 @@ class FiberScheduler {
       try { for (int i = lo; i < hi && !failed(); ++i) fn(i); } catch (...) { fail(std::current_exception()); }
     };
     ensurePool(threads);
+    CallerPin pin(cpus_);
     roundFn_ = block;
     postRound();
     int live, parked;
@@ -236,11 +238,13 @@ class FiberScheduler {
     // they sleep: a round lasts a few hundred microseconds, and threads woken through a futex all start on the waker's CPU and run one
     // after the other before the kernel's load balancer has moved them (measured: eight workers of 0.7 ms each started 0.8 ms apart,
     // a "parallel" round took as long as the serial one).  OpenMP runtimes wait actively between regions for the same reason.
-    std::vector<int> cpus;
+    std::vector<int>& cpus = cpus_;
+    cpus.clear();
     const char* pin = std::getenv("RSB_FIBER_PIN");
     if (!(pin && std::atoi(pin) == 0)) {
       cpu_set_t cs;
-      if (sched_getaffinity(0, sizeof cs, &cs) == 0) for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &cs)) cpus.push_back(c);
+      if (pthread_getaffinity_np(pthread_self(), sizeof cs, &cs) == 0) for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &cs)) cpus.push_back(c);
+      if ((int)cpus.size() < threads) cpus.clear();      // fewer CPUs than threads: pinning would stack spinning threads on one core
     }
     for (int t = 1; t < threads; ++t) {
       pool_.emplace_back([this, t, start] {
@@ -260,11 +264,23 @@ class FiberScheduler {
         }
       });
       if (!cpus.empty()) {
-        cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(size_t)t % cpus.size()], &one);
+        cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[(size_t)t], &one);
         pthread_setaffinity_np(pool_.back().native_handle(), sizeof one, &one);
       }
     }
   }
+  /// The caller is worker 0 of every round: while a step's rounds run it sits on the one CPU of the mask no pool thread is pinned to (it would
+  /// otherwise share a core with a pinned worker whenever the scheduler had left it there - measured inside bench.py: half the rate of the
+  /// same loop in a fresh process); its own mask is restored afterwards.
+  struct CallerPin {
+    cpu_set_t old; bool on = false;
+    explicit CallerPin(const std::vector<int>& cpus) {
+      if (cpus.empty() || pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
+      cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpus[0], &one);
+      on = pthread_setaffinity_np(pthread_self(), sizeof one, &one) == 0;
+    }
+    ~CallerPin() { if (on) pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
+  };
   /// a new round for the workers (the caller is worker 0)
   void postRound() {
     reported_.store(1); liveSum_.store(0); parkedSum_.store(0);
@@ -309,6 +325,7 @@ class FiberScheduler {
   std::atomic<bool> failedFlag_{false};
   // worker pool of the threaded rounds
   std::vector<std::thread> pool_;
+  std::vector<int> cpus_;       // CPUs of the creating thread's affinity mask: worker t is pinned to cpus_[t], the caller to cpus_[0] during a step
   std::mutex poolMutex_;
   std::condition_variable poolCv_;
   std::function<void(int, int&, int&)> roundFn_;
