@@ -656,6 +656,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                 "obs_all_gather": gath.describe(),
             },
             "roofline": roof,
+            "build": {"source_hash": world.L.rsb_source_hash().decode(), "library": os.path.relpath(os.path.realpath(__import__("raisimlib_amd")._capi.LIB_PATH), ROOT)},
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "state_at_end": {"solver_iters_mean": float(iters.mean()), "solver_iters_max": int(iters.max()),
                              "contacts_per_env": float(counts.mean()), "base_height_mean": float(q_end[:, 2].mean())},

@@ -578,8 +578,13 @@ __device__ __forceinline__ void tri_store(float* G, int a, int b, const float (&
 // instruction for instruction (code added to the shared epilogue moved the register allocation of the sub-step loop: +26 spill moves).
 // ML : body-level capacity (>= depth-1).  PROF : compile the cycle stamps / contact-problem dump / LDS poisoning of the
 // rsb_debug_* entry points in (the production instances carry none of it: fewer SGPRs, no branches in the solver loop).
+#ifdef RSB_X_WPE2   /* experiment: cap the instance at 256 registers (two waves per SIMD by registers; the allocator spills the rest to scratch) */
+#define RSB_X_WPE_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#else
+#define RSB_X_WPE_ATTR
+#endif
 template <int LPE, int KMAX, int CL, int ML, bool PROF>
-__global__ void __launch_bounds__(64) rsb_step_kernel(const StepArgs) {
+__global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepArgs) {
   const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();   // the by-value StepArgs sits at offset 0 of the kernarg segment
 #ifdef RSB_X_NOPS   /* experiment: shift the whole kernel's code by RSB_X_NOPS x 4 bytes (alignment of the hot loops' fetch windows) */
   static_for<0, RSB_X_NOPS>([&](auto) { asm volatile("s_nop 0"); });

@@ -1,1 +1,1 @@
-extern "C" const char* rsb_source_hash(void) { return "5f8e7ae1e34bca57080fe68d1cd158b7"; }
+extern "C" const char* rsb_source_hash(void) { return "0d06ddd7d908272b6df6b2235c21849f"; }
