@@ -206,8 +206,9 @@ int rsb_set_heightmap(rsb_world* w, int x_samples, int y_samples, double x_size,
  * default kernels are what they were): floating-base systems of tree depth <= 13, no peer-mapped obs exchange
  * (RSB_E_UNSUPPORTED from the step otherwise). */
 int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle_deg);
-/* Exact capsule x height map (default off: a capsule is its two end spheres - its exact contact set on a PLANE).  With on != 0 the
- * cylinder between the two end spheres of every capsule of the model (rsb_model_blob::col_capsule; <capsule> elements of the URDF)
+/* Exact capsule / cylinder x height map (default off: a capsule is its two end spheres, a cylinder the lowest points of its two rims -
+ * their exact contact sets on a PLANE).  With on != 0 the barrel between the two ends of every capsule and cylinder of the model
+ * (rsb_model_blob::col_capsule; <capsule> and <cylinder> elements of the URDF; a cylinder's samples keep r / L away from its flat caps)
  * also reports its deepest point against a height map when that point penetrates and is deeper than both end spheres by more than
  * 0.1 mm: a shank lying across a ridge rests on the ridge.  The point is located by four rounds of four closest-feature queries along
  * the capsule's axis (resolution 1.3 % of its length; faces, edges and vertices of the triangulated surface alike).  The contact

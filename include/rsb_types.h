@@ -76,9 +76,10 @@ typedef struct rsb_model_blob {
   double col_axis[RSB_MAX_COLLISIONS][3];
   double col_rim[RSB_MAX_COLLISIONS];
   char col_material[RSB_MAX_COLLISIONS][RSB_NAME_LEN];  /* <collision><material name=".."/> of the URDF, "default" if absent */
-  /* capsules: col_capsule[s] = e + 1 makes primitives s and e the two END SPHERES of one capsule (same body, same radius; set on the
-   * first of the two, 0 everywhere else).  On a plane the two end spheres are the capsule's exact contact set; against a height
-   * map the cylinder between them can touch where neither end does (a shank lying across a ridge): rsb_set_capsule_contacts. */
+  /* capsules and cylinders: col_capsule[s] = e + 1 makes primitives s and e the two ENDS of one capsule (two spheres of one radius) or of
+   * one cylinder (two rim primitives of one rim radius) - same body; set on the first of the two, 0 everywhere else.  On a plane the two
+   * ends are the exact contact set; against a height map the barrel between them can touch where neither end does (a shank lying
+   * across a ridge): rsb_set_capsule_contacts. */
   int32_t col_capsule[RSB_MAX_COLLISIONS];
 } rsb_model_blob;
 

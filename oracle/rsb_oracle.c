@@ -653,19 +653,23 @@ static int terrain_contact_ex(const orc_params* p, const double* c, double r, do
  * more than ORC_CAPSULE_MARGIN (a capsule lying on flat ground is held by its two ends: a third, redundant contact between them
  * would only slow the solver down).  Face, edge and vertex contacts all come from the same closest-feature test; the depth along
  * the segment is not unimodal over rough terrain, the first round's four samples decide which dip is refined.
+ * A CYLINDER's barrel is the same search between its two cap centres (its ends are rim primitives: radius 0, rim = the cylinder's radius) with
+ * t kept r / L away from either end: a sample sphere of the cylinder's radius then lies inside the cylinder (it reaches the flat cap, not past
+ * it), and at an interior minimum of the distance the normal is perpendicular to the axis, where sphere and barrel coincide.
  * The device runs the same rounds (step_kernel.h, class-4 kernels): lane = (sample, cell).
  * Upstream counterpart: ODE's capsule x height-field collider - absent from /root/reference. */
 #define ORC_CAPSULE_MARGIN 1e-4
 #define ORC_CAPSULE_ROUNDS 4
-static int capsule_contact(const orc_params* p, const double* a, const double* b, double r, double dep_ends, double* c_out, double* depth, double* n) {
+static int capsule_contact(const orc_params* p, const double* a, const double* b, double r, double tmin, double dep_ends, double* c_out, double* depth, double* n) {
   static const double off[4] = {-0.6, -0.2, 0.2, 0.6};
-  if (p->terrain_type != 1) return 0;
+  if (p->terrain_type != 1 || !(tmin < 0.5)) return 0;
+  const double tmax = 1.0 - tmin;
   double c = 0.5, w = 0.5, best_d = 0.0, best_n[3] = {0, 0, 1}, best_t = 0.5;
   for (int round = 0; round < ORC_CAPSULE_ROUNDS; ++round) {
     int have = 0;
     for (int k = 0; k < 4; ++k) {
       double t = c + w * off[k];
-      t = t < 0.02 ? 0.02 : (t > 0.98 ? 0.98 : t);
+      t = t < tmin ? tmin : (t > tmax ? tmax : t);
       const double pt[3] = {a[0] + t * (b[0] - a[0]), a[1] + t * (b[1] - a[1]), a[2] + t * (b[2] - a[2])};
       double d, nn[3];
       terrain_contact_ex(p, pt, r, &d, nn, NULL, NULL, 1);
@@ -1002,12 +1006,13 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   int csecond[MAXK];               /* second contact of a primitive with the terrain (a valley's other flank) */
   double sec_depth[RSB_MAX_COLLISIONS], sec_n[RSB_MAX_COLLISIONS][3], sec_c[RSB_MAX_COLLISIONS][3];
   double first_depth[RSB_MAX_COLLISIONS];   /* penetration of each primitive's first contact (0: none) */
+  double cap_c[RSB_MAX_COLLISIONS][3];      /* primitive centres as the model gives them (a rim primitive's cen[] is the lowest point of its rim) */
   for (int i = 0; i < MAXK; ++i) { cbody2[i] = -1; ccol2[i] = -1; csecond[i] = 0; }
   for (int s = 0; s < m->ncol; ++s) {
     int b = m->col_body[s];
     double t[3], c[3], cw[3], n[3], depth;
     mat3_vec(k->R[b], m->col_pos[s], t);
-    for (int a = 0; a < 3; ++a) c[a] = k->r[b][a] + t[a];
+    for (int a = 0; a < 3; ++a) { c[a] = k->r[b][a] + t[a]; cap_c[s][a] = c[a]; }
     if (m->col_rim[s] > 0.0) {
       /* rim primitive (end cap of a cylinder): the point of the circle of radius col_rim around c, normal to the cap's axis,
        * that is lowest along the world's vertical: c - rim * e / |e| with e = z - (z.a) a; a cap lying flat keeps its centre */
@@ -1049,11 +1054,14 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       if (m->col_capsule[s] == 0) continue;
       const int e = m->col_capsule[s] - 1;
       double aw[3], bw[3], cc[3], n[3], depth;
-      for (int a = 0; a < 3; ++a) { aw[a] = k->pbase[a] + cen[s][a]; bw[a] = k->pbase[a] + cen[e][a]; }
+      for (int a = 0; a < 3; ++a) { aw[a] = k->pbase[a] + cap_c[s][a]; bw[a] = k->pbase[a] + cap_c[e][a]; }
       const double dep_ends = first_depth[s] > first_depth[e] ? first_depth[s] : first_depth[e];
-      if (!capsule_contact(p, aw, bw, m->col_radius[s], dep_ends, cc, &depth, n)) continue;
+      const int cyl = m->col_rim[s] > 0.0;            /* a cylinder: radius = its rims', samples stay r / L away from the flat caps */
+      const double rr = cyl ? m->col_rim[s] : m->col_radius[s];
+      const double len = sqrt((bw[0] - aw[0]) * (bw[0] - aw[0]) + (bw[1] - aw[1]) * (bw[1] - aw[1]) + (bw[2] - aw[2]) * (bw[2] - aw[2]));
+      if (!capsule_contact(p, aw, bw, rr, cyl ? rr / len : 0.02, dep_ends, cc, &depth, n)) continue;
       if (nc >= kmax) { fl |= 1; continue; }
-      for (int a = 0; a < 3; ++a) { cx[nc][a] = cc[a] - k->pbase[a] - m->col_radius[s] * n[a]; cn[nc][a] = n[a]; }
+      for (int a = 0; a < 3; ++a) { cx[nc][a] = cc[a] - k->pbase[a] - rr * n[a]; cn[nc][a] = n[a]; }
       cdepth[nc] = depth; cbody[nc] = m->col_body[s]; ccol[nc] = s; csecond[nc] = 2;
       contact_frame(n, Rc[nc]);
       ++nc;

@@ -88,7 +88,7 @@ struct rsb_world {
   int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
   int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
   int hm_contacts = 1; double hm_second_cos = 0.70710678118654752;                                        // rsb_set_heightmap_contacts
-  bool hm_capsule = false;                                                                               // rsb_set_capsule_contacts
+  bool hm_capsule = false; int32_t* d_cap = nullptr; int n_cap = 0;                                       // rsb_set_capsule_contacts: [n_cap][2] end primitives of the model's capsules / cylinders
   double integ_theta = 1.0;                                                                // rsb_set_integration_scheme
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
@@ -435,7 +435,6 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
     ct[0] = (float)b.col_pos[i][0]; ct[1] = (float)b.col_pos[i][1]; ct[2] = (float)b.col_pos[i][2]; ct[3] = (float)b.col_radius[i];
     put_i(L.t_col + rsbk::kColSlot * i + 4, b.col_body[i]);
     ct[8] = (float)b.col_axis[i][0]; ct[9] = (float)b.col_axis[i][1]; ct[10] = (float)b.col_axis[i][2]; ct[11] = (float)b.col_rim[i];
-    if (b.col_capsule[i] != 0) { put_i(L.t_col + rsbk::kColSlot * i + 8, b.col_capsule[i] - 1); ct[11] = -1.0f; }   // first end sphere of a capsule: rim < 0, the other end's index in the axis slot (step_kernel.h: capsule search)
     // contact material of the primitive against the terrain: the per-primitive override where one is set, else the world's default
     ct[5] = (float)(w->col_mu[i] >= 0 ? w->col_mu[i] : w->mu);
     ct[6] = (float)(w->col_rest[i] >= 0 ? w->col_rest[i] : w->restitution);
@@ -498,11 +497,11 @@ int do_integrate(rsb_world* w, int nsub) {
   // a second contact per primitive against a height map (rsb_set_heightmap_contacts): a kernel class of its own, floating base, no peer exchange
   // an integration scheme other than semi-implicit Euler (rsb_set_integration_scheme): likewise a class of its own
   const bool th = w->integ_theta != 1.0;
-  if (th && (w->blob.fixed_base || peer || ((w->hm_contacts >= 2 || w->hm_capsule) && w->terrain_type == 1) || w->blob.depth - 1 > 12)) {
+  if (th && (w->blob.fixed_base || peer || ((w->hm_contacts >= 2 || (w->hm_capsule && w->n_cap > 0)) && w->terrain_type == 1) || w->blob.depth - 1 > 12)) {
     rsb::set_error("integration schemes other than SEMI_IMPLICIT: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange and with one contact per primitive");
     return RSB_E_UNSUPPORTED;
   }
-  const bool hm2 = (w->hm_contacts >= 2 || w->hm_capsule) && w->terrain_type == 1;   // class-4 kernels: more than one contact per primitive against a height map
+  const bool hm2 = (w->hm_contacts >= 2 || (w->hm_capsule && w->n_cap > 0)) && w->terrain_type == 1;   // class-4 kernels: more than one contact per primitive against a height map
   if (hm2 && (w->blob.fixed_base || peer || w->blob.depth - 1 > 12)) {
     rsb::set_error("two contacts per primitive against a height map: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange");
     return RSB_E_UNSUPPORTED;
@@ -539,7 +538,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.anderson = w->kmax > 8 ? w->anderson : 0;   // (rsb.h, oracle: worlds with kmax > 8 only - the large kernel classes also serve deep models at kmax <= 8)
   a.anderson_clip = (float)w->anderson_clip;
   a.hm_contacts = w->hm_contacts; a.hm_second_cos = (float)w->hm_second_cos; a.hm_slots = hm_slots_for(w->blob);
-  a.hm_capsule = w->hm_capsule ? 1 : 0;
+  a.hm_capsule = w->hm_capsule ? w->n_cap : 0; a.hm_cap = w->d_cap;
   a.integ_theta = (float)w->integ_theta;
   a.stall_window = w->stall_window; a.stall_factor = (float)w->stall_factor; a.freeze_after = w->freeze_after; a.refine = w->refine; a.settle_tol = (float)w->settle_tol; a.restitution = (float)w->restitution; a.res_threshold = (float)w->res_threshold;
   a.terrain_type = w->terrain_type; a.hm_xs = w->hm_xs; a.hm_ys = w->hm_ys; a.ground_z = (float)w->ground_z;
@@ -687,7 +686,7 @@ int rsb_destroy(rsb_world* w) {
   (void)rsb_obs_peer_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
                   w->d_tmp_gc, w->d_tmp_gv, w->d_tmp_mask, w->d_M, w->d_h, w->d_Minv, w->d_Mwork, w->d_obs_idx, w->d_dbg, w->d_prof, w->d_contacts,
-                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_genf, w->d_hm_index, w->d_launch_mask, w->d_view_masks, w->d_obs_local, w->d_obs_all,
+                  w->d_env_mean, w->d_env_gc0, w->d_env_gv0, w->d_env_io, w->d_env_ob, w->d_env_reward, w->d_env_tau2, w->d_env_done, w->d_warm, w->d_image, w->d_self_mat, w->d_genf, w->d_hm_index, w->d_launch_mask, w->d_view_masks, w->d_cap, w->d_obs_local, w->d_obs_all,
                   w->d_count, w->d_flags, w->d_iters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (hipEvent_t e : w->ring0) (void)hipEventDestroy(e);
@@ -842,6 +841,17 @@ int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle
 }
 int rsb_set_capsule_contacts(rsb_world* w, int on) {
   if (!w) { rsb::set_error("rsb_set_capsule_contacts: null world"); return RSB_E_INVALID; }
+  if (on && !w->d_cap) {      // the end pairs of the model's capsules and cylinders (rsb_model_blob::col_capsule), once
+    std::vector<int32_t> pairs;
+    for (int s = 0; s < w->blob.ncol; ++s)
+      if (w->blob.col_capsule[s] != 0) { pairs.push_back(s); pairs.push_back(w->blob.col_capsule[s] - 1); }
+    w->n_cap = (int)pairs.size() / 2;
+    if (w->n_cap > 0) {
+      HIP_TRY(hipSetDevice(w->device));
+      HIP_TRY(hipMalloc(&w->d_cap, pairs.size() * sizeof(int32_t)));
+      HIP_TRY(hipMemcpy(w->d_cap, pairs.data(), pairs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+  }
   w->hm_capsule = on != 0;
   return RSB_OK;
 }

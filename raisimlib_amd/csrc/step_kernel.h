@@ -1073,25 +1073,30 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
         // scan the cells under one sample); a contact of its own when it penetrates and is deeper than both ends by kCapsuleMargin
         if (ac.hm_capsule) {
           float* CAPR = G + (kHmRec + 8) * hm_slots + RSB_MAX_COLLISIONS;    // [4][4] depth, normal of the round's four samples
-          for (int ci = 0; ci < ncol; ++ci) {
-            if (!(COLT[kColSlot * ci + 11] < 0.f)) continue;                  // (the model's data: uniform over the wave)
-            const int ce = __float_as_int(COLT[kColSlot * ci + 8]);           // the capsule's other end sphere
+          for (int cp = 0; cp < ac.hm_capsule; ++cp) {
+            const int ci = ac.hm_cap[2 * cp], ce = ac.hm_cap[2 * cp + 1];     // the two ends (the model's data: uniform over the wave)
             float ca[3], cb[3];
             int cbody = 0;
-            float rad = 0.f;
+            float rad = 0.f, tmin = 0.02f;
             {
               float ct[4], P[12], t[3];
               ld4(COLT + kColSlot * ci, ct);
               cbody = __float_as_int(COLT[kColSlot * ci + 4]);
-              rad = ct[3];
+              const float rim = COLT[kColSlot * ci + 11];
+              rad = rim > 0.f ? rim : ct[3];          // a cylinder's ends are rim primitives (radius 0, rim = the cylinder's radius): COLT holds the cap CENTRES
               ldv<3>(BODY + cbody * kBodySlot, P);
               mat3_vec(P, ct, t);
               ca[0] = P[9] + t[0]; ca[1] = P[10] + t[1]; ca[2] = P[11] + t[2];
               ld4(COLT + kColSlot * ce, ct);
               mat3_vec(P, ct, t);
               cb[0] = P[9] + t[0]; cb[1] = P[10] + t[1]; cb[2] = P[11] + t[2];
+              if (rim > 0.f) {   // flat caps: a sample sphere must not reach past them (oracle: the same range)
+                const float dx = cb[0] - ca[0], dy = cb[1] - ca[1], dz = cb[2] - ca[2];
+                tmin = rad * __builtin_amdgcn_rsqf(dx * dx + dy * dy + dz * dz);
+              }
             }
-            const bool near = (pbz + fminf(ca[2], cb[2]) - rad <= ac.hm_max) && !dead;
+            const float tmax = 1.0f - tmin;
+            const bool near = (pbz + fminf(ca[2], cb[2]) - rad <= ac.hm_max) && !dead && tmin < 0.5f;
             if (!__any(near)) continue;
             const int sa = SLOTOF[ci], sb = SLOTOF[ce];
             const float dep_ends = fmaxf(fmaxf(sa > 0 ? RES[4 * (sa - 1)] : 0.f, sb > 0 ? RES[4 * (sb - 1)] : 0.f), 0.f);
@@ -1099,7 +1104,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
             const int ks = (s >> 2) & 3, t4 = s & 3;
             for (int round = 0; round < kCapsuleRounds; ++round) {
               {
-                const float t = fminf(fmaxf(cc + ww * (-0.6f + 0.4f * (float)ks), 0.02f), 0.98f);
+                const float t = fminf(fmaxf(cc + ww * (-0.6f + 0.4f * (float)ks), tmin), tmax);
                 const float x = pbx + ca[0] + t * (cb[0] - ca[0]), y = pby + ca[1] + t * (cb[1] - ca[1]), z = pbz + ca[2] + t * (cb[2] - ca[2]);
                 int ix0, iy0, nx, ny;
                 hm_cell_range(ac, x, y, rad, ix0, iy0, nx, ny);
@@ -1124,7 +1129,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
               RSB_UNROLL for (int k2 = 0; k2 < 4; ++k2) {
                 float o4[4];
                 ld4(CAPR + 4 * k2, o4);
-                const float tk = fminf(fmaxf(cc + ww * (-0.6f + 0.4f * (float)k2), 0.02f), 0.98f);
+                const float tk = fminf(fmaxf(cc + ww * (-0.6f + 0.4f * (float)k2), tmin), tmax);
                 const bool take = !have || o4[0] > bd + 2e-6f * rad;
                 bd = take ? o4[0] : bd; bt = take ? tk : bt;
                 bn3[0] = take ? o4[1] : bn3[0]; bn3[1] = take ? o4[2] : bn3[1]; bn3[2] = take ? o4[3] : bn3[2];

@@ -168,8 +168,10 @@ struct StepArgs {
   int n_obs_peers, obs_row0;
   uint32_t obs_step;                     // value published in the flags: the control step's sequence number (>= 1)
   // exact capsule x height map (rsb_set_capsule_contacts; class-4 kernels): the cylinder between a capsule's end spheres reports its deepest point.
-  // At the END of the struct: every offset the benchmark classes read stays where it was
+  // At the END of the struct: every offset the benchmark classes read stays where it was.  hm_cap: [hm_capsule][2] primitive indices of the
+  // two ends of every capsule / cylinder of the model (device memory); hm_capsule = 0: off
   int hm_capsule;
+  const int32_t* hm_cap;
 #ifdef RSB_X_ARGPAD
   char x_pad[RSB_X_ARGPAD];
 #endif

@@ -371,6 +371,29 @@ def test_ball_in_a_valley_rests_on_both_flanks(built_lib, mu):
     assert (res[1][1] == 1).all() and res[1][3] > 5e-3
 
 
+def test_cylinder_lying_across_a_ridge_rests_on_its_barrel(built_lib):
+    """rsb_set_capsule_contacts for a CYLINDER (two rim primitives paired in the blob): the barrel carries it across the ridge (oracle KAT of the
+    same name), equal to the oracle's contact"""
+    from test_oracle_kat import CYL_LOG_URDF, _ridge_map
+    from raisimlib_amd._capi import RSB_CONTACT_CAPSULE
+    m, w = world(CYL_LOG_URDF)
+    o = Oracle(m.blob)
+    hm = _ridge_map()
+    w.add_height_map(65, 65, 3.2, 3.2, 0.0, 0.0, hm); o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, hm)
+    w.set_capsule_contacts(True); o.p.hm_capsule = 1
+    gc = tile([0.0, -0.3, 0.3 + 0.05 - 1e-3, 1, 0, 0, 0.0])
+    gc[:, 0] = np.linspace(-0.2, 0.2, N)
+    w.set_state(gc, tile(np.zeros(6)))
+    w.integrate(1)
+    q, u = w.get_state(); cnt, con = w.get_contacts()
+    w.close()
+    assert (cnt == 1).all() and (con[:, 0]["collision"] == RSB_CONTACT_CAPSULE).all()
+    assert np.abs(con[:, 0]["position"][:, 0]).max() < 0.012 and np.abs(con[:, 0]["normal"][:, 2] - 1.0).max() < 5e-3
+    for e in (0, N // 2, N - 1):
+        qo, uo, co, _, _ = o.step(gc[e].astype(np.float32).astype(np.float64), np.zeros(6))
+        assert len(co) == 1 and np.abs(co["position"][0] - con[e, 0]["position"]).max() < 2e-4 and np.abs(uo - u[e]).max() < 2e-5
+
+
 def test_capsule_lying_across_a_ridge_rests_on_its_cylinder(built_lib):
     """rsb_set_capsule_contacts through the C-ABI (the oracle KAT of the same name): a 0.6 m capsule lying across a 0.3 m ridge rests on
     it with its cylinder - ONE contact flagged RSB_CONTACT_CAPSULE on the first end sphere's id, on the ridge line, wherever along the

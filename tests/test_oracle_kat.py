@@ -508,6 +508,7 @@ LOG_URDF = """<robot name="log"><link name="log">
  <inertial><mass value="4"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.12" iyz="0" izz="0.12"/></inertial>
  <collision><origin rpy="0 1.5707963267948966 0"/><geometry><capsule radius="0.05" length="0.6"/></geometry></collision>
 </link></robot>"""
+CYL_LOG_URDF = LOG_URDF.replace("capsule", "cylinder")
 SLAB_URDF = """<robot name="slab"><link name="slab">
  <inertial><mass value="6"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.2"/></inertial>
  <collision><geometry><box size="0.6 0.6 0.1"/></geometry></collision>
@@ -560,6 +561,32 @@ def test_sampled_colliders_find_the_contact_under_the_middle(built_lib, which):
     assert k == 0 and abs(q_samp[2] - z0) < 2e-3                     # carried from the first step on
     assert np.abs(con["position"][:, :2]).max() < 0.11               # under the middle, not at the ends / corners
     assert abs(con["impulse"][:, 2].sum() - mass * 9.81 * 0.0025) < 1e-3 * mass * 9.81 * 0.0025
+
+
+def test_cylinder_lying_across_a_ridge_rests_on_its_barrel(built_lib):
+    """The same search between a CYLINDER's two cap centres (its ends are rim primitives): the barrel of a 0.6 m cylinder lying across the
+    ridge carries it - one flagged contact on the ridge line, normal up, the weight's impulse - where its two rims hang in the air."""
+    from raisimlib_amd import Model
+    m = Model(urdf_string=CYL_LOG_URDF)
+    assert m.ncol == 2 and list(m.blob.col_capsule[:2]) == [2, 0] and m.blob.col_rim[0] == 0.05 and m.blob.col_radius[0] == 0.0
+    hm, z0, mass, dt = _ridge_map(), 0.3 + 0.05 - 1e-3, 4.0, 0.0025
+    for on in (0, 1):
+        o = Oracle(m.blob)
+        o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, hm)
+        o.p.hm_capsule = on
+        q, u, con, _, _ = o.step(np.array([0.05, -0.3, z0, 1, 0, 0, 0.0]), np.zeros(6))
+        if not on:
+            assert len(con) == 0 and abs(u[2] + 9.81 * dt) < 1e-9
+            continue
+        assert len(con) == 1 and con["collision"][0] == (0 | 0x80000)
+        assert abs(con["position"][0, 0]) < 0.012 and abs(con["position"][0, 1] + 0.3) < 1e-6 and abs(con["normal"][0, 2] - 1.0) < 5e-3
+        assert abs(con["depth"][0] - 1e-3) < 2e-4 and 0 < con["impulse"][0, 2] <= mass * 9.81 * dt * (1 + 1e-9)
+    # a cylinder too short for an interior sample (length < 2 radius) has no barrel contact; flat ground: the rims alone
+    short = Model(urdf_string=CYL_LOG_URDF.replace('length="0.6"', 'length="0.08"'))
+    o = Oracle(short.blob)
+    o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, hm); o.p.hm_capsule = 1
+    _, _, con, _, _ = o.step(np.array([0.0, 0.0, z0, 1, 0, 0, 0.0]), np.zeros(6))
+    assert not (con["collision"] & 0x80000).any()
 
 
 @pytest.mark.parametrize("shift", [0.0, 0.13, -0.21])
