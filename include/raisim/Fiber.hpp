@@ -47,6 +47,8 @@ struct FiberContext { void* sp = nullptr; };
 /// Saves the running context into `from`, continues `to`.  Every register the SysV ABI lets a callee keep is either saved on the
 /// stack (rbx, rbp: not allowed in a clobber list when they are the PIC / frame register) or declared clobbered, so the compiler
 /// spills what is live around the call; 128 bytes are skipped first because the enclosing function may keep data in the red zone.
+/// Not switched: the x87 control word and MXCSR (env bodies that change rounding or exception masks change them for their thread, as a
+/// plain function call would).
 __attribute__((noinline)) inline void fiber_switch(FiberContext* from, const FiberContext* to) {
   void** save = &from->sp;
   void* next = to->sp;

@@ -103,14 +103,15 @@ class PinnedArray {
   ~PinnedArray() { if (p_) rsb_host_free(p_); }
   PinnedArray(const PinnedArray&) = delete;
   PinnedArray& operator=(const PinnedArray&) = delete;
+  /// grow-only storage: shrinking or re-growing within the capacity touches no allocator (a flush whose launch masks change size from step to
+  /// step must not pay a hipHostFree / hipHostMalloc pair each time); new storage starts zeroed, kept storage keeps its contents
   void resize(size_t n) {
-    if (n == n_) return;
-    if (p_) { rsb_host_free(p_); p_ = nullptr; n_ = 0; }
-    if (n == 0) return;
+    if (n <= cap_) { n_ = n; return; }
     void* m = nullptr;
     RSB_CHECK(rsb_host_alloc(n * sizeof(T), &m));
-    p_ = static_cast<T*>(m); n_ = n;
-    std::memset(static_cast<void*>(p_), 0, n * sizeof(T));
+    std::memset(m, 0, n * sizeof(T));
+    if (p_) { std::memcpy(m, static_cast<void*>(p_), n_ * sizeof(T)); rsb_host_free(p_); }
+    p_ = static_cast<T*>(m); n_ = cap_ = n;
   }
   T* data() { return p_; }
   const T* data() const { return p_; }
@@ -119,7 +120,7 @@ class PinnedArray {
   const T& operator[](size_t i) const { return p_[i]; }
  private:
   T* p_ = nullptr;
-  size_t n_ = 0;
+  size_t n_ = 0, cap_ = 0;
 };
 
 /// One solved contact of an articulated system (upstream raisim::Contact).
