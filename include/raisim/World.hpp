@@ -136,7 +136,7 @@ class Contact {
   /// a self-collision is listed once per body: the two entries are neighbours in getContacts(), object A first
   bool isSelfCollision() const { return (c_.collision & (RSB_CONTACT_SELF_A | RSB_CONTACT_SELF_B)) != 0; }
   bool isSecondTerrainContact() const { return (c_.collision & RSB_CONTACT_SECOND) != 0; }   // extension: rsb_set_heightmap_contacts
-  bool isCapsuleCylinderContact() const { return (c_.collision & RSB_CONTACT_CAPSULE) != 0; }  // extension: rsb_set_capsule_contacts (the id is the capsule's first end sphere's)
+  bool isCapsuleCylinderContact() const { return (c_.collision & RSB_CONTACT_CAPSULE) != 0; }  // extension: rsb_set_capsule_contacts (a capsule's / cylinder's barrel, a box's face or edge; the id is the first end's / corner's)
   bool isObjectA() const { return (c_.collision & RSB_CONTACT_SELF_B) == 0; }
   bool skip() const { return false; }
  private:

@@ -215,7 +215,10 @@ int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle
  * carries RSB_CONTACT_CAPSULE | the FIRST end sphere's index in rsb_contact::collision, uses that primitive's material, starts cold
  * in every solve, follows the first (and second-flank) contacts in the list and counts as that primitive for the termination rule
  * and the foot forces.  Runs in the kernel class of rsb_set_heightmap_contacts (same restrictions); no effect on a plane.
- * Upstream counterpart: RaiSim's ODE capsule x height-field collider [RECALL; absent from /root/reference]. */
+ * Boxes (<box>: eight corner primitives, col_capsule = -1 on the first) get the same treatment: of each pair of opposite faces the one that
+ * looks down is searched for its deepest point (three rounds of 4 x 4 point samples, resolution 3.2 % of the face's edge), and the deepest
+ * of them is one more contact of the box when it penetrates and is deeper than every corner by more than 0.1 mm (a slab lying on a bump).
+ * Upstream counterpart: RaiSim's ODE capsule / box x height-field colliders [RECALL; absent from /root/reference]. */
 int rsb_set_capsule_contacts(rsb_world* w, int on);
 /* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
  * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */

@@ -79,7 +79,10 @@ typedef struct rsb_model_blob {
   /* capsules and cylinders: col_capsule[s] = e + 1 makes primitives s and e the two ENDS of one capsule (two spheres of one radius) or of
    * one cylinder (two rim primitives of one rim radius) - same body; set on the first of the two, 0 everywhere else.  On a plane the two
    * ends are the exact contact set; against a height map the barrel between them can touch where neither end does (a shank lying
-   * across a ridge): rsb_set_capsule_contacts. */
+   * across a ridge): rsb_set_capsule_contacts.
+   * boxes: col_capsule[s] = -1 makes primitives s .. s + 7 the eight CORNERS of one box (corner s + e: bit 0 of e = +x, bit 1 = +y, bit 2 = +z
+   * in the box's frame; same body, radius 0).  On a plane the corners are the exact contact set; against a height map a face can touch
+   * where no corner does (a slab lying on a bump): the same switch adds the deepest point of the box's faces. */
   int32_t col_capsule[RSB_MAX_COLLISIONS];
 } rsb_model_blob;
 
@@ -95,7 +98,7 @@ typedef struct rsb_contact {
                           sit next to each other, same position and depth, opposite normals and impulses */
 } rsb_contact;
 #define RSB_CONTACT_SECOND 0x40000   /* a primitive's second contact with a height map (rsb_set_heightmap_contacts) */
-#define RSB_CONTACT_CAPSULE 0x80000  /* contact of a capsule's cylinder, between its end spheres, with a height map; the id is the FIRST end sphere's (rsb_set_capsule_contacts) */
+#define RSB_CONTACT_CAPSULE 0x80000  /* contact of the barrel of a capsule / cylinder (between its two ends) or of a face of a box (between its corners) with a height map; the id is the FIRST end's / corner's (rsb_set_capsule_contacts) */
 #define RSB_CONTACT_SELF_A 0x10000
 #define RSB_CONTACT_SELF_B 0x20000
 #define RSB_CONTACT_PRIMITIVE(c) ((c) & 0xffff)

@@ -685,6 +685,134 @@ static int capsule_contact(const orc_params* p, const double* a, const double* b
   return 1;
 }
 
+/* Box x height map (orc_params::hm_capsule as well).  A box is stored as its eight corners (exact on a plane).  Against a height map a FACE or an
+ * EDGE can touch where no corner does (a slab lying on a bump, a beam across a ridge).  The surface is piecewise linear and the box convex, so the
+ * vertical penetration h(x, y) - z_box(x, y) of the box's lower surface takes its maximum at one of finitely many candidates:
+ *   (corners)   the eight corner primitives themselves;
+ *   (A)         a terrain VERTEX under the box: the vertical line through it enters the box at z_lo = the largest of the three slab entries
+ *               (box = intersection of three slabs |(p - centre) . a_k| <= l_k), through the face of that slab;  normal = that face's inward normal;
+ *   (B)         a CROSSING (in plan view) of one of the twelve box edges with a terrain edge - the grid lines x = const, y = const and the cells'
+ *               diagonals;  normal = box edge x terrain edge, pointing up.
+ * Depth of a candidate = vertical penetration x n_z.  All candidates within ORC_BOX_TIE of the deepest form the contact patch (a face lying flat on a
+ * plateau: every plateau vertex); the ONE contact reported is their mean position and mean normal, when that deepest candidate penetrates and is
+ * deeper than every corner by more than ORC_CAPSULE_MARGIN.  Two passes over the candidates (the maximum, then the patch): the result does not
+ * depend on the order of enumeration (device: lane = candidate). */
+#define ORC_BOX_TIE 1e-5
+#define ORC_BOX_SPAN 32            /* terrain vertices examined per axis under one box, crossings per edge and family: beyond, the contact-overflow flag */
+typedef struct { double dmax; double sum[7]; int pass; } box_acc;
+static void box_candidate(box_acc* A, double d, const double* pos, const double* n) {
+  if (A->pass == 0) { if (d > A->dmax) A->dmax = d; return; }
+  if (d >= A->dmax - ORC_BOX_TIE) { A->sum[0] += 1.0; for (int a = 0; a < 3; ++a) { A->sum[1 + a] += pos[a]; A->sum[4 + a] += n[a]; } }
+}
+static int box_face_contact(const orc_params* p, const double cw[8][3], double dep_corners, double* c_out, double* depth, double* n_out, int* overflow) {
+  if (p->terrain_type != 1) return 0;
+  const int xs = p->hm_xs, ys = p->hm_ys;
+  const double dx = p->hm_xsize / (xs - 1), dy = p->hm_ysize / (ys - 1), x0 = p->hm_cx - 0.5 * p->hm_xsize, y0 = p->hm_cy - 0.5 * p->hm_ysize;
+  double ctr[3], e[3][3], ax[3][3], len[3];
+  for (int a = 0; a < 3; ++a) {
+    ctr[a] = 0.5 * (cw[0][a] + cw[7][a]);
+    e[0][a] = 0.5 * (cw[1][a] - cw[0][a]); e[1][a] = 0.5 * (cw[2][a] - cw[0][a]); e[2][a] = 0.5 * (cw[4][a] - cw[0][a]);
+  }
+  for (int k = 0; k < 3; ++k) {
+    len[k] = sqrt(dot3(e[k], e[k]));
+    if (!(len[k] > 0.0)) return 0;
+    for (int a = 0; a < 3; ++a) ax[k][a] = e[k][a] / len[k];
+  }
+  const double X = fabs(e[0][0]) + fabs(e[1][0]) + fabs(e[2][0]), Y = fabs(e[0][1]) + fabs(e[1][1]) + fabs(e[2][1]);
+  int ix_lo = (int)ceil((ctr[0] - X - x0) / dx), ix_hi = (int)floor((ctr[0] + X - x0) / dx);
+  int iy_lo = (int)ceil((ctr[1] - Y - y0) / dy), iy_hi = (int)floor((ctr[1] + Y - y0) / dy);
+  if (ix_lo < 0) ix_lo = 0;
+  if (iy_lo < 0) iy_lo = 0;
+  if (ix_hi > xs - 1) ix_hi = xs - 1;
+  if (iy_hi > ys - 1) iy_hi = ys - 1;
+  if (ix_hi - ix_lo + 1 > ORC_BOX_SPAN) { ix_hi = ix_lo + ORC_BOX_SPAN - 1; *overflow = 1; }
+  if (iy_hi - iy_lo + 1 > ORC_BOX_SPAN) { iy_hi = iy_lo + ORC_BOX_SPAN - 1; *overflow = 1; }
+  box_acc A;
+  A.dmax = -1e300;
+  for (int a = 0; a < 7; ++a) A.sum[a] = 0.0;
+  for (A.pass = 0; A.pass < 2; ++A.pass) {
+    /* (A) terrain vertices */
+    for (int iy = iy_lo; iy <= iy_hi; ++iy)
+      for (int ix = ix_lo; ix <= ix_hi; ++ix) {
+        const double x = x0 + ix * dx, y = y0 + iy * dy, h = p->hm_heights[iy * xs + ix];
+        const double rx = x - ctr[0], ry = y - ctr[1];
+        double zlo = -1e300, zup = 1e300, nz = 1.0;
+        int face = 0, inside = 1;
+        for (int k = 0; k < 3; ++k) {
+          const double rho = rx * ax[k][0] + ry * ax[k][1], az = ax[k][2];
+          if (fabs(az) < 1e-6) { if (fabs(rho) > len[k]) inside = 0; continue; }
+          const double za = ctr[2] + (-len[k] - rho) / az, zb = ctr[2] + (len[k] - rho) / az;
+          const double lo = za < zb ? za : zb, hi = za < zb ? zb : za;
+          if (lo > zlo) { zlo = lo; face = k; nz = fabs(az); }
+          if (hi < zup) zup = hi;
+        }
+        if (!inside || !(zlo <= zup) || zlo < -1e299) continue;
+        const double sg = ax[face][2] > 0.0 ? 1.0 : -1.0;
+        const double pos[3] = {x, y, zlo}, nn[3] = {sg * ax[face][0], sg * ax[face][1], sg * ax[face][2]};
+        box_candidate(&A, (h - zlo) * nz, pos, nn);
+      }
+    /* (B) box edges x terrain edges */
+    for (int k = 0; k < 3; ++k)
+      for (int sb = 0; sb < 2; ++sb)
+        for (int sc = 0; sc < 2; ++sc) {
+          const int kb = (k + 1) % 3, kc = (k + 2) % 3;
+          double p0[3], dir[3];
+          for (int a = 0; a < 3; ++a) { p0[a] = ctr[a] - e[k][a] + (sb ? 1.0 : -1.0) * e[kb][a] + (sc ? 1.0 : -1.0) * e[kc][a]; dir[a] = 2.0 * e[k][a]; }
+          const double gx0 = (p0[0] - x0) / dx, gy0 = (p0[1] - y0) / dy, dgx = dir[0] / dx, dgy = dir[1] / dy;
+          for (int fam = 0; fam < 3; ++fam) {
+            const double g0 = fam == 0 ? gx0 : (fam == 1 ? gy0 : gx0 - gy0), dg = fam == 0 ? dgx : (fam == 1 ? dgy : dgx - dgy);
+            if (dg == 0.0) continue;
+            const double g1 = g0 + dg;
+            int lo = (int)ceil(g0 < g1 ? g0 : g1), hi = (int)floor(g0 < g1 ? g1 : g0);
+            const int lim_lo = fam == 2 ? -(ys - 2) : 0, lim_hi = fam == 0 ? xs - 1 : (fam == 1 ? ys - 1 : xs - 2);
+            if (lo < lim_lo) lo = lim_lo;
+            if (hi > lim_hi) hi = lim_hi;
+            if (hi - lo + 1 > ORC_BOX_SPAN) { hi = lo + ORC_BOX_SPAN - 1; *overflow = 1; }
+            for (int i = lo; i <= hi; ++i) {
+              double t = ((double)i - g0) / dg;
+              t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+              const double pt[3] = {p0[0] + t * dir[0], p0[1] + t * dir[1], p0[2] + t * dir[2]};
+              const double gx = (pt[0] - x0) / dx, gy = (pt[1] - y0) / dy;
+              double hA, hB, f, T[3];
+              if (fam == 0) {          /* grid line x = x0 + i dx: the terrain edge runs along y */
+                if (gy < 0.0 || gy > ys - 1) continue;
+                int j = (int)floor(gy); if (j > ys - 2) j = ys - 2;
+                f = gy - j; hA = p->hm_heights[j * xs + i]; hB = p->hm_heights[(j + 1) * xs + i];
+                T[0] = 0.0; T[1] = dy; T[2] = hB - hA;
+              } else if (fam == 1) {   /* grid line y = y0 + i dy: along x */
+                if (gx < 0.0 || gx > xs - 1) continue;
+                int j = (int)floor(gx); if (j > xs - 2) j = xs - 2;
+                f = gx - j; hA = p->hm_heights[i * xs + j]; hB = p->hm_heights[i * xs + j + 1];
+                T[0] = dx; T[1] = 0.0; T[2] = hB - hA;
+              } else {                 /* diagonal gx - gy = i: from vertex (jx, jx - i) to (jx + 1, jx - i + 1) */
+                int jx = (int)floor(gx);
+                if (jx > xs - 2) jx = xs - 2;
+                if (jx < 0) jx = 0;
+                const int jy = jx - i;
+                f = gx - jx;
+                if (jy < 0 || jy > ys - 2 || f < 0.0 || f > 1.0) continue;
+                hA = p->hm_heights[jy * xs + jx]; hB = p->hm_heights[(jy + 1) * xs + jx + 1];
+                T[0] = dx; T[1] = dy; T[2] = hB - hA;
+              }
+              const double h = hA + f * (hB - hA);
+              double nn[3];
+              cross3(dir, T, nn);
+              const double n2 = dot3(nn, nn);
+              if (!(n2 > 1e-12 * dot3(dir, dir) * dot3(T, T))) continue;    /* parallel edges: no crossing */
+              const double inv = (nn[2] < 0.0 ? -1.0 : 1.0) / sqrt(n2);
+              for (int a = 0; a < 3; ++a) nn[a] *= inv;
+              box_candidate(&A, (h - pt[2]) * nn[2], pt, nn);
+            }
+          }
+        }
+  }
+  if (!(A.sum[0] > 0.0 && A.dmax > 0.0 && A.dmax > dep_corners + ORC_CAPSULE_MARGIN)) return 0;
+  const double nl = sqrt(A.sum[4] * A.sum[4] + A.sum[5] * A.sum[5] + A.sum[6] * A.sum[6]);
+  for (int a = 0; a < 3; ++a) { c_out[a] = A.sum[1 + a] / A.sum[0]; n_out[a] = nl > 1e-9 ? A.sum[4 + a] / nl : (a == 2 ? 1.0 : 0.0); }
+  *depth = A.dmax;
+  return 1;
+}
+
 /* --------------------------------------------------------------------------- actuation */
 /* PD controller, integrated implicitly ("stable PD", Tan, Liu, Turk 2011; RaiSim's controller is of this kind [RECALL]):
  * the torque the joint feels over the step is  kp (q* - q+) + kd (u* - u+)  with  q+ = q + dt u+.  Written for
@@ -1052,6 +1180,20 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   if (p->hm_capsule && p->terrain_type == 1) {
     for (int s = 0; s < m->ncol; ++s) {
       if (m->col_capsule[s] == 0) continue;
+      if (m->col_capsule[s] == -1) {       /* a box: the deepest point of its faces */
+        double cwb[8][3], cc[3], n[3], depth, dep_c = 0.0;
+        for (int e = 0; e < 8; ++e) { for (int a = 0; a < 3; ++a) cwb[e][a] = k->pbase[a] + cap_c[s + e][a]; if (first_depth[s + e] > dep_c) dep_c = first_depth[s + e]; }
+        int over = 0;
+        const int got = box_face_contact(p, cwb, dep_c, cc, &depth, n, &over);
+        if (over) fl |= 1;
+        if (!got) continue;
+        if (nc >= kmax) { fl |= 1; continue; }
+        for (int a = 0; a < 3; ++a) { cx[nc][a] = cc[a] - k->pbase[a]; cn[nc][a] = n[a]; }
+        cdepth[nc] = depth; cbody[nc] = m->col_body[s]; ccol[nc] = s; csecond[nc] = 2;
+        contact_frame(n, Rc[nc]);
+        ++nc;
+        continue;
+      }
       const int e = m->col_capsule[s] - 1;
       double aw[3], bw[3], cc[3], n[3], depth;
       for (int a = 0; a < 3; ++a) { aw[a] = k->pbase[a] + cap_c[s][a]; bw[a] = k->pbase[a] + cap_c[e][a]; }

@@ -88,7 +88,7 @@ struct rsb_world {
   int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
   int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
   int hm_contacts = 1; double hm_second_cos = 0.70710678118654752;                                        // rsb_set_heightmap_contacts
-  bool hm_capsule = false; int32_t* d_cap = nullptr; int n_cap = 0;                                       // rsb_set_capsule_contacts: [n_cap][2] end primitives of the model's capsules / cylinders
+  bool hm_capsule = false; int32_t* d_cap = nullptr; int n_cap = 0;                                       // rsb_set_capsule_contacts: [n_cap][2] end primitives of the model's capsules / cylinders, (first corner, -1) of its boxes
   double integ_theta = 1.0;                                                                // rsb_set_integration_scheme
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
@@ -844,7 +844,7 @@ int rsb_set_capsule_contacts(rsb_world* w, int on) {
   if (on && !w->d_cap) {      // the end pairs of the model's capsules and cylinders (rsb_model_blob::col_capsule), once
     std::vector<int32_t> pairs;
     for (int s = 0; s < w->blob.ncol; ++s)
-      if (w->blob.col_capsule[s] != 0) { pairs.push_back(s); pairs.push_back(w->blob.col_capsule[s] - 1); }
+      if (w->blob.col_capsule[s] != 0) { pairs.push_back(s); pairs.push_back(w->blob.col_capsule[s] < 0 ? -1 : w->blob.col_capsule[s] - 1); }   // (s, -1): a box headed by corner s
     w->n_cap = (int)pairs.size() / 2;
     if (w->n_cap > 0) {
       HIP_TRY(hipSetDevice(w->device));

@@ -1075,6 +1075,148 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
           float* CAPR = G + (kHmRec + 8) * hm_slots + RSB_MAX_COLLISIONS;    // [4][4] depth, normal of the round's four samples
           for (int cp = 0; cp < ac.hm_capsule; ++cp) {
             const int ci = ac.hm_cap[2 * cp], ce = ac.hm_cap[2 * cp + 1];     // the two ends (the model's data: uniform over the wave)
+            if (ce < 0) {
+              // ---- a box (ci .. ci + 7 are its corners; oracle: box_face_contact): the candidates for the deepest point besides the corners are
+              // (A) the terrain vertices under the box and (B) the plan-view crossings of its twelve edges with the terrain's edges; two passes
+              // (the maximum, then the mean of the candidates within kBoxTie of it), lanes 0 .. 15 of the env = candidates, DPP row reductions
+              float ctr[3], e[3][3], axs[3][3], len[3];
+              const int cbody = __float_as_int(COLT[kColSlot * ci + 4]);
+              {
+                float P[12], c0[4], ck[4], t0[3], tk[3];
+                ldv<3>(BODY + cbody * kBodySlot, P);
+                ld4(COLT + kColSlot * ci, c0);
+                mat3_vec(P, c0, t0);
+                RSB_UNROLL for (int a = 0; a < 3; ++a) {
+                  ld4(COLT + kColSlot * (ci + (1 << a)), ck);
+                  mat3_vec(P, ck, tk);
+                  RSB_UNROLL for (int i = 0; i < 3; ++i) e[a][i] = 0.5f * (tk[i] - t0[i]);
+                  len[a] = sqrtf(dot3(e[a], e[a]));
+                  const float il = 1.0f / fmaxf(len[a], 1e-12f);
+                  RSB_UNROLL for (int i = 0; i < 3; ++i) axs[a][i] = e[a][i] * il;
+                }
+                ld4(COLT + kColSlot * (ci + 7), ck);
+                mat3_vec(P, ck, tk);
+                RSB_UNROLL for (int i = 0; i < 3; ++i) ctr[i] = P[9 + i] + 0.5f * (t0[i] + tk[i]);
+              }
+              ctr[0] += pbx; ctr[1] += pby; ctr[2] += pbz;             // world
+              const float low = ctr[2] - fabsf(e[0][2]) - fabsf(e[1][2]) - fabsf(e[2][2]);
+              const bool near = (low <= ac.hm_max) && !dead && s < 16;
+              if (!__any(near)) continue;
+              float dep_c = 0.f;
+              RSB_UNROLL for (int k2 = 0; k2 < 8; ++k2) { const int sl = SLOTOF[ci + k2]; dep_c = fmaxf(dep_c, sl > 0 ? RES[4 * (sl - 1)] : 0.f); }
+              const int xs = ac.hm_xs, ys = ac.hm_ys;
+              const float X = fabsf(e[0][0]) + fabsf(e[1][0]) + fabsf(e[2][0]), Y = fabsf(e[0][1]) + fabsf(e[1][1]) + fabsf(e[2][1]);
+              int ix_lo = max((int)ceilf((ctr[0] - X - ac.hm_x0) * ac.hm_inv_dx), 0), ix_hi = min((int)floorf((ctr[0] + X - ac.hm_x0) * ac.hm_inv_dx), xs - 1);
+              int iy_lo = max((int)ceilf((ctr[1] - Y - ac.hm_y0) * ac.hm_inv_dy), 0), iy_hi = min((int)floorf((ctr[1] + Y - ac.hm_y0) * ac.hm_inv_dy), ys - 1);
+              bool over = false;
+              if (ix_hi - ix_lo + 1 > kBoxSpan) { ix_hi = ix_lo + kBoxSpan - 1; over = true; }
+              if (iy_hi - iy_lo + 1 > kBoxSpan) { iy_hi = iy_lo + kBoxSpan - 1; over = true; }
+              const int ntx = env_groups_max<LPE>(near ? (ix_hi - ix_lo + 4) >> 2 : 0), nty = env_groups_max<LPE>(near ? (iy_hi - iy_lo + 4) >> 2 : 0);
+              const int si = s & 3, sj = (s >> 2) & 3;
+              // lane s < 12 owns box edge s: along axis k = s >> 2 from the corner with signs (sb, sc) on the two other axes
+              const int ek = s >> 2;
+              float p0[3], dir[3];
+              {
+                const float sb = (s & 1) ? 1.f : -1.f, sc = (s & 2) ? 1.f : -1.f;
+                RSB_UNROLL for (int i = 0; i < 3; ++i) {
+                  const float ea = ek == 0 ? e[0][i] : (ek == 1 ? e[1][i] : e[2][i]);
+                  const float eb = ek == 0 ? e[1][i] : (ek == 1 ? e[2][i] : e[0][i]);
+                  const float ec = ek == 0 ? e[2][i] : (ek == 1 ? e[0][i] : e[1][i]);
+                  p0[i] = ctr[i] - ea + sb * eb + sc * ec; dir[i] = 2.f * ea;
+                }
+              }
+              const float gx0 = (p0[0] - ac.hm_x0) * ac.hm_inv_dx, gy0 = (p0[1] - ac.hm_y0) * ac.hm_inv_dy, dgx = dir[0] * ac.hm_inv_dx, dgy = dir[1] * ac.hm_inv_dy;
+              float dmax = -3e38f, sum[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+              for (int pass = 0; pass < 2; ++pass) {
+                auto cand = [&](bool ok, float d, const float* pos, const float* nn) {
+                  if (pass == 0) { dmax = ok ? fmaxf(dmax, d) : dmax; return; }
+                  const float w = (ok && d >= dmax - kBoxTie) ? 1.f : 0.f;
+                  sum[0] += w;
+                  RSB_UNROLL for (int i = 0; i < 3; ++i) { sum[1 + i] += w * (pos[i] - ctr[i]); sum[4 + i] += w * nn[i]; }
+                };
+                // (A) terrain vertices, 4 x 4 per round
+                for (int ty = 0; ty < nty; ++ty)
+                  for (int tx = 0; tx < ntx; ++tx) {
+                    const int ix = ix_lo + 4 * tx + si, iy = iy_lo + 4 * ty + sj;
+                    bool ok = near && ix <= ix_hi && iy <= iy_hi;
+                    const float h = env_heights[min(iy, ys - 1) * xs + min(ix, xs - 1)];
+                    const float x = ac.hm_x0 + (float)ix * ac.hm_dx, y = ac.hm_y0 + (float)iy * ac.hm_dy;
+                    const float rx = x - ctr[0], ry = y - ctr[1];
+                    float zlo = -3e38f, zup = 3e38f, nf[3] = {0.f, 0.f, 1.f};
+                    RSB_UNROLL for (int k = 0; k < 3; ++k) {
+                      const float rho = rx * axs[k][0] + ry * axs[k][1], az = axs[k][2];
+                      const bool vert = fabsf(az) < 1e-6f;
+                      ok = ok && !(vert && fabsf(rho) > len[k]);
+                      const float iaz = 1.0f / (vert ? 1.f : az);
+                      const float za = ctr[2] + (-len[k] - rho) * iaz, zb = ctr[2] + (len[k] - rho) * iaz;
+                      const float lo = fminf(za, zb), hi = fmaxf(za, zb);
+                      const bool take = !vert && lo > zlo;
+                      const float sg = az > 0.f ? 1.f : -1.f;
+                      zlo = take ? lo : zlo;
+                      nf[0] = take ? sg * axs[k][0] : nf[0]; nf[1] = take ? sg * axs[k][1] : nf[1]; nf[2] = take ? sg * az : nf[2];
+                      zup = vert ? zup : fminf(zup, hi);
+                    }
+                    ok = ok && zlo <= zup && zlo > -1e37f;
+                    const float pos[3] = {x, y, zlo};
+                    cand(ok, (h - zlo) * nf[2], pos, nf);
+                  }
+                // (B) box edges x terrain edges: grid lines x = const (family 0), y = const (1), cell diagonals gx - gy = const (2)
+                for (int fam = 0; fam < 3; ++fam) {
+                  const float g0 = fam == 0 ? gx0 : (fam == 1 ? gy0 : gx0 - gy0), dg = fam == 0 ? dgx : (fam == 1 ? dgy : dgx - dgy);
+                  const float g1 = g0 + dg;
+                  int lo = max((int)ceilf(fminf(g0, g1)), fam == 2 ? -(ys - 2) : 0), hi = min((int)floorf(fmaxf(g0, g1)), fam == 0 ? xs - 1 : (fam == 1 ? ys - 1 : xs - 2));
+                  const bool edge = near && s < 12 && dg != 0.f;
+                  if (hi - lo + 1 > kBoxSpan) { hi = lo + kBoxSpan - 1; over = over || edge; }
+                  const int cnt = env_groups_max<LPE>(row_max_i32(edge ? hi - lo + 1 : 0));
+                  const float idg = 1.0f / (dg != 0.f ? dg : 1.f);
+                  for (int k = 0; k < cnt; ++k) {
+                    const int i = lo + k;
+                    bool ok = edge && i <= hi;
+                    const float t = fminf(fmaxf(((float)i - g0) * idg, 0.f), 1.f);
+                    const float pt[3] = {p0[0] + t * dir[0], p0[1] + t * dir[1], p0[2] + t * dir[2]};
+                    const float gx = (pt[0] - ac.hm_x0) * ac.hm_inv_dx, gy = (pt[1] - ac.hm_y0) * ac.hm_inv_dy;
+                    int ia, ib;          // offsets of the terrain edge's two vertices
+                    float f, T[3];
+                    if (fam == 0) {
+                      ok = ok && gy >= 0.f && gy <= (float)(ys - 1);
+                      const int j = min(max((int)floorf(gy), 0), ys - 2);
+                      f = gy - (float)j; ia = j * xs + min(max(i, 0), xs - 1); ib = ia + xs;
+                      T[0] = 0.f; T[1] = ac.hm_dy;
+                    } else if (fam == 1) {
+                      ok = ok && gx >= 0.f && gx <= (float)(xs - 1);
+                      const int j = min(max((int)floorf(gx), 0), xs - 2);
+                      f = gx - (float)j; ia = min(max(i, 0), ys - 1) * xs + j; ib = ia + 1;
+                      T[0] = ac.hm_dx; T[1] = 0.f;
+                    } else {
+                      const int jx = min(max((int)floorf(gx), 0), xs - 2), jy = jx - i;
+                      f = gx - (float)jx;
+                      ok = ok && jy >= 0 && jy <= ys - 2 && f >= 0.f && f <= 1.f;
+                      ia = min(max(jy, 0), ys - 2) * xs + jx; ib = ia + xs + 1;
+                      T[0] = ac.hm_dx; T[1] = ac.hm_dy;
+                    }
+                    const float hA = env_heights[ia], hB = env_heights[ib];
+                    T[2] = hB - hA;
+                    const float h = hA + f * T[2];
+                    float nn[3];
+                    cross3(dir, T, nn);
+                    const float n2 = dot3(nn, nn);
+                    ok = ok && n2 > 1e-12f * dot3(dir, dir) * dot3(T, T);
+                    const float inv = (nn[2] < 0.f ? -1.f : 1.f) * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-30f));
+                    RSB_UNROLL for (int q = 0; q < 3; ++q) nn[q] *= inv;
+                    cand(ok, (h - pt[2]) * nn[2], pt, nn);
+                  }
+                }
+                if (pass == 0) dmax = row_max_f32(dmax);
+              }
+              RSB_UNROLL for (int i = 0; i < 7; ++i) sum[i] = row_sum_f32(sum[i]);
+              flag |= row_max_i32((over && near) ? 1 : 0);      // (lane 0 of the env reports the flags)
+              const float icnt = 1.0f / fmaxf(sum[0], 1.f), nl2 = sum[4] * sum[4] + sum[5] * sum[5] + sum[6] * sum[6], inl = __builtin_amdgcn_rsqf(fmaxf(nl2, 1e-30f));
+              const float crel[3] = {ctr[0] + sum[1] * icnt - pbx, ctr[1] + sum[2] * icnt - pby, ctr[2] + sum[3] * icnt - pbz};
+              const float bn3[3] = {nl2 > 1e-18f ? sum[4] * inl : 0.f, nl2 > 1e-18f ? sum[5] * inl : 0.f, nl2 > 1e-18f ? sum[6] * inl : 1.f};
+              const bool hitb = near && sum[0] > 0.f && dmax > 0.f && dmax > dep_c + kCapsuleMargin && s == 0;
+              emit(hitb, ci, ci | kCapsule, cbody, crel, 0.f, bn3, dmax);
+              continue;
+            }
             float ca[3], cb[3];
             int cbody = 0;
             float rad = 0.f, tmin = 0.02f;

@@ -38,6 +38,8 @@ constexpr int kCapsule = 0x80000;     // ... of the contact of a capsule's cylin
 constexpr int kExtra = kSecond | kCapsule;   // contacts that belong to a primitive besides its first one (class-4 kernels): the primitive's material, a cold start
 constexpr float kCapsuleMargin = 1e-4f;   // == ORC_CAPSULE_MARGIN
 constexpr int kCapsuleRounds = 4;         // == ORC_CAPSULE_ROUNDS
+constexpr float kBoxTie = 1e-5f;          // == ORC_BOX_TIE
+constexpr int kBoxSpan = 32;              // == ORC_BOX_SPAN
 constexpr int kSelfA = 0x10000;       // collision id flags of the two entries of a self-collision (== RSB_CONTACT_SELF_A / _B, ORC_SELF_A / _B)
 constexpr int kSelfB = 0x20000;
 constexpr int kSelfBatch = 5;          // passes per batch of the self-collision sweep

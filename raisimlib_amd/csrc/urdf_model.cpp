@@ -473,6 +473,7 @@ struct Builder {
         blob.col_pos[s][0] = p.x; blob.col_pos[s][1] = p.y; blob.col_pos[s][2] = p.z;
         blob.col_radius[s] = c.type == 4 ? 0.0 : c.radius;
         if ((c.type == 1 || c.type == 4) && e == 0) blob.col_capsule[s] = s + 2;      // the capsule's / cylinder's other end is emitted next (rsb_model_blob::col_capsule)
+        if (c.type == 2 && e == 0) blob.col_capsule[s] = -1;                           // the first of a box's eight corners (emitted in bit order)
         if (c.type == 4) {   // end cap of a cylinder: the lowest point of its rim (see rsb_model_blob::col_rim)
           V3 ax = mul(bc.R, V3{0, 0, 1});
           blob.col_axis[s][0] = ax.x; blob.col_axis[s][1] = ax.y; blob.col_axis[s][2] = ax.z;
@@ -690,7 +691,11 @@ int validate_blob(const rsb_model_blob& b) {
       if (!(std::fabs(n2 - 1.0) < 1e-6)) { set_error("model: col_axis of a rim primitive must be a unit vector"); return RSB_E_INVALID; }
     }
     if (!std::memchr(b.col_material[s], 0, RSB_NAME_LEN)) { set_error("model: col_material is not NUL-terminated"); return RSB_E_INVALID; }
-    if (b.col_capsule[s] != 0) {
+    if (b.col_capsule[s] == -1) {
+      bool ok = s + 8 <= b.ncol;
+      for (int e = 1; ok && e < 8; ++e) ok = b.col_body[s + e] == b.col_body[s] && b.col_capsule[s + e] == 0 && b.col_rim[s + e] == 0;
+      if (!ok || b.col_rim[s] > 0) { set_error("model: col_capsule = -1 must head eight consecutive point primitives of one body (a box's corners)"); return RSB_E_INVALID; }
+    } else if (b.col_capsule[s] != 0) {
       const int e = b.col_capsule[s] - 1;
       if (e < 0 || e >= b.ncol || e == s || b.col_body[e] != b.col_body[s] || b.col_radius[e] != b.col_radius[s] || b.col_rim[e] != b.col_rim[s] || b.col_capsule[e] != 0) {
         set_error("model: col_capsule must pair two sphere primitives (a capsule's ends) or two rim primitives (a cylinder's caps) of one body and one radius (set on the first only)"); return RSB_E_INVALID;

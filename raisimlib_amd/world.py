@@ -233,7 +233,8 @@ class BatchedWorld:
         check(self.L.rsb_set_heightmap_contacts(self.handle, int(per_primitive), float(min_angle_deg)), "rsb_set_heightmap_contacts")
 
     def set_capsule_contacts(self, on=True):
-        """Exact capsule x height map: the cylinder between a capsule's end spheres reports its deepest point (rsb_set_capsule_contacts)."""
+        """Exact capsule / cylinder / box x height map: the barrel between a capsule's or cylinder's ends and the faces and edges between a box's corners
+        report their deepest point (rsb_set_capsule_contacts)."""
         check(self.L.rsb_set_capsule_contacts(self.handle, int(bool(on))), "rsb_set_capsule_contacts")
 
     def set_solver_anderson(self, first_sweep=2, clip=20.0):

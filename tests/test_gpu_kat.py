@@ -429,6 +429,55 @@ def test_capsule_lying_across_a_ridge_rests_on_its_cylinder(built_lib):
     assert (u[off, 4] * gc[off, 0] > 0).all()
 
 
+@pytest.mark.parametrize("case", ["slab on a plateau", "slab on a peak", "beam edge across a ridge"])
+def test_box_rests_on_a_face_or_an_edge_between_its_corners(built_lib, case):
+    """rsb_set_capsule_contacts for BOXES through the C-ABI (the oracle KAT of the same name): a slab lying on a plateau / on one raised
+    terrain vertex, a beam balanced on a long edge across a ridge - ONE contact flagged RSB_CONTACT_CAPSULE on the first corner's id, at
+    the plateau's centroid / AT the vertex / at the crossing of the two edges, normal up, exact depth; a different offset of the box in
+    every env; with the option off the eight corners hang in the air and the box falls."""
+    from test_oracle_kat import SLAB_URDF, BEAM_URDF, _bump_map, _peak_map, _ridge_map
+    from raisimlib_amd._capi import RSB_CONTACT_CAPSULE
+    rng = np.random.default_rng(5)
+    if case == "slab on a plateau":
+        urdf, hm, half = SLAB_URDF, _bump_map(), 0.05
+        gc = tile([0.0, 0.0, 0.2 + half - 1e-3, 1, 0, 0, 0.0]); gc[:, :2] = rng.uniform(-0.1, 0.1, (N, 2)); gc[0, :2] = 0.0
+        where, top = (0.0, 0.0), 0.2
+    elif case == "slab on a peak":
+        urdf, hm, half = SLAB_URDF, _peak_map(), 0.05
+        gc = tile([0.0, 0.0, 0.2 + half - 1e-3, 1, 0, 0, 0.0]); gc[:, :2] = rng.uniform(-0.25, 0.25, (N, 2))
+        where, top = (0.0, 0.0), 0.2
+    else:
+        urdf, hm, half = BEAM_URDF, _ridge_map(), 0.03 * np.sqrt(2.0)
+        a = np.pi / 4
+        gc = tile([0.0, 0.33, 0.3 + half - 1e-3, np.cos(a / 2), np.sin(a / 2), 0, 0.0]); gc[:, 0] = np.linspace(-0.25, 0.25, N)
+        where, top = (0.0, 0.33), 0.3
+    res = {}
+    for on in (False, True):
+        m, w = world(urdf)
+        w.add_height_map(65, 65, 3.2, 3.2, 0.0, 0.0, hm)
+        w.set_capsule_contacts(on)
+        w.set_state(gc, tile(np.zeros(6)))
+        w.integrate(1)
+        res[on] = (w.get_state(), w.get_contacts(), w.get_flags())
+        w.close()
+    (_, u0), (cnt0, _), _ = res[False]
+    assert (cnt0 == 0).all() and np.abs(u0[:, 2] + G * DT).max() < 1e-6
+    (q, u), (cnt, con), flags = res[True]
+    assert (flags == 0).all() and (cnt == 1).all() and (con[:, 0]["collision"] == RSB_CONTACT_CAPSULE).all() and (con[:, 0]["body"] == 0).all()
+    pos, nrm, dep = con[:, 0]["position"], con[:, 0]["normal"], con[:, 0]["depth"]
+    assert np.abs(pos[:, 0] - where[0]).max() < 2e-6 and np.abs(pos[:, 1] - where[1]).max() < 2e-6 and np.abs(pos[:, 2] - (top - 1e-3)).max() < 2e-6
+    assert np.abs(nrm[:, 2] - 1.0).max() < 1e-6 and np.abs(dep - 1e-3).max() < 2e-6          # exact up to fp32 coordinates
+    # the contact point stops; the oracle's step for a few envs
+    rc = pos - gc[:, :3]
+    assert np.abs((u[:, :3] + np.cross(u[:, 3:], rc))[:, 2]).max() < 2e-5
+    o = Oracle(m.blob); o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, hm); o.p.hm_capsule = 1
+    for e in (0, N // 3, N - 1):
+        qo, uo, co, _, _ = o.step(gc[e].astype(np.float32).astype(np.float64), np.zeros(6))
+        assert len(co) == 1 and np.abs(co["position"][0] - pos[e]).max() < 2e-6 and np.abs(uo - u[e]).max() < 2e-5
+    if case == "slab on a plateau":
+        assert abs(con[0, 0]["impulse"][2] - 6.0 * G * DT) < 1e-3 * 6.0 * G * DT and np.abs(u[0]).max() < 1e-5     # centred: carried, at rest
+
+
 @pytest.mark.parametrize("scheme,theta", [("semi_implicit", 1.0), ("euler", 0.0), ("trapezoid", 0.5)])
 def test_integration_schemes(anymal, scheme, theta):
     """rsb_set_integration_scheme through the C-ABI: the free-fall closed forms of the oracle KAT, one-step parity of the quadruped on

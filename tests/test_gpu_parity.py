@@ -677,9 +677,11 @@ def test_capsule_cylinder_contacts_on_a_rough_map_parity(built_lib):
     H = workload.smoothed_heightmap(64, 64, amplitude=0.25, seed=9)
     hm = (64, 64, 3.2, 3.2, 0.0, 0.0, H)
     rng = np.random.default_rng(4)
-    for name, model in (("capsule", Model(urdf_string=LOG_URDF)), ("quadruped", Model(urdf_path=__import__("raisimlib_amd").rsc_path("anymal_c_like.urdf")))):
+    from test_oracle_kat import SLAB_URDF, BEAM_URDF
+    for name, model in (("capsule", Model(urdf_string=LOG_URDF)), ("slab", Model(urdf_string=SLAB_URDF)), ("beam", Model(urdf_string=BEAM_URDF)),
+                        ("quadruped", Model(urdf_path=__import__("raisimlib_amd").rsc_path("anymal_c_like.urdf")))):
         N = 512
-        if name == "capsule":
+        if name in ("capsule", "slab", "beam"):
             gc = np.zeros((N, 7)); gv = rng.normal(size=(N, 6)) * 0.3
             gc[:, :2] = rng.uniform(-1.0, 1.0, (N, 2))
             ang = rng.uniform(-np.pi, np.pi, N); tilt = rng.uniform(-0.25, 0.25, N)
@@ -687,6 +689,11 @@ def test_capsule_cylinder_contacts_on_a_rough_map_parity(built_lib):
             cz, sz, cy, sy = np.cos(ang / 2), np.sin(ang / 2), np.cos(tilt / 2), np.sin(tilt / 2)
             gc[:, 3], gc[:, 4], gc[:, 5], gc[:, 6] = cz * cy, -sz * sy, cz * sy, sz * cy
             o0 = Oracle(model.blob); o0.set_heightmap(*hm)
+            if name == "beam":      # rolled about its long axis as well (edges down): Rz(ang) Ry(tilt) Rx(roll)
+                roll = rng.uniform(-np.pi, np.pi, N)
+                qa = np.stack([gc[:, 3], gc[:, 4], gc[:, 5], gc[:, 6]], axis=1); cr, sr = np.cos(roll / 2), np.sin(roll / 2)
+                gc[:, 3] = qa[:, 0] * cr - qa[:, 1] * sr; gc[:, 4] = qa[:, 0] * sr + qa[:, 1] * cr
+                gc[:, 5] = qa[:, 2] * cr + qa[:, 3] * sr; gc[:, 6] = qa[:, 3] * cr - qa[:, 2] * sr
             gc[:, 2] = [o0.terrain(x, y)[0] for x, y in gc[:, :2]] + rng.uniform(0.0, 0.12, N)
             kp = kd = np.zeros(6)
         else:
@@ -707,7 +714,7 @@ def test_capsule_cylinder_contacts_on_a_rough_map_parity(built_lib):
         valid = np.arange(ref["contacts"].shape[1])[None, :] < ref["n_contacts"][:, None]
         cyl = valid & ((ref["contacts"]["collision"] & 0x80000) != 0)
         print(f"{name}: {int(ref['n_contacts'].sum())} contacts, {int(cyl.sum())} on capsule cylinders in {int(cyl.any(axis=1).sum())} envs")
-        assert cyl.sum() > (60 if name == "capsule" else 5)                # the option matters on this map
+        assert cyl.sum() > (5 if name == "quadruped" else 60)                # the option matters on this map
         same = dev["cnt"] == ref["n_contacts"]
         for e in np.nonzero(same)[0]:
             same[e] = np.array_equal(dev["con"][e][:cnt[e]]["collision"], ref["contacts"][e][:cnt[e]]["collision"])

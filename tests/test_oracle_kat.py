@@ -634,6 +634,86 @@ def test_capsule_lying_across_a_ridge_rests_on_its_cylinder(built_lib, shift):
     assert np.array_equal(res[("flat", 0)][0], res[("flat", 1)][0]) and np.array_equal(res[("flat", 0)][1], res[("flat", 1)][1])
 
 
+BEAM_URDF = """<robot name="beam"><link name="beam">
+ <inertial><mass value="3"/><inertia ixx="0.01" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.1"/></inertial>
+ <collision><geometry><box size="0.6 0.06 0.06"/></geometry></collision>
+</link></robot>"""
+
+
+def _peak_map(n=65, height=0.2):
+    h = np.zeros((n, n), np.float32)
+    h[n // 2, n // 2] = height                    # ONE raised vertex: a pyramid one cell (0.05 m) wide, flanks of slope 4
+    return h
+
+
+@pytest.mark.parametrize("case", ["slab on a plateau", "slab on a plateau, off centre", "slab on a peak", "beam edge across a ridge"])
+def test_box_rests_on_a_face_or_an_edge_between_its_corners(built_lib, case):
+    """Exact box x height map (the same switch as the capsules': orc_params::hm_capsule / rsb_set_capsule_contacts).  The eight corners are
+    the exact contact set of a box on a PLANE; on a height map the deepest point can be where a terrain vertex meets a face or where a box
+    edge crosses a terrain edge.  Closed forms: (1) a slab lying flat on a plateau is carried by ONE contact at the centroid of the plateau
+    vertices under it (all equally deep), normal = the face's, impulse = its weight when the centroid is under the centre of mass, a
+    tipping torque otherwise; (2) on a single raised vertex (flanks of slope 4: a point sample 1 mm away from it would miss it) the contact is
+    AT the vertex with the exact depth; (3) a beam balanced on one of its long edges across a ridge touches where its edge crosses the
+    ridge line, normal = edge x ridge = up.  Without the option all three fall through; on flat ground the option adds nothing."""
+    from raisimlib_amd import Model
+    dt = 0.0025
+    if case.startswith("slab on a plateau"):
+        urdf, hm, mass = SLAB_URDF, _bump_map(), 6.0
+        xy = (0.0, 0.0) if case == "slab on a plateau" else (0.02, -0.03)
+        q0 = np.array([xy[0], xy[1], 0.2 + 0.05 - 1e-3, 1, 0, 0, 0.0])
+        where, top = (0.0, 0.0), float(np.float32(0.2))
+    elif case == "slab on a peak":
+        urdf, hm, mass = SLAB_URDF, _peak_map(), 6.0
+        q0 = np.array([0.11, -0.07, 0.2 + 0.05 - 1e-3, 1, 0, 0, 0.0])
+        where, top = (0.0, 0.0), float(np.float32(0.2))
+    else:
+        urdf, hm, mass = BEAM_URDF, _ridge_map(), 3.0
+        a = np.pi / 4                                # rolled 45 deg about its long axis (x): one long edge down, at 0.03 sqrt(2) under the axis
+        q0 = np.array([0.07, 0.33, 0.3 + 0.03 * np.sqrt(2.0) - 1e-3, np.cos(a / 2), np.sin(a / 2), 0, 0.0])
+        where, top = (0.0, 0.33), float(np.float32(0.3))
+    m = Model(urdf_string=urdf)
+    assert m.ncol == 8 and list(m.blob.col_capsule[:8]) == [-1, 0, 0, 0, 0, 0, 0, 0]       # the loader marks the first corner of the box
+    res = {}
+    for on in (0, 1):
+        o = Oracle(m.blob)
+        o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, hm)
+        o.p.hm_capsule = on
+        res[on] = o.step(q0.copy(), np.zeros(6))
+    _, u0, con0, _, _ = res[0]
+    q1, u1, con1, _, fl = res[1]
+    assert len(con0) == 0 and abs(u0[2] + 9.81 * dt) < 1e-9                # eight corners in the air: free fall
+    assert fl == 0 and len(con1) == 1 and con1["collision"][0] == (0 | 0x80000) and con1["body"][0] == 0
+    pos, nrm, dep = con1["position"][0], con1["normal"][0], con1["depth"][0]
+    assert abs(pos[0] - where[0]) < 1e-9 and abs(pos[1] - where[1]) < 1e-9 and abs(pos[2] - (q0[2] - (0.05 if urdf is SLAB_URDF else 0.03 * np.sqrt(2.0)))) < 1e-9      # exact: a vertex / a crossing, not a sample
+    assert abs(nrm[2] - 1.0) < 1e-12 and abs(dep - (top - pos[2])) < 1e-12 and abs(dep - 1e-3) < 2e-8
+    centred = case == "slab on a plateau"
+    if centred:
+        assert abs(con1["impulse"][0, 2] - mass * 9.81 * dt) < 1e-9 and np.abs(u1).max() < 1e-9           # carried, at rest
+    else:
+        assert 0 < con1["impulse"][0, 2] < mass * 9.81 * dt          # carried at the contact point, tipping about it towards the heavy side
+        r = pos[:2] - q0[:2]
+        tip = np.array([-r[1], r[0]]) * -1.0                           # gravity's torque about the contact: (r_com - r_c) x (-m g z) ~ (-(dy), +(dx)) with d = com - contact
+        assert np.dot(u1[3:5], tip) > 0
+        # the contact point itself stops: v + w x r = 0 along the normal
+        rc = np.array([pos[0] - q0[0], pos[1] - q0[1], pos[2] - q0[2]])
+        assert abs((u1[:3] + np.cross(u1[3:], rc))[2]) < 1e-7
+    # flat ground, lying flat and tilted onto a corner: the corners hold the box, nothing is added
+    for quat in ([1, 0, 0, 0.0], [np.cos(0.2), np.sin(0.2) * 0.6, np.sin(0.2) * 0.8, 0.0]):
+        outs = []
+        for on in (0, 1):
+            o = Oracle(m.blob)
+            o.set_heightmap(65, 65, 3.2, 3.2, 0.0, 0.0, np.zeros((65, 65), np.float32))
+            o.p.hm_capsule = on
+            w_, x_, y_, z_ = quat                      # third row of the rotation matrix: the corners' heights
+            row = np.array([2 * (x_ * z_ - w_ * y_), 2 * (y_ * z_ + w_ * x_), 1 - 2 * (x_ * x_ + y_ * y_)])
+            half = np.array([0.3, 0.3, 0.05]) if urdf is SLAB_URDF else np.array([0.3, 0.03, 0.03])
+            zc = float(np.abs(row) @ half)
+            q, u, con, _, _ = o.step(np.array([0.8, 0.4, zc - 5e-4] + list(quat)), np.zeros(6))
+            assert len(con) >= 1 and not (con["collision"] & 0x80000).any()
+            outs.append((q, u))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def valley_map(n=33, size=12.8, slope=0.5):
     """a V-shaped valley along y at x = 0, flanks of the given slope; cells of size / (n - 1) = 0.4 m"""
     xs = np.linspace(-size / 2, size / 2, n)
