@@ -127,6 +127,71 @@ def test_per_env_parity_on_the_benchmark_population_at_4096(anymal):
             assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all() and eu.max() < 1.0
 
 
+@pytest.mark.parametrize("config", [3, 5])
+def test_per_env_parity_on_the_height_map_and_humanoid_populations_at_4096(built_lib, config):
+    """The same per-env comparison at BASELINE.json's full size for configs[2] (4096 quadrupeds on the benchmark's height map) and configs[4]
+    (4096 humanoids, STANDING regime): the device runs bench.Recipe for 60 control steps, then ONE integrate() from that state (cold solver
+    on both sides) on the device and in the oracle, world and oracle set up by the recipe (solver policy of the configuration included).
+    Config 3: a closest-feature tie on a terrain edge may rank differently in fp32 for a handful of envs (pinned below 0.5 %), every other
+    env meets the one-step bar.  Config 5: redundant contact sets (two spheres of one foot edge) and a ~1 % share of solves that end on an
+    exit test: contact sets identical in > 99.5 % of the envs (a foot sphere within rounding of touching), the converged ones within the humanoid's
+    tolerance (condition number 4e5).  Measured (profiles/r04_ab_log.txt, call F): config 3 lists equal in 100 %, max relative |du| 2.6e-5;
+    config 5 lists equal in 99.88 %, converged 98.85 %, max |du| over the converged 3.8e-4."""
+    import sys
+    from common import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    N = 4096
+    recipe = bench.Recipe(config, -1.0)
+    model = recipe.model
+    w = BatchedWorld(model, N)
+    recipe.setup_world(w, N, 0)
+    gc0, gv0 = recipe.initial_state(N, 0)
+    w.set_state(gc0, gv0)
+    w.set_pd_target(None, np.zeros((N, model.nv), np.float32))
+    feet = np.asarray(recipe.feet, np.int32)
+    for k in range(60):
+        w.set_pd_target(recipe.targets(N, k, 0).astype(np.float32), None)
+        w.integrate(workload.SUBSTEPS)
+        w.reset_terminated(feet, gc0, gv0)
+    q, u = w.get_state()
+    w.close()
+    assert np.isfinite(q).all()
+    pt = recipe.targets(N, 60, 0)
+    gc, gv = q.astype(np.float64), u.astype(np.float64)
+    w = BatchedWorld(model, N)
+    recipe.setup_world(w, N, 0)
+    o = Oracle(model.blob)
+    recipe.setup_oracle(o, N, 0)
+    dtg = np.zeros((N, model.nv))
+    w.set_pd_target(pt, dtg); w.set_state(gc, gv)
+    w.integrate(1)
+    q1, u1 = w.get_state(); cnt, con = w.get_contacts()
+    dev = dict(q=q1, u=u1, cnt=cnt, con=con, iters=w.get_solver_iterations(), flags=w.get_flags())
+    w.close()
+    ref = o.step_batch(f32(gc), f32(gv), 1, np.asarray(recipe.kp, np.float64), np.asarray(recipe.kd, np.float64), f32(pt), dtg, None, want_contacts=True,
+                       lam_warm=o.new_warm_state(N))
+    same = dev["cnt"] == ref["n_contacts"]
+    for e in np.nonzero(same)[0]:
+        same[e] = np.array_equal(dev["con"][e][:cnt[e]]["collision"], ref["contacts"][e][:cnt[e]]["collision"])
+    conv = ((ref["flags"] | dev["flags"]) & 4) == 0
+    eu = np.abs(dev["u"] - ref["u"]).max(axis=1) / (1 + np.abs(ref["u"]).max(axis=1))
+    print(f"config {config}, N = {N}: contacts {int(ref['n_contacts'].sum())}, contact lists equal in {same.mean() * 100:.3f} %, solves converged on both sides "
+          f"{conv.mean() * 100:.2f} %, relative |du| p50 {np.median(eu):.1e} p99 {np.percentile(eu, 99):.1e} max over converged {eu[conv & same].max():.1e}, max {eu.max():.1e}")
+    assert ref["n_contacts"].sum() > 1.5 * N
+    pick = lambda m_: ({k: v[m_] for k, v in dev.items()}, {k: (v[m_] if isinstance(v, np.ndarray) and len(v) == len(m_) else v) for k, v in ref.items()})   # noqa: E731
+    if config == 3:
+        assert same.mean() > 0.995
+        check_step(*pick(same), min_conv=0.99)
+    else:
+        assert same.mean() > 0.995                      # (measured: 5 of 4096 - a foot sphere within fp32 rounding of touching)
+        conv &= same
+        assert conv.mean() > 0.97
+        assert np.all(eu[conv] < 5e-3) and np.median(eu) < 5e-4
+        assert np.abs(dev["q"] - ref["q"])[conv].max() < 5e-5
+        assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all() and eu.max() < 1.0
+
+
 def test_per_primitive_materials_parity(anymal):
     """Material pairs (rsb_set_collision_materials): every collision primitive slides / bounces with its own (mu, restitution,
     res_threshold) against the terrain; three sub-steps with the warm state, vs the oracle with the same table."""
