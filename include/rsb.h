@@ -220,6 +220,30 @@ int rsb_set_heightmap_contacts(rsb_world* w, int per_primitive, double min_angle
  * of them is one more contact of the box when it penetrates and is deeper than every corner by more than 0.1 mm (a slab lying on a bump).
  * Upstream counterpart: RaiSim's ODE capsule / box x height-field colliders [RECALL; absent from /root/reference]. */
 int rsb_set_capsule_contacts(rsb_world* w, int on);
+/* Pipelined control steps (default off).  A launch of the step kernel ends with its slowest wave (a robot that has just fallen: five contacts,
+ * three times the sweeps), and a stream runs one launch after the other: every SIMD whose wave has finished idles until the last one has.  With
+ * on != 0, consecutive rsb_control_step calls that upload nothing (p_target in device memory, d_target NULL, no peer exchange, no mask) go
+ * alternately to two private streams and OVERLAP on the device: workgroup b of launch k + 1 takes its envs as soon as workgroup b of launch k
+ * has published them (a per-workgroup sequence number in device memory, release / acquire at agent scope), whatever the other workgroups of
+ * launch k are still doing; a one-thread gate kernel in front of launch k + 1 keeps it off the chip until launch k has been dispatched
+ * completely, so that a waiting workgroup never holds a slot its predecessor needs.  Results are bit-identical to the un-pipelined sequence
+ * (envs are independent; each env's steps still run in order).  Every other entry point that touches the world's stream JOINS the pipeline
+ * first (the world's stream waits for both private streams), so reads, uploads, plain rsb_integrate calls and rsb_synchronize see completed
+ * steps as before.  What the caller must know: work it enqueues ITSELF on a borrowed stream (rsb_set_stream) between two control steps is not
+ * ordered after them unless it calls rsb_get_stream / rsb_synchronize (both join) first; and a consumer that needs every env of step k before
+ * step k + 1 may start (a policy network in the loop) joins at every step and gains nothing - the overlap pays in open-loop stepping
+ * (the benchmark's random PD targets, action sequences of sampling-based MPC, replay).  Upstream counterpart: none (RaiSim steps its
+ * worlds one after the other on CPU threads). */
+int rsb_set_step_pipelining(rsb_world* w, int on);
+/* Consumers and producers on OTHER streams while the pipeline keeps running (the obs all-gather of a multi-GPU run on its own stream):
+ *   rsb_step_pipeline_publish(w, stream)     `stream` waits for the most recent pipelined control step (and nothing else of the pipeline);
+ *   rsb_step_pipeline_wait_event(w, event)   the NEXT control step additionally waits for `event` (a hipEvent_t recorded by the caller, e.g.
+ *                                            behind the collective that still reads the buffer this step overwrites).
+ * Neither joins.  No pipelined step in flight: publish is a no-op (the world's stream orders everything), the event is honoured all the same. */
+int rsb_step_pipeline_publish(rsb_world* w, void* hip_stream);
+int rsb_step_pipeline_wait_event(rsb_world* w, void* hip_event);
+/* pipelined launches enqueued so far and the number of times other calls joined them (diagnostics) */
+int rsb_step_pipelining_stats(rsb_world* w, long long* launches, long long* joins);
 /* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
  * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */
 int rsb_set_heightmaps(rsb_world* w, int n_maps, int x_samples, int y_samples, double x_size, double y_size,

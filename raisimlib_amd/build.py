@@ -85,7 +85,7 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
     # (rsb_source_hash() then no longer describes the library: the test-suite refuses it - a full build() is what ships)
     only = {tuple(int(x) for x in tok.split(",")) for tok in os.environ.get("RSB_BUILD_ONLY", "").split()}
     for lpe, kmax, cl, ml in step_instances():
-        for prof in ((0,) if cl & 2 else (0, 1)):      # (the peer-exchange classes have no profiling twin: rsb_world.hip, launch_step)
+        for prof in ((0,) if cl & 18 else (0, 1)):     # (the peer-exchange and the pipelined classes have no profiling twin: rsb_world.hip, launch_step)
             obj = os.path.join(OBJ, f"step_{lpe}_{kmax}_{cl}_{ml}_{prof}" + (f".{tag}" if tag else "") + ".o")
             objs.append(obj)
             if only and (lpe, kmax, cl, ml) not in only and os.path.exists(obj):

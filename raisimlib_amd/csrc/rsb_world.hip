@@ -115,7 +115,7 @@ struct rsb_world {
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
   struct Fuse { bool peer = false; const float* act = nullptr; const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
                 int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1;
-                float* env_reward = nullptr; float* env_ob = nullptr; uint8_t* env_done = nullptr; bool env_task = false; } fuse;
+                float* env_reward = nullptr; float* env_ob = nullptr; uint8_t* env_done = nullptr; bool env_task = false; bool pipeline = false; } fuse;
   // device-resident vectorised env (rsb_env_*)
   bool env_ready = false;
   rsb_env_config env_cfg{};
@@ -127,9 +127,45 @@ struct rsb_world {
   int timing_stride = 1;       // events bracket every timing_stride-th launch only (an event pair costs ~7 us of stream time)
   long long launch_index = 0;
   float last_ms = -1.f;
+  // pipelined control steps (rsb_set_step_pipelining): consecutive rsb_control_step launches alternate between two private streams and
+  // overlap on the device (see StepArgs::pipe_prog); any other use of the world's stream joins them first (stream_of)
+  bool pipe_on = false, pipe_active = false;
+  hipStream_t pipe_stream[2] = {nullptr, nullptr};
+  hipEvent_t pipe_ev[3] = {nullptr, nullptr, nullptr};   // join events of the two streams, fork event of the world's stream
+  int pipe_next = 0, pipe_seq = 0, pipe_blocks = 0;
+  unsigned long long pipe_wg_total = 0;                  // workgroups of all pipelined launches so far (== *d_pipe_started once they have all started)
+  unsigned long long* d_pipe_started = nullptr;
+  int* d_pipe_prog = nullptr;
+  hipStream_t launch_stream = nullptr;                   // stream of the step launch being enqueued (do_integrate)
+  hipStream_t pipe_last = nullptr;                       // private stream of the most recent pipelined launch
+  hipEvent_t pipe_dep = nullptr, pipe_pub = nullptr;     // rsb_step_pipeline_wait_event: the next pipelined launch waits for it; event of rsb_step_pipeline_publish
+  long long pipe_launches = 0, pipe_joins = 0;
 };
 
 namespace {
+// Joins the pipelined control steps (if any are in flight) into the world's stream: whatever is enqueued on it next runs after them.
+int pipe_join(rsb_world* w) {
+  if (!w->pipe_active) return RSB_OK;
+  w->pipe_active = false;
+  ++w->pipe_joins;
+  for (int i = 0; i < 2; ++i) {
+    HIP_TRY(hipEventRecord(w->pipe_ev[i], w->pipe_stream[i]));
+    HIP_TRY(hipStreamWaitEvent(w->stream, w->pipe_ev[i], 0));
+  }
+  return RSB_OK;
+}
+// the world's stream for any use other than a pipelined step launch
+hipStream_t stream_of(rsb_world* w) {
+  if (w->pipe_active) (void)pipe_join(w);
+  return w->stream;
+}
+__global__ void pipe_gate_kernel(const unsigned long long* started, unsigned long long target) {
+  int spins = 0;      // (~2 s: a launch that never arrives would be a bug of the host side - trap rather than hang the device)
+  while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > (1 << 21)) __builtin_trap();
+  }
+}
 
 // Kernel arguments in device memory: with host-resident kernargs every wave's first scalar loads cross PCIe (measured: step
 // kernel prologue 20.6 k cycles instead of 9.2 k, 142 M instead of 149 M env-steps/s).  It is this image's default; set here
@@ -372,22 +408,29 @@ int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool prof) {
   // the profiling instance carries the cycle stamps / contact-problem dump / LDS poisoning; production launches use the lean one
   // (the peer-exchange classes, CL bit 2, are built without a profiling twin: profile the exchange-free class instead)
   hipError_t e;
-  if constexpr ((CL & 2) != 0) {
-    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange kernel class: disconnect the exchange (rsb_obs_peer_destroy) first"); return RSB_E_UNSUPPORTED; }
-    e = rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
+  if constexpr ((CL & 18) != 0) {
+    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange and the pipelined kernel classes: disconnect the exchange (rsb_obs_peer_destroy) / switch pipelining off first"); return RSB_E_UNSUPPORTED; }
+    e = rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->launch_stream);
   } else {
-    e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->stream)
-             : rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->stream);
+    e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->launch_stream)
+             : rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->launch_stream);
   }
   HIP_TRY(e);
   return RSB_OK;
 }
 
 template <int KMAX, int CL, int ML>
-int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool prof) {
+int launch_lpe_class(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool prof) {
   if (lpe == 16) return launch_step<16, KMAX, CL, ML>(w, a, lds_bytes, prof);
   if (lpe == 32) return launch_step<32, KMAX, CL, ML>(w, a, lds_bytes, prof);
   return launch_step<64, KMAX, CL, ML>(w, a, lds_bytes, prof);
+}
+template <int KMAX, int CL, int ML>
+int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool prof) {
+  if constexpr ((CL & 2) == 0) {     // a pipelined launch (StepArgs::pipe_prog) runs the class's pipelined twin: the plain instances carry none of its code
+    if (a.pipe_prog) return launch_lpe_class<KMAX, CL | 16, ML>(w, a, lds_bytes, lpe, prof);
+  }
+  return launch_lpe_class<KMAX, CL, ML>(w, a, lds_bytes, lpe, prof);
 }
 
 int n_self_pairs(const rsb_world* w) { return w->self_collision ? (int)w->self_pairs.size() / 2 : 0; }
@@ -462,7 +505,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.warm = w->warm_start ? w->d_warm : nullptr;
   if (w->image_dirty) {
     std::vector<float> img = build_lds_image(w, make_layout(w->blob, kcap, n_self_pairs(w)));
-    HIP_TRY(hipMemcpyAsync(w->d_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
     const int np = n_self_pairs(w);
     std::vector<float> mat((size_t)4 * np, 0.f);
     for (int k = 0; k < np; ++k) {
@@ -477,9 +520,9 @@ int do_integrate(rsb_world* w, int nsub) {
         HIP_TRY(hipMalloc(&w->d_self_mat, (size_t)4 * np * sizeof(float)));
         w->self_mat_cap = (size_t)np;
       }
-      HIP_TRY(hipMemcpyAsync(w->d_self_mat, mat.data(), mat.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+      HIP_TRY(hipMemcpyAsync(w->d_self_mat, mat.data(), mat.size() * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
     }
-    HIP_TRY(hipStreamSynchronize(w->stream));   // img / mat are stack-lifetime buffers
+    HIP_TRY(hipStreamSynchronize(stream_of(w)));   // img / mat are stack-lifetime buffers
     w->image_dirty = false;
   }
   a.lds_image = w->d_image;
@@ -523,6 +566,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
   if (!a.do_reset) { a.gc0 = w->d_gc; a.gv0 = w->d_gv; a.reset_rows = w->N; }   // never dereferenced, but keep the pointers valid
+  const bool pipe_ok = w->fuse.pipeline && !w->fuse.env_task;
   w->fuse = rsb_world::Fuse();
   a.prof = w->d_prof;
   a.dbg = w->dbg_env >= 0 ? w->d_dbg : nullptr;
@@ -560,10 +604,51 @@ int do_integrate(rsb_world* w, int nsub) {
   a.done_out = env_done ? env_done : w->d_done_out;
   a.tau_out = w->want_genf ? w->d_genf : nullptr;
   a.env_mask = w->launch_mask; w->launch_mask = nullptr;
+  // ---- pipelined control steps: this launch goes to one of the two private streams, behind a gate that lets it start only when the launch
+  // before it (on the other stream) has been dispatched completely - its workgroups wait for their predecessors' envs, which therefore must
+  // all be running or done (no deadlock: a waiting workgroup never keeps a predecessor off the chip)
+  hipStream_t ls = nullptr;
+  const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask;
+  if (pipelined) {
+    const int blocks = (w->N + (64 / lpe) - 1) / (64 / lpe);
+    if (blocks != w->pipe_blocks) {
+      (void)stream_of(w);
+      HIP_TRY(hipStreamSynchronize(w->stream));
+      if (w->d_pipe_prog) HIP_TRY(hipFree(w->d_pipe_prog));
+      w->d_pipe_prog = nullptr;
+      HIP_TRY(hipMalloc(&w->d_pipe_prog, (size_t)blocks * sizeof(int)));
+      HIP_TRY(hipMemset(w->d_pipe_prog, 0, (size_t)blocks * sizeof(int)));
+      if (!w->d_pipe_started) { HIP_TRY(hipMalloc(&w->d_pipe_started, sizeof(unsigned long long))); }
+      HIP_TRY(hipMemset(w->d_pipe_started, 0, sizeof(unsigned long long)));
+      w->pipe_wg_total = 0; w->pipe_blocks = blocks;
+      for (int i = 0; i < 2; ++i) if (!w->pipe_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&w->pipe_stream[i], hipStreamNonBlocking));
+      for (int i = 0; i < 3; ++i) if (!w->pipe_ev[i]) HIP_TRY(hipEventCreateWithFlags(&w->pipe_ev[i], hipEventDisableTiming));
+    }
+    ls = w->pipe_stream[w->pipe_next];
+    w->pipe_next ^= 1;
+    a.pipe_prog = w->d_pipe_prog; a.pipe_started = w->d_pipe_started;
+    if (!w->pipe_active) {     // fork: both streams run after everything that is on the world's stream now; nothing to wait for on the device
+      HIP_TRY(hipEventRecord(w->pipe_ev[2], w->stream));
+      HIP_TRY(hipStreamWaitEvent(w->pipe_stream[0], w->pipe_ev[2], 0));
+      HIP_TRY(hipStreamWaitEvent(w->pipe_stream[1], w->pipe_ev[2], 0));
+      w->pipe_active = true;
+      a.pipe_wait_on = 0;
+    } else {
+      a.pipe_wait_on = 1; a.pipe_wait = w->pipe_seq;
+      hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total);
+    }
+    if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }   // rsb_step_pipeline_wait_event
+    a.pipe_seq = (int)((unsigned)w->pipe_seq + 1u);
+    HIP_TRY(hipGetLastError());
+  } else {
+    ls = stream_of(w);
+    if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }
+  }
+  w->launch_stream = ls;
   hipEvent_t e0 = w->ev0, e1 = w->ev1;
   const bool rec = w->timing && (w->launch_index++ % w->timing_stride == 0);
   if (rec && !w->ring0.empty()) { e0 = w->ring0[w->ring_next]; e1 = w->ring1[w->ring_next]; }
-  if (rec) HIP_TRY(hipEventRecord(e0, w->stream));
+  if (rec) HIP_TRY(hipEventRecord(e0, ls));
   // kernel classes by the deepest body level (support-chain capacity of the contact-column / Delassus phases) and by the base (fixed-base systems have a class of their own)
   const int mlv = w->blob.depth - 1;
   if (mlv <= 4) {
@@ -582,8 +667,14 @@ int do_integrate(rsb_world* w, int nsub) {
     return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
+  if (pipelined) {   // (only a launch that is on its way counts: the gate of the next one waits for this one's workgroups)
+    w->pipe_seq = a.pipe_seq;
+    w->pipe_wg_total += (unsigned long long)((w->N + (64 / lpe) - 1) / (64 / lpe));
+    w->pipe_last = ls;
+    ++w->pipe_launches;
+  }
   if (rec) {
-    HIP_TRY(hipEventRecord(e1, w->stream));
+    HIP_TRY(hipEventRecord(e1, ls));
     if (!w->ring0.empty()) { w->ring_next = (w->ring_next + 1) % w->ring0.size(); if (w->ring_count < w->ring0.size()) ++w->ring_count; }
   }
   w->world_time += nsub * w->dt;
@@ -592,13 +683,13 @@ int do_integrate(rsb_world* w, int nsub) {
 }
 
 int copy_in(rsb_world* w, float* dst, const float* src, size_t n, int space) {
-  HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(float), space == RSB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, w->stream));
-  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(w->stream));  // the caller may reuse its host buffer
+  HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(float), space == RSB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream_of(w)));
+  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(stream_of(w)));  // the caller may reuse its host buffer
   return RSB_OK;
 }
 int copy_out(rsb_world* w, void* dst, const void* src, size_t bytes, int space) {
-  HIP_TRY(hipMemcpyAsync(dst, src, bytes, space == RSB_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, w->stream));
-  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, space == RSB_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, stream_of(w)));
+  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(stream_of(w)));
   return RSB_OK;
 }
 
@@ -681,7 +772,7 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
 int rsb_destroy(rsb_world* w) {
   if (!w) return RSB_OK;
   (void)hipSetDevice(w->device);
-  if (w->stream) (void)hipStreamSynchronize(w->stream);
+  if (w->stream) (void)hipStreamSynchronize(stream_of(w));
   (void)rsb_comm_destroy(w);
   (void)rsb_obs_peer_destroy(w);
   void* ptrs[] = {w->d_model, w->d_gc, w->d_gv, w->d_pt, w->d_dt, w->d_tff, w->d_kp, w->d_kd, w->d_heights,
@@ -693,6 +784,11 @@ int rsb_destroy(rsb_world* w) {
   for (hipEvent_t e : w->ring1) (void)hipEventDestroy(e);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
+  for (int i = 0; i < 2; ++i) if (w->pipe_stream[i]) (void)hipStreamDestroy(w->pipe_stream[i]);
+  for (int i = 0; i < 3; ++i) if (w->pipe_ev[i]) (void)hipEventDestroy(w->pipe_ev[i]);
+  if (w->pipe_pub) (void)hipEventDestroy(w->pipe_pub);
+  if (w->d_pipe_prog) (void)hipFree(w->d_pipe_prog);
+  if (w->d_pipe_started) (void)hipFree(w->d_pipe_started);
   if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return RSB_OK;
@@ -701,17 +797,17 @@ int rsb_destroy(rsb_world* w) {
 int rsb_set_stream(rsb_world* w, void* hip_stream) {
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   if (w->own_stream && w->stream) HIP_TRY(hipStreamDestroy(w->stream));
   w->stream = (hipStream_t)hip_stream;  // NULL is the (legacy) default stream, a valid stream to borrow
   w->own_stream = false;
   return RSB_OK;
 }
-void* rsb_get_stream(rsb_world* w) { return w ? (void*)w->stream : nullptr; }
+void* rsb_get_stream(rsb_world* w) { return w ? (void*)stream_of(w) : nullptr; }
 int rsb_synchronize(rsb_world* w) {
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   return RSB_OK;
 }
 
@@ -855,6 +951,33 @@ int rsb_set_capsule_contacts(rsb_world* w, int on) {
   w->hm_capsule = on != 0;
   return RSB_OK;
 }
+int rsb_set_step_pipelining(rsb_world* w, int on) {
+  if (!w) { rsb::set_error("rsb_set_step_pipelining: null world"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  (void)stream_of(w);
+  w->pipe_on = on != 0;
+  return RSB_OK;
+}
+int rsb_step_pipeline_publish(rsb_world* w, void* hip_stream) {
+  if (!w) { rsb::set_error("rsb_step_pipeline_publish: null world"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  if (!w->pipe_active || !w->pipe_last) return RSB_OK;       // nothing in flight: the world's stream already orders everything
+  if (!w->pipe_pub) HIP_TRY(hipEventCreateWithFlags(&w->pipe_pub, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(w->pipe_pub, w->pipe_last));
+  HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, w->pipe_pub, 0));
+  return RSB_OK;
+}
+int rsb_step_pipeline_wait_event(rsb_world* w, void* hip_event) {
+  if (!w) { rsb::set_error("rsb_step_pipeline_wait_event: null world"); return RSB_E_INVALID; }
+  w->pipe_dep = (hipEvent_t)hip_event;
+  return RSB_OK;
+}
+int rsb_step_pipelining_stats(rsb_world* w, long long* launches, long long* joins) {
+  if (!w) return RSB_E_INVALID;
+  if (launches) *launches = w->pipe_launches;
+  if (joins) *joins = w->pipe_joins;
+  return RSB_OK;
+}
 int rsb_set_integration_scheme(rsb_world* w, int scheme) {
   if (!w) return RSB_E_INVALID;
   if (scheme == RSB_INTEGRATION_SEMI_IMPLICIT) w->integ_theta = 1.0;
@@ -873,7 +996,7 @@ int rsb_set_solver_warm_start(rsb_world* w, int on) {
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
   w->warm_start = on != 0;
-  HIP_TRY(hipMemsetAsync(w->d_warm, 0, (size_t)w->N * rsbk::kWarmRow * sizeof(float), w->stream));
+  HIP_TRY(hipMemsetAsync(w->d_warm, 0, (size_t)w->N * rsbk::kWarmRow * sizeof(float), stream_of(w)));
   return RSB_OK;
 }
 int rsb_set_max_contacts(rsb_world* w, int kmax) {
@@ -904,7 +1027,7 @@ int rsb_set_heightmaps(rsb_world* w, int n_maps, int xs, int ys, double x_size, 
     for (int e = 0; e < w->N; ++e)
       if (env_map[e] < 0 || env_map[e] >= n_maps) { rsb::set_error("rsb_set_heightmaps: env_map entry out of range"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   if (w->d_heights) { HIP_TRY(hipFree(w->d_heights)); w->d_heights = nullptr; }
   if (w->d_hm_index) { HIP_TRY(hipFree(w->d_hm_index)); w->d_hm_index = nullptr; }
   const size_t n = (size_t)n_maps * xs * ys;
@@ -930,7 +1053,7 @@ int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t*
   w->integrate1_valid = false;
   const int n6 = rsbk::kWarmRow;
   if (!mask) {
-    if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, w->stream, w->d_warm, (const uint8_t*)nullptr, (int)N, n6);
+    if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, stream_of(w), w->d_warm, (const uint8_t*)nullptr, (int)N, n6);
     if (gc) { int st = copy_in(w, w->d_gc, gc, N * nq, space); if (st) return st; }
     if (gv) { int st = copy_in(w, w->d_gv, gv, N * nv, space); if (st) return st; }
     return RSB_OK;
@@ -943,16 +1066,16 @@ int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t*
       HIP_TRY(hipMalloc(&w->d_tmp_gv, N * nv * sizeof(float)));
       HIP_TRY(hipMalloc(&w->d_tmp_mask, N));
     }
-    HIP_TRY(hipMemcpyAsync(w->d_tmp_mask, mask, N, hipMemcpyHostToDevice, w->stream));
-    if (gc) HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, gc, N * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    if (gv) HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, gv, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_mask, mask, N, hipMemcpyHostToDevice, stream_of(w)));
+    if (gc) HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, gc, N * nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+    if (gv) HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, gv, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
     dmask = w->d_tmp_mask; sgc = gc ? w->d_tmp_gc : nullptr; sgv = gv ? w->d_tmp_gv : nullptr;
   }
-  if (sgc) hipLaunchKernelGGL(masked_row_copy, dim3((N * nq + 255) / 256), dim3(256), 0, w->stream, w->d_gc, sgc, dmask, (int)N, (int)nq);
-  if (sgv) hipLaunchKernelGGL(masked_row_copy, dim3((N * nv + 255) / 256), dim3(256), 0, w->stream, w->d_gv, sgv, dmask, (int)N, (int)nv);
-  if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, w->stream, w->d_warm, dmask, (int)N, n6);
+  if (sgc) hipLaunchKernelGGL(masked_row_copy, dim3((N * nq + 255) / 256), dim3(256), 0, stream_of(w), w->d_gc, sgc, dmask, (int)N, (int)nq);
+  if (sgv) hipLaunchKernelGGL(masked_row_copy, dim3((N * nv + 255) / 256), dim3(256), 0, stream_of(w), w->d_gv, sgv, dmask, (int)N, (int)nv);
+  if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, stream_of(w), w->d_warm, dmask, (int)N, n6);
   HIP_TRY(hipGetLastError());
-  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(w->stream));
+  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(stream_of(w)));
   return RSB_OK;
 }
 
@@ -986,10 +1109,10 @@ int rsb_set_env_row(rsb_world* w, int field, int env, const float* data) {
   int st = env_row(w, field, env, &base, &dim);
   if (st != RSB_OK || !data) return st != RSB_OK ? st : RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipMemcpyAsync(base + (size_t)env * dim, data, dim * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  HIP_TRY(hipMemcpyAsync(base + (size_t)env * dim, data, dim * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
   if ((field == RSB_F_GC || field == RSB_F_GV) && w->blob.ncol > 0)   // the env's state was overwritten: its solver state is stale
-    HIP_TRY(hipMemsetAsync(w->d_warm + (size_t)env * rsbk::kWarmRow, 0, (size_t)rsbk::kWarmRow * sizeof(float), w->stream));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(hipMemsetAsync(w->d_warm + (size_t)env * rsbk::kWarmRow, 0, (size_t)rsbk::kWarmRow * sizeof(float), stream_of(w)));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   w->integrate1_valid = false;
   return RSB_OK;
 }
@@ -998,8 +1121,8 @@ int rsb_get_env_row(rsb_world* w, int field, int env, float* data) {
   int st = env_row(w, field, env, &base, &dim);
   if (st != RSB_OK || !data) return st != RSB_OK ? st : RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipMemcpyAsync(data, base + (size_t)env * dim, dim * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipMemcpyAsync(data, base + (size_t)env * dim, dim * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   return RSB_OK;
 }
 
@@ -1031,9 +1154,9 @@ int rsb_set_control_mode(rsb_world* w, int mode) {
 int rsb_set_pd_gains(rsb_world* w, const float* kp, const float* kd) {
   if (!w || !kp || !kd) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipMemcpyAsync(w->d_kp, kp, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
-  HIP_TRY(hipMemcpyAsync(w->d_kd, kd, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipMemcpyAsync(w->d_kp, kp, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  HIP_TRY(hipMemcpyAsync(w->d_kd, kd, w->blob.nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   w->h_kp.assign(kp, kp + w->blob.nv); w->h_kd.assign(kd, kd + w->blob.nv);
   w->image_dirty = true;
   return RSB_OK;
@@ -1063,8 +1186,8 @@ int rsb_integrate_masked(rsb_world* w, int n_substeps, const uint8_t* mask, int 
   const uint8_t* dmask = mask;
   if (space == RSB_HOST) {
     if (!w->d_launch_mask) HIP_TRY(hipMalloc(&w->d_launch_mask, (size_t)w->N));
-    HIP_TRY(hipMemcpyAsync(w->d_launch_mask, mask, (size_t)w->N, hipMemcpyHostToDevice, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));   // pageable host memory: the caller may reuse its buffer
+    HIP_TRY(hipMemcpyAsync(w->d_launch_mask, mask, (size_t)w->N, hipMemcpyHostToDevice, stream_of(w)));
+    HIP_TRY(hipStreamSynchronize(stream_of(w)));   // pageable host memory: the caller may reuse its buffer
     dmask = w->d_launch_mask;
   }
   w->launch_mask = dmask;
@@ -1086,9 +1209,9 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
   if (!w || !io || io->n_launches < 0 || (io->n_launches > 0 && !io->launch_substeps)) { rsb::set_error("rsb_view_exchange: bad argument"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));
   const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
-  if (io->p_target) HIP_TRY(hipMemcpyAsync(w->d_pt, io->p_target, N * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
-  if (io->d_target) HIP_TRY(hipMemcpyAsync(w->d_dt, io->d_target, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
-  if (io->tau_ff) HIP_TRY(hipMemcpyAsync(w->d_tff, io->tau_ff, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  if (io->p_target) HIP_TRY(hipMemcpyAsync(w->d_pt, io->p_target, N * nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  if (io->d_target) HIP_TRY(hipMemcpyAsync(w->d_dt, io->d_target, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  if (io->tau_ff) HIP_TRY(hipMemcpyAsync(w->d_tff, io->tau_ff, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
   if (io->gc || io->gv) {
     if (!io->state_mask) { rsb::set_error("rsb_view_exchange: state rows need state_mask"); return RSB_E_INVALID; }
     if (!w->d_tmp_gc) {
@@ -1096,16 +1219,16 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
       HIP_TRY(hipMalloc(&w->d_tmp_gv, N * nv * sizeof(float)));
       HIP_TRY(hipMalloc(&w->d_tmp_mask, N));
     }
-    HIP_TRY(hipMemcpyAsync(w->d_tmp_mask, io->state_mask, N, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_mask, io->state_mask, N, hipMemcpyHostToDevice, stream_of(w)));
     if (io->gc) {
-      HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, io->gc, N * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
-      hipLaunchKernelGGL(masked_row_copy, dim3((N * nq + 255) / 256), dim3(256), 0, w->stream, w->d_gc, (const float*)w->d_tmp_gc, (const uint8_t*)w->d_tmp_mask, (int)N, (int)nq);
+      HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, io->gc, N * nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+      hipLaunchKernelGGL(masked_row_copy, dim3((N * nq + 255) / 256), dim3(256), 0, stream_of(w), w->d_gc, (const float*)w->d_tmp_gc, (const uint8_t*)w->d_tmp_mask, (int)N, (int)nq);
     }
     if (io->gv) {
-      HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, io->gv, N * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
-      hipLaunchKernelGGL(masked_row_copy, dim3((N * nv + 255) / 256), dim3(256), 0, w->stream, w->d_gv, (const float*)w->d_tmp_gv, (const uint8_t*)w->d_tmp_mask, (int)N, (int)nv);
+      HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, io->gv, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+      hipLaunchKernelGGL(masked_row_copy, dim3((N * nv + 255) / 256), dim3(256), 0, stream_of(w), w->d_gv, (const float*)w->d_tmp_gv, (const uint8_t*)w->d_tmp_mask, (int)N, (int)nv);
     }
-    hipLaunchKernelGGL(warm_clear_kernel, dim3((N * rsbk::kWarmRow + 255) / 256), dim3(256), 0, w->stream, w->d_warm, (const uint8_t*)w->d_tmp_mask, (int)N, rsbk::kWarmRow);
+    hipLaunchKernelGGL(warm_clear_kernel, dim3((N * rsbk::kWarmRow + 255) / 256), dim3(256), 0, stream_of(w), w->d_warm, (const uint8_t*)w->d_tmp_mask, (int)N, rsbk::kWarmRow);
     HIP_TRY(hipGetLastError());
     w->integrate1_valid = false;
   }
@@ -1117,7 +1240,7 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
       HIP_TRY(hipMalloc(&w->d_view_masks, need));
       w->view_masks_cap = need;
     }
-    HIP_TRY(hipMemcpyAsync(w->d_view_masks, io->launch_masks, need, hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_view_masks, io->launch_masks, need, hipMemcpyHostToDevice, stream_of(w)));
   }
   for (int i = 0; i < io->n_launches; ++i) {
     if (io->launch_substeps[i] < 1) { rsb::set_error("rsb_view_exchange: launch_substeps must be >= 1"); return RSB_E_INVALID; }
@@ -1125,15 +1248,15 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
     const int st = do_integrate(w, io->launch_substeps[i]);
     if (st != RSB_OK) return st;
   }
-  if (io->gc_out) HIP_TRY(hipMemcpyAsync(io->gc_out, w->d_gc, N * nq * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-  if (io->gv_out) HIP_TRY(hipMemcpyAsync(io->gv_out, w->d_gv, N * nv * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-  if (io->contact_counts) HIP_TRY(hipMemcpyAsync(io->contact_counts, w->d_count, N * sizeof(int32_t), hipMemcpyDeviceToHost, w->stream));
-  if (io->contacts) HIP_TRY(hipMemcpyAsync(io->contacts, w->d_contacts, N * w->kmax * sizeof(rsb_contact), hipMemcpyDeviceToHost, w->stream));
+  if (io->gc_out) HIP_TRY(hipMemcpyAsync(io->gc_out, w->d_gc, N * nq * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
+  if (io->gv_out) HIP_TRY(hipMemcpyAsync(io->gv_out, w->d_gv, N * nv * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
+  if (io->contact_counts) HIP_TRY(hipMemcpyAsync(io->contact_counts, w->d_count, N * sizeof(int32_t), hipMemcpyDeviceToHost, stream_of(w)));
+  if (io->contacts) HIP_TRY(hipMemcpyAsync(io->contacts, w->d_contacts, N * w->kmax * sizeof(rsb_contact), hipMemcpyDeviceToHost, stream_of(w)));
   if (io->generalized_force) {
     if (!w->want_genf || !w->d_genf) { rsb::set_error("rsb_view_exchange: generalized_force needs rsb_enable_generalized_force_output"); return RSB_E_INVALID; }
-    HIP_TRY(hipMemcpyAsync(io->generalized_force, w->d_genf, N * nv * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipMemcpyAsync(io->generalized_force, w->d_genf, N * nv * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
   }
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   return RSB_OK;
 }
 
@@ -1157,7 +1280,7 @@ int rsb_integrate1(rsb_world* w) {
   rsbq::QueryArgs qa;
   qa.model = w->d_model; qa.gc = w->d_gc; qa.gv = w->d_gv; qa.M = w->d_M; qa.h = w->d_h; qa.N = w->N;
   qa.gx = (float)w->gravity[0]; qa.gy = (float)w->gravity[1]; qa.gz = (float)w->gravity[2];
-  int st = rsbq::launch_query(qa, w->blob.nb, w->stream);
+  int st = rsbq::launch_query(qa, w->blob.nb, stream_of(w));
   if (st != 0) { rsb::set_error("integrate1: query kernel launch failed"); return RSB_E_HIP; }
   w->integrate1_valid = true;
   return RSB_OK;
@@ -1190,7 +1313,7 @@ int rsb_get_inverse_mass_matrix(rsb_world* w, float* Minv, int space) {
     HIP_TRY(hipMalloc(&w->d_Minv, n * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_Mwork, n * sizeof(float)));
   }
-  hipLaunchKernelGGL(rsbq::rsb_minv_kernel, dim3((w->N + 63) / 64), dim3(64), 0, w->stream, w->d_M, w->d_Mwork, w->d_Minv, w->N, w->blob.nv);
+  hipLaunchKernelGGL(rsbq::rsb_minv_kernel, dim3((w->N + 63) / 64), dim3(64), 0, stream_of(w), w->d_M, w->d_Mwork, w->d_Minv, w->N, w->blob.nv);
   HIP_TRY(hipGetLastError());
   return copy_out(w, Minv, w->d_Minv, n * sizeof(float), space);
 }
@@ -1220,8 +1343,8 @@ int upload_obs_idx(rsb_world* w, const int32_t* idx, int n) {
     if (idx[i] < 0 || idx[i] >= w->blob.ncol) { rsb::set_error("collision index out of range"); return RSB_E_INVALID; }
   if ((int)w->obs_idx_host.size() != n || std::memcmp(w->obs_idx_host.data(), idx, n * sizeof(int32_t)) != 0) {
     w->obs_idx_host.assign(idx, idx + n);
-    HIP_TRY(hipMemcpyAsync(w->d_obs_idx, w->obs_idx_host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_obs_idx, w->obs_idx_host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, stream_of(w)));
+    HIP_TRY(hipStreamSynchronize(stream_of(w)));
   }
   return RSB_OK;
 }
@@ -1256,7 +1379,7 @@ int rsb_gather_obs(rsb_world* w, float* out, const int32_t* collision_indices, i
   }
   const int od = w->blob.nq + w->blob.nv + 3 * n_force_slots;
   const size_t total = (size_t)w->N * od;
-  hipLaunchKernelGGL(gather_obs_kernel, dim3((total + 255) / 256), dim3(256), 0, w->stream, out, w->d_gc, w->d_gv,
+  hipLaunchKernelGGL(gather_obs_kernel, dim3((total + 255) / 256), dim3(256), 0, stream_of(w), out, w->d_gc, w->d_gv,
                      w->d_contacts, w->d_count, didx, w->N, w->blob.nq, w->blob.nv, w->kmax, n_force_slots,
                      (float)(1.0 / w->dt));
   HIP_TRY(hipGetLastError());
@@ -1284,17 +1407,17 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
       HIP_TRY(hipMalloc(&w->d_tmp_gv, N * nv * sizeof(float)));
       HIP_TRY(hipMalloc(&w->d_tmp_mask, N));
     }
-    HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, gc0, (size_t)rows * nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, gv0, (size_t)rows * nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_gc, gc0, (size_t)rows * nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+    HIP_TRY(hipMemcpyAsync(w->d_tmp_gv, gv0, (size_t)rows * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
     dgc0 = w->d_tmp_gc; dgv0 = w->d_tmp_gv; ddone = done ? w->d_tmp_mask : nullptr;
   }
-  hipLaunchKernelGGL(reset_terminated_kernel, dim3((N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_contacts,
+  hipLaunchKernelGGL(reset_terminated_kernel, dim3((N + 255) / 256), dim3(256), 0, stream_of(w), w->d_gc, w->d_gv, w->d_contacts,
                      w->d_count, w->d_flags, allowed, dgc0, dgv0, rows, ddone, (int)N, (int)nq, (int)nv, w->kmax, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   if (space == RSB_HOST) {
-    if (done) HIP_TRY(hipMemcpyAsync(done, w->d_tmp_mask, N, hipMemcpyDeviceToHost, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (done) HIP_TRY(hipMemcpyAsync(done, w->d_tmp_mask, N, hipMemcpyDeviceToHost, stream_of(w)));
+    HIP_TRY(hipStreamSynchronize(stream_of(w)));
   }
   return RSB_OK;
 }
@@ -1313,6 +1436,7 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
   if (d_target) { int st = copy_in(w, w->d_dt, d_target, (size_t)w->N * w->blob.nv, RSB_DEVICE); if (st) return st; }
   rsb_world::Fuse f;
   f.ptarget_src = p_target;   // read in place by the launch, which also refreshes the world's own copy
+  f.pipeline = p_target != nullptr && d_target == nullptr;   // (rsb_set_step_pipelining: control steps that upload nothing may overlap)
   if (w->peer.connected) {
     if (w->blob.fixed_base || w->blob.depth - 1 > 12) { rsb::set_error("rsb_control_step: the peer-mapped obs exchange is compiled for floating-base models of tree depth <= 13"); return RSB_E_UNSUPPORTED; }
     if (obs_out && n_force_slots != w->peer.slots) { rsb::set_error("rsb_control_step: obs_out must use the force slots the peer exchange was created with"); return RSB_E_INVALID; }
@@ -1369,10 +1493,10 @@ int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* acti
     HIP_TRY(hipMemset(w->d_env_tau2, 0, N * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_env_done, N));
   }
-  HIP_TRY(hipMemcpyAsync(w->d_env_mean, action_mean, nj * sizeof(float), hipMemcpyHostToDevice, w->stream));
-  HIP_TRY(hipMemcpyAsync(w->d_env_gc0, gc_init, nq * sizeof(float), hipMemcpyHostToDevice, w->stream));
-  HIP_TRY(hipMemcpyAsync(w->d_env_gv0, gv_init, nv * sizeof(float), hipMemcpyHostToDevice, w->stream));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipMemcpyAsync(w->d_env_mean, action_mean, nj * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  HIP_TRY(hipMemcpyAsync(w->d_env_gc0, gc_init, nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  HIP_TRY(hipMemcpyAsync(w->d_env_gv0, gv_init, nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   w->env_cfg = *cfg; w->env_allowed = allowed; w->env_ready = true;
   return RSB_OK;
 }
@@ -1390,7 +1514,7 @@ static int env_check(rsb_world* w, const char* who) {
 }
 int rsb_env_reset(rsb_world* w) {
   int st = env_check(w, "rsb_env_reset"); if (st != RSB_OK) return st;
-  hipLaunchKernelGGL(env_reset_kernel, dim3((w->N + 255) / 256), dim3(256), 0, w->stream, w->d_gc, w->d_gv, w->d_count,
+  hipLaunchKernelGGL(env_reset_kernel, dim3((w->N + 255) / 256), dim3(256), 0, stream_of(w), w->d_gc, w->d_gv, w->d_count,
                      w->d_flags, w->d_env_gc0, w->d_env_gv0, w->N, w->blob.nq, w->blob.nv, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
@@ -1401,7 +1525,7 @@ int rsb_env_observe(rsb_world* w, float* ob, int space) {
   if (!ob) return RSB_E_INVALID;
   const size_t od = 10 + 2 * (size_t)(w->blob.nv - 6);
   float* dob = space == RSB_DEVICE ? ob : w->d_env_io;
-  hipLaunchKernelGGL(env_obs_kernel, dim3((w->N + 255) / 256), dim3(256), 0, w->stream, dob, w->d_gc, w->d_gv, w->N,
+  hipLaunchKernelGGL(env_obs_kernel, dim3((w->N + 255) / 256), dim3(256), 0, stream_of(w), dob, w->d_gc, w->d_gv, w->N,
                      w->blob.nq, w->blob.nv);
   HIP_TRY(hipGetLastError());
   if (space == RSB_HOST) return copy_out(w, ob, dob, (size_t)w->N * od * sizeof(float), RSB_HOST);
@@ -1414,7 +1538,7 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   const size_t od = 10 + 2 * (size_t)nj;
   const float* dact = action;
   if (space == RSB_HOST) {
-    HIP_TRY(hipMemcpyAsync(w->d_env_io, action, (size_t)N * nj * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(w->d_env_io, action, (size_t)N * nj * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
     dact = w->d_env_io;
   }
   float* drew = space == RSB_DEVICE ? reward : (reward ? w->d_env_reward : nullptr);
@@ -1434,10 +1558,10 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   if (st != RSB_OK) return st;
   w->integrate1_valid = false;
   if (space == RSB_HOST) {
-    if (reward) HIP_TRY(hipMemcpyAsync(reward, w->d_env_reward, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-    if (done) HIP_TRY(hipMemcpyAsync(done, w->d_env_done, (size_t)N, hipMemcpyDeviceToHost, w->stream));
-    if (ob_next) HIP_TRY(hipMemcpyAsync(ob_next, w->d_env_ob, (size_t)N * od * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (reward) HIP_TRY(hipMemcpyAsync(reward, w->d_env_reward, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
+    if (done) HIP_TRY(hipMemcpyAsync(done, w->d_env_done, (size_t)N, hipMemcpyDeviceToHost, stream_of(w)));
+    if (ob_next) HIP_TRY(hipMemcpyAsync(ob_next, w->d_env_ob, (size_t)N * od * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
+    HIP_TRY(hipStreamSynchronize(stream_of(w)));
   }
   return RSB_OK;
 }
@@ -1465,7 +1589,7 @@ int rsb_debug_select_env(rsb_world* w, int env) {
   HIP_TRY(hipSetDevice(w->device));
   const size_t n = 1 + 3 * RSB_MAX_CONTACTS * 3 * RSB_MAX_CONTACTS + 6 * RSB_MAX_CONTACTS;
   if (!w->d_dbg) HIP_TRY(hipMalloc(&w->d_dbg, n * sizeof(float)));
-  HIP_TRY(hipMemsetAsync(w->d_dbg, 0, n * sizeof(float), w->stream));
+  HIP_TRY(hipMemsetAsync(w->d_dbg, 0, n * sizeof(float), stream_of(w)));
   w->dbg_env = env;
   return RSB_OK;
 }
@@ -1474,8 +1598,8 @@ int rsb_debug_read_contact_problem(rsb_world* w, int* nc, float* G, float* c, fl
   HIP_TRY(hipSetDevice(w->device));
   const size_t n = 1 + 3 * RSB_MAX_CONTACTS * 3 * RSB_MAX_CONTACTS + 6 * RSB_MAX_CONTACTS;
   std::vector<float> buf(n);
-  HIP_TRY(hipMemcpyAsync(buf.data(), w->d_dbg, n * sizeof(float), hipMemcpyDeviceToHost, w->stream));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipMemcpyAsync(buf.data(), w->d_dbg, n * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   const int k = (int)buf[0], n3 = 3 * k;
   *nc = k;
   if (G) std::memcpy(G, buf.data() + 1, sizeof(float) * n3 * n3);
@@ -1491,10 +1615,10 @@ int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16) {
   const size_t nprof = 16 + 16 * (size_t)w->N;  // 16 phase stamps + 16 words per workgroup (upper bound: one env per wave)
   if (enable && !w->d_prof) { HIP_TRY(hipMalloc(&w->d_prof, nprof * sizeof(long long))); HIP_TRY(hipMemset(w->d_prof, 0, nprof * sizeof(long long))); }
   if (out16 && w->d_prof) {
-    HIP_TRY(hipMemcpyAsync(out16, w->d_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(hipMemcpyAsync(out16, w->d_prof, 16 * sizeof(long long), hipMemcpyDeviceToHost, stream_of(w)));
+    HIP_TRY(hipStreamSynchronize(stream_of(w)));
   }
-  if (!enable && w->d_prof) { HIP_TRY(hipStreamSynchronize(w->stream)); HIP_TRY(hipFree(w->d_prof)); w->d_prof = nullptr; }
+  if (!enable && w->d_prof) { HIP_TRY(hipStreamSynchronize(stream_of(w))); HIP_TRY(hipFree(w->d_prof)); w->d_prof = nullptr; }
   return RSB_OK;
 }
 
@@ -1503,8 +1627,8 @@ int rsb_debug_phase_cycles(rsb_world* w, int enable, long long* out16) {
 int rsb_debug_wave_profile(rsb_world* w, long long* out, int n_blocks) {
   if (!w || !out || !w->d_prof || n_blocks > w->N) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipMemcpyAsync(out, w->d_prof + 16, 16 * (size_t)n_blocks * sizeof(long long), hipMemcpyDeviceToHost, w->stream));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipMemcpyAsync(out, w->d_prof + 16, 16 * (size_t)n_blocks * sizeof(long long), hipMemcpyDeviceToHost, stream_of(w)));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   return RSB_OK;
 }
 
@@ -1531,7 +1655,7 @@ int rsb_read_kernel_ms(rsb_world* w, float* ms, int n) {
   if (!w || !ms || n < 0) return RSB_E_INVALID;
   if (w->ring0.empty()) { rsb::set_error("rsb_read_kernel_ms: no timing ring (rsb_enable_timing(w, n) with n > 1)"); return RSB_E_STATE; }
   HIP_TRY(hipSetDevice(w->device));
-  HIP_TRY(hipStreamSynchronize(w->stream));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
   const size_t have = w->ring_count, cap = w->ring0.size();
   const size_t take = (size_t)n < have ? (size_t)n : have;
   for (size_t i = 0; i < take; ++i) {   // oldest of the last `take` launches first
@@ -1622,7 +1746,7 @@ int rsb_comm_init(rsb_world* w, int n_ranks, int rank, const char id[RSB_COMM_ID
 int rsb_comm_destroy(rsb_world* w) {
   if (!w || !w->comm) return RSB_OK;
   Rccl* R = rccl();
-  if (R) { (void)hipSetDevice(w->device); (void)hipStreamSynchronize(w->stream); (void)R->CommDestroy(w->comm); }
+  if (R) { (void)hipSetDevice(w->device); (void)hipStreamSynchronize(stream_of(w)); (void)R->CommDestroy(w->comm); }
   w->comm = nullptr; w->comm_ranks = 0;
   return RSB_OK;
 }
@@ -1669,13 +1793,13 @@ int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* coll
     if (P.d_idx) { (void)hipFree(P.d_idx); P.d_idx = nullptr; }
     return RSB_E_HIP;
   };
-  hipError_t e = hipMemsetAsync(P.base, 0, P.bytes, w->stream);
+  hipError_t e = hipMemsetAsync(P.base, 0, P.bytes, stream_of(w));
   if (e != hipSuccess) return fail(e);
   if (!P.idx.empty()) {
     if ((e = hipMalloc(&P.d_idx, P.idx.size() * sizeof(int32_t))) != hipSuccess) return fail(e);
-    if ((e = hipMemcpyAsync(P.d_idx, P.idx.data(), P.idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, w->stream)) != hipSuccess) return fail(e);
+    if ((e = hipMemcpyAsync(P.d_idx, P.idx.data(), P.idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_of(w))) != hipSuccess) return fail(e);
   }
-  if ((e = hipStreamSynchronize(w->stream)) != hipSuccess) return fail(e);
+  if ((e = hipStreamSynchronize(stream_of(w))) != hipSuccess) return fail(e);
   if (handle) {
     std::memset(handle, 0, RSB_OBS_HANDLE_BYTES);
     hipIpcMemHandle_t h;
@@ -1696,8 +1820,8 @@ static int obs_peer_finish_connect(rsb_world* w) {
   if (P.step != 0) {
     const size_t bufsz = (size_t)P.ranks * w->N * P.od;
     HIP_TRY(hipSetDevice(w->device));
-    HIP_TRY(hipMemsetAsync(static_cast<float*>(P.base) + 2 * bufsz, 0, (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t), w->stream));
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(hipMemsetAsync(static_cast<float*>(P.base) + 2 * bufsz, 0, (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t), stream_of(w)));
+    HIP_TRY(hipStreamSynchronize(stream_of(w)));
   }
   w->peer.connected = true; w->peer.step = 0;
   return RSB_OK;
@@ -1743,10 +1867,10 @@ int rsb_obs_peer_wait(rsb_world* w, float** gathered) {
   if (!P.wait_by_kernel) {
     // the command processor polls the flag words: no kernel, no CU
     for (int p = 0; p < P.ranks && !P.wait_by_kernel; ++p)
-      if (hipStreamWaitValue32(w->stream, flags + p, P.step, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) { (void)hipGetLastError(); P.wait_by_kernel = true; }
+      if (hipStreamWaitValue32(stream_of(w), flags + p, P.step, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) { (void)hipGetLastError(); P.wait_by_kernel = true; }
   }
   if (P.wait_by_kernel) {
-    hipLaunchKernelGGL(obs_peer_wait_kernel, dim3(1), dim3(64), 0, w->stream, flags, P.ranks, P.step);
+    hipLaunchKernelGGL(obs_peer_wait_kernel, dim3(1), dim3(64), 0, stream_of(w), flags, P.ranks, P.step);
     HIP_TRY(hipGetLastError());
   }
   if (gathered) *gathered = static_cast<float*>(P.base) + (size_t)par * bufsz;
@@ -1756,7 +1880,7 @@ int rsb_obs_peer_wait(rsb_world* w, float** gathered) {
 int rsb_obs_peer_destroy(rsb_world* w) {
   if (!w || !w->peer.base) return RSB_OK;
   (void)hipSetDevice(w->device);
-  (void)hipStreamSynchronize(w->stream);
+  (void)hipStreamSynchronize(stream_of(w));
   rsb_world::Peer& P = w->peer;
   for (int p = 0; p < P.ranks; ++p) if (P.imported[p]) (void)hipIpcCloseMemHandle(P.peer_base[p]);
   (void)hipFree(P.base);
@@ -1790,7 +1914,7 @@ int rsb_allgather_obs(rsb_world* w, const int32_t* collision_indices, int n_forc
   }
   int st = rsb_gather_obs(w, w->d_obs_local, collision_indices, n_force_slots, RSB_DEVICE);
   if (st != RSB_OK) return st;
-  NCCL_TRY(R->AllGather(w->d_obs_local, dall, local, kNcclFloat32, w->comm, w->stream));
+  NCCL_TRY(R->AllGather(w->d_obs_local, dall, local, kNcclFloat32, w->comm, stream_of(w)));
   if (space == RSB_HOST) return copy_out(w, out, dall, all * sizeof(float), RSB_HOST);
   return RSB_OK;
 }

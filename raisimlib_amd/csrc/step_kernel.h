@@ -593,7 +593,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   extern __shared__ __attribute__((aligned(16))) float lds[];
   long long t_entry = 0; if (PROF) t_entry = clock64();
   constexpr int EPW = 64 / LPE;
-  constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0, HM2 = (CL & 4) != 0, TH = (CL & 8) != 0;
+  constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0, HM2 = (CL & 4) != 0, TH = (CL & 8) != 0, PIPE = (CL & 16) != 0;
   constexpr bool TRI = KMAX > 8;    // packed lower-triangular Delassus blocks (see tri_off); the quadruped classes keep the square layout
   const int lane = threadIdx.x;
   const int el = lane / LPE;
@@ -609,6 +609,19 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   if (!env_valid) env = a.N - 1;
   // masked launch (per-env raisim::World views, rsb_integrate_masked): a masked-off env runs along but writes nothing back
   if (a.env_mask && !a.env_mask[env]) env_valid = false;
+  // pipelined control steps (StepArgs::pipe_prog): this workgroup's envs belong to workgroup `blk` of the previous launch until that one has
+  // published them; then an acquire at agent scope (the two workgroups may sit on different XCDs, i.e. behind different L2s)
+  if constexpr (PIPE) {
+    if (lane == 0) __hip_atomic_fetch_add(a.pipe_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.pipe_wait_on) {
+      int spins = 0;       // (a predecessor that never publishes would be a bug of the host side: trap after ~2 s rather than hang the device)
+      while (__hip_atomic_load(a.pipe_prog + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_wait < 0) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1 << 22)) __builtin_trap();
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
 
   // model dimensions travel in the kernel arguments (read through a.model they cost one more dependent load before anything can start)
   const int nb = a.nb, nq = a.nq, nv = a.nv, depth = a.depth, ncol = a.ncol, cw = a.cw;
@@ -2426,6 +2439,12 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
       ae.flags[env] = term ? 0 : flag;
       ae.iters[env] = iters_used;
     }
+  }
+  if constexpr (PIPE) {   // pipelined control steps: everything this workgroup wrote is released, then its envs are handed to the next launch
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    int pb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) pb = (pb & 7) * (gridDim.x >> 3) + (pb >> 3);
+    if (lane == 0) __hip_atomic_store(ae.pipe_prog + pb, ae.pipe_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (PEER) if (ae.n_obs_peers > 0) {
     // publication (see StepArgs::obs_peer): this wave's rows are acknowledged, it checks in; the last wave of the launch stores the

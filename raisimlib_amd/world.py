@@ -232,6 +232,24 @@ class BatchedWorld:
         """Contacts per collision primitive against a height map (1 = closest feature; 2 = also a second flank's; see rsb.h)."""
         check(self.L.rsb_set_heightmap_contacts(self.handle, int(per_primitive), float(min_angle_deg)), "rsb_set_heightmap_contacts")
 
+    def set_step_pipelining(self, on=True):
+        """Consecutive control steps overlap on the device (rsb_set_step_pipelining): bit-identical results, no launch waits for the slowest wave
+        of the one before it; any other call joins the pipeline first."""
+        check(self.L.rsb_set_step_pipelining(self.handle, int(bool(on))), "rsb_set_step_pipelining")
+
+    def step_pipeline_publish(self, stream_ptr):
+        """`stream_ptr` (a hipStream_t as an integer) waits for the most recent pipelined control step; the pipeline keeps running"""
+        check(self.L.rsb_step_pipeline_publish(self.handle, C.c_void_p(stream_ptr)), "rsb_step_pipeline_publish")
+
+    def step_pipeline_wait_event(self, event_ptr):
+        """the next control step additionally waits for the hipEvent_t `event_ptr` (an integer; the caller keeps it alive until then)"""
+        check(self.L.rsb_step_pipeline_wait_event(self.handle, C.c_void_p(event_ptr)), "rsb_step_pipeline_wait_event")
+
+    def step_pipelining_stats(self):
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        check(self.L.rsb_step_pipelining_stats(self.handle, C.byref(a), C.byref(b)), "rsb_step_pipelining_stats")
+        return int(a.value), int(b.value)
+
     def set_capsule_contacts(self, on=True):
         """Exact capsule / cylinder / box x height map: the barrel between a capsule's or cylinder's ends and the faces and edges between a box's corners
         report their deepest point (rsb_set_capsule_contacts)."""
