@@ -89,6 +89,10 @@ def parse():
                     help="how the per-control-step obs block reaches the other ranks: 'rccl' = all-gather (default until a multi-GPU box has "
                          "measured both), 'peer' = peer-mapped buffers written by the step kernel's epilogue (rsb_obs_peer_*: no collective, no copy kernel)")
     ap.add_argument("--peer-no-wait", action="store_true", help="diagnostic (--obs-exchange peer): rows and flags are written, nobody waits for them")
+    ap.add_argument("--lockstep", action="store_true",
+                    help="no pipelining of consecutive control steps (rsb_set_step_pipelining off): every launch waits for the slowest wave of the one "
+                         "before it - what a caller gets that consumes every step's output before it issues the next one.  The default line reports "
+                         "this number as `lockstep` next to the pipelined `value`")
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the `secondary` block (configs 3 and 5 with the same --steps / --warmup) and `boundary_template_path` "
                          "that the default single-GPU run of config 2 appends")
@@ -482,10 +486,12 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     # obs block of this rank and the gathered block of all ranks (raisimlib_amd/dist.py); with --overlap-collective
     # double-buffered, so that the all-gather of control step k (RCCL, its own stream) overlaps the kernel of step k+1
     from raisimlib_amd.dist import ObsGatherer, PeerObsGatherer
+    # consecutive control steps overlap on the device (rsb_set_step_pipelining) unless --lockstep; the peer-mapped exchange has no pipelined twin
+    pipelined = not args.lockstep and args.obs_exchange != "peer"
     if args.obs_exchange == "peer":
         gath = PeerObsGatherer(world, np.asarray(feet, np.int32), force=args.force_collective, no_wait=args.peer_no_wait)
     else:
-        gath = ObsGatherer(N, obs_dim, dev, overlap=args.overlap_collective, force=args.force_collective)
+        gath = ObsGatherer(N, obs_dim, dev, overlap=args.overlap_collective, force=args.force_collective, pipeline_world=world if pipelined else None)
     obs_b, nbuf = gath.local_bufs, gath.nbuf
     feet_idx = np.asarray(feet, np.int32)
     reset = not args.no_reset
@@ -508,9 +514,11 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     drain = gath.drain
 
     def track_ages():                       # untimed passes only: age += 1, reset envs start again at 0
+        world.get_stream()                  # (torch's kernels read the step's done flags on the borrowed stream: joins a pipelined step first)
         age_d.add_(1).mul_(1 - done_d.to(torch.int32))
 
     # ---- untimed: pre-roll into the stationary regime, then the caller's warm-up
+    world.set_step_pipelining(pipelined)
     kstep = 0
     for _ in range(args.preroll + args.warmup):
         control_step(kstep)
@@ -561,8 +569,10 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     for _ in range(SAMPLE_LAUNCHES):
         control_step(kstep)
         if reset:
-            track_ages()
+            track_ages()                    # (joins: the sampling pass's launches do not overlap, their brackets are the kernel's own duration)
             resets.append(done_d.sum())
+        else:
+            world.get_stream()
         kstep += 1
     drain()
     torch.cuda.synchronize()
@@ -578,6 +588,30 @@ def measure(args, rank, local_rank, world_size, dev, coll):
         torch.cuda.synchronize()
         bracket_overhead_ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
 
+    # ---- the same workload with every launch waiting for the one before it (rsb_set_step_pipelining off): same bracket, same number of steps
+    lockstep = None
+    if pipelined:
+        world.set_step_pipelining(False)
+        for _ in range(max(5, args.warmup // 4)):
+            control_step(kstep)
+            kstep += 1
+        drain()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0l = time.perf_counter()
+        for _ in range(args.steps):
+            control_step(kstep)
+            kstep += 1
+        drain()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tl = torch.tensor([time.perf_counter() - t0l], dtype=torch.float64, device=dev)
+        if world_size > 1:
+            dist.all_reduce(tl, op=dist.ReduceOp.MAX)
+        lockstep = float(tl.item())
+        world.set_step_pipelining(True)
     env_steps_per_step = N * workload.SUBSTEPS
     total_env_steps = world_size * env_steps_per_step * args.steps
     value = total_env_steps / elapsed
@@ -622,6 +656,16 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                               "sampling pass that continues the timed region's sequence; an empty event pair on the same stream is subtracted",
                     "algorithmic_bytes_per_env_step": bytes_per_env_step,
                     "algorithmic_bytes_per_launch": bytes_per_env_step * env_steps_per_step, "valu_issue": valu}
+            if pipelined:
+                # `achieved` above is the contract's figure (algorithmic bytes per launch / the kernel's own launch duration: the sampling
+                # pass joins after every step, its launches do not overlap).  In the timed region two launches are in flight: a launch
+                # completes every ms_per_step, and takes start -> end what the timed region's brackets say (waiting for slots included)
+                eff_ms = elapsed / args.steps * 1e3
+                ach_p = bytes_per_env_step * env_steps_per_step / (eff_ms * 1e-3) / 1e9
+                roof["pipelined"] = {"effective_ms_per_launch": eff_ms, "achieved": ach_p, "frac": ach_p / HBM_PEAK_GBS,
+                                     "launch_start_to_end_ms": roof["timed_region_brackets"]["kernel_ms_mean"],
+                                     "note": "timed region: consecutive launches overlap (two in flight); `achieved` / `frac` of the enclosing object are per "
+                                             "launch on the kernel's own duration (sampling pass, one launch at a time, the pipelined kernel instance)"}
         age_pct = [int(x) for x in np.percentile(ages, [10, 50, 90, 99])] if reset else None
         out = {
             "metric": recipe.metric,
@@ -653,20 +697,34 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                                    "warm_start": True},
                 "self_collision": {"enabled": not args.no_self_collision, "candidate_pairs": int(len(world.self_collision_pairs()))},
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
+                "step_pipelining": ("on: consecutive control-step launches overlap at workgroup granularity (rsb_set_step_pipelining; results bit-identical to "
+                                    "lock-step, tests/test_gpu_pipeline.py); `lockstep` = the same steps with every launch waiting for the one before it"
+                                    if pipelined else "off (--lockstep)" if args.lockstep else "off (the peer-mapped exchange has no pipelined kernel class)"),
                 "obs_all_gather": gath.describe(),
             },
             "roofline": roof,
+            "lockstep": ({"value": total_env_steps / lockstep, "unit": "env-steps/s", "ms_per_step": lockstep / args.steps * 1e3, "steps": args.steps,
+                          "what": "rsb_set_step_pipelining off, same bracket: every launch waits for the slowest wave of the one before it (what a caller "
+                                  "gets that consumes each step's output before issuing the next step, e.g. a policy in the loop)"} if lockstep else None),
             "build": {"source_hash": world.L.rsb_source_hash().decode(), "library": os.path.relpath(os.path.realpath(__import__("raisimlib_amd")._capi.LIB_PATH), ROOT)},
             "host_enqueue_ms_per_step": t_enqueued / args.steps * 1e3,
             "state_at_end": {"solver_iters_mean": float(iters.mean()), "solver_iters_max": int(iters.max()),
                              "contacts_per_env": float(counts.mean()), "base_height_mean": float(q_end[:, 2].mean())},
         }
         if world_size == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(recipe, args.max_iter, reset, args.cpu_seconds, q_start, u_start,
-                                               gc0.astype(np.float32).astype(np.float64), gv0, step_start,
-                                               self_collision=not args.no_self_collision)
+            # the CPU leg runs AFTER every GPU leg of the run (main): 16 busy threads exhaust the box's CPU quota, and a throttled host thread
+            # cannot feed a 2 ms timed region (measured: the secondary configurations lost up to 30 % at --steps 20 behind a CPU leg)
+            cpu_seconds, max_iter, nsc = args.cpu_seconds, args.max_iter, not args.no_self_collision
+            gcf = gc0.astype(np.float32).astype(np.float64)
+            out["_cpu_leg"] = lambda: cpu_baseline(recipe, max_iter, reset, cpu_seconds, q_start, u_start, gcf, gv0, step_start, self_collision=nsc)
     world.close()
     return out
+
+
+def finish_cpu_leg(o):
+    leg = o.pop("_cpu_leg", None) if o else None
+    if leg is not None:
+        o["cpu_baseline"] = leg()
 
 
 def main():
@@ -700,21 +758,28 @@ def main():
 
     out = measure(args, rank, local_rank, world_size, dev, coll)
     default_run = (world_size == 1 and args.config == 2 and not args.no_secondary and not args.no_cpu and args.envs_per_gpu == ENVS_PER_GPU
-                   and not (args.early_termination or args.no_reset or args.max_iter or args.lanes_per_env or args.no_self_collision or args.force_collective))
+                   and not (args.early_termination or args.no_reset or args.max_iter or args.lanes_per_env or args.no_self_collision or args.force_collective or args.lockstep))
     if rank == 0 and default_run:
         # what the driver's default run also records: the other single-GPU configurations of BASELINE.json with
         # the same --steps / --warmup, and the headline workload through the reference's own boundary
         import copy
         out["secondary"] = {}
-        for cfg in (3, 5):
+        second = {}
+        for cfg in (3, 5):          # the GPU legs first, ...
             a2 = copy.copy(args)
             a2.config, a2.cpu_seconds = cfg, min(args.cpu_seconds, 7.0)
             try:
-                o2 = measure(a2, rank, local_rank, world_size, dev, coll)
+                second[cfg] = measure(a2, rank, local_rank, world_size, dev, coll)
+            except Exception as e:      # a secondary line must never take the headline down
+                out["secondary"][f"config{cfg}"] = {"error": f"{type(e).__name__}: {e}"}
+        finish_cpu_leg(out)         # ... then the CPU legs
+        for cfg, o2 in second.items():
+            try:
+                finish_cpu_leg(o2)
                 r2, c2 = o2["roofline"], o2.get("cpu_baseline") or {}
                 out["secondary"][f"config{cfg}"] = {
                     "metric": o2["metric"], "value": o2["value"], "unit": o2["unit"], "steps": o2["steps"], "warmup": o2["warmup"], "ms_per_step": o2["ms_per_step"],
-                    "kernel_ms_mean": r2.get("kernel_ms_mean"), "roofline": {k: r2.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch")},
+                    "lockstep_value": (o2.get("lockstep") or {}).get("value"), "kernel_ms_mean": r2.get("kernel_ms_mean"), "roofline": {k: r2.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch")},
                     "cpu_baseline": {k: c2.get(k) for k in ("value", "unit", "cores", "kind", "sample")} if c2 else None,
                     "workload": o2["config"]["workload"], "regime": o2["config"]["regime"], "state_at_end": o2["state_at_end"]}
             except Exception as e:      # a secondary line must never take the headline down
@@ -723,6 +788,7 @@ def main():
             out["boundary_template_path"] = template_path(args.envs_per_gpu, max(args.steps // 4, 20))
         except Exception as e:
             out["boundary_template_path"] = {"error": f"{type(e).__name__}: {e}"}
+    finish_cpu_leg(out)
     if coll:
         dist.destroy_process_group()
     if rank == 0:

@@ -239,10 +239,13 @@ int rsb_set_step_pipelining(rsb_world* w, int on);
  *   rsb_step_pipeline_publish(w, stream)     `stream` waits for the most recent pipelined control step (and nothing else of the pipeline);
  *   rsb_step_pipeline_wait_event(w, event)   the NEXT control step additionally waits for `event` (a hipEvent_t recorded by the caller, e.g.
  *                                            behind the collective that still reads the buffer this step overwrites).
- * Neither joins.  No pipelined step in flight: publish is a no-op (the world's stream orders everything), the event is honoured all the same. */
+ * Neither joins.  No pipelined step in flight (pipelining off, or just joined): `stream` waits for the world's stream instead, the event is
+ * honoured by the next launch all the same - a caller can use the pair unconditionally. */
 int rsb_step_pipeline_publish(rsb_world* w, void* hip_stream);
 int rsb_step_pipeline_wait_event(rsb_world* w, void* hip_event);
-/* pipelined launches enqueued so far and the number of times other calls joined them (diagnostics) */
+/* pipelined launches enqueued so far and the number of times other calls joined them (diagnostics).  Returns 1 instead of RSB_OK when the
+ * library found no two streams whose kernels run concurrently (HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, default 4; a
+ * probe picks the pair when the pipeline is first used): results are the same, the launches run in order */
 int rsb_step_pipelining_stats(rsb_world* w, long long* launches, long long* joins);
 /* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
  * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */

@@ -132,14 +132,18 @@ struct rsb_world {
   bool pipe_on = false, pipe_active = false;
   hipStream_t pipe_stream[2] = {nullptr, nullptr};
   hipEvent_t pipe_ev[3] = {nullptr, nullptr, nullptr};   // join events of the two streams, fork event of the world's stream
-  int pipe_next = 0, pipe_seq = 0, pipe_blocks = 0;
-  unsigned long long pipe_wg_total = 0;                  // workgroups of all pipelined launches so far (== *d_pipe_started once they have all started)
+  int pipe_next = 0, pipe_blocks = 0;
+  unsigned long long pipe_n = 0;                         // pipelined launches since the fork
+  unsigned long long pipe_wg_total = 0;                  // their workgroups (== *d_pipe_started once they have all started)
+  unsigned pipe_seq = 0;                                 // sequence number of the last pipelined launch (published by its workgroups)
   unsigned long long* d_pipe_started = nullptr;
-  int* d_pipe_prog = nullptr;
+  int* d_pipe_prog = nullptr;                            // [pipe_blocks]
   hipStream_t launch_stream = nullptr;                   // stream of the step launch being enqueued (do_integrate)
   hipStream_t pipe_last = nullptr;                       // private stream of the most recent pipelined launch
   hipEvent_t pipe_dep = nullptr, pipe_pub = nullptr;     // rsb_step_pipeline_wait_event: the next pipelined launch waits for it; event of rsb_step_pipeline_publish
   long long pipe_launches = 0, pipe_joins = 0;
+  bool pipe_overlap = true;                              // the probe found two streams whose kernels run concurrently (pipe_make_streams)
+  int pipe_probe_rejected = 0;
 };
 
 namespace {
@@ -158,6 +162,46 @@ int pipe_join(rsb_world* w) {
 hipStream_t stream_of(rsb_world* w) {
   if (w->pipe_active) (void)pipe_join(w);
   return w->stream;
+}
+// Do kernels on streams a and b run CONCURRENTLY?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two
+// streams on one queue run in order: the pipeline would be correct but gain nothing (measured: 107 M instead of 160 M env-steps/s when the
+// second world of a process drew an aliased pair, profiles/r04_ab_log.txt).  Probe: a kernel on a waits (<= ~2 ms) for a flag that a kernel on b sets.
+__global__ void pipe_probe_wait_kernel(int* flag) {
+  const long long t0 = wall_clock64();
+  int seen = 0;
+  while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < 200000) __builtin_amdgcn_s_sleep(32);
+  flag[1] = seen ? 1 : 2;
+}
+__global__ void pipe_probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+int streams_run_concurrently(hipStream_t a, hipStream_t b, int* d_flag, bool* yes) {
+  HIP_TRY(hipMemset(d_flag, 0, 2 * sizeof(int)));
+  hipLaunchKernelGGL(pipe_probe_wait_kernel, dim3(1), dim3(1), 0, a, d_flag);
+  hipLaunchKernelGGL(pipe_probe_set_kernel, dim3(1), dim3(1), 0, b, d_flag);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(a));
+  HIP_TRY(hipStreamSynchronize(b));
+  int h[2] = {0, 0};
+  HIP_TRY(hipMemcpy(h, d_flag, sizeof h, hipMemcpyDeviceToHost));
+  *yes = h[1] == 1;
+  return RSB_OK;
+}
+// the two private streams of the pipeline: a pair that the probe has seen overlap (up to 8 candidates for the second one)
+int pipe_make_streams(rsb_world* w) {
+  if (w->pipe_stream[0]) return RSB_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&w->pipe_stream[0], hipStreamNonBlocking));
+  std::vector<hipStream_t> rejected;
+  int st = RSB_OK;
+  for (int attempt = 0; attempt < 8 && st == RSB_OK && !w->pipe_stream[1]; ++attempt) {
+    hipStream_t c = nullptr;
+    if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+    bool yes = false;
+    st = streams_run_concurrently(w->pipe_stream[0], c, reinterpret_cast<int*>(w->d_pipe_started) + 8, &yes);
+    if (st == RSB_OK && yes) w->pipe_stream[1] = c; else rejected.push_back(c);
+  }
+  w->pipe_probe_rejected = (int)rejected.size();
+  if (st == RSB_OK && !w->pipe_stream[1] && !rejected.empty()) { w->pipe_stream[1] = rejected.back(); rejected.pop_back(); w->pipe_overlap = false; }   // correct, but in order
+  for (hipStream_t c : rejected) (void)hipStreamDestroy(c);      // (after the search: a destroyed stream's queue slot would be handed out again)
+  return st;
 }
 __global__ void pipe_gate_kernel(const unsigned long long* started, unsigned long long target) {
   int spins = 0;      // (~2 s: a launch that never arrives would be a bug of the host side - trap rather than hang the device)
@@ -615,30 +659,31 @@ int do_integrate(rsb_world* w, int nsub) {
       (void)stream_of(w);
       HIP_TRY(hipStreamSynchronize(w->stream));
       if (w->d_pipe_prog) HIP_TRY(hipFree(w->d_pipe_prog));
-      w->d_pipe_prog = nullptr;
+      w->d_pipe_prog = nullptr; w->pipe_blocks = 0;
       HIP_TRY(hipMalloc(&w->d_pipe_prog, (size_t)blocks * sizeof(int)));
+      if (!w->d_pipe_started) HIP_TRY(hipMalloc(&w->d_pipe_started, 64));
       HIP_TRY(hipMemset(w->d_pipe_prog, 0, (size_t)blocks * sizeof(int)));
-      if (!w->d_pipe_started) { HIP_TRY(hipMalloc(&w->d_pipe_started, sizeof(unsigned long long))); }
-      HIP_TRY(hipMemset(w->d_pipe_started, 0, sizeof(unsigned long long)));
-      w->pipe_wg_total = 0; w->pipe_blocks = blocks;
-      for (int i = 0; i < 2; ++i) if (!w->pipe_stream[i]) HIP_TRY(hipStreamCreateWithFlags(&w->pipe_stream[i], hipStreamNonBlocking));
+      HIP_TRY(hipMemset(w->d_pipe_started, 0, 64));
+      w->pipe_blocks = blocks; w->pipe_wg_total = 0; w->pipe_seq = 0;
+      { const int ps = pipe_make_streams(w); if (ps != RSB_OK) return ps; }
+      HIP_TRY(hipMemset(w->d_pipe_started, 0, 64));
       for (int i = 0; i < 3; ++i) if (!w->pipe_ev[i]) HIP_TRY(hipEventCreateWithFlags(&w->pipe_ev[i], hipEventDisableTiming));
     }
-    ls = w->pipe_stream[w->pipe_next];
-    w->pipe_next ^= 1;
     a.pipe_prog = w->d_pipe_prog; a.pipe_started = w->d_pipe_started;
-    if (!w->pipe_active) {     // fork: both streams run after everything that is on the world's stream now; nothing to wait for on the device
+    if (!w->pipe_active) {
+      // fork: both streams run after everything that is on the world's stream now; nothing is in flight, the first launch waits for nobody
+      // (sequence numbers and the started count carry on: every earlier pipelined launch has completed)
       HIP_TRY(hipEventRecord(w->pipe_ev[2], w->stream));
       HIP_TRY(hipStreamWaitEvent(w->pipe_stream[0], w->pipe_ev[2], 0));
       HIP_TRY(hipStreamWaitEvent(w->pipe_stream[1], w->pipe_ev[2], 0));
-      w->pipe_active = true;
-      a.pipe_wait_on = 0;
-    } else {
-      a.pipe_wait_on = 1; a.pipe_wait = w->pipe_seq;
-      hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total);
+      w->pipe_n = 0;
     }
+    ls = w->pipe_stream[w->pipe_next];
+    a.pipe_wait_on = w->pipe_n > 0 ? 1 : 0;
+    a.pipe_wait = (int)w->pipe_seq; a.pipe_seq = (int)(w->pipe_seq + 1u);
+    if (a.pipe_wait_on)
+      hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total);
     if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }   // rsb_step_pipeline_wait_event
-    a.pipe_seq = (int)((unsigned)w->pipe_seq + 1u);
     HIP_TRY(hipGetLastError());
   } else {
     ls = stream_of(w);
@@ -668,8 +713,9 @@ int do_integrate(rsb_world* w, int nsub) {
   }
   if (st != RSB_OK) return st;
   if (pipelined) {   // (only a launch that is on its way counts: the gate of the next one waits for this one's workgroups)
-    w->pipe_seq = a.pipe_seq;
-    w->pipe_wg_total += (unsigned long long)((w->N + (64 / lpe) - 1) / (64 / lpe));
+    w->pipe_active = true;
+    ++w->pipe_n; w->pipe_next ^= 1; w->pipe_seq = (unsigned)a.pipe_seq;
+    w->pipe_wg_total += (unsigned long long)w->pipe_blocks;
     w->pipe_last = ls;
     ++w->pipe_launches;
   }
@@ -961,9 +1007,10 @@ int rsb_set_step_pipelining(rsb_world* w, int on) {
 int rsb_step_pipeline_publish(rsb_world* w, void* hip_stream) {
   if (!w) { rsb::set_error("rsb_step_pipeline_publish: null world"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));
-  if (!w->pipe_active || !w->pipe_last) return RSB_OK;       // nothing in flight: the world's stream already orders everything
   if (!w->pipe_pub) HIP_TRY(hipEventCreateWithFlags(&w->pipe_pub, hipEventDisableTiming));
-  HIP_TRY(hipEventRecord(w->pipe_pub, w->pipe_last));
+  const bool in_flight = w->pipe_active && w->pipe_last;
+  if (!in_flight && (hipStream_t)hip_stream == w->stream) return RSB_OK;       // nothing in flight and the world's own stream: already ordered
+  HIP_TRY(hipEventRecord(w->pipe_pub, in_flight ? w->pipe_last : w->stream));   // (no pipelined step in flight: the last step is on the world's stream)
   HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, w->pipe_pub, 0));
   return RSB_OK;
 }
@@ -976,7 +1023,7 @@ int rsb_step_pipelining_stats(rsb_world* w, long long* launches, long long* join
   if (!w) return RSB_E_INVALID;
   if (launches) *launches = w->pipe_launches;
   if (joins) *joins = w->pipe_joins;
-  return RSB_OK;
+  return w->pipe_overlap ? RSB_OK : 1;
 }
 int rsb_set_integration_scheme(rsb_world* w, int scheme) {
   if (!w) return RSB_E_INVALID;

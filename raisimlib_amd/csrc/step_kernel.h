@@ -516,6 +516,9 @@ __device__ __host__ constexpr int gv2sp(int a) { return a < 3 ? a + 3 : a - 3; }
 // 217 spilled SGPRs and ~1000 v_readlane reloads in round 1's ISA - each one an issue slot of the one wave a SIMD holds.
 typedef const __attribute__((address_space(4))) StepArgs* KArgs;
 __device__ __forceinline__ KArgs rsb_cold(KArgs p) { asm volatile("" : "+s"(p)); return p; }
+#ifndef RSB_X_PIPE_FENCE
+#define RSB_X_PIPE_FENCE 0   // experiment switch (profiles/r04_ab_log.txt): 1 / 2 replace the agent-scope release / acquire by cheaper, INCORRECT sequences to price the fences
+#endif
 #define RSB_ARGS(name) const __attribute__((address_space(4))) StepArgs& name = *rsb_cold(ka)
 
 #define RSB_STAMP(i) \
@@ -604,25 +607,28 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   // (profiles/r02_traffic_calibration.txt: 1.4x over-fetch of the 76-B rows without it)
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  if constexpr (PIPE) {
+    // pipelined control steps (StepArgs::pipe_prog): this workgroup's envs belong to workgroup `blk` of the previous launch until that one has
+    // published them; then an acquire at agent scope (the two workgroups sit on different XCDs, i.e. behind different L2s)
+    if (lane == 0) __hip_atomic_fetch_add(a.pipe_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.pipe_wait_on) {
+      int spins = 0;       // (a predecessor that never publishes would be a bug of the host side: trap after ~2 s rather than hang the device)
+      while (__hip_atomic_load(a.pipe_prog + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_wait < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 23)) __builtin_trap();
+      }
+    }
+#if RSB_X_PIPE_FENCE == 0
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#elif RSB_X_PIPE_FENCE == 1
+    asm volatile("buffer_inv sc1" ::: "memory");      // (measurement only: the vector L1 alone)
+#endif
+  }
   int env = blk * EPW + el;
   bool env_valid = env < a.N;
   if (!env_valid) env = a.N - 1;
   // masked launch (per-env raisim::World views, rsb_integrate_masked): a masked-off env runs along but writes nothing back
   if (a.env_mask && !a.env_mask[env]) env_valid = false;
-  // pipelined control steps (StepArgs::pipe_prog): this workgroup's envs belong to workgroup `blk` of the previous launch until that one has
-  // published them; then an acquire at agent scope (the two workgroups may sit on different XCDs, i.e. behind different L2s)
-  if constexpr (PIPE) {
-    if (lane == 0) __hip_atomic_fetch_add(a.pipe_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.pipe_wait_on) {
-      int spins = 0;       // (a predecessor that never publishes would be a bug of the host side: trap after ~2 s rather than hang the device)
-      while (__hip_atomic_load(a.pipe_prog + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_wait < 0) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1 << 22)) __builtin_trap();
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-
   // model dimensions travel in the kernel arguments (read through a.model they cost one more dependent load before anything can start)
   const int nb = a.nb, nq = a.nq, nv = a.nv, depth = a.depth, ncol = a.ncol, cw = a.cw;
   const bool fixed_base = a.fixed_base != 0;
@@ -2441,7 +2447,11 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
     }
   }
   if constexpr (PIPE) {   // pipelined control steps: everything this workgroup wrote is released, then its envs are handed to the next launch
+#if RSB_X_PIPE_FENCE == 0
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (measurement only: no L2 write-back - WRONG across XCDs)
+#endif
     int pb = blockIdx.x;
     if ((gridDim.x & 7) == 0) pb = (pb & 7) * (gridDim.x >> 3) + (pb >> 3);
     if (lane == 0) __hip_atomic_store(ae.pipe_prog + pb, ae.pipe_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

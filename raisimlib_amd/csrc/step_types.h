@@ -174,11 +174,14 @@ struct StepArgs {
   // two ends of every capsule / cylinder of the model (device memory); hm_capsule = 0: off
   int hm_capsule;
   const int32_t* hm_cap;
-  // pipelined control steps (rsb_set_step_pipelining): consecutive launches alternate between two streams and overlap on the device; workgroup b of
-  // launch k + 1 starts its env block when workgroup b of launch k has published pipe_seq in pipe_prog[b].  pipe_prog == nullptr: a plain launch
-  unsigned long long* pipe_started;      // workgroups of pipelined launches that have started (the gate before the next launch waits for a full launch)
+  // pipelined control steps (rsb_set_step_pipelining; classes | 16): consecutive launches alternate between two streams and overlap on the device;
+  // workgroup b of launch k + 1 starts its env block when workgroup b of launch k has published pipe_seq in pipe_prog[b] (release / acquire at
+  // agent scope: the dispatcher's round-robin over the XCDs starts somewhere else in every launch, so the two workgroups sit behind different
+  // L2s: profiles/r04_ubench_xcc_map.txt).  pipe_prog == nullptr: a plain launch.  (Measured alternative, not kept: a ticket queue that lets the
+  // j-th workgroup to arrive continue the j-th block to finish - 1-3 % slower than the fixed assignment, profiles/r04_ab_log.txt.)
+  unsigned long long* pipe_started;      // workgroups of pipelined launches that have started since the fork (the gate of the next launch waits for a full launch)
   int* pipe_prog;                        // [blocks] sequence number of the last pipelined launch whose workgroup b has finished
-  int pipe_wait_on, pipe_wait, pipe_seq; // wait for pipe_prog[b] == pipe_wait (unless !pipe_wait_on); publish pipe_seq
+  int pipe_wait_on, pipe_wait, pipe_seq; // wait for pipe_prog[b] >= pipe_wait (unless !pipe_wait_on: first launch after a fork); publish pipe_seq
 #ifdef RSB_X_ARGPAD
   char x_pad[RSB_X_ARGPAD];
 #endif

@@ -12,6 +12,9 @@ exactly the rows of the unsharded one (tests/test_distributed_gloo.py asserts it
   in line      the all-gather of control step k is enqueued behind the step's kernel on the same stream (default);
   overlapped   double-buffered: the all-gather of step k runs on the backend's own stream while the kernel of step k+1
                writes the other buffer; a buffer is only rewritten after the gather that reads it has finished.
+  pipelined    (pipeline_world = the BatchedWorld whose control steps are pipelined, rsb_set_step_pipelining) double-buffered on a stream of
+               its own: the gather of step k is ordered behind step k ALONE (rsb_step_pipeline_publish), step k + 2 behind the gather that
+               still reads its buffer (rsb_step_pipeline_wait_event); the pipeline of control steps is never joined.
 The C++ host side has the same collective without Python: rsb_comm_* / rsb_allgather_obs in include/rsb.h.
 """
 import torch
@@ -37,10 +40,15 @@ def gather_obs(local_obs: torch.Tensor, out: torch.Tensor = None) -> torch.Tenso
 class ObsGatherer:
     """Buffers + issue policy of the per-control-step obs all-gather (see the module docstring)."""
 
-    def __init__(self, n_local, obs_dim, device, overlap=False, force=False, dtype=torch.float32):
+    def __init__(self, n_local, obs_dim, device, overlap=False, force=False, dtype=torch.float32, pipeline_world=None):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
-        self.nbuf = 2 if (self.active and overlap) else 1
+        self.pipe = pipeline_world if self.active else None
+        if self.pipe is not None:
+            self.side = torch.cuda.Stream(device=device)
+            self.done = [torch.cuda.Event(), torch.cuda.Event()]     # recorded behind the gather that reads buffer b
+            self.used = [False, False]
+        self.nbuf = 2 if (self.active and (overlap or self.pipe is not None)) else 1
         self.local_bufs = [torch.empty((n_local, obs_dim), dtype=dtype, device=device) for _ in range(self.nbuf)]
         self.all_bufs = ([torch.empty((self.world * n_local, obs_dim), dtype=dtype, device=device) for _ in range(self.nbuf)]
                          if self.active else self.local_bufs)
@@ -60,6 +68,10 @@ class ObsGatherer:
     def acquire(self, k):
         """Before step k's kernel is enqueued: wait (stream-side) for the gather that still reads this slot."""
         b = self.slot(k)
+        if self.pipe is not None:
+            if self.used[b]:
+                self.pipe.step_pipeline_wait_event(self.done[b].cuda_event)
+            return
         if self.pending[b] is not None:
             self.pending[b].wait()
             self.pending[b] = None
@@ -69,12 +81,22 @@ class ObsGatherer:
         if not self.active:
             return
         b = self.slot(k)
+        if self.pipe is not None:
+            self.pipe.step_pipeline_publish(self.side.cuda_stream)
+            with torch.cuda.stream(self.side):
+                dist.all_gather_into_tensor(self.all_bufs[b], self.local_bufs[b])
+                self.done[b].record(self.side)
+            self.used[b] = True
+            return
         if self.nbuf == 2:
             self.pending[b] = dist.all_gather_into_tensor(self.all_bufs[b], self.local_bufs[b], async_op=True)
         else:
             dist.all_gather_into_tensor(self.all_bufs[b], self.local_bufs[b])
 
     def drain(self):
+        if self.pipe is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+            return
         for b in range(self.nbuf):
             if self.pending[b] is not None:
                 self.pending[b].wait()
@@ -83,6 +105,8 @@ class ObsGatherer:
     def describe(self):
         if not self.active:
             return "none (1 rank)"
+        if self.pipe is not None:
+            return "on a stream of its own behind each pipelined control step (double-buffered; publish / wait-event, the pipeline is never joined)"
         return "overlapped with the next control step (double-buffered)" if self.nbuf == 2 else "in line"
 
 

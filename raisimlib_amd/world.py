@@ -247,7 +247,10 @@ class BatchedWorld:
 
     def step_pipelining_stats(self):
         a, b = C.c_longlong(0), C.c_longlong(0)
-        check(self.L.rsb_step_pipelining_stats(self.handle, C.byref(a), C.byref(b)), "rsb_step_pipelining_stats")
+        st = self.L.rsb_step_pipelining_stats(self.handle, C.byref(a), C.byref(b))
+        if st not in (0, 1):
+            check(st, "rsb_step_pipelining_stats")
+        self.pipeline_overlaps = st == 0        # False: no two streams on different hardware queues were found (correct, but in order)
         return int(a.value), int(b.value)
 
     def set_capsule_contacts(self, on=True):
@@ -316,6 +319,10 @@ class BatchedWorld:
 
     def synchronize(self):
         check(self.L.rsb_synchronize(self.handle), "rsb_synchronize")
+
+    def get_stream(self):
+        """The world's stream (hipStream_t as an integer).  Joins pipelined control steps first: work enqueued on it afterwards sees them."""
+        return self.L.rsb_get_stream(self.handle) or 0
 
     def set_stream(self, hip_stream_ptr):
         check(self.L.rsb_set_stream(self.handle, C.c_void_p(hip_stream_ptr)), "rsb_set_stream")
