@@ -144,6 +144,8 @@ struct rsb_world {
   long long pipe_launches = 0, pipe_joins = 0;
   bool pipe_overlap = true;                              // the probe found two streams whose kernels run concurrently (pipe_make_streams)
   int pipe_probe_rejected = 0;
+  int pipe_xcds = 0;                                     // XCDs the dispatcher deals workgroups to round-robin (0: pattern not recognised -> agent-scope hand-over)
+  unsigned pipe_xcc_uses = 0;                            // pipelined launches since the counters were cleared
 };
 
 namespace {
@@ -195,13 +197,44 @@ int pipe_make_streams(rsb_world* w) {
     hipStream_t c = nullptr;
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
     bool yes = false;
-    st = streams_run_concurrently(w->pipe_stream[0], c, reinterpret_cast<int*>(w->d_pipe_started) + 8, &yes);
+    st = streams_run_concurrently(w->pipe_stream[0], c, reinterpret_cast<int*>(w->d_pipe_started) + 8, &yes);   // (+32 B: the probe's two flags)
     if (st == RSB_OK && yes) w->pipe_stream[1] = c; else rejected.push_back(c);
   }
   w->pipe_probe_rejected = (int)rejected.size();
   if (st == RSB_OK && !w->pipe_stream[1] && !rejected.empty()) { w->pipe_stream[1] = rejected.back(); rejected.pop_back(); w->pipe_overlap = false; }   // correct, but in order
   for (hipStream_t c : rejected) (void)hipStreamDestroy(c);      // (after the search: a destroyed stream's queue slot would be handed out again)
   return st;
+}
+// How many XCDs does the dispatcher deal this device's workgroups to, and is it a plain round-robin?  (MI355X in SPX mode: 8, and it is - but the
+// XCD of workgroup 0 differs from launch to launch, profiles/r04_ubench_xcc_map.txt.)  Returns 0 when the pattern is anything else.
+__global__ void pipe_xcc_probe_kernel(int* out) {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)(x & 15u);
+}
+int pipe_probe_xcds(rsb_world* w, int* n_xcds) {
+  *n_xcds = 0;
+  static const bool off = std::getenv("RSB_PIPE_XCD") && std::atoi(std::getenv("RSB_PIPE_XCD")) == 0;   // A/B switch: agent-scope hand-over everywhere
+  if (off) return RSB_OK;
+  constexpr int G = 256;
+  int* d = nullptr;
+  HIP_TRY(hipMalloc(&d, G * sizeof(int)));
+  int h[G];
+  bool ok = true;
+  int nx = 0;
+  for (int rep = 0; rep < 2 && ok; ++rep) {
+    hipLaunchKernelGGL(pipe_xcc_probe_kernel, dim3(G), dim3(64), 0, w->pipe_stream[rep], d);
+    if (hipStreamSynchronize(w->pipe_stream[rep]) != hipSuccess || hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+    int mx = 0;
+    for (int b = 0; b < G; ++b) mx = std::max(mx, h[b]);
+    const int n = mx + 1;
+    ok = n >= 1 && n <= 16 && G % n == 0 && (rep == 0 || n == nx);
+    for (int b = 0; ok && b < G; ++b) ok = h[b] == (h[0] + b) % n;
+    nx = n;
+  }
+  (void)hipFree(d);
+  if (ok) *n_xcds = nx;
+  return RSB_OK;
 }
 __global__ void pipe_gate_kernel(const unsigned long long* started, unsigned long long target) {
   int spins = 0;      // (~2 s: a launch that never arrives would be a bug of the host side - trap rather than hang the device)
@@ -661,12 +694,17 @@ int do_integrate(rsb_world* w, int nsub) {
       if (w->d_pipe_prog) HIP_TRY(hipFree(w->d_pipe_prog));
       w->d_pipe_prog = nullptr; w->pipe_blocks = 0;
       HIP_TRY(hipMalloc(&w->d_pipe_prog, (size_t)blocks * sizeof(int)));
-      if (!w->d_pipe_started) HIP_TRY(hipMalloc(&w->d_pipe_started, 64));
+      if (!w->d_pipe_started) HIP_TRY(hipMalloc(&w->d_pipe_started, 256));   // [0] started | +32 B: probe flags | +64 B: 16 per-XCD ticket counters
       HIP_TRY(hipMemset(w->d_pipe_prog, 0, (size_t)blocks * sizeof(int)));
-      HIP_TRY(hipMemset(w->d_pipe_started, 0, 64));
-      w->pipe_blocks = blocks; w->pipe_wg_total = 0; w->pipe_seq = 0;
-      { const int ps = pipe_make_streams(w); if (ps != RSB_OK) return ps; }
-      HIP_TRY(hipMemset(w->d_pipe_started, 0, 64));
+      HIP_TRY(hipMemset(w->d_pipe_started, 0, 256));
+      w->pipe_blocks = blocks; w->pipe_wg_total = 0; w->pipe_seq = 0; w->pipe_xcc_uses = 0;
+      if (!w->pipe_stream[0]) {
+        const int ps = pipe_make_streams(w);
+        if (ps != RSB_OK) return ps;
+        const int px = pipe_probe_xcds(w, &w->pipe_xcds);
+        if (px != RSB_OK) return px;
+      }
+      HIP_TRY(hipMemset(w->d_pipe_started, 0, 256));
       for (int i = 0; i < 3; ++i) if (!w->pipe_ev[i]) HIP_TRY(hipEventCreateWithFlags(&w->pipe_ev[i], hipEventDisableTiming));
     }
     a.pipe_prog = w->d_pipe_prog; a.pipe_started = w->d_pipe_started;
@@ -681,6 +719,9 @@ int do_integrate(rsb_world* w, int nsub) {
     ls = w->pipe_stream[w->pipe_next];
     a.pipe_wait_on = w->pipe_n > 0 ? 1 : 0;
     a.pipe_wait = (int)w->pipe_seq; a.pipe_seq = (int)(w->pipe_seq + 1u);
+    a.pipe_xcds = (w->pipe_xcds > 0 && blocks % w->pipe_xcds == 0) ? w->pipe_xcds : 0;
+    a.pipe_xcc_ctr = reinterpret_cast<unsigned*>(w->d_pipe_started) + 16;
+    a.pipe_xcc_base = a.pipe_xcds > 0 ? w->pipe_xcc_uses * (unsigned)(blocks / a.pipe_xcds) : 0u;
     if (a.pipe_wait_on)
       hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total);
     if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }   // rsb_step_pipeline_wait_event
@@ -715,6 +756,7 @@ int do_integrate(rsb_world* w, int nsub) {
   if (pipelined) {   // (only a launch that is on its way counts: the gate of the next one waits for this one's workgroups)
     w->pipe_active = true;
     ++w->pipe_n; w->pipe_next ^= 1; w->pipe_seq = (unsigned)a.pipe_seq;
+    if (a.pipe_xcds > 0) ++w->pipe_xcc_uses;
     w->pipe_wg_total += (unsigned long long)w->pipe_blocks;
     w->pipe_last = ls;
     ++w->pipe_launches;

@@ -516,9 +516,6 @@ __device__ __host__ constexpr int gv2sp(int a) { return a < 3 ? a + 3 : a - 3; }
 // 217 spilled SGPRs and ~1000 v_readlane reloads in round 1's ISA - each one an issue slot of the one wave a SIMD holds.
 typedef const __attribute__((address_space(4))) StepArgs* KArgs;
 __device__ __forceinline__ KArgs rsb_cold(KArgs p) { asm volatile("" : "+s"(p)); return p; }
-#ifndef RSB_X_PIPE_FENCE
-#define RSB_X_PIPE_FENCE 0   // experiment switch (profiles/r04_ab_log.txt): 1 / 2 replace the agent-scope release / acquire by cheaper, INCORRECT sequences to price the fences
-#endif
 #define RSB_ARGS(name) const __attribute__((address_space(4))) StepArgs& name = *rsb_cold(ka)
 
 #define RSB_STAMP(i) \
@@ -608,21 +605,21 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
   if constexpr (PIPE) {
-    // pipelined control steps (StepArgs::pipe_prog): this workgroup's envs belong to workgroup `blk` of the previous launch until that one has
-    // published them; then an acquire at agent scope (the two workgroups sit on different XCDs, i.e. behind different L2s)
+    // pipelined control steps (StepArgs::pipe_prog).  The gate of the next launch counts the workgroups of this one that are on the chip.
+    // pipe_xcds > 0: the env block is chosen by the XCD this workgroup landed on (block = XCD x (blocks / XCDs) + a ticket of that XCD), so that
+    // every block is always processed behind the same L2 and the hand-over needs no L2 write-back (see the wait below)
     if (lane == 0) __hip_atomic_fetch_add(a.pipe_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.pipe_wait_on) {
-      int spins = 0;       // (a predecessor that never publishes would be a bug of the host side: trap after ~2 s rather than hang the device)
-      while (__hip_atomic_load(a.pipe_prog + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_wait < 0) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 23)) __builtin_trap();
-      }
+    if (a.pipe_xcds > 0) {
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 15u;
+      unsigned t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add(a.pipe_xcc_ctr + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_xcc_base;
+      t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+      const unsigned per = gridDim.x / (unsigned)a.pipe_xcds;
+      if (t >= per || xcc >= (unsigned)a.pipe_xcds) __builtin_trap();      // (the dispatcher deals workgroups round-robin: checked by the host's probe)
+      blk = (int)(xcc * per + t);
     }
-#if RSB_X_PIPE_FENCE == 0
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#elif RSB_X_PIPE_FENCE == 1
-    asm volatile("buffer_inv sc1" ::: "memory");      // (measurement only: the vector L1 alone)
-#endif
   }
   int env = blk * EPW + el;
   bool env_valid = env < a.N;
@@ -680,6 +677,21 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   const float* env_heights = a.heights;   // this env's height map (terrain curricula: rsb_set_heightmaps)
   if (a.hm_index && a.terrain_type == 1) env_heights += (size_t)a.hm_index[env] * a.hm_xs * a.hm_ys;
   float rq[2], rpt[2], ru[2], rdt[2], rtf[2], ract[2] = {0.f, 0.f}, ramean[2] = {0.f, 0.f}, wrec[8];
+  if constexpr (PIPE) {
+    // the envs belong to workgroup `blk` of the previous launch until that one has published them.  Then an acquire - of the vector L1 alone when
+    // the block stays on its XCD (same L2), at agent scope when the two workgroups may sit behind different L2s (the dispatcher's round-robin
+    // over the XCDs starts somewhere else in every launch: profiles/r04_ubench_xcc_map.txt).  (Staging the tables BEFORE this wait - they do not
+    // depend on the predecessor - measured 1.5 % slower: the state loads then no longer overlap the table copy.)
+    if (a.pipe_wait_on) {
+      int spins = 0;       // (a predecessor that never publishes would be a bug of the host side: trap after ~2 s rather than hang the device)
+      while (__hip_atomic_load(a.pipe_prog + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_wait < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 23)) __builtin_trap();
+      }
+    }
+    if (a.pipe_xcds > 0) asm volatile("buffer_inv sc1" ::: "memory");
+    else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   RSB_UNROLL for (int k = 0; k < 2; ++k) {
     const int i = s + k * LPE;
     rq[k] = rpt[k] = ru[k] = rdt[k] = rtf[k] = 0.f;
@@ -2447,14 +2459,9 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
     }
   }
   if constexpr (PIPE) {   // pipelined control steps: everything this workgroup wrote is released, then its envs are handed to the next launch
-#if RSB_X_PIPE_FENCE == 0
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (measurement only: no L2 write-back - WRONG across XCDs)
-#endif
-    int pb = blockIdx.x;
-    if ((gridDim.x & 7) == 0) pb = (pb & 7) * (gridDim.x >> 3) + (pb >> 3);
-    if (lane == 0) __hip_atomic_store(ae.pipe_prog + pb, ae.pipe_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ae.pipe_xcds > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (same XCD, same L2: the stores only have to have arrived there)
+    else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) __hip_atomic_store(ae.pipe_prog + blk, ae.pipe_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (PEER) if (ae.n_obs_peers > 0) {
     // publication (see StepArgs::obs_peer): this wave's rows are acknowledged, it checks in; the last wave of the launch stores the

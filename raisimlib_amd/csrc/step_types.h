@@ -182,6 +182,9 @@ struct StepArgs {
   unsigned long long* pipe_started;      // workgroups of pipelined launches that have started since the fork (the gate of the next launch waits for a full launch)
   int* pipe_prog;                        // [blocks] sequence number of the last pipelined launch whose workgroup b has finished
   int pipe_wait_on, pipe_wait, pipe_seq; // wait for pipe_prog[b] >= pipe_wait (unless !pipe_wait_on: first launch after a fork); publish pipe_seq
+  int pipe_xcds;                         // > 0: XCD-affine blocks (the device's XCD count; the grid is a multiple of it): block = XCD x (grid / XCDs) + ticket
+  unsigned* pipe_xcc_ctr;                // [16] tickets taken per XCD (monotonic)
+  unsigned pipe_xcc_base;                // their value at the start of this launch
 #ifdef RSB_X_ARGPAD
   char x_pad[RSB_X_ARGPAD];
 #endif

@@ -30,6 +30,13 @@ def test_bench_prints_the_contract_line(built_lib, config):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    # consecutive control steps are pipelined by default: the same line also carries the lock-step number (same bracket, pipelining off) and
+    # the roofline object says what its per-launch figures refer to
+    assert b["config"]["step_pipelining"].startswith("on") and b["lockstep"]["value"] > 1e6 and b["lockstep"]["steps"] == 6
+    assert abs(b["lockstep"]["value"] - 4096 * 4 * 6 / (b["lockstep"]["ms_per_step"] * 6 * 1e-3)) < 1e-3 * b["lockstep"]["value"]
+    assert abs(roof["effective_ms_per_launch"] - b["ms_per_step"]) < 1e-9 and roof["launches_in_flight"] > 0.5
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["effective_ms_per_launch"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    assert abs(roof["achieved_over_one_launch_duration"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms_mean"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
     cb = b["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cb, k
@@ -41,7 +48,7 @@ def test_bench_prints_the_contract_line(built_lib, config):
         for name in ("config3", "config5"):
             c = sec[name]
             assert "error" not in c, c
-            assert c["steps"] == 6 and c["warmup"] == 2 and c["value"] > 1e5 and c["kernel_ms_mean"] > 0 and c["roofline"]["frac"] > 0
+            assert c["steps"] == 6 and c["warmup"] == 2 and c["value"] > 1e5 and c["lockstep_value"] > 1e5 and c["kernel_ms_mean"] > 0 and c["roofline"]["frac"] > 0
             assert c["cpu_baseline"]["value"] > 0 and abs(c["value"] - 4096 * 4 * 6 / (c["ms_per_step"] * 6 * 1e-3)) < 1e-3 * c["value"]
         tp = b["boundary_template_path"]
         assert "error" not in tp, tp
@@ -57,8 +64,19 @@ def test_bench_collective_path_on_one_rank(built_lib):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp")
     assert r.returncode == 0, r.stderr[-2000:]
     b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert b["n_gpus"] == 1 and b["config"]["obs_all_gather"] != "none (1 rank)"
-    assert len(b["ms_per_step_by_rank"]) == 1 and b["value"] > 1e6
+    assert b["n_gpus"] == 1 and b["config"]["obs_all_gather"].startswith("on a stream of its own behind each pipelined control step")
+    assert len(b["ms_per_step_by_rank"]) == 1 and b["value"] > 1e6 and b["lockstep"]["value"] > 1e6
+
+
+def test_bench_lockstep_flag(built_lib):
+    """`--lockstep`: no pipelining anywhere, the all-gather in line on the launch stream (the line of rounds 1-3)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--preroll", "8",
+           "--force-collective", "--no-cpu", "--lockstep"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["config"]["step_pipelining"].startswith("off") and b["lockstep"] is None and "launches_in_flight" not in b["roofline"]
+    assert b["config"]["obs_all_gather"] == "in line" and b["value"] > 1e6
 
 
 def test_bench_peer_obs_exchange_on_one_rank(built_lib):
