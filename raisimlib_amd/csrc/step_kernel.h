@@ -2006,6 +2006,8 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
           };
           // contacts 0-4 straight: the launch lasts as long as its slowest wave, and that wave holds a five-contact env (a robot
           // on a knee); the usual four-contact waves finish a third earlier and can afford the one unused exchange
+          // (pipelined classes run at the MEAN wave; putting the fifth contact behind a test there measured +0.4 %, inside the noise of the
+          // loop's fetch-window phase: one code path for both)
           static_for<0, 5>(one);
           {
             if (ncw > 5) {

@@ -60,6 +60,22 @@ for c, name, abytes in ((2, "config2", 456.0), (3, "config3", 520.0), (5, "confi
     rows = [r for r in csv.DictReader(open(os.path.join(O, f"trace_c{c}", "bench_kernel_trace.csv"))) if "rsb_step_kernel" in r["Kernel_Name"]]
     d = np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]) / 1e3
     steps, km = b["steps"], b["roofline"]["kernel_ms_mean"] * 1e3
+    pipe_note = ""
+    if b.get("lockstep"):
+        # round 4: the trace holds, in order, pre-roll + warm-up (pipelined kernel class, joined after every step), the TIMED REGION (pipelined,
+        # overlapping), the sampling pass (pipelined class, one launch at a time), the lock-step leg (the plain kernel class)
+        pre = b["config"]["preroll_control_steps"] + b["warmup"]
+        start = np.array([int(r["Start_Timestamp"]) for r in rows]); end = np.array([int(r["End_Timestamp"]) for r in rows])
+        tr = slice(pre, pre + steps)
+        span = (end[tr].max() - start[tr].min()) / 1e3
+        overlap = float(np.mean(start[pre + 1:pre + steps] < end[pre:pre + steps - 1]))
+        pipe_note = (f"\n  pipelined timed region ({steps} launches of the | 16 kernel class): start -> end mean {d[tr].mean():.1f} us, p50 {np.median(d[tr]):.1f}, max {d[tr].max():.1f};"
+                     f" first start -> last end {span:.1f} us = {span / steps:.2f} us per launch; {100 * overlap:.0f} % of the launches start before their predecessor has ended"
+                     f"\n  lock-step leg (last {steps} launches, plain kernel class): mean {d[-steps:].mean():.1f} us, p50 {np.median(d[-steps:]):.1f}, max {d[-steps:].max():.1f}"
+                     f"   (bench.py lockstep: {b['lockstep']['ms_per_step'] * 1e3:.1f} us per control step, {b['lockstep']['value'] / 1e6:.1f} M env-steps/s)")
+        d_timed = d[tr]
+    else:
+        d_timed = d[-steps:]
     f, kn = counters(f"pmc_fetch_c{c}"); w, _ = counters(f"pmc_write_c{c}")
     fetch_kb, write_kb = f["FETCH_SIZE"], w["WRITE_SIZE"]
     hbm = 1024.0 * (2.0 * fetch_kb + write_kb)
@@ -76,8 +92,8 @@ for c, name, abytes in ((2, "config2", 456.0), (3, "config3", 520.0), (5, "confi
     lines.append(f"""config {c}: {b['config']['workload'][:110]}...
   kernel {r['Kernel_Name'][:70]}  grid {r['Grid_Size_X']} work-items = {int(r['Grid_Size_X']) // 64} single-wave workgroups
   {ISA[c]}
-  rocprofv3 --kernel-trace: last {steps} launches (timed region) mean {d[-steps:].mean():.1f} us  p50 {np.median(d[-steps:]):.1f}  p90 {np.percentile(d[-steps:], 90):.1f}  max {d[-steps:].max():.1f}   (all {len(d)} launches incl. pre-roll: mean {d.mean():.1f} us)
-  bench.py without a profiler: value {b['value'] / 1e6:.1f} M env-steps/s, {b['ms_per_step']:.4f} ms per control step; HIP-event brackets of {b['roofline']['kernel_launches_timed']} launches: mean {km:.1f} us (trace vs bench: {100 * (d[-steps:].mean() / km - 1):+.1f} %)
+  rocprofv3 --kernel-trace: timed region's {steps} launches mean {d_timed.mean():.1f} us  p50 {np.median(d_timed):.1f}  p90 {np.percentile(d_timed, 90):.1f}  max {d_timed.max():.1f}   (all {len(d)} launches incl. pre-roll: mean {d.mean():.1f} us){pipe_note}
+  bench.py without a profiler: value {b['value'] / 1e6:.1f} M env-steps/s, {b['ms_per_step']:.4f} ms per control step; HIP-event brackets of {b['roofline']['kernel_launches_timed']} launches: mean {km:.1f} us (trace vs bench: {100 * (d_timed.mean() / km - 1):+.1f} %)
   algorithmic bytes {abytes:.0f} B x {b['config']['envs_per_gpu'] * b['config']['substeps_per_step']} env-steps = {alg / 1e6:.2f} MB per launch -> roofline.achieved {b['roofline']['achieved']:.1f} GB/s = {100 * b['roofline']['frac']:.2f} % of 8 TB/s
   HBM traffic (PMC, calibrated): 2 x {fetch_kb:.0f} KB + {write_kb:.0f} KB = {hbm / 1e6:.2f} MB per launch = {hbm / alg:.2f} x the unfused algorithmic bytes""")
     if "cpu_baseline" in b:
