@@ -722,6 +722,8 @@ int do_integrate(rsb_world* w, int nsub) {
     a.pipe_xcds = (w->pipe_xcds > 0 && blocks % w->pipe_xcds == 0) ? w->pipe_xcds : 0;
     a.pipe_xcc_ctr = reinterpret_cast<unsigned*>(w->d_pipe_started) + 16;
     a.pipe_xcc_base = a.pipe_xcds > 0 ? w->pipe_xcc_uses * (unsigned)(blocks / a.pipe_xcds) : 0u;
+    // (the gate also keeps the per-XCD tickets of consecutive launches apart: without it the first overlapping dispatch trips the kernels' ticket check
+    // and the process aborts - tried once, profiles/r04_ab_log.txt call R: a trap, not a hang)
     if (a.pipe_wait_on)
       hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total);
     if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }   // rsb_step_pipeline_wait_event
