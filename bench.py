@@ -518,7 +518,15 @@ def measure(args, rank, local_rank, world_size, dev, coll):
         age_d.add_(1).mul_(1 - done_d.to(torch.int32))
 
     # ---- untimed: pre-roll into the stationary regime, then the caller's warm-up
-    world.set_step_pipelining(pipelined)
+    if pipelined and not world.set_step_pipelining(True):
+        # RSB_STEP_PIPELINING=0, or a profiler that serialises dispatches (rocprofv3 --pmc): the library keeps the steps in lock-step
+        pipelined = False
+        if gath.pipe is not None:
+            gath = ObsGatherer(N, obs_dim, dev, overlap=args.overlap_collective, force=args.force_collective)
+            obs_b, nbuf = gath.local_bufs, gath.nbuf
+            step_fns = [world.control_step_plan(workload.SUBSTEPS, o.data_ptr() if o is not None else 0, feet_idx, feet_idx if reset else None,
+                                                gc0_d.data_ptr() if reset else 0, gv0_d.data_ptr() if reset else 0, N) for o in obs_b]
+            drain = gath.drain
     kstep = 0
     for _ in range(args.preroll + args.warmup):
         control_step(kstep)
@@ -710,7 +718,8 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                 "lanes_per_env": world.lanes_per_env(), "parallelism": f"env-shard x{world_size}",
                 "step_pipelining": ("on: consecutive control-step launches overlap at workgroup granularity (rsb_set_step_pipelining; results bit-identical to "
                                     "lock-step, tests/test_gpu_pipeline.py); `lockstep` = the same steps with every launch waiting for the one before it"
-                                    if pipelined else "off (--lockstep)" if args.lockstep else "off (the peer-mapped exchange has no pipelined kernel class)"),
+                                    if pipelined else "off (--lockstep)" if args.lockstep else "off (the peer-mapped exchange has no pipelined kernel class)"
+                                    if args.obs_exchange == "peer" else "off (RSB_STEP_PIPELINING=0 or a dispatch-serialising profiler in the environment)"),
                 "obs_all_gather": gath.describe(),
             },
             "roofline": roof,

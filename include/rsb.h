@@ -235,6 +235,11 @@ int rsb_set_capsule_contacts(rsb_world* w, int on);
  * (the benchmark's random PD targets, action sequences of sampling-based MPC, replay).  Upstream counterpart: none (RaiSim steps its
  * worlds one after the other on CPU threads). */
 int rsb_set_step_pipelining(rsb_world* w, int on);
+/* 1 when control steps are pipelined.  rsb_set_step_pipelining(w, 1) leaves it at 0 (and says so once on stderr) with RSB_STEP_PIPELINING=0 in the
+ * environment or under a profiler that SERIALISES dispatches (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION): such a tool runs one kernel at a
+ * time in an order of its own, a pipelined launch would wait for a predecessor that is not allowed to start (the kernels then trap after ~10 s
+ * instead of hanging the device).  Counter passes therefore see the plain kernel classes; kernel traces (no serialisation) see the pipeline. */
+int rsb_step_pipelining_enabled(const rsb_world* w);
 /* Consumers and producers on OTHER streams while the pipeline keeps running (the obs all-gather of a multi-GPU run on its own stream):
  *   rsb_step_pipeline_publish(w, stream)     `stream` waits for the most recent pipelined control step (and nothing else of the pipeline);
  *   rsb_step_pipeline_wait_event(w, event)   the NEXT control step additionally waits for `event` (a hipEvent_t recorded by the caller, e.g.

@@ -106,6 +106,7 @@ PROTOTYPES = {
     "rsb_set_heightmap_contacts": (_I, [_VP, _I, _D]),
     "rsb_set_capsule_contacts": (_I, [_VP, _I]),
     "rsb_set_step_pipelining": (_I, [_VP, _I]),
+    "rsb_step_pipelining_enabled": (_I, [_VP]),
     "rsb_step_pipeline_publish": (_I, [_VP, _VP]),
     "rsb_step_pipeline_wait_event": (_I, [_VP, _VP]),
     "rsb_step_pipelining_stats": (_I, [_VP, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

@@ -1041,13 +1041,30 @@ int rsb_set_capsule_contacts(rsb_world* w, int on) {
   w->hm_capsule = on != 0;
   return RSB_OK;
 }
+// A profiler that SERIALISES dispatches (rocprofv3 --pmc / counter collection, thread trace with serialize-all) runs one kernel at a time in an
+// order of its own: a pipelined launch then waits for a predecessor that is not allowed to start, the kernels trap after their ~10 s and
+// rocprofv3 hangs in its signal handler (measured: profiles/r04_ab_log.txt, call S).  Under such a tool - or with RSB_STEP_PIPELINING=0 - the
+// switch stays off: counters are collected on the plain kernel classes.
+bool pipelining_forbidden() {
+  auto set = [](const char* n) { const char* v = std::getenv(n); return v && *v && std::strcmp(v, "0") != 0 && std::strcmp(v, "false") != 0 && std::strcmp(v, "False") != 0; };
+  const char* force = std::getenv("RSB_STEP_PIPELINING");
+  if (force && std::strcmp(force, "0") == 0) return true;
+  return set("ROCPROF_COUNTER_COLLECTION") || set("ROCPROF_ATT_PARAM_SERIALIZE_ALL") || set("ROCPROFILER_COUNTER_COLLECTION");
+}
 int rsb_set_step_pipelining(rsb_world* w, int on) {
   if (!w) { rsb::set_error("rsb_set_step_pipelining: null world"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));
   (void)stream_of(w);
+  if (on && pipelining_forbidden()) {
+    static bool said = false;
+    if (!said) { std::fprintf(stderr, "raisimlib_amd: control steps stay un-pipelined (RSB_STEP_PIPELINING=0 or a dispatch-serialising profiler in the environment)\n"); said = true; }
+    w->pipe_on = false;
+    return RSB_OK;
+  }
   w->pipe_on = on != 0;
   return RSB_OK;
 }
+int rsb_step_pipelining_enabled(const rsb_world* w) { return w && w->pipe_on ? 1 : 0; }
 int rsb_step_pipeline_publish(rsb_world* w, void* hip_stream) {
   if (!w) { rsb::set_error("rsb_step_pipeline_publish: null world"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));

@@ -236,6 +236,10 @@ class BatchedWorld:
         """Consecutive control steps overlap on the device (rsb_set_step_pipelining): bit-identical results, no launch waits for the slowest wave
         of the one before it; any other call joins the pipeline first."""
         check(self.L.rsb_set_step_pipelining(self.handle, int(bool(on))), "rsb_set_step_pipelining")
+        return bool(self.L.rsb_step_pipelining_enabled(self.handle))     # False although asked for: RSB_STEP_PIPELINING=0 / a serialising profiler
+
+    def step_pipelining_enabled(self):
+        return bool(self.L.rsb_step_pipelining_enabled(self.handle))
 
     def step_pipeline_publish(self, stream_ptr):
         """`stream_ptr` (a hipStream_t as an integer) waits for the most recent pipelined control step; the pipeline keeps running"""

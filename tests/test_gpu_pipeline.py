@@ -67,12 +67,13 @@ def same(a, b):
     return None
 
 
-@pytest.mark.parametrize("config,n,lpe", [(2, 4096, 0), (2, 1000, 0), (2, 512, 32), (2, 256, 64), (3, 4096, 0), (5, 4096, 0), (5, 300, 64)])
+@pytest.mark.parametrize("config,n,lpe", [(2, 4096, 0), (2, 1000, 0), (2, 512, 32), (2, 256, 64), (2, 20000, 0), (3, 4096, 0), (5, 4096, 0), (5, 300, 64)])
 def test_pipelined_steps_are_bit_identical(built_lib, config, n, lpe):
     """60 control steps of the benchmark recipes (targets from device memory, obs block, in-kernel resets), pipelined and not: state,
     contact lists, flags, sweep counts, obs rows and done flags equal bit for bit; all 60 launches went through the pipeline, joined once
     (by the reads at the end).  Batches that fill the chip exactly (4096 x 16 lanes), partly (grid not a multiple of 8: the plain block
-    order), and the 32- / 64-lane mappings (other kernel instances)."""
+    order, hand-over at agent scope), five times the chip (20 000 envs: a launch is dispatched completely only when most of its predecessor has
+    finished), and the 32- / 64-lane mappings (other kernel instances)."""
     recipe = bench.Recipe(config, -1.0)
     out = {}
     for pipe in (False, True):
@@ -133,6 +134,27 @@ def test_any_other_call_joins_the_pipeline(built_lib, seed):
         assert a == b, f"read {i} differs"
     launches, joins = logs[True][1]
     assert launches == sum(c for op, c, _ in prog if op == "steps") and joins >= 1
+
+
+def test_two_pipelined_worlds_and_a_change_of_the_lane_mapping(built_lib):
+    """Two pipelined worlds of one process stepped alternately (their waiting workgroups compete for the same SIMDs: each world's gate only speaks
+    for its own launches), and a change of the lanes-per-env mapping in mid-run (another grid: the pipeline's bookkeeping is rebuilt): both
+    equal to plain twins."""
+    ra, rb = bench.Recipe(2, -1.0), bench.Recipe(3, -1.0)
+    out = {}
+    for pipe in (False, True):
+        a, b = Rig(ra, 4096, pipe), Rig(rb, 4096, pipe)
+        for k in range(40):
+            a.step(1); b.step(2 if k % 3 == 0 else 1)
+        a.w.set_lanes_per_env(32)
+        for k in range(10):
+            a.step(1); b.step(1)
+        a.w.set_lanes_per_env(16)
+        a.step(5)
+        out[pipe] = (a.snapshot(), b.snapshot(), a.w.step_pipelining_stats(), b.w.step_pipelining_stats())
+        a.close(); b.close()
+    assert same(out[False][0], out[True][0]) is None and same(out[False][1], out[True][1]) is None
+    assert out[True][2][0] == 55 and out[True][3][0] == 64
 
 
 def test_borrowed_stream_sees_the_steps_after_get_stream(built_lib):
@@ -253,4 +275,21 @@ def test_profiling_and_the_peer_exchange_fall_back_to_plain_launches(built_lib):
     assert launches == 5 and joins >= 1
     q, _ = r.w.get_state()
     assert np.isfinite(q).all()
+    r.close()
+
+
+def test_the_switch_stays_off_under_a_serialising_profiler(built_lib, monkeypatch):
+    """rocprofv3 --pmc (ROCPROF_COUNTER_COLLECTION=1) runs one kernel at a time in an order of its own: pipelined launches would wait for
+    predecessors that may not start.  The library keeps the steps in lock-step there (and with RSB_STEP_PIPELINING=0) and says so."""
+    recipe = bench.Recipe(2, -1.0)
+    for var in ("ROCPROF_COUNTER_COLLECTION", "RSB_STEP_PIPELINING"):
+        monkeypatch.setenv(var, "1" if var.startswith("ROCPROF") else "0")
+        r = Rig(recipe, 512, False)
+        assert r.w.set_step_pipelining(True) is False and not r.w.step_pipelining_enabled()
+        r.step(4)
+        assert r.w.step_pipelining_stats() == (0, 0)
+        r.close()
+        monkeypatch.delenv(var)
+    r = Rig(recipe, 512, False)
+    assert r.w.set_step_pipelining(True) is True and r.w.step_pipelining_enabled()
     r.close()

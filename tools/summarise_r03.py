@@ -106,6 +106,8 @@ c1, kn = counters("pmc_sq"); c2, _ = counters("pmc_sq2"); c = {**c1, **c2}
 b = json.load(open(os.path.join(O, "bench_c2.json")))
 W = b["config"]["envs_per_gpu"] * b["config"]["lanes_per_env"] // 64
 km = b["roofline"]["kernel_ms_mean"] * 1e3
+if os.path.exists(os.path.join(O, "bench_c2_lockstep.json")):     # (round 4: the SQ passes run in lock-step: the plain kernel class and its own launch time)
+    km = json.load(open(os.path.join(O, "bench_c2_lockstep.json")))["roofline"]["kernel_ms_mean"] * 1e3
 ninst = c["SQ_INSTS_VALU"] + c["SQ_INSTS_SALU"] + c["SQ_INSTS_LDS"]
 wave_cyc = 4 * c["SQ_WAVE_CYCLES"] / W
 t = f"""rocprofv3 --pmc <counters> --output-format csv -- python bench.py --no-cpu --steps 50 --warmup 50     (MI355X, {tag}, config 2)
