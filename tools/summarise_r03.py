@@ -60,7 +60,7 @@ for c, name, abytes in ((2, "config2", 456.0), (3, "config3", 520.0), (5, "confi
     rows = [r for r in csv.DictReader(open(os.path.join(O, f"trace_c{c}", "bench_kernel_trace.csv"))) if "rsb_step_kernel" in r["Kernel_Name"]]
     d = np.array([int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]) / 1e3
     steps, km = b["steps"], b["roofline"]["kernel_ms_mean"] * 1e3
-    pipe_note = ""
+    pipe_note, pre = "", 0
     if b.get("lockstep"):
         # round 4: the trace holds, in order, pre-roll + warm-up (pipelined kernel class, joined after every step), the TIMED REGION (pipelined,
         # overlapping), the sampling pass (pipelined class, one launch at a time), the lock-step leg (the plain kernel class)
@@ -90,7 +90,7 @@ for c, name, abytes in ((2, "config2", 456.0), (3, "config3", 520.0), (5, "confi
     r = rows[-1]
     alg = abytes * b["config"]["envs_per_gpu"] * b["config"]["substeps_per_step"]
     lines.append(f"""config {c}: {b['config']['workload'][:110]}...
-  kernel {r['Kernel_Name'][:70]}  grid {r['Grid_Size_X']} work-items = {int(r['Grid_Size_X']) // 64} single-wave workgroups
+  kernel {(rows[pre]['Kernel_Name'][:62] + ' (pipelined twin; timed region) | ') if b.get('lockstep') else ''}{r['Kernel_Name'][:70]}  grid {r['Grid_Size_X']} work-items = {int(r['Grid_Size_X']) // 64} single-wave workgroups
   {ISA[c]}
   rocprofv3 --kernel-trace: timed region's {steps} launches mean {d_timed.mean():.1f} us  p50 {np.median(d_timed):.1f}  p90 {np.percentile(d_timed, 90):.1f}  max {d_timed.max():.1f}   (all {len(d)} launches incl. pre-roll: mean {d.mean():.1f} us){pipe_note}
   bench.py without a profiler: value {b['value'] / 1e6:.1f} M env-steps/s, {b['ms_per_step']:.4f} ms per control step; HIP-event brackets of {b['roofline']['kernel_launches_timed']} launches: mean {km:.1f} us (trace vs bench: {100 * (d_timed.mean() / km - 1):+.1f} %)
