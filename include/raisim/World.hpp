@@ -191,6 +191,9 @@ class BatchedWorld {
   void setSolverAcceleration(int firstSweep, double clip = 20.0) { RSB_CHECK(rsb_set_solver_anderson(world_, firstSweep, clip)); }
   void setHeightMapContactsPerPrimitive(int n, double minAngleDeg = 45.0) { RSB_CHECK(rsb_set_heightmap_contacts(world_, n, minAngleDeg)); }
   void setExactCapsuleContacts(bool on) { RSB_CHECK(rsb_set_capsule_contacts(world_, on ? 1 : 0)); }
+  /// consecutive control steps of the BATCH (rsb_control_step: the device-resident loop, not the per-env views, whose flush reads every step's output)
+  /// overlap on the device; any other call joins first (rsb.h)
+  void setStepPipelining(bool on) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_step_pipelining(world_, on ? 1 : 0)); }
   void addGround(double zHeight = 0.0) { std::lock_guard<std::recursive_mutex> lk(mu_); RSB_CHECK(rsb_set_ground(world_, zHeight)); }
   void addHeightMap(int xSamples, int ySamples, double xSize, double ySize, double centerX, double centerY,
                     const std::vector<double>& height) {

@@ -119,6 +119,7 @@ int rsb_set_solver_multi_contact(rsb_world*, int, int, int, int) { return RSB_OK
 int rsb_set_solver_anderson(rsb_world*, int, double) { return RSB_OK; }
 int rsb_set_heightmap_contacts(rsb_world*, int, double) { return RSB_OK; }
 int rsb_set_capsule_contacts(rsb_world*, int) { return RSB_OK; }
+int rsb_set_step_pipelining(rsb_world*, int) { return RSB_OK; }
 int rsb_set_early_termination(rsb_world*, int) { return RSB_OK; }
 int rsb_set_ground(rsb_world*, double) { return RSB_OK; }
 int rsb_set_heightmap(rsb_world*, int, int, double, double, double, double, const float*) { return RSB_OK; }
