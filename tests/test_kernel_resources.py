@@ -11,7 +11,7 @@ from common import ROOT
 from raisimlib_amd import build as rb
 
 
-@pytest.mark.parametrize("lpe,kmax,ml,cl", [(16, 8, 4, 0), (32, 16, 12, 0), (64, 16, 12, 0), (16, 8, 4, 4)])   # the benchmark's ANYmal-like and Atlas-like (two envs / one env per wave) instances; the second-flank class
+@pytest.mark.parametrize("lpe,kmax,ml,cl", [(16, 8, 4, 0), (32, 16, 12, 0), (64, 16, 12, 0), (16, 8, 4, 4), (16, 8, 4, 16), (32, 16, 12, 16)])   # the benchmark's ANYmal-like and Atlas-like (two envs / one env per wave) instances; the second-flank class; the benchmark's pipelined twins
 def test_step_instances_use_no_scratch(tmp_path, lpe, kmax, ml, cl):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -33,3 +33,10 @@ def test_step_instances_use_no_scratch(tmp_path, lpe, kmax, ml, cl):
     # up pass's sums, and the sweep loop's fetch-window pin
     assert len(re.findall(r"\bv_pk_fma_f32\b", txt)) >= 48 and len(re.findall(r"\bv_pk_add_f32\b", txt)) >= 28
     assert re.search(r"\.p2align\s+5", txt)
+    # pipelined control steps live in the class twins (| 16) alone: the plain instances carry neither the hand-over's cache operations nor its
+    # spin ("the plain instances carry none of this"); the twins have the XCD-affine hand-over AND the agent-scope fallback
+    pipe_ops = [len(re.findall(p, txt)) for p in (r"\bbuffer_wbl2\b", r"\bbuffer_inv\b", r"\bs_sleep\b", r"HW_REG_XCC_ID")]
+    if cl & 16:
+        assert all(n >= 1 for n in pipe_ops), pipe_ops
+    else:
+        assert pipe_ops == [0, 0, 0, 0], pipe_ops
