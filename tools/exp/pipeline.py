@@ -59,13 +59,14 @@ if __name__ == "__main__":
     ap.add_argument("--config", type=int, nargs="+", default=[2, 3, 5])
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--envs", type=int, nargs="+", default=[4096])
     a = ap.parse_args()
-    for c in a.config:
+    for c, n_envs in [(c, n) for c in a.config for n in a.envs]:
         ref = None
         for pipe in (False, True, False, True):
-            v, ms, host_ms, kms, q, u, cnt, o, st = run(c, pipe, a.steps, a.warmup, timing=True)
+            v, ms, host_ms, kms, q, u, cnt, o, st = run(c, pipe, a.steps, a.warmup, N=n_envs, timing=True)
             same = "" if ref is None else f", state / contacts / obs bit-identical to the first run: {np.array_equal(q, ref[0]) and np.array_equal(u, ref[1]) and np.array_equal(cnt, ref[2]) and np.array_equal(o, ref[3])}"
             if ref is None:
                 ref = (q, u, cnt, o)
-            print(f"config {c} pipelining {int(pipe)}: {v / 1e6:8.2f} M env-steps/s, {ms:.4f} ms per control step (host enqueue {host_ms:.4f} ms, launch start->end {kms:.4f} ms), "
+            print(f"config {c} N {n_envs} pipelining {int(pipe)}: {v / 1e6:8.2f} M env-steps/s, {ms:.4f} ms per control step (host enqueue {host_ms:.4f} ms, launch start->end {kms:.4f} ms), "
                   f"pipelined launches / joins {st}{same}", flush=True)
