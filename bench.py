@@ -620,6 +620,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
             dist.all_reduce(tl, op=dist.ReduceOp.MAX)
         lockstep = float(tl.item())
         world.set_step_pipelining(True)
+    pipe_launches, pipe_joins = world.step_pipelining_stats()      # (also sets world.pipeline_overlaps: the probe found two streams on different hardware queues)
     env_steps_per_step = N * workload.SUBSTEPS
     total_env_steps = world_size * env_steps_per_step * args.steps
     value = total_env_steps / elapsed
@@ -720,6 +721,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                                     "lock-step, tests/test_gpu_pipeline.py); `lockstep` = the same steps with every launch waiting for the one before it"
                                     if pipelined else "off (--lockstep)" if args.lockstep else "off (the peer-mapped exchange has no pipelined kernel class)"
                                     if args.obs_exchange == "peer" else "off (RSB_STEP_PIPELINING=0 or a dispatch-serialising profiler in the environment)"),
+                "step_pipelining_stats": ({"pipelined_launches": pipe_launches, "joins": pipe_joins, "streams_overlap": bool(world.pipeline_overlaps)} if pipelined else None),
                 "obs_all_gather": gath.describe(),
             },
             "roofline": roof,

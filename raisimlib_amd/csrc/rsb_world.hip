@@ -203,6 +203,11 @@ int pipe_make_streams(rsb_world* w) {
   w->pipe_probe_rejected = (int)rejected.size();
   if (st == RSB_OK && !w->pipe_stream[1] && !rejected.empty()) { w->pipe_stream[1] = rejected.back(); rejected.pop_back(); w->pipe_overlap = false; }   // correct, but in order
   for (hipStream_t c : rejected) (void)hipStreamDestroy(c);      // (after the search: a destroyed stream's queue slot would be handed out again)
+  if (st == RSB_OK && !w->pipe_stream[1]) {                      // (not one more stream could be created)
+    (void)hipStreamDestroy(w->pipe_stream[0]); w->pipe_stream[0] = nullptr;
+    rsb::set_error("rsb_set_step_pipelining: no second stream could be created");
+    return RSB_E_HIP;
+  }
   return st;
 }
 // How many XCDs does the dispatcher deal this device's workgroups to, and is it a plain round-robin?  (MI355X in SPX mode: 8, and it is - but the

@@ -33,6 +33,8 @@ def test_bench_prints_the_contract_line(built_lib, config):
     # consecutive control steps are pipelined by default: the same line also carries the lock-step number (same bracket, pipelining off) and
     # the roofline object says what its per-launch figures refer to
     assert b["config"]["step_pipelining"].startswith("on") and b["lockstep"]["value"] > 1e6 and b["lockstep"]["steps"] == 6
+    ps = b["config"]["step_pipelining_stats"]
+    assert ps["streams_overlap"] is True and ps["pipelined_launches"] >= 6 + 2 + 8      # timed + warm-up + pre-roll at least; the probe found a pair of streams that overlap
     assert abs(b["lockstep"]["value"] - 4096 * 4 * 6 / (b["lockstep"]["ms_per_step"] * 6 * 1e-3)) < 1e-3 * b["lockstep"]["value"]
     assert abs(roof["effective_ms_per_launch"] - b["ms_per_step"]) < 1e-9 and roof["launches_in_flight"] > 0.5
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["effective_ms_per_launch"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
