@@ -40,9 +40,9 @@ timeout 200 python $R/tools/diag_phases.py > $O/diag_phases.txt 2>&1
 RSB_PROF_FINE=1 timeout 200 python $R/tools/diag_waves.py > $O/diag_waves.txt 2>&1
 timeout 300 python $R/tools/diag_atlas_phases.py standing > $O/diag_atlas.txt 2>&1
 timeout 200 python $R/tools/bench_vecenv.py > $O/bench_vecenv.txt 2>&1
-for t in 1 8 16 32 64 128; do RSB_FIBER_THREADS=$t timeout 300 python $R/tools/bench_gym.py 4096 40 $t > $O/bench_gym_t$t.json 2>>$O/bench_gym.err; done
+for t in 1 8 16 32 64 128; do RSB_FIBER_THREADS=$t timeout 300 python $R/tools/bench_gym.py 4096 1000 $t > $O/bench_gym_t$t.json 2>>$O/bench_gym.err; done
 cp $O/bench_gym_t32.json $O/bench_gym.json
-RSB_VIEW_FUSE=0 RSB_FIBER_THREADS=32 timeout 300 python $R/tools/bench_gym.py 4096 40 32 > $O/bench_gym_t32_nofuse.json 2>>$O/bench_gym.err
+RSB_VIEW_FUSE=0 RSB_FIBER_THREADS=32 timeout 300 python $R/tools/bench_gym.py 4096 1000 32 > $O/bench_gym_t32_nofuse.json 2>>$O/bench_gym.err
 python - <<PY
 import json
 for n in ("c2","c2_driverlike","c2_lockstep","c2_forced_collective","c2_forced_collective_lockstep","c3","c3_per_env_maps","c5","c5_collapsing"):
