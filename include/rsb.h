@@ -252,6 +252,13 @@ int rsb_step_pipeline_wait_event(rsb_world* w, void* hip_event);
  * library found no two streams whose kernels run concurrently (HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, default 4; a
  * probe picks the pair when the pipeline is first used): results are the same, the launches run in order */
 int rsb_step_pipelining_stats(rsb_world* w, long long* launches, long long* joins);
+/* Round 5: (a) no device trap anywhere in the pipeline - a fault (an env-block ticket outside its XCD's range, a wait past RSB_PIPE_TIMEOUT_MS) sets a
+ * device error word, the pipelined launches drain without touching their envs, and the next JOINING call restores the state of the last join,
+ * switches pipelining off, replays the steps in lock-step and returns RSB_E_PIPELINE once (the inputs of pipelined steps - p_target buffers,
+ * reset states - must therefore stay unchanged until the next joining call); a join now waits on the host.  (b) The closed loop: K control
+ * steps with an ACTION STAGE between them, handed over env block by env block so that the steps still overlap although every step's
+ * actions depend on the step before: rsb_closed_loop_run, rsb_closed_loop_run_linear, rsb_step_pipeline_join / _fault,
+ * rsb_debug_pipeline_fault and the device-side half of a caller's stage kernel are declared in rsb_pipeline.h. */
 /* terrain curricula: n_maps height maps of one geometry, heights [n_maps][y_samples][x_samples] (host), and the map
  * each env stands on, env_map [num_envs] (host; may be NULL when n_maps == 1) */
 int rsb_set_heightmaps(rsb_world* w, int n_maps, int x_samples, int y_samples, double x_size, double y_size,
@@ -434,6 +441,10 @@ typedef struct rsb_env_config {
 int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* action_mean, const float* gc_init,
                       const float* gv_init);
 int rsb_env_dims(const rsb_world* w, int* ob_dim, int* action_dim);
+/* Per-env reset states (optional; gc0 [N, nq], gv0 [N, nv] in `space`, copied): a terminated env - and rsb_env_reset - restarts from ITS row
+ * instead of the one gc_init / gv_init of rsb_env_configure (the benchmark's per-env base position and heading; raisimGymTorch environments
+ * that randomise their initial state in reset() [RECALL]).  NULL, NULL: back to the single initial state. */
+int rsb_env_set_reset_states(rsb_world* w, const float* gc0, const float* gv0, int space);
 int rsb_env_reset(rsb_world* w);                                   /* every env to gc_init / gv_init */
 int rsb_env_observe(rsb_world* w, float* ob, int space);           /* [N, ob_dim] */
 /* action [N, action_dim] in; reward [N] float, done [N] uint8 and ob_next [N, ob_dim] (the observation the next step
@@ -474,4 +485,7 @@ int rsb_debug_wave_profile(rsb_world* w, long long* out, int n_blocks);
 #ifdef __cplusplus
 }
 #endif
+
+#include "rsb_pipeline.h"   /* the closed-loop pipeline (C declarations; under hipcc also the device-side serve loop of an action stage) */
+
 #endif /* RSB_H_ */

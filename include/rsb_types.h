@@ -26,7 +26,8 @@ typedef enum rsb_status {
   RSB_E_UNSUPPORTED = -3,/* feature outside the supported subset           */
   RSB_E_NO_DEVICE = -4,  /* no HIP device / HIP runtime failure            */
   RSB_E_HIP = -5,        /* a HIP call failed                              */
-  RSB_E_STATE = -6       /* call not valid in the current state            */
+  RSB_E_STATE = -6,      /* call not valid in the current state            */
+  RSB_E_PIPELINE = -7    /* pipelined control steps faulted on the device; the library has replayed them in lock-step (rsb_pipeline.h) */
 } rsb_status;
 
 typedef enum rsb_memspace { RSB_HOST = 0, RSB_DEVICE = 1 } rsb_memspace;

@@ -58,9 +58,17 @@ class EnvConfig(C.Structure):
                 ("n_foot", C.c_int32), ("foot_collisions", C.c_int32 * RSB_MAX_COLLISIONS)]
 
 
+class LinearPolicy(C.Structure):
+    """rsb_linear_policy (include/rsb_pipeline.h): device pointers"""
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("noise", C.c_void_p), ("noise_period", C.c_int32), ("clip", C.c_float),
+                ("rollout_ob", C.c_void_p), ("rollout_act", C.c_void_p), ("rollout_reward", C.c_void_p), ("rollout_done", C.c_void_p)]
+
+
+RSB_E_PIPELINE = -7
+
 LIB_PATH = os.environ.get("RSB_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsb.so")   # RSB_LIB_PATH: kernel experiments built by build.build(extra_flags=...)
 
-# name -> (restype, argtypes); mirrors include/rsb.h one-to-one (tests check the two stay in sync)
+# name -> (restype, argtypes); mirrors include/rsb.h + include/rsb_pipeline.h one-to-one (tests check they stay in sync)
 _VP, _I, _D, _FP, _CP = C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_char_p
 PROTOTYPES = {
     "rsb_last_error": (C.c_char_p, []),
@@ -110,6 +118,13 @@ PROTOTYPES = {
     "rsb_step_pipeline_publish": (_I, [_VP, _VP]),
     "rsb_step_pipeline_wait_event": (_I, [_VP, _VP]),
     "rsb_step_pipelining_stats": (_I, [_VP, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "rsb_step_pipeline_join": (_I, [_VP]),
+    "rsb_step_pipeline_fault": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
+    "rsb_debug_pipeline_fault": (_I, [_VP, _I]),
+    "rsb_closed_loop_run": (_I, [_VP, _I, _VP, _VP]),
+    "rsb_closed_loop_run_linear": (_I, [_VP, _I, C.POINTER(LinearPolicy)]),
+    "rsb_closed_loop_buffers": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
+    "rsb_closed_loop_set_stage_grid": (_I, [_VP, _I]),
     "rsb_set_integration_scheme": (_I, [_VP, _I]),
     "rsb_set_early_termination": (_I, [_VP, _I]),
     "rsb_set_solver_warm_start": (_I, [_VP, _I]),
@@ -163,6 +178,7 @@ PROTOTYPES = {
     "rsb_reset_terminated": (_I, [_VP, _FP, _I, _FP, _FP, _I, _FP, _I]),
     "rsb_env_configure": (_I, [_VP, C.POINTER(EnvConfig), _FP, _FP, _FP]),
     "rsb_env_dims": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
+    "rsb_env_set_reset_states": (_I, [_VP, _FP, _FP, _I]),
     "rsb_env_reset": (_I, [_VP]),
     "rsb_env_observe": (_I, [_VP, _FP, _I]),
     "rsb_env_step": (_I, [_VP, _FP, _FP, _FP, _FP, _I]),

@@ -23,10 +23,14 @@ OUT = os.path.join(HERE, "lib", "librsb.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 RSB_H = os.path.join(ROOT, "include", "rsb.h")
 RSB_TYPES_H = os.path.join(ROOT, "include", "rsb_types.h")    # the part of the ABI the kernels compile against
+RSB_PIPELINE_H = os.path.join(ROOT, "include", "rsb_pipeline.h")   # the closed-loop pipeline: C declarations + the device-side serve loop of an action stage
+_WORLD_DEPS = ["rsb_world.h", "rsb_internal.h", "step_types.h", RSB_H, RSB_TYPES_H, RSB_PIPELINE_H]
 HOST_SOURCES = {   # source -> headers it depends on
     "urdf_model.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
     "terrain_io.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
-    "rsb_world.hip": ["rsb_internal.h", "step_types.h", "step_launch.h", "query_kernel.h", "env_task.h", RSB_H, RSB_TYPES_H],
+    "rsb_world.hip": _WORLD_DEPS + ["step_launch.h", "query_kernel.h", "env_task.h"],
+    "rsb_pipeline.hip": _WORLD_DEPS,
+    "rsb_comm.hip": _WORLD_DEPS,
 }
 KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", RSB_TYPES_H]
 # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and
@@ -48,7 +52,7 @@ def source_hash(extra_flags=()):
     into the library (rsb_source_hash()); tests/conftest.py compares the two, so a library built from other sources than the tree's -
     a stale object cache, a binary that travelled to the GPU box without its sources - fails the suite instead of passing it."""
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp"))) + [RSB_H, RSB_TYPES_H]
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp", ".inc"))) + [RSB_H, RSB_TYPES_H, RSB_PIPELINE_H]
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode() + b"\0")
         h.update(open(f, "rb").read())
@@ -96,6 +100,8 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
                                     _path("step_instance.hip"), "-o", obj]))
     # build provenance: the hash of the sources this library is built from, as a translation unit of its own (rsb_source_hash())
     shash = source_hash(extra_flags)
+    if only:
+        shash += "-partial"     # RSB_BUILD_ONLY leaves stale kernel objects in the library: it must not pass for a build of this tree (tests/conftest.py refuses it)
     # A library that says it was built from exactly these sources and flags IS up to date, whatever the object cache looks like: the GPU box
     # receives librsb.so without lib/obj/ (.gpurunignore) and used to recompile all ~95 objects in every test session.  The sidecar file only
     # short-cuts the build; tests/conftest.py asks the loaded library itself (rsb_source_hash()).
@@ -109,7 +115,7 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
         open(stamp_src, "w").write(stamp_txt)
         tasks.append((stamp_obj, ["g++", "-O1", "-fPIC", "-c", stamp_src, "-o", stamp_obj]))
     objs.append(stamp_obj)
-    if not tasks and os.path.exists(out) and all(os.path.getmtime(o) <= os.path.getmtime(out) for o in objs):
+    if not tasks and not only and os.path.exists(out) and all(os.path.getmtime(o) <= os.path.getmtime(out) for o in objs):
         open(side, "w").write(shash + "\n")     # (the library was linked from these objects, the stamp among them)
         return out
 
@@ -131,7 +137,11 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
     if verbose:
         print(" ".join(link[:6]), f"... ({len(objs)} objects) -lz", file=sys.stderr)
     subprocess.run(link, check=True)
-    open(side, "w").write(shash + "\n")
+    if only:
+        if os.path.exists(side):
+            os.remove(side)      # (no short-cut for the next build(): it has to look at the objects)
+    else:
+        open(side, "w").write(shash + "\n")
     return out
 
 

@@ -23,231 +23,10 @@
 #include "env_task.h"
 #include "step_types.h"
 
-using rsbk::DevModel;
-using rsbk::LdsLayout;
-using rsbk::StepArgs;
 
-#define HIP_TRY(expr)                                                                           \
-  do {                                                                                          \
-    hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess) {                                                                     \
-      rsb::set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                        \
-      return RSB_E_HIP;                                                                         \
-    }                                                                                           \
-  } while (0)
+#include "rsb_world.h"
 
-struct rsb_world {
-  rsb_model_blob blob;
-  int N = 0, device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = true;
-  DevModel* d_model = nullptr;
-  float *d_gc = nullptr, *d_gv = nullptr, *d_pt = nullptr, *d_dt = nullptr, *d_tff = nullptr;
-  float *d_kp = nullptr, *d_kd = nullptr, *d_heights = nullptr;
-  float *d_tmp_gc = nullptr, *d_tmp_gv = nullptr;
-  uint8_t* d_tmp_mask = nullptr;
-  float *d_M = nullptr, *d_h = nullptr, *d_Minv = nullptr, *d_Mwork = nullptr;
-  int32_t* d_obs_idx = nullptr;
-  int32_t* d_hm_index = nullptr;   // [N] height map of each env (rsb_set_heightmaps), NULL: all envs share map 0
-  float* d_image = nullptr;           // the step kernel's per-block tables in their LDS layout (StepArgs::lds_image), rebuilt when a setter dirties it
-  std::vector<float> h_kp, h_kd;      // host mirror of the PD gains (baked into the image)
-  std::vector<double> col_mu, col_rest, col_rthr;   // per-primitive overrides, < 0 = the world's default
-  bool image_dirty = true;
-  // self-collision (rsb_set_self_collision): candidate primitive pairs i < j in enumeration order, body pairs the caller
-  // excluded (rsb_ignore_collision_between), per-pair material overrides (< 0 = the world's default)
-  bool self_collision = true;
-  std::vector<uint8_t> self_ignore;            // [nb * nb]
-  std::vector<int> self_pairs;                 // 2 ints per pair
-  std::vector<double> self_mu, self_rest, self_rthr;
-  float* d_self_mat = nullptr;
-  float* d_genf = nullptr;              // [N, nv] generalized force applied in the last sub-step (rsb_enable_generalized_force_output)
-  bool want_genf = false;
-  size_t self_mat_cap = 0;
-  float* d_warm = nullptr;   // [N, kWarmRow] contact-solver warm state (StepArgs::warm: one record per contact of the last integrate())
-  bool warm_start = true;
-  uint8_t* d_done_out = nullptr;        // caller-owned device buffer (rsb_set_done_output): done flags of the fused control step
-  const uint8_t* launch_mask = nullptr; // env mask of the next launch only (rsb_integrate_masked)
-  uint8_t* d_launch_mask = nullptr;     // staging for host masks
-  uint8_t* d_view_masks = nullptr;      // [n_launches][N] launch masks of rsb_view_exchange
-  size_t view_masks_cap = 0;
-  void* comm = nullptr;                 // ncclComm_t (rsb_comm_init)
-  int comm_ranks = 0, comm_rank = 0;
-  float *d_obs_local = nullptr, *d_obs_all = nullptr;   // staging of rsb_allgather_obs
-  size_t obs_local_cap = 0, obs_all_cap = 0;
-  bool early_term = false;   // rsb_set_early_termination
-  std::vector<int32_t> obs_idx_host;   // what d_obs_idx currently holds (re-uploaded only when the caller's list changes)
-  float* d_dbg = nullptr;
-  long long* d_prof = nullptr;
-  int dbg_env = -1;
-  rsb_contact* d_contacts = nullptr;
-  int32_t *d_count = nullptr, *d_flags = nullptr, *d_iters = nullptr;
-  // parameters
-  double dt = 0.0025, gravity[3] = {0, 0, -9.81}, mu = 0.8, erp = 0.0;
-  double alpha_init = 1.0, alpha_min = 1.0, alpha_decay = 1.0, threshold = 1e-5;
-  int max_iter = 150, section_rounds = 2, stall_window = 4, freeze_after = 6, refine = 1, kmax = 8, control_mode = RSB_PD_PLUS_FEEDFORWARD_TORQUE;
-  int multi_depth = 3, multi_light = 0, multi_freeze_after = 0, multi_stall_window = 16;   // rsb_set_solver_multi_contact
-  int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
-  int hm_contacts = 1; double hm_second_cos = 0.70710678118654752;                                        // rsb_set_heightmap_contacts
-  bool hm_capsule = false; int32_t* d_cap = nullptr; int n_cap = 0;                                       // rsb_set_capsule_contacts: [n_cap][2] end primitives of the model's capsules / cylinders, (first corner, -1) of its boxes
-  double integ_theta = 1.0;                                                                // rsb_set_integration_scheme
-  // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
-  //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
-  //   [flags, parity 0 | parity 1]            2 x RSB_MAX_RANKS uint32: flags[parity][p] = last control step whose rows rank p delivered
-  struct Peer {
-    int ranks = 0, rank = 0, slots = 0, od = 0;
-    bool connected = false, wait_by_kernel = false;
-    void* base = nullptr; size_t bytes = 0;
-    void* peer_base[RSB_MAX_RANKS] = {};
-    bool imported[RSB_MAX_RANKS] = {};
-    uint32_t step = 0;                       // sequence number of the last control step issued with the exchange
-    std::vector<int32_t> idx;                // force slots' collision primitives (empty: 0..slots-1)
-    int32_t* d_idx = nullptr;
-  } peer;
-  int terrain_type = 0, hm_xs = 0, hm_ys = 0;
-  double ground_z = 0, hm_xsize = 0, hm_ysize = 0, hm_cx = 0, hm_cy = 0;
-  float hm_max = 0.f;
-  double stall_factor = 0.5, settle_tol = 0.0, restitution = 0.0, res_threshold = 0.0;
-  int lpe = 0, max_kid = 0;
-  double world_time = 0;
-  bool integrate1_valid = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool timing = false;
-  // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
-  struct Fuse { bool peer = false; const float* act = nullptr; const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
-                int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1;
-                float* env_reward = nullptr; float* env_ob = nullptr; uint8_t* env_done = nullptr; bool env_task = false; bool pipeline = false; } fuse;
-  // device-resident vectorised env (rsb_env_*)
-  bool env_ready = false;
-  rsb_env_config env_cfg{};
-  unsigned long long env_allowed = 0;
-  float *d_env_mean = nullptr, *d_env_gc0 = nullptr, *d_env_gv0 = nullptr, *d_env_io = nullptr, *d_env_ob = nullptr, *d_env_reward = nullptr, *d_env_tau2 = nullptr;
-  uint8_t* d_env_done = nullptr;
-  std::vector<hipEvent_t> ring0, ring1;   // event pairs around the most recent step-kernel launches (rsb_enable_timing(w, n))
-  size_t ring_next = 0, ring_count = 0;
-  int timing_stride = 1;       // events bracket every timing_stride-th launch only (an event pair costs ~7 us of stream time)
-  long long launch_index = 0;
-  float last_ms = -1.f;
-  // pipelined control steps (rsb_set_step_pipelining): consecutive rsb_control_step launches alternate between two private streams and
-  // overlap on the device (see StepArgs::pipe_prog); any other use of the world's stream joins them first (stream_of)
-  bool pipe_on = false, pipe_active = false;
-  hipStream_t pipe_stream[2] = {nullptr, nullptr};
-  hipEvent_t pipe_ev[3] = {nullptr, nullptr, nullptr};   // join events of the two streams, fork event of the world's stream
-  int pipe_next = 0, pipe_blocks = 0;
-  unsigned long long pipe_n = 0;                         // pipelined launches since the fork
-  unsigned long long pipe_wg_total = 0;                  // their workgroups (== *d_pipe_started once they have all started)
-  unsigned pipe_seq = 0;                                 // sequence number of the last pipelined launch (published by its workgroups)
-  unsigned long long* d_pipe_started = nullptr;
-  int* d_pipe_prog = nullptr;                            // [pipe_blocks]
-  hipStream_t launch_stream = nullptr;                   // stream of the step launch being enqueued (do_integrate)
-  hipStream_t pipe_last = nullptr;                       // private stream of the most recent pipelined launch
-  hipEvent_t pipe_dep = nullptr, pipe_pub = nullptr;     // rsb_step_pipeline_wait_event: the next pipelined launch waits for it; event of rsb_step_pipeline_publish
-  long long pipe_launches = 0, pipe_joins = 0;
-  bool pipe_overlap = true;                              // the probe found two streams whose kernels run concurrently (pipe_make_streams)
-  int pipe_probe_rejected = 0;
-  int pipe_xcds = 0;                                     // XCDs the dispatcher deals workgroups to round-robin (0: pattern not recognised -> agent-scope hand-over)
-  unsigned pipe_xcc_uses = 0;                            // pipelined launches since the counters were cleared
-};
-
-namespace {
-// Joins the pipelined control steps (if any are in flight) into the world's stream: whatever is enqueued on it next runs after them.
-int pipe_join(rsb_world* w) {
-  if (!w->pipe_active) return RSB_OK;
-  w->pipe_active = false;
-  ++w->pipe_joins;
-  for (int i = 0; i < 2; ++i) {
-    HIP_TRY(hipEventRecord(w->pipe_ev[i], w->pipe_stream[i]));
-    HIP_TRY(hipStreamWaitEvent(w->stream, w->pipe_ev[i], 0));
-  }
-  return RSB_OK;
-}
-// the world's stream for any use other than a pipelined step launch
-hipStream_t stream_of(rsb_world* w) {
-  if (w->pipe_active) (void)pipe_join(w);
-  return w->stream;
-}
-// Do kernels on streams a and b run CONCURRENTLY?  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, default 4) and two
-// streams on one queue run in order: the pipeline would be correct but gain nothing (measured: 107 M instead of 160 M env-steps/s when the
-// second world of a process drew an aliased pair, profiles/r04_ab_log.txt).  Probe: a kernel on a waits (<= ~2 ms) for a flag that a kernel on b sets.
-__global__ void pipe_probe_wait_kernel(int* flag) {
-  const long long t0 = wall_clock64();
-  int seen = 0;
-  while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < 200000) __builtin_amdgcn_s_sleep(32);
-  flag[1] = seen ? 1 : 2;
-}
-__global__ void pipe_probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-int streams_run_concurrently(hipStream_t a, hipStream_t b, int* d_flag, bool* yes) {
-  HIP_TRY(hipMemset(d_flag, 0, 2 * sizeof(int)));
-  hipLaunchKernelGGL(pipe_probe_wait_kernel, dim3(1), dim3(1), 0, a, d_flag);
-  hipLaunchKernelGGL(pipe_probe_set_kernel, dim3(1), dim3(1), 0, b, d_flag);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(a));
-  HIP_TRY(hipStreamSynchronize(b));
-  int h[2] = {0, 0};
-  HIP_TRY(hipMemcpy(h, d_flag, sizeof h, hipMemcpyDeviceToHost));
-  *yes = h[1] == 1;
-  return RSB_OK;
-}
-// the two private streams of the pipeline: a pair that the probe has seen overlap (up to 8 candidates for the second one)
-int pipe_make_streams(rsb_world* w) {
-  if (w->pipe_stream[0]) return RSB_OK;
-  HIP_TRY(hipStreamCreateWithFlags(&w->pipe_stream[0], hipStreamNonBlocking));
-  std::vector<hipStream_t> rejected;
-  int st = RSB_OK;
-  for (int attempt = 0; attempt < 8 && st == RSB_OK && !w->pipe_stream[1]; ++attempt) {
-    hipStream_t c = nullptr;
-    if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
-    bool yes = false;
-    st = streams_run_concurrently(w->pipe_stream[0], c, reinterpret_cast<int*>(w->d_pipe_started) + 8, &yes);   // (+32 B: the probe's two flags)
-    if (st == RSB_OK && yes) w->pipe_stream[1] = c; else rejected.push_back(c);
-  }
-  w->pipe_probe_rejected = (int)rejected.size();
-  if (st == RSB_OK && !w->pipe_stream[1] && !rejected.empty()) { w->pipe_stream[1] = rejected.back(); rejected.pop_back(); w->pipe_overlap = false; }   // correct, but in order
-  for (hipStream_t c : rejected) (void)hipStreamDestroy(c);      // (after the search: a destroyed stream's queue slot would be handed out again)
-  if (st == RSB_OK && !w->pipe_stream[1]) {                      // (not one more stream could be created)
-    (void)hipStreamDestroy(w->pipe_stream[0]); w->pipe_stream[0] = nullptr;
-    rsb::set_error("rsb_set_step_pipelining: no second stream could be created");
-    return RSB_E_HIP;
-  }
-  return st;
-}
-// How many XCDs does the dispatcher deal this device's workgroups to, and is it a plain round-robin?  (MI355X in SPX mode: 8, and it is - but the
-// XCD of workgroup 0 differs from launch to launch, profiles/r04_ubench_xcc_map.txt.)  Returns 0 when the pattern is anything else.
-__global__ void pipe_xcc_probe_kernel(int* out) {
-  unsigned x;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
-  if (threadIdx.x == 0) out[blockIdx.x] = (int)(x & 15u);
-}
-int pipe_probe_xcds(rsb_world* w, int* n_xcds) {
-  *n_xcds = 0;
-  static const bool off = std::getenv("RSB_PIPE_XCD") && std::atoi(std::getenv("RSB_PIPE_XCD")) == 0;   // A/B switch: agent-scope hand-over everywhere
-  if (off) return RSB_OK;
-  constexpr int G = 256;
-  int* d = nullptr;
-  HIP_TRY(hipMalloc(&d, G * sizeof(int)));
-  int h[G];
-  bool ok = true;
-  int nx = 0;
-  for (int rep = 0; rep < 2 && ok; ++rep) {
-    hipLaunchKernelGGL(pipe_xcc_probe_kernel, dim3(G), dim3(64), 0, w->pipe_stream[rep], d);
-    if (hipStreamSynchronize(w->pipe_stream[rep]) != hipSuccess || hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
-    int mx = 0;
-    for (int b = 0; b < G; ++b) mx = std::max(mx, h[b]);
-    const int n = mx + 1;
-    ok = n >= 1 && n <= 16 && G % n == 0 && (rep == 0 || n == nx);
-    for (int b = 0; ok && b < G; ++b) ok = h[b] == (h[0] + b) % n;
-    nx = n;
-  }
-  (void)hipFree(d);
-  if (ok) *n_xcds = nx;
-  return RSB_OK;
-}
-__global__ void pipe_gate_kernel(const unsigned long long* started, unsigned long long target) {
-  int spins = 0;      // (~2 s: a launch that never arrives would be a bug of the host side - trap rather than hang the device)
-  while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    __builtin_amdgcn_s_sleep(32);
-    if (++spins > (1 << 21)) __builtin_trap();
-  }
-}
+namespace rsbw {
 
 // Kernel arguments in device memory: with host-resident kernargs every wave's first scalar loads cross PCIe (measured: step
 // kernel prologue 20.6 k cycles instead of 9.2 k, 142 M instead of 149 M env-steps/s).  It is this image's default; set here
@@ -473,12 +252,13 @@ __global__ void env_obs_kernel(float* ob, const float* gc, const float* gv, int 
   env_write_obs(ob + (size_t)e * (10 + 2 * (nv - 6)), gc + (size_t)e * nq, gv + (size_t)e * nv, nv);
 }
 
-__global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* flags, const float* gc0, const float* gv0,
+__global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* flags, const float* gc0, const float* gv0, int rows,
                                  int N, int nq, int nv, float* warm, int n6) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= N) return;
-  for (int i = 0; i < nq; ++i) gc[(size_t)e * nq + i] = gc0[i];
-  for (int i = 0; i < nv; ++i) gv[(size_t)e * nv + i] = gv0[i];
+  const size_t r = rows == 1 ? 0 : (size_t)e;
+  for (int i = 0; i < nq; ++i) gc[(size_t)e * nq + i] = gc0[r * nq + i];
+  for (int i = 0; i < nv; ++i) gv[(size_t)e * nv + i] = gv0[r * nv + i];
   for (int i = 0; i < n6; ++i) warm[(size_t)e * n6 + i] = 0.f;
   count[e] = 0; flags[e] = 0;
 }
@@ -648,7 +428,9 @@ int do_integrate(rsb_world* w, int nsub) {
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
   if (!a.do_reset) { a.gc0 = w->d_gc; a.gv0 = w->d_gv; a.reset_rows = w->N; }   // never dereferenced, but keep the pointers valid
-  const bool pipe_ok = w->fuse.pipeline && !w->fuse.env_task;
+  const bool closed_loop = w->fuse.closed_loop;      // a step of rsb_closed_loop_run: waits for the action stage's word instead of its predecessor's
+  const bool pipe_ok = w->fuse.pipeline && (!w->fuse.env_task || closed_loop);
+  const rsb_world::Fuse fuse_in = w->fuse;
   w->fuse = rsb_world::Fuse();
   a.prof = w->d_prof;
   a.dbg = w->dbg_env >= 0 ? w->d_dbg : nullptr;
@@ -687,52 +469,21 @@ int do_integrate(rsb_world* w, int nsub) {
   a.tau_out = w->want_genf ? w->d_genf : nullptr;
   a.env_mask = w->launch_mask; w->launch_mask = nullptr;
   // ---- pipelined control steps: this launch goes to one of the two private streams, behind a gate that lets it start only when the launch
-  // before it (on the other stream) has been dispatched completely - its workgroups wait for their predecessors' envs, which therefore must
-  // all be running or done (no deadlock: a waiting workgroup never keeps a predecessor off the chip)
+  // before it (on the other stream) has been dispatched completely - its workgroups wait for their predecessors' envs (open loop) or for the
+  // action stage's rows (closed loop), which therefore must all be running or done (no deadlock: a waiting workgroup never keeps a
+  // predecessor off the chip).  rsb_pipeline.hip holds the bookkeeping.
   hipStream_t ls = nullptr;
   const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask;
   if (pipelined) {
     const int blocks = (w->N + (64 / lpe) - 1) / (64 / lpe);
-    if (blocks != w->pipe_blocks) {
-      (void)stream_of(w);
-      HIP_TRY(hipStreamSynchronize(w->stream));
-      if (w->d_pipe_prog) HIP_TRY(hipFree(w->d_pipe_prog));
-      w->d_pipe_prog = nullptr; w->pipe_blocks = 0;
-      HIP_TRY(hipMalloc(&w->d_pipe_prog, (size_t)blocks * sizeof(int)));
-      if (!w->d_pipe_started) HIP_TRY(hipMalloc(&w->d_pipe_started, 256));   // [0] started | +32 B: probe flags | +64 B: 16 per-XCD ticket counters
-      HIP_TRY(hipMemset(w->d_pipe_prog, 0, (size_t)blocks * sizeof(int)));
-      HIP_TRY(hipMemset(w->d_pipe_started, 0, 256));
-      w->pipe_blocks = blocks; w->pipe_wg_total = 0; w->pipe_seq = 0; w->pipe_xcc_uses = 0;
-      if (!w->pipe_stream[0]) {
-        const int ps = pipe_make_streams(w);
-        if (ps != RSB_OK) return ps;
-        const int px = pipe_probe_xcds(w, &w->pipe_xcds);
-        if (px != RSB_OK) return px;
-      }
-      HIP_TRY(hipMemset(w->d_pipe_started, 0, 256));
-      for (int i = 0; i < 3; ++i) if (!w->pipe_ev[i]) HIP_TRY(hipEventCreateWithFlags(&w->pipe_ev[i], hipEventDisableTiming));
+    st = pipe_begin_launch(w, a, blocks, closed_loop, &ls);
+    if (st != RSB_OK) return st;
+    if (!w->pipe_log_suppress) {      // what a faulted pipeline replays in lock-step (pipe_recover)
+      rsb_world::PipeLog e;
+      e.f = fuse_in; e.nsub = nsub; e.done_out = w->d_done_out;
+      w->pipe_log.push_back(e);
     }
-    a.pipe_prog = w->d_pipe_prog; a.pipe_started = w->d_pipe_started;
-    if (!w->pipe_active) {
-      // fork: both streams run after everything that is on the world's stream now; nothing is in flight, the first launch waits for nobody
-      // (sequence numbers and the started count carry on: every earlier pipelined launch has completed)
-      HIP_TRY(hipEventRecord(w->pipe_ev[2], w->stream));
-      HIP_TRY(hipStreamWaitEvent(w->pipe_stream[0], w->pipe_ev[2], 0));
-      HIP_TRY(hipStreamWaitEvent(w->pipe_stream[1], w->pipe_ev[2], 0));
-      w->pipe_n = 0;
-    }
-    ls = w->pipe_stream[w->pipe_next];
-    a.pipe_wait_on = w->pipe_n > 0 ? 1 : 0;
-    a.pipe_wait = (int)w->pipe_seq; a.pipe_seq = (int)(w->pipe_seq + 1u);
-    a.pipe_xcds = (w->pipe_xcds > 0 && blocks % w->pipe_xcds == 0) ? w->pipe_xcds : 0;
-    a.pipe_xcc_ctr = reinterpret_cast<unsigned*>(w->d_pipe_started) + 16;
-    a.pipe_xcc_base = a.pipe_xcds > 0 ? w->pipe_xcc_uses * (unsigned)(blocks / a.pipe_xcds) : 0u;
-    // (the gate also keeps the per-XCD tickets of consecutive launches apart: without it the first overlapping dispatch trips the kernels' ticket check
-    // and the process aborts - tried once, profiles/r04_ab_log.txt call R: a trap, not a hang)
-    if (a.pipe_wait_on)
-      hipLaunchKernelGGL(pipe_gate_kernel, dim3(1), dim3(1), 0, ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total);
-    if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }   // rsb_step_pipeline_wait_event
-    HIP_TRY(hipGetLastError());
+    w->pipe_time_logged += nsub * w->dt;
   } else {
     ls = stream_of(w);
     if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }
@@ -760,14 +511,7 @@ int do_integrate(rsb_world* w, int nsub) {
     return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
-  if (pipelined) {   // (only a launch that is on its way counts: the gate of the next one waits for this one's workgroups)
-    w->pipe_active = true;
-    ++w->pipe_n; w->pipe_next ^= 1; w->pipe_seq = (unsigned)a.pipe_seq;
-    if (a.pipe_xcds > 0) ++w->pipe_xcc_uses;
-    w->pipe_wg_total += (unsigned long long)w->pipe_blocks;
-    w->pipe_last = ls;
-    ++w->pipe_launches;
-  }
+  if (pipelined) pipe_end_launch(w, a, ls);
   if (rec) {
     HIP_TRY(hipEventRecord(e1, ls));
     if (!w->ring0.empty()) { w->ring_next = (w->ring_next + 1) % w->ring0.size(); if (w->ring_count < w->ring0.size()) ++w->ring_count; }
@@ -783,12 +527,22 @@ int copy_in(rsb_world* w, float* dst, const float* src, size_t n, int space) {
   return RSB_OK;
 }
 int copy_out(rsb_world* w, void* dst, const void* src, size_t bytes, int space) {
-  HIP_TRY(hipMemcpyAsync(dst, src, bytes, space == RSB_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, stream_of(w)));
-  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(stream_of(w)));
+  hipStream_t s = stream_of(w);
+  const int fs = fault_status(w);      // a read that joined a faulted pipeline says so ONCE (nothing is copied; the recovered state is there for the next call)
+  if (fs != RSB_OK) return fs;
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, space == RSB_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, s));
+  if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(s));
   return RSB_OK;
 }
 
-}  // namespace
+int launch_env_obs(rsb_world* w, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(env_obs_kernel, dim3((w->N + 255) / 256), dim3(256), 0, s, dst, w->d_gc, w->d_gv, w->N, w->blob.nq, w->blob.nv);
+  HIP_TRY(hipGetLastError());
+  return RSB_OK;
+}
+
+}  // namespace rsbw
+using namespace rsbw;
 
 extern "C" {
 
@@ -879,11 +633,9 @@ int rsb_destroy(rsb_world* w) {
   for (hipEvent_t e : w->ring1) (void)hipEventDestroy(e);
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
-  for (int i = 0; i < 2; ++i) if (w->pipe_stream[i]) (void)hipStreamDestroy(w->pipe_stream[i]);
-  for (int i = 0; i < 3; ++i) if (w->pipe_ev[i]) (void)hipEventDestroy(w->pipe_ev[i]);
-  if (w->pipe_pub) (void)hipEventDestroy(w->pipe_pub);
-  if (w->d_pipe_prog) (void)hipFree(w->d_pipe_prog);
-  if (w->d_pipe_started) (void)hipFree(w->d_pipe_started);
+  pipe_destroy(w);
+  if (w->d_env_act) (void)hipFree(w->d_env_act);
+  if (w->d_env_gc0_rows) { (void)hipFree(w->d_env_gc0_rows); (void)hipFree(w->d_env_gv0_rows); }
   if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
   delete w;
   return RSB_OK;
@@ -903,7 +655,7 @@ int rsb_synchronize(rsb_world* w) {
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipStreamSynchronize(stream_of(w)));
-  return RSB_OK;
+  return fault_status(w);
 }
 
 int rsb_num_envs(const rsb_world* w) { return w ? w->N : RSB_E_INVALID; }
@@ -1045,51 +797,6 @@ int rsb_set_capsule_contacts(rsb_world* w, int on) {
   }
   w->hm_capsule = on != 0;
   return RSB_OK;
-}
-// A profiler that SERIALISES dispatches (rocprofv3 --pmc / counter collection, thread trace with serialize-all) runs one kernel at a time in an
-// order of its own: a pipelined launch then waits for a predecessor that is not allowed to start, the kernels trap after their ~10 s and
-// rocprofv3 hangs in its signal handler (measured: profiles/r04_ab_log.txt, call S).  Under such a tool - or with RSB_STEP_PIPELINING=0 - the
-// switch stays off: counters are collected on the plain kernel classes.
-bool pipelining_forbidden() {
-  auto set = [](const char* n) { const char* v = std::getenv(n); return v && *v && std::strcmp(v, "0") != 0 && std::strcmp(v, "false") != 0 && std::strcmp(v, "False") != 0; };
-  const char* force = std::getenv("RSB_STEP_PIPELINING");
-  if (force && std::strcmp(force, "0") == 0) return true;
-  return set("ROCPROF_COUNTER_COLLECTION") || set("ROCPROF_ATT_PARAM_SERIALIZE_ALL") || set("ROCPROFILER_COUNTER_COLLECTION");
-}
-int rsb_set_step_pipelining(rsb_world* w, int on) {
-  if (!w) { rsb::set_error("rsb_set_step_pipelining: null world"); return RSB_E_INVALID; }
-  HIP_TRY(hipSetDevice(w->device));
-  (void)stream_of(w);
-  if (on && pipelining_forbidden()) {
-    static bool said = false;
-    if (!said) { std::fprintf(stderr, "raisimlib_amd: control steps stay un-pipelined (RSB_STEP_PIPELINING=0 or a dispatch-serialising profiler in the environment)\n"); said = true; }
-    w->pipe_on = false;
-    return RSB_OK;
-  }
-  w->pipe_on = on != 0;
-  return RSB_OK;
-}
-int rsb_step_pipelining_enabled(const rsb_world* w) { return w && w->pipe_on ? 1 : 0; }
-int rsb_step_pipeline_publish(rsb_world* w, void* hip_stream) {
-  if (!w) { rsb::set_error("rsb_step_pipeline_publish: null world"); return RSB_E_INVALID; }
-  HIP_TRY(hipSetDevice(w->device));
-  if (!w->pipe_pub) HIP_TRY(hipEventCreateWithFlags(&w->pipe_pub, hipEventDisableTiming));
-  const bool in_flight = w->pipe_active && w->pipe_last;
-  if (!in_flight && (hipStream_t)hip_stream == w->stream) return RSB_OK;       // nothing in flight and the world's own stream: already ordered
-  HIP_TRY(hipEventRecord(w->pipe_pub, in_flight ? w->pipe_last : w->stream));   // (no pipelined step in flight: the last step is on the world's stream)
-  HIP_TRY(hipStreamWaitEvent((hipStream_t)hip_stream, w->pipe_pub, 0));
-  return RSB_OK;
-}
-int rsb_step_pipeline_wait_event(rsb_world* w, void* hip_event) {
-  if (!w) { rsb::set_error("rsb_step_pipeline_wait_event: null world"); return RSB_E_INVALID; }
-  w->pipe_dep = (hipEvent_t)hip_event;
-  return RSB_OK;
-}
-int rsb_step_pipelining_stats(rsb_world* w, long long* launches, long long* joins) {
-  if (!w) return RSB_E_INVALID;
-  if (launches) *launches = w->pipe_launches;
-  if (joins) *joins = w->pipe_joins;
-  return w->pipe_overlap ? RSB_OK : 1;
 }
 int rsb_set_integration_scheme(rsb_world* w, int scheme) {
   if (!w) return RSB_E_INVALID;
@@ -1605,12 +1312,36 @@ int rsb_env_configure(rsb_world* w, const rsb_env_config* cfg, const float* acti
     HIP_TRY(hipMalloc(&w->d_env_tau2, N * sizeof(float)));
     HIP_TRY(hipMemset(w->d_env_tau2, 0, N * sizeof(float)));
     HIP_TRY(hipMalloc(&w->d_env_done, N));
+    HIP_TRY(hipMalloc(&w->d_env_act, N * nj * sizeof(float)));     // the closed loop's action rows (rsb_closed_loop_run)
+    HIP_TRY(hipMemset(w->d_env_act, 0, N * nj * sizeof(float)));
   }
   HIP_TRY(hipMemcpyAsync(w->d_env_mean, action_mean, nj * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
   HIP_TRY(hipMemcpyAsync(w->d_env_gc0, gc_init, nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
   HIP_TRY(hipMemcpyAsync(w->d_env_gv0, gv_init, nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
   HIP_TRY(hipStreamSynchronize(stream_of(w)));
   w->env_cfg = *cfg; w->env_allowed = allowed; w->env_ready = true;
+  return RSB_OK;
+}
+int rsb_env_set_reset_states(rsb_world* w, const float* gc0, const float* gv0, int space) {
+  if (!w || ((gc0 != nullptr) != (gv0 != nullptr)) || (space != RSB_HOST && space != RSB_DEVICE)) { rsb::set_error("rsb_env_set_reset_states: bad argument"); return RSB_E_INVALID; }
+  if (!w->env_ready) { rsb::set_error("rsb_env_set_reset_states: call rsb_env_configure first"); return RSB_E_STATE; }
+  HIP_TRY(hipSetDevice(w->device));
+  hipStream_t s = stream_of(w);
+  const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
+  if (!gc0) {
+    HIP_TRY(hipStreamSynchronize(s));
+    if (w->d_env_gc0_rows) { HIP_TRY(hipFree(w->d_env_gc0_rows)); HIP_TRY(hipFree(w->d_env_gv0_rows)); }
+    w->d_env_gc0_rows = w->d_env_gv0_rows = nullptr;
+    return RSB_OK;
+  }
+  if (!w->d_env_gc0_rows) {
+    HIP_TRY(hipMalloc(&w->d_env_gc0_rows, N * nq * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_env_gv0_rows, N * nv * sizeof(float)));
+  }
+  const hipMemcpyKind kind = space == RSB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  HIP_TRY(hipMemcpyAsync(w->d_env_gc0_rows, gc0, N * nq * sizeof(float), kind, s));
+  HIP_TRY(hipMemcpyAsync(w->d_env_gv0_rows, gv0, N * nv * sizeof(float), kind, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return RSB_OK;
 }
 int rsb_env_dims(const rsb_world* w, int* ob_dim, int* action_dim) {
@@ -1628,7 +1359,8 @@ static int env_check(rsb_world* w, const char* who) {
 int rsb_env_reset(rsb_world* w) {
   int st = env_check(w, "rsb_env_reset"); if (st != RSB_OK) return st;
   hipLaunchKernelGGL(env_reset_kernel, dim3((w->N + 255) / 256), dim3(256), 0, stream_of(w), w->d_gc, w->d_gv, w->d_count,
-                     w->d_flags, w->d_env_gc0, w->d_env_gv0, w->N, w->blob.nq, w->blob.nv, w->d_warm, rsbk::kWarmRow);
+                     w->d_flags, w->d_env_gc0_rows ? w->d_env_gc0_rows : w->d_env_gc0, w->d_env_gc0_rows ? w->d_env_gv0_rows : w->d_env_gv0,
+                     w->d_env_gc0_rows ? w->N : 1, w->N, w->blob.nq, w->blob.nv, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
   return RSB_OK;
@@ -1647,7 +1379,7 @@ int rsb_env_observe(rsb_world* w, float* ob, int space) {
 int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done, float* ob_next, int space) {
   int st = env_check(w, "rsb_env_step"); if (st != RSB_OK) return st;
   if (!action) return RSB_E_INVALID;
-  const int N = w->N, nq = w->blob.nq, nv = w->blob.nv, nj = nv - 6;
+  const int N = w->N, nv = w->blob.nv, nj = nv - 6;
   const size_t od = 10 + 2 * (size_t)nj;
   const float* dact = action;
   if (space == RSB_HOST) {
@@ -1664,6 +1396,7 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
     f.act = dact;
     f.have_allowed = 1; f.allowed = w->env_allowed;
     f.do_reset = 1; f.gc0 = w->d_env_gc0; f.gv0 = w->d_env_gv0; f.rows = 1;
+    if (w->d_env_gc0_rows) { f.gc0 = w->d_env_gc0_rows; f.gv0 = w->d_env_gv0_rows; f.rows = w->N; }      // rsb_env_set_reset_states
     f.env_task = true; f.env_reward = drew; f.env_ob = dob; f.env_done = ddone;
     w->fuse = f;
   }
@@ -1783,252 +1516,6 @@ int rsb_last_kernel_ms(rsb_world* w, float* ms) {
   HIP_TRY(hipSetDevice(w->device));
   HIP_TRY(hipEventSynchronize(w->ev1));
   HIP_TRY(hipEventElapsedTime(ms, w->ev0, w->ev1));
-  return RSB_OK;
-}
-
-}  // extern "C"
-
-// ---- RCCL (loaded at run time: a single-GPU host never needs it) -------------------------------------------------
-namespace {
-struct Rccl {
-  struct UniqueId { char internal[RSB_COMM_ID_BYTES]; };     // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
-  int (*GetUniqueId)(UniqueId*) = nullptr;
-  int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-  void* handle = nullptr;
-  std::string error;
-};
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.handle ? &r : nullptr;
-  tried = true;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) { r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.handle) break; }
-  if (!r.handle) { r.error = std::string("cannot load librccl.so.1: ") + dlerror(); return nullptr; }
-  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
-  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
-  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
-  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
-  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
-    r.error = "librccl.so.1 lacks an expected ncclXxx symbol"; dlclose(r.handle); r.handle = nullptr; return nullptr;
-  }
-  return &r;
-}
-Rccl* need_rccl() {
-  Rccl* r = rccl();
-  if (!r) rsb::set_error("RCCL unavailable (multi-GPU entry points need /opt/rocm/lib/librccl.so.1)");
-  return r;
-}
-constexpr int kNcclFloat32 = 7;   // ncclDataType_t::ncclFloat32 (rccl.h)
-#define NCCL_TRY(expr)                                                                                   \
-  do {                                                                                                   \
-    int r_ = (expr);                                                                                     \
-    if (r_ != 0) { rsb::set_error(std::string(#expr) + ": " + R->GetErrorString(r_)); return RSB_E_HIP; } \
-  } while (0)
-}  // namespace
-
-extern "C" {
-
-int rsb_comm_get_unique_id(char id[RSB_COMM_ID_BYTES]) {
-  if (!id) return RSB_E_INVALID;
-  Rccl* R = need_rccl();
-  if (!R) return RSB_E_UNSUPPORTED;
-  Rccl::UniqueId u;
-  NCCL_TRY(R->GetUniqueId(&u));
-  std::memcpy(id, u.internal, RSB_COMM_ID_BYTES);
-  return RSB_OK;
-}
-
-int rsb_comm_init(rsb_world* w, int n_ranks, int rank, const char id[RSB_COMM_ID_BYTES]) {
-  if (!w || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) { rsb::set_error("rsb_comm_init: bad argument"); return RSB_E_INVALID; }
-  if (w->comm) { rsb::set_error("rsb_comm_init: the world already has a communicator"); return RSB_E_STATE; }
-  Rccl* R = need_rccl();
-  if (!R) return RSB_E_UNSUPPORTED;
-  HIP_TRY(hipSetDevice(w->device));
-  Rccl::UniqueId u;
-  std::memcpy(u.internal, id, RSB_COMM_ID_BYTES);
-  NCCL_TRY(R->CommInitRank(&w->comm, n_ranks, u, rank));
-  w->comm_ranks = n_ranks; w->comm_rank = rank;
-  return RSB_OK;
-}
-
-int rsb_comm_destroy(rsb_world* w) {
-  if (!w || !w->comm) return RSB_OK;
-  Rccl* R = rccl();
-  if (R) { (void)hipSetDevice(w->device); (void)hipStreamSynchronize(stream_of(w)); (void)R->CommDestroy(w->comm); }
-  w->comm = nullptr; w->comm_ranks = 0;
-  return RSB_OK;
-}
-
-// ---- peer-mapped obs exchange: no collective, no copy kernel (see rsb.h) -------------------------------------------------
-__global__ void obs_peer_wait_kernel(const uint32_t* flags, int n, uint32_t step) {
-  // fallback of rsb_obs_peer_wait when the stream cannot wait on a memory value: lane p spins until rank p's flag has the step
-  const int p = threadIdx.x;
-  if (p < n) while ((int32_t)(__hip_atomic_load(flags + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - step) < 0) __builtin_amdgcn_s_sleep(8);
-}
-
-int rsb_obs_peer_create(rsb_world* w, int n_ranks, int rank, const int32_t* collision_indices, int n_force_slots, char handle[RSB_OBS_HANDLE_BYTES]) {
-  if (!w || n_ranks < 1 || n_ranks > RSB_MAX_RANKS || rank < 0 || rank >= n_ranks || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) {
-    rsb::set_error("rsb_obs_peer_create: bad argument (1 <= n_ranks <= RSB_MAX_RANKS)"); return RSB_E_INVALID;
-  }
-  if (w->peer.base) { rsb::set_error("rsb_obs_peer_create: the world already has an exchange (rsb_obs_peer_destroy first)"); return RSB_E_STATE; }
-  HIP_TRY(hipSetDevice(w->device));
-  rsb_world::Peer& P = w->peer;
-  P.ranks = n_ranks; P.rank = rank; P.slots = n_force_slots; P.od = w->blob.nq + w->blob.nv + 3 * n_force_slots;
-  P.idx.clear();
-  if (collision_indices) {
-    for (int i = 0; i < n_force_slots; ++i) {
-      if (collision_indices[i] < 0 || collision_indices[i] >= w->blob.ncol) { rsb::set_error("rsb_obs_peer_create: collision index out of range"); return RSB_E_INVALID; }
-      P.idx.push_back(collision_indices[i]);
-    }
-  }
-  const size_t bufsz = (size_t)n_ranks * w->N * P.od;
-  P.bytes = 2 * bufsz * sizeof(float) + (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t);
-  // fine-grained memory: stores of OTHER devices' kernels (and their system-scope flag writes) become visible without a kernel
-  // boundary on this device; plain hipMalloc is the fallback where the runtime refuses the flag
-  // Coarse-grained memory gives NO such guarantee (a remote rank's write-through stores and the flag a consumer polls may sit in a
-  // cache until a kernel boundary: a wait can hang), so without fine-grained memory the exchange is refused - RSB_OBS_PEER_COARSE=1
-  // forces plain hipMalloc for single-device diagnostics.
-  static const bool coarse = std::getenv("RSB_OBS_PEER_COARSE") != nullptr;
-  if (coarse) HIP_TRY(hipMalloc(&P.base, P.bytes));
-  else if (hipExtMallocWithFlags(&P.base, P.bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-    (void)hipGetLastError(); P.base = nullptr;
-    rsb::set_error("rsb_obs_peer_create: no fine-grained device memory on this system (the exchange's visibility rests on it); use the RCCL all-gather");
-    return RSB_E_UNSUPPORTED;
-  }
-  auto fail = [&](hipError_t e) {      // nothing half-created survives an error: a retry must not see "already has an exchange"
-    rsb::set_error(std::string("rsb_obs_peer_create: ") + hipGetErrorString(e));
-    (void)hipFree(P.base); P.base = nullptr;
-    if (P.d_idx) { (void)hipFree(P.d_idx); P.d_idx = nullptr; }
-    return RSB_E_HIP;
-  };
-  hipError_t e = hipMemsetAsync(P.base, 0, P.bytes, stream_of(w));
-  if (e != hipSuccess) return fail(e);
-  if (!P.idx.empty()) {
-    if ((e = hipMalloc(&P.d_idx, P.idx.size() * sizeof(int32_t))) != hipSuccess) return fail(e);
-    if ((e = hipMemcpyAsync(P.d_idx, P.idx.data(), P.idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream_of(w))) != hipSuccess) return fail(e);
-  }
-  if ((e = hipStreamSynchronize(stream_of(w))) != hipSuccess) return fail(e);
-  if (handle) {
-    std::memset(handle, 0, RSB_OBS_HANDLE_BYTES);
-    hipIpcMemHandle_t h;
-    static_assert(sizeof(hipIpcMemHandle_t) <= RSB_OBS_HANDLE_BYTES, "IPC handle does not fit RSB_OBS_HANDLE_BYTES");
-    if (hipIpcGetMemHandle(&h, P.base) == hipSuccess) std::memcpy(handle, &h, sizeof h);
-    else (void)hipGetLastError();       // (no IPC on this system: rsb_obs_peer_connect_ptrs within one process still works)
-  }
-  return RSB_OK;
-}
-
-static int obs_peer_finish_connect(rsb_world* w) {
-  // diagnostic: force the one-wave wait kernel instead of the stream's memory-wait packet
-  w->peer.wait_by_kernel = std::getenv("RSB_OBS_PEER_WAIT_KERNEL") != nullptr;
-  // a RE-connect starts the step numbers again at 0: the flag words and the arrival counter must not keep the numbers of the earlier
-  // connection, or the first waits (>= 1) would pass on stale rows.  (The first connect finds them zeroed by rsb_obs_peer_create; the ranks
-  // of a reconnecting job must meet at a barrier between their connects and their first control step, like at start-up.)
-  rsb_world::Peer& P = w->peer;
-  if (P.step != 0) {
-    const size_t bufsz = (size_t)P.ranks * w->N * P.od;
-    HIP_TRY(hipSetDevice(w->device));
-    HIP_TRY(hipMemsetAsync(static_cast<float*>(P.base) + 2 * bufsz, 0, (2 * RSB_MAX_RANKS + 4) * sizeof(uint32_t), stream_of(w)));
-    HIP_TRY(hipStreamSynchronize(stream_of(w)));
-  }
-  w->peer.connected = true; w->peer.step = 0;
-  return RSB_OK;
-}
-
-int rsb_obs_peer_connect(rsb_world* w, const char* handles) {
-  if (!w || !handles) { rsb::set_error("rsb_obs_peer_connect: bad argument"); return RSB_E_INVALID; }
-  if (!w->peer.base) { rsb::set_error("rsb_obs_peer_connect: call rsb_obs_peer_create first"); return RSB_E_STATE; }
-  HIP_TRY(hipSetDevice(w->device));
-  rsb_world::Peer& P = w->peer;
-  for (int p = 0; p < P.ranks; ++p) {
-    if (p == P.rank) { P.peer_base[p] = P.base; continue; }
-    hipIpcMemHandle_t h;
-    std::memcpy(&h, handles + (size_t)p * RSB_OBS_HANDLE_BYTES, sizeof h);
-    void* ptr = nullptr;
-    HIP_TRY(hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
-    P.peer_base[p] = ptr; P.imported[p] = true;
-  }
-  return obs_peer_finish_connect(w);
-}
-
-int rsb_obs_peer_connect_ptrs(rsb_world* w, void* const* bases) {
-  if (!w || !bases) { rsb::set_error("rsb_obs_peer_connect_ptrs: bad argument"); return RSB_E_INVALID; }
-  if (!w->peer.base) { rsb::set_error("rsb_obs_peer_connect_ptrs: call rsb_obs_peer_create first"); return RSB_E_STATE; }
-  rsb_world::Peer& P = w->peer;
-  for (int p = 0; p < P.ranks; ++p) {
-    if (p != P.rank && !bases[p]) { rsb::set_error("rsb_obs_peer_connect_ptrs: null base pointer"); return RSB_E_INVALID; }
-    P.peer_base[p] = p == P.rank ? P.base : bases[p];
-  }
-  return obs_peer_finish_connect(w);
-}
-
-void* rsb_obs_peer_base(rsb_world* w) { return w ? w->peer.base : nullptr; }
-
-int rsb_obs_peer_wait(rsb_world* w, float** gathered) {
-  if (!w) return RSB_E_INVALID;
-  rsb_world::Peer& P = w->peer;
-  if (!P.connected || P.step == 0) { rsb::set_error("rsb_obs_peer_wait: no control step has been issued with the exchange"); return RSB_E_STATE; }
-  HIP_TRY(hipSetDevice(w->device));
-  const size_t bufsz = (size_t)P.ranks * w->N * P.od;
-  const int par = (int)(P.step & 1u);
-  uint32_t* flags = reinterpret_cast<uint32_t*>(static_cast<float*>(P.base) + 2 * bufsz) + (size_t)par * RSB_MAX_RANKS;
-  if (!P.wait_by_kernel) {
-    // the command processor polls the flag words: no kernel, no CU
-    for (int p = 0; p < P.ranks && !P.wait_by_kernel; ++p)
-      if (hipStreamWaitValue32(stream_of(w), flags + p, P.step, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) { (void)hipGetLastError(); P.wait_by_kernel = true; }
-  }
-  if (P.wait_by_kernel) {
-    hipLaunchKernelGGL(obs_peer_wait_kernel, dim3(1), dim3(64), 0, stream_of(w), flags, P.ranks, P.step);
-    HIP_TRY(hipGetLastError());
-  }
-  if (gathered) *gathered = static_cast<float*>(P.base) + (size_t)par * bufsz;
-  return RSB_OK;
-}
-
-int rsb_obs_peer_destroy(rsb_world* w) {
-  if (!w || !w->peer.base) return RSB_OK;
-  (void)hipSetDevice(w->device);
-  (void)hipStreamSynchronize(stream_of(w));
-  rsb_world::Peer& P = w->peer;
-  for (int p = 0; p < P.ranks; ++p) if (P.imported[p]) (void)hipIpcCloseMemHandle(P.peer_base[p]);
-  (void)hipFree(P.base);
-  if (P.d_idx) (void)hipFree(P.d_idx);
-  w->peer = rsb_world::Peer();
-  return RSB_OK;
-}
-
-int rsb_allgather_obs(rsb_world* w, const int32_t* collision_indices, int n_force_slots, float* out, int space) {
-  if (!w || !out || n_force_slots < 0 || n_force_slots > RSB_MAX_COLLISIONS) { rsb::set_error("rsb_allgather_obs: bad argument"); return RSB_E_INVALID; }
-  if (!w->comm) { rsb::set_error("rsb_allgather_obs: call rsb_comm_init first"); return RSB_E_STATE; }
-  Rccl* R = need_rccl();
-  if (!R) return RSB_E_UNSUPPORTED;
-  HIP_TRY(hipSetDevice(w->device));
-  const size_t local = (size_t)w->N * (w->blob.nq + w->blob.nv + 3 * n_force_slots), all = local * w->comm_ranks;
-  if (w->obs_local_cap < local) {
-    if (w->d_obs_local) HIP_TRY(hipFree(w->d_obs_local));
-    w->d_obs_local = nullptr; w->obs_local_cap = 0;
-    HIP_TRY(hipMalloc(&w->d_obs_local, local * sizeof(float)));
-    w->obs_local_cap = local;
-  }
-  float* dall = out;
-  if (space == RSB_HOST) {
-    if (w->obs_all_cap < all) {
-      if (w->d_obs_all) HIP_TRY(hipFree(w->d_obs_all));
-      w->d_obs_all = nullptr; w->obs_all_cap = 0;
-      HIP_TRY(hipMalloc(&w->d_obs_all, all * sizeof(float)));
-      w->obs_all_cap = all;
-    }
-    dall = w->d_obs_all;
-  }
-  int st = rsb_gather_obs(w, w->d_obs_local, collision_indices, n_force_slots, RSB_DEVICE);
-  if (st != RSB_OK) return st;
-  NCCL_TRY(R->AllGather(w->d_obs_local, dall, local, kNcclFloat32, w->comm, stream_of(w)));
-  if (space == RSB_HOST) return copy_out(w, out, dall, all * sizeof(float), RSB_HOST);
   return RSB_OK;
 }
 

@@ -617,7 +617,13 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
       if (lane == 0) t = __hip_atomic_fetch_add(a.pipe_xcc_ctr + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_xcc_base;
       t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
       const unsigned per = gridDim.x / (unsigned)a.pipe_xcds;
-      if (t >= per || xcc >= (unsigned)a.pipe_xcds) __builtin_trap();      // (the dispatcher deals workgroups round-robin: checked by the host's probe)
+      if (t >= per || xcc >= (unsigned)a.pipe_xcds) {
+        // the dispatcher did not deal this launch's workgroups round-robin over the XCDs (the host's probe saw it do so on an idle device): no
+        // env block can be assigned.  Error word instead of a trap: this workgroup leaves without touching anything, the others follow (below),
+        // the host's next join replays the steps in lock-step
+        if (lane == 0) __hip_atomic_store(a.pipe_err, 1 /* RSB_PIPE_ERR_TICKET */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
       blk = (int)(xcc * per + t);
     }
   }
@@ -683,10 +689,21 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
     // over the XCDs starts somewhere else in every launch: profiles/r04_ubench_xcc_map.txt).  (Staging the tables BEFORE this wait - they do not
     // depend on the predecessor - measured 1.5 % slower: the state loads then no longer overlap the table copy.)
     if (a.pipe_wait_on) {
-      int spins = 0;       // (a predecessor that never publishes would be a bug of the host side: trap after ~2 s rather than hang the device)
-      while (__hip_atomic_load(a.pipe_prog + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_wait < 0) {
+      // (open loop: the word of this block's own predecessor; closed loop: the action stage's word for this block, StepArgs::pipe_wait_ptr)
+      int spins = 0;
+      long long t0 = 0;
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pipe_wait_ptr + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - a.pipe_wait < 0) {
+        // somebody failed (a ticket, a time-out): nobody will publish this block - leave without touching it (the host replays in lock-step)
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pipe_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 23)) __builtin_trap();
+        if ((++spins & 255) == 0) {      // a wait past the time-out is reported, not trapped (a predecessor that never publishes: a fault of the host side, a GPU shared with a long-running job, a debugger)
+          const long long now = wall_clock64();
+          if (t0 == 0) t0 = now;
+          else if (now - t0 > a.pipe_timeout) {
+            if (lane == 0) __hip_atomic_store(a.pipe_err, 2 /* RSB_PIPE_ERR_TIMEOUT */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+          }
+        }
       }
     }
     if (a.pipe_xcds > 0) asm volatile("buffer_inv sc1" ::: "memory");

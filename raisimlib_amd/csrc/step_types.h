@@ -185,6 +185,15 @@ struct StepArgs {
   int pipe_xcds;                         // > 0: XCD-affine blocks (the device's XCD count; the grid is a multiple of it): block = XCD x (grid / XCDs) + ticket
   unsigned* pipe_xcc_ctr;                // [16] tickets taken per XCD (monotonic)
   unsigned pipe_xcc_base;                // their value at the start of this launch
+  // round 5: no device trap anywhere in the pipeline.  A workgroup that draws a ticket outside its XCD's range, or whose wait runs past
+  // pipe_timeout (ticks of the 100 MHz wall clock), stores a code (rsb_pipeline.h: RSB_PIPE_ERR_*) into *pipe_err and returns WITHOUT integrating or
+  // publishing; every waiting workgroup (and gate) sees the word in its spin and returns too, so the streams drain and the host's next join
+  // finds the word: it restores the state of the last join and replays the steps in lock-step (rsb_world.hip: pipe_recover).
+  int* pipe_err;
+  long long pipe_timeout;
+  // closed loop (rsb_closed_loop_run): a step does not wait for its OWN predecessor's word but for the action stage's - workgroup b of step k + 1
+  // starts when the stage has published block b's actions computed from step k's observation (act_prog[b] >= pipe_wait).  Open loop: == pipe_prog
+  const int* pipe_wait_ptr;
 #ifdef RSB_X_ARGPAD
   char x_pad[RSB_X_ARGPAD];
 #endif

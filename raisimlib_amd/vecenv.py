@@ -130,6 +130,54 @@ class VecEnv:
         check(w.L.rsb_env_step(w.handle, _hp(a), _hp(reward), _hp(done), _hp(ob_next), RSB_HOST), "rsb_env_step")
         return reward, done
 
+    # -- the closed loop on the device (include/rsb_pipeline.h): K steps with a policy between them, handed over env block by env block ----
+    def set_reset_states(self, gc0=None, gv0=None):
+        """per-env reset states [num_envs, nq] / [num_envs, nv] (numpy; None, None: back to the single gc_init / gv_init)"""
+        w = self.world
+        if gc0 is None:
+            check(w.L.rsb_env_set_reset_states(w.handle, None, None, RSB_HOST), "rsb_env_set_reset_states")
+            return
+        a, b = np.ascontiguousarray(gc0, np.float32), np.ascontiguousarray(gv0, np.float32)
+        assert a.shape == (self.num_envs, self.nq) and b.shape == (self.num_envs, self.nv)
+        check(w.L.rsb_env_set_reset_states(w.handle, _hp(a), _hp(b), RSB_HOST), "rsb_env_set_reset_states")
+
+    def closed_loop_buffers(self):
+        """device pointers (ob [N, num_obs], act [N, num_acts], reward [N], done [N]) of the world's own env-task buffers"""
+        w = self.world
+        ps = [C.c_void_p(0) for _ in range(4)]
+        check(w.L.rsb_closed_loop_buffers(w.handle, *[C.byref(p) for p in ps]), "rsb_closed_loop_buffers")
+        return tuple(int(p.value or 0) for p in ps)
+
+    def set_stage_grid(self, workgroups):
+        check(self.world.L.rsb_closed_loop_set_stage_grid(self.world.handle, int(workgroups)), "rsb_closed_loop_set_stage_grid")
+
+    def rollout_linear(self, n_steps, W, bias=None, noise=None, clip=0.0, rollout=None):
+        """n_steps control steps with the in-repo reference stage in the loop: action = clip(bias + W ob + noise[step % period])  (torch CUDA
+        tensors: W [num_acts, num_obs], bias [num_acts], noise [period, num_envs, num_acts]).  `rollout` (optional): dict of torch CUDA tensors
+        ob [K + 1, N, num_obs], act [K, N, num_acts], reward [K, N] float32, done [K, N] uint8, filled on the device.  Nothing synchronises;
+        with world.set_step_pipelining(True) the steps overlap at env-block granularity, bit-identical to lock-step."""
+        import torch
+        w = self.world
+        K, N = int(n_steps), self.num_envs
+        self._check_tensor(W, (self.num_acts, self.num_obs), torch.float32, "W")
+        p = _capi.LinearPolicy()
+        p.W = W.data_ptr()
+        if bias is not None:
+            self._check_tensor(bias, (self.num_acts,), torch.float32, "bias")
+            p.bias = bias.data_ptr()
+        if noise is not None:
+            self._check_tensor(noise, (noise.shape[0], N, self.num_acts), torch.float32, "noise")
+            p.noise, p.noise_period = noise.data_ptr(), int(noise.shape[0])
+        p.clip = float(clip)
+        if rollout is not None:
+            for key, shape, dt in (("ob", (K + 1, N, self.num_obs), torch.float32), ("act", (K, N, self.num_acts), torch.float32),
+                                   ("reward", (K, N), torch.float32), ("done", (K, N), torch.uint8)):
+                if rollout.get(key) is not None:
+                    self._check_tensor(rollout[key], shape, dt, f"rollout[{key}]")
+                    setattr(p, "rollout_" + key, rollout[key].data_ptr())
+        self._keep = (W, bias, noise, rollout)       # the launches are asynchronous: keep the tensors alive until the next call
+        check(w.L.rsb_closed_loop_run_linear(w.handle, K, C.byref(p)), "rsb_closed_loop_run_linear")
+
     # -- running observation statistics (RaisimGymVecEnv's normalize_ob / RunningMeanStd [RECALL]) -------------------
     def observe_normalized(self, out, update_statistics=True, clip=10.0, eps=1e-8):
         """Observation tensor [num_envs, num_obs] (torch CUDA), normalised in place with running mean / variance kept on

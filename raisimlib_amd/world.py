@@ -257,6 +257,21 @@ class BatchedWorld:
         self.pipeline_overlaps = st == 0        # False: no two streams on different hardware queues were found (correct, but in order)
         return int(a.value), int(b.value)
 
+    def step_pipeline_join(self):
+        """Waits for every pipelined step / stage pass in flight; raises RsbError (status RSB_E_PIPELINE) ONCE after a device-side fault - the
+        library has by then restored the last joined state and replayed the steps in lock-step (include/rsb_pipeline.h)."""
+        check(self.L.rsb_step_pipeline_join(self.handle), "rsb_step_pipeline_join")
+
+    def step_pipeline_fault(self):
+        """(faults so far, device code of the last one: RSB_PIPE_ERR_*)"""
+        a, b = C.c_int(0), C.c_int(0)
+        check(self.L.rsb_step_pipeline_fault(self.handle, C.byref(a), C.byref(b)), "rsb_step_pipeline_fault")
+        return int(a.value), int(b.value)
+
+    def debug_pipeline_fault(self, kind):
+        """tests: the next pipelined launch fails on the device (1: ticket, 2: time-out, 4: error word set)"""
+        check(self.L.rsb_debug_pipeline_fault(self.handle, int(kind)), "rsb_debug_pipeline_fault")
+
     def set_capsule_contacts(self, on=True):
         """Exact capsule / cylinder / box x height map: the barrel between a capsule's or cylinder's ends and the faces and edges between a box's corners
         report their deepest point (rsb_set_capsule_contacts)."""

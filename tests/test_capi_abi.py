@@ -1,4 +1,4 @@
-"""The C-ABI library loads on a CPU-only box and exports every symbol include/rsb.h declares."""
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/rsb.h and include/rsb_pipeline.h declare."""
 import ctypes as C
 import os
 import re
@@ -9,9 +9,15 @@ from common import ROOT
 
 
 def header_functions():
-    src = open(os.path.join(ROOT, "include", "rsb.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(rsb_[a-z0-9_]+)\s*\(", src)))
+    """every function the C-ABI declares: include/rsb.h and the closed-loop pipeline's include/rsb_pipeline.h (its C part: the device-side
+    serve loop behind `#if defined(__HIPCC__)` is a header-only template of the caller's kernel, not a symbol of the library)"""
+    names = set()
+    for h in ("rsb.h", "rsb_pipeline.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = src.split("#if defined(__HIPCC__)")[0]
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(rsb_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_declares_the_boundary():
