@@ -96,6 +96,8 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true",
                     help="headline only: skip the `secondary` block (configs 3 and 5 with the same --steps / --warmup) and `boundary_template_path` "
                          "that the default single-GPU run of config 2 appends")
+    ap.add_argument("--closed-loop-only", action="store_true", help="diagnostic: only the `closed_loop` block (policy in the loop, include/rsb_pipeline.h), as its own JSON line")
+    ap.add_argument("--stage-grid", type=int, default=0, help="diagnostic (closed loop): workgroups of the action stage (library default 256)")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="plumbing check without GPUs: the ranks rendezvous on gloo, all-gather a host obs block per step and "
                          "print the contract line with dry_run=true (no device world, no physics; value is not a measurement)")
@@ -453,6 +455,62 @@ def template_path(n, steps, threads=0):
     return res
 
 
+def closed_loop_leg(args, dev, n):
+    """The headline workload with a POLICY IN THE LOOP (include/rsb_pipeline.h): config 2 as the device-resident vectorised env
+    (action -> PD targets nominal + 0.3 * action, 4 x integrate(), reward / termination / reset / next observation in the step's epilogue) and the
+    in-repo reference stage between two steps: action = W ob + noise[k], W a fixed 12 x 34 matrix, noise[k] the open-loop benchmark's own target draw
+    of control step k - every step's targets depend on the step before.  Step k + 1's workgroup b starts when the stage has published block b's
+    actions computed from step k's observation of block b: the steps still overlap.  Timed like the headline (same --steps, barrier-free single
+    GPU: synchronise, enqueue ONE run of --steps steps, join, synchronise), pipelined and in lock-step from the same pre-rolled population."""
+    import torch
+    from raisimlib_amd import Model, rsc_path, workload
+    model = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+    stream = torch.cuda.Stream(device=dev)
+    res = {"what": "rsb_closed_loop_run_linear: K control steps of the vectorised env with the reference action stage (fixed linear policy, 12 x 34, + the open-loop "
+                   "benchmark's target noise) between every two steps, handed over env block by env block; `lockstep` = the same run with pipelining off "
+                   "(pass, step, pass, ... on one stream)",
+           "policy": {"W": f"U(-{workload.CLOSED_LOOP_W_SCALE:g}, {workload.CLOSED_LOOP_W_SCALE:g}) seeded, [12, 34]", "noise": "config 2's target draws, period 128", "action_std": 0.3}}
+    with torch.cuda.stream(stream):
+        env = workload.closed_loop_env(model, n, device=dev.index or 0, stream=stream.cuda_stream)
+        W = torch.from_numpy(workload.closed_loop_policy(env.num_obs, env.num_acts)).to(dev)
+        noise = torch.from_numpy(workload.closed_loop_noise(n, TARGET_BANK)).to(dev)
+        w = env.world
+        if args.stage_grid:
+            env.set_stage_grid(args.stage_grid)
+        for mode in ("pipelined", "lockstep"):
+            on = w.set_step_pipelining(mode == "pipelined")
+            if mode == "pipelined" and not on:
+                res["pipelined"] = None
+                continue
+            env.reset()
+            w.synchronize()
+            # (env.reset() also restarts the world's closed-loop step counter, which selects the noise slice: both modes run the same sequence)
+            env.rollout_linear(args.preroll + args.warmup, W, noise=noise)
+            w.step_pipeline_join()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            env.rollout_linear(args.steps, W, noise=noise)
+            t_enq = time.perf_counter() - t0
+            w.step_pipeline_join()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            K2 = 64
+            ro = {"done": torch.zeros((K2, n), dtype=torch.uint8, device=dev)}
+            env.rollout_linear(K2, W, noise=noise, rollout=ro)
+            w.step_pipeline_join()
+            cnt, _ = w.get_contacts()
+            q, _ = w.get_state()
+            res[mode] = {"value": n * workload.SUBSTEPS * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+                         "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+                         "resets_per_control_step_mean": float(ro["done"].sum().item()) / K2, "contacts_per_env": float(cnt.mean()),
+                         "solver_iters_mean": float(w.get_solver_iterations().mean()), "base_height_mean": float(q[:, 2].mean())}
+        faults, code = w.step_pipeline_fault()
+        launches, joins = w.step_pipelining_stats()
+        res["pipeline"] = {"pipelined_launches": launches, "joins": joins, "faults": faults, "last_fault_code": code, "streams_overlap": bool(w.pipeline_overlaps)}
+        env.close()
+    return res
+
+
 def measure(args, rank, local_rank, world_size, dev, coll):
     """One configuration end to end on this rank: world, pre-roll, warm-up, the timed region (barrier + synchronise on both sides, MAX
     over ranks), the sampling pass behind `roofline`, the CPU leg.  Returns the contract dictionary on rank 0, None elsewhere."""
@@ -779,6 +837,7 @@ def main():
     if args.dry_run_ranks:
         sys.exit(dry_run_ranks(args, rank, world_size))
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (this image's default; see rsb_world.hip)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # the closed loop runs three streams that must overlap (two step streams + the action stage's) beside the caller's: HIP's default of 4 hardware queues aliases them
     import torch
     import torch.distributed as dist
 
@@ -795,6 +854,9 @@ def main():
     if coll:
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
 
+    if args.closed_loop_only:
+        print(json.dumps({"closed_loop": closed_loop_leg(args, dev, args.envs_per_gpu)}), flush=True)
+        return
     out = measure(args, rank, local_rank, world_size, dev, coll)
     default_run = (world_size == 1 and args.config == 2 and not args.no_secondary and not args.no_cpu and args.envs_per_gpu == ENVS_PER_GPU
                    and not (args.early_termination or args.no_reset or args.max_iter or args.lanes_per_env or args.no_self_collision or args.force_collective or args.lockstep))
@@ -811,6 +873,11 @@ def main():
                 second[cfg] = measure(a2, rank, local_rank, world_size, dev, coll)
             except Exception as e:      # a secondary line must never take the headline down
                 out["secondary"][f"config{cfg}"] = {"error": f"{type(e).__name__}: {e}"}
+        # ... the headline workload with a policy in the loop (closed-loop pipeline, include/rsb_pipeline.h) ...
+        try:
+            out["closed_loop"] = closed_loop_leg(args, dev, args.envs_per_gpu)
+        except Exception as e:
+            out["closed_loop"] = {"error": f"{type(e).__name__}: {e}"}
         # ... then the headline workload through the reference's own boundary (host threads + GPU; two attempts, both reported: 32 actively
         # waiting threads on a 16-CPU quota are sometimes throttled as a group for a whole attempt, profiles/r04_ab_log.txt) ...
         try:

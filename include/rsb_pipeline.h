@@ -18,7 +18,7 @@
  *
  * The action stage is ONE launch per run of K steps: `grid` workgroups of 64 threads that stay resident next to the step kernel's
  * waves (which leave 96 VGPRs per SIMD lane and no LDS: keep a stage under 96 VGPRs, no LDS, or it takes SIMDs from the steps),
- * poll the hand-over words of the blocks of THEIR XCD, claim a block whose step has finished, run the caller's body on it and publish.
+ * poll the hand-over words of THEIR share of the blocks of their XCD, run the caller's body on a block whose step has finished and publish.
  * rsb_stage::serve() below is that loop; the caller writes
  *
  *     __global__ void my_stage(rsb_stage_ctx c, MyPolicy p) {
@@ -64,19 +64,24 @@ extern "C" {
 #define RSB_PIPE_ERR_TIMEOUT 2   /* a wait ran past the time-out (RSB_PIPE_TIMEOUT_MS, default 10 000 ms)                                     */
 #define RSB_PIPE_ERR_STAGE 3     /* the action stage: workgroups of other than 64 threads, or a workgroup on an XCD outside the step's range  */
 #define RSB_PIPE_ERR_INJECTED 4  /* rsb_debug_pipeline_fault                                                                                  */
+#define RSB_PIPE_ERR_TIMEOUT_GATE 5   /* ... the time-out of a gate (the launch before it was not dispatched completely in time)              */
+#define RSB_PIPE_ERR_TIMEOUT_STAGE 6  /* ... of an action-stage wave (no block of its XCD moved in time)                                      */
 
 /* What an action-stage kernel receives (by value).  Filled by the library; the caller only reads it. */
 typedef struct rsb_stage_ctx {
   /* hand-over words, device memory, one per env block */
   const int32_t* step_prog;   /* sequence number of the last step whose workgroup b has finished                    */
   int32_t* act_prog;          /* ... of the last pass served for block b                                             */
-  int32_t* act_claim;         /* ... of the last pass CLAIMED for block b (a wave serves what it claimed)            */
+  uint32_t* ticket;           /* arrival counters of the stage's waves per XCD (monotonic; XCD x's at [64 x]); ticket_base: their value at the start of this run */
   int32_t* err;               /* the pipeline's error word (0 = fine)                                                */
   uint32_t* started;          /* stage workgroups that have started (the first step of a run is gated on all `grid`) */
   int32_t blocks;             /* env blocks = workgroups of the step kernel                                          */
   int32_t envs_per_block;     /* block b holds envs [b * envs_per_block, min(n_envs, (b + 1) * envs_per_block))      */
   int32_t n_envs;
   int32_t xcds;               /* > 0: block b is always processed on XCD b / (blocks / xcds) - hand-over inside one L2 */
+  uint32_t ticket_base;
+  int32_t poll_sleep;         /* units of s_sleep 8 (512 cycles) an idle stage wave sleeps between two polls */
+  int32_t word_stride;        /* block b's hand-over words: step_prog[b * word_stride], act_prog[b * word_stride] (spread over the memory channels) */
   int32_t seq0;               /* sequence number that pass 0 waits for                                               */
   int32_t pass_first, pass_last;   /* the passes THIS launch serves (pipelined: 0 .. K; lock-step: one pass)          */
   int32_t n_steps;            /* K of the run: pass K is the final one                                               */
@@ -135,6 +140,9 @@ int rsb_step_pipeline_fault(const struct rsb_world* w, int* faults, int* last_co
  * every XCD falls outside the range: RSB_PIPE_ERR_TICKET), kind 2 = it waits for a sequence number nobody will publish
  * (RSB_PIPE_ERR_TIMEOUT after RSB_PIPE_TIMEOUT_MS), kind 4 = the error word is set outright (RSB_PIPE_ERR_INJECTED). */
 int rsb_debug_pipeline_fault(struct rsb_world* w, int kind);
+/* Debug aid (RSB_PIPE_STATS=1 in the environment when the world is created): mean time (us) a pipelined step workgroup waited for its env block and the
+ * share of workgroups that waited at all, over the pipelined launches since the last call.  Joins. */
+int rsb_debug_pipeline_wait_stats(struct rsb_world* w, double* mean_wait_us, double* waited_frac);
 
 #ifdef __cplusplus
 }
@@ -150,10 +158,10 @@ namespace rsb_stage {
 
 __device__ __forceinline__ int ld_word(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fail(const rsb_stage_ctx& c, int code) {
-  if ((threadIdx.x & 63) == 0) __hip_atomic_store(c.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((threadIdx.x & 63) == 0) atomicCAS(c.err, 0, code);      /* the first code stays */
 }
 
-/* body(block, env0, n_env, pass, final): called by all 64 lanes of the wave that claimed `block` for `pass` */
+/* body(block, env0, n_env, pass, final): called by all 64 lanes of the wave that serves `block`, once per pass, in pass order */
 template <class Body>
 __device__ __forceinline__ void serve(const rsb_stage_ctx& c, Body&& body) {
   const int lane = (int)(threadIdx.x & 63u);
@@ -167,65 +175,62 @@ __device__ __forceinline__ void serve(const rsb_stage_ctx& c, Body&& body) {
   }
   if (threadIdx.x == 0) __hip_atomic_fetch_add(c.started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (blockDim.x != 64u) { fail(c, RSB_PIPE_ERR_STAGE); return; }
-  /* the blocks of this wave's XCD (every block is always processed behind the same L2: the hand-over needs no L2 write-back) */
-  int base = 0, per = c.blocks;
+  /* This wave's blocks: a FIXED share of the blocks of its XCD (every block is always processed behind the same L2: the hand-over needs no L2
+   * write-back).  rank = the order in which the stage's waves arrived on this XCD (one atomic per wave and run), share = blocks rank, rank + T, ...
+   * with T = the stage's waves per XCD (the dispatcher deals workgroups round-robin over the XCDs: a rank past T is a geometry fault).
+   * No claims, no scanning of other waves' blocks: round 5's first version let every wave of an XCD scan and claim any of its blocks - 32 waves
+   * raced for each block with memory-side atomics and a pass over 1024 blocks took 90 us. */
+  int base = 0, per = c.blocks, T = (int)gridDim.x, rank = (int)blockIdx.x;
   if (c.xcds > 0) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 15u;
-    if (xcc >= (unsigned)c.xcds) { fail(c, RSB_PIPE_ERR_STAGE); return; }
     per = c.blocks / c.xcds;
     base = (int)xcc * per;
+    T = (int)gridDim.x / c.xcds;
+    unsigned t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(c.ticket + ((xcc & 15u) << 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - c.ticket_base;
+    rank = __builtin_amdgcn_readfirstlane((int)t);
+    if (xcc >= (unsigned)c.xcds || rank >= T || T < 1) { fail(c, RSB_PIPE_ERR_STAGE); return; }
   }
+  /* lane i of the wave tracks block base + rank + i T (at most 64 blocks per wave: the host sizes the grid) */
+  const int mine = rank + lane * T;
+  const bool in = mine < per;
+  const int b = base + (in ? mine : rank);
+  if (rank + 64 * T < per) { fail(c, RSB_PIPE_ERR_STAGE); return; }
   const int last_seq = c.seq0 + c.pass_last;
-  const int rot = (int)((blockIdx.x * 29u) & 63u);      /* waves start their scan of the ready blocks at different places */
+  int served = c.seq0 + c.pass_first - 1;       /* sequence number of the last pass this wave has served for lane's block */
   long long t_progress = wall_clock64();
-  int prev_sig = 0;
+  int idle = 0;
   for (;;) {
-    bool all_done = true, served = false;
-    int sig = 0;
-    for (int j0 = 0; j0 < per; j0 += 64) {
-      const int j = j0 + lane;
-      const bool in = j < per;
-      const int b = base + (in ? j : 0);
-      const int pp = ld_word(c.step_prog + b), ap = ld_word(c.act_prog + b);
-      sig += in ? pp + ap : 0;
-      if (__ballot(in && ap - last_seq < 0) != 0ull) all_done = false;
-      unsigned long long ready = __ballot(in && pp - ap >= 1 && ap - last_seq < 0);
-      /* rotate: bits [rot, 64) first, then [0, rot) */
-      const unsigned long long lo_mask = rot ? ((1ull << rot) - 1ull) : 0ull;
-      for (int half = 0; half < 2; ++half) {
-        unsigned long long r = half == 0 ? (ready & ~lo_mask) : (ready & lo_mask);
-        while (r) {
-          const int l = __builtin_ctzll(r);
-          r &= r - 1ull;
-          const int bb = base + j0 + l;
-          const int seq = __builtin_amdgcn_readlane(ap, l) + 1;
-          int won = 0;
-          if (lane == 0) won = atomicCAS(c.act_claim + bb, seq - 1, seq) == seq - 1 ? 1 : 0;
-          won = __builtin_amdgcn_readfirstlane(won);
-          if (!won) continue;
-          /* acquire: the rows the step wrote (same XCD: the vector L1 alone; else agent scope) */
-          if (c.xcds > 0) asm volatile("buffer_inv sc1" ::: "memory");
-          else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          const int env0 = bb * c.envs_per_block;
-          const int pass = seq - c.seq0;
-          body(bb, env0, min(c.envs_per_block, c.n_envs - env0), pass, pass == c.n_steps);
-          /* release: the action rows have arrived in the L2 the next step's workgroup reads from, then the word */
-          if (c.xcds > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          if (lane == 0) __hip_atomic_store(c.act_prog + bb, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          served = true;
-        }
-      }
+    const unsigned long long open_ = __ballot(in && served - last_seq < 0);
+    if (open_ == 0ull) return;                   /* every block of the share has had its final pass */
+    const int pp = ld_word(c.step_prog + (size_t)b * c.word_stride);
+    unsigned long long ready = __ballot(in && served - last_seq < 0 && pp - served >= 1);
+    if (ready == 0ull) {
+      if ((++idle & 15) == 0 && __builtin_amdgcn_readfirstlane(ld_word(c.err)) != 0) return;      /* somebody failed: leave, the host replays in lock-step */
+      for (int k = 0; k < c.poll_sleep; ++k) __builtin_amdgcn_s_sleep(8);      /* an idle wave's poll goes to the memory side: not too often */
+      if (wall_clock64() - t_progress > c.timeout_ticks) { fail(c, RSB_PIPE_ERR_TIMEOUT_STAGE); return; }
+      continue;
     }
-    if (all_done) return;
-    if (__builtin_amdgcn_readfirstlane(ld_word(c.err)) != 0) return;      /* somebody failed: leave, the host replays in lock-step */
-    const bool moved = served || __ballot(sig != prev_sig) != 0ull;
-    prev_sig = sig;
-    if (moved) { t_progress = wall_clock64(); continue; }
-    __builtin_amdgcn_s_sleep(16);
-    if (wall_clock64() - t_progress > c.timeout_ticks) { fail(c, RSB_PIPE_ERR_TIMEOUT); return; }
+    while (ready) {
+      const int l = __builtin_ctzll(ready);
+      ready &= ready - 1ull;
+      const int bb = __builtin_amdgcn_readlane(b, l);
+      const int seq = __builtin_amdgcn_readlane(served, l) + 1;
+      /* acquire: the rows the step wrote (same XCD: the vector L1 alone; else agent scope) */
+      if (c.xcds > 0) asm volatile("buffer_inv sc1" ::: "memory");
+      else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const int env0 = bb * c.envs_per_block;
+      const int pass = seq - c.seq0;
+      body(bb, env0, min(c.envs_per_block, c.n_envs - env0), pass, pass == c.n_steps);
+      /* release: the action rows have arrived in the L2 the next step's workgroup reads from, then the word */
+      if (c.xcds > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (lane == 0) __hip_atomic_store(c.act_prog + (size_t)bb * c.word_stride, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == l) served = seq;
+    }
+    t_progress = wall_clock64();
   }
 }
 

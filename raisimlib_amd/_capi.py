@@ -121,6 +121,7 @@ PROTOTYPES = {
     "rsb_step_pipeline_join": (_I, [_VP]),
     "rsb_step_pipeline_fault": (_I, [_VP, C.POINTER(_I), C.POINTER(_I)]),
     "rsb_debug_pipeline_fault": (_I, [_VP, _I]),
+    "rsb_debug_pipeline_wait_stats": (_I, [_VP, C.POINTER(_D), C.POINTER(_D)]),
     "rsb_closed_loop_run": (_I, [_VP, _I, _VP, _VP]),
     "rsb_closed_loop_run_linear": (_I, [_VP, _I, C.POINTER(LinearPolicy)]),
     "rsb_closed_loop_buffers": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),

@@ -20,14 +20,28 @@
 namespace rsbw {
 
 namespace {
-// layout of the 256-byte control block d_pipe_started points to
-//   +0   u64  workgroups of pipelined step launches that have started since the block was cleared (the gates wait on it)
-//   +8   u32  workgroups of action stages that have started
-//   +12  i32  the pipeline's error word (RSB_PIPE_ERR_*)
-//   +32  2 x i32  the stream probe's flags
-//   +64  16 x u32 tickets taken per XCD (monotonic)
-inline uint32_t* stage_started_ptr(rsb_world* w) { return reinterpret_cast<uint32_t*>(w->d_pipe_started) + 2; }
-inline int* err_ptr(rsb_world* w) { return reinterpret_cast<int*>(w->d_pipe_started) + 3; }
+// Layout of the control block d_pipe_started points to.  Every word that somebody polls or hammers with atomics sits on a 256-byte line of its
+// own: the first layout packed them into 256 bytes, and the idle polls of the action stage's waves on the error word then queued - agent-scope
+// accesses are served at the memory side, one line at a time - in front of the `started` and ticket atomics every step workgroup issues before it
+// can pick its env block (measured: -25 % with 256 stage waves resident, profiles/r05_closed_loop_log.txt).
+//   +0     u64  workgroups of pipelined step launches that have started since the block was cleared (the gates wait on it)
+//   +256   u32  workgroups of action stages that have started
+//   +512   i32  the pipeline's error word (RSB_PIPE_ERR_*)
+//   +768   2 x i32  the stream probe's flags
+//   +1024  2 x u64  wait statistics (RSB_PIPE_STATS)
+//   +2048  16 x 256 B: ticket counter of the step workgroups of XCD x at +256 x (monotonic)
+//   +6144  16 x 256 B: arrival counter of the action stage's waves of XCD x at +256 x (monotonic)
+constexpr size_t kCtlBytes = 10240;
+
+inline char* ctl(rsb_world* w) { return reinterpret_cast<char*>(w->d_pipe_started); }
+inline uint32_t* stage_started_ptr(rsb_world* w) { return reinterpret_cast<uint32_t*>(ctl(w) + 256); }
+inline int* err_ptr(rsb_world* w) { return reinterpret_cast<int*>(ctl(w) + 512); }
+inline int* probe_flags_ptr(rsb_world* w) { return reinterpret_cast<int*>(ctl(w) + 768); }
+inline unsigned long long* stats_ptr(rsb_world* w) { return reinterpret_cast<unsigned long long*>(ctl(w) + 1024); }
+inline unsigned* step_ticket_ptr(rsb_world* w) { return reinterpret_cast<unsigned*>(ctl(w) + 2048); }
+inline uint32_t* stage_ticket_ptr(rsb_world* w) { return reinterpret_cast<uint32_t*>(ctl(w) + 6144); }
+
+constexpr int kStageGridDefault = 256;      // workgroups of the action stage (one per CU)
 
 long long timeout_ticks() {      // RSB_PIPE_TIMEOUT_MS (default 10 s), in ticks of the 100 MHz wall clock; read at every launch
   const char* e = std::getenv("RSB_PIPE_TIMEOUT_MS");
@@ -68,7 +82,7 @@ int make_concurrent_stream(rsb_world* w, const std::vector<hipStream_t>& with, h
     if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
     bool yes = true;
     for (size_t i = 0; i < with.size() && st == RSB_OK && yes; ++i)
-      st = streams_run_concurrently(with[i], c, reinterpret_cast<int*>(w->d_pipe_started) + 8, &yes);   // (+32 B: the probe's two flags)
+      st = streams_run_concurrently(with[i], c, probe_flags_ptr(w), &yes);
     if (st == RSB_OK && yes) *out = c; else rejected.push_back(c);
   }
   if (rejected_n) *rejected_n = (int)rejected.size();
@@ -150,7 +164,7 @@ __global__ void pipe_gate_kernel(const T* started, T target, int* err, long long
     if ((++spins & 63) == 0) {
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
-      else if (now - t0 > timeout) { __hip_atomic_store(err, RSB_PIPE_ERR_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+      else if (now - t0 > timeout) { atomicCAS(err, 0, RSB_PIPE_ERR_TIMEOUT_GATE); return; }
     }
   }
 }
@@ -158,7 +172,7 @@ __global__ void fill_i32_kernel(int* a, int n, int v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
 }
-__global__ void set_word_kernel(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void set_word_kernel(int* p, int v) { atomicCAS(p, 0, v); }
 // the state the steps since the last join started from: gc | gv | warm records, one buffer (restored by pipe_recover)
 __global__ void snapshot_kernel(float* dst, const float* gc, size_t n0, const float* gv, size_t n1, const float* warm, size_t n2, int restore,
                                 float* gc_w, float* gv_w, float* warm_w) {
@@ -191,17 +205,18 @@ int pipe_prepare(rsb_world* w, int blocks) {
   HIP_TRY(hipStreamSynchronize(w->stream));
   if (w->d_pipe_prog) HIP_TRY(hipFree(w->d_pipe_prog));
   w->d_pipe_prog = nullptr; w->pipe_blocks = 0;
-  HIP_TRY(hipMalloc(&w->d_pipe_prog, (size_t)3 * blocks * sizeof(int)));   // step_prog | act_prog | act_claim
-  if (!w->d_pipe_started) HIP_TRY(hipMalloc(&w->d_pipe_started, 256));
-  HIP_TRY(hipMemset(w->d_pipe_prog, 0, (size_t)3 * blocks * sizeof(int)));
-  HIP_TRY(hipMemset(w->d_pipe_started, 0, 256));
-  w->pipe_wg_total = 0; w->pipe_seq = 0; w->pipe_xcc_uses = 0; w->stage_started_total = 0;
+  if (const char* e = std::getenv("RSB_PIPE_WORD_STRIDE")) w->pipe_stride = std::min(std::max(std::atoi(e), 1), 4096);
+  HIP_TRY(hipMalloc(&w->d_pipe_prog, (size_t)2 * blocks * w->pipe_stride * sizeof(int)));   // step_prog | act_prog
+  if (!w->d_pipe_started) HIP_TRY(hipMalloc(&w->d_pipe_started, kCtlBytes));
+  HIP_TRY(hipMemset(w->d_pipe_prog, 0, (size_t)2 * blocks * w->pipe_stride * sizeof(int)));
+  HIP_TRY(hipMemset(w->d_pipe_started, 0, kCtlBytes));
+  w->pipe_wg_total = 0; w->pipe_stats_wg0 = 0; w->pipe_seq = 0; w->pipe_xcc_uses = 0; w->stage_started_total = 0; w->stage_ticket_total = 0;
   if (!w->pipe_stream[0]) {
     const int ps = pipe_make_streams(w);
     if (ps != RSB_OK) return ps;
     const int px = pipe_probe_xcds(w, &w->pipe_xcds);
     if (px != RSB_OK) return px;
-    HIP_TRY(hipMemset(w->d_pipe_started, 0, 256));
+    HIP_TRY(hipMemset(w->d_pipe_started, 0, kCtlBytes));
   }
   for (int i = 0; i < 4; ++i) if (!w->pipe_ev[i]) HIP_TRY(hipEventCreateWithFlags(&w->pipe_ev[i], hipEventDisableTiming));
   w->pipe_blocks = blocks;     // (last: a failure above leaves the world un-pipelined, not half set up)
@@ -229,11 +244,27 @@ int closed_loop_lockstep(rsb_world* w, int K, rsb_stage_launch_fn launch, void* 
 int pipe_recover(rsb_world* w, int code) {
   ++w->pipe_faults; w->pipe_last_code = code; w->pipe_fault_pending = true;
   std::fprintf(stderr, "raisimlib_amd: pipelined control steps faulted on the device (code %d: %s); restoring the last joined state and replaying %zu call(s) in lock-step, pipelining off\n",
-               code, code == RSB_PIPE_ERR_TICKET ? "env-block ticket outside its XCD's range" : code == RSB_PIPE_ERR_TIMEOUT ? "a wait ran past the time-out"
+               code, code == RSB_PIPE_ERR_TICKET ? "env-block ticket outside its XCD's range" : code == RSB_PIPE_ERR_TIMEOUT ? "a step workgroup's wait ran past the time-out"
+               : code == RSB_PIPE_ERR_TIMEOUT_GATE ? "a gate's wait ran past the time-out" : code == RSB_PIPE_ERR_TIMEOUT_STAGE ? "an action-stage wave's wait ran past the time-out"
                : code == RSB_PIPE_ERR_STAGE ? "action stage geometry" : "injected", w->pipe_log.size());
-  HIP_TRY(hipMemset(w->d_pipe_started, 0, 256));
-  w->pipe_wg_total = 0; w->pipe_xcc_uses = 0; w->stage_started_total = 0;
-  hipLaunchKernelGGL(fill_i32_kernel, dim3((3 * w->pipe_blocks + 255) / 256), dim3(256), 0, w->stream, w->d_pipe_prog, 3 * w->pipe_blocks, (int)w->pipe_seq);
+  {   // where everybody stood (the words are about to be cleared)
+    unsigned long long cb[1] = {};
+    unsigned stg[1] = {};
+    std::vector<int> all((size_t)2 * w->pipe_blocks * w->pipe_stride, 0), words((size_t)2 * w->pipe_blocks, 0);
+    if (hipMemcpy(cb, w->d_pipe_started, sizeof cb, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(stg, stage_started_ptr(w), sizeof stg, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(all.data(), w->d_pipe_prog, all.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && w->pipe_blocks > 0) {
+      for (size_t i = 0; i < words.size(); ++i) words[i] = all[i * w->pipe_stride];
+      auto mm = [&](int k) { auto b = words.begin() + (size_t)k * w->pipe_blocks; auto r = std::minmax_element(b, b + w->pipe_blocks); return std::make_pair(*r.first, *r.second); };
+      const auto sp = mm(0), ap = mm(1);
+      std::fprintf(stderr, "raisimlib_amd:   step workgroups started %llu of %llu launched, stage workgroups started %u of %llu, sequence %u, per block: step_prog [%d, %d] act_prog [%d, %d], "
+                   "XCDs %d, streams overlap: steps %d stage %d\n", cb[0], w->pipe_wg_total, stg[0], w->stage_started_total, w->pipe_seq, sp.first, sp.second, ap.first, ap.second,
+                   w->pipe_xcds, (int)w->pipe_overlap, (int)w->pipe_stage_overlap);
+    }
+  }
+  HIP_TRY(hipMemset(w->d_pipe_started, 0, kCtlBytes));
+  w->pipe_wg_total = 0; w->pipe_stats_wg0 = 0; w->pipe_xcc_uses = 0; w->stage_started_total = 0; w->stage_ticket_total = 0;
+  { const int nw = 2 * w->pipe_blocks * w->pipe_stride;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((nw + 255) / 256), dim3(256), 0, w->stream, w->d_pipe_prog, nw, (int)w->pipe_seq); }
   HIP_TRY(hipGetLastError());
   if (code == RSB_PIPE_ERR_TICKET) w->pipe_xcds = 0;       // should pipelining be switched on again: hand-over at agent scope, blocks by workgroup index
   w->pipe_on = false;
@@ -301,11 +332,15 @@ int pipe_begin_launch(rsb_world* w, StepArgs& a, int blocks, bool closed_loop, h
     if (st != RSB_OK) return st;
   }
   *ls = w->pipe_stream[w->pipe_next];
-  a.pipe_wait_ptr = closed_loop ? w->d_pipe_prog + blocks : w->d_pipe_prog;
+  a.pipe_stride = w->pipe_stride;
+  { static const bool stats = std::getenv("RSB_PIPE_STATS") != nullptr; a.pipe_stats = stats ? stats_ptr(w) : nullptr; }
+  a.pipe_wait_ptr = closed_loop ? w->d_pipe_prog + (size_t)blocks * w->pipe_stride : w->d_pipe_prog;
+  { static const bool nowait = std::getenv("RSB_X_CL_NOWAIT") != nullptr;      // experiment (WRONG results): closed-loop steps wait for their own predecessor, not for the stage
+    if (nowait) a.pipe_wait_ptr = w->d_pipe_prog; }
   a.pipe_wait_on = (closed_loop || w->pipe_n > 0) ? 1 : 0;
   a.pipe_wait = (int)w->pipe_seq; a.pipe_seq = (int)(w->pipe_seq + 1u);
   a.pipe_xcds = (w->pipe_xcds > 0 && blocks % w->pipe_xcds == 0) ? w->pipe_xcds : 0;
-  a.pipe_xcc_ctr = reinterpret_cast<unsigned*>(w->d_pipe_started) + 16;
+  a.pipe_xcc_ctr = step_ticket_ptr(w);
   a.pipe_xcc_base = a.pipe_xcds > 0 ? w->pipe_xcc_uses * (unsigned)(blocks / a.pipe_xcds) : 0u;
   if (w->debug_fault) {      // rsb_debug_pipeline_fault: this launch fails on the device
     if (w->debug_fault == 1 && a.pipe_xcds > 0) a.pipe_xcc_base -= 1u;
@@ -377,7 +412,7 @@ __global__ void __launch_bounds__(64) linear_stage_kernel(const rsb_stage_ctx c,
       if (p.rollout_reward) p.rollout_reward[(size_t)(pass - 1) * N + env0 + lane] = c.reward[env0 + lane];
       if (p.rollout_done) p.rollout_done[(size_t)(pass - 1) * N + env0 + lane] = c.done[env0 + lane];
     }
-    if (final) return;
+    if (final || p.clip == -777.f) return;      // (clip -777: experiment - a stage that only hands over)
     const long long gp = c.pass_global0 + pass;
     const float* nz = p.noise ? p.noise + (size_t)(gp % (p.noise_period > 0 ? p.noise_period : 1)) * N * ad : nullptr;
     constexpr int CH = 16;     // terms of the sum loaded together (weights and observation entries: 32 loads in flight, then 16 FMAs in index order)
@@ -464,27 +499,44 @@ int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user,
   cl_fill_ctx(w, &c, K, pg0);
   int st = check_lpe(w, effective_lpe(w));
   if (st != RSB_OK) return st;
+  st = upload_image(w);          // (do_integrate would do it - and JOIN for it, with the stage already in flight)
+  if (st != RSB_OK) return st;
   st = pipe_prepare(w, c.blocks);
   if (st != RSB_OK) return st;
   st = pipe_make_stage_stream(w);
   if (st != RSB_OK) return st;
+  if (!w->pipe_overlap || !w->pipe_stage_overlap) {
+    // an action stage that shares a hardware queue with a step stream would not be slow but STUCK (it stays resident until the steps behind it in
+    // that queue have run): without three streams that overlap the run stays in lock-step
+    static bool said = false;
+    if (!said) { std::fprintf(stderr, "raisimlib_amd: no three streams on different hardware queues (GPU_MAX_HW_QUEUES?): closed-loop runs stay in lock-step\n"); said = true; }
+    return closed_loop_lockstep(w, K, launch, user, pg0);
+  }
   st = launch_env_obs(w, w->d_env_ob, s);
   if (st != RSB_OK) return st;
   const int seq0 = (int)w->pipe_seq;
-  int* act_prog = w->d_pipe_prog + c.blocks;
-  hipLaunchKernelGGL(fill_i32_kernel, dim3((2 * c.blocks + 255) / 256), dim3(256), 0, s, act_prog, 2 * c.blocks, seq0 - 1);   // act_prog | act_claim
+  int* act_prog = w->d_pipe_prog + (size_t)c.blocks * w->pipe_stride;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((c.blocks * w->pipe_stride + 255) / 256), dim3(256), 0, s, act_prog, c.blocks * w->pipe_stride, seq0 - 1);
   HIP_TRY(hipGetLastError());
   st = pipe_fork(w, true);
   if (st != RSB_OK) return st;
-  c.step_prog = w->d_pipe_prog; c.act_prog = act_prog; c.act_claim = act_prog + c.blocks;
+  c.step_prog = w->d_pipe_prog; c.act_prog = act_prog; c.ticket = stage_ticket_ptr(w);
   c.err = err_ptr(w); c.started = stage_started_ptr(w);
+  c.word_stride = w->pipe_stride;
+  { const char* e = std::getenv("RSB_STAGE_POLL"); c.poll_sleep = e ? std::min(std::max(std::atoi(e), 0), 64) : 2; }
   c.xcds = (w->pipe_xcds > 0 && c.blocks % w->pipe_xcds == 0) ? w->pipe_xcds : 0;
   c.seq0 = seq0; c.pass_first = 0; c.pass_last = K; c.lockstep = 0;
   c.stream = w->pipe_stage_stream;
-  c.grid = w->cl_grid > 0 ? w->cl_grid : 256;
-  if (c.xcds > 0) c.grid = std::max(c.xcds, c.grid / c.xcds * c.xcds);
+  // the stage's waves: every wave serves a fixed share of at most 64 blocks of its XCD (rsb_stage::serve)
+  const int nx = c.xcds > 0 ? c.xcds : 1, per = c.blocks / nx;
+  int T = (w->cl_grid > 0 ? w->cl_grid : kStageGridDefault) / nx;
+  T = std::max(T, (per + 63) / 64);
+  T = std::min(std::max(T, 1), per);
+  c.grid = T * nx;
+  c.ticket_base = (uint32_t)w->stage_ticket_total;
+  w->stage_ticket_total += (unsigned long long)T;
   w->stage_started_total += (unsigned long long)c.grid;
-  if (launch(user, &c) != 0) { rsb::set_error("rsb_closed_loop_run: the action stage's launch function failed"); w->stage_started_total -= (unsigned long long)c.grid; return RSB_E_HIP; }
+  if (launch(user, &c) != 0) { rsb::set_error("rsb_closed_loop_run: the action stage's launch function failed"); w->stage_started_total -= (unsigned long long)c.grid; w->stage_ticket_total -= (unsigned long long)T; return RSB_E_HIP; }
   w->pipe_active = true;       // the stage is in flight: whatever happens below, the next join waits for it
   rsb_world::PipeLog e;
   e.closed = true; e.K = K; e.launch = launch; e.user = user; e.pass_global0 = pg0;
@@ -555,6 +607,22 @@ int rsb_step_pipeline_join(rsb_world* w) {
   HIP_TRY(hipSetDevice(w->device));
   if (w->pipe_active) { const int st = pipe_join(w); if (st != RSB_OK) return st; }
   return fault_status(w);
+}
+// diagnostics (RSB_PIPE_STATS=1 in the environment): mean wait of a pipelined step workgroup for its block, in microseconds, and the share of the
+// workgroups that had to wait at all, over the pipelined launches since the last call; joins
+int rsb_debug_pipeline_wait_stats(rsb_world* w, double* mean_wait_us, double* waited_frac) {
+  if (!w || !w->d_pipe_started) return RSB_E_INVALID;
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipStreamSynchronize(stream_of(w)));
+  unsigned long long st[2] = {0, 0};
+  unsigned long long* d = stats_ptr(w);
+  HIP_TRY(hipMemcpy(st, d, sizeof st, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(d, 0, sizeof st));
+  const double n = (double)(w->pipe_wg_total - w->pipe_stats_wg0);
+  w->pipe_stats_wg0 = w->pipe_wg_total;
+  if (mean_wait_us) *mean_wait_us = n > 0 ? (double)st[0] / n * 0.01 : 0.0;
+  if (waited_frac) *waited_frac = n > 0 ? (double)st[1] / n : 0.0;
+  return RSB_OK;
 }
 int rsb_step_pipeline_fault(const rsb_world* w, int* faults, int* last_code) {
   if (!w) return RSB_E_INVALID;

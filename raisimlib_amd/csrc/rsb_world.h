@@ -128,7 +128,8 @@ struct rsb_world {
   unsigned long long pipe_wg_total = 0;                  // their workgroups (== *d_pipe_started once they have all started)
   unsigned pipe_seq = 0;                                 // sequence number of the last pipelined launch (published by its workgroups)
   unsigned long long* d_pipe_started = nullptr;
-  int* d_pipe_prog = nullptr;                            // [pipe_blocks]
+  int* d_pipe_prog = nullptr;                            // step_prog [pipe_blocks * pipe_stride] | act_prog [pipe_blocks * pipe_stride]: block b's words at b * pipe_stride
+  int pipe_stride = 64;                                  // ints between the words of consecutive blocks (256 B: spread over the memory channels; RSB_PIPE_WORD_STRIDE)
   hipStream_t launch_stream = nullptr;                   // stream of the step launch being enqueued (do_integrate)
   hipStream_t pipe_last = nullptr;                       // private stream of the most recent pipelined launch
   hipEvent_t pipe_dep = nullptr, pipe_pub = nullptr;     // rsb_step_pipeline_wait_event: the next pipelined launch waits for it; event of rsb_step_pipeline_publish
@@ -153,6 +154,8 @@ struct rsb_world {
   double pipe_time_logged = 0.0;                         // world time the logged calls advanced (taken back before a replay)
   hipStream_t pipe_stage_stream = nullptr;               // the action stage's stream (overlaps with both step streams)
   bool pipe_stage_overlap = true;
+  unsigned long long pipe_stats_wg0 = 0;                 // rsb_debug_pipeline_wait_stats: workgroups counted up to the last call
+  unsigned long long stage_ticket_total = 0;             // per-XCD arrival tickets the stages launched so far have drawn
   unsigned long long stage_started_total = 0;            // stage workgroups launched since the control block was cleared (the first step of a run waits for them)
   float *d_env_gc0_rows = nullptr, *d_env_gv0_rows = nullptr;   // optional per-env reset states [N, nq] / [N, nv] (rsb_env_set_reset_states)
   float* d_env_act = nullptr;                            // [N, nv - 6] the env task's action rows (closed loop: written by the stage, read by the step)
@@ -163,6 +166,7 @@ struct rsb_world {
 // helpers shared by the translation units (rsb_world.hip unless noted)
 namespace rsbw {
 int do_integrate(rsb_world* w, int nsub);
+int upload_image(rsb_world* w);                                 // the step kernel's per-block tables, when a setter dirtied them (joins)
 int effective_lpe(const rsb_world* w);
 int check_lpe(const rsb_world* w, int lpe);
 int copy_in(rsb_world* w, float* dst, const float* src, size_t n, int space);

@@ -31,7 +31,9 @@ namespace rsbw {
 // Kernel arguments in device memory: with host-resident kernargs every wave's first scalar loads cross PCIe (measured: step
 // kernel prologue 20.6 k cycles instead of 9.2 k, 142 M instead of 149 M env-steps/s).  It is this image's default; set here
 // (without overriding the user's choice) for runtimes where it is not - effective when the library loads before HIP starts.
-struct DevKernargDefault { DevKernargDefault() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); } } g_dev_kernarg_default;
+// GPU_MAX_HW_QUEUES: HIP multiplexes its streams onto 4 hardware queues by default; the closed-loop pipeline needs three private streams that
+// overlap (two step streams + the action stage's) beside the caller's own - 8 queues make the probe's search for such a set short.
+struct DevKernargDefault { DevKernargDefault() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_dev_kernarg_default;
 
 int round4(int x) { return (x + 3) & ~3; }
 
@@ -350,22 +352,11 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
   return img;
 }
 
-int do_integrate(rsb_world* w, int nsub) {
-  HIP_TRY(hipSetDevice(w->device));
-  const int lpe = effective_lpe(w);
-  int st = check_lpe(w, lpe);
-  if (st != RSB_OK) return st;
+// the step kernel's per-block tables (build_lds_image) and the self-collision pairs' materials, re-uploaded when a setter dirtied them.
+// Joins (stream_of): callers that must not join later - a closed-loop run with its action stage in flight - call it up front.
+int upload_image(rsb_world* w) {
+  if (!w->image_dirty) return RSB_OK;
   const int kcap = kcap_of(w->blob, w->kmax);
-  StepArgs a;
-  std::memset(&a, 0, sizeof a);
-  a.model = w->d_model;
-  a.gc = w->d_gc; a.gv = w->d_gv; a.ptarget = w->d_pt; a.dtarget = w->d_dt; a.tauff = w->d_tff;
-  a.kp = w->d_kp; a.kd = w->d_kd;
-  a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
-  a.heights = w->d_heights;
-  a.hm_index = w->d_hm_index;
-  a.warm = w->warm_start ? w->d_warm : nullptr;
-  if (w->image_dirty) {
     std::vector<float> img = build_lds_image(w, make_layout(w->blob, kcap, n_self_pairs(w)));
     HIP_TRY(hipMemcpyAsync(w->d_image, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
     const int np = n_self_pairs(w);
@@ -386,7 +377,26 @@ int do_integrate(rsb_world* w, int nsub) {
     }
     HIP_TRY(hipStreamSynchronize(stream_of(w)));   // img / mat are stack-lifetime buffers
     w->image_dirty = false;
-  }
+  return RSB_OK;
+}
+
+int do_integrate(rsb_world* w, int nsub) {
+  HIP_TRY(hipSetDevice(w->device));
+  const int lpe = effective_lpe(w);
+  int st = check_lpe(w, lpe);
+  if (st != RSB_OK) return st;
+  const int kcap = kcap_of(w->blob, w->kmax);
+  StepArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.model = w->d_model;
+  a.gc = w->d_gc; a.gv = w->d_gv; a.ptarget = w->d_pt; a.dtarget = w->d_dt; a.tauff = w->d_tff;
+  a.kp = w->d_kp; a.kd = w->d_kd;
+  a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
+  a.heights = w->d_heights;
+  a.hm_index = w->d_hm_index;
+  a.warm = w->warm_start ? w->d_warm : nullptr;
+  st = upload_image(w);
+  if (st != RSB_OK) return st;
   a.lds_image = w->d_image;
   if (w->fuse.ptarget_src) { a.ptarget = w->fuse.ptarget_src; a.ptarget_store = w->d_pt; }
   if (w->fuse.act) { a.act = w->fuse.act; a.act_mean = w->d_env_mean; a.act_std = w->env_cfg.action_std; a.ptarget_store = w->d_pt; a.tau2_out = w->d_env_tau2; }
@@ -1363,6 +1373,7 @@ int rsb_env_reset(rsb_world* w) {
                      w->d_env_gc0_rows ? w->N : 1, w->N, w->blob.nq, w->blob.nv, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
   w->integrate1_valid = false;
+  w->cl_passes = 0;      // (a closed-loop run's global step index - the noise slice of the reference stage - restarts with the episodes)
   return RSB_OK;
 }
 int rsb_env_observe(rsb_world* w, float* ob, int space) {

@@ -609,19 +609,21 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
     // pipe_xcds > 0: the env block is chosen by the XCD this workgroup landed on (block = XCD x (blocks / XCDs) + a ticket of that XCD), so that
     // every block is always processed behind the same L2 and the hand-over needs no L2 write-back (see the wait below)
     if (lane == 0) __hip_atomic_fetch_add(a.pipe_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a fault earlier in the pipeline (the error word is set: the gates no longer hold the launches apart, tickets of several launches mix): leave at once
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pipe_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
     if (a.pipe_xcds > 0) {
       unsigned xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
       xcc &= 15u;
       unsigned t = 0;
-      if (lane == 0) t = __hip_atomic_fetch_add(a.pipe_xcc_ctr + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_xcc_base;
+      if (lane == 0) t = __hip_atomic_fetch_add(a.pipe_xcc_ctr + (xcc << 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.pipe_xcc_base;   // (one 256-byte line per XCD's counter)
       t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
       const unsigned per = gridDim.x / (unsigned)a.pipe_xcds;
       if (t >= per || xcc >= (unsigned)a.pipe_xcds) {
         // the dispatcher did not deal this launch's workgroups round-robin over the XCDs (the host's probe saw it do so on an idle device): no
         // env block can be assigned.  Error word instead of a trap: this workgroup leaves without touching anything, the others follow (below),
         // the host's next join replays the steps in lock-step
-        if (lane == 0) __hip_atomic_store(a.pipe_err, 1 /* RSB_PIPE_ERR_TICKET */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) atomicCAS(a.pipe_err, 0, 1 /* RSB_PIPE_ERR_TICKET; the first code stays */);
         return;
       }
       blk = (int)(xcc * per + t);
@@ -692,7 +694,8 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
       // (open loop: the word of this block's own predecessor; closed loop: the action stage's word for this block, StepArgs::pipe_wait_ptr)
       int spins = 0;
       long long t0 = 0;
-      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pipe_wait_ptr + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - a.pipe_wait < 0) {
+      const long long t_in = a.pipe_stats ? wall_clock64() : 0;
+      while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pipe_wait_ptr + (size_t)blk * a.pipe_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - a.pipe_wait < 0) {
         // somebody failed (a ticket, a time-out): nobody will publish this block - leave without touching it (the host replays in lock-step)
         if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(a.pipe_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) return;
         __builtin_amdgcn_s_sleep(8);
@@ -700,10 +703,14 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
           const long long now = wall_clock64();
           if (t0 == 0) t0 = now;
           else if (now - t0 > a.pipe_timeout) {
-            if (lane == 0) __hip_atomic_store(a.pipe_err, 2 /* RSB_PIPE_ERR_TIMEOUT */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) atomicCAS(a.pipe_err, 0, 2 /* RSB_PIPE_ERR_TIMEOUT */);
             return;
           }
         }
+      }
+      if (a.pipe_stats && lane == 0) {
+        __hip_atomic_fetch_add(a.pipe_stats, (unsigned long long)(wall_clock64() - t_in), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (spins > 0) __hip_atomic_fetch_add(a.pipe_stats + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (a.pipe_xcds > 0) asm volatile("buffer_inv sc1" ::: "memory");
@@ -2480,7 +2487,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   if constexpr (PIPE) {   // pipelined control steps: everything this workgroup wrote is released, then its envs are handed to the next launch
     if (ae.pipe_xcds > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (same XCD, same L2: the stores only have to have arrived there)
     else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) __hip_atomic_store(ae.pipe_prog + blk, ae.pipe_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(ae.pipe_prog + (size_t)blk * ae.pipe_stride, ae.pipe_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if constexpr (PEER) if (ae.n_obs_peers > 0) {
     // publication (see StepArgs::obs_peer): this wave's rows are acknowledged, it checks in; the last wave of the launch stores the

@@ -183,7 +183,7 @@ struct StepArgs {
   int* pipe_prog;                        // [blocks] sequence number of the last pipelined launch whose workgroup b has finished
   int pipe_wait_on, pipe_wait, pipe_seq; // wait for pipe_prog[b] >= pipe_wait (unless !pipe_wait_on: first launch after a fork); publish pipe_seq
   int pipe_xcds;                         // > 0: XCD-affine blocks (the device's XCD count; the grid is a multiple of it): block = XCD x (grid / XCDs) + ticket
-  unsigned* pipe_xcc_ctr;                // [16] tickets taken per XCD (monotonic)
+  unsigned* pipe_xcc_ctr;                // tickets taken per XCD (monotonic): XCD x's counter at [64 x] (a 256-byte line of its own)
   unsigned pipe_xcc_base;                // their value at the start of this launch
   // round 5: no device trap anywhere in the pipeline.  A workgroup that draws a ticket outside its XCD's range, or whose wait runs past
   // pipe_timeout (ticks of the 100 MHz wall clock), stores a code (rsb_pipeline.h: RSB_PIPE_ERR_*) into *pipe_err and returns WITHOUT integrating or
@@ -194,6 +194,11 @@ struct StepArgs {
   // closed loop (rsb_closed_loop_run): a step does not wait for its OWN predecessor's word but for the action stage's - workgroup b of step k + 1
   // starts when the stage has published block b's actions computed from step k's observation (act_prog[b] >= pipe_wait).  Open loop: == pipe_prog
   const int* pipe_wait_ptr;
+  // the words of consecutive blocks sit pipe_stride ints apart: polled densely packed, all of a launch's waiting workgroups (and the action stage's
+  // waves) hammer the one or two memory channels a 4-KB array maps to - agent-scope loads are served at the memory side
+  int pipe_stride;
+  // diagnostics (RSB_PIPE_STATS=1): [0] += wall-clock ticks (100 MHz) this workgroup spent waiting for its block, [1] += 1 per workgroup that had to wait at all
+  unsigned long long* pipe_stats;
 #ifdef RSB_X_ARGPAD
   char x_pad[RSB_X_ARGPAD];
 #endif

@@ -190,3 +190,38 @@ def smoothed_heightmap(xs=128, ys=128, amplitude=0.1, seed=7, passes=3):
 
 HEIGHTMAP_SIZE = 12.8          # config 3: 128 x 128 samples over 12.8 m x 12.8 m (0.1 m cells), centred on the origin
 HEIGHTMAP_CLEARANCE = 0.12     # initial base height is raised by this much so that no foot starts inside the +-0.1 m terrain
+
+
+# ---- the config-2 workload with a policy IN the loop (include/rsb_pipeline.h; bench.py `closed_loop`, tests/test_gpu_closed_loop.py) ----
+# The env task (rsb_env_*) turns an action into PD targets  nominal + action_std * action;  with action_std = the config's noise amplitude (0.3 rad)
+# and the noise bank below, a zero policy reproduces config 2's targets exactly (the same counter-based draws).  The reference stage adds the
+# feedback term W ob on top: a fixed linear policy whose output depends on every step's observation.
+CLOSED_LOOP_W_SCALE = 0.02
+
+
+def closed_loop_noise(n_envs, period, seed0=1234, env_offset=0, n_act=12):
+    """[period, N, n_act] float32 in [-1, 1): slice k is the draw config 2's targets use for control step k ((target - nominal) / amplitude)"""
+    out = np.empty((period, n_envs, n_act), np.float32)
+    for k in range(period):
+        out[k] = 2.0 * env_uniform(seed0 + env_offset + np.arange(n_envs), k, n_act) - 1.0
+    return out
+
+
+def closed_loop_policy(n_obs, n_act, scale=CLOSED_LOOP_W_SCALE, seed=5):
+    """the fixed linear policy of the closed-loop benchmark: W [n_act, n_obs] ~ U(-scale, scale), seeded"""
+    return np.random.default_rng(seed).uniform(-scale, scale, (n_act, n_obs)).astype(np.float32)
+
+
+def closed_loop_env(model, n_envs, device=0, env_offset=0, stream=None):
+    """config 2 as a device-resident vectorised env: ANYmal-like robots on flat ground, dt 0.0025 x 4, PD kp 50 / kd 0.2, action_std 0.3 around
+    the nominal joints, non-foot contact -> reset to the env's OWN initial state (per-env base xy / yaw as in the open-loop benchmark)"""
+    from .vecenv import VecEnv
+    gc_init = np.zeros(model.nq, np.float32)
+    gc_init[2], gc_init[3] = ANYMAL_INIT_HEIGHT, 1.0
+    gc_init[7:] = ANYMAL_NOMINAL_JOINTS
+    env = VecEnv(model, n_envs, device=device, simulation_dt=DT, control_dt=DT * SUBSTEPS, action_std=0.3, p_gain=KP, d_gain=KD,
+                 gc_init=gc_init, stream=stream)
+    gc0, gv0 = anymal_initial_state(n_envs, env_offset=env_offset)
+    env.set_reset_states(gc0, gv0)
+    env.reset()
+    return env

@@ -268,6 +268,12 @@ class BatchedWorld:
         check(self.L.rsb_step_pipeline_fault(self.handle, C.byref(a), C.byref(b)), "rsb_step_pipeline_fault")
         return int(a.value), int(b.value)
 
+    def debug_pipeline_wait_stats(self):
+        """(mean wait of a pipelined step workgroup for its block in us, share of workgroups that waited); needs RSB_PIPE_STATS=1"""
+        a, b = C.c_double(0), C.c_double(0)
+        check(self.L.rsb_debug_pipeline_wait_stats(self.handle, C.byref(a), C.byref(b)), "rsb_debug_pipeline_wait_stats")
+        return float(a.value), float(b.value)
+
     def debug_pipeline_fault(self, kind):
         """tests: the next pipelined launch fails on the device (1: ticket, 2: time-out, 4: error word set)"""
         check(self.L.rsb_debug_pipeline_fault(self.handle, int(kind)), "rsb_debug_pipeline_fault")

@@ -1,0 +1,252 @@
+"""The closed loop (include/rsb_pipeline.h): K control steps of the device-resident vectorised env with an action stage between them, handed
+over env block by env block - step k's workgroup b publishes its observation rows, the stage computes block b's actions, step k + 1's
+workgroup b starts.  The contract is bit-identity with the same run in lock-step (pass 0, step 1, pass 1, ...), whatever stage sits in the
+loop: the in-repo linear policy, or a kernel of the caller written against the public header.  And the pipeline's faults are errors, not
+traps: an injected fault yields RSB_E_PIPELINE once, a recovered state and a usable handle."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from common import ROOT
+from raisimlib_amd import RsbError, workload
+
+pytestmark = pytest.mark.gpu
+
+
+class Loop:
+    """config 2 as a vectorised env + the reference policy + its exploration noise (= the open-loop benchmark's target draws)"""
+
+    def __init__(self, model, n, pipe, scale=workload.CLOSED_LOOP_W_SCALE, period=16, lpe=0):
+        import torch
+        self.torch, self.n = torch, n
+        dev = torch.device("cuda:0")
+        self.env = workload.closed_loop_env(model, n)
+        if lpe:
+            self.env.world.set_lanes_per_env(lpe)
+        self.W = torch.from_numpy(workload.closed_loop_policy(self.env.num_obs, self.env.num_acts, scale)).to(dev)
+        self.noise = torch.from_numpy(workload.closed_loop_noise(n, period)).to(dev)
+        self.pipe = self.env.world.set_step_pipelining(pipe)
+        assert self.pipe == pipe
+
+    def rollout_buffers(self, K):
+        torch, e = self.torch, self.env
+        dev = torch.device("cuda:0")
+        return {"ob": torch.zeros((K + 1, self.n, e.num_obs), dtype=torch.float32, device=dev), "act": torch.zeros((K, self.n, e.num_acts), dtype=torch.float32, device=dev),
+                "reward": torch.zeros((K, self.n), dtype=torch.float32, device=dev), "done": torch.zeros((K, self.n), dtype=torch.uint8, device=dev)}
+
+    def run(self, K, rollout=None):
+        self.env.rollout_linear(K, self.W, noise=self.noise, rollout=rollout)
+
+    def final(self):
+        w = self.env.world
+        q, u = w.get_state()
+        cnt, con = w.get_contacts()
+        return dict(q=q, u=u, cnt=cnt, con=con.tobytes(), flags=w.get_flags(), iters=w.get_solver_iterations())
+
+    def close(self):
+        self.env.close()
+
+
+def equal(a, b):
+    for k in a:
+        same = a[k] == b[k] if isinstance(a[k], bytes) else np.array_equal(a[k], b[k])
+        if not same:
+            return k
+    return None
+
+
+@pytest.mark.parametrize("n,lpe,runs,K", [(4096, 0, 10, 100), (1000, 0, 3, 40), (512, 32, 2, 30), (20000, 0, 2, 25)])
+def test_closed_loop_pipelined_equals_lockstep(built_lib, anymal, n, lpe, runs, K):
+    """>= 1000 control steps at the benchmark's size (10 runs of 100) with resets, the policy's output depending on every observation: every row
+    of every step's rollout (observation, action, reward, done) and the final state / contact lists equal the lock-step run's bit for bit.
+    Also a batch that does not fill the chip (grid not a multiple of the XCD count: hand-over at agent scope), the 32-lane mapping (2 envs per
+    block) and five times the chip."""
+    ref = Loop(anymal, n, False, lpe=lpe)
+    pip = Loop(anymal, n, True, lpe=lpe)
+    resets = 0
+    for r in range(runs):
+        ra, rb = ref.rollout_buffers(K), pip.rollout_buffers(K)
+        ref.run(K, ra)
+        pip.run(K, rb)
+        pip.env.world.step_pipeline_join()
+        ref.env.world.synchronize()
+        for key in ra:
+            assert ref.torch.equal(ra[key], rb[key]), (r, key)
+        resets += int(ra["done"].sum().item())
+        assert bool(ref.torch.isfinite(ra["ob"]).all())
+        # the policy is in the loop: actions differ from the pure noise, and the observation of step t + 1 follows from the action of step t
+        assert float((ra["act"][0] - pip.noise[(r * K) % pip.noise.shape[0]]).abs().max()) > 1e-3
+    assert equal(ref.final(), pip.final()) is None
+    assert resets > 0, "the workload never reset an env: the test would not cover the reset path"
+    launches, joins = pip.env.world.step_pipelining_stats()
+    assert launches == runs * K and ref.env.world.step_pipelining_stats()[0] == 0
+    assert pip.env.world.step_pipeline_fault() == (0, 0)
+    ref.close(); pip.close()
+
+
+def test_closed_loop_matches_the_stepwise_vec_env(built_lib, anymal):
+    """The closed-loop run is the env task: the same K steps driven from the host - observe, the policy in torch (fp32 FMAs in the stage's
+    order are not torch's matmul: compare with a tolerance that leaves room for rounding only), step - give the same trajectories until
+    contact timing separates them; the first 3 steps agree to 1e-4."""
+    import torch
+    n, K = 1024, 3
+    lp = Loop(anymal, n, True)
+    ro = lp.rollout_buffers(K)
+    lp.run(K, ro)
+    lp.env.world.step_pipeline_join()
+    env = workload.closed_loop_env(anymal, n)
+    ob = torch.zeros((n, env.num_obs), dtype=torch.float32, device="cuda:0")
+    for t in range(K):
+        env.observe(ob)
+        assert torch.allclose(ob, ro["ob"][t], atol=1e-4, rtol=1e-4), t
+        act = ro["act"][t].clone()        # (the stage's own action rows: what is checked here is the env's response to them)
+        want = ob @ lp.W.T + lp.noise[t % lp.noise.shape[0]]
+        assert torch.allclose(act, want, atol=1e-4, rtol=1e-4), t
+        rew, done = env.step(act)
+        assert torch.allclose(rew, ro["reward"][t], atol=1e-3, rtol=1e-3) and torch.equal(done, ro["done"][t]), t
+    env.close(); lp.close()
+
+
+USER_STAGE = r"""
+// A caller's action stage written against the PUBLIC header only: a two-layer policy  a = W2 tanh(W1 ob)  with the hidden layer in registers.
+#include <hip/hip_runtime.h>
+#include "rsb_pipeline.h"
+struct Mlp { const float* W1; const float* W2; int hidden; float* act_log; };
+__global__ void __launch_bounds__(64) user_stage(const rsb_stage_ctx c, const Mlp p) {
+  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) {
+    if (final) return;
+    const int lane = threadIdx.x;
+    for (int e = 0; e < n_env; ++e) {
+      const float* ob = c.ob + (size_t)(env0 + e) * c.ob_dim;
+      float h = 0.f;                                   // lane = hidden unit
+      if (lane < p.hidden) { for (int i = 0; i < c.ob_dim; ++i) h = fmaf(p.W1[lane * c.ob_dim + i], ob[i], h); h = tanhf(h); }
+      for (int j = 0; j < c.act_dim; ++j) {            // one output at a time: wave reduction in a fixed order
+        float t = lane < p.hidden ? p.W2[j * p.hidden + lane] * h : 0.f;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if (lane == 0) { c.act[(size_t)(env0 + e) * c.act_dim + j] = t; if (p.act_log) p.act_log[((size_t)pass * c.n_envs + env0 + e) * c.act_dim + j] = t; }
+      }
+    }
+  });
+}
+extern "C" int launch_user_stage(void* user, const rsb_stage_ctx* c) {
+  hipLaunchKernelGGL(user_stage, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, *static_cast<const Mlp*>(user));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+"""
+
+
+class Mlp(C.Structure):
+    _fields_ = [("W1", C.c_void_p), ("W2", C.c_void_p), ("hidden", C.c_int), ("act_log", C.c_void_p)]
+
+
+def test_a_callers_own_stage_kernel_rides_the_pipeline(built_lib, anymal, tmp_path):
+    """The device-side hand-over helpers are a public header: a stage kernel compiled OUTSIDE the library (hipcc, include/rsb_pipeline.h only)
+    runs as the action stage through rsb_closed_loop_run - pipelined and in lock-step the same bits, over 200 steps with resets."""
+    import torch
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "user_stage.hip"
+    src.write_text(USER_STAGE)
+    so = tmp_path / "libuser_stage.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-o", str(so), str(src)], check=True)
+    lib = C.CDLL(str(so))
+    fn = C.cast(lib.launch_user_stage, C.c_void_p)
+    n, K, hidden = 4096, 50, 32
+    rng = np.random.default_rng(3)
+    dev = torch.device("cuda:0")
+    out = {}
+    for pipe in (False, True):
+        env = workload.closed_loop_env(anymal, n)
+        assert env.world.set_step_pipelining(pipe) == pipe
+        W1 = torch.from_numpy(rng.uniform(-0.3, 0.3, (hidden, env.num_obs)).astype(np.float32)).to(dev) if not out else out["W"][0]
+        W2 = torch.from_numpy(rng.uniform(-0.6, 0.6, (env.num_acts, hidden)).astype(np.float32)).to(dev) if not out else out["W"][1]
+        out["W"] = (W1, W2)
+        logs = []
+        for r in range(4):
+            log = torch.zeros((K, n, env.num_acts), dtype=torch.float32, device=dev)
+            m = Mlp(W1.data_ptr(), W2.data_ptr(), hidden, log.data_ptr())
+            st = built_lib.rsb_closed_loop_run(env.world.handle, K, fn, C.byref(m))
+            assert st == 0, built_lib.rsb_last_error()
+            env.world.step_pipeline_join()
+            logs.append(log.cpu().numpy())
+        q, u = env.world.get_state()
+        out[pipe] = (np.stack(logs), q, u, env.world.step_pipelining_stats()[0])
+        env.close()
+    assert out[True][3] == 4 * K and out[False][3] == 0
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1]) and np.array_equal(out[False][2], out[True][2])
+    assert np.isfinite(out[True][0]).all() and np.abs(out[True][0]).max() > 0.1
+
+
+@pytest.mark.parametrize("kind,code", [(1, 1), (2, 2), (4, 4)])
+@pytest.mark.parametrize("closed", [False, True])
+def test_a_pipeline_fault_is_an_error_code_and_the_handle_stays_usable(built_lib, anymal, monkeypatch, kind, code, closed):
+    """rsb_debug_pipeline_fault makes one pipelined launch fail on the device (a ticket outside its XCD's range / a wait past the time-out /
+    the error word set): nothing traps, the streams drain, the next joining call raises RSB_E_PIPELINE ONCE; by then the library has restored
+    the last joined state, switched pipelining off and replayed the logged steps in lock-step - the state equals a lock-step twin's, the
+    handle keeps working, and pipelining can be switched on again."""
+    import bench
+    from test_gpu_pipeline import Rig, same
+    monkeypatch.setenv("RSB_PIPE_TIMEOUT_MS", "300")
+    n = 4096
+    if closed:
+        twin, w = Loop(anymal, n, False), Loop(anymal, n, True)
+        world = w.env.world
+        twin.run(12); w.run(12)
+        world.step_pipeline_join()
+        world.debug_pipeline_fault(kind)
+        twin.run(20); w.run(20)
+        snap = lambda x: x.final()
+    else:
+        recipe = bench.Recipe(2, -1.0)
+        twin, w = Rig(recipe, n, False), Rig(recipe, n, True)
+        world = w.w
+        twin.step(12); w.step(12)
+        world.step_pipeline_join()
+        w.step(7)
+        world.debug_pipeline_fault(kind)
+        w.step(13)
+        twin.step(20)
+        snap = lambda x: x.snapshot()
+    with pytest.raises(RsbError, match="status -7"):
+        world.step_pipeline_join()
+    faults, got = world.step_pipeline_fault()
+    assert faults == 1 and (got == code or (kind == 2 and got in (2, 5, 6))), (faults, got)      # (a wait nobody ends: whichever waiter's clock runs out first reports)
+    assert not world.step_pipelining_enabled()
+    world.step_pipeline_join()            # reported once
+    a, b = snap(twin), snap(w)
+    assert (same(a, b) if not closed else equal(a, b)) is None
+    # the handle is usable: more steps in lock-step, then pipelined again (after a ticket fault: hand-over at agent scope)
+    assert world.set_step_pipelining(True)
+    if closed:
+        twin.run(15); w.run(15)
+    else:
+        twin.step(15); w.step(15)
+    world.step_pipeline_join()
+    a, b = snap(twin), snap(w)
+    assert (same(a, b) if not closed else equal(a, b)) is None
+    assert world.step_pipeline_fault() == (faults, got)
+    twin.close(); w.close()
+
+
+def test_no_trap_instruction_in_the_pipelined_classes(tmp_path):
+    """no __builtin_trap left in the | 16 kernel classes, the gate or the stage (ISA of this tree)."""
+    import re
+    from raisimlib_amd import build as rb
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "raisimlib_amd", "csrc")
+    inc = ["-I", os.path.join(ROOT, "include"), "-I", csrc]
+    a = tmp_path / "k.s"
+    subprocess.run([hipcc, *rb.FLAGS, *inc, "-DRSB_I_LPE=16", "-DRSB_I_KMAX=8", "-DRSB_I_CL=16", "-DRSB_I_ML=4", "-DRSB_I_PROF=0", "--cuda-device-only", "-S", "-o", str(a),
+                    os.path.join(csrc, "step_instance.hip")], check=True, capture_output=True)
+    b = tmp_path / "p.s"
+    subprocess.run([hipcc, *rb.FLAGS, "-x", "hip", *inc, "--cuda-device-only", "-S", "-o", str(b), os.path.join(csrc, "rsb_pipeline.hip")], check=True, capture_output=True)
+    for f in (a, b):
+        assert not re.search(r"\bs_trap\b", f.read_text()), f
+    # the stage stays small enough to share a SIMD with a step wave (96 of 512 registers left, no LDS)
+    txt = b.read_text()
+    i = txt.index("linear_stage_kernel", txt.index("amdhsa.kernels"))
+    blk = txt[i:i + 1500]
+    assert int(re.search(r"\.vgpr_count:\s*(\d+)", blk).group(1)) <= 96

@@ -1,0 +1,56 @@
+#!/bin/bash
+# tools/lease.sh <tag> <step> [<step> ...] - ONE parameterised script for a GPU call (replaces rounds 1-4's ~60 one-off tools/gpu_r0N_x.sh files).
+# Run through gpurun from the repo root:   gpurun --timeout 900 -- 'bash tools/lease.sh r05_a "pytest:tests/test_gpu_closed_loop.py" "bench:--steps 20 --warmup 5"'
+# Every step has a name:argument form, runs under its own `timeout`, and logs to gpurun_out/<tag>/NN_<name>.{log,json} (merged back by gpurun).
+#   pytest:<pytest args>        python -m pytest <args> -q -x --timeout 600             (pytest:-m gpu tests = the GPU tier)
+#   smoke                       __graft_entry__.smoke()
+#   bench:<bench.py args>       python bench.py <args>: last stdout line -> .json, stderr -> .log
+#   trace:<bench.py args>       rocprofv3 --kernel-trace --stats over bench.py <args> (csv under NN_trace/)
+#   pmc:<COUNTERS>:<bench args> rocprofv3 --pmc <COUNTERS (space separated)> over bench.py <args> - counters only, never with trace domains
+#   py:<script and args>        python <script and args>   (tools/diag_*.py, tools/exp/*.py)
+#   sh:<command>                bash -c <command>
+#   ab:<reps>:<lib>,<lib>:<bench args>   same-box A/B: librsb variants (RSB_LIB_PATH) alternating, `reps` rounds, one value per line
+# STEP_TIMEOUT (seconds, default 600) bounds every step.
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+TAG=${1:?tag}; shift
+O=$R/gpurun_out/$TAG
+mkdir -p "$O"
+cd "$R"
+export TMPDIR=/tmp
+T=${STEP_TIMEOUT:-600}
+i=0
+for step in "$@"; do
+  i=$((i + 1)); n=$(printf %02d $i)
+  kind=${step%%:*}; arg=${step#*:}; [ "$kind" = "$step" ] && arg=""
+  t0=$(date +%s)
+  case "$kind" in
+    pytest) ( timeout $T python -m pytest $arg -q -x --timeout 600 --durations=6 ) > "$O/${n}_pytest.log" 2>&1; echo "rc=$?" >> "$O/${n}_pytest.log"; tail -6 "$O/${n}_pytest.log" ;;
+    smoke)  timeout $T python -c "import __graft_entry__ as g; g.smoke()" > "$O/${n}_smoke.log" 2>&1; echo "rc=$?" >> "$O/${n}_smoke.log"; tail -2 "$O/${n}_smoke.log" ;;
+    bench)  timeout $T python bench.py $arg 2> "$O/${n}_bench.log" | tail -1 > "$O/${n}_bench.json"; echo "rc=${PIPESTATUS[0]} args: $arg" >> "$O/${n}_bench.log"
+            python - "$O/${n}_bench.json" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    c = d.get("closed_loop") or {}
+    print("bench:", {k: (round(v) if isinstance(v, float) and v > 1e3 else v) for k, v in d.items() if k in ("value", "ms_per_step", "n_gpus")},
+          "lockstep", round(((d.get("lockstep") or {}).get("value") or 0)),
+          "closed_loop", {m: round((c.get(m) or {}).get("value") or 0) for m in ("pipelined", "lockstep")} if c else None, c.get("error"))
+except Exception as e:
+    print("bench: no JSON line (", e, ")")
+PY
+            ;;
+    trace)  ( cd /tmp && timeout $T rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${n}_trace" -o run -- python "$R/bench.py" $arg ) > "$O/${n}_trace.log" 2>&1; echo "rc=$?" >> "$O/${n}_trace.log" ;;
+    pmc)    ctr=${arg%%:*}; barg=${arg#*:}
+            ( cd /tmp && timeout $T rocprofv3 --pmc $ctr --output-format csv -d "$O/${n}_pmc" -o run -- python "$R/bench.py" $barg ) > "$O/${n}_pmc.log" 2>&1; echo "rc=$? counters: $ctr" >> "$O/${n}_pmc.log" ;;
+    py)     timeout $T python $arg > "$O/${n}_py.log" 2>&1; echo "rc=$?" >> "$O/${n}_py.log"; tail -5 "$O/${n}_py.log" ;;
+    sh)     timeout $T bash -c "$arg" > "$O/${n}_sh.log" 2>&1; echo "rc=$?" >> "$O/${n}_sh.log"; tail -5 "$O/${n}_sh.log" ;;
+    ab)     reps=${arg%%:*}; rest=${arg#*:}; libs=${rest%%:*}; barg=${rest#*:}
+            : > "$O/${n}_ab.txt"
+            for r in $(seq 1 $reps); do for lib in ${libs//,/ }; do
+              v=$(RSB_LIB_PATH=$R/raisimlib_amd/lib/$lib timeout $T python bench.py $barg 2>/dev/null | tail -1 | python -c "import json,sys; d=json.load(sys.stdin); print(round(d['value']), round((d.get('lockstep') or {}).get('value') or 0))" 2>/dev/null)
+              echo "$lib $v" >> "$O/${n}_ab.txt"
+            done; done; cat "$O/${n}_ab.txt" ;;
+    *)      echo "lease.sh: unknown step kind '$kind'" ;;
+  esac
+  echo "[lease $TAG] step $n $kind done in $(( $(date +%s) - t0 )) s"
+done
