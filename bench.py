@@ -98,6 +98,7 @@ def parse():
                          "that the default single-GPU run of config 2 appends")
     ap.add_argument("--closed-loop-only", action="store_true", help="diagnostic: only the `closed_loop` block (policy in the loop, include/rsb_pipeline.h), as its own JSON line")
     ap.add_argument("--stage-grid", type=int, default=0, help="diagnostic (closed loop): workgroups of the action stage (library default 256)")
+    ap.add_argument("--dry-run-fail-leg", type=int, default=-1, help="test hook (--dry-run-ranks): the second leg raises on this rank")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="plumbing check without GPUs: the ranks rendezvous on gloo, all-gather a host obs block per step and "
                          "print the contract line with dry_run=true (no device world, no physics; value is not a measurement)")
@@ -154,8 +155,10 @@ def spawn_ranks(args):
 
 
 def dry_run_ranks(args, rank, world_size):
-    """The N>1 plumbing on CPU (gloo): rendezvous, env-shard bookkeeping, one obs all-gather per "step" through the same
-    ObsGatherer the device path uses, barrier-bracketed timing with the MAX over ranks, ONE JSON line on rank 0.  No physics."""
+    """The N>1 plumbing on CPU (gloo): rendezvous, env-shard bookkeeping, the communicator check (`rccl`), and the SAME two-leg order the device
+    path runs (two_legs): first the in-line all-gather per "step" through the ObsGatherer the device path uses, then - under the guard - the
+    double-buffered leg that stands for the pipelined steps + side-stream gather; barrier-bracketed timing with the MAX over ranks, ONE JSON line
+    on rank 0.  --dry-run-fail-leg R makes the second leg raise on rank R: the line must then be the first leg's.  No physics."""
     import torch
     import torch.distributed as dist
     from raisimlib_amd.dist import ObsGatherer, env_range
@@ -164,41 +167,72 @@ def dry_run_ranks(args, rank, world_size):
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     n, obs_dim = args.envs_per_gpu, 49
     lo, hi = env_range(rank, n)
-    gath = ObsGatherer(n, obs_dim, torch.device("cpu"), overlap=args.overlap_collective, force=args.force_collective)
+    ones = torch.ones(1, dtype=torch.float64)
+    dist.all_reduce(ones)
+    allr = [torch.zeros(2, dtype=torch.int64) for _ in range(world_size)]
+    dist.all_gather(allr, torch.tensor([rank, int(os.environ.get("LOCAL_RANK", rank))], dtype=torch.int64))
+    rccl_info = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
+                 "by_rank": [{"rank": int(r[0]), "local_rank": int(r[1])} for r in allr]}
     rows = torch.arange(lo, hi, dtype=torch.float32)[:, None].expand(n, obs_dim)
+    state = {"k": 0}
 
-    def step(k):
-        gath.acquire(k)
-        gath.local(k).copy_(rows + float(k))          # stands for the step kernel writing this rank's obs block
-        gath.gather(k)
+    def leg(overlap, fail):
+        gath = ObsGatherer(n, obs_dim, torch.device("cpu"), overlap=overlap, force=args.force_collective)
 
-    for k in range(args.warmup):
-        step(k)
-    gath.drain()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        step(k)
-    gath.drain()
-    dist.barrier()
-    mine = time.perf_counter() - t0
-    t = torch.tensor([mine], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world_size)]
-    dist.all_gather(per_rank, torch.tensor([mine], dtype=torch.float64))
-    last = gath.gathered(args.warmup + args.steps - 1)
-    want = torch.arange(0, world_size * n, dtype=torch.float32) + float(args.warmup + args.steps - 1)
-    ok = bool(torch.equal(last[:, 0], want)) if gath.active else True
+        def step(k):
+            gath.acquire(k)
+            gath.local(k).copy_(rows + float(k))          # stands for the step kernel writing this rank's obs block
+            gath.gather(k)
+        for _ in range(args.warmup):
+            step(state["k"]); state["k"] += 1
+        gath.drain()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(state["k"]); state["k"] += 1
+        gath.drain()
+        if fail:
+            raise RuntimeError("injected failure of the second leg (--dry-run-fail-leg)")
+        dist.barrier()
+        mine = time.perf_counter() - t0
+        t = torch.tensor([mine], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world_size)]
+        dist.all_gather(per_rank, torch.tensor([mine], dtype=torch.float64))
+        last = gath.gathered(state["k"] - 1)
+        want = torch.arange(0, world_size * n, dtype=torch.float32) + float(state["k"] - 1)
+        ok = bool(torch.equal(last[:, 0], want)) if gath.active else True
+        return {"elapsed": float(t.item()), "ms_by_rank": [float(x.item()) / args.steps * 1e3 for x in per_rank], "ok": ok, "obs_all_gather": gath.describe()}
+
+    def all_agree(ok):
+        f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        if ok or args.dry_run_fail_leg < 0:
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        else:
+            # (the rank that raised left the leg's collectives early: it catches up with the barrier and the two reductions the others are in)
+            dist.barrier(); dist.all_reduce(torch.zeros(1, dtype=torch.float64), op=dist.ReduceOp.MAX)
+            dist.all_gather([torch.zeros(1, dtype=torch.float64) for _ in range(world_size)], torch.zeros(1, dtype=torch.float64))
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return float(f.item()) == 1.0
+
+    two = world_size > 1
+    legs = two_legs((lambda: leg(False, False)) if two else None, lambda: leg(args.overlap_collective or two, rank == args.dry_run_fail_leg), all_agree)
+    use = legs[legs["use"]]
+    ok = use["ok"] and (legs["first"] is None or legs["first"]["ok"])
     dist.destroy_process_group()
     if rank == 0:
-        elapsed = float(t.item())
+        elapsed = use["elapsed"]
         print(json.dumps({
             "metric": "env-steps/sec (DRY RUN: rank plumbing only, no physics)", "value": world_size * n * 4 * args.steps / elapsed,
             "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_by_rank": [float(x.item()) / args.steps * 1e3 for x in per_rank],
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_by_rank": use["ms_by_rank"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dry_run": True,
+            "value_leg": ("second (stands for: pipelined steps + gather on a side stream)" if legs["use"] == "second" else "first (stands for: lock-step + in-line all-gather)"),
+            "pipelined_leg_error": legs["error"], "rccl": rccl_info,
+            "lockstep": ({"value": world_size * n * 4 * args.steps / legs["first"]["elapsed"], "ms_per_step": legs["first"]["elapsed"] / args.steps * 1e3, "ran_first": True,
+                          "obs_all_gather": legs["first"]["obs_all_gather"]} if legs["first"] else None),
             "config": {"workload": "dry run of the rank plumbing on gloo", "envs_per_gpu": n, "parallelism": f"env-shard x{world_size}",
-                       "obs_all_gather": gath.describe(), "gathered_rows_correct": ok}}), flush=True)
+                       "obs_all_gather": use["obs_all_gather"], "gathered_rows_correct": ok}}), flush=True)
     return 0 if ok else 1
 
 
@@ -511,6 +545,27 @@ def closed_loop_leg(args, dev, n):
     return res
 
 
+def two_legs(first, second, all_agree):
+    """The order of an N > 1 bench run (also what --dry-run-ranks exercises on CPU): `first` - the combination that has run
+    before, or None when there is only one leg - must succeed; `second` runs under a guard.  A second leg that raised on ANY rank (all_agree:
+    MIN over the ranks) does not count anywhere: every rank then reports the first leg.  Returns {"use": "first" | "second", "first": result |
+    None, "second": result | None, "error": message | None}; with no first leg a failure of the second one is re-raised."""
+    r1 = first() if first is not None else None
+    r2, err = None, None
+    try:
+        r2 = second()
+    except Exception as e:
+        if r1 is None:
+            raise
+        err = f"{type(e).__name__}: {e}"
+    ok = all_agree(err is None)
+    if not ok and err is None:
+        err = "the leg raised on another rank"
+    if r1 is None:
+        return {"use": "second", "first": None, "second": r2, "error": None}
+    return {"use": "second" if ok else "first", "first": r1, "second": r2 if ok else None, "error": err}
+
+
 def measure(args, rank, local_rank, world_size, dev, coll):
     """One configuration end to end on this rank: world, pre-roll, warm-up, the timed region (barrier + synchronise on both sides, MAX
     over ranks), the sampling pass behind `roofline`, the CPU leg.  Returns the contract dictionary on rank 0, None elsewhere."""
@@ -520,6 +575,20 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     from raisimlib_amd import BatchedWorld, workload
     out = None
     N = args.envs_per_gpu
+    # did the communicator come up with every rank, each on a GPU of its own?  (the driver's scaling run reads this: VERDICT r04 #2)
+    rccl_info = None
+    if world_size > 1 or coll:
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones)
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = torch.tensor([rank, local_rank, torch.cuda.current_device(), int(getattr(props, "pci_bus_id", -1)), int(getattr(props, "multi_processor_count", 0))],
+                            dtype=torch.int64, device=dev)
+        allr = torch.zeros(5 * world_size, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        rows = allr.view(world_size, 5).cpu().tolist()
+        rccl_info = {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(), "allreduce_of_ones": float(ones.item()),
+                     "by_rank": [{"rank": r[0], "local_rank": r[1], "device": r[2], "pci_bus_id": r[3], "compute_units": r[4]} for r in rows],
+                     "distinct_devices": len({(r[2], r[3]) for r in rows})}
     recipe = Recipe(args.config, args.target_amplitude, args.atlas_regime, args.per_env_maps, args.target_scale)
     if args.anderson >= 0:
         recipe.anderson = (args.anderson, recipe.anderson[1])
@@ -613,34 +682,114 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     q_start, u_start = world.get_state()    # the population the timed region starts from (the CPU leg starts from it too)
     step_start = kstep
 
-    # ---- timed region: exactly --steps control steps, every EVENT_STRIDE-th launch bracketed
-    n_in = 0
-    if not args.no_kernel_events:
-        stride = EVENT_STRIDE if args.steps >= 2 * EVENT_STRIDE else max(args.steps, 1)
-        n_in = (args.steps + stride - 1) // stride
-        world.enable_timing(max(n_in, 2))
+    # ---- the timed region(s).  N = 1: the pipelined steps (or lock-step with --lockstep).  N > 1: the combination that HAS run
+    # before goes first - lock-step control steps + the all-gather in line on the launch stream (tests/test_distributed_gloo.py, rounds 1-3's
+    # bench path) -, then the pipelined steps + gather on a side stream, which no hardware has run with N > 1 before the driver's scaling run,
+    # under a guard (two_legs): if that leg raises on any rank, `value` is the first leg's.
+    def timed(step_fn, drain_fn, k0):
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        err = None
+        try:
+            for k in range(k0, k0 + args.steps):
+                step_fn(k)
+            drain_fn()
+        except Exception as e:      # (kept until this rank has been through the collectives below: the other ranks are in them)
+            err = e
+        t_enq = time.perf_counter() - t0       # host side done; the GPU may still be working
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        try:
+            world.step_pipeline_join()           # (a pipeline fault surfaces HERE as RsbError: the library has replayed the steps in lock-step by then)
+        except Exception as e:
+            err = err or e
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        by_rank = [el / args.steps * 1e3]
+        if world_size > 1:
+            every = torch.zeros(world_size, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, t)
+            by_rank = [float(x) / args.steps * 1e3 for x in every.cpu()]
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if err is not None:
+            raise err
+        return {"elapsed": float(t.item()), "ms_by_rank": by_rank, "t_enqueued": t_enq}
+
+    def start_brackets():
+        if args.no_kernel_events:
+            return 0
+        stride = EVENT_STRIDE if args.steps >= 64 else 1      # (>= 16 brackets at the driver's --steps 20; a bracket costs ~7 us of stream time, stated in the line)
+        n = (args.steps + stride - 1) // stride
+        world.enable_timing(max(n, 2))
         world.set_timing_stride(stride)
-    if world_size > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        control_step(kstep)
-        kstep += 1
-    drain()
-    t_enqueued = time.perf_counter() - t0       # host side done; the GPU may still be working
-    if world_size > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ms_by_rank = [elapsed / args.steps * 1e3]
-    if world_size > 1:
-        every = torch.zeros(world_size, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(every, t)
-        ms_by_rank = [float(x) / args.steps * 1e3 for x in every.cpu()]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        return n
+
+    def leg_lockstep_inline():
+        nonlocal kstep
+        world.set_step_pipelining(False)
+        g2 = ObsGatherer(N, obs_dim, dev, overlap=False, force=args.force_collective)
+        fns2 = [world.control_step_plan(workload.SUBSTEPS, o.data_ptr() if o is not None else 0, feet_idx, feet_idx if reset else None,
+                                        gc0_d.data_ptr() if reset else 0, gv0_d.data_ptr() if reset else 0, N) for o in g2.local_bufs]
+
+        def step_inline(k):
+            g2.acquire(k)
+            fns2[g2.slot(k)](bank_ptr[k % TARGET_BANK])
+            g2.gather(k)
+        for _ in range(max(5, args.warmup // 4)):
+            step_inline(kstep)
+            kstep += 1
+        g2.drain()
+        r = timed(step_inline, g2.drain, kstep)
+        kstep += args.steps
+        if g2.active:      # this rank's slice of the gathered block of the last step = its own block
+            r["gathered_rows_of_this_rank_correct"] = bool(torch.equal(g2.gathered(kstep - 1)[rank * N:(rank + 1) * N], g2.local(kstep - 1)))
+        r["obs_all_gather"] = g2.describe()
+        return r
+
+    n_in = 0
+
+    def leg_primary():
+        nonlocal kstep, n_in, q_start, u_start, step_start
+        if lockstep_first_wanted:      # back into the pipelined regime before its timed region
+            world.set_step_pipelining(True)
+            for _ in range(max(5, args.warmup // 4)):
+                control_step(kstep)
+                kstep += 1
+            drain()
+            torch.cuda.synchronize()
+            q_start, u_start = world.get_state()
+            step_start = kstep
+        n_in = start_brackets()
+        r = timed(control_step, drain, kstep)
+        kstep += args.steps
+        return r
+
+    lockstep_first_wanted = world_size > 1 and pipelined
+
+    def all_agree(ok):
+        if world_size == 1:
+            return ok
+        f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return float(f.item()) == 1.0
+
+    legs = two_legs(leg_lockstep_inline if lockstep_first_wanted else None, leg_primary, all_agree)
+    lockstep_first = legs["first"]
+    value_leg, pipelined_leg_error = ("pipelined" if pipelined else "lockstep"), legs["error"]
+    if legs["use"] == "second":
+        elapsed, ms_by_rank, t_enqueued = legs["second"]["elapsed"], legs["second"]["ms_by_rank"], legs["second"]["t_enqueued"]
+    else:       # the pipelined leg raised (here or on another rank): the line is the first leg's
+        elapsed, ms_by_rank, t_enqueued = lockstep_first["elapsed"], lockstep_first["ms_by_rank"], lockstep_first["t_enqueued"]
+        value_leg = "lockstep + in-line all-gather (the pipelined leg raised: see pipelined_leg_error)"
+        try:
+            world.set_step_pipelining(False)
+        except Exception:
+            pass
+        pipelined = False
+        n_in = 0
     kernel_ms_in = world.read_kernel_ms(n_in).astype(np.float64) if n_in else np.zeros(0)
 
     # ---- sampling pass (untimed, same sequence continued): every launch bracketed; resets and env ages recorded
@@ -673,7 +822,9 @@ def measure(args, rank, local_rank, world_size, dev, coll):
 
     # ---- the same workload with every launch waiting for the one before it (rsb_set_step_pipelining off): same bracket, same number of steps
     lockstep = None
-    if pipelined:
+    if lockstep_first is not None:
+        lockstep = lockstep_first["elapsed"]
+    elif pipelined:
         world.set_step_pipelining(False)
         for _ in range(max(5, args.warmup // 4)):
             control_step(kstep)
@@ -737,14 +888,27 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                                 "(profiles/r02_ubench_lone_wave_latency.txt); valu_pipe_frac: the same at 2 cycles per wave64 instruction - what the "
                                 "SIMD-32 pipe can take from SEVERAL co-resident waves (MI355X_MICROARCH.md; profiles/r04_ubench_two_waves.txt: two waves "
                                 "per SIMD run dependent FMA chains and the sweep-loop mix at 0.8-1.0x the lone wave's time EACH).  Recorded PMC pass, measured launch time"}
+            alg_bytes = bytes_per_env_step * env_steps_per_step
+            fused_bytes = bytes_per_env_step * N          # with the sub-steps fused in one launch the state crosses HBM once per CONTROL step
+            bw_thr = alg_bytes / (eff_ms * 1e-3) / 1e9          # over the interval between two launches' completions (= ms_per_step: what the chip sustains)
+            bw_dur = alg_bytes / (kmean_ms * 1e-3) / 1e9        # over ONE launch's start -> end (pipelined launches overlap: this is the smaller number)
+            if valu is not None:
+                valu["recorded"] = True       # SQ_INSTS_VALU comes from the committed PMC pass named in traffic_source, not from this run
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": achieved / HBM_PEAK_GBS,
+                    # both fractions under explicit names.  `frac` (the contract field) = frac_throughput when launches are
+                    # pipelined, = frac_kernel_duration in lock-step (the two coincide there up to the launch gap)
+                    "frac_throughput": bw_thr / HBM_PEAK_GBS, "frac_kernel_duration": bw_dur / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src, "traffic_recorded": traffic is not None,
+                    "fused_algorithmic_bytes_per_launch": fused_bytes,
+                    "traffic_over_fused_algorithmic_bytes": (traffic / fused_bytes) if traffic else None,
+                    "traffic_over_algorithmic_bytes": (traffic / alg_bytes) if traffic else None,
                     "kernel": "rsb_step_kernel", "kernel_ms_mean": kmean_ms,
                     "kernel_ms_p50": float(np.median(kernel_ms_s)) - bracket_overhead_ms,
                     "kernel_ms_max": float(kernel_ms_s.max()) - bracket_overhead_ms,
                     "kernel_launches_timed": int(len(kernel_ms_s)),
                     "kernel_ms_mean_bracket_raw": raw, "event_pair_overhead_ms": bracket_overhead_ms,
-                    "timed_region_brackets": {"n": int(len(kernel_ms_in)), "stride": EVENT_STRIDE,
+                    "timed_region_brackets": {"n": int(len(kernel_ms_in)), "stride": (EVENT_STRIDE if args.steps >= 64 else 1),
                                               "kernel_ms_mean": (float(kernel_ms_in.mean()) - bracket_overhead_ms) if len(kernel_ms_in) else None},
                     "method": f"HIP event pairs recorded by the library on the launch stream around each of {len(kernel_ms_s)} launches of a "
                               "sampling pass that continues the timed region's sequence; an empty event pair on the same stream is subtracted",
@@ -766,6 +930,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
             "metric": recipe.metric,
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_by_rank": ms_by_rank, "higher_is_better": True, "scaling": "weak",
+            "value_leg": value_leg, "pipelined_leg_error": pipelined_leg_error,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": recipe.name + ", dt=0.0025, 4 sub-steps per control step fused in one launch"
@@ -800,7 +965,10 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                 "obs_all_gather": gath.describe(),
             },
             "roofline": roof,
+            "rccl": rccl_info,
             "lockstep": ({"value": total_env_steps / lockstep, "unit": "env-steps/s", "ms_per_step": lockstep / args.steps * 1e3, "steps": args.steps,
+                          "ran_first": lockstep_first is not None, "obs_all_gather": (lockstep_first or {}).get("obs_all_gather"),
+                          "gathered_rows_of_this_rank_correct": (lockstep_first or {}).get("gathered_rows_of_this_rank_correct"),
                           "what": "rsb_set_step_pipelining off, same bracket: every launch waits for the slowest wave of the one before it (what a caller "
                                   "gets that consumes each step's output before issuing the next step, e.g. a policy in the loop)"} if lockstep else None),
             "build": {"source_hash": world.L.rsb_source_hash().decode(), "library": os.path.relpath(os.path.realpath(__import__("raisimlib_amd")._capi.LIB_PATH), ROOT)},

@@ -74,6 +74,7 @@ typedef struct rsb_stage_ctx {
   int32_t* act_prog;          /* ... of the last pass served for block b                                             */
   uint32_t* ticket;           /* arrival counters of the stage's waves per XCD (monotonic; XCD x's at [64 x]); ticket_base: their value at the start of this run */
   int32_t* err;               /* the pipeline's error word (0 = fine)                                                */
+  int32_t* err_host;          /* ... its copy for the host (page-locked host memory)                                 */
   uint32_t* started;          /* stage workgroups that have started (the first step of a run is gated on all `grid`) */
   int32_t blocks;             /* env blocks = workgroups of the step kernel                                          */
   int32_t envs_per_block;     /* block b holds envs [b * envs_per_block, min(n_envs, (b + 1) * envs_per_block))      */
@@ -158,7 +159,8 @@ namespace rsb_stage {
 
 __device__ __forceinline__ int ld_word(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void fail(const rsb_stage_ctx& c, int code) {
-  if ((threadIdx.x & 63) == 0) atomicCAS(c.err, 0, code);      /* the first code stays */
+  if ((threadIdx.x & 63) == 0 && atomicCAS(c.err, 0, code) == 0)      /* the first code stays; the host reads its own copy */
+    __hip_atomic_store(c.err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 /* body(block, env0, n_env, pass, final): called by all 64 lanes of the wave that serves `block`, once per pass, in pass order */

@@ -154,8 +154,11 @@ int pipe_probe_xcds(rsb_world* w, int* n_xcds) {
 // The gate in front of a pipelined launch: one thread that spins until the launch before it (other stream) has been dispatched completely
 // (`started` has reached `target`), so that a waiting workgroup never holds a slot its predecessor needs.  No trap: past the time-out it
 // stores the error word and lets the launch behind it run into it (every workgroup of that launch then leaves at its first look at the word).
+__device__ inline void raise_error(int* err, int* err_host, int code) {      // the first code stays; the host reads its own copy
+  if (atomicCAS(err, 0, code) == 0) __hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 template <class T>
-__global__ void pipe_gate_kernel(const T* started, T target, int* err, long long timeout) {
+__global__ void pipe_gate_kernel(const T* started, T target, int* err, int* err_host, long long timeout) {
   int spins = 0;
   long long t0 = 0;
   while (__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
@@ -164,7 +167,7 @@ __global__ void pipe_gate_kernel(const T* started, T target, int* err, long long
     if ((++spins & 63) == 0) {
       const long long now = wall_clock64();
       if (t0 == 0) t0 = now;
-      else if (now - t0 > timeout) { atomicCAS(err, 0, RSB_PIPE_ERR_TIMEOUT_GATE); return; }
+      else if (now - t0 > timeout) { raise_error(err, err_host, RSB_PIPE_ERR_TIMEOUT_GATE); return; }
     }
   }
 }
@@ -172,7 +175,7 @@ __global__ void fill_i32_kernel(int* a, int n, int v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = v;
 }
-__global__ void set_word_kernel(int* p, int v) { atomicCAS(p, 0, v); }
+__global__ void set_word_kernel(int* err, int* err_host, int v) { raise_error(err, err_host, v); }
 // the state the steps since the last join started from: gc | gv | warm records, one buffer (restored by pipe_recover)
 __global__ void snapshot_kernel(float* dst, const float* gc, size_t n0, const float* gv, size_t n1, const float* warm, size_t n2, int restore,
                                 float* gc_w, float* gv_w, float* warm_w) {
@@ -208,6 +211,11 @@ int pipe_prepare(rsb_world* w, int blocks) {
   if (const char* e = std::getenv("RSB_PIPE_WORD_STRIDE")) w->pipe_stride = std::min(std::max(std::atoi(e), 1), 4096);
   HIP_TRY(hipMalloc(&w->d_pipe_prog, (size_t)2 * blocks * w->pipe_stride * sizeof(int)));   // step_prog | act_prog
   if (!w->d_pipe_started) HIP_TRY(hipMalloc(&w->d_pipe_started, kCtlBytes));
+  if (!w->h_pipe_err) {
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&w->h_pipe_err), 64, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&w->d_pipe_err_host), w->h_pipe_err, 0));
+    *w->h_pipe_err = 0;
+  }
   HIP_TRY(hipMemset(w->d_pipe_prog, 0, (size_t)2 * blocks * w->pipe_stride * sizeof(int)));
   HIP_TRY(hipMemset(w->d_pipe_started, 0, kCtlBytes));
   w->pipe_wg_total = 0; w->pipe_stats_wg0 = 0; w->pipe_seq = 0; w->pipe_xcc_uses = 0; w->stage_started_total = 0; w->stage_ticket_total = 0;
@@ -243,6 +251,7 @@ int closed_loop_lockstep(rsb_world* w, int K, rsb_stage_launch_fn launch, void* 
 // state of the last join, pipelining off, the logged steps once more in lock-step.
 int pipe_recover(rsb_world* w, int code) {
   ++w->pipe_faults; w->pipe_last_code = code; w->pipe_fault_pending = true;
+  *w->h_pipe_err = 0;
   std::fprintf(stderr, "raisimlib_amd: pipelined control steps faulted on the device (code %d: %s); restoring the last joined state and replaying %zu call(s) in lock-step, pipelining off\n",
                code, code == RSB_PIPE_ERR_TICKET ? "env-block ticket outside its XCD's range" : code == RSB_PIPE_ERR_TIMEOUT ? "a step workgroup's wait ran past the time-out"
                : code == RSB_PIPE_ERR_TIMEOUT_GATE ? "a gate's wait ran past the time-out" : code == RSB_PIPE_ERR_TIMEOUT_STAGE ? "an action-stage wave's wait ran past the time-out"
@@ -300,8 +309,7 @@ int pipe_join(rsb_world* w) {
   hipError_t e = hipSuccess;
   for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamSynchronize(w->pipe_stream[i]);
   if (e == hipSuccess && w->pipe_stage_stream) e = hipStreamSynchronize(w->pipe_stage_stream);
-  int code = 0;
-  if (e == hipSuccess) e = hipMemcpy(&code, err_ptr(w), sizeof code, hipMemcpyDeviceToHost);
+  const int code = e == hipSuccess ? *static_cast<volatile int*>(w->h_pipe_err) : 0;      // (written by whoever raised the error, visible once its kernel has completed)
   if (e != hipSuccess) { rsb::set_error(std::string("joining the pipelined control steps: ") + hipGetErrorString(e)); w->pipe_log.clear(); return RSB_E_HIP; }
   if (code != 0) return pipe_recover(w, code);
   w->pipe_log.clear();
@@ -325,7 +333,7 @@ int pipe_begin_launch(rsb_world* w, StepArgs& a, int blocks, bool closed_loop, h
   int st = pipe_prepare(w, blocks);
   if (st != RSB_OK) return st;
   a.pipe_prog = w->d_pipe_prog; a.pipe_started = w->d_pipe_started;
-  a.pipe_err = err_ptr(w); a.pipe_timeout = timeout_ticks();
+  a.pipe_err = err_ptr(w); a.pipe_err_host = w->d_pipe_err_host; a.pipe_timeout = timeout_ticks();
   if (!w->pipe_active) {
     // (sequence numbers and the started count carry on: every earlier pipelined launch has completed.  A closed-loop run forks itself.)
     st = pipe_fork(w, false);
@@ -345,14 +353,14 @@ int pipe_begin_launch(rsb_world* w, StepArgs& a, int blocks, bool closed_loop, h
   if (w->debug_fault) {      // rsb_debug_pipeline_fault: this launch fails on the device
     if (w->debug_fault == 1 && a.pipe_xcds > 0) a.pipe_xcc_base -= 1u;
     else if (w->debug_fault == 2) { a.pipe_wait_on = 1; a.pipe_wait += 1 << 20; }
-    else hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, *ls, err_ptr(w), RSB_PIPE_ERR_INJECTED);
+    else hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, *ls, err_ptr(w), w->d_pipe_err_host, RSB_PIPE_ERR_INJECTED);
     w->debug_fault = 0;
   }
   // (the gate also keeps the per-XCD tickets of consecutive launches apart)
   if (w->pipe_n > 0)
-    hipLaunchKernelGGL(pipe_gate_kernel<unsigned long long>, dim3(1), dim3(1), 0, *ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total, err_ptr(w), timeout_ticks());
+    hipLaunchKernelGGL(pipe_gate_kernel<unsigned long long>, dim3(1), dim3(1), 0, *ls, (const unsigned long long*)w->d_pipe_started, w->pipe_wg_total, err_ptr(w), w->d_pipe_err_host, timeout_ticks());
   else if (closed_loop)    // first step of a closed-loop run: the action stage is on the chip (it never has to compete with waiting step workgroups for a slot)
-    hipLaunchKernelGGL(pipe_gate_kernel<uint32_t>, dim3(1), dim3(1), 0, *ls, (const uint32_t*)stage_started_ptr(w), (uint32_t)w->stage_started_total, err_ptr(w), timeout_ticks());
+    hipLaunchKernelGGL(pipe_gate_kernel<uint32_t>, dim3(1), dim3(1), 0, *ls, (const uint32_t*)stage_started_ptr(w), (uint32_t)w->stage_started_total, err_ptr(w), w->d_pipe_err_host, timeout_ticks());
   if (w->pipe_dep) { HIP_TRY(hipStreamWaitEvent(*ls, w->pipe_dep, 0)); w->pipe_dep = nullptr; }   // rsb_step_pipeline_wait_event
   HIP_TRY(hipGetLastError());
   return RSB_OK;
@@ -375,6 +383,7 @@ void pipe_destroy(rsb_world* w) {
   if (w->d_pipe_prog) (void)hipFree(w->d_pipe_prog);
   if (w->d_pipe_started) (void)hipFree(w->d_pipe_started);
   if (w->d_snap) (void)hipFree(w->d_snap);
+  if (w->h_pipe_err) (void)hipHostFree(w->h_pipe_err);
 }
 
 namespace {
@@ -521,7 +530,7 @@ int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user,
   st = pipe_fork(w, true);
   if (st != RSB_OK) return st;
   c.step_prog = w->d_pipe_prog; c.act_prog = act_prog; c.ticket = stage_ticket_ptr(w);
-  c.err = err_ptr(w); c.started = stage_started_ptr(w);
+  c.err = err_ptr(w); c.err_host = w->d_pipe_err_host; c.started = stage_started_ptr(w);
   c.word_stride = w->pipe_stride;
   { const char* e = std::getenv("RSB_STAGE_POLL"); c.poll_sleep = e ? std::min(std::max(std::atoi(e), 0), 64) : 2; }
   c.xcds = (w->pipe_xcds > 0 && c.blocks % w->pipe_xcds == 0) ? w->pipe_xcds : 0;
@@ -550,7 +559,7 @@ int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user,
   w->pipe_log_suppress = false;
   if (st != RSB_OK) {
     // a step could not be enqueued: the stage would wait for it until its time-out.  Tell the device now, then join (recovers from the snapshot)
-    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, w->stream, err_ptr(w), RSB_PIPE_ERR_INJECTED);
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, w->stream, err_ptr(w), w->d_pipe_err_host, RSB_PIPE_ERR_INJECTED);
     const std::string msg = rsb::last_error();
     (void)pipe_join(w);
     rsb::set_error(msg);

@@ -142,6 +142,7 @@ struct rsb_world {
   int pipe_faults = 0, pipe_last_code = 0;               // faults so far, device code of the last one (RSB_PIPE_ERR_*)
   bool pipe_fault_pending = false;                       // the next status-returning call that joins reports RSB_E_PIPELINE once
   int debug_fault = 0;                                   // rsb_debug_pipeline_fault: the next pipelined launch fails this way
+  int* h_pipe_err = nullptr; int* d_pipe_err_host = nullptr;   // the error word's copy for the host: page-locked host memory and its device address
   float* d_snap = nullptr; size_t snap_cap = 0;          // gc | gv | warm records at the last fork (what a faulted pipeline is replayed from)
   struct PipeLog {                                       // one call since the last fork: a control step (open loop) or a whole closed-loop run
     bool closed = false;

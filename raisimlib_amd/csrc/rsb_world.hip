@@ -243,15 +243,16 @@ __global__ void reset_terminated_kernel(float* gc, float* gv, const rsb_contact*
 // ---- device-resident vectorised env (rsg_anymal task semantics, see rsb.h and env_task.h) ----------------------
 // The step itself (action -> targets, sub-steps, reward, termination, reset, next observation) is ONE launch of the step
 // kernel (StepArgs::env_*); what remains here is the stand-alone observation and the reset of all envs.
-__device__ inline void env_write_obs(float* o, const float* q, const float* u, int nv) {
-  const int nj = nv - 6;
-  for (int i = 0; i < 10 + 2 * nj; ++i) o[i] = rsbk::env_ob_entry(i, nj, [&](int k) { return q[k]; }, [&](int k) { return u[k]; });
-}
-
+// thread = (env, observation entry): env_ob_entry is the arithmetic the fused epilogue uses (bit-identical observations), so a thread per entry
+// only repeats the quaternion -> rotation part per entry - 3 us for 4096 envs where the thread-per-env loop took 13 (it opens every closed-loop run)
 __global__ void env_obs_kernel(float* ob, const float* gc, const float* gv, int N, int nq, int nv) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N) return;
-  env_write_obs(ob + (size_t)e * (10 + 2 * (nv - 6)), gc + (size_t)e * nq, gv + (size_t)e * nv, nv);
+  const int od = 10 + 2 * (nv - 6);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * od) return;
+  const int e = i / od, k = i - e * od;
+  const float* q = gc + (size_t)e * nq;
+  const float* u = gv + (size_t)e * nv;
+  ob[i] = rsbk::env_ob_entry(k, nv - 6, [&](int j) { return q[j]; }, [&](int j) { return u[j]; });
 }
 
 __global__ void env_reset_kernel(float* gc, float* gv, int32_t* count, int32_t* flags, const float* gc0, const float* gv0, int rows,
@@ -546,7 +547,8 @@ int copy_out(rsb_world* w, void* dst, const void* src, size_t bytes, int space) 
 }
 
 int launch_env_obs(rsb_world* w, float* dst, hipStream_t s) {
-  hipLaunchKernelGGL(env_obs_kernel, dim3((w->N + 255) / 256), dim3(256), 0, s, dst, w->d_gc, w->d_gv, w->N, w->blob.nq, w->blob.nv);
+  const int total = w->N * (10 + 2 * (w->blob.nv - 6));
+  hipLaunchKernelGGL(env_obs_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dst, w->d_gc, w->d_gv, w->N, w->blob.nq, w->blob.nv);
   HIP_TRY(hipGetLastError());
   return RSB_OK;
 }
@@ -1381,9 +1383,8 @@ int rsb_env_observe(rsb_world* w, float* ob, int space) {
   if (!ob) return RSB_E_INVALID;
   const size_t od = 10 + 2 * (size_t)(w->blob.nv - 6);
   float* dob = space == RSB_DEVICE ? ob : w->d_env_io;
-  hipLaunchKernelGGL(env_obs_kernel, dim3((w->N + 255) / 256), dim3(256), 0, stream_of(w), dob, w->d_gc, w->d_gv, w->N,
-                     w->blob.nq, w->blob.nv);
-  HIP_TRY(hipGetLastError());
+  st = launch_env_obs(w, dob, stream_of(w));
+  if (st != RSB_OK) return st;
   if (space == RSB_HOST) return copy_out(w, ob, dob, (size_t)w->N * od * sizeof(float), RSB_HOST);
   return RSB_OK;
 }

@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
         // the dispatcher did not deal this launch's workgroups round-robin over the XCDs (the host's probe saw it do so on an idle device): no
         // env block can be assigned.  Error word instead of a trap: this workgroup leaves without touching anything, the others follow (below),
         // the host's next join replays the steps in lock-step
-        if (lane == 0) atomicCAS(a.pipe_err, 0, 1 /* RSB_PIPE_ERR_TICKET; the first code stays */);
+        if (lane == 0 && atomicCAS(a.pipe_err, 0, 1 /* RSB_PIPE_ERR_TICKET; the first code stays */) == 0) __hip_atomic_store(a.pipe_err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
       }
       blk = (int)(xcc * per + t);
@@ -703,7 +703,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
           const long long now = wall_clock64();
           if (t0 == 0) t0 = now;
           else if (now - t0 > a.pipe_timeout) {
-            if (lane == 0) atomicCAS(a.pipe_err, 0, 2 /* RSB_PIPE_ERR_TIMEOUT */);
+            if (lane == 0 && atomicCAS(a.pipe_err, 0, 2 /* RSB_PIPE_ERR_TIMEOUT */) == 0) __hip_atomic_store(a.pipe_err_host, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
           }
         }

@@ -190,6 +190,7 @@ struct StepArgs {
   // publishing; every waiting workgroup (and gate) sees the word in its spin and returns too, so the streams drain and the host's next join
   // finds the word: it restores the state of the last join and replays the steps in lock-step (rsb_world.hip: pipe_recover).
   int* pipe_err;
+  int* pipe_err_host;                    // the same code for the host: page-locked host memory (a system-scope store; the join reads it without a copy)
   long long pipe_timeout;
   // closed loop (rsb_closed_loop_run): a step does not wait for its OWN predecessor's word but for the action stage's - workgroup b of step k + 1
   // starts when the stage has published block b's actions computed from step k's observation (act_prog[b] >= pipe_wait).  Open loop: == pipe_prog

@@ -27,8 +27,13 @@ def _json_lines(stdout):
     return [json.loads(l) for l in stdout.splitlines() if l.startswith("{")]
 
 
-def _check(b, n):
+def _check(b, n, leg="second"):
     assert b["n_gpus"] == n and b["dry_run"] is True and b["scaling"] == "weak" and b["steps"] == 4 and b["warmup"] == 1
+    # the two-leg order of an N > 1 run (bench.two_legs): the tested combination first, its numbers in `lockstep`; which leg `value` is
+    assert b["value_leg"].startswith(leg) and b["lockstep"]["ran_first"] is True and b["lockstep"]["obs_all_gather"] == "in line"
+    assert (b["pipelined_leg_error"] is None) == (leg == "second")
+    # the communicator saw every rank
+    assert b["rccl"]["rccl_ranks"] == n and b["rccl"]["allreduce_of_ones"] == float(n) and sorted(r["rank"] for r in b["rccl"]["by_rank"]) == list(range(n))
     assert len(b["ms_per_step_by_rank"]) == n
     assert abs(b["ms_per_step"] - max(b["ms_per_step_by_rank"])) < 1e-9          # the all-reduced MAX over ranks
     assert b["config"]["parallelism"] == f"env-shard x{n}"
@@ -45,6 +50,38 @@ def test_self_spawn(n, extra):
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout           # only rank 0 prints
     _check(lines[0], n)
+
+
+@pytest.mark.parametrize("bad_rank", [0, 1])
+def test_a_second_leg_that_raises_leaves_the_first_legs_line(bad_rank):
+    """the leg that never ran on hardware (pipelined steps + gather on a side stream) must not be able to lose the run - it raises
+    on one rank, every rank agrees to report the first leg (lock-step + in-line all-gather), the job exits 0 with ONE line that says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-ranks", "--steps", "4", "--warmup", "1", "--envs-per-gpu", "32", "--dry-run-fail-leg", str(bad_rank)],
+                       capture_output=True, text=True, timeout=120, cwd="/tmp", env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    _check(lines[0], 2, leg="first")
+    assert "injected failure" in lines[0]["pipelined_leg_error"] or "another rank" in lines[0]["pipelined_leg_error"]
+
+
+def test_two_legs_unit():
+    """bench.two_legs on its own: order, the guard, agreement, and that a single-leg run re-raises"""
+    import bench
+    calls = []
+    r = bench.two_legs(lambda: calls.append("a") or {"x": 1}, lambda: calls.append("b") or {"x": 2}, lambda ok: ok)
+    assert calls == ["a", "b"] and r["use"] == "second" and r["first"] == {"x": 1} and r["second"] == {"x": 2} and r["error"] is None
+
+    def boom():
+        raise ValueError("no")
+    r = bench.two_legs(lambda: {"x": 1}, boom, lambda ok: ok)
+    assert r["use"] == "first" and r["second"] is None and "ValueError: no" in r["error"]
+    r = bench.two_legs(lambda: {"x": 1}, lambda: {"x": 2}, lambda ok: False)       # raised on ANOTHER rank
+    assert r["use"] == "first" and r["second"] is None and "another rank" in r["error"]
+    with pytest.raises(ValueError):
+        bench.two_legs(None, boom, lambda ok: ok)
+    assert bench.two_legs(None, lambda: {"x": 3}, lambda ok: ok)["use"] == "second"
 
 
 def test_under_torch_distributed_run():
