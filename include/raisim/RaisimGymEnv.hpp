@@ -13,6 +13,9 @@
 #include "raisim/World.hpp"
 #include "raisim/Yaml.hpp"
 
+/// raisimGymTorch's Common.hpp [RECALL]: READ_YAML(double, action_std, cfg_["action_std"])
+#define READ_YAML(type, dst, node) { RSFATAL_IF((node).IsNone(), "Node " #node " doesn't exist"); dst = (node).template As<type>(); }
+
 namespace raisim {
 
 /// stand-in for Eigen::Ref<Eigen::Matrix<float, -1, 1>> (one row of the [num_envs, dim] observation / action matrix)
@@ -31,8 +34,24 @@ struct RowRef {
   Eigen::Map<Eigen::Matrix<typename std::remove_const<T>::type, Eigen::Dynamic, 1>> e() const { return {const_cast<typename std::remove_const<T>::type*>(p), n}; }
 #endif
 };
+#ifdef RAISIM_HAS_EIGEN
+// with Eigen in the include path the boundary carries upstream's own types [RECALL raisimGymTorch/env/RaisimGymEnv.hpp, Common.hpp]:
+//   virtual void observe(Eigen::Ref<EigenVec> ob);  virtual float step(const Eigen::Ref<EigenVec>& action);
+// EigenVecRef / ConstEigenVecRef name the same types, so an environment written against the spans keeps overriding them
+using EigenRowMajorMat = Eigen::Matrix<float, Eigen::Dynamic, Eigen::Dynamic, Eigen::RowMajor>;
+using EigenVec = Eigen::Matrix<float, Eigen::Dynamic, 1>;
+using EigenBoolVec = Eigen::Matrix<bool, Eigen::Dynamic, 1>;
+using EigenVecRef = Eigen::Ref<EigenVec>;
+using ConstEigenVecRef = Eigen::Ref<EigenVec>;
+/// one row of the caller's [num_envs, dim] float matrix as what observe() / step() take
+inline Eigen::Map<EigenVec> rowOf(float* p, int n) { return Eigen::Map<EigenVec>(p, n); }
+inline Eigen::Map<EigenVec> rowOf(const float* p, int n) { return Eigen::Map<EigenVec>(const_cast<float*>(p), n); }   // (upstream passes rows of a non-const Ref as well)
+#else
 using EigenVecRef = RowRef<float>;
 using ConstEigenVecRef = RowRef<const float>;
+inline EigenVecRef rowOf(float* p, int n) { return EigenVecRef(p, n); }
+inline ConstEigenVecRef rowOf(const float* p, int n) { return ConstEigenVecRef(p, n); }
+#endif
 
 /// upstream raisim::Reward: named reward terms with coefficients read from cfg["reward"]
 class Reward {

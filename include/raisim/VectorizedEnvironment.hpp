@@ -191,7 +191,7 @@ class VectorizedEnvironment {
   /// ob: float [num_envs, obDim] row-major (upstream: Eigen::Ref<EigenRowMajorMat>&)
   void observe(float* ob, int rows, int cols, bool updateStatistics) {
     RSFATAL_IF(rows != num_envs_ || cols != obDim_, "observe: buffer must be [num_envs, obDim]");
-    fibers_.forEach(num_envs_, [&](int i) { environments_[i]->observe(EigenVecRef(ob + (size_t)i * obDim_, obDim_)); }, threads_);   // (upstream: an OpenMP parallel-for)
+    fibers_.forEach(num_envs_, [&](int i) { environments_[i]->observe(rowOf(ob + (size_t)i * obDim_, obDim_)); }, threads_);   // (upstream: an OpenMP parallel-for)
     if (normalizeObservation_) updateObservationStatisticsAndNormalize(ob, updateStatistics);
   }
 
@@ -256,7 +256,7 @@ class VectorizedEnvironment {
   }
 
   inline void perAgentStep(int agentId, const float* action, float* reward, bool* done) {
-    reward[agentId] = environments_[agentId]->step(ConstEigenVecRef(action + (size_t)agentId * actionDim_, actionDim_));
+    reward[agentId] = environments_[agentId]->step(rowOf(action + (size_t)agentId * actionDim_, actionDim_));
     rewardInformation_[agentId] = environments_[agentId]->getRewards().getStdMap();
     float terminalReward = 0;
     done[agentId] = environments_[agentId]->isTerminalState(terminalReward);

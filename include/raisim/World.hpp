@@ -38,8 +38,10 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <iostream>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <shared_mutex>
 #include <stdexcept>
 #include <string>
@@ -51,7 +53,20 @@
 #include "raisim/math.hpp"
 #include "rsb.h"
 
-#define RSFATAL_IF(cond, msg) do { if (cond) throw std::runtime_error(std::string(msg)); } while (0)
+// raisim_message.hpp's macros [RECALL; absent from /root/reference - SURVEY.md section 5: "same names for source compat"]: stream-style messages,
+//   RSINFO("dt " << dt);  RSWARN_IF(n > 8, "contacts: " << n);  RSFATAL_IF(!ok, "cannot open " << path);
+// INFO / WARN print "[file:line] [INFO] message" to stderr.  FATAL upstream prints and exits; here it THROWS std::runtime_error with the same text
+// (an abort inside a Python extension module would take the interpreter down; pybind11 turns the exception into a Python one).
+#define RSB_MSG_(level, msg) do { std::ostringstream rs_os_; rs_os_ << "[" << __FILE__ << ":" << __LINE__ << "] [" level "] " << msg; std::cerr << rs_os_.str() << std::endl; } while (0)
+#define RSINFO(msg) RSB_MSG_("INFO", msg)
+#define RSWARN(msg) RSB_MSG_("WARN", msg)
+#define RSINFO_IF(cond, msg) do { if (cond) RSINFO(msg); } while (0)
+#define RSWARN_IF(cond, msg) do { if (cond) RSWARN(msg); } while (0)
+#define RSFATAL(msg) do { std::ostringstream rs_os_; rs_os_ << msg; throw std::runtime_error(rs_os_.str()); } while (0)
+#define RSFATAL_IF(cond, msg) do { if (cond) RSFATAL(msg); } while (0)
+#define RSASSERT(cond, msg) RSFATAL_IF(!(cond), msg)
+#define RSRETURN_IF(cond, msg) do { if (cond) { RSWARN(msg); return; } } while (0)
+#define RSISNAN(val) RSFATAL_IF(std::isnan(val), #val " is nan")
 #define RSB_CHECK(expr) do { int st_ = (expr); if (st_ != RSB_OK) throw std::runtime_error(std::string(#expr) + ": " + rsb_last_error()); } while (0)
 
 namespace raisim {
@@ -561,6 +576,13 @@ class ArticulatedSystem {
   void setGeneralizedVelocity(const VecDyn& gv) { putRow(RSB_F_GV, gv); }
   void setState(const VecDyn& gc, const VecDyn& gv) { putRow(RSB_F_GC, gc); putRow(RSB_F_GV, gv); }
   void getState(VecDyn& gc, VecDyn& gv) { getRow(RSB_F_GC, gc, w_->gcDim()); getRow(RSB_F_GV, gv, w_->dof()); }
+#ifdef RAISIM_HAS_EIGEN
+  /// upstream's getState(Eigen::VectorXd&, Eigen::VectorXd&) [RECALL]; the setters take Eigen vectors through VecDyn's converting constructor
+  template <class A, class B> void getState(Eigen::MatrixBase<A>& gc, Eigen::MatrixBase<B>& gv) {
+    getRow(RSB_F_GC, gc_, w_->gcDim()); getRow(RSB_F_GV, gv_, w_->dof());
+    gc.derived() = gc_.e(); gv.derived() = gv_.e();
+  }
+#endif
   const VecDyn& getGeneralizedCoordinate() { getRow(RSB_F_GC, gc_, w_->gcDim()); return gc_; }
   const VecDyn& getGeneralizedVelocity() { getRow(RSB_F_GV, gv_, w_->dof()); return gv_; }
 

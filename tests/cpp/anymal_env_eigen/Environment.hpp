@@ -1,0 +1,150 @@
+// An rsg_anymal-style ENVIRONMENT written THE WAY UPSTREAM'S IS [RECALL raisimGymTorch/env/envs/rsg_anymal/Environment.hpp; absent from
+// /root/reference]: Eigen vectors and expressions (gc_.tail(12), rot.e().row(2), cast<float>(), the comma initialiser), Eigen::Ref<EigenVec>
+// in observe() / step(), and termination by BODY - footIndices_ holds the shanks' body indices and a contact ends the episode when
+// contact.getlocalBodyIndex() is not one of them.  It compiles only where <Eigen/Core> exists: the facade's Eigen-typed boundary
+// (include/raisim/*.hpp behind RAISIM_HAS_EIGEN) is what this file exercises; tests build it with -I tests/cpp/eigen_stub.
+// tests/cpp/facade_eigen_test.cpp runs N of these under raisim::VectorizedEnvironment<ENVIRONMENT> against the device-resident env.
+#pragma once
+
+#include <cmath>
+#include <set>
+#include <string>
+
+#include "raisim/RaisimGymEnv.hpp"
+
+#ifndef RAISIM_HAS_EIGEN
+#error "tests/cpp/anymal_env_eigen/Environment.hpp is the Eigen-typed environment: add an Eigen (or tests/cpp/eigen_stub) include path"
+#endif
+
+namespace raisim {
+
+class ENVIRONMENT : public RaisimGymEnv {
+ public:
+  explicit ENVIRONMENT(const std::string& resourceDir, const Yaml::Node& cfg, bool visualizable)
+      : RaisimGymEnv(resourceDir, cfg), visualizable_(visualizable) {
+    /// create world
+    world_ = std::make_unique<raisim::World>();
+
+    /// add objects
+    anymal_ = world_->addArticulatedSystem(resourceDir_ + "/anymal_c_like.urdf");
+    anymal_->setName("anymal");
+    anymal_->setControlMode(raisim::ControlMode::PD_PLUS_FEEDFORWARD_TORQUE);
+    world_->addGround();
+
+    /// get robot data
+    gcDim_ = anymal_->getGeneralizedCoordinateDim();
+    gvDim_ = anymal_->getDOF();
+    nJoints_ = gvDim_ - 6;
+
+    /// initialize containers
+    gc_.setZero(gcDim_); gc_init_.setZero(gcDim_);
+    gv_.setZero(gvDim_); gv_init_.setZero(gvDim_);
+    pTarget_.setZero(gcDim_); vTarget_.setZero(gvDim_); pTarget12_.setZero(nJoints_);
+
+    /// this is nominal configuration of anymal
+    gc_init_ << 0, 0, 0.57, 1.0, 0.0, 0.0, 0.0, 0.03, 0.4, -0.8, -0.03, 0.4, -0.8, 0.03, -0.4, 0.8, -0.03, -0.4, 0.8;
+
+    /// set pd gains
+    Eigen::VectorXd jointPgain(gvDim_), jointDgain(gvDim_);
+    jointPgain.setZero(); jointPgain.tail(nJoints_).setConstant(50.0);
+    jointDgain.setZero(); jointDgain.tail(nJoints_).setConstant(0.2);
+    anymal_->setPdGains(jointPgain, jointDgain);
+    anymal_->setGeneralizedForce(Eigen::VectorXd::Zero(gvDim_));
+
+    /// MUST BE DONE FOR ALL ENVIRONMENTS
+    obDim_ = 34;
+    actionDim_ = nJoints_; actionMean_.setZero(actionDim_); actionStd_.setZero(actionDim_);
+    obDouble_.setZero(obDim_);
+
+    /// action scaling
+    actionMean_ = gc_init_.tail(nJoints_);
+    double action_std;
+    READ_YAML(double, action_std, cfg_["action_std"])   /// example of reading params from the config
+    actionStd_.setConstant(action_std);
+
+    /// Reward coefficients
+    rewards_.initializeFromConfigurationFile(cfg["reward"]);
+
+    /// indices of links that should not make contact with ground
+    footIndices_.insert(anymal_->getBodyIdx("LF_SHANK"));
+    footIndices_.insert(anymal_->getBodyIdx("RF_SHANK"));
+    footIndices_.insert(anymal_->getBodyIdx("LH_SHANK"));
+    footIndices_.insert(anymal_->getBodyIdx("RH_SHANK"));
+    RSFATAL_IF(footIndices_.size() != 4, "expected four shank bodies, found " << footIndices_.size());
+  }
+
+  void init() final {}
+
+  void reset() final {
+    anymal_->setState(gc_init_, gv_init_);
+    updateObservation();
+  }
+
+  float step(const Eigen::Ref<EigenVec>& action) final {
+    /// action scaling
+    pTarget12_ = action.cast<double>();
+    pTarget12_ = pTarget12_.cwiseProduct(actionStd_);
+    pTarget12_ += actionMean_;
+    pTarget_.tail(nJoints_) = pTarget12_;
+
+    anymal_->setPdTarget(pTarget_, vTarget_);
+
+    for (int i = 0; i < int(control_dt_ / simulation_dt_ + 1e-10); i++) {
+      world_->integrate();
+    }
+
+    updateObservation();
+
+    rewards_.record("torque", anymal_->getGeneralizedForce().squaredNorm());
+    rewards_.record("forwardVel", std::min(4.0, bodyLinearVel_[0]));
+
+    return rewards_.sum();
+  }
+
+  void updateObservation() {
+    anymal_->getState(gc_, gv_);
+    raisim::Vec<4> quat;
+    raisim::Mat<3, 3> rot;
+    quat[0] = gc_[3]; quat[1] = gc_[4]; quat[2] = gc_[5]; quat[3] = gc_[6];
+    raisim::quatToRotMat(quat, rot);
+    bodyLinearVel_ = rot.e().transpose() * gv_.segment(0, 3);
+    bodyAngularVel_ = rot.e().transpose() * gv_.segment(3, 3);
+
+    obDouble_ << gc_[2],                 /// body height
+        rot.e().row(2).transpose(),      /// body orientation
+        gc_.tail(12),                    /// joint angles
+        bodyLinearVel_, bodyAngularVel_, /// body linear&angular velocity
+        gv_.tail(12);                    /// joint velocity
+  }
+
+  void observe(Eigen::Ref<EigenVec> ob) final {
+    /// convert it to float
+    ob = obDouble_.cast<float>();
+  }
+
+  bool isTerminalState(float& terminalReward) final {
+    terminalReward = float(terminalRewardCoeff_);
+
+    /// if the contact body is not feet
+    for (auto& contact : anymal_->getContacts())
+      if (footIndices_.find(contact.getlocalBodyIndex()) == footIndices_.end())
+        return true;
+
+    terminalReward = 0.f;
+    return false;
+  }
+
+  void curriculumUpdate() {}
+
+ private:
+  int gcDim_, gvDim_, nJoints_;
+  bool visualizable_ = false;
+  raisim::ArticulatedSystem* anymal_;
+  Eigen::VectorXd gc_init_, gv_init_, gc_, gv_, pTarget_, pTarget12_, vTarget_;
+  double terminalRewardCoeff_ = -10.;
+  Eigen::VectorXd actionMean_, actionStd_, obDouble_;
+  Eigen::Vector3d bodyLinearVel_, bodyAngularVel_;
+  std::set<size_t> footIndices_;
+};
+
+}  // namespace raisim
