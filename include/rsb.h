@@ -161,6 +161,21 @@ int rsb_set_solver_multi_contact(rsb_world* w, int depth, int light_passes, int 
  * never returns an extrapolated iterate unchecked.  Measured on the Atlas-like standing population (oracle): 18.8 -> 10.6 sweeps,
  * p99 86 -> 41, unconverged 3.9 % -> 0.9 %, natural-map residual p99 2.7e-2 -> 1.1e-5.  first_sweep = 0 switches it off. */
 int rsb_set_solver_anderson(rsb_world* w, int first_sweep, double clip);
+/* Slip rule of the per-contact iteration (not a RaiSim parameter; default RSB_SLIP_ENERGY).
+ *   RSB_SLIP_ENERGY   the published rule (Hwangbo, Lee, Hutter 2018): a slipping contact takes the point of {v_n+ = 0} x {cone boundary} of least
+ *                     contact-space kinetic energy;
+ *   RSB_SLIP_COULOMB  classical Coulomb friction (Stewart-Trinkle, Anitescu-Potra): the point of the same curve where the post-impulse slip
+ *                     velocity is ANTI-PARALLEL to the friction impulse.
+ * The two coincide where the normal row of the contact's Delassus block does not couple with the tangential ones (a sphere or a box corner on flat
+ * ground); on the foot of a bent leg they differ - the energy rule's friction impulse sits 45 deg (p50) off the opposite of its own slip
+ * velocity, 29 % of the impulse (tests/test_oracle_independent.py).  Whether RaiSim's shipped solver is the one or the other
+ * cannot be read from /root/reference.  The Coulomb root is located like the energy minimum (16 grid directions, 16-section, Newton) on
+ * P = N x d instead of dE/dtheta; a contact problem without a bracketed root (6 % of random strongly coupled blocks) takes the energy rule's point.
+ * A kernel class of its own: floating-base systems of tree depth <= 5 with <= 8 contact slots, default integration scheme, one contact per
+ * primitive, no peer-mapped obs exchange, no pipelined twin (RSB_E_UNSUPPORTED from the step otherwise). */
+#define RSB_SLIP_ENERGY 0
+#define RSB_SLIP_COULOMB 1
+int rsb_set_slip_rule(rsb_world* w, int rule);
 /* ArticulatedSystem::setIntegrationScheme [RECALL; upstream file absent].  The velocity update is the same for every scheme (one
  * dynamics evaluation, one contact solve: u+ = u + M^-1 (dt tau + J^T lambda)); the scheme picks the velocity the positions move with:
  *   RSB_INTEGRATION_SEMI_IMPLICIT (default, RaiSim's)  q+ = q (+) dt u+

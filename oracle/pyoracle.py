@@ -39,6 +39,8 @@ class Params(C.Structure):
         ("hm_second_cos", C.c_double),
         ("integ_theta", C.c_double),
         ("hm_capsule", C.c_int32),
+        ("hm_plane_test", C.c_int32),
+        ("slip_rule", C.c_int32),
     ]
 
 
@@ -188,9 +190,13 @@ class Oracle:
                              _p(_d(pt)), _p(_d(dt_)), _p(_d(tau_ff)), _p(t))
         return t
 
-    def solve_contact(self, G, v, mu, section_rounds=2):
-        """Open / stick / slip rule for one isolated contact (G 3x3 contact-frame Delassus block, v free velocity)."""
+    def solve_contact(self, G, v, mu, section_rounds=2, rule=0):
+        """Open / stick / slip rule for one isolated contact (G 3x3 contact-frame Delassus block, v free velocity); rule 0 = the published
+        least-energy slip point, 1 = classical Coulomb (orc_params::slip_rule)."""
         lam = np.zeros(3)
+        if rule:
+            self.L.orc_solve_contact_rule(_p(_d(np.asarray(G).reshape(9))), _p(_d(v)), C.c_double(mu), C.c_int(section_rounds), C.c_int(rule), _p(lam))
+            return lam
         self.L.orc_solve_contact(_p(_d(np.asarray(G).reshape(9))), _p(_d(v)), C.c_double(mu), C.c_int(section_rounds), _p(lam))
         return lam
 

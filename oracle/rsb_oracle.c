@@ -542,13 +542,14 @@ static void closest_on_triangle(const double* a, const double* b, const double* 
  * *depth2 <= 0 when there is none. */
 static int terrain_contact_ex(const orc_params* p, const double* c, double r, double* depth, double* n, double* depth2, double* n2, int above_test);
 static int terrain_contact(const orc_params* p, const double* c, double r, double* depth, double* n, double* depth2, double* n2) {
-  return terrain_contact_ex(p, c, r, depth, n, depth2, n2, 0);
+  return terrain_contact_ex(p, c, r, depth, n, depth2, n2, p->hm_plane_test ? 0 : 1);     /* round 5: the height field decides (orc_params::hm_plane_test) */
 }
-/* above_test = 1 (the capsule search): "the centre is outside the terrain" is decided by the height field itself (c_z above the surface
- * at (c_x, c_y)) instead of by the plane of the triangle that holds the closest point.  At a CONVEX edge sharper than the sphere is
- * close the two differ: past the ridge line the centre is below the extended plane of the first face although it is above the
- * surface, and the sphere path then falls back to the plane of the face under the centre (a usable answer for one sphere; for the
- * capsule search it would rank a point beside the ridge deeper than the point above it). */
+/* above_test = 1 (since round 5 every caller; round 4: the capsule search only): "the centre is outside the terrain" is decided by the height field
+ * itself (c_z above the surface at (c_x, c_y)) instead of by the plane of the triangle that holds the closest point.  At a CONVEX edge sharper
+ * than the sphere is close the two differ: past the ridge line the centre is below the extended plane of the first face although it is above the
+ * surface, and the plane test then falls back to the plane of the face under the centre - depth and normal of the wrong feature (a sphere resting
+ * against a kerb; for the capsule search it ranked a point beside the ridge deeper than the point above it).  above_test = 0 survives as
+ * orc_params::hm_plane_test for the KAT that shows the difference. */
 static int terrain_contact_ex(const orc_params* p, const double* c, double r, double* depth, double* n, double* depth2, double* n2, int above_test) {
   if (depth2) *depth2 = 0.0;
   if (p->terrain_type == 0) {
@@ -875,13 +876,13 @@ static const double kSin16[16] = {0.0, 0.38268343236508977, 0.70710678118654752,
  *   den(d) = a0 + a1 x + a2 y,   N(d) := den * v_t^+ = [n00 + n01 x + n02 y ; n10 + n11 x + n12 y]
  * so a candidate costs a handful of FMAs and slip_dE needs no division (its value is dE/dtheta times den^2 / (mu ln),
  * a positive factor).  The device computes the coefficients once per solve on the contact's own lane. */
-typedef struct slip_coef { double a0, a1, a2, n00, n01, n02, n10, n11, n12, vn, ls0, ls1, mu, bx, by; } slip_coef;
+typedef struct slip_coef { double a0, a1, a2, n00, n01, n02, n10, n11, n12, vn, ls0, ls1, mu, bx, by; int coul; } slip_coef;
 
 static void slip_prepare(const double* G, const double* v, const double* ls, double mu, slip_coef* k) {
   k->a0 = G[8]; k->a1 = mu * G[6]; k->a2 = mu * G[7];
   k->n00 = k->a0 * v[0] - v[2] * G[2]; k->n01 = k->a1 * v[0] - v[2] * mu * G[0]; k->n02 = k->a2 * v[0] - v[2] * mu * G[1];
   k->n10 = k->a0 * v[1] - v[2] * G[5]; k->n11 = k->a1 * v[1] - v[2] * mu * G[3]; k->n12 = k->a2 * v[1] - v[2] * mu * G[4];
-  k->vn = v[2]; k->ls0 = ls[0]; k->ls1 = ls[1]; k->mu = mu;
+  k->vn = v[2]; k->ls0 = ls[0]; k->ls1 = ls[1]; k->mu = mu; k->coul = 0;
 }
 static double slip_E(const slip_coef* k, double x, double y) {
   double den = k->a0 + k->a1 * x + k->a2 * y;
@@ -890,6 +891,8 @@ static double slip_E(const slip_coef* k, double x, double y) {
   double vt0 = (k->n00 + k->n01 * x + k->n02 * y) * inv, vt1 = (k->n10 + k->n11 * x + k->n12 * y) * inv;
   return 0.5 * (vt0 * (k->mu * ln * x - k->ls0) + vt1 * (k->mu * ln * y - k->ls1));
 }
+/* k->coul != 0: the CLASSICAL COULOMB rule (orc_params::slip_rule) - the root of  P(theta) = N x d = den v_t+ x d  (slip velocity parallel to the
+ * impulse direction) that P crosses upwards, where v_t+ . d < 0: the same formulas with (den, a0, mdp) replaced by (1, 1, 0) */
 static double slip_dE(const slip_coef* k, double x, double y) {
   double den = k->a0 + k->a1 * x + k->a2 * y;
   double mdp = k->a2 * x - k->a1 * y;                 /* mu * G_nt . dperp, dperp = (-y, x) */
@@ -897,6 +900,7 @@ static double slip_dE(const slip_coef* k, double x, double y) {
    * round-0 best direction b, so the minimiser lies on b's side of the candidate */
   if (!(den > ORC_DEN_MIN * k->a0)) return (k->bx * y - k->by * x > 0.0) ? 1.0 : -1.0;
   double N0 = k->n00 + k->n01 * x + k->n02 * y, N1 = k->n10 + k->n11 * x + k->n12 * y;
+  if (k->coul) return N1 * x - N0 * y;
   return den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
 }
 
@@ -920,9 +924,15 @@ static double slip_newton_step(const slip_coef* k, double x0, double y0, double*
   double N0 = k->n00 + k->n01 * x0 + k->n02 * y0, N1 = k->n10 + k->n11 * x0 + k->n12 * y0;
   double dN0 = k->n02 * x0 - k->n01 * y0, dN1 = k->n12 * x0 - k->n11 * y0;
   double P = N1 * x0 - N0 * y0, Q = N0 * x0 + N1 * y0;
+  if (k->coul) { *hp = (dN1 * x0 - dN0 * y0) - Q; return -P / *hp; }      /* Coulomb: h = P */
   double h = den * P - mdp * Q;
   *hp = den * (dN1 * x0 - dN0 * y0) - k->a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
   return -h / *hp;
+}
+/* |P| and Q = N . d at a unit direction (the Coulomb rule's residual and the sign of the slip along the impulse) */
+static void slip_PQ(const slip_coef* k, double x, double y, double* P, double* Q) {
+  double N0 = k->n00 + k->n01 * x + k->n02 * y, N1 = k->n10 + k->n11 * x + k->n12 * y;
+  *P = N1 * x - N0 * y; *Q = N0 * x + N1 * y;
 }
 /* (x0, y0) rotated by the small angle d (|d| <= 0.25: degree-5 Taylor polynomials), renormalised */
 static void slip_rotate(double x0, double y0, double d, double* x1, double* y1) {
@@ -940,6 +950,11 @@ static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, dou
   double x, y;
   slip_rotate(x0, y0, d, &x, &y);
   if (!(k->a0 + k->a1 * x + k->a2 * y > ORC_DEN_NEWTON * k->a0)) { ORC_STAT(4); return 0; }
+  if (k->coul) {      /* Coulomb: the slip must oppose the impulse at the new direction, and a large step must reduce the residual */
+    double P0, Q0, P1, Q1;
+    slip_PQ(k, x0, y0, &P0, &Q0); slip_PQ(k, x, y, &P1, &Q1);
+    if (!(Q1 < 0.0) || (fabs(d) > 0.02 && !(fabs(P1) <= fabs(P0)))) { ORC_STAT(5); return 0; }
+  } else
   if (fabs(d) > 0.02 && !(slip_E(k, x, y) <= slip_E(k, x0, y0))) { ORC_STAT(5); return 0; }
   ORC_STAT(0);
   *x1 = x; *y1 = y; *step = d;
@@ -966,8 +981,17 @@ static int slip_newton(const slip_coef* k, double x0, double y0, double* x1, dou
  * ("lagged friction direction", used by the caller after `freeze_after` sweeps, and from the sweep after a Newton
  * refinement moved the direction by less than settle_tol rad: sdir[2] = 2 marks such a settled direction).  With refine != 0 and a valid
  * direction the global search is replaced by slip_newton() whenever that step is accepted. */
+/* coulomb != 0 (orc_params::slip_rule = ORC_SLIP_COULOMB): the slip case looks for the CLASSICAL COULOMB point of the same curve instead of the
+ * least-energy one - the direction where the post-impulse slip velocity is anti-parallel to the friction impulse:
+ *   round 0 : P = den v_t+ x d at the 16 grid directions; an interval [k, k+1] of feasible directions with P_k < 0 <= P_k+1 holds such a root
+ *             (upward crossing: there v_t+ . d < 0; the downward crossings are the roots where friction would PUSH the contact along its slip);
+ *             of several the one whose lower end has the least energy; NONE (two roots inside one 22.5 deg interval, or no feasible crossing):
+ *             the energy rule's search for this solve;
+ *   rounds 1.. and the polish: the same 16-section and Newton steps on P instead of dE/dtheta;
+ *   refinement of an earlier direction: one Newton step on P, accepted when the slip opposes the impulse there (and a step above 0.02 rad
+ *             reduces |P|); an inherited direction needs no basin check (it was a root of the previous step's problem). */
 static void solve_one_contact(const double* G, const double* Ginv, const double* v, double mu,
-                              int section_rounds, int use_frozen, int refine, double settle_tol, double* sdir, double* lam) {
+                              int section_rounds, int use_frozen, int refine, double settle_tol, double* sdir, double* lam, int coulomb) {
   if (v[2] > 0.0) { lam[0] = lam[1] = lam[2] = 0.0; return; }
   double ls[3];
   for (int r = 0; r < 3; ++r) ls[r] = -(Ginv[3 * r] * v[0] + Ginv[3 * r + 1] * v[1] + Ginv[3 * r + 2] * v[2]);
@@ -975,6 +999,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
   if (ls[2] >= 0.0 && lt2 <= mu * mu * ls[2] * ls[2]) { lam[0] = ls[0]; lam[1] = ls[1]; lam[2] = ls[2]; return; }
   slip_coef k;
   slip_prepare(G, v, ls, mu, &k);
+  k.coul = coulomb;
   /* sdir[2]: 0 no direction, 1 direction of an earlier slip solve of THIS integrate(), 2 the same and settled,
    * 3 inherited from the previous integrate() through the warm state and not yet used in this one */
   const int inherited = sdir[2] == 3.0;
@@ -991,7 +1016,7 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
   if (refine && sdir[2] != 0.0) {
     double x, y, d;
     int ok = slip_newton(&k, sdir[0], sdir[1], &x, &y, &d);
-    if (ok && inherited) {
+    if (ok && inherited && !coulomb) {
       /* basin check: E restricted to the curve can have two local minima, and a direction carried over from the previous
        * time step may sit in the one the global search would not choose (measured: 1 solve in 24 000 of the config-2
        * population, 0.3 m/s off).  The refined direction is accepted only if it is at least as good as every direction
@@ -1015,9 +1040,27 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
     double e = slip_E(&k, kCos16[i], kSin16[i]);
     if (e < ebest) { ebest = e; kbest = i; }
   }
-  k.bx = kCos16[kbest]; k.by = kSin16[kbest];
   double lox = kCos16[(kbest + 15) & 15], loy = kSin16[(kbest + 15) & 15];
   double hix = kCos16[(kbest + 1) & 15], hiy = kSin16[(kbest + 1) & 15];
+  if (coulomb) {
+    int kc = -1;
+    double ec = 1e300;
+    for (int i = 0; i < 16; ++i) {
+      const int j = (i + 1) & 15;
+      const double d0 = k.a0 + k.a1 * kCos16[i] + k.a2 * kSin16[i], d1 = k.a0 + k.a1 * kCos16[j] + k.a2 * kSin16[j];
+      if (!(d0 > ORC_DEN_MIN * k.a0) || !(d1 > ORC_DEN_MIN * k.a0)) continue;
+      double P0, Q0, P1, Q1;
+      slip_PQ(&k, kCos16[i], kSin16[i], &P0, &Q0); slip_PQ(&k, kCos16[j], kSin16[j], &P1, &Q1);
+      if (!(P0 < 0.0 && P1 >= 0.0)) continue;
+      if (!(Q0 < 0.0 && Q1 < 0.0)) continue;      /* the slip opposes the impulse on the whole interval (with coupling an upward crossing alone does not say so) */
+      const double e = slip_E(&k, kCos16[i], kSin16[i]);
+      if (e < ec) { ec = e; kc = i; }
+    }
+    if (kc >= 0) { kbest = kc; lox = kCos16[kc]; loy = kSin16[kc]; hix = kCos16[(kc + 1) & 15]; hiy = kSin16[(kc + 1) & 15]; }
+    else k.coul = 0;      /* no bracketed Coulomb root: the energy rule for this solve */
+  }
+  if (coulomb && k.coul) { k.bx = lox + hix; k.by = loy + hiy; }      /* (a direction inside the bracket: the side rule of slip_dE) */
+  else { k.bx = kCos16[kbest]; k.by = kSin16[kbest]; }
   for (int r = 0; r < section_rounds; ++r) {
     double ex = hix - lox, ey = hiy - loy;
     int kstar = 15;
@@ -1053,7 +1096,14 @@ static void solve_one_contact(const double* G, const double* Ginv, const double*
 void orc_solve_contact(const double* G, const double* v, double mu, int section_rounds, double* lam) {
   double Ginv[9], sdir[3] = {0.0, 0.0, 0.0};
   inv3(G, Ginv);
-  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, 0, 0.0, sdir, lam);
+  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, 0, 0.0, sdir, lam, 0);
+}
+/* ... with the slip rule chosen (ORC_SLIP_ENERGY / ORC_SLIP_COULOMB); *used_rule (may be NULL) receives the rule the slip case ended up with
+ * (a Coulomb solve without a bracketed root falls back to the energy rule) */
+void orc_solve_contact_rule(const double* G, const double* v, double mu, int section_rounds, int rule, double* lam) {
+  double Ginv[9], sdir[3] = {0.0, 0.0, 0.0};
+  inv3(G, Ginv);
+  solve_one_contact(G, Ginv, v, mu, section_rounds, 0, 0, 0.0, sdir, lam, rule);
 }
 
 static void contact_frame(const double* n, double* Rc /* columns t1 t2 n, row-major */) {
@@ -1563,8 +1613,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
               const double* lj = (glocal && gid[j] == gid[i]) ? lam[j] : lam0[j];
               for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lj[0] + G[i][j][3 * r + 1] * lj[1] + G[i][j][3 * r + 2] * lj[2];
             }
-            if (light && kpos > 0) solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, 1, 0, 0.0, sdir[i], ln);
-            else solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], ln);
+            if (light && kpos > 0) solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, 1, 0, 0.0, sdir[i], ln, p->slip_rule);
+            else solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], ln, p->slip_rule);
             if (gpos[i] != kpos) continue;   /* light variant, pass 0: a later member only refreshed its direction */
             for (int r = 0; r < 3; ++r) {
               const double base = glocal ? lam[i][r] : lam0[i][r];
@@ -1590,7 +1640,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
             if (j == i) continue;
             for (int r = 0; r < 3; ++r) v[r] += G[i][j][3 * r] * lam0[j][0] + G[i][j][3 * r + 1] * lam0[j][1] + G[i][j][3 * r + 2] * lam0[j][2];
           }
-          solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], tmp);
+          solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], tmp, p->slip_rule);
         }
         /* an inherited direction that the first refresh did not pick up is dropped: a contact that starts to slip later in
          * the solve runs the global search (the device checks inherited directions against the coarse scan in the first
@@ -1606,7 +1656,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
         /* per-sweep mode: the pass keeps every usable direction (frozen formula); a contact without one - it started to slip
          * inside this sweep, or its direction is inherited / ill conditioned - runs the global search right here (no Newton) */
         solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds,
-                          p->dir_per_sweep ? 1 : lag, p->dir_per_sweep ? 0 : p->refine, p->dir_per_sweep ? 0.0 : p->settle_tol, sdir[i], ln);
+                          p->dir_per_sweep ? 1 : lag, p->dir_per_sweep ? 0 : p->refine, p->dir_per_sweep ? 0.0 : p->settle_tol, sdir[i], ln, p->slip_rule);
         for (int r = 0; r < 3; ++r) {
           double dl = alpha * (ln[r] - lam[i][r]);
           lam[i][r] += dl;

@@ -126,6 +126,7 @@ PROTOTYPES = {
     "rsb_closed_loop_run_linear": (_I, [_VP, _I, C.POINTER(LinearPolicy)]),
     "rsb_closed_loop_buffers": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     "rsb_closed_loop_set_stage_grid": (_I, [_VP, _I]),
+    "rsb_set_slip_rule": (_I, [_VP, _I]),
     "rsb_set_integration_scheme": (_I, [_VP, _I]),
     "rsb_set_early_termination": (_I, [_VP, _I]),
     "rsb_set_solver_warm_start": (_I, [_VP, _I]),

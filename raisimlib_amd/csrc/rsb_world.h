@@ -80,6 +80,7 @@ struct rsb_world {
   int anderson = 2; double anderson_clip = 20.0;                                           // rsb_set_solver_anderson
   int hm_contacts = 1; double hm_second_cos = 0.70710678118654752;                                        // rsb_set_heightmap_contacts
   bool hm_capsule = false; int32_t* d_cap = nullptr; int n_cap = 0;                                       // rsb_set_capsule_contacts: [n_cap][2] end primitives of the model's capsules / cylinders, (first corner, -1) of its boxes
+  int slip_rule = 0;                                                                       // rsb_set_slip_rule (RSB_SLIP_ENERGY / RSB_SLIP_COULOMB)
   double integ_theta = 1.0;                                                                // rsb_set_integration_scheme
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats

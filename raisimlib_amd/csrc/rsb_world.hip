@@ -292,7 +292,7 @@ int launch_lpe_class(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe,
 }
 template <int KMAX, int CL, int ML>
 int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool prof) {
-  if constexpr ((CL & 2) == 0) {     // a pipelined launch (StepArgs::pipe_prog) runs the class's pipelined twin: the plain instances carry none of its code
+  if constexpr ((CL & (2 | 32)) == 0) {     // a pipelined launch (StepArgs::pipe_prog) runs the class's pipelined twin: the plain instances carry none of its code
     if (a.pipe_prog) return launch_lpe_class<KMAX, CL | 16, ML>(w, a, lds_bytes, lpe, prof);
   }
   return launch_lpe_class<KMAX, CL, ML>(w, a, lds_bytes, lpe, prof);
@@ -417,6 +417,12 @@ int do_integrate(rsb_world* w, int nsub) {
     rsb::set_error("integration schemes other than SEMI_IMPLICIT: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange and with one contact per primitive");
     return RSB_E_UNSUPPORTED;
   }
+  // the classical Coulomb slip rule (rsb_set_slip_rule): a kernel class of its own (bit 32), built for the quadruped-sized models
+  const bool coul = w->slip_rule == RSB_SLIP_COULOMB;
+  if (coul && (w->blob.fixed_base || peer || th || w->blob.depth - 1 > 4 || kcap != 8 || ((w->hm_contacts >= 2 || (w->hm_capsule && w->n_cap > 0)) && w->terrain_type == 1))) {
+    rsb::set_error("RSB_SLIP_COULOMB: built for floating-base systems of tree depth <= 5 with <= 8 contact slots, the default integration scheme, one contact per primitive, no peer-mapped obs exchange");
+    return RSB_E_UNSUPPORTED;
+  }
   const bool hm2 = (w->hm_contacts >= 2 || (w->hm_capsule && w->n_cap > 0)) && w->terrain_type == 1;   // class-4 kernels: more than one contact per primitive against a height map
   if (hm2 && (w->blob.fixed_base || peer || w->blob.depth - 1 > 12)) {
     rsb::set_error("two contacts per primitive against a height map: built for floating-base systems of tree depth <= 13 without the peer-mapped obs exchange");
@@ -484,7 +490,7 @@ int do_integrate(rsb_world* w, int nsub) {
   // action stage's rows (closed loop), which therefore must all be running or done (no deadlock: a waiting workgroup never keeps a
   // predecessor off the chip).  rsb_pipeline.hip holds the bookkeeping.
   hipStream_t ls = nullptr;
-  const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask;
+  const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask && !coul;      // (the Coulomb class has no pipelined twin)
   if (pipelined) {
     const int blocks = (w->N + (64 / lpe) - 1) / (64 / lpe);
     st = pipe_begin_launch(w, a, blocks, closed_loop, &ls);
@@ -508,6 +514,7 @@ int do_integrate(rsb_world* w, int nsub) {
   const int mlv = w->blob.depth - 1;
   if (mlv <= 4) {
     if (w->blob.fixed_base) st = kcap == 8 ? launch_lpe<8, 1, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 1, 4>(w, a, lds_bytes, lpe, prof);
+    else if (coul) st = launch_lpe<8, 32, 4>(w, a, lds_bytes, lpe, prof);
     else if (hm2) st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe, prof);
     else if (th) st = kcap == 8 ? launch_lpe<8, 8, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 8, 4>(w, a, lds_bytes, lpe, prof);
     else if (peer) st = kcap == 8 ? launch_lpe<8, 2, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 2, 4>(w, a, lds_bytes, lpe, prof);
@@ -808,6 +815,11 @@ int rsb_set_capsule_contacts(rsb_world* w, int on) {
     }
   }
   w->hm_capsule = on != 0;
+  return RSB_OK;
+}
+int rsb_set_slip_rule(rsb_world* w, int rule) {
+  if (!w || (rule != RSB_SLIP_ENERGY && rule != RSB_SLIP_COULOMB)) { rsb::set_error("rsb_set_slip_rule: RSB_SLIP_ENERGY or RSB_SLIP_COULOMB"); return RSB_E_INVALID; }
+  w->slip_rule = rule;
   return RSB_OK;
 }
 int rsb_set_integration_scheme(rsb_world* w, int scheme) {

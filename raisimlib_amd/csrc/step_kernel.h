@@ -235,21 +235,33 @@ __device__ __forceinline__ void terrain_eval(const Args& a, const float* heights
 }
 // closest point bp (relative to the centre (x, y, z)) on a triangle with face normal bn -> penetration depth and unit contact
 // normal; a centre at / below the surface or beyond the map's border falls back to the plane of the triangle under it
+// Round 5: "the centre is outside the terrain" is decided by the HEIGHT FIELD (z above the surface at (x, y)), read from the slot's own patch of
+// corner heights (LDS: the patch always holds the cell under the clamped centre) - not by the plane of the triangle that holds the closest point,
+// which past a convex edge sharper than the sphere is close answered with the wrong feature (oracle: terrain_contact_ex, above_test; VERDICT r04 #4a).
 template <class Args>
-__device__ __forceinline__ bool hm_resolve(const Args& a, const float* heights, const float* bp, const float* bn, float x, float y, float z, float r,
+__device__ __forceinline__ bool hm_resolve(const Args& a, const float* patch, int ix0, int iy0, const float* bp, float x, float y, float z, float r,
                                            float& depth, float* n) {
   const float dist = sqrtf(dot3(bp, bp));
   const bool inside = (x >= a.hm_x0) & (x <= a.hm_x0 + a.hm_dx * (float)(a.hm_xs - 1)) & (y >= a.hm_y0) & (y <= a.hm_y0 + a.hm_dy * (float)(a.hm_ys - 1));
-  const bool feature = inside & (-dot3(bp, bn) > 0.f) & (dist > 1e-9f);   // (returned: the contact is the closest feature's, not the fallback's)
-  if (feature) {
-    const float id = 1.0f / dist;
-    RSB_UNROLL for (int i = 0; i < 3; ++i) n[i] = -bp[i] * id;
-    depth = r - dist;
-  } else {
-    float h;
-    terrain_eval(a, heights, x, y, h, n);
-    depth = r - (z - h) * n[2];
-  }
+  // height and unit normal of the triangle under (x, y), coordinates clamped to the map (oracle: orc_terrain), from the patch
+  float gx = (x - a.hm_x0) * a.hm_inv_dx, gy = (y - a.hm_y0) * a.hm_inv_dy;
+  gx = fminf(fmaxf(gx, 0.f), (float)(a.hm_xs - 1));
+  gy = fminf(fmaxf(gy, 0.f), (float)(a.hm_ys - 1));
+  const int ix = min((int)floorf(gx), a.hm_xs - 2), iy = min((int)floorf(gy), a.hm_ys - 2);
+  const float fx = gx - (float)ix, fy = gy - (float)iy;
+  const float* H = patch + 4 * min(max(iy - iy0, 0), 2) + min(max(ix - ix0, 0), 2);
+  const float h00 = H[0], h10 = H[1], h01 = H[4], h11 = H[5];
+  const bool lower = fx >= fy;
+  const float sx = lower ? h10 - h00 : h11 - h01, sy = lower ? h11 - h10 : h01 - h00;
+  const float h = h00 + sx * fx + sy * fy;
+  const float gxs = sx * a.hm_inv_dx, gys = sy * a.hm_inv_dy;
+  const float inv = 1.0f / sqrtf(gxs * gxs + gys * gys + 1.0f);
+  const bool feature = inside & (z > h) & (dist > 1e-9f);   // (returned: the contact is the closest feature's, not the fallback's)
+  const float id = 1.0f / fmaxf(dist, 1e-30f);
+  n[0] = feature ? -bp[0] * id : -gxs * inv;
+  n[1] = feature ? -bp[1] * id : -gys * inv;
+  n[2] = feature ? -bp[2] * id : inv;
+  depth = feature ? r - dist : r - (z - h) * inv;
   return feature;
 }
 
@@ -327,23 +339,31 @@ __device__ __forceinline__ float slip_E(const SlipCoef& k, float mu, float x, fl
 }
 // (bx, by): any positive multiple of the round-0 best direction; where the curve has no point (den <= 0) the
 // minimiser lies on that direction's side of the candidate (the infeasible arc is contiguous and < 180 deg)
-__device__ __forceinline__ float slip_dE(const SlipCoef& k, float x, float y, float bx, float by) {
+// coul (the class-32 kernels, rsb_set_slip_rule; everywhere else the compile-time constant false: the energy rule's instructions are what they were):
+// the CLASSICAL COULOMB rule looks for the root of  P(theta) = N x d  (slip velocity parallel to the impulse direction) instead of the root of
+// dE/dtheta - the same formulas with (den, a0, mdp) replaced by (1, 1, 0)  (oracle: slip_coef::coul)
+__device__ __forceinline__ float slip_dE(const SlipCoef& k, float x, float y, float bx, float by, bool coul = false) {
   const float den = k.a0 + k.a1 * x + k.a2 * y;
   const float mdp = k.a2 * x - k.a1 * y;
   const float N0 = k.n00 + k.n01 * x + k.n02 * y, N1 = k.n10 + k.n11 * x + k.n12 * y;
-  const float h = den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
+  const float h = coul ? (N1 * x - N0 * y) : den * (N1 * x - N0 * y) - mdp * (N0 * x + N1 * y);
   return (den > kDenMin * k.a0) ? h : ((bx * y - by * x > 0.f) ? 1.f : -1.f);
 }
 // Newton step of h(theta) = slip_dE at the unit direction (x0, y0) (oracle: slip_newton_step): dtheta and h'
-__device__ __forceinline__ float slip_newton_step(const SlipCoef& k, float x0, float y0, float& hp) {
+__device__ __forceinline__ float slip_newton_step(const SlipCoef& k, float x0, float y0, float& hp, bool coul = false) {
   const float den = k.a0 + k.a1 * x0 + k.a2 * y0;
   const float mdp = k.a2 * x0 - k.a1 * y0;
   const float N0 = k.n00 + k.n01 * x0 + k.n02 * y0, N1 = k.n10 + k.n11 * x0 + k.n12 * y0;
   const float dN0 = k.n02 * x0 - k.n01 * y0, dN1 = k.n12 * x0 - k.n11 * y0;
   const float P = N1 * x0 - N0 * y0, Q = N0 * x0 + N1 * y0;
-  const float h = den * P - mdp * Q;
-  hp = den * (dN1 * x0 - dN0 * y0) - k.a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
+  const float h = coul ? P : den * P - mdp * Q;
+  hp = coul ? (dN1 * x0 - dN0 * y0) - Q : den * (dN1 * x0 - dN0 * y0) - k.a0 * Q - mdp * (dN0 * x0 + dN1 * y0);
   return -h * __builtin_amdgcn_rcpf(hp);
+}
+// P = N x d and Q = N . d at a unit direction (the Coulomb rule's residual and the sign of the slip along the impulse; oracle: slip_PQ)
+__device__ __forceinline__ void slip_PQ(const SlipCoef& k, float x, float y, float& P, float& Q) {
+  const float N0 = k.n00 + k.n01 * x + k.n02 * y, N1 = k.n10 + k.n11 * x + k.n12 * y;
+  P = N1 * x - N0 * y; Q = N0 * x + N1 * y;
 }
 // (x0, y0) rotated by the small angle d (oracle: slip_rotate), renormalised
 __device__ __forceinline__ void slip_rotate(float x0, float y0, float d, float& x1, float& y1) {
@@ -356,14 +376,21 @@ __device__ __forceinline__ void slip_rotate(float x0, float y0, float d, float& 
 // One guarded Newton step from the direction (x0, y0) of an earlier slip solve of the same contact (oracle:
 // slip_newton).  Branch-free: every lane runs it on its own contact, the result says whether the step is a safe
 // descent step (else the caller runs the cooperative global search).
+template <bool COUL = false>
 __device__ __forceinline__ bool slip_newton(const SlipCoef& k, float mu, float x0, float y0, float& x1, float& y1, float& step) {
   float hp;
-  const float d = slip_newton_step(k, x0, y0, hp);
+  const float d = slip_newton_step(k, x0, y0, hp, COUL);
   float x, y;
   slip_rotate(x0, y0, d, x, y);
   bool ok = (k.a0 + k.a1 * x0 + k.a2 * y0 > kDenNewton * k.a0) && (hp > 0.f) && (fabsf(d) <= 0.25f) &&
             (k.a0 + k.a1 * x + k.a2 * y > kDenNewton * k.a0);
-  if (__any(ok && fabsf(d) > 0.02f)) ok = ok && (fabsf(d) <= 0.02f || slip_E(k, mu, x, y) <= slip_E(k, mu, x0, y0));
+  if constexpr (COUL) {      // Coulomb: the slip opposes the impulse at the new direction, and a large step reduces the residual (oracle: slip_newton)
+    float P0, Q0, P1, Q1;
+    slip_PQ(k, x0, y0, P0, Q0); slip_PQ(k, x, y, P1, Q1);
+    ok = ok && (Q1 < 0.f) && (fabsf(d) <= 0.02f || fabsf(P1) <= fabsf(P0));
+  } else {
+    if (__any(ok && fabsf(d) > 0.02f)) ok = ok && (fabsf(d) <= 0.02f || slip_E(k, mu, x, y) <= slip_E(k, mu, x0, y0));
+  }
   x1 = x; y1 = y; step = d;
   return ok;
 }
@@ -458,23 +485,45 @@ __device__ constexpr float kSin16[16] = {0.0f, 0.38268343236508977f, 0.707106781
 // BR16[k] = {dir(k-1), dir(k+1)} as a float4 in LDS (the bracket around grid point k).  Bracket ends stay
 // un-normalised chord points between rounds (as in the oracle); candidates are normalised.  After the section
 // rounds every lane polishes the bracket midpoint by two clamped Newton steps (oracle: ORC_POLISH_STEPS).
-template <int LPE>
+template <int LPE, bool COUL = false>
 __device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int rounds, int s, int el, float c16, float s16,
                                             const float* BR16, float* dir) {
   const int k = s & 15;
   const float e0 = slip_E(kf, mu, c16, s16);
   const unsigned key = (__float_as_uint(e0) & ~15u) | (unsigned)k;
-  const int kbest = (int)(row_min_u32(key) & 15u);
+  int kbest = (int)(row_min_u32(key) & 15u);
   float br[4];
   ld4(BR16 + 4 * kbest, br);
   float lox = br[0], loy = br[1], hix = br[2], hiy = br[3];
+  bool coul = false;
+  if constexpr (COUL) {
+    // the Coulomb root (oracle: solve_one_contact, "coulomb"): lane k looks at the interval [k, k + 1] of the 22.5 deg grid - both ends on the curve,
+    // P crossing upwards, the slip opposing the impulse at both ends; of several such intervals the one whose lower end has the least energy;
+    // none: the energy rule's search for this solve (coul stays false)
+    float b1[4];
+    ld4(BR16 + 4 * k, b1);                                 // BR16[k] = {dir(k - 1), dir(k + 1)}
+    const float c1 = b1[2], s1 = b1[3];
+    float P0, Q0, P1, Q1;
+    slip_PQ(kf, c16, s16, P0, Q0); slip_PQ(kf, c1, s1, P1, Q1);
+    const bool cross = (kf.a0 + kf.a1 * c16 + kf.a2 * s16 > kDenMin * kf.a0) && (kf.a0 + kf.a1 * c1 + kf.a2 * s1 > kDenMin * kf.a0) &&
+                       (P0 < 0.f) && (P1 >= 0.f) && (Q0 < 0.f) && (Q1 < 0.f);
+    const unsigned kc = row_min_u32(cross ? key : 0xffffffffu);
+    coul = kc != 0xffffffffu;
+    if (coul) {
+      kbest = (int)(kc & 15u);
+      float bl[4], bh[4];
+      ld4(BR16 + 4 * ((kbest + 1) & 15), bl);              // .lo = dir(kbest)
+      ld4(BR16 + 4 * kbest, bh);                           // .hi = dir(kbest + 1)
+      lox = bl[0]; loy = bl[1]; hix = bh[2]; hiy = bh[3];
+    }
+  }
   const float bx = lox + hix, by = loy + hiy;
   const float t = (float)((k < 15 ? k : 14) + 1) * (1.0f / 16.0f);
   for (int r = 0; r < rounds; ++r) {
     const float ex = hix - lox, ey = hiy - loy;
     float cx = lox + t * ex, cy = loy + t * ey;
     const float inv = __builtin_amdgcn_rsqf(cx * cx + cy * cy);
-    const float h = slip_dE(kf, cx * inv, cy * inv, bx, by);
+    const float h = slip_dE(kf, cx * inv, cy * inv, bx, by, COUL && coul);
     const unsigned long long bal = __ballot(h >= 0.f && k < 15);
     // every 16-lane row of the group holds the same candidates; use the group's first row
     const unsigned gm = (unsigned)(bal >> (el * LPE)) & 0x7fffu;
@@ -490,7 +539,7 @@ __device__ __forceinline__ void slip_search(const SlipCoef& kf, float mu, int ro
   float x = mx * im, y = my * im;
   RSB_UNROLL for (int r = 0; r < kPolishSteps; ++r) {
     float hp;
-    float d = slip_newton_step(kf, x, y, hp);
+    float d = slip_newton_step(kf, x, y, hp, COUL && coul);
     d = (hp > 0.f) ? d : 0.f;
     d = fminf(fmaxf(d, -w), w);
     slip_rotate(x, y, d, x, y);
@@ -594,6 +643,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   long long t_entry = 0; if (PROF) t_entry = clock64();
   constexpr int EPW = 64 / LPE;
   constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0, HM2 = (CL & 4) != 0, TH = (CL & 8) != 0, PIPE = (CL & 16) != 0;
+  constexpr bool COUL = (CL & 32) != 0;   // classical Coulomb slip rule (rsb_set_slip_rule) instead of the published least-energy point
   constexpr bool TRI = KMAX > 8;    // packed lower-triangular Delassus blocks (see tri_off); the quadruped classes keep the square layout
   const int lane = threadIdx.x;
   const int el = lane / LPE;
@@ -1049,7 +1099,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
         kmin = min(kmin, (unsigned)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x4E, 0xf, 0xf, false));            // quad_perm [2,3,0,1]
         if (valid && key == kmin) {     // the scan position makes the keys of a quad distinct
           float o4[4];
-          const bool feature = hm_resolve(ac, env_heights, bp, bn, R[0], R[1], R[2], R[3], o4[0], o4 + 1);
+          const bool feature = hm_resolve(ac, rec + 12, ix0, iy0, bp, R[0], R[1], R[2], R[3], o4[0], o4 + 1);
           st4(RES + 4 * k, o4);
           if constexpr (HM2) { const float f4[4] = {(feature && o4[0] > 0.f) ? 1.f : 0.f, 0.f, 0.f, 1.f}; st4(RES2 + 4 * k, f4); }
         }
@@ -2081,7 +2131,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
           kb.a0 = c12[0]; kb.a1 = c12[1]; kb.a2 = c12[2]; kb.n00 = c12[3]; kb.n01 = c12[4]; kb.n02 = c12[5];
           kb.n10 = c12[6]; kb.n11 = c12[7]; kb.n12 = c12[8]; kb.vn = c12[9]; kb.ls0 = c12[10]; kb.ls1 = c12[11];
           float dxy[2];
-          slip_search<LPE>(kb, c12[12], section_rounds, s, el, c16, s16, DIR16, dxy);
+          slip_search<LPE, COUL>(kb, c12[12], section_rounds, s, el, c16, s16, DIR16, dxy);
           if (take) { sdx = dxy[0]; sdy = dxy[1]; sdst = 1; }
         };
 
@@ -2142,8 +2192,8 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
               // one guarded Newton step on every lane (the common case; lanes without a candidate ignore the result)
               if (PROF && a.prof) ++p_newton;
               float nx, ny, dstep;
-              bool ok = slip_newton(kc, mu, sdx, sdy, nx, ny, dstep) & need & (sdst != 0) & (refine != 0);
-              if (it == 0) {
+              bool ok = slip_newton<COUL>(kc, mu, sdx, sdy, nx, ny, dstep) & need & (sdst != 0) & (refine != 0);
+              if (it == 0 && !COUL) {      // (Coulomb: an inherited direction was a root of the previous step's problem - no basin to check)
                 const bool chk = ok & (sdst == 3);
                 if (__any(chk)) {
                   // basin check (oracle: "basin check"): a direction inherited from the previous integrate() may sit in the

@@ -228,6 +228,12 @@ class BatchedWorld:
         code = {"trapezoid": 0, "semi_implicit": 1, "euler": 2, "runge_kutta_4": 3}[scheme] if isinstance(scheme, str) else int(scheme)
         check(self.L.rsb_set_integration_scheme(self.handle, code), "rsb_set_integration_scheme")
 
+    def set_slip_rule(self, rule="energy"):
+        """Slip rule of the per-contact iteration: "energy" (default: the published least-energy point) or "coulomb" (slip velocity anti-parallel to the
+        friction impulse; a kernel class of its own, see rsb_set_slip_rule in include/rsb.h)."""
+        code = {"energy": 0, "coulomb": 1}[rule] if isinstance(rule, str) else int(rule)
+        check(self.L.rsb_set_slip_rule(self.handle, code), "rsb_set_slip_rule")
+
     def set_heightmap_contacts(self, per_primitive=2, min_angle_deg=45.0):
         """Contacts per collision primitive against a height map (1 = closest feature; 2 = also a second flank's; see rsb.h)."""
         check(self.L.rsb_set_heightmap_contacts(self.handle, int(per_primitive), float(min_angle_deg)), "rsb_set_heightmap_contacts")

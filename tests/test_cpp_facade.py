@@ -61,7 +61,7 @@ def test_eigen_typed_boundary_compiles_and_its_host_part_runs(built_lib):
 @pytest.mark.gpu
 def test_eigen_typed_environment_runs_on_gpu(built_lib):
     """... and on the GPU: VectorizedEnvironment<ENVIRONMENT> over the Eigen-typed environment == the device-resident env with the same
-    termination rule (by body: feet and knees sit on the shanks), 64 envs x 30 control steps with resets, one launch per control step"""
+    termination rule (by body: feet and knees sit on the shanks), 64 envs x 80 control steps with resets, one launch per control step"""
     compile_eigen_facade()
     r = subprocess.run([EIGEN_BIN, URDF], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "facade_eigen_test OK" in r.stdout and "equal to the device-resident env" in r.stdout, r.stdout + r.stderr

@@ -204,6 +204,29 @@ def test_sphere_beside_a_ridge_touches_the_edge_not_the_flank(built_lib):
     w.close()
 
 
+def test_sphere_just_past_a_sharp_convex_ridge_touches_the_ridge(built_lib):
+    """VERDICT r04 #4a on the device (oracle KAT of the same name): the centre is above the surface but below the extended plane of the flank it has
+    just left - the closest feature, the ridge line, is the contact (rounds 1-4: the plane of the face under the centre, twice the depth, a normal
+    pointing sideways); a centre below the surface still falls back to the face under it."""
+    from test_oracle_kat import sharp_ridge_map
+    r = 0.15
+    _, w = world(sphere_urdf(2.0, r))
+    w.add_height_map(*sharp_ridge_map())
+    w.set_state(tile([2.05, 2.1, 1.1, 1, 0, 0, 0]), tile(np.zeros(6)))
+    w.integrate(1)
+    cnt, con = w.get_contacts()
+    d = np.hypot(0.05, 0.1)
+    assert (cnt == 1).all()
+    for e in (0, 17, 63):
+        assert abs(con[e][0]["depth"] - (r - d)) < 2e-6 and np.allclose(con[e][0]["normal"], np.array([0.05, 0.0, 0.1]) / d, atol=3e-6)
+    nz = 1.0 / np.sqrt(17.0)
+    w.set_state(tile([2.05, 2.1, 0.75, 1, 0, 0, 0]), tile(np.zeros(6)))
+    w.integrate(1)
+    cnt, con = w.get_contacts()
+    assert (cnt == 1).all() and abs(con[9][0]["depth"] - (r + 0.05 * nz)) < 3e-6 and np.allclose(con[9][0]["normal"], [4 * nz, 0, nz], atol=3e-6)
+    w.close()
+
+
 def test_fixed_base_pendulum_period(built_lib):
     from test_oracle_kat import FIXED_PENDULUM
     l = 0.5

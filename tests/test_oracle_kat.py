@@ -284,6 +284,40 @@ def ridge_map():
     return (5, 5, 4.0, 4.0, 2.0, 2.0, h)
 
 
+def sharp_ridge_map():
+    """17 x 17 samples over 4 m x 4 m (0.25 m cells) centred on (2, 2): a tent ridge of height 1 along y at x = 2 whose flanks have slope 4"""
+    xs = np.linspace(0.0, 4.0, 17)
+    prof = np.maximum(0.0, 1.0 - 4.0 * np.abs(xs - 2.0))
+    return (17, 17, 4.0, 4.0, 2.0, 2.0, np.tile(prof[None, :], (17, 1)).astype(np.float32))
+
+
+def test_sphere_just_past_a_sharp_convex_ridge_touches_the_ridge(built_lib):
+    """VERDICT r04 #4a.  A ridge sharper than the sphere is close (flank slope 4): the centre sits 0.05 m past the crest and 0.1 m above it - above
+    the surface, but BELOW the extended plane of the flank it has just left (1 + 4 * 0.05 = 1.2 > 1.1).  The closest feature is the ridge line:
+    distance sqrt(0.05^2 + 0.1^2), normal along (0.05, 0, 0.1).  Rounds 1-4 decided "outside the terrain" by the plane of the triangle that holds
+    the closest point - the far flank's, scanned first - and fell back to the plane of the face under the centre: twice the depth and a normal
+    that points sideways (kept as orc_params::hm_plane_test = 1 to show it).  Since round 5 the height field itself decides, as the capsule search's
+    samples always did."""
+    r = 0.15
+    _, o = make(sphere_urdf(2.0, r))
+    o.set_heightmap(*sharp_ridge_map())
+    q = np.array([2.05, 2.1, 1.1, 1, 0, 0, 0.0])
+    _, _, con, _, _ = o.step(q, np.zeros(6))
+    d = np.hypot(0.05, 0.1)
+    assert len(con) == 1 and abs(con["depth"][0] - (r - d)) < 1e-7
+    assert np.allclose(con["normal"][0], np.array([0.05, 0.0, 0.1]) / d, atol=1e-6)
+    o.p.hm_plane_test = 1
+    _, _, old, _, _ = o.step(q, np.zeros(6))
+    nz = 1.0 / np.sqrt(17.0)
+    assert len(old) == 1 and abs(old["depth"][0] - (r - (1.1 - 0.8) * nz)) < 1e-6 and np.allclose(old["normal"][0], [4 * nz, 0, nz], atol=1e-6)
+    assert old["depth"][0] > 1.9 * con["depth"][0]
+    o.p.hm_plane_test = 0
+    # a centre BELOW the surface still falls back to the face under it (a zero-radius box corner, a sphere pushed in by more than its radius)
+    q = np.array([2.05, 2.1, 0.75, 1, 0, 0, 0.0])
+    _, _, con, _, _ = o.step(q, np.zeros(6))
+    assert len(con) == 1 and abs(con["depth"][0] - (r + 0.05 * nz)) < 1e-6 and np.allclose(con["normal"][0], [4 * nz, 0, nz], atol=1e-6)
+
+
 def test_sphere_beside_a_ridge_touches_the_edge_not_the_flank(built_lib):
     """Closest-feature narrow phase: the centre sits 0.1 m beside the crest and 0.25 m above it; the foot of the perpendicular
     onto the flank under the centre lies beyond the crest, so the closest feature is the ridge EDGE: distance
