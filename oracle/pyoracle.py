@@ -41,6 +41,7 @@ class Params(C.Structure):
         ("hm_capsule", C.c_int32),
         ("hm_plane_test", C.c_int32),
         ("slip_rule", C.c_int32),
+        ("pair_inner", C.c_int32),
     ]
 
 

@@ -479,6 +479,8 @@ void orc_momentum(const rsb_model_blob* m, const double* q, const double* u, dou
   free(k);
 }
 
+long orc_pair_evals = 0;   /* EXPERIMENT orc_params::pair_inner: one-contact rule evaluations spent inside joint pair solves (not thread safe: statistics of single-threaded runs) */
+
 /* ------------------------------------------------------------------------------ terrain */
 void orc_terrain(const orc_params* p, double x, double y, double* h, double* n) {
   if (p->terrain_type == 0) { *h = p->ground_z; n[0] = 0; n[1] = 0; n[2] = 1; return; }
@@ -1598,7 +1600,8 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
           }
         }
         double lamS[MAXK][3];
-        for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lamS[i][r] = lam[i][r];
+        int pair_done[MAXK];
+        for (int i = 0; i < nc; ++i) { pair_done[i] = 0; for (int r = 0; r < 3; ++r) lamS[i][r] = lam[i][r]; }
         for (int kpos = 0; kpos < gdepth; ++kpos) {
           double lam0[MAXK][3];
           for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam0[i][r] = lam[i][r];
@@ -1607,6 +1610,43 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
           for (int i = 0; i < nc; ++i) {
             if (gpos[i] != kpos && !(light && kpos == 0)) continue;
             if (body_done[i]) continue;     /* its body took the all-stick solution in this sweep */
+            if (pair_done[i]) continue;     /* EXPERIMENT orc_params::pair_inner: solved together with its partner on the same link */
+            if (p->pair_inner > 0 && !light && gpos[i] == kpos && i < nreal && cbody2[i] < 0) {
+              int j = -1;
+              for (int c2 = i + 1; c2 < nreal; ++c2)
+                if (gid[c2] == gid[i] && gpos[c2] == kpos + 1 && cbody[c2] == cbody[i] && cbody2[c2] < 0 && !body_done[c2]) { j = c2; break; }
+              if (j >= 0) {
+                double vi0[3] = {cfree[i][0], cfree[i][1], cfree[i][2]}, vj0[3] = {cfree[j][0], cfree[j][1], cfree[j][2]};
+                for (int m2 = 0; m2 < nc; ++m2) {
+                  if (m2 == i || m2 == j) continue;
+                  for (int r = 0; r < 3; ++r) {
+                    vi0[r] += G[i][m2][3 * r] * lam0[m2][0] + G[i][m2][3 * r + 1] * lam0[m2][1] + G[i][m2][3 * r + 2] * lam0[m2][2];
+                    vj0[r] += G[j][m2][3 * r] * lam0[m2][0] + G[j][m2][3 * r + 1] * lam0[m2][1] + G[j][m2][3 * r + 2] * lam0[m2][2];
+                  }
+                }
+                double li[3] = {lam0[i][0], lam0[i][1], lam0[i][2]}, lj[3] = {lam0[j][0], lam0[j][1], lam0[j][2]};
+                for (int t = 0; t < p->pair_inner; ++t) {
+                  double v[3], ln[3], ch = 0.0;
+                  for (int r = 0; r < 3; ++r) v[r] = vi0[r] + G[i][j][3 * r] * lj[0] + G[i][j][3 * r + 1] * lj[1] + G[i][j][3 * r + 2] * lj[2];
+                  solve_one_contact(G[i][i], Ginv[i], v, cmu[i], p->section_rounds, lag, p->refine, 0.0, sdir[i], ln, p->slip_rule);
+                  for (int r = 0; r < 3; ++r) { const double d = alpha * (ln[r] - li[r]); li[r] += d; if (fabs(d) > ch) ch = fabs(d); }
+                  for (int r = 0; r < 3; ++r) v[r] = vj0[r] + G[j][i][3 * r] * li[0] + G[j][i][3 * r + 1] * li[1] + G[j][i][3 * r + 2] * li[2];
+                  solve_one_contact(G[j][j], Ginv[j], v, cmu[j], p->section_rounds, lag, p->refine, 0.0, sdir[j], ln, p->slip_rule);
+                  for (int r = 0; r < 3; ++r) { const double d = alpha * (ln[r] - lj[r]); lj[r] += d; if (fabs(d) > ch) ch = fabs(d); }
+                  orc_pair_evals += 2;
+                  double sc = li[2] > lj[2] ? li[2] : lj[2];
+                  if (ch <= 1e-3 * p->threshold * (sc + ORC_LAMBDA_FLOOR)) break;
+                }
+                for (int r = 0; r < 3; ++r) {
+                  const double di = li[r] - lam0[i][r], dj = lj[r] - lam0[j][r];
+                  lam[i][r] = li[r]; lam[j][r] = lj[r];
+                  if (fabs(di) > err) err = fabs(di);
+                  if (fabs(dj) > err) err = fabs(dj);
+                }
+                pair_done[j] = 1;
+                continue;
+              }
+            }
             double v[3] = {cfree[i][0], cfree[i][1], cfree[i][2]}, ln[3];
             for (int j = 0; j < nc; ++j) {
               if (j == i) continue;

@@ -114,6 +114,13 @@ typedef struct orc_params {
    * the contact's Delassus block does not couple with the tangential ones (a sphere on flat ground); on a quadruped's foot they differ by 29 % of the
    * impulse (p50; DESIGN.md section 2, tests/test_oracle_independent.py).  See solve_one_contact. */
   int32_t slip_rule;
+  /* EXPERIMENT (round 5; default 0 = off, never adopted on the device - profiles/r05_pair_solve.txt): the joint rule for two contacts
+   * on ONE link (knee + foot sphere of a shank: a rank-5 6 x 6 block on which the two friction directions chase each other).  With pair_inner = K > 0
+   * the first of such a pair, when its pass comes, solves BOTH contacts together - the one-contact rule applied alternately to the two, against
+   * each other's newest impulse and everybody else's impulses of the pass's start, until neither moves by more than 1e-3 of the convergence
+   * threshold or K rounds are up -; the partner is skipped in its own pass.  Same fixed points as the plain iteration. *pair_evals (orc_step_debug
+   * statistics) counts the one-contact rule evaluations spent inside. */
+  int32_t pair_inner;
 } orc_params;
 #define ORC_SLIP_ENERGY 0
 #define ORC_SLIP_COULOMB 1
