@@ -72,7 +72,7 @@
 namespace raisim {
 
 namespace IntegrationScheme {
-enum Type : int { TRAPEZOID = 0, SEMI_IMPLICIT = 1, EULER = 2, RUNGE_KUTTA_4 = 3 };   // RUNGE_KUTTA_4 is refused (rsb_set_integration_scheme)
+enum Type : int { TRAPEZOID = 0, SEMI_IMPLICIT = 1, EULER = 2, RUNGE_KUTTA_4 = 3 };   // RUNGE_KUTTA_4: host-driven, four dynamics evaluations per integrate() (rsb_set_integration_scheme)
 }
 
 namespace ControlMode {

@@ -181,7 +181,12 @@ int rsb_set_slip_rule(rsb_world* w, int rule);
  *   RSB_INTEGRATION_SEMI_IMPLICIT (default, RaiSim's)  q+ = q (+) dt u+
  *   RSB_INTEGRATION_EULER                               q+ = q (+) dt u
  *   RSB_INTEGRATION_TRAPEZOID                           q+ = q (+) dt (u + u+) / 2     (exact positions under a constant acceleration)
- *   RSB_INTEGRATION_RUNGE_KUTTA_4                       RSB_E_UNSUPPORTED
+ *   RSB_INTEGRATION_RUNGE_KUTTA_4                       the classical four-stage scheme on the smooth equations of motion (explicit PD at the stage
+ *                                                       states, the base orientation advanced on SO(3)), contacts and joint limits on top of it as in the
+ *                                                       other schemes: one detection at q, one solve (rsb_rk4.hip states the construction).  Host-driven
+ *                                                       over the query kernels - four dynamics evaluations with a dense M^-1 per integrate(): the slow,
+ *                                                       accurate path; plain rsb_integrate / rsb_integrate_masked / World-view calls only
+ *                                                       (RSB_E_UNSUPPORTED from rsb_control_step / rsb_env_step)
  * (the enum values are raisim::IntegrationScheme's [RECALL]).  EULER and TRAPEZOID run in a kernel class of their own (floating-base systems
  * of tree depth <= 13, no peer-mapped obs exchange, one contact per primitive; RSB_E_UNSUPPORTED from the step otherwise): the default's
  * kernels do not carry the choice. */

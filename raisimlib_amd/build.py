@@ -31,6 +31,7 @@ HOST_SOURCES = {   # source -> headers it depends on
     "rsb_world.hip": _WORLD_DEPS + ["step_launch.h", "query_kernel.h", "env_task.h"],
     "rsb_pipeline.hip": _WORLD_DEPS,
     "rsb_comm.hip": _WORLD_DEPS,
+    "rsb_rk4.hip": _WORLD_DEPS,
 }
 KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", RSB_TYPES_H]
 # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and

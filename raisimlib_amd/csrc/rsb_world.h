@@ -81,6 +81,8 @@ struct rsb_world {
   int hm_contacts = 1; double hm_second_cos = 0.70710678118654752;                                        // rsb_set_heightmap_contacts
   bool hm_capsule = false; int32_t* d_cap = nullptr; int n_cap = 0;                                       // rsb_set_capsule_contacts: [n_cap][2] end primitives of the model's capsules / cylinders, (first corner, -1) of its boxes
   int slip_rule = 0;                                                                       // rsb_set_slip_rule (RSB_SLIP_ENERGY / RSB_SLIP_COULOMB)
+  bool integ_rk4 = false, rk4_inner = false;                                                // IntegrationScheme::RUNGE_KUTTA_4 (rsb_rk4.hip); rk4_inner: the scheme's own contact step is being launched
+  float* d_rk = nullptr;                                                                   // its scratch
   double integ_theta = 1.0;                                                                // rsb_set_integration_scheme
   // peer-mapped obs exchange (rsb_obs_peer_*).  ONE allocation per rank, the same layout on every rank:
   //   [gathered buffer, parity 0 | parity 1]  2 x n_ranks * N * obs_dim floats
@@ -173,7 +175,9 @@ int effective_lpe(const rsb_world* w);
 int check_lpe(const rsb_world* w, int lpe);
 int copy_in(rsb_world* w, float* dst, const float* src, size_t n, int space);
 int copy_out(rsb_world* w, void* dst, const void* src, size_t bytes, int space);
-int launch_env_obs(rsb_world* w, float* dst, hipStream_t s);     // the stand-alone env-task observation of the current state
+int launch_env_obs(rsb_world* w, float* dst, hipStream_t s);
+int launch_dynamics_query(rsb_world* w, hipStream_t s);           // M, h and M^-1 of the current state into d_M / d_h / d_Minv (the query kernels)
+int rk4_integrate(rsb_world* w, int nsub);                        // rsb_rk4.hip     // the stand-alone env-task observation of the current state
 // rsb_pipeline.hip
 hipStream_t stream_of(rsb_world* w);                              // the world's stream for any use other than a pipelined launch (joins first)
 int pipe_join(rsb_world* w);

@@ -325,6 +325,7 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
   auto put_i = [&](int off, int v) { std::memcpy(&img[off], &v, sizeof(int)); };
   for (int i = 0; i < b.nb; ++i) {
     for (int c = 0; c < rsbk::kModelSlot; ++c) img[L.t_model + i * rsbk::kModelSlot + c] = dm->bodyf[i][c];
+    if (w->rk4_inner) img[L.t_model + i * rsbk::kModelSlot + 28] = 0.f;      // (RUNGE_KUTTA_4's contact step: its generalized force carries inertial terms, the effort clip was applied in the stages)
     const bool pd = w->control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && i >= 1;
     img[L.t_gain + 2 * i] = pd ? w->h_kp[i + 5] : 0.f;
     img[L.t_gain + 2 * i + 1] = pd ? w->h_kd[i + 5] : 0.f;
@@ -383,6 +384,7 @@ int upload_image(rsb_world* w) {
 
 int do_integrate(rsb_world* w, int nsub) {
   HIP_TRY(hipSetDevice(w->device));
+  if (w->integ_rk4 && !w->rk4_inner) return rk4_integrate(w, nsub);      // IntegrationScheme::RUNGE_KUTTA_4: host-driven over the query kernels (rsb_rk4.hip)
   const int lpe = effective_lpe(w);
   int st = check_lpe(w, lpe);
   if (st != RSB_OK) return st;
@@ -553,6 +555,24 @@ int copy_out(rsb_world* w, void* dst, const void* src, size_t bytes, int space) 
   return RSB_OK;
 }
 
+int launch_dynamics_query(rsb_world* w, hipStream_t s) {
+  const size_t N = w->N, nv = w->blob.nv;
+  if (!w->d_M) {
+    HIP_TRY(hipMalloc(&w->d_M, N * nv * nv * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_h, N * nv * sizeof(float)));
+  }
+  if (!w->d_Minv) {
+    HIP_TRY(hipMalloc(&w->d_Minv, N * nv * nv * sizeof(float)));
+    HIP_TRY(hipMalloc(&w->d_Mwork, N * nv * nv * sizeof(float)));
+  }
+  rsbq::QueryArgs qa;
+  qa.model = w->d_model; qa.gc = w->d_gc; qa.gv = w->d_gv; qa.M = w->d_M; qa.h = w->d_h; qa.N = w->N;
+  qa.gx = (float)w->gravity[0]; qa.gy = (float)w->gravity[1]; qa.gz = (float)w->gravity[2];
+  if (rsbq::launch_query(qa, w->blob.nb, s) != 0) { rsb::set_error("RUNGE_KUTTA_4: query kernel launch failed"); return RSB_E_HIP; }
+  hipLaunchKernelGGL(rsbq::rsb_minv_kernel, dim3((w->N + 63) / 64), dim3(64), 0, s, w->d_M, w->d_Mwork, w->d_Minv, w->N, w->blob.nv);
+  HIP_TRY(hipGetLastError());
+  return RSB_OK;
+}
 int launch_env_obs(rsb_world* w, float* dst, hipStream_t s) {
   const int total = w->N * (10 + 2 * (w->blob.nv - 6));
   hipLaunchKernelGGL(env_obs_kernel, dim3((total + 255) / 256), dim3(256), 0, s, dst, w->d_gc, w->d_gv, w->N, w->blob.nq, w->blob.nv);
@@ -653,6 +673,7 @@ int rsb_destroy(rsb_world* w) {
   if (w->ev0) (void)hipEventDestroy(w->ev0);
   if (w->ev1) (void)hipEventDestroy(w->ev1);
   pipe_destroy(w);
+  if (w->d_rk) (void)hipFree(w->d_rk);
   if (w->d_env_act) (void)hipFree(w->d_env_act);
   if (w->d_env_gc0_rows) { (void)hipFree(w->d_env_gc0_rows); (void)hipFree(w->d_env_gv0_rows); }
   if (w->own_stream && w->stream) (void)hipStreamDestroy(w->stream);
@@ -824,11 +845,14 @@ int rsb_set_slip_rule(rsb_world* w, int rule) {
 }
 int rsb_set_integration_scheme(rsb_world* w, int scheme) {
   if (!w) return RSB_E_INVALID;
+  (void)stream_of(w);
+  const bool was_rk4 = w->integ_rk4;
+  w->integ_rk4 = false;
   if (scheme == RSB_INTEGRATION_SEMI_IMPLICIT) w->integ_theta = 1.0;
   else if (scheme == RSB_INTEGRATION_EULER) w->integ_theta = 0.0;
   else if (scheme == RSB_INTEGRATION_TRAPEZOID) w->integ_theta = 0.5;
-  else if (scheme == RSB_INTEGRATION_RUNGE_KUTTA_4) { rsb::set_error("rsb_set_integration_scheme: RUNGE_KUTTA_4 is not implemented (one dynamics evaluation and one contact solve per step)"); return RSB_E_UNSUPPORTED; }
-  else { rsb::set_error("rsb_set_integration_scheme: unknown scheme"); return RSB_E_INVALID; }
+  else if (scheme == RSB_INTEGRATION_RUNGE_KUTTA_4) { w->integ_theta = 1.0; w->integ_rk4 = true; }
+  else { w->integ_rk4 = was_rk4; rsb::set_error("rsb_set_integration_scheme: unknown scheme"); return RSB_E_INVALID; }
   return RSB_OK;
 }
 int rsb_set_early_termination(rsb_world* w, int on) {

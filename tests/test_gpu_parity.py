@@ -858,3 +858,81 @@ def test_capsule_cylinder_contacts_on_a_rough_map_parity(built_lib):
         pick = lambda m_: ({k: v[m_] for k, v in dev.items()}, {k: (v[m_] if isinstance(v, np.ndarray) and len(v) == len(m_) else v) for k, v in ref.items()})   # noqa: E731
         check_step(*pick(same), min_conv=0.75, both_converged=True, du_tol=5e-4)
         assert np.isfinite(dev["q"]).all() and np.isfinite(dev["u"]).all()
+
+
+def test_runge_kutta_4_step_against_an_fp64_restatement_over_the_oracles_queries(anymal):
+    """RUNGE_KUTTA_4 on the quadruped: (a) in the air (no contact) the device step equals the classical scheme written in numpy over the ORACLE's
+    M(q), h(q, u) and explicit PD torques, the base orientation advanced by the same Munthe-Kaas stages; (b) on the ground the velocity equals the
+    free Runge-Kutta increment plus what the contact solve adds - checked against the oracle's own one-evaluation step fed with the generalized
+    force that reproduces the increment (the construction rsb_rk4.hip states)."""
+    N = 64
+    o = Oracle(anymal.blob)
+    kp, kd = workload.anymal_gains()
+    kp64, kd64 = kp.astype(np.float64), kd.astype(np.float64)
+    dt = workload.DT
+
+    def quat_mul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+    def add(q0, th):
+        q = q0.copy()
+        q[:3] += th[:3]
+        ang = np.linalg.norm(th[3:6])
+        d = np.r_[np.cos(ang / 2), (np.sin(ang / 2) / ang if ang > 1e-12 else 0.5) * th[3:6]]
+        q[3:7] = quat_mul(d, q0[3:7]); q[3:7] /= np.linalg.norm(q[3:7])
+        q[7:] += th[6:]
+        return q
+
+    def accel(q, u, pt):
+        tau = np.zeros(18)
+        tau[6:] = kp64[6:] * (pt[7:] - q[7:]) + kd64[6:] * (0.0 - u[6:])
+        return np.linalg.solve(o.mass_matrix(q), tau - o.nonlinearities(q, u))
+
+    def rk4(q0, u0, pt):
+        ks, kv, th = [], [], np.zeros(18)
+        for i, c in enumerate((0.0, 0.5, 0.5, 1.0)):
+            th = c * dt * kv[-1] if i else np.zeros(18)
+            q = add(q0, th); u = u0 + (c * dt * ks[-1] if i else 0.0)
+            a = accel(q, u, pt)
+            v = u.copy()
+            t3 = th[3:6]
+            v[3:6] = u[3:6] - 0.5 * np.cross(t3, u[3:6]) + np.cross(t3, np.cross(t3, u[3:6])) / 12.0
+            ks.append(a); kv.append(v)
+        du = dt / 6 * (ks[0] + 2 * ks[1] + 2 * ks[2] + ks[3])
+        theta = dt / 6 * (kv[0] + 2 * kv[1] + 2 * kv[2] + kv[3])
+        return theta, du
+
+    gc, gv = standing_states(N, seed=77, z=(0.45, 0.62), vel=1.0)
+    for lift in (1.0, 0.0):                      # in the air / on the ground
+        g0 = f32(gc); g0[:, 2] += lift
+        u0 = f32(gv)
+        w = BatchedWorld(anymal, N)
+        w.set_integration_scheme("runge_kutta_4")
+        w.set_pd_gains(kp, kd); w.set_pd_target(g0, np.zeros((N, 18))); w.set_state(g0, u0)
+        w.integrate(1)
+        q1, u1 = w.get_state()
+        cnt, _ = w.get_contacts()
+        w.close()
+        if lift > 0:
+            assert cnt.sum() == 0
+            for e in range(0, N, 7):
+                theta, du = rk4(g0[e], u0[e], g0[e])
+                assert np.abs(u1[e] - (u0[e] + du)).max() < 3e-4 * (1 + np.abs(u0[e]).max()), e
+                assert np.abs(q1[e] - add(g0[e], theta)).max() < 5e-6, e
+        else:
+            assert (cnt > 0).mean() > 0.8
+            checked = 0
+            for e in range(0, N, 5):
+                theta, du = rk4(g0[e], u0[e], g0[e])
+                tau_eff = o.mass_matrix(g0[e]) @ du / dt + o.nonlinearities(g0[e], u0[e])
+                oo = Oracle(anymal.blob)
+                oo.p.control_mode = 0                          # FORCE_AND_TORQUE: the generalized force alone
+                r = oo.step_batch(g0[e][None], u0[e][None], 1, np.zeros(18), np.zeros(18), g0[e][None], np.zeros((1, 18)), tau_eff[None], lam_warm=None)
+                if r["flags"][0] & 4:
+                    continue
+                up = r["u"][0]
+                assert np.abs(u1[e] - up).max() < 2e-3 * (1 + np.abs(up).max()), e
+                assert np.abs(q1[e] - add(g0[e], theta + dt * (up - u0[e] - du))).max() < 2e-5, e
+                checked += 1
+            assert checked >= 8
