@@ -33,7 +33,10 @@ HOST_SOURCES = {   # source -> headers it depends on
     "rsb_comm.hip": _WORLD_DEPS,
     "rsb_rk4.hip": _WORLD_DEPS,
 }
-KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", RSB_TYPES_H]
+# the fused step kernel: the template's skeleton (step_kernel.h), its device helpers (step_math / step_terrain / step_slip .h) and its body, one
+# fragment per phase (step_phase_*.inc, included inside the kernel: same token stream as the one 2 500-line function of rounds 1-4)
+KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", "step_math.h", "step_terrain.h", "step_slip.h",
+               *sorted(f for f in os.listdir(CSRC) if f.startswith("step_phase_") and f.endswith(".inc")), RSB_TYPES_H]
 # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and
 # pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed at the stated parity tolerance
 # (2.5 ulp hardware approximations + Newton step instead)
