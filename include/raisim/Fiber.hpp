@@ -20,7 +20,7 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
-#if !defined(__x86_64__)
+#if !defined(__x86_64__) || defined(__SHSTK__)
 #include <ucontext.h>
 #endif
 
@@ -41,7 +41,10 @@
 namespace raisim {
 namespace detail {
 
-#if defined(__x86_64__)
+// The hand-written switch changes stacks with a jmp and later returns on the stack it was parked on: a CET shadow stack (-fcf-protection=return /
+// full with user-mode shadow stacks enabled) would fault on that return.  Where the compiler says shadow stacks are on (__SHSTK__) the portable
+// ucontext path below is used instead (it saves the shadow-stack pointer with the context).
+#if defined(__x86_64__) && !defined(__SHSTK__)
 /// A parked context is its stack pointer; the stack holds (from the pointer upwards) rbx, rbp and the address to continue at.
 struct FiberContext { void* sp = nullptr; };
 /// Saves the running context into `from`, continues `to`.  Every register the SysV ABI lets a callee keep is either saved on the
@@ -261,8 +264,10 @@ class FiberScheduler {
           int live = 0, parked = 0;
           roundFn_(t, live, parked);
           liveSum_ += live; parkedSum_ += parked;
-          reported_.fetch_add(1, std::memory_order_acq_rel);
-          if (mainSleeps_.load(std::memory_order_acquire)) { std::lock_guard<std::mutex> lk(poolMutex_); poolCv_.notify_all(); }
+          // (store-then-load across two variables: the worker's increment must be ordered before its look at mainSleeps_, and the main thread's
+          //  mainSleeps_ = true before its re-check of reported_ - sequential consistency on both sides, not acquire / release: ADVICE r04)
+          reported_.fetch_add(1, std::memory_order_seq_cst);
+          if (mainSleeps_.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(poolMutex_); poolCv_.notify_all(); }
         }
       });
       if (!cpus.empty()) {
@@ -293,8 +298,8 @@ class FiberScheduler {
   void awaitWorkers(int threads) {
     if (spinUntil([&] { return reported_.load(std::memory_order_acquire) == threads; })) return;
     std::unique_lock<std::mutex> lk(poolMutex_);
-    mainSleeps_.store(true);
-    poolCv_.wait(lk, [&] { return reported_.load() == threads; });
+    mainSleeps_.store(true, std::memory_order_seq_cst);
+    poolCv_.wait(lk, [&] { return reported_.load(std::memory_order_seq_cst) == threads; });
     mainSleeps_.store(false);
   }
   /// polls `ready` for up to ~200 us (RSB_FIBER_SPIN_US); false = not yet, the caller goes to sleep on the condition variable

@@ -75,6 +75,11 @@ def test_fiber_scheduler_and_yaml_parser_on_cpu():
                     os.path.join(ROOT, "tests", "cpp", "fiber_yaml_test.cpp")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "fiber_yaml_test OK" in r.stdout, r.stdout + r.stderr
+    # ... and on the portable ucontext path that a CET shadow-stack build selects (the hand-written switch returns on a foreign stack)
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-D__SHSTK__", "-I", os.path.join(ROOT, "include"), "-o", exe + "_ucontext",
+                    os.path.join(ROOT, "tests", "cpp", "fiber_yaml_test.cpp")], check=True)
+    r = subprocess.run([exe + "_ucontext"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "fiber_yaml_test OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_facade_host_side_against_the_c_abi_double():
