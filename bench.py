@@ -687,7 +687,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     # bench path) -, then the pipelined steps + gather on a side stream, which no hardware has run with N > 1 before the driver's scaling run,
     # under a guard (two_legs): if that leg raises on any rank, `value` is the first leg's.
     def timed(step_fn, drain_fn, k0):
-        if world_size > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -699,7 +699,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
         except Exception as e:      # (kept until this rank has been through the collectives below: the other ranks are in them)
             err = e
         t_enq = time.perf_counter() - t0       # host side done; the GPU may still be working
-        if world_size > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
@@ -709,7 +709,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
             err = err or e
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         by_rank = [el / args.steps * 1e3]
-        if world_size > 1:
+        if coll:
             every = torch.zeros(world_size, dtype=torch.float64, device=dev)
             dist.all_gather_into_tensor(every, t)
             by_rank = [float(x) / args.steps * 1e3 for x in every.cpu()]
@@ -767,10 +767,12 @@ def measure(args, rank, local_rank, world_size, dev, coll):
         kstep += args.steps
         return r
 
-    lockstep_first_wanted = world_size > 1 and pipelined
+    # (RSB_BENCH_TWO_LEGS=1 with --force-collective: the N > 1 order of legs on ONE rank - the only way this path meets a GPU before the driver's scaling run)
+    forced_two_legs = bool(os.environ.get("RSB_BENCH_TWO_LEGS")) and coll
+    lockstep_first_wanted = (world_size > 1 or forced_two_legs) and pipelined
 
     def all_agree(ok):
-        if world_size == 1:
+        if not coll:
             return ok
         f = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MIN)

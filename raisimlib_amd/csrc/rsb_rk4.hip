@@ -205,7 +205,10 @@ int rk4_integrate(rsb_world* w, int nsub) {
     const double theta_keep = w->integ_theta;
     w->control_mode = RSB_FORCE_AND_TORQUE; w->rk4_inner = true; w->integ_theta = 1.0; w->image_dirty = true;
     w->launch_mask = mask;
+    const bool tz = w->tff_zero;
+    w->tff_zero = false;          // (tau_eff lives in d_tff for this launch)
     int st = do_integrate(w, 1);
+    w->tff_zero = tz;
     w->control_mode = mode; w->rk4_inner = false; w->integ_theta = theta_keep; w->image_dirty = true;
     if (st != RSB_OK) return st;
     hipLaunchKernelGGL(rk4_position_kernel, dim3(blocks), dim3(64), 0, s, w->d_gc, w->d_gv, q0, u0, theta, du, mask, w->d_model, (int)N, (int)nq, (int)nv, (float)w->dt);

@@ -35,6 +35,7 @@ struct rsb_world {
   DevModel* d_model = nullptr;
   float *d_gc = nullptr, *d_gv = nullptr, *d_pt = nullptr, *d_dt = nullptr, *d_tff = nullptr;
   float *d_kp = nullptr, *d_kd = nullptr, *d_heights = nullptr;
+  bool dt_zero = true, tff_zero = true;   // d_dt / d_tff hold nothing but zeros (never written, or written with zeros from the host): the step kernel does not read them
   float *d_tmp_gc = nullptr, *d_tmp_gv = nullptr;
   uint8_t* d_tmp_mask = nullptr;
   float *d_M = nullptr, *d_h = nullptr, *d_Minv = nullptr, *d_Mwork = nullptr;

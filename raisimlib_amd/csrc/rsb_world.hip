@@ -393,6 +393,10 @@ int do_integrate(rsb_world* w, int nsub) {
   std::memset(&a, 0, sizeof a);
   a.model = w->d_model;
   a.gc = w->d_gc; a.gv = w->d_gv; a.ptarget = w->d_pt; a.dtarget = w->d_dt; a.tauff = w->d_tff;
+#ifndef RSB_X_READ_ZERO_ROWS      /* (A/B switch: read the rows although they are known to be zero, as rounds 1-4 did) */
+  if (w->dt_zero) a.dtarget = nullptr;
+  if (w->tff_zero) a.tauff = nullptr;
+#endif
   a.kp = w->d_kp; a.kd = w->d_kd;
   a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
   a.heights = w->d_heights;
@@ -541,6 +545,12 @@ int do_integrate(rsb_world* w, int nsub) {
   return RSB_OK;
 }
 
+// does a field the caller uploads hold nothing but zeros?  (host data: looked at; device data: unknown -> no)
+bool all_zero(const float* src, size_t n, int space) {
+  if (space != RSB_HOST) return false;
+  for (size_t i = 0; i < n; ++i) if (src[i] != 0.f) return false;
+  return true;
+}
 int copy_in(rsb_world* w, float* dst, const float* src, size_t n, int space) {
   HIP_TRY(hipMemcpyAsync(dst, src, n * sizeof(float), space == RSB_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, stream_of(w)));
   if (space == RSB_HOST) HIP_TRY(hipStreamSynchronize(stream_of(w)));  // the caller may reuse its host buffer
@@ -981,6 +991,8 @@ int rsb_set_env_row(rsb_world* w, int field, int env, const float* data) {
   if ((field == RSB_F_GC || field == RSB_F_GV) && w->blob.ncol > 0)   // the env's state was overwritten: its solver state is stale
     HIP_TRY(hipMemsetAsync(w->d_warm + (size_t)env * rsbk::kWarmRow, 0, (size_t)rsbk::kWarmRow * sizeof(float), stream_of(w)));
   HIP_TRY(hipStreamSynchronize(stream_of(w)));
+  if (field == RSB_F_DTARGET && !all_zero(data, dim, RSB_HOST)) w->dt_zero = false;
+  if (field == RSB_F_TAU_FF && !all_zero(data, dim, RSB_HOST)) w->tff_zero = false;
   w->integrate1_valid = false;
   return RSB_OK;
 }
@@ -1034,12 +1046,13 @@ int rsb_set_pd_target(rsb_world* w, const float* p_target, const float* d_target
   HIP_TRY(hipSetDevice(w->device));
   const size_t N = w->N;
   if (p_target) { int st = copy_in(w, w->d_pt, p_target, N * w->blob.nq, space); if (st) return st; }
-  if (d_target) { int st = copy_in(w, w->d_dt, d_target, N * w->blob.nv, space); if (st) return st; }
+  if (d_target) { int st = copy_in(w, w->d_dt, d_target, N * w->blob.nv, space); if (st) return st; w->dt_zero = all_zero(d_target, N * w->blob.nv, space); }
   return RSB_OK;
 }
 int rsb_set_generalized_force(rsb_world* w, const float* tau, int space) {
   if (!w || !tau) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
+  w->tff_zero = all_zero(tau, (size_t)w->N * w->blob.nv, space);
   return copy_in(w, w->d_tff, tau, (size_t)w->N * w->blob.nv, space);
 }
 
@@ -1078,8 +1091,8 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
   HIP_TRY(hipSetDevice(w->device));
   const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
   if (io->p_target) HIP_TRY(hipMemcpyAsync(w->d_pt, io->p_target, N * nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
-  if (io->d_target) HIP_TRY(hipMemcpyAsync(w->d_dt, io->d_target, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
-  if (io->tau_ff) HIP_TRY(hipMemcpyAsync(w->d_tff, io->tau_ff, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
+  if (io->d_target) { HIP_TRY(hipMemcpyAsync(w->d_dt, io->d_target, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w))); w->dt_zero = false; }      // (staged rows of the views: not scanned)
+  if (io->tau_ff) { HIP_TRY(hipMemcpyAsync(w->d_tff, io->tau_ff, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w))); w->tff_zero = false; }
   if (io->gc || io->gv) {
     if (!io->state_mask) { rsb::set_error("rsb_view_exchange: state rows need state_mask"); return RSB_E_INVALID; }
     if (!w->d_tmp_gc) {
@@ -1301,7 +1314,7 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
     return RSB_E_INVALID;
   }
   HIP_TRY(hipSetDevice(w->device));
-  if (d_target) { int st = copy_in(w, w->d_dt, d_target, (size_t)w->N * w->blob.nv, RSB_DEVICE); if (st) return st; }
+  if (d_target) { int st = copy_in(w, w->d_dt, d_target, (size_t)w->N * w->blob.nv, RSB_DEVICE); if (st) return st; w->dt_zero = false; }
   rsb_world::Fuse f;
   f.ptarget_src = p_target;   // read in place by the launch, which also refreshes the world's own copy
   f.pipeline = p_target != nullptr && d_target == nullptr;   // (rsb_set_step_pipelining: control steps that upload nothing may overlap)
@@ -1466,8 +1479,8 @@ void* rsb_device_ptr(rsb_world* w, int field) {
     case RSB_F_GC: return w->d_gc;
     case RSB_F_GV: return w->d_gv;
     case RSB_F_PTARGET: return w->d_pt;
-    case RSB_F_DTARGET: return w->d_dt;
-    case RSB_F_TAU_FF: return w->d_tff;
+    case RSB_F_DTARGET: w->dt_zero = false; return w->d_dt;       // (the caller may write through the pointer: the rows are read from now on)
+    case RSB_F_TAU_FF: w->tff_zero = false; return w->d_tff;
     case RSB_F_CONTACT_COUNT: return w->d_count;
     case RSB_F_CONTACTS: return w->d_contacts;
     case RSB_F_FLAGS: return w->d_flags;

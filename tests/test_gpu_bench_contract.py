@@ -89,3 +89,38 @@ def test_bench_peer_obs_exchange_on_one_rank(built_lib):
     assert r.returncode == 0, r.stderr[-2000:]
     b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == 1 and b["config"]["obs_all_gather"].startswith("peer-mapped") and b["value"] > 1e6
+
+
+def test_bench_two_leg_order_of_an_n_gpu_run_on_one_rank(built_lib):
+    """what `bench.py --gpus N` (N > 1) runs per rank - first the combination that has run before (lock-step control steps + the RCCL
+    all-gather in line), then the pipelined steps + gather on a side stream under a guard, both in the one JSON line, the communicator's rank count
+    and the ranks' devices with them - forced onto a one-rank group (RSB_BENCH_TWO_LEGS=1 --force-collective): the only way this code path meets a
+    GPU before the driver's scaling run.  And the default single-GPU line's closed_loop block and roofline fractions."""
+    env = dict(os.environ, RSB_BENCH_TWO_LEGS="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--preroll", "8", "--force-collective", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp", env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["value_leg"] == "pipelined" and b["pipelined_leg_error"] is None
+    ls = b["lockstep"]
+    assert ls["ran_first"] is True and ls["obs_all_gather"] == "in line" and ls["gathered_rows_of_this_rank_correct"] is True and ls["value"] > 1e6
+    assert b["value"] > 1e6                                          # (six steps are not a measurement: which leg is faster is bench.py's business)
+    rc = b["rccl"]
+    assert rc["rccl_ranks"] == 1 and rc["allreduce_of_ones"] == 1.0 and rc["distinct_devices"] == 1 and rc["by_rank"][0]["rank"] == 0 and rc["by_rank"][0]["compute_units"] > 0
+    roof = b["roofline"]
+    assert abs(roof["frac"] - roof["frac_throughput"]) < 1e-12 and 0 < roof["frac_kernel_duration"] <= roof["frac_throughput"] * 1.05
+    assert roof["timed_region_brackets"]["stride"] == 1 and roof["timed_region_brackets"]["n"] == 6
+
+
+def test_bench_closed_loop_block(built_lib):
+    """`closed_loop` of the default line (here on its own: --closed-loop-only): the policy-in-the-loop run pipelined and in lock-step from the same
+    pre-rolled population - identical populations (the runs are bit-identical), the pipelined one faster, no pipeline fault"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--closed-loop-only", "--steps", "40", "--warmup", "5", "--preroll", "20"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])["closed_loop"]
+    p, l = c["pipelined"], c["lockstep"]
+    assert p["value"] > 1.1 * l["value"] > 1e6
+    for k in ("resets_per_control_step_mean", "contacts_per_env", "solver_iters_mean", "base_height_mean"):
+        assert p[k] == l[k], k
+    assert c["pipeline"]["faults"] == 0 and c["pipeline"]["streams_overlap"] is True and c["pipeline"]["pipelined_launches"] >= 40
