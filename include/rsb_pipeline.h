@@ -208,7 +208,8 @@ __device__ __forceinline__ void serve(const rsb_stage_ctx& c, Body&& body) {
     const unsigned long long open_ = __ballot(in && served - last_seq < 0);
     if (open_ == 0ull) return;                   /* every block of the share has had its final pass */
     const int pp = ld_word(c.step_prog + (size_t)b * c.word_stride);
-    unsigned long long ready = __ballot(in && served - last_seq < 0 && pp - served >= 1);
+    /* pass 0 sees the state the run starts from: nothing to wait for (the host has made the observation rows current before the launch) */
+    unsigned long long ready = __ballot(in && served - last_seq < 0 && (pp - served >= 1 || (c.pass_first == 0 && served - (c.seq0 - 1) == 0)));
     if (ready == 0ull) {
       if ((++idle & 15) == 0 && __builtin_amdgcn_readfirstlane(ld_word(c.err)) != 0) return;      /* somebody failed: leave, the host replays in lock-step */
       for (int k = 0; k < c.poll_sleep; ++k) __builtin_amdgcn_s_sleep(8);      /* an idle wave's poll goes to the memory side: not too often */

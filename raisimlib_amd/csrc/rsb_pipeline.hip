@@ -187,7 +187,9 @@ __global__ void snapshot_kernel(float* dst, const float* gc, size_t n0, const fl
     else warm_w[i - n0 - n1] = dst[i];
   }
 }
-int snapshot(rsb_world* w, bool restore) {
+int snapshot_on(rsb_world* w, bool restore, hipStream_t stream);
+int snapshot(rsb_world* w, bool restore) { return snapshot_on(w, restore, w->stream); }
+int snapshot_on(rsb_world* w, bool restore, hipStream_t stream) {
   const size_t n0 = (size_t)w->N * w->blob.nq, n1 = (size_t)w->N * w->blob.nv, n2 = (size_t)w->N * rsbk::kWarmRow;
   if (!restore && w->snap_cap < n0 + n1 + n2) {
     if (w->d_snap) HIP_TRY(hipFree(w->d_snap));
@@ -195,7 +197,7 @@ int snapshot(rsb_world* w, bool restore) {
     HIP_TRY(hipMalloc(&w->d_snap, (n0 + n1 + n2) * sizeof(float)));
     w->snap_cap = n0 + n1 + n2;
   }
-  hipLaunchKernelGGL(snapshot_kernel, dim3(1024), dim3(256), 0, w->stream, w->d_snap, w->d_gc, n0, w->d_gv, n1, w->d_warm, n2, restore ? 1 : 0,
+  hipLaunchKernelGGL(snapshot_kernel, dim3(1024), dim3(256), 0, stream, w->d_snap, w->d_gc, n0, w->d_gv, n1, w->d_warm, n2, restore ? 1 : 0,
                      w->d_gc, w->d_gv, w->d_warm);
   HIP_TRY(hipGetLastError());
   return RSB_OK;
@@ -231,14 +233,18 @@ int pipe_prepare(rsb_world* w, int blocks) {
   return RSB_OK;
 }
 
-// fork: the private streams run after everything that is on the world's stream now; nothing is in flight
-int pipe_fork(rsb_world* w, bool with_stage) {
-  const int st = snapshot(w, false);       // what a faulted pipeline is replayed from
+// fork (open loop): nothing is in flight.  The snapshot a fault is replayed from goes to the stream of the FIRST launch, in front of it; the second
+// launch (other stream) is gated on the first having started, so it needs no event of its own.  The world's stream is waited for only when it is
+// busy: an event wait between streams costs ~50 us even when there is nothing to wait for (2.5 % of a 20-step run).
+int pipe_fork(rsb_world* w) {
+  hipStream_t first = w->pipe_stream[w->pipe_next];
+  if (hipStreamQuery(w->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(hipEventRecord(w->pipe_ev[2], w->stream));
+    HIP_TRY(hipStreamWaitEvent(first, w->pipe_ev[2], 0));
+  }
+  const int st = snapshot_on(w, false, first);
   if (st != RSB_OK) return st;
-  HIP_TRY(hipEventRecord(w->pipe_ev[2], w->stream));
-  HIP_TRY(hipStreamWaitEvent(w->pipe_stream[0], w->pipe_ev[2], 0));
-  HIP_TRY(hipStreamWaitEvent(w->pipe_stream[1], w->pipe_ev[2], 0));
-  if (with_stage) HIP_TRY(hipStreamWaitEvent(w->pipe_stage_stream, w->pipe_ev[2], 0));
   w->pipe_n = 0;
   w->pipe_log.clear();
   w->pipe_time_logged = 0.0;
@@ -336,7 +342,7 @@ int pipe_begin_launch(rsb_world* w, StepArgs& a, int blocks, bool closed_loop, h
   a.pipe_err = err_ptr(w); a.pipe_err_host = w->d_pipe_err_host; a.pipe_timeout = timeout_ticks();
   if (!w->pipe_active) {
     // (sequence numbers and the started count carry on: every earlier pipelined launch has completed.  A closed-loop run forks itself.)
-    st = pipe_fork(w, false);
+    st = pipe_fork(w);
     if (st != RSB_OK) return st;
   }
   *ls = w->pipe_stream[w->pipe_next];
@@ -521,14 +527,27 @@ int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user,
     if (!said) { std::fprintf(stderr, "raisimlib_amd: no three streams on different hardware queues (GPU_MAX_HW_QUEUES?): closed-loop runs stay in lock-step\n"); said = true; }
     return closed_loop_lockstep(w, K, launch, user, pg0);
   }
-  st = launch_env_obs(w, w->d_env_ob, s);
-  if (st != RSB_OK) return st;
+  // The run's own sequence numbers start ONE past the last one published (pass 0 publishes act_prog = seq0, the steps seq0 + 1 .. seq0 + K): whatever
+  // an earlier run left in the words is smaller than anything this run waits for - no kernel has to reset them.
+  w->pipe_seq += 1u;
   const int seq0 = (int)w->pipe_seq;
   int* act_prog = w->d_pipe_prog + (size_t)c.blocks * w->pipe_stride;
-  hipLaunchKernelGGL(fill_i32_kernel, dim3((c.blocks * w->pipe_stride + 255) / 256), dim3(256), 0, s, act_prog, c.blocks * w->pipe_stride, seq0 - 1);
-  HIP_TRY(hipGetLastError());
-  st = pipe_fork(w, true);
+  // Everything the run needs before its first step goes to the STAGE's stream, in front of the stage kernel: the observation of the current state
+  // (unless the last env-task step left it there), the snapshot a fault is replayed from.  The first step is gated on the stage having started, the
+  // second on the first, ...: the step streams need no event of their own.  The world's stream is waited for only when it is busy (an event wait
+  // between streams costs ~50 us of a 20-step run's 1.7 ms even when there is nothing to wait for).
+  hipStream_t A = w->pipe_stage_stream;
+  if (hipStreamQuery(s) != hipSuccess) {
+    (void)hipGetLastError();
+    HIP_TRY(hipEventRecord(w->pipe_ev[2], s));
+    HIP_TRY(hipStreamWaitEvent(A, w->pipe_ev[2], 0));
+  }
+  if (!w->env_ob_valid) { st = launch_env_obs(w, w->d_env_ob, A); if (st != RSB_OK) return st; }
+  st = snapshot_on(w, false, A);
   if (st != RSB_OK) return st;
+  w->pipe_n = 0;
+  w->pipe_log.clear();
+  w->pipe_time_logged = 0.0;
   c.step_prog = w->d_pipe_prog; c.act_prog = act_prog; c.ticket = stage_ticket_ptr(w);
   c.err = err_ptr(w); c.err_host = w->d_pipe_err_host; c.started = stage_started_ptr(w);
   c.word_stride = w->pipe_stride;

@@ -105,6 +105,7 @@ struct rsb_world {
   int lpe = 0, max_kid = 0;
   double world_time = 0;
   bool integrate1_valid = false;
+  bool env_ob_valid = false;            // d_env_ob holds the env-task observation of the CURRENT state (left there by the last env-task step; any other state change clears it)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)

@@ -542,6 +542,7 @@ int do_integrate(rsb_world* w, int nsub) {
   }
   w->world_time += nsub * w->dt;
   w->integrate1_valid = false;
+  w->env_ob_valid = a.env_ob != nullptr && a.env_ob == w->d_env_ob;      // (the fused epilogue left the observation the NEXT step starts from in the world's own buffer)
   return RSB_OK;
 }
 
@@ -928,7 +929,7 @@ int rsb_set_state(rsb_world* w, const float* gc, const float* gv, const uint8_t*
   if (!w) return RSB_E_INVALID;
   HIP_TRY(hipSetDevice(w->device));
   const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
-  w->integrate1_valid = false;
+  w->integrate1_valid = false; w->env_ob_valid = false;
   const int n6 = rsbk::kWarmRow;
   if (!mask) {
     if (n6 > 0) hipLaunchKernelGGL(warm_clear_kernel, dim3((N * n6 + 255) / 256), dim3(256), 0, stream_of(w), w->d_warm, (const uint8_t*)nullptr, (int)N, n6);
@@ -993,7 +994,7 @@ int rsb_set_env_row(rsb_world* w, int field, int env, const float* data) {
   HIP_TRY(hipStreamSynchronize(stream_of(w)));
   if (field == RSB_F_DTARGET && !all_zero(data, dim, RSB_HOST)) w->dt_zero = false;
   if (field == RSB_F_TAU_FF && !all_zero(data, dim, RSB_HOST)) w->tff_zero = false;
-  w->integrate1_valid = false;
+  w->integrate1_valid = false; w->env_ob_valid = false;
   return RSB_OK;
 }
 int rsb_get_env_row(rsb_world* w, int field, int env, float* data) {
@@ -1111,7 +1112,7 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
     }
     hipLaunchKernelGGL(warm_clear_kernel, dim3((N * rsbk::kWarmRow + 255) / 256), dim3(256), 0, stream_of(w), w->d_warm, (const uint8_t*)w->d_tmp_mask, (int)N, rsbk::kWarmRow);
     HIP_TRY(hipGetLastError());
-    w->integrate1_valid = false;
+    w->integrate1_valid = false; w->env_ob_valid = false;
   }
   if (io->n_launches > 0 && io->launch_masks) {
     const size_t need = (size_t)io->n_launches * N;
@@ -1295,7 +1296,7 @@ int rsb_reset_terminated(rsb_world* w, const int32_t* allowed_collisions, int n_
   hipLaunchKernelGGL(reset_terminated_kernel, dim3((N + 255) / 256), dim3(256), 0, stream_of(w), w->d_gc, w->d_gv, w->d_contacts,
                      w->d_count, w->d_flags, allowed, dgc0, dgv0, rows, ddone, (int)N, (int)nq, (int)nv, w->kmax, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
-  w->integrate1_valid = false;
+  w->integrate1_valid = false; w->env_ob_valid = false;
   if (space == RSB_HOST) {
     if (done) HIP_TRY(hipMemcpyAsync(done, w->d_tmp_mask, N, hipMemcpyDeviceToHost, stream_of(w)));
     HIP_TRY(hipStreamSynchronize(stream_of(w)));
@@ -1423,7 +1424,7 @@ int rsb_env_reset(rsb_world* w) {
                      w->d_flags, w->d_env_gc0_rows ? w->d_env_gc0_rows : w->d_env_gc0, w->d_env_gc0_rows ? w->d_env_gv0_rows : w->d_env_gv0,
                      w->d_env_gc0_rows ? w->N : 1, w->N, w->blob.nq, w->blob.nv, w->d_warm, rsbk::kWarmRow);
   HIP_TRY(hipGetLastError());
-  w->integrate1_valid = false;
+  w->integrate1_valid = false; w->env_ob_valid = false;
   w->cl_passes = 0;      // (a closed-loop run's global step index - the noise slice of the reference stage - restarts with the episodes)
   return RSB_OK;
 }
@@ -1463,7 +1464,7 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
   }
   st = do_integrate(w, w->env_cfg.n_substeps);
   if (st != RSB_OK) return st;
-  w->integrate1_valid = false;
+  w->integrate1_valid = false; w->env_ob_valid = false;
   if (space == RSB_HOST) {
     if (reward) HIP_TRY(hipMemcpyAsync(reward, w->d_env_reward, (size_t)N * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
     if (done) HIP_TRY(hipMemcpyAsync(done, w->d_env_done, (size_t)N, hipMemcpyDeviceToHost, stream_of(w)));
