@@ -244,21 +244,23 @@ int rsb_set_capsule_contacts(rsb_world* w, int on);
  * three times the sweeps), and a stream runs one launch after the other: every SIMD whose wave has finished idles until the last one has.  With
  * on != 0, consecutive rsb_control_step calls that upload nothing (p_target in device memory, d_target NULL, no peer exchange, no mask) go
  * alternately to two private streams and OVERLAP on the device: workgroup b of launch k + 1 takes its envs as soon as workgroup b of launch k
- * has published them (a per-workgroup sequence number in device memory, release / acquire at agent scope), whatever the other workgroups of
+ * has published them (a per-workgroup sequence number in device memory; an env block is always processed behind the same XCD's L2, release =
+ * s_waitcnt vmcnt(0), acquire = buffer_inv sc1 - or agent-scope fences when the host's probe does not find the round-robin XCD pattern), whatever the other workgroups of
  * launch k are still doing; a one-thread gate kernel in front of launch k + 1 keeps it off the chip until launch k has been dispatched
  * completely, so that a waiting workgroup never holds a slot its predecessor needs.  Results are bit-identical to the un-pipelined sequence
  * (envs are independent; each env's steps still run in order).  Every other entry point that touches the world's stream JOINS the pipeline
  * first (the world's stream waits for both private streams), so reads, uploads, plain rsb_integrate calls and rsb_synchronize see completed
  * steps as before.  What the caller must know: work it enqueues ITSELF on a borrowed stream (rsb_set_stream) between two control steps is not
  * ordered after them unless it calls rsb_get_stream / rsb_synchronize (both join) first; and a consumer that needs every env of step k before
- * step k + 1 may start (a policy network in the loop) joins at every step and gains nothing - the overlap pays in open-loop stepping
- * (the benchmark's random PD targets, action sequences of sampling-based MPC, replay).  Upstream counterpart: none (RaiSim steps its
+ * step k + 1 may start joins at every step and gains nothing - the overlap pays in open-loop stepping (the benchmark's random PD targets,
+ * action sequences of sampling-based MPC, replay) and, since round 5, in the CLOSED loop when the policy runs as an action stage per env block
+ * (rsb_closed_loop_run in rsb_pipeline.h: 203 M against 147 M env-steps/s in lock-step on the headline workload).  Upstream counterpart: none (RaiSim steps its
  * worlds one after the other on CPU threads). */
 int rsb_set_step_pipelining(rsb_world* w, int on);
 /* 1 when control steps are pipelined.  rsb_set_step_pipelining(w, 1) leaves it at 0 (and says so once on stderr) with RSB_STEP_PIPELINING=0 in the
  * environment or under a profiler that SERIALISES dispatches (rocprofv3 --pmc sets ROCPROF_COUNTER_COLLECTION): such a tool runs one kernel at a
- * time in an order of its own, a pipelined launch would wait for a predecessor that is not allowed to start (the kernels then trap after ~10 s
- * instead of hanging the device).  Counter passes therefore see the plain kernel classes; kernel traces (no serialisation) see the pipeline. */
+ * time in an order of its own, a pipelined launch would wait for a predecessor that is not allowed to start (its wait then times out after RSB_PIPE_TIMEOUT_MS,
+ * default 10 s, and the fault path of rsb_pipeline.h replays the steps in lock-step).  Counter passes therefore see the plain kernel classes; kernel traces (no serialisation) see the pipeline. */
 int rsb_step_pipelining_enabled(const rsb_world* w);
 /* Consumers and producers on OTHER streams while the pipeline keeps running (the obs all-gather of a multi-GPU run on its own stream):
  *   rsb_step_pipeline_publish(w, stream)     `stream` waits for the most recent pipelined control step (and nothing else of the pipeline);
