@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--hm-contacts", type=int, default=1, choices=(1, 2), help="diagnostic (config 3): contacts per primitive against the height map (rsb_set_heightmap_contacts; 2 = the second-flank kernel class)")
     ap.add_argument("--hm-angle", type=float, default=45.0, help="diagnostic (--hm-contacts 2): least angle in degrees between the two contact normals")
     ap.add_argument("--integration", default="semi_implicit", choices=("semi_implicit", "euler", "trapezoid"), help="diagnostic: rsb_set_integration_scheme (non-default schemes run in their own kernel class)")
+    ap.add_argument("--slip-rule", default="energy", choices=("energy", "coulomb"), help="diagnostic: rsb_set_slip_rule (coulomb = the classical law, a kernel class of its own)")
     ap.add_argument("--anderson", type=int, default=-1, help="diagnostic: first sweep of the Anderson step in multi-contact envs of kmax > 8 worlds (library default 2; 0 = off)")
     ap.add_argument("--no-reset", action="store_true", help="disable the non-foot-contact termination rule")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -600,8 +601,10 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     recipe.setup_world(world, N, rank * N)
     if args.max_iter > 0:
         world.set_contact_solver_param(1.0, 1.0, 1.0, args.max_iter, 1e-5)
-    if (args.hm_contacts != 1 or args.integration != "semi_implicit") and not args.no_cpu:
-        raise SystemExit("--hm-contacts / --integration are diagnostics of the device path: run them with --no-cpu (the CPU leg measures the default rules)")
+    if (args.hm_contacts != 1 or args.integration != "semi_implicit" or args.slip_rule != "energy") and not args.no_cpu:
+        raise SystemExit("--hm-contacts / --integration / --slip-rule are diagnostics of the device path: run them with --no-cpu (the CPU leg measures the default rules)")
+    if args.slip_rule != "energy":
+        world.set_slip_rule(args.slip_rule)
     if args.hm_contacts != 1:
         world.set_heightmap_contacts(args.hm_contacts, args.hm_angle)
     if args.integration != "semi_implicit":

@@ -50,6 +50,9 @@ struct VecEnvConfig {
 class DeviceVectorizedEnvironment {
  public:
   DeviceVectorizedEnvironment(const std::string& urdfPath, const VecEnvConfig& cfg) : cfg_(cfg), world_(urdfPath, cfg.num_envs, cfg.device) {}
+  ~DeviceVectorizedEnvironment() { if (dW_) rsb_device_free(world_.handle(), dW_); if (dBias_) rsb_device_free(world_.handle(), dBias_); }
+  DeviceVectorizedEnvironment(const DeviceVectorizedEnvironment&) = delete;
+  DeviceVectorizedEnvironment& operator=(const DeviceVectorizedEnvironment&) = delete;
 
   void init() {
     n_ = world_.numEnvs(); nq_ = world_.gcDim(); nv_ = world_.dof(); nj_ = nv_ - 6;
@@ -101,6 +104,30 @@ class DeviceVectorizedEnvironment {
     RSB_CHECK(rsb_env_step(world_.handle(), action_device, reward_device, done_device, ob_next_device, RSB_DEVICE));
   }
 
+  // ---- the policy in the loop ON THE DEVICE (round 5; include/rsb_pipeline.h).  K control steps with an action stage between every two, handed
+  // over env block by env block: with setStepPipelining(true) consecutive steps overlap although each step's actions depend on the one before.
+  /// consecutive control steps overlap on the device (bit-identical results); returns what the library granted (false under a serialising profiler)
+  bool setStepPipelining(bool on) { RSB_CHECK(rsb_set_step_pipelining(world_.handle(), on ? 1 : 0)); return rsb_step_pipelining_enabled(world_.handle()) != 0; }
+  /// K control steps with the CALLER's stage kernel (a HIP kernel built around rsb_stage::serve).  Nothing synchronises.
+  void closedLoopRun(int steps, rsb_stage_launch_fn launch, void* user) { RSB_CHECK(rsb_closed_loop_run(world_.handle(), steps, launch, user)); }
+  /// K control steps with the in-repo linear policy  action = clip(bias + W ob):  W [actionDim, obDim] row-major and bias [actionDim] are HOST
+  /// arrays (uploaded when they change: pass the same pointers to skip the upload); clip <= 0: none.  Nothing synchronises.
+  void rolloutLinear(int steps, const float* W, const float* bias = nullptr, float clip = 0.f) {
+    RSFATAL_IF(!W, "rolloutLinear: W is null");
+    const size_t wb = (size_t)actionDim_ * obDim_ * sizeof(float), bb = (size_t)actionDim_ * sizeof(float);
+    if (!dW_) { RSB_CHECK(rsb_device_alloc(world_.handle(), wb, &dW_)); RSB_CHECK(rsb_device_alloc(world_.handle(), bb, &dBias_)); }
+    if (W != lastW_ || bias != lastBias_) {
+      RSB_CHECK(rsb_device_copy(world_.handle(), dW_, W, wb, 0));
+      if (bias) RSB_CHECK(rsb_device_copy(world_.handle(), dBias_, bias, bb, 0));
+      lastW_ = W; lastBias_ = bias;
+    }
+    rsb_linear_policy p{};
+    p.W = static_cast<const float*>(dW_); p.bias = bias ? static_cast<const float*>(dBias_) : nullptr; p.clip = clip;
+    RSB_CHECK(rsb_closed_loop_run_linear(world_.handle(), steps, &p));
+  }
+  /// waits for everything in flight; RSB_OK, or RSB_E_PIPELINE once after a pipeline fault (the steps were then replayed in lock-step: results are valid)
+  int join() { return rsb_step_pipeline_join(world_.handle()); }
+
   void isTerminalState(bool* terminalState) { for (int e = 0; e < n_; ++e) terminalState[e] = done_[e] != 0; }
   void setSeed(int) {}            // the simulation is deterministic; randomness lives in the caller's actions
   void close() {}
@@ -131,6 +158,8 @@ class DeviceVectorizedEnvironment {
   std::vector<float> gcInit_, gvInit_;
   std::vector<int32_t> feet_;
   std::vector<uint8_t> done_;
+  void* dW_ = nullptr; void* dBias_ = nullptr;       // rolloutLinear's weights on the device (freed with the world's context)
+  const float* lastW_ = nullptr; const float* lastBias_ = nullptr;
 };
 
 /// Upstream's template: N arbitrary ChildEnvironment objects on one GPU batch (see the header comment).

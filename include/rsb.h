@@ -172,7 +172,7 @@ int rsb_set_solver_anderson(rsb_world* w, int first_sweep, double clip);
  * cannot be read from /root/reference.  The Coulomb root is located like the energy minimum (16 grid directions, 16-section, Newton) on
  * P = N x d instead of dE/dtheta; a contact problem without a bracketed root (6 % of random strongly coupled blocks) takes the energy rule's point.
  * A kernel class of its own: floating-base systems of tree depth <= 5 with <= 8 contact slots, default integration scheme, one contact per
- * primitive, no peer-mapped obs exchange, no pipelined twin (RSB_E_UNSUPPORTED from the step otherwise). */
+ * primitive, no peer-mapped obs exchange (RSB_E_UNSUPPORTED from the step otherwise); pipelined twin: yes (open and closed loop). */
 #define RSB_SLIP_ENERGY 0
 #define RSB_SLIP_COULOMB 1
 int rsb_set_slip_rule(rsb_world* w, int rule);
@@ -363,6 +363,12 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io);
 /* page-locked host memory for the buffers of rsb_view_exchange (and any other RSB_HOST argument) */
 int rsb_host_alloc(size_t bytes, void** out);
 int rsb_host_free(void* p);
+/* device memory for a C / C++ caller that does not link the HIP runtime itself (a policy's weights for rsb_closed_loop_run_linear, action
+ * buffers for RSB_DEVICE arguments): allocation on the world's device, synchronous copies (kind: 0 = host -> device, 1 = device -> host),
+ * ordered behind everything the world has enqueued (they join a step pipeline like every other call) */
+int rsb_device_alloc(rsb_world* w, size_t bytes, void** out);
+int rsb_device_free(rsb_world* w, void* p);
+int rsb_device_copy(rsb_world* w, void* dst, const void* src, size_t bytes, int kind);
 
 /* contacts of the last sub-step: counts [N] int32, contacts [N,kmax] rsb_contact */
 int rsb_get_contacts(rsb_world* w, int32_t* counts, rsb_contact* contacts, int space);

@@ -156,6 +156,9 @@ PROTOTYPES = {
     "rsb_view_exchange": (_I, [_VP, _VP]),
     "rsb_host_alloc": (_I, [C.c_size_t, _VP]),
     "rsb_host_free": (_I, [_VP]),
+    "rsb_device_alloc": (_I, [_VP, C.c_size_t, _VP]),
+    "rsb_device_free": (_I, [_VP, _VP]),
+    "rsb_device_copy": (_I, [_VP, _VP, _VP, C.c_size_t, _I]),
     "rsb_set_done_output": (_I, [_VP, _VP]),
     "rsb_comm_get_unique_id": (_I, [C.c_char_p]),
     "rsb_comm_init": (_I, [_VP, _I, _I, C.c_char_p]),

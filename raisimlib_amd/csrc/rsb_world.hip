@@ -292,7 +292,7 @@ int launch_lpe_class(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe,
 }
 template <int KMAX, int CL, int ML>
 int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool prof) {
-  if constexpr ((CL & (2 | 32)) == 0) {     // a pipelined launch (StepArgs::pipe_prog) runs the class's pipelined twin: the plain instances carry none of its code
+  if constexpr ((CL & 2) == 0) {     // a pipelined launch (StepArgs::pipe_prog) runs the class's pipelined twin: the plain instances carry none of its code
     if (a.pipe_prog) return launch_lpe_class<KMAX, CL | 16, ML>(w, a, lds_bytes, lpe, prof);
   }
   return launch_lpe_class<KMAX, CL, ML>(w, a, lds_bytes, lpe, prof);
@@ -496,7 +496,7 @@ int do_integrate(rsb_world* w, int nsub) {
   // action stage's rows (closed loop), which therefore must all be running or done (no deadlock: a waiting workgroup never keeps a
   // predecessor off the chip).  rsb_pipeline.hip holds the bookkeeping.
   hipStream_t ls = nullptr;
-  const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask && !coul;      // (the Coulomb class has no pipelined twin)
+  const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask;
   if (pipelined) {
     const int blocks = (w->N + (64 / lpe) - 1) / (64 / lpe);
     st = pipe_begin_launch(w, a, blocks, closed_loop, &ls);
@@ -1084,6 +1084,26 @@ int rsb_host_alloc(size_t bytes, void** out) {
 int rsb_host_free(void* p) {
   if (p) HIP_TRY(hipHostFree(p));
   return RSB_OK;
+}
+int rsb_device_alloc(rsb_world* w, size_t bytes, void** out) {
+  if (!w || !out || bytes == 0) { rsb::set_error("rsb_device_alloc: bad argument"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  HIP_TRY(hipMalloc(out, bytes));
+  return RSB_OK;
+}
+int rsb_device_free(rsb_world* w, void* p) {
+  if (!w) { rsb::set_error("rsb_device_free: bad argument"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  if (p) { HIP_TRY(hipStreamSynchronize(stream_of(w))); HIP_TRY(hipFree(p)); }
+  return RSB_OK;
+}
+int rsb_device_copy(rsb_world* w, void* dst, const void* src, size_t bytes, int kind) {
+  if (!w || !dst || !src || (kind != 0 && kind != 1)) { rsb::set_error("rsb_device_copy: bad argument"); return RSB_E_INVALID; }
+  HIP_TRY(hipSetDevice(w->device));
+  hipStream_t st = stream_of(w);
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return fault_status(w);
 }
 
 // One flush of the facade's per-env views: uploads, launches and downloads queued on the world's stream, ONE synchronisation at the end.

@@ -172,6 +172,28 @@ int main(int argc, char** argv) {
     }
     std::printf("DeviceVectorizedEnvironment: 50 control steps x 512 envs, %d resets, mean height %.3f\n", resets, ob[0]);
 
+    // ---- the policy in the loop on the device: K control steps with the in-repo linear stage, pipelined == lock-step bit for bit
+    {
+      std::vector<float> W((size_t)12 * 34), bias(12, 0.05f), obA((size_t)512 * 34), obB((size_t)512 * 34);
+      unsigned ws = 99u;
+      for (auto& x : W) { ws = ws * 1664525u + 1013904223u; x = ((ws >> 8) / 16777216.0f - 0.5f) * 0.6f; }     // strong enough to make robots fall and reset
+      for (int pipe = 0; pipe < 2; ++pipe) {
+        raisim::DeviceVectorizedEnvironment cl(urdf, cfg);
+        cl.init();
+        const bool granted = cl.setStepPipelining(pipe != 0);
+        if (pipe) CHECK(granted);
+        cl.rolloutLinear(40, W.data(), bias.data(), 2.0f);
+        cl.rolloutLinear(25, W.data(), bias.data(), 2.0f);        // a second run continues the first (same weights: no upload)
+        CHECK(cl.join() == RSB_OK);
+        cl.observe(pipe ? obB.data() : obA.data(), 512, 34);
+      }
+      int moved = 0;
+      for (size_t i = 0; i < obA.size(); ++i) { CHECK(obA[i] == obB[i]); CHECK(std::isfinite(obA[i])); }
+      for (int e = 0; e < 512; ++e) moved += std::fabs(obA[(size_t)e * 34] - ob[(size_t)e * 34]) > 1e-3f ? 1 : 0;
+      CHECK(moved > 256);
+      std::printf("DeviceVectorizedEnvironment::rolloutLinear: 65 control steps x 512 envs, pipelined == lock-step bit for bit\n");
+    }
+
     // ---- N per-env World VIEWS of one batch: N integrate() calls = ONE launch in which every replica advances once
     {
       const int NV = 8;

@@ -217,10 +217,10 @@ def test_consumer_on_another_stream_with_publish_and_wait_event(built_lib):
     r.close()
 
 
-@pytest.mark.parametrize("which", ["fixed base", "second flank", "trapezoid"])
+@pytest.mark.parametrize("which", ["fixed base", "second flank", "trapezoid", "coulomb"])
 def test_pipelined_twins_of_the_other_kernel_classes(built_lib, which):
-    """Classes 1, 4 and 8 have pipelined twins as well (17, 20, 24): a fixed-base pendulum, the quadruped with two contacts per primitive on
-    the benchmark's height map, the trapezoidal scheme."""
+    """Classes 1, 4, 8 and 32 have pipelined twins as well (17, 20, 24, 48): a fixed-base pendulum, the quadruped with two contacts per primitive on
+    the benchmark's height map, the trapezoidal scheme, the classical Coulomb slip rule."""
     import torch
     dev = torch.device("cuda:0")
     n, K = 1024, 30
@@ -241,6 +241,8 @@ def test_pipelined_twins_of_the_other_kernel_classes(built_lib, which):
             recipe.setup_world(w, n, 0)
             if which == "second flank":
                 w.set_heightmap_contacts(2, 30.0)
+            elif which == "coulomb":
+                w.set_slip_rule("coulomb")
             else:
                 w.set_integration_scheme("trapezoid")
             gc, gv = recipe.initial_state(n, 0)
