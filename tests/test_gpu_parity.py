@@ -373,6 +373,43 @@ def test_golden_fixture_parity(anymal):
     assert (np.abs(dev["u"] - g["u1"]).max(axis=1) / (1 + np.abs(g["u1"]).max(axis=1)))[conv].max() < 2e-4
 
 
+@pytest.mark.parametrize("tag", ["hm", "coul", "atlas"])
+def test_feature_golden_fixture_parity(built_lib, tag):
+    """Device vs the SECOND committed fixture (tests/golden/features_golden.npz, round 5): one integrate() of the height-map recipe's states (the
+    height-field outer-side test), of the first fixture's states under RSB_SLIP_COULOMB, and of the humanoid recipe's states (multi-contact solver
+    settings + Anderson step).  Contact lists (collision ids in order) identical; states within the one-step tolerances of the configuration."""
+    import os
+    import sys
+    from common import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    g = np.load(os.path.join(ROOT, "tests", "golden", "features_golden.npz"))
+    if tag == "coul":
+        a = np.load(os.path.join(ROOT, "tests", "golden", "anymal_golden.npz"))
+        recipe, gc, gv, pt = bench.Recipe(2, -1.0), a["gc"], a["gv"], a["pt"]
+    else:
+        recipe, gc, gv, pt = bench.Recipe(3 if tag == "hm" else 5, -1.0), g[tag + "_gc"], g[tag + "_gv"], g[tag + "_pt"]
+    n = len(gc)
+    w = BatchedWorld(recipe.model, n)
+    recipe.setup_world(w, n, 0)
+    if tag == "coul":
+        w.set_slip_rule("coulomb")
+    w.set_pd_target(pt, np.zeros((n, recipe.model.nv))); w.set_state(gc, gv)
+    w.integrate(1)
+    q1, u1 = w.get_state(); cnt, con = w.get_contacts(); flags = w.get_flags(); iters = w.get_solver_iterations()
+    w.close()
+    assert np.array_equal(cnt, g[tag + "_n"])
+    for e in range(n):
+        assert np.array_equal(con[e][:cnt[e]]["collision"], g[tag + "_ids"][e][:cnt[e]]), e
+    conv = ((g[tag + "_flags"] | flags) & 4) == 0
+    assert conv.mean() > (0.8 if tag == "atlas" else 0.95)
+    eu = np.abs(u1 - g[tag + "_u1"]).max(axis=1) / (1 + np.abs(g[tag + "_u1"]).max(axis=1))
+    eq = np.abs(q1 - g[tag + "_q1"]).max(axis=1)
+    print(f"{tag}: contacts {int(cnt.sum())}, converged {conv.mean():.2f}, relative |du| max over converged {eu[conv].max():.1e}, |dq| {eq[conv].max():.1e}, sweeps dev {iters.max()} golden {g[tag + '_iters'].max()}")
+    assert eu[conv].max() < (5e-3 if tag == "atlas" else 2e-4) and eq[conv].max() < (5e-5 if tag == "atlas" else 3e-6)
+    assert np.isfinite(q1).all() and np.isfinite(u1).all()
+
+
 def test_contact_problem_parity(anymal):
     """Delassus matrix G, free contact velocity c and solved impulses of single envs vs the oracle."""
     gc, gv = standing_states(64, seed=21)

@@ -50,3 +50,33 @@ def test_grouped_sweep_agrees_with_the_sequential_sweep_on_the_golden_states(any
     b = o.step_batch(g["gc"], g["gv"], 1, kp, kd, g["pt"], np.zeros((24, 18)))
     assert np.abs(a["q"] - b["q"]).max() < 1e-7 and np.abs(a["u"] - b["u"]).max() < 1e-5      # measured 1e-8, 3.8e-6
     assert np.abs(a["iters"] - b["iters"]).max() <= 2
+
+
+def _features():
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import bench
+    import make_golden_features as mk
+    return np.load(os.path.join(ROOT, "tests", "golden", "features_golden.npz")), bench, mk
+
+
+def test_oracle_matches_the_feature_golden_vectors():
+    """tests/golden/features_golden.npz (round 5): the height-map narrow phase with the height-field outer-side test, the Coulomb slip rule and the
+    humanoid's multi-contact solver settings + Anderson step, each frozen on one integrate() of its recipe's states."""
+    g, bench, mk = _features()
+    a = np.load(os.path.join(ROOT, "tests", "golden", "anymal_golden.npz"))
+
+    def coulomb(o):
+        o.p.slip_rule = 1
+    for tag, recipe, q, u, pt, tweak in (("hm", bench.Recipe(3, -1.0), g["hm_gc"], g["hm_gv"], g["hm_pt"], None),
+                                         ("coul", bench.Recipe(2, -1.0), a["gc"], a["gv"], a["pt"], coulomb),
+                                         ("atlas", bench.Recipe(5, -1.0), g["atlas_gc"], g["atlas_gv"], g["atlas_pt"], None)):
+        r = mk.one_step(recipe, q, u, pt, tweak)
+        assert np.array_equal(r["n"], g[tag + "_n"]) and np.array_equal(r["ids"], g[tag + "_ids"]), tag
+        assert np.array_equal(r["iters"], g[tag + "_iters"]) and np.array_equal(r["flags"], g[tag + "_flags"]), tag
+        assert np.allclose(r["q1"], g[tag + "_q1"], rtol=0, atol=1e-12) and np.allclose(r["u1"], g[tag + "_u1"], rtol=0, atol=1e-9), tag
+    # the fixtures exercise what they are meant to: contacts on sloped terrain, slipping contacts whose two rules differ, redundant foot contacts
+    assert g["hm_n"].sum() > 100 and g["atlas_n"].max() >= 6 and g["atlas_iters"].max() > 10
+    e = mk.one_step(bench.Recipe(2, -1.0), a["gc"], a["gv"], a["pt"])
+    assert np.abs(e["u1"] - g["coul_u1"]).max() > 1e-3          # the energy rule gives other velocities on these states
