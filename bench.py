@@ -512,33 +512,44 @@ def closed_loop_leg(args, dev, n):
         w = env.world
         if args.stage_grid:
             env.set_stage_grid(args.stage_grid)
-        for mode in ("pipelined", "lockstep"):
-            on = w.set_step_pipelining(mode == "pipelined")
-            if mode == "pipelined" and not on:
-                res["pipelined"] = None
-                continue
-            env.reset()
-            w.synchronize()
-            # (env.reset() also restarts the world's closed-loop step counter, which selects the noise slice: both modes run the same sequence)
-            env.rollout_linear(args.preroll + args.warmup, W, noise=noise)
-            w.step_pipeline_join()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            env.rollout_linear(args.steps, W, noise=noise)
-            t_enq = time.perf_counter() - t0
-            w.step_pipeline_join()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            K2 = 64
-            ro = {"done": torch.zeros((K2, n), dtype=torch.uint8, device=dev)}
-            env.rollout_linear(K2, W, noise=noise, rollout=ro)
-            w.step_pipeline_join()
-            cnt, _ = w.get_contacts()
-            q, _ = w.get_state()
-            res[mode] = {"value": n * workload.SUBSTEPS * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
-                         "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
-                         "resets_per_control_step_mean": float(ro["done"].sum().item()) / K2, "contacts_per_env": float(cnt.mean()),
-                         "solver_iters_mean": float(w.get_solver_iterations().mean()), "base_height_mean": float(q[:, 2].mean())}
+        mlp = [(torch.from_numpy(Wl).to(dev), torch.from_numpy(bl).to(dev)) for Wl, bl in workload.closed_loop_mlp(env.num_obs, env.num_acts)]
+        ob_mean, ob_var = torch.zeros(env.num_obs, device=dev), torch.ones(env.num_obs, device=dev)
+        res["mlp"] = {"what": "rsb_closed_loop_run_mlp: the same run with an ACTOR NETWORK as the action stage - raisimGymTorch's default architecture (MLP 34 -> 128 -> 128 "
+                              "-> 12, LeakyReLU [RECALL]), observation normalisation (clamp((ob - mean) / sqrt(var + eps), +-10), frozen statistics), fp32, evaluated per env block "
+                              "by the stage's waves (lane = unit, no LDS, <= 96 registers: a stage wave shares its SIMD with a step wave)",
+                      "policy": {"layers": "34-128-128-12, hidden U(+-1/sqrt(fan_in)), output U(+-%g), zero biases, seeded" % workload.CLOSED_LOOP_W_SCALE,
+                                 "activation": "leaky_relu(0.01)", "noise": "config 2's target draws, period 128", "action_std": 0.3}}
+        runners = {"linear": lambda K, ro=None: env.rollout_linear(K, W, noise=noise, rollout=ro),
+                   "mlp": lambda K, ro=None: env.rollout_mlp(K, mlp, activation="leaky_relu", ob_mean=ob_mean, ob_var=ob_var, noise=noise, rollout=ro)}
+        for kind, run in runners.items():
+            dst = res if kind == "linear" else res["mlp"]
+            for mode in ("pipelined", "lockstep"):
+                on = w.set_step_pipelining(mode == "pipelined")
+                if mode == "pipelined" and not on:
+                    dst["pipelined"] = None
+                    continue
+                env.reset()
+                w.synchronize()
+                # (env.reset() also restarts the world's closed-loop step counter, which selects the noise slice: both modes run the same sequence)
+                run(args.preroll + args.warmup)
+                w.step_pipeline_join()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run(args.steps)
+                t_enq = time.perf_counter() - t0
+                w.step_pipeline_join()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                K2 = 64
+                ro = {"done": torch.zeros((K2, n), dtype=torch.uint8, device=dev)}
+                run(K2, ro)
+                w.step_pipeline_join()
+                cnt, _ = w.get_contacts()
+                q, _ = w.get_state()
+                dst[mode] = {"value": n * workload.SUBSTEPS * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+                             "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+                             "resets_per_control_step_mean": float(ro["done"].sum().item()) / K2, "contacts_per_env": float(cnt.mean()),
+                             "solver_iters_mean": float(w.get_solver_iterations().mean()), "base_height_mean": float(q[:, 2].mean())}
         faults, code = w.step_pipeline_fault()
         launches, joins = w.step_pipelining_stats()
         res["pipeline"] = {"pipelined_launches": launches, "joins": joins, "faults": faults, "last_fault_code": code, "streams_overlap": bool(w.pipeline_overlaps)}

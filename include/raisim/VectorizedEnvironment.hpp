@@ -50,7 +50,7 @@ struct VecEnvConfig {
 class DeviceVectorizedEnvironment {
  public:
   DeviceVectorizedEnvironment(const std::string& urdfPath, const VecEnvConfig& cfg) : cfg_(cfg), world_(urdfPath, cfg.num_envs, cfg.device) {}
-  ~DeviceVectorizedEnvironment() { if (dW_) rsb_device_free(world_.handle(), dW_); if (dBias_) rsb_device_free(world_.handle(), dBias_); }
+  ~DeviceVectorizedEnvironment() { if (dW_) rsb_device_free(world_.handle(), dW_); if (dBias_) rsb_device_free(world_.handle(), dBias_); for (void* d : mlpDev_) rsb_device_free(world_.handle(), d); }
   DeviceVectorizedEnvironment(const DeviceVectorizedEnvironment&) = delete;
   DeviceVectorizedEnvironment& operator=(const DeviceVectorizedEnvironment&) = delete;
 
@@ -125,6 +125,41 @@ class DeviceVectorizedEnvironment {
     p.W = static_cast<const float*>(dW_); p.bias = bias ? static_cast<const float*>(dBias_) : nullptr; p.clip = clip;
     RSB_CHECK(rsb_closed_loop_run_linear(world_.handle(), steps, &p));
   }
+  /// K control steps with an ACTOR NETWORK in the loop (the in-repo MLP stage, rsb_closed_loop_run_mlp): layer l = (weights[l] [dims[l + 1], dims[l]]
+  /// row-major as torch.nn.Linear stores them, biases[l] [dims[l + 1]] or null), HOST arrays, uploaded (transposed) when `weights` changes;
+  /// dims.front() = obDim, dims.back() = actionDim, even widths <= 256; activation RSB_ACT_TANH / _RELU / _LEAKY_RELU on the hidden layers.
+  void rolloutMlp(int steps, const std::vector<int>& dims, const std::vector<const float*>& weights, const std::vector<const float*>& biases,
+                  int activation = RSB_ACT_LEAKY_RELU, float clip = 0.f) {
+    const int L = (int)dims.size() - 1;
+    RSFATAL_IF(L < 1 || L > RSB_MLP_MAX_LAYERS || (int)weights.size() != L || (int)biases.size() != L, "rolloutMlp: 1 .. 4 layers, one weight and one bias pointer per layer");
+    if (weights != mlpHostW_ || dims != mlpDims_) {
+      for (void* d : mlpDev_) rsb_device_free(world_.handle(), d);
+      mlpDev_.clear();
+      mlp_ = rsb_mlp_policy{};
+      mlp_.n_layers = L;
+      for (int l = 0; l <= L; ++l) mlp_.dims[l] = dims[l];
+      for (int l = 0; l < L; ++l) {
+        const int in = dims[l], out = dims[l + 1];
+        std::vector<float> wt((size_t)in * out);
+        for (int o = 0; o < out; ++o) for (int i = 0; i < in; ++i) wt[(size_t)i * out + o] = weights[l][(size_t)o * in + i];
+        void* dw = nullptr;
+        RSB_CHECK(rsb_device_alloc(world_.handle(), wt.size() * sizeof(float), &dw));
+        mlpDev_.push_back(dw);
+        RSB_CHECK(rsb_device_copy(world_.handle(), dw, wt.data(), wt.size() * sizeof(float), 0));
+        mlp_.Wt[l] = static_cast<const float*>(dw);
+        if (biases[l]) {
+          void* db = nullptr;
+          RSB_CHECK(rsb_device_alloc(world_.handle(), (size_t)out * sizeof(float), &db));
+          mlpDev_.push_back(db);
+          RSB_CHECK(rsb_device_copy(world_.handle(), db, biases[l], (size_t)out * sizeof(float), 0));
+          mlp_.bias[l] = static_cast<const float*>(db);
+        }
+      }
+      mlpHostW_ = weights; mlpDims_ = dims;
+    }
+    mlp_.activation = activation; mlp_.leaky_slope = 0.01f; mlp_.clip = clip;
+    RSB_CHECK(rsb_closed_loop_run_mlp(world_.handle(), steps, &mlp_));
+  }
   /// waits for everything in flight; RSB_OK, or RSB_E_PIPELINE once after a pipeline fault (the steps were then replayed in lock-step: results are valid)
   int join() { return rsb_step_pipeline_join(world_.handle()); }
 
@@ -160,6 +195,8 @@ class DeviceVectorizedEnvironment {
   std::vector<uint8_t> done_;
   void* dW_ = nullptr; void* dBias_ = nullptr;       // rolloutLinear's weights on the device (freed with the world's context)
   const float* lastW_ = nullptr; const float* lastBias_ = nullptr;
+  rsb_mlp_policy mlp_{};                             // rolloutMlp's network on the device
+  std::vector<void*> mlpDev_; std::vector<const float*> mlpHostW_; std::vector<int> mlpDims_;
 };
 
 /// Upstream's template: N arbitrary ChildEnvironment objects on one GPU batch (see the header comment).

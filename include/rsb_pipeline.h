@@ -126,6 +126,36 @@ typedef struct rsb_linear_policy {
 } rsb_linear_policy;
 int rsb_closed_loop_run_linear(struct rsb_world* w, int n_steps, const rsb_linear_policy* policy);
 
+/* The in-repo MLP stage: the actor network of a raisimGymTorch-style PPO run (upstream's default: MLP ob -> 128 -> 128 -> act, LeakyReLU
+ * [RECALL raisimGymTorch/algo/ppo/module.py; absent from /root/reference]) evaluated per env block between every two control steps - the policy
+ * a rollout actually has in its loop.  All pointers device memory; any but Wt may be NULL.
+ *   layer l:  y = f(W_l x + b_l),  dims[0] = ob_dim, dims[n_layers] = act_dim, 1 <= n_layers <= RSB_MLP_MAX_LAYERS, every width even and <= 256;
+ *             hidden layers use `activation`, the last layer is linear;
+ *   Wt[l]     the layer's weight TRANSPOSED: [dims[l], dims[l + 1]] row-major (torch: linear.weight.t().contiguous()), 8-byte aligned - units
+ *             2 s, 2 s + 1 of a layer are lane s of the stage's wave, so a row of Wt is one coalesced 8-byte load per lane;  bias[l] [dims[l + 1]];
+ *   input     x = clamp((ob - ob_mean) * ob_inv_std, -ob_clip, ob_clip)  (RaisimGymVecEnv's normalize_ob with frozen statistics [RECALL];
+ *             ob_mean / ob_inv_std [ob_dim], NULL: the raw observation; ob_clip <= 0: none);
+ *   output    action = clip(y + noise[pass % noise_period]), noise [noise_period, n_envs, act_dim] (pre-sampled exploration noise), clip <= 0: none;
+ *   rollout   as rsb_linear_policy's.
+ * Arithmetic: fp32 FMAs in input-index order, the same instruction sequence pipelined and in lock-step (bit-identical runs); against a torch
+ * fp32 forward pass the actions agree to rounding (tests/test_gpu_closed_loop.py). */
+#define RSB_MLP_MAX_LAYERS 4
+#define RSB_ACT_TANH 0
+#define RSB_ACT_RELU 1
+#define RSB_ACT_LEAKY_RELU 2
+typedef struct rsb_mlp_policy {
+  int32_t n_layers;
+  int32_t dims[RSB_MLP_MAX_LAYERS + 1];
+  const float* Wt[RSB_MLP_MAX_LAYERS];
+  const float* bias[RSB_MLP_MAX_LAYERS];
+  int32_t activation;
+  float leaky_slope;            /* RSB_ACT_LEAKY_RELU: f(x) = x > 0 ? x : leaky_slope x  (torch's default 0.01) */
+  const float* ob_mean; const float* ob_inv_std; float ob_clip;
+  const float* noise; int32_t noise_period; float clip;
+  float* rollout_ob; float* rollout_act; float* rollout_reward; uint8_t* rollout_done;
+} rsb_mlp_policy;
+int rsb_closed_loop_run_mlp(struct rsb_world* w, int n_steps, const rsb_mlp_policy* policy);
+
 /* the world's own env-task buffers (device memory): ob [N, ob_dim], act [N, act_dim], reward [N], done [N] */
 int rsb_closed_loop_buffers(struct rsb_world* w, float** ob, float** act, float** reward, uint8_t** done);
 /* workgroups of the action stage per run (default 256 = one per CU; 0 restores the default) */

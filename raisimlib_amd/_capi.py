@@ -64,6 +64,13 @@ class LinearPolicy(C.Structure):
                 ("rollout_ob", C.c_void_p), ("rollout_act", C.c_void_p), ("rollout_reward", C.c_void_p), ("rollout_done", C.c_void_p)]
 
 
+class MlpPolicy(C.Structure):
+    """rsb_mlp_policy (include/rsb_pipeline.h): device pointers"""
+    _fields_ = [("n_layers", C.c_int32), ("dims", C.c_int32 * 5), ("Wt", C.c_void_p * 4), ("bias", C.c_void_p * 4), ("activation", C.c_int32), ("leaky_slope", C.c_float),
+                ("ob_mean", C.c_void_p), ("ob_inv_std", C.c_void_p), ("ob_clip", C.c_float), ("noise", C.c_void_p), ("noise_period", C.c_int32), ("clip", C.c_float),
+                ("rollout_ob", C.c_void_p), ("rollout_act", C.c_void_p), ("rollout_reward", C.c_void_p), ("rollout_done", C.c_void_p)]
+
+
 RSB_E_PIPELINE = -7
 
 LIB_PATH = os.environ.get("RSB_LIB_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librsb.so")   # RSB_LIB_PATH: kernel experiments built by build.build(extra_flags=...)
@@ -124,6 +131,7 @@ PROTOTYPES = {
     "rsb_debug_pipeline_wait_stats": (_I, [_VP, C.POINTER(_D), C.POINTER(_D)]),
     "rsb_closed_loop_run": (_I, [_VP, _I, _VP, _VP]),
     "rsb_closed_loop_run_linear": (_I, [_VP, _I, C.POINTER(LinearPolicy)]),
+    "rsb_closed_loop_run_mlp": (_I, [_VP, _I, C.POINTER(MlpPolicy)]),
     "rsb_closed_loop_buffers": (_I, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP), C.POINTER(_VP)]),
     "rsb_closed_loop_set_stage_grid": (_I, [_VP, _I]),
     "rsb_set_slip_rule": (_I, [_VP, _I]),

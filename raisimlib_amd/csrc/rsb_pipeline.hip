@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rsb_world.h"
@@ -42,6 +43,8 @@ inline unsigned* step_ticket_ptr(rsb_world* w) { return reinterpret_cast<unsigne
 inline uint32_t* stage_ticket_ptr(rsb_world* w) { return reinterpret_cast<uint32_t*>(ctl(w) + 6144); }
 
 constexpr int kStageGridDefault = 256;      // workgroups of the action stage (one per CU)
+constexpr int kStageGridMlp = 512;          // ... of the MLP stage: a block's network takes ~25 us of one wave, so fewer blocks queue behind one wave (two waves per CU; with one on
+                                            // every SIMD - 1024 - the dispatcher once stopped dealing the step workgroups round-robin over the XCDs: profiles/r05_closed_loop_log.txt)
 
 long long timeout_ticks() {      // RSB_PIPE_TIMEOUT_MS (default 10 s), in ticks of the 100 MHz wall clock; read at every launch
   const char* e = std::getenv("RSB_PIPE_TIMEOUT_MS");
@@ -252,6 +255,7 @@ int pipe_fork(rsb_world* w) {
 }
 
 int closed_loop_lockstep(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user, long long pass_global0);
+int launch_mlp_stage(void* user, const rsb_stage_ctx* c);
 
 // A fault on the device: every pipelined workgroup since has left without touching its envs, the envs are at different steps.  Back to the
 // state of the last join, pipelining off, the logged steps once more in lock-step.
@@ -291,7 +295,7 @@ int pipe_recover(rsb_world* w, int code) {
   const uint8_t* keep_done = w->d_done_out;
   for (auto& e : log) {
     if (e.closed) {
-      st = closed_loop_lockstep(w, e.K, e.is_linear ? nullptr : e.launch, e.is_linear ? (void*)&e.lin : e.user, e.pass_global0);
+      st = closed_loop_lockstep(w, e.K, e.is_linear ? nullptr : e.is_mlp ? launch_mlp_stage : e.launch, e.is_linear ? (void*)&e.lin : e.is_mlp ? (void*)&e.mlp : e.user, e.pass_global0);
     } else {
       w->fuse = e.f; w->fuse.pipeline = false;
       w->d_done_out = e.done_out;
@@ -408,25 +412,31 @@ bool pipelining_forbidden() {
 // ---- the in-repo reference stage: a fixed linear policy (rsb_linear_policy) --------------------------------------------------------
 // lane = (env of the block, action entry); the sum runs over the observation in index order with one FMA per term - the same instruction
 // sequence whether the pass is served from the pipeline or launched in lock-step, so the two produce the same bits.
+// what an on-policy learner stores of a pass: the block's observation rows, and the reward / done flags of the step just finished
+__device__ __forceinline__ void record_rollout(const rsb_stage_ctx& c, float* rollout_ob, float* rollout_reward, uint8_t* rollout_done, int env0, int n_env, int pass) {
+  const int lane = (int)threadIdx.x, od = c.ob_dim;
+  const size_t N = (size_t)c.n_envs;
+  if (rollout_ob) {      // (four rows of a block in flight at once: a stage wave pays the full L2 latency for every load -> wait round)
+    const float* src = c.ob + (size_t)env0 * od;
+    float* dst = rollout_ob + ((size_t)pass * N + env0) * od;
+    const int n = n_env * od;
+    for (int i0 = lane; i0 < n; i0 += 256) {
+      float v[4];
+      RSB_PRAGMA_UNROLL for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + 64 * k, n - 1)];
+      RSB_PRAGMA_UNROLL for (int k = 0; k < 4; ++k) if (i0 + 64 * k < n) dst[i0 + 64 * k] = v[k];
+    }
+  }
+  if (pass > 0 && lane < n_env) {
+    if (rollout_reward) rollout_reward[(size_t)(pass - 1) * N + env0 + lane] = c.reward[env0 + lane];
+    if (rollout_done) rollout_done[(size_t)(pass - 1) * N + env0 + lane] = c.done[env0 + lane];
+  }
+}
 __global__ void __launch_bounds__(64) linear_stage_kernel(const rsb_stage_ctx c, const rsb_linear_policy p) {
   rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) {
     const int lane = (int)threadIdx.x;
     const int od = c.ob_dim, ad = c.act_dim;
     const size_t N = (size_t)c.n_envs;
-    if (p.rollout_ob) {      // (four rows of a block in flight at once: a stage wave pays the full L2 latency for every load -> wait round)
-      const float* src = c.ob + (size_t)env0 * od;
-      float* dst = p.rollout_ob + ((size_t)pass * N + env0) * od;
-      const int n = n_env * od;
-      for (int i0 = lane; i0 < n; i0 += 256) {
-        float v[4];
-        RSB_PRAGMA_UNROLL for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + 64 * k, n - 1)];
-        RSB_PRAGMA_UNROLL for (int k = 0; k < 4; ++k) if (i0 + 64 * k < n) dst[i0 + 64 * k] = v[k];
-      }
-    }
-    if (pass > 0 && lane < n_env) {
-      if (p.rollout_reward) p.rollout_reward[(size_t)(pass - 1) * N + env0 + lane] = c.reward[env0 + lane];
-      if (p.rollout_done) p.rollout_done[(size_t)(pass - 1) * N + env0 + lane] = c.done[env0 + lane];
-    }
+    record_rollout(c, p.rollout_ob, p.rollout_reward, p.rollout_done, env0, n_env, pass);
     if (final || p.clip == -777.f) return;      // (clip -777: experiment - a stage that only hands over)
     const long long gp = c.pass_global0 + pass;
     const float* nz = p.noise ? p.noise + (size_t)(gp % (p.noise_period > 0 ? p.noise_period : 1)) * N * ad : nullptr;
@@ -451,6 +461,165 @@ __global__ void __launch_bounds__(64) linear_stage_kernel(const rsb_stage_ctx c,
 }
 int launch_linear_stage(void* user, const rsb_stage_ctx* c) {
   hipLaunchKernelGGL(linear_stage_kernel, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, *static_cast<const rsb_linear_policy*>(user));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- the in-repo MLP stage (rsb_mlp_policy): the actor network of a PPO rollout, per env block ------------------------------------------
+// lane = unit pair: units 2 s, 2 s + 1 (+ 128 per further register pair) of a layer are lane s; the (up to four) envs of the block are four
+// accumulator pairs per unit pair.  A layer walks its inputs in index order: input k of env e sits in lane (k & 127) >> 1 of x[e][(k & 1) + 2 (k >> 7)]
+// - where the layer before left it - and reaches every lane as a scalar (v_readlane); its weights for a lane's pair are ONE 8-byte load of the
+// transposed matrix (64 lanes: 512 contiguous bytes), loaded once per block whatever the number of envs, and feed one v_pk_fma_f32 per env.
+// What bounds it is LATENCY: a stage wave has nobody to hide a load behind and 96 registers to park loads in (no LDS: the step kernel's workgroups
+// own all of it; 96 registers: what a step wave leaves of its SIMD - tests/test_gpu_closed_loop.py reads both off the ISA).  The weight rows
+// therefore run through a RING of NB groups of KU rows with explicit loads and waits (inline asm: the compiler's own schedule waited for every
+// group - 34 us per block in the first version, 19 us with a double buffer it re-serialised; the steps starved for their actions): NB - 1 groups
+// are in flight while one is consumed.
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {      // f(integral_constant<int, I>) for I = 0 .. N - 1: register-array indices stay compile-time
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+// explicit loads and waits of the ring (the operands tie the wait to the registers it guards: nothing that reads them moves above it)
+__device__ __forceinline__ void ring_load(f2v& dst, unsigned voff, const char* sbase) {
+  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// ... and the wait hands the group's first input index THROUGH itself: the v_readlanes of the group's inputs - and with them every FMA that
+// reads the ring - depend on its result, so none of them moves above it (tying the ring registers to the wait instead made the register allocator
+// copy each of them: + 2 v_mov per row)
+template <int CNT>
+__device__ __forceinline__ int ring_wait(int k_first) {
+  int r;
+  asm volatile("s_waitcnt vmcnt(%1)\n\ts_mov_b32 %0, %2" : "=s"(r) : "n"(CNT), "s"(k_first));
+  return r;
+}
+template <int UP>       // register pairs per lane: layer widths up to 128 UP
+__device__ __forceinline__ void mlp_block(const rsb_stage_ctx& c, const rsb_mlp_policy& p, int env0, int n_env, int pass, bool final) {
+  constexpr int EPB = 4;                      // envs per block (64 / lanes_per_env <= 4)
+  constexpr int KU = 4 / UP;                  // weight rows per group (4 register pairs)
+  constexpr int NB = UP == 2 ? 2 : 6;         // groups in the ring: 4 / 24 rows = 16 / 48 registers (the wide class holds 40 registers of state, and its bodies must divide 128)
+  constexpr int LOADS = KU * UP;              // loads per group (4)
+  const int lane = (int)threadIdx.x;
+  const int od = c.ob_dim, ad = c.act_dim;
+  const size_t N = (size_t)c.n_envs;
+  record_rollout(c, p.rollout_ob, p.rollout_reward, p.rollout_done, env0, n_env, pass);
+  if (final) return;
+  f2v x[EPB][UP];
+  RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
+    float v2[EPB][2];
+    RSB_PRAGMA_UNROLL for (int h = 0; h < 2; ++h) {
+      const int k = 128 * q + 2 * lane + h;
+      const float m = (p.ob_mean && k < od) ? p.ob_mean[k] : 0.f, is = (p.ob_inv_std && k < od) ? p.ob_inv_std[k] : 1.f;
+      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
+        float v = (k < od && e < n_env) ? c.ob[(size_t)(env0 + e) * od + k] : 0.f;
+        v = (v - m) * is;
+        if (p.ob_clip > 0.f) v = fminf(fmaxf(v, -p.ob_clip), p.ob_clip);
+        v2[e][h] = k < od ? v : 0.f;
+      }
+    }
+    RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) x[e][q] = f2v{v2[e][0], v2[e][1]};
+  }
+  for (int l = 0; l < p.n_layers; ++l) {
+    const int in = p.dims[l], out = p.dims[l + 1];      // (both even: rsb_closed_loop_run_mlp checks)
+    const char* Wb = reinterpret_cast<const char*>(p.Wt[l]);
+    unsigned voff[UP];
+    f2v acc[EPB][UP];
+    RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
+      const int u = 128 * q + 2 * lane;
+      voff[q] = 4u * (unsigned)min(u, out - 2);    // byte offset of the pair in a row (clamped: no load is predicated; pairs past the layer's width are zeroed below)
+      const f2v b = (p.bias[l] && u < out) ? f2v{p.bias[l][u], p.bias[l][u + 1]} : f2v{0.f, 0.f};
+      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) acc[e][q] = b;
+    }
+    f2v ring[NB][KU][UP];
+    const int ngroups = (in + KU - 1) / KU;
+    // (rows past the end are clamped and meet zero inputs; uniform 64-bit row base in SGPRs + 32-bit lane offset: no address registers)
+    auto issue = [&](int g, auto slot) {
+      constexpr int S = decltype(slot)::value;
+      static_for<0, KU>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const char* rowp = Wb + (size_t)((unsigned)min(g * KU + j, in - 1) * (unsigned)out) * 4u;
+        static_for<0, UP>([&](auto qc) { ring_load(ring[S][j][decltype(qc)::value], voff[decltype(qc)::value], rowp); });
+      });
+    };
+    static_for<0, NB - 1>([&](auto sc) { if (decltype(sc)::value < ngroups) issue(decltype(sc)::value, sc); });
+    for (int g0 = 0; g0 < ngroups; g0 += NB) {          // groups g0 .. g0 + NB - 1 sit in slots 0 .. NB - 1 (wide class: g0 KU is a multiple of 8, a body never straddles input 128)
+      f2v xs[EPB];
+      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
+        xs[e] = x[e][0];
+        RSB_PRAGMA_UNROLL for (int q = 1; q < UP; ++q) if (((g0 * KU) >> 7) == q) xs[e] = x[e][q];      // (uniform: the register pair that holds this body's inputs)
+      }
+      static_for<0, NB>([&](auto sc) {
+        constexpr int S = decltype(sc)::value;
+        const int g = g0 + S;
+        if (g < ngroups) {
+          // one more group goes into the slot consumed last, then wait until THIS slot's loads - the oldest in flight - have landed
+          int kg;
+          if (g + NB - 1 < ngroups) {
+            issue(g + NB - 1, std::integral_constant<int, (S + NB - 1) % NB>{});
+            kg = ring_wait<(NB - 1) * LOADS>(g * KU);
+          } else {
+            kg = ring_wait<0>(g * KU);
+          }
+          static_for<0, KU>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int k = kg + j;                 // (kg is a multiple of KU: the parity of k is j's - which half of the pair - at compile time)
+            float sx[EPB];
+            RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e)
+              sx[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (j & 1) ? xs[e].y : xs[e].x), (k & 127) >> 1));
+            RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q)
+              RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) acc[e][q] = __builtin_elementwise_fma(ring[S][j][q], f2v{sx[e], sx[e]}, acc[e][q]);
+          });
+        }
+      });
+    }
+    const bool hidden = l + 1 < p.n_layers;
+    RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
+      const bool live = 128 * q + 2 * lane < out;
+      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
+        f2v v = acc[e][q];
+        if (hidden) {
+          RSB_PRAGMA_UNROLL for (int h = 0; h < 2; ++h) {
+            float t = h ? v.y : v.x;
+            t = p.activation == RSB_ACT_TANH ? tanhf(t) : p.activation == RSB_ACT_RELU ? fmaxf(t, 0.f) : (t > 0.f ? t : p.leaky_slope * t);
+            if (h) v.y = t; else v.x = t;
+          }
+        }
+        x[e][q] = live ? v : f2v{0.f, 0.f};         // (pairs past the layer's width loaded clamped weights: zero them, the next layer reads lanes by index)
+      }
+    }
+  }
+  const long long gp = c.pass_global0 + pass;
+  const float* nz = p.noise ? p.noise + (size_t)(gp % (p.noise_period > 0 ? p.noise_period : 1)) * N * ad : nullptr;
+  RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
+    RSB_PRAGMA_UNROLL for (int h = 0; h < 2; ++h) {
+      const int j = 128 * q + 2 * lane + h;
+      if (j < ad) {
+        RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
+          if (e < n_env) {
+            float a = (h ? x[e][q].y : x[e][q].x) + (nz ? nz[(size_t)(env0 + e) * ad + j] : 0.f);
+            if (p.clip > 0.f) a = fminf(fmaxf(a, -p.clip), p.clip);
+            c.act[(size_t)(env0 + e) * ad + j] = a;
+            if (p.rollout_act) p.rollout_act[((size_t)pass * N + env0 + e) * ad + j] = a;
+          }
+        }
+      }
+    }
+  }
+}
+template <int UP>
+__global__ void __launch_bounds__(64) mlp_stage_kernel(const rsb_stage_ctx c, const rsb_mlp_policy p) {
+  // (a block's actions are on the critical path of its next step, the step wave that shares this SIMD is not: issue priority while a block is being served)
+  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) __attribute__((always_inline)) {
+    __builtin_amdgcn_s_setprio(3);
+    mlp_block<UP>(c, p, env0, n_env, pass, final);
+    __builtin_amdgcn_s_setprio(0);
+  });
+}
+int mlp_width(const rsb_mlp_policy& p) { int m = 0; for (int l = 0; l <= p.n_layers; ++l) m = std::max(m, (int)p.dims[l]); return m; }
+int launch_mlp_stage(void* user, const rsb_stage_ctx* c) {
+  const rsb_mlp_policy& p = *static_cast<const rsb_mlp_policy*>(user);
+  const int wd = mlp_width(p);
+  if (wd <= 128) hipLaunchKernelGGL(mlp_stage_kernel<1>, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, p);
+  else hipLaunchKernelGGL(mlp_stage_kernel<2>, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -501,11 +670,13 @@ int closed_loop_lockstep(rsb_world* w, int K, rsb_stage_launch_fn launch, void* 
   return RSB_OK;
 }
 
-int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user, const rsb_linear_policy* lin) {
+int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user, const rsb_linear_policy* lin, const rsb_mlp_policy* mlp = nullptr) {
   const long long pg0 = w->cl_passes;
   w->cl_passes += K;       // (pass K of this run sees what pass 0 of the next one sees: the global index counts steps)
   rsb_linear_policy lin_copy{};
+  rsb_mlp_policy mlp_copy{};
   if (lin) { lin_copy = *lin; user = &lin_copy; launch = launch_linear_stage; }
+  if (mlp) { mlp_copy = *mlp; user = &mlp_copy; launch = launch_mlp_stage; }
   if (!w->pipe_on) return closed_loop_lockstep(w, K, launch, user, pg0);
   // ---- pipelined: ONE launch of the stage for passes 0 .. K on its own stream, K step launches alternating between the two step streams
   hipStream_t s = stream_of(w);        // joins: a run starts from a quiet world (its snapshot is what a fault is replayed from)
@@ -557,7 +728,7 @@ int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user,
   c.stream = w->pipe_stage_stream;
   // the stage's waves: every wave serves a fixed share of at most 64 blocks of its XCD (rsb_stage::serve)
   const int nx = c.xcds > 0 ? c.xcds : 1, per = c.blocks / nx;
-  int T = (w->cl_grid > 0 ? w->cl_grid : kStageGridDefault) / nx;
+  int T = (w->cl_grid > 0 ? w->cl_grid : mlp ? kStageGridMlp : kStageGridDefault) / nx;
   T = std::max(T, (per + 63) / 64);
   T = std::min(std::max(T, 1), per);
   c.grid = T * nx;
@@ -569,6 +740,7 @@ int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user,
   rsb_world::PipeLog e;
   e.closed = true; e.K = K; e.launch = launch; e.user = user; e.pass_global0 = pg0;
   e.is_linear = lin != nullptr; if (lin) e.lin = *lin;
+  e.is_mlp = mlp != nullptr; if (mlp) e.mlp = *mlp;
   w->pipe_log.push_back(e);
   w->pipe_log_suppress = true;
   for (int t = 0; t < K && st == RSB_OK; ++t) {
@@ -673,6 +845,18 @@ int rsb_closed_loop_run_linear(rsb_world* w, int n_steps, const rsb_linear_polic
   int st = cl_check(w, n_steps, "rsb_closed_loop_run_linear"); if (st != RSB_OK) return st;
   if (!policy || !policy->W || (policy->noise && policy->noise_period < 1)) { rsb::set_error("rsb_closed_loop_run_linear: W is required, noise needs noise_period >= 1"); return RSB_E_INVALID; }
   return closed_loop_run(w, n_steps, nullptr, nullptr, policy);
+}
+int rsb_closed_loop_run_mlp(rsb_world* w, int n_steps, const rsb_mlp_policy* p) {
+  int st = cl_check(w, n_steps, "rsb_closed_loop_run_mlp"); if (st != RSB_OK) return st;
+  if (!p || p->n_layers < 1 || p->n_layers > RSB_MLP_MAX_LAYERS) { rsb::set_error("rsb_closed_loop_run_mlp: 1 .. RSB_MLP_MAX_LAYERS layers"); return RSB_E_INVALID; }
+  const int od = 10 + 2 * (w->blob.nv - 6), ad = w->blob.nv - 6;
+  if (p->dims[0] != od || p->dims[p->n_layers] != ad) { rsb::set_error("rsb_closed_loop_run_mlp: dims[0] must be the env's observation size and dims[n_layers] its action size"); return RSB_E_INVALID; }
+  for (int l = 0; l <= p->n_layers; ++l) if (p->dims[l] < 2 || p->dims[l] > 256 || (p->dims[l] & 1)) { rsb::set_error("rsb_closed_loop_run_mlp: layer widths must be even, 2 .. 256 (a lane holds a pair of units)"); return RSB_E_INVALID; }
+  for (int l = 0; l < p->n_layers; ++l) if (!p->Wt[l]) { rsb::set_error("rsb_closed_loop_run_mlp: a layer's weight pointer is null"); return RSB_E_INVALID; }
+  if (p->activation != RSB_ACT_TANH && p->activation != RSB_ACT_RELU && p->activation != RSB_ACT_LEAKY_RELU) { rsb::set_error("rsb_closed_loop_run_mlp: unknown activation"); return RSB_E_INVALID; }
+  if (p->noise && p->noise_period < 1) { rsb::set_error("rsb_closed_loop_run_mlp: noise needs noise_period >= 1"); return RSB_E_INVALID; }
+  if (effective_lpe(w) < 16) { rsb::set_error("rsb_closed_loop_run_mlp: at most four envs per block"); return RSB_E_UNSUPPORTED; }
+  return closed_loop_run(w, n_steps, nullptr, nullptr, nullptr, p);
 }
 int rsb_closed_loop_buffers(rsb_world* w, float** ob, float** act, float** reward, uint8_t** done) {
   int st = cl_check(w, 1, "rsb_closed_loop_buffers"); if (st != RSB_OK) return st;

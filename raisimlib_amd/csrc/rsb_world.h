@@ -154,6 +154,7 @@ struct rsb_world {
     Fuse f; int nsub = 0; uint8_t* done_out = nullptr;
     int K = 0; rsb_stage_launch_fn launch = nullptr; void* user = nullptr; long long pass_global0 = 0;
     bool is_linear = false; rsb_linear_policy lin{};
+    bool is_mlp = false; rsb_mlp_policy mlp{};
   };
   std::vector<PipeLog> pipe_log;
   bool pipe_log_suppress = false;                        // the steps of a closed-loop run are logged as ONE entry

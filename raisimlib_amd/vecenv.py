@@ -178,6 +178,58 @@ class VecEnv:
         self._keep = (W, bias, noise, rollout)       # the launches are asynchronous: keep the tensors alive until the next call
         check(w.L.rsb_closed_loop_run_linear(w.handle, K, C.byref(p)), "rsb_closed_loop_run_linear")
 
+    def rollout_mlp(self, n_steps, layers, activation="leaky_relu", leaky_slope=0.01, ob_mean=None, ob_var=None, ob_clip=10.0, eps=1e-8,
+                    noise=None, clip=0.0, rollout=None):
+        """n_steps control steps with the in-repo MLP stage in the loop (rsb_closed_loop_run_mlp): the actor of a raisimGymTorch-style PPO run.
+        `layers`: [(weight [out, in], bias [out] or None), ...] torch CUDA tensors in torch.nn.Linear's layout (e.g. [(l.weight, l.bias) for l in
+        actor if isinstance(l, torch.nn.Linear)]); hidden layers use `activation` ("tanh" | "relu" | "leaky_relu"), the last one is linear.
+        ob_mean / ob_var [num_obs]: frozen running statistics, the network sees clamp((ob - mean) / sqrt(var + eps), +-ob_clip) (this class's
+        observe_normalized); None: the raw observation.  noise / clip / rollout as rollout_linear.  Nothing synchronises."""
+        import torch
+        w = self.world
+        K, N = int(n_steps), self.num_envs
+        p = _capi.MlpPolicy()
+        p.n_layers = len(layers)
+        if not 1 <= len(layers) <= 4:
+            raise ValueError("rollout_mlp: 1 .. 4 layers")
+        keep = []
+        dims = [self.num_obs]
+        for l, (W, b) in enumerate(layers):
+            self._check_tensor(W, (W.shape[0], dims[-1]), torch.float32, f"layers[{l}].weight")
+            Wt = W.detach().t().contiguous()                # [in, out]: a row = the weights of one input for all units (one coalesced load)
+            keep.append(Wt)
+            p.Wt[l] = Wt.data_ptr()
+            if b is not None:
+                self._check_tensor(b, (W.shape[0],), torch.float32, f"layers[{l}].bias")
+                bb = b.detach().contiguous()
+                keep.append(bb)
+                p.bias[l] = bb.data_ptr()
+            dims.append(int(W.shape[0]))
+        if dims[-1] != self.num_acts:
+            raise ValueError(f"rollout_mlp: the last layer must have {self.num_acts} outputs")
+        for i, d in enumerate(dims):
+            p.dims[i] = d
+        p.activation = {"tanh": 0, "relu": 1, "leaky_relu": 2}[activation]
+        p.leaky_slope = float(leaky_slope)
+        if ob_mean is not None:
+            self._check_tensor(ob_mean, (self.num_obs,), torch.float32, "ob_mean")
+            self._check_tensor(ob_var, (self.num_obs,), torch.float32, "ob_var")
+            inv = torch.rsqrt(ob_var + eps).contiguous()
+            keep += [ob_mean, inv]
+            p.ob_mean, p.ob_inv_std, p.ob_clip = ob_mean.data_ptr(), inv.data_ptr(), float(ob_clip)
+        if noise is not None:
+            self._check_tensor(noise, (noise.shape[0], N, self.num_acts), torch.float32, "noise")
+            p.noise, p.noise_period = noise.data_ptr(), int(noise.shape[0])
+        p.clip = float(clip)
+        if rollout is not None:
+            for key, shape, dt in (("ob", (K + 1, N, self.num_obs), torch.float32), ("act", (K, N, self.num_acts), torch.float32),
+                                   ("reward", (K, N), torch.float32), ("done", (K, N), torch.uint8)):
+                if rollout.get(key) is not None:
+                    self._check_tensor(rollout[key], shape, dt, f"rollout[{key}]")
+                    setattr(p, "rollout_" + key, rollout[key].data_ptr())
+        self._keep = (keep, noise, rollout)          # the launches are asynchronous: keep the tensors alive until the next call
+        check(w.L.rsb_closed_loop_run_mlp(w.handle, K, C.byref(p)), "rsb_closed_loop_run_mlp")
+
     # -- running observation statistics (RaisimGymVecEnv's normalize_ob / RunningMeanStd [RECALL]) -------------------
     def observe_normalized(self, out, update_statistics=True, clip=10.0, eps=1e-8):
         """Observation tensor [num_envs, num_obs] (torch CUDA), normalised in place with running mean / variance kept on

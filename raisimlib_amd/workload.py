@@ -212,6 +212,19 @@ def closed_loop_policy(n_obs, n_act, scale=CLOSED_LOOP_W_SCALE, seed=5):
     return np.random.default_rng(seed).uniform(-scale, scale, (n_act, n_obs)).astype(np.float32)
 
 
+def closed_loop_mlp(n_obs, n_act, hidden=(128, 128), out_scale=CLOSED_LOOP_W_SCALE, seed=6):
+    """the actor of the closed-loop benchmark's MLP leg: raisimGymTorch's default architecture [RECALL: MLP ob -> 128 -> 128 -> act, LeakyReLU],
+    random weights - hidden layers U(+-1/sqrt(fan_in)) as torch.nn.Linear initialises them, the output layer U(+-out_scale) so that the actions stay
+    in the regime of the linear leg (the noise does the exploring) -, zero biases.  Returns [(W [out, in], b [out]), ...] float32."""
+    rng = np.random.default_rng(seed)
+    dims = [n_obs, *hidden, n_act]
+    layers = []
+    for i in range(len(dims) - 1):
+        bound = out_scale if i + 2 == len(dims) else 1.0 / np.sqrt(dims[i])
+        layers.append((rng.uniform(-bound, bound, (dims[i + 1], dims[i])).astype(np.float32), np.zeros(dims[i + 1], np.float32)))
+    return layers
+
+
 def closed_loop_env(model, n_envs, device=0, env_offset=0, stream=None):
     """config 2 as a device-resident vectorised env: ANYmal-like robots on flat ground, dt 0.0025 x 4, PD kp 50 / kd 0.2, action_std 0.3 around
     the nominal joints, non-foot contact -> reset to the env's OWN initial state (per-env base xy / yaw as in the open-loop benchmark)"""

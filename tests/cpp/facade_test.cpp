@@ -193,6 +193,30 @@ int main(int argc, char** argv) {
       CHECK(moved > 256);
       std::printf("DeviceVectorizedEnvironment::rolloutLinear: 65 control steps x 512 envs, pipelined == lock-step bit for bit\n");
     }
+    // ---- ... and with an actor network (34 -> 64 -> 32 -> 12, tanh) as the stage
+    {
+      const std::vector<int> dims = {34, 64, 32, 12};
+      std::vector<std::vector<float>> Wm(3), Bm(3);
+      unsigned ws = 4242u;
+      for (int l = 0; l < 3; ++l) {
+        Wm[l].resize((size_t)dims[l] * dims[l + 1]); Bm[l].assign(dims[l + 1], 0.01f * (l + 1));
+        const float bound = (l == 2 ? 0.5f : 1.0f) / std::sqrt((float)dims[l]);
+        for (auto& x : Wm[l]) { ws = ws * 1664525u + 1013904223u; x = ((ws >> 8) / 16777216.0f - 0.5f) * 2.0f * bound; }
+      }
+      const std::vector<const float*> wp = {Wm[0].data(), Wm[1].data(), Wm[2].data()}, bp = {Bm[0].data(), Bm[1].data(), Bm[2].data()};
+      std::vector<float> obA((size_t)512 * 34), obB((size_t)512 * 34);
+      for (int pipe = 0; pipe < 2; ++pipe) {
+        raisim::DeviceVectorizedEnvironment cl(urdf, cfg);
+        cl.init();
+        cl.setStepPipelining(pipe != 0);
+        cl.rolloutMlp(30, dims, wp, bp, RSB_ACT_TANH, 2.0f);
+        cl.rolloutMlp(20, dims, wp, bp, RSB_ACT_TANH, 2.0f);
+        CHECK(cl.join() == RSB_OK);
+        cl.observe(pipe ? obB.data() : obA.data(), 512, 34);
+      }
+      for (size_t i = 0; i < obA.size(); ++i) { CHECK(obA[i] == obB[i]); CHECK(std::isfinite(obA[i])); }
+      std::printf("DeviceVectorizedEnvironment::rolloutMlp: 50 control steps x 512 envs, pipelined == lock-step bit for bit\n");
+    }
 
     // ---- N per-env World VIEWS of one batch: N integrate() calls = ONE launch in which every replica advances once
     {

@@ -247,6 +247,77 @@ def test_no_trap_instruction_in_the_pipelined_classes(tmp_path):
         assert not re.search(r"\bs_trap\b", f.read_text()), f
     # the stage stays small enough to share a SIMD with a step wave (96 of 512 registers left, no LDS)
     txt = b.read_text()
-    i = txt.index("linear_stage_kernel", txt.index("amdhsa.kernels"))
-    blk = txt[i:i + 1500]
-    assert int(re.search(r"\.vgpr_count:\s*(\d+)", blk).group(1)) <= 96
+    meta = txt[txt.index("amdhsa.kernels"):]
+    seen = 0
+    for blk in meta.split("- .agpr_count")[1:]:
+        if "stage_kernel" not in re.search(r"\.name:\s+(\S+)", blk).group(1):
+            continue
+        seen += 1
+        assert int(re.search(r"\.vgpr_count:\s*(\d+)", blk).group(1)) <= 96, blk[:400]
+        assert int(re.search(r"\.group_segment_fixed_size:\s*(\d+)", blk).group(1)) == 0 and int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1)) == 0
+    assert seen == 3          # the linear stage and the MLP stage's two width classes
+
+
+@pytest.mark.parametrize("n,lpe,hidden,act,normalise,runs,K", [(4096, 0, (128, 128), "leaky_relu", True, 3, 100), (1000, 0, (64,), "tanh", False, 2, 40),
+                                                              (512, 32, (256, 256), "relu", True, 2, 30), (300, 64, (50, 20, 34), "tanh", False, 2, 25)])
+def test_mlp_stage_pipelined_equals_lockstep_and_matches_torch(built_lib, anymal, n, lpe, hidden, act, normalise, runs, K):
+    """rsb_closed_loop_run_mlp: the actor of a raisimGymTorch-style PPO run (upstream's default 128-128 LeakyReLU; also one hidden layer, the widest
+    class, widths that are no multiple of four) as the action stage.  (a) pipelined == lock-step bit for bit - every row of every step's rollout
+    and the final state -, with resets; (b) the recorded actions equal a torch fp32 forward pass over the recorded observations (+ the noise) to
+    rounding: the stage IS the network."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    dims = [34, *hidden, 12]
+    layers = []
+    for i in range(len(dims) - 1):
+        bound = (0.25 if i + 2 == len(dims) else 1.0) / np.sqrt(dims[i])
+        layers.append((((torch.rand((dims[i + 1], dims[i]), generator=g) * 2 - 1) * bound).to(dev), ((torch.rand(dims[i + 1], generator=g) * 2 - 1) * 0.1).to(dev)))
+    mean = (torch.rand(34, generator=g) * 0.2 - 0.1).to(dev) if normalise else None
+    var = (torch.rand(34, generator=g) * 2 + 0.05).to(dev) if normalise else None
+    noise = torch.from_numpy(workload.closed_loop_noise(n, 16)).to(dev)
+    f = {"tanh": torch.tanh, "relu": torch.relu, "leaky_relu": lambda v: torch.nn.functional.leaky_relu(v, 0.01)}[act]
+
+    def forward(ob):
+        x = ob.double()
+        if normalise:
+            x = torch.clamp((x - mean.double()) * torch.rsqrt(var + 1e-8).double(), -10.0, 10.0)
+        for i, (W, b) in enumerate(layers):
+            x = x @ W.double().t() + b.double()
+            if i + 1 < len(layers):
+                x = f(x)
+        return x
+
+    envs = {}
+    for pipe in (False, True):
+        env = workload.closed_loop_env(anymal, n)
+        if lpe:
+            env.world.set_lanes_per_env(lpe)
+        assert env.world.set_step_pipelining(pipe) == pipe
+        envs[pipe] = env
+    resets = 0
+    for r in range(runs):
+        ro = {}
+        for pipe in (False, True):
+            env = envs[pipe]
+            ro[pipe] = {"ob": torch.zeros((K + 1, n, 34), device=dev), "act": torch.zeros((K, n, 12), device=dev),
+                        "reward": torch.zeros((K, n), device=dev), "done": torch.zeros((K, n), dtype=torch.uint8, device=dev)}
+            env.rollout_mlp(K, layers, activation=act, ob_mean=mean, ob_var=var, noise=noise, clip=3.0, rollout=ro[pipe])
+            env.world.step_pipeline_join()
+        for key in ro[False]:
+            assert torch.equal(ro[False][key], ro[True][key]), (r, key)
+        resets += int(ro[True]["done"].sum().item())
+        t = torch.arange(K, device=dev)
+        nz = noise[(r * K + t) % noise.shape[0]]
+        want = torch.clamp(forward(ro[True]["ob"][:K]) + nz.double(), -3.0, 3.0)
+        err = (ro[True]["act"].double() - want).abs().max().item()
+        assert err < 2e-5, err
+        assert bool(torch.isfinite(ro[True]["ob"]).all())
+    qa, ua = envs[False].world.get_state()
+    qb, ub = envs[True].world.get_state()
+    assert np.array_equal(qa, qb) and np.array_equal(ua, ub)
+    assert resets > 0
+    assert envs[True].world.step_pipelining_stats()[0] == runs * K and envs[True].world.step_pipeline_fault() == (0, 0)
+    for e in envs.values():
+        e.close()
+

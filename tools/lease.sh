@@ -35,7 +35,8 @@ try:
     c = d.get("closed_loop") or {}
     print("bench:", {k: (round(v) if isinstance(v, float) and v > 1e3 else v) for k, v in d.items() if k in ("value", "ms_per_step", "n_gpus")},
           "lockstep", round(((d.get("lockstep") or {}).get("value") or 0)),
-          "closed_loop", {m: round((c.get(m) or {}).get("value") or 0) for m in ("pipelined", "lockstep")} if c else None, c.get("error"))
+          "closed_loop", {m: round((c.get(m) or {}).get("value") or 0) for m in ("pipelined", "lockstep")} if c else None,
+          "mlp", {m: round(((c.get("mlp") or {}).get(m) or {}).get("value") or 0) for m in ("pipelined", "lockstep")} if c.get("mlp") else None, c.get("error"))
 except Exception as e:
     print("bench: no JSON line (", e, ")")
 PY
