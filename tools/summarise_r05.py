@@ -159,17 +159,22 @@ open(os.path.join(P, f"{tag}_pmc_summary_config5.txt"), "w").write(
 rows = list(csv.DictReader(open(os.path.join(F("trace_closed"), "run_kernel_trace.csv"))))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 cl = json.load(open(F("closed300", ".json")))["closed_loop"]
-stage = [r for r in rows if "stage_kernel" in r["Kernel_Name"]]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-pers = [r for r in stage if dur(r) > 400]
-txt = [f"closed loop (bench.py --closed-loop-only, {tag}): pipelined {cl['pipelined']['value'] / 1e6:.1f} M env-steps/s ({cl['pipelined']['ms_per_step'] * 1e3:.1f} us per control step), lock-step {cl['lockstep']['value'] / 1e6:.1f} M",
-       f"  kernel trace of the same command: {len(pers)} persistent launches of the action stage (one per run; {', '.join(f'{dur(r) / 1e3:.2f} ms' for r in pers)}), {len(stage) - len(pers)} per-pass launches of the lock-step leg (mean {np.mean([dur(r) for r in stage if dur(r) <= 400]):.1f} us)"]
-if pers:
-    p = max(pers, key=dur)
-    s0, e0 = int(p["Start_Timestamp"]), int(p["End_Timestamp"])
-    st = [r for r in rows if "rsb_step_kernel" in r["Kernel_Name"] and int(r["Start_Timestamp"]) >= s0 and int(r["End_Timestamp"]) <= e0 + 1000]
-    d = np.array([dur(r) for r in st]); starts = np.array([int(r["Start_Timestamp"]) for r in st]); ends = np.array([int(r["End_Timestamp"]) for r in st])
-    txt.append(f"  longest run: {len(st)} step launches inside the stage's {dur(p) / 1e3:.2f} ms; start -> end mean {d.mean():.1f} us, one completes every {(ends.max() - starts.min()) / 1e3 / len(st):.1f} us; "
-               f"{100 * np.mean(starts[1:] < ends[:-1]):.0f} % start before their predecessor has ended")
+txt = []
+for kind, key, blk in (("linear policy 12 x 34", "linear_stage_kernel", cl), ("actor network 34-128-128-12", "mlp_stage_kernel", cl.get("mlp"))):
+    if not blk or not blk.get("pipelined"):
+        continue
+    stage = [r for r in rows if key in r["Kernel_Name"]]
+    pers = [r for r in stage if dur(r) > 400]
+    short = [dur(r) for r in stage if dur(r) <= 400]
+    txt += [f"closed loop, stage = {kind} (bench.py --closed-loop-only, {tag}): pipelined {blk['pipelined']['value'] / 1e6:.1f} M env-steps/s ({blk['pipelined']['ms_per_step'] * 1e3:.1f} us per control step), lock-step {blk['lockstep']['value'] / 1e6:.1f} M",
+            f"  kernel trace of the same command: {len(pers)} persistent launches of the action stage (one per run; {', '.join(f'{dur(r) / 1e3:.2f} ms' for r in pers)}), {len(short)} per-pass launches of the lock-step leg (mean {np.mean(short) if short else 0:.1f} us)"]
+    if pers:
+        p = max(pers, key=dur)
+        s0, e0 = int(p["Start_Timestamp"]), int(p["End_Timestamp"])
+        st = [r for r in rows if "rsb_step_kernel" in r["Kernel_Name"] and int(r["Start_Timestamp"]) >= s0 and int(r["End_Timestamp"]) <= e0 + 1000]
+        d = np.array([dur(r) for r in st]); starts = np.array([int(r["Start_Timestamp"]) for r in st]); ends = np.array([int(r["End_Timestamp"]) for r in st])
+        txt.append(f"  longest run: {len(st)} step launches inside the stage's {dur(p) / 1e3:.2f} ms; start -> end mean {d.mean():.1f} us, one completes every {(ends.max() - starts.min()) / 1e3 / len(st):.1f} us; "
+                   f"{100 * np.mean(starts[1:] < ends[:-1]):.0f} % start before their predecessor has ended")
 open(os.path.join(P, f"{tag}_closed_loop_trace_summary.txt"), "w").write("\n".join(txt) + "\n")
 print("\n".join(txt))
