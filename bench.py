@@ -23,6 +23,16 @@ next to it.  The same pass counts resets per step and the env-age distribution (
 Output: ONE JSON line on rank 0 with `roofline` (HBM; SURVEY.md §8d algorithmic bytes per env-step x env-steps per launch
 over the step kernel's mean launch duration) and `cpu_baseline` (the in-repo fp64 oracle, OpenMP over envs on the host
 cores, started from the GPU population's state at the start of the timed region; rank 0, N=1 only).
+
+What else the default single-GPU line carries (round 4-5):
+  value / lockstep      the timed region with consecutive control steps pipelined on the device (rsb_set_step_pipelining) and, same bracket,
+                        with every launch waiting for the one before it; roofline.frac_throughput / frac_kernel_duration say which time each
+                        fraction divides by; below 64 steps every launch of the timed region is bracketed (stride 1)
+  closed_loop           the same workload with a POLICY IN THE LOOP (rsb_closed_loop_run_*: an action stage between every two steps, handed over
+                        env block by env block): the linear reference stage and, under `mlp`, an actor network 34-128-128-12; pipelined and lock-step
+  secondary             configs 3 and 5 with the same --steps / --warmup;  boundary_template_path: the pybind gym module over Environment.hpp
+N > 1 (--gpus N): leg 1 = lock-step + in-line all-gather (must succeed), leg 2 = pipelined + gather on a side stream (under a guard); `value_leg`,
+`pipelined_leg_error` and the `rccl` block (rank count, device ids) say what ran.
 """
 import argparse
 import json
