@@ -353,8 +353,6 @@ int pipe_begin_launch(rsb_world* w, StepArgs& a, int blocks, bool closed_loop, h
   a.pipe_stride = w->pipe_stride;
   { static const bool stats = std::getenv("RSB_PIPE_STATS") != nullptr; a.pipe_stats = stats ? stats_ptr(w) : nullptr; }
   a.pipe_wait_ptr = closed_loop ? w->d_pipe_prog + (size_t)blocks * w->pipe_stride : w->d_pipe_prog;
-  { static const bool nowait = std::getenv("RSB_X_CL_NOWAIT") != nullptr;      // experiment (WRONG results): closed-loop steps wait for their own predecessor, not for the stage
-    if (nowait) a.pipe_wait_ptr = w->d_pipe_prog; }
   a.pipe_wait_on = (closed_loop || w->pipe_n > 0) ? 1 : 0;
   a.pipe_wait = (int)w->pipe_seq; a.pipe_seq = (int)(w->pipe_seq + 1u);
   a.pipe_xcds = (w->pipe_xcds > 0 && blocks % w->pipe_xcds == 0) ? w->pipe_xcds : 0;
@@ -437,7 +435,7 @@ __global__ void __launch_bounds__(64) linear_stage_kernel(const rsb_stage_ctx c,
     const int od = c.ob_dim, ad = c.act_dim;
     const size_t N = (size_t)c.n_envs;
     record_rollout(c, p.rollout_ob, p.rollout_reward, p.rollout_done, env0, n_env, pass);
-    if (final || p.clip == -777.f) return;      // (clip -777: experiment - a stage that only hands over)
+    if (final) return;
     const long long gp = c.pass_global0 + pass;
     const float* nz = p.noise ? p.noise + (size_t)(gp % (p.noise_period > 0 ? p.noise_period : 1)) * N * ad : nullptr;
     constexpr int CH = 16;     // terms of the sum loaded together (weights and observation entries: 32 loads in flight, then 16 FMAs in index order)

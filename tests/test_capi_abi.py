@@ -47,6 +47,29 @@ def test_struct_layouts_match(built_lib):
     assert C.sizeof(_capi.Contact) == 48
 
 
+def test_policy_struct_mirrors_have_the_c_layout(tmp_path):
+    """rsb_linear_policy / rsb_mlp_policy are passed by pointer from Python: the ctypes mirrors must have the C compiler's sizes and field offsets."""
+    import subprocess
+    from raisimlib_amd import _capi
+    src = tmp_path / "sizes.c"
+    src.write_text(r'''#include <stdio.h>
+#include <stddef.h>
+#include "rsb.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(rsb_linear_policy), offsetof(rsb_linear_policy, clip), offsetof(rsb_linear_policy, rollout_done), sizeof(rsb_contact));
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(rsb_mlp_policy), offsetof(rsb_mlp_policy, Wt), offsetof(rsb_mlp_policy, activation), offsetof(rsb_mlp_policy, ob_mean),
+         offsetof(rsb_mlp_policy, noise_period), offsetof(rsb_mlp_policy, rollout_done));
+  return 0;
+}
+''')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    a, b = (list(map(int, l.split())) for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines())
+    L, M = _capi.LinearPolicy, _capi.MlpPolicy
+    assert a == [C.sizeof(L), L.clip.offset, L.rollout_done.offset, C.sizeof(_capi.Contact)]
+    assert b == [C.sizeof(M), M.Wt.offset, M.activation.offset, M.ob_mean.offset, M.noise_period.offset, M.rollout_done.offset]
+
+
 def test_no_cpu_fallback(built_lib):
     """Without a GPU rsb_create must fail loudly (RSB_E_NO_DEVICE), never fall back to a CPU path."""
     from raisimlib_amd import BatchedWorld, Model, RsbError, rsc_path

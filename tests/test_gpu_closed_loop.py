@@ -321,3 +321,47 @@ def test_mlp_stage_pipelined_equals_lockstep_and_matches_torch(built_lib, anymal
     for e in envs.values():
         e.close()
 
+
+
+def test_mlp_stage_refuses_what_it_cannot_run_and_device_memory_helpers(built_lib, anymal):
+    """Argument checks of rsb_closed_loop_run_mlp (layer count, odd or oversized widths, dims that do not match the env, a missing weight pointer, noise
+    without a period) return RSB_E_INVALID with a message and leave the world usable; rsb_device_alloc / _copy / _free round-trip host data."""
+    import torch
+    from raisimlib_amd import _capi
+    env = workload.closed_loop_env(anymal, 64)
+    w, L = env.world, env.world.L
+    dev = torch.device("cuda:0")
+    Wt = torch.zeros((256, 256), device=dev)
+
+    def policy(dims, missing=None):
+        p = _capi.MlpPolicy()
+        p.n_layers = len(dims) - 1
+        for i, d in enumerate(dims[:5]):
+            p.dims[i] = d
+        for l in range(min(p.n_layers, 4)):
+            if l != missing:
+                p.Wt[l] = Wt.data_ptr()
+        p.activation = 0
+        return p
+    bad = [policy([34]), policy([34, 8, 8, 8, 8, 12]), policy([34, 33, 12]), policy([34, 258, 12]), policy([32, 16, 12]), policy([34, 16, 10]), policy([34, 16, 12], missing=1)]
+    noisy = policy([34, 16, 12]); noisy.noise = Wt.data_ptr(); noisy.noise_period = 0
+    act = policy([34, 16, 12]); act.activation = 7
+    for p in bad + [noisy, act]:
+        assert L.rsb_closed_loop_run_mlp(w.handle, 5, C.byref(p)) == -1          # RSB_E_INVALID
+        assert b"rsb_closed_loop_run_mlp" in L.rsb_last_error()
+    assert L.rsb_closed_loop_run_mlp(w.handle, 0, C.byref(policy([34, 16, 12]))) == -1
+    assert L.rsb_closed_loop_run_mlp(w.handle, 5, C.byref(policy([34, 16, 12]))) == 0      # ... and a valid one runs (zero weights: zero actions)
+    w.step_pipeline_join()
+    q, _ = w.get_state()
+    assert np.isfinite(q).all()
+    # device memory for callers without a HIP runtime of their own
+    host = np.arange(1000, dtype=np.float32)
+    back = np.zeros_like(host)
+    ptr = C.c_void_p()
+    assert L.rsb_device_alloc(w.handle, host.nbytes, C.byref(ptr)) == 0 and ptr.value
+    assert L.rsb_device_copy(w.handle, ptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 0) == 0
+    assert L.rsb_device_copy(w.handle, back.ctypes.data_as(C.c_void_p), ptr, host.nbytes, 1) == 0
+    assert np.array_equal(host, back)
+    assert L.rsb_device_copy(w.handle, ptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 2) == -1
+    assert L.rsb_device_free(w.handle, ptr) == 0 and L.rsb_device_alloc(w.handle, 0, C.byref(ptr)) == -1
+    env.close()

@@ -63,7 +63,7 @@ for g in grids:
             env.world.step_pipeline_join()
             if pipe:
                 env.world.debug_pipeline_wait_stats()
-            v = rate(lambda k: env.rollout_linear(k, W, noise=noise, clip=float(os.environ.get('X_CLIP', 0))), env.world.step_pipeline_join, K)
+            v = rate(lambda k: env.rollout_linear(k, W, noise=noise, clip=0.0), env.world.step_pipeline_join, K)
             st = env.world.debug_pipeline_wait_stats() if pipe else (0, 0)
             print(f"closed loop {'pipelined' if pipe else 'lock-step'} (stage grid {g or 'default'}): {v:7.1f} M env-steps/s   wait {st[0]:6.2f} us/workgroup, waited {st[1]:.2f}   faults {env.world.step_pipeline_fault()}", flush=True)
         env.close()
