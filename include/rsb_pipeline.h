@@ -13,8 +13,8 @@
  *     step k+1, workgroup b : waits for act_prog[b] = seq(k), reads block b's action rows, integrates ...
  *
  * Block b never waits for another block: a robot that has just fallen onto a knee (three times the solver sweeps) delays its own block
- * only.  The action stage is a kernel of the CALLER - this header is its device-side half - or the in-repo reference stage (a fixed
- * linear policy, rsb_closed_loop_run_linear).
+ * only.  The action stage is a kernel of the CALLER - this header is its device-side half - or one of the in-repo stages: a fixed
+ * linear policy (rsb_closed_loop_run_linear) or an actor network (rsb_closed_loop_run_mlp).
  *
  * The action stage is ONE launch per run of K steps: `grid` workgroups of 64 threads that stay resident next to the step kernel's
  * waves (which leave 96 VGPRs per SIMD lane and no LDS: keep a stage under 96 VGPRs, no LDS, or it takes SIMDs from the steps),
@@ -129,16 +129,17 @@ int rsb_closed_loop_run_linear(struct rsb_world* w, int n_steps, const rsb_linea
 /* The in-repo MLP stage: the actor network of a raisimGymTorch-style PPO run (upstream's default: MLP ob -> 128 -> 128 -> act, LeakyReLU
  * [RECALL raisimGymTorch/algo/ppo/module.py; absent from /root/reference]) evaluated per env block between every two control steps - the policy
  * a rollout actually has in its loop.  All pointers device memory; any but Wt may be NULL.
- *   layer l:  y = f(W_l x + b_l),  dims[0] = ob_dim, dims[n_layers] = act_dim, 1 <= n_layers <= RSB_MLP_MAX_LAYERS, every width even and <= 256;
+ *   layer l:  y = f(W_l x + b_l),  dims[0] = ob_dim, dims[n_layers] = act_dim, 1 <= n_layers <= RSB_MLP_MAX_LAYERS, every width <= 256;
  *             hidden layers use `activation`, the last layer is linear;
- *   Wt[l]     the layer's weight TRANSPOSED: [dims[l], dims[l + 1]] row-major (torch: linear.weight.t().contiguous()), 8-byte aligned - units
- *             2 s, 2 s + 1 of a layer are lane s of the stage's wave, so a row of Wt is one coalesced 8-byte load per lane;  bias[l] [dims[l + 1]];
+ *   Wt[l]     the layer's weight TRANSPOSED: [dims[l], dims[l + 1]] row-major (torch: linear.weight.t().contiguous()) - unit u of a layer is lane
+ *             u & 63 of the stage's wave, so a row of Wt is one coalesced load and the B operand of a matrix instruction as it stands;  bias[l] [dims[l + 1]];
  *   input     x = clamp((ob - ob_mean) * ob_inv_std, -ob_clip, ob_clip)  (RaisimGymVecEnv's normalize_ob with frozen statistics [RECALL];
  *             ob_mean / ob_inv_std [ob_dim], NULL: the raw observation; ob_clip <= 0: none);
  *   output    action = clip(y + noise[pass % noise_period]), noise [noise_period, n_envs, act_dim] (pre-sampled exploration noise), clip <= 0: none;
  *   rollout   as rsb_linear_policy's.
- * Arithmetic: fp32 FMAs in input-index order, the same instruction sequence pipelined and in lock-step (bit-identical runs); against a torch
- * fp32 forward pass the actions agree to rounding (tests/test_gpu_closed_loop.py). */
+ * Arithmetic: fp32 on the matrix cores (v_mfma_f32_4x4x1_16B_f32: a block's four envs x 64 units per instruction, one rank-1 update per input in
+ * index order), the same instruction sequence pipelined and in lock-step (bit-identical runs); against a torch fp32 forward pass the actions agree
+ * to rounding (tests/test_gpu_closed_loop.py). */
 #define RSB_MLP_MAX_LAYERS 4
 #define RSB_ACT_TANH 0
 #define RSB_ACT_RELU 1

@@ -462,162 +462,154 @@ int launch_linear_stage(void* user, const rsb_stage_ctx* c) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// ---- the in-repo MLP stage (rsb_mlp_policy): the actor network of a PPO rollout, per env block ------------------------------------------
-// lane = unit pair: units 2 s, 2 s + 1 (+ 128 per further register pair) of a layer are lane s; the (up to four) envs of the block are four
-// accumulator pairs per unit pair.  A layer walks its inputs in index order: input k of env e sits in lane (k & 127) >> 1 of x[e][(k & 1) + 2 (k >> 7)]
-// - where the layer before left it - and reaches every lane as a scalar (v_readlane); its weights for a lane's pair are ONE 8-byte load of the
-// transposed matrix (64 lanes: 512 contiguous bytes), loaded once per block whatever the number of envs, and feed one v_pk_fma_f32 per env.
-// What bounds it is LATENCY: a stage wave has nobody to hide a load behind and 96 registers to park loads in (no LDS: the step kernel's workgroups
-// own all of it; 96 registers: what a step wave leaves of its SIMD - tests/test_gpu_closed_loop.py reads both off the ISA).  The weight rows
-// therefore run through a RING of NB groups of KU rows with explicit loads and waits (inline asm: the compiler's own schedule waited for every
-// group - 34 us per block in the first version, 19 us with a double buffer it re-serialised; the steps starved for their actions): NB - 1 groups
-// are in flight while one is consumed.
-typedef float f2v __attribute__((ext_vector_type(2)));
+// ---- the in-repo MLP stage (rsb_mlp_policy): the actor network of a PPO rollout, per env block, on the matrix cores ------------------------
+// A block is FOUR envs: y[unit][env] += W[unit][k] x[k][env] is a rank-1 update of a (units x 4) matrix per input k - v_mfma_f32_4x4x1_16B_f32
+// does sixteen 4 x 4 blocks of it at once = 64 units x 4 envs per instruction, every multiplier busy:
+//   B (1 x 4 per block, lane 4 b + j)  = the weights of input k for units 4 b + j: lane = unit, ONE coalesced row of the transposed matrix;
+//   A (4 x 1 per block, lane 4 b' + i) = the four envs' input k - the same for all sixteen blocks: the instruction's A-BROADCAST (cbsz 4, abid q)
+//                                        feeds every block from quad q of the register, so ONE register holds sixteen inputs x four envs
+//                                        (lane l: env l & 3, input 16 r + (l >> 2)) and nothing is broadcast by hand;
+//   D (4 x 4 per block)                = register i: env i, lane = unit - the layout the activation, the bias and the action rows want.
+// (tools/ubench/mfma_4x4_bcast.hip reads both layouts and the broadcast off the hardware.)  Between two layers the (env, unit) registers are
+// turned into (input, env) registers by ds_bpermute (the LDS crossbar, no LDS memory: the step kernel's workgroups own all of it).
+// The first versions ran on the vector ALU: the input had to become a scalar per env (v_readlane) - 65 cycles per input row, half of them
+// the readlanes (tools/ubench/mlp_inner.hip), 20 us per block; here a row is two matrix instructions.
+// The weight rows still come from L2 (the stage has nowhere to keep 89 KB) through a RING of NB groups of KU rows with explicit loads and waits
+// (inline asm: the compiler's own schedule waited for every group): NB - 1 groups are in flight while one is consumed.  No LDS memory, <= 96
+// registers: what a step wave leaves of its SIMD (tests/test_gpu_closed_loop.py reads both off the ISA).
+typedef float f4v __attribute__((ext_vector_type(4)));
 template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {      // f(integral_constant<int, I>) for I = 0 .. N - 1: register-array indices stay compile-time
+__device__ __forceinline__ void static_for(F&& f) {      // f(integral_constant<int, I>) for I = 0 .. N - 1: register indices and abid stay compile-time
   if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
-// explicit loads and waits of the ring (the operands tie the wait to the registers it guards: nothing that reads them moves above it)
-__device__ __forceinline__ void ring_load(f2v& dst, unsigned voff, const char* sbase) {
-  asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+__device__ __forceinline__ void ring_load(float& dst, unsigned voff, const char* sbase) {
+  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
-// ... and the wait hands the group's first input index THROUGH itself: the v_readlanes of the group's inputs - and with them every FMA that
-// reads the ring - depend on its result, so none of them moves above it (tying the ring registers to the wait instead made the register allocator
-// copy each of them: + 2 v_mov per row)
+// the wait passes the group's INPUT REGISTER through itself (a tied operand, no instruction): every matrix instruction of the group reads it, so
+// none of them moves above the wait (tying the ring registers cost 2 v_mov per row, tying the accumulators 8 v_accvgpr_mov per group)
 template <int CNT>
-__device__ __forceinline__ int ring_wait(int k_first) {
-  int r;
-  asm volatile("s_waitcnt vmcnt(%1)\n\ts_mov_b32 %0, %2" : "=s"(r) : "n"(CNT), "s"(k_first));
-  return r;
+__device__ __forceinline__ void ring_wait(float& xr) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr) : "n"(CNT));
 }
-template <int UP>       // register pairs per lane: layer widths up to 128 UP
+template <int NS>       // sets of 64 units: layer widths up to 64 NS
 __device__ __forceinline__ void mlp_block(const rsb_stage_ctx& c, const rsb_mlp_policy& p, int env0, int n_env, int pass, bool final) {
-  constexpr int EPB = 4;                      // envs per block (64 / lanes_per_env <= 4)
-  constexpr int KU = 4 / UP;                  // weight rows per group (4 register pairs)
-  constexpr int NB = UP == 2 ? 2 : 6;         // groups in the ring: 4 / 24 rows = 16 / 48 registers (the wide class holds 40 registers of state, and its bodies must divide 128)
-  constexpr int LOADS = KU * UP;              // loads per group (4)
+  constexpr int XR = 4 * NS;                  // input registers: 16 inputs x 4 envs each
+  constexpr int KU = NS == 2 ? 4 : 2;         // weight rows per group (8 loads)
+  constexpr int NB = NS == 2 ? 5 : 2;         // groups in the ring: 16 / 2 rows in flight = 40 / 16 registers
+  constexpr int LOADS = KU * NS;
   const int lane = (int)threadIdx.x;
   const int od = c.ob_dim, ad = c.act_dim;
   const size_t N = (size_t)c.n_envs;
   record_rollout(c, p.rollout_ob, p.rollout_reward, p.rollout_done, env0, n_env, pass);
   if (final) return;
-  f2v x[EPB][UP];
-  RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
-    float v2[EPB][2];
-    RSB_PRAGMA_UNROLL for (int h = 0; h < 2; ++h) {
-      const int k = 128 * q + 2 * lane + h;
-      const float m = (p.ob_mean && k < od) ? p.ob_mean[k] : 0.f, is = (p.ob_inv_std && k < od) ? p.ob_inv_std[k] : 1.f;
-      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
-        float v = (k < od && e < n_env) ? c.ob[(size_t)(env0 + e) * od + k] : 0.f;
-        v = (v - m) * is;
-        if (p.ob_clip > 0.f) v = fminf(fmaxf(v, -p.ob_clip), p.ob_clip);
-        v2[e][h] = k < od ? v : 0.f;
-      }
+  const int le = lane & 3, lq = lane >> 2;    // this lane's env and input slot in an input register
+  float x[XR];
+  RSB_PRAGMA_UNROLL for (int r = 0; r < XR; ++r) {
+    const int k = 16 * r + lq;
+    float v = 0.f;
+    if (k < od && le < n_env) {
+      v = c.ob[(size_t)(env0 + le) * od + k];
+      if (p.ob_mean) v -= p.ob_mean[k];
+      if (p.ob_inv_std) v *= p.ob_inv_std[k];
+      if (p.ob_clip > 0.f) v = fminf(fmaxf(v, -p.ob_clip), p.ob_clip);
     }
-    RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) x[e][q] = f2v{v2[e][0], v2[e][1]};
+    x[r] = v;
   }
+  f4v acc[NS];                                // [set][env]: unit 64 s + lane
   for (int l = 0; l < p.n_layers; ++l) {
-    const int in = p.dims[l], out = p.dims[l + 1];      // (both even: rsb_closed_loop_run_mlp checks)
+    const int in = p.dims[l], out = p.dims[l + 1];
     const char* Wb = reinterpret_cast<const char*>(p.Wt[l]);
-    unsigned voff[UP];
-    f2v acc[EPB][UP];
-    RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
-      const int u = 128 * q + 2 * lane;
-      voff[q] = 4u * (unsigned)min(u, out - 2);    // byte offset of the pair in a row (clamped: no load is predicated; pairs past the layer's width are zeroed below)
-      const f2v b = (p.bias[l] && u < out) ? f2v{p.bias[l][u], p.bias[l][u + 1]} : f2v{0.f, 0.f};
-      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) acc[e][q] = b;
+    unsigned voff[NS];
+    RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) {
+      const int u = 64 * s + lane;
+      voff[s] = 4u * (unsigned)min(u, out - 1);      // byte offset in a row (clamped: no load is predicated; units past the layer's width are zeroed below)
+      const float b = (p.bias[l] && u < out) ? p.bias[l][u] : 0.f;
+      acc[s] = f4v{b, b, b, b};
     }
-    f2v ring[NB][KU][UP];
-    const int ngroups = (in + KU - 1) / KU;
-    // (rows past the end are clamped and meet zero inputs; uniform 64-bit row base in SGPRs + 32-bit lane offset: no address registers)
-    auto issue = [&](int g, auto slot) {
-      constexpr int S = decltype(slot)::value;
+    float ring[NB][KU][NS];
+    // Rows run in chunks of 16 (one input register): a chunk that starts at or past `in` ends the layer, inside a chunk nothing branches - a lone
+    // wave pays 20-45 cycles per branch, a group's eight matrix instructions 64.  Rows past the end are clamped to the last one and meet zero inputs
+    // (so do the few groups the ring fetches ahead of the last chunk).  Uniform 64-bit row base in SGPRs + 32-bit lane offset: no address registers.
+    const unsigned rowbytes = 4u * (unsigned)out;
+    const int last = in - 1;
+    auto issue = [&](auto gc, auto slot) {
+      constexpr int g = decltype(gc)::value, S = decltype(slot)::value;
       static_for<0, KU>([&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const char* rowp = Wb + (size_t)((unsigned)min(g * KU + j, in - 1) * (unsigned)out) * 4u;
-        static_for<0, UP>([&](auto qc) { ring_load(ring[S][j][decltype(qc)::value], voff[decltype(qc)::value], rowp); });
+        const char* rowp = Wb + (size_t)((unsigned)min(g * KU + j, last) * rowbytes);
+        static_for<0, NS>([&](auto sc) { ring_load(ring[S][j][decltype(sc)::value], voff[decltype(sc)::value], rowp); });
       });
     };
-    static_for<0, NB - 1>([&](auto sc) { if (decltype(sc)::value < ngroups) issue(decltype(sc)::value, sc); });
-    for (int g0 = 0; g0 < ngroups; g0 += NB) {          // groups g0 .. g0 + NB - 1 sit in slots 0 .. NB - 1 (wide class: g0 KU is a multiple of 8, a body never straddles input 128)
-      f2v xs[EPB];
-      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
-        xs[e] = x[e][0];
-        RSB_PRAGMA_UNROLL for (int q = 1; q < UP; ++q) if (((g0 * KU) >> 7) == q) xs[e] = x[e][q];      // (uniform: the register pair that holds this body's inputs)
-      }
-      static_for<0, NB>([&](auto sc) {
-        constexpr int S = decltype(sc)::value;
-        const int g = g0 + S;
-        if (g < ngroups) {
+    static_for<0, NB - 1>([&](auto gc) { issue(gc, gc); });
+    bool more = true;
+    static_for<0, XR>([&](auto rc) {          // chunk r: inputs 16 r .. 16 r + 15 = 16 / KU groups, statically: ring slot g % NB, quad k & 15
+      constexpr int r = decltype(rc)::value;
+      if (more && 16 * r < in) {
+        static_for<(16 / KU) * r, (16 / KU) * (r + 1)>([&](auto gc) {
+          constexpr int g = decltype(gc)::value, S = g % NB;
           // one more group goes into the slot consumed last, then wait until THIS slot's loads - the oldest in flight - have landed
-          int kg;
-          if (g + NB - 1 < ngroups) {
-            issue(g + NB - 1, std::integral_constant<int, (S + NB - 1) % NB>{});
-            kg = ring_wait<(NB - 1) * LOADS>(g * KU);
-          } else {
-            kg = ring_wait<0>(g * KU);
-          }
+          issue(std::integral_constant<int, g + NB - 1>{}, std::integral_constant<int, (g + NB - 1) % NB>{});
+          ring_wait<(NB - 1) * LOADS>(x[r]);
           static_for<0, KU>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int k = kg + j;                 // (kg is a multiple of KU: the parity of k is j's - which half of the pair - at compile time)
-            float sx[EPB];
-            RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e)
-              sx[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (j & 1) ? xs[e].y : xs[e].x), (k & 127) >> 1));
-            RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q)
-              RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) acc[e][q] = __builtin_elementwise_fma(ring[S][j][q], f2v{sx[e], sx[e]}, acc[e][q]);
+            constexpr int j = decltype(jc)::value, k = g * KU + j;
+            RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[r], ring[S][j][s], acc[s], 4, k & 15, 0);
           });
-        }
-      });
-    }
+        });
+      } else {
+        more = false;
+      }
+    });
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the groups fetched past the last chunk: the ring is reused by the next layer)
     const bool hidden = l + 1 < p.n_layers;
-    RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
-      const bool live = 128 * q + 2 * lane < out;
-      RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
-        f2v v = acc[e][q];
-        if (hidden) {
-          RSB_PRAGMA_UNROLL for (int h = 0; h < 2; ++h) {
-            float t = h ? v.y : v.x;
-            t = p.activation == RSB_ACT_TANH ? tanhf(t) : p.activation == RSB_ACT_RELU ? fmaxf(t, 0.f) : (t > 0.f ? t : p.leaky_slope * t);
-            if (h) v.y = t; else v.x = t;
-          }
-        }
-        x[e][q] = live ? v : f2v{0.f, 0.f};         // (pairs past the layer's width loaded clamped weights: zero them, the next layer reads lanes by index)
+    RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) {
+      const bool live = 64 * s + lane < out;
+      RSB_PRAGMA_UNROLL for (int e = 0; e < 4; ++e) {
+        float v = acc[s][e];
+        if (hidden) v = p.activation == RSB_ACT_TANH ? tanhf(v) : p.activation == RSB_ACT_RELU ? fmaxf(v, 0.f) : (v > 0.f ? v : p.leaky_slope * v);
+        acc[s][e] = live ? v : 0.f;         // (units past the layer's width loaded clamped weights)
+      }
+    }
+    if (hidden) {
+      // (env, unit) -> (input, env): input register r, lane l takes unit 16 r + (l >> 2) of env l & 3 = lane 16 (r & 3) + (l >> 2) of set r >> 2
+      RSB_PRAGMA_UNROLL for (int r = 0; r < XR; ++r) {
+        const int src = 4 * (16 * (r & 3) + lq);
+        // (the permutes are OPAQUE to the compiler - inline asm: it folds  select(c, bpermute(a, x), bpermute(a, y))  into  bpermute(a, select(c, x, y)),
+        //  and the masked-or form of the same, as if the permute were a lane-wise function; the condition is the DESTINATION lane's, so every env then
+        //  received what its source lane's env had computed.  Found by tests/test_gpu_closed_loop.py's comparison with torch once the envs differed.)
+        float t0, t1, t2, t3;
+        asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\tds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(src), "v"(acc[r >> 2][0]), "v"(acc[r >> 2][1]), "v"(acc[r >> 2][2]), "v"(acc[r >> 2][3]));
+        x[r] = le == 0 ? t0 : le == 1 ? t1 : le == 2 ? t2 : t3;
       }
     }
   }
   const long long gp = c.pass_global0 + pass;
   const float* nz = p.noise ? p.noise + (size_t)(gp % (p.noise_period > 0 ? p.noise_period : 1)) * N * ad : nullptr;
-  RSB_PRAGMA_UNROLL for (int q = 0; q < UP; ++q) {
-    RSB_PRAGMA_UNROLL for (int h = 0; h < 2; ++h) {
-      const int j = 128 * q + 2 * lane + h;
-      if (j < ad) {
-        RSB_PRAGMA_UNROLL for (int e = 0; e < EPB; ++e) {
-          if (e < n_env) {
-            float a = (h ? x[e][q].y : x[e][q].x) + (nz ? nz[(size_t)(env0 + e) * ad + j] : 0.f);
-            if (p.clip > 0.f) a = fminf(fmaxf(a, -p.clip), p.clip);
-            c.act[(size_t)(env0 + e) * ad + j] = a;
-            if (p.rollout_act) p.rollout_act[((size_t)pass * N + env0 + e) * ad + j] = a;
-          }
+  RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) {
+    const int j = 64 * s + lane;
+    if (j < ad) {
+      RSB_PRAGMA_UNROLL for (int e = 0; e < 4; ++e) {
+        if (e < n_env) {
+          float a = acc[s][e] + (nz ? nz[(size_t)(env0 + e) * ad + j] : 0.f);
+          if (p.clip > 0.f) a = fminf(fmaxf(a, -p.clip), p.clip);
+          c.act[(size_t)(env0 + e) * ad + j] = a;
+          if (p.rollout_act) p.rollout_act[((size_t)pass * N + env0 + e) * ad + j] = a;
         }
       }
     }
   }
 }
-template <int UP>
+template <int NS>
 __global__ void __launch_bounds__(64) mlp_stage_kernel(const rsb_stage_ctx c, const rsb_mlp_policy p) {
-  // (a block's actions are on the critical path of its next step, the step wave that shares this SIMD is not: issue priority while a block is being served)
-  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) __attribute__((always_inline)) {
-    __builtin_amdgcn_s_setprio(3);
-    mlp_block<UP>(c, p, env0, n_env, pass, final);
-    __builtin_amdgcn_s_setprio(0);
-  });
+  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) __attribute__((always_inline)) { mlp_block<NS>(c, p, env0, n_env, pass, final); });
 }
 int mlp_width(const rsb_mlp_policy& p) { int m = 0; for (int l = 0; l <= p.n_layers; ++l) m = std::max(m, (int)p.dims[l]); return m; }
 int launch_mlp_stage(void* user, const rsb_stage_ctx* c) {
   const rsb_mlp_policy& p = *static_cast<const rsb_mlp_policy*>(user);
   const int wd = mlp_width(p);
-  if (wd <= 128) hipLaunchKernelGGL(mlp_stage_kernel<1>, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, p);
-  else hipLaunchKernelGGL(mlp_stage_kernel<2>, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, p);
+  if (wd <= 128) hipLaunchKernelGGL(mlp_stage_kernel<2>, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, p);
+  else hipLaunchKernelGGL(mlp_stage_kernel<4>, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -849,7 +841,7 @@ int rsb_closed_loop_run_mlp(rsb_world* w, int n_steps, const rsb_mlp_policy* p) 
   if (!p || p->n_layers < 1 || p->n_layers > RSB_MLP_MAX_LAYERS) { rsb::set_error("rsb_closed_loop_run_mlp: 1 .. RSB_MLP_MAX_LAYERS layers"); return RSB_E_INVALID; }
   const int od = 10 + 2 * (w->blob.nv - 6), ad = w->blob.nv - 6;
   if (p->dims[0] != od || p->dims[p->n_layers] != ad) { rsb::set_error("rsb_closed_loop_run_mlp: dims[0] must be the env's observation size and dims[n_layers] its action size"); return RSB_E_INVALID; }
-  for (int l = 0; l <= p->n_layers; ++l) if (p->dims[l] < 2 || p->dims[l] > 256 || (p->dims[l] & 1)) { rsb::set_error("rsb_closed_loop_run_mlp: layer widths must be even, 2 .. 256 (a lane holds a pair of units)"); return RSB_E_INVALID; }
+  for (int l = 0; l <= p->n_layers; ++l) if (p->dims[l] < 1 || p->dims[l] > 256) { rsb::set_error("rsb_closed_loop_run_mlp: layer widths 1 .. 256"); return RSB_E_INVALID; }
   for (int l = 0; l < p->n_layers; ++l) if (!p->Wt[l]) { rsb::set_error("rsb_closed_loop_run_mlp: a layer's weight pointer is null"); return RSB_E_INVALID; }
   if (p->activation != RSB_ACT_TANH && p->activation != RSB_ACT_RELU && p->activation != RSB_ACT_LEAKY_RELU) { rsb::set_error("rsb_closed_loop_run_mlp: unknown activation"); return RSB_E_INVALID; }
   if (p->noise && p->noise_period < 1) { rsb::set_error("rsb_closed_loop_run_mlp: noise needs noise_period >= 1"); return RSB_E_INVALID; }

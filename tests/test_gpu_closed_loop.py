@@ -259,10 +259,10 @@ def test_no_trap_instruction_in_the_pipelined_classes(tmp_path):
 
 
 @pytest.mark.parametrize("n,lpe,hidden,act,normalise,runs,K", [(4096, 0, (128, 128), "leaky_relu", True, 3, 100), (1000, 0, (64,), "tanh", False, 2, 40),
-                                                              (512, 32, (256, 256), "relu", True, 2, 30), (300, 64, (50, 20, 34), "tanh", False, 2, 25)])
+                                                              (512, 32, (256, 256), "relu", True, 2, 30), (300, 64, (50, 21, 33), "tanh", False, 2, 25)])
 def test_mlp_stage_pipelined_equals_lockstep_and_matches_torch(built_lib, anymal, n, lpe, hidden, act, normalise, runs, K):
     """rsb_closed_loop_run_mlp: the actor of a raisimGymTorch-style PPO run (upstream's default 128-128 LeakyReLU; also one hidden layer, the widest
-    class, widths that are no multiple of four) as the action stage.  (a) pipelined == lock-step bit for bit - every row of every step's rollout
+    class, widths that are no multiple of anything) as the action stage.  (a) pipelined == lock-step bit for bit - every row of every step's rollout
     and the final state -, with resets; (b) the recorded actions equal a torch fp32 forward pass over the recorded observations (+ the noise) to
     rounding: the stage IS the network."""
     import torch
@@ -324,7 +324,7 @@ def test_mlp_stage_pipelined_equals_lockstep_and_matches_torch(built_lib, anymal
 
 
 def test_mlp_stage_refuses_what_it_cannot_run_and_device_memory_helpers(built_lib, anymal):
-    """Argument checks of rsb_closed_loop_run_mlp (layer count, odd or oversized widths, dims that do not match the env, a missing weight pointer, noise
+    """Argument checks of rsb_closed_loop_run_mlp (layer count, empty or oversized widths, dims that do not match the env, a missing weight pointer, noise
     without a period) return RSB_E_INVALID with a message and leave the world usable; rsb_device_alloc / _copy / _free round-trip host data."""
     import torch
     from raisimlib_amd import _capi
@@ -343,7 +343,7 @@ def test_mlp_stage_refuses_what_it_cannot_run_and_device_memory_helpers(built_li
                 p.Wt[l] = Wt.data_ptr()
         p.activation = 0
         return p
-    bad = [policy([34]), policy([34, 8, 8, 8, 8, 12]), policy([34, 33, 12]), policy([34, 258, 12]), policy([32, 16, 12]), policy([34, 16, 10]), policy([34, 16, 12], missing=1)]
+    bad = [policy([34]), policy([34, 8, 8, 8, 8, 12]), policy([34, 0, 12]), policy([34, 258, 12]), policy([32, 16, 12]), policy([34, 16, 10]), policy([34, 16, 12], missing=1)]
     noisy = policy([34, 16, 12]); noisy.noise = Wt.data_ptr(); noisy.noise_period = 0
     act = policy([34, 16, 12]); act.activation = 7
     for p in bad + [noisy, act]:
