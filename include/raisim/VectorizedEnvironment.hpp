@@ -127,7 +127,7 @@ class DeviceVectorizedEnvironment {
   }
   /// K control steps with an ACTOR NETWORK in the loop (the in-repo MLP stage, rsb_closed_loop_run_mlp): layer l = (weights[l] [dims[l + 1], dims[l]]
   /// row-major as torch.nn.Linear stores them, biases[l] [dims[l + 1]] or null), HOST arrays, uploaded (transposed) when `weights` changes;
-  /// dims.front() = obDim, dims.back() = actionDim, even widths <= 256; activation RSB_ACT_TANH / _RELU / _LEAKY_RELU on the hidden layers.
+  /// dims.front() = obDim, dims.back() = actionDim, widths <= 256; activation RSB_ACT_TANH / _RELU / _LEAKY_RELU on the hidden layers.
   void rolloutMlp(int steps, const std::vector<int>& dims, const std::vector<const float*>& weights, const std::vector<const float*>& biases,
                   int activation = RSB_ACT_LEAKY_RELU, float clip = 0.f) {
     const int L = (int)dims.size() - 1;
