@@ -573,9 +573,11 @@ __device__ __forceinline__ void mlp_block(const rsb_stage_ctx& c, const rsb_mlp_
       // (env, unit) -> (input, env): input register r, lane l takes unit 16 r + (l >> 2) of env l & 3 = lane 16 (r & 3) + (l >> 2) of set r >> 2
       RSB_PRAGMA_UNROLL for (int r = 0; r < XR; ++r) {
         const int src = 4 * (16 * (r & 3) + lq);
-        // (the permutes are OPAQUE to the compiler - inline asm: it folds  select(c, bpermute(a, x), bpermute(a, y))  into  bpermute(a, select(c, x, y)),
-        //  and the masked-or form of the same, as if the permute were a lane-wise function; the condition is the DESTINATION lane's, so every env then
-        //  received what its source lane's env had computed.  Found by tests/test_gpu_closed_loop.py's comparison with torch once the envs differed.)
+        // (the permutes are inline asm ON PURPOSE.  Written with __builtin_amdgcn_ds_bpermute and a select over the destination lane's env - or a masked
+        //  OR of the four results - this kernel came out with ONE permute per register instead of four: envs 1 .. 3 of a block received values computed
+        //  for other envs.  The bit-identity tests passed (both runs wrong alike) and so did the comparison with torch while a block's envs still moved
+        //  alike; it failed at 0.28 once they had parted (tests/test_gpu_closed_loop.py).  The pattern alone does not reproduce it
+        //  (tools/ubench/bpermute_select_fold.hip: four permutes, right results), so it is this kernel's context; the asm form leaves nothing to fold.)
         float t0, t1, t2, t3;
         asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\tds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
