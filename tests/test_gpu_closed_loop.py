@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 class Loop:
     """config 2 as a vectorised env + the reference policy + its exploration noise (= the open-loop benchmark's target draws)"""
 
-    def __init__(self, model, n, pipe, scale=workload.CLOSED_LOOP_W_SCALE, period=16, lpe=0):
+    def __init__(self, model, n, pipe, scale=workload.CLOSED_LOOP_W_SCALE, period=16, lpe=0, stage="linear"):
         import torch
         self.torch, self.n = torch, n
         dev = torch.device("cuda:0")
@@ -31,6 +31,8 @@ class Loop:
         self.noise = torch.from_numpy(workload.closed_loop_noise(n, period)).to(dev)
         self.pipe = self.env.world.set_step_pipelining(pipe)
         assert self.pipe == pipe
+        self.stage = stage
+        self.mlp = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in workload.closed_loop_mlp(self.env.num_obs, self.env.num_acts, hidden=(64, 32), out_scale=0.3)]
 
     def rollout_buffers(self, K):
         torch, e = self.torch, self.env
@@ -39,7 +41,10 @@ class Loop:
                 "reward": torch.zeros((K, self.n), dtype=torch.float32, device=dev), "done": torch.zeros((K, self.n), dtype=torch.uint8, device=dev)}
 
     def run(self, K, rollout=None):
-        self.env.rollout_linear(K, self.W, noise=self.noise, rollout=rollout)
+        if self.stage == "mlp":
+            self.env.rollout_mlp(K, self.mlp, activation="tanh", noise=self.noise, rollout=rollout)
+        else:
+            self.env.rollout_linear(K, self.W, noise=self.noise, rollout=rollout)
 
     def final(self):
         w = self.env.world
@@ -181,7 +186,7 @@ def test_a_callers_own_stage_kernel_rides_the_pipeline(built_lib, anymal, tmp_pa
 
 
 @pytest.mark.parametrize("kind,code", [(1, 1), (2, 2), (4, 4)])
-@pytest.mark.parametrize("closed", [False, True])
+@pytest.mark.parametrize("closed", [False, True, "mlp"])
 def test_a_pipeline_fault_is_an_error_code_and_the_handle_stays_usable(built_lib, anymal, monkeypatch, kind, code, closed):
     """rsb_debug_pipeline_fault makes one pipelined launch fail on the device (a ticket outside its XCD's range / a wait past the time-out /
     the error word set): nothing traps, the streams drain, the next joining call raises RSB_E_PIPELINE ONCE; by then the library has restored
@@ -192,7 +197,8 @@ def test_a_pipeline_fault_is_an_error_code_and_the_handle_stays_usable(built_lib
     monkeypatch.setenv("RSB_PIPE_TIMEOUT_MS", "300")
     n = 4096
     if closed:
-        twin, w = Loop(anymal, n, False), Loop(anymal, n, True)
+        stage = "mlp" if closed == "mlp" else "linear"          # (the replay of a faulted run re-launches the library's own stage from its logged copy of the policy)
+        twin, w = Loop(anymal, n, False, stage=stage), Loop(anymal, n, True, stage=stage)
         world = w.env.world
         twin.run(12); w.run(12)
         world.step_pipeline_join()
