@@ -371,3 +371,40 @@ def test_mlp_stage_refuses_what_it_cannot_run_and_device_memory_helpers(built_li
     assert L.rsb_device_copy(w.handle, ptr, host.ctypes.data_as(C.c_void_p), host.nbytes, 2) == -1
     assert L.rsb_device_free(w.handle, ptr) == 0 and L.rsb_device_alloc(w.handle, 0, C.byref(ptr)) == -1
     env.close()
+
+
+def test_closed_loop_on_a_height_map(built_lib, anymal):
+    """The closed loop is not a flat-ground special case: the config-3 terrain (shared 128 x 128 height map, robots spread over it and reset to their
+    own spots) under the vectorised env with the MLP stage in the loop - pipelined == lock-step bit for bit over 150 steps with resets."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    n, K = 4096, 75
+    dev = torch.device("cuda:0")
+    recipe = bench.Recipe(3, -1.0)
+    maps, env_map = recipe.terrain(n, 0)
+    gc0, gv0 = recipe.initial_state(n, 0)
+    mlp = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in workload.closed_loop_mlp(34, 12, hidden=(64, 64), out_scale=0.2)]
+    noise = torch.from_numpy(workload.closed_loop_noise(n, 16)).to(dev)
+    out = {}
+    for pipe in (False, True):
+        env = workload.closed_loop_env(anymal, n)
+        env.world.add_height_map(128, 128, workload.HEIGHTMAP_SIZE, workload.HEIGHTMAP_SIZE, 0.0, 0.0, maps[0])
+        env.set_reset_states(gc0, gv0)
+        env.reset()
+        assert env.world.set_step_pipelining(pipe) == pipe
+        done = 0
+        for r in range(2):
+            ro = {"ob": torch.zeros((K + 1, n, 34), device=dev), "done": torch.zeros((K, n), dtype=torch.uint8, device=dev)}
+            env.rollout_mlp(K, mlp, activation="tanh", noise=noise, rollout=ro)
+            env.world.step_pipeline_join()
+            done += int(ro["done"].sum().item())
+        q, u = env.world.get_state()
+        cnt, con = env.world.get_contacts()
+        out[pipe] = (q, u, cnt, con.tobytes(), ro["ob"].cpu().numpy(), done, env.world.step_pipeline_fault())
+        env.close()
+    a, b = out[False], out[True]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and np.array_equal(a[4], b[4])
+    assert a[5] == b[5] > 0 and b[6] == (0, 0)
+    assert np.isfinite(b[0]).all() and np.ptp(b[0][:, 2]) > 0.05          # robots stand at different terrain heights
