@@ -408,3 +408,41 @@ def test_closed_loop_on_a_height_map(built_lib, anymal):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and np.array_equal(a[4], b[4])
     assert a[5] == b[5] > 0 and b[6] == (0, 0)
     assert np.isfinite(b[0]).all() and np.ptp(b[0][:, 2]) > 0.05          # robots stand at different terrain heights
+
+
+def test_closed_loop_with_the_humanoid(built_lib):
+    """... nor a quadruped special case: the Atlas-like humanoid (30 actuated joints: observation 70, action 30; 16 contact slots, two envs per block, the
+    multi-contact solver settings of config 5) as the vectorised env with an MLP 70 -> 96 -> 30 in the loop - pipelined == lock-step bit for bit."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from raisimlib_amd.vecenv import VecEnv
+    n, K = 1024, 40
+    dev = torch.device("cuda:0")
+    recipe = bench.Recipe(5, -1.0)
+    gc0, gv0 = recipe.initial_state(n, 0)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    dims = [70, 96, 30]
+    mlp = [(((torch.rand((dims[i + 1], dims[i]), generator=g) * 2 - 1) * (0.1 if i else 1.0) / np.sqrt(dims[i])).to(dev), torch.zeros(dims[i + 1], device=dev)) for i in range(2)]
+    noise = (torch.rand((8, n, 30), generator=g) * 0.1 - 0.05).to(dev)
+    out = {}
+    for pipe in (False, True):
+        env = VecEnv(recipe.model, n, gc_init=gc0[0].astype(np.float32), action_std=0.1)
+        assert env.num_obs == 70 and env.num_acts == 30
+        recipe.setup_world(env.world, n, 0)
+        env.set_reset_states(gc0, gv0)
+        env.reset()
+        assert env.world.set_step_pipelining(pipe) == pipe
+        for r in range(2):
+            ro = {"ob": torch.zeros((K + 1, n, 70), device=dev), "act": torch.zeros((K, n, 30), device=dev)}
+            env.rollout_mlp(K, mlp, activation="tanh", noise=noise, rollout=ro)
+            env.world.step_pipeline_join()
+        q, u = env.world.get_state()
+        out[pipe] = (q, u, ro["ob"].cpu().numpy(), ro["act"].cpu().numpy(), env.world.step_pipelining_stats()[0], env.world.step_pipeline_fault())
+        env.close()
+    a, b = out[False], out[True]
+    for i in range(4):
+        assert np.array_equal(a[i], b[i]), i
+    assert b[4] == 2 * K and a[4] == 0 and b[5] == (0, 0)
+    assert np.isfinite(b[0]).all() and np.abs(b[3]).max() > 1e-3
