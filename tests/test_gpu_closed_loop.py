@@ -141,6 +141,28 @@ extern "C" int launch_user_stage(void* user, const rsb_stage_ctx* c) {
   hipLaunchKernelGGL(user_stage, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, *static_cast<const Mlp*>(user));
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// a caller's mistake: workgroups of two waves on the pipelined path (serve() wants one wave per workgroup; a kernel without launch bounds, or HIP
+// itself refuses the launch)
+__global__ void user_stage_unbounded(const rsb_stage_ctx c, const Mlp p) {
+  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) {
+    if (final) return;
+    const int lane = threadIdx.x & 63;
+    for (int e = 0; e < n_env; ++e) {
+      const float* ob = c.ob + (size_t)(env0 + e) * c.ob_dim;
+      float h = 0.f;
+      if (lane < p.hidden) { for (int i = 0; i < c.ob_dim; ++i) h = fmaf(p.W1[lane * c.ob_dim + i], ob[i], h); h = tanhf(h); }
+      for (int j = 0; j < c.act_dim; ++j) {
+        float t = lane < p.hidden ? p.W2[j * p.hidden + lane] * h : 0.f;
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if (lane == 0) { c.act[(size_t)(env0 + e) * c.act_dim + j] = t; if (p.act_log) p.act_log[((size_t)pass * c.n_envs + env0 + e) * c.act_dim + j] = t; }
+      }
+    }
+  });
+}
+extern "C" int launch_user_stage_two_waves(void* user, const rsb_stage_ctx* c) {
+  hipLaunchKernelGGL(user_stage_unbounded, dim3(c->grid), dim3(c->lockstep ? 64 : 128), 0, (hipStream_t)c->stream, *c, *static_cast<const Mlp*>(user));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 """
 
 
@@ -183,6 +205,41 @@ def test_a_callers_own_stage_kernel_rides_the_pipeline(built_lib, anymal, tmp_pa
     assert out[True][3] == 4 * K and out[False][3] == 0
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1]) and np.array_equal(out[False][2], out[True][2])
     assert np.isfinite(out[True][0]).all() and np.abs(out[True][0]).max() > 0.1
+
+
+def test_a_stage_with_the_wrong_geometry_is_a_reported_fault(built_lib, anymal, tmp_path):
+    """A caller's stage launched with workgroups of two waves: serve() reports RSB_PIPE_ERR_STAGE instead of serving, the steps drain, the join
+    returns RSB_E_PIPELINE once and the run has been replayed in lock-step (where the same launch function is well-formed): the rollout equals the
+    well-formed stage's."""
+    import torch
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    src = tmp_path / "user_stage.hip"
+    src.write_text(USER_STAGE)
+    so = tmp_path / "libuser_stage.so"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-o", str(so), str(src)], check=True)
+    lib = C.CDLL(str(so))
+    good, bad = C.cast(lib.launch_user_stage, C.c_void_p), C.cast(lib.launch_user_stage_two_waves, C.c_void_p)
+    n, K, hidden = 1024, 30, 16
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    W1 = torch.from_numpy(rng.uniform(-0.3, 0.3, (hidden, 34)).astype(np.float32)).to(dev)
+    W2 = torch.from_numpy(rng.uniform(-0.6, 0.6, (12, hidden)).astype(np.float32)).to(dev)
+    out = {}
+    for fn in (good, bad):
+        env = workload.closed_loop_env(anymal, n)
+        assert env.world.set_step_pipelining(True)
+        log = torch.zeros((K, n, 12), dtype=torch.float32, device=dev)
+        m = Mlp(W1.data_ptr(), W2.data_ptr(), hidden, log.data_ptr())
+        assert built_lib.rsb_closed_loop_run(env.world.handle, K, fn, C.byref(m)) == 0, built_lib.rsb_last_error()
+        st = built_lib.rsb_step_pipeline_join(env.world.handle)
+        assert st == (0 if fn is good else -7), st
+        assert env.world.step_pipeline_fault() == ((0, 0) if fn is good else (1, 3))          # RSB_PIPE_ERR_STAGE
+        assert built_lib.rsb_step_pipeline_join(env.world.handle) == 0                          # reported once
+        q, u = env.world.get_state()
+        out[fn is good] = (log.cpu().numpy(), q, u)
+        env.close()
+    for a, b in zip(out[True], out[False]):
+        assert np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("kind,code", [(1, 1), (2, 2), (4, 4)])
