@@ -7,6 +7,7 @@ import ctypes as C
 import os
 import shutil
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -503,3 +504,33 @@ def test_closed_loop_with_the_humanoid(built_lib):
         assert np.array_equal(a[i], b[i]), i
     assert b[4] == 2 * K and a[4] == 0 and b[5] == (0, 0)
     assert np.isfinite(b[0]).all() and np.abs(b[3]).max() > 1e-3
+
+
+def test_closed_loop_without_overlapping_streams_stays_in_lock_step(built_lib, tmp_path):
+    """With ONE hardware queue (GPU_MAX_HW_QUEUES=1) no two streams overlap: a resident action stage would never see the steps queued behind it.  The
+    library's probe finds that out and runs closed-loop runs in lock-step (and open-loop steps in order) - same results, no hang."""
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from raisimlib_amd import Model, rsc_path, workload
+dev = torch.device("cuda:0")
+model = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+out = []
+for pipe in (False, True):
+    env = workload.closed_loop_env(model, 1024)
+    env.world.set_step_pipelining(pipe)
+    W = torch.from_numpy(workload.closed_loop_policy(34, 12, 0.3)).to(dev)
+    noise = torch.from_numpy(workload.closed_loop_noise(1024, 16)).to(dev)
+    env.rollout_linear(60, W, noise=noise)
+    env.world.step_pipeline_join()
+    q, u = env.world.get_state()
+    env.world.step_pipelining_stats()          # (sets pipeline_overlaps)
+    out.append((q, u, env.world.pipeline_overlaps, env.world.step_pipeline_fault()))
+    env.close()
+assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.isfinite(out[1][0]).all()
+print("OVERLAP", out[1][2], "FAULTS", out[1][3])
+""" % ROOT
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "OVERLAP False" in r.stdout and "FAULTS (0, 0)" in r.stdout, r.stdout + r.stderr[-500:]
