@@ -405,6 +405,37 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
                      const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
                      int n_allowed, const float* gc0, const float* gv0, int rows);
 
+/* ---- round 6: RESIDENT control steps.  K control steps of a vectorised env in ONE launch of the step kernel: an env block's state (and the solver's
+ * warm table, the model tables) stays in LDS from the first sub-step to the last; per control step only the obs block, the done flags and - env task -
+ * reward / next observation go to HBM; state rows, warm records and contact records are written after the LAST control step (the world then holds exactly
+ * what K separate rsb_control_step calls leave: the tests compare bit for bit).  A terminated env restarts in LDS.  Why: a launch lasts as long as its
+ * slowest wave, and a wave's time over K control steps is a SUM - the tail averages out with no hand-over between launches, and the per-launch
+ * prologue / epilogue (8 k of a launch's 180 k cycles) is paid once.  Upstream counterpart: the loop over VectorizedEnvironment::step
+ * [RECALL raisimGymTorch/env/VectorizedEnvironment.hpp; absent from /root/reference].
+ *
+ * rsb_control_steps: K control steps of the OPEN loop.  p_targets [period][N][nq] device memory: control step j reads slice (first + j) % period (the
+ * benchmark's pre-drawn PD-target bank; an action sequence of sampling-based MPC; a replay).  obs_out (may be NULL): control step j's obs block goes to
+ * obs_out + j * obs_step_stride floats (0: every step overwrites the same block; N * rsb_obs_dim: a [K, N, obs_dim] rollout); done_out (may be NULL, device
+ * memory): its done flags to done_out + j * done_step_stride bytes.  The other arguments are rsb_control_step's.
+ * With residency OFF (the default), or for a world outside the resident kernel classes (see rsb_step_residency_status), the same call runs K
+ * rsb_control_step launches - pipelined or in lock-step as rsb_set_step_pipelining says - with the same results. */
+int rsb_control_steps(rsb_world* w, int n_steps, const float* p_targets, int period, long long first, int n_substeps, float* obs_out,
+                      long long obs_step_stride, const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions, int n_allowed,
+                      const float* gc0, const float* gv0, int rows, uint8_t* done_out, long long done_step_stride);
+/* on != 0: rsb_control_steps and the closed-loop runs with an in-repo stage (rsb_closed_loop_run_linear / _mlp, rsb_pipeline.h) use ONE resident launch
+ * per call when the world's kernel class has a resident twin; a caller-supplied stage (rsb_closed_loop_run) cannot be compiled into the step kernel and
+ * keeps the pipelined path. */
+int rsb_set_step_residency(rsb_world* w, int on);
+int rsb_step_residency_enabled(const rsb_world* w);
+/* 1 when a resident launch exists for this world as it is configured now (stage: 0 open loop, 1 linear policy, 2 actor network; K = control steps per
+ * launch), else 0 with the reason in rsb_last_error(): floating base, the plain contact / integration / slip rules, no peer exchange, N a multiple of the
+ * envs per workgroup, and one of the two compiled model sizes (tree depth <= 5 with <= 8 contact slots at 16 lanes per env; tree depth <= 13 with 16 slots at 32). */
+int rsb_step_residency_status(rsb_world* w, int stage);
+/* resident launches so far */
+long long rsb_step_residency_launches(const rsb_world* w);
+/* debug aid: 1 = every control step of a resident launch writes everything a separate launch writes (state rows, warm records, contact records) */
+int rsb_debug_resident_full_writes(rsb_world* w, int on);
+
 /* ---- multi-GPU without Python: the obs all-gather over RCCL / xGMI.  One process per GPU; envs are sharded
  * contiguously, rank r owns global envs [r*N, (r+1)*N); nothing inside integrate() communicates.  librccl.so.1 is loaded
  * at run time by the first rsb_comm_* call (a host that never calls them needs no RCCL).  Upstream has no counterpart

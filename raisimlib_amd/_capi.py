@@ -201,6 +201,12 @@ PROTOTYPES = {
     "rsb_set_timing_stride": (_I, [_VP, _I]),
     "rsb_read_kernel_ms": (_I, [_VP, _FP, _I]),
     "rsb_control_step": (_I, [_VP, _FP, _FP, _I, _FP, _FP, _I, _FP, _I, _FP, _FP, _I]),
+    "rsb_control_steps": (_I, [_VP, _I, _FP, _I, C.c_longlong, _I, _FP, C.c_longlong, _FP, _I, _FP, _I, _FP, _FP, _I, _VP, C.c_longlong]),
+    "rsb_set_step_residency": (_I, [_VP, _I]),
+    "rsb_step_residency_enabled": (_I, [_VP]),
+    "rsb_step_residency_status": (_I, [_VP, _I]),
+    "rsb_step_residency_launches": (C.c_longlong, [_VP]),
+    "rsb_debug_resident_full_writes": (_I, [_VP, _I]),
     "rsb_debug_select_env": (_I, [_VP, _I]),
     "rsb_debug_phase_cycles": (_I, [_VP, _I, _FP]),
     "rsb_debug_wave_profile": (_I, [_VP, _FP, _I]),

@@ -29,13 +29,13 @@ HOST_SOURCES = {   # source -> headers it depends on
     "urdf_model.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
     "terrain_io.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
     "rsb_world.hip": _WORLD_DEPS + ["step_launch.h", "query_kernel.h", "env_task.h"],
-    "rsb_pipeline.hip": _WORLD_DEPS,
+    "rsb_pipeline.hip": _WORLD_DEPS + ["stage_bodies.h"],
     "rsb_comm.hip": _WORLD_DEPS,
     "rsb_rk4.hip": _WORLD_DEPS,
 }
 # the fused step kernel: the template's skeleton (step_kernel.h), its device helpers (step_math / step_terrain / step_slip .h) and its body, one
 # fragment per phase (step_phase_*.inc, included inside the kernel: same token stream as the one 2 500-line function of rounds 1-4)
-KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", "step_math.h", "step_terrain.h", "step_slip.h",
+KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", "step_math.h", "step_terrain.h", "step_slip.h", "stage_bodies.h", RSB_PIPELINE_H,
                *sorted(f for f in os.listdir(CSRC) if f.startswith("step_phase_") and f.endswith(".inc")), RSB_TYPES_H]
 # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and
 # pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed at the stated parity tolerance
@@ -93,7 +93,7 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
     # (rsb_source_hash() then no longer describes the library: the test-suite refuses it - a full build() is what ships)
     only = {tuple(int(x) for x in tok.split(",")) for tok in os.environ.get("RSB_BUILD_ONLY", "").split()}
     for lpe, kmax, cl, ml in step_instances():
-        for prof in ((0,) if cl & 18 else (0, 1)):     # (the peer-exchange and the pipelined classes have no profiling twin: rsb_world.hip, launch_step)
+        for prof in ((0,) if cl & (18 | 64) else (0, 1)):     # (the peer-exchange, the pipelined and the resident classes have no profiling twin: rsb_world.hip, launch_step)
             obj = os.path.join(OBJ, f"step_{lpe}_{kmax}_{cl}_{ml}_{prof}" + (f".{tag}" if tag else "") + ".o")
             objs.append(obj)
             if only and (lpe, kmax, cl, ml) not in only and os.path.exists(obj):

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "rsb_world.h"
+#include "stage_bodies.h"
 
 #define RSB_PRAGMA_UNROLL _Pragma("unroll")
 
@@ -407,204 +408,19 @@ bool pipelining_forbidden() {
   return set("ROCPROF_COUNTER_COLLECTION") || set("ROCPROF_ATT_PARAM_SERIALIZE_ALL") || set("ROCPROFILER_COUNTER_COLLECTION");
 }
 
-// ---- the in-repo reference stage: a fixed linear policy (rsb_linear_policy) --------------------------------------------------------
-// lane = (env of the block, action entry); the sum runs over the observation in index order with one FMA per term - the same instruction
-// sequence whether the pass is served from the pipeline or launched in lock-step, so the two produce the same bits.
-// what an on-policy learner stores of a pass: the block's observation rows, and the reward / done flags of the step just finished
-__device__ __forceinline__ void record_rollout(const rsb_stage_ctx& c, float* rollout_ob, float* rollout_reward, uint8_t* rollout_done, int env0, int n_env, int pass) {
-  const int lane = (int)threadIdx.x, od = c.ob_dim;
-  const size_t N = (size_t)c.n_envs;
-  if (rollout_ob) {      // (four rows of a block in flight at once: a stage wave pays the full L2 latency for every load -> wait round)
-    const float* src = c.ob + (size_t)env0 * od;
-    float* dst = rollout_ob + ((size_t)pass * N + env0) * od;
-    const int n = n_env * od;
-    for (int i0 = lane; i0 < n; i0 += 256) {
-      float v[4];
-      RSB_PRAGMA_UNROLL for (int k = 0; k < 4; ++k) v[k] = src[min(i0 + 64 * k, n - 1)];
-      RSB_PRAGMA_UNROLL for (int k = 0; k < 4; ++k) if (i0 + 64 * k < n) dst[i0 + 64 * k] = v[k];
-    }
-  }
-  if (pass > 0 && lane < n_env) {
-    if (rollout_reward) rollout_reward[(size_t)(pass - 1) * N + env0 + lane] = c.reward[env0 + lane];
-    if (rollout_done) rollout_done[(size_t)(pass - 1) * N + env0 + lane] = c.done[env0 + lane];
-  }
-}
+// ---- the in-repo stages: a fixed linear policy (rsb_linear_policy) and an actor network on the matrix cores (rsb_mlp_policy).  Their per-env-block bodies
+// live in stage_bodies.h: the resident step classes evaluate the same code inside the step kernel
 __global__ void __launch_bounds__(64) linear_stage_kernel(const rsb_stage_ctx c, const rsb_linear_policy p) {
-  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) {
-    const int lane = (int)threadIdx.x;
-    const int od = c.ob_dim, ad = c.act_dim;
-    const size_t N = (size_t)c.n_envs;
-    record_rollout(c, p.rollout_ob, p.rollout_reward, p.rollout_done, env0, n_env, pass);
-    if (final) return;
-    const long long gp = c.pass_global0 + pass;
-    const float* nz = p.noise ? p.noise + (size_t)(gp % (p.noise_period > 0 ? p.noise_period : 1)) * N * ad : nullptr;
-    constexpr int CH = 16;     // terms of the sum loaded together (weights and observation entries: 32 loads in flight, then 16 FMAs in index order)
-    for (int idx = lane; idx < n_env * ad; idx += 64) {
-      const int e = idx / ad, j = idx - e * ad;
-      const float* ob = c.ob + (size_t)(env0 + e) * od;
-      const float* wr = p.W + (size_t)j * od;
-      float acc = p.bias ? p.bias[j] : 0.f;
-      const float noise = nz ? nz[(size_t)(env0 + e) * ad + j] : 0.f;
-      for (int i0 = 0; i0 < od; i0 += CH) {
-        float wv[CH], ov[CH];
-        RSB_PRAGMA_UNROLL for (int k = 0; k < CH; ++k) { const int i = min(i0 + k, od - 1); wv[k] = wr[i]; ov[k] = ob[i]; }
-        RSB_PRAGMA_UNROLL for (int k = 0; k < CH; ++k) if (i0 + k < od) acc = fmaf(wv[k], ov[k], acc);
-      }
-      acc += noise;
-      if (p.clip > 0.f) acc = fminf(fmaxf(acc, -p.clip), p.clip);
-      c.act[(size_t)(env0 + e) * ad + j] = acc;
-      if (p.rollout_act) p.rollout_act[((size_t)pass * N + env0 + e) * ad + j] = acc;
-    }
-  });
+  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) { rsb_stage_body::linear_block(c, p, env0, n_env, pass, final); });
 }
 int launch_linear_stage(void* user, const rsb_stage_ctx* c) {
   hipLaunchKernelGGL(linear_stage_kernel, dim3(c->grid), dim3(64), 0, (hipStream_t)c->stream, *c, *static_cast<const rsb_linear_policy*>(user));
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// ---- the in-repo MLP stage (rsb_mlp_policy): the actor network of a PPO rollout, per env block, on the matrix cores ------------------------
-// A block is FOUR envs: y[unit][env] += W[unit][k] x[k][env] is a rank-1 update of a (units x 4) matrix per input k - v_mfma_f32_4x4x1_16B_f32
-// does sixteen 4 x 4 blocks of it at once = 64 units x 4 envs per instruction, every multiplier busy:
-//   B (1 x 4 per block, lane 4 b + j)  = the weights of input k for units 4 b + j: lane = unit, ONE coalesced row of the transposed matrix;
-//   A (4 x 1 per block, lane 4 b' + i) = the four envs' input k - the same for all sixteen blocks: the instruction's A-BROADCAST (cbsz 4, abid q)
-//                                        feeds every block from quad q of the register, so ONE register holds sixteen inputs x four envs
-//                                        (lane l: env l & 3, input 16 r + (l >> 2)) and nothing is broadcast by hand;
-//   D (4 x 4 per block)                = register i: env i, lane = unit - the layout the activation, the bias and the action rows want.
-// (tools/ubench/mfma_4x4_bcast.hip reads both layouts and the broadcast off the hardware.)  Between two layers the (env, unit) registers are
-// turned into (input, env) registers by ds_bpermute (the LDS crossbar, no LDS memory: the step kernel's workgroups own all of it).
-// The first versions ran on the vector ALU: the input had to become a scalar per env (v_readlane) - 65 cycles per input row, half of them
-// the readlanes (tools/ubench/mlp_inner.hip), 20 us per block; here a row is two matrix instructions.
-// The weight rows still come from L2 (the stage has nowhere to keep 89 KB) through a RING of NB groups of KU rows with explicit loads and waits
-// (inline asm: the compiler's own schedule waited for every group): NB - 1 groups are in flight while one is consumed.  No LDS memory, <= 96
-// registers: what a step wave leaves of its SIMD (tests/test_gpu_closed_loop.py reads both off the ISA).
-typedef float f4v __attribute__((ext_vector_type(4)));
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {      // f(integral_constant<int, I>) for I = 0 .. N - 1: register indices and abid stay compile-time
-  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-__device__ __forceinline__ void ring_load(float& dst, unsigned voff, const char* sbase) {
-  asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-// the wait passes the group's INPUT REGISTER through itself (a tied operand, no instruction): every matrix instruction of the group reads it, so
-// none of them moves above the wait (tying the ring registers cost 2 v_mov per row, tying the accumulators 8 v_accvgpr_mov per group)
-template <int CNT>
-__device__ __forceinline__ void ring_wait(float& xr) {
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr) : "n"(CNT));
-}
-template <int NS>       // sets of 64 units: layer widths up to 64 NS
-__device__ __forceinline__ void mlp_block(const rsb_stage_ctx& c, const rsb_mlp_policy& p, int env0, int n_env, int pass, bool final) {
-  constexpr int XR = 4 * NS;                  // input registers: 16 inputs x 4 envs each
-  constexpr int KU = NS == 2 ? 4 : 2;         // weight rows per group (8 loads)
-  constexpr int NB = NS == 2 ? 5 : 2;         // groups in the ring: 16 / 2 rows in flight = 40 / 16 registers
-  constexpr int LOADS = KU * NS;
-  const int lane = (int)threadIdx.x;
-  const int od = c.ob_dim, ad = c.act_dim;
-  const size_t N = (size_t)c.n_envs;
-  record_rollout(c, p.rollout_ob, p.rollout_reward, p.rollout_done, env0, n_env, pass);
-  if (final) return;
-  const int le = lane & 3, lq = lane >> 2;    // this lane's env and input slot in an input register
-  float x[XR];
-  RSB_PRAGMA_UNROLL for (int r = 0; r < XR; ++r) {
-    const int k = 16 * r + lq;
-    float v = 0.f;
-    if (k < od && le < n_env) {
-      v = c.ob[(size_t)(env0 + le) * od + k];
-      if (p.ob_mean) v -= p.ob_mean[k];
-      if (p.ob_inv_std) v *= p.ob_inv_std[k];
-      if (p.ob_clip > 0.f) v = fminf(fmaxf(v, -p.ob_clip), p.ob_clip);
-    }
-    x[r] = v;
-  }
-  f4v acc[NS];                                // [set][env]: unit 64 s + lane
-  for (int l = 0; l < p.n_layers; ++l) {
-    const int in = p.dims[l], out = p.dims[l + 1];
-    const char* Wb = reinterpret_cast<const char*>(p.Wt[l]);
-    unsigned voff[NS];
-    RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) {
-      const int u = 64 * s + lane;
-      voff[s] = 4u * (unsigned)min(u, out - 1);      // byte offset in a row (clamped: no load is predicated; units past the layer's width are zeroed below)
-      const float b = (p.bias[l] && u < out) ? p.bias[l][u] : 0.f;
-      acc[s] = f4v{b, b, b, b};
-    }
-    float ring[NB][KU][NS];
-    // Rows run in chunks of 16 (one input register): a chunk that starts at or past `in` ends the layer, inside a chunk nothing branches - a lone
-    // wave pays 20-45 cycles per branch, a group's eight matrix instructions 64.  Rows past the end are clamped to the last one and meet zero inputs
-    // (so do the few groups the ring fetches ahead of the last chunk).  Uniform 64-bit row base in SGPRs + 32-bit lane offset: no address registers.
-    const unsigned rowbytes = 4u * (unsigned)out;
-    const int last = in - 1;
-    auto issue = [&](auto gc, auto slot) {
-      constexpr int g = decltype(gc)::value, S = decltype(slot)::value;
-      static_for<0, KU>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const char* rowp = Wb + (size_t)((unsigned)min(g * KU + j, last) * rowbytes);
-        static_for<0, NS>([&](auto sc) { ring_load(ring[S][j][decltype(sc)::value], voff[decltype(sc)::value], rowp); });
-      });
-    };
-    static_for<0, NB - 1>([&](auto gc) { issue(gc, gc); });
-    bool more = true;
-    static_for<0, XR>([&](auto rc) {          // chunk r: inputs 16 r .. 16 r + 15 = 16 / KU groups, statically: ring slot g % NB, quad k & 15
-      constexpr int r = decltype(rc)::value;
-      if (more && 16 * r < in) {
-        static_for<(16 / KU) * r, (16 / KU) * (r + 1)>([&](auto gc) {
-          constexpr int g = decltype(gc)::value, S = g % NB;
-          // one more group goes into the slot consumed last, then wait until THIS slot's loads - the oldest in flight - have landed
-          issue(std::integral_constant<int, g + NB - 1>{}, std::integral_constant<int, (g + NB - 1) % NB>{});
-          ring_wait<(NB - 1) * LOADS>(x[r]);
-          static_for<0, KU>([&](auto jc) {
-            constexpr int j = decltype(jc)::value, k = g * KU + j;
-            RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f32_4x4x1f32(x[r], ring[S][j][s], acc[s], 4, k & 15, 0);
-          });
-        });
-      } else {
-        more = false;
-      }
-    });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the groups fetched past the last chunk: the ring is reused by the next layer)
-    const bool hidden = l + 1 < p.n_layers;
-    RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) {
-      const bool live = 64 * s + lane < out;
-      RSB_PRAGMA_UNROLL for (int e = 0; e < 4; ++e) {
-        float v = acc[s][e];
-        if (hidden) v = p.activation == RSB_ACT_TANH ? tanhf(v) : p.activation == RSB_ACT_RELU ? fmaxf(v, 0.f) : (v > 0.f ? v : p.leaky_slope * v);
-        acc[s][e] = live ? v : 0.f;         // (units past the layer's width loaded clamped weights)
-      }
-    }
-    if (hidden) {
-      // (env, unit) -> (input, env): input register r, lane l takes unit 16 r + (l >> 2) of env l & 3 = lane 16 (r & 3) + (l >> 2) of set r >> 2
-      RSB_PRAGMA_UNROLL for (int r = 0; r < XR; ++r) {
-        const int src = 4 * (16 * (r & 3) + lq);
-        // (the permutes are inline asm ON PURPOSE.  Written with __builtin_amdgcn_ds_bpermute and a select over the destination lane's env - or a masked
-        //  OR of the four results - this kernel came out with ONE permute per register instead of four: envs 1 .. 3 of a block received values computed
-        //  for other envs.  The bit-identity tests passed (both runs wrong alike) and so did the comparison with torch while a block's envs still moved
-        //  alike; it failed at 0.28 once they had parted (tests/test_gpu_closed_loop.py).  The pattern alone does not reproduce it
-        //  (tools/ubench/bpermute_select_fold.hip: four permutes, right results), so it is this kernel's context; the asm form leaves nothing to fold.)
-        float t0, t1, t2, t3;
-        asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\tds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
-                     : "v"(src), "v"(acc[r >> 2][0]), "v"(acc[r >> 2][1]), "v"(acc[r >> 2][2]), "v"(acc[r >> 2][3]));
-        x[r] = le == 0 ? t0 : le == 1 ? t1 : le == 2 ? t2 : t3;
-      }
-    }
-  }
-  const long long gp = c.pass_global0 + pass;
-  const float* nz = p.noise ? p.noise + (size_t)(gp % (p.noise_period > 0 ? p.noise_period : 1)) * N * ad : nullptr;
-  RSB_PRAGMA_UNROLL for (int s = 0; s < NS; ++s) {
-    const int j = 64 * s + lane;
-    if (j < ad) {
-      RSB_PRAGMA_UNROLL for (int e = 0; e < 4; ++e) {
-        if (e < n_env) {
-          float a = acc[s][e] + (nz ? nz[(size_t)(env0 + e) * ad + j] : 0.f);
-          if (p.clip > 0.f) a = fminf(fmaxf(a, -p.clip), p.clip);
-          c.act[(size_t)(env0 + e) * ad + j] = a;
-          if (p.rollout_act) p.rollout_act[((size_t)pass * N + env0 + e) * ad + j] = a;
-        }
-      }
-    }
-  }
-}
 template <int NS>
 __global__ void __launch_bounds__(64) mlp_stage_kernel(const rsb_stage_ctx c, const rsb_mlp_policy p) {
-  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) __attribute__((always_inline)) { mlp_block<NS>(c, p, env0, n_env, pass, final); });
+  rsb_stage::serve(c, [&](int, int env0, int n_env, int pass, bool final) __attribute__((always_inline)) { rsb_stage_body::mlp_block<NS>(c, p, env0, n_env, pass, final); });
 }
 int mlp_width(const rsb_mlp_policy& p) { int m = 0; for (int l = 0; l <= p.n_layers; ++l) m = std::max(m, (int)p.dims[l]); return m; }
 int launch_mlp_stage(void* user, const rsb_stage_ctx* c) {
@@ -662,17 +478,48 @@ int closed_loop_lockstep(rsb_world* w, int K, rsb_stage_launch_fn launch, void* 
   return RSB_OK;
 }
 
+// ONE resident launch of the step kernel for the whole run (rsb_set_step_residency): pass 0, step 1, pass 1, ..., step K, pass K by the env block's own wave
+int closed_loop_resident(rsb_world* w, int K, const rsb_linear_policy* lin, const rsb_mlp_policy* mlp, long long pass_global0) {
+  hipStream_t s = stream_of(w);      // joins
+  int st = RSB_OK;
+  if (!w->env_ob_valid) { st = launch_env_obs(w, w->d_env_ob, s); if (st != RSB_OK) return st; }
+  cl_fuse(w, false);
+  w->fuse.res_steps = K; w->fuse.res_stage = lin ? 1 : 2; w->fuse.res_pass_global0 = pass_global0;
+  if (lin) w->fuse.res_lin = *lin;
+  if (mlp) w->fuse.res_mlp = *mlp;
+  st = do_integrate(w, w->env_cfg.n_substeps);
+  w->integrate1_valid = false;
+  return st;
+}
+
+// the conditions under which do_integrate launches a step of a closed-loop run on the pipeline (else it takes the world's stream - and joins, with the
+// action stage in flight: ADVICE r05).  Checked BEFORE the stage is launched; a run that fails the test stays in lock-step.
+bool closed_loop_can_pipeline(const rsb_world* w) {
+  static const bool poison = std::getenv("RSB_POISON_LDS") != nullptr;
+  return w->pipe_on && !w->d_prof && w->dbg_env < 0 && !poison && !w->peer.connected && !w->launch_mask && !(w->integ_rk4 && !w->rk4_inner);
+}
+
+int closed_loop_run_inner(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user, const rsb_linear_policy* lin, const rsb_mlp_policy* mlp, long long pg0);
 int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user, const rsb_linear_policy* lin, const rsb_mlp_policy* mlp = nullptr) {
+  // the world's global pass index (the noise slice of the in-repo stages) advances only when the run has been enqueued (a refused run
+  // used to shift the slices of every later one).  Pass K of this run sees what pass 0 of the next one sees: the index counts steps.
   const long long pg0 = w->cl_passes;
-  w->cl_passes += K;       // (pass K of this run sees what pass 0 of the next one sees: the global index counts steps)
+  const int st = closed_loop_run_inner(w, K, launch, user, lin, mlp, pg0);
+  if (st == RSB_OK) w->cl_passes = pg0 + K;
+  return st;
+}
+int closed_loop_run_inner(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user, const rsb_linear_policy* lin, const rsb_mlp_policy* mlp, const long long pg0) {
   rsb_linear_policy lin_copy{};
   rsb_mlp_policy mlp_copy{};
   if (lin) { lin_copy = *lin; user = &lin_copy; launch = launch_linear_stage; }
   if (mlp) { mlp_copy = *mlp; user = &mlp_copy; launch = launch_mlp_stage; }
-  if (!w->pipe_on) return closed_loop_lockstep(w, K, launch, user, pg0);
+  if (w->res_on && (lin || mlp)) {     // (a caller-supplied stage cannot be compiled into the step kernel: it keeps the paths below)
+    if (resident_class(w, lin ? 1 : 2, mlp ? mlp_width(*mlp) : 0) >= 0) return closed_loop_resident(w, K, lin, mlp, pg0);
+  }
+  if (!closed_loop_can_pipeline(w)) return closed_loop_lockstep(w, K, launch, user, pg0);
   // ---- pipelined: ONE launch of the stage for passes 0 .. K on its own stream, K step launches alternating between the two step streams
   hipStream_t s = stream_of(w);        // joins: a run starts from a quiet world (its snapshot is what a fault is replayed from)
-  if (!w->pipe_on) return closed_loop_lockstep(w, K, launch, user, pg0);      // (that join found a fault: pipelining is off now)
+  if (!closed_loop_can_pipeline(w)) return closed_loop_lockstep(w, K, launch, user, pg0);      // (that join found a fault: pipelining is off now)
   rsb_stage_ctx c;
   cl_fill_ctx(w, &c, K, pg0);
   int st = check_lpe(w, effective_lpe(w));
@@ -738,6 +585,10 @@ int closed_loop_run(rsb_world* w, int K, rsb_stage_launch_fn launch, void* user,
   for (int t = 0; t < K && st == RSB_OK; ++t) {
     cl_fuse(w, true);
     st = do_integrate(w, w->env_cfg.n_substeps);
+    if (st == RSB_OK && !w->pipe_active) {      // the step did not go to the pipeline (it joined): the stage has nobody to wait for - treat it as a failed enqueue
+      rsb::set_error("rsb_closed_loop_run: a step of the run left the pipeline (profiling / debug instrumentation switched on mid-run?)");
+      st = RSB_E_STATE;
+    }
   }
   w->pipe_log_suppress = false;
   if (st != RSB_OK) {

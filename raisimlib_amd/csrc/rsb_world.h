@@ -111,7 +111,10 @@ struct rsb_world {
   // epilogue / prologue fused into the next launch by rsb_control_step (consumed by do_integrate)
   struct Fuse { bool peer = false; const float* act = nullptr; const float* ptarget_src = nullptr; float* obs_out = nullptr; const int32_t* obs_idx = nullptr; int obs_slots = 0;
                 int do_reset = 0, have_allowed = 0; unsigned long long allowed = 0; const float *gc0 = nullptr, *gv0 = nullptr; int rows = 1;
-                float* env_reward = nullptr; float* env_ob = nullptr; uint8_t* env_done = nullptr; bool env_task = false; bool pipeline = false; bool closed_loop = false; } fuse;
+                float* env_reward = nullptr; float* env_ob = nullptr; uint8_t* env_done = nullptr; bool env_task = false; bool pipeline = false; bool closed_loop = false;
+                // resident launch (rsb_set_step_residency): K control steps in this ONE launch; stage 0 = open loop (targets from a bank), 1 = linear policy, 2 = actor network
+                int res_steps = 0, res_stage = 0; const float* res_targets = nullptr; int res_period = 0; long long res_first = 0, res_obs_stride = 0, res_done_stride = 0, res_pass_global0 = 0;
+                uint8_t* res_done = nullptr; rsb_linear_policy res_lin{}; rsb_mlp_policy res_mlp{}; } fuse;
   // device-resident vectorised env (rsb_env_*)
   bool env_ready = false;
   rsb_env_config env_cfg{};
@@ -168,6 +171,9 @@ struct rsb_world {
   float* d_env_act = nullptr;                            // [N, nv - 6] the env task's action rows (closed loop: written by the stage, read by the step)
   long long cl_passes = 0;                               // closed-loop steps this world has run (index of the next run's pass 0)
   int cl_grid = 0;                                       // workgroups of the action stage (0: default)
+  // ---- round 6: resident launches (rsb_set_step_residency): K control steps per launch of the step kernel, the env blocks stay in LDS
+  bool res_on = false, res_full = false;
+  long long res_launches = 0;
 };
 
 // helpers shared by the translation units (rsb_world.hip unless noted)
@@ -180,6 +186,7 @@ int copy_in(rsb_world* w, float* dst, const float* src, size_t n, int space);
 int copy_out(rsb_world* w, void* dst, const void* src, size_t bytes, int space);
 int launch_env_obs(rsb_world* w, float* dst, hipStream_t s);
 int launch_dynamics_query(rsb_world* w, hipStream_t s);           // M, h and M^-1 of the current state into d_M / d_h / d_Minv (the query kernels)
+int resident_class(rsb_world* w, int stage, int mlp_width);          // the resident kernel class (CL bits) of this world as configured, or -1 with the reason in the error string
 int rk4_integrate(rsb_world* w, int nsub);                        // rsb_rk4.hip     // the stand-alone env-task observation of the current state
 // rsb_pipeline.hip
 hipStream_t stream_of(rsb_world* w);                              // the world's stream for any use other than a pipelined launch (joins first)

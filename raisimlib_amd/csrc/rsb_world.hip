@@ -273,8 +273,8 @@ int launch_step(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool prof) {
   // the profiling instance carries the cycle stamps / contact-problem dump / LDS poisoning; production launches use the lean one
   // (the peer-exchange classes, CL bit 2, are built without a profiling twin: profile the exchange-free class instead)
   hipError_t e;
-  if constexpr ((CL & 18) != 0) {
-    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange and the pipelined kernel classes: disconnect the exchange (rsb_obs_peer_destroy) / switch pipelining off first"); return RSB_E_UNSUPPORTED; }
+  if constexpr ((CL & (18 | 64)) != 0) {
+    if (prof) { rsb::set_error("profiling / debug instrumentation is not built for the peer-exchange, the pipelined and the resident kernel classes: disconnect the exchange (rsb_obs_peer_destroy) / switch pipelining and residency off first"); return RSB_E_UNSUPPORTED; }
     e = rsbk::launch_step_instance<LPE, KMAX, CL, ML, false>(a, blocks, lds_bytes, w->launch_stream);
   } else {
     e = prof ? rsbk::launch_step_instance<LPE, KMAX, CL, ML, true>(a, blocks, lds_bytes, w->launch_stream)
@@ -300,6 +300,24 @@ int launch_lpe(rsb_world* w, const StepArgs& a, size_t lds_bytes, int lpe, bool 
 
 int n_self_pairs(const rsb_world* w) { return w->self_collision ? (int)w->self_pairs.size() / 2 : 0; }
 
+// ---- resident launches (StepArgs::res_steps; kernel classes | 64): compiled for the benchmark's two model sizes
+template <int CLR>
+int launch_resident_class(rsb_world* w, const StepArgs& a, size_t lds_bytes, bool quadruped) {
+  if (quadruped) return launch_step<16, 8, CLR, 4>(w, a, lds_bytes, false);
+  if constexpr (CLR == (64 | 384)) return RSB_E_UNSUPPORTED;      // (never reached: resident_class refuses it)
+  else return launch_step<32, 16, CLR, 12>(w, a, lds_bytes, false);
+}
+int launch_resident(rsb_world* w, const StepArgs& a, size_t lds_bytes, int cl, bool quadruped) {
+  switch (cl) {
+    case 64: return launch_resident_class<64>(w, a, lds_bytes, quadruped);
+    case 64 | 128: return launch_resident_class<64 | 128>(w, a, lds_bytes, quadruped);
+    case 64 | 256: return launch_resident_class<64 | 256>(w, a, lds_bytes, quadruped);
+    case 64 | 384: return launch_resident_class<64 | 384>(w, a, lds_bytes, quadruped);
+  }
+  rsb::set_error("internal: unknown resident kernel class");
+  return RSB_E_UNSUPPORTED;
+}
+
 int effective_lpe(const rsb_world* w) {
   int lpe = w->lpe > 0 ? w->lpe : default_lpe(w->blob, w->kmax, n_self_pairs(w));
   return lpe;
@@ -312,6 +330,31 @@ int check_lpe(const rsb_world* w, int lpe) {
   if (n_self_pairs(w) > 30 * lpe) { rsb::set_error("too many self-collision candidate pairs for this lanes_per_env (<= 30 per lane): exclude body pairs with rsb_ignore_collision_between or switch self-collision off"); return RSB_E_UNSUPPORTED; }
   if (lds_bytes_for(w->blob, kcap, lpe, n_self_pairs(w)) > 160 * 1024) { rsb::set_error("lanes_per_env too small: the workgroup's envs do not fit in 160 KiB of LDS"); return RSB_E_INVALID; }
   return RSB_OK;
+}
+
+// The resident kernel class (CL bits) a launch of this world would run as it is configured now, or -1 with the reason in the error string.
+// stage: 0 open loop, 1 linear policy, 2 actor network of greatest width mlp_width.
+int resident_class(rsb_world* w, int stage, int mlp_width) {
+  auto no = [](const char* why) { rsb::set_error(std::string("no resident launch for this world: ") + why); return -1; };
+  const rsb_model_blob& b = w->blob;
+  const int lpe = effective_lpe(w), kcap = kcap_of(b, w->kmax), mlv = b.depth - 1;
+  if (b.fixed_base) return no("fixed-base systems");
+  if (w->peer.connected) return no("the peer-mapped obs exchange is connected");
+  if (w->integ_rk4 || w->integ_theta != 1.0) return no("an integration scheme other than SEMI_IMPLICIT");
+  if (w->slip_rule == RSB_SLIP_COULOMB) return no("RSB_SLIP_COULOMB");
+  if ((w->hm_contacts >= 2 || (w->hm_capsule && w->n_cap > 0)) && w->terrain_type == 1) return no("more than one contact per primitive against a height map");
+  if (w->d_prof || w->dbg_env >= 0 || std::getenv("RSB_POISON_LDS")) return no("profiling / debug instrumentation is active");
+  if (w->N % (64 / lpe) != 0) return no("the number of envs is not a multiple of the envs per workgroup");
+  const bool quad = mlv <= 4 && kcap == 8 && lpe == 16, humanoid = mlv <= 12 && kcap == 16 && lpe == 32;
+  if (!quad && !humanoid) return no("compiled for tree depth <= 5 / <= 8 contact slots / 16 lanes per env and for tree depth <= 13 / 16 slots / 32 lanes per env");
+  if (stage == 0) return 64;
+  if (stage == 1) return 64 | 128;
+  if (stage == 2) {
+    if (mlp_width <= 128) return 64 | 256;
+    if (mlp_width <= 256 && quad) return 64 | 384;
+    return no("actor-network widths above 128 (humanoid-sized models) / 256");
+  }
+  return no("unknown stage");
 }
 
 // The per-block tables of the step kernel exactly as they sit in LDS (LdsLayout::t_*): the kernel copies this image with
@@ -451,6 +494,23 @@ int do_integrate(rsb_world* w, int nsub) {
   a.early_term = (w->early_term && w->fuse.have_allowed) ? 1 : 0;
   a.do_reset = w->fuse.do_reset; a.allowed = w->fuse.allowed; a.gc0 = w->fuse.gc0; a.gv0 = w->fuse.gv0; a.reset_rows = w->fuse.rows;
   if (!a.do_reset) { a.gc0 = w->d_gc; a.gv0 = w->d_gv; a.reset_rows = w->N; }   // never dereferenced, but keep the pointers valid
+  // resident launch: K control steps in this ONE launch (the caller has checked resident_class)
+  int res_cl = -1;
+  if (w->fuse.res_steps > 0) {
+    const rsb_world::Fuse& f = w->fuse;
+    int width = 0;
+    if (f.res_stage == 2) for (int l = 0; l <= f.res_mlp.n_layers; ++l) width = std::max(width, (int)f.res_mlp.dims[l]);
+    res_cl = resident_class(w, f.res_stage, width);
+    if (res_cl < 0 || w->launch_mask) { w->fuse = rsb_world::Fuse(); w->launch_mask = nullptr; if (res_cl >= 0) rsb::set_error("no resident launch with an env mask"); return RSB_E_UNSUPPORTED; }
+    a.res_steps = f.res_steps; a.res_full = w->res_full ? 1 : 0;
+    a.res_targets = f.res_targets; a.res_period = f.res_period; a.res_first = f.res_first;
+    a.res_obs_stride = f.res_obs_stride; a.res_done_stride = f.res_done_stride; a.res_pass_global0 = f.res_pass_global0;
+    if (f.res_stage == 1) a.res_pol.lin = f.res_lin;
+    if (f.res_stage == 2) a.res_pol.mlp = f.res_mlp;
+    if (f.res_stage == 0) { a.ptarget = f.res_targets + (size_t)(f.res_first % f.res_period) * ((size_t)w->N * w->blob.nq); a.ptarget_store = w->d_pt; }
+  }
+  uint8_t* res_done = w->fuse.res_done;
+  const int res_steps = std::max(w->fuse.res_steps, 1);
   const bool closed_loop = w->fuse.closed_loop;      // a step of rsb_closed_loop_run: waits for the action stage's word instead of its predecessor's
   const bool pipe_ok = w->fuse.pipeline && (!w->fuse.env_task || closed_loop);
   const rsb_world::Fuse fuse_in = w->fuse;
@@ -488,7 +548,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.prof_fine = prof_fine ? 1 : 0;
   a.lds_floats = (int)(lds_bytes / sizeof(float));
   const bool prof = a.prof != nullptr || a.dbg != nullptr || a.poison_lds != 0;
-  a.done_out = env_done ? env_done : w->d_done_out;
+  a.done_out = env_done ? env_done : res_done ? res_done : w->d_done_out;
   a.tau_out = w->want_genf ? w->d_genf : nullptr;
   a.env_mask = w->launch_mask; w->launch_mask = nullptr;
   // ---- pipelined control steps: this launch goes to one of the two private streams, behind a gate that lets it start only when the launch
@@ -496,7 +556,7 @@ int do_integrate(rsb_world* w, int nsub) {
   // action stage's rows (closed loop), which therefore must all be running or done (no deadlock: a waiting workgroup never keeps a
   // predecessor off the chip).  rsb_pipeline.hip holds the bookkeeping.
   hipStream_t ls = nullptr;
-  const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask;
+  const bool pipelined = w->pipe_on && pipe_ok && !prof && !peer && !a.env_mask && res_cl < 0;
   if (pipelined) {
     const int blocks = (w->N + (64 / lpe) - 1) / (64 / lpe);
     st = pipe_begin_launch(w, a, blocks, closed_loop, &ls);
@@ -518,7 +578,10 @@ int do_integrate(rsb_world* w, int nsub) {
   if (rec) HIP_TRY(hipEventRecord(e0, ls));
   // kernel classes by the deepest body level (support-chain capacity of the contact-column / Delassus phases) and by the base (fixed-base systems have a class of their own)
   const int mlv = w->blob.depth - 1;
-  if (mlv <= 4) {
+  if (res_cl >= 0) {
+    st = launch_resident(w, a, lds_bytes, res_cl, mlv <= 4);
+    if (st == RSB_OK) ++w->res_launches;
+  } else if (mlv <= 4) {
     if (w->blob.fixed_base) st = kcap == 8 ? launch_lpe<8, 1, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 1, 4>(w, a, lds_bytes, lpe, prof);
     else if (coul) st = launch_lpe<8, 32, 4>(w, a, lds_bytes, lpe, prof);
     else if (hm2) st = kcap == 8 ? launch_lpe<8, 4, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 4, 4>(w, a, lds_bytes, lpe, prof);
@@ -540,7 +603,7 @@ int do_integrate(rsb_world* w, int nsub) {
     HIP_TRY(hipEventRecord(e1, ls));
     if (!w->ring0.empty()) { w->ring_next = (w->ring_next + 1) % w->ring0.size(); if (w->ring_count < w->ring0.size()) ++w->ring_count; }
   }
-  w->world_time += nsub * w->dt;
+  w->world_time += (double)res_steps * nsub * w->dt;
   w->integrate1_valid = false;
   w->env_ob_valid = a.env_ob != nullptr && a.env_ob == w->d_env_ob;      // (the fused epilogue left the observation the NEXT step starts from in the world's own buffer)
   return RSB_OK;
@@ -1368,6 +1431,68 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
   }
   w->fuse = f;
   return rsb_integrate(w, n_substeps);
+}
+
+// K control steps of the open loop (rsb.h): ONE resident launch when residency is on and the world's class has a resident twin, else K control steps
+int rsb_control_steps(rsb_world* w, int n_steps, const float* p_targets, int period, long long first, int n_substeps, float* obs_out,
+                      long long obs_step_stride, const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions, int n_allowed,
+                      const float* gc0, const float* gv0, int rows, uint8_t* done_out, long long done_step_stride) {
+  if (!w || n_steps < 1 || !p_targets || period < 1 || first < 0 || n_substeps < 1 || obs_step_stride < 0 || done_step_stride < 0 || n_force_slots < 0 ||
+      n_force_slots > RSB_MAX_COLLISIONS || n_allowed < 0 || (n_allowed > 0 && !allowed_collisions) || ((gc0 != nullptr) != (gv0 != nullptr)) ||
+      (gc0 && rows != 1 && rows != w->N)) {
+    rsb::set_error("rsb_control_steps: bad argument");
+    return RSB_E_INVALID;
+  }
+  HIP_TRY(hipSetDevice(w->device));
+  const size_t slice = (size_t)w->N * w->blob.nq;
+  if (!(w->res_on && resident_class(w, 0, 0) >= 0)) {
+    uint8_t* const saved = w->d_done_out;
+    int st = RSB_OK;
+    for (int j = 0; j < n_steps && st == RSB_OK; ++j) {
+      if (done_out) w->d_done_out = done_out + (size_t)j * (size_t)done_step_stride;
+      st = rsb_control_step(w, p_targets + (size_t)((first + j) % period) * slice, nullptr, n_substeps, obs_out ? obs_out + (size_t)j * (size_t)obs_step_stride : nullptr,
+                            force_collisions, n_force_slots, allowed_collisions, n_allowed, gc0, gv0, rows);
+    }
+    w->d_done_out = saved;
+    return st;
+  }
+  rsb_world::Fuse f;
+  if (obs_out) {
+    f.obs_out = obs_out; f.obs_slots = n_force_slots;
+    if (force_collisions && n_force_slots > 0) {
+      int st = upload_obs_idx(w, force_collisions, n_force_slots);
+      if (st != RSB_OK) return st;
+      f.obs_idx = w->d_obs_idx;
+    }
+  }
+  if (gc0) {
+    unsigned long long allowed = 0;
+    for (int i = 0; i < n_allowed; ++i) {
+      if (allowed_collisions[i] < 0 || allowed_collisions[i] >= w->blob.ncol) { rsb::set_error("rsb_control_steps: collision index out of range"); return RSB_E_INVALID; }
+      allowed |= 1ull << allowed_collisions[i];
+    }
+    f.do_reset = 1; f.have_allowed = 1; f.allowed = allowed; f.gc0 = gc0; f.gv0 = gv0; f.rows = rows;
+  }
+  f.res_steps = n_steps; f.res_stage = 0; f.res_targets = p_targets; f.res_period = period; f.res_first = first;
+  f.res_obs_stride = obs_step_stride; f.res_done_stride = done_step_stride; f.res_done = done_out;
+  w->fuse = f;
+  return do_integrate(w, n_substeps);
+}
+int rsb_set_step_residency(rsb_world* w, int on) {
+  if (!w) { rsb::set_error("rsb_set_step_residency: null world"); return RSB_E_INVALID; }
+  w->res_on = on != 0;
+  return RSB_OK;
+}
+int rsb_step_residency_enabled(const rsb_world* w) { return w && w->res_on ? 1 : 0; }
+int rsb_step_residency_status(rsb_world* w, int stage) {
+  if (!w) { rsb::set_error("rsb_step_residency_status: null world"); return 0; }
+  return resident_class(w, stage, 128) >= 0 ? 1 : 0;
+}
+long long rsb_step_residency_launches(const rsb_world* w) { return w ? w->res_launches : 0; }
+int rsb_debug_resident_full_writes(rsb_world* w, int on) {
+  if (!w) return RSB_E_INVALID;
+  w->res_full = on != 0;
+  return RSB_OK;
 }
 
 // ---- device-resident vectorised env ------------------------------------------------------------------------------

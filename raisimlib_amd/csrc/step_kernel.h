@@ -45,6 +45,16 @@
 #include "step_math.h"      // vectors, spatial algebra, LDS access
 #include "step_terrain.h"   // sphere x height map narrow phase
 #include "step_slip.h"      // slip case of the one-contact rule, DPP row reductions
+#include "stage_bodies.h"   // the in-repo action stages' per-block bodies (resident closed-loop classes)
+
+// The resident classes (kernel class bit 64) wrap the sub-step loop and the epilogue in a loop over control steps.  The wrapper is PREPROCESSOR-selected
+// (every instance is its own translation unit, compiled with -DRSB_I_CL=...): written as `if constexpr` / a one-trip loop it moved the register
+// allocation of every other class (+4 VGPRs, +2 spilled SGPRs in the benchmark's instance) - those stay instruction for instruction what they were.
+#if defined(RSB_I_CL) && ((RSB_I_CL) & 64)
+#define RSB_RESIDENT 1
+#else
+#define RSB_RESIDENT 0
+#endif
 
 namespace rsbk {
 
@@ -111,6 +121,25 @@ __device__ __forceinline__ void tri_store(float* G, int a, int b, const float (&
   }
 }
 
+// ---- resident closed loop: pass `pass` of the action stage for env block `blk`, evaluated by the block's own wave (stage_bodies.h).  The rows the
+// body reads (observation, reward, done) were written by this wave's epilogue: the stores have to have arrived (vmcnt) and the wave's L1 must not
+// serve an older copy of the lines (buffer_inv); likewise behind it for the action rows the next control step reads.
+template <int STG, int EPW>
+__device__ __forceinline__ void resident_stage(KArgs ka, int blk, int pass, int n_steps) {
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of a translation unit that includes this header cannot copy a struct out of the kernarg address space)
+  RSB_ARGS(as);
+  asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+  rsb_stage_ctx c;
+  c.ob = as.env_ob; c.act = const_cast<float*>(as.act); c.reward = as.env_reward; c.done = as.done_out;
+  c.n_envs = as.N; c.ob_dim = 10 + 2 * (as.nv - 6); c.act_dim = as.nv - 6;
+  c.n_steps = n_steps; c.pass_global0 = as.res_pass_global0;
+  const int env0 = blk * EPW, n_env = min(EPW, as.N - env0);
+  if constexpr (STG == 1) rsb_stage_body::linear_block(c, as.res_pol.lin, env0, n_env, pass, pass == n_steps);
+  else rsb_stage_body::mlp_block<(STG == 2 ? 2 : 4)>(c, as.res_pol.mlp, env0, n_env, pass, pass == n_steps);
+  asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
+#endif
+}
+
 // ------------------------------------------------------------------------------- the kernel
 // LPE : lanes per env.  KMAX : contact capacity.  CL : kernel class bits: 1 = fixed-base systems (their contact blocks get a compliance, see the Delassus
 // phase), 2 = peer-mapped obs exchange in the epilogue (rsb_obs_peer_*); 0 = floating base, no exchange - the benchmark's class stays what it was,
@@ -134,6 +163,12 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   constexpr int EPW = 64 / LPE;
   constexpr bool FIXED = (CL & 1) != 0, PEER = (CL & 2) != 0, HM2 = (CL & 4) != 0, TH = (CL & 8) != 0, PIPE = (CL & 16) != 0;
   constexpr bool COUL = (CL & 32) != 0;   // classical Coulomb slip rule (rsb_set_slip_rule) instead of the published least-energy point
+  // RESIDENT launch (StepArgs::res_steps): several control steps per launch, the env block's state stays in LDS; STG: the action stage the block's own
+  // wave evaluates between two control steps (0 = open loop: PD targets from a bank; 1 = linear policy; 2 / 3 = actor network, widths <= 128 / <= 256)
+  constexpr bool RES = (CL & 64) != 0;
+  [[maybe_unused]] constexpr int STG = RES ? ((CL >> 7) & 3) : 0;
+  static_assert(!RES || (CL & ~(64 | 128 | 256)) == 0, "resident launches exist for the plain floating-base class");
+  static_assert(RES == (RSB_RESIDENT != 0), "the control-step loop of the resident classes is selected by the preprocessor (RSB_I_CL)");
   constexpr bool TRI = KMAX > 8;    // packed lower-triangular Delassus blocks (see tri_off); the quadruped classes keep the square layout
   const int lane = threadIdx.x;
   const int el = lane / LPE;
@@ -216,7 +251,16 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
     for (int i = lane; i < a.lds_floats; i += 64) lds[i] = __int_as_float(0x7fc00000);
     __syncthreads();
   }
+#if RSB_RESIDENT
+  const int ncs = a.res_steps;   // control steps of this launch
+  // closed loop: pass 0 of the action stage - the actions of the first control step from the observation the host left in env_ob - before the
+  // prologue reads the action rows
+  if constexpr (STG != 0) resident_stage<STG, EPW>(ka, blk, 0, ncs);
+#endif
 #include "step_phase_prologue.inc"
+#if RSB_RESIDENT
+  for (int cs = 0; cs < ncs; ++cs) {
+#endif
   for (int sub = 0; sub < nsub; ++sub) {
     RSB_STAMP(0)
     RSB_ARGS(ab);
@@ -242,6 +286,9 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
 
   if (PROF && a.prof && lane == 0) { long long* P = a.prof + 16 + 16 * (long long)blk; P[8] = t_setup; P[9] = t_newt; P[10] = t_epi; P[11] = t_rule; P[12] = t_exch; P[13] = t_end; P[14] = t_start - t_entry; P[15] = t_mag; P[0] = clock64() - t_start; P[1] = t_gs; P[2] = p_iters; P[3] = p_ncw; P[4] = p_search; P[5] = p_newton; P[6] = p_solves; P[7] = t_srch; }
 #include "step_phase_epilogue.inc"
+#if RSB_RESIDENT
+  }  // control steps
+#endif
 }
 
 }  // namespace rsbk

@@ -7,6 +7,7 @@
 #include <stdint.h>
 
 #include "rsb_types.h"
+#include "rsb_pipeline.h"   // rsb_linear_policy / rsb_mlp_policy: the resident classes carry the action stage's policy in their arguments
 
 namespace rsbk {
 
@@ -200,6 +201,23 @@ struct StepArgs {
   int pipe_stride;
   // diagnostics (RSB_PIPE_STATS=1): [0] += wall-clock ticks (100 MHz) this workgroup spent waiting for its block, [1] += 1 per workgroup that had to wait at all
   unsigned long long* pipe_stats;
+  // ---- round 6: RESIDENT launches (classes | 64; rsb_set_step_residency).  ONE launch runs res_steps control steps: an env block's state stays in
+  // LDS from the first sub-step to the last, per control step only the obs block / reward / done flags / next observation go to HBM (state rows,
+  // warm records and contact records after the LAST control step, or after every one with res_full), a terminated env is reset in LDS.  A wave's time
+  // over the launch is a SUM over control steps, so the slowest-wave tail of the lock-step launches averages out without any cross-launch hand-over.
+  // Open loop (class | 64): control step j reads its PD-target rows from slice (res_first + j) % res_period of res_targets.
+  // Closed loop (| 128 linear policy, | 256 actor network of widths <= 128, | 384 <= 256): the env block's own wave evaluates the action stage between
+  // two control steps (stage_bodies.h: the SAME body the stage kernels of rsb_pipeline.hip run, so resident == pipelined == lock-step bit for bit).
+  // At the END of the struct: every offset the other classes read stays where it was.
+  int res_steps;                         // control steps of this launch (0 / 1 in every other class)
+  int res_full;                          // 1: every control step writes what a lock-step launch writes
+  const float* res_targets;              // [res_period][N][nq]
+  int res_period;
+  long long res_first;
+  long long res_obs_stride;              // floats between the obs_out blocks of consecutive control steps (0: each step overwrites obs_out)
+  long long res_done_stride;             // bytes between their done_out rows (0: each step overwrites done_out)
+  long long res_pass_global0;            // closed loop: passes served by earlier runs of this world (rsb_stage_ctx::pass_global0)
+  union ResPolicy { rsb_linear_policy lin; rsb_mlp_policy mlp; } res_pol;
 #ifdef RSB_X_ARGPAD
   char x_pad[RSB_X_ARGPAD];
 #endif

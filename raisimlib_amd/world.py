@@ -178,6 +178,12 @@ class BatchedWorld:
         check(self.L.rsb_get_field(self.handle, RSB_F_GENERALIZED_FORCE, _hp(out), RSB_HOST), "rsb_get_field(GENERALIZED_FORCE)")
         return out
 
+    def get_pd_target(self):
+        """the world's own copy of the position targets, [N, nq] (what the last control step / setPdTarget left)"""
+        out = np.zeros((self.N, self.model.nq), np.float32)
+        check(self.L.rsb_get_field(self.handle, 2, _hp(out), RSB_HOST), "rsb_get_field(PTARGET)")
+        return out
+
     def set_self_collision(self, enable=True):
         """Collisions between non-adjacent bodies of the system (sphere x sphere; on by default, as in RaiSim)."""
         check(self.L.rsb_set_self_collision(self.handle, int(bool(enable))), "rsb_set_self_collision")
@@ -480,6 +486,42 @@ class BatchedWorld:
             if st != 0:
                 check(st, "rsb_control_step")
         return step
+
+    # -- resident control steps (rsb_control_steps / rsb_set_step_residency: K control steps per launch, the env blocks stay in LDS) ------------
+    def set_step_residency(self, on=True):
+        """rsb_control_steps and the closed-loop runs with an in-repo stage use ONE resident launch per call where the world's kernel class has a
+        resident twin (residency_status says whether it does)."""
+        check(self.L.rsb_set_step_residency(self.handle, int(bool(on))), "rsb_set_step_residency")
+
+    def residency_status(self, stage=0):
+        """True when a resident launch exists for this world as configured now (stage 0 open loop, 1 linear policy, 2 actor network)"""
+        return bool(self.L.rsb_step_residency_status(self.handle, int(stage)))
+
+    def residency_launches(self):
+        return int(self.L.rsb_step_residency_launches(self.handle))
+
+    def debug_resident_full_writes(self, on=True):
+        check(self.L.rsb_debug_resident_full_writes(self.handle, int(bool(on))), "rsb_debug_resident_full_writes")
+
+    def control_steps_plan(self, n_substeps, targets_ptr, period, obs_ptr, obs_step_stride, force_collisions, allowed_collisions, gc0_ptr, gv0_ptr, rows,
+                           done_ptr=0, done_step_stride=0):
+        """Pre-marshalled rsb_control_steps call: returns f(n_steps, first) that enqueues n_steps control steps of the open loop reading the PD-target
+        slices (first + j) % period of the device bank at targets_ptr ([period, N, nq]); one resident launch with set_step_residency(True)."""
+        fidx = _host(force_collisions, np.int32)
+        aidx = _host(allowed_collisions, np.int32) if allowed_collisions is not None else None
+        fn, h = self.L.rsb_control_steps, self.handle
+        head = (C.c_void_p(targets_ptr), int(period))
+        tail = (int(n_substeps), C.c_void_p(obs_ptr) if obs_ptr else None, int(obs_step_stride), _hp(fidx), 0 if fidx is None else fidx.shape[0],
+                _hp(aidx), 0 if aidx is None else aidx.shape[0],
+                C.c_void_p(gc0_ptr) if gc0_ptr else None, C.c_void_p(gv0_ptr) if gv0_ptr else None, int(rows),
+                C.c_void_p(done_ptr) if done_ptr else None, int(done_step_stride))
+        keep = (fidx, aidx)
+
+        def steps(n_steps, first, _keep=keep):
+            st = fn(h, int(n_steps), *head, int(first), *tail)
+            if st != 0:
+                check(st, "rsb_control_steps")
+        return steps
 
     # -- peer-mapped obs exchange (rsb_obs_peer_*: no collective, no copy kernel; see include/rsb.h) ------------
     OBS_HANDLE_BYTES = 64
