@@ -2,7 +2,9 @@
 // [RECALL raisimGymTorch/env/RaisimGymEnv.hpp, Reward.hpp; absent from /root/reference, SURVEY.md §8b].
 // Same members and virtuals as upstream; Eigen::Ref<EigenVec> is replaced by raisim::EigenVecRef, a (float*, size)
 // span with operator[] / size() / setZero() (Eigen is not installed here; where <Eigen/Core> exists the span converts
-// from and to Eigen maps).  There is no RaisimServer (visualisation is out of scope): `server_` stays null.
+// from and to Eigen maps).  `server_` is upstream's std::unique_ptr<raisim::RaisimServer>; the class behind it is a no-op (raisim/RaisimServer.hpp:
+// visualisation is out of scope) so that an environment's `if (visualizable_) { server_ = std::make_unique<...> ... }` block and its lock / unlock
+// pairs around integrate() compile and run as written.
 #pragma once
 
 #include <map>
@@ -10,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include "raisim/RaisimServer.hpp"
 #include "raisim/World.hpp"
 #include "raisim/Yaml.hpp"
 
@@ -85,12 +88,10 @@ class Reward {
   std::map<std::string, float>::iterator sumIt_;
 };
 
-class RaisimServer;   // not provided (visualisation is out of scope)
-
 class RaisimGymEnv {
  public:
   explicit RaisimGymEnv(std::string resourceDir, const Yaml::Node& cfg) : resourceDir_(std::move(resourceDir)), cfg_(cfg) {}
-  virtual ~RaisimGymEnv() = default;
+  virtual ~RaisimGymEnv() { if (server_) server_->killServer(); }      // (as upstream's destructor does [RECALL])
 
   /////// implement these methods /////////
   virtual void init() = 0;
@@ -113,10 +114,10 @@ class RaisimGymEnv {
   double getControlTimeStep() { return control_dt_; }
   double getSimulationTimeStep() { return simulation_dt_; }
   raisim::World* getWorld() { return world_.get(); }
-  void turnOffVisualization() {}
-  void turnOnVisualization() {}
-  void startRecordingVideo(const std::string&) {}
-  void stopRecordingVideo() {}
+  void turnOffVisualization() { if (server_) server_->hibernate(); }      // [RECALL upstream: server_->hibernate() / wakeup()]
+  void turnOnVisualization() { if (server_) server_->wakeup(); }
+  void startRecordingVideo(const std::string& videoName) { if (server_) server_->startRecordingVideo(videoName); }
+  void stopRecordingVideo() { if (server_) server_->stopRecordingVideo(); }
   raisim::Reward& getRewards() { return rewards_; }
 
  protected:
@@ -126,7 +127,7 @@ class RaisimGymEnv {
   std::string resourceDir_;
   Yaml::Node cfg_;
   int obDim_ = 0, actionDim_ = 0;
-  RaisimServer* server_ = nullptr;
+  std::unique_ptr<raisim::RaisimServer> server_;
   raisim::Reward rewards_;
 };
 

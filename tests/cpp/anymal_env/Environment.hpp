@@ -65,6 +65,13 @@ class ENVIRONMENT : public RaisimGymEnv {
     footIndices_.insert(anymal_->getBodyIdx("LH_SHANK"));
     footIndices_.insert(anymal_->getBodyIdx("RH_SHANK"));
     footCollisions_ = {7, 11, 15, 19};   // the stand-in URDF also has knee spheres on the shanks: feet by collision primitive
+
+    /// visualize if it is the first environment
+    if (visualizable_) {
+      server_ = std::make_unique<raisim::RaisimServer>(world_.get());
+      server_->launchServer();
+      server_->focusOn(anymal_);
+    }
   }
 
   void init() final {}
@@ -85,7 +92,9 @@ class ENVIRONMENT : public RaisimGymEnv {
     anymal_->setPdTarget(pTarget_, vTarget_);
 
     for (int i = 0; i < int(control_dt_ / simulation_dt_ + 1e-10); i++) {
+      if (server_) server_->lockVisualizationServerMutex();
       world_->integrate();
+      if (server_) server_->unlockVisualizationServerMutex();
     }
 
     updateObservation();

@@ -71,6 +71,13 @@ class ENVIRONMENT : public RaisimGymEnv {
     footIndices_.insert(anymal_->getBodyIdx("LH_SHANK"));
     footIndices_.insert(anymal_->getBodyIdx("RH_SHANK"));
     RSFATAL_IF(footIndices_.size() != 4, "expected four shank bodies, found " << footIndices_.size());
+
+    /// visualize if it is the first environment
+    if (visualizable_) {
+      server_ = std::make_unique<raisim::RaisimServer>(world_.get());
+      server_->launchServer();
+      server_->focusOn(anymal_);
+    }
   }
 
   void init() final {}
@@ -90,7 +97,9 @@ class ENVIRONMENT : public RaisimGymEnv {
     anymal_->setPdTarget(pTarget_, vTarget_);
 
     for (int i = 0; i < int(control_dt_ / simulation_dt_ + 1e-10); i++) {
+      if (server_) server_->lockVisualizationServerMutex();
       world_->integrate();
+      if (server_) server_->unlockVisualizationServerMutex();
     }
 
     updateObservation();

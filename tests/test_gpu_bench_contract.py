@@ -30,13 +30,26 @@ def test_bench_prints_the_contract_line(built_lib, config):
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in roof, k
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
-    # consecutive control steps are pipelined by default: the same line also carries the lock-step number (same bracket, pipelining off) and
+    # round 6: `value` is the RESIDENT leg (the bracket's control steps are one launch of the step kernel), the median of `repeats` fresh brackets; the
+    # pipelined and the lock-step legs of the same line carry their own repeats
+    assert b["value_leg"] == "resident" and b["resident_leg_error"] is None and b["resident"]["value"] == b["value"]
+    for blk in (b, b["resident"], b["pipelined"], b["lockstep"]):
+        assert blk["repeats"] == 7 and len(blk["value_repeats"]) == 7 and blk["value_min"] <= blk["value"] <= blk["value_max"]
+        assert sorted(blk["value_repeats"])[3] == pytest.approx(blk["value"], rel=1e-9)
+    assert roof["control_steps_per_launch"] == 6 and roof["kernel_launches_timed"] == 7
+    assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms_mean"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
+    assert roof["algorithmic_bytes_per_launch"] == roof["algorithmic_bytes_per_env_step"] * 4096 * 4 * 6
+    assert roof["kernel_ms_mean"] <= b["ms_per_step"] * 6 * 1.02          # the launch's own duration fits in the bracket it is the only launch of
+    assert b["pipelined"]["value"] > 1e6
+    roof = roof["control_step_launches"]            # the per-control-step launches of the pipelined leg, as round 5 reported them
+    pipe_ms = b["pipelined"]["ms_per_step"]
+    # consecutive control steps of that leg are pipelined: the same line also carries the lock-step number (same bracket, pipelining off) and
     # the roofline object says what its per-launch figures refer to
     assert b["config"]["step_pipelining"].startswith("on") and b["lockstep"]["value"] > 1e6 and b["lockstep"]["steps"] == 6
     ps = b["config"]["step_pipelining_stats"]
-    assert ps["streams_overlap"] is True and ps["pipelined_launches"] >= 6 + 2 + 8      # timed + warm-up + pre-roll at least; the probe found a pair of streams that overlap
+    assert ps["streams_overlap"] is True and ps["pipelined_launches"] >= 7 * 6 + 2 + 8      # timed + warm-up + pre-roll at least; the probe found a pair of streams that overlap
     assert abs(b["lockstep"]["value"] - 4096 * 4 * 6 / (b["lockstep"]["ms_per_step"] * 6 * 1e-3)) < 1e-3 * b["lockstep"]["value"]
-    assert abs(roof["effective_ms_per_launch"] - b["ms_per_step"]) < 1e-9 and roof["launches_in_flight"] > 0.5
+    assert abs(roof["effective_ms_per_launch"] - pipe_ms) < 1e-9 and roof["launches_in_flight"] > 0.5
     assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["effective_ms_per_launch"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
     assert abs(roof["achieved_over_one_launch_duration"] - roof["algorithmic_bytes_per_launch"] / (roof["kernel_ms_mean"] * 1e-3) / 1e9) < 1e-6 * roof["achieved"]
     cb = b["cpu_baseline"]
@@ -55,6 +68,7 @@ def test_bench_prints_the_contract_line(built_lib, config):
         tp = b["boundary_template_path"]
         assert "error" not in tp, tp
         assert tp["env_steps_per_s"] > 1e5 and tp["kernel_launches_per_control_step"] == 1.0
+        assert len(tp["attempts_env_steps_per_s"]) == 3 and sorted(tp["attempts_env_steps_per_s"])[1] == tp["env_steps_per_s"]      # the median of three attempts
     else:
         assert "secondary" not in b
 
@@ -68,6 +82,9 @@ def test_bench_collective_path_on_one_rank(built_lib):
     b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert b["n_gpus"] == 1 and b["config"]["obs_all_gather"].startswith("on a stream of its own behind each pipelined control step")
     assert len(b["ms_per_step_by_rank"]) == 1 and b["value"] > 1e6 and b["lockstep"]["value"] > 1e6
+    # the resident leg's collective: ONE all-gather of the launch's [steps, N, obs] block behind the launch, and this rank's slice of the result is its own block
+    rs = b["resident"]
+    assert b["value_leg"] == "resident" and rs["gathered_rows_of_this_rank_correct"] is True and rs["obs_all_gather"]["block"] == [6, 4096, 49]
 
 
 def test_bench_lockstep_flag(built_lib):
@@ -101,15 +118,16 @@ def test_bench_two_leg_order_of_an_n_gpu_run_on_one_rank(built_lib):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp", env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert b["value_leg"] == "pipelined" and b["pipelined_leg_error"] is None
+    assert b["value_leg"] == "resident" and b["pipelined_leg_error"] is None and b["resident_leg_error"] is None and b["pipelined"]["leg"] == "pipelined"
+    assert b["resident"]["gathered_rows_of_this_rank_correct"] is True
     ls = b["lockstep"]
     assert ls["ran_first"] is True and ls["obs_all_gather"] == "in line" and ls["gathered_rows_of_this_rank_correct"] is True and ls["value"] > 1e6
     assert b["value"] > 1e6                                          # (six steps are not a measurement: which leg is faster is bench.py's business)
     rc = b["rccl"]
     assert rc["rccl_ranks"] == 1 and rc["allreduce_of_ones"] == 1.0 and rc["distinct_devices"] == 1 and rc["by_rank"][0]["rank"] == 0 and rc["by_rank"][0]["compute_units"] > 0
-    roof = b["roofline"]
+    roof = b["roofline"]["control_step_launches"]
     assert abs(roof["frac"] - roof["frac_throughput"]) < 1e-12 and 0 < roof["frac_kernel_duration"] <= roof["frac_throughput"] * 1.05
-    assert roof["timed_region_brackets"]["stride"] == 1 and roof["timed_region_brackets"]["n"] == 6
+    assert roof["timed_region_brackets"]["stride"] == 1 and roof["timed_region_brackets"]["n"] == 7 * 6
 
 
 def test_bench_closed_loop_block(built_lib):
@@ -120,8 +138,11 @@ def test_bench_closed_loop_block(built_lib):
     assert r.returncode == 0, r.stderr[-2000:]
     c = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])["closed_loop"]
     for blk, gain in ((c, 1.1), (c["mlp"], 0.9)):          # (40 steps: the MLP leg's 6 % are within a noisy box's reach; what is pinned is the block and the equal populations)          # the linear reference stage and the actor network (34-128-128-12) as the stage (whose 89 KB of weights per env block bound it: DESIGN.md 4.3)
-        p, l = blk["pipelined"], blk["lockstep"]
-        assert p["value"] > gain * l["value"] > 1e6
+        p, l, rs = blk["pipelined"], blk["lockstep"], blk["resident"]
+        assert p["value"] > gain * l["value"] > 1e6 and rs["value"] > gain * l["value"]
         for k in ("resets_per_control_step_mean", "contacts_per_env", "solver_iters_mean", "base_height_mean"):
-            assert p[k] == l[k], k
+            assert p[k] == l[k] == rs[k], k
+        for m in (p, l, rs):
+            assert m["repeats"] == 7 and m["value_min"] <= m["value"] <= m["value_max"]
+        assert rs["resident_launches"] >= 7
     assert c["pipeline"]["faults"] == 0 and c["pipeline"]["streams_overlap"] is True and c["pipeline"]["pipelined_launches"] >= 40
