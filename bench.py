@@ -114,6 +114,11 @@ def parse():
                     help="no resident leg (rsb_set_step_residency: --steps control steps in ONE launch of the step kernel): `value` is then the pipelined leg's, as in round 5")
     ap.add_argument("--closed-loop-only", action="store_true", help="diagnostic: only the `closed_loop` block (policy in the loop, include/rsb_pipeline.h), as its own JSON line")
     ap.add_argument("--stage-grid", type=int, default=0, help="diagnostic (closed loop): workgroups of the action stage (library default 256)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank uses cuda:0 (VERDICT r05 #4: the legs of an N > 1 run with real kernels and real processes - "
+                         "lock-step + in-line gather, pipelined + side-stream gather, resident + one gather per launch - before a multi-GPU node runs them). "
+                         "RCCL refuses two ranks on one device: use --backend gloo.  Not a measurement: the ranks share the chip")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="torch.distributed backend of the obs all-gather (nccl = RCCL; gloo: --share-device runs)")
     ap.add_argument("--dry-run-fail-leg", type=int, default=-1, help="test hook (--dry-run-ranks): the second leg raises on this rank")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="plumbing check without GPUs: the ranks rendezvous on gloo, all-gather a host obs block per step and "
@@ -137,7 +142,7 @@ def spawn_ranks(args):
     if not args.dry_run_ranks:
         import torch
         have = torch.cuda.device_count()
-        if have < n:
+        if have < (1 if args.share_device else n):
             print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have} (no CPU or single-GPU fallback for N>1)",
                   file=sys.stderr)
             return 2
@@ -831,6 +836,9 @@ def measure(args, rank, local_rank, world_size, dev, coll):
             step_start = kstep
         n_in = start_brackets()
         r = repeated(per_step(control_step), drain)
+        if gath.active and hasattr(gath, "gathered"):      # this rank's slice of the gathered block of the last step = its own block
+            torch.cuda.synchronize()
+            r["gathered_rows_of_this_rank_correct"] = bool(torch.equal(gath.gathered(kstep - 1)[rank * N:(rank + 1) * N], gath.local(kstep - 1)))
         return r
 
     # ---- the RESIDENT leg (round 6; rsb_set_step_residency): the timed region's --steps control steps are ONE launch of the step kernel - an env block's
@@ -890,6 +898,11 @@ def measure(args, rank, local_rank, world_size, dev, coll):
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         return float(f.item()) == 1.0
 
+    def rows_ok_everywhere(r):
+        """gathered_rows_of_this_rank_correct of a leg -> also ..._on_all_ranks (MIN over the ranks: rank 0 prints the line)"""
+        if r is not None and coll and r.get("gathered_rows_of_this_rank_correct") is not None:
+            r["gathered_rows_correct_on_all_ranks"] = all_agree(bool(r["gathered_rows_of_this_rank_correct"]))
+
     legs = two_legs(leg_lockstep_inline if lockstep_first_wanted else None, leg_primary, all_agree)
     lockstep_first = legs["first"]
     value_leg, pipelined_leg_error = ("pipelined" if pipelined else "lockstep"), legs["error"]
@@ -908,6 +921,8 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     if n_in:
         world.enable_timing(0)
     primary_leg = legs["second"] if legs["use"] == "second" else lockstep_first
+    rows_ok_everywhere(lockstep_first)
+    rows_ok_everywhere(legs["second"])
 
     # ---- the resident leg, under a guard (N > 1: every rank agrees whether it counts; a leg that raised anywhere counts nowhere)
     res_leg, resident_leg_error = None, None
@@ -923,6 +938,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
         if not all_agree(resident_leg_error is None):
             res_leg = None
             resident_leg_error = resident_leg_error or "the leg raised on another rank"
+        rows_ok_everywhere(res_leg)
 
     # ---- sampling pass (untimed, same sequence continued): every launch bracketed; resets and env ages recorded
     kernel_ms_s = np.zeros(0)
@@ -1084,11 +1100,13 @@ def measure(args, rank, local_rank, world_size, dev, coll):
             "value_leg": value_leg, "pipelined_leg_error": pipelined_leg_error, "resident_leg_error": resident_leg_error,
             "resident": ({"value": value, "unit": "env-steps/s", "ms_per_step": res_leg["elapsed"] / args.steps * 1e3, "steps": args.steps, **spread(res_leg, total_env_steps),
                           "launches_per_bracket": 1, "obs_all_gather": res_state["gather"], "gathered_rows_of_this_rank_correct": res_leg.get("gathered_rows_of_this_rank_correct"),
+                          "gathered_rows_correct_on_all_ranks": res_leg.get("gathered_rows_correct_on_all_ranks"),
                           "what": "rsb_control_steps with rsb_set_step_residency: the bracket's --steps control steps are ONE launch of the step kernel's resident class - env blocks "
                                   "stay in LDS, terminated envs restart in LDS, obs block / done flags go to HBM per control step, state / warm / contact records after the "
                                   "last one; bit-identical to the lock-step steps (tests/test_gpu_resident.py)"} if res_leg is not None else None),
             "pipelined": ({"value": primary_value, "unit": "env-steps/s", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps, **spread(primary_leg, total_env_steps),
-                           "leg": primary_name, "what": "round 5's `value`: one launch per control step, consecutive launches overlapping on the device (rsb_set_step_pipelining)"}
+                           "leg": primary_name, "gathered_rows_of_this_rank_correct": primary_leg.get("gathered_rows_of_this_rank_correct"),
+                           "gathered_rows_correct_on_all_ranks": primary_leg.get("gathered_rows_correct_on_all_ranks"), "what": "round 5's `value`: one launch per control step, consecutive launches overlapping on the device (rsb_set_step_pipelining)"}
                           if res_leg is not None else None),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
@@ -1128,6 +1146,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
             "lockstep": ({"value": total_env_steps / lockstep, "unit": "env-steps/s", "ms_per_step": lockstep / args.steps * 1e3, "steps": args.steps, **spread(lockstep_leg, total_env_steps),
                           "ran_first": lockstep_first is not None, "obs_all_gather": (lockstep_first or {}).get("obs_all_gather"),
                           "gathered_rows_of_this_rank_correct": (lockstep_first or {}).get("gathered_rows_of_this_rank_correct"),
+                          "gathered_rows_correct_on_all_ranks": (lockstep_first or {}).get("gathered_rows_correct_on_all_ranks"),
                           "what": "rsb_set_step_pipelining off, same bracket: every launch waits for the slowest wave of the one before it (what a caller "
                                   "gets that consumes each step's output before issuing the next step, e.g. a policy in the loop)"} if lockstep else None),
             "build": {"source_hash": world.L.rsb_source_hash().decode(), "library": os.path.relpath(os.path.realpath(__import__("raisimlib_amd")._capi.LIB_PATH), ROOT)},
@@ -1170,6 +1189,8 @@ def main():
 
     from raisimlib_amd import BatchedWorld, workload
 
+    if args.share_device:
+        local_rank = 0          # every rank on cuda:0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, this node shows {torch.cuda.device_count()} (no CPU fallback)")
     coll = world_size > 1 or args.force_collective     # the obs all-gather is part of the step
@@ -1179,7 +1200,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if coll:
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size)
 
     if args.closed_loop_only:
         print(json.dumps({"closed_loop": closed_loop_leg(args, dev, args.envs_per_gpu)}), flush=True)

@@ -108,54 +108,55 @@ class DeviceVectorizedEnvironment {
   // over env block by env block: with setStepPipelining(true) consecutive steps overlap although each step's actions depend on the one before.
   /// consecutive control steps overlap on the device (bit-identical results); returns what the library granted (false under a serialising profiler)
   bool setStepPipelining(bool on) { RSB_CHECK(rsb_set_step_pipelining(world_.handle(), on ? 1 : 0)); return rsb_step_pipelining_enabled(world_.handle()) != 0; }
+  /// round 6: K control steps of rolloutLinear / rolloutMlp run as ONE resident launch of the step kernel - the env blocks stay in LDS, each block's own wave
+  /// evaluates the policy between two control steps (rsb_set_step_residency; bit-identical results).  Returns whether this world has a resident kernel class.
+  bool setStepResidency(bool on) { RSB_CHECK(rsb_set_step_residency(world_.handle(), on ? 1 : 0)); return rsb_step_residency_status(world_.handle(), 1) != 0; }
   /// K control steps with the CALLER's stage kernel (a HIP kernel built around rsb_stage::serve).  Nothing synchronises.
   void closedLoopRun(int steps, rsb_stage_launch_fn launch, void* user) { RSB_CHECK(rsb_closed_loop_run(world_.handle(), steps, launch, user)); }
   /// K control steps with the in-repo linear policy  action = clip(bias + W ob):  W [actionDim, obDim] row-major and bias [actionDim] are HOST
-  /// arrays (uploaded when they change: pass the same pointers to skip the upload); clip <= 0: none.  Nothing synchronises.
+  /// arrays, uploaded at EVERY call - a learner updates its weights in place, so the pointers say nothing about the contents; the copy is
+  /// 1.6 KB next to a K-step run.  clip <= 0: none.  The run itself does not synchronise.
   void rolloutLinear(int steps, const float* W, const float* bias = nullptr, float clip = 0.f) {
     RSFATAL_IF(!W, "rolloutLinear: W is null");
     const size_t wb = (size_t)actionDim_ * obDim_ * sizeof(float), bb = (size_t)actionDim_ * sizeof(float);
     if (!dW_) { RSB_CHECK(rsb_device_alloc(world_.handle(), wb, &dW_)); RSB_CHECK(rsb_device_alloc(world_.handle(), bb, &dBias_)); }
-    if (W != lastW_ || bias != lastBias_) {
-      RSB_CHECK(rsb_device_copy(world_.handle(), dW_, W, wb, 0));
-      if (bias) RSB_CHECK(rsb_device_copy(world_.handle(), dBias_, bias, bb, 0));
-      lastW_ = W; lastBias_ = bias;
-    }
+    RSB_CHECK(rsb_device_copy(world_.handle(), dW_, W, wb, 0));
+    if (bias) RSB_CHECK(rsb_device_copy(world_.handle(), dBias_, bias, bb, 0));
     rsb_linear_policy p{};
     p.W = static_cast<const float*>(dW_); p.bias = bias ? static_cast<const float*>(dBias_) : nullptr; p.clip = clip;
     RSB_CHECK(rsb_closed_loop_run_linear(world_.handle(), steps, &p));
   }
   /// K control steps with an ACTOR NETWORK in the loop (the in-repo MLP stage, rsb_closed_loop_run_mlp): layer l = (weights[l] [dims[l + 1], dims[l]]
-  /// row-major as torch.nn.Linear stores them, biases[l] [dims[l + 1]] or null), HOST arrays, uploaded (transposed) when `weights` changes;
+  /// row-major as torch.nn.Linear stores them, biases[l] [dims[l + 1]] or null), HOST arrays, uploaded (weights transposed) at EVERY call (in-place updates of
+  /// the learner's buffers are the normal case: ADVICE r05; 89 KB for 34-128-128-12); the device buffers are re-allocated only when `dims` changes;
   /// dims.front() = obDim, dims.back() = actionDim, widths <= 256; activation RSB_ACT_TANH / _RELU / _LEAKY_RELU on the hidden layers.
   void rolloutMlp(int steps, const std::vector<int>& dims, const std::vector<const float*>& weights, const std::vector<const float*>& biases,
                   int activation = RSB_ACT_LEAKY_RELU, float clip = 0.f) {
     const int L = (int)dims.size() - 1;
     RSFATAL_IF(L < 1 || L > RSB_MLP_MAX_LAYERS || (int)weights.size() != L || (int)biases.size() != L, "rolloutMlp: 1 .. 4 layers, one weight and one bias pointer per layer");
-    if (weights != mlpHostW_ || dims != mlpDims_) {
+    for (int l = 0; l < L; ++l) RSFATAL_IF(!weights[l], "rolloutMlp: a layer's weight pointer is null");
+    if (dims != mlpDims_) {      // device buffers: one weight and one bias buffer per layer, sized by dims
       for (void* d : mlpDev_) rsb_device_free(world_.handle(), d);
-      mlpDev_.clear();
-      mlp_ = rsb_mlp_policy{};
-      mlp_.n_layers = L;
-      for (int l = 0; l <= L; ++l) mlp_.dims[l] = dims[l];
+      mlpDev_.assign(2 * (size_t)L, nullptr);
       for (int l = 0; l < L; ++l) {
-        const int in = dims[l], out = dims[l + 1];
-        std::vector<float> wt((size_t)in * out);
-        for (int o = 0; o < out; ++o) for (int i = 0; i < in; ++i) wt[(size_t)i * out + o] = weights[l][(size_t)o * in + i];
-        void* dw = nullptr;
-        RSB_CHECK(rsb_device_alloc(world_.handle(), wt.size() * sizeof(float), &dw));
-        mlpDev_.push_back(dw);
-        RSB_CHECK(rsb_device_copy(world_.handle(), dw, wt.data(), wt.size() * sizeof(float), 0));
-        mlp_.Wt[l] = static_cast<const float*>(dw);
-        if (biases[l]) {
-          void* db = nullptr;
-          RSB_CHECK(rsb_device_alloc(world_.handle(), (size_t)out * sizeof(float), &db));
-          mlpDev_.push_back(db);
-          RSB_CHECK(rsb_device_copy(world_.handle(), db, biases[l], (size_t)out * sizeof(float), 0));
-          mlp_.bias[l] = static_cast<const float*>(db);
-        }
+        RSB_CHECK(rsb_device_alloc(world_.handle(), (size_t)dims[l] * dims[l + 1] * sizeof(float), &mlpDev_[2 * l]));
+        RSB_CHECK(rsb_device_alloc(world_.handle(), (size_t)dims[l + 1] * sizeof(float), &mlpDev_[2 * l + 1]));
       }
-      mlpHostW_ = weights; mlpDims_ = dims;
+      mlpDims_ = dims;
+    }
+    mlp_ = rsb_mlp_policy{};
+    mlp_.n_layers = L;
+    for (int l = 0; l <= L; ++l) mlp_.dims[l] = dims[l];
+    for (int l = 0; l < L; ++l) {
+      const int in = dims[l], out = dims[l + 1];
+      mlpStage_.resize((size_t)in * out);
+      for (int o = 0; o < out; ++o) for (int i = 0; i < in; ++i) mlpStage_[(size_t)i * out + o] = weights[l][(size_t)o * in + i];
+      RSB_CHECK(rsb_device_copy(world_.handle(), mlpDev_[2 * l], mlpStage_.data(), mlpStage_.size() * sizeof(float), 0));      // (joins and waits: the staging vector is free again)
+      mlp_.Wt[l] = static_cast<const float*>(mlpDev_[2 * l]);
+      if (biases[l]) {
+        RSB_CHECK(rsb_device_copy(world_.handle(), mlpDev_[2 * l + 1], biases[l], (size_t)out * sizeof(float), 0));
+        mlp_.bias[l] = static_cast<const float*>(mlpDev_[2 * l + 1]);
+      }
     }
     mlp_.activation = activation; mlp_.leaky_slope = 0.01f; mlp_.clip = clip;
     RSB_CHECK(rsb_closed_loop_run_mlp(world_.handle(), steps, &mlp_));
@@ -194,9 +195,8 @@ class DeviceVectorizedEnvironment {
   std::vector<int32_t> feet_;
   std::vector<uint8_t> done_;
   void* dW_ = nullptr; void* dBias_ = nullptr;       // rolloutLinear's weights on the device (freed with the world's context)
-  const float* lastW_ = nullptr; const float* lastBias_ = nullptr;
   rsb_mlp_policy mlp_{};                             // rolloutMlp's network on the device
-  std::vector<void*> mlpDev_; std::vector<const float*> mlpHostW_; std::vector<int> mlpDims_;
+  std::vector<void*> mlpDev_; std::vector<int> mlpDims_; std::vector<float> mlpStage_;
 };
 
 /// Upstream's template: N arbitrary ChildEnvironment objects on one GPU batch (see the header comment).

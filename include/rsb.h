@@ -446,6 +446,9 @@ int rsb_debug_resident_full_writes(rsb_world* w, int on);
  *                            handle's stream; out in `space` (DEVICE: gathered in place, nothing synchronises; HOST: staged) */
 /* RSB_MAX_RANKS (ranks of one node; peer-mapped obs exchange below): rsb_types.h */
 #define RSB_COMM_ID_BYTES 128
+/* versions of RCCL as NCCL_VERSION_CODE: of the librccl.so.1 loaded at run time (ncclGetVersion) and of the <rccl/rccl.h> this library's constants were checked
+ * against when it was built (0: the header was not installed on the build host).  Either pointer may be NULL. */
+int rsb_comm_rccl_version(int* runtime_version, int* header_version);
 int rsb_comm_get_unique_id(char id[RSB_COMM_ID_BYTES]);
 int rsb_comm_init(rsb_world* w, int n_ranks, int rank, const char id[RSB_COMM_ID_BYTES]);
 int rsb_comm_destroy(rsb_world* w);

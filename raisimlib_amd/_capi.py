@@ -168,6 +168,7 @@ PROTOTYPES = {
     "rsb_device_free": (_I, [_VP, _VP]),
     "rsb_device_copy": (_I, [_VP, _VP, _VP, C.c_size_t, _I]),
     "rsb_set_done_output": (_I, [_VP, _VP]),
+    "rsb_comm_rccl_version": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rsb_comm_get_unique_id": (_I, [C.c_char_p]),
     "rsb_comm_init": (_I, [_VP, _I, _I, C.c_char_p]),
     "rsb_comm_destroy": (_I, [_VP]),

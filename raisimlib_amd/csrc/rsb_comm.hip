@@ -6,9 +6,17 @@
 
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rsb_world.h"
+
+// RCCL is bound by dlopen + hand-written prototypes (a single-GPU host never loads it).  Where its header is installed, the constants this file
+// copies from it are checked against it AT BUILD TIME - the header is included for these assertions only, no symbol of it is used.
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define RSB_HAVE_RCCL_HEADER 1
+#endif
 
 using namespace rsbw;
 
@@ -21,6 +29,7 @@ struct Rccl {
   int (*CommDestroy)(void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
   void* handle = nullptr;
   std::string error;
 };
@@ -37,6 +46,7 @@ Rccl* rccl() {
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
   r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+  r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));      // (optional: rsb_comm_rccl_version)
   if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
     r.error = "librccl.so.1 lacks an expected ncclXxx symbol"; dlclose(r.handle); r.handle = nullptr; return nullptr;
   }
@@ -48,6 +58,16 @@ Rccl* need_rccl() {
   return r;
 }
 constexpr int kNcclFloat32 = 7;   // ncclDataType_t::ncclFloat32 (rccl.h)
+#ifdef RSB_HAVE_RCCL_HEADER
+static_assert((int)ncclFloat32 == kNcclFloat32, "rccl.h: ncclFloat32 is not the value rsb_comm.hip passes to ncclAllGather");
+static_assert((int)ncclSuccess == 0, "rccl.h: ncclSuccess is not 0");
+static_assert(sizeof(ncclUniqueId) == RSB_COMM_ID_BYTES, "rccl.h: ncclUniqueId is not RSB_COMM_ID_BYTES bytes");
+static_assert(std::is_same<decltype(&ncclAllGather), ncclResult_t (*)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t)>::value, "rccl.h: ncclAllGather's signature changed");
+static_assert(std::is_same<decltype(&ncclCommInitRank), ncclResult_t (*)(ncclComm_t*, int, ncclUniqueId, int)>::value, "rccl.h: ncclCommInitRank's signature changed");
+constexpr int kRcclHeaderVersion = NCCL_VERSION_CODE;
+#else
+constexpr int kRcclHeaderVersion = 0;
+#endif
 #define NCCL_TRY(expr)                                                                                   \
   do {                                                                                                   \
     int r_ = (expr);                                                                                     \
@@ -56,6 +76,17 @@ constexpr int kNcclFloat32 = 7;   // ncclDataType_t::ncclFloat32 (rccl.h)
 }  // namespace
 
 extern "C" {
+
+int rsb_comm_rccl_version(int* runtime_version, int* header_version) {
+  if (header_version) *header_version = kRcclHeaderVersion;
+  if (runtime_version) {
+    *runtime_version = 0;
+    Rccl* R = need_rccl();
+    if (!R) return RSB_E_UNSUPPORTED;
+    if (R->GetVersion) { int v = 0; NCCL_TRY(R->GetVersion(&v)); *runtime_version = v; }
+  }
+  return RSB_OK;
+}
 
 int rsb_comm_get_unique_id(char id[RSB_COMM_ID_BYTES]) {
   if (!id) return RSB_E_INVALID;

@@ -102,6 +102,15 @@ int rank_main(const char* urdf, int rank, int ranks, int id_out_fd, int id_in_fd
   rsb_world* w = nullptr;
   if (make_shard(model, device, rank * kEnvs, &w)) return 1;
   CHECK(rsb_comm_init(w, ranks, rank, id));
+  if (rank == 0) {
+    // which RCCL is this, and is it the one the library's hand-copied constants were checked against at build time (static_asserts in rsb_comm.hip)?
+    int rt = 0, hdr = 0;
+    CHECK(rsb_comm_rccl_version(&rt, &hdr));
+    std::printf("comm_launcher: RCCL runtime version code %d, header version code %d (0 = no header on the build host)\n", rt, hdr);
+    std::fflush(stdout);      // (a rank leaves through _exit: buffered output would be lost)
+    if (rt <= 0) { std::fprintf(stderr, "rank 0: ncclGetVersion reported nothing\n"); return 1; }
+    if (hdr > 0 && rt / 10000 != hdr / 10000 && rt / 1000 != hdr / 1000) { std::fprintf(stderr, "rank 0: RCCL major version of the runtime (%d) and of the build header (%d) differ\n", rt, hdr); return 1; }
+  }
   const int feet = 4, od = rsb_obs_dim(w, feet);
   std::vector<float> all((size_t)ranks * kEnvs * od, -1.f), local((size_t)kEnvs * od);
   CHECK(rsb_allgather_obs(w, nullptr, feet, all.data(), RSB_HOST));

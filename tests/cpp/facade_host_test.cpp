@@ -28,9 +28,10 @@ rsbd_counter_block* rsbd_counters(void);
 
 using VecEnv = raisim::VectorizedEnvironment<raisim::ENVIRONMENT>;
 
+static bool g_render = false;      // render: true -> env 0 is built `visualizable`: the upstream-style block creates its raisim::RaisimServer (a no-op here)
 static std::string cfg(int n, int threads) {
   return "num_envs: " + std::to_string(n) + "\nnum_threads: " + std::to_string(threads) +
-         "\nsimulation_dt: 0.0025\ncontrol_dt: 0.01\nrender: false\naction_std: 0.3\nreward:\n  forwardVel:\n    coeff: 0.3\n  torque:\n    coeff: -4e-5\n";
+         "\nsimulation_dt: 0.0025\ncontrol_dt: 0.01\nrender: " + (g_render ? "true" : "false") + "\naction_std: 0.3\nreward:\n  forwardVel:\n    coeff: 0.3\n  torque:\n    coeff: -4e-5\n";
 }
 
 struct Run { std::vector<float> ob, rew; std::vector<char> done; long launches = 0, exchanges = 0, substeps = 0, reentries = 0; };
@@ -186,6 +187,26 @@ int main(int argc, char** argv) {
     }
     CHECK(bad.load() == 0);
     CHECK(rsbd_counters()->reentries == 0);
+  }
+  {
+    // 5. raisim::RaisimServer (include/raisim/RaisimServer.hpp, a no-op: visualisation is out of scope).  With `render: true` env 0 runs upstream's
+    // `if (visualizable_) { server_ = std::make_unique<RaisimServer>(world_.get()); launchServer(); focusOn(robot); }` block and brackets every
+    // integrate() with the server's lock / unlock - the results are those of the run without it, nothing listens, the mutex is a real one
+    g_render = true;
+    const Run v = run_env(rsc, N, 5, true, STEPS);
+    g_render = false;
+    CHECK(v.ob == a.ob && v.rew == a.rew && v.done == a.done && v.launches == STEPS);
+    raisim::World w0;
+    raisim::RaisimServer srv(&w0);
+    CHECK(!srv.isLaunched() && !srv.isConnected());
+    srv.launchServer();
+    CHECK(srv.isLaunched() && srv.getPort() == 8080 && !srv.isConnected());
+    srv.focusOn(&w0);
+    CHECK(srv.focusedObject() == &w0);
+    srv.lockVisualizationServerMutex(); srv.unlockVisualizationServerMutex();
+    srv.hibernate(); CHECK(srv.isHibernating()); srv.wakeup(); CHECK(!srv.isHibernating());
+    srv.startRecordingVideo("x.mp4"); CHECK(srv.isRecording()); srv.stopRecordingVideo(); CHECK(!srv.isRecording());
+    srv.killServer(); CHECK(!srv.isLaunched());
   }
   std::printf("facade_host_test OK\n");
   return 0;

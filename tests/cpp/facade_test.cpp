@@ -1,6 +1,7 @@
 // Compiles against include/raisim/*.hpp only (the way an upstream Environment.hpp would) and links librsb.so.
 // Exercises: per-env raisim::World (N = 1 replica), ArticulatedSystem views, integrate1/2 queries, contacts,
 // and the batched VectorizedEnvironment.  Exit code 0 = all checks passed.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <memory>
@@ -42,6 +43,35 @@ class FlakyEnv : public raisim::RaisimGymEnv {
 int main(int argc, char** argv) {
   if (argc < 2) { std::printf("usage: facade_test <urdf>\n"); return 2; }
   const std::string urdf = argv[1];
+  if (argc >= 3 && std::string(argv[2]) == "config1") {
+    // BASELINE.json configs[0] as SURVEY.md 8d writes it: ONE env through raisim::World (N = 1 on the device), flat ground, dt 0.0025,
+    // 4000 integrate() calls from gc_init, gv = 0, kp 50 / kd 0.2 on the twelve joints, targets = gc_init.  Prints what tests/test_cpp_facade.py compares
+    // with the oracle's run of the same configuration: base height, velocity norm, the collision primitives in contact at the end.
+    try {
+      raisim::World world;
+      world.setTimeStep(0.0025);
+      auto* anymal = world.addArticulatedSystem(urdf);
+      world.addGround();
+      raisim::VecDyn gc(19), gv(18), kp(18), kd(18), dT(18);
+      const double init[19] = {0, 0, 0.50, 1, 0, 0, 0, 0.03, 0.4, -0.8, -0.03, 0.4, -0.8, 0.03, -0.4, 0.8, -0.03, -0.4, 0.8};
+      for (int i = 0; i < 19; ++i) gc[i] = init[i];
+      for (int j = 0; j < 12; ++j) { kp[6 + j] = 50.0; kd[6 + j] = 0.2; }
+      anymal->setState(gc, gv);
+      anymal->setControlMode(raisim::ControlMode::PD_PLUS_FEEDFORWARD_TORQUE);
+      anymal->setPdGains(kp, kd);
+      anymal->setPdTarget(gc, dT);
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 4000; ++i) world.integrate();
+      anymal->getState(gc, gv);
+      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      double vmax = 0;
+      for (int i = 0; i < 18; ++i) vmax = std::max(vmax, std::fabs(gv[i]));
+      std::printf("config1 z=%.6f qw=%.6f vmax=%.6f t=%.4f steps_per_s=%.0f contacts=", gc[2], gc[3], vmax, world.getWorldTime(), 4000.0 / sec);
+      for (auto& c : anymal->getContacts()) std::printf("%d,", (int)c.getCollisionIndex());
+      std::printf("\n");
+      return 0;
+    } catch (const std::exception& e) { std::printf("config1 failed: %s\n", e.what()); return 1; }
+  }
   try {
     // ---- the upstream single-env pattern (what an rsg_anymal Environment.hpp does)
     raisim::World world;
@@ -174,24 +204,31 @@ int main(int argc, char** argv) {
 
     // ---- the policy in the loop on the device: K control steps with the in-repo linear stage, pipelined == lock-step bit for bit
     {
-      std::vector<float> W((size_t)12 * 34), bias(12, 0.05f), obA((size_t)512 * 34), obB((size_t)512 * 34);
+      std::vector<float> W0((size_t)12 * 34), bias(12, 0.05f), obA((size_t)512 * 34), obB((size_t)512 * 34), obC((size_t)512 * 34), obD((size_t)512 * 34);
       unsigned ws = 99u;
-      for (auto& x : W) { ws = ws * 1664525u + 1013904223u; x = ((ws >> 8) / 16777216.0f - 0.5f) * 0.6f; }     // strong enough to make robots fall and reset
-      for (int pipe = 0; pipe < 2; ++pipe) {
+      for (auto& x : W0) { ws = ws * 1664525u + 1013904223u; x = ((ws >> 8) / 16777216.0f - 0.5f) * 0.6f; }     // strong enough to make robots fall and reset
+      // mode 0 lock-step, 1 pipelined, 2 RESIDENT (round 6: each run is ONE launch of the step kernel), 3 lock-step WITHOUT the in-place weight update
+      for (int mode = 0; mode < 4; ++mode) {
+        std::vector<float> W = W0;
         raisim::DeviceVectorizedEnvironment cl(urdf, cfg);
         cl.init();
-        const bool granted = cl.setStepPipelining(pipe != 0);
-        if (pipe) CHECK(granted);
+        const bool granted = cl.setStepPipelining(mode == 1);
+        if (mode == 1) CHECK(granted);
+        if (mode == 2) CHECK(cl.setStepResidency(true));
         cl.rolloutLinear(40, W.data(), bias.data(), 2.0f);
-        cl.rolloutLinear(25, W.data(), bias.data(), 2.0f);        // a second run continues the first (same weights: no upload)
+        // the learner updates its weights IN PLACE - same pointers, new contents (the upload used to be skipped on pointer identity)
+        if (mode != 3) for (auto& x : W) x = -x;
+        cl.rolloutLinear(25, W.data(), bias.data(), 2.0f);
         CHECK(cl.join() == RSB_OK);
-        cl.observe(pipe ? obB.data() : obA.data(), 512, 34);
+        if (mode == 2) CHECK(rsb_step_residency_launches(cl.world().handle()) == 2);
+        cl.observe(mode == 0 ? obA.data() : mode == 1 ? obB.data() : mode == 2 ? obC.data() : obD.data(), 512, 34);
       }
-      int moved = 0;
-      for (size_t i = 0; i < obA.size(); ++i) { CHECK(obA[i] == obB[i]); CHECK(std::isfinite(obA[i])); }
+      int moved = 0, differs = 0;
+      for (size_t i = 0; i < obA.size(); ++i) { CHECK(obA[i] == obB[i]); CHECK(obA[i] == obC[i]); CHECK(std::isfinite(obA[i])); differs += obA[i] != obD[i] ? 1 : 0; }
+      CHECK(differs > 1000);       // the second run saw the updated weights
       for (int e = 0; e < 512; ++e) moved += std::fabs(obA[(size_t)e * 34] - ob[(size_t)e * 34]) > 1e-3f ? 1 : 0;
       CHECK(moved > 256);
-      std::printf("DeviceVectorizedEnvironment::rolloutLinear: 65 control steps x 512 envs, pipelined == lock-step bit for bit\n");
+      std::printf("DeviceVectorizedEnvironment::rolloutLinear: 65 control steps x 512 envs, resident == pipelined == lock-step bit for bit; in-place weight update seen\n");
     }
     // ---- ... and with an actor network (34 -> 64 -> 32 -> 12, tanh) as the stage
     {
@@ -204,18 +241,21 @@ int main(int argc, char** argv) {
         for (auto& x : Wm[l]) { ws = ws * 1664525u + 1013904223u; x = ((ws >> 8) / 16777216.0f - 0.5f) * 2.0f * bound; }
       }
       const std::vector<const float*> wp = {Wm[0].data(), Wm[1].data(), Wm[2].data()}, bp = {Bm[0].data(), Bm[1].data(), Bm[2].data()};
-      std::vector<float> obA((size_t)512 * 34), obB((size_t)512 * 34);
-      for (int pipe = 0; pipe < 2; ++pipe) {
+      std::vector<float> obA((size_t)512 * 34), obB((size_t)512 * 34), obC((size_t)512 * 34);
+      for (int mode = 0; mode < 3; ++mode) {      // lock-step, pipelined, resident
+        for (int l = 0; l < 3; ++l) for (auto& x : Bm[l]) x = 0.01f * (l + 1);
         raisim::DeviceVectorizedEnvironment cl(urdf, cfg);
         cl.init();
-        cl.setStepPipelining(pipe != 0);
+        cl.setStepPipelining(mode == 1);
+        if (mode == 2) CHECK(cl.setStepResidency(true));
         cl.rolloutMlp(30, dims, wp, bp, RSB_ACT_TANH, 2.0f);
+        for (int l = 0; l < 3; ++l) for (auto& x : Bm[l]) x = -x;      // in-place update of the BIASES alone (the cache key used to ignore them)
         cl.rolloutMlp(20, dims, wp, bp, RSB_ACT_TANH, 2.0f);
         CHECK(cl.join() == RSB_OK);
-        cl.observe(pipe ? obB.data() : obA.data(), 512, 34);
+        cl.observe(mode == 0 ? obA.data() : mode == 1 ? obB.data() : obC.data(), 512, 34);
       }
-      for (size_t i = 0; i < obA.size(); ++i) { CHECK(obA[i] == obB[i]); CHECK(std::isfinite(obA[i])); }
-      std::printf("DeviceVectorizedEnvironment::rolloutMlp: 50 control steps x 512 envs, pipelined == lock-step bit for bit\n");
+      for (size_t i = 0; i < obA.size(); ++i) { CHECK(obA[i] == obB[i]); CHECK(obA[i] == obC[i]); CHECK(std::isfinite(obA[i])); }
+      std::printf("DeviceVectorizedEnvironment::rolloutMlp: 50 control steps x 512 envs, resident == pipelined == lock-step bit for bit\n");
     }
 
     // ---- N per-env World VIEWS of one batch: N integrate() calls = ONE launch in which every replica advances once

@@ -34,6 +34,48 @@ def test_facade_runs_on_gpu(built_lib):
     assert "facade_test OK" in r.stdout
 
 
+def config1_on_the_oracle():
+    """BASELINE.json configs[0] as SURVEY.md 8d writes it: 1 env, flat ground, dt 0.0025, 4000 integrate() from gc_init (base at 0.50 m, nominal joints),
+    gv = 0, PD kp 50 / kd 0.2 on the twelve joints with the initial pose as target, mu 0.8 - on the fp64 oracle, one thread"""
+    import time
+    import numpy as np
+    from common import Oracle
+    from raisimlib_amd import Model
+    m = Model(urdf_path=URDF)
+    o = Oracle(m.blob)
+    gc = np.array([[0, 0, 0.50, 1, 0, 0, 0, 0.03, 0.4, -0.8, -0.03, 0.4, -0.8, 0.03, -0.4, 0.8, -0.03, -0.4, 0.8]], np.float64)
+    kp, kd = np.r_[np.zeros(6), np.full(12, 50.0)], np.r_[np.zeros(6), np.full(12, 0.2)]
+    t0 = time.perf_counter()
+    r = o.step_batch(gc, np.zeros((1, 18)), 4000, kp, kd, gc.copy(), np.zeros((1, 18)), nthreads=1, want_contacts=True, lam_warm=o.new_warm_state(1))
+    rate = 4000 / (time.perf_counter() - t0)
+    n = int(r["n_contacts"][0])
+    return {"z": float(r["q"][0, 2]), "qw": float(r["q"][0, 3]), "vmax": float(np.abs(r["u"]).max()), "contacts": sorted(int(c) & 0xffff for c in r["contacts"]["collision"][0, :n]),
+            "steps_per_s": rate, "feet": sorted(m.collision_indices("_foot"))}
+
+
+def test_config1_as_written_on_the_oracle(built_lib):
+    """VERDICT r05 next #8 (plumbing): the robot dropped from 0.50 m settles on its four feet and stands for the 10 s of the run"""
+    c = config1_on_the_oracle()
+    print(f"config 1 on the oracle: base height {c['z']:.4f} m after 4000 steps, {c['steps_per_s']:.0f} env-steps/s on one thread")
+    assert 0.40 < c["z"] < 0.50 and c["qw"] > 0.999 and c["vmax"] < 0.1
+    assert c["contacts"] == c["feet"] and len(c["feet"]) == 4
+
+
+@pytest.mark.gpu
+def test_config1_as_written_through_raisim_world_on_the_device(built_lib):
+    """... and the same 4000 integrate() calls through raisim::World (the facade over an N = 1 batch on the device): both stand, base heights within 2 cm
+    of each other, the same four feet in contact at the end"""
+    compile_facade()
+    r = subprocess.run([BIN, URDF, "config1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("config1 ")][-1]
+    f = dict(kv.split("=") for kv in line.split()[1:])
+    c = config1_on_the_oracle()
+    print(line, "| oracle:", c)
+    assert abs(float(f["z"]) - c["z"]) < 0.02 and float(f["qw"]) > 0.999 and float(f["vmax"]) < 0.1 and abs(float(f["t"]) - 10.0) < 1e-6
+    assert sorted(int(x) for x in f["contacts"].split(",") if x) == c["feet"] == c["contacts"]
+
+
 EIGEN_BIN = os.path.join(ROOT, "tests", "cpp", "_build", "facade_eigen_test")
 
 
@@ -123,7 +165,12 @@ def test_comm_launcher_runs_rsb_allgather_obs_across_processes(built_lib):
     """one process per GPU through rsb_comm_get_unique_id / rsb_comm_init / rsb_allgather_obs: two ranks on a box with >= 2
     GPUs, one rank (same fork / pipe / communicator path) on a 1-GPU box"""
     compile_launcher()
-    r = subprocess.run([LAUNCHER, URDF], capture_output=True, text=True, timeout=300)
+    # NCCL_DEBUG=INFO: RCCL prints its own banner ("RCCL version x.y.z ...") - the run binds the library by dlopen, so its identity is part of the evidence
+    r = subprocess.run([LAUNCHER, URDF], capture_output=True, text=True, timeout=300, env=dict(os.environ, NCCL_DEBUG="INFO"))
     assert r.returncode == 0, r.stdout + r.stderr
     want = 2 if built_lib.rsb_device_count() >= 2 else 1
     assert f"comm_launcher OK ranks={want}" in r.stdout
+    import re
+    m = re.search(r"RCCL runtime version code (\d+), header version code (\d+)", r.stdout)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, r.stdout      # (the build host has <rccl/rccl.h>: the constants were static_assert-ed against it)
+    assert re.search(r"(RCCL|NCCL) version", r.stdout + r.stderr), (r.stdout + r.stderr)[-1500:]

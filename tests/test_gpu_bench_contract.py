@@ -146,3 +146,22 @@ def test_bench_closed_loop_block(built_lib):
             assert m["repeats"] == 7 and m["value_min"] <= m["value"] <= m["value_max"]
         assert rs["resident_launches"] >= 7
     assert c["pipeline"]["faults"] == 0 and c["pipeline"]["streams_overlap"] is True and c["pipeline"]["pipelined_launches"] >= 40
+
+
+def test_bench_two_real_ranks_on_one_device(built_lib):
+    """what one GPU allows of the first N > 1 run - TWO real processes, both on cuda:0, device tensors, torch.distributed gloo as the
+    all-gather: leg 1 (lock-step + in-line gather), leg 2 (pipelined steps + gather on a side stream through rsb_step_pipeline_publish / _wait_event) and the
+    resident leg (one gather of the launch's [steps, N, obs] block) with real kernels and real ranks.  Every leg's gathered block holds this rank's own rows
+    in its slice, on BOTH ranks; the two ranks' shards differ (per-env seeds by global index)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--backend", "gloo", "--steps", "6", "--warmup", "2", "--preroll", "8",
+           "--no-cpu", "--envs-per-gpu", "1024"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-3000:]
+    b = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["rccl"]["backend"] == "gloo" and b["rccl"]["rccl_ranks"] == 2 and b["rccl"]["allreduce_of_ones"] == 2.0
+    assert len(b["ms_per_step_by_rank"]) == 2
+    assert b["pipelined_leg_error"] is None and b["resident_leg_error"] is None and b["value_leg"] == "resident"
+    for leg in (b["lockstep"], b["pipelined"], b["resident"]):
+        assert leg["gathered_rows_of_this_rank_correct"] is True and leg["gathered_rows_correct_on_all_ranks"] is True, leg
+        assert leg["value"] > 0          # (gloo stages every device block through the host and the two ranks share one chip: not a measurement)
+    assert b["lockstep"]["ran_first"] is True and b["resident"]["obs_all_gather"]["block"] == [6, 1024, 49]
