@@ -177,9 +177,14 @@ int rk4_integrate(rsb_world* w, int nsub) {
   float* q0 = w->d_rk; float* u0 = q0 + N * nq; float* ka = u0 + N * nv; float* kv = ka + 4 * N * nv; float* theta = kv + 4 * N * nv;
   float* du = theta + N * nv; float* h0 = du + N * nv; float* tff_save = h0 + N * nv; float* M0 = tff_save + N * nv;
   const int blocks = (int)((N + 63) / 64);
-  for (int sub = 0; sub < nsub; ++sub) {
+  // One sub-step; on ANY failure part-way through the world is put back to the state the sub-step started from (gc / gv used to be left at
+  // a stage state, d_tff at tau_eff, the launch mask set - the next integrate() then ran from corrupted inputs without a word)
+  bool have_q0 = false, tff_dirty = false;
+  auto substep = [&]() -> int {
+    have_q0 = false; tff_dirty = false;
     HIP_TRY(hipMemcpyAsync(q0, w->d_gc, N * nq * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(u0, w->d_gv, N * nv * sizeof(float), hipMemcpyDeviceToDevice, s));
+    have_q0 = true;
     for (int stage = 0; stage < 4; ++stage) {
       int st = launch_dynamics_query(w, s);        // M, h, M^-1 of the state in gc / gv
       if (st != RSB_OK) return st;
@@ -198,6 +203,7 @@ int rk4_integrate(rsb_world* w, int nsub) {
     Rk4Final c;
     c.model = w->d_model; c.gc = w->d_gc; c.gv = w->d_gv; c.tff_eff = w->d_tff; c.q0 = q0; c.u0 = u0; c.M0 = M0; c.h0 = h0; c.ka = ka; c.kv = kv;
     c.theta = theta; c.du = du; c.mask = mask; c.N = (int)N; c.nq = (int)nq; c.nv = (int)nv; c.dt = (float)w->dt;
+    tff_dirty = true;       // (the combine kernel overwrites d_tff with tau_eff)
     hipLaunchKernelGGL(rk4_combine_kernel, dim3(blocks), dim3(64), 0, s, c);
     HIP_TRY(hipGetLastError());
     // the contact step: the one-evaluation kernel in force mode, without the effort clip (tau_eff carries inertial terms), semi-implicit positions
@@ -214,10 +220,24 @@ int rk4_integrate(rsb_world* w, int nsub) {
     hipLaunchKernelGGL(rk4_position_kernel, dim3(blocks), dim3(64), 0, s, w->d_gc, w->d_gv, q0, u0, theta, du, mask, w->d_model, (int)N, (int)nq, (int)nv, (float)w->dt);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(w->d_tff, tff_save, N * nv * sizeof(float), hipMemcpyDeviceToDevice, s));
+    tff_dirty = false;
+    return RSB_OK;
+  };
+  int status = RSB_OK;
+  for (int sub = 0; sub < nsub && status == RSB_OK; ++sub) status = substep();
+  if (status != RSB_OK) {
+    const std::string msg = rsb::last_error();
+    if (have_q0) {
+      (void)hipMemcpyAsync(w->d_gc, q0, N * nq * sizeof(float), hipMemcpyDeviceToDevice, s);
+      (void)hipMemcpyAsync(w->d_gv, u0, N * nv * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
+    if (tff_dirty) (void)hipMemcpyAsync(w->d_tff, tff_save, N * nv * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipGetLastError();
+    rsb::set_error(msg + " (RUNGE_KUTTA_4: the sub-step was rolled back)");
   }
   w->launch_mask = nullptr;
-  w->integrate1_valid = false;
-  return RSB_OK;
+  w->integrate1_valid = false; w->env_ob_valid = false;
+  return status;
 }
 
 }  // namespace rsbw

@@ -35,6 +35,7 @@ struct rsb_world {
   DevModel* d_model = nullptr;
   float *d_gc = nullptr, *d_gv = nullptr, *d_pt = nullptr, *d_dt = nullptr, *d_tff = nullptr;
   float *d_kp = nullptr, *d_kd = nullptr, *d_heights = nullptr;
+  bool raw_dt = false, raw_tff = false, raw_state = false;   // rsb_device_ptr handed the field's device pointer out: the zero-row shortcut / the cached env observation are off for good
   bool dt_zero = true, tff_zero = true;   // d_dt / d_tff hold nothing but zeros (never written, or written with zeros from the host): the step kernel does not read them
   float *d_tmp_gc = nullptr, *d_tmp_gv = nullptr;
   uint8_t* d_tmp_mask = nullptr;

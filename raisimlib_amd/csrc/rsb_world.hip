@@ -437,8 +437,9 @@ int do_integrate(rsb_world* w, int nsub) {
   a.model = w->d_model;
   a.gc = w->d_gc; a.gv = w->d_gv; a.ptarget = w->d_pt; a.dtarget = w->d_dt; a.tauff = w->d_tff;
 #ifndef RSB_X_READ_ZERO_ROWS      /* (A/B switch: read the rows although they are known to be zero, as rounds 1-4 did) */
-  if (w->dt_zero) a.dtarget = nullptr;
-  if (w->tff_zero) a.tauff = nullptr;
+  // (a field whose raw device pointer has been handed out - rsb_device_ptr - is read whatever the host thinks it holds: ADVICE r05)
+  if (w->dt_zero && !w->raw_dt) a.dtarget = nullptr;
+  if (w->tff_zero && !w->raw_tff) a.tauff = nullptr;
 #endif
   a.kp = w->d_kp; a.kd = w->d_kd;
   a.contacts = w->d_contacts; a.contact_count = w->d_count; a.flags = w->d_flags; a.iters = w->d_iters;
@@ -605,7 +606,9 @@ int do_integrate(rsb_world* w, int nsub) {
   }
   w->world_time += (double)res_steps * nsub * w->dt;
   w->integrate1_valid = false;
-  w->env_ob_valid = a.env_ob != nullptr && a.env_ob == w->d_env_ob;      // (the fused epilogue left the observation the NEXT step starts from in the world's own buffer)
+  // (the fused epilogue left the observation the NEXT step starts from in the world's own buffer - unless the caller holds raw pointers to the state rows
+  //  and may write through them behind the library's back: then every closed-loop run recomputes its first observation, as the lock-step path does)
+  w->env_ob_valid = a.env_ob != nullptr && a.env_ob == w->d_env_ob && !w->raw_state;
   return RSB_OK;
 }
 
@@ -1622,11 +1625,11 @@ int rsb_env_step(rsb_world* w, const float* action, float* reward, uint8_t* done
 void* rsb_device_ptr(rsb_world* w, int field) {
   if (!w) return nullptr;
   switch (field) {
-    case RSB_F_GC: return w->d_gc;
-    case RSB_F_GV: return w->d_gv;
+    case RSB_F_GC: w->raw_state = true; w->env_ob_valid = false; return w->d_gc;      // (sticky: the caller may write through the pointer at any time)
+    case RSB_F_GV: w->raw_state = true; w->env_ob_valid = false; return w->d_gv;
     case RSB_F_PTARGET: return w->d_pt;
-    case RSB_F_DTARGET: w->dt_zero = false; return w->d_dt;       // (the caller may write through the pointer: the rows are read from now on)
-    case RSB_F_TAU_FF: w->tff_zero = false; return w->d_tff;
+    case RSB_F_DTARGET: w->dt_zero = false; w->raw_dt = true; return w->d_dt;       // (the caller may write through the pointer: the rows are read from now on, whatever a later upload of zeros says)
+    case RSB_F_TAU_FF: w->tff_zero = false; w->raw_tff = true; return w->d_tff;
     case RSB_F_CONTACT_COUNT: return w->d_count;
     case RSB_F_CONTACTS: return w->d_contacts;
     case RSB_F_FLAGS: return w->d_flags;

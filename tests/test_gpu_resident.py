@@ -239,3 +239,53 @@ def test_closed_loop_with_profiling_on_stays_in_lockstep(built_lib, anymal):
     assert pip.env.world.step_pipeline_fault() == (0, 0)
     assert abs(pip.env.world.get_world_time() - ref.env.world.get_world_time()) < 1e-12
     ref.close(); pip.close()
+
+
+@pytest.mark.parametrize("n,hidden,act,normalise,K", [(4096, (128, 128), "leaky_relu", True, 60), (1024, (256, 192), "relu", True, 30), (512, (50, 21, 33), "tanh", False, 25), (8, (64,), "tanh", False, 10)])
+def test_resident_mlp_stage_matches_torch_and_lockstep(built_lib, anymal, n, hidden, act, normalise, K):
+    """The actor network INSIDE the step kernel (classes | 320 widths <= 128, | 448 widths <= 256): the recorded actions equal a torch forward pass over the
+    recorded observations (+ noise) to rounding - the comparison that catches a wrong weight ring or permute, which resident == lock-step cannot (ADVICE r05:
+    both would be wrong alike) - AND the run equals the lock-step one bit for bit.  Also a batch smaller than a workgroup's share of inputs (n = 8: two env blocks)."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(7)
+    dims = [34, *hidden, 12]
+    layers = []
+    for i in range(len(dims) - 1):
+        bound = (0.25 if i + 2 == len(dims) else 1.0) / np.sqrt(dims[i])
+        layers.append((((torch.rand((dims[i + 1], dims[i]), generator=g) * 2 - 1) * bound).to(dev), ((torch.rand(dims[i + 1], generator=g) * 2 - 1) * 0.1).to(dev)))
+    mean = (torch.rand(34, generator=g) * 0.2 - 0.1).to(dev) if normalise else None
+    var = (torch.rand(34, generator=g) * 2 + 0.05).to(dev) if normalise else None
+    noise = torch.from_numpy(workload.closed_loop_noise(n, 16)).to(dev)
+    f = {"tanh": torch.tanh, "relu": torch.relu, "leaky_relu": lambda v: torch.nn.functional.leaky_relu(v, 0.01)}[act]
+
+    def forward(ob):
+        x = ob.double()
+        if normalise:
+            x = torch.clamp((x - mean.double()) * torch.rsqrt(var + 1e-8).double(), -10.0, 10.0)
+        for i, (W, b) in enumerate(layers):
+            x = x @ W.double().t() + b.double()
+            if i + 1 < len(layers):
+                x = f(x)
+        return x
+
+    ro = {}
+    for resident in (False, True):
+        env = workload.closed_loop_env(anymal, n)
+        env.world.set_step_residency(resident)
+        if resident:
+            assert env.world.residency_status(2)
+        for r in range(2):
+            ro[resident] = {"ob": torch.zeros((K + 1, n, 34), device=dev), "act": torch.zeros((K, n, 12), device=dev),
+                            "reward": torch.zeros((K, n), device=dev), "done": torch.zeros((K, n), dtype=torch.uint8, device=dev)}
+            env.rollout_mlp(K, layers, activation=act, ob_mean=mean, ob_var=var, noise=noise, clip=3.0, rollout=ro[resident])
+            env.world.synchronize()
+        assert env.world.residency_launches() == (2 if resident else 0)
+        env.close()
+    for key in ro[False]:
+        assert torch.equal(ro[False][key], ro[True][key]), key
+    t = torch.arange(K, device=dev)
+    nz = noise[(K + t) % noise.shape[0]]
+    want = torch.clamp(forward(ro[True]["ob"][:K]) + nz.double(), -3.0, 3.0)
+    err = (ro[True]["act"].double() - want).abs().max().item()
+    assert err < 2e-5, err
