@@ -24,6 +24,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -269,9 +270,24 @@ class VectorizedEnvironment {
     if (!batch_) { for (int i = 0; i < num_envs_; i++) body(i); return; }     // envs that never created a World
     struct Guard { BatchedWorld* b; ~Guard() { b->setFiberBatch(false); b->abortViews(); } } guard{batch_.get()};   // (after a clean run nothing is pending)
     batch_->setFiberBatch(true);
-    fibers_.run(num_envs_, body, [this] { batch_->flushViews(); }, threads_);
+    const auto t0 = std::chrono::steady_clock::now();
+    long long inFlush = 0;
+    fibers_.run(num_envs_, body, [this, &inFlush] {
+      const auto f0 = std::chrono::steady_clock::now();
+      batch_->flushViews();
+      inFlush += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - f0).count();
+      ++stepProfile_.flushes;
+    }, threads_);
     batch_->flushViews();      // integrate() calls of bodies that ended without reading anything afterwards
+    stepProfile_.total_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    stepProfile_.flush_ns += inFlush;
+    ++stepProfile_.steps;
   }
+  /// (new) where step() spends the host's time, accumulated: total, inside the flushes (BatchedWorld::flushPrepNs / flushExchangeNs split those further;
+  /// the rest = the rounds of the N step() bodies on the fiber threads + the scheduler's hand-overs).  tools/prof_template_path.py prints the table.
+  struct StepProfile { long long total_ns = 0, flush_ns = 0, steps = 0, flushes = 0; };
+  const StepProfile& stepProfile() const { return stepProfile_; }
+  void resetStepProfile() { stepProfile_ = StepProfile(); }
 
   void turnOnVisualization() { if (render_) environments_[0]->turnOnVisualization(); }
   void turnOffVisualization() { if (render_) environments_[0]->turnOffVisualization(); }
@@ -336,6 +352,7 @@ class VectorizedEnvironment {
   std::vector<std::map<std::string, float>> rewardInformation_;
   std::shared_ptr<BatchedWorld> batch_;
   detail::FiberScheduler fibers_;
+  StepProfile stepProfile_;
   int num_envs_ = 1, obDim_ = 0, actionDim_ = 0, threads_ = 1;
   bool recordVideo_ = false, render_ = false;
   std::string resourceDir_;

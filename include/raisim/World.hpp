@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -306,6 +307,7 @@ class BatchedWorld {
   /// one rsb_view_exchange for everything that is pending: staged rows up, the recorded integrate() calls (ONE launch when every
   /// replica recorded the same number, else masked launches by count), the fields the environments read down; one synchronisation
   void flushViews() {
+    const auto tf0 = std::chrono::steady_clock::now();
     std::lock_guard<std::recursive_mutex> lk(mu_);
     int cmin = 1 << 30, cmax = 0;
     for (int e = 0; e < n_; ++e) { cmin = std::min(cmin, pending_[e]); cmax = std::max(cmax, pending_[e]); }
@@ -340,7 +342,11 @@ class BatchedWorld {
       io.contact_counts = cnt_.data(); io.contacts = con_.data();
     }
     if (gf) { genf_.resize((size_t)n_ * blob_.nv); io.generalized_force = genf_.data(); }
+    const auto tf1 = std::chrono::steady_clock::now();
     RSB_CHECK(rsb_view_exchange(world_, &io));
+    const auto tf2 = std::chrono::steady_clock::now();
+    flushPrepNs_ += std::chrono::duration_cast<std::chrono::nanoseconds>(tf1 - tf0).count();
+    flushExchangeNs_ += std::chrono::duration_cast<std::chrono::nanoseconds>(tf2 - tf1).count();
     std::fill(pending_.begin(), pending_.end(), 0);
     nPending_ = 0;
     viewLaunches_ += (long)launchSub_.size();
@@ -354,6 +360,9 @@ class BatchedWorld {
   void setFuseIntegrateCalls(bool on) { fuse_ = on; }     ///< (tests, A/B) false = a flush per integrate()
   long viewLaunches() const { return viewLaunches_; }     ///< launches issued by flushViews() (tests: N views x k integrate() -> 1 launch)
   long viewFlushes() const { return viewFlushes_; }       ///< rsb_view_exchange calls issued by flushViews()
+  /// host time (ns) flushViews() has spent preparing its exchanges (scan of the pending counters, upload lists) and inside rsb_view_exchange
+  long long flushPrepNs() const { return flushPrepNs_; }
+  long long flushExchangeNs() const { return flushExchangeNs_; }
   int pendingViews() const { int k = 0; for (int c : pending_) k += c != 0; return k; }
   /// contacts of the last integrate() of every env, downloaded once per flush
   const PinnedArray<rsb_contact>& contactsOf(int env, int& count, int& kmax) {
@@ -499,6 +508,7 @@ class BatchedWorld {
   PinnedArray<uint8_t> launchMasks_, stateMask_;
   int kmax_ = 0;
   long viewLaunches_ = 0, viewFlushes_ = 0;
+  long long flushPrepNs_ = 0, flushExchangeNs_ = 0;
   bool fuse_ = !(std::getenv("RSB_VIEW_FUSE") && std::atoi(std::getenv("RSB_VIEW_FUSE")) == 0);
   std::atomic<bool> wantState_{false}, wantContacts_{false}, wantGenf_{false};   // what the environments read: downloaded by every flush
   BigReaderLock stageMu_;                    // shared: an env stages one of its rows; exclusive: whole-array upload / refresh of the mirrors (after mu_)

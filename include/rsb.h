@@ -405,6 +405,10 @@ int rsb_control_step(rsb_world* w, const float* p_target, const float* d_target,
                      const int32_t* force_collisions, int n_force_slots, const int32_t* allowed_collisions,
                      int n_allowed, const float* gc0, const float* gv0, int rows);
 
+/* Debug aid: where the HOST spends its time inside rsb_view_exchange, accumulated since the last reset - out[0] ns enqueueing the uploads (+ the masked
+ * state-row kernels), [1] the launches, [2] the downloads, [3] waiting for the stream, [4] calls (tools/prof_template_path.py). */
+int rsb_debug_view_profile(rsb_world* w, long long out[5], int reset);
+
 /* ---- round 6: RESIDENT control steps.  K control steps of a vectorised env in ONE launch of the step kernel: an env block's state (and the solver's
  * warm table, the model tables) stays in LDS from the first sub-step to the last; per control step only the obs block, the done flags and - env task -
  * reward / next observation go to HBM; state rows, warm records and contact records are written after the LAST control step (the world then holds exactly

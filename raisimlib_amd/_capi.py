@@ -208,6 +208,7 @@ PROTOTYPES = {
     "rsb_step_residency_status": (_I, [_VP, _I]),
     "rsb_step_residency_launches": (C.c_longlong, [_VP]),
     "rsb_debug_resident_full_writes": (_I, [_VP, _I]),
+    "rsb_debug_view_profile": (_I, [_VP, C.POINTER(C.c_longlong), _I]),
     "rsb_debug_select_env": (_I, [_VP, _I]),
     "rsb_debug_phase_cycles": (_I, [_VP, _I, _FP]),
     "rsb_debug_wave_profile": (_I, [_VP, _FP, _I]),

@@ -173,6 +173,7 @@ struct rsb_world {
   long long cl_passes = 0;                               // closed-loop steps this world has run (index of the next run's pass 0)
   int cl_grid = 0;                                       // workgroups of the action stage (0: default)
   // ---- round 6: resident launches (rsb_set_step_residency): K control steps per launch of the step kernel, the env blocks stay in LDS
+  long long view_prof[5] = {0, 0, 0, 0, 0};             // rsb_debug_view_profile: ns the host spent in rsb_view_exchange enqueueing uploads / launches / downloads, waiting; calls
   bool res_on = false, res_full = false;
   long long res_launches = 0;
 };

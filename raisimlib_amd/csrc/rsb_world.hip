@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -1177,6 +1178,10 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
   if (!w || !io || io->n_launches < 0 || (io->n_launches > 0 && !io->launch_substeps)) { rsb::set_error("rsb_view_exchange: bad argument"); return RSB_E_INVALID; }
   HIP_TRY(hipSetDevice(w->device));
   const size_t N = w->N, nq = w->blob.nq, nv = w->blob.nv;
+  // host-side cost of the exchange by part (rsb_debug_view_profile): [0] enqueue of the uploads, [1] of the launches, [2] of the downloads, [3] the wait
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto lap_ns = [](std::chrono::steady_clock::time_point& t) { const auto n = std::chrono::steady_clock::now(); const long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(); t = n; return d; };
+  auto tp = tp0;
   if (io->p_target) HIP_TRY(hipMemcpyAsync(w->d_pt, io->p_target, N * nq * sizeof(float), hipMemcpyHostToDevice, stream_of(w)));
   if (io->d_target) { HIP_TRY(hipMemcpyAsync(w->d_dt, io->d_target, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w))); w->dt_zero = false; }      // (staged rows of the views: not scanned)
   if (io->tau_ff) { HIP_TRY(hipMemcpyAsync(w->d_tff, io->tau_ff, N * nv * sizeof(float), hipMemcpyHostToDevice, stream_of(w))); w->tff_zero = false; }
@@ -1210,12 +1215,14 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
     }
     HIP_TRY(hipMemcpyAsync(w->d_view_masks, io->launch_masks, need, hipMemcpyHostToDevice, stream_of(w)));
   }
+  w->view_prof[0] += lap_ns(tp);
   for (int i = 0; i < io->n_launches; ++i) {
     if (io->launch_substeps[i] < 1) { rsb::set_error("rsb_view_exchange: launch_substeps must be >= 1"); return RSB_E_INVALID; }
     if (io->launch_masks) w->launch_mask = w->d_view_masks + (size_t)i * N;
     const int st = do_integrate(w, io->launch_substeps[i]);
     if (st != RSB_OK) return st;
   }
+  w->view_prof[1] += lap_ns(tp);
   if (io->gc_out) HIP_TRY(hipMemcpyAsync(io->gc_out, w->d_gc, N * nq * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
   if (io->gv_out) HIP_TRY(hipMemcpyAsync(io->gv_out, w->d_gv, N * nv * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
   if (io->contact_counts) HIP_TRY(hipMemcpyAsync(io->contact_counts, w->d_count, N * sizeof(int32_t), hipMemcpyDeviceToHost, stream_of(w)));
@@ -1224,7 +1231,16 @@ int rsb_view_exchange(rsb_world* w, const rsb_view_io* io) {
     if (!w->want_genf || !w->d_genf) { rsb::set_error("rsb_view_exchange: generalized_force needs rsb_enable_generalized_force_output"); return RSB_E_INVALID; }
     HIP_TRY(hipMemcpyAsync(io->generalized_force, w->d_genf, N * nv * sizeof(float), hipMemcpyDeviceToHost, stream_of(w)));
   }
+  w->view_prof[2] += lap_ns(tp);
   HIP_TRY(hipStreamSynchronize(stream_of(w)));
+  w->view_prof[3] += lap_ns(tp);
+  ++w->view_prof[4];
+  return RSB_OK;
+}
+int rsb_debug_view_profile(rsb_world* w, long long out[5], int reset) {
+  if (!w) return RSB_E_INVALID;
+  if (out) for (int i = 0; i < 5; ++i) out[i] = w->view_prof[i];
+  if (reset) for (int i = 0; i < 5; ++i) w->view_prof[i] = 0;
   return RSB_OK;
 }
 

@@ -96,7 +96,21 @@ PYBIND11_MODULE(RSG_MODULE_NAME, m) {
            })
       .def("getRewardInfo", &VecEnv::getRewardInfo)
       // what upstream does not have: how many kernel launches the batch has issued (tests: N envs x k integrate() calls -> ONE fused launch)
-      .def("viewLaunches", [](VecEnv& e) { return e.batch() ? e.batch()->viewLaunches() : 0L; });
+      .def("viewLaunches", [](VecEnv& e) { return e.batch() ? e.batch()->viewLaunches() : 0L; })
+      // ... and where step() spends the host's time (ns, accumulated; reset = True clears the counters): tools/prof_template_path.py
+      .def("stepProfile", [](VecEnv& e, bool reset) {
+             py::dict d;
+             const auto& p = e.stepProfile();
+             d["total_ns"] = p.total_ns; d["flush_ns"] = p.flush_ns; d["steps"] = p.steps; d["flushes"] = p.flushes;
+             if (e.batch()) {
+               d["flush_prep_ns"] = e.batch()->flushPrepNs(); d["flush_exchange_ns"] = e.batch()->flushExchangeNs();
+               long long v[5] = {0, 0, 0, 0, 0};
+               rsb_debug_view_profile(e.batch()->handle(), v, reset ? 1 : 0);
+               d["exchange_upload_enqueue_ns"] = v[0]; d["exchange_launch_enqueue_ns"] = v[1]; d["exchange_download_enqueue_ns"] = v[2]; d["exchange_wait_ns"] = v[3]; d["exchanges"] = v[4];
+             }
+             if (reset) e.resetStepProfile();
+             return d;
+           }, py::arg("reset") = false);
 
   py::class_<raisim::VecEnvConfig>(m, "VecEnvConfig")
       .def(py::init<>())

@@ -68,10 +68,13 @@ int main(int argc, char** argv) {
       std::vector<char> done(n);
       env.reset();
       for (int k = 0; k < 5; ++k) { env.step(act.data(), n, 12, rew.data(), reinterpret_cast<bool*>(done.data())); env.observe(ob.data(), n, 34, false); }
+      env.resetStepProfile();
       const auto t0 = std::chrono::steady_clock::now();
       for (int k = 0; k < steps; ++k) { env.step(act.data(), n, 12, rew.data(), reinterpret_cast<bool*>(done.data())); env.observe(ob.data(), n, 34, false); }
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / steps;
-      std::printf("host cost of the template path (C-ABI double), N = %d, %d threads, fuse = %d: %.3f ms per control step\n", n, threads, fuse, ms);
+      const auto& sp = env.stepProfile();
+      std::printf("host cost of the template path (C-ABI double), N = %d, %d threads, fuse = %d: %.3f ms per control step (step(): rounds %.3f ms + flushes %.3f ms)\n", n, threads, fuse, ms,
+                  (sp.total_ns - sp.flush_ns) / 1e6 / sp.steps, sp.flush_ns / 1e6 / sp.steps);
     }
     return 0;
   }
