@@ -42,6 +42,7 @@ class Params(C.Structure):
         ("hm_plane_test", C.c_int32),
         ("slip_rule", C.c_int32),
         ("pair_inner", C.c_int32),
+        ("reduce_dist", C.c_double),
     ]
 
 

@@ -1291,7 +1291,7 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
   /* joint limits (RaiSim enforces them in the same solver [RECALL]): a joint beyond its range adds one unilateral row
    * s * qdot >= 0 (s = -1 above the upper limit, +1 below the lower one), carried through the solver as a contact whose
    * two tangential rows are empty (unit dummy diagonal); it is not reported by getContacts */
-  const int nreal = nc;
+  int nreal = nc;   /* (not const: the contact-set reduction experiment runs the solver on a compacted set and restores it) */
   double lim_sign[MAXK];
   for (int i = 0; i < nc; ++i) lim_sign[i] = 0.0;
   for (int i = 1; i < m->nb; ++i) {
@@ -1386,6 +1386,53 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
       /* warm start: the impulse (contact frame) this collision primitive carried in the previous integrate() */
       /* (a self-collision starts cold: the warm state is kept per primitive for its contact with the terrain) */
       for (int r = 0; r < 3; ++r) lam[i][r] = (lam_warm && p->warm_start && i < nreal && cbody2[i] < 0 && !csecond[i]) ? lam_warm[ORC_WARM * ccol[i] + r] : 0.0;
+    }
+    /* EXPERIMENT orc_params::reduce_dist: contact-set reduction.  The solver below then runs on the merged set (the arrays are compacted in place);
+     * red_map / red_w / the saved per-contact arrays expand its result back to the original contacts behind the solve. */
+    int red_on = 0, red_map[MAXK], nc0 = nc, nreal0 = nreal, cbody_s[MAXK], cbody2_s[MAXK], ccol_s[MAXK], csecond_s[MAXK];
+    double red_w[MAXK], lim_s[MAXK];
+    if (p->reduce_dist > 0.0 && nc > 1) {
+      static _Thread_local double* tl_G2 = NULL;
+      if (!tl_G2) tl_G2 = (double*)malloc(sizeof(double) * MAXK * MAXK * 9);
+      int partner[MAXK], first[MAXK], nm = 0;
+      for (int i = 0; i < nc; ++i) partner[i] = -1;
+      for (int i = 0; i < nreal; ++i) {
+        if (partner[i] >= 0 || cbody2[i] >= 0 || csecond[i] || lim_sign[i] != 0.0) continue;
+        for (int j = i + 1; j < nreal; ++j) {
+          if (partner[j] >= 0 || cbody2[j] >= 0 || csecond[j] || lim_sign[j] != 0.0 || cbody[j] != cbody[i]) continue;
+          const double d[3] = {cx[i][0] - cx[j][0], cx[i][1] - cx[j][1], cx[i][2] - cx[j][2]};
+          if (dot3(d, d) >= p->reduce_dist * p->reduce_dist || dot3(cn[i], cn[j]) < 1.0 - 1e-12) continue;
+          partner[i] = j; partner[j] = i; red_on = 1;
+          break;
+        }
+      }
+      if (red_on) {
+        for (int i = 0; i < nc; ++i) {          /* merged index of every original contact, its weight */
+          if (partner[i] >= 0 && partner[i] < i) { red_map[i] = red_map[partner[i]]; }
+          else { red_map[i] = nm; first[nm] = i; ++nm; }
+          red_w[i] = 1.0;
+          if (partner[i] >= 0) { const int j = partner[i]; red_w[i] = (cdepth[i] + 1e-4) / (cdepth[i] + cdepth[j] + 2e-4); }
+        }
+        /* G' = P^T G P, c' = P^T c, lam' = sum of the members' warm impulses; in place behind a copy of G */
+        for (int a = 0; a < nc; ++a) for (int b = 0; b < nc; ++b) for (int e = 0; e < 9; ++e) tl_G2[(a * MAXK + b) * 9 + e] = G[a][b][e];
+        double c2[MAXK][3], l2[MAXK][3];
+        for (int a = 0; a < nm; ++a) { for (int r = 0; r < 3; ++r) { c2[a][r] = 0.0; l2[a][r] = 0.0; } for (int b = 0; b < nm; ++b) for (int e = 0; e < 9; ++e) G[a][b][e] = 0.0; }
+        for (int i = 0; i < nc; ++i) {
+          for (int r = 0; r < 3; ++r) { c2[red_map[i]][r] += red_w[i] * cfree[i][r]; l2[red_map[i]][r] += lam[i][r]; }
+          for (int j = 0; j < nc; ++j) for (int e = 0; e < 9; ++e) G[red_map[i]][red_map[j]][e] += red_w[i] * red_w[j] * tl_G2[(i * MAXK + j) * 9 + e];
+        }
+        for (int a = 0; a < nc; ++a) { cbody_s[a] = cbody[a]; cbody2_s[a] = cbody2[a]; lim_s[a] = lim_sign[a]; ccol_s[a] = ccol[a]; csecond_s[a] = csecond[a]; }
+        int nreal2 = 0;
+        for (int a = 0; a < nm; ++a) {
+          const int i = first[a];
+          for (int r = 0; r < 3; ++r) { cfree[a][r] = c2[a][r]; lam[a][r] = l2[a][r]; }
+          cbody[a] = cbody_s[i]; cbody2[a] = cbody2_s[i]; lim_sign[a] = lim_s[i]; ccol[a] = ccol_s[i]; csecond[a] = csecond_s[i];
+          if (i < nreal) nreal2 = a + 1;
+          if (lim_sign[a] != 0.0) G[a][a][0] = G[a][a][4] = 1.0;
+          inv3(G[a][a], Ginv[a]);
+        }
+        nc = nm; nreal = nreal2;
+      }
     }
     /* per-contact Gauss-Seidel (Hwangbo et al. 2018 Alg. 1) */
     if (dbgG)   /* debug views cover the real contacts (joint-limit rows follow them and are left out) */
@@ -1751,6 +1798,15 @@ static void step_impl(const rsb_model_blob* m, const orc_params* p, double* q, d
        * 1.9e4 N s impulse on a jammed shank); return the iterate with the smallest sweep-to-sweep change instead */
       fl |= 4;
       for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) lam[i][r] = lam_best[i][r];
+    }
+    if (red_on) {      /* back to the original contacts: lam_i = w_i lam_m, the merged contact's friction direction for both members */
+      double lm[MAXK][3], sm[MAXK][3];
+      for (int a = 0; a < nc; ++a) for (int r = 0; r < 3; ++r) { lm[a][r] = lam[a][r]; sm[a][r] = sdir[a][r]; }
+      nc = nc0; nreal = nreal0;
+      for (int i = 0; i < nc; ++i) {
+        for (int r = 0; r < 3; ++r) { lam[i][r] = red_w[i] * lm[red_map[i]][r]; sdir[i][r] = sm[red_map[i]][r]; }
+        cbody[i] = cbody_s[i]; cbody2[i] = cbody2_s[i]; lim_sign[i] = lim_s[i]; ccol[i] = ccol_s[i]; csecond[i] = csecond_s[i];
+      }
     }
     if (dbglam) for (int i = 0; i < nreal; ++i) for (int r = 0; r < 3; ++r) dbglam[3 * i + r] = lam[i][r];
     for (int i = 0; i < nc; ++i) for (int r = 0; r < 3; ++r) sdir_out[i][r] = sdir[i][r];

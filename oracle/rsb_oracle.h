@@ -121,6 +121,14 @@ typedef struct orc_params {
    * threshold or K rounds are up -; the partner is skipped in its own pass.  Same fixed points as the plain iteration. *pair_evals (orc_step_debug
    * statistics) counts the one-contact rule evaluations spent inside. */
   int32_t pair_inner;
+  /* EXPERIMENT (round 6; default 0 = off): CONTACT-SET REDUCTION before the solve.  Two terrain contacts of ONE body whose points are
+   * closer than reduce_dist (m) and whose normals coincide - the two spheres of one edge of a humanoid's foot - are solved as ONE contact at their
+   * weighted midpoint x_m = w_i x_i + w_j x_j (w by penetration depth: the deeper sphere carries more): J_m = w_i J_i + w_j J_j is exact for a rigid
+   * body, so G' = P^T G P, c' = P^T c with P = [w_i I; w_j I]; afterwards the impulse is split back, lam_i = w_i lam_m, which reproduces the merged
+   * contact's generalized impulse exactly (J_i^T lam_i + J_j^T lam_j = J_m^T lam_m).  What is lost: the pair can no longer carry a torque about the
+   * axis through its midpoint normal to the edge, and its load split is the weights', not the solver's.  Contact list, warm state and sweep counts are
+   * reported for the ORIGINAL contacts.  tools/exp/contact_reduction.py measures sweeps saved against the velocity error. */
+  double reduce_dist;
 } orc_params;
 #define ORC_SLIP_ENERGY 0
 #define ORC_SLIP_COULOMB 1
