@@ -987,8 +987,12 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     value = total_env_steps / elapsed
     # what `value` is: the resident leg when it ran (on every rank), else the pipelined leg, else lock-step
     primary_value, primary_name = value, value_leg
-    if res_leg is not None:
-        value = total_env_steps / res_leg["elapsed"]
+    resident_value = total_env_steps / res_leg["elapsed"] if res_leg is not None else None
+    # N = 1: the resident leg when it ran.  N > 1: the FASTER of the legs that succeeded on every rank (elapsed is the MAX over ranks, so all ranks agree):
+    # the resident leg's one all-gather of [steps, N, obs] per launch sits behind the launch, the pipelined leg hides its per-step gathers on a side stream
+    value_is_resident = res_leg is not None and (world_size == 1 or res_leg["elapsed"] <= elapsed)
+    if value_is_resident:
+        value = resident_value
         value_leg = "resident"
     iters = world.get_solver_iterations()
     counts, _ = world.get_contacts()
@@ -1065,7 +1069,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                                        "durations) - two launches overlap, so `achieved` = algorithmic bytes per launch / effective_ms_per_launch (= ms_per_step), "
                                        "the rate the chip sustains; achieved_over_one_launch_duration divides by kernel_ms_mean instead; kernel_ms_standalone = a "
                                        "pipelined launch with nothing else in flight (sampling pass: joined after every step)"})
-        if res_leg is not None and len(res_state["launch_ms"]) and roof.get("achieved") is not None:
+        if value_is_resident and len(res_state["launch_ms"]) and roof.get("achieved") is not None:
             # `value` is the resident leg: the dominant kernel is the resident class of rsb_step_kernel, ONE launch = --steps control steps.  Algorithmic bytes
             # per launch = SURVEY 8d's contract figure x env-steps per launch (the unfused 456 B / env-step - never the fused figure silently); duration = the
             # launch's own start -> end (HIP event pair recorded by the library on the launch stream, one per repeat).  Nothing overlaps it: throughput and
@@ -1094,11 +1098,12 @@ def measure(args, rank, local_rank, world_size, dev, coll):
         out = {
             "metric": recipe.metric,
             "value": value, "unit": "env-steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": (res_leg or primary_leg)["elapsed"] / args.steps * 1e3, "ms_per_step_by_rank": (res_leg or primary_leg)["ms_by_rank"], "higher_is_better": True, "scaling": "weak",
-            **spread(res_leg or primary_leg, total_env_steps),
+            "ms_per_step": (res_leg if value_is_resident else primary_leg)["elapsed"] / args.steps * 1e3,
+            "ms_per_step_by_rank": (res_leg if value_is_resident else primary_leg)["ms_by_rank"], "higher_is_better": True, "scaling": "weak",
+            **spread(res_leg if value_is_resident else primary_leg, total_env_steps),
             "value_is": "the MEDIAN of `repeats` fresh brackets of exactly --steps control steps each (barrier + synchronise on both sides, MAX over ranks), back to back",
             "value_leg": value_leg, "pipelined_leg_error": pipelined_leg_error, "resident_leg_error": resident_leg_error,
-            "resident": ({"value": value, "unit": "env-steps/s", "ms_per_step": res_leg["elapsed"] / args.steps * 1e3, "steps": args.steps, **spread(res_leg, total_env_steps),
+            "resident": ({"value": resident_value, "unit": "env-steps/s", "ms_per_step": res_leg["elapsed"] / args.steps * 1e3, "steps": args.steps, **spread(res_leg, total_env_steps),
                           "launches_per_bracket": 1, "obs_all_gather": res_state["gather"], "gathered_rows_of_this_rank_correct": res_leg.get("gathered_rows_of_this_rank_correct"),
                           "gathered_rows_correct_on_all_ranks": res_leg.get("gathered_rows_correct_on_all_ranks"),
                           "what": "rsb_control_steps with rsb_set_step_residency: the bracket's --steps control steps are ONE launch of the step kernel's resident class - env blocks "
@@ -1150,7 +1155,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
                           "what": "rsb_set_step_pipelining off, same bracket: every launch waits for the slowest wave of the one before it (what a caller "
                                   "gets that consumes each step's output before issuing the next step, e.g. a policy in the loop)"} if lockstep else None),
             "build": {"source_hash": world.L.rsb_source_hash().decode(), "library": os.path.relpath(os.path.realpath(__import__("raisimlib_amd")._capi.LIB_PATH), ROOT)},
-            "host_enqueue_ms_per_step": (res_leg["t_enqueued"] if res_leg is not None else t_enqueued) / args.steps * 1e3,
+            "host_enqueue_ms_per_step": (res_leg["t_enqueued"] if value_is_resident else t_enqueued) / args.steps * 1e3,
             "state_at_end": {"solver_iters_mean": float(iters.mean()), "solver_iters_max": int(iters.max()),
                              "contacts_per_env": float(counts.mean()), "base_height_mean": float(q_end[:, 2].mean())},
         }
