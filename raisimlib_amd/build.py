@@ -23,11 +23,12 @@ OUT = os.path.join(HERE, "lib", "librsb.so")
 OBJ = os.path.join(HERE, "lib", "obj")
 RSB_H = os.path.join(ROOT, "include", "rsb.h")
 RSB_TYPES_H = os.path.join(ROOT, "include", "rsb_types.h")    # the part of the ABI the kernels compile against
+RSB_EXT_H = os.path.join(ROOT, "include", "rsb_ext.h")         # the entry points without an upstream counterpart (solver heuristics, scheduling, timing, debug aids); included by rsb.h
 RSB_PIPELINE_H = os.path.join(ROOT, "include", "rsb_pipeline.h")   # the closed-loop pipeline: C declarations + the device-side serve loop of an action stage
-_WORLD_DEPS = ["rsb_world.h", "rsb_internal.h", "step_types.h", RSB_H, RSB_TYPES_H, RSB_PIPELINE_H]
+_WORLD_DEPS = ["rsb_world.h", "rsb_internal.h", "step_types.h", RSB_H, RSB_EXT_H, RSB_TYPES_H, RSB_PIPELINE_H]
 HOST_SOURCES = {   # source -> headers it depends on
-    "urdf_model.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
-    "terrain_io.cpp": ["rsb_internal.h", RSB_H, RSB_TYPES_H],
+    "urdf_model.cpp": ["rsb_internal.h", RSB_H, RSB_EXT_H, RSB_TYPES_H],
+    "terrain_io.cpp": ["rsb_internal.h", RSB_H, RSB_EXT_H, RSB_TYPES_H],
     "rsb_world.hip": _WORLD_DEPS + ["step_launch.h", "query_kernel.h", "env_task.h"],
     "rsb_pipeline.hip": _WORLD_DEPS + ["stage_bodies.h"],
     "rsb_comm.hip": _WORLD_DEPS,
@@ -56,7 +57,7 @@ def source_hash(extra_flags=()):
     into the library (rsb_source_hash()); tests/conftest.py compares the two, so a library built from other sources than the tree's -
     a stale object cache, a binary that travelled to the GPU box without its sources - fails the suite instead of passing it."""
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp", ".inc"))) + [RSB_H, RSB_TYPES_H, RSB_PIPELINE_H]
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip", ".cpp", ".inc"))) + [RSB_H, RSB_EXT_H, RSB_TYPES_H, RSB_PIPELINE_H]
     for f in files:
         h.update(os.path.relpath(f, ROOT).encode() + b"\0")
         h.update(open(f, "rb").read())

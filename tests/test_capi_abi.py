@@ -1,4 +1,4 @@
-"""The C-ABI library loads on a CPU-only box and exports every symbol include/rsb.h and include/rsb_pipeline.h declare."""
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/rsb.h, include/rsb_ext.h and include/rsb_pipeline.h declare."""
 import ctypes as C
 import os
 import re
@@ -12,7 +12,7 @@ def header_functions():
     """every function the C-ABI declares: include/rsb.h and the closed-loop pipeline's include/rsb_pipeline.h (its C part: the device-side
     serve loop behind `#if defined(__HIPCC__)` is a header-only template of the caller's kernel, not a symbol of the library)"""
     names = set()
-    for h in ("rsb.h", "rsb_pipeline.h"):
+    for h in ("rsb.h", "rsb_ext.h", "rsb_pipeline.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = src.split("#if defined(__HIPCC__)")[0]
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
