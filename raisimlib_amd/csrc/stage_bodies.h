@@ -100,12 +100,16 @@ template <int CNT>
 __device__ __forceinline__ void ring_wait(float& xr) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(xr) : "n"(CNT));
 }
-template <int NS, class P>       // NS sets of 64 units: layer widths up to 64 NS; P: rsb_mlp_policy, or the same struct in the kernarg address space (a COPY of it
-                                 // in registers would be indexed by the layer loop - private memory, and the weight rows' base no longer a scalar)
+template <int NS, class P, int RING = 0>   // NS sets of 64 units: layer widths up to 64 NS; P: rsb_mlp_policy, or the same struct in the kernarg address space (a COPY of it
+                                 // in registers would be indexed by the layer loop - private memory, and the weight rows' base no longer a scalar);
+                                 // RING: groups in the weight ring (0 = the stage kernels' 5 / 2: they must stay under 96 registers next to a step wave; the resident step
+                                 // classes evaluate the stage while the step's own registers are dead and take 8 = 56 loads in flight, the most s_waitcnt vmcnt can count:
+                                 // the network is bound by L2 latency per round trip of the ring.  The order of the accumulations - the result - does not depend on it)
 __device__ __forceinline__ void mlp_block(const rsb_stage_ctx& c, const P& p, int env0, int n_env, int pass, bool final) {
   constexpr int XR = 4 * NS;                  // input registers: 16 inputs x 4 envs each
   constexpr int KU = NS == 2 ? 4 : 2;         // weight rows per group (8 loads)
-  constexpr int NB = NS == 2 ? 5 : 2;         // groups in the ring: 16 / 2 rows in flight = 40 / 16 registers
+  constexpr int NB = RING > 0 ? RING : (NS == 2 ? 5 : 2);         // groups in the ring: 16 / 2 rows in flight = 40 / 16 registers
+  static_assert((NB - 1) * KU * NS <= 63, "s_waitcnt vmcnt counts 63 outstanding loads at most");
   constexpr int LOADS = KU * NS;
   const int lane = (int)threadIdx.x;
   const int od = c.ob_dim, ad = c.act_dim;

@@ -50,6 +50,11 @@
 // The resident classes (kernel class bit 64) wrap the sub-step loop and the epilogue in a loop over control steps.  The wrapper is PREPROCESSOR-selected
 // (every instance is its own translation unit, compiled with -DRSB_I_CL=...): written as `if constexpr` / a one-trip loop it moved the register
 // allocation of every other class (+4 VGPRs, +2 spilled SGPRs in the benchmark's instance) - those stay instruction for instruction what they were.
+#ifndef RSB_X_RES_RING   /* groups in the weight ring of the actor network inside the resident classes (stage_bodies.h: mlp_block); 0 = the stage kernels' ring.
+                            8 (56 loads in flight instead of 32) measured no faster - 198.2 against 198.6 M with the 34-128-128-12 network in the loop: the block's network
+                            is bound by its dependent matrix-instruction chains, not by the ring (profiles/r06_ab_log.txt #3) */
+#define RSB_X_RES_RING 0
+#endif
 #if defined(RSB_I_CL) && ((RSB_I_CL) & 64)
 #define RSB_RESIDENT 1
 #else
@@ -135,7 +140,7 @@ __device__ __forceinline__ void resident_stage(KArgs ka, int blk, int pass, int 
   c.n_steps = n_steps; c.pass_global0 = as.res_pass_global0;
   const int env0 = blk * EPW, n_env = min(EPW, as.N - env0);
   if constexpr (STG == 1) rsb_stage_body::linear_block(c, as.res_pol.lin, env0, n_env, pass, pass == n_steps);
-  else rsb_stage_body::mlp_block<(STG == 2 ? 2 : 4)>(c, as.res_pol.mlp, env0, n_env, pass, pass == n_steps);
+  else rsb_stage_body::mlp_block<(STG == 2 ? 2 : 4), std::remove_reference_t<decltype(as.res_pol.mlp)>, RSB_X_RES_RING>(c, as.res_pol.mlp, env0, n_env, pass, pass == n_steps);
   asm volatile("s_waitcnt vmcnt(0)\n\tbuffer_inv sc1" ::: "memory");
 #endif
 }
