@@ -74,6 +74,11 @@ int rsb_model_from_urdf_string(const char* xml, rsb_model** out);
  * contacts where the unsampled set was already exact.  h = 0: the functions above. */
 int rsb_model_from_urdf_file_sampled(const char* path, double sample_spacing, rsb_model** out);
 int rsb_model_from_urdf_string_sampled(const char* xml, double sample_spacing, rsb_model** out);
+/* <mesh> colliders (upstream: the mesh itself against the terrain, through ODE's trimesh collider [RECALL; absent]) are loaded as a POINT SET: support
+ * vertices of the mesh's convex hull, each a zero-radius primitive - exact against a plane for a convex mesh whose lowest vertices are among them.
+ * n = points kept per mesh: default 8 (the body diagonals' support vertices: a box keeps its corners), at most 26 (+ the 6 axes' and the 12 face
+ * diagonals'); they count against RSB_MAX_COLLISIONS.  Process-wide, read when a URDF is loaded. */
+int rsb_set_mesh_point_budget(int n);
 int rsb_model_from_blob(const rsb_model_blob* blob, rsb_model** out);
 int rsb_model_destroy(rsb_model* m);
 int rsb_model_get_blob(const rsb_model* m, rsb_model_blob* out);

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "rsb_model_from_urdf_file_sampled": (_I, [_CP, _D, C.POINTER(_VP)]),
     "rsb_model_from_urdf_string_sampled": (_I, [_CP, _D, C.POINTER(_VP)]),
     "rsb_model_from_blob": (_I, [C.POINTER(ModelBlob), C.POINTER(_VP)]),
+    "rsb_set_mesh_point_budget": (_I, [_I]),
     "rsb_model_destroy": (_I, [_VP]),
     "rsb_model_get_blob": (_I, [_VP, C.POINTER(ModelBlob)]),
     "rsb_model_body_index": (_I, [_VP, _CP]),

@@ -211,7 +211,9 @@ struct UJoint {
 
 
 // ------------------------------------------------------------------------------ mesh colliders
-constexpr int kMeshPoints = 8;   // collision points kept per mesh (the model holds RSB_MAX_COLLISIONS primitives in total)
+constexpr int kMeshPoints = 8;   // collision points kept per mesh by default (the model holds RSB_MAX_COLLISIONS primitives in total)
+constexpr int kMeshPointsMax = 26;   // ... and at most: one support vertex per direction of thin_point_set (8 body diagonals, 6 axes, 12 face diagonals)
+static int g_mesh_points = kMeshPoints;   // rsb_set_mesh_point_budget (process-wide; read when a URDF is loaded)
 
 static bool file_exists(const std::string& p) { std::ifstream f(p, std::ios::binary); return (bool)f; }
 
@@ -596,7 +598,7 @@ static void build_from_xml(const std::string& xml, rsb_model_blob* out, int* ski
           if (ms->get("scale") && !parse_doubles(ms->get("scale"), sc, 3)) throw std::runtime_error("URDF: bad <mesh scale> on link " + L.name);
           for (auto& v : verts) v = {v.x * sc[0], v.y * sc[1], v.z * sc[2]};
           col.type = 3; col.radius = 0; col.length = 0;
-          col.pts = thin_point_set(verts, kMeshPoints);
+          col.pts = thin_point_set(verts, g_mesh_points);
         } else { ++B.skipped_collisions; continue; }   // unknown geometry
         if (col.type != 2 && col.type != 3 && col.radius <= 0) throw std::runtime_error("URDF: non-positive collision radius on link " + L.name);
         L.cols.push_back(col);
@@ -799,3 +801,10 @@ const char* rsb_model_collision_material(const rsb_model* m, int collision) {
 }
 
 }  // extern "C"
+
+// <mesh> colliders keep up to n support vertices of their convex hull (default 8, at most 26); applies to the models loaded afterwards
+extern "C" int rsb_set_mesh_point_budget(int n) {
+  if (n < 1 || n > rsb::kMeshPointsMax) { rsb::set_error("rsb_set_mesh_point_budget: 1 .. 26 points per mesh"); return RSB_E_INVALID; }
+  rsb::g_mesh_points = n;
+  return RSB_OK;
+}

@@ -345,3 +345,53 @@ def test_collada_node_transforms_place_the_geometry(built_lib, tmp_path):
     order = lambda A: A[np.lexsort(np.round(A, 4).T[::-1])]
     assert np.allclose(order(P - off), order(base), atol=1e-9)
     assert np.allclose(np.ptp(P, axis=0), [1.0, 2.0, 1.0], atol=1e-9)   # the cube became 1 x 2 x 1 (scaled along x, then turned)
+
+
+def test_mesh_point_budget_keeps_more_hull_vertices(built_lib, tmp_path):
+    """rsb_set_mesh_point_budget: a <mesh> collider keeps up to 26 support vertices of its convex hull (default 8).  A 42-vertex geodesic ball: 8 points by
+    default, 20 distinct ones with the budget at 20 - every one a vertex of the mesh on its hull (radius 0.3), none an interior point -, 26 at most; the
+    budget is refused outside 1 .. 26 and applies to models loaded afterwards."""
+    from raisimlib_amd import _capi
+    L = _capi.lib()
+    # icosahedron subdivided once, projected on the sphere (42 vertices) + interior points the hull must drop
+    t = (1.0 + 5 ** 0.5) / 2
+    V = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    F = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8),
+         (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    V = [np.array(v, float) / np.linalg.norm(v) for v in V]
+    mid, F2 = {}, []
+    for a, b, c in F:
+        m = []
+        for i, j in ((a, b), (b, c), (c, a)):
+            key = (min(i, j), max(i, j))
+            if key not in mid:
+                p = V[i] + V[j]
+                V.append(p / np.linalg.norm(p)); mid[key] = len(V) - 1
+            m.append(mid[key])
+        F2 += [(a, m[0], m[2]), (b, m[1], m[0]), (c, m[2], m[1]), (m[0], m[1], m[2])]
+    assert len(V) == 42
+    P = [0.3 * v for v in V] + [np.array([0.05, 0.02, -0.03]), np.zeros(3)]
+    pkg = tmp_path / "ball_description"
+    os.makedirs(pkg / "meshes"); os.makedirs(pkg / "urdf")
+    with open(pkg / "meshes" / "ball.obj", "w") as f:
+        for p in P:
+            f.write(f"v {p[0]:.9f} {p[1]:.9f} {p[2]:.9f}\n")
+        for a, b, c in F2:
+            f.write(f"f {a + 1} {b + 1} {c + 1}\n")
+    urdf = pkg / "urdf" / "ball.urdf"
+    urdf.write_text("""<robot name="ball"><link name="base"><inertial><mass value="2"/><inertia ixx="0.1" iyy="0.1" izz="0.1" ixy="0" ixz="0" iyz="0"/></inertial>
+ <collision name="skin"><geometry><mesh filename="package://ball_description/meshes/ball.obj"/></geometry></collision></link></robot>""")
+    try:
+        assert Model(urdf_path=str(urdf)).ncol == 8
+        assert L.rsb_set_mesh_point_budget(20) == 0
+        m = Model(urdf_path=str(urdf))
+        assert m.ncol == 20
+        Q = np.array([[m.blob.col_pos[i][k] for k in range(3)] for i in range(20)])
+        assert np.allclose(np.linalg.norm(Q, axis=1), 0.3, atol=1e-6)                     # hull vertices, not the interior points
+        assert len({tuple(np.round(q, 6)) for q in Q}) == 20                              # distinct
+        assert all(min(np.linalg.norm(np.array(P[:42]) - q, axis=1)) < 1e-6 for q in Q)   # vertices of the mesh
+        assert L.rsb_set_mesh_point_budget(26) == 0 and Model(urdf_path=str(urdf)).ncol <= 26 and Model(urdf_path=str(urdf)).ncol > 20
+        assert L.rsb_set_mesh_point_budget(27) != 0 and L.rsb_set_mesh_point_budget(0) != 0
+    finally:
+        L.rsb_set_mesh_point_budget(8)
+    assert Model(urdf_path=str(urdf)).ncol == 8
