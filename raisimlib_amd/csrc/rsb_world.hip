@@ -1493,7 +1493,7 @@ int rsb_control_steps(rsb_world* w, int n_steps, const float* p_targets, int per
     f.do_reset = 1; f.have_allowed = 1; f.allowed = allowed; f.gc0 = gc0; f.gv0 = gv0; f.rows = rows;
   }
   f.res_steps = n_steps; f.res_stage = 0; f.res_targets = p_targets; f.res_period = period; f.res_first = first;
-  f.res_obs_stride = obs_step_stride; f.res_done_stride = done_step_stride; f.res_done = done_out;
+  f.res_obs_stride = obs_out ? obs_step_stride : 0; f.res_done_stride = done_out ? done_step_stride : 0; f.res_done = done_out;   // (a stride without its buffer must not walk the world's own done flags)
   w->fuse = f;
   return do_integrate(w, n_substeps);
 }
