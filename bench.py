@@ -110,6 +110,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=7,
                     help="every timed leg is R fresh brackets of exactly --steps steps, back to back; `value` = the MEDIAN bracket, value_repeats / value_min / "
                          "value_max beside it (VERDICT r05 #2: a 1.7 ms region measured once is not a measurement)")
+    ap.add_argument("--specialization", default="compile", choices=("compile", "cached", "off"),
+                    help="specialised code objects of the step kernel (rsb_set_specialization; csrc/step_spec.h): compile = a key build() did not prebuild is compiled during "
+                         "warm-up (~3 s, never inside a timed region); cached = prebuilt objects only; off = the ahead-of-time kernel classes (rounds 1-5)")
     ap.add_argument("--no-resident", action="store_true",
                     help="no resident leg (rsb_set_step_residency: --steps control steps in ONE launch of the step kernel): `value` is then the pipelined leg's, as in round 5")
     ap.add_argument("--closed-loop-only", action="store_true", help="diagnostic: only the `closed_loop` block (policy in the loop, include/rsb_pipeline.h), as its own JSON line")
@@ -994,6 +997,10 @@ def measure(args, rank, local_rank, world_size, dev, coll):
     if value_is_resident:
         value = resident_value
         value_leg = "resident"
+    spec_mode, spec_n, gen_n = world.specialization_status()
+    spec_info = {"mode": ("off", "cached", "compile")[spec_mode], "step_launches_specialized": spec_n, "step_launches_generic": gen_n,
+                 "what": "specialised code objects of the step kernel (raisimlib_amd/csrc/step_spec.h): the SAME kernel class compiled with the model's dimensions and the world's "
+                         "switches as compile-time constants; results bit-identical to the ahead-of-time class (tests/test_gpu_spec.py); counts are this world's launches of all legs"}
     iters = world.get_solver_iterations()
     counts, _ = world.get_contacts()
     q_end, _ = world.get_state()
@@ -1103,6 +1110,7 @@ def measure(args, rank, local_rank, world_size, dev, coll):
             **spread(res_leg if value_is_resident else primary_leg, total_env_steps),
             "value_is": "the MEDIAN of `repeats` fresh brackets of exactly --steps control steps each (barrier + synchronise on both sides, MAX over ranks), back to back",
             "value_leg": value_leg, "pipelined_leg_error": pipelined_leg_error, "resident_leg_error": resident_leg_error,
+            "specialization": spec_info,
             "resident": ({"value": resident_value, "unit": "env-steps/s", "ms_per_step": res_leg["elapsed"] / args.steps * 1e3, "steps": args.steps, **spread(res_leg, total_env_steps),
                           "launches_per_bracket": 1, "obs_all_gather": res_state["gather"], "gathered_rows_of_this_rank_correct": res_leg.get("gathered_rows_of_this_rank_correct"),
                           "gathered_rows_correct_on_all_ranks": res_leg.get("gathered_rows_correct_on_all_ranks"),
@@ -1187,6 +1195,7 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world_size} rank(s); the launcher's count is used", file=sys.stderr)
     if args.dry_run_ranks:
         sys.exit(dry_run_ranks(args, rank, world_size))
+    os.environ.setdefault("RSB_SPECIALIZE", {"compile": "compile", "cached": "1", "off": "0"}[args.specialization])   # every world of this process (the library reads it at rsb_create)
     os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments in device memory (this image's default; see rsb_world.hip)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")       # the closed loop runs three streams that must overlap (two step streams + the action stage's) beside the caller's: HIP's default of 4 hardware queues aliases them
     import torch

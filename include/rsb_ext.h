@@ -174,6 +174,26 @@ long long rsb_step_residency_launches(const rsb_world* w);
 /* debug aid: 1 = every control step of a resident launch writes everything a separate launch writes (state rows, warm records, contact records) */
 int rsb_debug_resident_full_writes(rsb_world* w, int on);
 
+/* ---- specialised step kernels.  The ahead-of-time kernel classes read the model's dimensions (bodies, coordinates, tree depth, collision primitives,
+ * self-collision pairs) and the world's switches (terrain kind, sub-steps per call, warm start, solver lags) from their kernel arguments.  A SPECIALISED code
+ * object is the same kernel compiled with those values as constants (-30 % instructions, -40 % branches; +13 % env-steps/s on the benchmark; results bit for
+ * bit the same).  Code objects live in rsb_spec_dir() ($RSB_SPEC_DIR, default spec/ next to librsb.so), one per (kernel class, values, source hash of the
+ * library).  mode: RSB_SPEC_OFF - ahead-of-time classes only; RSB_SPEC_CACHED (default; $RSB_SPECIALIZE=0 / compile change it) - a code object found there is
+ * used, a miss runs the ahead-of-time class; RSB_SPEC_COMPILE - a miss compiles it first (hipcc over the kernel sources, $RSB_SRC_DIR / $RSB_INCLUDE_DIR when
+ * they are not where the in-tree build left them; ~25 s once per key).  A code object that fails to load or was compiled against another argument layout is
+ * refused (message on stderr), never launched. */
+#define RSB_SPEC_OFF 0
+#define RSB_SPEC_CACHED 1
+#define RSB_SPEC_COMPILE 2
+int rsb_set_specialization(rsb_world* w, int mode);
+/* returns the mode; step launches so far that ran a specialised code object / an ahead-of-time class */
+int rsb_specialization_status(const rsb_world* w, long long* specialized_launches, long long* generic_launches);
+const char* rsb_spec_dir(void);
+/* host only (no GPU): compile the code object of one manifest line "<lpe> <kmax> <cl> <ml> | -DRSB_SPECIALIZED -DRSB_SPEC_NB=13 ..." into rsb_spec_dir()
+ * (what a miss appends to $RSB_SPEC_RECORD; raisimlib_amd/spec_manifest.txt holds the shipped workloads' lines and build() compiles them); its file name */
+int rsb_spec_compile(const char* manifest_line);
+int rsb_spec_file_name(const char* manifest_line, char* out, int capacity);
+
 
 /* elapsed device time (ms) of the most recent rsb_integrate launch, measured with HIP events
  * on the handle's stream; also the kernel's static resource usage for reports. */

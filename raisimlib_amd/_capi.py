@@ -209,6 +209,11 @@ PROTOTYPES = {
     "rsb_step_residency_status": (_I, [_VP, _I]),
     "rsb_step_residency_launches": (C.c_longlong, [_VP]),
     "rsb_debug_resident_full_writes": (_I, [_VP, _I]),
+    "rsb_set_specialization": (_I, [_VP, _I]),
+    "rsb_specialization_status": (_I, [_VP, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "rsb_spec_dir": (C.c_char_p, []),
+    "rsb_spec_compile": (_I, [C.c_char_p]),
+    "rsb_spec_file_name": (_I, [C.c_char_p, C.c_char_p, _I]),
     "rsb_debug_view_profile": (_I, [_VP, C.POINTER(C.c_longlong), _I]),
     "rsb_debug_select_env": (_I, [_VP, _I]),
     "rsb_debug_phase_cycles": (_I, [_VP, _I, _FP]),

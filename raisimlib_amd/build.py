@@ -25,7 +25,7 @@ RSB_H = os.path.join(ROOT, "include", "rsb.h")
 RSB_TYPES_H = os.path.join(ROOT, "include", "rsb_types.h")    # the part of the ABI the kernels compile against
 RSB_EXT_H = os.path.join(ROOT, "include", "rsb_ext.h")         # the entry points without an upstream counterpart (solver heuristics, scheduling, timing, debug aids); included by rsb.h
 RSB_PIPELINE_H = os.path.join(ROOT, "include", "rsb_pipeline.h")   # the closed-loop pipeline: C declarations + the device-side serve loop of an action stage
-_WORLD_DEPS = ["rsb_world.h", "rsb_internal.h", "step_types.h", RSB_H, RSB_EXT_H, RSB_TYPES_H, RSB_PIPELINE_H]
+_WORLD_DEPS = ["rsb_world.h", "rsb_internal.h", "rsb_spec.h", "step_types.h", "step_spec.h", RSB_H, RSB_EXT_H, RSB_TYPES_H, RSB_PIPELINE_H]
 HOST_SOURCES = {   # source -> headers it depends on
     "urdf_model.cpp": ["rsb_internal.h", RSB_H, RSB_EXT_H, RSB_TYPES_H],
     "terrain_io.cpp": ["rsb_internal.h", RSB_H, RSB_EXT_H, RSB_TYPES_H],
@@ -33,10 +33,11 @@ HOST_SOURCES = {   # source -> headers it depends on
     "rsb_pipeline.hip": _WORLD_DEPS + ["stage_bodies.h"],
     "rsb_comm.hip": _WORLD_DEPS,
     "rsb_rk4.hip": _WORLD_DEPS,
+    "rsb_spec.hip": _WORLD_DEPS,       # specialised code objects of the step kernel: key, cache directory, compile, load, launch
 }
 # the fused step kernel: the template's skeleton (step_kernel.h), its device helpers (step_math / step_terrain / step_slip .h) and its body, one
 # fragment per phase (step_phase_*.inc, included inside the kernel: same token stream as the one 2 500-line function of rounds 1-4)
-KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_launch.h", "env_task.h", "step_math.h", "step_terrain.h", "step_slip.h", "stage_bodies.h", RSB_PIPELINE_H,
+KERNEL_DEPS = ["step_instance.hip", "step_kernel.h", "step_types.h", "step_spec.h", "step_launch.h", "env_task.h", "step_math.h", "step_terrain.h", "step_slip.h", "stage_bodies.h", RSB_PIPELINE_H,
                *sorted(f for f in os.listdir(CSRC) if f.startswith("step_phase_") and f.endswith(".inc")), RSB_TYPES_H]
 # measured on the step kernel (profiles/r01_notes.md): SLP packing into v_pk_* costs more v_mov shuffles than it saves and
 # pushes the kernel into scratch; IEEE-exact fp32 div/sqrt sequences are not needed at the stated parity tolerance
@@ -150,5 +151,46 @@ def build(force=False, verbose=True, extra_flags=(), jobs=None):
     return out
 
 
+SPEC_MANIFEST = os.path.join(HERE, "spec_manifest.txt")
+
+
+def build_specializations(verbose=True, jobs=None):
+    """Compile the specialised code objects of the shipped workloads (csrc/step_spec.h): one per line of spec_manifest.txt - "<lpe> <kmax> <cl> <ml> | -D..." as
+    a miss appends it to $RSB_SPEC_RECORD - into lib/spec/ through the library's own host-only entry point (rsb_spec_compile: hipcc --genco, ~3 s each, no GPU
+    needed).  File names carry the library's source hash, so objects of older sources are never loaded; they are removed here.  A world whose key is not in the
+    manifest runs its ahead-of-time class (or compiles on demand: rsb_set_specialization(RSB_SPEC_COMPILE))."""
+    import ctypes
+    lib = ctypes.CDLL(OUT)
+    lib.rsb_spec_dir.restype = ctypes.c_char_p
+    lib.rsb_last_error.restype = ctypes.c_char_p
+    lines = [l.strip() for l in open(SPEC_MANIFEST) if l.strip() and not l.startswith("#")] if os.path.exists(SPEC_MANIFEST) else []
+    spec_dir = lib.rsb_spec_dir().decode()
+    os.makedirs(spec_dir, exist_ok=True)
+    want = set()
+    for l in lines:
+        buf = ctypes.create_string_buffer(256)
+        if lib.rsb_spec_file_name(l.encode(), buf, 256) != 0:
+            raise RuntimeError(f"spec_manifest.txt: bad line: {l}")
+        want.add(buf.value.decode())
+    for f in os.listdir(spec_dir):
+        if f not in want:
+            os.remove(os.path.join(spec_dir, f))
+    todo = [l for l in lines]
+
+    def one(l):
+        rc = lib.rsb_spec_compile(l.encode())
+        if rc != 0:
+            raise RuntimeError(f"rsb_spec_compile failed ({rc}) for: {l}\n{(lib.rsb_last_error() or b'').decode()}")
+    jobs = jobs or int(os.environ.get("RSB_BUILD_JOBS", "0")) or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(max_workers=jobs) as pool:
+        list(pool.map(one, todo))
+    if verbose:
+        print(f"specialised code objects: {len(want)} in {spec_dir}", file=sys.stderr)
+    return sorted(want)
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-") and a != "--force"])
+    flags = [a for a in sys.argv[1:] if a.startswith("-") and a not in ("--force", "--spec")]
+    build(force="--force" in sys.argv, extra_flags=flags)
+    if not flags:
+        build_specializations()

@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -176,6 +177,10 @@ struct rsb_world {
   long long view_prof[5] = {0, 0, 0, 0, 0};             // rsb_debug_view_profile: ns the host spent in rsb_view_exchange enqueueing uploads / launches / downloads, waiting; calls
   bool res_on = false, res_full = false;
   long long res_launches = 0;
+  // ---- specialised code objects of the step kernel (rsb_set_specialization; rsb_spec.hip)
+  int spec_mode = RSB_SPEC_CACHED;
+  long long spec_launches = 0, generic_launches = 0;     // step launches that ran a specialised code object / an ahead-of-time class
+  std::map<std::vector<int>, void*> spec_memo;           // (class, field values, mode) -> hipFunction_t or nullptr
 };
 
 // helpers shared by the translation units (rsb_world.hip unless noted)

@@ -26,6 +26,7 @@
 
 
 #include "rsb_world.h"
+#include "rsb_spec.h"
 
 namespace rsbw {
 
@@ -580,9 +581,26 @@ int do_integrate(rsb_world* w, int nsub) {
   if (rec) HIP_TRY(hipEventRecord(e0, ls));
   // kernel classes by the deepest body level (support-chain capacity of the contact-column / Delassus phases) and by the base (fixed-base systems have a class of their own)
   const int mlv = w->blob.depth - 1;
-  if (res_cl >= 0) {
+  // a specialised code object of the class this launch is about to run (rsb_spec.hip): same kernel, the model's dimensions and the world's switches as constants
+  hipFunction_t spec_fn = nullptr;
+  if (w->spec_mode != RSB_SPEC_OFF && !prof && mlv <= 16) {
+    rsbw::SpecClass sc{lpe, kcap, 0, mlv <= 4 ? 4 : mlv <= 12 ? 12 : 16};
+    if (res_cl >= 0) sc = mlv <= 4 ? rsbw::SpecClass{16, 8, res_cl, 4} : rsbw::SpecClass{32, 16, res_cl, 12};
+    else {
+      if (mlv > 4) sc.kmax = 16;
+      sc.cl = w->blob.fixed_base ? 1 : (coul && mlv <= 4) ? 32 : (hm2 && mlv <= 12) ? 4 : (th && mlv <= 12) ? 8 : (peer && mlv <= 12) ? 2 : 0;
+      if (coul && mlv <= 4) sc.kmax = 8;
+      if (!(sc.cl & 2) && a.pipe_prog) sc.cl |= 16;     // the class's pipelined twin (launch_lpe)
+    }
+    spec_fn = rsbw::spec_find(w, sc, a);
+  }
+  if (spec_fn) {
+    const int epw = 64 / (res_cl >= 0 ? (mlv <= 4 ? 16 : 32) : lpe);
+    st = rsbw::spec_launch(spec_fn, a, (w->N + epw - 1) / epw, lds_bytes, w->launch_stream);
+    if (st == RSB_OK) { ++w->spec_launches; if (res_cl >= 0) ++w->res_launches; }
+  } else if (res_cl >= 0) {
     st = launch_resident(w, a, lds_bytes, res_cl, mlv <= 4);
-    if (st == RSB_OK) ++w->res_launches;
+    if (st == RSB_OK) { ++w->res_launches; ++w->generic_launches; }
   } else if (mlv <= 4) {
     if (w->blob.fixed_base) st = kcap == 8 ? launch_lpe<8, 1, 4>(w, a, lds_bytes, lpe, prof) : launch_lpe<16, 1, 4>(w, a, lds_bytes, lpe, prof);
     else if (coul) st = launch_lpe<8, 32, 4>(w, a, lds_bytes, lpe, prof);
@@ -600,6 +618,7 @@ int do_integrate(rsb_world* w, int nsub) {
     return RSB_E_UNSUPPORTED;
   }
   if (st != RSB_OK) return st;
+  if (!spec_fn && res_cl < 0) ++w->generic_launches;
   if (pipelined) pipe_end_launch(w, a, ls);
   if (rec) {
     HIP_TRY(hipEventRecord(e1, ls));
@@ -681,6 +700,7 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   // every early return below (HIP_TRY) goes through rsb_destroy, which frees whatever has been allocated so far
   struct Destroyer { void operator()(rsb_world* p) const { rsb_destroy(p); } };
   std::unique_ptr<rsb_world, Destroyer> w(new rsb_world());
+  w->spec_mode = rsbw::spec_default_mode();
   w->blob = m->blob;
   w->N = num_envs;
   w->device = device;

@@ -5,8 +5,16 @@
 #include "step_kernel.h"
 #include "step_launch.h"
 
+#include <cstddef>
+
 #if !defined(RSB_I_LPE) || !defined(RSB_I_KMAX) || !defined(RSB_I_CL) || !defined(RSB_I_ML) || !defined(RSB_I_PROF)
 #error "step_instance.hip needs -DRSB_I_LPE= -DRSB_I_KMAX= -DRSB_I_CL= -DRSB_I_ML= -DRSB_I_PROF="
+#endif
+
+#ifdef RSB_SPECIALIZED
+// the layout this code object was compiled against: the loader (rsb_spec.hip) compares it with the library's own before it launches anything
+extern "C" __device__ __attribute__((used)) const unsigned rsb_spec_abi[4] = {(unsigned)sizeof(rsbk::StepArgs), (unsigned)sizeof(rsbk::LdsLayout),
+                                                                              (unsigned)offsetof(rsbk::StepArgs, L), (unsigned)rsbk::kSpecFields};
 #endif
 
 namespace rsbk {

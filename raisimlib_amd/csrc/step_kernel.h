@@ -42,6 +42,7 @@
 #include "env_task.h"
 #include "rsb_types.h"
 #include "step_types.h"
+#include "step_spec.h"     // RSB_DIM: model dimensions / world switches as compile-time constants in specialised code objects
 #include "step_math.h"      // vectors, spatial algebra, LDS access
 #include "step_terrain.h"   // sphere x height map narrow phase
 #include "step_slip.h"      // slip case of the one-contact rule, DPP row reductions
@@ -215,8 +216,14 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   // masked launch (per-env raisim::World views, rsb_integrate_masked): a masked-off env runs along but writes nothing back
   if (a.env_mask && !a.env_mask[env]) env_valid = false;
   // model dimensions travel in the kernel arguments (read through a.model they cost one more dependent load before anything can start)
-  const int nb = a.nb, nq = a.nq, nv = a.nv, depth = a.depth, ncol = a.ncol, cw = a.cw;
-  const bool fixed_base = a.fixed_base != 0;
+  // (RSB_DIM: a compile-time constant in a specialised code object, the kernel argument in the ahead-of-time classes - step_spec.h)
+  const int nb = RSB_DIM(NB, a.nb), nq = RSB_DIM(NQ, a.nq), nv = RSB_DIM(NV, a.nv), depth = RSB_DIM(DEPTH, a.depth), ncol = RSB_DIM(NCOL, a.ncol);
+#ifdef RSB_SPECIALIZED
+  constexpr int cw = (6 + RSB_SPEC_DEPTH - 1 + 3) & ~3;   // (round4(6 + depth - 1): rsb_world.hip)
+#else
+  const int cw = a.cw;
+#endif
+  const bool fixed_base = RSB_DIM(FIXED_BASE, a.fixed_base != 0);
   const auto& L = a.L;
 
   float* MODELF = lds + L.t_model;
@@ -248,7 +255,7 @@ __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepA
   const int* SPAIR = reinterpret_cast<const int*>(lds + L.t_spair);   // [n_self + 1] candidate pairs of self-collision: byte offset of centre i in CEN | of centre j << 16; the last entry pairs primitive 0 with itself (never a hit)
   float* CEN = E + L.cen;                                        // [ncol][4] primitive centres (relative to the base position) + radius; may alias WC
   float* SELFT = E + L.selft;                                    // [kmax][4] per contact slot of a self-collision: mu, restitution, threshold | J u of the slot's normal row
-  const int n_self = a.n_self;                                   // candidate pairs; 0 = self-collision off
+  const int n_self = RSB_DIM(N_SELF, a.n_self);                                   // candidate pairs; 0 = self-collision off
   const int nwarm = 6 * ncol;
   const int GS = L.gstride;
 

@@ -500,6 +500,20 @@ class BatchedWorld:
     def residency_launches(self):
         return int(self.L.rsb_step_residency_launches(self.handle))
 
+    # -- specialised step kernels (rsb_set_specialization: the model's dimensions and the world's switches as compile-time constants) ------------
+    SPEC_OFF, SPEC_CACHED, SPEC_COMPILE = 0, 1, 2
+
+    def set_specialization(self, mode):
+        """"off" / "cached" (default: use a code object found in rsb_spec_dir()) / "compile" (a miss compiles it first, ~25 s once per key)"""
+        m = {"off": 0, "cached": 1, "compile": 2}.get(mode, mode)
+        check(self.L.rsb_set_specialization(self.handle, int(m)), "rsb_set_specialization")
+
+    def specialization_status(self):
+        """(mode, step launches that ran a specialised code object, step launches that ran an ahead-of-time class)"""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        mode = self.L.rsb_specialization_status(self.handle, C.byref(a), C.byref(b))
+        return int(mode), int(a.value), int(b.value)
+
     def debug_resident_full_writes(self, on=True):
         check(self.L.rsb_debug_resident_full_writes(self.handle, int(bool(on))), "rsb_debug_resident_full_writes")
 
