@@ -112,6 +112,8 @@ class DeviceVectorizedEnvironment {
   /// round 6: K control steps of rolloutLinear / rolloutMlp run as ONE resident launch of the step kernel - the env blocks stay in LDS, each block's own wave
   /// evaluates the policy between two control steps (rsb_set_step_residency; bit-identical results).  Returns whether this world has a resident kernel class.
   bool setStepResidency(bool on) { RSB_CHECK(rsb_set_step_residency(world_.handle(), on ? 1 : 0)); return rsb_step_residency_status(world_.handle(), 1) != 0; }
+  /// specialised step kernels (rsb_ext.h: RSB_SPEC_OFF / RSB_SPEC_CACHED (default) / RSB_SPEC_COMPILE; bit-identical results)
+  void setKernelSpecialization(int mode) { RSB_CHECK(rsb_set_specialization(world_.handle(), mode)); }
   /// K control steps with the CALLER's stage kernel (a HIP kernel built around rsb_stage::serve).  Nothing synchronises.
   void closedLoopRun(int steps, rsb_stage_launch_fn launch, void* user) { RSB_CHECK(rsb_closed_loop_run(world_.handle(), steps, launch, user)); }
   /// K control steps with the in-repo linear policy  action = clip(bias + W ob):  W [actionDim, obDim] row-major and bias [actionDim] are HOST

@@ -160,9 +160,8 @@ def build_specializations(verbose=True, jobs=None):
     needed).  File names carry the library's source hash, so objects of older sources are never loaded; they are removed here.  A world whose key is not in the
     manifest runs its ahead-of-time class (or compiles on demand: rsb_set_specialization(RSB_SPEC_COMPILE))."""
     import ctypes
-    lib = ctypes.CDLL(OUT)
-    lib.rsb_spec_dir.restype = ctypes.c_char_p
-    lib.rsb_last_error.restype = ctypes.c_char_p
+    from . import _capi
+    lib = _capi.lib()
     lines = [l.strip() for l in open(SPEC_MANIFEST) if l.strip() and not l.startswith("#")] if os.path.exists(SPEC_MANIFEST) else []
     spec_dir = lib.rsb_spec_dir().decode()
     os.makedirs(spec_dir, exist_ok=True)

@@ -65,16 +65,19 @@ std::string defs_of(const StepArgs& a) {
 #define RSB_SPEC_DEF(NAME, expr) d += std::string(" -DRSB_SPEC_" #NAME "=") + std::to_string((int)(expr));
   RSB_SPEC_FIELDS(RSB_SPEC_DEF)
 #undef RSB_SPEC_DEF
+  // kernel experiments (tools/exp): extra -DRSB_X_... flags become part of the key, so an A/B of kernel variants is two runs on one box, each compiling its own code object
+  static const std::string extra = env_or("RSB_SPEC_EXTRA_DEFS", "");
+  if (!extra.empty()) d += " " + extra;
   return d;
 }
 
 std::string key_line(const rsbw::SpecClass& c, const std::string& defs) {
-  return std::to_string(c.lpe) + " " + std::to_string(c.kmax) + " " + std::to_string(c.cl) + " " + std::to_string(c.ml) + " | " + defs;
+  return std::to_string(c.lpe) + " " + std::to_string(c.kmax) + " " + std::to_string(c.cl) + " " + std::to_string(c.ml) + (c.prof ? " p" : "") + " | " + defs;
 }
 
 std::string file_of(const rsbw::SpecClass& c, const std::string& defs) {
   char buf[160];
-  std::snprintf(buf, sizeof buf, "step_%d_%d_%d_%d_%016llx.hsaco", c.lpe, c.kmax, c.cl, c.ml,
+  std::snprintf(buf, sizeof buf, "step_%d_%d_%d_%d%s_%016llx.hsaco", c.lpe, c.kmax, c.cl, c.ml, c.prof ? "p" : "",
                 (unsigned long long)fnv1a64(std::string(rsb_source_hash()) + " " + key_line(c, defs)));
   return buf;
 }
@@ -82,13 +85,17 @@ std::string file_of(const rsbw::SpecClass& c, const std::string& defs) {
 // Itanium mangling of rsbk::rsb_step_kernel<LPE, KMAX, CL, ML, false>(rsbk::StepArgs)
 std::string symbol_of(const rsbw::SpecClass& c) {
   char buf[160];
-  std::snprintf(buf, sizeof buf, "_ZN4rsbk15rsb_step_kernelILi%dELi%dELi%dELi%dELb0EEEvNS_8StepArgsE", c.lpe, c.kmax, c.cl, c.ml);
+  std::snprintf(buf, sizeof buf, "_ZN4rsbk15rsb_step_kernelILi%dELi%dELi%dELi%dELb%dEEEvNS_8StepArgsE", c.lpe, c.kmax, c.cl, c.ml, c.prof ? 1 : 0);
   return buf;
 }
 
 bool parse_line(const char* line, rsbw::SpecClass& c, std::string& defs) {
   int n = 0;
-  if (!line || std::sscanf(line, "%d %d %d %d | %n", &c.lpe, &c.kmax, &c.cl, &c.ml, &n) != 4 || n == 0) return false;
+  c.prof = 0;
+  if (!line || std::sscanf(line, "%d %d %d %d %n", &c.lpe, &c.kmax, &c.cl, &c.ml, &n) != 4 || n == 0) return false;
+  if (line[n] == 'p') { c.prof = 1; ++n; while (line[n] == ' ') ++n; }
+  if (line[n] != '|') return false;
+  ++n; while (line[n] == ' ') ++n;
   defs = line + n;
   while (!defs.empty() && (defs.back() == '\n' || defs.back() == '\r' || defs.back() == ' ')) defs.pop_back();
   // the flags go onto a compiler command line: nothing but -DRSB_SPEC... tokens of [A-Z_0-9=] (and a leading -DRSB_SPECIALIZED)
@@ -109,7 +116,7 @@ int compile(const rsbw::SpecClass& c, const std::string& defs) {
   // (the flags of raisimlib_amd/build.py FLAGS; --genco: device code object only)
   const std::string cmd = hipcc + " --genco --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -I '" + inc + "' -I '" + src + "'" +
                           " -DRSB_I_LPE=" + std::to_string(c.lpe) + " -DRSB_I_KMAX=" + std::to_string(c.kmax) + " -DRSB_I_CL=" + std::to_string(c.cl) +
-                          " -DRSB_I_ML=" + std::to_string(c.ml) + " -DRSB_I_PROF=0 " + defs + " -o '" + tmp + "' '" + src + "/step_instance.hip' > '" + tmp + ".log' 2>&1";
+                          " -DRSB_I_ML=" + std::to_string(c.ml) + " -DRSB_I_PROF=" + std::to_string(c.prof ? 1 : 0) + " " + defs + " -o '" + tmp + "' '" + src + "/step_instance.hip' > '" + tmp + ".log' 2>&1";
   const int rc = std::system(cmd.c_str());
   if (rc != 0 || !file_exists(tmp)) {
     rsb::set_error("rsb specialisation: hipcc failed (log: " + tmp + ".log) for " + key_line(c, defs));
@@ -173,7 +180,7 @@ hipFunction_t spec_find(rsb_world* w, const SpecClass& c, const StepArgs& a) {
   // the world's own memo: class + field values -> function (or nullptr), looked up at every launch
   std::array<int, 4 + rsbk::kSpecFields> k{};
   int n = 0;
-  k[n++] = c.lpe; k[n++] = c.kmax; k[n++] = c.cl; k[n++] = c.ml;
+  k[n++] = c.lpe; k[n++] = c.kmax; k[n++] = c.cl | (c.prof ? (1 << 20) : 0); k[n++] = c.ml;
 #define RSB_SPEC_VAL(NAME, expr) k[n++] = (int)(expr);
   RSB_SPEC_FIELDS(RSB_SPEC_VAL)
 #undef RSB_SPEC_VAL

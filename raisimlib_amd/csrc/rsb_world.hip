@@ -583,7 +583,7 @@ int do_integrate(rsb_world* w, int nsub) {
   const int mlv = w->blob.depth - 1;
   // a specialised code object of the class this launch is about to run (rsb_spec.hip): same kernel, the model's dimensions and the world's switches as constants
   hipFunction_t spec_fn = nullptr;
-  if (w->spec_mode != RSB_SPEC_OFF && !prof && mlv <= 16) {
+  if (w->spec_mode != RSB_SPEC_OFF && mlv <= 16 && !(prof && (res_cl >= 0 || peer || a.pipe_prog))) {   // (the classes without a profiling twin refuse `prof` below)
     rsbw::SpecClass sc{lpe, kcap, 0, mlv <= 4 ? 4 : mlv <= 12 ? 12 : 16};
     if (res_cl >= 0) sc = mlv <= 4 ? rsbw::SpecClass{16, 8, res_cl, 4} : rsbw::SpecClass{32, 16, res_cl, 12};
     else {
@@ -592,6 +592,7 @@ int do_integrate(rsb_world* w, int nsub) {
       if (coul && mlv <= 4) sc.kmax = 8;
       if (!(sc.cl & 2) && a.pipe_prog) sc.cl |= 16;     // the class's pipelined twin (launch_lpe)
     }
+    sc.prof = prof ? 1 : 0;
     spec_fn = rsbw::spec_find(w, sc, a);
   }
   if (spec_fn) {

@@ -41,5 +41,8 @@ for _ in range(R):
     fn(K, k); k += K
     w.synchronize()
 dt = time.perf_counter() - t0
-print(f"config {config} {mode} K={K} R={R}: {N * 4 * K * R / dt / 1e6:.1f} M env-steps/s", flush=True)
+import hashlib
+q_end, u_end = w.get_state()
+digest = hashlib.sha1(q_end.tobytes() + u_end.tobytes() + obs.cpu().numpy().tobytes()).hexdigest()[:12]      # (same kernel semantics => same digest: an A/B of kernel variants that must not change results)
+print(f"config {config} {mode} K={K} R={R}: {N * 4 * K * R / dt / 1e6:.1f} M env-steps/s  state digest {digest} sweeps mean {w.get_solver_iterations().mean():.3f} flags&16: {int(((w.get_flags() & 16) != 0).sum())} contacts/env {w.get_contacts()[0].mean():.3f} envs with > 4: {int((w.get_contacts()[0] > 4).sum())}", flush=True)
 w.close()
