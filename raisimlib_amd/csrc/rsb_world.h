@@ -105,6 +105,7 @@ struct rsb_world {
   float hm_max = 0.f;
   double stall_factor = 0.5, settle_tol = 0.0, restitution = 0.0, res_threshold = 0.0;
   int lpe = 0, max_kid = 0;
+  bool chain = false;         // base + consecutively numbered serial chains, <= 16 bodies (StepArgs::chain)
   double world_time = 0;
   bool integrate1_valid = false;
   bool env_ob_valid = false;            // d_env_ob holds the env-task observation of the CURRENT state (left there by the last env-task step; any other state change clears it)

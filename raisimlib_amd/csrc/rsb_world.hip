@@ -523,7 +523,7 @@ int do_integrate(rsb_world* w, int nsub) {
   a.dbg_env = w->dbg_env;
   a.N = w->N; a.nsub = nsub; a.kmax = w->kmax; a.control_mode = w->control_mode;
   a.nb = w->blob.nb; a.nq = w->blob.nq; a.nv = w->blob.nv; a.ncol = w->blob.ncol; a.depth = w->blob.depth;
-  a.cw = round4(6 + w->blob.depth - 1); a.max_kid = w->max_kid; a.fixed_base = w->blob.fixed_base;
+  a.cw = round4(6 + w->blob.depth - 1); a.max_kid = w->max_kid; a.fixed_base = w->blob.fixed_base; a.chain = (w->chain && lpe == 16) ? 1 : 0;
   a.dt = (float)w->dt; a.gx = (float)w->gravity[0]; a.gy = (float)w->gravity[1]; a.gz = (float)w->gravity[2];
   a.mu = (float)w->mu; a.erp = (float)w->erp;
   a.alpha_init = (float)w->alpha_init; a.alpha_min = (float)w->alpha_min; a.alpha_decay = (float)w->alpha_decay;
@@ -716,6 +716,8 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   HIP_TRY(hipMalloc(&w->d_model, sizeof(DevModel)));
   HIP_TRY(hipMemcpy(w->d_model, dm.get(), sizeof(DevModel), hipMemcpyHostToDevice));
   w->max_kid = dm->max_kid;
+  w->chain = w->blob.nb <= 16;
+  for (int b = 1; b < w->blob.nb; ++b) if (dm->level[b] >= 2 && dm->parent[b] != b - 1) w->chain = false;
   HIP_TRY(hipMalloc(&w->d_gc, N * nq * sizeof(float)));
   HIP_TRY(hipMalloc(&w->d_gv, N * nv * sizeof(float)));
   HIP_TRY(hipMalloc(&w->d_pt, N * nq * sizeof(float)));

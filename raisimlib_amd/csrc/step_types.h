@@ -132,6 +132,8 @@ struct StepArgs {
   int lds_floats;
   int N, nsub, kmax, control_mode;
   int nb, nq, nv, ncol, depth, cw, max_kid, fixed_base;   // model dimensions (DevModel's, repeated here: see the kernel's first lines)
+  int chain;                   // the tree is the base + serial chains numbered consecutively (every body of level >= 2 has parent = itself - 1) and fits a 16-lane row:
+                               // specialised code objects then hand a body's results to its child by a DPP row shift instead of through LDS (step_spec.h)
   float dt, gx, gy, gz, mu, erp;
   float alpha_init, alpha_min, alpha_decay, threshold;
   int max_iter, section_rounds, stall_window, freeze_after, refine;

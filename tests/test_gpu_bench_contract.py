@@ -33,6 +33,10 @@ def test_bench_prints_the_contract_line(built_lib, config):
     # round 6: `value` is the RESIDENT leg (the bracket's control steps are one launch of the step kernel), the median of `repeats` fresh brackets; the
     # pipelined and the lock-step legs of the same line carry their own repeats
     assert b["value_leg"] == "resident" and b["resident_leg_error"] is None and b["resident"]["value"] == b["value"]
+    # every step launch of the line's world ran a SPECIALISED code object of its kernel class (csrc/step_spec.h): the keys of bench.py's workloads are in
+    # raisimlib_amd/spec_manifest.txt and build() compiled them; a key that is missing is compiled during warm-up (--specialization compile, the default)
+    sp = b["specialization"]
+    assert sp["mode"] == "compile" and sp["step_launches_generic"] == 0 and sp["step_launches_specialized"] > 7 * 6, sp
     for blk in (b, b["resident"], b["pipelined"], b["lockstep"]):
         assert blk["repeats"] == 7 and len(blk["value_repeats"]) == 7 and blk["value_min"] <= blk["value"] <= blk["value_max"]
         assert sorted(blk["value_repeats"])[3] == pytest.approx(blk["value"], rel=1e-9)

@@ -122,3 +122,19 @@ def test_cached_mode_never_compiles_and_a_bad_code_object_is_refused(built_lib, 
     assert p.returncode == 0, p.stdout + p.stderr
     st, s2, err = child("cached")
     assert st == [1, 5, 0] and s2 == s0, (st, err)
+
+
+def test_the_manifest_covers_the_workloads_of_bench_py(built_lib, tmp_path):
+    """build() compiles one code object per line of raisimlib_amd/spec_manifest.txt; the default bench line (configs 2, 3, 5, closed loop, template path)
+    must not meet a key outside it: with prebuilt objects only, nothing is recorded as missing and no launch of the line's world runs an ahead-of-time class."""
+    import json
+    rec = tmp_path / "missing.txt"
+    env = dict(os.environ, RSB_SPEC_RECORD=str(rec))
+    env.pop("RSB_SPECIALIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--specialization", "cached", "--steps", "4", "--warmup", "2", "--no-cpu", "--repeats", "3"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    b = json.loads([l for l in p.stdout.strip().splitlines() if l.startswith("{")][-1])
+    missing = rec.read_text().splitlines() if rec.exists() else []
+    assert not missing, "keys outside raisimlib_amd/spec_manifest.txt:\n" + "\n".join(missing)
+    assert b["specialization"]["mode"] == "cached" and b["specialization"]["step_launches_generic"] == 0
