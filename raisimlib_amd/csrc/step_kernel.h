@@ -157,6 +157,10 @@ __device__ __forceinline__ void resident_stage(KArgs ka, int blk, int pass, int 
 #else
 #define RSB_X_WPE_ATTR
 #endif
+// Register budget of the pipelined classes (| 16): they share their SIMD with a wave of the action stage in a closed-loop run (rsb_pipeline.hip: the stage
+// kernels are held under 96 registers for this), so they may take 416 of the SIMD's 512 - tests/test_kernel_budget.py reads the compiler's report.  (An
+// __attribute__((amdgpu_num_vgpr(416))) does nothing here: on gfx950 it bounds the 256 architectural registers only.  What keeps the classes inside the budget
+// is the number of coupling blocks the solver holds in registers: step_phase_solver.inc, NPK.)
 template <int LPE, int KMAX, int CL, int ML, bool PROF>
 __global__ void __launch_bounds__(64) RSB_X_WPE_ATTR rsb_step_kernel(const StepArgs) {
   const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();   // the by-value StepArgs sits at offset 0 of the kernarg segment
