@@ -29,9 +29,10 @@ def test_step_instances_use_no_scratch(tmp_path, lpe, kmax, ml, cl):
     assert "scratch_store" not in txt and "scratch_load" not in txt
     assert vgpr <= 512                       # arch VGPRs + AGPRs of the one wave a SIMD holds
     assert not re.search(r"\bv_mfma", txt)   # documented in DESIGN.md section 4: no MFMA on this path, by measurement
-    # round 3's instruction-level steps stay in the ISA: packed fp32 in the contact exchange (2 sites x 8 or 12 blocks x 3 columns) and in the
-    # up pass's sums, and the sweep loop's fetch-window pin
-    assert len(re.findall(r"\bv_pk_fma_f32\b", txt)) >= 48 and len(re.findall(r"\bv_pk_add_f32\b", txt)) >= 28
+    # round 3's instruction-level steps stay in the ISA: packed fp32 in the contact exchange (2 sites x the register-held coupling blocks x 3 columns: five
+    # blocks in the quadruped classes since round 6 - step_phase_solver.inc, NPK -, twelve in the large ones) and in the up pass's sums, and the sweep loop's
+    # fetch-window pin
+    assert len(re.findall(r"\bv_pk_fma_f32\b", txt)) >= (30 if kmax == 8 else 48) and len(re.findall(r"\bv_pk_add_f32\b", txt)) >= 28
     assert re.search(r"\.p2align\s+5", txt)
     # pipelined control steps live in the class twins (| 16) alone: the plain instances carry neither the hand-over's cache operations nor its
     # spin ("the plain instances carry none of this"); the twins have the XCD-affine hand-over AND the agent-scope fallback
