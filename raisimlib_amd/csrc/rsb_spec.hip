@@ -17,6 +17,7 @@
 #include <array>
 #include <cstddef>
 #include <cstdio>
+#include <cctype>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
@@ -66,7 +67,11 @@ std::string defs_of(const StepArgs& a) {
   RSB_SPEC_FIELDS(RSB_SPEC_DEF)
 #undef RSB_SPEC_DEF
   // kernel experiments (tools/exp): extra -DRSB_X_... flags become part of the key, so an A/B of kernel variants is two runs on one box, each compiling its own code object
-  static const std::string extra = env_or("RSB_SPEC_EXTRA_DEFS", "");
+  static const std::string extra = [] {
+    std::string e = env_or("RSB_SPEC_EXTRA_DEFS", "");
+    for (char ch : e) if (!(std::isalnum((unsigned char)ch) || ch == '_' || ch == '=' || ch == '-' || ch == ' ')) { std::fprintf(stderr, "librsb: RSB_SPEC_EXTRA_DEFS ignored (only -DNAME[=value] tokens)\n"); return std::string(); }
+    return e;
+  }();
   if (!extra.empty()) d += " " + extra;
   return d;
 }
@@ -110,6 +115,8 @@ int compile(const rsbw::SpecClass& c, const std::string& defs) {
   ::mkdir(dir.c_str(), 0777);
   const std::string lib = lib_dir();
   const std::string src = env_or("RSB_SRC_DIR", lib + "/../csrc"), inc = env_or("RSB_INCLUDE_DIR", lib + "/../../include");
+  for (const std::string* pth : {&dir, &src, &inc})      // (the paths go onto a shell command line, single-quoted)
+    if (pth->find('\'') != std::string::npos) { rsb::set_error("rsb specialisation: a path with a single quote in it: " + *pth); return RSB_E_INVALID; }
   if (!file_exists(src + "/step_instance.hip")) { rsb::set_error("rsb specialisation: kernel sources not found in " + src + " (RSB_SRC_DIR)"); return RSB_E_UNSUPPORTED; }
   const std::string hipcc = env_or("HIPCC", file_exists("/opt/rocm/bin/hipcc") ? "/opt/rocm/bin/hipcc" : "hipcc");
   const std::string tmp = out + ".tmp" + std::to_string((long)::getpid());
