@@ -20,6 +20,7 @@ torch.cuda.set_stream(stream)
 w = BatchedWorld(r.model, N)
 w.set_stream(stream.cuda_stream)
 r.setup_world(w, N, 0)
+if os.environ.get("RSB_EXP_NO_SELF"): w.set_self_collision(False)      # (what the self-collision sweep costs: the benchmark's population has next to no self-collisions)
 gc0, gv0 = r.initial_state(N, 0)
 w.set_state(gc0, gv0)
 w.set_pd_target(None, np.zeros((N, r.model.nv), np.float32))
