@@ -114,7 +114,7 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   const int cw = round4(6 + b.depth - 1);
   int o = 0;
   auto take = [&](int n) { int r = o; o += round4(n); return r; };
-  L.t_model = take(b.nb * rsbk::kModelSlot);
+  L.t_model = take(b.nb * rsbk::kModelPitch);
   L.t_gain = take(2 * b.nb);
   L.t_parlv = take(b.nb);
   L.t_anc = take(b.nb * b.depth);
@@ -369,8 +369,8 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
   std::vector<float> img((size_t)L.shared_total, 0.f);
   auto put_i = [&](int off, int v) { std::memcpy(&img[off], &v, sizeof(int)); };
   for (int i = 0; i < b.nb; ++i) {
-    for (int c = 0; c < rsbk::kModelSlot; ++c) img[L.t_model + i * rsbk::kModelSlot + c] = dm->bodyf[i][c];
-    if (w->rk4_inner) img[L.t_model + i * rsbk::kModelSlot + 28] = 0.f;      // (RUNGE_KUTTA_4's contact step: its generalized force carries inertial terms, the effort clip was applied in the stages)
+    for (int c = 0; c < rsbk::kModelSlot; ++c) img[L.t_model + i * rsbk::kModelPitch + c] = dm->bodyf[i][c];
+    if (w->rk4_inner) img[L.t_model + i * rsbk::kModelPitch + 28] = 0.f;      // (RUNGE_KUTTA_4's contact step: its generalized force carries inertial terms, the effort clip was applied in the stages)
     const bool pd = w->control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && i >= 1;
     img[L.t_gain + 2 * i] = pd ? w->h_kp[i + 5] : 0.f;
     img[L.t_gain + 2 * i + 1] = pd ? w->h_kd[i + 5] : 0.f;

@@ -29,6 +29,12 @@ constexpr int kFactSlot = 16;    // S6 UD6 rsD invD pad2
 constexpr int kConSlot = 16;     // x3 depth | t1 body | t2 col | n pad
 constexpr int kColSlot = 12;     // per collision primitive in LDS: centre3 radius | body mu restitution res_threshold | axis3 rim (rim > 0: see rsb_model_blob::col_rim)
 constexpr int kModelSlot = 32;   // per-body constants staged in LDS (see DevModel::bodyf)
+#ifndef RSB_X_MODEL_PITCH
+#define RSB_X_MODEL_PITCH 36
+#endif
+constexpr int kModelPitch = RSB_X_MODEL_PITCH;   // floats between two bodies' constants IN LDS: with 36 the sixteen lanes of an env (lane = body) start their 16-byte reads on
+                                  // sixteen different four-bank groups (36 i mod 64 = 0, 36, 8, 44 ...); with the slot's own 32 they shared two - an 8-way bank conflict
+                                  // on each of the eight reads of the down pass
 constexpr float kLambdaFloor = 1e-3f;  // N s, floor of the relative convergence test (== ORC_LAMBDA_FLOOR)
 constexpr float kDenMin = 1e-6f;       // == ORC_DEN_MIN
 constexpr float kDenFreeze = 0.1f;    // == ORC_DEN_FREEZE
