@@ -174,6 +174,12 @@ long long rsb_step_residency_launches(const rsb_world* w);
 /* debug aid: 1 = every control step of a resident launch writes everything a separate launch writes (state rows, warm records, contact records) */
 int rsb_debug_resident_full_writes(rsb_world* w, int on);
 
+/* host only (no GPU): LDS bytes of ONE workgroup of the step kernel for this model (kmax contact slots, self-collision on / off, lanes_per_env 16 / 32 / 64 or 0 =
+ * the library's choice).  A CU holds min(4, 160 KiB / this) workgroups of one wave each: the layout of the benchmark's models sits close to such a boundary
+ * (4 x 40 048 B for the ANYmal-like model, 3 workgroups for the Atlas-like one), and a table that grows by a few hundred bytes can cost a quarter or a third of the
+ * resident waves (tests/test_kernel_budget.py pins the counts). */
+int rsb_model_lds_bytes(const rsb_model* m, int kmax, int self_collision, int lanes_per_env);
+
 /* ---- specialised step kernels.  The ahead-of-time kernel classes read the model's dimensions (bodies, coordinates, tree depth, collision primitives,
  * self-collision pairs) and the world's switches (terrain kind, sub-steps per call, warm start, solver lags) from their kernel arguments.  A SPECIALISED code
  * object is the same kernel compiled with those values as constants (-30 % instructions, -40 % branches; +13 % env-steps/s on the benchmark; results bit for

@@ -209,6 +209,7 @@ PROTOTYPES = {
     "rsb_step_residency_status": (_I, [_VP, _I]),
     "rsb_step_residency_launches": (C.c_longlong, [_VP]),
     "rsb_debug_resident_full_writes": (_I, [_VP, _I]),
+    "rsb_model_lds_bytes": (_I, [_VP, _I, _I, _I]),
     "rsb_set_specialization": (_I, [_VP, _I]),
     "rsb_specialization_status": (_I, [_VP, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "rsb_spec_dir": (C.c_char_p, []),

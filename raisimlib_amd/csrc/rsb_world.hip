@@ -109,12 +109,13 @@ int hm_slots_for(const rsb_model_blob& b) { return std::max(rsbk::kHmSlots, (int
 // default kmax 8 ran the KMAX-16 kernel (packed triangular Delassus blocks) on the square layout.
 int kcap_of(const rsb_model_blob& b, int kmax) { return (kmax <= 8 && b.depth - 1 <= 4) ? 8 : 16; }
 
-LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
+static LdsLayout make_layout_pitch(const rsb_model_blob& b, int kcap, int n_self, int model_pitch) {
   LdsLayout L;
+  L.model_pitch = model_pitch;
   const int cw = round4(6 + b.depth - 1);
   int o = 0;
   auto take = [&](int n) { int r = o; o += round4(n); return r; };
-  L.t_model = take(b.nb * rsbk::kModelPitch);
+  L.t_model = take(b.nb * model_pitch);
   L.t_gain = take(2 * b.nb);
   L.t_parlv = take(b.nb);
   L.t_anc = take(b.nb * b.depth);
@@ -154,6 +155,19 @@ LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
   }
   L.per_env = o + rsbk::kEnvPad;
   return L;
+}
+
+// The conflict-free pitch of the model table (step_types.h: kModelPitch) costs 4 floats per body - and a workgroup per CU where the layout sits on a 160-KiB
+// cliff (the Atlas-like humanoid at 32 lanes per env: 3 workgroups -> 2, config 5 fell from 38.9 M to 26.4 M env-steps/s in gpurun r06d): it is taken only
+// where no lanes-per-env choice loses a workgroup to it.
+LdsLayout make_layout(const rsb_model_blob& b, int kcap, int n_self) {
+  const LdsLayout tight = make_layout_pitch(b, kcap, n_self, rsbk::kModelSlot), wide = make_layout_pitch(b, kcap, n_self, rsbk::kModelPitch);
+  auto wgs = [](const LdsLayout& L, int lpe) {
+    const size_t bytes = sizeof(float) * ((size_t)L.shared_total + (size_t)(64 / lpe) * L.per_env);
+    return bytes > 160 * 1024 ? 0 : (int)std::min<size_t>(4, (160 * 1024) / bytes);
+  };
+  for (int lpe : {16, 32, 64}) if (wgs(wide, lpe) != wgs(tight, lpe)) return tight;
+  return wide;
 }
 
 size_t lds_bytes_for(const rsb_model_blob& b, int kcap, int lpe, int n_self) {
@@ -320,6 +334,15 @@ int launch_resident(rsb_world* w, const StepArgs& a, size_t lds_bytes, int cl, b
   return RSB_E_UNSUPPORTED;
 }
 
+}  // namespace rsbw
+extern "C" int rsb_model_lds_bytes(const rsb_model* m, int kmax, int self_collision, int lanes_per_env) {
+  if (!m || kmax < 1 || kmax > RSB_MAX_CONTACTS || (lanes_per_env != 0 && lanes_per_env != 16 && lanes_per_env != 32 && lanes_per_env != 64)) { rsb::set_error("rsb_model_lds_bytes: bad argument"); return RSB_E_INVALID; }
+  const rsb_model_blob& b = m->blob;
+  const int n_self = self_collision ? (int)rsbw::enumerate_self_pairs(b, std::vector<uint8_t>()).size() / 2 : 0;
+  const int lpe = lanes_per_env ? lanes_per_env : rsbw::default_lpe(b, kmax, n_self);
+  return (int)rsbw::lds_bytes_for(b, rsbw::kcap_of(b, kmax), lpe, n_self);
+}
+namespace rsbw {
 int effective_lpe(const rsb_world* w) {
   int lpe = w->lpe > 0 ? w->lpe : default_lpe(w->blob, w->kmax, n_self_pairs(w));
   return lpe;
@@ -369,8 +392,8 @@ std::vector<float> build_lds_image(const rsb_world* w, const LdsLayout& L) {
   std::vector<float> img((size_t)L.shared_total, 0.f);
   auto put_i = [&](int off, int v) { std::memcpy(&img[off], &v, sizeof(int)); };
   for (int i = 0; i < b.nb; ++i) {
-    for (int c = 0; c < rsbk::kModelSlot; ++c) img[L.t_model + i * rsbk::kModelPitch + c] = dm->bodyf[i][c];
-    if (w->rk4_inner) img[L.t_model + i * rsbk::kModelPitch + 28] = 0.f;      // (RUNGE_KUTTA_4's contact step: its generalized force carries inertial terms, the effort clip was applied in the stages)
+    for (int c = 0; c < rsbk::kModelSlot; ++c) img[L.t_model + i * L.model_pitch + c] = dm->bodyf[i][c];
+    if (w->rk4_inner) img[L.t_model + i * L.model_pitch + 28] = 0.f;      // (RUNGE_KUTTA_4's contact step: its generalized force carries inertial terms, the effort clip was applied in the stages)
     const bool pd = w->control_mode == RSB_PD_PLUS_FEEDFORWARD_TORQUE && i >= 1;
     img[L.t_gain + 2 * i] = pd ? w->h_kp[i + 5] : 0.f;
     img[L.t_gain + 2 * i + 1] = pd ? w->h_kd[i + 5] : 0.f;
@@ -730,7 +753,7 @@ int rsb_create(const rsb_model* m, int num_envs, int device, rsb_world** out) {
   HIP_TRY(hipMalloc(&w->d_flags, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_iters, N * sizeof(int32_t)));
   HIP_TRY(hipMalloc(&w->d_obs_idx, RSB_MAX_COLLISIONS * sizeof(int32_t)));
-  HIP_TRY(hipMalloc(&w->d_image, (size_t)make_layout(w->blob, 8, w->blob.ncol * (w->blob.ncol - 1) / 2).shared_total * sizeof(float)));   // (room for every primitive pair)
+  HIP_TRY(hipMalloc(&w->d_image, (size_t)make_layout_pitch(w->blob, 8, w->blob.ncol * (w->blob.ncol - 1) / 2, rsbk::kModelPitch).shared_total * sizeof(float)));   // (room for every primitive pair)
   w->self_ignore.assign((size_t)w->blob.nb * w->blob.nb, 0);
   w->self_pairs = enumerate_self_pairs(w->blob, w->self_ignore);
   w->self_mu.assign(w->self_pairs.size() / 2, -1.0); w->self_rest = w->self_mu; w->self_rthr = w->self_mu;

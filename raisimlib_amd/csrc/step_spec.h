@@ -17,7 +17,7 @@
   X(N_SELF, a.n_self) X(NSUB, a.nsub) X(KMAX, a.kmax) X(HAS_WARM, (a.warm != nullptr)) X(TERRAIN, a.terrain_type)                      \
   X(EARLY_TERM, (a.early_term != 0)) X(SECTION_ROUNDS, a.section_rounds) X(STALL_WINDOW, a.stall_window) X(FREEZE_AFTER, a.freeze_after) \
   X(REFINE, a.refine) X(MULTI_FA, a.multi_freeze_after) X(MULTI_DEPTH, a.multi_depth) X(MULTI_LIGHT, a.multi_light)                    \
-  X(MULTI_SW, a.multi_stall_window) X(CHAIN, (a.chain != 0))
+  X(MULTI_SW, a.multi_stall_window) X(CHAIN, (a.chain != 0)) X(MODEL_PITCH, a.L.model_pitch)
 
 #ifdef RSB_SPECIALIZED
 #define RSB_DIM(NAME, expr) (RSB_SPEC_##NAME)

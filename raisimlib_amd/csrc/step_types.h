@@ -81,6 +81,7 @@ struct LdsLayout {
   int cen, selft;   // self-collision: primitive centres [ncol][4] (may alias wc: dead before the contact columns), per-slot pair record [kcap][4]
   int gstride;
   int per_env;
+  int model_pitch;  // floats between two bodies' constants in the t_model table: kModelPitch where that costs no workgroup per CU, else kModelSlot (make_layout)
 };
 
 struct StepArgs {

@@ -73,6 +73,12 @@ class Model:
     def collision_names(self):
         return [self.blob.col_name[i].value.decode() for i in range(self.ncol)]
 
+    def lds_bytes(self, kmax=8, self_collision=True, lanes_per_env=0):
+        """LDS bytes of one workgroup of the step kernel for this model (host only; rsb_model_lds_bytes)"""
+        n = lib().rsb_model_lds_bytes(self.handle, int(kmax), int(bool(self_collision)), int(lanes_per_env))
+        check(min(n, 0), "rsb_model_lds_bytes")
+        return n
+
     def collision_indices(self, suffix):
         return [i for i, n in enumerate(self.collision_names()) if n.endswith(suffix)]
 

@@ -49,3 +49,19 @@ def test_benchmark_classes_do_not_spill_to_scratch():
     for cl in (0, 64, 192, 320):
         assert _resources(16, 8, cl, 4)["private_segment_fixed_size"] == 0, cl
         assert _resources(16, 8, cl, 4, _manifest_defs(f"16 8 {cl} 4", "TERRAIN=0"))["private_segment_fixed_size"] == 0, cl
+
+
+def test_lds_layouts_of_the_benchmark_models_keep_their_workgroups_per_cu():
+    """A CU holds min(4, 160 KiB / workgroup LDS) single-wave workgroups.  Both benchmark models run FOUR (one wave per SIMD; the Atlas-like one at 32 lanes per
+    env, two envs per workgroup): 4 x 40 032 B and 4 x 40 624 B of 163 840 - within 1.3 KB of the boundary, and both have been pushed over it once (an 84-float per-env
+    table in round 6's first session: config 2 halved; the model table's conflict-free pitch in the second: config 5 fell from 38.9 M to 26.4 M env-steps/s,
+    gpurun r06d - make_layout now takes that pitch only where it costs no workgroup)."""
+    import bench
+    from raisimlib_amd import Model, rsc_path
+    anymal = Model(urdf_path=rsc_path("anymal_c_like.urdf"))
+    n = anymal.lds_bytes(kmax=8, self_collision=True, lanes_per_env=16)
+    assert 4 * n <= 160 * 1024, n
+    atlas = bench.Recipe(5, -1.0).model
+    n = atlas.lds_bytes(kmax=16, self_collision=True, lanes_per_env=32)
+    assert 4 * n <= 160 * 1024, n
+    assert atlas.lds_bytes(kmax=16, self_collision=True, lanes_per_env=0) == n      # (and 32 lanes per env is what the library picks for it)
