@@ -17,6 +17,7 @@ def built_lib():
     """librsb.so built in-tree (hipcc cross-compiles gfx950 without a GPU)."""
     from raisimlib_amd import build
     build.build(verbose=False)
+    build.build_specializations(verbose=False)      # (the manifest's code objects: nothing to do where build() has run; an object of other sources is replaced)
     from raisimlib_amd import _capi
     lib = _capi.lib()
     # provenance: the library under test must have been built from THIS tree's sources (a stale object cache or a binary shipped

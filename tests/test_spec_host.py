@@ -30,7 +30,7 @@ def test_manifest_lines_name_one_code_object_each_and_build_left_them_there(buil
         names.add(n)
         assert os.path.getsize(os.path.join(d, n)) > 10000, f"{n}: not built (python -c 'import __graft_entry__ as g; g.build()')"
     assert len(names) == len(_lines()) >= 11                       # distinct keys -> distinct files
-    assert set(os.listdir(d)) == names                               # build() removes the objects of older sources / older manifests
+    assert names <= set(os.listdir(d))                               # (beside them: objects a GPU session compiled on demand; build() removes those of older sources)
     # every field of step_spec.h appears in every line, in the list's order
     fields = re.findall(r"X\((\w+),", open(os.path.join(_b.CSRC, "step_spec.h")).read().split("#define RSB_SPEC_FIELDS(X)")[1].split("#ifdef")[0])
     for line in _lines():
