@@ -76,6 +76,16 @@ std::string defs_of(const StepArgs& a) {
   return d;
 }
 
+// compiler-flag experiments (tools/exp/ab_defs.sh): $RSB_SPEC_EXTRA_FLAGS is appended to the hipcc command line of a code object and is part of its name
+const std::string& extra_flags() {
+  static const std::string flags = [] {
+    std::string e = env_or("RSB_SPEC_EXTRA_FLAGS", "");
+    for (char ch : e) if (!(std::isalnum((unsigned char)ch) || ch == '_' || ch == '=' || ch == '-' || ch == ' ' || ch == '.' || ch == ',')) { std::fprintf(stderr, "librsb: RSB_SPEC_EXTRA_FLAGS ignored (unexpected character)\n"); return std::string(); }
+    return e;
+  }();
+  return flags;
+}
+
 std::string key_line(const rsbw::SpecClass& c, const std::string& defs) {
   return std::to_string(c.lpe) + " " + std::to_string(c.kmax) + " " + std::to_string(c.cl) + " " + std::to_string(c.ml) + (c.prof ? " p" : "") + " | " + defs;
 }
@@ -83,7 +93,7 @@ std::string key_line(const rsbw::SpecClass& c, const std::string& defs) {
 std::string file_of(const rsbw::SpecClass& c, const std::string& defs) {
   char buf[160];
   std::snprintf(buf, sizeof buf, "step_%d_%d_%d_%d%s_%016llx.hsaco", c.lpe, c.kmax, c.cl, c.ml, c.prof ? "p" : "",
-                (unsigned long long)fnv1a64(std::string(rsb_source_hash()) + " " + key_line(c, defs)));
+                (unsigned long long)fnv1a64(std::string(rsb_source_hash()) + " " + key_line(c, defs) + (extra_flags().empty() ? "" : " ## " + extra_flags())));
   return buf;
 }
 
@@ -123,7 +133,7 @@ int compile(const rsbw::SpecClass& c, const std::string& defs) {
   // (the flags of raisimlib_amd/build.py FLAGS; --genco: device code object only)
   const std::string cmd = hipcc + " --genco --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -fno-hip-fp32-correctly-rounded-divide-sqrt -I '" + inc + "' -I '" + src + "'" +
                           " -DRSB_I_LPE=" + std::to_string(c.lpe) + " -DRSB_I_KMAX=" + std::to_string(c.kmax) + " -DRSB_I_CL=" + std::to_string(c.cl) +
-                          " -DRSB_I_ML=" + std::to_string(c.ml) + " -DRSB_I_PROF=" + std::to_string(c.prof ? 1 : 0) + " " + defs + " -o '" + tmp + "' '" + src + "/step_instance.hip' > '" + tmp + ".log' 2>&1";
+                          " -DRSB_I_ML=" + std::to_string(c.ml) + " -DRSB_I_PROF=" + std::to_string(c.prof ? 1 : 0) + " " + defs + " " + extra_flags() + " -o '" + tmp + "' '" + src + "/step_instance.hip' > '" + tmp + ".log' 2>&1";
   const int rc = std::system(cmd.c_str());
   if (rc != 0 || !file_exists(tmp)) {
     rsb::set_error("rsb specialisation: hipcc failed (log: " + tmp + ".log) for " + key_line(c, defs));
